@@ -1,0 +1,138 @@
+"""TEST INFRASTRUCTURE — ctypes binding of the CPU oracle (oracle/libgf_oracle.so).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class TrackerCfg(C.Structure):
+    _fields_ = [("max_cnt", C.c_int), ("min_dist", C.c_int), ("flow_back", C.c_int), ("depth_cam", C.c_int),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("k1", C.c_double), ("k2", C.c_double), ("p1", C.c_double), ("p2", C.c_double)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        p = os.path.join(_HERE, "libgf_oracle.so")
+        if not os.path.exists(p):
+            build()
+        _LIB = C.CDLL(p)
+        _LIB.gfo_tracker_create.restype = C.c_void_p
+        _LIB.gfo_tracker_lk_iters.restype = C.c_longlong
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def default_cfg(max_cnt=150, min_dist=30, flow_back=1, depth_cam=1):
+    return TrackerCfg(max_cnt, min_dist, flow_back, depth_cam, 603.95556640625, 603.1257934570312,
+                      324.0858154296875, 232.72303771972656, 0.0, 0.0, 0.0, 0.0)
+
+
+class Tracker:
+    def __init__(self, cfg=None):
+        self.cfg = cfg or default_cfg()
+        self.h = C.c_void_p(lib().gfo_tracker_create(C.byref(self.cfg)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().gfo_tracker_destroy(self.h)
+            self.h = None
+
+    def track(self, t, img, depth=None, cap=4096):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        ids = np.zeros(cap, np.int32)
+        obs = np.zeros((cap, 8), np.float64)
+        if depth is not None:
+            depth = np.ascontiguousarray(depth, np.uint16)
+            dp, ds = _p(depth, C.c_uint16), depth.shape[1]
+        else:
+            dp, ds = None, 0
+        n = lib().gfo_tracker_track(self.h, C.c_double(t), _p(img, C.c_uint8), w, h, w, dp, ds,
+                                    _p(ids, C.c_int), _p(obs, C.c_double), cap)
+        return ids[:n].copy(), obs[:n].copy()
+
+    def set_prediction(self, ids, xyz):
+        ids = np.ascontiguousarray(ids, np.int32)
+        xyz = np.ascontiguousarray(xyz, np.float64)
+        lib().gfo_tracker_set_prediction(self.h, _p(ids, C.c_int), _p(xyz, C.c_double), len(ids))
+
+    def remove_outliers(self, ids):
+        ids = np.ascontiguousarray(ids, np.int32)
+        lib().gfo_tracker_remove_outliers(self.h, _p(ids, C.c_int), len(ids))
+
+    def state(self, cap=4096):
+        ids = np.zeros(cap, np.int32)
+        cnt = np.zeros(cap, np.int32)
+        pts = np.zeros((cap, 2), np.float32)
+        n = lib().gfo_tracker_state(self.h, _p(ids, C.c_int), _p(cnt, C.c_int), _p(pts, C.c_float), cap)
+        return ids[:n].copy(), cnt[:n].copy(), pts[:n].copy()
+
+    def lk_iters(self):
+        return int(lib().gfo_tracker_lk_iters(self.h))
+
+
+def pyr_down(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros(((h + 1) // 2, (w + 1) // 2), np.uint8)
+    lib().gfo_pyr_down(_p(img, C.c_uint8), w, h, _p(out, C.c_uint8))
+    return out
+
+
+def scharr(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((h, w, 2), np.int16)
+    lib().gfo_scharr(_p(img, C.c_uint8), w, h, _p(out, C.c_int16))
+    return out
+
+
+def lk(prev, nxt, prev_pts, next_pts=None, max_level=3, max_count=30, eps=0.01):
+    prev = np.ascontiguousarray(prev, np.uint8)
+    nxt = np.ascontiguousarray(nxt, np.uint8)
+    h, w = prev.shape
+    pp = np.ascontiguousarray(prev_pts, np.float32)
+    use_init = next_pts is not None
+    npnts = np.ascontiguousarray(next_pts, np.float32).copy() if use_init else np.zeros_like(pp)
+    st = np.zeros(len(pp), np.uint8)
+    it = C.c_longlong(0)
+    lib().gfo_lk(_p(prev, C.c_uint8), _p(nxt, C.c_uint8), w, h, _p(pp, C.c_float), _p(npnts, C.c_float), _p(st, C.c_uint8),
+                 len(pp), max_level, max_count, C.c_double(eps), int(use_init), C.byref(it))
+    return npnts, st, it.value
+
+
+def fill_circle(img, cx, cy, r, color=0):
+    h, w = img.shape
+    lib().gfo_fill_circle(_p(img, C.c_uint8), w, h, cx, cy, r, color)
+    return img
+
+
+def min_eigen_val(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((h, w), np.float32)
+    lib().gfo_min_eigen_val(_p(img, C.c_uint8), w, h, _p(out, C.c_float))
+    return out
+
+
+def good_features(img, max_corners, quality=0.01, min_dist=30.0, mask=None):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((max(max_corners, 1) if max_corners > 0 else w * h, 2), np.float32)
+    mp = _p(np.ascontiguousarray(mask, np.uint8), C.c_uint8) if mask is not None else None
+    n = lib().gfo_good_features(_p(img, C.c_uint8), w, h, _p(out, C.c_float), max_corners, C.c_double(quality),
+                                C.c_double(min_dist), mp)
+    return out[:n].copy()

@@ -1,0 +1,605 @@
+// ============================================================================
+// TEST INFRASTRUCTURE — CPU ORACLE for the Ground-Fusion front end (feature tracker).
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this.
+// The product path (ground-fusion_amd/) never links, imports or calls it.
+//
+// PARITY UNPINNED: the reference (SJTU-ViSYS/Ground-Fusion) holds no tests or golden
+// vectors for this path and its arithmetic lives in un-vendored OpenCV 4 (ROS Noetic
+// ships 4.2.0).  This file restates
+//   * the reference's own logic   vins_estimator/src/featureTracker/feature_tracker.cpp
+//     (cited below as FT:line), and
+//   * the published OpenCV 4.2 algorithms it calls (cited by upstream file name):
+//       modules/video/src/lkpyramid.cpp   buildOpticalFlowPyramid, calcSharrDeriv,
+//                                         LKTrackerInvoker, calcOpticalFlowPyrLK
+//       modules/imgproc/src/pyramids.cpp  pyrDown (8u, 5-tap [1 4 6 4 1], (s+128)>>8)
+//       modules/imgproc/src/featureselect.cpp goodFeaturesToTrack
+//       modules/imgproc/src/corner.cpp    cornerMinEigenVal (Sobel 3x3, box 3x3)
+//       modules/imgproc/src/drawing.cpp   Circle (filled midpoint circle)
+//   * camodocal PinholeCamera::liftProjective / spaceToPlane / distortion
+//     camera_models/src/camera_models/PinholeCamera.cc:450-510, :520-542, :646-662
+//
+// Documented arithmetic choices (where OpenCV's result depends on its build):
+//   A. LK structure-tensor / mismatch sums are accumulated in int64 (OpenCV's own
+//      CV_NEON configuration: `typedef int64 acctype; typedef int itemtype`), not in
+//      float as in its x86 SIMD build: exact, hence reduction-order independent.
+//   B. No fused multiply-add anywhere (compiled with -ffp-contract=off), matching a
+//      baseline (SSE2/SSE3) OpenCV build.
+//   C. cornerMinEigenVal: Sobel row/column passes in float exactly as the generic
+//      FilterEngine kernels compute them (see sobel_dx/sobel_dy), the unnormalised 3x3
+//      box sum in double (OpenCV's sumType for 32F is CV_64F) summed row-major.
+//   D. FT:160-163 indexes cur_img.at<uchar>(p_u,p_v) with x as the ROW; for rows
+//      outside the image the reference reads out of bounds (UB).  The oracle defines
+//      such reads as 0 (never "> 250").
+// ============================================================================
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <set>
+#include <vector>
+#include <cfloat>
+
+#include "gf_oracle.h"
+
+namespace gfo {
+
+static inline int cvRoundf(float v) { return (int)lrintf(v); }      // round-half-even (default FE mode)
+static inline int cvRoundd(double v) { return (int)lrint(v); }
+static inline int cvFloorf(float v) { int i = (int)v; return i - (i > v); }
+#define GF_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
+
+static inline int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) { if (p < 0) p = -p; else p = 2 * len - 2 - p; }
+    return p;
+}
+
+// ---------------------------------------------------------------- padded images
+template <class T, int CN>
+struct PImg {
+    int rows = 0, cols = 0, pad = 0, stride = 0;  // stride in elements of T
+    std::vector<T> buf;
+    void create(int r, int c, int p) {
+        rows = r; cols = c; pad = p; stride = (c + 2 * p) * CN;
+        buf.assign((size_t)(r + 2 * p) * stride, (T)0);
+    }
+    T* ptr(int y) { return buf.data() + (size_t)(y + pad) * stride + (size_t)pad * CN; }
+    const T* ptr(int y) const { return buf.data() + (size_t)(y + pad) * stride + (size_t)pad * CN; }
+};
+typedef PImg<uint8_t, 1> Img8;
+typedef PImg<int16_t, 2> Deriv;
+
+static void fill_border_reflect101(Img8& im) {
+    for (int y = -im.pad; y < im.rows + im.pad; y++) {
+        int sy = reflect101(y, im.rows);
+        uint8_t* d = im.ptr(y);
+        const uint8_t* s = im.ptr(sy);
+        for (int x = -im.pad; x < im.cols + im.pad; x++) {
+            if (y >= 0 && y < im.rows && x >= 0 && x < im.cols) continue;
+            d[x] = s[reflect101(x, im.cols)];
+        }
+    }
+}
+
+// pyramids.cpp pyrDown_<FixPtCast<uchar,8>>: separable [1 4 6 4 1], REFLECT_101, (s+128)>>8
+static void pyr_down(const Img8& src, Img8& dst, int pad) {
+    int dw = (src.cols + 1) / 2, dh = (src.rows + 1) / 2;
+    dst.create(dh, dw, pad);
+    static const int k[5] = {1, 4, 6, 4, 1};
+    for (int y = 0; y < dh; y++) {
+        uint8_t* d = dst.ptr(y);
+        for (int x = 0; x < dw; x++) {
+            int s = 0;
+            for (int dy = -2; dy <= 2; dy++) {
+                const uint8_t* r = src.ptr(reflect101(2 * y + dy, src.rows));
+                int hs = 0;
+                for (int dx = -2; dx <= 2; dx++) hs += k[dx + 2] * r[reflect101(2 * x + dx, src.cols)];
+                s += k[dy + 2] * hs;
+            }
+            d[x] = (uint8_t)((s + 128) >> 8);
+        }
+    }
+}
+
+// lkpyramid.cpp buildOpticalFlowPyramid(img, pyr, winSize, maxLevel, withDerivatives=false,
+// pyrBorder=BORDER_REFLECT_101): returns the number of levels above the base actually built.
+static int build_pyramid(const uint8_t* img, int w, int h, int stride, int win, int maxLevel,
+                         std::vector<Img8>& pyr) {
+    pyr.clear();
+    pyr.resize(maxLevel + 1);
+    int sw = w, sh = h;
+    for (int level = 0; level <= maxLevel; level++) {
+        if (level == 0) {
+            pyr[0].create(h, w, win);
+            for (int y = 0; y < h; y++) memcpy(pyr[0].ptr(y), img + (size_t)y * stride, w);
+        } else {
+            pyr_down(pyr[level - 1], pyr[level], win);
+        }
+        fill_border_reflect101(pyr[level]);
+        sw = (sw + 1) / 2; sh = (sh + 1) / 2;
+        if (sw <= win || sh <= win) { pyr.resize(level + 1); return level; }
+    }
+    return maxLevel;
+}
+
+// lkpyramid.cpp calcSharrDeriv (ScharrDerivInvoker): dst[2x]=d/dx, dst[2x+1]=d/dy,
+// kernel (3,10,3)x(-1,0,1), REFLECT_101 inside the level image.  The padded level image
+// already carries the REFLECT_101 border so plain neighbour reads are equivalent.
+static void scharr_deriv(const Img8& src, Deriv& dst, int pad) {
+    dst.create(src.rows, src.cols, pad);  // zero border == copyMakeBorder(BORDER_CONSTANT)
+    for (int y = 0; y < src.rows; y++) {
+        const uint8_t* r0 = src.ptr(y - 1);
+        const uint8_t* r1 = src.ptr(y);
+        const uint8_t* r2 = src.ptr(y + 1);
+        int16_t* d = dst.ptr(y);
+        for (int x = 0; x < src.cols; x++) {
+            auto t0 = [&](int xx) { return (r0[xx] + r2[xx]) * 3 + r1[xx] * 10; };
+            auto t1 = [&](int xx) { return (int)r2[xx] - (int)r0[xx]; };
+            d[2 * x] = (int16_t)(t0(x + 1) - t0(x - 1));
+            d[2 * x + 1] = (int16_t)((t1(x + 1) + t1(x - 1)) * 3 + t1(x) * 10);
+        }
+    }
+}
+
+struct P2f { float x, y; };
+
+static const int W_BITS = 14;
+static const float FLT_SCALE = 1.f / (1 << 20);
+
+static inline float i64_to_f32(int64_t v) { return (float)(double)v; }  // |v| < 2^53: single rounding
+
+// lkpyramid.cpp LKTrackerInvoker::operator() for one pyramid level, all points.
+static void lk_level(const Img8& I, const Deriv& dI, const Img8& J, const P2f* prevPts, P2f* nextPts,
+                     uint8_t* status, int npts, int win, int maxCount, double epsilon, int level,
+                     int maxLevel, bool useInitialFlow, float minEigThreshold, int64_t* iters_out) {
+    const float half = (win - 1) * 0.5f;
+    std::vector<int16_t> Ibuf(win * win), dbuf(win * win * 2);
+    const int stepI = I.stride, stepJ = J.stride, dstep = dI.stride;
+    for (int p = 0; p < npts; p++) {
+        P2f prevPt = {prevPts[p].x * (float)(1. / (1 << level)), prevPts[p].y * (float)(1. / (1 << level))};
+        P2f nextPt;
+        if (level == maxLevel) {
+            if (useInitialFlow) nextPt = {nextPts[p].x * (float)(1. / (1 << level)), nextPts[p].y * (float)(1. / (1 << level))};
+            else nextPt = prevPt;
+        } else nextPt = {nextPts[p].x * 2.f, nextPts[p].y * 2.f};
+        nextPts[p] = nextPt;
+
+        prevPt.x -= half; prevPt.y -= half;
+        int ipx = cvFloorf(prevPt.x), ipy = cvFloorf(prevPt.y);
+        if (ipx < -win || ipx >= dI.cols || ipy < -win || ipy >= dI.rows) {
+            if (level == 0) status[p] = 0;
+            continue;
+        }
+        float a = prevPt.x - ipx, b = prevPt.y - ipy;
+        int iw00 = cvRoundf((1.f - a) * (1.f - b) * (1 << W_BITS));
+        int iw01 = cvRoundf(a * (1.f - b) * (1 << W_BITS));
+        int iw10 = cvRoundf((1.f - a) * b * (1 << W_BITS));
+        int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+        int64_t iA11 = 0, iA12 = 0, iA22 = 0;
+        for (int y = 0; y < win; y++) {
+            const uint8_t* src = I.ptr(y + ipy) + ipx;
+            const int16_t* dsrc = dI.ptr(y + ipy) + ipx * 2;
+            int16_t* Ip = &Ibuf[y * win];
+            int16_t* dp = &dbuf[y * win * 2];
+            for (int x = 0; x < win; x++, dsrc += 2, dp += 2) {
+                int ival = GF_DESCALE(src[x] * iw00 + src[x + 1] * iw01 + src[x + stepI] * iw10 + src[x + stepI + 1] * iw11, W_BITS - 5);
+                int ixval = GF_DESCALE(dsrc[0] * iw00 + dsrc[2] * iw01 + dsrc[dstep] * iw10 + dsrc[dstep + 2] * iw11, W_BITS);
+                int iyval = GF_DESCALE(dsrc[1] * iw00 + dsrc[3] * iw01 + dsrc[dstep + 1] * iw10 + dsrc[dstep + 3] * iw11, W_BITS);
+                Ip[x] = (int16_t)ival; dp[0] = (int16_t)ixval; dp[1] = (int16_t)iyval;
+                iA11 += (int64_t)(ixval * ixval); iA12 += (int64_t)(ixval * iyval); iA22 += (int64_t)(iyval * iyval);
+            }
+        }
+        float A11 = i64_to_f32(iA11) * FLT_SCALE, A12 = i64_to_f32(iA12) * FLT_SCALE, A22 = i64_to_f32(iA22) * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        float minEig = (A22 + A11 - std::sqrt((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * win * win);
+        if (minEig < minEigThreshold || D < FLT_EPSILON) {
+            if (level == 0) status[p] = 0;
+            continue;
+        }
+        D = 1.f / D;
+        nextPt.x -= half; nextPt.y -= half;
+        P2f prevDelta = {0.f, 0.f};
+        for (int j = 0; j < maxCount; j++) {
+            int inx = cvFloorf(nextPt.x), iny = cvFloorf(nextPt.y);
+            if (inx < -win || inx >= J.cols || iny < -win || iny >= J.rows) {
+                if (level == 0) status[p] = 0;
+                break;
+            }
+            if (iters_out) (*iters_out)++;
+            a = nextPt.x - inx; b = nextPt.y - iny;
+            iw00 = cvRoundf((1.f - a) * (1.f - b) * (1 << W_BITS));
+            iw01 = cvRoundf(a * (1.f - b) * (1 << W_BITS));
+            iw10 = cvRoundf((1.f - a) * b * (1 << W_BITS));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            int64_t ib1 = 0, ib2 = 0;
+            for (int y = 0; y < win; y++) {
+                const uint8_t* Jp = J.ptr(y + iny) + inx;
+                const int16_t* Ip = &Ibuf[y * win];
+                const int16_t* dp = &dbuf[y * win * 2];
+                for (int x = 0; x < win; x++, dp += 2) {
+                    int diff = GF_DESCALE(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + stepJ] * iw10 + Jp[x + stepJ + 1] * iw11, W_BITS - 5) - Ip[x];
+                    ib1 += (int64_t)(diff * dp[0]); ib2 += (int64_t)(diff * dp[1]);
+                }
+            }
+            float b1 = i64_to_f32(ib1) * FLT_SCALE, b2 = i64_to_f32(ib2) * FLT_SCALE;
+            P2f delta = {(float)((A12 * b2 - A22 * b1) * D), (float)((A12 * b1 - A11 * b2) * D)};
+            nextPt.x += delta.x; nextPt.y += delta.y;
+            nextPts[p] = {nextPt.x + half, nextPt.y + half};
+            if ((double)delta.x * delta.x + (double)delta.y * delta.y <= epsilon) break;
+            if (j > 0 && std::abs(delta.x + prevDelta.x) < 0.01 && std::abs(delta.y + prevDelta.y) < 0.01) {
+                nextPts[p].x -= delta.x * 0.5f; nextPts[p].y -= delta.y * 0.5f;
+                break;
+            }
+            prevDelta = delta;
+        }
+        // err block (err is always requested by the reference, FT:122-142): its only observable
+        // side effect is the bounds re-check on the final point at level 0.
+        if (status[p] && level == 0) {
+            P2f np = {nextPts[p].x - half, nextPts[p].y - half};
+            int inx = cvFloorf(np.x), iny = cvFloorf(np.y);
+            if (inx < -win || inx >= J.cols || iny < -win || iny >= J.rows) status[p] = 0;
+        }
+    }
+}
+
+// lkpyramid.cpp SparsePyrLKOpticalFlowImpl::calc, winSize 21x21, minEigThreshold 1e-4
+static void calc_optical_flow_pyr_lk(const uint8_t* prev, const uint8_t* next, int w, int h, int stride,
+                                     const P2f* prevPts, P2f* nextPts, uint8_t* status, int npts, int maxLevel,
+                                     int maxCount, double eps, bool useInitialFlow, int64_t* iters_out) {
+    const int win = 21;
+    if (npts == 0) return;
+    for (int i = 0; i < npts; i++) status[i] = 1;
+    maxCount = std::min(std::max(maxCount, 0), 100);
+    eps = std::min(std::max(eps, 0.), 10.);
+    eps *= eps;
+    std::vector<Img8> prevPyr, nextPyr;
+    int l1 = build_pyramid(prev, w, h, stride, win, maxLevel, prevPyr);
+    int l2 = build_pyramid(next, w, h, stride, win, maxLevel, nextPyr);
+    maxLevel = std::min(l1, l2);
+    for (int level = maxLevel; level >= 0; level--) {
+        Deriv dI;
+        scharr_deriv(prevPyr[level], dI, win);
+        lk_level(prevPyr[level], dI, nextPyr[level], prevPts, nextPts, status, npts, win, maxCount, eps, level,
+                 maxLevel, useInitialFlow, 1e-4f, iters_out);
+    }
+}
+
+// drawing.cpp Circle(img, center, radius, color, fill=1) for an 8-bit single channel image, colour 0
+static void fill_circle(uint8_t* img, int w, int h, int stride, int cx, int cy, int radius, uint8_t color) {
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    auto hline = [&](int y, int x1, int x2) {
+        if ((unsigned)y >= (unsigned)h) return;
+        x1 = std::max(x1, 0); x2 = std::min(x2, w - 1);
+        for (int x = x1; x <= x2; x++) img[(size_t)y * stride + x] = color;
+    };
+    while (dx >= dy) {
+        int y11 = cy - dy, y12 = cy + dy, y21 = cy - dx, y22 = cy + dx;
+        int x11 = cx - dx, x12 = cx + dx, x21 = cx - dy, x22 = cx + dy;
+        // the "inside" fast path and the clipped path of OpenCV paint the same pixels
+        if (x11 < w && x12 >= 0 && y21 < h && y22 >= 0) {
+            hline(y11, x11, x12); hline(y12, x11, x12);
+            if (x21 < w && x22 >= 0) { hline(y21, x21, x22); hline(y22, x21, x22); }
+        }
+        dy++; err += plus; plus += 2;
+        int mask = (err <= 0) - 1;
+        err -= minus & mask; dx += mask; minus -= mask & 2;
+    }
+}
+
+// corner.cpp cornerEigenValsVecs(MINEIGENVAL, block 3, aperture 3) on 8U
+static void corner_min_eigen_val(const uint8_t* img, int w, int h, int stride, std::vector<float>& eig) {
+    const double scale_d = 1.0 / ((double)(1 << 2) * 3 * 255.0);
+    // Sobel(): the smoothing kernel [1 2 1] is scaled, stored as CV_32F
+    const float f1 = (float)(1.0 * scale_d), f0 = (float)(2.0 * scale_d);
+    std::vector<float> dxx((size_t)w * h), dxy((size_t)w * h), dyy((size_t)w * h);
+    auto px = [&](int y, int x) { return (int)img[(size_t)reflect101(y, h) * stride + reflect101(x, w)]; };
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            // Dx: row pass [-1 0 1] (exact), column pass symmetric: (S0+S2)*f1 + S1*f0
+            float t0 = (float)(px(y - 1, x + 1) - px(y - 1, x - 1));
+            float t1 = (float)(px(y, x + 1) - px(y, x - 1));
+            float t2 = (float)(px(y + 1, x + 1) - px(y + 1, x - 1));
+            float dx = (t0 + t2) * f1 + t1 * f0;
+            // Dy: row pass [f1 f0 f1] sequential, column pass S2 - S0
+            auto row = [&](int yy) { float s = f1 * (float)px(yy, x - 1); s += f0 * (float)px(yy, x); s += f1 * (float)px(yy, x + 1); return s; };
+            float dy = row(y + 1) - row(y - 1);
+            dxx[(size_t)y * w + x] = dx * dx; dxy[(size_t)y * w + x] = dx * dy; dyy[(size_t)y * w + x] = dy * dy;
+        }
+    eig.assign((size_t)w * h, 0.f);
+    auto box = [&](const std::vector<float>& c, int y, int x) {
+        double s = 0;
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) s += (double)c[(size_t)reflect101(y + dy, h) * w + reflect101(x + dx, w)];
+        return (float)s;
+    };
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            float a = box(dxx, y, x) * 0.5f, b = box(dxy, y, x), c = box(dyy, y, x) * 0.5f;
+            eig[(size_t)y * w + x] = (float)((a + c) - std::sqrt((a - c) * (a - c) + b * b));
+        }
+}
+
+// featureselect.cpp goodFeaturesToTrack(image, corners, maxCorners, qualityLevel, minDistance, mask, 3, 3, false)
+static void good_features_to_track(const uint8_t* img, int w, int h, int stride, std::vector<P2f>& corners,
+                                   int maxCorners, double qualityLevel, double minDistance, const uint8_t* mask, int mstride) {
+    corners.clear();
+    std::vector<float> eig;
+    corner_min_eigen_val(img, w, h, stride, eig);
+    double maxVal = 0;  // minMaxLoc with mask
+    {
+        bool any = false; float mv = 0;
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++)
+                if (!mask || mask[(size_t)y * mstride + x]) { float v = eig[(size_t)y * w + x]; if (!any || v > mv) { mv = v; any = true; } }
+        maxVal = any ? mv : 0;
+    }
+    const float thresh = (float)(maxVal * qualityLevel);  // threshold(THRESH_TOZERO)
+    for (auto& v : eig) if (!(v > thresh)) v = 0.f;
+    std::vector<uint32_t> cand;  // pixel offsets; address order == offset order
+    for (int y = 1; y < h - 1; y++)
+        for (int x = 1; x < w - 1; x++) {
+            float val = eig[(size_t)y * w + x];
+            if (val == 0) continue;
+            float m = val;  // dilate 3x3 (border excluded)
+            for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) m = std::max(m, eig[(size_t)(y + dy) * w + x + dx]);
+            if (val == m && (!mask || mask[(size_t)y * mstride + x])) cand.push_back((uint32_t)(y * w + x));
+        }
+    if (cand.empty()) return;
+    // greaterThanPtr: (*a > *b) ? true : (*a < *b) ? false : (a > b)
+    std::sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) { float va = eig[a], vb = eig[b]; return va > vb ? true : va < vb ? false : a > b; });
+    if (minDistance >= 1) {
+        const int cell = cvRoundd(minDistance);
+        const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
+        std::vector<std::vector<P2f>> grid((size_t)gw * gh);
+        minDistance *= minDistance;
+        for (size_t i = 0; i < cand.size(); i++) {
+            int y = cand[i] / w, x = cand[i] % w;
+            bool good = true;
+            int xc = x / cell, yc = y / cell;
+            int x1 = std::max(0, xc - 1), y1 = std::max(0, yc - 1), x2 = std::min(gw - 1, xc + 1), y2 = std::min(gh - 1, yc + 1);
+            for (int yy = y1; yy <= y2 && good; yy++)
+                for (int xx = x1; xx <= x2 && good; xx++)
+                    for (auto& m : grid[(size_t)yy * gw + xx]) {
+                        float dx = x - m.x, dy = y - m.y;
+                        if (dx * dx + dy * dy < minDistance) { good = false; break; }
+                    }
+            if (good) {
+                grid[(size_t)yc * gw + xc].push_back({(float)x, (float)y});
+                corners.push_back({(float)x, (float)y});
+                if (maxCorners > 0 && (int)corners.size() == maxCorners) break;
+            }
+        }
+    } else {
+        for (size_t i = 0; i < cand.size(); i++) {
+            corners.push_back({(float)(cand[i] % w), (float)(cand[i] / w)});
+            if (maxCorners > 0 && (int)corners.size() == maxCorners) break;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- FeatureTracker restatement
+struct Tracker {
+    gfo_tracker_cfg cfg;
+    int row = 0, col = 0;
+    std::vector<uint8_t> prev_img, cur_img, mask;
+    std::vector<P2f> n_pts, predict_pts, prev_pts, cur_pts, prev_un_pts, cur_un_pts, pts_velocity;
+    std::vector<int> ids, track_cnt;
+    std::map<int, P2f> cur_un_pts_map, prev_un_pts_map;
+    double cur_time = 0, prev_time = 0;
+    int n_id = 0;            // FT:52
+    bool hasPrediction = false;
+    int64_t lk_iters = 0;    // instrumentation only
+
+    bool inBorder(const P2f& pt) const {  // FT:14-20
+        const int B = 1;
+        int x = cvRoundf(pt.x), y = cvRoundf(pt.y);
+        return B <= x && x < col - B && B <= y && y < row - B;
+    }
+    template <class V> static void reduceVector(std::vector<V>& v, const std::vector<uint8_t>& st) {  // FT:30-46
+        int j = 0;
+        for (int i = 0; i < (int)v.size(); i++) if (st[i]) v[j++] = v[i];
+        v.resize(j);
+    }
+    void liftProjective(double u, double v, double& X, double& Y) const {  // PinholeCamera.cc:450-510
+        double inv11 = 1.0 / cfg.fx, inv13 = -cfg.cx / cfg.fx, inv22 = 1.0 / cfg.fy, inv23 = -cfg.cy / cfg.fy;
+        double mx_d = inv11 * u + inv13, my_d = inv22 * v + inv23, mx_u, my_u;
+        bool noDist = cfg.k1 == 0.0 && cfg.k2 == 0.0 && cfg.p1 == 0.0 && cfg.p2 == 0.0;
+        if (noDist) { mx_u = mx_d; my_u = my_d; }
+        else {
+            double dux, duy;
+            distortion(mx_d, my_d, dux, duy);
+            mx_u = mx_d - dux; my_u = my_d - duy;
+            for (int i = 1; i < 8; ++i) { distortion(mx_u, my_u, dux, duy); mx_u = mx_d - dux; my_u = my_d - duy; }
+        }
+        X = mx_u; Y = my_u;
+    }
+    void distortion(double x, double y, double& dx, double& dy) const {  // PinholeCamera.cc:646-662
+        double k1 = cfg.k1, k2 = cfg.k2, p1 = cfg.p1, p2 = cfg.p2;
+        double mx2 = x * x, my2 = y * y, mxy = x * y, rho2 = mx2 + my2, rad = k1 * rho2 + k2 * rho2 * rho2;
+        dx = x * rad + 2.0 * p1 * mxy + p2 * (rho2 + 2.0 * mx2);
+        dy = y * rad + 2.0 * p2 * mxy + p1 * (rho2 + 2.0 * my2);
+    }
+    void spaceToPlane(const double P[3], double& u, double& v) const {  // PinholeCamera.cc:520-542
+        double xu = P[0] / P[2], yu = P[1] / P[2], xd, yd;
+        bool noDist = cfg.k1 == 0.0 && cfg.k2 == 0.0 && cfg.p1 == 0.0 && cfg.p2 == 0.0;
+        if (noDist) { xd = xu; yd = yu; } else { double dx, dy; distortion(xu, yu, dx, dy); xd = xu + dx; yd = yu + dy; }
+        u = cfg.fx * xd + cfg.cx; v = cfg.fy * yd + cfg.cy;
+    }
+    void setMask() {  // FT:56-83
+        mask.assign((size_t)row * col, 255);
+        struct E { int cnt; P2f pt; int id; };
+        std::vector<E> v;
+        for (size_t i = 0; i < cur_pts.size(); i++) v.push_back({track_cnt[i], cur_pts[i], ids[i]});
+        std::sort(v.begin(), v.end(), [](const E& a, const E& b) { return a.cnt > b.cnt; });
+        cur_pts.clear(); ids.clear(); track_cnt.clear();
+        for (auto& it : v) {
+            int x = cvRoundf(it.pt.x), y = cvRoundf(it.pt.y);  // Point2f -> Point (saturate_cast)
+            if (mask[(size_t)y * col + x] == 255) {
+                cur_pts.push_back(it.pt); ids.push_back(it.id); track_cnt.push_back(it.cnt);
+                fill_circle(mask.data(), col, row, col, x, y, cfg.min_dist, 0);
+            }
+        }
+    }
+    std::vector<P2f> undistortedPts(const std::vector<P2f>& pts) const {  // FT:797-808
+        std::vector<P2f> un;
+        for (auto& p : pts) { double X, Y; liftProjective((double)p.x, (double)p.y, X, Y); un.push_back({(float)(X / 1.0), (float)(Y / 1.0)}); }
+        return un;
+    }
+    std::vector<P2f> ptsVelocity(const std::vector<int>& ids_, const std::vector<P2f>& pts, std::map<int, P2f>& cur_map,
+                                 std::map<int, P2f>& prev_map) const {  // FT:810-847
+        std::vector<P2f> vel;
+        cur_map.clear();
+        for (size_t i = 0; i < ids_.size(); i++) cur_map.insert({ids_[i], pts[i]});
+        if (!prev_map.empty()) {
+            double dt = cur_time - prev_time;
+            for (size_t i = 0; i < pts.size(); i++) {
+                auto it = prev_map.find(ids_[i]);
+                if (it != prev_map.end()) {
+                    double vx = (pts[i].x - it->second.x) / dt, vy = (pts[i].y - it->second.y) / dt;
+                    vel.push_back({(float)vx, (float)vy});
+                } else vel.push_back({0.f, 0.f});
+            }
+        } else for (size_t i = 0; i < cur_pts.size(); i++) vel.push_back({0.f, 0.f});  // FT:841 (member size)
+        return vel;
+    }
+
+    int trackImage(double t, const uint8_t* img, int w, int h, int stride, const uint16_t* depth, int dstride,
+                   int* out_ids, double* out_obs, int cap) {  // FT:103-372
+        cur_time = t; row = h; col = w;
+        cur_img.resize((size_t)w * h);
+        for (int y = 0; y < h; y++) memcpy(&cur_img[(size_t)y * w], img + (size_t)y * stride, w);
+        cur_pts.clear();
+        if (!prev_pts.empty()) {
+            std::vector<uint8_t> status(prev_pts.size(), 0);
+            if (hasPrediction) {  // FT:118-133
+                cur_pts = predict_pts;
+                calc_optical_flow_pyr_lk(prev_img.data(), cur_img.data(), w, h, w, prev_pts.data(), cur_pts.data(), status.data(),
+                                         (int)prev_pts.size(), 1, 30, 0.01, true, &lk_iters);
+                int succ = 0;
+                for (auto s : status) if (s) succ++;
+                if (succ < 10) {
+                    // NOTE: without OPTFLOW_USE_INITIAL_FLOW OpenCV re-creates nextPts, values are reset from prevPts
+                    calc_optical_flow_pyr_lk(prev_img.data(), cur_img.data(), w, h, w, prev_pts.data(), cur_pts.data(), status.data(),
+                                             (int)prev_pts.size(), 3, 30, 0.01, false, &lk_iters);
+                }
+            } else {
+                cur_pts.assign(prev_pts.size(), P2f{0, 0});
+                calc_optical_flow_pyr_lk(prev_img.data(), cur_img.data(), w, h, w, prev_pts.data(), cur_pts.data(), status.data(),
+                                         (int)prev_pts.size(), 3, 30, 0.01, false, &lk_iters);
+            }
+            if (cfg.flow_back) {  // FT:138-153
+                std::vector<uint8_t> rstatus(prev_pts.size(), 0);
+                std::vector<P2f> rpts = prev_pts;
+                calc_optical_flow_pyr_lk(cur_img.data(), prev_img.data(), w, h, w, cur_pts.data(), rpts.data(), rstatus.data(),
+                                         (int)prev_pts.size(), 1, 30, 0.01, true, &lk_iters);
+                for (size_t i = 0; i < status.size(); i++) {
+                    double dx = prev_pts[i].x - rpts[i].x, dy = prev_pts[i].y - rpts[i].y;  // FT:22-28 (float diff -> double)
+                    dx = (double)(prev_pts[i].x - rpts[i].x); dy = (double)(prev_pts[i].y - rpts[i].y);
+                    status[i] = (status[i] && rstatus[i] && std::sqrt(dx * dx + dy * dy) <= 0.5) ? 1 : 0;
+                }
+            }
+            for (int i = 0; i < (int)cur_pts.size(); i++) {  // FT:155-168
+                if (status[i] && !inBorder(cur_pts[i])) status[i] = 0;
+                int p_u = (int)cur_pts[i].x, p_v = (int)cur_pts[i].y;
+                float grey = 0.f;  // choice D
+                if (p_u >= 0 && p_u < row && p_v >= 0 && p_v < col) grey = cur_img[(size_t)p_u * col + p_v];
+                if (status[i] && grey > 250) status[i] = 0;
+            }
+            reduceVector(prev_pts, status); reduceVector(cur_pts, status); reduceVector(ids, status); reduceVector(track_cnt, status);
+        }
+        for (auto& n : track_cnt) n++;  // FT:178
+        setMask();                      // FT:186
+        int n_max_cnt = cfg.max_cnt - (int)cur_pts.size();
+        if (n_max_cnt > 0)
+            good_features_to_track(cur_img.data(), w, h, w, n_pts, n_max_cnt, 0.01, (double)cfg.min_dist, mask.data(), w);  // FT:198
+        else n_pts.clear();
+        for (auto& p : n_pts) { cur_pts.push_back(p); ids.push_back(n_id++); track_cnt.push_back(1); }  // FT:85-93
+        cur_un_pts = undistortedPts(cur_pts);                                                            // FT:210
+        pts_velocity = ptsVelocity(ids, cur_un_pts, cur_un_pts_map, prev_un_pts_map);                    // FT:211
+        // FT:214-258 depth_cam branch only copies (status all 1): no observable effect on the output
+        prev_img = cur_img; prev_pts = cur_pts; prev_un_pts = cur_un_pts; prev_un_pts_map = cur_un_pts_map;
+        prev_time = cur_time; hasPrediction = false;
+        int n = (int)ids.size();
+        for (int i = 0; i < n && i < cap; i++) {  // FT:322-368
+            double* o = out_obs + (size_t)i * 8;
+            out_ids[i] = ids[i];
+            o[0] = cur_un_pts[i].x; o[1] = cur_un_pts[i].y; o[2] = 1; o[3] = cur_pts[i].x; o[4] = cur_pts[i].y;
+            o[5] = pts_velocity[i].x; o[6] = pts_velocity[i].y;
+            if (cfg.depth_cam && depth) {
+                long ry = lround((double)cur_pts[i].y), rx = lround((double)cur_pts[i].x);
+                double d = (int)depth[(size_t)ry * dstride + rx];
+                o[7] = d / 1000;
+            } else o[7] = -2.4;
+        }
+        return n;
+    }
+    void setPrediction(const int* pid, const double* xyz, int n) {  // FT:1006-1027
+        hasPrediction = true;
+        predict_pts.clear();
+        std::map<int, const double*> m;
+        for (int i = 0; i < n; i++) m[pid[i]] = xyz + 3 * i;
+        for (size_t i = 0; i < ids.size(); i++) {
+            auto it = m.find(ids[i]);
+            if (it != m.end()) { double u, v; spaceToPlane(it->second, u, v); predict_pts.push_back({(float)u, (float)v}); }
+            else predict_pts.push_back(prev_pts[i]);
+        }
+    }
+    void removeOutliers(const int* rid, int n) {  // FT:1029-1045
+        std::set<int> s(rid, rid + n);
+        std::vector<uint8_t> status;
+        for (size_t i = 0; i < ids.size(); i++) status.push_back(s.count(ids[i]) ? 0 : 1);
+        reduceVector(prev_pts, status); reduceVector(ids, status); reduceVector(track_cnt, status);
+    }
+};
+
+}  // namespace gfo
+
+using namespace gfo;
+
+extern "C" {
+void* gfo_tracker_create(const gfo_tracker_cfg* cfg) { Tracker* t = new Tracker(); t->cfg = *cfg; return t; }
+void gfo_tracker_destroy(void* h) { delete (Tracker*)h; }
+int gfo_tracker_track(void* h, double t, const uint8_t* img, int w, int hh, int stride, const uint16_t* depth, int dstride,
+                      int* out_ids, double* out_obs, int cap) {
+    return ((Tracker*)h)->trackImage(t, img, w, hh, stride, depth, dstride, out_ids, out_obs, cap);
+}
+void gfo_tracker_set_prediction(void* h, const int* ids, const double* xyz, int n) { ((Tracker*)h)->setPrediction(ids, xyz, n); }
+void gfo_tracker_remove_outliers(void* h, const int* ids, int n) { ((Tracker*)h)->removeOutliers(ids, n); }
+int gfo_tracker_state(void* h, int* ids, int* track_cnt, float* prev_pts, int cap) {
+    Tracker* t = (Tracker*)h;
+    int n = (int)t->ids.size();
+    for (int i = 0; i < n && i < cap; i++) { ids[i] = t->ids[i]; track_cnt[i] = t->track_cnt[i]; prev_pts[2 * i] = t->prev_pts[i].x; prev_pts[2 * i + 1] = t->prev_pts[i].y; }
+    return n;
+}
+long long gfo_tracker_lk_iters(void* h) { return ((Tracker*)h)->lk_iters; }
+
+void gfo_pyr_down(const uint8_t* src, int w, int h, uint8_t* dst) {
+    Img8 s, d; s.create(h, w, 0);
+    memcpy(s.buf.data(), src, (size_t)w * h);
+    pyr_down(s, d, 0);
+    memcpy(dst, d.buf.data(), (size_t)d.rows * d.cols);
+}
+void gfo_scharr(const uint8_t* src, int w, int h, int16_t* dst) {
+    Img8 s; s.create(h, w, 1);
+    for (int y = 0; y < h; y++) memcpy(s.ptr(y), src + (size_t)y * w, w);
+    fill_border_reflect101(s);
+    Deriv d; scharr_deriv(s, d, 0);
+    memcpy(dst, d.buf.data(), (size_t)w * h * 2 * sizeof(int16_t));
+}
+void gfo_lk(const uint8_t* prev, const uint8_t* next, int w, int h, const float* prevPts, float* nextPts, uint8_t* status, int n,
+            int maxLevel, int maxCount, double eps, int useInitialFlow, long long* iters) {
+    int64_t it = 0;
+    calc_optical_flow_pyr_lk(prev, next, w, h, w, (const P2f*)prevPts, (P2f*)nextPts, status, n, maxLevel, maxCount, eps, useInitialFlow != 0, &it);
+    if (iters) *iters = it;
+}
+void gfo_fill_circle(uint8_t* img, int w, int h, int cx, int cy, int radius, int color) { fill_circle(img, w, h, w, cx, cy, radius, (uint8_t)color); }
+void gfo_min_eigen_val(const uint8_t* img, int w, int h, float* eig) {
+    std::vector<float> e; corner_min_eigen_val(img, w, h, w, e); memcpy(eig, e.data(), e.size() * sizeof(float));
+}
+int gfo_good_features(const uint8_t* img, int w, int h, float* corners, int maxCorners, double quality, double minDist, const uint8_t* mask) {
+    std::vector<P2f> c; good_features_to_track(img, w, h, w, c, maxCorners, quality, minDist, mask, w);
+    for (size_t i = 0; i < c.size(); i++) { corners[2 * i] = c[i].x; corners[2 * i + 1] = c[i].y; }
+    return (int)c.size();
+}
+}
