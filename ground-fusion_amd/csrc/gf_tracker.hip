@@ -1,0 +1,728 @@
+// gf_tracker.hip — C-ABI front end (include/groundfusion_hip.h): host orchestration of the HIP tracker.
+//
+// Mirrors FeatureTracker (vins_estimator/src/featureTracker/feature_tracker.{h,cpp}) for `batch`
+// independent sequences driven in lock-step on one GPU stream.  Host keeps exactly the bookkeeping the
+// reference keeps in C++ (ids, track_cnt, n_id, maps for velocity; setMask's std::sort + greedy keep,
+// feature_tracker.cpp:56-83); all image work (pyramids, Scharr, LK forward/reverse, mask rasterisation,
+// Shi-Tomasi, candidate sort and min-distance selection, depth sampling) runs in the kernels of
+// gf_lk_kernels.hpp / gf_detect_kernels.hpp.  There is no CPU fallback: without a HIP device every entry
+// point fails with GF_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/groundfusion_hip.h"
+#include "gf_detect_kernels.hpp"
+#include "gf_lk_kernels.hpp"
+
+namespace gf {
+
+static thread_local std::string g_err;
+int set_err(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return gf::set_err(GF_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+static int require_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return set_err(GF_ERR_NO_DEVICE, "no HIP device available (%s); the HIP path has no CPU fallback", hipGetErrorString(e));
+    return GF_OK;
+}
+
+struct P2f { float x, y; };
+
+struct SeqState {  // per-sequence FeatureTracker members (feature_tracker.h:76-98)
+    std::vector<P2f> prev_pts, cur_pts, predict_pts, prev_un_pts, cur_un_pts, pts_velocity;
+    std::vector<int> ids, track_cnt;
+    std::vector<uint16_t> cur_depth;
+    std::map<int, P2f> cur_un_pts_map, prev_un_pts_map;
+    double cur_time = 0, prev_time = 0;
+    int n_id = 0;
+    bool hasPrediction = false;
+};
+
+template <class T> struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    int alloc(size_t count) { n = count; hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)); if (e != hipSuccess) return set_err(GF_ERR_HIP, "hipMalloc(%zu B) failed: %s", count * sizeof(T), hipGetErrorString(e)); return GF_OK; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; }
+};
+template <class T> struct PinBuf {
+    T* p = nullptr; size_t n = 0;
+    int alloc(size_t count) { n = count; hipError_t e = hipHostMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault); if (e != hipSuccess) return set_err(GF_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(e)); memset(p, 0, std::max<size_t>(count, 1) * sizeof(T)); return GF_OK; }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; }
+};
+
+static void make_disk_table(int radius, DiskTable& T) {  // drawing.cpp Circle(): union of the h-lines per row offset
+    T.radius = radius;
+    for (int i = 0; i <= kMaxRadius; i++) T.hw[i] = -1;
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        T.hw[dy] = std::max<short>(T.hw[dy], (short)dx);
+        T.hw[dx] = std::max<short>(T.hw[dx], (short)dy);
+        dy++; err += plus; plus += 2;
+        int mask = (err <= 0) - 1;
+        err -= minus & mask; dx += mask; minus -= mask & 2;
+    }
+}
+
+static int build_geom(int w, int h, PyrGeom& G) {
+    memset(&G, 0, sizeof G);
+    int lw = w, lh = h;
+    size_t off = 0;
+    int level = 0;
+    for (; level < kMaxLevels; level++) {
+        LevelGeom& g = G.lv[level];
+        g.w = lw; g.h = lh; g.stride = lw + 2 * kPad;
+        const size_t rows = lh + 2 * kPad;
+        g.img_off = (int)(off + (size_t)kPad * g.stride + kPad);
+        g.der_off = g.img_off;
+        off += rows * g.stride;
+        off = (off + 255) & ~(size_t)255;
+        lw = (lw + 1) / 2; lh = (lh + 1) / 2;
+        if (lw <= kWin || lh <= kWin) { level++; break; }  // buildOpticalFlowPyramid stop rule
+    }
+    G.nlevels = level;
+    G.img_bytes = off;
+    G.der_elems = off;
+    return GF_OK;
+}
+
+}  // namespace gf
+
+using namespace gf;
+
+struct gf_tracker {
+    gf_tracker_cfg cfg;
+    PyrGeom G;
+    DiskTable disk;
+    int B = 0, cap = 0, cand_cap = 0, frame = 0, cur_slot = 0;
+    bool profiling = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    gf_tracker_stats stats{};
+    std::vector<SeqState> seq;
+    // device
+    DevBuf<uint8_t> d_img, d_raw, d_mask, d_status, d_fwd_status, d_seqmask;
+    DevBuf<int> d_der, d_npts, d_cand_count, d_want, d_ncenters, d_out_n;
+    DevBuf<uint16_t> d_depth, d_depth_out, d_out_depth;
+    DevBuf<float2> d_prev_pts, d_init_pts, d_cur_pts, d_out_pts;
+    DevBuf<unsigned> d_counters, d_maxkey;
+    DevBuf<float> d_eig;
+    DevBuf<unsigned long long> d_cand;
+    DevBuf<int2> d_centers;
+    // pinned host mirrors
+    PinBuf<int> h_npts, h_want, h_ncenters, h_out_n, h_cand_count;
+    PinBuf<float2> h_prev_pts, h_init_pts, h_cur_pts, h_out_pts;
+    PinBuf<uint8_t> h_status, h_fwd_status, h_seqmask;
+    PinBuf<uint16_t> h_depth_out, h_out_depth;
+    PinBuf<unsigned> h_counters;
+    PinBuf<int2> h_centers;
+    size_t eig_stride = 0, mask_stride = 0;
+    size_t select_lds = 0;
+
+    void release() {
+        d_img.release(); d_raw.release(); d_mask.release(); d_status.release(); d_fwd_status.release(); d_seqmask.release(); d_der.release(); d_npts.release();
+        d_cand_count.release(); d_want.release(); d_ncenters.release(); d_out_n.release(); d_depth.release(); d_depth_out.release();
+        d_out_depth.release(); d_prev_pts.release(); d_init_pts.release(); d_cur_pts.release(); d_out_pts.release(); d_counters.release();
+        d_maxkey.release(); d_eig.release(); d_cand.release(); d_centers.release();
+        h_npts.release(); h_want.release(); h_ncenters.release(); h_out_n.release(); h_cand_count.release(); h_prev_pts.release();
+        h_init_pts.release(); h_cur_pts.release(); h_out_pts.release(); h_status.release(); h_fwd_status.release(); h_seqmask.release(); h_depth_out.release();
+        h_out_depth.release(); h_counters.release(); h_centers.release();
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace gf {
+
+static inline int cvRoundf(float v) { return (int)lrintf(v); }
+
+// camodocal PinholeCamera (camera_models/src/camera_models/PinholeCamera.cc:450-510, :520-542, :646-662)
+static void distortion(const gf_tracker_cfg& c, double x, double y, double& dx, double& dy) {
+    double mx2 = x * x, my2 = y * y, mxy = x * y, rho2 = mx2 + my2, rad = c.k1 * rho2 + c.k2 * rho2 * rho2;
+    dx = x * rad + 2.0 * c.p1 * mxy + c.p2 * (rho2 + 2.0 * mx2);
+    dy = y * rad + 2.0 * c.p2 * mxy + c.p1 * (rho2 + 2.0 * my2);
+}
+static bool no_distortion(const gf_tracker_cfg& c) { return c.k1 == 0.0 && c.k2 == 0.0 && c.p1 == 0.0 && c.p2 == 0.0; }
+static void lift_projective(const gf_tracker_cfg& c, double u, double v, double& X, double& Y) {
+    const double i11 = 1.0 / c.fx, i13 = -c.cx / c.fx, i22 = 1.0 / c.fy, i23 = -c.cy / c.fy;
+    const double mx_d = i11 * u + i13, my_d = i22 * v + i23;
+    if (no_distortion(c)) { X = mx_d; Y = my_d; return; }
+    double dux, duy;
+    distortion(c, mx_d, my_d, dux, duy);
+    double mx_u = mx_d - dux, my_u = my_d - duy;
+    for (int i = 1; i < 8; ++i) { distortion(c, mx_u, my_u, dux, duy); mx_u = mx_d - dux; my_u = my_d - duy; }
+    X = mx_u; Y = my_u;
+}
+static void space_to_plane(const gf_tracker_cfg& c, const double* P, double& u, double& v) {
+    double xu = P[0] / P[2], yu = P[1] / P[2], xd = xu, yd = yu;
+    if (!no_distortion(c)) { double dx, dy; distortion(c, xu, yu, dx, dy); xd = xu + dx; yd = yu + dy; }
+    u = c.fx * xd + c.cx; v = c.fy * yd + c.cy;
+}
+
+template <class V> static void reduce_vector(std::vector<V>& v, const uint8_t* st) {  // feature_tracker.cpp:30-46
+    int j = 0;
+    for (int i = 0; i < (int)v.size(); i++) if (st[i]) v[j++] = v[i];
+    v.resize(j);
+}
+
+static int launch_pyramid(gf_tracker* h, const uint8_t* d_raw_frames) {
+    const PyrGeom& G = h->G;
+    const size_t seq_img = 2 * G.img_bytes, seq_der = 2 * G.der_elems;
+    uint8_t* img = h->d_img.p + (size_t)h->cur_slot * G.img_bytes;
+    int* der = h->d_der.p + (size_t)h->cur_slot * G.der_elems;
+    const LevelGeom g0 = G.lv[0];
+    {
+        const int n = ((g0.w + 2 * kPad) / 4) * (g0.h + 2 * kPad);
+        pyr_level0_kernel<<<dim3((n + 255) / 256, h->B), 256, 0, h->stream>>>(d_raw_frames, (size_t)g0.w * g0.h, g0.w, img, seq_img, g0);
+    }
+    for (int l = 1; l < G.nlevels; l++) {
+        const LevelGeom d = G.lv[l];
+        const int n = (d.w + 2 * kPad) * (d.h + 2 * kPad);
+        pyr_down_kernel<<<dim3((n + 255) / 256, h->B), 256, 0, h->stream>>>(img, seq_img, G.lv[l - 1], d);
+    }
+    scharr_kernel<<<dim3((g0.w * g0.h + 255) / 256, h->B, G.nlevels), 256, 0, h->stream>>>(img, seq_img, der, seq_der, G);
+    HIPCHK(hipGetLastError());
+    return GF_OK;
+}
+
+static LkBatchArgs lk_args(gf_tracker* h, int fwd_max_level, int use_init, int flow_back, int post_checks, const uint8_t* seqmask,
+                           const uint16_t* d_depth) {
+    LkBatchArgs A{};
+    A.img = h->d_img.p; A.der = h->d_der.p; A.prev_slot = 1 - h->cur_slot; A.cap = h->cap;
+    A.n_pts = h->d_npts.p; A.prev_pts = h->d_prev_pts.p; A.init_pts = h->d_init_pts.p; A.cur_pts = h->d_cur_pts.p;
+    A.status = h->d_status.p; A.fwd_status = h->d_fwd_status.p; A.depth_out = h->d_depth_out.p; A.depth = d_depth;
+    A.depth_seq_stride = (size_t)h->cfg.width * h->cfg.height; A.depth_stride = h->cfg.width;
+    A.counters = h->d_counters.p; A.fwd_max_level = fwd_max_level; A.fwd_use_init = use_init; A.flow_back = flow_back;
+    A.post_checks = post_checks; A.seq_mask = seqmask;
+    return A;
+}
+
+// setMask (feature_tracker.cpp:56-83): std::sort by track count (same comparator, same libstdc++ algorithm as
+// the reference) and greedy keep of points not covered by an earlier kept point's filled circle.
+static void set_mask_host(gf_tracker* h, SeqState& s, int2* centers, int& n_centers) {
+    struct E { int cnt; P2f pt; int id; uint16_t depth; };
+    std::vector<E> v;
+    v.reserve(s.cur_pts.size());
+    for (size_t i = 0; i < s.cur_pts.size(); i++) v.push_back({s.track_cnt[i], s.cur_pts[i], s.ids[i], s.cur_depth[i]});
+    std::sort(v.begin(), v.end(), [](const E& a, const E& b) { return a.cnt > b.cnt; });
+    s.cur_pts.clear(); s.ids.clear(); s.track_cnt.clear(); s.cur_depth.clear();
+    n_centers = 0;
+    const DiskTable& T = h->disk;
+    for (auto& it : v) {
+        const int x = cvRoundf(it.pt.x), y = cvRoundf(it.pt.y);
+        bool covered = false;
+        for (int k = 0; k < n_centers && !covered; k++) {
+            const int dy = std::abs(y - centers[k].y), dx = std::abs(x - centers[k].x);
+            if (dy <= T.radius && dx <= T.hw[dy]) covered = true;
+        }
+        if (!covered) {
+            s.cur_pts.push_back(it.pt); s.ids.push_back(it.id); s.track_cnt.push_back(it.cnt); s.cur_depth.push_back(it.depth);
+            centers[n_centers++] = make_int2(x, y);
+        }
+    }
+}
+
+static void pts_velocity(SeqState& s) {  // feature_tracker.cpp:810-847
+    s.pts_velocity.clear();
+    s.cur_un_pts_map.clear();
+    for (size_t i = 0; i < s.ids.size(); i++) s.cur_un_pts_map.insert({s.ids[i], s.cur_un_pts[i]});
+    if (!s.prev_un_pts_map.empty()) {
+        const double dt = s.cur_time - s.prev_time;
+        for (size_t i = 0; i < s.cur_un_pts.size(); i++) {
+            auto it = s.prev_un_pts_map.find(s.ids[i]);
+            if (it != s.prev_un_pts_map.end()) {
+                const double vx = (s.cur_un_pts[i].x - it->second.x) / dt, vy = (s.cur_un_pts[i].y - it->second.y) / dt;
+                s.pts_velocity.push_back({(float)vx, (float)vy});
+            } else s.pts_velocity.push_back({0.f, 0.f});
+        }
+    } else for (size_t i = 0; i < s.cur_pts.size(); i++) s.pts_velocity.push_back({0.f, 0.f});
+}
+
+static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, const uint16_t* d_depth, gf_feature_obs* out, int cap_out,
+                      int* n_out) {
+    const int B = h->B, cap = h->cap, W = h->cfg.width, H = h->cfg.height;
+    const bool prof = h->profiling;
+    h->cur_slot = h->frame & 1;
+    for (int b = 0; b < B; b++) { h->seq[b].cur_time = t[b]; h->seq[b].cur_pts.clear(); h->seq[b].cur_depth.clear(); }
+    if (prof) HIPCHK(hipEventRecord(h->ev[0], h->stream));
+    if (int rc = launch_pyramid(h, d_gray)) return rc;
+    if (prof) HIPCHK(hipEventRecord(h->ev[1], h->stream));
+
+    // ---- temporal optical flow (feature_tracker.cpp:113-176)
+    bool any_prev = false, any_pred = false, any_plain = false;
+    for (int b = 0; b < B; b++) {
+        SeqState& s = h->seq[b];
+        const int n = (int)s.prev_pts.size();
+        h->h_npts.p[b] = n;
+        if (n > cap) return set_err(GF_ERR_CAPACITY, "sequence %d holds %d points > capacity %d", b, n, cap);
+        for (int i = 0; i < n; i++) h->h_prev_pts.p[(size_t)b * cap + i] = make_float2(s.prev_pts[i].x, s.prev_pts[i].y);
+        if (n > 0) {
+            any_prev = true;
+            if (s.hasPrediction && (int)s.predict_pts.size() != n) return set_err(GF_ERR_INVALID, "sequence %d: prediction holds %d points but %d are tracked (call removeOutliers before setPrediction, estimator.cpp:1134-1135)", b, (int)s.predict_pts.size(), n);
+            if (s.hasPrediction) { any_pred = true; for (int i = 0; i < n; i++) h->h_init_pts.p[(size_t)b * cap + i] = make_float2(s.predict_pts[i].x, s.predict_pts[i].y); }
+            else any_plain = true;
+        }
+    }
+    bool lk_timed = false;
+    if (any_prev) {
+        HIPCHK(hipMemcpyAsync(h->d_npts.p, h->h_npts.p, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_prev_pts.p, h->h_prev_pts.p, (size_t)B * cap * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+        const uint8_t* mask_plain = nullptr; const uint8_t* mask_pred = nullptr;
+        if (any_pred) {
+            HIPCHK(hipMemcpyAsync(h->d_init_pts.p, h->h_init_pts.p, (size_t)B * cap * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+            for (int b = 0; b < B; b++) { h->h_seqmask.p[b] = h->seq[b].hasPrediction ? 0 : 1; h->h_seqmask.p[B + b] = h->seq[b].hasPrediction ? 1 : 0; }
+            HIPCHK(hipMemcpyAsync(h->d_seqmask.p, h->h_seqmask.p, 2 * B, hipMemcpyHostToDevice, h->stream));
+            mask_plain = h->d_seqmask.p; mask_pred = h->d_seqmask.p + B;
+        }
+        if (prof) HIPCHK(hipEventRecord(h->ev[2], h->stream));
+        const dim3 grid((cap + 3) / 4, B);
+        if (any_plain) { lk_track_kernel<<<grid, 256, 0, h->stream>>>(h->G, lk_args(h, 3, 0, h->cfg.flow_back, 1, mask_plain, d_depth)); h->stats.lk_launches++; }
+        if (any_pred) { lk_track_kernel<<<grid, 256, 0, h->stream>>>(h->G, lk_args(h, 1, 1, h->cfg.flow_back, 1, mask_pred, d_depth)); h->stats.lk_launches++; }
+        HIPCHK(hipGetLastError());
+        if (prof) { HIPCHK(hipEventRecord(h->ev[3], h->stream)); lk_timed = true; }
+        auto fetch = [&]() -> int {
+            HIPCHK(hipMemcpyAsync(h->h_cur_pts.p, h->d_cur_pts.p, (size_t)B * cap * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(h->h_status.p, h->d_status.p, (size_t)B * cap, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(h->h_fwd_status.p, h->d_fwd_status.p, (size_t)B * cap, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(h->h_depth_out.p, h->d_depth_out.p, (size_t)B * cap * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(h->h_counters.p, h->d_counters.p, (size_t)B * cap * 2 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+            return GF_OK;
+        };
+        if (int rc = fetch()) return rc;
+    }
+    // the Shi-Tomasi response does not depend on the mask: enqueue it behind LK so it overlaps the host's setMask
+    HIPCHK(hipEventRecord(h->ev[6], h->stream));
+    if (prof) HIPCHK(hipEventRecord(h->ev[4], h->stream));
+    {
+        const LevelGeom g0 = h->G.lv[0];
+        min_eig_kernel<<<dim3((W + 31) / 32, (H + 7) / 8, B), 256, 0, h->stream>>>(h->d_img.p + (size_t)h->cur_slot * h->G.img_bytes, 2 * h->G.img_bytes, g0,
+                                                                                     h->d_eig.p, h->eig_stride);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventSynchronize(h->ev[6]));
+
+    if (any_pred) {  // feature_tracker.cpp:124-132: fewer than 10 forward successes -> redo with 3 levels from scratch
+        bool need = false;
+        for (int b = 0; b < B; b++) {
+            h->h_seqmask.p[b] = 0;
+            if (!h->seq[b].hasPrediction || h->h_npts.p[b] == 0) continue;
+            int succ = 0;
+            for (int i = 0; i < h->h_npts.p[b]; i++) succ += h->h_fwd_status.p[(size_t)b * cap + i] ? 1 : 0;
+            if (succ < 10) { h->h_seqmask.p[b] = 1; need = true; }
+        }
+        if (need) {
+            std::vector<uint8_t> redo(h->h_seqmask.p, h->h_seqmask.p + B);
+            std::vector<uint8_t> keep_status(h->h_status.p, h->h_status.p + (size_t)B * cap);
+            std::vector<float2> keep_pts(h->h_cur_pts.p, h->h_cur_pts.p + (size_t)B * cap);
+            std::vector<uint16_t> keep_depth(h->h_depth_out.p, h->h_depth_out.p + (size_t)B * cap);
+            std::vector<unsigned> keep_cnt(h->h_counters.p, h->h_counters.p + (size_t)B * cap * 2);
+            HIPCHK(hipMemcpyAsync(h->d_seqmask.p, h->h_seqmask.p, B, hipMemcpyHostToDevice, h->stream));
+            lk_track_kernel<<<dim3((cap + 3) / 4, B), 256, 0, h->stream>>>(h->G, lk_args(h, 3, 0, h->cfg.flow_back, 1, h->d_seqmask.p, d_depth));
+            h->stats.lk_launches++;
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(h->h_cur_pts.p, h->d_cur_pts.p, (size_t)B * cap * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(h->h_status.p, h->d_status.p, (size_t)B * cap, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(h->h_depth_out.p, h->d_depth_out.p, (size_t)B * cap * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(h->h_counters.p, h->d_counters.p, (size_t)B * cap * 2 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            for (int b = 0; b < B; b++) {
+                unsigned* cn = h->h_counters.p + (size_t)b * cap * 2;
+                const unsigned* kc = keep_cnt.data() + (size_t)b * cap * 2;
+                if (redo[b]) { for (int i = 0; i < 2 * cap; i++) cn[i] += kc[i]; continue; }  // both passes did work
+                memcpy(h->h_status.p + (size_t)b * cap, keep_status.data() + (size_t)b * cap, cap);
+                memcpy(h->h_cur_pts.p + (size_t)b * cap, keep_pts.data() + (size_t)b * cap, cap * sizeof(float2));
+                memcpy(h->h_depth_out.p + (size_t)b * cap, keep_depth.data() + (size_t)b * cap, cap * sizeof(uint16_t));
+                memcpy(cn, kc, cap * 2 * sizeof(unsigned));
+            }
+        }
+    }
+
+    // ---- host bookkeeping per sequence (feature_tracker.cpp:170-186)
+    bool any_want = false;
+    for (int b = 0; b < B; b++) {
+        SeqState& s = h->seq[b];
+        const int n = (int)s.prev_pts.size();
+        if (n > 0) {
+            const uint8_t* st = h->h_status.p + (size_t)b * cap;
+            s.cur_pts.resize(n); s.cur_depth.resize(n);
+            for (int i = 0; i < n; i++) {
+                const float2 c = h->h_cur_pts.p[(size_t)b * cap + i];
+                s.cur_pts[i] = {c.x, c.y};
+                s.cur_depth[i] = h->h_depth_out.p[(size_t)b * cap + i];
+                h->stats.lk_level_passes += h->h_counters.p[2 * ((size_t)b * cap + i)];
+                h->stats.lk_iterations += h->h_counters.p[2 * ((size_t)b * cap + i) + 1];
+            }
+            h->stats.lk_points += n;
+            reduce_vector(s.prev_pts, st); reduce_vector(s.cur_pts, st); reduce_vector(s.ids, st); reduce_vector(s.track_cnt, st);
+            reduce_vector(s.cur_depth, st);
+            h->stats.tracked_features += (long long)s.cur_pts.size();
+        }
+        for (auto& c : s.track_cnt) c++;
+        int nc = 0;
+        set_mask_host(h, s, h->h_centers.p + (size_t)b * cap, nc);
+        h->h_ncenters.p[b] = nc;
+        const int want = h->cfg.max_cnt - (int)s.cur_pts.size();
+        h->h_want.p[b] = want;
+        if (want > 0) any_want = true;
+        h->h_out_n.p[b] = 0;
+    }
+
+    // ---- Shi-Tomasi top-up (feature_tracker.cpp:190-206)
+    if (any_want) {
+        HIPCHK(hipMemcpyAsync(h->d_centers.p, h->h_centers.p, (size_t)B * cap * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_ncenters.p, h->h_ncenters.p, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_want.p, h->h_want.p, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemsetAsync(h->d_mask.p, 255, h->mask_stride * B, h->stream));
+        HIPCHK(hipMemsetAsync(h->d_maxkey.p, 0, B * sizeof(unsigned), h->stream));
+        HIPCHK(hipMemsetAsync(h->d_cand_count.p, 0, B * sizeof(int), h->stream));
+        mask_disks_kernel<<<dim3(cap, B), 256, 0, h->stream>>>(h->d_mask.p, h->mask_stride, W, H, h->d_centers.p, h->d_ncenters.p, cap, h->disk);
+        masked_max_kernel<<<dim3(64, B), 256, 0, h->stream>>>(h->d_eig.p, h->eig_stride, h->d_mask.p, h->mask_stride, W * H, h->d_maxkey.p);
+        const int npx = (W - 2) * (H - 2);
+        nms_collect_kernel<<<dim3((npx + 255) / 256, B), 256, 0, h->stream>>>(h->d_eig.p, h->eig_stride, h->d_mask.p, h->mask_stride, W, H, h->d_maxkey.p,
+                                                                            h->d_cand.p, (size_t)h->cand_cap, h->cand_cap, h->d_cand_count.p, h->d_want.p);
+        SelectArgs S{};
+        S.cand = h->d_cand.p; S.cand_seq_stride = (size_t)h->cand_cap; S.cand_cap = h->cand_cap; S.cand_count = h->d_cand_count.p; S.want = h->d_want.p;
+        S.w = W; S.h = H; S.min_dist = h->cfg.min_dist; S.out_cap = cap; S.out_pts = h->d_out_pts.p; S.out_depth = h->d_out_depth.p; S.out_n = h->d_out_n.p;
+        S.depth = d_depth; S.depth_seq_stride = (size_t)W * H; S.depth_stride = W;
+        select_corners_kernel<<<dim3(B), 1024, h->select_lds, h->stream>>>(S);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h->h_out_n.p, h->d_out_n.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(h->h_out_pts.p, h->d_out_pts.p, (size_t)B * cap * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(h->h_out_depth.p, h->d_out_depth.p, (size_t)B * cap * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(h->h_cand_count.p, h->d_cand_count.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (prof) HIPCHK(hipEventRecord(h->ev[5], h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (prof) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); h->stats.ms_pyramid += ms;
+        if (lk_timed) { HIPCHK(hipEventElapsedTime(&ms, h->ev[2], h->ev[3])); h->stats.ms_lk += ms; }
+        HIPCHK(hipEventElapsedTime(&ms, h->ev[4], h->ev[5])); h->stats.ms_detect += ms;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[5])); h->stats.ms_total_gpu += ms;
+    }
+    if (any_want)
+        for (int b = 0; b < B; b++)
+            if (h->h_want.p[b] > 0 && h->h_cand_count.p[b] > h->cand_cap)
+                return set_err(GF_ERR_CAPACITY, "sequence %d: %d corner candidates exceed capacity %d", b, h->h_cand_count.p[b], h->cand_cap);
+
+    // ---- addPoints, undistortedPts, ptsVelocity, pack (feature_tracker.cpp:85-93, 210-211, 322-368)
+    for (int b = 0; b < B; b++) {
+        SeqState& s = h->seq[b];
+        const int nn = h->h_want.p[b] > 0 ? h->h_out_n.p[b] : 0;
+        for (int i = 0; i < nn; i++) {
+            const float2 p = h->h_out_pts.p[(size_t)b * cap + i];
+            s.cur_pts.push_back({p.x, p.y}); s.ids.push_back(s.n_id++); s.track_cnt.push_back(1);
+            s.cur_depth.push_back(h->h_out_depth.p[(size_t)b * cap + i]);
+        }
+        s.cur_un_pts.clear();
+        for (auto& p : s.cur_pts) { double X, Y; lift_projective(h->cfg, (double)p.x, (double)p.y, X, Y); s.cur_un_pts.push_back({(float)(X / 1.0), (float)(Y / 1.0)}); }
+        pts_velocity(s);
+        s.prev_pts = s.cur_pts; s.prev_un_pts = s.cur_un_pts; s.prev_un_pts_map = s.cur_un_pts_map; s.prev_time = s.cur_time;
+        s.hasPrediction = false;
+        const int n = (int)s.ids.size();
+        if (n > cap_out) return set_err(GF_ERR_CAPACITY, "output capacity %d < %d features", cap_out, n);
+        gf_feature_obs* o = out + (size_t)b * cap_out;
+        for (int i = 0; i < n; i++) {
+            o[i].id = s.ids[i]; o[i].camera_id = 0;
+            o[i].v[0] = s.cur_un_pts[i].x; o[i].v[1] = s.cur_un_pts[i].y; o[i].v[2] = 1; o[i].v[3] = s.cur_pts[i].x; o[i].v[4] = s.cur_pts[i].y;
+            o[i].v[5] = s.pts_velocity[i].x; o[i].v[6] = s.pts_velocity[i].y;
+            o[i].v[7] = (h->cfg.depth_cam && d_depth) ? (double)(int)s.cur_depth[i] / 1000 : -2.4;
+        }
+        n_out[b] = n;
+        h->stats.output_features += n;
+    }
+    h->frame++;
+    h->stats.frames++;
+    return GF_OK;
+}
+
+}  // namespace gf
+
+// =============================================================================== C-ABI
+extern "C" {
+
+const char* gf_last_error(void) { return gf::g_err.c_str(); }
+
+int gf_device_count(int* n) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return gf::set_err(GF_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *n = c;
+    return GF_OK;
+}
+int gf_set_device(int device) { HIPCHK(hipSetDevice(device)); return GF_OK; }
+
+int gf_tracker_create(const gf_tracker_cfg* cfg, gf_tracker** out) {
+    if (!cfg || !out) return gf::set_err(GF_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->width < 32 || cfg->height < 32 || cfg->width % 4 || cfg->batch < 1 || cfg->max_cnt < 1 || cfg->min_dist < 0 || cfg->min_dist > gf::kMaxRadius)
+        return gf::set_err(GF_ERR_INVALID, "unsupported tracker configuration (width %% 4 == 0, width/height >= 32, 0 <= min_dist <= %d)", gf::kMaxRadius);
+    if (int rc = gf::require_device()) return rc;
+    gf_tracker* h = new gf_tracker();
+    h->cfg = *cfg;
+    h->B = cfg->batch;
+    h->cap = (cfg->max_cnt + 3) & ~3;
+    gf::build_geom(cfg->width, cfg->height, h->G);
+    gf::make_disk_table(cfg->min_dist, h->disk);
+    h->seq.resize(h->B);
+    const int W = cfg->width, H = cfg->height, B = h->B, cap = h->cap;
+    int cc = 1024;
+    while (cc < (W * H) / 2) cc <<= 1;
+    h->cand_cap = cc;
+    h->eig_stride = ((size_t)W * H + 3) & ~(size_t)3;
+    h->mask_stride = ((size_t)W * H + 15) & ~(size_t)15;
+    const int cell = std::max(cfg->min_dist, 1);
+    const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
+    h->select_lds = (size_t)gf::kSortLds * 8 + (size_t)((gw * gh + 3) & ~3) * 2 + (size_t)cap * 3 * 2 + 64;
+    if (h->select_lds > 160 * 1024) { delete h; return gf::set_err(GF_ERR_INVALID, "min_dist %d too small for the selection grid at %dx%d", cfg->min_dist, W, H); }
+#define A_(x) do { if (int rc_ = (x)) { h->release(); delete h; return rc_; } } while (0)
+#define H_(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { gf::set_err(GF_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); h->release(); delete h; return GF_ERR_HIP; } } while (0)
+    H_(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (auto& e : h->ev) H_(hipEventCreate(&e));
+    A_(h->d_img.alloc((size_t)B * 2 * h->G.img_bytes));
+    A_(h->d_der.alloc((size_t)B * 2 * h->G.der_elems));
+    A_(h->d_raw.alloc((size_t)B * W * H));
+    A_(h->d_depth.alloc((size_t)B * W * H));
+    A_(h->d_mask.alloc(h->mask_stride * B));
+    A_(h->d_eig.alloc(h->eig_stride * B));
+    A_(h->d_cand.alloc((size_t)B * h->cand_cap));
+    A_(h->d_status.alloc((size_t)B * cap)); A_(h->d_fwd_status.alloc((size_t)B * cap)); A_(h->d_seqmask.alloc(2 * (size_t)B));
+    A_(h->d_npts.alloc(B)); A_(h->d_cand_count.alloc(B)); A_(h->d_want.alloc(B)); A_(h->d_ncenters.alloc(B)); A_(h->d_out_n.alloc(B));
+    A_(h->d_depth_out.alloc((size_t)B * cap)); A_(h->d_out_depth.alloc((size_t)B * cap));
+    A_(h->d_prev_pts.alloc((size_t)B * cap)); A_(h->d_init_pts.alloc((size_t)B * cap)); A_(h->d_cur_pts.alloc((size_t)B * cap)); A_(h->d_out_pts.alloc((size_t)B * cap));
+    A_(h->d_counters.alloc((size_t)B * cap * 2)); A_(h->d_maxkey.alloc(B)); A_(h->d_centers.alloc((size_t)B * cap));
+    A_(h->h_npts.alloc(B)); A_(h->h_want.alloc(B)); A_(h->h_ncenters.alloc(B)); A_(h->h_out_n.alloc(B)); A_(h->h_cand_count.alloc(B));
+    A_(h->h_prev_pts.alloc((size_t)B * cap)); A_(h->h_init_pts.alloc((size_t)B * cap)); A_(h->h_cur_pts.alloc((size_t)B * cap)); A_(h->h_out_pts.alloc((size_t)B * cap));
+    A_(h->h_status.alloc((size_t)B * cap)); A_(h->h_fwd_status.alloc((size_t)B * cap)); A_(h->h_seqmask.alloc(2 * (size_t)B)); A_(h->h_depth_out.alloc((size_t)B * cap)); A_(h->h_out_depth.alloc((size_t)B * cap));
+    A_(h->h_counters.alloc((size_t)B * cap * 2)); A_(h->h_centers.alloc((size_t)B * cap));
+    H_(hipMemsetAsync(h->d_img.p, 0, h->d_img.n, h->stream));
+    H_(hipMemsetAsync(h->d_der.p, 0, h->d_der.n * sizeof(int), h->stream));  // derivative borders stay zero for ever
+    H_(hipFuncSetAttribute(reinterpret_cast<const void*>(gf::select_corners_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->select_lds));
+    H_(hipStreamSynchronize(h->stream));
+#undef A_
+#undef H_
+    *out = h;
+    return GF_OK;
+}
+
+int gf_tracker_destroy(gf_tracker* h) {
+    if (!h) return GF_OK;
+    h->release();
+    delete h;
+    return GF_OK;
+}
+
+int gf_tracker_track_batch_device(gf_tracker* h, const double* t, const void* d_gray, const void* d_depth, gf_feature_obs* out, int cap,
+                                  int* n_out) {
+    if (!h || !t || !d_gray || !out || !n_out) return gf::set_err(GF_ERR_INVALID, "null argument");
+    return gf::track_core(h, t, (const uint8_t*)d_gray, (const uint16_t*)d_depth, out, cap, n_out);
+}
+
+int gf_tracker_track_batch(gf_tracker* h, const double* t, const uint8_t* const* gray, int stride, const uint16_t* const* depth, int dstride,
+                           gf_feature_obs* out, int cap, int* n_out) {
+    if (!h || !t || !gray || !out || !n_out) return gf::set_err(GF_ERR_INVALID, "null argument");
+    const int W = h->cfg.width, H = h->cfg.height;
+    bool have_depth = depth != nullptr;
+    for (int b = 0; b < h->B; b++) {
+        if (!gray[b]) return gf::set_err(GF_ERR_INVALID, "null image for sequence %d", b);
+        HIPCHK(hipMemcpy2DAsync(h->d_raw.p + (size_t)b * W * H, W, gray[b], stride, W, H, hipMemcpyHostToDevice, h->stream));
+        if (have_depth && !depth[b]) have_depth = false;
+    }
+    if (have_depth)
+        for (int b = 0; b < h->B; b++)
+            HIPCHK(hipMemcpy2DAsync(h->d_depth.p + (size_t)b * W * H, (size_t)W * 2, depth[b], (size_t)dstride * 2, (size_t)W * 2, H, hipMemcpyHostToDevice, h->stream));
+    return gf::track_core(h, t, h->d_raw.p, have_depth ? h->d_depth.p : nullptr, out, cap, n_out);
+}
+
+int gf_tracker_track(gf_tracker* h, int seq, double t, const uint8_t* gray, int stride, const uint16_t* depth, int dstride, gf_feature_obs* out,
+                     int cap, int* n_out) {
+    if (!h) return gf::set_err(GF_ERR_INVALID, "null handle");
+    if (h->B != 1 || seq != 0) return gf::set_err(GF_ERR_INVALID, "gf_tracker_track drives a batch-1 handle (sequences of a batch advance in lock-step: use gf_tracker_track_batch)");
+    const uint8_t* g[1] = {gray};
+    const uint16_t* d[1] = {depth};
+    return gf_tracker_track_batch(h, &t, g, stride, depth ? d : nullptr, dstride, out, cap, n_out);
+}
+
+int gf_tracker_set_prediction(gf_tracker* h, int seq, const int* ids, const double* xyz, int n) {
+    if (!h || seq < 0 || seq >= h->B || (n > 0 && (!ids || !xyz))) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    gf::SeqState& s = h->seq[seq];
+    s.hasPrediction = true;
+    s.predict_pts.clear();
+    std::map<int, const double*> m;
+    for (int i = 0; i < n; i++) m[ids[i]] = xyz + 3 * i;
+    for (size_t i = 0; i < s.ids.size(); i++) {
+        auto it = m.find(s.ids[i]);
+        if (it != m.end()) { double u, v; gf::space_to_plane(h->cfg, it->second, u, v); s.predict_pts.push_back({(float)u, (float)v}); }
+        else s.predict_pts.push_back(s.prev_pts[i]);
+    }
+    return GF_OK;
+}
+
+int gf_tracker_remove_outliers(gf_tracker* h, int seq, const int* ids, int n) {
+    if (!h || seq < 0 || seq >= h->B || (n > 0 && !ids)) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    gf::SeqState& s = h->seq[seq];
+    std::set<int> rm(ids, ids + n);
+    std::vector<uint8_t> st;
+    for (size_t i = 0; i < s.ids.size(); i++) st.push_back(rm.count(s.ids[i]) ? 0 : 1);
+    gf::reduce_vector(s.prev_pts, st.data()); gf::reduce_vector(s.ids, st.data()); gf::reduce_vector(s.track_cnt, st.data());
+    return GF_OK;
+}
+
+int gf_tracker_get_state(gf_tracker* h, int seq, int* ids, int* track_cnt, float* prev_pts_xy, int cap, int* n) {
+    if (!h || seq < 0 || seq >= h->B || !n) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    gf::SeqState& s = h->seq[seq];
+    *n = (int)s.ids.size();
+    if (*n > cap) return gf::set_err(GF_ERR_CAPACITY, "capacity %d < %d", cap, *n);
+    for (int i = 0; i < *n; i++) {
+        if (ids) ids[i] = s.ids[i];
+        if (track_cnt) track_cnt[i] = s.track_cnt[i];
+        if (prev_pts_xy) { prev_pts_xy[2 * i] = s.prev_pts[i].x; prev_pts_xy[2 * i + 1] = s.prev_pts[i].y; }
+    }
+    return GF_OK;
+}
+
+int gf_tracker_set_profiling(gf_tracker* h, int enable) { if (!h) return gf::set_err(GF_ERR_INVALID, "null handle"); h->profiling = enable != 0; return GF_OK; }
+int gf_tracker_get_stats(gf_tracker* h, gf_tracker_stats* out) { if (!h || !out) return gf::set_err(GF_ERR_INVALID, "null argument"); *out = h->stats; return GF_OK; }
+int gf_tracker_reset_stats(gf_tracker* h) { if (!h) return gf::set_err(GF_ERR_INVALID, "null handle"); h->stats = gf_tracker_stats{}; return GF_OK; }
+
+// ------------------------------------------------------------------ building blocks for parity tests
+static int tmp_handle(int width, int height, int max_cnt, int min_dist, gf_tracker** h) {
+    gf_tracker_cfg c{};
+    c.width = width; c.height = height; c.batch = 1; c.max_cnt = max_cnt; c.min_dist = min_dist; c.flow_back = 0; c.depth_cam = 0;
+    c.fx = c.fy = 1; c.cx = c.cy = 0;
+    return gf_tracker_create(&c, h);
+}
+
+int gf_lk_track(const uint8_t* prev, const uint8_t* next, int width, int height, const float* prev_pts, float* next_pts, uint8_t* status, int n,
+                int max_level, int use_initial_flow, long long* iterations) {
+    if (!prev || !next || !prev_pts || !next_pts || !status || n < 0) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    if (n == 0) return GF_OK;
+    gf_tracker* h = nullptr;
+    if (int rc = tmp_handle(width, height, n, 30, &h)) return rc;
+    int rc = GF_OK;
+    auto body = [&]() -> int {
+        const size_t px = (size_t)width * height;
+        HIPCHK(hipMemcpyAsync(h->d_raw.p, prev, px, hipMemcpyHostToDevice, h->stream));
+        h->cur_slot = 0;
+        if (int r = gf::launch_pyramid(h, h->d_raw.p)) return r;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_raw.p, next, px, hipMemcpyHostToDevice, h->stream));
+        h->cur_slot = 1;
+        if (int r = gf::launch_pyramid(h, h->d_raw.p)) return r;
+        h->h_npts.p[0] = n;
+        for (int i = 0; i < n; i++) {
+            h->h_prev_pts.p[i] = make_float2(prev_pts[2 * i], prev_pts[2 * i + 1]);
+            h->h_init_pts.p[i] = make_float2(next_pts[2 * i], next_pts[2 * i + 1]);
+        }
+        HIPCHK(hipMemcpyAsync(h->d_npts.p, h->h_npts.p, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_prev_pts.p, h->h_prev_pts.p, (size_t)h->cap * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_init_pts.p, h->h_init_pts.p, (size_t)h->cap * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+        gf::lk_track_kernel<<<dim3((h->cap + 3) / 4, 1), 256, 0, h->stream>>>(h->G, gf::lk_args(h, max_level, use_initial_flow ? 1 : 0, 0, 0, nullptr, nullptr));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h->h_cur_pts.p, h->d_cur_pts.p, (size_t)h->cap * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(h->h_status.p, h->d_status.p, (size_t)h->cap, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(h->h_counters.p, h->d_counters.p, (size_t)h->cap * 2 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        long long it = 0;
+        for (int i = 0; i < n; i++) {
+            next_pts[2 * i] = h->h_cur_pts.p[i].x; next_pts[2 * i + 1] = h->h_cur_pts.p[i].y;
+            status[i] = h->h_status.p[i];
+            it += h->h_counters.p[2 * i + 1];
+        }
+        if (iterations) *iterations = it;
+        return GF_OK;
+    };
+    rc = body();
+    gf_tracker_destroy(h);
+    return rc;
+}
+
+int gf_pyramid_level(const uint8_t* img, int width, int height, int level, uint8_t* out, int16_t* deriv_xy) {
+    if (!img || level < 0) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    gf_tracker* h = nullptr;
+    if (int rc = tmp_handle(width, height, 4, 30, &h)) return rc;
+    auto body = [&]() -> int {
+        if (level >= h->G.nlevels) return gf::set_err(GF_ERR_INVALID, "level %d not built (pyramid has %d levels)", level, h->G.nlevels);
+        HIPCHK(hipMemcpyAsync(h->d_raw.p, img, (size_t)width * height, hipMemcpyHostToDevice, h->stream));
+        h->cur_slot = 0;
+        if (int r = gf::launch_pyramid(h, h->d_raw.p)) return r;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const gf::LevelGeom g = h->G.lv[level];
+        if (out) HIPCHK(hipMemcpy2D(out, g.w, h->d_img.p + g.img_off, g.stride, g.w, g.h, hipMemcpyDeviceToHost));
+        if (deriv_xy) HIPCHK(hipMemcpy2D(deriv_xy, (size_t)g.w * 4, h->d_der.p + g.der_off, (size_t)g.stride * 4, (size_t)g.w * 4, g.h, hipMemcpyDeviceToHost));
+        return GF_OK;
+    };
+    int rc = body();
+    gf_tracker_destroy(h);
+    return rc;
+}
+
+int gf_min_eigen_val(const uint8_t* img, int width, int height, float* eig) {
+    if (!img || !eig) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    gf_tracker* h = nullptr;
+    if (int rc = tmp_handle(width, height, 4, 30, &h)) return rc;
+    auto body = [&]() -> int {
+        HIPCHK(hipMemcpyAsync(h->d_raw.p, img, (size_t)width * height, hipMemcpyHostToDevice, h->stream));
+        h->cur_slot = 0;
+        if (int r = gf::launch_pyramid(h, h->d_raw.p)) return r;
+        gf::min_eig_kernel<<<dim3((width + 31) / 32, (height + 7) / 8, 1), 256, 0, h->stream>>>(h->d_img.p, 2 * h->G.img_bytes, h->G.lv[0], h->d_eig.p, h->eig_stride);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(eig, h->d_eig.p, (size_t)width * height * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return GF_OK;
+    };
+    int rc = body();
+    gf_tracker_destroy(h);
+    return rc;
+}
+
+int gf_good_features(const uint8_t* img, int width, int height, const uint8_t* mask, int max_corners, int min_dist, float* corners_xy, int* n_out) {
+    if (!img || !corners_xy || !n_out || max_corners < 1) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    gf_tracker* h = nullptr;
+    if (int rc = tmp_handle(width, height, max_corners, min_dist, &h)) return rc;
+    auto body = [&]() -> int {
+        const int W = width, H = height;
+        HIPCHK(hipMemcpyAsync(h->d_raw.p, img, (size_t)W * H, hipMemcpyHostToDevice, h->stream));
+        h->cur_slot = 0;
+        if (int r = gf::launch_pyramid(h, h->d_raw.p)) return r;
+        gf::min_eig_kernel<<<dim3((W + 31) / 32, (H + 7) / 8, 1), 256, 0, h->stream>>>(h->d_img.p, 2 * h->G.img_bytes, h->G.lv[0], h->d_eig.p, h->eig_stride);
+        if (mask) HIPCHK(hipMemcpyAsync(h->d_mask.p, mask, (size_t)W * H, hipMemcpyHostToDevice, h->stream));
+        else HIPCHK(hipMemsetAsync(h->d_mask.p, 255, (size_t)W * H, h->stream));
+        h->h_want.p[0] = max_corners;
+        HIPCHK(hipMemcpyAsync(h->d_want.p, h->h_want.p, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemsetAsync(h->d_maxkey.p, 0, sizeof(unsigned), h->stream));
+        HIPCHK(hipMemsetAsync(h->d_cand_count.p, 0, sizeof(int), h->stream));
+        gf::masked_max_kernel<<<dim3(64, 1), 256, 0, h->stream>>>(h->d_eig.p, h->eig_stride, h->d_mask.p, h->mask_stride, W * H, h->d_maxkey.p);
+        const int npx = (W - 2) * (H - 2);
+        gf::nms_collect_kernel<<<dim3((npx + 255) / 256, 1), 256, 0, h->stream>>>(h->d_eig.p, h->eig_stride, h->d_mask.p, h->mask_stride, W, H, h->d_maxkey.p, h->d_cand.p,
+                                                                                (size_t)h->cand_cap, h->cand_cap, h->d_cand_count.p, h->d_want.p);
+        gf::SelectArgs S{};
+        S.cand = h->d_cand.p; S.cand_seq_stride = (size_t)h->cand_cap; S.cand_cap = h->cand_cap; S.cand_count = h->d_cand_count.p; S.want = h->d_want.p;
+        S.w = W; S.h = H; S.min_dist = min_dist; S.out_cap = h->cap; S.out_pts = h->d_out_pts.p; S.out_depth = h->d_out_depth.p; S.out_n = h->d_out_n.p;
+        gf::select_corners_kernel<<<dim3(1), 1024, h->select_lds, h->stream>>>(S);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h->h_out_n.p, h->d_out_n.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(h->h_out_pts.p, h->d_out_pts.p, (size_t)h->cap * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        *n_out = h->h_out_n.p[0];
+        for (int i = 0; i < *n_out; i++) { corners_xy[2 * i] = h->h_out_pts.p[i].x; corners_xy[2 * i + 1] = h->h_out_pts.p[i].y; }
+        return GF_OK;
+    };
+    int rc = body();
+    gf_tracker_destroy(h);
+    return rc;
+}
+
+}  // extern "C"

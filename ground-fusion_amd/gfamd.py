@@ -1,0 +1,203 @@
+"""ctypes binding of the C-ABI (include/groundfusion_hip.h) — the call surface tests and bench.py use.
+Mirrors the reference's FeatureTracker interface names (trackImage / setPrediction / removeOutliers).
+Raises if the HIP library is missing or no GPU is present: there is no CPU fallback in the product path."""
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libgroundfusion_hip.so")
+_LIB = None
+
+
+class GfError(RuntimeError):
+    pass
+
+
+class TrackerCfg(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("batch", C.c_int), ("max_cnt", C.c_int), ("min_dist", C.c_int),
+                ("flow_back", C.c_int), ("depth_cam", C.c_int),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("k1", C.c_double), ("k2", C.c_double), ("p1", C.c_double), ("p2", C.c_double)]
+
+
+class FeatureObs(C.Structure):
+    _fields_ = [("id", C.c_int), ("camera_id", C.c_int), ("v", C.c_double * 8)]
+
+
+class TrackerStats(C.Structure):
+    _fields_ = [("ms_pyramid", C.c_double), ("ms_lk", C.c_double), ("ms_detect", C.c_double), ("ms_total_gpu", C.c_double),
+                ("frames", C.c_longlong), ("lk_launches", C.c_longlong), ("lk_points", C.c_longlong),
+                ("lk_level_passes", C.c_longlong), ("lk_iterations", C.c_longlong), ("tracked_features", C.c_longlong),
+                ("output_features", C.c_longlong)]
+
+
+OBS_DTYPE = np.dtype([("id", np.int32), ("camera_id", np.int32), ("v", np.float64, (8,))])
+assert OBS_DTYPE.itemsize == C.sizeof(FeatureObs)
+
+EXPORTS = ["gf_last_error", "gf_device_count", "gf_set_device", "gf_tracker_create", "gf_tracker_destroy", "gf_tracker_track",
+           "gf_tracker_track_batch", "gf_tracker_track_batch_device", "gf_tracker_set_prediction", "gf_tracker_remove_outliers",
+           "gf_tracker_get_state", "gf_tracker_set_profiling", "gf_tracker_get_stats", "gf_tracker_reset_stats", "gf_lk_track",
+           "gf_good_features", "gf_min_eigen_val", "gf_pyramid_level"]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise GfError("HIP extension %s is missing: run `python __graft_entry__.py` (build) first; there is no CPU fallback" % LIB_PATH)
+        _LIB = C.CDLL(LIB_PATH)
+        _LIB.gf_last_error.restype = C.c_char_p
+    return _LIB
+
+
+def _chk(rc):
+    if rc != 0:
+        raise GfError("gf status %d: %s" % (rc, lib().gf_last_error().decode()))
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def device_count():
+    n = C.c_int(0)
+    lib().gf_device_count(C.byref(n))
+    return n.value
+
+
+def default_cfg(width=640, height=480, batch=1, max_cnt=150, min_dist=30, flow_back=1, depth_cam=1):
+    return TrackerCfg(width, height, batch, max_cnt, min_dist, flow_back, depth_cam, 603.95556640625, 603.1257934570312,
+                      324.0858154296875, 232.72303771972656, 0.0, 0.0, 0.0, 0.0)
+
+
+class FeatureTracker:
+    """`batch` independent FeatureTracker instances (feature_tracker.h:43-99) advanced in lock-step on one GPU."""
+
+    def __init__(self, cfg=None):
+        self.cfg = cfg or default_cfg()
+        self.h = C.c_void_p()
+        _chk(lib().gf_tracker_create(C.byref(self.cfg), C.byref(self.h)))
+        self.cap = 4 * ((self.cfg.max_cnt + 3) // 4)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gf_tracker_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _unpack(self, out, n):
+        res = []
+        for b in range(self.cfg.batch):
+            o = out[b, :n[b]]
+            res.append((o["id"].copy(), o["v"].copy()))
+        return res
+
+    def trackImage(self, t, img, depth=None):
+        """batch == 1 convenience: returns (ids, obs[n,8])."""
+        return self.trackImageBatch([t], [img], None if depth is None else [depth])[0]
+
+    def trackImageBatch(self, ts, imgs, depths=None):
+        B = self.cfg.batch
+        ts = np.ascontiguousarray(ts, np.float64)
+        imgs = [np.ascontiguousarray(i, np.uint8) for i in imgs]
+        gp = (C.POINTER(C.c_uint8) * B)(*[_p(i, C.c_uint8) for i in imgs])
+        if depths is not None:
+            depths = [np.ascontiguousarray(d, np.uint16) for d in depths]
+            dp = (C.POINTER(C.c_uint16) * B)(*[_p(d, C.c_uint16) for d in depths])
+        else:
+            dp = None
+        out = np.zeros((B, self.cap), OBS_DTYPE)
+        n = np.zeros(B, np.int32)
+        _chk(lib().gf_tracker_track_batch(self.h, _p(ts, C.c_double), gp, self.cfg.width, dp, self.cfg.width,
+                                          out.ctypes.data_as(C.POINTER(FeatureObs)), self.cap, _p(n, C.c_int)))
+        return self._unpack(out, n)
+
+    def trackImageBatchDevice(self, ts, d_gray_ptr, d_depth_ptr=None, unpack=True):
+        """d_*_ptr: integer device addresses (e.g. torch tensor .data_ptr()) of batch contiguous frames."""
+        B = self.cfg.batch
+        ts = np.ascontiguousarray(ts, np.float64)
+        if not hasattr(self, "_out"):
+            self._out = np.zeros((B, self.cap), OBS_DTYPE)
+            self._n = np.zeros(B, np.int32)
+        _chk(lib().gf_tracker_track_batch_device(self.h, _p(ts, C.c_double), C.c_void_p(d_gray_ptr),
+                                                 C.c_void_p(d_depth_ptr) if d_depth_ptr else None,
+                                                 self._out.ctypes.data_as(C.POINTER(FeatureObs)), self.cap, _p(self._n, C.c_int)))
+        return self._unpack(self._out, self._n) if unpack else self._n
+
+    def setPrediction(self, ids, xyz, seq=0):
+        ids = np.ascontiguousarray(ids, np.int32)
+        xyz = np.ascontiguousarray(xyz, np.float64)
+        _chk(lib().gf_tracker_set_prediction(self.h, seq, _p(ids, C.c_int), _p(xyz, C.c_double), len(ids)))
+
+    def removeOutliers(self, ids, seq=0):
+        ids = np.ascontiguousarray(ids, np.int32)
+        _chk(lib().gf_tracker_remove_outliers(self.h, seq, _p(ids, C.c_int), len(ids)))
+
+    def state(self, seq=0):
+        ids = np.zeros(self.cap, np.int32)
+        cnt = np.zeros(self.cap, np.int32)
+        pts = np.zeros((self.cap, 2), np.float32)
+        n = C.c_int(0)
+        _chk(lib().gf_tracker_get_state(self.h, seq, _p(ids, C.c_int), _p(cnt, C.c_int), _p(pts, C.c_float), self.cap, C.byref(n)))
+        return ids[:n.value].copy(), cnt[:n.value].copy(), pts[:n.value].copy()
+
+    def set_profiling(self, on=True):
+        _chk(lib().gf_tracker_set_profiling(self.h, int(on)))
+
+    def stats(self):
+        s = TrackerStats()
+        _chk(lib().gf_tracker_get_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in TrackerStats._fields_}
+
+    def reset_stats(self):
+        _chk(lib().gf_tracker_reset_stats(self.h))
+
+
+def lk_track(prev, nxt, prev_pts, next_pts=None, max_level=3):
+    prev = np.ascontiguousarray(prev, np.uint8)
+    nxt = np.ascontiguousarray(nxt, np.uint8)
+    h, w = prev.shape
+    pp = np.ascontiguousarray(prev_pts, np.float32)
+    use_init = next_pts is not None
+    npn = np.ascontiguousarray(next_pts, np.float32).copy() if use_init else np.zeros_like(pp)
+    st = np.zeros(len(pp), np.uint8)
+    it = C.c_longlong(0)
+    _chk(lib().gf_lk_track(_p(prev, C.c_uint8), _p(nxt, C.c_uint8), w, h, _p(pp, C.c_float), _p(npn, C.c_float), _p(st, C.c_uint8),
+                           len(pp), max_level, int(use_init), C.byref(it)))
+    return npn, st, it.value
+
+
+def good_features(img, max_corners, min_dist=30, mask=None):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((max_corners, 2), np.float32)
+    n = C.c_int(0)
+    mp = _p(np.ascontiguousarray(mask, np.uint8), C.c_uint8) if mask is not None else None
+    _chk(lib().gf_good_features(_p(img, C.c_uint8), w, h, mp, max_corners, min_dist, _p(out, C.c_float), C.byref(n)))
+    return out[:n.value].copy()
+
+
+def min_eigen_val(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((h, w), np.float32)
+    _chk(lib().gf_min_eigen_val(_p(img, C.c_uint8), w, h, _p(out, C.c_float)))
+    return out
+
+
+def pyramid_level(img, level):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    lw, lh = w, h
+    for _ in range(level):
+        lw, lh = (lw + 1) // 2, (lh + 1) // 2
+    out = np.zeros((lh, lw), np.uint8)
+    der = np.zeros((lh, lw, 2), np.int16)
+    _chk(lib().gf_pyramid_level(_p(img, C.c_uint8), w, h, level, _p(out, C.c_uint8), _p(der, C.c_int16)))
+    return out, der

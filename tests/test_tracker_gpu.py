@@ -1,0 +1,162 @@
+"""Parity tests proper: HIP path (through the C-ABI) vs the CPU oracle, bit-exact. Run with -m gpu."""
+import numpy as np
+import pytest
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(seed, n, w=640, h=480):
+    return synth.tracker_sequence(seed, n, w, h)
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (120, 160), (97, 132)])
+def test_pyramid_and_scharr_bit_exact(gf, oracle, shape):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    ref = img
+    level = 0
+    while True:
+        out, der = gf.pyramid_level(img, level)
+        assert np.array_equal(out, ref), "level %d image" % level
+        assert np.array_equal(der, oracle.scharr(ref)), "level %d derivative" % level
+        nxt = oracle.pyr_down(ref)
+        if level == 3 or nxt.shape[0] <= 21 or nxt.shape[1] <= 21:
+            break
+        ref = nxt
+        level += 1
+
+
+@pytest.mark.parametrize("max_level,use_init", [(3, False), (1, True), (0, False), (1, False)])
+def test_lk_bit_exact(gf, oracle, max_level, use_init):
+    tex = synth.make_texture(21)
+    f0 = synth.warp_frame(tex, 0, 0)
+    f1 = synth.warp_frame(tex, -3.7, 2.2, 0.004, 1.003)
+    pts = oracle.good_features(f0, 300, min_dist=15.0)
+    rng = np.random.default_rng(4)
+    # add hard cases: image border, outside the image, flat-ish areas
+    extra = np.array([[0.2, 0.3], [639.5, 479.2], [-30.0, 10.0], [700.0, 100.0], [320.25, 1.5], [5.5, 470.1]], np.float32)
+    pts = np.concatenate([pts, extra, rng.uniform(0, 1, (40, 2)).astype(np.float32) * [640, 480]]).astype(np.float32)
+    init = (pts + rng.normal(0, 1.5, pts.shape)).astype(np.float32) if use_init else None
+    r_pts, r_st, r_it = oracle.lk(f0, f1, pts, init, max_level=max_level)
+    g_pts, g_st, g_it = gf.lk_track(f0, f1, pts, init, max_level=max_level)
+    assert np.array_equal(r_st, g_st)
+    ok = r_st > 0
+    assert ok.sum() > 250
+    assert np.array_equal(r_pts[ok].view(np.uint32), g_pts[ok].view(np.uint32)), "tracked coordinates differ"
+    assert r_it == g_it
+
+
+def test_lk_small_image_fewer_levels(gf, oracle):
+    tex = synth.make_texture(8)
+    f0 = synth.warp_frame(tex, 0, 0, w=160, h=120)
+    f1 = synth.warp_frame(tex, 1.2, -0.8, w=160, h=120)
+    pts = oracle.good_features(f0, 60, min_dist=8.0)
+    r_pts, r_st, r_it = oracle.lk(f0, f1, pts, None, max_level=3)
+    g_pts, g_st, g_it = gf.lk_track(f0, f1, pts, None, max_level=3)
+    assert np.array_equal(r_st, g_st) and r_it == g_it
+    assert np.array_equal(r_pts[r_st > 0].view(np.uint32), g_pts[g_st > 0].view(np.uint32))
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (96, 128)])
+def test_min_eigen_val_bit_exact(gf, oracle, shape):
+    tex = synth.make_texture(13)
+    img = synth.warp_frame(tex, 3, 4, w=shape[1], h=shape[0])
+    a = oracle.min_eigen_val(img)
+    b = gf.min_eigen_val(img)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("max_corners,min_dist,masked", [(150, 30, False), (300, 20, False), (500, 12, True), (40, 30, True), (2000, 5, False)])
+def test_good_features_bit_exact(gf, oracle, max_corners, min_dist, masked):
+    tex = synth.make_texture(17)
+    img = synth.warp_frame(tex, 0, 0)
+    mask = None
+    if masked:
+        mask = np.full(img.shape, 255, np.uint8)
+        for (cx, cy) in [(100, 100), (320, 240), (600, 20), (10, 470)]:
+            oracle.fill_circle(mask, cx, cy, min_dist)
+        mask[200:260, :] = 0
+    a = oracle.good_features(img, max_corners, min_dist=float(min_dist), mask=mask)
+    b = gf.good_features(img, max_corners, min_dist=min_dist, mask=mask)
+    assert len(a) == len(b) and np.array_equal(a, b)
+
+
+def test_good_features_degenerate_images(gf, oracle):
+    flat = np.full((480, 640), 128, np.uint8)
+    assert len(gf.good_features(flat, 50)) == 0 == len(oracle.good_features(flat, 50))
+    allmasked = np.zeros((480, 640), np.uint8)
+    img = synth.warp_frame(synth.make_texture(2), 0, 0)
+    assert len(gf.good_features(img, 50, mask=allmasked)) == 0 == len(oracle.good_features(img, 50, mask=allmasked))
+
+
+@pytest.mark.parametrize("max_cnt,min_dist", [(150, 30), (300, 20), (500, 12)])
+def test_track_image_sequence_bit_exact_ids(gf, oracle, max_cnt, min_dist):
+    frames = _frames(1000, 8)
+    depth = [np.full(f.shape, 1000 + 37 * k, np.uint16) for k, f in enumerate(frames)]
+    ocfg = oracle.default_cfg(max_cnt=max_cnt, min_dist=min_dist)
+    otr = oracle.Tracker(ocfg)
+    gtr = gf.FeatureTracker(gf.default_cfg(max_cnt=max_cnt, min_dist=min_dist))
+    for k, f in enumerate(frames):
+        t = 0.0666 * k
+        oi, oo = otr.track(t, f, depth[k])
+        gi, go = gtr.trackImage(t, f, depth[k])
+        assert np.array_equal(oi, gi), "frame %d: feature id lists differ" % k
+        assert np.array_equal(oo.view(np.uint64), go.view(np.uint64)), "frame %d: observations differ" % k
+        os_, gs_ = otr.state(), gtr.state()
+        assert np.array_equal(os_[0], gs_[0]) and np.array_equal(os_[1], gs_[1]) and np.array_equal(os_[2], gs_[2])
+    assert gtr.stats()["lk_iterations"] == otr.lk_iters()
+    gtr.close()
+
+
+def test_track_image_prediction_and_outlier_feedback(gf, oracle):
+    """setPrediction / removeOutliers path (feature_tracker.cpp:118-133, :1006-1045), incl. the <10 fallback."""
+    frames = _frames(1003, 6)
+    otr = oracle.Tracker(oracle.default_cfg())
+    gtr = gf.FeatureTracker(gf.default_cfg())
+    rng = np.random.default_rng(9)
+    for k, f in enumerate(frames):
+        t = 0.0666 * k
+        oi, oo = otr.track(t, f, None)
+        gi, go = gtr.trackImage(t, f, None)
+        assert np.array_equal(oi, gi) and np.array_equal(oo.view(np.uint64), go.view(np.uint64)), "frame %d" % k
+        rm = oi[rng.random(len(oi)) < 0.05]
+        otr.remove_outliers(rm); gtr.removeOutliers(rm)
+        ids, _, pts = otr.state()
+        sel = rng.random(len(ids)) < 0.7
+        # predictions: normalised rays of the current pixel + noise; frame 3 gets garbage to force the fallback
+        noise = 200.0 if k == 3 else 1.0
+        uv = pts[sel] + rng.normal(0, noise, (sel.sum(), 2))
+        xyz = np.stack([(uv[:, 0] - 324.0858154296875) / 603.95556640625 * 2.0, (uv[:, 1] - 232.72303771972656) / 603.1257934570312 * 2.0,
+                        np.full(len(uv), 2.0)], 1)
+        otr.set_prediction(ids[sel], xyz); gtr.setPrediction(ids[sel], xyz)
+    gtr.close()
+
+
+def test_batched_sequences_match_individual_runs(gf, oracle):
+    B = 3
+    seqs = [_frames(1000 + b, 4) for b in range(B)]
+    gtr = gf.FeatureTracker(gf.default_cfg(batch=B))
+    otrs = [oracle.Tracker(oracle.default_cfg()) for _ in range(B)]
+    for k in range(4):
+        res = gtr.trackImageBatch([0.05 * k] * B, [seqs[b][k] for b in range(B)], None)
+        for b in range(B):
+            oi, oo = otrs[b].track(0.05 * k, seqs[b][k], None)
+            assert np.array_equal(oi, res[b][0]) and np.array_equal(oo.view(np.uint64), res[b][1].view(np.uint64))
+    gtr.close()
+
+
+def test_device_resident_entry_point(gf, oracle):
+    import torch
+    frames = _frames(1001, 3)
+    depth = [np.full(f.shape, 2000, np.uint16) for f in frames]
+    gtr = gf.FeatureTracker(gf.default_cfg())
+    otr = oracle.Tracker(oracle.default_cfg())
+    for k, f in enumerate(frames):
+        dg = torch.from_numpy(f).cuda()
+        dd = torch.from_numpy(depth[k].view(np.int16)).cuda()
+        torch.cuda.synchronize()
+        gi, go = gtr.trackImageBatchDevice([0.1 * k], dg.data_ptr(), dd.data_ptr())[0]
+        oi, oo = otr.track(0.1 * k, f, depth[k])
+        assert np.array_equal(oi, gi) and np.array_equal(oo.view(np.uint64), go.view(np.uint64))
+    gtr.close()

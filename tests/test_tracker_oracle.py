@@ -1,0 +1,128 @@
+"""CPU tests of the tracker oracle (checker) and of the C-ABI library's loadability. No GPU needed."""
+import ctypes as C
+import os
+import re
+import numpy as np
+import synth
+
+
+def test_pyrdown_matches_direct_formula(oracle):
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (37, 52), dtype=np.uint8)
+    out = oracle.pyr_down(img)
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    pad = np.pad(img.astype(np.int64), 2, mode="reflect")  # numpy 'reflect' == BORDER_REFLECT_101
+    ref = np.zeros(((37 + 1) // 2, (52 + 1) // 2), np.int64)
+    for y in range(ref.shape[0]):
+        for x in range(ref.shape[1]):
+            win = pad[2 * y:2 * y + 5, 2 * x:2 * x + 5]
+            ref[y, x] = (k[:, None] * k[None, :] * win).sum()
+    assert np.array_equal(out, ((ref + 128) >> 8).astype(np.uint8))
+
+
+def test_scharr_kernel(oracle):
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (24, 31), dtype=np.uint8)
+    d = oracle.scharr(img)
+    p = np.pad(img.astype(np.int64), 1, mode="reflect")
+    sm = np.array([3, 10, 3])
+    for y in (0, 5, 23):
+        for x in (0, 7, 30):
+            w = p[y:y + 3, x:x + 3]
+            dx = (sm * (w[:, 2] - w[:, 0])).sum()
+            dy = (sm * (w[2, :] - w[0, :])).sum()
+            assert d[y, x, 0] == dx and d[y, x, 1] == dy
+
+
+def test_lk_recovers_subpixel_shift(oracle):
+    tex = synth.make_texture(11)
+    f0 = synth.warp_frame(tex, 0, 0)
+    f1 = synth.warp_frame(tex, -2.4, 1.3)  # content moves by (+2.4, -1.3)
+    pts = oracle.good_features(f0, 100)
+    nxt, st, iters = oracle.lk(f0, f1, pts)
+    assert st.sum() >= 95 and iters > 0
+    d = (nxt - pts)[st > 0]
+    assert np.abs(np.median(d, 0) - np.array([2.4, -1.3])).max() < 0.05
+
+
+def test_fill_circle_shape(oracle):
+    m = np.full((101, 101), 255, np.uint8)
+    oracle.fill_circle(m, 50, 50, 30)
+    ys, xs = np.nonzero(m == 0)
+    assert ys.min() == 20 and ys.max() == 80 and xs.min() == 20 and xs.max() == 80
+    assert np.array_equal(m, m[::-1]) and np.array_equal(m, m[:, ::-1]) and np.array_equal(m, m.T)
+    r2 = (ys - 50) ** 2 + (xs - 50) ** 2
+    assert r2.max() <= 31 ** 2  # midpoint circle stays within radius + 1
+    # clipped drawing near the border paints the same pixels as the unclipped one
+    big = np.full((161, 161), 255, np.uint8)
+    oracle.fill_circle(big, 35, 40, 30)
+    small = np.full((101, 101), 255, np.uint8)
+    oracle.fill_circle(small, 5, 10, 30)
+    assert np.array_equal(small, big[30:131, 30:131])
+
+
+def test_good_features_min_distance_and_order(oracle):
+    tex = synth.make_texture(5)
+    img = synth.warp_frame(tex, 0, 0)
+    c = oracle.good_features(img, 150, min_dist=30.0)
+    assert len(c) == 150
+    d = np.linalg.norm(c[:, None] - c[None], axis=2) + np.eye(len(c)) * 1e9
+    assert d.min() >= 30.0
+    e = oracle.min_eigen_val(img)
+    v = e[c[:, 1].astype(int), c[:, 0].astype(int)]
+    assert np.all(np.diff(v) <= 0)  # accepted in descending response order
+    mask = np.full(img.shape, 255, np.uint8)
+    mask[:, :320] = 0
+    c2 = oracle.good_features(img, 50, min_dist=30.0, mask=mask)
+    assert len(c2) > 0 and c2[:, 0].min() >= 320
+
+
+def test_min_eig_checkerboard_corner(oracle):
+    img = np.full((64, 64), 40, np.uint8)
+    img[:32, :32] = 200
+    img[32:, 32:] = 200
+    e = oracle.min_eigen_val(img)
+    y, x = np.unravel_index(np.argmax(e), e.shape)
+    assert abs(y - 31.5) <= 1.5 and abs(x - 31.5) <= 1.5
+    assert e[5, 5] == 0 and e[10, 32] < 1e-6  # flat area, pure edge
+
+
+def test_tracker_ids_are_monotone_and_persistent(oracle):
+    tr = oracle.Tracker(oracle.default_cfg())
+    frames = synth.tracker_sequence(1000, 4)
+    prev = None
+    for k, f in enumerate(frames):
+        ids, obs = tr.track(0.0666 * k, f, np.full(f.shape, 1500, np.uint16))
+        assert len(ids) <= 150 and len(set(ids.tolist())) == len(ids)
+        assert np.all(obs[:, 2] == 1) and np.all(obs[:, 7] == 1.5)
+        if prev is not None:
+            common = set(ids.tolist()) & prev
+            assert len(common) > 60
+            new = sorted(set(ids.tolist()) - prev)
+            assert not new or new[0] > max(prev)  # n_id++ allocator (feature_tracker.cpp:90)
+        prev = set(ids.tolist())
+    _, cnt, _ = tr.state()
+    assert cnt.max() == 4
+
+
+def test_capi_library_exports_every_declared_symbol():
+    import gfamd
+    lib = gfamd.lib()  # loads without a GPU
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "groundfusion_hip.h")).read()
+    declared = set(re.findall(r"\b(gf_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    for name in sorted(declared):
+        assert hasattr(lib, name), "missing export " + name
+    assert set(gfamd.EXPORTS) <= declared
+
+
+def test_no_cpu_fallback_without_gpu():
+    import gfamd
+    if gfamd.device_count() > 0:
+        return
+    try:
+        gfamd.FeatureTracker()
+    except gfamd.GfError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("tracker creation must fail loudly without a HIP device")
