@@ -137,13 +137,14 @@ struct SelectArgs {
     const int* cand_count;
     const int* want;         // [batch] maxCorners for this frame (<=0: none)
     int w, h, min_dist, out_cap;
+    int sort_cap;            // keys that fit the LDS sort area (power of two <= kSortLds)
     float2* out_pts;         // [batch][out_cap]
     uint16_t* out_depth;     // [batch][out_cap]
     int* out_n;              // [batch]
     const uint16_t* depth; size_t depth_seq_stride; int depth_stride;
 };
 
-constexpr int kSortLds = 16384;  // keys sorted inside LDS (128 KiB); larger candidate sets sort in global memory
+constexpr int kSortLds = 16384;  // most keys sorted inside LDS (128 KiB); larger candidate sets sort in global memory
 
 template <class P>
 __device__ __forceinline__ void bitonic_desc(P keys, int npow2, int tid, int nthreads) {
@@ -175,7 +176,7 @@ __global__ void __launch_bounds__(1024) select_corners_kernel(SelectArgs A) {
     int npow2 = 64;
     while (npow2 < n) npow2 <<= 1;
     unsigned long long* lk = reinterpret_cast<unsigned long long*>(smem);
-    const bool in_lds = npow2 <= kSortLds;
+    const bool in_lds = npow2 <= A.sort_cap;
     if (in_lds) {
         for (int i = tid; i < npow2; i += 1024) lk[i] = i < n ? gk[i] : 0ull;
         __syncthreads();
@@ -193,7 +194,7 @@ __global__ void __launch_bounds__(1024) select_corners_kernel(SelectArgs A) {
     const int cell = A.min_dist >= 1 ? A.min_dist : 1;
     const int gw = (A.w + cell - 1) / cell, gh = (A.h + cell - 1) / cell;
     // accepted corners live after the key area: head[gw*gh] (int16 index or -1), then (x,y,next) records
-    short* head = reinterpret_cast<short*>(smem + (size_t)kSortLds * 8);
+    short* head = reinterpret_cast<short*>(smem + (size_t)A.sort_cap * 8);
     short* rec = head + ((gw * gh + 3) & ~3);  // rec[3*i] = x, y, next
     for (int i = lane; i < gw * gh; i += 64) head[i] = -1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -106,7 +106,7 @@ struct gf_tracker {
     gf_tracker_cfg cfg;
     PyrGeom G;
     DiskTable disk;
-    int B = 0, cap = 0, cand_cap = 0, frame = 0, cur_slot = 0;
+    int B = 0, cap = 0, cand_cap = 0, frame = 0, cur_slot = 0, sort_cap = 0;
     bool profiling = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
@@ -394,7 +394,7 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
                                                                             h->d_cand.p, (size_t)h->cand_cap, h->cand_cap, h->d_cand_count.p, h->d_want.p);
         SelectArgs S{};
         S.cand = h->d_cand.p; S.cand_seq_stride = (size_t)h->cand_cap; S.cand_cap = h->cand_cap; S.cand_count = h->d_cand_count.p; S.want = h->d_want.p;
-        S.w = W; S.h = H; S.min_dist = h->cfg.min_dist; S.out_cap = cap; S.out_pts = h->d_out_pts.p; S.out_depth = h->d_out_depth.p; S.out_n = h->d_out_n.p;
+        S.w = W; S.h = H; S.min_dist = h->cfg.min_dist; S.out_cap = cap; S.sort_cap = h->sort_cap; S.out_pts = h->d_out_pts.p; S.out_depth = h->d_out_depth.p; S.out_n = h->d_out_n.p;
         S.depth = d_depth; S.depth_seq_stride = (size_t)W * H; S.depth_stride = W;
         select_corners_kernel<<<dim3(B), 1024, h->select_lds, h->stream>>>(S);
         HIPCHK(hipGetLastError());
@@ -485,7 +485,10 @@ int gf_tracker_create(const gf_tracker_cfg* cfg, gf_tracker** out) {
     h->mask_stride = ((size_t)W * H + 15) & ~(size_t)15;
     const int cell = std::max(cfg->min_dist, 1);
     const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
-    h->select_lds = (size_t)gf::kSortLds * 8 + (size_t)((gw * gh + 3) & ~3) * 2 + (size_t)cap * 3 * 2 + 64;
+    const size_t grid_lds = (size_t)((gw * gh + 3) & ~3) * 2 + (size_t)cap * 3 * 2 + 64;
+    h->sort_cap = gf::kSortLds;
+    while (h->sort_cap > 64 && (size_t)h->sort_cap * 8 + grid_lds > 160 * 1024) h->sort_cap >>= 1;
+    h->select_lds = (size_t)h->sort_cap * 8 + grid_lds;
     if (h->select_lds > 160 * 1024) { delete h; return gf::set_err(GF_ERR_INVALID, "min_dist %d too small for the selection grid at %dx%d", cfg->min_dist, W, H); }
 #define A_(x) do { if (int rc_ = (x)) { h->release(); delete h; return rc_; } } while (0)
 #define H_(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { gf::set_err(GF_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); h->release(); delete h; return GF_ERR_HIP; } } while (0)
@@ -710,7 +713,7 @@ int gf_good_features(const uint8_t* img, int width, int height, const uint8_t* m
                                                                                 (size_t)h->cand_cap, h->cand_cap, h->d_cand_count.p, h->d_want.p);
         gf::SelectArgs S{};
         S.cand = h->d_cand.p; S.cand_seq_stride = (size_t)h->cand_cap; S.cand_cap = h->cand_cap; S.cand_count = h->d_cand_count.p; S.want = h->d_want.p;
-        S.w = W; S.h = H; S.min_dist = min_dist; S.out_cap = h->cap; S.out_pts = h->d_out_pts.p; S.out_depth = h->d_out_depth.p; S.out_n = h->d_out_n.p;
+        S.w = W; S.h = H; S.min_dist = min_dist; S.out_cap = h->cap; S.sort_cap = h->sort_cap; S.out_pts = h->d_out_pts.p; S.out_depth = h->d_out_depth.p; S.out_n = h->d_out_n.p;
         gf::select_corners_kernel<<<dim3(1), 1024, h->select_lds, h->stream>>>(S);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h->h_out_n.p, h->d_out_n.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));

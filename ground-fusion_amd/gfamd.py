@@ -46,6 +46,13 @@ def lib():
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise GfError("HIP extension %s is missing: run `python __graft_entry__.py` (build) first; there is no CPU fallback" % LIB_PATH)
+        # torch bundles its own libamdhip64.so (SONAME libamdhip64.so.7, same as /opt/rocm's). Two HIP runtimes in
+        # one process cannot both own the device, so let torch's copy load first; ours then binds to it by SONAME.
+        if os.environ.get("GF_NO_TORCH_PRELOAD") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         _LIB = C.CDLL(LIB_PATH)
         _LIB.gf_last_error.restype = C.c_char_p
     return _LIB
