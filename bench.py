@@ -167,6 +167,7 @@ def main():
                                    % (B, args.max_cnt, args.min_dist), "sequences_per_gpu": B, "window": 10, "features": args.max_cnt},
             "frames_per_s": B * world * K / el_max, "output_features_per_s": outf / el_max, "solves_per_s": None,
             "gpu_ms_per_step": {"pyramid": st["ms_pyramid"] / K, "lk": st["ms_lk"] / K, "detect": st["ms_detect"] / K, "total": st["ms_total_gpu"] / K},
+            "host_ms_per_step": {k: st[k] / K for k in ("ms_host_pre", "ms_wait_lk", "ms_host_mid", "ms_wait_detect", "ms_host_post")},
             "roofline": {"kernel": "lk_track_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms": lk_ms, "algorithmic_bytes_per_launch": alg_bytes / launches,
                          "points_per_launch": st["lk_points"] / launches, "iterations_per_launch": st["lk_iterations"] / launches},

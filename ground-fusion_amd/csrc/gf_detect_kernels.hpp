@@ -132,9 +132,128 @@ __global__ void __launch_bounds__(256) nms_collect_kernel(const float* __restric
         cand[b * cand_seq_stride + slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(y * w + x);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fused Shi-Tomasi pass: image tile -> covariance (LDS) -> min-eigenvalue (LDS) -> masked maximum and
+// 3x3 local-maximum candidates.  The response image never touches HBM.  The mask is either an explicit
+// u8 image (building-block entry point) or, in trackImage, the union of filled circles of radius MIN_DIST
+// around the kept points, tested analytically with OpenCV's midpoint-circle row table (no rasterised mask).
+// Tile: 64x16 outputs per 256-thread block (4 pixels per thread).
+constexpr int kDT_W = 64, kDT_H = 16;
+struct DetectArgs {
+    const uint8_t* pyr; size_t pyr_seq_stride; LevelGeom g;
+    const uint8_t* mask; size_t mask_seq_stride;            // optional explicit mask (non-zero = allowed)
+    const int2* centers; const int* n_centers; int cap;     // else: disks
+    const int* want;                                        // [batch] skip sequences that need no new corners
+    unsigned* maxkey;                                       // [batch] orderable max over unmasked pixels (0 = none)
+    unsigned long long* cand; size_t cand_seq_stride; int cand_cap; int* cand_count;
+};
+
+__global__ void __launch_bounds__(256) detect_fused_kernel(DetectArgs A, DiskTable T) {
+    __shared__ float cxx[kDT_H + 4][kDT_W + 5], cxy[kDT_H + 4][kDT_W + 5], cyy[kDT_H + 4][kDT_W + 5];
+    __shared__ float eg[kDT_H + 2][kDT_W + 3];
+    __shared__ int2 dsk[512];
+    __shared__ int n_dsk, n_cand, cand_base;
+    __shared__ unsigned blk_max;
+    __shared__ unsigned long long ckeys[kDT_W * kDT_H];
+    const int b = blockIdx.z;
+    if (A.want[b] <= 0) return;
+    const LevelGeom g = A.g;
+    const int bx = blockIdx.x * kDT_W, by = blockIdx.y * kDT_H, tid = threadIdx.x;
+    if (tid == 0) { n_dsk = 0; n_cand = 0; blk_max = 0; }
+    __syncthreads();
+    if (!A.mask) {  // disks whose bounding box touches this tile
+        const int n = A.n_centers[b];
+        for (int i = tid; i < n; i += 256) {
+            const int2 c = A.centers[(size_t)b * A.cap + i];
+            if (c.x + T.radius >= bx && c.x - T.radius < bx + kDT_W && c.y + T.radius >= by && c.y - T.radius < by + kDT_H) {
+                const int k = atomicAdd(&n_dsk, 1);
+                if (k < 512) dsk[k] = c;
+            }
+        }
+    }
+    const uint8_t* img = A.pyr + b * A.pyr_seq_stride + g.img_off;
+    const float f1 = (float)(1.0 * (1.0 / (4.0 * 3.0 * 255.0))), f0 = (float)(2.0 * (1.0 / (4.0 * 3.0 * 255.0)));
+    for (int t = tid; t < (kDT_W + 4) * (kDT_H + 4); t += 256) {
+        const int ty = t / (kDT_W + 4), tx = t - ty * (kDT_W + 4);
+        const int x = reflect101(bx + tx - 2, g.w), y = reflect101(by + ty - 2, g.h);
+        const uint8_t* p = img + (size_t)y * g.stride + x;
+        const int a0 = p[-g.stride - 1], a1 = p[-g.stride], a2 = p[-g.stride + 1];
+        const int m0 = p[-1], m2 = p[1];
+        const int c0 = p[g.stride - 1], c1 = p[g.stride], c2 = p[g.stride + 1];
+        const float t0 = (float)(a2 - a0), t1 = (float)(m2 - m0), t2 = (float)(c2 - c0);
+        const float dx = (t0 + t2) * f1 + t1 * f0;
+        float rt = f1 * (float)a0; rt += f0 * (float)a1; rt += f1 * (float)a2;
+        float rb = f1 * (float)c0; rb += f0 * (float)c1; rb += f1 * (float)c2;
+        const float dy = rb - rt;
+        cxx[ty][tx] = dx * dx; cxy[ty][tx] = dx * dy; cyy[ty][tx] = dy * dy;
+    }
+    __syncthreads();
+    // eig on the tile + 1 halo.  NOTE cov halo entries were evaluated at REFLECT_101 coordinates, which is what the
+    // box filter needs for in-image pixels; eig halo entries outside the image are never consulted below.
+    for (int t = tid; t < (kDT_W + 2) * (kDT_H + 2); t += 256) {
+        const int ty = t / (kDT_W + 2), tx = t - ty * (kDT_W + 2);
+        // the box window of an in-image pixel next to the border must see cov(reflect(x+-1)); the LDS entry at tile
+        // offset -1 relative to an image edge holds cov(reflect(-1)) = cov(1) only if that entry's own coordinate was
+        // reflected — it was (see above) — so plain neighbour reads are correct for in-image centres.
+        double sa = 0, sb = 0, sc = 0;
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) {
+                sa += (double)cxx[ty + dy][tx + dx];
+                sb += (double)cxy[ty + dy][tx + dx];
+                sc += (double)cyy[ty + dy][tx + dx];
+            }
+        const float a = (float)sa * 0.5f, bb = (float)sb, c = (float)sc * 0.5f;
+        eg[ty][tx] = (a + c) - sqrtf((a - c) * (a - c) + bb * bb);
+    }
+    __syncthreads();
+    const int nd = min(n_dsk, 512);
+    unsigned best = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int li = tid + q * 256;
+        const int ly = li / kDT_W, lx = li - ly * kDT_W;
+        const int x = bx + lx, y = by + ly;
+        if (x >= g.w || y >= g.h) continue;
+        bool allowed;
+        if (A.mask) allowed = A.mask[b * A.mask_seq_stride + (size_t)y * g.w + x] != 0;
+        else {
+            allowed = true;
+            for (int k = 0; k < nd; k++) {
+                const int dy = abs(y - dsk[k].y), dx = abs(x - dsk[k].x);
+                if (dy <= T.radius && dx <= T.hw[dy]) { allowed = false; break; }
+            }
+        }
+        if (!allowed) continue;
+        const float v = eg[ly + 1][lx + 1];
+        best = max(best, f32_orderable(v));
+        if (x < 1 || y < 1 || x >= g.w - 1 || y >= g.h - 1 || v == 0.f) continue;
+        const bool ismax = v >= eg[ly][lx] && v >= eg[ly][lx + 1] && v >= eg[ly][lx + 2] && v >= eg[ly + 1][lx] && v >= eg[ly + 1][lx + 2] &&
+                           v >= eg[ly + 2][lx] && v >= eg[ly + 2][lx + 1] && v >= eg[ly + 2][lx + 2];
+        if (ismax) {
+            const int k = atomicAdd(&n_cand, 1);
+            ckeys[k] = ((unsigned long long)f32_orderable(v) << 32) | (unsigned)(y * g.w + x);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o));
+    if ((tid & 63) == 0 && best) atomicMax(&blk_max, best);
+    __syncthreads();
+    if (tid == 0) {
+        if (blk_max) atomicMax(A.maxkey + b, blk_max);
+        cand_base = n_cand ? atomicAdd(A.cand_count + b, n_cand) : 0;
+    }
+    __syncthreads();
+    for (int k = tid; k < n_cand; k += 256)
+        if (cand_base + k < A.cand_cap) A.cand[b * A.cand_seq_stride + cand_base + k] = ckeys[k];
+}
+
 struct SelectArgs {
     unsigned long long* cand; size_t cand_seq_stride; int cand_cap;
     const int* cand_count;
+    const unsigned* maxkey;  // [batch] orderable masked maximum (threshold = 0.01 * max, THRESH_TOZERO)
     const int* want;         // [batch] maxCorners for this frame (<=0: none)
     int w, h, min_dist, out_cap;
     int sort_cap;            // keys that fit the LDS sort area (power of two <= kSortLds)
@@ -177,12 +296,17 @@ __global__ void __launch_bounds__(1024) select_corners_kernel(SelectArgs A) {
     while (npow2 < n) npow2 <<= 1;
     unsigned long long* lk = reinterpret_cast<unsigned long long*>(smem);
     const bool in_lds = npow2 <= A.sort_cap;
+    const unsigned mk = A.maxkey[b];
+    const double maxVal = mk ? (double)f32_from_orderable(mk) : 0.0;
+    const float thresh = (float)(maxVal * 0.01);
+    // candidates are all unmasked non-zero local maxima; keep those above the quality threshold (others sort last as 0)
+    auto keep = [&](unsigned long long k) -> unsigned long long { return f32_from_orderable((unsigned)(k >> 32)) > thresh ? k : 0ull; };
     if (in_lds) {
-        for (int i = tid; i < npow2; i += 1024) lk[i] = i < n ? gk[i] : 0ull;
+        for (int i = tid; i < npow2; i += 1024) lk[i] = i < n ? keep(gk[i]) : 0ull;
         __syncthreads();
         bitonic_desc(lk, npow2, tid, 1024);
     } else {
-        for (int i = n + tid; i < npow2; i += 1024) gk[i] = 0ull;  // cand buffers are sized to a power of two
+        for (int i = tid; i < npow2; i += 1024) gk[i] = i < n ? keep(gk[i]) : 0ull;  // cand buffers are sized to a power of two
         __threadfence_block();
         __syncthreads();
         bitonic_desc(gk, npow2, tid, 1024);
@@ -203,8 +327,10 @@ __global__ void __launch_bounds__(1024) select_corners_kernel(SelectArgs A) {
     int naccept = 0;
     for (int base = 0; base < n && naccept < want; base += 64) {
         const int ci = base + lane;
-        const bool valid = ci < n;
-        const unsigned off = valid ? (unsigned)(keys[ci] & 0xffffffffu) : 0u;
+        const unsigned long long key = ci < n ? keys[ci] : 0ull;
+        const bool valid = key != 0ull;
+        if (!__any(valid)) break;  // zero keys (below threshold / padding) sort last
+        const unsigned off = (unsigned)(key & 0xffffffffu);
         const int y = (int)(off / (unsigned)A.w), x = (int)(off - (unsigned)y * A.w);
         const int xc = x / cell, yc = y / cell;
         bool good = valid;

@@ -9,6 +9,7 @@
 // point fails with GF_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -46,7 +47,9 @@ struct SeqState {  // per-sequence FeatureTracker members (feature_tracker.h:76-
     std::vector<P2f> prev_pts, cur_pts, predict_pts, prev_un_pts, cur_un_pts, pts_velocity;
     std::vector<int> ids, track_cnt;
     std::vector<uint16_t> cur_depth;
-    std::map<int, P2f> cur_un_pts_map, prev_un_pts_map;
+    // cur_un_pts_map / prev_un_pts_map (feature_tracker.h:89): id -> point, kept as id-sorted vectors (ids are unique)
+    std::vector<std::pair<int, P2f>> cur_un_pts_map, prev_un_pts_map;
+    std::vector<int> grid_head, grid_next;  // scratch of set_mask_host
     double cur_time = 0, prev_time = 0;
     int n_id = 0;
     bool hasPrediction = false;
@@ -213,41 +216,55 @@ static LkBatchArgs lk_args(gf_tracker* h, int fwd_max_level, int use_init, int f
 // the reference) and greedy keep of points not covered by an earlier kept point's filled circle.
 static void set_mask_host(gf_tracker* h, SeqState& s, int2* centers, int& n_centers) {
     struct E { int cnt; P2f pt; int id; uint16_t depth; };
-    std::vector<E> v;
-    v.reserve(s.cur_pts.size());
+    static thread_local std::vector<E> v;
+    v.clear();
     for (size_t i = 0; i < s.cur_pts.size(); i++) v.push_back({s.track_cnt[i], s.cur_pts[i], s.ids[i], s.cur_depth[i]});
     std::sort(v.begin(), v.end(), [](const E& a, const E& b) { return a.cnt > b.cnt; });
     s.cur_pts.clear(); s.ids.clear(); s.track_cnt.clear(); s.cur_depth.clear();
     n_centers = 0;
     const DiskTable& T = h->disk;
+    // `mask.at(pt) == 255` <=> pt is inside no earlier kept point's filled circle; circles reach at most `radius`
+    // pixels, so only centres in the 3x3 neighbourhood of radius-sized cells can cover pt.
+    const int cell = std::max(T.radius, 1);
+    const int gw = h->cfg.width / cell + 1, gh = h->cfg.height / cell + 1;
+    s.grid_head.assign((size_t)gw * gh, -1);
+    s.grid_next.clear();
     for (auto& it : v) {
         const int x = cvRoundf(it.pt.x), y = cvRoundf(it.pt.y);
+        const int cx = x / cell, cy = y / cell;
         bool covered = false;
-        for (int k = 0; k < n_centers && !covered; k++) {
-            const int dy = std::abs(y - centers[k].y), dx = std::abs(x - centers[k].x);
-            if (dy <= T.radius && dx <= T.hw[dy]) covered = true;
-        }
+        for (int yy = std::max(cy - 1, 0); yy <= std::min(cy + 1, gh - 1) && !covered; yy++)
+            for (int xx = std::max(cx - 1, 0); xx <= std::min(cx + 1, gw - 1) && !covered; xx++)
+                for (int k = s.grid_head[(size_t)yy * gw + xx]; k >= 0; k = s.grid_next[k]) {
+                    const int dy = std::abs(y - centers[k].y), dx = std::abs(x - centers[k].x);
+                    if (dy <= T.radius && dx <= T.hw[dy]) { covered = true; break; }
+                }
         if (!covered) {
             s.cur_pts.push_back(it.pt); s.ids.push_back(it.id); s.track_cnt.push_back(it.cnt); s.cur_depth.push_back(it.depth);
-            centers[n_centers++] = make_int2(x, y);
+            centers[n_centers] = make_int2(x, y);
+            s.grid_next.push_back(s.grid_head[(size_t)cy * gw + cx]);
+            s.grid_head[(size_t)cy * gw + cx] = n_centers++;
         }
     }
 }
 
 static void pts_velocity(SeqState& s) {  // feature_tracker.cpp:810-847
-    s.pts_velocity.clear();
-    s.cur_un_pts_map.clear();
-    for (size_t i = 0; i < s.ids.size(); i++) s.cur_un_pts_map.insert({s.ids[i], s.cur_un_pts[i]});
+    const size_t n = s.ids.size();
+    s.pts_velocity.resize(n);
+    s.cur_un_pts_map.resize(n);
+    for (size_t i = 0; i < n; i++) s.cur_un_pts_map[i] = {s.ids[i], s.cur_un_pts[i]};
+    std::sort(s.cur_un_pts_map.begin(), s.cur_un_pts_map.end(), [](const std::pair<int, P2f>& a, const std::pair<int, P2f>& b) { return a.first < b.first; });
     if (!s.prev_un_pts_map.empty()) {
         const double dt = s.cur_time - s.prev_time;
-        for (size_t i = 0; i < s.cur_un_pts.size(); i++) {
-            auto it = s.prev_un_pts_map.find(s.ids[i]);
-            if (it != s.prev_un_pts_map.end()) {
+        for (size_t i = 0; i < n; i++) {
+            const int id = s.ids[i];
+            auto it = std::lower_bound(s.prev_un_pts_map.begin(), s.prev_un_pts_map.end(), id, [](const std::pair<int, P2f>& a, int v) { return a.first < v; });
+            if (it != s.prev_un_pts_map.end() && it->first == id) {
                 const double vx = (s.cur_un_pts[i].x - it->second.x) / dt, vy = (s.cur_un_pts[i].y - it->second.y) / dt;
-                s.pts_velocity.push_back({(float)vx, (float)vy});
-            } else s.pts_velocity.push_back({0.f, 0.f});
+                s.pts_velocity[i] = {(float)vx, (float)vy};
+            } else s.pts_velocity[i] = {0.f, 0.f};
         }
-    } else for (size_t i = 0; i < s.cur_pts.size(); i++) s.pts_velocity.push_back({0.f, 0.f});
+    } else for (size_t i = 0; i < n; i++) s.pts_velocity[i] = {0.f, 0.f};
 }
 
 static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, const uint16_t* d_depth, gf_feature_obs* out, int cap_out,
@@ -255,6 +272,9 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
     const int B = h->B, cap = h->cap, W = h->cfg.width, H = h->cfg.height;
     const bool prof = h->profiling;
     h->cur_slot = h->frame & 1;
+    using clk = std::chrono::steady_clock;
+    auto tp = clk::now();
+    auto lap = [&](double& acc) { auto n = clk::now(); acc += std::chrono::duration<double, std::milli>(n - tp).count(); tp = n; };
     for (int b = 0; b < B; b++) { h->seq[b].cur_time = t[b]; h->seq[b].cur_pts.clear(); h->seq[b].cur_depth.clear(); }
     if (prof) HIPCHK(hipEventRecord(h->ev[0], h->stream));
     if (int rc = launch_pyramid(h, d_gray)) return rc;
@@ -302,16 +322,10 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
         };
         if (int rc = fetch()) return rc;
     }
-    // the Shi-Tomasi response does not depend on the mask: enqueue it behind LK so it overlaps the host's setMask
     HIPCHK(hipEventRecord(h->ev[6], h->stream));
-    if (prof) HIPCHK(hipEventRecord(h->ev[4], h->stream));
-    {
-        const LevelGeom g0 = h->G.lv[0];
-        min_eig_kernel<<<dim3((W + 31) / 32, (H + 7) / 8, B), 256, 0, h->stream>>>(h->d_img.p + (size_t)h->cur_slot * h->G.img_bytes, 2 * h->G.img_bytes, g0,
-                                                                                     h->d_eig.p, h->eig_stride);
-        HIPCHK(hipGetLastError());
-    }
+    lap(h->stats.ms_host_pre);
     HIPCHK(hipEventSynchronize(h->ev[6]));
+    lap(h->stats.ms_wait_lk);
 
     if (any_pred) {  // feature_tracker.cpp:124-132: fewer than 10 forward successes -> redo with 3 levels from scratch
         bool need = false;
@@ -384,16 +398,18 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
         HIPCHK(hipMemcpyAsync(h->d_centers.p, h->h_centers.p, (size_t)B * cap * sizeof(int2), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d_ncenters.p, h->h_ncenters.p, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d_want.p, h->h_want.p, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemsetAsync(h->d_mask.p, 255, h->mask_stride * B, h->stream));
         HIPCHK(hipMemsetAsync(h->d_maxkey.p, 0, B * sizeof(unsigned), h->stream));
         HIPCHK(hipMemsetAsync(h->d_cand_count.p, 0, B * sizeof(int), h->stream));
-        mask_disks_kernel<<<dim3(cap, B), 256, 0, h->stream>>>(h->d_mask.p, h->mask_stride, W, H, h->d_centers.p, h->d_ncenters.p, cap, h->disk);
-        masked_max_kernel<<<dim3(64, B), 256, 0, h->stream>>>(h->d_eig.p, h->eig_stride, h->d_mask.p, h->mask_stride, W * H, h->d_maxkey.p);
-        const int npx = (W - 2) * (H - 2);
-        nms_collect_kernel<<<dim3((npx + 255) / 256, B), 256, 0, h->stream>>>(h->d_eig.p, h->eig_stride, h->d_mask.p, h->mask_stride, W, H, h->d_maxkey.p,
-                                                                            h->d_cand.p, (size_t)h->cand_cap, h->cand_cap, h->d_cand_count.p, h->d_want.p);
+        if (prof) HIPCHK(hipEventRecord(h->ev[4], h->stream));
+        {
+            DetectArgs D{};
+            D.pyr = h->d_img.p + (size_t)h->cur_slot * h->G.img_bytes; D.pyr_seq_stride = 2 * h->G.img_bytes; D.g = h->G.lv[0];
+            D.mask = nullptr; D.mask_seq_stride = 0; D.centers = h->d_centers.p; D.n_centers = h->d_ncenters.p; D.cap = cap; D.want = h->d_want.p;
+            D.maxkey = h->d_maxkey.p; D.cand = h->d_cand.p; D.cand_seq_stride = (size_t)h->cand_cap; D.cand_cap = h->cand_cap; D.cand_count = h->d_cand_count.p;
+            detect_fused_kernel<<<dim3((W + kDT_W - 1) / kDT_W, (H + kDT_H - 1) / kDT_H, B), 256, 0, h->stream>>>(D, h->disk);
+        }
         SelectArgs S{};
-        S.cand = h->d_cand.p; S.cand_seq_stride = (size_t)h->cand_cap; S.cand_cap = h->cand_cap; S.cand_count = h->d_cand_count.p; S.want = h->d_want.p;
+        S.cand = h->d_cand.p; S.cand_seq_stride = (size_t)h->cand_cap; S.cand_cap = h->cand_cap; S.cand_count = h->d_cand_count.p; S.maxkey = h->d_maxkey.p; S.want = h->d_want.p;
         S.w = W; S.h = H; S.min_dist = h->cfg.min_dist; S.out_cap = cap; S.sort_cap = h->sort_cap; S.out_pts = h->d_out_pts.p; S.out_depth = h->d_out_depth.p; S.out_n = h->d_out_n.p;
         S.depth = d_depth; S.depth_seq_stride = (size_t)W * H; S.depth_stride = W;
         select_corners_kernel<<<dim3(B), 1024, h->select_lds, h->stream>>>(S);
@@ -403,8 +419,11 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
         HIPCHK(hipMemcpyAsync(h->h_out_depth.p, h->d_out_depth.p, (size_t)B * cap * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(h->h_cand_count.p, h->d_cand_count.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     }
+    if (prof && !any_want) HIPCHK(hipEventRecord(h->ev[4], h->stream));
     if (prof) HIPCHK(hipEventRecord(h->ev[5], h->stream));
+    lap(h->stats.ms_host_mid);
     HIPCHK(hipStreamSynchronize(h->stream));
+    lap(h->stats.ms_wait_detect);
     if (prof) {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); h->stats.ms_pyramid += ms;
@@ -429,7 +448,7 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
         s.cur_un_pts.clear();
         for (auto& p : s.cur_pts) { double X, Y; lift_projective(h->cfg, (double)p.x, (double)p.y, X, Y); s.cur_un_pts.push_back({(float)(X / 1.0), (float)(Y / 1.0)}); }
         pts_velocity(s);
-        s.prev_pts = s.cur_pts; s.prev_un_pts = s.cur_un_pts; s.prev_un_pts_map = s.cur_un_pts_map; s.prev_time = s.cur_time;
+        s.prev_pts = s.cur_pts; s.prev_un_pts = s.cur_un_pts; s.prev_un_pts_map.swap(s.cur_un_pts_map); s.prev_time = s.cur_time;
         s.hasPrediction = false;
         const int n = (int)s.ids.size();
         if (n > cap_out) return set_err(GF_ERR_CAPACITY, "output capacity %d < %d features", cap_out, n);
@@ -445,6 +464,7 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
     }
     h->frame++;
     h->stats.frames++;
+    lap(h->stats.ms_host_post);
     return GF_OK;
 }
 
@@ -498,8 +518,8 @@ int gf_tracker_create(const gf_tracker_cfg* cfg, gf_tracker** out) {
     A_(h->d_der.alloc((size_t)B * 2 * h->G.der_elems));
     A_(h->d_raw.alloc((size_t)B * W * H));
     A_(h->d_depth.alloc((size_t)B * W * H));
-    A_(h->d_mask.alloc(h->mask_stride * B));
-    A_(h->d_eig.alloc(h->eig_stride * B));
+    A_(h->d_mask.alloc(h->mask_stride));  // explicit masks exist only in the gf_good_features building block
+    A_(h->d_eig.alloc(h->eig_stride));    // response image materialised only by gf_min_eigen_val
     A_(h->d_cand.alloc((size_t)B * h->cand_cap));
     A_(h->d_status.alloc((size_t)B * cap)); A_(h->d_fwd_status.alloc((size_t)B * cap)); A_(h->d_seqmask.alloc(2 * (size_t)B));
     A_(h->d_npts.alloc(B)); A_(h->d_cand_count.alloc(B)); A_(h->d_want.alloc(B)); A_(h->d_ncenters.alloc(B)); A_(h->d_out_n.alloc(B));
@@ -700,19 +720,21 @@ int gf_good_features(const uint8_t* img, int width, int height, const uint8_t* m
         HIPCHK(hipMemcpyAsync(h->d_raw.p, img, (size_t)W * H, hipMemcpyHostToDevice, h->stream));
         h->cur_slot = 0;
         if (int r = gf::launch_pyramid(h, h->d_raw.p)) return r;
-        gf::min_eig_kernel<<<dim3((W + 31) / 32, (H + 7) / 8, 1), 256, 0, h->stream>>>(h->d_img.p, 2 * h->G.img_bytes, h->G.lv[0], h->d_eig.p, h->eig_stride);
         if (mask) HIPCHK(hipMemcpyAsync(h->d_mask.p, mask, (size_t)W * H, hipMemcpyHostToDevice, h->stream));
         else HIPCHK(hipMemsetAsync(h->d_mask.p, 255, (size_t)W * H, h->stream));
         h->h_want.p[0] = max_corners;
         HIPCHK(hipMemcpyAsync(h->d_want.p, h->h_want.p, sizeof(int), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemsetAsync(h->d_maxkey.p, 0, sizeof(unsigned), h->stream));
         HIPCHK(hipMemsetAsync(h->d_cand_count.p, 0, sizeof(int), h->stream));
-        gf::masked_max_kernel<<<dim3(64, 1), 256, 0, h->stream>>>(h->d_eig.p, h->eig_stride, h->d_mask.p, h->mask_stride, W * H, h->d_maxkey.p);
-        const int npx = (W - 2) * (H - 2);
-        gf::nms_collect_kernel<<<dim3((npx + 255) / 256, 1), 256, 0, h->stream>>>(h->d_eig.p, h->eig_stride, h->d_mask.p, h->mask_stride, W, H, h->d_maxkey.p, h->d_cand.p,
-                                                                                (size_t)h->cand_cap, h->cand_cap, h->d_cand_count.p, h->d_want.p);
+        {
+            gf::DetectArgs D{};
+            D.pyr = h->d_img.p; D.pyr_seq_stride = 2 * h->G.img_bytes; D.g = h->G.lv[0];
+            D.mask = h->d_mask.p; D.mask_seq_stride = h->mask_stride; D.centers = nullptr; D.n_centers = nullptr; D.cap = h->cap; D.want = h->d_want.p;
+            D.maxkey = h->d_maxkey.p; D.cand = h->d_cand.p; D.cand_seq_stride = (size_t)h->cand_cap; D.cand_cap = h->cand_cap; D.cand_count = h->d_cand_count.p;
+            gf::detect_fused_kernel<<<dim3((W + gf::kDT_W - 1) / gf::kDT_W, (H + gf::kDT_H - 1) / gf::kDT_H, 1), 256, 0, h->stream>>>(D, h->disk);
+        }
         gf::SelectArgs S{};
-        S.cand = h->d_cand.p; S.cand_seq_stride = (size_t)h->cand_cap; S.cand_cap = h->cand_cap; S.cand_count = h->d_cand_count.p; S.want = h->d_want.p;
+        S.cand = h->d_cand.p; S.cand_seq_stride = (size_t)h->cand_cap; S.cand_cap = h->cand_cap; S.cand_count = h->d_cand_count.p; S.maxkey = h->d_maxkey.p; S.want = h->d_want.p;
         S.w = W; S.h = H; S.min_dist = min_dist; S.out_cap = h->cap; S.sort_cap = h->sort_cap; S.out_pts = h->d_out_pts.p; S.out_depth = h->d_out_depth.p; S.out_n = h->d_out_n.p;
         gf::select_corners_kernel<<<dim3(1), 1024, h->select_lds, h->stream>>>(S);
         HIPCHK(hipGetLastError());

@@ -27,6 +27,7 @@ class FeatureObs(C.Structure):
 
 class TrackerStats(C.Structure):
     _fields_ = [("ms_pyramid", C.c_double), ("ms_lk", C.c_double), ("ms_detect", C.c_double), ("ms_total_gpu", C.c_double),
+                ("ms_host_pre", C.c_double), ("ms_wait_lk", C.c_double), ("ms_host_mid", C.c_double), ("ms_wait_detect", C.c_double), ("ms_host_post", C.c_double),
                 ("frames", C.c_longlong), ("lk_launches", C.c_longlong), ("lk_points", C.c_longlong),
                 ("lk_level_passes", C.c_longlong), ("lk_iterations", C.c_longlong), ("tracked_features", C.c_longlong),
                 ("output_features", C.c_longlong)]

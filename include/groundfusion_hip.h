@@ -56,6 +56,8 @@ typedef struct gf_feature_obs {
 typedef struct gf_tracker_stats {
     /* accumulated since the last gf_tracker_reset_stats(); times from hipEvents on the handle's stream */
     double ms_pyramid, ms_lk, ms_detect, ms_total_gpu;
+    /* host wall-clock split of the same frames: enqueue/pack, wait for LK, setMask bookkeeping, wait for detector, pack output */
+    double ms_host_pre, ms_wait_lk, ms_host_mid, ms_wait_detect, ms_host_post;
     long long frames;            /* frame-batches processed */
     long long lk_launches;       /* launches of the LK kernel */
     long long lk_points;         /* points submitted to LK */
