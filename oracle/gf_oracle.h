@@ -36,3 +36,54 @@ int gfo_good_features(const uint8_t* img, int w, int h, float* corners, int maxC
 #ifdef __cplusplus
 }
 #endif
+
+/* ------------------------------------------------------------------ back end (window solve) */
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* Parameter-block ids used by priors: kind * 4096 + index */
+enum { GFO_POSE = 0, GFO_SPEEDBIAS = 1, GFO_EX_POSE = 2, GFO_EX_WHEEL = 3, GFO_SX = 4, GFO_SY = 5, GFO_SW = 6, GFO_TD = 7, GFO_TD_WHEEL = 8, GFO_FEATURE = 9 };
+
+typedef struct gfo_window {
+    int W, n_feature, n_visual, n_imu, n_wheel;
+    int fix_ex_pose, fix_ex_wheel, fix_ix, fix_td, fix_td_wheel, fix_poses;
+    double G[3];
+    double vis_sqrt_info;
+    double* para_Pose; double* para_SpeedBias; double* para_Ex_Pose; double* para_Ex_Pose_wheel; double* para_Ix; double* para_Td;
+    double* para_Td_wheel; double* para_Feature;
+    const unsigned char* feature_fixed;
+    const int* vis_feature; const int* vis_i; const int* vis_j;
+    const double* vis_pts_i; const double* vis_pts_j; const double* vis_vel_i; const double* vis_vel_j; const double* vis_td_i; const double* vis_td_j;
+    const int* imu_i; const double* imu_sum_dt; const double* imu_delta_p; const double* imu_delta_q; const double* imu_delta_v;
+    const double* imu_lin_ba; const double* imu_lin_bg; const double* imu_jacobian; const double* imu_covariance;
+    const int* wh_i; const double* wh_sum_dt; const double* wh_delta_p; const double* wh_delta_q; const double* wh_jacobian;
+    const double* wh_covariance; const double* wh_lin; const double* wh_lin_vel; const double* wh_lin_gyr; const double* wh_vel_1; const double* wh_gyr_1;
+    int prior_n, prior_nblocks;
+    const int* prior_block_id; const double* prior_J; const double* prior_r; const double* prior_x0;
+} gfo_window;
+
+typedef struct gfo_summary {
+    int iterations, successful_steps, termination; /* 0 max iterations, 1 function tol, 2 parameter tol, 3 gradient tol, 4 failure */
+    double initial_cost, final_cost;
+    double radius;
+} gfo_summary;
+
+/* Estimator::optimization() lines estimator.cpp:2890-3327: ceres::Solve with DENSE_SCHUR + DOGLEG, max_iters iterations */
+int gfo_ba_solve(gfo_window* w, int max_iters, gfo_summary* s);
+/* estimator.cpp:3334-3631: mode 0 = MARGIN_OLD, 1 = MARGIN_SECOND_NEW. Outputs the next prior (block ids already address-shifted). */
+int gfo_ba_marginalize(const gfo_window* w, int mode, int cap_n, int* out_n, int* out_nblocks, int* out_block_id, double* out_J, double* out_r,
+                       double* out_x0, int* out_m);
+/* factor evaluation for unit tests: kind 0 visual k, 1 imu k, 2 wheel k, 3 prior; returns residuals and the dense Jacobian wrt the factor's
+ * parameter blocks in GLOBAL size (row-major, blocks concatenated), as ceres::CostFunction::Evaluate fills them */
+int gfo_factor_eval(const gfo_window* w, int kind, int k, double* residuals, double* jacobians, int* nres, int* ncols);
+/* IntegrationBase::push_back loop (integration_base.h:39-167); noise = ACC_N, GYR_N, ACC_W, GYR_W */
+void gfo_imu_preintegrate(int n, const double* dt, const double* acc, const double* gyr, const double* acc0, const double* gyr0, const double* ba,
+                          const double* bg, const double* noise, double* delta_p, double* delta_q, double* delta_v, double* jacobian, double* covariance,
+                          double* sum_dt);
+/* WheelIntegrationBase::push_back loop (wheel_integration_base.h:41-178); noise = VEL_N_wheel, GYR_N_wheel; lin = sx, sy, sw */
+void gfo_wheel_preintegrate(int n, const double* dt, const double* vel, const double* gyr, const double* vel0, const double* gyr0, const double* lin,
+                            const double* noise, double* delta_p, double* delta_q, double* jacobian, double* covariance, double* sum_dt);
+void gfo_sym_eig(int n, const double* A, double* d, double* V);
+#ifdef __cplusplus
+}
+#endif

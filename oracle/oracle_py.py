@@ -136,3 +136,83 @@ def good_features(img, max_corners, quality=0.01, min_dist=30.0, mask=None):
     n = lib().gfo_good_features(_p(img, C.c_uint8), w, h, _p(out, C.c_float), max_corners, C.c_double(quality),
                                 C.c_double(min_dist), mp)
     return out[:n].copy()
+
+
+# ------------------------------------------------------------------ back end
+def _bind_backend():
+    import gfwindow
+    L = lib()
+    L.gfo_ba_solve.argtypes = [C.POINTER(gfwindow.WindowC), C.c_int, C.POINTER(gfwindow.SummaryC)]
+    return gfwindow
+
+
+def ba_solve(win, max_iters=8):
+    """in-place on win's state arrays; returns summary dict"""
+    gw = _bind_backend()
+    c = win.to_c()
+    s = gw.SummaryC()
+    rc = lib().gfo_ba_solve(C.byref(c), max_iters, C.byref(s))
+    assert rc == 0
+    return {k: getattr(s, k) for k, _ in gw.SummaryC._fields_}
+
+
+def ba_marginalize(win, mode=0, cap_n=512):
+    gw = _bind_backend()
+    c = win.to_c()
+    n, nb, m = C.c_int(0), C.c_int(0), C.c_int(0)
+    bidv = np.zeros(256, np.int32)
+    J = np.zeros(cap_n * cap_n)
+    r = np.zeros(cap_n)
+    x0 = np.zeros(cap_n * 2)
+    rc = lib().gfo_ba_marginalize(C.byref(c), mode, cap_n, C.byref(n), C.byref(nb), _p(bidv, C.c_int), _p(J, C.c_double), _p(r, C.c_double),
+                                  _p(x0, C.c_double), C.byref(m))
+    if rc != 0:
+        return None
+    nn = n.value
+    ids = bidv[:nb.value].copy()
+    gs = sum(gw.gsize(int(i) // 4096) for i in ids)
+    return {"block_id": ids, "J": J[:nn * nn].copy(), "r": r[:nn].copy(), "x0": x0[:gs].copy(), "m": m.value, "n": nn}
+
+
+def factor_eval(win, kind, k):
+    _bind_backend()
+    c = win.to_c()
+    res = np.zeros(512)
+    jac = np.zeros(512 * 64)
+    nres, ncols = C.c_int(0), C.c_int(0)
+    rc = lib().gfo_factor_eval(C.byref(c), kind, k, _p(res, C.c_double), _p(jac, C.c_double), C.byref(nres), C.byref(ncols))
+    assert rc == 0
+    return res[:nres.value].copy(), jac[:nres.value * ncols.value].reshape(nres.value, ncols.value).copy()
+
+
+def imu_preintegrate(dt, acc, gyr, acc0, gyr0, ba, bg, noise):
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    dt, acc, gyr, acc0, gyr0, ba, bg, noise = map(f, (dt, acc, gyr, acc0, gyr0, ba, bg, noise))
+    out = {"delta_p": np.zeros(3), "delta_q": np.zeros(4), "delta_v": np.zeros(3), "jacobian": np.zeros(225), "covariance": np.zeros(225)}
+    sd = C.c_double(0)
+    lib().gfo_imu_preintegrate(len(dt), _p(dt, C.c_double), _p(acc, C.c_double), _p(gyr, C.c_double), _p(acc0, C.c_double), _p(gyr0, C.c_double),
+                               _p(ba, C.c_double), _p(bg, C.c_double), _p(noise, C.c_double), _p(out["delta_p"], C.c_double), _p(out["delta_q"], C.c_double),
+                               _p(out["delta_v"], C.c_double), _p(out["jacobian"], C.c_double), _p(out["covariance"], C.c_double), C.byref(sd))
+    out["sum_dt"] = sd.value
+    return out
+
+
+def wheel_preintegrate(dt, vel, gyr, vel0, gyr0, lin, noise):
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    dt, vel, gyr, vel0, gyr0, lin, noise = map(f, (dt, vel, gyr, vel0, gyr0, lin, noise))
+    out = {"delta_p": np.zeros(3), "delta_q": np.zeros(4), "jacobian": np.zeros(18), "covariance": np.zeros(36)}
+    sd = C.c_double(0)
+    lib().gfo_wheel_preintegrate(len(dt), _p(dt, C.c_double), _p(vel, C.c_double), _p(gyr, C.c_double), _p(vel0, C.c_double), _p(gyr0, C.c_double),
+                                 _p(lin, C.c_double), _p(noise, C.c_double), _p(out["delta_p"], C.c_double), _p(out["delta_q"], C.c_double),
+                                 _p(out["jacobian"], C.c_double), _p(out["covariance"], C.c_double), C.byref(sd))
+    out["sum_dt"] = sd.value
+    return out
+
+
+def sym_eig(A):
+    A = np.ascontiguousarray(A, np.float64)
+    n = A.shape[0]
+    d = np.zeros(n)
+    V = np.zeros((n, n))
+    lib().gfo_sym_eig(n, _p(A, C.c_double), _p(d, C.c_double), _p(V, C.c_double))
+    return d, V
