@@ -140,7 +140,8 @@ def test_marginalisation_prior_consistency(oracle, mode):
     ev = np.linalg.eigvalsh(H)
     assert np.allclose(H, H.T) and ev.min() > -1e-12 * ev.max()
     if mode == 1:
-        assert gw.bid(gw.POSE, w["W"]) not in p1["block_id"] and gw.bid(gw.POSE, w["W"] - 1) in p1["block_id"]
+        # the previous prior never holds the newest pose W; second-new marginalisation drops pose W-1 from it (estimator.cpp:3536-3558)
+        assert gw.bid(gw.POSE, w["W"] - 1) not in p1["block_id"] and gw.bid(gw.POSE, w["W"] - 2) in p1["block_id"]
         assert p1["m"] == 6
     # evaluating the new prior at its own linearisation point reproduces r
     w3 = SW.make_window(4, oracle, frame0=2 if mode == 0 else 1, prior=p1)
