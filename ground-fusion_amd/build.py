@@ -22,7 +22,7 @@ def build(force=False, verbose=False):
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -ffp-contract=off: the float solves must not be fused (bit parity with the CPU oracle / OpenCV baseline build)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-munsafe-fp-atomics",
            "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-o", LIB] + SRCS
     if verbose:
         print(" ".join(cmd))

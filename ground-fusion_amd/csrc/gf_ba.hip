@@ -1,0 +1,410 @@
+// gf_ba.hip — C-ABI back end (include/groundfusion_hip.h): host orchestration of the HIP sliding-window solver.
+//
+// Replaces the Ceres problem of Estimator::optimization() (estimator.cpp:2890-3327) for a batch of independent windows:
+// packs the para_* arrays and factor tables into device SoA buffers, runs a fixed schedule of dogleg iterations
+// (gf_ba_kernels.hpp) without host round trips, and builds the next marginalisation prior (gf_ba_marg.hpp).
+// No CPU fallback: every entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/groundfusion_hip.h"
+#include "gf_ba_kernels.hpp"
+
+namespace gf { int set_err(int code, const char* fmt, ...); }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return gf::set_err(GF_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+using namespace gfb;
+
+namespace {
+template <class T> struct Buf {  // device buffer + pinned host mirror
+    T* d = nullptr; T* h = nullptr; size_t n = 0;
+    int alloc(size_t count, bool host) {
+        n = count;
+        if (hipMalloc((void**)&d, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipMalloc(%zu B) failed", count * sizeof(T));
+        if (host) { if (hipHostMalloc((void**)&h, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipHostMalloc failed"); memset(h, 0, std::max<size_t>(count, 1) * sizeof(T)); }
+        return GF_OK;
+    }
+    void release() { if (d) (void)hipFree(d); if (h) (void)hipHostFree(h); d = nullptr; h = nullptr; }
+    hipError_t up(hipStream_t s) { return hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, s); }
+    hipError_t down(hipStream_t s) { return hipMemcpyAsync(h, d, n * sizeof(T), hipMemcpyDeviceToHost, s); }
+};
+}  // namespace
+
+struct gf_ba {
+    gf_ba_cfg cfg;
+    Dims d;
+    int count = 0;       // windows currently resident
+    bool any_ex = false; // some window estimates the camera extrinsic
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {};
+    gf_ba_stats stats{};
+    size_t step_lds = 0;
+    // inputs (host mirror + device)
+    Buf<double> xs0;     // pristine states [B][XS] (for reset)
+    Buf<double> xs;      // [2][B][XS]
+    Buf<int> colf, cole, nvis, nimu, nwh, nfeat, vis_feat, vis_i, vis_j, order, norder, feat_ptr, feat_fac, imu_i, wh_i, pri_n, pri_nb, pri_bid;
+    Buf<double> vis_data, imu_data, wh_data, pri_J, pri_r, pri_x0;
+    Buf<SolverState> st, st0;
+    // work
+    Buf<double> imu_sqrt, wh_sqrt, pri_A, pri_b, pri_c, H, g, cost, efac;
+    Buf<double> scale, diag, grad, gn, step, u, Et, Es, ete, etb, rhs, yv;
+    std::vector<Buf<double>*> dbl() { return {&xs0, &xs, &vis_data, &imu_data, &wh_data, &pri_J, &pri_r, &pri_x0, &imu_sqrt, &wh_sqrt, &pri_A, &pri_b, &pri_c, &H, &g, &cost, &efac,
+                                              &scale, &diag, &grad, &gn, &step, &u, &Et, &Es, &ete, &etb, &rhs, &yv}; }
+    std::vector<Buf<int>*> ints() { return {&colf, &cole, &nvis, &nimu, &nwh, &nfeat, &vis_feat, &vis_i, &vis_j, &order, &norder, &feat_ptr, &feat_fac, &imu_i, &wh_i, &pri_n, &pri_nb, &pri_bid}; }
+    void release() {
+        for (auto* b : dbl()) b->release();
+        for (auto* b : ints()) b->release();
+        st.release(); st0.release();
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    Win win() {
+        Win w{};
+        w.d = d; w.xs = xs.d; w.colf = colf.d; w.cole = cole.d; w.nvis = nvis.d; w.nimu = nimu.d; w.nwh = nwh.d; w.nfeat = nfeat.d;
+        w.vis_feat = vis_feat.d; w.vis_i = vis_i.d; w.vis_j = vis_j.d; w.vis_data = vis_data.d; w.order = order.d; w.norder = norder.d;
+        w.feat_ptr = feat_ptr.d; w.feat_fac = feat_fac.d; w.imu_i = imu_i.d; w.imu_data = imu_data.d; w.wh_i = wh_i.d; w.wh_data = wh_data.d;
+        w.imu_sqrt = imu_sqrt.d; w.wh_sqrt = wh_sqrt.d; w.pri_n = pri_n.d; w.pri_nb = pri_nb.d; w.pri_bid = pri_bid.d; w.pri_J = pri_J.d; w.pri_r = pri_r.d;
+        w.pri_x0 = pri_x0.d; w.pri_A = pri_A.d; w.pri_b = pri_b.d; w.pri_c = pri_c.d; w.H = H.d; w.g = g.d; w.cost = cost.d; w.efac = efac.d; w.st = st.d;
+        w.G[0] = G[0]; w.G[1] = G[1]; w.G[2] = G[2]; w.vis_sqrt_info = vis_sqrt_info;
+        return w;
+    }
+    StepBufs sbufs() {
+        StepBufs s{};
+        s.scale = scale.d; s.diag = diag.d; s.grad = grad.d; s.gn = gn.d; s.step = step.d; s.u = u.d; s.Et = Et.d; s.Es = Es.d; s.ete = ete.d; s.etb = etb.d;
+        s.rhs = rhs.d; s.yv = yv.d; s.VS = d.RP + d.FP;
+        return s;
+    }
+    double G[3] = {0, 0, 9.805};
+    double vis_sqrt_info = 400.0;
+};
+
+namespace {
+
+int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
+    const Dims& d = h->d;
+    if (count < 1 || count > d.B) return gf::set_err(GF_ERR_INVALID, "count %d outside 1..%d", count, d.B);
+    h->any_ex = false;
+    for (int b = 0; b < d.B; b++) {
+        const gf_ba_window& w = ws[std::min(b, count - 1)];  // unused slots replicate the last window (kernels run on the whole batch)
+        if (w.W != d.W) return gf::set_err(GF_ERR_INVALID, "window %d: W=%d, handle built for %d", b, w.W, d.W);
+        if (w.n_feature > d.F || w.n_visual > d.NV || w.n_imu > d.W || w.n_wheel > d.W || w.prior_n > d.NPRI || w.prior_nblocks > 64)
+            return gf::set_err(GF_ERR_CAPACITY, "window %d exceeds capacity (features %d/%d, visual %d/%d, prior %d/%d)", b, w.n_feature, d.F, w.n_visual, d.NV, w.prior_n, d.NPRI);
+        if (b == 0) { h->G[0] = w.G[0]; h->G[1] = w.G[1]; h->G[2] = w.G[2]; h->vis_sqrt_info = w.vis_sqrt_info; }
+        double* x = h->xs0.h + (size_t)b * d.XS;
+        memset(x, 0, d.XS * sizeof(double));
+        for (int i = 0; i < d.NP; i++) { memcpy(x + off_pose(i), w.para_Pose + 7 * i, 56); memcpy(x + off_sb(i), w.para_SpeedBias + 9 * i, 72); }
+        memcpy(x + off_ex(d.NP), w.para_Ex_Pose, 56); memcpy(x + off_exw(d.NP), w.para_Ex_Pose_wheel, 56); memcpy(x + off_ix(d.NP), w.para_Ix, 24);
+        x[off_td(d.NP)] = w.para_Td[0]; x[off_tdw(d.NP)] = w.para_Td_wheel[0];
+        for (int f = 0; f < w.n_feature; f++) x[off_feat(d.NP) + f] = w.para_Feature[f];
+        if (w.fix_poses) for (int i = 0; i < d.NP; i++) x[off_sb(i)] = x[off_sb(i) + 1] = x[off_sb(i) + 2] = 0.0;  // estimator.cpp:3233-3246
+        // column maps (canonical order: pose0, sb0, pose1, ..., ex, exw, sx, sy, sw, td, tdw)
+        int* cf = h->colf.h + (size_t)b * d.NFB;
+        int col = 0;
+        auto add = [&](int blk, bool constant, int ls) { if (constant) cf[blk] = -1; else { cf[blk] = col; col += ls; } };
+        for (int i = 0; i < d.NP; i++) { add(fb_pose(i), w.fix_poses != 0, 6); add(fb_sb(i), w.fix_poses != 0, 9); }
+        add(fb_ex(d.NP), w.fix_ex_pose != 0, 6);
+        const bool wheel = w.n_wheel > 0;
+        add(fb_exw(d.NP), !wheel || w.fix_ex_wheel, 6);
+        for (int q = 0; q < 3; q++) add(fb_sx(d.NP) + q, !wheel || w.fix_ix, 1);
+        add(fb_td(d.NP), w.fix_td != 0, 1);
+        add(fb_tdw(d.NP), !wheel || w.fix_td_wheel, 1);
+        if (!w.fix_ex_pose) h->any_ex = true;
+        SolverState& st = h->st0.h[b];
+        memset(&st, 0, sizeof st);
+        st.radius = 1e4; st.mu = 1e-8; st.R = col; st.last_successful = 1;
+        // visual factors
+        std::vector<char> used(std::max(w.n_feature, 1), 0);
+        for (int k = 0; k < w.n_visual; k++) {
+            const size_t kk = (size_t)b * d.NV + k;
+            if (w.vis_feature[k] < 0 || w.vis_feature[k] >= w.n_feature || w.vis_i[k] < 0 || w.vis_i[k] > d.W || w.vis_j[k] < 0 || w.vis_j[k] > d.W)
+                return gf::set_err(GF_ERR_INVALID, "window %d: visual factor %d has bad indices", b, k);
+            h->vis_feat.h[kk] = w.vis_feature[k]; h->vis_i.h[kk] = w.vis_i[k]; h->vis_j.h[kk] = w.vis_j[k];
+            double* vd = h->vis_data.h + kk * 12;
+            memcpy(vd, w.vis_pts_i + 3 * k, 24); memcpy(vd + 3, w.vis_pts_j + 3 * k, 24); memcpy(vd + 6, w.vis_vel_i + 2 * k, 16); memcpy(vd + 8, w.vis_vel_j + 2 * k, 16);
+            vd[10] = w.vis_td_i[k]; vd[11] = w.vis_td_j[k];
+            used[w.vis_feature[k]] = 1;
+        }
+        int ne = 0;
+        for (int f = 0; f < d.F; f++) {
+            const bool free_f = f < w.n_feature && used[f] && !(w.feature_fixed && w.feature_fixed[f]);
+            h->cole.h[(size_t)b * d.F + f] = free_f ? ne++ : -1;
+        }
+        st.NE = ne;
+        h->nvis.h[b] = w.n_visual; h->nimu.h[b] = w.n_imu; h->nwh.h[b] = w.n_wheel; h->nfeat.h[b] = w.n_feature;
+        {   // pair-sorted order with even padding (each MFMA consumes two factors of one frame pair)
+            std::vector<int> idx(w.n_visual);
+            for (int k = 0; k < w.n_visual; k++) idx[k] = k;
+            std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return w.vis_i[a] * 64 + w.vis_j[a] < w.vis_i[c] * 64 + w.vis_j[c]; });
+            int* ord = h->order.h + (size_t)b * d.NVP;
+            int n = 0;
+            for (size_t p = 0; p < idx.size();) {
+                size_t q = p;
+                const int key = w.vis_i[idx[p]] * 64 + w.vis_j[idx[p]];
+                while (q < idx.size() && w.vis_i[idx[q]] * 64 + w.vis_j[idx[q]] == key) ord[n++] = idx[q++];
+                if ((q - p) & 1) ord[n++] = -1;
+                p = q;
+            }
+            if (n > d.NVP) return gf::set_err(GF_ERR_CAPACITY, "factor order overflow");
+            h->norder.h[b] = n;
+            for (int i = n; i < d.NVP; i++) ord[i] = -1;
+        }
+        {   // CSR feature -> factors
+            int* fp = h->feat_ptr.h + (size_t)b * (d.F + 1);
+            std::vector<int> cnt(d.F + 1, 0);
+            for (int k = 0; k < w.n_visual; k++) cnt[w.vis_feature[k] + 1]++;
+            fp[0] = 0;
+            for (int f = 0; f < d.F; f++) fp[f + 1] = fp[f] + cnt[f + 1];
+            std::vector<int> cur(fp, fp + d.F);
+            for (int k = 0; k < w.n_visual; k++) h->feat_fac.h[(size_t)b * d.NV + cur[w.vis_feature[k]]++] = k;
+        }
+        for (int k = 0; k < w.n_imu; k++) {
+            h->imu_i.h[(size_t)b * d.W + k] = w.imu_i[k];
+            double* dd = h->imu_data.h + ((size_t)b * d.W + k) * IMU_STRIDE2;
+            dd[0] = w.imu_sum_dt[k];
+            memcpy(dd + 1, w.imu_delta_p + 3 * k, 24); memcpy(dd + 4, w.imu_delta_q + 4 * k, 32); memcpy(dd + 8, w.imu_delta_v + 3 * k, 24);
+            memcpy(dd + 11, w.imu_lin_ba + 3 * k, 24); memcpy(dd + 14, w.imu_lin_bg + 3 * k, 24);
+            memcpy(dd + IMU_JAC, w.imu_jacobian + 225 * k, 225 * 8); memcpy(dd + IMU_COV, w.imu_covariance + 225 * k, 225 * 8);
+        }
+        for (int k = 0; k < w.n_wheel; k++) {
+            h->wh_i.h[(size_t)b * d.W + k] = w.wh_i[k];
+            double* dd = h->wh_data.h + ((size_t)b * d.W + k) * WH_STRIDE;
+            dd[0] = w.wh_sum_dt[k];
+            memcpy(dd + 1, w.wh_delta_p + 3 * k, 24); memcpy(dd + 4, w.wh_delta_q + 4 * k, 32); memcpy(dd + 8, w.wh_jacobian + 18 * k, 144);
+            memcpy(dd + 26, w.wh_covariance + 36 * k, 288); memcpy(dd + 62, w.wh_lin + 4 * k, 32); memcpy(dd + 66, w.wh_lin_vel + 3 * k, 24);
+            memcpy(dd + 69, w.wh_lin_gyr + 3 * k, 24); memcpy(dd + 72, w.wh_vel_1 + 3 * k, 24); memcpy(dd + 75, w.wh_gyr_1 + 3 * k, 24);
+        }
+        h->pri_n.h[b] = w.prior_n; h->pri_nb.h[b] = w.prior_nblocks;
+        if (w.prior_n > 0) {
+            int gs = 0;
+            for (int q = 0; q < w.prior_nblocks; q++) { h->pri_bid.h[(size_t)b * 64 + q] = w.prior_block_id[q]; gs += gsize_kind(w.prior_block_id[q] / 4096); }
+            memcpy(h->pri_J.h + (size_t)b * d.NPRI * d.NPRI, w.prior_J, (size_t)w.prior_n * w.prior_n * 8);
+            memcpy(h->pri_r.h + (size_t)b * d.NPRI, w.prior_r, (size_t)w.prior_n * 8);
+            memcpy(h->pri_x0.h + (size_t)b * d.NPRI * 2, w.prior_x0, (size_t)gs * 8);
+        }
+    }
+    h->count = count;
+    return GF_OK;
+}
+
+int upload(gf_ba* h) {
+    hipStream_t s = h->stream;
+    HIPCHK(h->xs0.up(s));
+    for (auto* b : {&h->colf, &h->cole, &h->nvis, &h->nimu, &h->nwh, &h->nfeat, &h->vis_feat, &h->vis_i, &h->vis_j, &h->order, &h->norder, &h->feat_ptr, &h->feat_fac,
+                    &h->imu_i, &h->wh_i, &h->pri_n, &h->pri_nb, &h->pri_bid})
+        HIPCHK(b->up(s));
+    for (auto* b : {&h->vis_data, &h->imu_data, &h->wh_data, &h->pri_J, &h->pri_r, &h->pri_x0}) HIPCHK(b->up(s));
+    HIPCHK(hipMemcpyAsync(h->st0.d, h->st0.h, h->st0.n * sizeof(SolverState), hipMemcpyHostToDevice, s));
+    ba_setup<<<dim3(h->d.B), 256, 0, s>>>(h->win());
+    HIPCHK(hipGetLastError());
+    return GF_OK;
+}
+
+int reset_state(gf_ba* h) {
+    const Dims& d = h->d;
+    HIPCHK(hipMemcpyAsync(h->xs.d, h->xs0.d, (size_t)d.B * d.XS * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->st.d, h->st0.d, (size_t)d.B * sizeof(SolverState), hipMemcpyDeviceToDevice, h->stream));
+    return GF_OK;
+}
+
+int launch_linearize(gf_ba* h, int which, int which_state, int cost_only, int only_valid, bool timed) {
+    const Dims& d = h->d;
+    Win w = h->win();
+    if (timed) HIPCHK(hipEventRecord(h->ev[2], h->stream));
+    if (h->any_ex) ba_linearize_visual<true><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(w, which, which_state, cost_only, only_valid);
+    else ba_linearize_visual<false><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(w, which, which_state, cost_only, only_valid);
+    if (timed) HIPCHK(hipEventRecord(h->ev[3], h->stream));
+    ba_linearize_misc<<<dim3(d.B), 256, 0, h->stream>>>(w, which, which_state, cost_only, only_valid);
+    HIPCHK(hipGetLastError());
+    return GF_OK;
+}
+
+// The fixed launch schedule of one batch solve: initial linearisation, then max_iters x (step, linearise candidate), final accept.
+int run_solve(gf_ba* h, int max_iters) {
+    const Dims& d = h->d;
+    HIPCHK(hipMemsetAsync(h->H.d, 0, (size_t)d.B * d.RP * d.RP * sizeof(double), h->stream));   // buffer 0 only
+    HIPCHK(hipMemsetAsync(h->g.d, 0, (size_t)d.B * d.RP * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->cost.d, 0, (size_t)2 * d.B * sizeof(double), h->stream));
+    if (int rc = launch_linearize(h, 0, 0, 0, 0, false)) return rc;
+    Win w = h->win();
+    StepBufs sb = h->sbufs();
+    for (int it = 0; it <= max_iters; it++) {
+        ba_step<<<dim3(d.B), 512, h->step_lds, h->stream>>>(w, sb, it == 0 ? 1 : 0, max_iters, it == max_iters ? 1 : 0);
+        HIPCHK(hipGetLastError());
+        if (it < max_iters) {
+            // candidate state lives in buffer (1 - cur) of each window: linearise both ... the kernels pick the right one per window
+            if (int rc = launch_linearize(h, -1, -1, 0, 1, it == 0)) return rc;
+            if (it == 0) { h->stats.jtj_launches++; }
+        }
+    }
+    h->stats.solves += h->count;
+    return GF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
+    if (!cfg || !out) return gf::set_err(GF_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->window_size < 2 || cfg->window_size > 62 || cfg->max_features < 1 || cfg->max_visual < 1 || cfg->batch < 1) return gf::set_err(GF_ERR_INVALID, "bad gf_ba_cfg");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return gf::set_err(GF_ERR_NO_DEVICE, "no HIP device available; the HIP path has no CPU fallback");
+    gf_ba* h = new gf_ba();
+    h->cfg = *cfg;
+    Dims& d = h->d;
+    d.B = cfg->batch; d.W = cfg->window_size; d.NP = d.W + 1; d.F = cfg->max_features; d.NV = cfg->max_visual;
+    d.NVP = ((d.NV + d.NP * d.NP / 2 + 63) / 64) * 64;
+    const int Rmax = 15 * d.NP + 17;
+    d.RP = (Rmax + 15) & ~15; d.XS = (16 * d.NP + 20 + d.F + 3) & ~3; d.NFB = 2 * d.NP + 7; d.FP = (d.F + 3) & ~3; d.NPRI = d.RP;
+    h->step_lds = (size_t)Rmax * (Rmax + 1) / 2 * sizeof(double);
+    if (h->step_lds + 8 * 1024 > 160 * 1024) { delete h; return gf::set_err(GF_ERR_INVALID, "window_size %d: reduced system (%d) does not fit the LDS-resident Cholesky of this build", d.W, Rmax); }
+#define A_(x) do { if (int rc_ = (x)) { h->release(); delete h; return rc_; } } while (0)
+#define H_(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { gf::set_err(GF_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); h->release(); delete h; return GF_ERR_HIP; } } while (0)
+    H_(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (auto& e : h->ev) H_(hipEventCreate(&e));
+    const size_t B = d.B, VS = d.RP + d.FP;
+    A_(h->xs0.alloc(B * d.XS, true)); A_(h->xs.alloc(2 * B * d.XS, true));
+    A_(h->colf.alloc(B * d.NFB, true)); A_(h->cole.alloc(B * d.F, true)); A_(h->nvis.alloc(B, true)); A_(h->nimu.alloc(B, true)); A_(h->nwh.alloc(B, true)); A_(h->nfeat.alloc(B, true));
+    A_(h->vis_feat.alloc(B * d.NV, true)); A_(h->vis_i.alloc(B * d.NV, true)); A_(h->vis_j.alloc(B * d.NV, true)); A_(h->vis_data.alloc(B * d.NV * 12, true));
+    A_(h->order.alloc(B * d.NVP, true)); A_(h->norder.alloc(B, true)); A_(h->feat_ptr.alloc(B * (d.F + 1), true)); A_(h->feat_fac.alloc(B * d.NV, true));
+    A_(h->imu_i.alloc(B * d.W, true)); A_(h->imu_data.alloc(B * d.W * IMU_STRIDE2, true)); A_(h->wh_i.alloc(B * d.W, true)); A_(h->wh_data.alloc(B * d.W * WH_STRIDE, true));
+    A_(h->pri_n.alloc(B, true)); A_(h->pri_nb.alloc(B, true)); A_(h->pri_bid.alloc(B * 64, true)); A_(h->pri_J.alloc(B * d.NPRI * d.NPRI, true));
+    A_(h->pri_r.alloc(B * d.NPRI, true)); A_(h->pri_x0.alloc(B * d.NPRI * 2, true));
+    if (hipMalloc((void**)&h->st.d, B * sizeof(SolverState)) != hipSuccess || hipHostMalloc((void**)&h->st.h, B * sizeof(SolverState), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void**)&h->st0.d, B * sizeof(SolverState)) != hipSuccess || hipHostMalloc((void**)&h->st0.h, B * sizeof(SolverState), hipHostMallocDefault) != hipSuccess) {
+        h->release(); delete h; return gf::set_err(GF_ERR_HIP, "allocation of solver state failed");
+    }
+    h->st.n = h->st0.n = B;
+    A_(h->imu_sqrt.alloc(B * d.W * 225, false)); A_(h->wh_sqrt.alloc(B * d.W * 36, false)); A_(h->pri_A.alloc(B * d.NPRI * d.NPRI, false)); A_(h->pri_b.alloc(B * d.NPRI, false));
+    A_(h->pri_c.alloc(B, false)); A_(h->H.alloc(2 * B * d.RP * d.RP, true)); A_(h->g.alloc(2 * B * d.RP, true)); A_(h->cost.alloc(2 * B, true)); A_(h->efac.alloc(2 * B * d.NV * EF, false));
+    A_(h->scale.alloc(B * VS, false)); A_(h->diag.alloc(B * VS, false)); A_(h->grad.alloc(B * VS, false)); A_(h->gn.alloc(B * VS, false)); A_(h->step.alloc(B * VS, false));
+    A_(h->u.alloc(B * VS, false)); A_(h->Et.alloc(B * d.FP * d.RP, true)); A_(h->Es.alloc(B * d.FP * d.RP, false)); A_(h->ete.alloc(B * d.FP, true)); A_(h->etb.alloc(B * d.FP, true));
+    A_(h->rhs.alloc(B * d.RP, false)); A_(h->yv.alloc(B * VS, false));
+    H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->step_lds));
+    H_(hipStreamSynchronize(h->stream));
+#undef A_
+#undef H_
+    *out = h;
+    return GF_OK;
+}
+
+int gf_ba_destroy(gf_ba* h) {
+    if (!h) return GF_OK;
+    h->release();
+    delete h;
+    return GF_OK;
+}
+
+int gf_ba_upload(gf_ba* h, const gf_ba_window* windows, int count) {
+    if (!h || !windows) return gf::set_err(GF_ERR_INVALID, "null argument");
+    if (int rc = pack_windows(h, windows, count)) return rc;
+    HIPCHK(hipEventRecord(h->ev[0], h->stream));
+    if (int rc = upload(h)) return rc;
+    HIPCHK(hipEventRecord(h->ev[1], h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); h->stats.ms_upload += ms;
+    return GF_OK;
+}
+
+int gf_ba_solve_resident(gf_ba* h, int max_iters, int marginalize_mode, int reset) {
+    if (!h || h->count < 1) return gf::set_err(GF_ERR_INVALID, "no resident windows");
+    if (max_iters < 0 || max_iters > 64) return gf::set_err(GF_ERR_INVALID, "max_iters out of range");
+    if (reset) { if (int rc = reset_state(h)) return rc; }
+    HIPCHK(hipEventRecord(h->ev[0], h->stream));
+    if (int rc = run_solve(h, max_iters)) return rc;
+    HIPCHK(hipEventRecord(h->ev[1], h->stream));
+    if (marginalize_mode >= 0) return gf::set_err(GF_ERR_INVALID, "marginalisation not built yet");
+    HIPCHK(hipEventRecord(h->ev[4], h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); h->stats.ms_solve += ms;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev[1], h->ev[4])); h->stats.ms_marginalize += ms;
+    if (max_iters > 0) { HIPCHK(hipEventElapsedTime(&ms, h->ev[2], h->ev[3])); h->stats.ms_jtj += ms; }
+    return GF_OK;
+}
+
+
+int gf_ba_download(gf_ba* h, gf_ba_window* windows, int count, gf_ba_summary* summaries, gf_ba_prior* priors) {
+    if (!h || count < 1 || count > h->count) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    (void)priors;
+    const Dims& d = h->d;
+    HIPCHK(hipEventRecord(h->ev[0], h->stream));
+    HIPCHK(h->xs.down(h->stream));
+    HIPCHK(hipMemcpyAsync(h->st.h, h->st.d, (size_t)d.B * sizeof(SolverState), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipEventRecord(h->ev[1], h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); h->stats.ms_download += ms;
+    for (int b = 0; b < count; b++) {
+        const SolverState& st = h->st.h[b];
+        if (windows) {
+            gf_ba_window& w = windows[b];
+            const double* x = h->xs.h + ((size_t)st.cur * d.B + b) * d.XS;
+            for (int i = 0; i < d.NP; i++) { memcpy(w.para_Pose + 7 * i, x + off_pose(i), 56); memcpy(w.para_SpeedBias + 9 * i, x + off_sb(i), 72); }
+            memcpy(w.para_Ex_Pose, x + off_ex(d.NP), 56); memcpy(w.para_Ex_Pose_wheel, x + off_exw(d.NP), 56); memcpy(w.para_Ix, x + off_ix(d.NP), 24);
+            w.para_Td[0] = x[off_td(d.NP)]; w.para_Td_wheel[0] = x[off_tdw(d.NP)];
+            for (int f = 0; f < w.n_feature; f++) w.para_Feature[f] = x[off_feat(d.NP) + f];
+        }
+        if (summaries) {
+            gf_ba_summary& s = summaries[b];
+            s.iterations = st.iterations; s.successful_steps = st.successful; s.termination = st.termination; s.initial_cost = st.initial_cost; s.final_cost = st.x_cost;
+            s.radius = st.radius;
+        }
+    }
+    return GF_OK;
+}
+
+int gf_ba_solve(gf_ba* h, gf_ba_window* windows, int count, int max_iters, gf_ba_summary* summaries) {
+    if (int rc = gf_ba_upload(h, windows, count)) return rc;
+    if (int rc = gf_ba_solve_resident(h, max_iters, -1, 1)) return rc;
+    return gf_ba_download(h, windows, count, summaries, nullptr);
+}
+
+int gf_ba_marginalize(gf_ba* h, const gf_ba_window* windows, int count, int mode, gf_ba_prior* priors) {
+    (void)h; (void)windows; (void)count; (void)mode; (void)priors;
+    return gf::set_err(GF_ERR_INVALID, "marginalisation not built yet");
+}
+
+int gf_ba_linearize(gf_ba* h, const gf_ba_window* w, int cap, double* Hout, double* gout, double* cost, int* n_f, int* n_e, int* col_block_id) {
+    if (!h || !w || !Hout || !gout || !cost) return gf::set_err(GF_ERR_INVALID, "null argument");
+    if (int rc = gf_ba_upload(h, w, 1)) return rc;
+    if (int rc = reset_state(h)) return rc;
+    const Dims& d = h->d;
+    HIPCHK(hipMemsetAsync(h->H.d, 0, (size_t)d.B * d.RP * d.RP * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->g.d, 0, (size_t)d.B * d.RP * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->cost.d, 0, (size_t)2 * d.B * sizeof(double), h->stream));
+    if (int rc = launch_linearize(h, 0, 0, 0, 0, false)) return rc;
+    // run the accept/eliminated-column phase of ba_step once (finalize_only) to materialise ete / etb / Et
+    ba_step<<<dim3(d.B), 512, h->step_lds, h->stream>>>(h->win(), h->sbufs(), 1, 1, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(h->H.down(h->stream)); HIPCHK(h->g.down(h->stream)); HIPCHK(h->cost.down(h->stream)); HIPCHK(h->Et.down(h->stream)); HIPCHK(h->ete.down(h->stream)); HIPCHK(h->etb.down(h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const SolverState& st = h->st0.h[0];
+    const int R = st.R, NE = st.NE, n = R + NE;
+    if (n > cap) return gf::set_err(GF_ERR_CAPACITY, "capacity %d < %d columns", cap, n);
+    for (int i = 0; i < n * n; i++) Hout[i] = 0;
+    for (int r = 0; r < R; r++) { for (int c = 0; c < R; c++) Hout[(size_t)r * n + c] = h->H.h[(size_t)r * d.RP + c]; gout[r] = h->g.h[r]; }
+    for (int e = 0; e < NE; e++) {
+        Hout[(size_t)(R + e) * n + R + e] = h->ete.h[e]; gout[R + e] = h->etb.h[e];
+        for (int c = 0; c < R; c++) { Hout[(size_t)(R + e) * n + c] = h->Et.h[(size_t)e * d.RP + c]; Hout[(size_t)c * n + R + e] = h->Et.h[(size_t)e * d.RP + c]; }
+    }
+    *cost = h->cost.h[0]; *n_f = R; *n_e = NE;
+    if (col_block_id) {
+        const int* cf = h->colf.h;
+        for (int i = 0; i < d.NP; i++) { if (cf[fb_pose(i)] >= 0) for (int q = 0; q < 6; q++) col_block_id[cf[fb_pose(i)] + q] = GF_POSE * 4096 + i; if (cf[fb_sb(i)] >= 0) for (int q = 0; q < 9; q++) col_block_id[cf[fb_sb(i)] + q] = GF_SPEEDBIAS * 4096 + i; }
+        const int kinds[7] = {GF_EX_POSE, GF_EX_WHEEL, GF_SX, GF_SY, GF_SW, GF_TD, GF_TD_WHEEL};
+        for (int q = 0; q < 7; q++) { const int c0 = cf[2 * d.NP + q]; if (c0 >= 0) for (int k = 0; k < (q < 2 ? 6 : 1); k++) col_block_id[c0 + k] = kinds[q] * 4096; }
+        for (int f = 0; f < d.F; f++) if (h->cole.h[f] >= 0) col_block_id[R + h->cole.h[f]] = GF_FEATURE * 4096 + f;
+    }
+    return GF_OK;
+}
+
+int gf_ba_get_stats(gf_ba* h, gf_ba_stats* out) { if (!h || !out) return gf::set_err(GF_ERR_INVALID, "null argument"); *out = h->stats; return GF_OK; }
+int gf_ba_reset_stats(gf_ba* h) { if (!h) return gf::set_err(GF_ERR_INVALID, "null handle"); h->stats = gf_ba_stats{}; return GF_OK; }
+
+}  // extern "C"

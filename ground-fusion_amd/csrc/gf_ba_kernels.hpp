@@ -1,0 +1,1070 @@
+// gf_ba_kernels.hpp — gfx950 device code of the sliding-window back end (Estimator::optimization()).
+//
+// Batched over independent windows (grid.y / grid.x = window).  Per LM iteration:
+//   ba_linearize_visual : one lane per ProjectionTwoFrameOneCamFactor (residual, analytic Jacobian, Huber corrector),
+//                         block rows staged in LDS, J^T J / J^T r of each frame pair contracted with
+//                         v_mfma_f64_16x16x4_f64 and scattered into the dense normal equations
+//   ba_linearize_misc   : IMU / wheel factors (one wavefront each) and the marginalisation prior
+//   ba_step             : Jacobi scaling, dogleg (Cauchy point, Schur complement via MFMA, blocked Cholesky), candidate
+// Semantics: reference factors (file:line cited per function) + Ceres 1.14 trust_region_minimizer.cc / dogleg_strategy.cc.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gf_dmath.hpp"
+
+namespace gfb {
+using namespace gfd;
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct Dims {
+    int B, W, NP, F, NV, NVP, RP, XS, NFB, FP, NPRI;
+    // NP = W+1 poses; NVP = padded length of the pair-sorted factor order; RP = padded reduced dimension (multiple of 16);
+    // XS = state vector stride; NFB = 2*NP + 7 non-feature parameter blocks; FP = F rounded up to 4; NPRI = prior capacity (= RP)
+};
+__host__ __device__ inline int off_pose(int i) { return 16 * i; }
+__host__ __device__ inline int off_sb(int i) { return 16 * i + 7; }
+__host__ __device__ inline int off_ex(int NP) { return 16 * NP; }
+__host__ __device__ inline int off_exw(int NP) { return 16 * NP + 7; }
+__host__ __device__ inline int off_ix(int NP) { return 16 * NP + 14; }
+__host__ __device__ inline int off_td(int NP) { return 16 * NP + 17; }
+__host__ __device__ inline int off_tdw(int NP) { return 16 * NP + 18; }
+__host__ __device__ inline int off_feat(int NP) { return 16 * NP + 20; }
+// f-block indices
+__host__ __device__ inline int fb_pose(int i) { return 2 * i; }
+__host__ __device__ inline int fb_sb(int i) { return 2 * i + 1; }
+__host__ __device__ inline int fb_ex(int NP) { return 2 * NP; }
+__host__ __device__ inline int fb_exw(int NP) { return 2 * NP + 1; }
+__host__ __device__ inline int fb_sx(int NP) { return 2 * NP + 2; }
+__host__ __device__ inline int fb_td(int NP) { return 2 * NP + 5; }
+__host__ __device__ inline int fb_tdw(int NP) { return 2 * NP + 6; }
+
+struct SolverState {  // per window, lives in device memory
+    double radius, mu, alpha, x_cost, cand_cost, model_cost_change, dogleg_step_norm, gmax, initial_cost, x_norm, step_norm;
+    int cur;            // which of the two state / normal-equation buffers is current
+    int reuse, done, termination, iterations, successful, invalid_run, last_successful, have_scale, cand_valid;
+    int R, NE;          // reduced dimension and number of eliminated (free inverse-depth) columns
+};
+
+struct Win {  // device view of the whole batch
+    Dims d;
+    double* xs;               // [2][B][XS] states: current / candidate
+    const int* colf;          // [B][NFB] column of each non-feature block or -1 (constant)
+    const int* cole;          // [B][F]   index of each free feature among the eliminated columns or -1
+    const int* nvis; const int* nimu; const int* nwh; const int* nfeat;   // [B]
+    const int* vis_feat; const int* vis_i; const int* vis_j;              // [B][NV]
+    const double* vis_data;   // [B][NV][12] pts_i(3) pts_j(3) vel_i(2) vel_j(2) td_i td_j
+    const int* order;         // [B][NVP] factor index sorted by (i,j) pair, pairs padded to even length with -1
+    const int* norder;        // [B]
+    const int* feat_ptr;      // [B][F+1] CSR: factors of each feature
+    const int* feat_fac;      // [B][NV]
+    const int* imu_i; const double* imu_data;   // [B][W], [B][W][IMU_STRIDE]
+    const int* wh_i; const double* wh_data;     // [B][W], [B][W][WH_STRIDE]
+    double* imu_sqrt; double* wh_sqrt;          // [B][W][225], [B][W][36]
+    const int* pri_n; const int* pri_nb; const int* pri_bid;  // [B], [B], [B][64]
+    const double* pri_J; const double* pri_r; const double* pri_x0;  // [B][NPRI*NPRI], [B][NPRI], [B][NPRI*2]
+    double* pri_A; double* pri_b; double* pri_c;  // J0^T J0, J0^T r0, r0^T r0
+    double* H;                // [2][B][RP*RP]
+    double* g;                // [2][B][RP]
+    double* cost;             // [2][B]
+    double* efac;             // [2][B][NV][EF]
+    SolverState* st;          // [B]
+    double G[3];
+    double vis_sqrt_info;
+};
+constexpr int IMU_STRIDE = 16 + 225 + 225;  // sum_dt, dp3, dq4, dv3, lba3, lbg3(=17 used incl. sum_dt -> 0..16) jac, cov
+constexpr int IMU_JAC = 17, IMU_COV = 17 + 225;
+constexpr int IMU_STRIDE2 = 17 + 450;
+constexpr int WH_STRIDE = 1 + 3 + 4 + 18 + 36 + 4 + 12;  // sum_dt, dp, dq, jac(6x3), cov(6x6), lin(4), lin_vel, lin_gyr, vel_1, gyr_1
+constexpr int EF = 24;  // per-factor eliminated-column products: Jd^T[Ji(6) Jj(6) Jtd(1) Jex(6)] , Jd^T Jd, Jd^T r
+
+__device__ __forceinline__ Q4 q_of(const double* p) { return Q4{p[6], p[3], p[4], p[5]}; }
+__device__ __forceinline__ V3 p_of(const double* p) { return V3{p[0], p[1], p[2]}; }
+
+// Huber(1.0) + ceres Corrector (loss_function.h / corrector.cc; same arithmetic at marginalization_factor.cpp:27-57)
+__device__ __forceinline__ void huber_corrector(double sq, double& rho0, double& sqrt_rho1, double& residual_scaling, double& alpha_sq_norm) {
+    double rho1, rho2;
+    if (sq > 1.0) { const double r = sqrt(sq); rho0 = 2.0 * r - 1.0; rho1 = fmax(2.2250738585072014e-308, 1.0 / r); rho2 = -rho1 / (2.0 * sq); }
+    else { rho0 = sq; rho1 = 1.0; rho2 = 0.0; }
+    sqrt_rho1 = sqrt(rho1);
+    if (sq == 0.0 || rho2 <= 0.0) { residual_scaling = sqrt_rho1; alpha_sq_norm = 0.0; }
+    else { const double D = 1.0 + 2.0 * sq * rho2 / rho1, alpha = 1.0 - sqrt(D); residual_scaling = sqrt_rho1 / (1 - alpha); alpha_sq_norm = alpha / sq; }
+}
+
+// ProjectionTwoFrameOneCamFactor::Evaluate (projectionTwoFrameOneCamFactor.cpp:43-151).  row[r][c]: c 0-5 pose_i, 6-11 pose_j, 12 td,
+// 13 residual, 16-21 ex_pose; jd[r] = d r / d inv_depth.  want_jac=false: residual only.
+struct VisEval { double row[2][22]; double jd[2]; };
+__device__ __forceinline__ void visual_eval(const double* Pi_, const double* Pj_, const double* Ex_, double inv_dep_i, double td, const double* vd,
+                                            double si, bool want_jac, VisEval& o) {
+    const V3 Pi = p_of(Pi_), Pj = p_of(Pj_), tic = p_of(Ex_);
+    const Q4 Qi = q_of(Pi_), Qj = q_of(Pj_), qic = q_of(Ex_);
+    const V3 pts_i = v3(vd[0], vd[1], vd[2]), pts_j = v3(vd[3], vd[4], vd[5]), vel_i = v3(vd[6], vd[7], 0), vel_j = v3(vd[8], vd[9], 0);
+    const double td_i = vd[10], td_j = vd[11];
+    const V3 pts_i_td = pts_i - vel_i * (td - td_i), pts_j_td = pts_j - vel_j * (td - td_j);
+    const V3 pts_camera_i = pts_i_td / inv_dep_i;
+    const V3 pts_imu_i = qrot(qic, pts_camera_i) + tic;
+    const V3 pts_w = qrot(Qi, pts_imu_i) + Pi;
+    const V3 pts_imu_j = qrot(qinverse(Qj), pts_w - Pj);
+    const V3 pts_camera_j = qrot(qinverse(qic), pts_imu_j - tic);
+    const double dep_j = pts_camera_j.z;
+    o.row[0][13] = si * (pts_camera_j.x / dep_j - pts_j_td.x);
+    o.row[1][13] = si * (pts_camera_j.y / dep_j - pts_j_td.y);
+    if (!want_jac) return;
+    const M3 Ri = qmat(Qi), Rj = qmat(Qj), ric = qmat(qic);
+    const double r00 = si / dep_j, r02 = -si * pts_camera_j.x / (dep_j * dep_j), r11 = si / dep_j, r12 = -si * pts_camera_j.y / (dep_j * dep_j);
+    auto red = [&](const M3& m, int c, double& o0, double& o1) { o0 = r00 * m.m[c] + r02 * m.m[6 + c]; o1 = r11 * m.m[3 + c] + r12 * m.m[6 + c]; };
+    auto redv = [&](V3 v, double& o0, double& o1) { o0 = r00 * v.x + r02 * v.z; o1 = r11 * v.y + r12 * v.z; };
+    const M3 A = transpose(ric) * transpose(Rj);
+    const M3 ARi = A * Ri;
+    const M3 Jir = ARi * (-skew(pts_imu_i));
+    const M3 Jjr = transpose(ric) * skew(pts_imu_j);
+    const M3 nA = -A;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        red(A, c, o.row[0][c], o.row[1][c]);
+        red(Jir, c, o.row[0][3 + c], o.row[1][3 + c]);
+        red(nA, c, o.row[0][6 + c], o.row[1][6 + c]);
+        red(Jjr, c, o.row[0][9 + c], o.row[1][9 + c]);
+    }
+    const M3 tmp_r = ARi * ric;
+    {
+        const M3 Jep = transpose(ric) * (transpose(Rj) * Ri - m3_identity());
+        const M3 Jer = (-tmp_r) * skew(pts_camera_i) + skew(tmp_r * pts_camera_i) + skew(transpose(ric) * (transpose(Rj) * (Ri * tic + Pi - Pj) - tic));
+#pragma unroll
+        for (int c = 0; c < 3; c++) { red(Jep, c, o.row[0][16 + c], o.row[1][16 + c]); red(Jer, c, o.row[0][19 + c], o.row[1][19 + c]); }
+    }
+    {
+        double a0, a1;
+        redv(tmp_r * pts_i_td, a0, a1);
+        const double f = -1.0 / (inv_dep_i * inv_dep_i);
+        o.jd[0] = a0 * f; o.jd[1] = a1 * f;
+        redv(tmp_r * vel_i, a0, a1);
+        o.row[0][12] = a0 / inv_dep_i * -1.0 + si * vel_j.x;
+        o.row[1][12] = a1 / inv_dep_i * -1.0 + si * vel_j.y;
+    }
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// grid (NVP/64, B), 64 threads.  EX: the camera extrinsic block is free (second 16-column tile).
+// which: buffer (0/1) of H/g/cost/efac to fill; state read from xs[which_state].
+template <bool EX>
+__global__ void __launch_bounds__(64) ba_linearize_visual(Win w, int which, int which_state, int cost_only, int only_cand_valid) {
+    constexpr int COLS = EX ? 32 : 16;
+    constexpr int LSTR = 2 * COLS + 1;  // odd stride: de-phases the per-lane writes
+    __shared__ double Jbuf[64 * LSTR];
+    __shared__ int s_pair[64];
+    const Dims d = w.d;
+    const int b = blockIdx.y, lane = threadIdx.x;
+    const SolverState& st = w.st[b];
+    if (st.done) return;
+    if (only_cand_valid && !st.cand_valid) return;
+    const int n_order = w.norder[b];
+    const int e0 = blockIdx.x * 64;
+    if (e0 >= n_order) return;
+    if (which < 0) which = 1 - st.cur;            // the candidate's buffers
+    if (which_state < 0) which_state = 1 - st.cur;
+    const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
+    const int* colf = w.colf + (size_t)b * d.NFB;
+    const int entry = e0 + lane;
+    const int k = entry < n_order ? w.order[(size_t)b * d.NVP + entry] : -1;
+    double cost = 0.0;
+    int fi = 0, fj = 0, feat = 0;
+    VisEval ev;
+#pragma unroll
+    for (int r = 0; r < 2; r++) { for (int c = 0; c < 22; c++) ev.row[r][c] = 0.0; ev.jd[r] = 0.0; }
+    if (k >= 0) {
+        const size_t kk = (size_t)b * d.NV + k;
+        fi = w.vis_i[kk]; fj = w.vis_j[kk]; feat = w.vis_feat[kk];
+        visual_eval(xs + off_pose(fi), xs + off_pose(fj), xs + off_ex(d.NP), xs[off_feat(d.NP) + feat], xs[off_td(d.NP)], w.vis_data + kk * 12,
+                    w.vis_sqrt_info, !cost_only, ev);
+        const double r0 = ev.row[0][13], r1 = ev.row[1][13];
+        const double sq = r0 * r0 + r1 * r1;
+        double rho0, sqrt_rho1, rs, asn;
+        huber_corrector(sq, rho0, sqrt_rho1, rs, asn);
+        cost = 0.5 * rho0;
+        if (!cost_only) {
+            // J = sqrt_rho1 * (J - alpha_sq_norm * r * (r^T J)), r *= residual_scaling
+#pragma unroll
+            for (int c = 0; c < 22; c++) {
+                if (c == 13 || c == 14 || c == 15) continue;
+                const double rtj = r0 * ev.row[0][c] + r1 * ev.row[1][c];
+                ev.row[0][c] = sqrt_rho1 * (ev.row[0][c] - asn * r0 * rtj);
+                ev.row[1][c] = sqrt_rho1 * (ev.row[1][c] - asn * r1 * rtj);
+            }
+            const double rtj = r0 * ev.jd[0] + r1 * ev.jd[1];
+            ev.jd[0] = sqrt_rho1 * (ev.jd[0] - asn * r0 * rtj);
+            ev.jd[1] = sqrt_rho1 * (ev.jd[1] - asn * r1 * rtj);
+            ev.row[0][13] = r0 * rs; ev.row[1][13] = r1 * rs;
+            // constant blocks contribute no columns
+            if (colf[fb_pose(fi)] < 0) for (int c = 0; c < 6; c++) ev.row[0][c] = ev.row[1][c] = 0.0;
+            if (colf[fb_pose(fj)] < 0) for (int c = 6; c < 12; c++) ev.row[0][c] = ev.row[1][c] = 0.0;
+            if (colf[fb_td(d.NP)] < 0) ev.row[0][12] = ev.row[1][12] = 0.0;
+            // eliminated (free inverse depth) column: products needed by the Schur complement
+            if (w.cole[(size_t)b * d.F + feat] >= 0) {
+                double* ef = w.efac + (((size_t)which * d.B + b) * d.NV + k) * EF;
+#pragma unroll
+                for (int c = 0; c < 13; c++) ef[c] = ev.jd[0] * ev.row[0][c] + ev.jd[1] * ev.row[1][c];
+#pragma unroll
+                for (int c = 0; c < 6; c++) ef[13 + c] = EX ? ev.jd[0] * ev.row[0][16 + c] + ev.jd[1] * ev.row[1][16 + c] : 0.0;
+                ef[19] = ev.jd[0] * ev.jd[0] + ev.jd[1] * ev.jd[1];
+                ef[20] = ev.jd[0] * ev.row[0][13] + ev.jd[1] * ev.row[1][13];
+            }
+        }
+    }
+    cost = wave_sum_f64(cost);
+    if (lane == 0) atomicAdd(w.cost + (size_t)which * d.B + b, cost);
+    if (cost_only) return;
+    // ---- stage block rows in LDS
+    s_pair[lane] = k >= 0 ? fi * 64 + fj : -1;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) Jbuf[lane * LSTR + r * COLS + c] = (c < 14) ? ev.row[r][c] : 0.0;
+        if (EX) {
+#pragma unroll
+            for (int c = 0; c < 16; c++) Jbuf[lane * LSTR + r * COLS + 16 + c] = (c < 6) ? ev.row[r][16 + c] : 0.0;
+        }
+    }
+    __syncthreads();
+    // ---- J^T J per frame pair on the matrix cores: D[a][b] += sum_k J[k][a] J[k][b], 4 rows (2 factors) per instruction
+    double* H = w.H + ((size_t)which * d.B + b) * d.RP * d.RP;
+    double* g = w.g + ((size_t)which * d.B + b) * d.RP;
+    const int exc = EX ? colf[fb_ex(d.NP)] : -1;
+    const int tdc = colf[fb_td(d.NP)];
+    d4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
+    int cur_pair = -1;
+    auto flush = [&](int pair) {
+        if (pair < 0) return;
+        const int pi = pair >> 6, pj = pair & 63;
+        const int ci = colf[fb_pose(pi)], cj = colf[fb_pose(pj)];
+        auto cmap = [&](int t) -> int { return t < 6 ? (ci >= 0 ? ci + t : -1) : t < 12 ? (cj >= 0 ? cj + t - 6 : -1) : t == 12 ? tdc : t == 13 ? -2 : -1; };
+        const int tb = lane & 15, cb = cmap(tb);
+        const int cb1 = (EX && tb < 6 && exc >= 0) ? exc + tb : -1;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int ta = (lane >> 4) + 4 * r, ca = cmap(ta);
+            const double v00 = acc00[r];
+            if (ca >= 0 && cb >= 0) atomicAdd(H + (size_t)ca * d.RP + cb, v00);
+            if (ca >= 0 && cb == -2) atomicAdd(g + ca, v00);
+            if (EX) {
+                const double v01 = acc01[r], v11 = acc11[r];
+                if (ca >= 0 && cb1 >= 0) { atomicAdd(H + (size_t)ca * d.RP + cb1, v01); atomicAdd(H + (size_t)cb1 * d.RP + ca, v01); }
+                if (ca == -2 && cb1 >= 0) atomicAdd(g + cb1, v01);
+                const int ca1 = (ta < 6 && exc >= 0) ? exc + ta : -1;
+                if (ca1 >= 0 && cb1 >= 0) atomicAdd(H + (size_t)ca1 * d.RP + cb1, v11);
+            }
+        }
+        acc00 = d4{0, 0, 0, 0}; acc01 = d4{0, 0, 0, 0}; acc11 = d4{0, 0, 0, 0};
+    };
+    for (int m = 0; m < 32; m++) {
+        const int pair = s_pair[2 * m];  // pairs are padded to even length: entries 2m and 2m+1 share the pair (or are padding)
+        if (pair < 0) continue;
+        if (pair != cur_pair) { flush(cur_pair); cur_pair = pair; }
+        const int e = 2 * m + (lane >> 5), r = (lane >> 4) & 1, c = lane & 15;
+        const double a0 = Jbuf[e * LSTR + r * COLS + c];
+        acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc00, 0, 0, 0);
+        if (EX) {
+            const double a1 = Jbuf[e * LSTR + r * COLS + 16 + c];
+            acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a1, acc01, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc11, 0, 0, 0);
+        }
+    }
+    flush(cur_pair);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// small dense helpers on LDS matrices, executed by one wavefront
+__device__ inline void wave_inverse_spd_sqrt(double* M, double* T, int n, int lane) {
+    // in: M (n x n row-major, symmetric positive definite covariance).  out: M = upper factor U with U^T U = M^-1, i.e.
+    // LLT(M^-1).matrixL().transpose() (imu_factor.h:73, wheel_factor.h:85).  T: n x 2n scratch.  Gauss-Jordan with partial pivoting.
+    for (int i = lane; i < n * 2 * n; i += 64) { const int r = i / (2 * n), c = i % (2 * n); T[i] = c < n ? M[r * n + c] : (c - n == r ? 1.0 : 0.0); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    for (int col = 0; col < n; col++) {
+        int piv = col; double best = fabs(T[col * 2 * n + col]);
+        for (int r = col + 1; r < n; r++) { const double v = fabs(T[r * 2 * n + col]); if (v > best) { best = v; piv = r; } }
+        if (piv != col) for (int c = lane; c < 2 * n; c += 64) { const double t = T[col * 2 * n + c]; T[col * 2 * n + c] = T[piv * 2 * n + c]; T[piv * 2 * n + c] = t; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        const double dinv = 1.0 / T[col * 2 * n + col];
+        // factors first (they are overwritten by the update)
+        double fr[4];
+        for (int q = 0; q < 4; q++) { const int r = lane / 16 * 4 + q; fr[q] = (r < n && r != col) ? T[r * 2 * n + col] * dinv : 0.0; }
+        __builtin_amdgcn_wave_barrier();
+        for (int c = lane & 15; c < 2 * n; c += 16) {
+            const double pv = T[col * 2 * n + c];
+            for (int q = 0; q < 4; q++) { const int r = lane / 16 * 4 + q; if (r < n && r != col) T[r * 2 * n + c] -= fr[q] * pv; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        for (int c = lane; c < 2 * n; c += 64) T[col * 2 * n + c] *= dinv;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
+    // M <- inverse (right half), then Cholesky (lower, column by column), store transposed
+    for (int i = lane; i < n * n; i += 64) M[i] = T[(i / n) * 2 * n + n + (i % n)];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < n; j++) {
+        double dd = M[j * n + j];
+        for (int k2 = 0; k2 < j; k2++) dd -= M[j * n + k2] * M[j * n + k2];
+        dd = sqrt(dd);
+        for (int i = j + 1 + lane; i < n; i += 64) {
+            double s = M[i * n + j];
+            for (int k2 = 0; k2 < j; k2++) s -= M[i * n + k2] * M[j * n + k2];
+            M[i * n + j] = s / dd;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) M[j * n + j] = dd;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
+    // U = L^T: write into T then back
+    for (int i = lane; i < n * n; i += 64) { const int r = i / n, c = i % n; T[i] = c >= r ? M[c * n + r] : 0.0; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < n * n; i += 64) M[i] = T[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+}
+
+// One-time per solve: sqrt information of every IMU / wheel factor and the prior's normal-equation form.
+// grid (B), 256 threads (4 wavefronts).
+__global__ void __launch_bounds__(256) ba_setup(Win w) {
+    __shared__ double sM[4][225];
+    __shared__ double sT[4][450];
+    const Dims d = w.d;
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int t = wave; t < w.nimu[b] + w.nwh[b]; t += 4) {
+        if (t < w.nimu[b]) {
+            const double* src = w.imu_data + ((size_t)b * d.W + t) * IMU_STRIDE2 + IMU_COV;
+            for (int i = lane; i < 225; i += 64) sM[wave][i] = src[i];
+            wave_inverse_spd_sqrt(sM[wave], sT[wave], 15, lane);
+            double* dst = w.imu_sqrt + ((size_t)b * d.W + t) * 225;
+            for (int i = lane; i < 225; i += 64) dst[i] = sM[wave][i];
+        } else {
+            const int k = t - w.nimu[b];
+            const double* src = w.wh_data + ((size_t)b * d.W + k) * WH_STRIDE + 26;
+            for (int i = lane; i < 36; i += 64) sM[wave][i] = src[i];
+            wave_inverse_spd_sqrt(sM[wave], sT[wave], 6, lane);
+            double* dst = w.wh_sqrt + ((size_t)b * d.W + k) * 36;
+            for (int i = lane; i < 36; i += 64) dst[i] = sM[wave][i];
+        }
+    }
+    // prior: A = J0^T J0, b0 = J0^T r0, c0 = r0^T r0
+    const int n = w.pri_n[b];
+    if (n > 0) {
+        const double* J = w.pri_J + (size_t)b * d.NPRI * d.NPRI;
+        const double* r = w.pri_r + (size_t)b * d.NPRI;
+        double* A = w.pri_A + (size_t)b * d.NPRI * d.NPRI;
+        for (int i = threadIdx.x; i < n * n; i += 256) {
+            const int a = i / n, c = i % n;
+            double s = 0;
+            for (int k2 = 0; k2 < n; k2++) s += J[(size_t)k2 * n + a] * J[(size_t)k2 * n + c];
+            A[i] = s;
+        }
+        for (int a = threadIdx.x; a < n; a += 256) { double s = 0; for (int k2 = 0; k2 < n; k2++) s += J[(size_t)k2 * n + a] * r[k2]; w.pri_b[(size_t)b * d.NPRI + a] = s; }
+        if (threadIdx.x == 0) { double s = 0; for (int k2 = 0; k2 < n; k2++) s += r[k2] * r[k2]; w.pri_c[b] = s; }
+    }
+}
+
+// IMUFactor::Evaluate (imu_factor.h:28-191) + IntegrationBase::evaluate (integration_base.h:169-195): raw (un-whitened) residual and Jacobian.
+// Jraw: 15 x 30 row-major in LDS, columns [pose_i 6 | speedbias_i 9 | pose_j 6 | speedbias_j 9].  Executed redundantly by every lane; lane 0 stores.
+__device__ inline void imu_raw(const double* Pi_, const double* SBi, const double* Pj_, const double* SBj, const double* dat, const double* G_, double* rraw,
+                               double* Jraw, bool want_jac, int lane) {
+    const V3 Pi = p_of(Pi_), Pj = p_of(Pj_), Vi = v3(SBi[0], SBi[1], SBi[2]), Bai = v3(SBi[3], SBi[4], SBi[5]), Bgi = v3(SBi[6], SBi[7], SBi[8]);
+    const V3 Vj = v3(SBj[0], SBj[1], SBj[2]), Baj = v3(SBj[3], SBj[4], SBj[5]), Bgj = v3(SBj[6], SBj[7], SBj[8]);
+    const Q4 Qi = q_of(Pi_), Qj = q_of(Pj_);
+    const double sum_dt = dat[0];
+    const V3 delta_p = v3(dat[1], dat[2], dat[3]), delta_v = v3(dat[8], dat[9], dat[10]), lba = v3(dat[11], dat[12], dat[13]), lbg = v3(dat[14], dat[15], dat[16]);
+    const Q4 delta_q = Q4{dat[4], dat[5], dat[6], dat[7]};
+    const double* jac = dat + IMU_JAC;
+    auto blk = [&](int r0, int c0) { M3 m; for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) m.m[3 * r + c] = jac[(r0 + r) * 15 + c0 + c]; return m; };
+    const M3 dp_dba = blk(0, 9), dp_dbg = blk(0, 12), dq_dbg = blk(3, 12), dv_dba = blk(6, 9), dv_dbg = blk(6, 12);
+    const V3 G = v3(G_[0], G_[1], G_[2]);
+    const V3 dba = Bai - lba, dbg = Bgi - lbg;
+    const Q4 cdq = qmul(delta_q, deltaQ(dq_dbg * dbg));
+    const V3 cdv = delta_v + dv_dba * dba + dv_dbg * dbg;
+    const V3 cdp = delta_p + dp_dba * dba + dp_dbg * dbg;
+    const Q4 Qi_inv = qinverse(Qi);
+    const V3 t_p = qrot(Qi_inv, G * (0.5 * sum_dt * sum_dt) + Pj - Pi - Vi * sum_dt);
+    const V3 t_v = qrot(Qi_inv, G * sum_dt + Vj - Vi);
+    const V3 rp = t_p - cdp, rq = qvec(qmul(qinverse(cdq), qmul(Qi_inv, Qj))) * 2.0, rv = t_v - cdv, rba = Baj - Bai, rbg = Bgj - Bgi;
+    if (lane == 0) {
+        rraw[0] = rp.x; rraw[1] = rp.y; rraw[2] = rp.z; rraw[3] = rq.x; rraw[4] = rq.y; rraw[5] = rq.z; rraw[6] = rv.x; rraw[7] = rv.y; rraw[8] = rv.z;
+        rraw[9] = rba.x; rraw[10] = rba.y; rraw[11] = rba.z; rraw[12] = rbg.x; rraw[13] = rbg.y; rraw[14] = rbg.z;
+    }
+    if (!want_jac) return;
+    for (int i = lane; i < 450; i += 64) Jraw[i] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        auto put = [&](int r0, int c0, const M3& m) { for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Jraw[(r0 + r) * 30 + c0 + c] = m.m[3 * r + c]; };
+        const M3 Rit = qmat(Qi_inv);
+        // pose_i (cols 0..5)
+        put(0, 0, -Rit);
+        put(0, 3, skew(t_p));
+        put(3, 3, -qleft_qright33(qmul(qinverse(Qj), Qi), cdq));
+        put(6, 3, skew(t_v));
+        // speedbias_i (cols 6..14)
+        put(0, 6, (-Rit) * sum_dt);
+        put(0, 9, -dp_dba); put(0, 12, -dp_dbg);
+        put(3, 12, (-qleft33(qmul(qmul(qinverse(Qj), Qi), delta_q))) * dq_dbg);
+        put(6, 6, -Rit);
+        put(6, 9, -dv_dba); put(6, 12, -dv_dbg);
+        put(9, 9, -m3_identity()); put(12, 12, -m3_identity());
+        // pose_j (cols 15..20)
+        put(0, 15, Rit);
+        put(3, 18, qleft33(qmul(qmul(qinverse(cdq), Qi_inv), Qj)));
+        // speedbias_j (cols 21..29)
+        put(6, 21, Rit);
+        put(9, 24, m3_identity()); put(12, 27, m3_identity());
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+}
+
+// WheelFactor::Evaluate (wheel_factor.h:28-247) + WheelIntegrationBase::evaluate (wheel_integration_base.h:180-219).
+// Jraw: 6 x 22, columns [pose_i 6 | pose_j 6 | T_io 6 | sx | sy | sw | td_wheel].
+__device__ inline void wheel_raw(const double* Pi_, const double* Pj_, const double* Ex, double sx, double sy, double sw, double td, const double* dat, double* rraw,
+                                 double* Jraw, bool want_jac, int lane) {
+    const V3 Pi = p_of(Pi_), Pj = p_of(Pj_), tio = p_of(Ex);
+    const Q4 Qi = q_of(Pi_), Qj = q_of(Pj_), qio = q_of(Ex);
+    const M3 sv = m3_diag(sx, sy, 1);
+    const V3 delta_p = v3(dat[1], dat[2], dat[3]);
+    const Q4 delta_q = Q4{dat[4], dat[5], dat[6], dat[7]};
+    const double* jac = dat + 8;  // 6 x 3
+    const double lsx = dat[62], lsy = dat[63], lsw = dat[64], ltd = dat[65];
+    const V3 lin_vel = v3(dat[66], dat[67], dat[68]), lin_gyr = v3(dat[69], dat[70], dat[71]), vel_1 = v3(dat[72], dat[73], dat[74]), gyr_1 = v3(dat[75], dat[76], dat[77]);
+    const V3 dp_dsx = v3(jac[0], jac[3], jac[6]), dp_dsy = v3(jac[1], jac[4], jac[7]), dp_dsw = v3(jac[2], jac[5], jac[8]), dq_dsw = v3(jac[11], jac[14], jac[17]);
+    const double dsx = sx - lsx, dsy = sy - lsy, dsw = sw - lsw;
+    const M3 Ri = qmat(Qi), Rj = qmat(Qj), rio = qmat(qio);
+    const V3 cdp = delta_p + dp_dsx * dsx + dp_dsy * dsy + dp_dsw * dsw;
+    const Q4 cdq = qnormalized(qmul(qnormalized(delta_q), so3_exp(dq_dsw * dsw)));
+    const double dtd = td - ltd;
+    const Q4 e_fw = so3_exp(lin_gyr * (sw * dtd));
+    const Q4 dq_time = qnormalized(qmul(qnormalized(qmul(e_fw, cdq)), so3_exp(gyr_1 * (-sw * dtd))));
+    const V3 dp_time = qmat(e_fw) * (sv * lin_vel * dtd + cdp - qrot(cdq, sv * vel_1 * dtd));
+    const M3 Rio_t = transpose(Ri * rio);
+    const V3 rp = Rio_t * (Rj * tio + Pj - Ri * tio - Pi) - dp_time;
+    const Q4 Qio = qmul(Qi, qio);
+    const V3 rr = so3_log(qmul(qmul(qmul(qinverse(dq_time), qinverse(Qio)), Qj), qio));
+    if (lane == 0) { rraw[0] = rp.x; rraw[1] = rp.y; rraw[2] = rp.z; rraw[3] = rr.x; rraw[4] = rr.y; rraw[5] = rr.z; }
+    if (!want_jac) return;
+    for (int i = lane; i < 132; i += 64) Jraw[i] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        auto put = [&](int r0, int c0, const M3& m) { for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Jraw[(r0 + r) * 22 + c0 + c] = m.m[3 * r + c]; };
+        auto putv = [&](int r0, int c0, V3 v) { Jraw[r0 * 22 + c0] = v.x; Jraw[(r0 + 1) * 22 + c0] = v.y; Jraw[(r0 + 2) * 22 + c0] = v.z; };
+        const M3 Jr_inv = rightJacobianInvSO3(rr);
+        const M3 Jr_drdsw = rightJacobianSO3(dq_dsw * (sw - lsw));
+        const M3 Rcq = qmat(cdq);
+        const M3 Rqio_inv = qmat(qinverse(Qio));
+        put(0, 0, -Rqio_inv);
+        put(0, 3, Rio_t * (Ri * skew(tio)) + transpose(rio) * skew(transpose(Ri) * (Rj * tio + Pj - Ri * tio - Pi)));
+        put(3, 3, -(Jr_inv * qmat(qmul(qinverse(qmul(Qj, qio)), Qi))));
+        put(0, 6, Rqio_inv);
+        put(0, 9, -(qmat(qmul(qinverse(Qio), Qj)) * skew(tio)));
+        put(3, 9, Jr_inv * qmat(qinverse(qio)));
+        put(0, 12, Rqio_inv * (Rj - Ri));
+        put(0, 15, skew(qrot(qinverse(Qio), qrot(Qj, tio) + Pj - qrot(Qi, tio) - Pi)));
+        put(3, 15, Jr_inv * (m3_identity() - qmat(qmul(qmul(qinverse(qmul(Qj, qio)), Qi), qio))));
+        const V3 fcw = lin_gyr * (sw * dtd), fcv = sv * lin_vel * dtd, bcv = sv * vel_1 * dtd, bcw = gyr_1 * (sw * dtd);
+        const M3 Jrtd = rightJacobianSO3(fcw), Jr_mtd = rightJacobianSO3(-fcw);
+        const M3 I1 = m3_diag(1, 0, 0), I2 = m3_diag(0, 1, 0);
+        const M3 Efv = qmat(so3_exp(fcv)), Efw = qmat(so3_exp(fcw));   // wheel_factor.h:199,211 use exp(forward_compensate_v): kept as is
+        putv(0, 18, -(Efv * (I1 * lin_vel * dtd + dp_dsx - Rcq * (I1 * vel_1) * dtd)));
+        putv(0, 19, -(Efv * (I2 * lin_vel * dtd + dp_dsy - Rcq * (I2 * vel_1) * dtd)));
+        putv(0, 20, -(Efw * (dp_dsw - Rcq * skew(Jr_drdsw * dq_dsw) * (sv * vel_1) * dtd + skew(Jrtd * lin_gyr * dtd) * (fcv + cdp - qrot(cdq, bcv)))));
+        const M3 Em = qmat(so3_exp(-rr)), Ebw = qmat(so3_exp(bcw)), Rcq_inv = qmat(qinverse(cdq));
+        putv(3, 20, -(Jr_inv * Em * Ebw * (Rcq_inv * (Jrtd * lin_gyr) * dtd + Jr_drdsw * dq_dsw)));
+        putv(0, 21, -(Efw * (sv * lin_vel - Rcq * (sv * vel_1) + skew(Jrtd * lin_gyr * sw) * (fcv + cdp - Rcq * bcv))));
+        putv(3, 21, -(Jr_inv * Em * (Ebw * Rcq_inv * (Jrtd * lin_gyr) * sw - Jr_mtd * gyr_1 * sw)));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+}
+
+// dx of the marginalisation prior for one kept block (marginalization_factor.cpp:348-372)
+__device__ __forceinline__ void prior_block_dx(int kind, const double* x, const double* x0, double* dx) {
+    const int gs = (kind == 0 || kind == 2 || kind == 3) ? 7 : kind == 1 ? 9 : 1;
+    if (gs != 7) { for (int i = 0; i < gs; i++) dx[i] = x[i] - x0[i]; return; }
+    for (int i = 0; i < 3; i++) dx[i] = x[i] - x0[i];
+    const Q4 dq = qmul(qinverse(Q4{x0[6], x0[3], x0[4], x0[5]}), Q4{x[6], x[3], x[4], x[5]});
+    const double sgn = (dq.w >= 0) ? 2.0 : -2.0;
+    dx[3] = sgn * dq.x; dx[4] = sgn * dq.y; dx[5] = sgn * dq.z;
+}
+__device__ __forceinline__ int state_off_of(int id, int NP) {
+    const int kind = id / 4096, i = id % 4096;
+    switch (kind) {
+        case 0: return off_pose(i); case 1: return off_sb(i); case 2: return off_ex(NP); case 3: return off_exw(NP);
+        case 4: return off_ix(NP); case 5: return off_ix(NP) + 1; case 6: return off_ix(NP) + 2; case 7: return off_td(NP); case 8: return off_tdw(NP);
+        default: return off_feat(NP) + i;
+    }
+}
+__device__ __forceinline__ int fblock_of(int id, int NP) {
+    const int kind = id / 4096, i = id % 4096;
+    switch (kind) {
+        case 0: return fb_pose(i); case 1: return fb_sb(i); case 2: return fb_ex(NP); case 3: return fb_exw(NP);
+        case 4: return fb_sx(NP); case 5: return fb_sx(NP) + 1; case 6: return fb_sx(NP) + 2; case 7: return fb_td(NP); case 8: return fb_tdw(NP);
+        default: return -1;
+    }
+}
+__host__ __device__ inline int lsize_kind(int kind) { return (kind == 0 || kind == 2 || kind == 3) ? 6 : kind == 1 ? 9 : 1; }
+__host__ __device__ inline int gsize_kind(int kind) { return (kind == 0 || kind == 2 || kind == 3) ? 7 : kind == 1 ? 9 : 1; }
+
+// grid (B), 256 threads: wavefront t handles IMU / wheel factors round-robin; afterwards the whole block adds the prior.
+__global__ void __launch_bounds__(256) ba_linearize_misc(Win w, int which, int which_state, int cost_only, int only_cand_valid) {
+    __shared__ double sJ[4][450];
+    __shared__ double sSJ[4][450];
+    __shared__ double sr[4][32];
+    __shared__ int scol[4][32];
+    __shared__ double sdx[512];
+    __shared__ double sred[256];
+    const Dims d = w.d;
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const SolverState& st = w.st[b];
+    if (st.done) return;
+    if (only_cand_valid && !st.cand_valid) return;
+    if (which < 0) which = 1 - st.cur;
+    if (which_state < 0) which_state = 1 - st.cur;
+    const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
+    const int* colf = w.colf + (size_t)b * d.NFB;
+    double* H = w.H + ((size_t)which * d.B + b) * d.RP * d.RP;
+    double* g = w.g + ((size_t)which * d.B + b) * d.RP;
+    double cost_acc = 0.0;
+    const int nimu = w.nimu[b], nwh = w.nwh[b];
+    for (int t = wave; t < nimu + nwh; t += 4) {
+        int nres, ncol;
+        const double* S;
+        if (t < nimu) {
+            const int i = w.imu_i[(size_t)b * d.W + t], j = i + 1;
+            imu_raw(xs + off_pose(i), xs + off_sb(i), xs + off_pose(j), xs + off_sb(j), w.imu_data + ((size_t)b * d.W + t) * IMU_STRIDE2, w.G, sr[wave] + 16,
+                    sJ[wave], !cost_only, lane);
+            nres = 15; ncol = 30; S = w.imu_sqrt + ((size_t)b * d.W + t) * 225;
+            if (lane < 30) {
+                const int blk = lane < 6 ? fb_pose(i) : lane < 15 ? fb_sb(i) : lane < 21 ? fb_pose(j) : fb_sb(j);
+                const int o = lane < 6 ? lane : lane < 15 ? lane - 6 : lane < 21 ? lane - 15 : lane - 21;
+                scol[wave][lane] = colf[blk] >= 0 ? colf[blk] + o : -1;
+            }
+        } else {
+            const int k = t - nimu;
+            const int i = w.wh_i[(size_t)b * d.W + k], j = i + 1;
+            wheel_raw(xs + off_pose(i), xs + off_pose(j), xs + off_exw(d.NP), xs[off_ix(d.NP)], xs[off_ix(d.NP) + 1], xs[off_ix(d.NP) + 2], xs[off_tdw(d.NP)],
+                      w.wh_data + ((size_t)b * d.W + k) * WH_STRIDE, sr[wave] + 16, sJ[wave], !cost_only, lane);
+            nres = 6; ncol = 22; S = w.wh_sqrt + ((size_t)b * d.W + k) * 36;
+            if (lane < 22) {
+                const int blk = lane < 6 ? fb_pose(i) : lane < 12 ? fb_pose(j) : lane < 18 ? fb_exw(d.NP) : lane < 21 ? fb_sx(d.NP) + (lane - 18) : fb_tdw(d.NP);
+                const int o = lane < 6 ? lane : lane < 12 ? lane - 6 : lane < 18 ? lane - 12 : 0;
+                scol[wave][lane] = colf[blk] >= 0 ? colf[blk] + o : -1;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        // whitened residual
+        if (lane < nres) { double s = 0; for (int k2 = 0; k2 < nres; k2++) s += S[lane * nres + k2] * sr[wave][16 + k2]; sr[wave][lane] = s; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        double c = 0;
+        if (lane < nres) c = 0.5 * sr[wave][lane] * sr[wave][lane];
+        cost_acc += wave_sum_f64(c);
+        if (cost_only) continue;
+        for (int e = lane; e < nres * ncol; e += 64) {
+            const int r = e / ncol, cc = e % ncol;
+            double s = 0;
+            for (int k2 = r; k2 < nres; k2++) s += S[r * nres + k2] * sJ[wave][k2 * ncol + cc];  // S is upper triangular
+            sSJ[wave][e] = s;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < ncol * ncol; e += 64) {
+            const int a = e / ncol, c2 = e % ncol;
+            const int ca = scol[wave][a], cb = scol[wave][c2];
+            if (ca < 0 || cb < 0) continue;
+            double s = 0;
+            for (int r = 0; r < nres; r++) s += sSJ[wave][r * ncol + a] * sSJ[wave][r * ncol + c2];
+            if (s != 0.0) atomicAdd(H + (size_t)ca * d.RP + cb, s);
+        }
+        if (lane < ncol && scol[wave][lane] >= 0) {
+            double s = 0;
+            for (int r = 0; r < nres; r++) s += sSJ[wave][r * ncol + lane] * sr[wave][r];
+            atomicAdd(g + scol[wave][lane], s);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- prior: r = r0 + J0 dx  =>  cost = 1/2 (c0 + 2 b0.dx + dx^T A dx), g += b0 + A dx, H += A   (marginalization_factor.cpp:344-392)
+    __syncthreads();
+    const int n = w.pri_n[b];
+    double pc = 0.0;
+    if (n > 0) {
+        const int nb = w.pri_nb[b];
+        const int* bid = w.pri_bid + (size_t)b * 64;
+        const double* x0 = w.pri_x0 + (size_t)b * d.NPRI * 2;
+        // sdx[0..n) = dx, sdx[256..256+n) = column map
+        if (threadIdx.x < nb) {
+            int idx = 0, o0 = 0;
+            for (int q = 0; q < (int)threadIdx.x; q++) { idx += lsize_kind(bid[q] / 4096); o0 += gsize_kind(bid[q] / 4096); }
+            const int id = bid[threadIdx.x], kind = id / 4096;
+            double dx[9];
+            prior_block_dx(kind, xs + state_off_of(id, d.NP), x0 + o0, dx);
+            const int fb = fblock_of(id, d.NP);
+            const int c0 = fb >= 0 ? colf[fb] : -1;
+            for (int q = 0; q < lsize_kind(kind); q++) { sdx[idx + q] = dx[q]; sdx[256 + idx + q] = c0 >= 0 ? (double)(c0 + q) : -1.0; }
+        }
+        __syncthreads();
+        const double* A = w.pri_A + (size_t)b * d.NPRI * d.NPRI;
+        const double* b0 = w.pri_b + (size_t)b * d.NPRI;
+        for (int a = threadIdx.x; a < n; a += 256) {
+            double v = 0;
+            for (int c2 = 0; c2 < n; c2++) v += A[(size_t)a * n + c2] * sdx[c2];
+            pc += sdx[a] * (b0[a] + 0.5 * v);
+            const int ca = (int)sdx[256 + a];
+            if (!cost_only && ca >= 0) atomicAdd(g + ca, b0[a] + v);
+        }
+        if (!cost_only)
+            for (int e = threadIdx.x; e < n * n; e += 256) {
+                const int ca = (int)sdx[256 + e / n], cb = (int)sdx[256 + e % n];
+                if (ca >= 0 && cb >= 0) atomicAdd(H + (size_t)ca * d.RP + cb, A[e]);
+            }
+        if (threadIdx.x == 0) pc += 0.5 * w.pri_c[b];
+    }
+    sred[threadIdx.x] = pc + (lane == 0 ? cost_acc : 0.0);
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sred[threadIdx.x] += sred[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) atomicAdd(w.cost + (size_t)which * d.B + b, sred[0]);
+}
+
+}  // namespace gfb
+
+namespace gfb {
+
+struct StepBufs {  // per-window global scratch of ba_step
+    double* scale;  // [B][VS] Jacobi column scaling 1/(1+|J_c|)        (VS = RP + FP: reduced columns, then eliminated columns)
+    double* diag;   // [B][VS] dogleg diagonal
+    double* grad;   // [B][VS] scaled gradient / diag
+    double* gn;     // [B][VS] Gauss-Newton step (dogleg space)
+    double* step;   // [B][VS] last step (scaled space, after /diag)
+    double* u;      // [B][VS] scratch
+    double* Et;     // [B][FP][RP] E^T F rows of the eliminated columns (unscaled)
+    double* Es;     // [B][FP][RP] scaled by s_e s_c / sqrt(ete~)
+    double* ete;    // [B][FP]
+    double* etb;    // [B][FP]
+    double* rhs;    // [B][RP]
+    double* yv;     // [B][VS]
+    int VS;
+};
+
+__device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }  // packed lower, i >= j
+
+__device__ __forceinline__ double block_sum(double v, double* sred, int tid, int nthreads) {
+    __syncthreads();
+    sred[tid] = v;
+    __syncthreads();
+    for (int s = nthreads / 2; s > 0; s >>= 1) { if (tid < s) sred[tid] += sred[tid + s]; __syncthreads(); }
+    const double r = sred[0];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ double block_max(double v, double* sred, int tid, int nthreads) {
+    __syncthreads();
+    sred[tid] = v;
+    __syncthreads();
+    for (int s = nthreads / 2; s > 0; s >>= 1) { if (tid < s) sred[tid] = fmax(sred[tid], sred[tid + s]); __syncthreads(); }
+    const double r = sred[0];
+    __syncthreads();
+    return r;
+}
+
+// u^T H u over reduced + eliminated columns: u_f^T Hff u_f + 2 u_e . (Et u_f) + sum ete u_e^2, and u^T g
+__device__ inline void quad_form(const double* H, const double* g, const double* Et, const double* ete, const double* etb, const double* u, int R, int NE, int RP,
+                                 double* sred, int tid, double& uHu, double& ug) {
+    double a = 0, c = 0;
+    for (int r = tid; r < R; r += 512) {
+        double s = 0;
+        const double* row = H + (size_t)r * RP;
+        for (int k = 0; k < R; k++) s += row[k] * u[k];
+        a += u[r] * s; c += u[r] * g[r];
+    }
+    for (int e = tid; e < NE; e += 512) {
+        double s = 0;
+        const double* row = Et + (size_t)e * RP;
+        for (int k = 0; k < R; k++) s += row[k] * u[k];
+        const double ue = u[RP + e];
+        a += 2.0 * ue * s + ete[e] * ue * ue; c += ue * etb[e];
+    }
+    uHu = block_sum(a, sred, tid, 512);
+    ug = block_sum(c, sred, tid, 512);
+}
+
+// PoseLocalParameterization::Plus (pose_local_parameterization.cpp:12-28)
+__device__ __forceinline__ void pose_plus(const double* x, const double* dl, double* out) {
+    out[0] = x[0] + dl[0]; out[1] = x[1] + dl[1]; out[2] = x[2] + dl[2];
+    const Q4 q = qnormalized(qmul(Q4{x[6], x[3], x[4], x[5]}, deltaQ(v3(dl[3], dl[4], dl[5]))));
+    out[3] = q.x; out[4] = q.y; out[5] = q.z; out[6] = q.w;
+}
+
+// One 512-thread block per window: accept/reject of the previous candidate (trust_region_minimizer.cc), then the next
+// dogleg step (dogleg_strategy.cc): Jacobi scaling, Cauchy point, Gauss-Newton step through the Schur complement
+// (MFMA GEMM) and an LDS-resident blocked Cholesky, candidate point.  first: the call that follows the initial linearisation.
+__global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, int max_iters, int finalize_only) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double sred[512];
+    __shared__ double s_blk[16 * 17];
+    __shared__ double s_y[16];
+    __shared__ int s_flag[4];
+    const Dims d = w.d;
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    SolverState& st = w.st[b];
+    if (st.done) return;
+    const int R = st.R, NE = st.NE, RP = d.RP, VS = sb.VS;
+    double* S = smem;  // packed lower R(R+1)/2
+    const int* colf = w.colf + (size_t)b * d.NFB;
+    const int* cole = w.cole + (size_t)b * d.F;
+    double* scale = sb.scale + (size_t)b * VS; double* diag = sb.diag + (size_t)b * VS; double* grad = sb.grad + (size_t)b * VS;
+    double* gn = sb.gn + (size_t)b * VS; double* stepv = sb.step + (size_t)b * VS; double* u = sb.u + (size_t)b * VS; double* yv = sb.yv + (size_t)b * VS;
+    double* Et = sb.Et + (size_t)b * d.FP * RP; double* Es = sb.Es + (size_t)b * d.FP * RP;
+    double* ete = sb.ete + (size_t)b * d.FP; double* etb = sb.etb + (size_t)b * d.FP; double* rhs = sb.rhs + (size_t)b * RP;
+
+    // ---------------- accept / reject the candidate of the previous iteration
+    if (tid == 0) {
+        s_flag[0] = 0;  // accepted now
+        if (first) {
+            st.x_cost = w.cost[(size_t)st.cur * d.B + b];
+            st.initial_cost = st.x_cost;
+            st.last_successful = 1;
+        } else if (st.cand_valid) {
+            const double cand_cost = w.cost[(size_t)(1 - st.cur) * d.B + b];
+            st.cand_cost = cand_cost;
+            if (st.step_norm <= 1e-8 * (st.x_norm + 1e-8)) { st.done = 1; st.termination = 2; }
+            else if (fabs(st.x_cost - cand_cost) <= 1e-6 * st.x_cost) { st.done = 1; st.termination = 1; }
+            else {
+                const double rel = (st.x_cost - cand_cost) / st.model_cost_change;
+                if (rel > 1e-3) {
+                    st.cur = 1 - st.cur; st.x_cost = cand_cost; st.successful++; st.last_successful = 1; s_flag[0] = 1;
+                    if (rel < 0.25) st.radius *= 0.5;
+                    if (rel > 0.75) st.radius = fmax(st.radius, 3.0 * st.dogleg_step_norm);
+                    st.mu = fmax(1e-8, 2.0 * st.mu / 10.0);
+                    st.reuse = 0;
+                } else { st.radius *= 0.5; st.reuse = 1; st.last_successful = 0; }
+            }
+        }
+    }
+    __syncthreads();
+    if (st.done) return;
+    const int cur = st.cur;
+    double* H = w.H + ((size_t)cur * d.B + b) * RP * RP;
+    double* g = w.g + ((size_t)cur * d.B + b) * RP;
+    const double* efac = w.efac + ((size_t)cur * d.B + b) * d.NV * EF;
+    const double* xs = w.xs + ((size_t)cur * d.B + b) * d.XS;
+
+    if (!st.reuse) {
+        // ---------------- eliminated columns: ete, etb and the rows of E^T F (per free feature, over its factors)
+        for (int i = tid; i < NE * RP; i += 512) Et[i] = 0.0;
+        __syncthreads();
+        const int nf = w.nfeat[b];
+        for (int f = wave; f < nf; f += 8) {
+            const int e = cole[f];
+            if (e < 0) continue;
+            const int p0 = w.feat_ptr[(size_t)b * (d.F + 1) + f], p1 = w.feat_ptr[(size_t)b * (d.F + 1) + f + 1];
+            double a = 0, c = 0;
+            for (int p = p0; p < p1; p++) {
+                const int k = w.feat_fac[(size_t)b * d.NV + p];
+                const double* ef = efac + (size_t)k * EF;
+                if (lane == 0) { a += ef[19]; c += ef[20]; }
+                if (lane < 19) {
+                    const size_t kk = (size_t)b * d.NV + k;
+                    const int fi = w.vis_i[kk], fj = w.vis_j[kk];
+                    const int blk = lane < 6 ? fb_pose(fi) : lane < 12 ? fb_pose(fj) : lane == 12 ? fb_td(d.NP) : fb_ex(d.NP);
+                    const int o = lane < 6 ? lane : lane < 12 ? lane - 6 : lane == 12 ? 0 : lane - 13;
+                    const int c0 = colf[blk];
+                    if (c0 >= 0) Et[(size_t)e * RP + c0 + o] += ef[lane];
+                }
+            }
+            if (lane == 0) { ete[e] = a; etb[e] = c; }
+        }
+        __syncthreads();
+        // ---------------- Jacobi scaling from the initial Jacobian (trust_region_minimizer.cc: jacobian_scaling_)
+        if (!st.have_scale) {
+            for (int c = tid; c < R; c += 512) scale[c] = 1.0 / (1.0 + sqrt(H[(size_t)c * RP + c]));
+            for (int e = tid; e < NE; e += 512) scale[RP + e] = 1.0 / (1.0 + sqrt(ete[e]));
+            __syncthreads();
+            if (tid == 0) st.have_scale = 1;
+        }
+        // unscaled gradient max norm (gradient tolerance)
+        double gm = 0;
+        for (int c = tid; c < R; c += 512) gm = fmax(gm, fabs(g[c]));
+        for (int e = tid; e < NE; e += 512) gm = fmax(gm, fabs(etb[e]));
+        gm = block_max(gm, sred, tid, 512);
+        if (tid == 0) st.gmax = gm;
+    }
+    // ---------------- FinalizeIterationAndCheckIfMinimizerCanContinue
+    if (tid == 0) {
+        if (st.iterations >= max_iters) { st.done = 1; st.termination = 0; }
+        else if (st.last_successful && st.gmax <= 1e-10) { st.done = 1; st.termination = 3; }
+        else if (st.radius <= 1e-32) { st.done = 1; st.termination = 4; }
+        else st.iterations++;
+    }
+    __syncthreads();
+    if (st.done || finalize_only) return;
+
+    if (!st.reuse) {
+        // ---------------- dogleg diagonal, scaled gradient, Cauchy point
+        for (int c = tid; c < R; c += 512) {
+            const double dd = sqrt(fmin(fmax(scale[c] * scale[c] * H[(size_t)c * RP + c], 1e-6), 1e32));
+            diag[c] = dd; grad[c] = scale[c] * g[c] / dd; u[c] = scale[c] * (grad[c] / dd);
+        }
+        for (int e = tid; e < NE; e += 512) {
+            const double sc = scale[RP + e];
+            const double dd = sqrt(fmin(fmax(sc * sc * ete[e], 1e-6), 1e32));
+            diag[RP + e] = dd; grad[RP + e] = sc * etb[e] / dd; u[RP + e] = sc * (grad[RP + e] / dd);
+        }
+        __syncthreads();
+        double gsq = 0;
+        for (int c = tid; c < R; c += 512) gsq += grad[c] * grad[c];
+        for (int e = tid; e < NE; e += 512) gsq += grad[RP + e] * grad[RP + e];
+        gsq = block_sum(gsq, sred, tid, 512);
+        double uHu, ug;
+        quad_form(H, g, Et, ete, etb, u, R, NE, RP, sred, tid, uHu, ug);
+        if (tid == 0) st.alpha = gsq / uHu;
+        // ---------------- Gauss-Newton step: (J^T J + mu D^2) y = J^T r through the Schur complement, retry with larger mu on failure
+        bool ok = false;
+        while (!ok) {
+            const double mu = st.mu;
+            if (!(mu < 1.0)) break;
+            // eliminated columns
+            for (int e = tid; e < NE; e += 512) {
+                const double sc = scale[RP + e], lm = diag[RP + e] * sqrt(mu);
+                yv[RP + e] = sc * sc * ete[e] + lm * lm;  // ete~ (kept in yv's tail until back-substitution)
+            }
+            __syncthreads();
+            for (int i = tid; i < NE * RP; i += 512) {
+                const int e = i / RP, c = i - e * RP;
+                Es[i] = c < R ? scale[RP + e] * scale[c] * Et[i] / sqrt(yv[RP + e]) : 0.0;
+            }
+            for (int i = NE * RP + tid; i < ((NE + 3) & ~3) * RP; i += 512) Es[i] = 0.0;
+            // reduced system: S = s H s + mu D^2 (packed lower in LDS), rhs = s g - sum_e (E~ row) etb~ / sqrt(ete~)
+            for (int i = tid; i < R * (R + 1) / 2; i += 512) {
+                int r = (int)((sqrt(8.0 * i + 1.0) - 1.0) * 0.5);
+                while (pk(r + 1, 0) <= i) r++;
+                while (pk(r, 0) > i) r--;
+                const int c = i - pk(r, 0);
+                double v = scale[r] * scale[c] * H[(size_t)r * RP + c];
+                if (r == c) { const double lm = diag[r] * sqrt(mu); v += lm * lm; }
+                S[i] = v;
+            }
+            __syncthreads();
+            for (int c = tid; c < R; c += 512) {
+                double v = scale[c] * g[c];
+                for (int e = 0; e < NE; e++) v -= Es[(size_t)e * RP + c] * (scale[RP + e] * etb[e] / sqrt(yv[RP + e]));
+                rhs[c] = v;
+            }
+            // S -= Es^T Es on the matrix cores: 16x16 tiles of the lower triangle, K = eliminated columns (4 per instruction)
+            {
+                const int nt = (R + 15) / 16, ntiles = nt * (nt + 1) / 2, nk = (NE + 3) / 4;
+                for (int t = wave; t < ntiles; t += 8) {
+                    int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+                    while (ti * (ti + 1) / 2 > t) ti--;
+                    while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+                    const int tk = t - ti * (ti + 1) / 2;
+                    d4 acc = {0, 0, 0, 0};
+                    const double* pa = Es + (size_t)(lane >> 4) * RP + 16 * ti + (lane & 15);
+                    const double* pb = Es + (size_t)(lane >> 4) * RP + 16 * tk + (lane & 15);
+                    for (int k = 0; k < nk; k++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(size_t)4 * k * RP], pb[(size_t)4 * k * RP], acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tk + (lane & 15);
+                        if (row < R && col <= row) S[pk(row, col)] -= acc[r];
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- blocked Cholesky of S in LDS (block 16): diagonal block by wavefront 0, panel by rows, trailing update on the matrix cores
+            if (tid == 0) s_flag[1] = 1;
+            __syncthreads();
+            for (int j0 = 0; j0 < R; j0 += 16) {
+                const int nb = min(16, R - j0);
+                if (wave == 0) {
+                    for (int i = lane; i < nb * nb; i += 64) { const int r = i / nb, c = i % nb; if (c <= r) s_blk[r * 17 + c] = S[pk(j0 + r, j0 + c)]; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    for (int j = 0; j < nb; j++) {
+                        const double djj = s_blk[j * 17 + j];
+                        if (!(djj > 0.0)) { if (lane == 0) s_flag[1] = 0; break; }
+                        const double dd = sqrt(djj);
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane == 0) s_blk[j * 17 + j] = dd;
+                        if (lane > j && lane < nb) s_blk[lane * 17 + j] /= dd;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                        for (int i = lane; i < nb * nb; i += 64) { const int r = i / nb, c = i % nb; if (c > j && c <= r) s_blk[r * 17 + c] -= s_blk[r * 17 + j] * s_blk[c * 17 + j]; }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    }
+                    for (int i = lane; i < nb * nb; i += 64) { const int r = i / nb, c = i % nb; if (c <= r) S[pk(j0 + r, j0 + c)] = s_blk[r * 17 + c]; }
+                }
+                __syncthreads();
+                if (!s_flag[1]) break;
+                // panel: rows below the block, L21 = A21 L11^-T
+                for (int r = j0 + nb + tid; r < R; r += 512) {
+                    double x[16];
+                    for (int c = 0; c < nb; c++) {
+                        double s = S[pk(r, j0 + c)];
+                        for (int k = 0; k < c; k++) s -= x[k] * s_blk[c * 17 + k];
+                        x[c] = s / s_blk[c * 17 + c];
+                    }
+                    for (int c = 0; c < nb; c++) S[pk(r, j0 + c)] = x[c];
+                }
+                __syncthreads();
+                // trailing update A22 -= L21 L21^T (lower tiles)
+                const int r0 = j0 + nb;
+                if (r0 < R) {
+                    const int nt = (R - r0 + 15) / 16, ntiles = nt * (nt + 1) / 2;
+                    for (int t = wave; t < ntiles; t += 8) {
+                        int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+                        while (ti * (ti + 1) / 2 > t) ti--;
+                        while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+                        const int tk = t - ti * (ti + 1) / 2;
+                        const int ra = r0 + 16 * ti + (lane & 15), rb = r0 + 16 * tk + (lane & 15);
+                        d4 acc = {0, 0, 0, 0};
+                        for (int k = 0; k < 4; k++) {
+                            const int c = j0 + 4 * k + (lane >> 4);
+                            const double a = (ra < R && c < j0 + nb) ? S[pk(ra, c)] : 0.0;
+                            const double bb = (rb < R && c < j0 + nb) ? S[pk(rb, c)] : 0.0;
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int row = r0 + 16 * ti + (lane >> 4) + 4 * r, col = r0 + 16 * tk + (lane & 15);
+                            if (row < R && col <= row) S[pk(row, col)] -= acc[r];
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            ok = s_flag[1] != 0;
+            if (ok) {
+                // forward substitution L z = rhs (blocks of 16), then backward L^T y = z
+                for (int j0 = 0; j0 < R; j0 += 16) {
+                    const int nb = min(16, R - j0);
+                    if (tid == 0) {
+                        for (int c = 0; c < nb; c++) {
+                            double s = rhs[j0 + c];
+                            for (int k = 0; k < c; k++) s -= S[pk(j0 + c, j0 + k)] * s_y[k];
+                            s_y[c] = s / S[pk(j0 + c, j0 + c)];
+                        }
+                        for (int c = 0; c < nb; c++) rhs[j0 + c] = s_y[c];
+                    }
+                    __syncthreads();
+                    for (int r = j0 + nb + tid; r < R; r += 512) { double s = rhs[r]; for (int c = 0; c < nb; c++) s -= S[pk(r, j0 + c)] * s_y[c]; rhs[r] = s; }
+                    __syncthreads();
+                }
+                for (int j0 = ((R - 1) / 16) * 16; j0 >= 0; j0 -= 16) {
+                    const int nb = min(16, R - j0);
+                    if (tid == 0) {
+                        for (int c = nb - 1; c >= 0; c--) {
+                            double s = rhs[j0 + c];
+                            for (int k = c + 1; k < nb; k++) s -= S[pk(j0 + k, j0 + c)] * s_y[k];
+                            s_y[c] = s / S[pk(j0 + c, j0 + c)];
+                        }
+                        for (int c = 0; c < nb; c++) rhs[j0 + c] = s_y[c];
+                    }
+                    __syncthreads();
+                    for (int r = tid; r < j0; r += 512) { double s = rhs[r]; for (int c = 0; c < nb; c++) s -= S[pk(j0 + c, r)] * s_y[c]; rhs[r] = s; }
+                    __syncthreads();
+                }
+                // back-substitute the eliminated columns, check finiteness
+                double bad = 0;
+                for (int c = tid; c < R; c += 512) { yv[c] = rhs[c]; if (!isfinite(rhs[c])) bad = 1; }
+                __syncthreads();
+                for (int e = tid; e < NE; e += 512) {
+                    const double et = yv[RP + e];
+                    double s = scale[RP + e] * etb[e];
+                    double acc = 0;
+                    for (int c = 0; c < R; c++) acc += Es[(size_t)e * RP + c] * yv[c];
+                    s -= acc * sqrt(et);
+                    const double ye = s / et;
+                    u[RP + e] = ye;  // stash
+                    if (!isfinite(ye)) bad = 1;
+                }
+                bad = block_max(bad, sred, tid, 512);
+                if (bad > 0) ok = false;
+            }
+            if (!ok) { __syncthreads(); if (tid == 0) st.mu *= 10.0; __syncthreads(); }
+        }
+        if (tid == 0) s_flag[2] = ok ? 1 : 0;
+        __syncthreads();
+        if (ok) {
+            for (int c = tid; c < R; c += 512) gn[c] = -diag[c] * yv[c];
+            for (int e = tid; e < NE; e += 512) gn[RP + e] = -diag[RP + e] * u[RP + e];
+        }
+        __syncthreads();
+        if (tid == 0) st.reuse = 1;
+    } else if (tid == 0) s_flag[2] = 1;
+    __syncthreads();
+    bool valid = s_flag[2] != 0;
+    // ---------------- traditional dogleg interpolation (dogleg_strategy.cc ComputeTraditionalDoglegStep)
+    if (valid) {
+        double a = 0, c2 = 0, dt = 0;
+        for (int c = tid; c < R; c += 512) { a += grad[c] * grad[c]; c2 += gn[c] * gn[c]; dt += grad[c] * gn[c]; }
+        for (int e = tid; e < NE; e += 512) { a += grad[RP + e] * grad[RP + e]; c2 += gn[RP + e] * gn[RP + e]; dt += grad[RP + e] * gn[RP + e]; }
+        const double gnorm = sqrt(block_sum(a, sred, tid, 512)), gnn = sqrt(block_sum(c2, sred, tid, 512)), gdot = block_sum(dt, sred, tid, 512);
+        const double radius = st.radius, alpha = st.alpha;
+        double ca, cb, dsn;  // step = ca * grad + cb * gn
+        if (gnn <= radius) { ca = 0; cb = 1; dsn = gnn; }
+        else if (gnorm * alpha >= radius) { ca = -(radius / gnorm); cb = 0; dsn = radius; }
+        else {
+            const double b_dot_a = -alpha * gdot, a_sq = pow(alpha * gnorm, 2.0), bma = a_sq - 2 * b_dot_a + pow(gnn, 2.0);
+            const double cc = b_dot_a - a_sq, dd = sqrt(cc * cc + bma * (pow(radius, 2.0) - a_sq));
+            const double beta = (cc <= 0) ? (dd - cc) / bma : (radius * radius - a_sq) / (dd + cc);
+            ca = -alpha * (1.0 - beta); cb = beta; dsn = -1;
+        }
+        double nn = 0;
+        for (int c = tid; c < R; c += 512) { const double s = ca * grad[c] + cb * gn[c]; nn += s * s; stepv[c] = s / diag[c]; u[c] = scale[c] * stepv[c]; }
+        for (int e = tid; e < NE; e += 512) { const double s = ca * grad[RP + e] + cb * gn[RP + e]; nn += s * s; stepv[RP + e] = s / diag[RP + e]; u[RP + e] = scale[RP + e] * stepv[RP + e]; }
+        nn = block_sum(nn, sred, tid, 512);
+        if (dsn < 0) dsn = sqrt(nn);
+        if (tid == 0) st.dogleg_step_norm = dsn;
+        // model_cost_change = -(J s)^T (r + J s / 2) = -(u^T g + u^T H u / 2), u = scale .* step (trust_region_minimizer.cc)
+        double uHu, ug;
+        quad_form(H, g, Et, ete, etb, u, R, NE, RP, sred, tid, uHu, ug);
+        const double mcc = -(ug + 0.5 * uHu);
+        if (tid == 0) st.model_cost_change = mcc;
+        valid = mcc > 0.0;
+    }
+    __syncthreads();
+    // ---------------- candidate point x (+) delta, delta = step .* scale = u ; zero the candidate's normal equations
+    double* xc = w.xs + ((size_t)(1 - cur) * d.B + b) * d.XS;
+    for (int i = tid; i < d.XS; i += 512) xc[i] = xs[i];
+    {
+        double* Hc = w.H + ((size_t)(1 - cur) * d.B + b) * RP * RP;
+        for (int i = tid; i < RP * RP; i += 512) Hc[i] = 0.0;
+        double* gc = w.g + ((size_t)(1 - cur) * d.B + b) * RP;
+        for (int i = tid; i < RP; i += 512) gc[i] = 0.0;
+        if (tid == 0) w.cost[(size_t)(1 - cur) * d.B + b] = 0.0;
+    }
+    __syncthreads();
+    double sn = 0, xn = 0;
+    if (valid) {
+        for (int blk = tid; blk < d.NFB + d.F; blk += 512) {
+            int c0, off, kind;
+            if (blk < d.NFB) {
+                c0 = colf[blk];
+                if (blk < 2 * d.NP) { kind = (blk & 1) ? 1 : 0; off = (blk & 1) ? off_sb(blk >> 1) : off_pose(blk >> 1); }
+                else { const int q = blk - 2 * d.NP; kind = q == 0 ? 2 : q == 1 ? 3 : q <= 4 ? 4 : q == 5 ? 7 : 8; off = q == 0 ? off_ex(d.NP) : q == 1 ? off_exw(d.NP) : q <= 4 ? off_ix(d.NP) + (q - 2) : q == 5 ? off_td(d.NP) : off_tdw(d.NP); }
+            } else {
+                const int f = blk - d.NFB;
+                if (f >= w.nfeat[b]) continue;
+                const int e = cole[f];
+                c0 = e >= 0 ? RP + e : -1; kind = 9; off = off_feat(d.NP) + f;
+            }
+            if (c0 < 0) continue;
+            const int gs = gsize_kind(kind);
+            if (gs == 7) pose_plus(xs + off, u + c0, xc + off);
+            else for (int q = 0; q < gs; q++) xc[off + q] = xs[off + q] + u[c0 + q];
+            for (int q = 0; q < gs; q++) { const double dv = xs[off + q] - xc[off + q]; sn += dv * dv; xn += xs[off + q] * xs[off + q]; }
+        }
+    }
+    sn = block_sum(sn, sred, tid, 512);
+    xn = block_sum(xn, sred, tid, 512);
+    if (tid == 0) {
+        st.step_norm = sqrt(sn); st.x_norm = sqrt(xn);
+        st.cand_valid = valid ? 1 : 0;
+        if (valid) st.invalid_run = 0;
+        else {  // HandleInvalidStep
+            st.last_successful = 0;
+            if (++st.invalid_run >= 5) { st.done = 1; st.termination = 4; }
+            st.mu *= 10.0; st.reuse = 0;
+        }
+    }
+}
+
+}  // namespace gfb

@@ -1,0 +1,133 @@
+// gf_preint.hip — host-side pre-integration (SURVEY.md row B2 stays on the host: ~40 kFLOP per IMU sample).
+// IntegrationBase::push_back/propagate/midPointIntegration (factor/integration_base.h:39-167) and
+// WheelIntegrationBase (factor/wheel_integration_base.h:41-178), restated on the small matrix type below.
+#include <cstring>
+#include <vector>
+#include "../../include/groundfusion_hip.h"
+#include "gf_dmath.hpp"
+
+namespace gf { int set_err(int code, const char* fmt, ...); }
+using namespace gfd;
+
+namespace {
+struct DM {  // tiny dense row-major matrix
+    int r, c; std::vector<double> a;
+    DM(int r_, int c_) : r(r_), c(c_), a((size_t)r_ * c_, 0.0) {}
+    double& operator()(int i, int j) { return a[(size_t)i * c + j]; }
+    double operator()(int i, int j) const { return a[(size_t)i * c + j]; }
+    void set3(int r0, int c0, const M3& m) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) (*this)(r0 + i, c0 + j) = m.m[3 * i + j]; }
+};
+DM mul(const DM& x, const DM& y) { DM o(x.r, y.c); for (int i = 0; i < x.r; i++) for (int k = 0; k < x.c; k++) { const double v = x(i, k); if (v != 0.0) for (int j = 0; j < y.c; j++) o(i, j) += v * y(k, j); } return o; }
+DM tr(const DM& x) { DM o(x.c, x.r); for (int i = 0; i < x.r; i++) for (int j = 0; j < x.c; j++) o(j, i) = x(i, j); return o; }
+DM add(const DM& x, const DM& y) { DM o(x.r, x.c); for (size_t i = 0; i < o.a.size(); i++) o.a[i] = x.a[i] + y.a[i]; return o; }
+V3 arr(const double* p) { return v3(p[0], p[1], p[2]); }
+}  // namespace
+
+extern "C" {
+
+int gf_imu_preintegrate(int n, const double* dt, const double* acc, const double* gyr, const double* acc0, const double* gyr0, const double* ba, const double* bg,
+                        const double* noise, double* delta_p, double* delta_q, double* delta_v, double* jacobian, double* covariance, double* sum_dt) {
+    if (n < 0 || !acc0 || !gyr0 || !ba || !bg || !noise) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    V3 acc_0 = arr(acc0), gyr_0 = arr(gyr0), lba = arr(ba), lbg = arr(bg), dp = v3(0, 0, 0), dv = v3(0, 0, 0);
+    Q4 dq{1, 0, 0, 0};
+    DM J(15, 15), P(15, 15), N(18, 18);
+    for (int i = 0; i < 15; i++) J(i, i) = 1;
+    for (int i = 0; i < 3; i++) {
+        N(i, i) = noise[0] * noise[0]; N(3 + i, 3 + i) = noise[1] * noise[1]; N(6 + i, 6 + i) = noise[0] * noise[0]; N(9 + i, 9 + i) = noise[1] * noise[1];
+        N(12 + i, 12 + i) = noise[2] * noise[2]; N(15 + i, 15 + i) = noise[3] * noise[3];
+    }
+    double sdt = 0;
+    for (int s = 0; s < n; s++) {
+        const double t = dt[s];
+        const V3 acc_1 = arr(acc + 3 * s), gyr_1 = arr(gyr + 3 * s);
+        const V3 un_acc_0 = qrot(dq, acc_0 - lba);
+        const V3 un_gyr = (gyr_0 + gyr_1) * 0.5 - lbg;
+        const Q4 rq = qmul(dq, Q4{1, un_gyr.x * t / 2, un_gyr.y * t / 2, un_gyr.z * t / 2});
+        const V3 un_acc_1 = qrot(rq, acc_1 - lba);
+        const V3 un_acc = (un_acc_0 + un_acc_1) * 0.5;
+        const V3 rp = dp + dv * t + un_acc * (0.5 * t * t), rv = dv + un_acc * t;
+        const M3 Rwx = skew(un_gyr), Ra0 = skew(acc_0 - lba), Ra1 = skew(acc_1 - lba), Rd = qmat(dq), Rr = qmat(rq), I = m3_identity();
+        DM F(15, 15), V(15, 18);
+        F.set3(0, 0, I);
+        F.set3(0, 3, Rd * Ra0 * (-0.25 * t * t) + Rr * Ra1 * (I - Rwx * t) * (-0.25 * t * t));
+        F.set3(0, 6, I * t);
+        F.set3(0, 9, (Rd + Rr) * (-0.25 * t * t));
+        F.set3(0, 12, Rr * Ra1 * (-0.25 * t * t * -t));
+        F.set3(3, 3, I - Rwx * t);
+        F.set3(3, 12, I * (-1.0 * t));
+        F.set3(6, 3, Rd * Ra0 * (-0.5 * t) + Rr * Ra1 * (I - Rwx * t) * (-0.5 * t));
+        F.set3(6, 6, I);
+        F.set3(6, 9, (Rd + Rr) * (-0.5 * t));
+        F.set3(6, 12, Rr * Ra1 * (-0.5 * t * -t));
+        F.set3(9, 9, I); F.set3(12, 12, I);
+        V.set3(0, 0, Rd * (0.25 * t * t));
+        const M3 v03 = (-Rr) * Ra1 * (0.25 * t * t * 0.5 * t);
+        V.set3(0, 3, v03); V.set3(0, 6, Rr * (0.25 * t * t)); V.set3(0, 9, v03);
+        V.set3(3, 3, I * (0.5 * t)); V.set3(3, 9, I * (0.5 * t));
+        V.set3(6, 0, Rd * (0.5 * t));
+        const M3 v63 = (-Rr) * Ra1 * (0.5 * t * 0.5 * t);
+        V.set3(6, 3, v63); V.set3(6, 6, Rr * (0.5 * t)); V.set3(6, 9, v63);
+        V.set3(9, 12, I * t); V.set3(12, 15, I * t);
+        J = mul(F, J);
+        P = add(mul(mul(F, P), tr(F)), mul(mul(V, N), tr(V)));
+        dp = rp; dq = qnormalized(rq); dv = rv;
+        sdt += t; acc_0 = acc_1; gyr_0 = gyr_1;
+    }
+    delta_p[0] = dp.x; delta_p[1] = dp.y; delta_p[2] = dp.z; delta_v[0] = dv.x; delta_v[1] = dv.y; delta_v[2] = dv.z;
+    delta_q[0] = dq.w; delta_q[1] = dq.x; delta_q[2] = dq.y; delta_q[3] = dq.z;
+    memcpy(jacobian, J.a.data(), 225 * 8); memcpy(covariance, P.a.data(), 225 * 8);
+    *sum_dt = sdt;
+    return GF_OK;
+}
+
+int gf_wheel_preintegrate(int n, const double* dt, const double* vel, const double* gyr, const double* vel0, const double* gyr0, const double* lin, const double* noise,
+                          double* delta_p, double* delta_q, double* jacobian, double* covariance, double* sum_dt) {
+    if (n < 0 || !vel0 || !gyr0 || !lin || !noise) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    V3 vel_0 = arr(vel0), gyr_0 = arr(gyr0), dp = v3(0, 0, 0);
+    Q4 dq{1, 0, 0, 0};
+    const double sx = lin[0], sy = lin[1], sw = lin[2];
+    DM Jm(6, 3), P(6, 6), N(12, 12);
+    for (int i = 0; i < 3; i++) { N(i, i) = noise[0] * noise[0]; N(3 + i, 3 + i) = noise[1] * noise[1]; N(6 + i, 6 + i) = noise[0] * noise[0]; N(9 + i, 9 + i) = noise[1] * noise[1]; }
+    double sdt = 0;
+    const M3 sv = m3_diag(sx, sy, 1), I = m3_identity(), I1 = m3_diag(1, 0, 0), I2 = m3_diag(0, 1, 0);
+    for (int s = 0; s < n; s++) {
+        const double t = dt[s];
+        const V3 vel_1 = arr(vel + 3 * s), gyr_1 = arr(gyr + 3 * s);
+        const V3 un_vel_0 = qrot(dq, sv * vel_0);
+        const V3 un_gyr = (gyr_0 + gyr_1) * (0.5 * sw);
+        const Q4 ddq{1, un_gyr.x * t / 2, un_gyr.y * t / 2, un_gyr.z * t / 2};
+        const Q4 rq = qmul(dq, ddq);
+        const V3 un_vel_1 = qrot(rq, sv * vel_1);
+        const V3 rp = dp + (un_vel_0 + un_vel_1) * 0.5 * t;
+        const M3 Rv0 = skew(sv * vel_0), Rv1 = skew(sv * vel_1), Rd = qmat(dq), Rr = qmat(rq), Rdd = qmat(ddq);
+        DM F(6, 6), V(6, 12);
+        F.set3(0, 0, I);
+        F.set3(0, 3, (Rd * Rv0 + Rr * Rv1 * transpose(Rdd)) * (-0.5 * t));
+        F.set3(3, 3, transpose(Rdd));
+        const M3 Jr = rightJacobianSO3(un_gyr * t);
+        V.set3(0, 0, Rd * sv * (0.5 * t));
+        V.set3(0, 3, Rr * Rv1 * Jr * (-0.25 * t * t));
+        V.set3(0, 6, Rr * sv * (0.5 * t));
+        V.set3(0, 9, Rr * Rv1 * Jr * (-0.25 * t * t));
+        V.set3(3, 3, Jr * (0.5 * sw * t));
+        V.set3(3, 9, Jr * (0.5 * sw * t));
+        auto col = [&](int r0, int c) { return v3(Jm(r0, c), Jm(r0 + 1, c), Jm(r0 + 2, c)); };
+        auto setc = [&](int r0, int c, V3 v) { Jm(r0, c) = v.x; Jm(r0 + 1, c) = v.y; Jm(r0 + 2, c) = v.z; };
+        const V3 j00 = col(0, 0) + (Rd * (I1 * vel_0) + Rr * (I1 * vel_1)) * (0.5 * t);
+        const V3 j01 = col(0, 1) + (Rd * (I2 * vel_0) + Rr * (I2 * vel_1)) * (0.5 * t);
+        const V3 last = col(3, 2);
+        const V3 j32 = last + Jr * ((gyr_0 + gyr_1) * 0.5) * t;
+        setc(0, 0, j00); setc(0, 1, j01); setc(3, 2, j32);
+        const V3 j02 = col(0, 2) + (Rd * (skew(last) * (sv * vel_0)) + Rr * (skew(j32) * (sv * vel_1))) * (0.5 * t);
+        setc(0, 2, j02);
+        P = add(mul(mul(F, P), tr(F)), mul(mul(V, N), tr(V)));
+        dp = rp; dq = qnormalized(rq);
+        sdt += t; vel_0 = vel_1; gyr_0 = gyr_1;
+    }
+    delta_p[0] = dp.x; delta_p[1] = dp.y; delta_p[2] = dp.z;
+    delta_q[0] = dq.w; delta_q[1] = dq.x; delta_q[2] = dq.y; delta_q[3] = dq.z;
+    memcpy(jacobian, Jm.a.data(), 18 * 8); memcpy(covariance, P.a.data(), 36 * 8);
+    *sum_dt = sdt;
+    return GF_OK;
+}
+}

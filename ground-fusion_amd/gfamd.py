@@ -209,3 +209,143 @@ def pyramid_level(img, level):
     der = np.zeros((lh, lw, 2), np.int16)
     _chk(lib().gf_pyramid_level(_p(img, C.c_uint8), w, h, level, _p(out, C.c_uint8), _p(der, C.c_int16)))
     return out, der
+
+
+# ------------------------------------------------------------------ back end (Estimator::optimization)
+import gfwindow as _gw  # noqa: E402
+
+
+class BaCfg(C.Structure):
+    _fields_ = [("window_size", C.c_int), ("max_features", C.c_int), ("max_visual", C.c_int), ("batch", C.c_int)]
+
+
+class BaPriorC(C.Structure):
+    _fields_ = [("cap_n", C.c_int), ("cap_blocks", C.c_int), ("n", C.c_int), ("nblocks", C.c_int), ("m", C.c_int), ("valid", C.c_int),
+                ("block_id", C.POINTER(C.c_int)), ("J", C.POINTER(C.c_double)), ("r", C.POINTER(C.c_double)), ("x0", C.POINTER(C.c_double))]
+
+
+class BaStats(C.Structure):
+    _fields_ = [("ms_upload", C.c_double), ("ms_solve", C.c_double), ("ms_marginalize", C.c_double), ("ms_download", C.c_double), ("ms_jtj", C.c_double),
+                ("solves", C.c_longlong), ("jtj_launches", C.c_longlong), ("jtj_flops", C.c_longlong)]
+
+
+EXPORTS += ["gf_ba_create", "gf_ba_destroy", "gf_ba_solve", "gf_ba_marginalize", "gf_ba_upload", "gf_ba_solve_resident", "gf_ba_download", "gf_ba_get_stats",
+            "gf_ba_reset_stats", "gf_ba_linearize", "gf_imu_preintegrate", "gf_wheel_preintegrate"]
+
+
+class Estimator:
+    """Batched window solver: the Ceres problem of Estimator::optimization() (estimator.cpp:2890-3631) on the GPU."""
+
+    def __init__(self, window_size=10, max_features=150, max_visual=1500, batch=1):
+        self.cfg = BaCfg(window_size, max_features, max_visual, batch)
+        self.h = C.c_void_p()
+        _chk(lib().gf_ba_create(C.byref(self.cfg), C.byref(self.h)))
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gf_ba_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _carr(self, wins):
+        arr = (_gw.WindowC * len(wins))()
+        for i, w in enumerate(wins):
+            arr[i] = w.to_c()
+        return arr
+
+    def solve(self, wins, max_iters=8):
+        """in place on the windows' state arrays; returns list of summary dicts"""
+        arr = self._carr(wins)
+        sums = (_gw.SummaryC * len(wins))()
+        _chk(lib().gf_ba_solve(self.h, arr, len(wins), max_iters, sums))
+        return [{k: getattr(s, k) for k, _ in _gw.SummaryC._fields_} for s in sums]
+
+    def upload(self, wins):
+        arr = self._carr(wins)
+        self._keep = (wins, arr)
+        _chk(lib().gf_ba_upload(self.h, arr, len(wins)))
+
+    def solve_resident(self, max_iters=8, marginalize_mode=-1, reset=True):
+        _chk(lib().gf_ba_solve_resident(self.h, max_iters, marginalize_mode, int(reset)))
+
+    def download(self, wins=None, with_priors=False, cap_n=256):
+        wins = wins if wins is not None else self._keep[0]
+        arr = self._carr(wins)
+        sums = (_gw.SummaryC * len(wins))()
+        priors, pc = None, None
+        if with_priors:
+            pc = (BaPriorC * len(wins))()
+            priors = []
+            for i in range(len(wins)):
+                p = {"block_id": np.zeros(64, np.int32), "J": np.zeros(cap_n * cap_n), "r": np.zeros(cap_n), "x0": np.zeros(cap_n * 2)}
+                priors.append(p)
+                pc[i].cap_n, pc[i].cap_blocks = cap_n, 64
+                pc[i].block_id, pc[i].J, pc[i].r, pc[i].x0 = _p(p["block_id"], C.c_int), _p(p["J"], C.c_double), _p(p["r"], C.c_double), _p(p["x0"], C.c_double)
+        _chk(lib().gf_ba_download(self.h, arr, len(wins), sums, pc))
+        out = [{k: getattr(s, k) for k, _ in _gw.SummaryC._fields_} for s in sums]
+        if with_priors:
+            res = []
+            for i, p in enumerate(priors):
+                if not pc[i].valid:
+                    res.append(None)
+                    continue
+                n, nb = pc[i].n, pc[i].nblocks
+                ids = p["block_id"][:nb].copy()
+                gs = sum(_gw.gsize(int(q) // 4096) for q in ids)
+                res.append({"block_id": ids, "J": p["J"][:n * n].copy(), "r": p["r"][:n].copy(), "x0": p["x0"][:gs].copy(), "m": pc[i].m, "n": n})
+            return out, res
+        return out
+
+    def marginalize(self, wins, mode=0, cap_n=256):
+        self.upload(wins)
+        self.solve_resident(0, mode, True)
+        return self.download(wins, True, cap_n)[1]
+
+    def linearize(self, win, cap=1024):
+        c = win.to_c()
+        H = np.zeros(cap * cap)
+        g = np.zeros(cap)
+        cost = C.c_double(0)
+        nf, ne = C.c_int(0), C.c_int(0)
+        ids = np.zeros(cap, np.int32)
+        _chk(lib().gf_ba_linearize(self.h, C.byref(c), cap, _p(H, C.c_double), _p(g, C.c_double), C.byref(cost), C.byref(nf), C.byref(ne), _p(ids, C.c_int)))
+        n = nf.value + ne.value
+        return {"H": H[:n * n].reshape(n, n).copy(), "g": g[:n].copy(), "cost": cost.value, "n_f": nf.value, "n_e": ne.value, "ids": ids[:n].copy()}
+
+    def stats(self):
+        s = BaStats()
+        _chk(lib().gf_ba_get_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in BaStats._fields_}
+
+    def reset_stats(self):
+        _chk(lib().gf_ba_reset_stats(self.h))
+
+
+def imu_preintegrate(dt, acc, gyr, acc0, gyr0, ba, bg, noise):
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    dt, acc, gyr, acc0, gyr0, ba, bg, noise = map(f, (dt, acc, gyr, acc0, gyr0, ba, bg, noise))
+    out = {"delta_p": np.zeros(3), "delta_q": np.zeros(4), "delta_v": np.zeros(3), "jacobian": np.zeros(225), "covariance": np.zeros(225)}
+    sd = C.c_double(0)
+    _chk(lib().gf_imu_preintegrate(len(dt), _p(dt, C.c_double), _p(acc, C.c_double), _p(gyr, C.c_double), _p(acc0, C.c_double), _p(gyr0, C.c_double),
+                                   _p(ba, C.c_double), _p(bg, C.c_double), _p(noise, C.c_double), _p(out["delta_p"], C.c_double), _p(out["delta_q"], C.c_double),
+                                   _p(out["delta_v"], C.c_double), _p(out["jacobian"], C.c_double), _p(out["covariance"], C.c_double), C.byref(sd)))
+    out["sum_dt"] = sd.value
+    return out
+
+
+def wheel_preintegrate(dt, vel, gyr, vel0, gyr0, lin, noise):
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    dt, vel, gyr, vel0, gyr0, lin, noise = map(f, (dt, vel, gyr, vel0, gyr0, lin, noise))
+    out = {"delta_p": np.zeros(3), "delta_q": np.zeros(4), "jacobian": np.zeros(18), "covariance": np.zeros(36)}
+    sd = C.c_double(0)
+    _chk(lib().gf_wheel_preintegrate(len(dt), _p(dt, C.c_double), _p(vel, C.c_double), _p(gyr, C.c_double), _p(vel0, C.c_double), _p(gyr0, C.c_double),
+                                     _p(lin, C.c_double), _p(noise, C.c_double), _p(out["delta_p"], C.c_double), _p(out["delta_q"], C.c_double),
+                                     _p(out["jacobian"], C.c_double), _p(out["covariance"], C.c_double), C.byref(sd)))
+    out["sum_dt"] = sd.value
+    return out

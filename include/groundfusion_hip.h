@@ -111,6 +111,96 @@ int gf_min_eigen_val(const uint8_t* img, int width, int height, float* eig);
 /* pyramid level l (0..3) of buildOpticalFlowPyramid and its Scharr derivative (interior only) */
 int gf_pyramid_level(const uint8_t* img, int width, int height, int level, uint8_t* out, int16_t* deriv_xy);
 
+
+/* ------------------------------------------------------------------ back end: Estimator::optimization() */
+/* Replaces the Ceres problem built and solved in Estimator::optimization() (vins_estimator/src/estimator/estimator.cpp:2890-3327:
+ * vector2double -> ceres::Solve(DENSE_SCHUR, DOGLEG, max_num_iterations) ) and the construction of the next marginalisation prior
+ * (estimator.cpp:3334-3631, factor/marginalization_factor.cpp:119-308).  A window is handed over exactly as the reference hands it to
+ * Ceres: the para_* arrays of vector2double (estimator.cpp:2276-2353) plus the constructor arguments of each factor. */
+typedef struct gf_ba gf_ba;
+
+/* parameter-block ids used by priors: kind * 4096 + index */
+enum { GF_POSE = 0, GF_SPEEDBIAS = 1, GF_EX_POSE = 2, GF_EX_WHEEL = 3, GF_SX = 4, GF_SY = 5, GF_SW = 6, GF_TD = 7, GF_TD_WHEEL = 8, GF_FEATURE = 9 };
+
+typedef struct gf_ba_cfg {
+    int window_size;   /* WINDOW_SIZE (parameters.h:24 fixes 10; here a runtime value) */
+    int max_features;  /* capacity of para_Feature (NUM_OF_F, parameters.h:25) */
+    int max_visual;    /* capacity of visual factors per window */
+    int batch;         /* independent windows solved per call */
+} gf_ba_cfg;
+
+typedef struct gf_ba_window {
+    int W, n_feature, n_visual, n_imu, n_wheel;
+    /* SetParameterBlockConstant decisions of estimator.cpp:2990-3100, :3233-3246 */
+    int fix_ex_pose, fix_ex_wheel, fix_ix, fix_td, fix_td_wheel, fix_poses;
+    double G[3];              /* gravity, estimator.h `g` */
+    double vis_sqrt_info;     /* FOCAL_LENGTH / 1.5 (estimator.cpp:193) */
+    /* parameter blocks, in/out (estimator.h:335-341) */
+    double* para_Pose;        /* (W+1) x 7: px py pz qx qy qz qw */
+    double* para_SpeedBias;   /* (W+1) x 9 */
+    double* para_Ex_Pose;     /* 7 */
+    double* para_Ex_Pose_wheel; /* 7 */
+    double* para_Ix;          /* sx, sy, sw */
+    double* para_Td;          /* 1 */
+    double* para_Td_wheel;    /* 1 */
+    double* para_Feature;     /* n_feature inverse depths */
+    const unsigned char* feature_fixed; /* estimate_flag == 1 -> constant (estimator.cpp:3291-3292) */
+    /* ProjectionTwoFrameOneCamFactor(pts_i, pts_j, velocity_i, velocity_j, td_i, td_j) on (Pose[i], Pose[j], Ex_Pose, Feature[f], Td) */
+    const int* vis_feature; const int* vis_i; const int* vis_j;
+    const double* vis_pts_i; const double* vis_pts_j; const double* vis_vel_i; const double* vis_vel_j; const double* vis_td_i; const double* vis_td_j;
+    /* IMUFactor(pre_integrations[i+1]) on (Pose[i], SpeedBias[i], Pose[i+1], SpeedBias[i+1]); delta_q as (w,x,y,z); 15x15 row-major */
+    const int* imu_i; const double* imu_sum_dt; const double* imu_delta_p; const double* imu_delta_q; const double* imu_delta_v;
+    const double* imu_lin_ba; const double* imu_lin_bg; const double* imu_jacobian; const double* imu_covariance;
+    /* WheelFactor(pre_integrations_wheel[i+1]); jacobian 6x3, covariance 6x6 row-major; wh_lin = linearized sx, sy, sw, td */
+    const int* wh_i; const double* wh_sum_dt; const double* wh_delta_p; const double* wh_delta_q; const double* wh_jacobian;
+    const double* wh_covariance; const double* wh_lin; const double* wh_lin_vel; const double* wh_lin_gyr; const double* wh_vel_1; const double* wh_gyr_1;
+    /* MarginalizationFactor(last_marginalization_info): linearized_jacobians (n x n row-major), linearized_residuals, keep_block_data */
+    int prior_n, prior_nblocks;
+    const int* prior_block_id; const double* prior_J; const double* prior_r; const double* prior_x0;
+} gf_ba_window;
+
+typedef struct gf_ba_summary {
+    int iterations, successful_steps, termination; /* 0 max iterations, 1 function tol, 2 parameter tol, 3 gradient tol, 4 failure */
+    double initial_cost, final_cost, radius;
+} gf_ba_summary;
+
+/* caller-owned output of gf_ba_marginalize: J is n x n (row-major, capacity cap_n*cap_n), block ids already address-shifted */
+typedef struct gf_ba_prior {
+    int cap_n, cap_blocks;
+    int n, nblocks, m, valid;
+    int* block_id; double* J; double* r; double* x0;
+} gf_ba_prior;
+
+typedef struct gf_ba_stats {
+    double ms_upload, ms_solve, ms_marginalize, ms_download;   /* hipEvent times accumulated over calls */
+    double ms_jtj;                                             /* time inside the visual J^T J (MFMA) kernel */
+    long long solves, jtj_launches, jtj_flops;                 /* jtj_flops: MFMA flops issued by that kernel */
+} gf_ba_stats;
+
+int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out);
+int gf_ba_destroy(gf_ba* h);
+/* ceres::Solve on `count` <= batch windows (estimator.cpp:3303-3318 with max_solver_time disabled); states updated in place */
+int gf_ba_solve(gf_ba* h, gf_ba_window* windows, int count, int max_iters, gf_ba_summary* summaries);
+/* next prior; mode 0 = MARGIN_OLD (estimator.cpp:3334-3534), 1 = MARGIN_SECOND_NEW (:3536-3631) */
+int gf_ba_marginalize(gf_ba* h, const gf_ba_window* windows, int count, int mode, gf_ba_prior* priors);
+/* throughput path: windows stay resident in HBM between calls */
+int gf_ba_upload(gf_ba* h, const gf_ba_window* windows, int count);
+int gf_ba_solve_resident(gf_ba* h, int max_iters, int marginalize_mode /* -1: none */, int reset_state);
+int gf_ba_download(gf_ba* h, gf_ba_window* windows, int count, gf_ba_summary* summaries, gf_ba_prior* priors);
+int gf_ba_get_stats(gf_ba* h, gf_ba_stats* out);
+int gf_ba_reset_stats(gf_ba* h);
+/* inspection for parity tests: H = J^T J, g = J^T r (loss-corrected, unscaled), cost; canonical column order
+ * [free blocks: pose0, sb0, pose1, ..., ex, exw, sx, sy, sw, td, tdw | free features by index] */
+int gf_ba_linearize(gf_ba* h, const gf_ba_window* w, int cap, double* H, double* g, double* cost, int* n_f, int* n_e, int* col_block_id);
+
+/* IntegrationBase::push_back loop (factor/integration_base.h:39-167), host side; noise = ACC_N, GYR_N, ACC_W, GYR_W */
+int gf_imu_preintegrate(int n, const double* dt, const double* acc, const double* gyr, const double* acc0, const double* gyr0, const double* ba,
+                        const double* bg, const double* noise, double* delta_p, double* delta_q, double* delta_v, double* jacobian,
+                        double* covariance, double* sum_dt);
+/* WheelIntegrationBase::push_back loop (factor/wheel_integration_base.h:41-178); noise = VEL_N_wheel, GYR_N_wheel; lin = sx, sy, sw */
+int gf_wheel_preintegrate(int n, const double* dt, const double* vel, const double* gyr, const double* vel0, const double* gyr0, const double* lin,
+                          const double* noise, double* delta_p, double* delta_q, double* jacobian, double* covariance, double* sum_dt);
+
 #ifdef __cplusplus
 }
 #endif

@@ -990,4 +990,38 @@ void gfo_wheel_preintegrate(int n, const double* dt, const double* vel, const do
     *sum_dt = p.sum_dt;
 }
 void gfo_sym_eig(int n, const double* A, double* d, double* V) { sym_eig(n, A, d, V); }
+
+// Debug/inspection: H = J^T J, g = J^T r (loss-corrected, UNscaled) and cost at the window's state, dense, in the canonical
+// column order [free f-blocks: pose0, sb0, pose1, ..., ex, exw, sx, sy, sw, td, tdw | free features by index].
+int gfo_ba_linearize(const gfo_window* w, int cap, double* H, double* g, double* cost, int* n_f, int* n_e, int* col_block_id) {
+    Problem P; P.w = w; P.build();
+    State x; x.load(w);
+    std::vector<RowBlock> rows;
+    *cost = P.evaluate(x, &rows);
+    const int n = P.n_cols, ne = P.n_e, nf = n - ne;
+    if (n > cap) return -1;
+    auto canon = [&](int c) { return c < ne ? nf + c : c - ne; };
+    for (int i = 0; i < n * n; i++) H[i] = 0;
+    for (int i = 0; i < n; i++) g[i] = 0;
+    for (auto& rb : rows)
+        for (int q = 0; q < rb.nb; q++) {
+            const int c0 = P.col_of.at(rb.id[q]);
+            for (int a = 0; a < rb.lsz[q]; a++) {
+                double sg = 0;
+                for (int r = 0; r < rb.nres; r++) sg += rb.J[q][(size_t)r * rb.lsz[q] + a] * rb.r[r];
+                g[canon(c0 + a)] += sg;
+            }
+            for (int q2 = 0; q2 < rb.nb; q2++) {
+                const int c1 = P.col_of.at(rb.id[q2]);
+                for (int a = 0; a < rb.lsz[q]; a++) for (int b = 0; b < rb.lsz[q2]; b++) {
+                    double sh = 0;
+                    for (int r = 0; r < rb.nres; r++) sh += rb.J[q][(size_t)r * rb.lsz[q] + a] * rb.J[q2][(size_t)r * rb.lsz[q2] + b];
+                    H[(size_t)canon(c0 + a) * n + canon(c1 + b)] += sh;
+                }
+            }
+        }
+    *n_f = nf; *n_e = ne;
+    for (int id : P.ids) { const int c0 = P.col_of.at(id); for (int a = 0; a < lsize_of(id / 4096); a++) col_block_id[canon(c0 + a)] = id; }
+    return 0;
+}
 }

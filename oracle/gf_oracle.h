@@ -84,6 +84,7 @@ void gfo_imu_preintegrate(int n, const double* dt, const double* acc, const doub
 void gfo_wheel_preintegrate(int n, const double* dt, const double* vel, const double* gyr, const double* vel0, const double* gyr0, const double* lin,
                             const double* noise, double* delta_p, double* delta_q, double* jacobian, double* covariance, double* sum_dt);
 void gfo_sym_eig(int n, const double* A, double* d, double* V);
+int gfo_ba_linearize(const gfo_window* w, int cap, double* H, double* g, double* cost, int* n_f, int* n_e, int* col_block_id);
 #ifdef __cplusplus
 }
 #endif

@@ -216,3 +216,17 @@ def sym_eig(A):
     V = np.zeros((n, n))
     lib().gfo_sym_eig(n, _p(A, C.c_double), _p(d, C.c_double), _p(V, C.c_double))
     return d, V
+
+
+def ba_linearize(win, cap=1024):
+    _bind_backend()
+    c = win.to_c()
+    H = np.zeros(cap * cap)
+    g = np.zeros(cap)
+    cost = C.c_double(0)
+    nf, ne = C.c_int(0), C.c_int(0)
+    ids = np.zeros(cap, np.int32)
+    rc = lib().gfo_ba_linearize(C.byref(c), cap, _p(H, C.c_double), _p(g, C.c_double), C.byref(cost), C.byref(nf), C.byref(ne), _p(ids, C.c_int))
+    assert rc == 0
+    n = nf.value + ne.value
+    return {"H": H[:n * n].reshape(n, n).copy(), "g": g[:n].copy(), "cost": cost.value, "n_f": nf.value, "n_e": ne.value, "ids": ids[:n].copy()}
