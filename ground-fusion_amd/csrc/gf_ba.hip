@@ -14,6 +14,7 @@
 
 #include "../../include/groundfusion_hip.h"
 #include "gf_ba_kernels.hpp"
+#include "gf_ba_marg.hpp"
 
 namespace gf { int set_err(int code, const char* fmt, ...); }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return gf::set_err(GF_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
@@ -53,12 +54,19 @@ struct gf_ba {
     // work
     Buf<double> imu_sqrt, wh_sqrt, pri_A, pri_b, pri_c, H, g, cost, efac;
     Buf<double> scale, diag, grad, gn, step, u, Et, Es, ete, etb, rhs, yv;
+    // marginalisation: column maps per mode (0 MARGIN_OLD, 1 MARGIN_SECOND_NEW), outputs
+    Buf<int> mcolf[2], mcole[2], morder[2], mnorder[2], minfo[2];
+    Buf<double> outJ, outr;
+    std::vector<std::vector<int>> keep_ids[2];   // per window: kept block ids (before the address shift), in column order
+    size_t marg_lds = 0; int marg_ncap = 0, last_marg_mode = -1;
     std::vector<Buf<double>*> dbl() { return {&xs0, &xs, &vis_data, &imu_data, &wh_data, &pri_J, &pri_r, &pri_x0, &imu_sqrt, &wh_sqrt, &pri_A, &pri_b, &pri_c, &H, &g, &cost, &efac,
                                               &scale, &diag, &grad, &gn, &step, &u, &Et, &Es, &ete, &etb, &rhs, &yv}; }
     std::vector<Buf<int>*> ints() { return {&colf, &cole, &nvis, &nimu, &nwh, &nfeat, &vis_feat, &vis_i, &vis_j, &order, &norder, &feat_ptr, &feat_fac, &imu_i, &wh_i, &pri_n, &pri_nb, &pri_bid}; }
     void release() {
         for (auto* b : dbl()) b->release();
         for (auto* b : ints()) b->release();
+        for (int m = 0; m < 2; m++) { mcolf[m].release(); mcole[m].release(); morder[m].release(); mnorder[m].release(); minfo[m].release(); }
+        outJ.release(); outr.release();
         st.release(); st0.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -187,6 +195,71 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
             memcpy(h->pri_x0.h + (size_t)b * d.NPRI * 2, w.prior_x0, (size_t)gs * 8);
         }
     }
+    // ---- marginalisation layouts (first-appearance order of the blocks over [prior, IMU0, wheel0, visual factors from frame 0])
+    for (int mode = 0; mode < 2; mode++) {
+        h->keep_ids[mode].assign(d.B, {});
+        for (int b = 0; b < d.B; b++) {
+            const gf_ba_window& w = ws[std::min(b, count - 1)];
+            std::vector<int> dropb, keepb, dropf;
+            auto has = [](const std::vector<int>& v, int id) { return std::find(v.begin(), v.end(), id) != v.end(); };
+            auto touch = [&](int id, bool dropped) {
+                if (id / 4096 == GF_FEATURE) { if (!has(dropf, id)) dropf.push_back(id); return; }
+                if (dropped) { if (!has(dropb, id)) dropb.push_back(id); }
+                else if (!has(keepb, id) && !has(dropb, id)) keepb.push_back(id);
+            };
+            bool valid = true;
+            if (mode == 0) {
+                for (int q = 0; q < w.prior_nblocks; q++) { const int id = w.prior_block_id[q]; touch(id, id == GF_POSE * 4096 || id == GF_SPEEDBIAS * 4096); }
+                for (int k = 0; k < w.n_imu; k++) if (w.imu_i[k] == 0 && w.imu_sum_dt[k] < 10.0) { touch(GF_POSE * 4096, true); touch(GF_SPEEDBIAS * 4096, true); touch(GF_POSE * 4096 + 1, false); touch(GF_SPEEDBIAS * 4096 + 1, false); }
+                for (int k = 0; k < w.n_wheel; k++) if (w.wh_i[k] == 0 && w.wh_sum_dt[k] < 10.0) {
+                    touch(GF_POSE * 4096, true); touch(GF_POSE * 4096 + 1, false); touch(GF_EX_WHEEL * 4096, false); touch(GF_SX * 4096, false); touch(GF_SY * 4096, false);
+                    touch(GF_SW * 4096, false); touch(GF_TD_WHEEL * 4096, false);
+                }
+                for (int k = 0; k < w.n_visual; k++) if (w.vis_i[k] == 0) {
+                    touch(GF_POSE * 4096, true); touch(GF_POSE * 4096 + w.vis_j[k], false); touch(GF_EX_POSE * 4096, false); touch(GF_FEATURE * 4096 + w.vis_feature[k], true);
+                    touch(GF_TD * 4096, false);
+                }
+            } else {
+                bool found = false;
+                for (int q = 0; q < w.prior_nblocks; q++) { const int id = w.prior_block_id[q]; const bool dr = id == GF_POSE * 4096 + (d.W - 1); found |= dr; touch(id, dr); }
+                valid = found && w.prior_n > 0;
+            }
+            int* mc = h->mcolf[mode].h + (size_t)b * d.NFB;
+            int* me = h->mcole[mode].h + (size_t)b * d.F;
+            for (int q = 0; q < d.NFB; q++) mc[q] = -1;
+            for (int f = 0; f < d.F; f++) me[f] = -1;
+            auto fblk = [&](int id) {
+                const int kind = id / 4096, i = id % 4096;
+                switch (kind) { case 0: return fb_pose(i); case 1: return fb_sb(i); case 2: return fb_ex(d.NP); case 3: return fb_exw(d.NP); case 4: return fb_sx(d.NP);
+                                case 5: return fb_sx(d.NP) + 1; case 6: return fb_sx(d.NP) + 2; case 7: return fb_td(d.NP); default: return fb_tdw(d.NP); }
+            };
+            int mp = 0, n = 0;
+            for (int id : dropb) { mc[fblk(id)] = mp; mp += lsize_kind(id / 4096); }
+            for (int id : keepb) { mc[fblk(id)] = mp + n; n += lsize_kind(id / 4096); }
+            for (size_t q = 0; q < dropf.size(); q++) me[dropf[q] % 4096] = (int)q;
+            if (mp + (int)dropf.size() == 0) valid = false;
+            if (valid && (n > h->marg_ncap || mp > 15 || mp + n > d.RP)) return gf::set_err(GF_ERR_CAPACITY, "window %d: marginalisation sizes mp=%d n=%d exceed this build (n <= %d)", b, mp, n, h->marg_ncap);
+            int* inf = h->minfo[mode].h + (size_t)b * 4;
+            inf[0] = mp; inf[1] = (int)dropf.size(); inf[2] = n; inf[3] = valid ? 1 : 0;
+            h->keep_ids[mode][b] = keepb;
+            // factor order (mode 0: visual factors of features starting at frame 0)
+            int* ord = h->morder[mode].h + (size_t)b * d.NVP;
+            int no = 0;
+            if (mode == 0) {
+                std::vector<int> idx;
+                for (int k = 0; k < w.n_visual; k++) if (w.vis_i[k] == 0) idx.push_back(k);
+                std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return w.vis_j[a] < w.vis_j[c]; });
+                for (size_t p = 0; p < idx.size();) {
+                    size_t q = p;
+                    while (q < idx.size() && w.vis_j[idx[q]] == w.vis_j[idx[p]]) ord[no++] = idx[q++];
+                    if ((q - p) & 1) ord[no++] = -1;
+                    p = q;
+                }
+            }
+            h->mnorder[mode].h[b] = no;
+            for (int i = no; i < d.NVP; i++) ord[i] = -1;
+        }
+    }
     h->count = count;
     return GF_OK;
 }
@@ -198,6 +271,7 @@ int upload(gf_ba* h) {
                     &h->imu_i, &h->wh_i, &h->pri_n, &h->pri_nb, &h->pri_bid})
         HIPCHK(b->up(s));
     for (auto* b : {&h->vis_data, &h->imu_data, &h->wh_data, &h->pri_J, &h->pri_r, &h->pri_x0}) HIPCHK(b->up(s));
+    for (int m = 0; m < 2; m++) for (auto* b : {&h->mcolf[m], &h->mcole[m], &h->morder[m], &h->mnorder[m], &h->minfo[m]}) HIPCHK(b->up(s));
     HIPCHK(hipMemcpyAsync(h->st0.d, h->st0.h, h->st0.n * sizeof(SolverState), hipMemcpyHostToDevice, s));
     ba_setup<<<dim3(h->d.B), 256, 0, s>>>(h->win());
     HIPCHK(hipGetLastError());
@@ -218,7 +292,7 @@ int launch_linearize(gf_ba* h, int which, int which_state, int cost_only, int on
     if (h->any_ex) ba_linearize_visual<true><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(w, which, which_state, cost_only, only_valid);
     else ba_linearize_visual<false><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(w, which, which_state, cost_only, only_valid);
     if (timed) HIPCHK(hipEventRecord(h->ev[3], h->stream));
-    ba_linearize_misc<<<dim3(d.B), 256, 0, h->stream>>>(w, which, which_state, cost_only, only_valid);
+    ba_linearize_misc<<<dim3(d.B), 256, 0, h->stream>>>(w, which, which_state, cost_only, only_valid, 0);
     HIPCHK(hipGetLastError());
     return GF_OK;
 }
@@ -242,6 +316,20 @@ int run_solve(gf_ba* h, int max_iters) {
         }
     }
     h->stats.solves += h->count;
+    return GF_OK;
+}
+
+int run_marginalize(gf_ba* h, int mode) {
+    const Dims& d = h->d;
+    Win w = h->win();
+    Win wm = w;
+    wm.colf = h->mcolf[mode].d; wm.cole = h->mcole[mode].d; wm.order = h->morder[mode].d; wm.norder = h->mnorder[mode].d;
+    ba_zero_other<<<dim3(d.B), 256, 0, h->stream>>>(w);
+    if (mode == 0) ba_linearize_visual<true><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(wm, -1, -2, 0, 2);
+    ba_linearize_misc<<<dim3(d.B), 256, 0, h->stream>>>(wm, -1, -2, 0, 2, mode == 0 ? 1 : 2);
+    MargOut mo{h->outJ.d, h->outr.d};
+    ba_marg_finish<<<dim3(d.B), 512, h->marg_lds, h->stream>>>(wm, h->sbufs(), reinterpret_cast<const MargInfo*>(h->minfo[mode].d), mo);
+    HIPCHK(hipGetLastError());
     return GF_OK;
 }
 
@@ -286,7 +374,12 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     A_(h->scale.alloc(B * VS, false)); A_(h->diag.alloc(B * VS, false)); A_(h->grad.alloc(B * VS, false)); A_(h->gn.alloc(B * VS, false)); A_(h->step.alloc(B * VS, false));
     A_(h->u.alloc(B * VS, false)); A_(h->Et.alloc(B * d.FP * d.RP, true)); A_(h->Es.alloc(B * d.FP * d.RP, false)); A_(h->ete.alloc(B * d.FP, true)); A_(h->etb.alloc(B * d.FP, true));
     A_(h->rhs.alloc(B * d.RP, false)); A_(h->yv.alloc(B * VS, false));
+    for (int m = 0; m < 2; m++) { A_(h->mcolf[m].alloc(B * d.NFB, true)); A_(h->mcole[m].alloc(B * d.F, true)); A_(h->morder[m].alloc(B * d.NVP, true)); A_(h->mnorder[m].alloc(B, true)); A_(h->minfo[m].alloc(B * 4, true)); }
+    A_(h->outJ.alloc(B * (size_t)d.NPRI * d.NPRI, true)); A_(h->outr.alloc(B * d.NPRI, true));
+    h->marg_ncap = std::min(d.NPRI, 96);   // A and V of the kept system live in LDS
+    h->marg_lds = (size_t)2 * h->marg_ncap * h->marg_ncap * sizeof(double);
     H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->step_lds));
+    H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_marg_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds));
     H_(hipStreamSynchronize(h->stream));
 #undef A_
 #undef H_
@@ -319,7 +412,8 @@ int gf_ba_solve_resident(gf_ba* h, int max_iters, int marginalize_mode, int rese
     HIPCHK(hipEventRecord(h->ev[0], h->stream));
     if (int rc = run_solve(h, max_iters)) return rc;
     HIPCHK(hipEventRecord(h->ev[1], h->stream));
-    if (marginalize_mode >= 0) return gf::set_err(GF_ERR_INVALID, "marginalisation not built yet");
+    if (marginalize_mode > 1) return gf::set_err(GF_ERR_INVALID, "marginalize_mode must be -1, 0 or 1");
+    if (marginalize_mode >= 0) { if (int rc = run_marginalize(h, marginalize_mode)) return rc; h->last_marg_mode = marginalize_mode; }
     HIPCHK(hipEventRecord(h->ev[4], h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     float ms = 0;
@@ -332,8 +426,11 @@ int gf_ba_solve_resident(gf_ba* h, int max_iters, int marginalize_mode, int rese
 
 int gf_ba_download(gf_ba* h, gf_ba_window* windows, int count, gf_ba_summary* summaries, gf_ba_prior* priors) {
     if (!h || count < 1 || count > h->count) return gf::set_err(GF_ERR_INVALID, "bad argument");
-    (void)priors;
     const Dims& d = h->d;
+    if (priors) {
+        if (h->last_marg_mode < 0) return gf::set_err(GF_ERR_INVALID, "no marginalisation has been run on the resident windows");
+        HIPCHK(h->outJ.down(h->stream)); HIPCHK(h->outr.down(h->stream));
+    }
     HIPCHK(hipEventRecord(h->ev[0], h->stream));
     HIPCHK(h->xs.down(h->stream));
     HIPCHK(hipMemcpyAsync(h->st.h, h->st.d, (size_t)d.B * sizeof(SolverState), hipMemcpyDeviceToHost, h->stream));
@@ -349,6 +446,33 @@ int gf_ba_download(gf_ba* h, gf_ba_window* windows, int count, gf_ba_summary* su
             memcpy(w.para_Ex_Pose, x + off_ex(d.NP), 56); memcpy(w.para_Ex_Pose_wheel, x + off_exw(d.NP), 56); memcpy(w.para_Ix, x + off_ix(d.NP), 24);
             w.para_Td[0] = x[off_td(d.NP)]; w.para_Td_wheel[0] = x[off_tdw(d.NP)];
             for (int f = 0; f < w.n_feature; f++) w.para_Feature[f] = x[off_feat(d.NP) + f];
+        }
+        if (priors) {
+            gf_ba_prior& p = priors[b];
+            const int mode = h->last_marg_mode;
+            const int* inf = h->minfo[mode].h + (size_t)b * 4;
+            p.valid = inf[3]; p.m = inf[0] + inf[1]; p.n = 0; p.nblocks = 0;
+            if (inf[3]) {
+                const int n = inf[2];
+                const std::vector<int>& keep = h->keep_ids[mode][b];
+                if (n > p.cap_n || (int)keep.size() > p.cap_blocks) return gf::set_err(GF_ERR_CAPACITY, "prior capacity too small (n=%d, blocks=%zu)", n, keep.size());
+                p.n = n; p.nblocks = (int)keep.size();
+                memcpy(p.J, h->outJ.h + (size_t)b * d.NPRI * d.NPRI, (size_t)n * n * sizeof(double));
+                memcpy(p.r, h->outr.h + (size_t)b * d.NPRI, (size_t)n * sizeof(double));
+                const double* x = h->xs.h + ((size_t)st.cur * d.B + b) * d.XS;
+                int xo = 0;
+                for (size_t q = 0; q < keep.size(); q++) {
+                    const int id = keep[q], kind = id / 4096, i = id % 4096;
+                    int nid = id;  // addr_shift (estimator.cpp:3471-3500 / :3583-3626)
+                    if (kind == GF_POSE || kind == GF_SPEEDBIAS) nid = mode == 0 ? kind * 4096 + i - 1 : (i == d.W ? kind * 4096 + d.W - 1 : id);
+                    p.block_id[q] = nid;
+                    int off;
+                    switch (kind) { case 0: off = off_pose(i); break; case 1: off = off_sb(i); break; case 2: off = off_ex(d.NP); break; case 3: off = off_exw(d.NP); break;
+                                    case 4: off = off_ix(d.NP); break; case 5: off = off_ix(d.NP) + 1; break; case 6: off = off_ix(d.NP) + 2; break; case 7: off = off_td(d.NP); break;
+                                    default: off = off_tdw(d.NP); }
+                    for (int k = 0; k < gsize_kind(kind); k++) p.x0[xo++] = x[off + k];
+                }
+            }
         }
         if (summaries) {
             gf_ba_summary& s = summaries[b];
@@ -366,8 +490,10 @@ int gf_ba_solve(gf_ba* h, gf_ba_window* windows, int count, int max_iters, gf_ba
 }
 
 int gf_ba_marginalize(gf_ba* h, const gf_ba_window* windows, int count, int mode, gf_ba_prior* priors) {
-    (void)h; (void)windows; (void)count; (void)mode; (void)priors;
-    return gf::set_err(GF_ERR_INVALID, "marginalisation not built yet");
+    if (!h || !windows || !priors || mode < 0 || mode > 1) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    if (int rc = gf_ba_upload(h, windows, count)) return rc;
+    if (int rc = gf_ba_solve_resident(h, 0, mode, 1)) return rc;
+    return gf_ba_download(h, nullptr, count, nullptr, priors);
 }
 
 int gf_ba_linearize(gf_ba* h, const gf_ba_window* w, int cap, double* Hout, double* gout, double* cost, int* n_f, int* n_e, int* col_block_id) {

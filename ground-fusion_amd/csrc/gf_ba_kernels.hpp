@@ -162,13 +162,13 @@ __global__ void __launch_bounds__(64) ba_linearize_visual(Win w, int which, int 
     const Dims d = w.d;
     const int b = blockIdx.y, lane = threadIdx.x;
     const SolverState& st = w.st[b];
-    if (st.done) return;
-    if (only_cand_valid && !st.cand_valid) return;
+    if (st.done && only_cand_valid != 2) return;   // only_cand_valid == 2: marginalisation pass (runs on finished windows)
+    if (only_cand_valid == 1 && !st.cand_valid) return;
     const int n_order = w.norder[b];
     const int e0 = blockIdx.x * 64;
     if (e0 >= n_order) return;
     if (which < 0) which = 1 - st.cur;            // the candidate's buffers
-    if (which_state < 0) which_state = 1 - st.cur;
+    if (which_state == -2) which_state = st.cur; else if (which_state < 0) which_state = 1 - st.cur;
     const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
     const int* colf = w.colf + (size_t)b * d.NFB;
     const int entry = e0 + lane;
@@ -509,7 +509,8 @@ __host__ __device__ inline int lsize_kind(int kind) { return (kind == 0 || kind 
 __host__ __device__ inline int gsize_kind(int kind) { return (kind == 0 || kind == 2 || kind == 3) ? 7 : kind == 1 ? 9 : 1; }
 
 // grid (B), 256 threads: wavefront t handles IMU / wheel factors round-robin; afterwards the whole block adds the prior.
-__global__ void __launch_bounds__(256) ba_linearize_misc(Win w, int which, int which_state, int cost_only, int only_cand_valid) {
+// frame_filter: 0 all factors; 1 only IMU/wheel factors starting at frame 0 (MARGIN_OLD); 2 no IMU/wheel factor (MARGIN_SECOND_NEW)
+__global__ void __launch_bounds__(256) ba_linearize_misc(Win w, int which, int which_state, int cost_only, int only_cand_valid, int frame_filter) {
     __shared__ double sJ[4][450];
     __shared__ double sSJ[4][450];
     __shared__ double sr[4][32];
@@ -519,10 +520,10 @@ __global__ void __launch_bounds__(256) ba_linearize_misc(Win w, int which, int w
     const Dims d = w.d;
     const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const SolverState& st = w.st[b];
-    if (st.done) return;
-    if (only_cand_valid && !st.cand_valid) return;
+    if (st.done && only_cand_valid != 2) return;
+    if (only_cand_valid == 1 && !st.cand_valid) return;
     if (which < 0) which = 1 - st.cur;
-    if (which_state < 0) which_state = 1 - st.cur;
+    if (which_state == -2) which_state = st.cur; else if (which_state < 0) which_state = 1 - st.cur;
     const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
     const int* colf = w.colf + (size_t)b * d.NFB;
     double* H = w.H + ((size_t)which * d.B + b) * d.RP * d.RP;
@@ -532,6 +533,8 @@ __global__ void __launch_bounds__(256) ba_linearize_misc(Win w, int which, int w
     for (int t = wave; t < nimu + nwh; t += 4) {
         int nres, ncol;
         const double* S;
+        if (frame_filter == 2) continue;
+        if (frame_filter == 1 && (t < nimu ? w.imu_i[(size_t)b * d.W + t] : w.wh_i[(size_t)b * d.W + t - nimu]) != 0) continue;
         if (t < nimu) {
             const int i = w.imu_i[(size_t)b * d.W + t], j = i + 1;
             imu_raw(xs + off_pose(i), xs + off_sb(i), xs + off_pose(j), xs + off_sb(j), w.imu_data + ((size_t)b * d.W + t) * IMU_STRIDE2, w.G, sr[wave] + 16,

@@ -68,3 +68,60 @@ def test_batched_solve_matches_single(gf, oracle):
         assert dp < 1e-6 and dr < 1e-6
     assert all(s["iterations"] == 6 for s in sums)
     est.close()
+
+
+def _prior_invariants(p):
+    n = p["n"]
+    J = p["J"].reshape(n, n)
+    return J.T @ J, J.T @ p["r"], float(p["r"] @ p["r"])
+
+
+@pytest.mark.parametrize("seed,kw", [(4, {}), (7, {"use_wheel": False})])
+def test_marginalisation_matches_oracle(gf, oracle, seed, kw):
+    """prior built on the GPU == prior built by the oracle, compared through the basis-independent J^T J, J^T r
+    (the eigenvector basis of marginalization_factor.cpp:294-302 is not unique)"""
+    est = gf.Estimator()
+    w = SW.make_window(seed, oracle, **kw)
+    oracle.ba_solve(w, 4)
+    po = oracle.ba_marginalize(w, 0)
+    pg = est.marginalize([w], 0)[0]
+    assert pg is not None and np.array_equal(po["block_id"], pg["block_id"]) and po["n"] == pg["n"] and po["m"] == pg["m"]
+    assert np.array_equal(po["x0"], pg["x0"])
+    Ao, bo, co = _prior_invariants(po)
+    Ag, bg, cg = _prior_invariants(pg)
+    sc = np.sqrt(np.outer(np.diag(Ao), np.diag(Ao))) + 1e-9 * np.abs(Ao).max()
+    assert (np.abs(Ao - Ag) / sc).max() < 1e-6
+    assert np.abs(bo - bg).max() <= 1e-6 * np.abs(bo).max()
+    # second window: solve with that prior on both sides, then both marginalisation modes
+    w2 = SW.make_window(seed, oracle, frame0=1, prior=po, **kw)
+    wo, wg = w2.copy(), w2.copy()
+    oracle.ba_solve(wo, 8)
+    est.solve([wg], 8)
+    dp, dr = _pose_diff(wo, wg)
+    assert dp < 1e-6 and dr < 1e-6
+    for mode in (0, 1):
+        p1o = oracle.ba_marginalize(wo, mode)
+        p1g = est.marginalize([wo], mode)[0]
+        assert np.array_equal(p1o["block_id"], p1g["block_id"]) and p1o["m"] == p1g["m"]
+        Ao, bo, co = _prior_invariants(p1o)
+        Ag, bg, cg = _prior_invariants(p1g)
+        sc = np.sqrt(np.outer(np.diag(Ao), np.diag(Ao))) + 1e-9 * np.abs(Ao).max()
+        assert (np.abs(Ao - Ag) / sc).max() < 1e-6, mode
+        assert np.abs(bo - bg).max() <= 1e-6 * np.abs(bo).max(), mode
+    est.close()
+
+
+def test_prior_chain_solve_with_gpu_prior(gf, oracle):
+    """a prior produced on the GPU, fed back into the next window, gives the same poses as the all-oracle chain"""
+    est = gf.Estimator()
+    w = SW.make_window(9, oracle)
+    wg = w.copy()
+    oracle.ba_solve(w, 8); est.solve([wg], 8)
+    po = oracle.ba_marginalize(w, 0)
+    pg = est.marginalize([wg], 0)[0]
+    w2o = SW.make_window(9, oracle, frame0=1, prior=po)
+    w2g = SW.make_window(9, oracle, frame0=1, prior=pg)
+    oracle.ba_solve(w2o, 8); est.solve([w2g], 8)
+    dp, dr = _pose_diff(w2o, w2g)
+    assert dp < 1e-6 and dr < 1e-6, (dp, dr)
+    est.close()
