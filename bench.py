@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""bench.py — Ground-Fusion hot path on MI355X (contract: see the task brief / DESIGN.md "Measurement").
+"""bench.py — Ground-Fusion sliding-window hot path on MI355X (contract: task brief; details in DESIGN.md "Measurement").
 
-A step = one pass of the hot path over one batch of synthetic input resident in HBM: every one of the
-`--batch` independent 640x480 sequences owned by this GPU advances by one frame through
-FeatureTracker::trackImage (HIP pyramid + Scharr + LK fwd/rev + Shi-Tomasi top-up) [+ the sliding-window
-solve once the back end is enabled].  One process per GPU; sequences are sharded across ranks with no
-data-path collective (weak scaling); the only collectives are the timing/throughput reductions.
+A step = one pass of the hot path over one batch of synthetic input already resident in HBM: every one of the `--batch`
+independent 640x480 RGBD+IMU+wheel sequences owned by this GPU advances by one frame:
+  front end  FeatureTracker::trackImage   (HIP pyramid + Scharr + LK forward/reverse + Shi-Tomasi top-up), and
+  back end   Estimator::optimization()    (8 dogleg iterations of the 10-frame / 150-feature window + MARGIN_OLD prior).
+One process per GPU.  Sequences are independent, so they are sharded across ranks with no data-path collective (weak
+scaling); after the timed region the newest pose of every sequence is gathered over RCCL (north_star's pose gather).
 """
 import argparse
 import json
@@ -22,16 +23,16 @@ import numpy as np
 import torch
 
 W, H = 640, 480
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_MFMA_PEAK_TF = 78.6  # MI355X FP64 matrix peak (v_mfma_f64_16x16x4_f64)
 
 
 def make_frames(n_frames, batch, seed0, device):
     """Synthetic sequences generated on the GPU (plumbing): band-limited texture, similarity warp per frame.
     Returns uint8 [n_frames, batch, H, W] and uint16-as-int16 depth [batch, H, W]."""
     import synth
-    g = torch.Generator(device="cpu")
     n_tex = min(batch, 8)
-    tex = torch.stack([torch.from_numpy(synth.make_texture(seed0 + i)) for i in range(n_tex)]).to(device)  # [n_tex,1024,1024]
+    tex = torch.stack([torch.from_numpy(synth.make_texture(seed0 + i)) for i in range(n_tex)]).to(device)
     ys, xs = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float32), torch.arange(W, device=device, dtype=torch.float32), indexing="ij")
     frames = torch.empty((n_frames, batch, H, W), dtype=torch.uint8, device=device)
     rng = np.random.default_rng(seed0)
@@ -55,24 +56,49 @@ def make_frames(n_frames, batch, seed0, device):
     return frames, depth
 
 
-def cpu_baseline(frames_host, dt, threads):
-    """Oracle (CPU restatement, kind 'port') on a bounded sample of the same workload: `threads` sequences in parallel,
-    each single-threaded like the reference's FeatureTracker; returns tracked-features/s (same definition as the GPU)."""
+def make_windows(gfamd, batch, seed0, features):
+    """Steady-state windows (with a marginalisation prior) for `batch` sequences: window 0 is solved and marginalised on the
+    GPU with the product path itself, the resulting prior feeds window 1 which is what the bench solves."""
+    import synth_window as SW
+    est = gfamd.Estimator(window_size=10, max_features=features, max_visual=features * 10, batch=batch)
+    w0 = [SW.make_window(seed0 + b, gfamd, max_features=features, n_landmarks=int(features * 1.5)) for b in range(batch)]
+    est.upload(w0)
+    est.solve_resident(8, 0, True)
+    _, priors = est.download(w0, True)
+    w1 = [SW.make_window(seed0 + b, gfamd, frame0=1, prior=priors[b], max_features=features, n_landmarks=int(features * 1.5)) for b in range(batch)]
+    return est, w1
+
+
+def cpu_baseline(frames_host, dt, wins, threads, ba_iters):
+    """CPU oracle (kind 'port') on a bounded sample of the same workload, `threads` sequences in parallel, each sequence
+    single-threaded like the reference (Ceres num_threads = 1, estimator.cpp:3306).  Returns per-unit rates."""
     import threading
     import oracle_py
     oracle_py.lib()
     n_frames, nseq = frames_host.shape[0], frames_host.shape[1]
     depth = np.full((H, W), 1800, np.uint16)
     counts = [0] * nseq
+    t_track = [0.0] * nseq
+    t_ba = [0.0] * nseq
+    n_ba = [0] * nseq
 
     def run(b):
         tr = oracle_py.Tracker(oracle_py.default_cfg())
         prev = set()
+        t0 = time.perf_counter()
         for k in range(n_frames):
             ids, _ = tr.track(dt * k, frames_host[k, b], depth)
             if k > 0:
                 counts[b] += len(prev & set(ids.tolist()))
             prev = set(ids.tolist())
+        t_track[b] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(max(1, n_frames // 4)):
+            w = wins[b].copy()
+            oracle_py.ba_solve(w, ba_iters)
+            oracle_py.ba_marginalize(w, 0)
+            n_ba[b] += 1
+        t_ba[b] = time.perf_counter() - t0
 
     t0 = time.perf_counter()
     ths = [threading.Thread(target=run, args=(b,)) for b in range(nseq)]
@@ -82,7 +108,12 @@ def cpu_baseline(frames_host, dt, threads):
         for th in ths[i:i + threads]:
             th.join()
     el = time.perf_counter() - t0
-    return sum(counts) / el, el
+    # time for one full step of one sequence on one core = tracker frame + solve; `threads` cores run in parallel
+    per_frame = sum(t_track) / (nseq * (n_frames - 1)) + 0.0
+    per_solve = sum(t_ba) / sum(n_ba)
+    steps_per_s = threads / (per_frame + per_solve)
+    return {"steps_per_s": steps_per_s, "tracked_features_per_s": threads * (sum(counts) / (nseq * (n_frames - 1))) / per_frame,
+            "solves_only_per_s": threads / per_solve, "ms_track_frame_1core": 1e3 * per_frame, "ms_solve_marg_1core": 1e3 * per_solve, "wall_s": el}
 
 
 def main():
@@ -93,7 +124,10 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="independent sequences per GPU")
     ap.add_argument("--max-cnt", type=int, default=150)
     ap.add_argument("--min-dist", type=int, default=30)
+    ap.add_argument("--ba-iters", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-frontend", action="store_true")
+    ap.add_argument("--no-backend", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,26 +143,34 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     import gfamd
+    import shard
     gfamd._chk(gfamd.lib().gf_set_device(local_rank))
     B, K, Wm = args.batch, args.steps, args.warmup
     dt = 1.0 / 15.0
     n_frames = Wm + K + 1
-    frames, depth = make_frames(n_frames, B, 1000 + 100 * rank, dev)
+    seq0 = shard.first_sequence(rank, B)  # global sequence ids [seq0, seq0 + B)
+    frames, depth = make_frames(n_frames, B, 1000 + seq0, dev)
     torch.cuda.synchronize()
     frame_bytes = B * H * W
 
     trk = gfamd.FeatureTracker(gfamd.default_cfg(batch=B, max_cnt=args.max_cnt, min_dist=args.min_dist))
     trk.set_profiling(True)
+    est, wins = make_windows(gfamd, B, 1000 + seq0, args.max_cnt)
+    est.upload(wins)
     step = [0]
 
     def do_step():
         k = step[0]
-        trk.trackImageBatchDevice([dt * k] * B, frames.data_ptr() + k * frame_bytes, depth.data_ptr(), unpack=False)
+        if not args.no_frontend:
+            trk.trackImageBatchDevice([dt * k] * B, frames.data_ptr() + k * frame_bytes, depth.data_ptr(), unpack=False)
+        if not args.no_backend:
+            est.solve_resident(args.ba_iters, 0, True)
         step[0] += 1
 
     for _ in range(Wm + 1):  # frame 0 only detects; it is part of the warm-up
         do_step()
     trk.reset_stats()
+    est.reset_stats()
 
     def barrier():
         if dist is not None:
@@ -142,45 +184,67 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     st = trk.stats()
+    bs = est.stats()
 
-    tot = torch.tensor([el, float(st["tracked_features"]), float(st["output_features"])], dtype=torch.float64, device=dev)
+    # north_star: gather the newest pose of every sequence on rank 0 (7 doubles per sequence, latency-bound)
+    sums = est.download(wins)
+    newest = torch.tensor(np.stack([w["para_Pose"].reshape(-1, 7)[-1] for w in wins]), dtype=torch.float64, device=dev)
+    gathered = shard.gather_poses(newest, dist, world)
+
+    tot = torch.tensor([el, float(st["tracked_features"]), float(st["output_features"]), float(bs["solves"])], dtype=torch.float64, device=dev)
     if dist is not None:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tot.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        el_max, tracked, outf = mx[0].item(), sm[1].item(), sm[2].item()
+        el_max, tracked, outf, solves = mx[0].item(), sm[1].item(), sm[2].item(), sm[3].item()
     else:
-        el_max, tracked, outf = el, st["tracked_features"], st["output_features"]
+        el_max, tracked, outf, solves = el, st["tracked_features"], st["output_features"], bs["solves"]
 
     if rank == 0:
+        assert gathered.shape == (B * world, 7) and bool(torch.isfinite(gathered).all())
         # roofline of the dominant kernel (lk_track_kernel): algorithmic bytes per SURVEY.md §8(d):
         #   484*(1+4) B per (point, level pass) [u8 window + s16x2 derivative window] + 484 B per iteration [moving window]
         launches = max(st["lk_launches"], 1)
         alg_bytes = 484.0 * 5.0 * st["lk_level_passes"] + 484.0 * st["lk_iterations"]
         lk_ms = st["ms_lk"] / launches
         achieved = alg_bytes / launches / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
+        jtj_ms = bs["ms_jtj"] / max(bs["jtj_launches"], 1)
+        jtj_tf = bs["jtj_flops"] / max(bs["jtj_launches"], 1) / (jtj_ms * 1e-3) / 1e12 if jtj_ms > 0 else 0.0
+        unit = "window-solves/s (each with its tracker frame)" if not (args.no_frontend or args.no_backend) else ("tracked-features/s" if args.no_backend else "window-solves/s")
+        value = (tracked / el_max) if args.no_backend else (solves / el_max)
         res = {
             "metric": "sliding-window solves/sec + tracked-features/sec, 640x480x10-frame window",
-            "value": tracked / el_max, "unit": "tracked-features/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "value": value, "unit": unit, "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": 1e3 * el_max / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/s16 fixed-point + f32 (LK), f32/f64 (Shi-Tomasi)", "data": "synthetic",
-            "config": {"workload": "configs[1] front end: %d independent 640x480 RGBD sequences per GPU, max_cnt %d, min_dist %d, LK 21x21 3 levels + flow-back, Shi-Tomasi top-up"
-                                   % (B, args.max_cnt, args.min_dist), "sequences_per_gpu": B, "window": 10, "features": args.max_cnt},
-            "frames_per_s": B * world * K / el_max, "output_features_per_s": outf / el_max, "solves_per_s": None,
-            "gpu_ms_per_step": {"pyramid": st["ms_pyramid"] / K, "lk": st["ms_lk"] / K, "detect": st["ms_detect"] / K, "total": st["ms_total_gpu"] / K},
+            "dtype": "front end u8/s16 fixed point + f32; back end f64", "data": "synthetic",
+            "config": {"workload": "configs[1] (150 features, 10-frame window, visual+IMU+wheel+prior factors, 8 dogleg iterations + MARGIN_OLD marginalisation; "
+                                   "LK 21x21 3 levels + flow-back, Shi-Tomasi top-up) run as %d independent 640x480 RGBD sequences per GPU (the per-GPU share of configs[3])" % B,
+                       "sequences_per_gpu": B, "window": 10, "features": args.max_cnt, "ba_iterations": args.ba_iters},
+            "solves_per_s": solves / el_max, "tracked_features_per_s": tracked / el_max, "frames_per_s": B * world * K / el_max,
+            "output_features_per_s": outf / el_max,
+            "gpu_ms_per_step": {"pyramid": st["ms_pyramid"] / K, "lk": st["ms_lk"] / K, "detect": st["ms_detect"] / K, "tracker_total": st["ms_total_gpu"] / K,
+                                "ba_solve": bs["ms_solve"] / K, "ba_marginalize": bs["ms_marginalize"] / K},
             "host_ms_per_step": {k: st[k] / K for k in ("ms_host_pre", "ms_wait_lk", "ms_host_mid", "ms_wait_detect", "ms_host_post")},
             "roofline": {"kernel": "lk_track_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms": lk_ms, "algorithmic_bytes_per_launch": alg_bytes / launches,
                          "points_per_launch": st["lk_points"] / launches, "iterations_per_launch": st["lk_iterations"] / launches},
+            "roofline_jtj": {"kernel": "ba_linearize_visual", "bound": "mfma", "achieved": jtj_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                             "frac": jtj_tf / FP64_MFMA_PEAK_TF, "launch_ms": jtj_ms, "mfma_flops_per_launch": bs["jtj_flops"] / max(bs["jtj_launches"], 1),
+                             "note": "kernel time includes the per-factor residual/Jacobian evaluation (FP64 VALU) that feeds the MFMA contraction"},
+            "ba_summary_seq0": sums[0],
         }
         if not args.no_cpu_baseline:
             nseq = min(8, B)
             cores = min(os.cpu_count() or 1, nseq)
-            fh = frames[: min(n_frames, 12), :nseq].cpu().numpy()
-            v, cel = cpu_baseline(fh, dt, cores)
-            res["cpu_baseline"] = {"value": v, "unit": "tracked-features/s", "cores": cores, "kind": "port",
-                                   "sample": "%d sequences x %d frames of the same synthetic streams through the CPU oracle tracker, %d threads (one per sequence), %.1f s" % (nseq, fh.shape[0], cores, cel)}
+            fh = frames[: min(n_frames, 13), :nseq].cpu().numpy()
+            cb = cpu_baseline(fh, dt, wins[:nseq], cores, args.ba_iters)
+            res["cpu_baseline"] = {"value": cb["steps_per_s"] if not args.no_backend else cb["tracked_features_per_s"],
+                                   "unit": unit, "cores": cores, "kind": "port",
+                                   "sample": "%d sequences x %d frames (tracker) and %d solve+marginalise per sequence through the CPU oracle, %d threads, one sequence per thread; %.1f s wall"
+                                             % (nseq, fh.shape[0], max(1, fh.shape[0] // 4), cores, cb["wall_s"]),
+                                   "detail": cb}
         print(json.dumps(res))
     trk.close()
+    est.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

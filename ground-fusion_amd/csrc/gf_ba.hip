@@ -59,6 +59,7 @@ struct gf_ba {
     Buf<double> outJ, outr;
     std::vector<std::vector<int>> keep_ids[2];   // per window: kept block ids (before the address shift), in column order
     size_t marg_lds = 0; int marg_ncap = 0, last_marg_mode = -1;
+    long long mfma_per_lin = 0;   // v_mfma_f64_16x16x4 instructions of one visual linearisation of the resident batch
     std::vector<Buf<double>*> dbl() { return {&xs0, &xs, &vis_data, &imu_data, &wh_data, &pri_J, &pri_r, &pri_x0, &imu_sqrt, &wh_sqrt, &pri_A, &pri_b, &pri_c, &H, &g, &cost, &efac,
                                               &scale, &diag, &grad, &gn, &step, &u, &Et, &Es, &ete, &etb, &rhs, &yv}; }
     std::vector<Buf<int>*> ints() { return {&colf, &cole, &nvis, &nimu, &nwh, &nfeat, &vis_feat, &vis_i, &vis_j, &order, &norder, &feat_ptr, &feat_fac, &imu_i, &wh_i, &pri_n, &pri_nb, &pri_bid}; }
@@ -97,6 +98,7 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
     const Dims& d = h->d;
     if (count < 1 || count > d.B) return gf::set_err(GF_ERR_INVALID, "count %d outside 1..%d", count, d.B);
     h->any_ex = false;
+    h->mfma_per_lin = 0;
     for (int b = 0; b < d.B; b++) {
         const gf_ba_window& w = ws[std::min(b, count - 1)];  // unused slots replicate the last window (kernels run on the whole batch)
         if (w.W != d.W) return gf::set_err(GF_ERR_INVALID, "window %d: W=%d, handle built for %d", b, w.W, d.W);
@@ -160,6 +162,7 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
             if (n > d.NVP) return gf::set_err(GF_ERR_CAPACITY, "factor order overflow");
             h->norder.h[b] = n;
             for (int i = n; i < d.NVP; i++) ord[i] = -1;
+            if (b < count) h->mfma_per_lin += (long long)(n / 2) * (w.fix_ex_pose ? 1 : 3);
         }
         {   // CSR feature -> factors
             int* fp = h->feat_ptr.h + (size_t)b * (d.F + 1);
@@ -312,7 +315,7 @@ int run_solve(gf_ba* h, int max_iters) {
         if (it < max_iters) {
             // candidate state lives in buffer (1 - cur) of each window: linearise both ... the kernels pick the right one per window
             if (int rc = launch_linearize(h, -1, -1, 0, 1, it == 0)) return rc;
-            if (it == 0) { h->stats.jtj_launches++; }
+            if (it == 0) { h->stats.jtj_launches++; h->stats.jtj_flops += h->mfma_per_lin * 2048; }
         }
     }
     h->stats.solves += h->count;
