@@ -57,6 +57,7 @@ struct gf_ba {
     // marginalisation: column maps per mode (0 MARGIN_OLD, 1 MARGIN_SECOND_NEW), outputs
     Buf<int> mcolf[2], mcole[2], morder[2], mnorder[2], minfo[2];
     Buf<double> outJ, outr;
+    Buf<long long> stamps;
     std::vector<std::vector<int>> keep_ids[2];   // per window: kept block ids (before the address shift), in column order
     size_t marg_lds = 0; int marg_ncap = 0, last_marg_mode = -1;
     long long mfma_per_lin = 0;   // v_mfma_f64_16x16x4 instructions of one visual linearisation of the resident batch
@@ -67,7 +68,7 @@ struct gf_ba {
         for (auto* b : dbl()) b->release();
         for (auto* b : ints()) b->release();
         for (int m = 0; m < 2; m++) { mcolf[m].release(); mcole[m].release(); morder[m].release(); mnorder[m].release(); minfo[m].release(); }
-        outJ.release(); outr.release();
+        outJ.release(); outr.release(); stamps.release();
         st.release(); st0.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -85,7 +86,7 @@ struct gf_ba {
     StepBufs sbufs() {
         StepBufs s{};
         s.scale = scale.d; s.diag = diag.d; s.grad = grad.d; s.gn = gn.d; s.step = step.d; s.u = u.d; s.Et = Et.d; s.Es = Es.d; s.ete = ete.d; s.etb = etb.d;
-        s.rhs = rhs.d; s.yv = yv.d; s.VS = d.RP + d.FP;
+        s.rhs = rhs.d; s.yv = yv.d; s.VS = d.RP + d.FP; s.stamps = stamps.d;
         return s;
     }
     double G[3] = {0, 0, 9.805};
@@ -295,7 +296,8 @@ int launch_linearize(gf_ba* h, int which, int which_state, int cost_only, int on
     if (h->any_ex) ba_linearize_visual<true><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(w, which, which_state, cost_only, only_valid);
     else ba_linearize_visual<false><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(w, which, which_state, cost_only, only_valid);
     if (timed) HIPCHK(hipEventRecord(h->ev[3], h->stream));
-    ba_linearize_misc<<<dim3(d.B), 256, 0, h->stream>>>(w, which, which_state, cost_only, only_valid, 0);
+    ba_linearize_misc<<<dim3(2 * d.W + 1, d.B), 256, 0, h->stream>>>(w, which, which_state, cost_only, only_valid, 0);
+    if (!cost_only) ba_build_et<<<dim3(d.F, d.B), 64, 0, h->stream>>>(w, h->sbufs(), which, 0);
     HIPCHK(hipGetLastError());
     return GF_OK;
 }
@@ -329,7 +331,8 @@ int run_marginalize(gf_ba* h, int mode) {
     wm.colf = h->mcolf[mode].d; wm.cole = h->mcole[mode].d; wm.order = h->morder[mode].d; wm.norder = h->mnorder[mode].d;
     ba_zero_other<<<dim3(d.B), 256, 0, h->stream>>>(w);
     if (mode == 0) ba_linearize_visual<true><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(wm, -1, -2, 0, 2);
-    ba_linearize_misc<<<dim3(d.B), 256, 0, h->stream>>>(wm, -1, -2, 0, 2, mode == 0 ? 1 : 2);
+    ba_linearize_misc<<<dim3(2 * d.W + 1, d.B), 256, 0, h->stream>>>(wm, -1, -2, 0, 2, mode == 0 ? 1 : 2);
+    ba_build_et<<<dim3(d.F, d.B), 64, 0, h->stream>>>(wm, h->sbufs(), -1, 1);
     MargOut mo{h->outJ.d, h->outr.d};
     ba_marg_finish<<<dim3(d.B), 512, h->marg_lds, h->stream>>>(wm, h->sbufs(), reinterpret_cast<const MargInfo*>(h->minfo[mode].d), mo);
     HIPCHK(hipGetLastError());
@@ -343,7 +346,7 @@ extern "C" {
 int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     if (!cfg || !out) return gf::set_err(GF_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (cfg->window_size < 2 || cfg->window_size > 62 || cfg->max_features < 1 || cfg->max_visual < 1 || cfg->batch < 1) return gf::set_err(GF_ERR_INVALID, "bad gf_ba_cfg");
+    if (cfg->window_size < 2 || cfg->window_size > 19 || cfg->max_features < 1 || cfg->max_visual < 1 || cfg->batch < 1) return gf::set_err(GF_ERR_INVALID, "bad gf_ba_cfg");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return gf::set_err(GF_ERR_NO_DEVICE, "no HIP device available; the HIP path has no CPU fallback");
     gf_ba* h = new gf_ba();
@@ -352,8 +355,8 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     d.B = cfg->batch; d.W = cfg->window_size; d.NP = d.W + 1; d.F = cfg->max_features; d.NV = cfg->max_visual;
     d.NVP = ((d.NV + d.NP * d.NP / 2 + 63) / 64) * 64;
     const int Rmax = 15 * d.NP + 17;
-    d.RP = (Rmax + 15) & ~15; d.XS = (16 * d.NP + 20 + d.F + 3) & ~3; d.NFB = 2 * d.NP + 7; d.FP = (d.F + 3) & ~3; d.NPRI = d.RP;
-    h->step_lds = (size_t)Rmax * (Rmax + 1) / 2 * sizeof(double);
+    d.RP = (Rmax + 1 + 15) & ~15; /* one spare column: the Schur GEMM carries the right-hand side in column R */ d.XS = (16 * d.NP + 20 + d.F + 3) & ~3; d.NFB = 2 * d.NP + 7; d.FP = (d.F + 3) & ~3; d.NPRI = d.RP; d.ECW = (6 * d.NP + 8 + 15) & ~15;
+    h->step_lds = (size_t)(Rmax + 1) * (Rmax + 2) / 2 * sizeof(double);  // packed lower S plus the right-hand-side row
     if (h->step_lds + 8 * 1024 > 160 * 1024) { delete h; return gf::set_err(GF_ERR_INVALID, "window_size %d: reduced system (%d) does not fit the LDS-resident Cholesky of this build", d.W, Rmax); }
 #define A_(x) do { if (int rc_ = (x)) { h->release(); delete h; return rc_; } } while (0)
 #define H_(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { gf::set_err(GF_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); h->release(); delete h; return GF_ERR_HIP; } } while (0)
@@ -375,10 +378,10 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     A_(h->imu_sqrt.alloc(B * d.W * 225, false)); A_(h->wh_sqrt.alloc(B * d.W * 36, false)); A_(h->pri_A.alloc(B * d.NPRI * d.NPRI, false)); A_(h->pri_b.alloc(B * d.NPRI, false));
     A_(h->pri_c.alloc(B, false)); A_(h->H.alloc(2 * B * d.RP * d.RP, true)); A_(h->g.alloc(2 * B * d.RP, true)); A_(h->cost.alloc(2 * B, true)); A_(h->efac.alloc(2 * B * d.NV * EF, false));
     A_(h->scale.alloc(B * VS, false)); A_(h->diag.alloc(B * VS, false)); A_(h->grad.alloc(B * VS, false)); A_(h->gn.alloc(B * VS, false)); A_(h->step.alloc(B * VS, false));
-    A_(h->u.alloc(B * VS, false)); A_(h->Et.alloc(B * d.FP * d.RP, true)); A_(h->Es.alloc(B * d.FP * d.RP, false)); A_(h->ete.alloc(B * d.FP, true)); A_(h->etb.alloc(B * d.FP, true));
+    A_(h->u.alloc(B * VS, false)); A_(h->Et.alloc(2 * B * d.FP * d.ECW, true)); A_(h->Es.alloc(B * d.FP * d.ECW, false)); A_(h->ete.alloc(2 * B * d.FP, true)); A_(h->etb.alloc(2 * B * d.FP, true));
     A_(h->rhs.alloc(B * d.RP, false)); A_(h->yv.alloc(B * VS, false));
     for (int m = 0; m < 2; m++) { A_(h->mcolf[m].alloc(B * d.NFB, true)); A_(h->mcole[m].alloc(B * d.F, true)); A_(h->morder[m].alloc(B * d.NVP, true)); A_(h->mnorder[m].alloc(B, true)); A_(h->minfo[m].alloc(B * 4, true)); }
-    A_(h->outJ.alloc(B * (size_t)d.NPRI * d.NPRI, true)); A_(h->outr.alloc(B * d.NPRI, true));
+    A_(h->outJ.alloc(B * (size_t)d.NPRI * d.NPRI, true)); A_(h->outr.alloc(B * d.NPRI, true)); A_(h->stamps.alloc(64, true));
     h->marg_ncap = std::min(d.NPRI, 96);   // A and V of the kept system live in LDS
     h->marg_lds = (size_t)2 * h->marg_ncap * h->marg_ncap * sizeof(double);
     H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->step_lds));
@@ -520,7 +523,14 @@ int gf_ba_linearize(gf_ba* h, const gf_ba_window* w, int cap, double* Hout, doub
     for (int r = 0; r < R; r++) { for (int c = 0; c < R; c++) Hout[(size_t)r * n + c] = h->H.h[(size_t)r * d.RP + c]; gout[r] = h->g.h[r]; }
     for (int e = 0; e < NE; e++) {
         Hout[(size_t)(R + e) * n + R + e] = h->ete.h[e]; gout[R + e] = h->etb.h[e];
-        for (int c = 0; c < R; c++) { Hout[(size_t)(R + e) * n + c] = h->Et.h[(size_t)e * d.RP + c]; Hout[(size_t)c * n + R + e] = h->Et.h[(size_t)e * d.RP + c]; }
+        for (int k = 0; k < 6 * d.NP + 7; k++) {   // compact row -> reduced columns
+            const int* cf = h->colf.h;
+            int c = -1;
+            if (k < 6 * d.NP) { if (cf[fb_pose(k / 6)] >= 0) c = cf[fb_pose(k / 6)] + k % 6; }
+            else if (k < 6 * d.NP + 6) { if (cf[fb_ex(d.NP)] >= 0) c = cf[fb_ex(d.NP)] + k - 6 * d.NP; }
+            else c = cf[fb_td(d.NP)];
+            if (c >= 0) { Hout[(size_t)(R + e) * n + c] = h->Et.h[(size_t)e * d.ECW + k]; Hout[(size_t)c * n + R + e] = h->Et.h[(size_t)e * d.ECW + k]; }
+        }
     }
     *cost = h->cost.h[0]; *n_f = R; *n_e = NE;
     if (col_block_id) {
@@ -530,6 +540,12 @@ int gf_ba_linearize(gf_ba* h, const gf_ba_window* w, int cap, double* Hout, doub
         for (int q = 0; q < 7; q++) { const int c0 = cf[2 * d.NP + q]; if (c0 >= 0) for (int k = 0; k < (q < 2 ? 6 : 1); k++) col_block_id[c0 + k] = kinds[q] * 4096; }
         for (int f = 0; f < d.F; f++) if (h->cole.h[f] >= 0) col_block_id[R + h->cole.h[f]] = GF_FEATURE * 4096 + f;
     }
+    return GF_OK;
+}
+
+int gf_ba_debug_stamps(gf_ba* h, long long* out, int n) {  // phase timestamps of the last ba_step launch (profiling builds)
+    if (!h || !out || n > 64) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    HIPCHK(hipMemcpy(out, h->stamps.d, n * sizeof(long long), hipMemcpyDeviceToHost));
     return GF_OK;
 }
 

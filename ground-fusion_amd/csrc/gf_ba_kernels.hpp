@@ -18,9 +18,11 @@ using namespace gfd;
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 struct Dims {
-    int B, W, NP, F, NV, NVP, RP, XS, NFB, FP, NPRI;
+    int B, W, NP, F, NV, NVP, RP, XS, NFB, FP, NPRI, ECW;
     // NP = W+1 poses; NVP = padded length of the pair-sorted factor order; RP = padded reduced dimension (multiple of 16);
     // XS = state vector stride; NFB = 2*NP + 7 non-feature parameter blocks; FP = F rounded up to 4; NPRI = prior capacity (= RP)
+    // ECW = width of the compact rows of the eliminated columns: a feature only touches pose blocks, the camera extrinsic and td
+    //       (compact column 6i+q = pose i, 6NP+q = ex_pose, 6NP+6 = td, 6NP+7 = right-hand-side slot), rounded up to 16
 };
 __host__ __device__ inline int off_pose(int i) { return 16 * i; }
 __host__ __device__ inline int off_sb(int i) { return 16 * i + 7; }
@@ -508,17 +510,17 @@ __device__ __forceinline__ int fblock_of(int id, int NP) {
 __host__ __device__ inline int lsize_kind(int kind) { return (kind == 0 || kind == 2 || kind == 3) ? 6 : kind == 1 ? 9 : 1; }
 __host__ __device__ inline int gsize_kind(int kind) { return (kind == 0 || kind == 2 || kind == 3) ? 7 : kind == 1 ? 9 : 1; }
 
-// grid (B), 256 threads: wavefront t handles IMU / wheel factors round-robin; afterwards the whole block adds the prior.
+// grid (2W + 1, B), 256 threads: block t < W evaluates IMU factor t (wavefront 0), W <= t < 2W wheel factor t - W, block 2W adds the prior.
 // frame_filter: 0 all factors; 1 only IMU/wheel factors starting at frame 0 (MARGIN_OLD); 2 no IMU/wheel factor (MARGIN_SECOND_NEW)
 __global__ void __launch_bounds__(256) ba_linearize_misc(Win w, int which, int which_state, int cost_only, int only_cand_valid, int frame_filter) {
-    __shared__ double sJ[4][450];
-    __shared__ double sSJ[4][450];
-    __shared__ double sr[4][32];
-    __shared__ int scol[4][32];
+    __shared__ double sJ[450];
+    __shared__ double sSJ[450];
+    __shared__ double sr[32];
+    __shared__ int scol[32];
     __shared__ double sdx[512];
     __shared__ double sred[256];
     const Dims d = w.d;
-    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.y, task = blockIdx.x, lane = threadIdx.x & 63;
     const SolverState& st = w.st[b];
     if (st.done && only_cand_valid != 2) return;
     if (only_cand_valid == 1 && !st.cand_valid) return;
@@ -528,75 +530,73 @@ __global__ void __launch_bounds__(256) ba_linearize_misc(Win w, int which, int w
     const int* colf = w.colf + (size_t)b * d.NFB;
     double* H = w.H + ((size_t)which * d.B + b) * d.RP * d.RP;
     double* g = w.g + ((size_t)which * d.B + b) * d.RP;
-    double cost_acc = 0.0;
     const int nimu = w.nimu[b], nwh = w.nwh[b];
-    for (int t = wave; t < nimu + nwh; t += 4) {
+    if (task < 2 * d.W) {
+        if (threadIdx.x >= 64) return;   // one wavefront per factor
+        const bool is_imu = task < d.W;
+        const int k = is_imu ? task : task - d.W;
+        if (k >= (is_imu ? nimu : nwh) || frame_filter == 2) return;
+        const int i = is_imu ? w.imu_i[(size_t)b * d.W + k] : w.wh_i[(size_t)b * d.W + k], j = i + 1;
+        if (frame_filter == 1 && i != 0) return;
         int nres, ncol;
         const double* S;
-        if (frame_filter == 2) continue;
-        if (frame_filter == 1 && (t < nimu ? w.imu_i[(size_t)b * d.W + t] : w.wh_i[(size_t)b * d.W + t - nimu]) != 0) continue;
-        if (t < nimu) {
-            const int i = w.imu_i[(size_t)b * d.W + t], j = i + 1;
-            imu_raw(xs + off_pose(i), xs + off_sb(i), xs + off_pose(j), xs + off_sb(j), w.imu_data + ((size_t)b * d.W + t) * IMU_STRIDE2, w.G, sr[wave] + 16,
-                    sJ[wave], !cost_only, lane);
-            nres = 15; ncol = 30; S = w.imu_sqrt + ((size_t)b * d.W + t) * 225;
+        if (is_imu) {
+            imu_raw(xs + off_pose(i), xs + off_sb(i), xs + off_pose(j), xs + off_sb(j), w.imu_data + ((size_t)b * d.W + k) * IMU_STRIDE2, w.G, sr + 16, sJ, !cost_only, lane);
+            nres = 15; ncol = 30; S = w.imu_sqrt + ((size_t)b * d.W + k) * 225;
             if (lane < 30) {
                 const int blk = lane < 6 ? fb_pose(i) : lane < 15 ? fb_sb(i) : lane < 21 ? fb_pose(j) : fb_sb(j);
                 const int o = lane < 6 ? lane : lane < 15 ? lane - 6 : lane < 21 ? lane - 15 : lane - 21;
-                scol[wave][lane] = colf[blk] >= 0 ? colf[blk] + o : -1;
+                scol[lane] = colf[blk] >= 0 ? colf[blk] + o : -1;
             }
         } else {
-            const int k = t - nimu;
-            const int i = w.wh_i[(size_t)b * d.W + k], j = i + 1;
             wheel_raw(xs + off_pose(i), xs + off_pose(j), xs + off_exw(d.NP), xs[off_ix(d.NP)], xs[off_ix(d.NP) + 1], xs[off_ix(d.NP) + 2], xs[off_tdw(d.NP)],
-                      w.wh_data + ((size_t)b * d.W + k) * WH_STRIDE, sr[wave] + 16, sJ[wave], !cost_only, lane);
+                      w.wh_data + ((size_t)b * d.W + k) * WH_STRIDE, sr + 16, sJ, !cost_only, lane);
             nres = 6; ncol = 22; S = w.wh_sqrt + ((size_t)b * d.W + k) * 36;
             if (lane < 22) {
                 const int blk = lane < 6 ? fb_pose(i) : lane < 12 ? fb_pose(j) : lane < 18 ? fb_exw(d.NP) : lane < 21 ? fb_sx(d.NP) + (lane - 18) : fb_tdw(d.NP);
                 const int o = lane < 6 ? lane : lane < 12 ? lane - 6 : lane < 18 ? lane - 12 : 0;
-                scol[wave][lane] = colf[blk] >= 0 ? colf[blk] + o : -1;
+                scol[lane] = colf[blk] >= 0 ? colf[blk] + o : -1;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-        // whitened residual
-        if (lane < nres) { double s = 0; for (int k2 = 0; k2 < nres; k2++) s += S[lane * nres + k2] * sr[wave][16 + k2]; sr[wave][lane] = s; }
+        if (lane < nres) { double sv = 0; for (int k2 = 0; k2 < nres; k2++) sv += S[lane * nres + k2] * sr[16 + k2]; sr[lane] = sv; }   // whitened residual
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-        double c = 0;
-        if (lane < nres) c = 0.5 * sr[wave][lane] * sr[wave][lane];
-        cost_acc += wave_sum_f64(c);
-        if (cost_only) continue;
+        double c = lane < nres ? 0.5 * sr[lane] * sr[lane] : 0.0;
+        c = wave_sum_f64(c);
+        if (lane == 0) atomicAdd(w.cost + (size_t)which * d.B + b, c);
+        if (cost_only) return;
         for (int e = lane; e < nres * ncol; e += 64) {
             const int r = e / ncol, cc = e % ncol;
-            double s = 0;
-            for (int k2 = r; k2 < nres; k2++) s += S[r * nres + k2] * sJ[wave][k2 * ncol + cc];  // S is upper triangular
-            sSJ[wave][e] = s;
+            double sv = 0;
+            for (int k2 = r; k2 < nres; k2++) sv += S[r * nres + k2] * sJ[k2 * ncol + cc];  // S is upper triangular
+            sSJ[e] = sv;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
         for (int e = lane; e < ncol * ncol; e += 64) {
             const int a = e / ncol, c2 = e % ncol;
-            const int ca = scol[wave][a], cb = scol[wave][c2];
+            const int ca = scol[a], cb = scol[c2];
             if (ca < 0 || cb < 0) continue;
-            double s = 0;
-            for (int r = 0; r < nres; r++) s += sSJ[wave][r * ncol + a] * sSJ[wave][r * ncol + c2];
-            if (s != 0.0) atomicAdd(H + (size_t)ca * d.RP + cb, s);
+            double sv = 0;
+            for (int r = 0; r < nres; r++) sv += sSJ[r * ncol + a] * sSJ[r * ncol + c2];
+            if (sv != 0.0) atomicAdd(H + (size_t)ca * d.RP + cb, sv);
         }
-        if (lane < ncol && scol[wave][lane] >= 0) {
-            double s = 0;
-            for (int r = 0; r < nres; r++) s += sSJ[wave][r * ncol + lane] * sr[wave][r];
-            atomicAdd(g + scol[wave][lane], s);
+        if (lane < ncol && scol[lane] >= 0) {
+            double sv = 0;
+            for (int r = 0; r < nres; r++) sv += sSJ[r * ncol + lane] * sr[r];
+            atomicAdd(g + scol[lane], sv);
         }
-        __builtin_amdgcn_wave_barrier();
+        return;
     }
     // ---- prior: r = r0 + J0 dx  =>  cost = 1/2 (c0 + 2 b0.dx + dx^T A dx), g += b0 + A dx, H += A   (marginalization_factor.cpp:344-392)
-    __syncthreads();
     const int n = w.pri_n[b];
+    if (n <= 0) return;
     double pc = 0.0;
-    if (n > 0) {
+    {
         const int nb = w.pri_nb[b];
         const int* bid = w.pri_bid + (size_t)b * 64;
         const double* x0 = w.pri_x0 + (size_t)b * d.NPRI * 2;
         // sdx[0..n) = dx, sdx[256..256+n) = column map
-        if (threadIdx.x < nb) {
+        if ((int)threadIdx.x < nb) {
             int idx = 0, o0 = 0;
             for (int q = 0; q < (int)threadIdx.x; q++) { idx += lsize_kind(bid[q] / 4096); o0 += gsize_kind(bid[q] / 4096); }
             const int id = bid[threadIdx.x], kind = id / 4096;
@@ -623,15 +623,21 @@ __global__ void __launch_bounds__(256) ba_linearize_misc(Win w, int which, int w
             }
         if (threadIdx.x == 0) pc += 0.5 * w.pri_c[b];
     }
-    sred[threadIdx.x] = pc + (lane == 0 ? cost_acc : 0.0);
+    sred[threadIdx.x] = pc;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sred[threadIdx.x] += sred[threadIdx.x + s]; __syncthreads(); }
+    for (int sft = 128; sft > 0; sft >>= 1) { if ((int)threadIdx.x < sft) sred[threadIdx.x] += sred[threadIdx.x + sft]; __syncthreads(); }
     if (threadIdx.x == 0) atomicAdd(w.cost + (size_t)which * d.B + b, sred[0]);
 }
 
 }  // namespace gfb
 
 namespace gfb {
+
+#ifdef GF_PROFILE_STEP
+#define GF_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && sb.stamps) sb.stamps[i] = clock64(); } while (0)
+#else
+#define GF_STAMP(i) do { } while (0)
+#endif
 
 struct StepBufs {  // per-window global scratch of ba_step
     double* scale;  // [B][VS] Jacobi column scaling 1/(1+|J_c|)        (VS = RP + FP: reduced columns, then eliminated columns)
@@ -646,49 +652,90 @@ struct StepBufs {  // per-window global scratch of ba_step
     double* etb;    // [B][FP]
     double* rhs;    // [B][RP]
     double* yv;     // [B][VS]
+    long long* stamps;  // optional phase timestamps of window 0 (builds with -DGF_PROFILE_STEP)
     int VS;
 };
 
 __device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }  // packed lower, i >= j
 
-__device__ __forceinline__ double block_sum(double v, double* sred, int tid, int nthreads) {
+// 512-thread block reductions through wavefront shuffles + 8 LDS partials (sred >= 64 doubles)
+template <int NV_>
+__device__ __forceinline__ void block_sum_n(double (&v)[NV_], double* sred, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int q = 0; q < NV_; q++) v[q] = wave_sum_f64(v[q]);
     __syncthreads();
-    sred[tid] = v;
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NV_; q++) sred[wave * NV_ + q] = v[q];
+    }
     __syncthreads();
-    for (int s = nthreads / 2; s > 0; s >>= 1) { if (tid < s) sred[tid] += sred[tid + s]; __syncthreads(); }
-    const double r = sred[0];
-    __syncthreads();
-    return r;
+#pragma unroll
+    for (int q = 0; q < NV_; q++) { double t = 0; for (int w8 = 0; w8 < 8; w8++) t += sred[w8 * NV_ + q]; v[q] = t; }
 }
+__device__ __forceinline__ double block_sum(double v, double* sred, int tid, int nthreads) { double a[1] = {v}; block_sum_n(a, sred, tid); return a[0]; }
 __device__ __forceinline__ double block_max(double v, double* sred, int tid, int nthreads) {
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
     __syncthreads();
-    sred[tid] = v;
+    if (lane == 0) sred[wave] = v;
     __syncthreads();
-    for (int s = nthreads / 2; s > 0; s >>= 1) { if (tid < s) sred[tid] = fmax(sred[tid], sred[tid + s]); __syncthreads(); }
-    const double r = sred[0];
-    __syncthreads();
-    return r;
+    double t = sred[0];
+    for (int w8 = 1; w8 < 8; w8++) t = fmax(t, sred[w8]);
+    return t;
 }
 
-// u^T H u over reduced + eliminated columns: u_f^T Hff u_f + 2 u_e . (Et u_f) + sum ete u_e^2, and u^T g
-__device__ inline void quad_form(const double* H, const double* g, const double* Et, const double* ete, const double* etb, const double* u, int R, int NE, int RP,
-                                 double* sred, int tid, double& uHu, double& ug) {
+// u^T H u over reduced + eliminated columns: u_f^T Hff u_f + 2 u_e . (Et uc) + sum ete u_e^2, and u^T g.  Rows are streamed by wavefronts
+// (coalesced, four rows in flight), every lane keeps private partial sums, one block reduction at the end.  uc: u gathered to the compact
+// column layout of Et (LDS).
+__device__ __forceinline__ int tri_row(int t) {  // largest i with i(i+1)/2 <= t
+    int i = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while (i * (i + 1) / 2 > t) i--;
+    while ((i + 1) * (i + 2) / 2 <= t) i++;
+    return i;
+}
+__device__ inline void quad_form(const double* H, const double* g, const double* Et, const double* ete, const double* etb, const double* u, const double* uc, int R,
+                                 int NE, int RP, int ECW, double* sred, int tid, double& uHu, double& ug) {
+    const int wave = tid >> 6, lane = tid & 63;
     double a = 0, c = 0;
-    for (int r = tid; r < R; r += 512) {
-        double s = 0;
-        const double* row = H + (size_t)r * RP;
-        for (int k = 0; k < R; k++) s += row[k] * u[k];
-        a += u[r] * s; c += u[r] * g[r];
+    double uk[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) uk[q] = (lane + 64 * q) < R ? u[lane + 64 * q] : 0.0;   // R <= 192
+    for (int r0 = wave; r0 < R; r0 += 32) {
+        double sv[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int r = r0 + 8 * m;
+            sv[m] = 0;
+            if (r < R) {
+                const double* row = H + (size_t)r * RP;
+#pragma unroll
+                for (int q = 0; q < 3; q++) if (lane + 64 * q < R) sv[m] += row[lane + 64 * q] * uk[q];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) if (r0 + 8 * m < R) a += u[r0 + 8 * m] * sv[m];
     }
-    for (int e = tid; e < NE; e += 512) {
-        double s = 0;
-        const double* row = Et + (size_t)e * RP;
-        for (int k = 0; k < R; k++) s += row[k] * u[k];
-        const double ue = u[RP + e];
-        a += 2.0 * ue * s + ete[e] * ue * ue; c += ue * etb[e];
+    const double ucl0 = lane < ECW ? uc[lane] : 0.0, ucl1 = (lane + 64) < ECW ? uc[lane + 64] : 0.0;   // ECW <= 128
+    for (int e0 = wave; e0 < NE; e0 += 32) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int e = e0 + 8 * m;
+            if (e < NE) {
+                const double* row = Et + (size_t)e * ECW;
+                double sv = 0;
+                if (lane < ECW) sv += row[lane] * ucl0;
+                if (lane + 64 < ECW) sv += row[lane + 64] * ucl1;
+                a += 2.0 * u[RP + e] * sv;
+            }
+        }
     }
-    uHu = block_sum(a, sred, tid, 512);
-    ug = block_sum(c, sred, tid, 512);
+    for (int r = tid; r < R; r += 512) c += u[r] * g[r];
+    for (int e = tid; e < NE; e += 512) { const double ue = u[RP + e]; a += ete[e] * ue * ue; c += ue * etb[e]; }
+    double v2[2] = {a, c};
+    block_sum_n(v2, sred, tid);
+    uHu = v2[0]; ug = v2[1];
 }
 
 // PoseLocalParameterization::Plus (pose_local_parameterization.cpp:12-28)
@@ -698,31 +745,131 @@ __device__ __forceinline__ void pose_plus(const double* x, const double* dl, dou
     out[3] = q.x; out[4] = q.y; out[5] = q.z; out[6] = q.w;
 }
 
+// Compact rows of E^T F, ete, etb of the eliminated (free inverse-depth) columns: grid (F, B), one wavefront per feature.
+// Every factor of a feature shares its pose_i / ex / td entries (register sums); its pose_j entries are unique (direct stores).
+__global__ void __launch_bounds__(64) ba_build_et(Win w, StepBufs sb, int which, int ignore_done) {
+    const Dims d = w.d;
+    const int b = blockIdx.y, f = blockIdx.x, lane = threadIdx.x;
+    const SolverState& st = w.st[b];
+    if (st.done && !ignore_done) return;
+    if (!ignore_done && which < 0 && !st.cand_valid) return;
+    if (f >= w.nfeat[b]) return;
+    const int e = w.cole[(size_t)b * d.F + f];
+    if (e < 0) return;
+    if (which < 0) which = 1 - st.cur;
+    const double* efac = w.efac + ((size_t)which * d.B + b) * d.NV * EF;
+    double* Et = sb.Et + (((size_t)which * d.B + b) * d.FP + e) * d.ECW;
+    for (int c = lane; c < d.ECW; c += 64) Et[c] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    const int p0 = w.feat_ptr[(size_t)b * (d.F + 1) + f], p1 = w.feat_ptr[(size_t)b * (d.F + 1) + f + 1];
+    double acc = 0;
+    int fi = 0;
+    for (int p = p0; p < p1; p++) {
+        const int k = w.feat_fac[(size_t)b * d.NV + p];
+        const double* ef = efac + (size_t)k * EF;
+        const size_t kk = (size_t)b * d.NV + k;
+        fi = w.vis_i[kk];
+        if (lane < 6 || (lane >= 12 && lane < 21)) acc += ef[lane];
+        else if (lane < 12) Et[6 * w.vis_j[kk] + lane - 6] = ef[lane];
+    }
+    if (lane < 6) Et[6 * fi + lane] = acc;
+    else if (lane == 12) Et[6 * d.NP + 6] = acc;                    // td
+    else if (lane >= 13 && lane < 19) Et[6 * d.NP + lane - 13] = acc;  // ex_pose
+    else if (lane == 19) sb.ete[((size_t)which * d.B + b) * d.FP + e] = acc;
+    else if (lane == 20) sb.etb[((size_t)which * d.B + b) * d.FP + e] = acc;
+}
+// reduced column of compact column k (or -1); the right-hand-side slot maps to `rhs_col`
+__device__ __forceinline__ int compact_to_col(int k, const int* colf, int NP, int rhs_col) {
+    if (k < 6 * NP) { const int c0 = colf[fb_pose(k / 6)]; return c0 >= 0 ? c0 + k % 6 : -1; }
+    if (k < 6 * NP + 6) { const int c0 = colf[fb_ex(NP)]; return c0 >= 0 ? c0 + k - 6 * NP : -1; }
+    if (k == 6 * NP + 6) return colf[fb_td(NP)];
+    if (k == 6 * NP + 7) return rhs_col;
+    return -1;
+}
+
+// In-register Cholesky of a 16x16 SPD block by 16 lanes (lane r holds row r), followed by the explicit inverse of the factor.
+// s_L / s_inv: 16 x 17 LDS tiles.  Returns false if a pivot is not positive.  All 64 lanes of the wavefront must call it.
+__device__ __forceinline__ double bcast_lane(double v, int srclane) {  // srclane must be wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane), hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline bool wave_chol16_inv(double* s_L, double* s_inv, double* s_rdiag, int lane) {
+    const int r = lane & 15;   // the four 16-lane groups work redundantly on identical data, so lane j of the wavefront speaks for row j
+    double a[16], rd[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) a[c] = s_L[r * 17 + c];
+    bool good = true;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const double piv = bcast_lane(a[j], j);
+        if (!(piv > 0.0)) good = false;
+        double rs = __builtin_amdgcn_rsq(piv);          // ~2^-26 seed, two Newton steps
+        rs = rs * (1.5 - 0.5 * piv * rs * rs);
+        rs = rs * (1.5 - 0.5 * piv * rs * rs);
+        rd[j] = rs;                                         // 1 / L_jj
+        const double l = (r == j) ? piv * rs : a[j] * rs;   // L_rj (rows r >= j)
+        a[j] = l;
+#pragma unroll
+        for (int c = j + 1; c < 16; c++) a[c] -= l * bcast_lane(l, c);   // L_rj * L_cj
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) s_L[r * 17 + c] = (c <= r) ? a[c] : 0.0;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) s_rdiag[c] = rd[c];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    // inverse: lane j solves L x = e_j (column j of L^-1); L is read as LDS broadcasts
+    {
+        const int j = r;
+        double x[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            double sv = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < i; k++) sv -= s_L[i * 17 + k] * x[k];
+            x[i] = sv * rd[i];
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) s_inv[i * 17 + j] = x[i];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    return good;
+}
+
 // One 512-thread block per window: accept/reject of the previous candidate (trust_region_minimizer.cc), then the next
 // dogleg step (dogleg_strategy.cc): Jacobi scaling, Cauchy point, Gauss-Newton step through the Schur complement
 // (MFMA GEMM) and an LDS-resident blocked Cholesky, candidate point.  first: the call that follows the initial linearisation.
 __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, int max_iters, int finalize_only) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double sred[512];
-    __shared__ double s_blk[16 * 17];
+    __shared__ double s_blk[16 * 17], s_inv[16 * 17];
     __shared__ double s_y[16];
     __shared__ int s_flag[4];
+    __shared__ int s_cmap[128];      // compact column -> reduced column (or -1), right-hand-side slot -> R
+    __shared__ double s_uc[128];     // a vector gathered to the compact layout
+    __shared__ double s_rd[208];     // reciprocals of the Cholesky diagonal
     const Dims d = w.d;
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     SolverState& st = w.st[b];
     if (st.done) return;
-    const int R = st.R, NE = st.NE, RP = d.RP, VS = sb.VS;
-    double* S = smem;  // packed lower R(R+1)/2
+    const int R = st.R, NE = st.NE, RP = d.RP, VS = sb.VS, ECW = d.ECW;
+    double* S = smem;  // packed lower (R+1)(R+2)/2: row R carries the right-hand side
     const int* colf = w.colf + (size_t)b * d.NFB;
     const int* cole = w.cole + (size_t)b * d.F;
     double* scale = sb.scale + (size_t)b * VS; double* diag = sb.diag + (size_t)b * VS; double* grad = sb.grad + (size_t)b * VS;
     double* gn = sb.gn + (size_t)b * VS; double* stepv = sb.step + (size_t)b * VS; double* u = sb.u + (size_t)b * VS; double* yv = sb.yv + (size_t)b * VS;
-    double* Et = sb.Et + (size_t)b * d.FP * RP; double* Es = sb.Es + (size_t)b * d.FP * RP;
-    double* ete = sb.ete + (size_t)b * d.FP; double* etb = sb.etb + (size_t)b * d.FP; double* rhs = sb.rhs + (size_t)b * RP;
-
+    double* Es = sb.Es + (size_t)b * d.FP * ECW;
+    double* rhs = sb.rhs + (size_t)b * RP;
+    if (tid < ECW) s_cmap[tid] = compact_to_col(tid, colf, d.NP, R);
+    GF_STAMP(0);
     // ---------------- accept / reject the candidate of the previous iteration
     if (tid == 0) {
-        s_flag[0] = 0;  // accepted now
+        s_flag[0] = 0;
         if (first) {
             st.x_cost = w.cost[(size_t)st.cur * d.B + b];
             st.initial_cost = st.x_cost;
@@ -749,35 +896,12 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
     const int cur = st.cur;
     double* H = w.H + ((size_t)cur * d.B + b) * RP * RP;
     double* g = w.g + ((size_t)cur * d.B + b) * RP;
-    const double* efac = w.efac + ((size_t)cur * d.B + b) * d.NV * EF;
     const double* xs = w.xs + ((size_t)cur * d.B + b) * d.XS;
-
+    const double* Et = sb.Et + ((size_t)cur * d.B + b) * d.FP * ECW;
+    const double* ete = sb.ete + ((size_t)cur * d.B + b) * d.FP;
+    const double* etb = sb.etb + ((size_t)cur * d.B + b) * d.FP;
+    GF_STAMP(1);
     if (!st.reuse) {
-        // ---------------- eliminated columns: ete, etb and the rows of E^T F (per free feature, over its factors)
-        for (int i = tid; i < NE * RP; i += 512) Et[i] = 0.0;
-        __syncthreads();
-        const int nf = w.nfeat[b];
-        for (int f = wave; f < nf; f += 8) {
-            const int e = cole[f];
-            if (e < 0) continue;
-            const int p0 = w.feat_ptr[(size_t)b * (d.F + 1) + f], p1 = w.feat_ptr[(size_t)b * (d.F + 1) + f + 1];
-            double a = 0, c = 0;
-            for (int p = p0; p < p1; p++) {
-                const int k = w.feat_fac[(size_t)b * d.NV + p];
-                const double* ef = efac + (size_t)k * EF;
-                if (lane == 0) { a += ef[19]; c += ef[20]; }
-                if (lane < 19) {
-                    const size_t kk = (size_t)b * d.NV + k;
-                    const int fi = w.vis_i[kk], fj = w.vis_j[kk];
-                    const int blk = lane < 6 ? fb_pose(fi) : lane < 12 ? fb_pose(fj) : lane == 12 ? fb_td(d.NP) : fb_ex(d.NP);
-                    const int o = lane < 6 ? lane : lane < 12 ? lane - 6 : lane == 12 ? 0 : lane - 13;
-                    const int c0 = colf[blk];
-                    if (c0 >= 0) Et[(size_t)e * RP + c0 + o] += ef[lane];
-                }
-            }
-            if (lane == 0) { ete[e] = a; etb[e] = c; }
-        }
-        __syncthreads();
         // ---------------- Jacobi scaling from the initial Jacobian (trust_region_minimizer.cc: jacobian_scaling_)
         if (!st.have_scale) {
             for (int c = tid; c < R; c += 512) scale[c] = 1.0 / (1.0 + sqrt(H[(size_t)c * RP + c]));
@@ -792,6 +916,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
         gm = block_max(gm, sred, tid, 512);
         if (tid == 0) st.gmax = gm;
     }
+    GF_STAMP(2);
     // ---------------- FinalizeIterationAndCheckIfMinimizerCanContinue
     if (tid == 0) {
         if (st.iterations >= max_iters) { st.done = 1; st.termination = 0; }
@@ -800,9 +925,11 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
         else st.iterations++;
     }
     __syncthreads();
+    GF_STAMP(3);
     if (st.done || finalize_only) return;
 
     if (!st.reuse) {
+        GF_STAMP(4);
         // ---------------- dogleg diagonal, scaled gradient, Cauchy point
         for (int c = tid; c < R; c += 512) {
             const double dd = sqrt(fmin(fmax(scale[c] * scale[c] * H[(size_t)c * RP + c], 1e-6), 1e32));
@@ -814,168 +941,190 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
             diag[RP + e] = dd; grad[RP + e] = sc * etb[e] / dd; u[RP + e] = sc * (grad[RP + e] / dd);
         }
         __syncthreads();
+        if (tid < ECW) { const int c = s_cmap[tid]; s_uc[tid] = (c >= 0 && c < R) ? u[c] : 0.0; }
         double gsq = 0;
         for (int c = tid; c < R; c += 512) gsq += grad[c] * grad[c];
         for (int e = tid; e < NE; e += 512) gsq += grad[RP + e] * grad[RP + e];
         gsq = block_sum(gsq, sred, tid, 512);
         double uHu, ug;
-        quad_form(H, g, Et, ete, etb, u, R, NE, RP, sred, tid, uHu, ug);
+        quad_form(H, g, Et, ete, etb, u, s_uc, R, NE, RP, ECW, sred, tid, uHu, ug);
         if (tid == 0) st.alpha = gsq / uHu;
         // ---------------- Gauss-Newton step: (J^T J + mu D^2) y = J^T r through the Schur complement, retry with larger mu on failure
         bool ok = false;
         while (!ok) {
             const double mu = st.mu;
             if (!(mu < 1.0)) break;
-            // eliminated columns
+            GF_STAMP(5);
+            // eliminated columns: ete~ = s_e^2 ete + mu D_e^2 (kept in yv's tail), row factor f_e = s_e / sqrt(ete~) (in u's tail)
             for (int e = tid; e < NE; e += 512) {
                 const double sc = scale[RP + e], lm = diag[RP + e] * sqrt(mu);
-                yv[RP + e] = sc * sc * ete[e] + lm * lm;  // ete~ (kept in yv's tail until back-substitution)
+                const double et = sc * sc * ete[e] + lm * lm;
+                yv[RP + e] = et; u[RP + e] = sc / sqrt(et);
             }
             __syncthreads();
-            for (int i = tid; i < NE * RP; i += 512) {
-                const int e = i / RP, c = i - e * RP;
-                Es[i] = c < R ? scale[RP + e] * scale[c] * Et[i] / sqrt(yv[RP + e]) : 0.0;
+            // compact Es[e][k] = f_e s_c Et[e][k] (c = reduced column of k); the right-hand-side slot carries etb~ / sqrt(ete~) so that the
+            // GEMM also reduces the right-hand side
+            const int NE4 = (NE + 3) & ~3;
+            for (int i = tid; i < NE4 * ECW; i += 512) {
+                const int e = i / ECW, k = i - e * ECW;
+                double v = 0.0;
+                if (e < NE) { const int c = s_cmap[k]; if (c >= 0 && c < R) v = u[RP + e] * scale[c] * Et[i]; else if (c == R) v = u[RP + e] * etb[e]; }
+                Es[i] = v;
             }
-            for (int i = NE * RP + tid; i < ((NE + 3) & ~3) * RP; i += 512) Es[i] = 0.0;
-            // reduced system: S = s H s + mu D^2 (packed lower in LDS), rhs = s g - sum_e (E~ row) etb~ / sqrt(ete~)
-            for (int i = tid; i < R * (R + 1) / 2; i += 512) {
-                int r = (int)((sqrt(8.0 * i + 1.0) - 1.0) * 0.5);
-                while (pk(r + 1, 0) <= i) r++;
-                while (pk(r, 0) > i) r--;
-                const int c = i - pk(r, 0);
-                double v = scale[r] * scale[c] * H[(size_t)r * RP + c];
-                if (r == c) { const double lm = diag[r] * sqrt(mu); v += lm * lm; }
-                S[i] = v;
+            GF_STAMP(6);
+            // reduced system in LDS (packed lower): S = s H s + mu D^2, row R = s g
+            for (int r = wave; r <= R; r += 8) {
+                const int base = pk(r, 0);
+                if (r < R) {
+                    const double sr = scale[r];
+                    const double* hr = H + (size_t)r * RP;
+                    for (int c = lane; c <= r; c += 64) {
+                        double v = sr * scale[c] * hr[c];
+                        if (c == r) { const double lm = diag[r] * sqrt(mu); v += lm * lm; }
+                        S[base + c] = v;
+                    }
+                } else for (int c = lane; c < R; c += 64) S[base + c] = scale[c] * g[c];
             }
             __syncthreads();
-            for (int c = tid; c < R; c += 512) {
-                double v = scale[c] * g[c];
-                for (int e = 0; e < NE; e++) v -= Es[(size_t)e * RP + c] * (scale[RP + e] * etb[e] / sqrt(yv[RP + e]));
-                rhs[c] = v;
-            }
-            // S -= Es^T Es on the matrix cores: 16x16 tiles of the lower triangle, K = eliminated columns (4 per instruction)
+            GF_STAMP(7);
+            // S -= Es^T Es on the matrix cores over the COMPACT columns (poses, ex, td, rhs slot; speed-bias / wheel columns are structurally
+            // zero): 16x16 tiles of the compact lower triangle, K = eliminated columns (4 per MFMA), scattered into the packed S.
             {
-                const int nt = (R + 15) / 16, ntiles = nt * (nt + 1) / 2, nk = (NE + 3) / 4;
+                const int nt = ECW / 16, ntiles = nt * (nt + 1) / 2, nk = NE4 / 4;
                 for (int t = wave; t < ntiles; t += 8) {
-                    int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-                    while (ti * (ti + 1) / 2 > t) ti--;
-                    while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
-                    const int tk = t - ti * (ti + 1) / 2;
+                    const int ti = tri_row(t), tk = t - ti * (ti + 1) / 2;
+                    const double* pa = Es + (size_t)(lane >> 4) * ECW + 16 * ti + (lane & 15);
+                    const double* pb = Es + (size_t)(lane >> 4) * ECW + 16 * tk + (lane & 15);
                     d4 acc = {0, 0, 0, 0};
-                    const double* pa = Es + (size_t)(lane >> 4) * RP + 16 * ti + (lane & 15);
-                    const double* pb = Es + (size_t)(lane >> 4) * RP + 16 * tk + (lane & 15);
-                    for (int k = 0; k < nk; k++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(size_t)4 * k * RP], pb[(size_t)4 * k * RP], acc, 0, 0, 0);
+                    int k = 0;
+                    for (; k + 8 <= nk; k += 8) {
+                        double av[8], bv2[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) { av[q] = pa[(size_t)4 * (k + q) * ECW]; bv2[q] = pb[(size_t)4 * (k + q) * ECW]; }
+#pragma unroll
+                        for (int q = 0; q < 8; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv2[q], acc, 0, 0, 0);
+                    }
+                    for (; k < nk; k++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(size_t)4 * k * ECW], pb[(size_t)4 * k * ECW], acc, 0, 0, 0);
+                    const int col = s_cmap[16 * tk + (lane & 15)];
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tk + (lane & 15);
-                        if (row < R && col <= row) S[pk(row, col)] -= acc[r];
+                        const int row = s_cmap[16 * ti + (lane >> 4) + 4 * r];   // compact -> reduced is monotone: lower stays lower
+                        if (row >= 0 && col >= 0 && col <= row && col < R) S[pk(row, col)] -= acc[r];
                     }
                 }
             }
             __syncthreads();
-            // ---- blocked Cholesky of S in LDS (block 16): diagonal block by wavefront 0, panel by rows, trailing update on the matrix cores
+            GF_STAMP(8);
+            // ---- blocked Cholesky (block 16).  The right-hand side rides along as row R, so the panel multiply performs the forward
+            //      substitution.  Diagonal block: in-register factor + explicit inverse (wavefront 0); panel and trailing update: MFMA.
             if (tid == 0) s_flag[1] = 1;
             __syncthreads();
+#ifdef GF_PROFILE_STEP
+            long long tA = 0, tB = 0, tC = 0, t0c = clock64();
+#define GF_SUB(acc) do { const long long n_ = clock64(); acc += n_ - t0c; t0c = n_; } while (0)
+#else
+#define GF_SUB(acc) do { } while (0)
+#endif
             for (int j0 = 0; j0 < R; j0 += 16) {
                 const int nb = min(16, R - j0);
                 if (wave == 0) {
-                    for (int i = lane; i < nb * nb; i += 64) { const int r = i / nb, c = i % nb; if (c <= r) s_blk[r * 17 + c] = S[pk(j0 + r, j0 + c)]; }
+                    for (int i = lane; i < 256; i += 64) { const int r = i >> 4, c = i & 15; s_blk[r * 17 + c] = (r < nb && c < nb) ? S[pk(j0 + max(r, c), j0 + min(r, c))] : (r == c ? 1.0 : 0.0); }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                    for (int j = 0; j < nb; j++) {
-                        const double djj = s_blk[j * 17 + j];
-                        if (!(djj > 0.0)) { if (lane == 0) s_flag[1] = 0; break; }
-                        const double dd = sqrt(djj);
-                        __builtin_amdgcn_wave_barrier();
-                        if (lane == 0) s_blk[j * 17 + j] = dd;
-                        if (lane > j && lane < nb) s_blk[lane * 17 + j] /= dd;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                        for (int i = lane; i < nb * nb; i += 64) { const int r = i / nb, c = i % nb; if (c > j && c <= r) s_blk[r * 17 + c] -= s_blk[r * 17 + j] * s_blk[c * 17 + j]; }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                    }
+                    const bool good = wave_chol16_inv(s_blk, s_inv, s_rd + j0, lane);
+                    if (!good && lane == 0) s_flag[1] = 0;
                     for (int i = lane; i < nb * nb; i += 64) { const int r = i / nb, c = i % nb; if (c <= r) S[pk(j0 + r, j0 + c)] = s_blk[r * 17 + c]; }
                 }
                 __syncthreads();
+                GF_SUB(tA);
                 if (!s_flag[1]) break;
-                // panel: rows below the block, L21 = A21 L11^-T
-                for (int r = j0 + nb + tid; r < R; r += 512) {
-                    double x[16];
-                    for (int c = 0; c < nb; c++) {
-                        double s = S[pk(r, j0 + c)];
-                        for (int k = 0; k < c; k++) s -= x[k] * s_blk[c * 17 + k];
-                        x[c] = s / s_blk[c * 17 + c];
+                // panel: X = A21 L11^-T for the rows below the block and the rhs row; 16-row tiles, X[i][c] = sum_k A[i][k] Linv[c][k]
+                const int r0 = j0 + nb;
+                {
+                    const int nrows = R + 1 - r0, nt = (nrows + 15) / 16;
+                    for (int t = wave; t < nt; t += 8) {
+                        const int ra = r0 + 16 * t + (lane & 15);
+                        d4 acc = {0, 0, 0, 0};
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int kc = 4 * k + (lane >> 4);
+                            const double av = (ra <= R && kc < nb) ? S[pk(ra, j0 + kc)] : 0.0;
+                            const double bv2 = s_inv[(lane & 15) * 17 + kc];          // B[k][c] = Linv[c][k]
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv2, acc, 0, 0, 0);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int row = r0 + 16 * t + (lane >> 4) + 4 * r, c = lane & 15;
+                            if (row <= R && c < nb) S[pk(row, j0 + c)] = acc[r];
+                        }
                     }
-                    for (int c = 0; c < nb; c++) S[pk(r, j0 + c)] = x[c];
                 }
                 __syncthreads();
+                GF_SUB(tB);
                 // trailing update A22 -= L21 L21^T (lower tiles)
-                const int r0 = j0 + nb;
-                if (r0 < R) {
-                    const int nt = (R - r0 + 15) / 16, ntiles = nt * (nt + 1) / 2;
+                if (r0 <= R) {
+                    const int nrows = R + 1 - r0, nt = (nrows + 15) / 16, ntiles = nt * (nt + 1) / 2;
                     for (int t = wave; t < ntiles; t += 8) {
-                        int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-                        while (ti * (ti + 1) / 2 > t) ti--;
-                        while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
-                        const int tk = t - ti * (ti + 1) / 2;
+                        const int ti = tri_row(t), tk = t - ti * (ti + 1) / 2;
                         const int ra = r0 + 16 * ti + (lane & 15), rb = r0 + 16 * tk + (lane & 15);
+                        const int ba_ = ra <= R ? pk(ra, j0) : -1, bb_ = rb < R ? pk(rb, j0) : -1;   // row R (rhs) never acts as a column
                         d4 acc = {0, 0, 0, 0};
+#pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            const int c = j0 + 4 * k + (lane >> 4);
-                            const double a = (ra < R && c < j0 + nb) ? S[pk(ra, c)] : 0.0;
-                            const double bb = (rb < R && c < j0 + nb) ? S[pk(rb, c)] : 0.0;
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+                            const int c = 4 * k + (lane >> 4);
+                            const double av = (ba_ >= 0 && c < nb) ? S[ba_ + c] : 0.0;
+                            const double bv2 = (bb_ >= 0 && c < nb) ? S[bb_ + c] : 0.0;
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv2, acc, 0, 0, 0);
                         }
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             const int row = r0 + 16 * ti + (lane >> 4) + 4 * r, col = r0 + 16 * tk + (lane & 15);
-                            if (row < R && col <= row) S[pk(row, col)] -= acc[r];
+                            if (row <= R && col <= row && col < R) S[pk(row, col)] -= acc[r];
                         }
                     }
                 }
                 __syncthreads();
+                GF_SUB(tC);
             }
+#ifdef GF_PROFILE_STEP
+            if (blockIdx.x == 0 && tid == 0 && sb.stamps) { sb.stamps[20] = tA; sb.stamps[21] = tB; sb.stamps[22] = tC; }
+#endif
             ok = s_flag[1] != 0;
             if (ok) {
-                // forward substitution L z = rhs (blocks of 16), then backward L^T y = z
-                for (int j0 = 0; j0 < R; j0 += 16) {
-                    const int nb = min(16, R - j0);
-                    if (tid == 0) {
-                        for (int c = 0; c < nb; c++) {
-                            double s = rhs[j0 + c];
-                            for (int k = 0; k < c; k++) s -= S[pk(j0 + c, j0 + k)] * s_y[k];
-                            s_y[c] = s / S[pk(j0 + c, j0 + c)];
-                        }
-                        for (int c = 0; c < nb; c++) rhs[j0 + c] = s_y[c];
-                    }
-                    __syncthreads();
-                    for (int r = j0 + nb + tid; r < R; r += 512) { double s = rhs[r]; for (int c = 0; c < nb; c++) s -= S[pk(r, j0 + c)] * s_y[c]; rhs[r] = s; }
-                    __syncthreads();
-                }
+                GF_STAMP(9);
+                // backward substitution L^T y = z (z = row R), 16-column blocks from the bottom: in-block solve by wavefront 0
                 for (int j0 = ((R - 1) / 16) * 16; j0 >= 0; j0 -= 16) {
                     const int nb = min(16, R - j0);
-                    if (tid == 0) {
+                    if (wave == 0) {
+                        double z = lane < nb ? S[pk(R, j0 + lane)] : 0.0;
                         for (int c = nb - 1; c >= 0; c--) {
-                            double s = rhs[j0 + c];
-                            for (int k = c + 1; k < nb; k++) s -= S[pk(j0 + k, j0 + c)] * s_y[k];
-                            s_y[c] = s / S[pk(j0 + c, j0 + c)];
+                            const double yc = bcast_lane(z, c) * s_rd[j0 + c];
+                            if (lane == c) z = yc;
+                            else if (lane < c) z -= S[pk(j0 + c, j0 + lane)] * yc;
                         }
-                        for (int c = 0; c < nb; c++) rhs[j0 + c] = s_y[c];
+                        if (lane < nb) { s_y[lane] = z; yv[j0 + lane] = z; }
                     }
                     __syncthreads();
-                    for (int r = tid; r < j0; r += 512) { double s = rhs[r]; for (int c = 0; c < nb; c++) s -= S[pk(j0 + c, r)] * s_y[c]; rhs[r] = s; }
+                    for (int r = tid; r < j0; r += 512) {
+                        double sv = S[pk(R, r)];
+                        for (int c = 0; c < nb; c++) sv -= S[pk(j0 + c, r)] * s_y[c];
+                        S[pk(R, r)] = sv;
+                    }
                     __syncthreads();
                 }
-                // back-substitute the eliminated columns, check finiteness
+                GF_STAMP(10);
+                // back-substitute the eliminated columns (one wavefront per row), check finiteness
                 double bad = 0;
-                for (int c = tid; c < R; c += 512) { yv[c] = rhs[c]; if (!isfinite(rhs[c])) bad = 1; }
+                for (int c = tid; c < R; c += 512) if (!isfinite(yv[c])) bad = 1;
+                if (tid < ECW) { const int c = s_cmap[tid]; s_uc[tid] = (c >= 0 && c < R) ? yv[c] : 0.0; }
                 __syncthreads();
-                for (int e = tid; e < NE; e += 512) {
-                    const double et = yv[RP + e];
-                    double s = scale[RP + e] * etb[e];
+                for (int e = tid; e < NE; e += 512) {   // compact rows are short (ECW entries): one thread per eliminated column
+                    const double* row = Es + (size_t)e * ECW;
                     double acc = 0;
-                    for (int c = 0; c < R; c++) acc += Es[(size_t)e * RP + c] * yv[c];
-                    s -= acc * sqrt(et);
-                    const double ye = s / et;
-                    u[RP + e] = ye;  // stash
+                    for (int k = 0; k < ECW; k++) acc += row[k] * s_uc[k];
+                    const double et = yv[RP + e];
+                    const double ye = (scale[RP + e] * etb[e] - acc * sqrt(et)) / et;
+                    gn[RP + e] = -diag[RP + e] * ye;
                     if (!isfinite(ye)) bad = 1;
                 }
                 bad = block_max(bad, sred, tid, 512);
@@ -985,21 +1134,21 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
         }
         if (tid == 0) s_flag[2] = ok ? 1 : 0;
         __syncthreads();
-        if (ok) {
-            for (int c = tid; c < R; c += 512) gn[c] = -diag[c] * yv[c];
-            for (int e = tid; e < NE; e += 512) gn[RP + e] = -diag[RP + e] * u[RP + e];
-        }
+        if (ok) for (int c = tid; c < R; c += 512) gn[c] = -diag[c] * yv[c];
         __syncthreads();
         if (tid == 0) st.reuse = 1;
     } else if (tid == 0) s_flag[2] = 1;
     __syncthreads();
     bool valid = s_flag[2] != 0;
+    GF_STAMP(11);
     // ---------------- traditional dogleg interpolation (dogleg_strategy.cc ComputeTraditionalDoglegStep)
     if (valid) {
         double a = 0, c2 = 0, dt = 0;
         for (int c = tid; c < R; c += 512) { a += grad[c] * grad[c]; c2 += gn[c] * gn[c]; dt += grad[c] * gn[c]; }
         for (int e = tid; e < NE; e += 512) { a += grad[RP + e] * grad[RP + e]; c2 += gn[RP + e] * gn[RP + e]; dt += grad[RP + e] * gn[RP + e]; }
-        const double gnorm = sqrt(block_sum(a, sred, tid, 512)), gnn = sqrt(block_sum(c2, sred, tid, 512)), gdot = block_sum(dt, sred, tid, 512);
+        double v3[3] = {a, c2, dt};
+        block_sum_n(v3, sred, tid);
+        const double gnorm = sqrt(v3[0]), gnn = sqrt(v3[1]), gdot = v3[2];
         const double radius = st.radius, alpha = st.alpha;
         double ca, cb, dsn;  // step = ca * grad + cb * gn
         if (gnn <= radius) { ca = 0; cb = 1; dsn = gnn; }
@@ -1011,19 +1160,24 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
             ca = -alpha * (1.0 - beta); cb = beta; dsn = -1;
         }
         double nn = 0;
-        for (int c = tid; c < R; c += 512) { const double s = ca * grad[c] + cb * gn[c]; nn += s * s; stepv[c] = s / diag[c]; u[c] = scale[c] * stepv[c]; }
-        for (int e = tid; e < NE; e += 512) { const double s = ca * grad[RP + e] + cb * gn[RP + e]; nn += s * s; stepv[RP + e] = s / diag[RP + e]; u[RP + e] = scale[RP + e] * stepv[RP + e]; }
+        for (int c = tid; c < R; c += 512) { const double sv = ca * grad[c] + cb * gn[c]; nn += sv * sv; stepv[c] = sv / diag[c]; u[c] = scale[c] * stepv[c]; }
+        for (int e = tid; e < NE; e += 512) { const double sv = ca * grad[RP + e] + cb * gn[RP + e]; nn += sv * sv; stepv[RP + e] = sv / diag[RP + e]; u[RP + e] = scale[RP + e] * stepv[RP + e]; }
         nn = block_sum(nn, sred, tid, 512);
         if (dsn < 0) dsn = sqrt(nn);
         if (tid == 0) st.dogleg_step_norm = dsn;
+        GF_STAMP(12);
         // model_cost_change = -(J s)^T (r + J s / 2) = -(u^T g + u^T H u / 2), u = scale .* step (trust_region_minimizer.cc)
+        __syncthreads();
+        if (tid < ECW) { const int c = s_cmap[tid]; s_uc[tid] = (c >= 0 && c < R) ? u[c] : 0.0; }
+        __syncthreads();
         double uHu, ug;
-        quad_form(H, g, Et, ete, etb, u, R, NE, RP, sred, tid, uHu, ug);
+        quad_form(H, g, Et, ete, etb, u, s_uc, R, NE, RP, ECW, sred, tid, uHu, ug);
         const double mcc = -(ug + 0.5 * uHu);
         if (tid == 0) st.model_cost_change = mcc;
         valid = mcc > 0.0;
     }
     __syncthreads();
+    GF_STAMP(13);
     // ---------------- candidate point x (+) delta, delta = step .* scale = u ; zero the candidate's normal equations
     double* xc = w.xs + ((size_t)(1 - cur) * d.B + b) * d.XS;
     for (int i = tid; i < d.XS; i += 512) xc[i] = xs[i];
@@ -1056,8 +1210,8 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
             for (int q = 0; q < gs; q++) { const double dv = xs[off + q] - xc[off + q]; sn += dv * dv; xn += xs[off + q] * xs[off + q]; }
         }
     }
-    sn = block_sum(sn, sred, tid, 512);
-    xn = block_sum(xn, sred, tid, 512);
+    { double v2[2] = {sn, xn}; block_sum_n(v2, sred, tid); sn = v2[0]; xn = v2[1]; }
+    GF_STAMP(14);
     if (tid == 0) {
         st.step_norm = sqrt(sn); st.x_norm = sqrt(xn);
         st.cand_valid = valid ? 1 : 0;

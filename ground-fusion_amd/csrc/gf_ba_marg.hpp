@@ -28,57 +28,73 @@ __global__ void __launch_bounds__(256) ba_zero_other(Win w) {
     if (threadIdx.x == 0) w.cost[(size_t)o * d.B + b] = 0.0;
 }
 
-// cyclic Jacobi eigen-decomposition of the symmetric n x n matrix A (row-major, leading dim n) by a 512-thread block;
-// V (n x n) receives the eigenvectors in its columns, the eigenvalues end on A's diagonal.  Round-robin pair ordering.
+// Cyclic Jacobi eigen-decomposition of the symmetric n x n matrix A (row-major, leading dim n) by `nthreads` threads of one block
+// (nthreads == 64: a single wavefront, barriers degrade to wave barriers).  V (n x n) receives the eigenvectors in its columns, the
+// eigenvalues end on A's diagonal.  Round-robin pairing; every round applies A <- J^T A J on 2x2 blocks (pair k x pair k') in one
+// pass, so a round costs two barriers.
+template <bool WAVE>
+__device__ inline void jacobi_sync() {
+    if (WAVE) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+}
+template <bool WAVE>
 __device__ inline void block_jacobi_eig(double* A, double* V, int n, double* s_c, double* s_s, int* s_p, int* s_q, int* s_flag, int tid, int nthreads) {
     for (int i = tid; i < n * n; i += nthreads) V[i] = (i / n == i % n) ? 1.0 : 0.0;
     const int ne = (n + 1) & ~1, half = ne / 2;
-    __syncthreads();
+    double dmax = 0;   // rotations below machine precision of the largest diagonal are noise and are skipped (norm-relative criterion)
+    for (int i = 0; i < n; i++) dmax = fmax(dmax, fabs(A[i * n + i]));
+    const double skip = 1e-16 * dmax;
+    jacobi_sync<WAVE>();
     for (int sweep = 0; sweep < 30; sweep++) {
         if (tid == 0) *s_flag = 0;
-        __syncthreads();
+        jacobi_sync<WAVE>();
         for (int round = 0; round < ne - 1; round++) {
-            // pairing: positions 0..ne-1 on a ring, position 0 fixed
-            for (int k = tid; k < half; k += nthreads) {
-                int a = (k == 0) ? 0 : 1 + (k - 1 + round) % (ne - 1);
-                int bq = 1 + (ne - 1 - k - 1 + round) % (ne - 1);
+            for (int k = tid; k < half; k += nthreads) {  // pairing: positions on a ring, position 0 fixed
+                const int a = (k == 0) ? 0 : 1 + (k - 1 + round) % (ne - 1);
+                const int bq = 1 + (ne - 1 - k - 1 + round) % (ne - 1);
                 int p = min(a, bq), q = max(a, bq);
                 double c = 1.0, s = 0.0;
                 if (q < n) {
-                    const double apq = A[p * n + q];
-                    const double app = A[p * n + p], aqq = A[q * n + q];
-                    if (fabs(apq) > 1e-300 && fabs(apq) > 1e-17 * sqrt(fabs(app * aqq))) {
+                    const double apq = A[p * n + q], app = A[p * n + p], aqq = A[q * n + q];
+                    if (fabs(apq) > skip && fabs(apq) > 1e-15 * sqrt(fabs(app * aqq))) {
                         const double tau = (aqq - app) / (2.0 * apq);
                         const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
                         c = 1.0 / sqrt(1.0 + t * t); s = t * c;
                         *s_flag = 1;
                     }
-                } else { p = -1; }
+                } else { q = -1; }   // odd n: the unpaired index idles (identity rotation)
                 s_p[k] = p; s_q[k] = q; s_c[k] = c; s_s[k] = s;
             }
-            __syncthreads();
-            // rows: A <- J^T A
-            for (int e = tid; e < half * n; e += nthreads) {
-                const int k = e / n, j = e - k * n, p = s_p[k], q = s_q[k];
-                if (p < 0 || s_s[k] == 0.0) continue;
-                const double c = s_c[k], s = s_s[k], x = A[p * n + j], y = A[q * n + j];
-                A[p * n + j] = c * x - s * y; A[q * n + j] = s * x + c * y;
+            jacobi_sync<WAVE>();
+            // A <- J^T A J: block (k, k2) = rows {p,q} x cols {p2,q2}
+            for (int e = tid; e < half * half; e += nthreads) {
+                const int k = e / half, k2 = e - k * half;
+                const int p = s_p[k], q = s_q[k], p2 = s_p[k2], q2 = s_q[k2];
+                const double c = s_c[k], s = s_s[k], c2 = s_c[k2], s2 = s_s[k2];
+                if (s == 0.0 && s2 == 0.0) continue;
+                double a00 = A[p * n + p2], a01 = q2 >= 0 ? A[p * n + q2] : 0.0, a10 = q >= 0 ? A[q * n + p2] : 0.0, a11 = (q >= 0 && q2 >= 0) ? A[q * n + q2] : 0.0;
+                // left rotation (rows p,q): [r0; r1] = [c -s; s c] [a0; a1]
+                double b00 = c * a00 - s * a10, b01 = c * a01 - s * a11, b10 = s * a00 + c * a10, b11 = s * a01 + c * a11;
+                // right rotation (cols p2,q2): [x y] <- [x y] [c2 s2; -s2 c2]
+                a00 = c2 * b00 - s2 * b01; a01 = s2 * b00 + c2 * b01; a10 = c2 * b10 - s2 * b11; a11 = s2 * b10 + c2 * b11;
+                A[p * n + p2] = a00;
+                if (q2 >= 0) A[p * n + q2] = a01;
+                if (q >= 0) A[q * n + p2] = a10;
+                if (q >= 0 && q2 >= 0) A[q * n + q2] = a11;
             }
-            __syncthreads();
-            // columns: A <- A J, V <- V J
-            for (int e = tid; e < half * n; e += nthreads) {
-                const int k = e / n, i = e - k * n, p = s_p[k], q = s_q[k];
-                if (p < 0 || s_s[k] == 0.0) continue;
-                const double c = s_c[k], s = s_s[k];
-                double x = A[i * n + p], y = A[i * n + q];
-                A[i * n + p] = c * x - s * y; A[i * n + q] = s * x + c * y;
-                x = V[i * n + p]; y = V[i * n + q];
-                V[i * n + p] = c * x - s * y; V[i * n + q] = s * x + c * y;
+            // V <- V J
+            for (int e = tid; e < n * half; e += nthreads) {
+                const int i = e / half, k2 = e - i * half;
+                const int p2 = s_p[k2], q2 = s_q[k2];
+                const double c2 = s_c[k2], s2 = s_s[k2];
+                if (s2 == 0.0 || q2 < 0) continue;
+                const double x = V[i * n + p2], y = V[i * n + q2];
+                V[i * n + p2] = c2 * x - s2 * y; V[i * n + q2] = s2 * x + c2 * y;
             }
-            __syncthreads();
+            jacobi_sync<WAVE>();
         }
         if (!*s_flag) break;
-        __syncthreads();
+        jacobi_sync<WAVE>();
     }
 }
 
@@ -101,65 +117,49 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     const int mp = mi.mp, NE = mi.nfe, n = mi.n, R = mp + n;
     double* M = w.H + ((size_t)o * d.B + b) * RP * RP;
     double* bv = w.g + ((size_t)o * d.B + b) * RP;
-    const double* efac = w.efac + ((size_t)o * d.B + b) * d.NV * EF;
-    const int* colf = w.colf + (size_t)b * d.NFB;   // marginalisation maps (the caller swapped them in)
-    const int* cole = w.cole + (size_t)b * d.F;
-    double* Et = sb.Et + (size_t)b * d.FP * RP; double* Es = sb.Es + (size_t)b * d.FP * RP;
-    double* ete = sb.ete + (size_t)b * d.FP; double* etb = sb.etb + (size_t)b * d.FP;
+    const int ECW = d.ECW;
+    const double* Et = sb.Et + ((size_t)o * d.B + b) * d.FP * ECW;   // compact rows built by ba_build_et
+    double* Es = sb.Es + (size_t)b * d.FP * ECW;
+    __shared__ int s_cmap[128];
+    if (tid < ECW) s_cmap[tid] = compact_to_col(tid, w.colf + (size_t)b * d.NFB, d.NP, -1);   // marginalisation column map (swapped in by the caller)
+    const double* ete = sb.ete + ((size_t)o * d.B + b) * d.FP; const double* etb = sb.etb + ((size_t)o * d.B + b) * d.FP;
     const double eps = 1e-8;
-    // ---- rows of the eliminated feature columns
-    for (int i = tid; i < NE * RP; i += 512) Et[i] = 0.0;
-    __syncthreads();
-    const int nf = w.nfeat[b];
-    for (int f = wave; f < nf; f += 8) {
-        const int e = cole[f];
-        if (e < 0) continue;
-        const int p0 = w.feat_ptr[(size_t)b * (d.F + 1) + f], p1 = w.feat_ptr[(size_t)b * (d.F + 1) + f + 1];
-        double a = 0, c = 0;
-        for (int p = p0; p < p1; p++) {
-            const int k = w.feat_fac[(size_t)b * d.NV + p];
-            const double* ef = efac + (size_t)k * EF;
-            if (lane == 0) { a += ef[19]; c += ef[20]; }
-            if (lane < 19) {
-                const size_t kk = (size_t)b * d.NV + k;
-                const int fi = w.vis_i[kk], fj = w.vis_j[kk];
-                const int blk = lane < 6 ? fb_pose(fi) : lane < 12 ? fb_pose(fj) : lane == 12 ? fb_td(d.NP) : fb_ex(d.NP);
-                const int oo = lane < 6 ? lane : lane < 12 ? lane - 6 : lane == 12 ? 0 : lane - 13;
-                const int c0 = colf[blk];
-                if (c0 >= 0) Et[(size_t)e * RP + c0 + oo] += ef[lane];
-            }
-        }
-        if (lane == 0) { ete[e] = a; etb[e] = c; }
-    }
-    __syncthreads();
+#ifdef GF_PROFILE_STEP
+#define GF_MST(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && sb.stamps) sb.stamps[32 + (i)] = clock64(); } while (0)
+#else
+#define GF_MST(i) do { } while (0)
+#endif
+    GF_MST(0);
     // ---- eliminate the features: M -= sum_f w_f^T w_f / d_f, bv -= sum_f w_f b_f / d_f  (d_f <= eps: no information, dropped)
-    for (int i = tid; i < NE * RP; i += 512) {
-        const int e = i / RP, c = i - e * RP;
-        const double df = ete[e];
-        Es[i] = (c < R && df > eps) ? Et[i] / sqrt(df) : 0.0;
-    }
-    for (int i = NE * RP + tid; i < ((NE + 3) & ~3) * RP; i += 512) Es[i] = 0.0;
+    double* fe = sb.u + (size_t)b * sb.VS;   // per-feature 1/sqrt(d_f) (0: dropped) and b_f/sqrt(d_f)
+    for (int e = tid; e < NE; e += 512) { const double df = ete[e]; const double f = df > eps ? 1.0 / sqrt(df) : 0.0; fe[e] = f; fe[d.FP + e] = f * etb[e]; }
     __syncthreads();
-    for (int c = tid; c < R; c += 512) {
+    for (int i = tid; i < ((NE + 3) & ~3) * ECW; i += 512) {
+        const int e = i / ECW, k = i - e * ECW;
+        Es[i] = (e < NE && s_cmap[k] >= 0) ? Et[i] * fe[e] : 0.0;
+    }
+    __syncthreads();
+    for (int k = tid; k < ECW; k += 512) {
+        const int c = s_cmap[k];
+        if (c < 0) continue;
         double v = bv[c];
-        for (int e = 0; e < NE; e++) { const double df = ete[e]; if (df > eps) v -= Es[(size_t)e * RP + c] * (etb[e] / sqrt(df)); }
+        for (int e = 0; e < NE; e++) v -= Es[(size_t)e * ECW + k] * fe[d.FP + e];
         bv[c] = v;
     }
+    GF_MST(1);
     {
-        const int nt = (R + 15) / 16, ntiles = nt * (nt + 1) / 2, nk = (NE + 3) / 4;
+        const int nt = ECW / 16, ntiles = nt * (nt + 1) / 2, nk = (NE + 3) / 4;
         for (int t = wave; t < ntiles; t += 8) {
-            int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-            while (ti * (ti + 1) / 2 > t) ti--;
-            while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
-            const int tk = t - ti * (ti + 1) / 2;
+            const int ti = tri_row(t), tk = t - ti * (ti + 1) / 2;
             d4 acc = {0, 0, 0, 0};
-            const double* pa = Es + (size_t)(lane >> 4) * RP + 16 * ti + (lane & 15);
-            const double* pb = Es + (size_t)(lane >> 4) * RP + 16 * tk + (lane & 15);
-            for (int k = 0; k < nk; k++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(size_t)4 * k * RP], pb[(size_t)4 * k * RP], acc, 0, 0, 0);
+            const double* pa = Es + (size_t)(lane >> 4) * ECW + 16 * ti + (lane & 15);
+            const double* pb = Es + (size_t)(lane >> 4) * ECW + 16 * tk + (lane & 15);
+            for (int k = 0; k < nk; k++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(size_t)4 * k * ECW], pb[(size_t)4 * k * ECW], acc, 0, 0, 0);
+            const int col = s_cmap[16 * tk + (lane & 15)];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tk + (lane & 15);
-                if (row < R && col < R) {
+                const int row = s_cmap[16 * ti + (lane >> 4) + 4 * r];
+                if (row >= 0 && col >= 0) {
                     M[(size_t)row * RP + col] -= acc[r];
                     if (ti != tk) M[(size_t)col * RP + row] -= acc[r];
                 }
@@ -167,10 +167,11 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
         }
     }
     __syncthreads();
+    GF_MST(2);
     // ---- pseudo-inverse of the dropped pose / speed-bias block (eigenvalues <= eps are dropped)
     for (int i = tid; i < mp * mp; i += 512) { const int r = i / mp, c = i % mp; sP[i] = 0.5 * (M[(size_t)r * RP + c] + M[(size_t)c * RP + r]); }
     __syncthreads();
-    block_jacobi_eig(sP, sPV, mp, s_c, s_s, s_p, s_q, &s_flag, tid, 512);
+    if (wave == 0) block_jacobi_eig<true>(sP, sPV, mp, s_c, s_s, s_p, s_q, &s_flag, lane, 64);
     __syncthreads();
     for (int i = tid; i < mp * mp; i += 512) {
         const int r = i / mp, c = i % mp;
@@ -181,48 +182,82 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     __syncthreads();
     if (tid < mp) { double v = 0; for (int k = 0; k < mp; k++) v += sPinv[tid * mp + k] * bv[k]; sbp[tid] = v; }
     __syncthreads();
+    GF_MST(3);
     // ---- kept system: A_r = M_kk - M_kp Pinv M_pk (LDS), b_r = b_k - M_kp Pinv b_p
     double* A = smem;            // n x n
     double* V = smem + n * n;    // n x n
     double* br = sb.rhs + (size_t)b * RP;
+    double* T = V;   // T = Pinv * M_pk (mp x n), staged in the not-yet-used V area
+    for (int i = tid; i < mp * n; i += 512) {
+        const int a = i / n, c = i % n;
+        double t = 0;
+        for (int k = 0; k < mp; k++) t += sPinv[a * mp + k] * M[(size_t)k * RP + mp + c];
+        T[i] = t;
+    }
+    __syncthreads();
     for (int i = tid; i < n * n; i += 512) {
         const int r = i / n, c = i % n;
         double v = M[(size_t)(mp + r) * RP + mp + c];
-        for (int a = 0; a < mp; a++) {
-            double t = 0;
-            for (int k = 0; k < mp; k++) t += sPinv[a * mp + k] * M[(size_t)k * RP + mp + c];
-            v -= M[(size_t)(mp + r) * RP + a] * t;
-        }
+        const double* mr = M + (size_t)(mp + r) * RP;
+        for (int a = 0; a < mp; a++) v -= mr[a] * T[a * n + c];
         A[i] = v;
     }
     for (int r = tid; r < n; r += 512) { double v = bv[mp + r]; for (int a = 0; a < mp; a++) v -= M[(size_t)(mp + r) * RP + a] * sbp[a]; br[r] = v; }
     __syncthreads();
     for (int i = tid; i < n * n; i += 512) { const int r = i / n, c = i % n; if (c > r) { const double v = 0.5 * (A[i] + A[c * n + r]); A[i] = v; A[c * n + r] = v; } }
     __syncthreads();
-    block_jacobi_eig(A, V, n, s_c, s_s, s_p, s_q, &s_flag, tid, 512);
+    GF_MST(4);
+    // ---- square-root factor of the kept system.  The reference takes sqrt(S) V^T from an eigen-decomposition with eigenvalues <= eps
+    // dropped (marginalization_factor.cpp:294-302); any J with J^T J = A_r and J^T r = b_r is the same prior to the solver (only J^T J,
+    // J^T r and |r|^2 enter Ceres), so a rank-revealing (diagonally pivoted) Cholesky with the same absolute threshold is used:
+    // A_r = P L L^T P^T, J = L^T P^T (rows beyond the detected rank are zero), r = L^-1 P^T b (forward substitution rides along).
+    int* perm = reinterpret_cast<int*>(V);          // n ints
+    double* zb = V + 64;                            // n doubles: permuted right-hand side being forward-substituted
+    int* sidx = reinterpret_cast<int*>(V + 64 + 128);   // 512 ints for the arg-max reduction
+    for (int i = tid; i < n; i += 512) { perm[i] = i; zb[i] = br[i]; }
     __syncthreads();
-    // ---- linearized_jacobians = sqrt(S) V^T, linearized_residuals = sqrt(S^-1) V^T b   (rows ordered by ascending eigenvalue like Eigen)
-    int* rank = reinterpret_cast<int*>(sred);
-    for (int k = tid; k < n; k += 512) {
-        const double ev = A[k * n + k];
-        int rk = 0;
-        for (int j = 0; j < n; j++) { const double ej = A[j * n + j]; if (ej < ev || (ej == ev && j < k)) rk++; }
-        rank[k] = rk;
+    int rank = n;
+    for (int k = 0; k < n; k++) {
+        double best = -1.0; int bi = k;
+        for (int i = k + tid; i < n; i += 512) { const double v = A[perm[i] * n + perm[i]]; if (v > best) { best = v; bi = i; } }
+        sred[tid] = best; sidx[tid] = bi;
+        __syncthreads();
+        for (int sft = 256; sft > 0; sft >>= 1) {
+            if (tid < sft && (sred[tid + sft] > sred[tid] || (sred[tid + sft] == sred[tid] && sidx[tid + sft] < sidx[tid]))) { sred[tid] = sred[tid + sft]; sidx[tid] = sidx[tid + sft]; }
+            __syncthreads();
+        }
+        const double piv = sred[0];
+        const int pi = sidx[0];
+        __syncthreads();
+        if (!(piv > eps)) { rank = k; break; }
+        if (tid == 0) { const int t = perm[k]; perm[k] = perm[pi]; perm[pi] = t; const double tz = zb[k]; zb[k] = zb[pi]; zb[pi] = tz; }
+        __syncthreads();
+        const int pk_ = perm[k];
+        const double dinv = 1.0 / sqrt(piv);
+        const double rk = zb[k] * dinv;
+        __syncthreads();
+        // column k of L: L[i][k] = A[perm[i]][pk_] / d (stored in place), forward substitution of the right-hand side
+        for (int i = k + tid; i < n; i += 512) {
+            if (i == k) { A[pk_ * n + pk_] = piv * dinv; zb[k] = rk; }
+            else { const double l = A[perm[i] * n + pk_] * dinv; A[perm[i] * n + pk_] = l; zb[i] -= l * rk; }
+        }
+        __syncthreads();
+        // trailing update on the symmetric full storage
+        const int m = n - k - 1;
+        for (int e = tid; e < m * m; e += 512) {
+            const int i = k + 1 + e / m, j = k + 1 + e % m;
+            A[perm[i] * n + perm[j]] -= A[perm[i] * n + pk_] * A[perm[j] * n + pk_];
+        }
+        __syncthreads();
     }
-    __syncthreads();
+    GF_MST(5);
     double* J = out.J + (size_t)b * d.NPRI * d.NPRI;
     double* rr = out.r + (size_t)b * d.NPRI;
     for (int i = tid; i < n * n; i += 512) {
-        const int k = i / n, j = i % n;
-        const double ev = A[k * n + k];
-        J[(size_t)rank[k] * n + j] = ev > eps ? sqrt(ev) * V[j * n + k] : 0.0;
+        const int k = i / n, pos = i % n;   // J[k][perm[pos]] = L[pos][k] for pos >= k, k < rank
+        J[(size_t)k * n + perm[pos]] = (k < rank && pos >= k) ? A[perm[pos] * n + perm[k]] : 0.0;
     }
-    for (int k = tid; k < n; k += 512) {
-        const double ev = A[k * n + k];
-        double vb = 0;
-        for (int j = 0; j < n; j++) vb += V[j * n + k] * br[j];
-        rr[rank[k]] = ev > eps ? sqrt(1.0 / ev) * vb : 0.0;
-    }
+    for (int k = tid; k < n; k += 512) rr[k] = k < rank ? zb[k] : 0.0;
 }
 
 }  // namespace gfb

@@ -1,0 +1,15 @@
+import sys, ctypes as C
+sys.path.insert(0,'ground-fusion_amd')
+import numpy as np, gfamd, synth_window as SW
+est=gfamd.Estimator(batch=64)
+wins=[SW.make_window(1000+b, gfamd) for b in range(64)]
+est.upload(wins)
+est.solve_resident(8, 0, True)
+_, pri = est.download(wins, True)
+w1=[SW.make_window(1000+b, gfamd, frame0=1, prior=pri[b]) for b in range(64)]
+est.upload(w1)
+for it in range(2):
+    est.solve_resident(8, 0, True)
+    st=np.zeros(48, np.int64)
+    gfamd._chk(gfamd.lib().gf_ba_debug_stamps(est.h, st.ctypes.data_as(C.POINTER(C.c_longlong)), 48))
+    print('marg phases', np.diff(st[32:38]).tolist(), est.stats()['ms_marginalize'])
