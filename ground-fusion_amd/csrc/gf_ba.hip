@@ -52,7 +52,7 @@ struct gf_ba {
     Buf<double> vis_data, imu_data, wh_data, pri_J, pri_r, pri_x0;
     Buf<SolverState> st, st0;
     // work
-    Buf<double> imu_sqrt, wh_sqrt, pri_A, pri_b, pri_c, H, g, cost, efac;
+    Buf<double> imu_sqrt, wh_sqrt, pri_A, pri_b, pri_c, pri_H0, H, g, cost, efac;
     Buf<double> scale, diag, grad, gn, step, u, Et, Es, ete, etb, rhs, yv;
     // marginalisation: column maps per mode (0 MARGIN_OLD, 1 MARGIN_SECOND_NEW), outputs
     Buf<int> mcolf[2], mcole[2], morder[2], mnorder[2], minfo[2];
@@ -61,7 +61,7 @@ struct gf_ba {
     std::vector<std::vector<int>> keep_ids[2];   // per window: kept block ids (before the address shift), in column order
     size_t marg_lds = 0; int marg_ncap = 0, last_marg_mode = -1;
     long long mfma_per_lin = 0;   // v_mfma_f64_16x16x4 instructions of one visual linearisation of the resident batch
-    std::vector<Buf<double>*> dbl() { return {&xs0, &xs, &vis_data, &imu_data, &wh_data, &pri_J, &pri_r, &pri_x0, &imu_sqrt, &wh_sqrt, &pri_A, &pri_b, &pri_c, &H, &g, &cost, &efac,
+    std::vector<Buf<double>*> dbl() { return {&xs0, &xs, &vis_data, &imu_data, &wh_data, &pri_J, &pri_r, &pri_x0, &imu_sqrt, &wh_sqrt, &pri_A, &pri_b, &pri_c, &pri_H0, &H, &g, &cost, &efac,
                                               &scale, &diag, &grad, &gn, &step, &u, &Et, &Es, &ete, &etb, &rhs, &yv}; }
     std::vector<Buf<int>*> ints() { return {&colf, &cole, &nvis, &nimu, &nwh, &nfeat, &vis_feat, &vis_i, &vis_j, &order, &norder, &feat_ptr, &feat_fac, &imu_i, &wh_i, &pri_n, &pri_nb, &pri_bid}; }
     void release() {
@@ -79,7 +79,7 @@ struct gf_ba {
         w.vis_feat = vis_feat.d; w.vis_i = vis_i.d; w.vis_j = vis_j.d; w.vis_data = vis_data.d; w.order = order.d; w.norder = norder.d;
         w.feat_ptr = feat_ptr.d; w.feat_fac = feat_fac.d; w.imu_i = imu_i.d; w.imu_data = imu_data.d; w.wh_i = wh_i.d; w.wh_data = wh_data.d;
         w.imu_sqrt = imu_sqrt.d; w.wh_sqrt = wh_sqrt.d; w.pri_n = pri_n.d; w.pri_nb = pri_nb.d; w.pri_bid = pri_bid.d; w.pri_J = pri_J.d; w.pri_r = pri_r.d;
-        w.pri_x0 = pri_x0.d; w.pri_A = pri_A.d; w.pri_b = pri_b.d; w.pri_c = pri_c.d; w.H = H.d; w.g = g.d; w.cost = cost.d; w.efac = efac.d; w.st = st.d;
+        w.pri_x0 = pri_x0.d; w.pri_H0 = pri_H0.d; w.prior_preloaded = 1; w.pri_A = pri_A.d; w.pri_b = pri_b.d; w.pri_c = pri_c.d; w.H = H.d; w.g = g.d; w.cost = cost.d; w.efac = efac.d; w.st = st.d;
         w.G[0] = G[0]; w.G[1] = G[1]; w.G[2] = G[2]; w.vis_sqrt_info = vis_sqrt_info;
         return w;
     }
@@ -296,7 +296,8 @@ int launch_linearize(gf_ba* h, int which, int which_state, int cost_only, int on
     if (h->any_ex) ba_linearize_visual<true><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(w, which, which_state, cost_only, only_valid);
     else ba_linearize_visual<false><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(w, which, which_state, cost_only, only_valid);
     if (timed) HIPCHK(hipEventRecord(h->ev[3], h->stream));
-    ba_linearize_misc<<<dim3(2 * d.W + 1, d.B), 256, 0, h->stream>>>(w, which, which_state, cost_only, only_valid, 0);
+    ba_linearize_misc<<<dim3(2 * d.W, d.B), 64, 0, h->stream>>>(w, which, which_state, cost_only, only_valid, 0, 0);
+    ba_linearize_misc<<<dim3(1, d.B), 256, 0, h->stream>>>(w, which, which_state, cost_only, only_valid, 0, 2 * d.W);
     if (!cost_only) ba_build_et<<<dim3(d.F, d.B), 64, 0, h->stream>>>(w, h->sbufs(), which, 0);
     HIPCHK(hipGetLastError());
     return GF_OK;
@@ -305,7 +306,7 @@ int launch_linearize(gf_ba* h, int which, int which_state, int cost_only, int on
 // The fixed launch schedule of one batch solve: initial linearisation, then max_iters x (step, linearise candidate), final accept.
 int run_solve(gf_ba* h, int max_iters) {
     const Dims& d = h->d;
-    HIPCHK(hipMemsetAsync(h->H.d, 0, (size_t)d.B * d.RP * d.RP * sizeof(double), h->stream));   // buffer 0 only
+    HIPCHK(hipMemcpyAsync(h->H.d, h->pri_H0.d, (size_t)d.B * d.RP * d.RP * sizeof(double), hipMemcpyDeviceToDevice, h->stream));   // buffer 0 <- prior
     HIPCHK(hipMemsetAsync(h->g.d, 0, (size_t)d.B * d.RP * sizeof(double), h->stream));
     HIPCHK(hipMemsetAsync(h->cost.d, 0, (size_t)2 * d.B * sizeof(double), h->stream));
     if (int rc = launch_linearize(h, 0, 0, 0, 0, false)) return rc;
@@ -328,10 +329,12 @@ int run_marginalize(gf_ba* h, int mode) {
     const Dims& d = h->d;
     Win w = h->win();
     Win wm = w;
+    wm.prior_preloaded = 0;   // marginalisation columns differ from the solver's: the prior is added explicitly
     wm.colf = h->mcolf[mode].d; wm.cole = h->mcole[mode].d; wm.order = h->morder[mode].d; wm.norder = h->mnorder[mode].d;
     ba_zero_other<<<dim3(d.B), 256, 0, h->stream>>>(w);
     if (mode == 0) ba_linearize_visual<true><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(wm, -1, -2, 0, 2);
-    ba_linearize_misc<<<dim3(2 * d.W + 1, d.B), 256, 0, h->stream>>>(wm, -1, -2, 0, 2, mode == 0 ? 1 : 2);
+    if (mode == 0) ba_linearize_misc<<<dim3(2 * d.W, d.B), 64, 0, h->stream>>>(wm, -1, -2, 0, 2, 1, 0);
+    ba_linearize_misc<<<dim3(1, d.B), 256, 0, h->stream>>>(wm, -1, -2, 0, 2, 2, 2 * d.W);
     ba_build_et<<<dim3(d.F, d.B), 64, 0, h->stream>>>(wm, h->sbufs(), -1, 1);
     MargOut mo{h->outJ.d, h->outr.d};
     ba_marg_finish<<<dim3(d.B), 512, h->marg_lds, h->stream>>>(wm, h->sbufs(), reinterpret_cast<const MargInfo*>(h->minfo[mode].d), mo);
@@ -376,7 +379,7 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     }
     h->st.n = h->st0.n = B;
     A_(h->imu_sqrt.alloc(B * d.W * 225, false)); A_(h->wh_sqrt.alloc(B * d.W * 36, false)); A_(h->pri_A.alloc(B * d.NPRI * d.NPRI, false)); A_(h->pri_b.alloc(B * d.NPRI, false));
-    A_(h->pri_c.alloc(B, false)); A_(h->H.alloc(2 * B * d.RP * d.RP, true)); A_(h->g.alloc(2 * B * d.RP, true)); A_(h->cost.alloc(2 * B, true)); A_(h->efac.alloc(2 * B * d.NV * EF, false));
+    A_(h->pri_c.alloc(B, false)); A_(h->pri_H0.alloc(B * d.RP * d.RP, false)); A_(h->H.alloc(2 * B * d.RP * d.RP, true)); A_(h->g.alloc(2 * B * d.RP, true)); A_(h->cost.alloc(2 * B, true)); A_(h->efac.alloc(2 * B * d.NV * EF, false));
     A_(h->scale.alloc(B * VS, false)); A_(h->diag.alloc(B * VS, false)); A_(h->grad.alloc(B * VS, false)); A_(h->gn.alloc(B * VS, false)); A_(h->step.alloc(B * VS, false));
     A_(h->u.alloc(B * VS, false)); A_(h->Et.alloc(2 * B * d.FP * d.ECW, true)); A_(h->Es.alloc(B * d.FP * d.ECW, false)); A_(h->ete.alloc(2 * B * d.FP, true)); A_(h->etb.alloc(2 * B * d.FP, true));
     A_(h->rhs.alloc(B * d.RP, false)); A_(h->yv.alloc(B * VS, false));
@@ -507,7 +510,7 @@ int gf_ba_linearize(gf_ba* h, const gf_ba_window* w, int cap, double* Hout, doub
     if (int rc = gf_ba_upload(h, w, 1)) return rc;
     if (int rc = reset_state(h)) return rc;
     const Dims& d = h->d;
-    HIPCHK(hipMemsetAsync(h->H.d, 0, (size_t)d.B * d.RP * d.RP * sizeof(double), h->stream));
+    HIPCHK(hipMemcpyAsync(h->H.d, h->pri_H0.d, (size_t)d.B * d.RP * d.RP * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemsetAsync(h->g.d, 0, (size_t)d.B * d.RP * sizeof(double), h->stream));
     HIPCHK(hipMemsetAsync(h->cost.d, 0, (size_t)2 * d.B * sizeof(double), h->stream));
     if (int rc = launch_linearize(h, 0, 0, 0, 0, false)) return rc;
@@ -520,7 +523,7 @@ int gf_ba_linearize(gf_ba* h, const gf_ba_window* w, int cap, double* Hout, doub
     const int R = st.R, NE = st.NE, n = R + NE;
     if (n > cap) return gf::set_err(GF_ERR_CAPACITY, "capacity %d < %d columns", cap, n);
     for (int i = 0; i < n * n; i++) Hout[i] = 0;
-    for (int r = 0; r < R; r++) { for (int c = 0; c < R; c++) Hout[(size_t)r * n + c] = h->H.h[(size_t)r * d.RP + c]; gout[r] = h->g.h[r]; }
+    for (int r = 0; r < R; r++) { for (int c = 0; c <= r; c++) Hout[(size_t)r * n + c] = Hout[(size_t)c * n + r] = h->H.h[(size_t)r * d.RP + c]; gout[r] = h->g.h[r]; }   // device H holds the lower triangle
     for (int e = 0; e < NE; e++) {
         Hout[(size_t)(R + e) * n + R + e] = h->ete.h[e]; gout[R + e] = h->etb.h[e];
         for (int k = 0; k < 6 * d.NP + 7; k++) {   // compact row -> reduced columns

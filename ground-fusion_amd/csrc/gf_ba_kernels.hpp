@@ -66,6 +66,7 @@ struct Win {  // device view of the whole batch
     const int* pri_n; const int* pri_nb; const int* pri_bid;  // [B], [B], [B][64]
     const double* pri_J; const double* pri_r; const double* pri_x0;  // [B][NPRI*NPRI], [B][NPRI], [B][NPRI*2]
     double* pri_A; double* pri_b; double* pri_c;  // J0^T J0, J0^T r0, r0^T r0
+    double* pri_H0;           // [B][RP*RP] the prior's J0^T J0 scattered to the solver's columns (lower triangle): initial value of every H buffer
     double* H;                // [2][B][RP*RP]
     double* g;                // [2][B][RP]
     double* cost;             // [2][B]
@@ -73,6 +74,7 @@ struct Win {  // device view of the whole batch
     SolverState* st;          // [B]
     double G[3];
     double vis_sqrt_info;
+    int prior_preloaded;      // 1: every H buffer starts as a copy of pri_H0, the prior kernel adds only g and cost
 };
 constexpr int IMU_STRIDE = 16 + 225 + 225;  // sum_dt, dp3, dq4, dv3, lba3, lbg3(=17 used incl. sum_dt -> 0..16) jac, cov
 constexpr int IMU_JAC = 17, IMU_COV = 17 + 225;
@@ -252,14 +254,14 @@ __global__ void __launch_bounds__(64) ba_linearize_visual(Win w, int which, int 
         for (int r = 0; r < 4; r++) {
             const int ta = (lane >> 4) + 4 * r, ca = cmap(ta);
             const double v00 = acc00[r];
-            if (ca >= 0 && cb >= 0) atomicAdd(H + (size_t)ca * d.RP + cb, v00);
+            if (ca >= 0 && cb >= 0 && cb <= ca) atomicAdd(H + (size_t)ca * d.RP + cb, v00);   // lower triangle only (H is symmetric)
             if (ca >= 0 && cb == -2) atomicAdd(g + ca, v00);
             if (EX) {
                 const double v01 = acc01[r], v11 = acc11[r];
-                if (ca >= 0 && cb1 >= 0) { atomicAdd(H + (size_t)ca * d.RP + cb1, v01); atomicAdd(H + (size_t)cb1 * d.RP + ca, v01); }
+                if (ca >= 0 && cb1 >= 0) atomicAdd(H + (size_t)max(ca, cb1) * d.RP + min(ca, cb1), v01);
                 if (ca == -2 && cb1 >= 0) atomicAdd(g + cb1, v01);
                 const int ca1 = (ta < 6 && exc >= 0) ? exc + ta : -1;
-                if (ca1 >= 0 && cb1 >= 0) atomicAdd(H + (size_t)ca1 * d.RP + cb1, v11);
+                if (ca1 >= 0 && cb1 >= 0 && cb1 <= ca1) atomicAdd(H + (size_t)ca1 * d.RP + cb1, v11);
             }
         }
         acc00 = d4{0, 0, 0, 0}; acc01 = d4{0, 0, 0, 0}; acc11 = d4{0, 0, 0, 0};
@@ -328,6 +330,10 @@ __device__ inline void wave_inverse_spd_sqrt(double* M, double* T, int n, int la
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
 }
 
+__device__ __forceinline__ int fblock_of(int id, int NP);
+__host__ __device__ inline int lsize_kind(int kind);
+__host__ __device__ inline int gsize_kind(int kind);
+
 // One-time per solve: sqrt information of every IMU / wheel factor and the prior's normal-equation form.
 // grid (B), 256 threads (4 wavefronts).
 __global__ void __launch_bounds__(256) ba_setup(Win w) {
@@ -365,6 +371,29 @@ __global__ void __launch_bounds__(256) ba_setup(Win w) {
         }
         for (int a = threadIdx.x; a < n; a += 256) { double s = 0; for (int k2 = 0; k2 < n; k2++) s += J[(size_t)k2 * n + a] * r[k2]; w.pri_b[(size_t)b * d.NPRI + a] = s; }
         if (threadIdx.x == 0) { double s = 0; for (int k2 = 0; k2 < n; k2++) s += r[k2] * r[k2]; w.pri_c[b] = s; }
+    }
+    // H0: zero, then the prior's A scattered to solver columns (lower triangle).  Every linearisation starts from a copy of it.
+    __syncthreads();
+    double* H0 = w.pri_H0 + (size_t)b * d.RP * d.RP;
+    for (int i = threadIdx.x; i < d.RP * d.RP; i += 256) H0[i] = 0.0;
+    __syncthreads();
+    if (n > 0) {
+        __shared__ int s_pcol[256];
+        if (threadIdx.x == 0) {
+            int idx = 0;
+            for (int q = 0; q < w.pri_nb[b]; q++) {
+                const int id = w.pri_bid[(size_t)b * 64 + q], kind = id / 4096;
+                const int fb = fblock_of(id, d.NP);
+                const int c0 = fb >= 0 ? w.colf[(size_t)b * d.NFB + fb] : -1;
+                for (int k2 = 0; k2 < lsize_kind(kind); k2++) s_pcol[idx++] = c0 >= 0 ? c0 + k2 : -1;
+            }
+        }
+        __syncthreads();
+        const double* A = w.pri_A + (size_t)b * d.NPRI * d.NPRI;
+        for (int i = threadIdx.x; i < n * n; i += 256) {
+            const int ca = s_pcol[i / n], cb = s_pcol[i % n];
+            if (ca >= 0 && cb >= 0 && cb <= ca) H0[(size_t)ca * d.RP + cb] = A[i];
+        }
     }
 }
 
@@ -512,7 +541,8 @@ __host__ __device__ inline int gsize_kind(int kind) { return (kind == 0 || kind 
 
 // grid (2W + 1, B), 256 threads: block t < W evaluates IMU factor t (wavefront 0), W <= t < 2W wheel factor t - W, block 2W adds the prior.
 // frame_filter: 0 all factors; 1 only IMU/wheel factors starting at frame 0 (MARGIN_OLD); 2 no IMU/wheel factor (MARGIN_SECOND_NEW)
-__global__ void __launch_bounds__(256) ba_linearize_misc(Win w, int which, int which_state, int cost_only, int only_cand_valid, int frame_filter) {
+__global__ void __launch_bounds__(256) ba_linearize_misc(Win w, int which, int which_state, int cost_only, int only_cand_valid, int frame_filter, int task_base) {
+    __shared__ double sS[225];
     __shared__ double sJ[450];
     __shared__ double sSJ[450];
     __shared__ double sr[32];
@@ -520,7 +550,7 @@ __global__ void __launch_bounds__(256) ba_linearize_misc(Win w, int which, int w
     __shared__ double sdx[512];
     __shared__ double sred[256];
     const Dims d = w.d;
-    const int b = blockIdx.y, task = blockIdx.x, lane = threadIdx.x & 63;
+    const int b = blockIdx.y, task = task_base + blockIdx.x, lane = threadIdx.x & 63;   // factor tasks: 64-thread blocks; prior task: 256 threads
     const SolverState& st = w.st[b];
     if (st.done && only_cand_valid != 2) return;
     if (only_cand_valid == 1 && !st.cand_valid) return;
@@ -543,6 +573,7 @@ __global__ void __launch_bounds__(256) ba_linearize_misc(Win w, int which, int w
         if (is_imu) {
             imu_raw(xs + off_pose(i), xs + off_sb(i), xs + off_pose(j), xs + off_sb(j), w.imu_data + ((size_t)b * d.W + k) * IMU_STRIDE2, w.G, sr + 16, sJ, !cost_only, lane);
             nres = 15; ncol = 30; S = w.imu_sqrt + ((size_t)b * d.W + k) * 225;
+            for (int q = lane; q < 225; q += 64) sS[q] = S[q];
             if (lane < 30) {
                 const int blk = lane < 6 ? fb_pose(i) : lane < 15 ? fb_sb(i) : lane < 21 ? fb_pose(j) : fb_sb(j);
                 const int o = lane < 6 ? lane : lane < 15 ? lane - 6 : lane < 21 ? lane - 15 : lane - 21;
@@ -552,6 +583,7 @@ __global__ void __launch_bounds__(256) ba_linearize_misc(Win w, int which, int w
             wheel_raw(xs + off_pose(i), xs + off_pose(j), xs + off_exw(d.NP), xs[off_ix(d.NP)], xs[off_ix(d.NP) + 1], xs[off_ix(d.NP) + 2], xs[off_tdw(d.NP)],
                       w.wh_data + ((size_t)b * d.W + k) * WH_STRIDE, sr + 16, sJ, !cost_only, lane);
             nres = 6; ncol = 22; S = w.wh_sqrt + ((size_t)b * d.W + k) * 36;
+            if (lane < 36) sS[lane] = S[lane];
             if (lane < 22) {
                 const int blk = lane < 6 ? fb_pose(i) : lane < 12 ? fb_pose(j) : lane < 18 ? fb_exw(d.NP) : lane < 21 ? fb_sx(d.NP) + (lane - 18) : fb_tdw(d.NP);
                 const int o = lane < 6 ? lane : lane < 12 ? lane - 6 : lane < 18 ? lane - 12 : 0;
@@ -559,6 +591,7 @@ __global__ void __launch_bounds__(256) ba_linearize_misc(Win w, int which, int w
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        S = sS;
         if (lane < nres) { double sv = 0; for (int k2 = 0; k2 < nres; k2++) sv += S[lane * nres + k2] * sr[16 + k2]; sr[lane] = sv; }   // whitened residual
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
         double c = lane < nres ? 0.5 * sr[lane] * sr[lane] : 0.0;
@@ -575,7 +608,7 @@ __global__ void __launch_bounds__(256) ba_linearize_misc(Win w, int which, int w
         for (int e = lane; e < ncol * ncol; e += 64) {
             const int a = e / ncol, c2 = e % ncol;
             const int ca = scol[a], cb = scol[c2];
-            if (ca < 0 || cb < 0) continue;
+            if (ca < 0 || cb < 0 || cb > ca) continue;   // lower triangle only
             double sv = 0;
             for (int r = 0; r < nres; r++) sv += sSJ[r * ncol + a] * sSJ[r * ncol + c2];
             if (sv != 0.0) atomicAdd(H + (size_t)ca * d.RP + cb, sv);
@@ -616,10 +649,10 @@ __global__ void __launch_bounds__(256) ba_linearize_misc(Win w, int which, int w
             const int ca = (int)sdx[256 + a];
             if (!cost_only && ca >= 0) atomicAdd(g + ca, b0[a] + v);
         }
-        if (!cost_only)
+        if (!cost_only && !w.prior_preloaded)
             for (int e = threadIdx.x; e < n * n; e += 256) {
                 const int ca = (int)sdx[256 + e / n], cb = (int)sdx[256 + e % n];
-                if (ca >= 0 && cb >= 0) atomicAdd(H + (size_t)ca * d.RP + cb, A[e]);
+                if (ca >= 0 && cb >= 0 && cb <= ca) atomicAdd(H + (size_t)ca * d.RP + cb, A[e]);
             }
         if (threadIdx.x == 0) pc += 0.5 * w.pri_c[b];
     }
@@ -711,7 +744,7 @@ __device__ inline void quad_form(const double* H, const double* g, const double*
             if (r < R) {
                 const double* row = H + (size_t)r * RP;
 #pragma unroll
-                for (int q = 0; q < 3; q++) if (lane + 64 * q < R) sv[m] += row[lane + 64 * q] * uk[q];
+                for (int q = 0; q < 3; q++) { const int c = lane + 64 * q; if (c <= r) sv[m] += (c == r ? 1.0 : 2.0) * row[c] * uk[q]; }   // H holds its lower triangle
             }
         }
 #pragma unroll
@@ -1183,7 +1216,8 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
     for (int i = tid; i < d.XS; i += 512) xc[i] = xs[i];
     {
         double* Hc = w.H + ((size_t)(1 - cur) * d.B + b) * RP * RP;
-        for (int i = tid; i < RP * RP; i += 512) Hc[i] = 0.0;
+        const double* H0 = w.pri_H0 + (size_t)b * RP * RP;
+        for (int i = tid; i < RP * RP; i += 512) Hc[i] = H0[i];
         double* gc = w.g + ((size_t)(1 - cur) * d.B + b) * RP;
         for (int i = tid; i < RP; i += 512) gc[i] = 0.0;
         if (tid == 0) w.cost[(size_t)(1 - cur) * d.B + b] = 0.0;

@@ -159,17 +159,15 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = s_cmap[16 * ti + (lane >> 4) + 4 * r];
-                if (row >= 0 && col >= 0) {
-                    M[(size_t)row * RP + col] -= acc[r];
-                    if (ti != tk) M[(size_t)col * RP + row] -= acc[r];
-                }
+                // M holds its lower triangle; the marginalisation column order is not monotone in the compact index, so order per element
+                if (row >= 0 && col >= 0 && (ti != tk || (lane >> 4) + 4 * r >= (lane & 15))) M[(size_t)max(row, col) * RP + min(row, col)] -= acc[r];
             }
         }
     }
     __syncthreads();
     GF_MST(2);
     // ---- pseudo-inverse of the dropped pose / speed-bias block (eigenvalues <= eps are dropped)
-    for (int i = tid; i < mp * mp; i += 512) { const int r = i / mp, c = i % mp; sP[i] = 0.5 * (M[(size_t)r * RP + c] + M[(size_t)c * RP + r]); }
+    for (int i = tid; i < mp * mp; i += 512) { const int r = i / mp, c = i % mp; sP[i] = M[(size_t)max(r, c) * RP + min(r, c)]; }
     __syncthreads();
     if (wave == 0) block_jacobi_eig<true>(sP, sPV, mp, s_c, s_s, s_p, s_q, &s_flag, lane, 64);
     __syncthreads();
@@ -191,13 +189,13 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     for (int i = tid; i < mp * n; i += 512) {
         const int a = i / n, c = i % n;
         double t = 0;
-        for (int k = 0; k < mp; k++) t += sPinv[a * mp + k] * M[(size_t)k * RP + mp + c];
+        for (int k = 0; k < mp; k++) t += sPinv[a * mp + k] * M[(size_t)(mp + c) * RP + k];
         T[i] = t;
     }
     __syncthreads();
     for (int i = tid; i < n * n; i += 512) {
         const int r = i / n, c = i % n;
-        double v = M[(size_t)(mp + r) * RP + mp + c];
+        double v = M[(size_t)(mp + max(r, c)) * RP + mp + min(r, c)];
         const double* mr = M + (size_t)(mp + r) * RP;
         for (int a = 0; a < mp; a++) v -= mr[a] * T[a * n + c];
         A[i] = v;
