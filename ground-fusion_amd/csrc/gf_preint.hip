@@ -23,7 +23,52 @@ DM add(const DM& x, const DM& y) { DM o(x.r, x.c); for (size_t i = 0; i < o.a.si
 V3 arr(const double* p) { return v3(p[0], p[1], p[2]); }
 }  // namespace
 
+namespace {
+// Utility::R2ypr / ypr2R work in DEGREES (utility/utility.h:78-118)
+V3 R2ypr(const M3& R) {
+    const V3 n = v3(R.m[0], R.m[3], R.m[6]), o = v3(R.m[1], R.m[4], R.m[7]), a = v3(R.m[2], R.m[5], R.m[8]);
+    const double y = atan2(n.y, n.x);
+    const double p = atan2(-n.z, n.x * cos(y) + n.y * sin(y));
+    const double r = atan2(a.x * sin(y) - a.y * cos(y), -o.x * sin(y) + o.y * cos(y));
+    return v3(y / M_PI * 180.0, p / M_PI * 180.0, r / M_PI * 180.0);
+}
+M3 ypr2R(V3 ypr) {
+    const double y = ypr.x / 180.0 * M_PI, p = ypr.y / 180.0 * M_PI, r = ypr.z / 180.0 * M_PI;
+    M3 Rz = m3_zero(), Ry = m3_zero(), Rx = m3_zero();
+    Rz.m[0] = cos(y); Rz.m[1] = -sin(y); Rz.m[3] = sin(y); Rz.m[4] = cos(y); Rz.m[8] = 1;
+    Ry.m[0] = cos(p); Ry.m[2] = sin(p); Ry.m[4] = 1; Ry.m[6] = -sin(p); Ry.m[8] = cos(p);
+    Rx.m[0] = 1; Rx.m[4] = cos(r); Rx.m[5] = -sin(r); Rx.m[7] = sin(r); Rx.m[8] = cos(r);
+    return Rz * Ry * Rx;
+}
+}  // namespace
+
 extern "C" {
+
+// Estimator::double2vector, pose part (estimator.cpp:2440-2497, USE_IMU branch): the optimised window is rotated about the
+// vertical and shifted so that yaw and position of pose 0 keep their pre-optimisation values (the 4 unobservable DoF).
+int gf_ba_double2vector(int W, const double* R0_before, const double* P0_before, const double* para_Pose, const double* para_SpeedBias, double* Rs, double* Ps,
+                        double* Vs, double* Bas, double* Bgs) {
+    if (W < 0 || !R0_before || !P0_before || !para_Pose || !para_SpeedBias || !Rs || !Ps || !Vs || !Bas || !Bgs) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    M3 R0; for (int i = 0; i < 9; i++) R0.m[i] = R0_before[i];
+    const V3 origin_R0 = R2ypr(R0), origin_P0 = arr(P0_before);
+    const M3 R00m = qmat(Q4{para_Pose[6], para_Pose[3], para_Pose[4], para_Pose[5]});
+    const V3 origin_R00 = R2ypr(R00m);
+    const double y_diff = origin_R0.x - origin_R00.x;
+    M3 rot_diff = ypr2R(v3(y_diff, 0, 0));
+    if (fabs(fabs(origin_R0.y) - 90) < 1.0 || fabs(fabs(origin_R00.y) - 90) < 1.0) rot_diff = R0 * transpose(R00m);  // euler singular point (:2462-2471)
+    for (int i = 0; i <= W; i++) {
+        const double* pp = para_Pose + 7 * i;
+        const double* sb = para_SpeedBias + 9 * i;
+        const M3 Ri = rot_diff * qmat(qnormalized(Q4{pp[6], pp[3], pp[4], pp[5]}));
+        for (int k = 0; k < 9; k++) Rs[9 * i + k] = Ri.m[k];
+        const V3 P = rot_diff * v3(pp[0] - para_Pose[0], pp[1] - para_Pose[1], pp[2] - para_Pose[2]) + origin_P0;
+        Ps[3 * i] = P.x; Ps[3 * i + 1] = P.y; Ps[3 * i + 2] = P.z;
+        const V3 Vv = rot_diff * v3(sb[0], sb[1], sb[2]);
+        Vs[3 * i] = Vv.x; Vs[3 * i + 1] = Vv.y; Vs[3 * i + 2] = Vv.z;
+        for (int k = 0; k < 3; k++) { Bas[3 * i + k] = sb[3 + k]; Bgs[3 * i + k] = sb[6 + k]; }
+    }
+    return GF_OK;
+}
 
 int gf_imu_preintegrate(int n, const double* dt, const double* acc, const double* gyr, const double* acc0, const double* gyr0, const double* ba, const double* bg,
                         const double* noise, double* delta_p, double* delta_q, double* delta_v, double* jacobian, double* covariance, double* sum_dt) {

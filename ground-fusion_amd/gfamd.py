@@ -230,7 +230,7 @@ class BaStats(C.Structure):
 
 
 EXPORTS += ["gf_ba_create", "gf_ba_destroy", "gf_ba_solve", "gf_ba_marginalize", "gf_ba_upload", "gf_ba_solve_resident", "gf_ba_download", "gf_ba_get_stats",
-            "gf_ba_reset_stats", "gf_ba_linearize", "gf_imu_preintegrate", "gf_wheel_preintegrate"]
+            "gf_ba_reset_stats", "gf_ba_linearize", "gf_imu_preintegrate", "gf_wheel_preintegrate", "gf_ba_double2vector"]
 
 
 class Estimator:
@@ -348,4 +348,13 @@ def wheel_preintegrate(dt, vel, gyr, vel0, gyr0, lin, noise):
                                      _p(lin, C.c_double), _p(noise, C.c_double), _p(out["delta_p"], C.c_double), _p(out["delta_q"], C.c_double),
                                      _p(out["jacobian"], C.c_double), _p(out["covariance"], C.c_double), C.byref(sd)))
     out["sum_dt"] = sd.value
+    return out
+
+
+def double2vector(W, R0, P0, para_Pose, para_SpeedBias):
+    """Estimator::double2vector pose part (host code, no GPU needed)"""
+    f = lambda a: np.ascontiguousarray(a, np.float64).reshape(-1)
+    R0, P0, pp, sb = map(f, (R0, P0, para_Pose, para_SpeedBias))
+    out = [np.zeros(9 * (W + 1)), np.zeros(3 * (W + 1)), np.zeros(3 * (W + 1)), np.zeros(3 * (W + 1)), np.zeros(3 * (W + 1))]
+    _chk(lib().gf_ba_double2vector(W, _p(R0, C.c_double), _p(P0, C.c_double), _p(pp, C.c_double), _p(sb, C.c_double), *[_p(o, C.c_double) for o in out]))
     return out

@@ -193,6 +193,11 @@ int gf_ba_reset_stats(gf_ba* h);
  * [free blocks: pose0, sb0, pose1, ..., ex, exw, sx, sy, sw, td, tdw | free features by index] */
 int gf_ba_linearize(gf_ba* h, const gf_ba_window* w, int cap, double* H, double* g, double* cost, int* n_f, int* n_e, int* col_block_id);
 
+/* Estimator::double2vector, pose part (estimator.cpp:2440-2497, USE_IMU branch; R2ypr/ypr2R in degrees, utility.h:78-118):
+ * R0_before = Rs[0] (3x3 row-major) and P0_before = Ps[0] before the solve; outputs Rs (W+1)x9 row-major, Ps/Vs/Bas/Bgs (W+1)x3. */
+int gf_ba_double2vector(int W, const double* R0_before, const double* P0_before, const double* para_Pose, const double* para_SpeedBias,
+                        double* Rs, double* Ps, double* Vs, double* Bas, double* Bgs);
+
 /* IntegrationBase::push_back loop (factor/integration_base.h:39-167), host side; noise = ACC_N, GYR_N, ACC_W, GYR_W */
 int gf_imu_preintegrate(int n, const double* dt, const double* acc, const double* gyr, const double* acc0, const double* gyr0, const double* ba,
                         const double* bg, const double* noise, double* delta_p, double* delta_q, double* delta_v, double* jacobian,

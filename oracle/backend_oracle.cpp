@@ -991,6 +991,41 @@ void gfo_wheel_preintegrate(int n, const double* dt, const double* vel, const do
 }
 void gfo_sym_eig(int n, const double* A, double* d, double* V) { sym_eig(n, A, d, V); }
 
+// Estimator::double2vector pose part, estimator.cpp:2440-2497 (USE_IMU); Utility::R2ypr / ypr2R (degrees), utility.h:78-118
+static V3 o_R2ypr(const M3& R) {
+    V3 n = v3(R(0, 0), R(1, 0), R(2, 0)), o = v3(R(0, 1), R(1, 1), R(2, 1)), a = v3(R(0, 2), R(1, 2), R(2, 2));
+    double y = atan2(n[1], n[0]);
+    double p = atan2(-n[2], n[0] * cos(y) + n[1] * sin(y));
+    double r = atan2(a[0] * sin(y) - a[1] * cos(y), -o[0] * sin(y) + o[1] * cos(y));
+    return v3(y, p, r) / M_PI * 180.0;
+}
+static M3 o_ypr2R(const V3& ypr) {
+    double y = ypr[0] / 180.0 * M_PI, p = ypr[1] / 180.0 * M_PI, r = ypr[2] / 180.0 * M_PI;
+    M3 Rz, Ry, Rx;
+    Rz(0, 0) = cos(y); Rz(0, 1) = -sin(y); Rz(1, 0) = sin(y); Rz(1, 1) = cos(y); Rz(2, 2) = 1;
+    Ry(0, 0) = cos(p); Ry(0, 2) = sin(p); Ry(1, 1) = 1; Ry(2, 0) = -sin(p); Ry(2, 2) = cos(p);
+    Rx(0, 0) = 1; Rx(1, 1) = cos(r); Rx(1, 2) = -sin(r); Rx(2, 1) = sin(r); Rx(2, 2) = cos(r);
+    return Rz * Ry * Rx;
+}
+void gfo_double2vector(int W, const double* R0_before, const double* P0_before, const double* para_Pose, const double* para_SpeedBias, double* Rs, double* Ps,
+                       double* Vs, double* Bas, double* Bgs) {
+    M3 R0; memcpy(R0.a, R0_before, 72);
+    V3 origin_R0 = o_R2ypr(R0), origin_P0 = v3(P0_before[0], P0_before[1], P0_before[2]);
+    M3 R00 = Quat(para_Pose[6], para_Pose[3], para_Pose[4], para_Pose[5]).toRotationMatrix();
+    V3 origin_R00 = o_R2ypr(R00);
+    double y_diff = origin_R0[0] - origin_R00[0];
+    M3 rot_diff = o_ypr2R(v3(y_diff, 0, 0));
+    if (std::abs(std::abs(origin_R0[1]) - 90) < 1.0 || std::abs(std::abs(origin_R00[1]) - 90) < 1.0) rot_diff = R0 * R00.T();
+    for (int i = 0; i <= W; i++) {
+        const double* pp = para_Pose + 7 * i; const double* sb = para_SpeedBias + 9 * i;
+        M3 Ri = rot_diff * Quat(pp[6], pp[3], pp[4], pp[5]).normalized().toRotationMatrix();
+        memcpy(Rs + 9 * i, Ri.a, 72);
+        V3 P = rot_diff * v3(pp[0] - para_Pose[0], pp[1] - para_Pose[1], pp[2] - para_Pose[2]) + origin_P0;
+        V3 Vv = rot_diff * v3(sb[0], sb[1], sb[2]);
+        for (int k = 0; k < 3; k++) { Ps[3 * i + k] = P[k]; Vs[3 * i + k] = Vv[k]; Bas[3 * i + k] = sb[3 + k]; Bgs[3 * i + k] = sb[6 + k]; }
+    }
+}
+
 // Debug/inspection: H = J^T J, g = J^T r (loss-corrected, UNscaled) and cost at the window's state, dense, in the canonical
 // column order [free f-blocks: pose0, sb0, pose1, ..., ex, exw, sx, sy, sw, td, tdw | free features by index].
 int gfo_ba_linearize(const gfo_window* w, int cap, double* H, double* g, double* cost, int* n_f, int* n_e, int* col_block_id) {

@@ -84,6 +84,8 @@ void gfo_imu_preintegrate(int n, const double* dt, const double* acc, const doub
 void gfo_wheel_preintegrate(int n, const double* dt, const double* vel, const double* gyr, const double* vel0, const double* gyr0, const double* lin,
                             const double* noise, double* delta_p, double* delta_q, double* jacobian, double* covariance, double* sum_dt);
 void gfo_sym_eig(int n, const double* A, double* d, double* V);
+void gfo_double2vector(int W, const double* R0_before, const double* P0_before, const double* para_Pose, const double* para_SpeedBias, double* Rs, double* Ps,
+                       double* Vs, double* Bas, double* Bgs);
 int gfo_ba_linearize(const gfo_window* w, int cap, double* H, double* g, double* cost, int* n_f, int* n_e, int* col_block_id);
 #ifdef __cplusplus
 }

@@ -230,3 +230,11 @@ def ba_linearize(win, cap=1024):
     assert rc == 0
     n = nf.value + ne.value
     return {"H": H[:n * n].reshape(n, n).copy(), "g": g[:n].copy(), "cost": cost.value, "n_f": nf.value, "n_e": ne.value, "ids": ids[:n].copy()}
+
+
+def double2vector(W, R0, P0, para_Pose, para_SpeedBias):
+    f = lambda a: np.ascontiguousarray(a, np.float64).reshape(-1)
+    R0, P0, pp, sb = map(f, (R0, P0, para_Pose, para_SpeedBias))
+    out = [np.zeros(9 * (W + 1)), np.zeros(3 * (W + 1)), np.zeros(3 * (W + 1)), np.zeros(3 * (W + 1)), np.zeros(3 * (W + 1))]
+    lib().gfo_double2vector(W, _p(R0, C.c_double), _p(P0, C.c_double), _p(pp, C.c_double), _p(sb, C.c_double), *[_p(o, C.c_double) for o in out])
+    return out

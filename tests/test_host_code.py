@@ -1,0 +1,57 @@
+"""Host-side product code that needs no GPU (pre-integration, double2vector gauge fix) against the oracle."""
+import numpy as np
+import synth_window as SW
+
+
+def test_host_preintegration_matches_oracle(oracle):
+    import gfamd
+    rng = np.random.default_rng(3)
+    n = 14
+    dt = np.full(n, 0.005)
+    acc = rng.normal(0, 1, (n, 3)) + [0, 0, 9.8]
+    gyr = rng.normal(0, 0.3, (n, 3))
+    a = oracle.imu_preintegrate(dt, acc, gyr, acc[0], gyr[0], [0.01, -0.02, 0.03], [0.001, 0.002, -0.001], [0.1, 0.01, 0.001, 0.0001])
+    b = gfamd.imu_preintegrate(dt, acc, gyr, acc[0], gyr[0], [0.01, -0.02, 0.03], [0.001, 0.002, -0.001], [0.1, 0.01, 0.001, 0.0001])
+    for k in a:
+        assert np.allclose(a[k], b[k], rtol=1e-12, atol=1e-15), k
+    vel = rng.normal(1, 0.1, (n, 3))
+    a = oracle.wheel_preintegrate(dt, vel, gyr, vel[0], gyr[0], [1.01, 0.99, 1.02], [0.1, 0.01])
+    b = gfamd.wheel_preintegrate(dt, vel, gyr, vel[0], gyr[0], [1.01, 0.99, 1.02], [0.1, 0.01])
+    for k in a:
+        assert np.allclose(a[k], b[k], rtol=1e-12, atol=1e-15), k
+
+
+def test_double2vector_keeps_yaw_and_position_of_pose0(oracle):
+    import gfamd
+    w = SW.make_window(3, oracle)
+    W = w["W"]
+    pp = w["para_Pose"].reshape(-1, 7).copy()
+    q = pp[0, 3:]
+    x, y, z, qw = q
+    R0 = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * qw), 2 * (x * z + y * qw)], [2 * (x * y + z * qw), 1 - 2 * (x * x + z * z), 2 * (y * z - x * qw)],
+                   [2 * (x * z - y * qw), 2 * (y * z + x * qw), 1 - 2 * (x * x + y * y)]])
+    P0 = pp[0, :3].copy()
+    oracle.ba_solve(w, 4)  # moves pose 0 (gauge drift)
+    a = oracle.double2vector(W, R0, P0, w["para_Pose"], w["para_SpeedBias"])
+    b = gfamd.double2vector(W, R0, P0, w["para_Pose"], w["para_SpeedBias"])
+    for u, v in zip(a, b):
+        assert np.allclose(u, v, rtol=0, atol=1e-13)
+    Rs, Ps = b[0].reshape(-1, 3, 3), b[1].reshape(-1, 3)
+    assert np.allclose(Ps[0], P0, atol=1e-12)
+    yaw = lambda R: np.arctan2(R[1, 0], R[0, 0])
+    assert abs(yaw(Rs[0]) - yaw(R0)) < 1e-12
+    assert np.allclose(Rs[5] @ Rs[5].T, np.eye(3), atol=1e-12)
+
+
+def test_cpp_host_mirror_compiles_and_links(tmp_path):
+    """The C++ drop-in classes (host/feature_tracker.h, host/estimator_backend.h) compile against the C-ABI with plain g++."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.cpp"
+    src.write_text('#include <cmath>\n#include "ground-fusion_amd/host/feature_tracker.h"\n#include "ground-fusion_amd/host/estimator_backend.h"\n'
+                   'int main() { gf::FeatureTracker t; t.setIntrinsics(640, 480, 600, 600, 320, 240); (void)sizeof(gf::EstimatorBackend); return t.MAX_CNT == 150 ? 0 : 1; }\n')
+    exe = tmp_path / "t"
+    lib = os.path.join(root, "ground-fusion_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-I", root, str(src), "-L", lib, "-lgroundfusion_hip", "-Wl,-rpath," + lib, "-o", str(exe)])
+    assert subprocess.call([str(exe)]) == 0
