@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="independent sequences per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="independent sequences per GPU")
     ap.add_argument("--max-cnt", type=int, default=150)
     ap.add_argument("--min-dist", type=int, default=30)
     ap.add_argument("--ba-iters", type=int, default=8)
