@@ -161,10 +161,14 @@ def main():
 
     def do_step():
         k = step[0]
+        # the back end of this step is enqueued first and runs on its own stream while the tracker (GPU kernels + host bookkeeping)
+        # proceeds — the reference runs processImage and trackImage on separate threads as well (estimator.cpp:209, rosNodeTest.cpp:713)
+        if not args.no_backend:
+            est.solve_resident_async(args.ba_iters, 0, True)
         if not args.no_frontend:
             trk.trackImageBatchDevice([dt * k] * B, frames.data_ptr() + k * frame_bytes, depth.data_ptr(), unpack=False)
         if not args.no_backend:
-            est.solve_resident(args.ba_iters, 0, True)
+            est.wait()
         step[0] += 1
 
     for _ in range(Wm + 1):  # frame 0 only detects; it is part of the warm-up

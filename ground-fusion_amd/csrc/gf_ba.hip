@@ -41,8 +41,11 @@ struct gf_ba {
     Dims d;
     int count = 0;       // windows currently resident
     bool any_ex = false; // some window estimates the camera extrinsic
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: IMU / wheel / prior linearisation, concurrent with the visual sweep
     hipEvent_t ev[6] = {};
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool pending = false;   // an asynchronous solve is in flight
+    int pending_iters = 0;
     gf_ba_stats stats{};
     size_t step_lds = 0;
     // inputs (host mirror + device)
@@ -71,7 +74,10 @@ struct gf_ba {
         outJ.release(); outr.release(); stamps.release();
         st.release(); st0.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
         if (stream) (void)hipStreamDestroy(stream);
+        if (stream2) (void)hipStreamDestroy(stream2);
     }
     Win win() {
         Win w{};
@@ -292,13 +298,18 @@ int reset_state(gf_ba* h) {
 int launch_linearize(gf_ba* h, int which, int which_state, int cost_only, int only_valid, bool timed) {
     const Dims& d = h->d;
     Win w = h->win();
+    HIPCHK(hipEventRecord(h->ev_fork, h->stream));   // everything enqueued so far (state, zeroed buffers) precedes the forked work
     if (timed) HIPCHK(hipEventRecord(h->ev[2], h->stream));
     if (h->any_ex) ba_linearize_visual<true><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(w, which, which_state, cost_only, only_valid);
     else ba_linearize_visual<false><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(w, which, which_state, cost_only, only_valid);
     if (timed) HIPCHK(hipEventRecord(h->ev[3], h->stream));
-    ba_linearize_misc<<<dim3(2 * d.W, d.B), 64, 0, h->stream>>>(w, which, which_state, cost_only, only_valid, 0, 0);
-    ba_linearize_misc<<<dim3(1, d.B), 256, 0, h->stream>>>(w, which, which_state, cost_only, only_valid, 0, 2 * d.W);
     if (!cost_only) ba_build_et<<<dim3(d.F, d.B), 64, 0, h->stream>>>(w, h->sbufs(), which, 0);
+    // IMU / wheel / prior factors only share the atomically accumulated H, g, cost with the visual sweep: second stream
+    HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+    ba_linearize_misc<<<dim3(2 * d.W, d.B), 64, 0, h->stream2>>>(w, which, which_state, cost_only, only_valid, 0, 0);
+    ba_linearize_misc<<<dim3(1, d.B), 256, 0, h->stream2>>>(w, which, which_state, cost_only, only_valid, 0, 2 * d.W);
+    HIPCHK(hipEventRecord(h->ev_join, h->stream2));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
     HIPCHK(hipGetLastError());
     return GF_OK;
 }
@@ -364,7 +375,10 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
 #define A_(x) do { if (int rc_ = (x)) { h->release(); delete h; return rc_; } } while (0)
 #define H_(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { gf::set_err(GF_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); h->release(); delete h; return GF_ERR_HIP; } } while (0)
     H_(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    H_(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     for (auto& e : h->ev) H_(hipEventCreate(&e));
+    H_(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    H_(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     const size_t B = d.B, VS = d.RP + d.FP;
     A_(h->xs0.alloc(B * d.XS, true)); A_(h->xs.alloc(2 * B * d.XS, true));
     A_(h->colf.alloc(B * d.NFB, true)); A_(h->cole.alloc(B * d.F, true)); A_(h->nvis.alloc(B, true)); A_(h->nimu.alloc(B, true)); A_(h->nwh.alloc(B, true)); A_(h->nfeat.alloc(B, true));
@@ -405,6 +419,7 @@ int gf_ba_destroy(gf_ba* h) {
 
 int gf_ba_upload(gf_ba* h, const gf_ba_window* windows, int count) {
     if (!h || !windows) return gf::set_err(GF_ERR_INVALID, "null argument");
+    if (int rc = gf_ba_wait(h)) return rc;
     if (int rc = pack_windows(h, windows, count)) return rc;
     HIPCHK(hipEventRecord(h->ev[0], h->stream));
     if (int rc = upload(h)) return rc;
@@ -414,27 +429,42 @@ int gf_ba_upload(gf_ba* h, const gf_ba_window* windows, int count) {
     return GF_OK;
 }
 
-int gf_ba_solve_resident(gf_ba* h, int max_iters, int marginalize_mode, int reset) {
+int gf_ba_solve_resident_async(gf_ba* h, int max_iters, int marginalize_mode, int reset) {
     if (!h || h->count < 1) return gf::set_err(GF_ERR_INVALID, "no resident windows");
+    if (h->pending) return gf::set_err(GF_ERR_INVALID, "a solve is already in flight: call gf_ba_wait first");
     if (max_iters < 0 || max_iters > 64) return gf::set_err(GF_ERR_INVALID, "max_iters out of range");
+    if (marginalize_mode > 1) return gf::set_err(GF_ERR_INVALID, "marginalize_mode must be -1, 0 or 1");
     if (reset) { if (int rc = reset_state(h)) return rc; }
     HIPCHK(hipEventRecord(h->ev[0], h->stream));
     if (int rc = run_solve(h, max_iters)) return rc;
     HIPCHK(hipEventRecord(h->ev[1], h->stream));
-    if (marginalize_mode > 1) return gf::set_err(GF_ERR_INVALID, "marginalize_mode must be -1, 0 or 1");
     if (marginalize_mode >= 0) { if (int rc = run_marginalize(h, marginalize_mode)) return rc; h->last_marg_mode = marginalize_mode; }
     HIPCHK(hipEventRecord(h->ev[4], h->stream));
+    h->pending = true; h->pending_iters = max_iters;
+    return GF_OK;
+}
+
+int gf_ba_wait(gf_ba* h) {
+    if (!h) return gf::set_err(GF_ERR_INVALID, "null handle");
+    if (!h->pending) return GF_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->pending = false;
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); h->stats.ms_solve += ms;
     HIPCHK(hipEventElapsedTime(&ms, h->ev[1], h->ev[4])); h->stats.ms_marginalize += ms;
-    if (max_iters > 0) { HIPCHK(hipEventElapsedTime(&ms, h->ev[2], h->ev[3])); h->stats.ms_jtj += ms; }
+    if (h->pending_iters > 0) { HIPCHK(hipEventElapsedTime(&ms, h->ev[2], h->ev[3])); h->stats.ms_jtj += ms; }
     return GF_OK;
+}
+
+int gf_ba_solve_resident(gf_ba* h, int max_iters, int marginalize_mode, int reset) {
+    if (int rc = gf_ba_solve_resident_async(h, max_iters, marginalize_mode, reset)) return rc;
+    return gf_ba_wait(h);
 }
 
 
 int gf_ba_download(gf_ba* h, gf_ba_window* windows, int count, gf_ba_summary* summaries, gf_ba_prior* priors) {
     if (!h || count < 1 || count > h->count) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    if (int rc = gf_ba_wait(h)) return rc;
     const Dims& d = h->d;
     if (priors) {
         if (h->last_marg_mode < 0) return gf::set_err(GF_ERR_INVALID, "no marginalisation has been run on the resident windows");

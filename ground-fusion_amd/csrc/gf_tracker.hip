@@ -9,7 +9,12 @@
 // point fails with GF_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -53,6 +58,47 @@ struct SeqState {  // per-sequence FeatureTracker members (feature_tracker.h:76-
     double cur_time = 0, prev_time = 0;
     int n_id = 0;
     bool hasPrediction = false;
+};
+
+// Small persistent pool for the per-sequence host bookkeeping (sequences are independent).  GF_HOST_THREADS overrides the size.
+class HostPool {
+  public:
+    explicit HostPool(int n) {
+        for (int i = 0; i < n; i++) workers_.emplace_back([this] { run(); });
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; gen_++; }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    // calls fn(b) for b in [0, n); the calling thread takes part
+    void parallel_for(int n, const std::function<void(int)>& fn) {
+        if (workers_.empty() || n < 8) { for (int b = 0; b < n; b++) fn(b); return; }
+        { std::lock_guard<std::mutex> l(m_); fn_ = &fn; n_ = n; next_ = 0; active_ = (int)workers_.size(); gen_++; }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [this] { return active_ == 0; });
+        fn_ = nullptr;
+    }
+  private:
+    void work() { for (;;) { const int b = next_.fetch_add(1); if (b >= n_) break; (*fn_)(b); } }
+    void run() {
+        unsigned long long seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return gen_ != seen; }); seen = gen_; if (stop_) return; }
+            work();
+            { std::lock_guard<std::mutex> l(m_); if (--active_ == 0) done_.notify_one(); }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)>* fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_ = 0, active_ = 0;
+    unsigned long long gen_ = 0;
+    bool stop_ = false;
 };
 
 template <class T> struct DevBuf {
@@ -115,6 +161,7 @@ struct gf_tracker {
     hipEvent_t ev[8] = {};
     gf_tracker_stats stats{};
     std::vector<SeqState> seq;
+    HostPool* pool = nullptr;
     // device
     DevBuf<uint8_t> d_img, d_raw, d_mask, d_status, d_fwd_status, d_seqmask;
     DevBuf<int> d_der, d_npts, d_cand_count, d_want, d_ncenters, d_out_n;
@@ -144,6 +191,7 @@ struct gf_tracker {
         h_out_depth.release(); h_counters.release(); h_centers.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
+        delete pool; pool = nullptr;
     }
 };
 
@@ -364,24 +412,26 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
     }
 
     // ---- host bookkeeping per sequence (feature_tracker.cpp:170-186)
-    bool any_want = false;
-    for (int b = 0; b < B; b++) {
+    std::atomic<long long> a_levels{0}, a_iters{0}, a_points{0}, a_tracked{0};
+    std::atomic<int> a_want{0};
+    h->pool->parallel_for(B, [&](int b) {
         SeqState& s = h->seq[b];
         const int n = (int)s.prev_pts.size();
         if (n > 0) {
             const uint8_t* st = h->h_status.p + (size_t)b * cap;
             s.cur_pts.resize(n); s.cur_depth.resize(n);
+            long long lv = 0, it = 0;
             for (int i = 0; i < n; i++) {
                 const float2 c = h->h_cur_pts.p[(size_t)b * cap + i];
                 s.cur_pts[i] = {c.x, c.y};
                 s.cur_depth[i] = h->h_depth_out.p[(size_t)b * cap + i];
-                h->stats.lk_level_passes += h->h_counters.p[2 * ((size_t)b * cap + i)];
-                h->stats.lk_iterations += h->h_counters.p[2 * ((size_t)b * cap + i) + 1];
+                lv += h->h_counters.p[2 * ((size_t)b * cap + i)];
+                it += h->h_counters.p[2 * ((size_t)b * cap + i) + 1];
             }
-            h->stats.lk_points += n;
+            a_levels += lv; a_iters += it; a_points += n;
             reduce_vector(s.prev_pts, st); reduce_vector(s.cur_pts, st); reduce_vector(s.ids, st); reduce_vector(s.track_cnt, st);
             reduce_vector(s.cur_depth, st);
-            h->stats.tracked_features += (long long)s.cur_pts.size();
+            a_tracked += (long long)s.cur_pts.size();
         }
         for (auto& c : s.track_cnt) c++;
         int nc = 0;
@@ -389,9 +439,11 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
         h->h_ncenters.p[b] = nc;
         const int want = h->cfg.max_cnt - (int)s.cur_pts.size();
         h->h_want.p[b] = want;
-        if (want > 0) any_want = true;
+        if (want > 0) a_want = 1;
         h->h_out_n.p[b] = 0;
-    }
+    });
+    const bool any_want = a_want.load() != 0;
+    h->stats.lk_level_passes += a_levels; h->stats.lk_iterations += a_iters; h->stats.lk_points += a_points; h->stats.tracked_features += a_tracked;
 
     // ---- Shi-Tomasi top-up (feature_tracker.cpp:190-206)
     if (any_want) {
@@ -437,7 +489,9 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
                 return set_err(GF_ERR_CAPACITY, "sequence %d: %d corner candidates exceed capacity %d", b, h->h_cand_count.p[b], h->cand_cap);
 
     // ---- addPoints, undistortedPts, ptsVelocity, pack (feature_tracker.cpp:85-93, 210-211, 322-368)
-    for (int b = 0; b < B; b++) {
+    std::atomic<int> a_overflow{-1};
+    std::atomic<long long> a_out{0};
+    h->pool->parallel_for(B, [&](int b) {
         SeqState& s = h->seq[b];
         const int nn = h->h_want.p[b] > 0 ? h->h_out_n.p[b] : 0;
         for (int i = 0; i < nn; i++) {
@@ -451,7 +505,7 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
         s.prev_pts = s.cur_pts; s.prev_un_pts = s.cur_un_pts; s.prev_un_pts_map.swap(s.cur_un_pts_map); s.prev_time = s.cur_time;
         s.hasPrediction = false;
         const int n = (int)s.ids.size();
-        if (n > cap_out) return set_err(GF_ERR_CAPACITY, "output capacity %d < %d features", cap_out, n);
+        if (n > cap_out) { a_overflow = n; n_out[b] = 0; return; }
         gf_feature_obs* o = out + (size_t)b * cap_out;
         for (int i = 0; i < n; i++) {
             o[i].id = s.ids[i]; o[i].camera_id = 0;
@@ -460,8 +514,10 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
             o[i].v[7] = (h->cfg.depth_cam && d_depth) ? (double)(int)s.cur_depth[i] / 1000 : -2.4;
         }
         n_out[b] = n;
-        h->stats.output_features += n;
-    }
+        a_out += n;
+    });
+    if (a_overflow.load() >= 0) return set_err(GF_ERR_CAPACITY, "output capacity %d < %d features", cap_out, a_overflow.load());
+    h->stats.output_features += a_out;
     h->frame++;
     h->stats.frames++;
     lap(h->stats.ms_host_post);
@@ -497,6 +553,12 @@ int gf_tracker_create(const gf_tracker_cfg* cfg, gf_tracker** out) {
     gf::build_geom(cfg->width, cfg->height, h->G);
     gf::make_disk_table(cfg->min_dist, h->disk);
     h->seq.resize(h->B);
+    {
+        int nthr = 4;
+        if (const char* e = getenv("GF_HOST_THREADS")) nthr = atoi(e);
+        nthr = std::max(1, std::min(nthr, (int)std::thread::hardware_concurrency()));
+        h->pool = new gf::HostPool(h->B >= 8 ? nthr - 1 : 0);
+    }
     const int W = cfg->width, H = cfg->height, B = h->B, cap = h->cap;
     int cc = 1024;
     while (cc < (W * H) / 2) cc <<= 1;

@@ -230,7 +230,7 @@ class BaStats(C.Structure):
 
 
 EXPORTS += ["gf_ba_create", "gf_ba_destroy", "gf_ba_solve", "gf_ba_marginalize", "gf_ba_upload", "gf_ba_solve_resident", "gf_ba_download", "gf_ba_get_stats",
-            "gf_ba_reset_stats", "gf_ba_linearize", "gf_imu_preintegrate", "gf_wheel_preintegrate", "gf_ba_double2vector"]
+            "gf_ba_reset_stats", "gf_ba_linearize", "gf_ba_solve_resident_async", "gf_ba_wait", "gf_ba_debug_stamps", "gf_imu_preintegrate", "gf_wheel_preintegrate", "gf_ba_double2vector"]
 
 
 class Estimator:
@@ -273,6 +273,12 @@ class Estimator:
 
     def solve_resident(self, max_iters=8, marginalize_mode=-1, reset=True):
         _chk(lib().gf_ba_solve_resident(self.h, max_iters, marginalize_mode, int(reset)))
+
+    def solve_resident_async(self, max_iters=8, marginalize_mode=-1, reset=True):
+        _chk(lib().gf_ba_solve_resident_async(self.h, max_iters, marginalize_mode, int(reset)))
+
+    def wait(self):
+        _chk(lib().gf_ba_wait(self.h))
 
     def download(self, wins=None, with_priors=False, cap_n=256):
         wins = wins if wins is not None else self._keep[0]

@@ -186,8 +186,12 @@ int gf_ba_marginalize(gf_ba* h, const gf_ba_window* windows, int count, int mode
 /* throughput path: windows stay resident in HBM between calls */
 int gf_ba_upload(gf_ba* h, const gf_ba_window* windows, int count);
 int gf_ba_solve_resident(gf_ba* h, int max_iters, int marginalize_mode /* -1: none */, int reset_state);
+/* same, returning as soon as the work is enqueued (the reference runs processImage on its own thread, estimator.cpp:209); gf_ba_wait joins */
+int gf_ba_solve_resident_async(gf_ba* h, int max_iters, int marginalize_mode, int reset_state);
+int gf_ba_wait(gf_ba* h);
 int gf_ba_download(gf_ba* h, gf_ba_window* windows, int count, gf_ba_summary* summaries, gf_ba_prior* priors);
 int gf_ba_get_stats(gf_ba* h, gf_ba_stats* out);
+int gf_ba_debug_stamps(gf_ba* h, long long* out, int n); /* per-phase clock stamps of ba_step (profiling builds, -DGF_PROFILE_STEP) */
 int gf_ba_reset_stats(gf_ba* h);
 /* inspection for parity tests: H = J^T J, g = J^T r (loss-corrected, unscaled), cost; canonical column order
  * [free blocks: pose0, sb0, pose1, ..., ex, exw, sx, sy, sw, td, tdw | free features by index] */
