@@ -119,6 +119,13 @@ __device__ __forceinline__ float i64_to_f32(long long v) { return (float)(double
 
 struct __attribute__((packed, aligned(4))) U4a { uint32_t x, y, z, w; };
 
+// d = a * b + c on the 24-bit integer multiplier (full rate); |a|, |b| < 2^23
+__device__ __forceinline__ int mad_i24(int a, int b, int c) {
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 // bytes o..o+7 of the 12-byte little-endian string w0 w1 w2
 __device__ __forceinline__ void align8(uint32_t w0, uint32_t w1, uint32_t w2, int o, uint32_t& lo, uint32_t& hi) {
     lo = __builtin_amdgcn_alignbyte(w1, w0, o);
@@ -188,15 +195,15 @@ __device__ __forceinline__ int lk_solve(const PyrGeom& G, const LkImages im, flo
 #pragma unroll
             for (int k = 0; k < 7; k++) {
                 int i00 = byte_of(l0, h0, k), i01 = byte_of(l0, h0, k + 1), i10 = byte_of(l1, h1, k), i11 = byte_of(l1, h1, k + 1);
-                int iv = (i00 * iw00 + i01 * iw01 + i10 * iw10 + i11 * iw11 + (1 << 8)) >> 9;
+                int iv = (__mul24(i00, iw00) + __mul24(i01, iw01) + __mul24(i10, iw10) + __mul24(i11, iw11) + (1 << 8)) >> 9;   // all operands < 2^15
                 int x00 = (short)(top[k] & 0xffff), x01 = (short)(top[k + 1] & 0xffff), x10 = (short)(bot[k] & 0xffff), x11 = (short)(bot[k + 1] & 0xffff);
                 int y00 = top[k] >> 16, y01 = top[k + 1] >> 16, y10 = bot[k] >> 16, y11 = bot[k + 1] >> 16;
-                int ix = (x00 * iw00 + x01 * iw01 + x10 * iw10 + x11 * iw11 + (1 << 13)) >> 14;
-                int iy = (y00 * iw00 + y01 * iw01 + y10 * iw10 + y11 * iw11 + (1 << 13)) >> 14;
+                int ix = (__mul24(x00, iw00) + __mul24(x01, iw01) + __mul24(x10, iw10) + __mul24(x11, iw11) + (1 << 13)) >> 14;
+                int iy = (__mul24(y00, iw00) + __mul24(y01, iw01) + __mul24(y10, iw10) + __mul24(y11, iw11) + (1 << 13)) >> 14;
                 ix = (short)ix; iy = (short)iy; iv = (short)iv;
                 if (!live) { ix = 0; iy = 0; iv = 0; }
                 tI[k] = iv; tX[k] = ix; tY[k] = iy;
-                a11 += ix * ix; a12 += ix * iy; a22 += iy * iy;
+                a11 += __mul24(ix, ix); a12 += __mul24(ix, iy); a22 += __mul24(iy, iy);
             }
         }
         const long long iA11 = wave_sum_exact(a11), iA12 = wave_sum_exact(a12), iA22 = wave_sum_exact(a22);
@@ -247,12 +254,26 @@ __device__ __forceinline__ int lk_solve(const PyrGeom& G, const LkImages im, flo
                 uint32_t l0, h0, l1, h1;
                 align8(q0[0], q0[1], q0[2], o, l0, h0);
                 align8(q1[0], q1[1], q1[2], o, l1, h1);
+                const uint32_t m0 = __builtin_amdgcn_alignbyte(h0, l0, 3), m1 = __builtin_amdgcn_alignbyte(h1, l1, 3);   // bytes 3..6 of each row
+                // weights split into 7-bit halves (w = 128 * wh + wl, wh <= 128): the 4-tap sum becomes two v_dot4_u32_u8
+                // iw11 = 2^14 - iw00 - iw01 - iw10 can come out as -1/-2 after the three roundings: keep that part out of the unsigned dots
+                const int iw11p = iw11 > 0 ? iw11 : 0, iw11n = iw11 < 0 ? iw11 : 0;
+                const uint32_t wh = (uint32_t)(iw00 >> 7) | ((uint32_t)(iw01 >> 7) << 8) | ((uint32_t)(iw10 >> 7) << 16) | ((uint32_t)(iw11p >> 7) << 24);
+                const uint32_t wl = (uint32_t)(iw00 & 127) | ((uint32_t)(iw01 & 127) << 8) | ((uint32_t)(iw10 & 127) << 16) | ((uint32_t)(iw11p & 127) << 24);
 #pragma unroll
                 for (int k = 0; k < 7; k++) {
-                    int j00 = byte_of(l0, h0, k), j01 = byte_of(l0, h0, k + 1), j10 = byte_of(l1, h1, k), j11 = byte_of(l1, h1, k + 1);
-                    int diff = ((j00 * iw00 + j01 * iw01 + j10 * iw10 + j11 * iw11 + (1 << 8)) >> 9) - tI[k];
-                    b1 += diff * tX[k];
-                    b2 += diff * tY[k];
+                    // p = { J[r][k], J[r][k+1], J[r+1][k], J[r+1][k+1] }
+                    const uint32_t s0 = k < 3 ? l0 : k == 3 ? m0 : h0, s1 = k < 3 ? l1 : k == 3 ? m1 : h1;
+                    const int kb = k < 3 ? k : k == 3 ? 0 : k - 4;
+                    const uint32_t sel = (uint32_t)kb | ((uint32_t)(kb + 1) << 8) | ((uint32_t)(4 + kb) << 16) | ((uint32_t)(5 + kb) << 24);
+                    const uint32_t pq = __builtin_amdgcn_perm(s1, s0, sel);
+                    const uint32_t hi = __builtin_amdgcn_udot4(pq, wh, 0u, false);
+                    const uint32_t lo = __builtin_amdgcn_udot4(pq, wl, 256u, false);
+                    int raw = (int)((hi << 7) + lo);
+                    if (iw11n) raw += (int)(pq >> 24) * iw11n;   // wave-uniform, rare
+                    const int diff = (raw >> 9) - tI[k];
+                    b1 = mad_i24(diff, tX[k], b1);
+                    b2 = mad_i24(diff, tY[k], b2);
                 }
             }
             const long long ib1 = wave_sum_exact(b1), ib2 = wave_sum_exact(b2);
@@ -302,7 +323,7 @@ struct LkBatchArgs {
 // grid.x = ceil(cap/4) blocks of 4 wavefronts, grid.y = sequence.  Forward LK (feature_tracker.cpp:118-135),
 // reverse LK and flow-back test (:138-153), inBorder and the brightness test with the reference's swapped
 // row/column indexing (:155-168).
-__global__ void __launch_bounds__(256) lk_track_kernel(PyrGeom G, LkBatchArgs A) {
+__global__ void __launch_bounds__(256, 8) lk_track_kernel(PyrGeom G, LkBatchArgs A) {
     __shared__ __attribute__((aligned(16))) uint8_t tiles[4 * kTileBytes];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y;
