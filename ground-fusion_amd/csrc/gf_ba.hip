@@ -125,11 +125,12 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
         auto add = [&](int blk, bool constant, int ls) { if (constant) cf[blk] = -1; else { cf[blk] = col; col += ls; } };
         for (int i = 0; i < d.NP; i++) { add(fb_pose(i), w.fix_poses != 0, 6); add(fb_sb(i), w.fix_poses != 0, 9); }
         add(fb_ex(d.NP), w.fix_ex_pose != 0, 6);
-        const bool wheel = w.n_wheel > 0;
-        add(fb_exw(d.NP), !wheel || w.fix_ex_wheel, 6);
-        for (int q = 0; q < 3; q++) add(fb_sx(d.NP) + q, !wheel || w.fix_ix, 1);
+        // wheel blocks take part when a wheel factor or the prior mentions them (Ceres drops parameter blocks without residual blocks)
+        auto part = [&](int id) { if (w.n_wheel > 0) return true; for (int q = 0; q < w.prior_nblocks; q++) if (w.prior_block_id[q] == id) return true; return false; };
+        add(fb_exw(d.NP), !part(GF_EX_WHEEL * 4096) || w.fix_ex_wheel, 6);
+        for (int q = 0; q < 3; q++) add(fb_sx(d.NP) + q, !part((GF_SX + q) * 4096) || w.fix_ix, 1);
         add(fb_td(d.NP), w.fix_td != 0, 1);
-        add(fb_tdw(d.NP), !wheel || w.fix_td_wheel, 1);
+        add(fb_tdw(d.NP), !part(GF_TD_WHEEL * 4096) || w.fix_td_wheel, 1);
         if (!w.fix_ex_pose) h->any_ex = true;
         SolverState& st = h->st0.h[b];
         memset(&st, 0, sizeof st);

@@ -1,0 +1,1064 @@
+// gf_estimator.hip — host side of the sliding-window back end: the parts of Estimator (vins_estimator/src/estimator/estimator.cpp) and
+// FeatureManager (feature_manager.cpp) that decide WHAT the optimiser sees, written on plain arrays.
+// All dense numerics go through the HIP back end (gf_ba_*); nothing in this file evaluates factors or solves on the CPU.
+//
+//   reference                                                   here
+//   Estimator::inputIMU / inputWheel / inputImage  EST:213-360   gf_estimator_input_imu / _input_wheel / _input_image / _input_feature
+//   Estimator::processMeasurements                 EST:526-709   Estimator::processMeasurements
+//   Estimator::processIMU / processWheel           EST:743-842   Estimator::processIMU / processWheel
+//   Estimator::processImage                        EST:843-1163  Estimator::processImage
+//   Estimator::initialStructure (stationary and wheel-activated shortcuts only, EST:1557-1682; the SfM path is SURVEY.md §8(f)1)
+//   Estimator::vector2double / double2vector       EST:2276-2353, :2440-2569
+//   Estimator::optimization                        EST:2890-3636 (problem construction -> one gf_ba_window)
+//   Estimator::slideWindow / slideWindowNew / Old  EST:3638-3837
+//   Estimator::predictPtsInNextFrame, movingConsistencyCheckW, reprojectionError(3D)  EST:3862-4010
+//   FeatureManager::*                              FM:43-110, :198-302, :669-934, :978-1010
+// Unsupported switches are rejected at create time: ESTIMATE_EXTRINSIC==2, USE_LINE, USE_PLANE, USE_MOTION, GNSS_ENABLE, STEREO, !USE_IMU.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <list>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/groundfusion_hip.h"
+#include "gf_dmath.hpp"
+
+namespace gf { int set_err(int code, const char* fmt, ...); }
+using namespace gfd;
+
+namespace {
+
+V3 arr3(const double* p) { return v3(p[0], p[1], p[2]); }
+M3 arr9(const double* p) { M3 m; for (int i = 0; i < 9; i++) m.m[i] = p[i]; return m; }
+double norm(V3 a) { return sqrt(sqn(a)); }
+V3 normalized(V3 a) { return a / norm(a); }
+
+// Utility::R2ypr / ypr2R in DEGREES (utility/utility.h:78-118)
+V3 R2ypr(const M3& R) {
+    const V3 n = v3(R.m[0], R.m[3], R.m[6]), o = v3(R.m[1], R.m[4], R.m[7]), a = v3(R.m[2], R.m[5], R.m[8]);
+    const double y = atan2(n.y, n.x);
+    const double p = atan2(-n.z, n.x * cos(y) + n.y * sin(y));
+    const double r = atan2(a.x * sin(y) - a.y * cos(y), -o.x * sin(y) + o.y * cos(y));
+    return v3(y / M_PI * 180.0, p / M_PI * 180.0, r / M_PI * 180.0);
+}
+M3 ypr2R(V3 ypr) {
+    const double y = ypr.x / 180.0 * M_PI, p = ypr.y / 180.0 * M_PI, r = ypr.z / 180.0 * M_PI;
+    M3 Rz = m3_zero(), Ry = m3_zero(), Rx = m3_zero();
+    Rz.m[0] = cos(y); Rz.m[1] = -sin(y); Rz.m[3] = sin(y); Rz.m[4] = cos(y); Rz.m[8] = 1;
+    Ry.m[0] = cos(p); Ry.m[2] = sin(p); Ry.m[4] = 1; Ry.m[6] = -sin(p); Ry.m[8] = cos(p);
+    Rx.m[0] = 1; Rx.m[4] = cos(r); Rx.m[5] = -sin(r); Rx.m[7] = sin(r); Rx.m[8] = cos(r);
+    return Rz * Ry * Rx;
+}
+// Eigen::Quaterniond(Matrix3d)
+Q4 rot_to_quat(const M3& Rm) {
+    const double* R = Rm.m;
+    double t = R[0] + R[4] + R[8], w, v[3];
+    if (t > 0) { t = sqrt(t + 1.0); w = 0.5 * t; t = 0.5 / t; v[0] = (R[7] - R[5]) * t; v[1] = (R[2] - R[6]) * t; v[2] = (R[3] - R[1]) * t; }
+    else {
+        int i = 0; if (R[4] > R[0]) i = 1; if (R[8] > R[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0); v[i] = 0.5 * t; t = 0.5 / t;
+        w = (R[3 * k + j] - R[3 * j + k]) * t; v[j] = (R[3 * j + i] + R[3 * i + j]) * t; v[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+    }
+    return Q4{w, v[0], v[1], v[2]};
+}
+// Utility::g2R (utility/utility.cpp:12-22) with Eigen's Quaterniond::FromTwoVectors (regular branch; the antiparallel branch needs g ≈ -z)
+M3 g2R(V3 g) {
+    const V3 v0 = normalized(g), v1 = v3(0, 0, 1);
+    const double c = dot(v1, v0);
+    M3 R0;
+    if (c < -1.0 + 1e-12) R0 = m3_diag(1, -1, -1);  // rotation by pi about x: any axis orthogonal to z serves
+    else {
+        const V3 axis = cross(v0, v1);
+        const double s = sqrt((1.0 + c) * 2.0), invs = 1.0 / s;
+        R0 = qmat(Q4{s * 0.5, axis.x * invs, axis.y * invs, axis.z * invs});
+    }
+    const double yaw = R2ypr(R0).x;
+    return ypr2R(v3(-yaw, 0, 0)) * R0;
+}
+
+// right singular vector of the smallest singular value of A (rows x 4), one-sided Jacobi (stands in for Eigen::JacobiSVD, FM:710)
+void smallest_right_singular_vector(std::vector<double>& A, int rows, double out[4]) {
+    double V[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0;
+        for (int p = 0; p < 3; p++)
+            for (int q = p + 1; q < 4; q++) {
+                double a = 0, b = 0, g = 0;
+                for (int r = 0; r < rows; r++) { const double x = A[4 * r + p], y = A[4 * r + q]; a += x * x; b += y * y; g += x * y; }
+                if (g == 0.0 || fabs(g) <= 1e-300) continue;
+                const double lim = 1e-15 * sqrt(a * b);
+                if (fabs(g) <= lim) continue;
+                off = std::max(off, fabs(g) / sqrt(a * b));
+                const double zeta = (b - a) / (2.0 * g);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int r = 0; r < rows; r++) { const double x = A[4 * r + p], y = A[4 * r + q]; A[4 * r + p] = c * x - s * y; A[4 * r + q] = s * x + c * y; }
+                for (int r = 0; r < 4; r++) { const double x = V[4 * r + p], y = V[4 * r + q]; V[4 * r + p] = c * x - s * y; V[4 * r + q] = s * x + c * y; }
+            }
+        if (off == 0.0) break;
+    }
+    int best = 0; double bn = -1;
+    for (int c = 0; c < 4; c++) { double n = 0; for (int r = 0; r < rows; r++) n += A[4 * r + c] * A[4 * r + c]; if (bn < 0 || n < bn) { bn = n; best = c; } }
+    for (int r = 0; r < 4; r++) out[r] = V[4 * r + best];
+}
+
+// ---------------------------------------------------------------- FeatureManager (feature_manager.h:30-80, :139-215)
+struct FeaturePerFrame { V3 point; double uv[2], velocity[2], depth, cur_td; };
+struct FeaturePerId {
+    int feature_id, start_frame;
+    std::vector<FeaturePerFrame> feature_per_frame;
+    int used_num = 0; double estimated_depth = -1.0; int estimate_flag = 0, solve_flag = 0;
+    FeaturePerId(int id, int sf) : feature_id(id), start_frame(sf) {}
+    int endFrame() const { return start_frame + (int)feature_per_frame.size() - 1; }
+};
+
+struct FeatureManager {
+    std::list<FeaturePerId> feature;
+    int last_track_num = 0, new_feature_num = 0, long_track_num = 0;
+    double last_average_parallax = 0;
+    int WINDOW_SIZE = 10; double FOCAL_LENGTH = 600, MIN_PARALLAX = 10.0 / 600, INIT_DEPTH = 5, depth_threshold = 3;
+
+    int getFeatureCount() {  // FM:43-55
+        int cnt = 0;
+        for (auto& it : feature) { it.used_num = (int)it.feature_per_frame.size(); if (it.used_num >= 4) cnt++; }
+        return cnt;
+    }
+    static double compensatedParallax2(const FeaturePerId& it, int frame_count) {  // FM:978-1010 (the compensation is the identity)
+        const FeaturePerFrame& fi = it.feature_per_frame[frame_count - 2 - it.start_frame];
+        const FeaturePerFrame& fj = it.feature_per_frame[frame_count - 1 - it.start_frame];
+        const double u_j = fj.point.x, v_j = fj.point.y;
+        const double dep_i = fi.point.z, u_i = fi.point.x / dep_i, v_i = fi.point.y / dep_i;
+        const double du = u_i - u_j, dv = v_i - v_j;
+        return std::max(0.0, sqrt(std::min(du * du + dv * dv, du * du + dv * dv)));
+    }
+    bool addFeatureCheckParallax(int frame_count, const gf_feature_obs* obs, int n, double td) {  // FM:57-116; `obs` sorted by id (std::map order)
+        double parallax_sum = 0; int parallax_num = 0;
+        last_track_num = 0; last_average_parallax = 0; new_feature_num = 0; long_track_num = 0;
+        for (int k = 0; k < n; k++) {
+            const double* p = obs[k].v;
+            FeaturePerFrame f{v3(p[0], p[1], p[2]), {p[3], p[4]}, {p[5], p[6]}, p[7], td};
+            const int feature_id = obs[k].id;
+            auto it = std::find_if(feature.begin(), feature.end(), [feature_id](const FeaturePerId& x) { return x.feature_id == feature_id; });
+            if (it == feature.end()) { feature.emplace_back(feature_id, frame_count); feature.back().feature_per_frame.push_back(f); new_feature_num++; }
+            else { it->feature_per_frame.push_back(f); last_track_num++; if (it->feature_per_frame.size() >= 4) long_track_num++; }
+        }
+        if (frame_count < 2 || last_track_num < 20 || long_track_num < 40 || new_feature_num > 0.5 * last_track_num) return true;
+        for (auto& it : feature)
+            if (it.start_frame <= frame_count - 2 && it.start_frame + (int)it.feature_per_frame.size() - 1 >= frame_count - 1) { parallax_sum += compensatedParallax2(it, frame_count); parallax_num++; }
+        if (parallax_num == 0) return true;
+        last_average_parallax = parallax_sum / parallax_num * FOCAL_LENGTH;
+        return parallax_sum / parallax_num >= MIN_PARALLAX;
+    }
+    // FM:219-247: pairs (a, b) of depth-scaled observations, flat as 6 doubles
+    std::vector<double> getCorrespondingWithDepth(int l, int r) const {
+        std::vector<double> c;
+        for (auto& it : feature)
+            if (it.start_frame <= l && it.endFrame() >= r) {
+                const FeaturePerFrame &fa = it.feature_per_frame[l - it.start_frame], &fb = it.feature_per_frame[r - it.start_frame];
+                if (fa.depth < 0.1 || fa.depth > 10) continue;
+                if (fb.depth < 0.1 || fb.depth > 10) continue;
+                const V3 a = fa.point * fa.depth, b = fb.point * fb.depth;
+                c.insert(c.end(), {a.x, a.y, a.z, b.x, b.y, b.z});
+            }
+        return c;
+    }
+    void setDepth(const double* x) {  // FM:249-267
+        int idx = -1;
+        for (auto& it : feature) {
+            it.used_num = (int)it.feature_per_frame.size();
+            if (it.used_num < 4) continue;
+            it.estimated_depth = 1.0 / x[++idx];
+            it.solve_flag = it.estimated_depth < 0 ? 2 : 1;
+        }
+    }
+    void removeFailures() { for (auto it = feature.begin(); it != feature.end();) it = it->solve_flag == 2 ? feature.erase(it) : std::next(it); }  // FM:269-278
+    void getDepthVector(std::vector<double>& dep) {  // FM:286-302
+        dep.clear();
+        for (auto& it : feature) { it.used_num = (int)it.feature_per_frame.size(); if (it.used_num < 4) continue; dep.push_back(1.0 / it.estimated_depth); }
+    }
+    void triangulate(const V3* Ps, const M3* Rs, V3 tic, const M3& ric) {  // FM:669-724
+        for (auto& it : feature) {
+            if (it.estimated_depth > 0) continue;
+            it.used_num = (int)it.feature_per_frame.size();
+            if (it.used_num < 4) continue;
+            const int imu_i = it.start_frame; int imu_j = imu_i - 1;
+            std::vector<double> A(2 * it.feature_per_frame.size() * 4);
+            int row = 0;
+            const V3 t0 = Ps[imu_i] + Rs[imu_i] * tic; const M3 R0 = Rs[imu_i] * ric;
+            for (auto& fr : it.feature_per_frame) {
+                imu_j++;
+                const V3 t1 = Ps[imu_j] + Rs[imu_j] * tic; const M3 R1 = Rs[imu_j] * ric;
+                const V3 t = transpose(R0) * (t1 - t0); const M3 R = transpose(R0) * R1;
+                const M3 Rt = transpose(R); const V3 pt = -(Rt * t);
+                const double P[3][4] = {{Rt.m[0], Rt.m[1], Rt.m[2], pt.x}, {Rt.m[3], Rt.m[4], Rt.m[5], pt.y}, {Rt.m[6], Rt.m[7], Rt.m[8], pt.z}};
+                const V3 f = normalized(fr.point);
+                for (int c = 0; c < 4; c++) A[4 * row + c] = f.x * P[2][c] - f.z * P[0][c];
+                row++;
+                for (int c = 0; c < 4; c++) A[4 * row + c] = f.y * P[2][c] - f.z * P[1][c];
+                row++;
+            }
+            double sv[4];
+            smallest_right_singular_vector(A, row, sv);
+            it.estimated_depth = sv[2] / sv[3];
+            it.estimate_flag = 2;
+            if (it.estimated_depth < 0.1) { it.estimated_depth = INIT_DEPTH; it.estimate_flag = 0; }
+        }
+    }
+    void triangulateWithDepth(const V3* Ps, const M3* Rs, V3 tic, const M3& ric) {  // FM:726-799
+        for (auto& it : feature) {
+            it.used_num = (int)it.feature_per_frame.size();
+            if (it.used_num < 4) continue;
+            if (it.estimated_depth > 0) continue;
+            const int s = it.start_frame, n = (int)it.feature_per_frame.size();
+            double depth_sum = 0.0; size_t cnt = 0;
+            const V3 tr = Ps[s] + Rs[s] * tic; const M3 Rr = Rs[s] * ric;
+            for (int i = 0; i < n; i++) {
+                const V3 t0 = Ps[s + i] + Rs[s + i] * tic; const M3 R0 = Rs[s + i] * ric;
+                const double d = it.feature_per_frame[i].depth;
+                if (d < 0.1 || d > depth_threshold) continue;
+                const V3 point0 = it.feature_per_frame[i].point * d;
+                const V3 t2r = transpose(Rr) * (t0 - tr); const M3 R2r = transpose(Rr) * R0;
+                for (int j = 0; j < n; j++) {
+                    if (i == j) continue;
+                    const V3 t1 = Ps[s + j] + Rs[s + j] * tic; const M3 R1 = Rs[s + j] * ric;
+                    const V3 t20 = transpose(R0) * (t1 - t0); const M3 R20 = transpose(R0) * R1;
+                    const V3 pp = transpose(R20) * point0 - transpose(R20) * t20;
+                    const double rx = it.feature_per_frame[j].point.x - pp.x / pp.z, ry = it.feature_per_frame[j].point.y - pp.y / pp.z;
+                    if (sqrt(rx * rx + ry * ry) < 10.0 / 460) { const V3 pr = R2r * point0 + t2r; depth_sum += pr.z; cnt++; }
+                }
+            }
+            if (cnt == 0) continue;
+            it.estimated_depth = depth_sum / cnt;
+            it.estimate_flag = 1;
+            if (it.estimated_depth < 0.1) { it.estimated_depth = INIT_DEPTH; it.estimate_flag = 0; }
+        }
+    }
+    void removeOutlier(const std::set<int>& idx) { for (auto it = feature.begin(); it != feature.end();) it = idx.count(it->feature_id) ? feature.erase(it) : std::next(it); }  // FM:801-816
+    void removeBackShiftDepth(const M3& marg_R, V3 marg_P, const M3& new_R, V3 new_P) {  // FM:818-856
+        for (auto it = feature.begin(); it != feature.end();) {
+            auto cur = it++;
+            if (cur->start_frame != 0) { cur->start_frame--; continue; }
+            const V3 uv_i = cur->feature_per_frame[0].point;
+            cur->feature_per_frame.erase(cur->feature_per_frame.begin());
+            if (cur->feature_per_frame.size() < 2) { feature.erase(cur); continue; }
+            const V3 pts_i = uv_i * cur->estimated_depth, w_pts_i = marg_R * pts_i + marg_P, pts_j = transpose(new_R) * (w_pts_i - new_P);
+            cur->estimated_depth = pts_j.z > 0 ? pts_j.z : INIT_DEPTH;
+        }
+    }
+    void removeBack() {  // FM:858-874
+        for (auto it = feature.begin(); it != feature.end();) {
+            auto cur = it++;
+            if (cur->start_frame != 0) cur->start_frame--;
+            else { cur->feature_per_frame.erase(cur->feature_per_frame.begin()); if (cur->feature_per_frame.empty()) feature.erase(cur); }
+        }
+    }
+    void removeFront(int frame_count) {  // FM:914-934
+        for (auto it = feature.begin(); it != feature.end();) {
+            auto cur = it++;
+            if (cur->start_frame == frame_count) cur->start_frame--;
+            else {
+                const int j = WINDOW_SIZE - 1 - cur->start_frame;
+                if (cur->endFrame() < frame_count - 1) continue;
+                cur->feature_per_frame.erase(cur->feature_per_frame.begin() + j);
+                if (cur->feature_per_frame.empty()) feature.erase(cur);
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------- pre-integration holders (IntegrationBase / WheelIntegrationBase as sample buffers)
+struct ImuPre {  // integration_base.h:22-62: linearized_acc/gyr, linearized_ba/bg, the three sample buffers; results evaluated on demand
+    V3 acc0, gyr0, lin_ba, lin_bg;
+    std::vector<double> dt, acc, gyr;
+    double sum_dt = 0, delta_p[3] = {0, 0, 0}, delta_q[4] = {1, 0, 0, 0}, delta_v[3] = {0, 0, 0};
+    std::vector<double> jacobian, covariance;
+    bool dirty = true;
+    ImuPre(V3 a0, V3 g0, V3 ba, V3 bg) : acc0(a0), gyr0(g0), lin_ba(ba), lin_bg(bg), jacobian(225), covariance(225) {}
+    void push_back(double t, V3 a, V3 g) { dt.push_back(t); acc.insert(acc.end(), {a.x, a.y, a.z}); gyr.insert(gyr.end(), {g.x, g.y, g.z}); dirty = true; }
+    void repropagate(V3 ba, V3 bg) { lin_ba = ba; lin_bg = bg; dirty = true; }  // integration_base.h:51-62
+    int eval(const double* noise) {
+        if (!dirty) return GF_OK;
+        const double a0[3] = {acc0.x, acc0.y, acc0.z}, g0[3] = {gyr0.x, gyr0.y, gyr0.z}, ba[3] = {lin_ba.x, lin_ba.y, lin_ba.z}, bg[3] = {lin_bg.x, lin_bg.y, lin_bg.z};
+        const int rc = gf_imu_preintegrate((int)dt.size(), dt.data(), acc.data(), gyr.data(), a0, g0, ba, bg, noise, delta_p, delta_q, delta_v, jacobian.data(), covariance.data(), &sum_dt);
+        dirty = rc != GF_OK;
+        return rc;
+    }
+};
+struct WheelPre {  // wheel_integration_base.h:23-60
+    V3 vel0, gyr0; double lin[4];  // linearized sx, sy, sw, td
+    std::vector<double> dt, vel, gyr;
+    double sum_dt = 0, delta_p[3] = {0, 0, 0}, delta_q[4] = {1, 0, 0, 0}, jacobian[18], covariance[36];
+    bool dirty = true;
+    WheelPre(V3 v0, V3 g0, double sx, double sy, double sw, double td) : vel0(v0), gyr0(g0), lin{sx, sy, sw, td} {}
+    void push_back(double t, V3 v, V3 g) { dt.push_back(t); vel.insert(vel.end(), {v.x, v.y, v.z}); gyr.insert(gyr.end(), {g.x, g.y, g.z}); dirty = true; }
+    V3 vel_1() const { return dt.empty() ? vel0 : arr3(&vel[vel.size() - 3]); }
+    V3 gyr_1() const { return dt.empty() ? gyr0 : arr3(&gyr[gyr.size() - 3]); }
+    int eval(const double* noise) {
+        if (!dirty) return GF_OK;
+        const double v0[3] = {vel0.x, vel0.y, vel0.z}, g0[3] = {gyr0.x, gyr0.y, gyr0.z};
+        const int rc = gf_wheel_preintegrate((int)dt.size(), dt.data(), vel.data(), gyr.data(), v0, g0, lin, noise, delta_p, delta_q, jacobian, covariance, &sum_dt);
+        dirty = rc != GF_OK;
+        return rc;
+    }
+};
+struct ImageFrame {  // initial/initial_alignment.h ImageFrame: only what the non-SfM paths read
+    M3 R = m3_identity(); V3 T = v3(0, 0, 0);
+    std::shared_ptr<ImuPre> pre_integration;
+    std::shared_ptr<WheelPre> pre_integration_wheel;
+    bool pre_deleted = false;  // the reference deletes the pointer of the oldest frame but keeps the map entry (EST:3722-3726)
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------- Estimator
+struct gf_estimator {
+    gf_estimator_cfg cfg;
+    int WINDOW_SIZE;
+    enum { INITIAL = 0, NON_LINEAR = 1 };
+    enum { MARGIN_OLD = 0, MARGIN_SECOND_NEW = 1 };
+    FeatureManager f_manager;
+    gf_ba* ba = nullptr;
+    gf_tracker* tracker = nullptr;
+    // measurement queues (estimator.h:182-190)
+    std::deque<std::pair<double, V3>> accBuf, gyrBuf, wheelVelBuf, wheelGyrBuf;
+    std::deque<std::pair<double, std::vector<gf_feature_obs>>> featureBuf;
+    double prevTime = -1, curTime = 0, prevTime_wheel = -1, curTime_wheel = 0;
+    int inputImageCnt = 0;
+    // window state (estimator.h:262-300)
+    std::vector<V3> Ps, Vs, Bas, Bgs; std::vector<M3> Rs; std::vector<double> Headers;
+    V3 tic = v3(0, 0, 0), tio = v3(0, 0, 0), g = v3(0, 0, 9.805); M3 ric = m3_identity(), rio = m3_identity();
+    double td = 0, td_wheel = 0, sx = 1, sy = 1, sw = 1;
+    int frame_count = 0, solver_flag = INITIAL, marginalization_flag = MARGIN_OLD, sum_of_back = 0, sum_of_front = 0;
+    bool first_imu = false, first_wheel = false, initFirstPoseFlag = false;
+    V3 acc_0 = v3(0, 0, 0), gyr_0 = v3(0, 0, 0), vel_0_wheel = v3(0, 0, 0), gyr_0_wheel = v3(0, 0, 0), latest_vel_wheel_0 = v3(0, 0, 0);
+    std::vector<std::shared_ptr<ImuPre>> pre_integrations; std::vector<std::shared_ptr<WheelPre>> pre_integrations_wheel;
+    std::shared_ptr<ImuPre> tmp_pre_integration; std::shared_ptr<WheelPre> tmp_wheel_pre_integration;
+    std::map<double, ImageFrame> all_image_frame;
+    double initial_timestamp = 0;
+    // stationarity / anomaly votes (estimator.h, EST:26-35)
+    bool wheelanomaly = false, visualstationary = false, wheelstationary = false, imustationary = false, systemstationary = false, varstationary = false,
+         preintegrationstationary = false, is_imu_excited = false, Bas_calibok = false;
+    V3 dP_imu = v3(0, 0, 0), dP_wheel = v3(0, 0, 0);
+    int openExEstimation = 0, openExWheelEstimation = 0, openIxEstimation = 0;
+    M3 back_R0 = m3_identity(), last_R = m3_identity(), last_R0 = m3_identity(); V3 back_P0 = v3(0, 0, 0), last_P = v3(0, 0, 0), last_P0 = v3(0, 0, 0);
+    // para_* (estimator.h:335-341)
+    std::vector<double> para_Pose, para_SpeedBias, para_Feature;
+    double para_Ex_Pose[7], para_Ex_Pose_wheel[7], para_Ix[3], para_Td[1], para_Td_wheel[1];
+    // last_marginalization_info in C-ABI form
+    bool prior_valid = false; int prior_n = 0;
+    std::vector<int> prior_block_id; std::vector<double> prior_J, prior_r, prior_x0;
+    // feedback to the tracker (EST:1132-1136)
+    std::vector<int> predict_ids, remove_ids; std::vector<double> predict_xyz;
+    gf_ba_summary last_summary{};
+    long long n_optimizations = 0;
+    double imu_noise[4], wheel_noise[2];
+    std::string err;
+
+    explicit gf_estimator(const gf_estimator_cfg& c) : cfg(c), WINDOW_SIZE(c.window_size) {
+        const int NP = WINDOW_SIZE + 1;
+        Ps.assign(NP, v3(0, 0, 0)); Vs = Bas = Bgs = Ps; Rs.assign(NP, m3_identity()); Headers.assign(NP, 0.0);
+        pre_integrations.assign(NP, nullptr); pre_integrations_wheel.assign(NP, nullptr);
+        para_Pose.assign(7 * NP, 0); para_SpeedBias.assign(9 * NP, 0); para_Feature.assign(std::max(1, c.max_features), 0);
+        tic = arr3(c.tic); ric = arr9(c.ric); tio = arr3(c.tio); rio = arr9(c.rio);   // setParameter EST:176-199
+        td = c.td; td_wheel = c.td_wheel; sx = c.sx; sy = c.sy; sw = c.sw; g = v3(0, 0, c.g_norm);
+        imu_noise[0] = c.acc_n; imu_noise[1] = c.gyr_n; imu_noise[2] = c.acc_w; imu_noise[3] = c.gyr_w;
+        wheel_noise[0] = c.wheel_vel_n; wheel_noise[1] = c.wheel_gyr_n;
+        f_manager.WINDOW_SIZE = WINDOW_SIZE; f_manager.FOCAL_LENGTH = c.focal_length; f_manager.MIN_PARALLAX = c.min_parallax_px / c.focal_length;
+        f_manager.INIT_DEPTH = c.init_depth; f_manager.depth_threshold = c.depth_threshold;
+    }
+    ~gf_estimator() { if (ba) gf_ba_destroy(ba); if (tracker) gf_tracker_destroy(tracker); }
+
+    // ------------------------------------------------------------ measurement intake
+    bool getInterval(std::deque<std::pair<double, V3>>& a, std::deque<std::pair<double, V3>>& b, double t0, double t1, std::vector<std::pair<double, V3>>& av,
+                     std::vector<std::pair<double, V3>>& bv) {  // getIMUInterval EST:406-439 / getWheelInterval EST:440-474
+        if (a.empty()) return false;
+        if (!(t1 <= a.back().first)) return false;
+        while (!a.empty() && a.front().first <= t0) { a.pop_front(); b.pop_front(); }
+        while (!a.empty() && a.front().first < t1) { av.push_back(a.front()); a.pop_front(); bv.push_back(b.front()); b.pop_front(); }
+        if (!a.empty()) { av.push_back(a.front()); bv.push_back(b.front()); }
+        return true;
+    }
+    void initFirstIMUPose(const std::vector<std::pair<double, V3>>& accVector) {  // EST:710-731
+        initFirstPoseFlag = true;
+        V3 averAcc = v3(0, 0, 0);
+        for (auto& a : accVector) averAcc = averAcc + a.second;
+        averAcc = averAcc / (double)(int)accVector.size();
+        M3 R0 = g2R(averAcc);
+        const double yaw = R2ypr(R0).x;
+        R0 = ypr2R(v3(-yaw, 0, 0)) * R0;
+        Rs[0] = R0 * arr9(cfg.rio);  // RIO: the configured wheel extrinsic rotation
+    }
+    void processIMU(double t, double dt, V3 linear_acceleration, V3 angular_velocity) {  // EST:743-785
+        if (!first_imu) { first_imu = true; acc_0 = linear_acceleration; gyr_0 = angular_velocity; }
+        if (!pre_integrations[frame_count]) pre_integrations[frame_count] = std::make_shared<ImuPre>(acc_0, gyr_0, Bas[frame_count], Bgs[frame_count]);
+        if (frame_count != 0) {
+            pre_integrations[frame_count]->push_back(dt, linear_acceleration, angular_velocity);
+            tmp_pre_integration->push_back(dt, linear_acceleration, angular_velocity);
+            const int j = frame_count;
+            const V3 un_acc_0 = Rs[j] * (acc_0 - Bas[j]) - g;
+            const V3 un_acc_1 = Rs[j] * (linear_acceleration - Bas[j]) - g;
+            const V3 un_acc = (un_acc_0 + un_acc_1) * 0.5;
+            dP_imu = dP_imu + Vs[j] * dt + un_acc * (0.5 * dt * dt);
+        }
+        acc_0 = linear_acceleration; gyr_0 = angular_velocity;
+    }
+    void processWheel(double t, double dt, V3 linear_velocity, V3 angular_velocity) {  // EST:786-842
+        if (!first_wheel) { first_wheel = true; vel_0_wheel = linear_velocity; gyr_0_wheel = angular_velocity; }
+        if (!pre_integrations_wheel[frame_count]) pre_integrations_wheel[frame_count] = std::make_shared<WheelPre>(vel_0_wheel, gyr_0_wheel, sx, sy, sw, td_wheel);
+        if (frame_count != 0) {
+            pre_integrations_wheel[frame_count]->push_back(dt, linear_velocity, angular_velocity);
+            tmp_wheel_pre_integration->push_back(dt, linear_velocity, angular_velocity);
+            const int j = frame_count;
+            const V3 un_gyr = (gyr_0_wheel + angular_velocity) * 0.5;
+            const V3 un_vel_0 = Rs[j] * latest_vel_wheel_0;
+            if (!systemstationary) {
+                Rs[j] = Rs[j] * qmat(deltaQ(un_gyr * dt));
+                Vs[j] = (Rs[j] * linear_velocity + un_vel_0) * 0.5;
+                Ps[j] = Ps[j] + Vs[j] * dt;
+            }
+            if (systemstationary) Vs[j] = v3(0, 0, 0);
+            latest_vel_wheel_0 = linear_velocity;
+            dP_wheel.x -= dt * Vs[j].y; dP_wheel.y += dt * Vs[j].x; dP_wheel.z -= dt * Vs[j].z;
+        }
+        vel_0_wheel = linear_velocity; gyr_0_wheel = angular_velocity;
+    }
+    int processMeasurements() {  // EST:526-709, single-thread form: one feature frame per call
+        if (featureBuf.empty()) return GF_OK;
+        auto& feature = featureBuf.front();
+        curTime = feature.first + td; curTime_wheel = curTime - td_wheel;
+        if (cfg.use_imu && !(!accBuf.empty() && feature.first + td <= accBuf.back().first)) return GF_OK;                                  // wait for imu
+        if (cfg.use_wheel && !(!wheelVelBuf.empty() && feature.first + td - td_wheel <= wheelVelBuf.back().first)) return GF_OK;           // wait for wheel
+        std::vector<std::pair<double, V3>> accVector, gyrVector, velWheelVector, gyrWheelVector;
+        if (cfg.use_imu) getInterval(accBuf, gyrBuf, prevTime, curTime, accVector, gyrVector);
+        const double header = feature.first;
+        std::vector<gf_feature_obs> image = std::move(feature.second);
+        featureBuf.pop_front();
+        if (cfg.use_wheel) getInterval(wheelVelBuf, wheelGyrBuf, prevTime_wheel, curTime_wheel, velWheelVector, gyrWheelVector);
+        if (cfg.use_imu) {
+            dP_imu = v3(0, 0, 0);
+            if (!initFirstPoseFlag) initFirstIMUPose(accVector);
+            for (size_t i = 0; i < accVector.size(); i++) {
+                double dt;
+                if (i == 0) dt = accVector[i].first - prevTime;
+                else if (i == accVector.size() - 1) dt = curTime - accVector[i - 1].first;
+                else dt = accVector[i].first - accVector[i - 1].first;
+                processIMU(accVector[i].first, dt, accVector[i].second, gyrVector[i].second);
+            }
+        }
+        if (cfg.use_wheel) {
+            dP_wheel = v3(0, 0, 0);
+            for (size_t i = 0; i < velWheelVector.size(); i++) {
+                double dt;
+                if (i == 0) dt = velWheelVector[i].first - prevTime_wheel;
+                else if (i == velWheelVector.size() - 1) dt = curTime_wheel - velWheelVector[i - 1].first;
+                else dt = velWheelVector[i].first - velWheelVector[i - 1].first;
+                processWheel(velWheelVector[i].first, dt, velWheelVector[i].second, gyrWheelVector[i].second);
+            }
+            const double dis = norm(dP_wheel - dP_imu);
+            if (dis > 0.02 && cfg.wdetect) wheelanomaly = true;
+            wheelstationary = norm(dP_wheel) < 0.001;
+            preintegrationstationary = norm(dP_imu) < 0.001;
+        }
+        const int rc = processImage(image, header);
+        prevTime = curTime; prevTime_wheel = curTime_wheel;
+        return rc;
+    }
+
+    // ------------------------------------------------------------ stationarity votes
+    void checkimu() {  // EST:2173-2216 (sum_g is an uninitialised local in the reference; zero here)
+        const int n = (int)all_image_frame.size() - 1;
+        V3 sum_g = v3(0, 0, 0);
+        bool first = true;
+        for (auto& kv : all_image_frame) {
+            if (first) { first = false; continue; }
+            kv.second.pre_integration->eval(imu_noise);
+            sum_g = sum_g + arr3(kv.second.pre_integration->delta_v) / kv.second.pre_integration->sum_dt;
+        }
+        const V3 aver_g = sum_g * 1.0 / (double)n;
+        double var = 0;
+        first = true;
+        for (auto& kv : all_image_frame) {
+            if (first) { first = false; continue; }
+            const V3 tmp_g = arr3(kv.second.pre_integration->delta_v) / kv.second.pre_integration->sum_dt;
+            var += sqn(tmp_g - aver_g);
+        }
+        var = sqrt(var / (double)n);
+        varstationary = var < 0.1;  // NaN (n == 0) compares false, as in the reference
+    }
+    bool checkvisual() {  // EST:2218-2274; solveRelativeRT_PNP always succeeds, its pose is unused
+        for (int i = 0; i < WINDOW_SIZE; i++) {
+            const std::vector<double> corres = f_manager.getCorrespondingWithDepth(i, WINDOW_SIZE);
+            const int nc = (int)(corres.size() / 6);
+            if (nc > 20) {
+                double sum_parallax = 0;
+                for (int j = 0; j < nc; j++) {
+                    const double* c = &corres[6 * j];
+                    const double dx = c[0] / c[2] - c[3] / c[5], dy = c[1] / c[2] - c[4] / c[5];
+                    sum_parallax = sum_parallax + sqrt(dx * dx + dy * dy);
+                }
+                const double average_parallax = 1.0 * sum_parallax / nc;
+                if (average_parallax * 460 < 0.5) return true;
+                visualstationary = false;
+            }
+            visualstationary = false;
+        }
+        return false;
+    }
+
+    // ------------------------------------------------------------ initialisation shortcuts
+    void solveGyroscopeBias() {  // initial/initial_aligment.cpp:14-47
+        double A[9] = {0}, b[3] = {0};
+        for (auto fi = all_image_frame.begin(); std::next(fi) != all_image_frame.end(); ++fi) {
+            auto fj = std::next(fi);
+            ImuPre& p = *fj->second.pre_integration;
+            p.eval(imu_noise);
+            const Q4 q_ij = rot_to_quat(transpose(fi->second.R) * fj->second.R);
+            double tA[9];
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) tA[3 * r + c] = p.jacobian[(3 + r) * 15 + 12 + c];  // block<3,3>(O_R, O_BG)
+            const V3 tb = qvec(qmul(qinverse(Q4{p.delta_q[0], p.delta_q[1], p.delta_q[2], p.delta_q[3]}), q_ij)) * 2.0;
+            const double tbv[3] = {tb.x, tb.y, tb.z};
+            for (int r = 0; r < 3; r++) {
+                for (int c = 0; c < 3; c++) { double s = 0; for (int k = 0; k < 3; k++) s += tA[3 * k + r] * tA[3 * k + c]; A[3 * r + c] += s; }
+                double s = 0; for (int k = 0; k < 3; k++) s += tA[3 * k + r] * tbv[k];
+                b[r] += s;
+            }
+        }
+        // A.ldlt().solve(b) on a symmetric 3x3
+        const double d0 = A[0], l10 = A[3] / d0, l20 = A[6] / d0, d1 = A[4] - l10 * l10 * d0, l21 = (A[7] - l20 * l10 * d0) / d1, d2 = A[8] - l20 * l20 * d0 - l21 * l21 * d1;
+        const double y0 = b[0], y1 = b[1] - l10 * y0, y2 = b[2] - l20 * y0 - l21 * y1;
+        const double z0 = y0 / d0, z1 = y1 / d1, z2 = y2 / d2;
+        const double x2 = z2, x1 = z1 - l21 * x2, x0 = z0 - l10 * x1 - l20 * x2;
+        const V3 delta_bg = v3(x0, x1, x2);
+        for (int i = 0; i <= WINDOW_SIZE; i++) Bgs[i] = Bgs[i] + delta_bg;
+        for (auto fi = all_image_frame.begin(); std::next(fi) != all_image_frame.end(); ++fi) std::next(fi)->second.pre_integration->repropagate(v3(0, 0, 0), Bgs[0]);
+    }
+    bool initialStructure() {  // EST:1557-1682; the SfM / PnP path (EST:1684-1847) is not built -> false
+        V3 aver_g;
+        {
+            const int n = (int)all_image_frame.size() - 1;
+            V3 sum_g = v3(0, 0, 0);
+            bool first = true;
+            for (auto& kv : all_image_frame) { if (first) { first = false; continue; } kv.second.pre_integration->eval(imu_noise); sum_g = sum_g + arr3(kv.second.pre_integration->delta_v) / kv.second.pre_integration->sum_dt; }
+            aver_g = sum_g * 1.0 / (double)n;
+            double var = 0;
+            first = true;
+            for (auto& kv : all_image_frame) { if (first) { first = false; continue; } var += sqn(arr3(kv.second.pre_integration->delta_v) / kv.second.pre_integration->sum_dt - aver_g); }
+            var = sqrt(var / (double)n);
+            if (!(var < 0.35)) is_imu_excited = true;
+        }
+        const V3 G = v3(0, 0, cfg.g_norm);
+        if (!Bas_calibok && systemstationary && solver_flag != NON_LINEAR) {
+            const V3 tmp_Bas = aver_g - transpose(g2R(aver_g)) * G;   // R.inverse() of a rotation
+            for (int i = 0; i <= WINDOW_SIZE; i++) Bas[i] = tmp_Bas;
+            Bas_calibok = true;
+            solveGyroscopeBias();
+            return true;
+        }
+        if (!Bas_calibok && is_imu_excited) {
+            const V3 tmp_Bas = aver_g - transpose(g2R(aver_g)) * G;
+            for (int i = 0; i <= WINDOW_SIZE; i++) Bas[i] = tmp_Bas;
+            Bas_calibok = true;
+            solveGyroscopeBias();
+            M3 R0 = g2R(g);
+            const V3 ypr = R2ypr(R0 * Rs[0]);
+            R0 = ypr2R(v3(-ypr.x, -ypr.y, -ypr.z)) * R0;
+            g = R0 * g;
+            for (int i = 0; i <= frame_count; i++) { Ps[i] = R0 * Ps[i]; Rs[i] = R0 * Rs[i]; Vs[i] = R0 * Vs[i]; }
+            return true;
+        }
+        return false;
+    }
+
+    // ------------------------------------------------------------ processImage
+    int processImage(const std::vector<gf_feature_obs>& image, double header) {  // EST:843-1163
+        marginalization_flag = f_manager.addFeatureCheckParallax(frame_count, image.data(), (int)image.size(), td) ? MARGIN_OLD : MARGIN_SECOND_NEW;
+        Headers[frame_count] = header;
+        ImageFrame imageframe;
+        imageframe.pre_integration = tmp_pre_integration; imageframe.pre_integration_wheel = tmp_wheel_pre_integration;
+        all_image_frame.insert(std::make_pair(header, imageframe));
+        tmp_pre_integration = std::make_shared<ImuPre>(acc_0, gyr_0, Bas[frame_count], Bgs[frame_count]);
+        tmp_wheel_pre_integration = std::make_shared<WheelPre>(vel_0_wheel, gyr_0_wheel, sx, sy, sw, td_wheel);
+        checkimu();
+        imustationary = varstationary && preintegrationstationary;
+        if (checkvisual()) visualstationary = true;
+        systemstationary = (imustationary && wheelstationary) || (visualstationary && wheelstationary) || (imustationary && visualstationary);
+        predict_ids.clear(); predict_xyz.clear(); remove_ids.clear();
+
+        if (solver_flag == INITIAL) {
+            if (frame_count == WINDOW_SIZE) {  // DEPTH && USE_IMU branch, EST:967-1037
+                int i = 0;
+                for (auto& kv : all_image_frame) { if (i <= WINDOW_SIZE) { kv.second.R = Rs[i]; kv.second.T = Ps[i]; } i++; }
+                bool result = false;
+                if (header - initial_timestamp > 0.1) { result = initialStructure(); initial_timestamp = header; }
+                if (result) {
+                    solveGyroscopeBias();
+                    for (int k = 0; k <= WINDOW_SIZE; k++) pre_integrations[k]->repropagate(v3(0, 0, 0), Bgs[k]);
+                    solver_flag = NON_LINEAR;
+                    if (int rc = optimization()) return rc;
+                    slideWindow();
+                } else {
+                    if (int rc = optimization()) return rc;
+                    slideWindow();
+                }
+            }
+            if (frame_count < WINDOW_SIZE) {
+                frame_count++;
+                const int prev = frame_count - 1;
+                Ps[frame_count] = Ps[prev]; Vs[frame_count] = Vs[prev]; Rs[frame_count] = Rs[prev]; Bas[frame_count] = Bas[prev]; Bgs[frame_count] = Bgs[prev];
+            }
+        } else {
+            f_manager.triangulateWithDepth(Ps.data(), Rs.data(), tic, ric);   // DEPTH, EST:1086-1089
+            f_manager.triangulate(Ps.data(), Rs.data(), tic, ric);            // EST:1101
+            std::set<int> removeIndex;
+            if (cfg.use_mcc) { movingConsistencyCheckW(removeIndex); f_manager.removeOutlier(removeIndex); }
+            if (int rc = optimization()) return rc;
+            if (!cfg.use_mcc) { std::set<int> inner; movingConsistencyCheckW(inner); f_manager.removeOutlier(inner); }  // shadowing set, SURVEY.md quirk 13
+            if (!cfg.multiple_thread) {
+                remove_ids.assign(removeIndex.begin(), removeIndex.end());
+                predictPtsInNextFrame();
+                if (tracker) {
+                    if (int rc = gf_tracker_remove_outliers(tracker, 0, remove_ids.data(), (int)remove_ids.size())) return rc;
+                    if (int rc = gf_tracker_set_prediction(tracker, 0, predict_ids.data(), predict_xyz.data(), (int)predict_ids.size())) return rc;
+                }
+            }
+            slideWindow();
+            f_manager.removeFailures();
+            last_R = Rs[WINDOW_SIZE]; last_P = Ps[WINDOW_SIZE]; last_R0 = Rs[0]; last_P0 = Ps[0];
+        }
+        return GF_OK;
+    }
+
+    // ------------------------------------------------------------ optimisation
+    void vector2double() {  // EST:2276-2353
+        for (int i = 0; i <= WINDOW_SIZE; i++) {
+            double* p = &para_Pose[7 * i];
+            p[0] = Ps[i].x; p[1] = Ps[i].y; p[2] = Ps[i].z;
+            const Q4 q = rot_to_quat(Rs[i]);
+            p[3] = q.x; p[4] = q.y; p[5] = q.z; p[6] = q.w;
+            double* s = &para_SpeedBias[9 * i];
+            s[0] = Vs[i].x; s[1] = Vs[i].y; s[2] = Vs[i].z; s[3] = Bas[i].x; s[4] = Bas[i].y; s[5] = Bas[i].z; s[6] = Bgs[i].x; s[7] = Bgs[i].y; s[8] = Bgs[i].z;
+        }
+        Q4 q = rot_to_quat(ric);
+        para_Ex_Pose[0] = tic.x; para_Ex_Pose[1] = tic.y; para_Ex_Pose[2] = tic.z; para_Ex_Pose[3] = q.x; para_Ex_Pose[4] = q.y; para_Ex_Pose[5] = q.z; para_Ex_Pose[6] = q.w;
+        q = rot_to_quat(rio);
+        para_Ex_Pose_wheel[0] = tio.x; para_Ex_Pose_wheel[1] = tio.y; para_Ex_Pose_wheel[2] = tio.z;
+        para_Ex_Pose_wheel[3] = q.x; para_Ex_Pose_wheel[4] = q.y; para_Ex_Pose_wheel[5] = q.z; para_Ex_Pose_wheel[6] = q.w;
+        para_Ix[0] = sx; para_Ix[1] = sy; para_Ix[2] = sw;
+        std::vector<double> dep;
+        f_manager.getDepthVector(dep);
+        if (dep.size() > para_Feature.size()) para_Feature.resize(dep.size());
+        std::copy(dep.begin(), dep.end(), para_Feature.begin());
+        para_Td[0] = td; para_Td_wheel[0] = td_wheel;
+    }
+    int double2vector() {  // EST:2440-2569
+        std::vector<double> R(9 * (WINDOW_SIZE + 1)), P(3 * (WINDOW_SIZE + 1)), V(P.size()), Ba(P.size()), Bg(P.size());
+        if (int rc = gf_ba_double2vector(WINDOW_SIZE, Rs[0].m, &Ps[0].x, para_Pose.data(), para_SpeedBias.data(), R.data(), P.data(), V.data(), Ba.data(), Bg.data())) return rc;
+        for (int i = 0; i <= WINDOW_SIZE; i++) { Rs[i] = arr9(&R[9 * i]); Ps[i] = arr3(&P[3 * i]); Vs[i] = arr3(&V[3 * i]); Bas[i] = arr3(&Ba[3 * i]); Bgs[i] = arr3(&Bg[3 * i]); }
+        tic = arr3(para_Ex_Pose); ric = qmat(Q4{para_Ex_Pose[6], para_Ex_Pose[3], para_Ex_Pose[4], para_Ex_Pose[5]});
+        if (cfg.use_wheel) {
+            tio = arr3(para_Ex_Pose_wheel);
+            rio = qmat(qnormalized(Q4{para_Ex_Pose_wheel[6], para_Ex_Pose_wheel[3], para_Ex_Pose_wheel[4], para_Ex_Pose_wheel[5]}));
+            sx = para_Ix[0]; sy = para_Ix[1]; sw = para_Ix[2]; td_wheel = para_Td_wheel[0];
+        }
+        f_manager.setDepth(para_Feature.data());
+        td = para_Td[0];
+        return GF_OK;
+    }
+    int optimization() {  // EST:2890-3636
+        if (!ba) {
+            gf_ba_cfg bc{WINDOW_SIZE, cfg.max_features, cfg.max_visual, 1};
+            if (int rc = gf_ba_create(&bc, &ba)) return rc;
+        }
+        vector2double();
+        gf_ba_window w;
+        memset(&w, 0, sizeof(w));
+        w.W = WINDOW_SIZE; w.G[0] = g.x; w.G[1] = g.y; w.G[2] = g.z; w.vis_sqrt_info = cfg.focal_length / 1.5;
+        const bool moving = norm(Vs[0]) > 0.2;
+        if ((cfg.estimate_extrinsic && frame_count == WINDOW_SIZE && moving) || openExEstimation) openExEstimation = 1; else w.fix_ex_pose = 1;            // EST:2990-2999
+        const bool wheel_on = cfg.use_wheel && !cfg.only_initial_with_wheel;
+        if (wheel_on) {
+            if ((cfg.estimate_wheel_extrinsic && frame_count == WINDOW_SIZE && moving) || openExWheelEstimation) openExWheelEstimation = 1; else w.fix_ex_wheel = 1;  // :3032-3041
+            if ((cfg.estimate_wheel_intrinsic && frame_count == WINDOW_SIZE && moving) || openIxEstimation) openIxEstimation = 1; else w.fix_ix = 1;                 // :3045-3056
+        } else { w.fix_ex_wheel = 1; w.fix_ix = 1; }
+        w.fix_td = (!cfg.estimate_td || norm(Vs[0]) < 0.2) ? 1 : 0;                                                                                      // :3097-3100
+        w.fix_td_wheel = (!cfg.estimate_td_wheel || norm(Vs[0]) < 0.2) ? 1 : 0;
+        // IMU factors :3109-3119
+        std::vector<int> imu_i, wh_i;
+        std::vector<double> imu_sum_dt, imu_dp, imu_dq, imu_dv, imu_ba, imu_bg, imu_J, imu_P;
+        for (int i = 0; i < frame_count; i++) {
+            ImuPre& p = *pre_integrations[i + 1];
+            if (int rc = p.eval(imu_noise)) return rc;
+            if (p.sum_dt > 10.0) continue;
+            imu_i.push_back(i); imu_sum_dt.push_back(p.sum_dt);
+            imu_dp.insert(imu_dp.end(), p.delta_p, p.delta_p + 3); imu_dq.insert(imu_dq.end(), p.delta_q, p.delta_q + 4); imu_dv.insert(imu_dv.end(), p.delta_v, p.delta_v + 3);
+            imu_ba.insert(imu_ba.end(), {p.lin_ba.x, p.lin_ba.y, p.lin_ba.z}); imu_bg.insert(imu_bg.end(), {p.lin_bg.x, p.lin_bg.y, p.lin_bg.z});
+            imu_J.insert(imu_J.end(), p.jacobian.begin(), p.jacobian.end()); imu_P.insert(imu_P.end(), p.covariance.begin(), p.covariance.end());
+        }
+        // wheel factors :3120-3151
+        std::vector<double> wh_sum_dt, wh_dp, wh_dq, wh_J, wh_P, wh_lin, wh_lv, wh_lg, wh_v1, wh_g1;
+        if (wheel_on)
+            for (int i = 0; i < frame_count; i++) {
+                WheelPre& p = *pre_integrations_wheel[i + 1];
+                if (int rc = p.eval(wheel_noise)) return rc;
+                if (p.sum_dt > 10.0) continue;
+                if (cfg.wdetect && wheelanomaly) continue;
+                wh_i.push_back(i); wh_sum_dt.push_back(p.sum_dt);
+                wh_dp.insert(wh_dp.end(), p.delta_p, p.delta_p + 3); wh_dq.insert(wh_dq.end(), p.delta_q, p.delta_q + 4);
+                wh_J.insert(wh_J.end(), p.jacobian, p.jacobian + 18); wh_P.insert(wh_P.end(), p.covariance, p.covariance + 36); wh_lin.insert(wh_lin.end(), p.lin, p.lin + 4);
+                const V3 v1 = p.vel_1(), g1 = p.gyr_1();
+                wh_lv.insert(wh_lv.end(), {p.vel0.x, p.vel0.y, p.vel0.z}); wh_lg.insert(wh_lg.end(), {p.gyr0.x, p.gyr0.y, p.gyr0.z});
+                wh_v1.insert(wh_v1.end(), {v1.x, v1.y, v1.z}); wh_g1.insert(wh_g1.end(), {g1.x, g1.y, g1.z});
+            }
+        // stationary: zero the velocities, hold every pose / speed-bias block :3233-3246
+        if (systemstationary && cfg.stationary_detect) {
+            for (int i = 0; i <= WINDOW_SIZE; i++) { para_SpeedBias[9 * i] = 0; para_SpeedBias[9 * i + 1] = 0; para_SpeedBias[9 * i + 2] = 0; }
+            w.fix_poses = 1;
+        }
+        // visual factors :3262-3297
+        std::vector<int> vf, vi, vj; std::vector<double> vpi, vpj, vvi, vvj, vti, vtj; std::vector<unsigned char> fixed;
+        int feature_index = -1;
+        for (auto& it : f_manager.feature) {
+            it.used_num = (int)it.feature_per_frame.size();
+            if (it.used_num < 4) continue;
+            ++feature_index;
+            fixed.push_back(it.estimate_flag == 1 ? 1 : 0);
+            const int imu_i_ = it.start_frame; int imu_j_ = imu_i_ - 1;
+            const FeaturePerFrame& f0 = it.feature_per_frame[0];
+            for (auto& fr : it.feature_per_frame) {
+                imu_j_++;
+                if (imu_i_ == imu_j_) continue;
+                vf.push_back(feature_index); vi.push_back(imu_i_); vj.push_back(imu_j_);
+                vpi.insert(vpi.end(), {f0.point.x, f0.point.y, f0.point.z}); vpj.insert(vpj.end(), {fr.point.x, fr.point.y, fr.point.z});
+                vvi.insert(vvi.end(), {f0.velocity[0], f0.velocity[1]}); vvj.insert(vvj.end(), {fr.velocity[0], fr.velocity[1]});
+                vti.push_back(f0.cur_td); vtj.push_back(fr.cur_td);
+            }
+        }
+        const int nf = feature_index + 1;
+        if (nf > cfg.max_features || (int)vf.size() > cfg.max_visual)
+            return gf::set_err(GF_ERR_CAPACITY, "window has %d features / %d visual factors, capacity %d / %d", nf, (int)vf.size(), cfg.max_features, cfg.max_visual);
+        w.n_feature = nf; w.n_visual = (int)vf.size(); w.n_imu = (int)imu_i.size(); w.n_wheel = (int)wh_i.size();
+        w.para_Pose = para_Pose.data(); w.para_SpeedBias = para_SpeedBias.data(); w.para_Ex_Pose = para_Ex_Pose; w.para_Ex_Pose_wheel = para_Ex_Pose_wheel;
+        w.para_Ix = para_Ix; w.para_Td = para_Td; w.para_Td_wheel = para_Td_wheel; w.para_Feature = para_Feature.data(); w.feature_fixed = fixed.data();
+        w.vis_feature = vf.data(); w.vis_i = vi.data(); w.vis_j = vj.data(); w.vis_pts_i = vpi.data(); w.vis_pts_j = vpj.data(); w.vis_vel_i = vvi.data(); w.vis_vel_j = vvj.data();
+        w.vis_td_i = vti.data(); w.vis_td_j = vtj.data();
+        w.imu_i = imu_i.data(); w.imu_sum_dt = imu_sum_dt.data(); w.imu_delta_p = imu_dp.data(); w.imu_delta_q = imu_dq.data(); w.imu_delta_v = imu_dv.data();
+        w.imu_lin_ba = imu_ba.data(); w.imu_lin_bg = imu_bg.data(); w.imu_jacobian = imu_J.data(); w.imu_covariance = imu_P.data();
+        w.wh_i = wh_i.data(); w.wh_sum_dt = wh_sum_dt.data(); w.wh_delta_p = wh_dp.data(); w.wh_delta_q = wh_dq.data(); w.wh_jacobian = wh_J.data(); w.wh_covariance = wh_P.data();
+        w.wh_lin = wh_lin.data(); w.wh_lin_vel = wh_lv.data(); w.wh_lin_gyr = wh_lg.data(); w.wh_vel_1 = wh_v1.data(); w.wh_gyr_1 = wh_g1.data();
+        if (prior_valid) { w.prior_n = prior_n; w.prior_nblocks = (int)prior_block_id.size(); w.prior_block_id = prior_block_id.data(); w.prior_J = prior_J.data(); w.prior_r = prior_r.data(); w.prior_x0 = prior_x0.data(); }
+        if (int rc = gf_ba_solve(ba, &w, 1, cfg.num_iterations, &last_summary)) return rc;   // ceres::Solve, EST:3303-3318
+        n_optimizations++;
+        if (int rc = double2vector()) return rc;                                            // :3327
+        if (frame_count < WINDOW_SIZE) { wheelanomaly = false; return GF_OK; }
+        bool run_marg = marginalization_flag == MARGIN_OLD;
+        if (!run_marg) {  // :3538-3539: only when the prior mentions the second-newest pose
+            run_marg = prior_valid && std::count(prior_block_id.begin(), prior_block_id.end(), GF_POSE * 4096 + WINDOW_SIZE - 1) > 0;
+            // the reference tests last_marginalization_info != nullptr only; an invalid info still owns its block list
+        }
+        if (run_marg) {
+            vector2double();                                                                // :3337 / :3543
+            if (systemstationary && cfg.stationary_detect) { /* para_SpeedBias already refreshed from Vs by vector2double */ }
+            const int cap_n = 16 * (WINDOW_SIZE + 1) + 64, cap_b = 2 * (WINDOW_SIZE + 1) + 16;
+            std::vector<double> pJ((size_t)cap_n * cap_n), pr(cap_n), px0(16 * (WINDOW_SIZE + 1) + 64); std::vector<int> pid(cap_b);
+            gf_ba_prior p{};
+            p.cap_n = cap_n; p.cap_blocks = cap_b; p.block_id = pid.data(); p.J = pJ.data(); p.r = pr.data(); p.x0 = px0.data();
+            if (int rc = gf_ba_marginalize(ba, &w, 1, marginalization_flag, &p)) return rc;
+            prior_valid = p.valid != 0;
+            if (p.valid) {
+                prior_n = p.n;
+                prior_block_id.assign(pid.begin(), pid.begin() + p.nblocks);
+                prior_J.assign(pJ.begin(), pJ.begin() + (size_t)p.n * p.n); prior_r.assign(pr.begin(), pr.begin() + p.n);
+                int gs = 0;
+                for (int id : prior_block_id) { const int k = id / 4096; gs += (k == GF_POSE || k == GF_EX_POSE || k == GF_EX_WHEEL) ? 7 : k == GF_SPEEDBIAS ? 9 : 1; }
+                prior_x0.assign(px0.begin(), px0.begin() + gs);
+            }
+        }
+        wheelanomaly = false;   // :3633
+        return GF_OK;
+    }
+
+    // ------------------------------------------------------------ window bookkeeping
+    void slideWindow() {  // EST:3638-3790
+        if (marginalization_flag == MARGIN_OLD) {
+            const double t_0 = Headers[0];
+            back_R0 = Rs[0]; back_P0 = Ps[0];
+            if (frame_count != WINDOW_SIZE) return;
+            for (int i = 0; i < WINDOW_SIZE; i++) {
+                Headers[i] = Headers[i + 1];
+                std::swap(Rs[i], Rs[i + 1]); std::swap(Ps[i], Ps[i + 1]);
+                std::swap(pre_integrations[i], pre_integrations[i + 1]);
+                std::swap(Vs[i], Vs[i + 1]); std::swap(Bas[i], Bas[i + 1]); std::swap(Bgs[i], Bgs[i + 1]);
+                if (cfg.use_wheel) std::swap(pre_integrations_wheel[i], pre_integrations_wheel[i + 1]);
+            }
+            Headers[WINDOW_SIZE] = Headers[WINDOW_SIZE - 1]; Ps[WINDOW_SIZE] = Ps[WINDOW_SIZE - 1]; Rs[WINDOW_SIZE] = Rs[WINDOW_SIZE - 1];
+            Vs[WINDOW_SIZE] = Vs[WINDOW_SIZE - 1]; Bas[WINDOW_SIZE] = Bas[WINDOW_SIZE - 1]; Bgs[WINDOW_SIZE] = Bgs[WINDOW_SIZE - 1];
+            pre_integrations[WINDOW_SIZE] = std::make_shared<ImuPre>(acc_0, gyr_0, Bas[WINDOW_SIZE], Bgs[WINDOW_SIZE]);
+            if (cfg.use_wheel) pre_integrations_wheel[WINDOW_SIZE] = std::make_shared<WheelPre>(vel_0_wheel, gyr_0_wheel, sx, sy, sw, td_wheel);
+            auto it_0 = all_image_frame.find(t_0);
+            if (it_0 != all_image_frame.end()) { it_0->second.pre_integration.reset(); it_0->second.pre_integration_wheel.reset(); all_image_frame.erase(all_image_frame.begin(), it_0); }
+            slideWindowOld();
+        } else {
+            if (frame_count != WINDOW_SIZE) return;
+            Headers[frame_count - 1] = Headers[frame_count]; Ps[frame_count - 1] = Ps[frame_count]; Rs[frame_count - 1] = Rs[frame_count];
+            {
+                if (pre_integrations[frame_count] && pre_integrations[frame_count - 1]) {  // always true once IMU data arrived for the newest frame
+                    ImuPre& src = *pre_integrations[frame_count]; ImuPre& dst = *pre_integrations[frame_count - 1];
+                    for (size_t i = 0; i < src.dt.size(); i++) dst.push_back(src.dt[i], arr3(&src.acc[3 * i]), arr3(&src.gyr[3 * i]));
+                }
+                Vs[frame_count - 1] = Vs[frame_count]; Bas[frame_count - 1] = Bas[frame_count]; Bgs[frame_count - 1] = Bgs[frame_count];
+                pre_integrations[WINDOW_SIZE] = std::make_shared<ImuPre>(acc_0, gyr_0, Bas[WINDOW_SIZE], Bgs[WINDOW_SIZE]);
+            }
+            if (cfg.use_wheel) {
+                if (pre_integrations_wheel[frame_count] && pre_integrations_wheel[frame_count - 1]) {
+                    WheelPre& src = *pre_integrations_wheel[frame_count]; WheelPre& dst = *pre_integrations_wheel[frame_count - 1];
+                    for (size_t i = 0; i < src.dt.size(); i++) dst.push_back(src.dt[i], arr3(&src.vel[3 * i]), arr3(&src.gyr[3 * i]));
+                }
+                pre_integrations_wheel[WINDOW_SIZE] = std::make_shared<WheelPre>(vel_0_wheel, gyr_0_wheel, sx, sy, sw, td_wheel);
+            }
+            sum_of_front++;
+            f_manager.removeFront(frame_count);   // slideWindowNew, EST:3792-3802
+        }
+    }
+    void slideWindowOld() {  // EST:3804-3837
+        sum_of_back++;
+        if (solver_flag == NON_LINEAR) {
+            const M3 R0 = back_R0 * ric, R1 = Rs[0] * ric;
+            const V3 P0 = back_P0 + back_R0 * tic, P1 = Ps[0] + Rs[0] * tic;
+            f_manager.removeBackShiftDepth(R0, P0, R1, P1);
+        } else f_manager.removeBack();
+    }
+    double reprojectionError(const M3& Ri, V3 Pi, const M3& Rj, V3 Pj, double depth, V3 uvi, V3 uvj) const {  // EST:3899-3910
+        const V3 pts_w = Ri * (ric * (uvi * depth) + tic) + Pi;
+        const V3 pts_cj = transpose(ric) * (transpose(Rj) * (pts_w - Pj) - tic);
+        const double rx = pts_cj.x / pts_cj.z - uvj.x, ry = pts_cj.y / pts_cj.z - uvj.y;
+        return sqrt(rx * rx + ry * ry);
+    }
+    double reprojectionError3D(const M3& Ri, V3 Pi, const M3& Rj, V3 Pj, double depth, V3 uvi, V3 uvj) const {  // EST:3912-3919
+        const V3 pts_w = Ri * (ric * (uvi * depth) + tic) + Pi;
+        const V3 pts_cj = transpose(ric) * (transpose(Rj) * (pts_w - Pj) - tic);
+        return norm(pts_cj - uvj) / depth;
+    }
+    void movingConsistencyCheckW(std::set<int>& removeIndex) {  // EST:3955-3995
+        for (auto& it : f_manager.feature) {
+            it.used_num = (int)it.feature_per_frame.size();
+            if (!(it.used_num >= 2 && it.start_frame < WINDOW_SIZE - 2)) continue;
+            const double depth = it.estimated_depth;
+            if (depth < 0) continue;
+            double err = 0, err3D = 0; int errCnt = 0;
+            const int wi = it.start_frame; int wj = wi - 1;
+            const V3 pts_i = it.feature_per_frame[0].point;
+            for (auto& fr : it.feature_per_frame) {
+                wj++;
+                if (wi == wj) continue;
+                err += reprojectionError(Rs[wi], Ps[wi], Rs[wj], Ps[wj], depth, pts_i, fr.point);
+                err3D += reprojectionError3D(Rs[wi], Ps[wi], Rs[wj], Ps[wj], depth, pts_i, fr.point);
+                errCnt++;
+            }
+            if (errCnt > 0 && (cfg.focal_length * err / errCnt > 10 || err3D / errCnt > 2.0)) removeIndex.insert(it.feature_id);
+        }
+    }
+    void predictPtsInNextFrame() {  // EST:3862-3897; nextT = curT * (prevT^-1 * curT) on rigid transforms
+        if (frame_count < 2) return;
+        const M3 Rc = Rs[frame_count], Rp = Rs[frame_count - 1];
+        const V3 Pc = Ps[frame_count], Pp = Ps[frame_count - 1];
+        const M3 Rrel = transpose(Rp) * Rc; const V3 Prel = transpose(Rp) * (Pc - Pp);
+        const M3 Rn = Rc * Rrel; const V3 Pn = Rc * Prel + Pc;
+        std::map<int, V3> predictPts;
+        for (auto& it : f_manager.feature) {
+            if (!(it.estimated_depth > 0)) continue;
+            const int firstIndex = it.start_frame, lastIndex = it.start_frame + (int)it.feature_per_frame.size() - 1;
+            if ((int)it.feature_per_frame.size() >= 2 && lastIndex == frame_count) {
+                const V3 pts_j = ric * (it.feature_per_frame[0].point * it.estimated_depth) + tic;
+                const V3 pts_w = Rs[firstIndex] * pts_j + Ps[firstIndex];
+                const V3 pts_local = transpose(Rn) * (pts_w - Pn);
+                predictPts[it.feature_id] = transpose(ric) * (pts_local - tic);
+            }
+        }
+        for (auto& kv : predictPts) { predict_ids.push_back(kv.first); predict_xyz.insert(predict_xyz.end(), {kv.second.x, kv.second.y, kv.second.z}); }
+    }
+};
+
+// ---------------------------------------------------------------- C-ABI
+extern "C" {
+
+int gf_estimator_default_cfg(gf_estimator_cfg* c) {
+    if (!c) return gf::set_err(GF_ERR_INVALID, "null cfg");
+    memset(c, 0, sizeof(*c));
+    c->window_size = 10; c->max_features = 512; c->max_visual = 4096;
+    c->use_imu = 1; c->use_wheel = 1; c->depth = 1;                                     // m2dgrp.yaml:4-6
+    c->estimate_extrinsic = 0; c->estimate_wheel_extrinsic = 1; c->estimate_wheel_intrinsic = 0; c->estimate_td = 0; c->estimate_td_wheel = 0;
+    c->use_mcc = 0; c->wdetect = 1; c->stationary_detect = 1; c->only_initial_with_wheel = 0; c->multiple_thread = 1;
+    c->num_iterations = 8;
+    c->acc_n = 1.2374091609523514e-02; c->gyr_n = 3.0032654435730201e-03; c->acc_w = 1.9218003442176448e-04; c->gyr_w = 5.4692100664858005e-05;
+    c->g_norm = 9.805; c->wheel_vel_n = 0.01; c->wheel_gyr_n = 0.004;
+    c->min_parallax_px = 10.0; c->depth_threshold = 3.0; c->init_depth = 5.0; c->focal_length = 600.0;
+    c->sx = c->sy = c->sw = 1.0;
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    memcpy(c->ric, I, sizeof(I));
+    const double rio[9] = {0.352551, -0.935764, -0.00734672, 0.0145238, 0.0133214, -0.999806, 0.93568, 0.352375, 0.0182873};   // body_T_wheel, m2dgrp.yaml:107-114
+    const double tio[3] = {0.0497956, 1.06332, -0.037465};
+    memcpy(c->rio, rio, sizeof(rio)); memcpy(c->tio, tio, sizeof(tio));
+    return GF_OK;
+}
+
+int gf_estimator_create(const gf_estimator_cfg* c, gf_estimator** out) {
+    if (!c || !out) return gf::set_err(GF_ERR_INVALID, "null argument");
+    if (c->window_size < 2 || c->window_size > 19) return gf::set_err(GF_ERR_INVALID, "window_size must be in [2, 19]");
+    if (!c->use_imu || !c->depth) return gf::set_err(GF_ERR_INVALID, "only the RGB-D + IMU configuration is built (USE_IMU=1, DEPTH=1)");
+    if (c->estimate_extrinsic == 2) return gf::set_err(GF_ERR_INVALID, "ESTIMATE_EXTRINSIC=2 (online rotation calibration) is not built");
+    gf_estimator* e = new gf_estimator(*c);
+    if (c->with_tracker) {
+        gf_tracker_cfg tc = c->tracker; tc.batch = 1;
+        if (int rc = gf_tracker_create(&tc, &e->tracker)) { delete e; return rc; }
+    }
+    *out = e;
+    return GF_OK;
+}
+int gf_estimator_destroy(gf_estimator* e) { delete e; return GF_OK; }
+
+int gf_estimator_input_imu(gf_estimator* e, double t, const double* acc, const double* gyr) {  // Estimator::inputIMU EST:330-346
+    if (!e || !acc || !gyr) return gf::set_err(GF_ERR_INVALID, "null argument");
+    e->accBuf.emplace_back(t, arr3(acc)); e->gyrBuf.emplace_back(t, arr3(gyr));
+    return GF_OK;
+}
+int gf_estimator_input_wheel(gf_estimator* e, double t, const double* vel, const double* gyr) {  // Estimator::inputWheel EST:347-360
+    if (!e || !vel || !gyr) return gf::set_err(GF_ERR_INVALID, "null argument");
+    e->wheelVelBuf.emplace_back(t, arr3(vel)); e->wheelGyrBuf.emplace_back(t, arr3(gyr));
+    return GF_OK;
+}
+// Estimator::inputFeature (EST:362-375) + processMeasurements: `obs` is the tracker's map flattened in id order
+int gf_estimator_input_feature(gf_estimator* e, double t, const gf_feature_obs* obs, int n) {
+    if (!e || (n > 0 && !obs) || n < 0) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    std::vector<gf_feature_obs> v(obs, obs + n);
+    std::stable_sort(v.begin(), v.end(), [](const gf_feature_obs& a, const gf_feature_obs& b) { return a.id < b.id; });
+    e->featureBuf.emplace_back(t, std::move(v));
+    return e->processMeasurements();
+}
+// Estimator::inputImage (EST:213-242): track, then (multiple_thread: every second frame) hand the features to the back end
+int gf_estimator_input_image(gf_estimator* e, double t, const uint8_t* gray, int stride, const uint16_t* depth, int dstride, gf_feature_obs* out, int cap, int* n_out) {
+    if (!e || !e->tracker) return gf::set_err(GF_ERR_INVALID, "estimator was created without a tracker (cfg.with_tracker)");
+    std::vector<gf_feature_obs> tmp;
+    if (!out) { cap = e->cfg.tracker.max_cnt + 8; tmp.resize(cap); out = tmp.data(); }
+    int n = 0;
+    if (int rc = gf_tracker_track(e->tracker, 0, t, gray, stride, depth, dstride, out, cap, &n)) return rc;
+    if (n_out) *n_out = n;
+    e->inputImageCnt++;
+    if (e->cfg.multiple_thread && e->inputImageCnt % 2 != 0) return GF_OK;
+    return gf_estimator_input_feature(e, t, out, n);
+}
+
+int gf_estimator_get_state(gf_estimator* e, double* Ps, double* Rs, double* Vs, double* Bas, double* Bgs, double* Headers, int* info, double* extr) {
+    if (!e) return gf::set_err(GF_ERR_INVALID, "null handle");
+    for (int i = 0; i <= e->WINDOW_SIZE; i++) {
+        if (Ps) memcpy(Ps + 3 * i, &e->Ps[i].x, 24);
+        if (Rs) memcpy(Rs + 9 * i, e->Rs[i].m, 72);
+        if (Vs) memcpy(Vs + 3 * i, &e->Vs[i].x, 24);
+        if (Bas) memcpy(Bas + 3 * i, &e->Bas[i].x, 24);
+        if (Bgs) memcpy(Bgs + 3 * i, &e->Bgs[i].x, 24);
+        if (Headers) Headers[i] = e->Headers[i];
+    }
+    if (info) {
+        const int v[16] = {e->frame_count, e->solver_flag, e->marginalization_flag, (int)e->f_manager.feature.size(), e->prior_valid ? 1 : 0, e->prior_valid ? e->prior_n : 0,
+                           e->systemstationary ? 1 : 0, e->last_summary.iterations, e->last_summary.successful_steps, (int)e->n_optimizations, e->openExWheelEstimation,
+                           e->f_manager.last_track_num, e->f_manager.long_track_num, e->f_manager.new_feature_num, e->sum_of_back, e->sum_of_front};
+        memcpy(info, v, sizeof(v));
+    }
+    if (extr) {
+        memcpy(extr, &e->tic.x, 24); memcpy(extr + 3, e->ric.m, 72); memcpy(extr + 12, &e->tio.x, 24); memcpy(extr + 15, e->rio.m, 72);
+        extr[24] = e->sx; extr[25] = e->sy; extr[26] = e->sw; extr[27] = e->td; extr[28] = e->td_wheel; extr[29] = e->last_summary.initial_cost; extr[30] = e->last_summary.final_cost;
+        extr[31] = e->f_manager.last_average_parallax;
+    }
+    return GF_OK;
+}
+int gf_estimator_set_state(gf_estimator* e, int frame_count, int solver_flag, const double* Ps, const double* Rs, const double* Vs, const double* Bas, const double* Bgs) {
+    if (!e || frame_count < 0 || frame_count > e->WINDOW_SIZE) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    e->frame_count = frame_count; e->solver_flag = solver_flag;
+    for (int i = 0; i <= e->WINDOW_SIZE; i++) {
+        if (Ps) e->Ps[i] = arr3(Ps + 3 * i);
+        if (Rs) e->Rs[i] = arr9(Rs + 9 * i);
+        if (Vs) e->Vs[i] = arr3(Vs + 3 * i);
+        if (Bas) e->Bas[i] = arr3(Bas + 3 * i);
+        if (Bgs) e->Bgs[i] = arr3(Bgs + 3 * i);
+    }
+    return GF_OK;
+}
+int gf_estimator_get_features(gf_estimator* e, int cap, int* id, int* start_frame, int* n_obs, double* estimated_depth, int* estimate_flag, int* solve_flag, int* n) {
+    if (!e || !n) return gf::set_err(GF_ERR_INVALID, "null argument");
+    *n = (int)e->f_manager.feature.size();
+    if (*n > cap) return gf::set_err(GF_ERR_CAPACITY, "%d features, capacity %d", *n, cap);
+    int k = 0;
+    for (auto& it : e->f_manager.feature) {
+        if (id) id[k] = it.feature_id;
+        if (start_frame) start_frame[k] = it.start_frame;
+        if (n_obs) n_obs[k] = (int)it.feature_per_frame.size();
+        if (estimated_depth) estimated_depth[k] = it.estimated_depth;
+        if (estimate_flag) estimate_flag[k] = it.estimate_flag;
+        if (solve_flag) solve_flag[k] = it.solve_flag;
+        k++;
+    }
+    return GF_OK;
+}
+int gf_estimator_get_feedback(gf_estimator* e, int cap, int* predict_ids, double* predict_xyz, int* n_predict, int* remove_ids, int* n_remove) {
+    if (!e || !n_predict || !n_remove) return gf::set_err(GF_ERR_INVALID, "null argument");
+    *n_predict = (int)e->predict_ids.size(); *n_remove = (int)e->remove_ids.size();
+    if (*n_predict > cap || *n_remove > cap) return gf::set_err(GF_ERR_CAPACITY, "feedback lists need capacity %d", std::max(*n_predict, *n_remove));
+    if (predict_ids) std::copy(e->predict_ids.begin(), e->predict_ids.end(), predict_ids);
+    if (predict_xyz) std::copy(e->predict_xyz.begin(), e->predict_xyz.end(), predict_xyz);
+    if (remove_ids) std::copy(e->remove_ids.begin(), e->remove_ids.end(), remove_ids);
+    return GF_OK;
+}
+int gf_estimator_get_prior(gf_estimator* e, int cap_n, int cap_blocks, int* n, int* nblocks, int* block_id, double* J, double* r) {
+    if (!e || !n || !nblocks) return gf::set_err(GF_ERR_INVALID, "null argument");
+    *n = e->prior_valid ? e->prior_n : 0; *nblocks = e->prior_valid ? (int)e->prior_block_id.size() : 0;
+    if (*n > cap_n || *nblocks > cap_blocks) return gf::set_err(GF_ERR_CAPACITY, "prior is %d x %d with %d blocks", *n, *n, *nblocks);
+    if (block_id) std::copy(e->prior_block_id.begin(), e->prior_block_id.begin() + *nblocks, block_id);
+    if (J && *n) std::copy(e->prior_J.begin(), e->prior_J.begin() + (size_t)*n * *n, J);
+    if (r && *n) std::copy(e->prior_r.begin(), e->prior_r.begin() + *n, r);
+    return GF_OK;
+}
+
+// Host-only pieces of the estimator, callable one by one (tests; none of these touches the GPU):
+//   "triangulate", "triangulateWithDepth", "removeBack", "removeFront" (in: frame_count), "removeFailures", "removeBackShiftDepth" (in: R0 9, P0 3, R1 9, P1 3),
+//   "movingConsistencyCheckW" (out: ids), "predictPtsInNextFrame" (out: id,x,y,z ...), "slideWindow" (in: marginalization_flag), "setDepth" (in: inverse depths),
+//   "getDepthVector" (out), "addFeature" (in: frame_count, td, then n x (id, 8 values); out: keyframe flag), "checkvisual" (out: flag), "getFeatureCount" (out)
+int gf_estimator_debug(gf_estimator* e, const char* op, const double* in, int n_in, double* out, int cap_out, int* n_out) {
+    if (!e || !op) return gf::set_err(GF_ERR_INVALID, "null argument");
+    std::vector<double> o;
+    const std::string s(op);
+    if (s == "triangulate") e->f_manager.triangulate(e->Ps.data(), e->Rs.data(), e->tic, e->ric);
+    else if (s == "triangulateWithDepth") e->f_manager.triangulateWithDepth(e->Ps.data(), e->Rs.data(), e->tic, e->ric);
+    else if (s == "removeBack") e->f_manager.removeBack();
+    else if (s == "removeFront" && n_in >= 1) e->f_manager.removeFront((int)in[0]);
+    else if (s == "removeFailures") e->f_manager.removeFailures();
+    else if (s == "removeBackShiftDepth" && n_in >= 24) e->f_manager.removeBackShiftDepth(arr9(in), arr3(in + 9), arr9(in + 12), arr3(in + 21));
+    else if (s == "movingConsistencyCheckW") { std::set<int> r; e->movingConsistencyCheckW(r); for (int id : r) o.push_back(id); }
+    else if (s == "predictPtsInNextFrame") {
+        e->predict_ids.clear(); e->predict_xyz.clear(); e->predictPtsInNextFrame();
+        for (size_t i = 0; i < e->predict_ids.size(); i++) o.insert(o.end(), {(double)e->predict_ids[i], e->predict_xyz[3 * i], e->predict_xyz[3 * i + 1], e->predict_xyz[3 * i + 2]});
+    }
+    else if (s == "slideWindow" && n_in >= 1) { e->marginalization_flag = (int)in[0]; e->slideWindow(); }
+    else if (s == "setDepth") { if (n_in < e->f_manager.getFeatureCount()) return gf::set_err(GF_ERR_INVALID, "setDepth needs %d values", e->f_manager.getFeatureCount()); e->f_manager.setDepth(in); }
+    else if (s == "getDepthVector") e->f_manager.getDepthVector(o);
+    else if (s == "getFeatureCount") o.push_back(e->f_manager.getFeatureCount());
+    else if (s == "checkvisual") o.push_back(e->checkvisual() ? 1 : 0);
+    else if (s == "addFeature" && n_in >= 2 && (n_in - 2) % 9 == 0) {
+        const int n = (n_in - 2) / 9;
+        std::vector<gf_feature_obs> v(n);
+        for (int i = 0; i < n; i++) { v[i].id = (int)in[2 + 9 * i]; v[i].camera_id = 0; memcpy(v[i].v, in + 3 + 9 * i, 64); }
+        std::stable_sort(v.begin(), v.end(), [](const gf_feature_obs& a, const gf_feature_obs& b) { return a.id < b.id; });
+        o.push_back(e->f_manager.addFeatureCheckParallax((int)in[0], v.data(), n, in[1]) ? 1 : 0);
+    }
+    else return gf::set_err(GF_ERR_INVALID, "unknown debug op '%s' or too few inputs", op);
+    if (n_out) *n_out = (int)o.size();
+    if ((int)o.size() > cap_out) return gf::set_err(GF_ERR_CAPACITY, "debug op '%s' returns %d values", op, (int)o.size());
+    if (out) std::copy(o.begin(), o.end(), out);
+    return GF_OK;
+}
+
+}  // extern "C"

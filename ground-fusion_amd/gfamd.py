@@ -364,3 +364,131 @@ def double2vector(W, R0, P0, para_Pose, para_SpeedBias):
     out = [np.zeros(9 * (W + 1)), np.zeros(3 * (W + 1)), np.zeros(3 * (W + 1)), np.zeros(3 * (W + 1)), np.zeros(3 * (W + 1))]
     _chk(lib().gf_ba_double2vector(W, _p(R0, C.c_double), _p(P0, C.c_double), _p(pp, C.c_double), _p(sb, C.c_double), *[_p(o, C.c_double) for o in out]))
     return out
+
+
+# ------------------------------------------------------------------ Estimator::processImage surface (gf_estimator_*)
+class EstimatorCfg(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("window_size", "max_features", "max_visual", "use_imu", "use_wheel", "depth", "estimate_extrinsic",
+                                       "estimate_wheel_extrinsic", "estimate_wheel_intrinsic", "estimate_td", "estimate_td_wheel", "use_mcc", "wdetect",
+                                       "stationary_detect", "only_initial_with_wheel", "multiple_thread", "num_iterations", "with_tracker")] + \
+               [(k, C.c_double) for k in ("acc_n", "gyr_n", "acc_w", "gyr_w", "g_norm", "wheel_vel_n", "wheel_gyr_n", "min_parallax_px", "depth_threshold",
+                                          "init_depth", "focal_length", "td", "td_wheel", "sx", "sy", "sw")] + \
+               [("tic", C.c_double * 3), ("ric", C.c_double * 9), ("tio", C.c_double * 3), ("rio", C.c_double * 9), ("tracker", TrackerCfg)]
+
+
+def default_estimator_cfg(**kw):
+    c = EstimatorCfg()
+    _chk(lib().gf_estimator_default_cfg(C.byref(c)))
+    for k, v in kw.items():
+        if k in ("tic", "ric", "tio", "rio"):
+            a = np.asarray(v, np.float64).reshape(-1)
+            for i in range(len(a)):
+                getattr(c, k)[i] = a[i]
+        else:
+            setattr(c, k, v)
+    return c
+
+
+class SlidingWindowEstimator:
+    """Estimator::inputIMU / inputWheel / inputFeature / inputImage / processImage (estimator.h:104-116) on the C-ABI."""
+
+    def __init__(self, cfg=None):
+        self.cfg = cfg or default_estimator_cfg()
+        self.h = C.c_void_p()
+        _chk(lib().gf_estimator_create(C.byref(self.cfg), C.byref(self.h)))
+        self.W = self.cfg.window_size
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gf_estimator_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def inputIMU(self, t, acc, gyr):
+        a, g = np.ascontiguousarray(acc, np.float64), np.ascontiguousarray(gyr, np.float64)
+        _chk(lib().gf_estimator_input_imu(self.h, C.c_double(t), _p(a, C.c_double), _p(g, C.c_double)))
+
+    def inputWheel(self, t, vel, gyr):
+        v, g = np.ascontiguousarray(vel, np.float64), np.ascontiguousarray(gyr, np.float64)
+        _chk(lib().gf_estimator_input_wheel(self.h, C.c_double(t), _p(v, C.c_double), _p(g, C.c_double)))
+
+    def inputFeature(self, t, image):
+        """image: {feature_id: 8-vector} (the map trackImage returns)"""
+        ids = sorted(image)
+        obs = (FeatureObs * max(len(ids), 1))()
+        for k, i in enumerate(ids):
+            obs[k].id, obs[k].camera_id = int(i), 0
+            v = np.asarray(image[i], np.float64).reshape(-1)
+            for j in range(8):
+                obs[k].v[j] = v[j]
+        _chk(lib().gf_estimator_input_feature(self.h, C.c_double(t), obs, len(ids)))
+
+    def inputImage(self, t, img, depth=None):
+        img = np.ascontiguousarray(img, np.uint8)
+        cap = self.cfg.tracker.max_cnt + 8
+        out = (FeatureObs * cap)()
+        n = C.c_int(0)
+        if depth is not None:
+            depth = np.ascontiguousarray(depth, np.uint16)
+            dp, ds = _p(depth, C.c_uint16), depth.shape[1]
+        else:
+            dp, ds = None, 0
+        _chk(lib().gf_estimator_input_image(self.h, C.c_double(t), _p(img, C.c_uint8), img.shape[1], dp, ds, out, cap, C.byref(n)))
+        return {out[k].id: np.array(out[k].v[:]) for k in range(n.value)}
+
+    def state(self):
+        N = self.W + 1
+        Ps, Rs, Vs, Bas, Bgs, H = np.zeros((N, 3)), np.zeros((N, 3, 3)), np.zeros((N, 3)), np.zeros((N, 3)), np.zeros((N, 3)), np.zeros(N)
+        info = np.zeros(16, np.int32)
+        extr = np.zeros(32)
+        _chk(lib().gf_estimator_get_state(self.h, _p(Ps, C.c_double), _p(Rs, C.c_double), _p(Vs, C.c_double), _p(Bas, C.c_double), _p(Bgs, C.c_double),
+                                          _p(H, C.c_double), _p(info, C.c_int), _p(extr, C.c_double)))
+        keys = ("frame_count", "solver_flag", "marginalization_flag", "n_features", "prior_valid", "prior_n", "systemstationary", "iterations",
+                "successful_steps", "n_optimizations", "openExWheelEstimation", "last_track_num", "long_track_num", "new_feature_num", "sum_of_back",
+                "sum_of_front")
+        d = dict(zip(keys, (int(x) for x in info)))
+        d.update(Ps=Ps, Rs=Rs, Vs=Vs, Bas=Bas, Bgs=Bgs, Headers=H, tic=extr[0:3].copy(), ric=extr[3:12].reshape(3, 3).copy(), tio=extr[12:15].copy(),
+                 rio=extr[15:24].reshape(3, 3).copy(), sx=extr[24], sy=extr[25], sw=extr[26], td=extr[27], td_wheel=extr[28], initial_cost=extr[29],
+                 final_cost=extr[30], last_average_parallax=extr[31])
+        return d
+
+    def set_state(self, frame_count, solver_flag, Ps=None, Rs=None, Vs=None, Bas=None, Bgs=None):
+        f = lambda a: None if a is None else _p(np.ascontiguousarray(a, np.float64), C.c_double)
+        keep = [np.ascontiguousarray(a, np.float64) if a is not None else None for a in (Ps, Rs, Vs, Bas, Bgs)]
+        _chk(lib().gf_estimator_set_state(self.h, frame_count, solver_flag, *[None if a is None else _p(a, C.c_double) for a in keep]))
+
+    def features(self, cap=4096):
+        ids, sf, nobs, ef, sflag = (np.zeros(cap, np.int32) for _ in range(5))
+        dep = np.zeros(cap)
+        n = C.c_int(0)
+        _chk(lib().gf_estimator_get_features(self.h, cap, _p(ids, C.c_int), _p(sf, C.c_int), _p(nobs, C.c_int), _p(dep, C.c_double), _p(ef, C.c_int),
+                                             _p(sflag, C.c_int), C.byref(n)))
+        k = n.value
+        return dict(id=ids[:k].copy(), start_frame=sf[:k].copy(), n_obs=nobs[:k].copy(), estimated_depth=dep[:k].copy(), estimate_flag=ef[:k].copy(),
+                    solve_flag=sflag[:k].copy())
+
+    def feedback(self, cap=4096):
+        pid, rid = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        xyz = np.zeros((cap, 3))
+        npred, nrem = C.c_int(0), C.c_int(0)
+        _chk(lib().gf_estimator_get_feedback(self.h, cap, _p(pid, C.c_int), _p(xyz, C.c_double), C.byref(npred), _p(rid, C.c_int), C.byref(nrem)))
+        return pid[:npred.value].copy(), xyz[:npred.value].copy(), rid[:nrem.value].copy()
+
+    def prior(self, cap_n=512):
+        n, nb = C.c_int(0), C.c_int(0)
+        ids = np.zeros(256, np.int32)
+        J, r = np.zeros(cap_n * cap_n), np.zeros(cap_n)
+        _chk(lib().gf_estimator_get_prior(self.h, cap_n, 256, C.byref(n), C.byref(nb), _p(ids, C.c_int), _p(J, C.c_double), _p(r, C.c_double)))
+        return dict(n=n.value, block_id=ids[:nb.value].copy(), J=J[:n.value ** 2].reshape(n.value, n.value).copy(), r=r[:n.value].copy())
+
+    def debug(self, op, args=(), cap=8192):
+        a = np.ascontiguousarray(args, np.float64).reshape(-1)
+        out = np.zeros(cap)
+        n = C.c_int(0)
+        _chk(lib().gf_estimator_debug(self.h, op.encode(), _p(a, C.c_double) if a.size else None, int(a.size), _p(out, C.c_double), cap, C.byref(n)))
+        return out[:n.value].copy()

@@ -1,0 +1,118 @@
+// estimator.h — C++ host mirror of the reference's Estimator call surface (vins_estimator/src/estimator/estimator.h:86-132, :262-356)
+// on top of gf_estimator_* of libgroundfusion_hip.so.  The ROS callbacks of rosNodeTest.cpp keep calling
+//   estimator.inputIMU(t, acc, gyr)      estimator.h:104        estimator.inputWheel(t, vel, gyr)   :106
+//   estimator.inputImage(t, img, depth)  :105                   estimator.inputFeature(t, frame)    :108
+// and the publishers of utility/visualization.cpp keep reading Ps, Rs, Vs, Bas, Bgs, tic, ric, tio, rio, sx, sy, sw, td, td_wheel,
+// Headers, solver_flag, marginalization_flag, which are refreshed after every call.
+// Build with -DGF_WITH_EIGEN / -DGF_WITH_OPENCV to get the Eigen / cv::Mat signatures (absent in this container: std::array / gf::ImageView).
+// Errors: a failing C-ABI call throws std::runtime_error(gf_last_error()) instead of the reference's log-and-continue.
+#pragma once
+#include <array>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "feature_tracker.h"
+
+namespace gf {
+
+#ifdef GF_WITH_EIGEN
+typedef Eigen::Matrix3d Mat3;
+#else
+typedef std::array<double, 9> Mat3;  // row-major
+#endif
+
+class Estimator {
+  public:
+    enum SolverFlag { INITIAL, NON_LINEAR };
+    enum MarginalizationFlag { MARGIN_OLD = 0, MARGIN_SECOND_NEW = 1 };
+    gf_estimator_cfg cfg;                         // what parameters.cpp reads from the YAML; defaults = config/realsense/m2dgrp.yaml
+    SolverFlag solver_flag = INITIAL;
+    MarginalizationFlag marginalization_flag = MARGIN_OLD;
+    int frame_count = 0;
+    std::vector<Vec3> Ps, Vs, Bas, Bgs;           // (WINDOW_SIZE + 1)
+    std::vector<Mat3> Rs;
+    std::vector<double> Headers;
+    Vec3 tic[1], tio; Mat3 ric[1], rio;
+    double td = 0, td_wheel = 0, sx = 1, sy = 1, sw = 1;
+    bool systemstationary = false;
+
+    Estimator() { gf_estimator_default_cfg(&cfg); }
+    ~Estimator() { if (h_) gf_estimator_destroy(h_); }
+    Estimator(const Estimator&) = delete;
+    Estimator& operator=(const Estimator&) = delete;
+
+    void setParameter() {                          // estimator.cpp:176-211: (re)create with the current cfg
+        if (h_) { gf_estimator_destroy(h_); h_ = nullptr; }
+        check(gf_estimator_create(&cfg, &h_));
+        refresh();
+    }
+    void clearState() { setParameter(); }          // estimator.cpp:51-174
+
+    void inputIMU(double t, const Vec3& linearAcceleration, const Vec3& angularVelocity) {
+        need();
+        const double a[3] = {linearAcceleration[0], linearAcceleration[1], linearAcceleration[2]}, g[3] = {angularVelocity[0], angularVelocity[1], angularVelocity[2]};
+        check(gf_estimator_input_imu(h_, t, a, g));
+    }
+    void inputWheel(double t, const Vec3& linearVelocity, const Vec3& angularVelocity) {
+        need();
+        const double v[3] = {linearVelocity[0], linearVelocity[1], linearVelocity[2]}, g[3] = {angularVelocity[0], angularVelocity[1], angularVelocity[2]};
+        check(gf_estimator_input_wheel(h_, t, v, g));
+    }
+    void inputFeature(double t, const FeatureFrame& featureFrame) {   // + processMeasurements -> processImage
+        need();
+        std::vector<gf_feature_obs> obs;
+        for (auto& kv : featureFrame) {
+            gf_feature_obs o;
+            o.id = kv.first; o.camera_id = kv.second[0].first;
+            for (int k = 0; k < 8; k++) o.v[k] = kv.second[0].second[k];
+            obs.push_back(o);
+        }
+        check(gf_estimator_input_feature(h_, t, obs.data(), (int)obs.size()));
+        refresh();
+    }
+    // needs cfg.with_tracker = 1 and cfg.tracker filled before setParameter()
+    void inputImage(double t, const GrayImage& _img, const DepthImage& _img1 = DepthImage()) {
+        need();
+        check(gf_estimator_input_image(h_, t, _img.data, _img.stride, _img1.empty() ? nullptr : _img1.data, _img1.stride, nullptr, 0, nullptr));
+        refresh();
+    }
+#ifdef GF_WITH_OPENCV
+    void inputImage(double t, const cv::Mat& _img, const cv::Mat& _img1 = cv::Mat()) {
+        GrayImage g{_img.ptr<uint8_t>(), _img.rows, _img.cols, (int)_img.step};
+        DepthImage d;
+        if (!_img1.empty()) d = DepthImage{_img1.ptr<uint16_t>(), _img1.rows, _img1.cols, (int)(_img1.step / 2)};
+        inputImage(t, g, d);
+    }
+#endif
+
+  private:
+    gf_estimator* h_ = nullptr;
+    static void check(int rc) { if (rc != GF_OK) throw std::runtime_error(std::string("groundfusion_hip: ") + gf_last_error()); }
+    void need() { if (!h_) setParameter(); }
+    static Vec3 v3(const double* p) { Vec3 v; v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; return v; }
+    static Mat3 m3(const double* p) {
+        Mat3 m;
+#ifdef GF_WITH_EIGEN
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) m(r, c) = p[3 * r + c];
+#else
+        for (int i = 0; i < 9; i++) m[i] = p[i];
+#endif
+        return m;
+    }
+    void refresh() {
+        const int N = cfg.window_size + 1;
+        std::vector<double> P(3 * N), R(9 * N), V(3 * N), Ba(3 * N), Bg(3 * N);
+        Headers.assign(N, 0.0);
+        int info[16]; double extr[32];
+        check(gf_estimator_get_state(h_, P.data(), R.data(), V.data(), Ba.data(), Bg.data(), Headers.data(), info, extr));
+        Ps.resize(N); Vs.resize(N); Bas.resize(N); Bgs.resize(N); Rs.resize(N);
+        for (int i = 0; i < N; i++) { Ps[i] = v3(&P[3 * i]); Vs[i] = v3(&V[3 * i]); Bas[i] = v3(&Ba[3 * i]); Bgs[i] = v3(&Bg[3 * i]); Rs[i] = m3(&R[9 * i]); }
+        frame_count = info[0]; solver_flag = info[1] ? NON_LINEAR : INITIAL; marginalization_flag = info[2] ? MARGIN_SECOND_NEW : MARGIN_OLD; systemstationary = info[6] != 0;
+        tic[0] = v3(extr); ric[0] = m3(extr + 3); tio = v3(extr + 12); rio = m3(extr + 15);
+        sx = extr[24]; sy = extr[25]; sw = extr[26]; td = extr[27]; td_wheel = extr[28];
+    }
+};
+
+}  // namespace gf

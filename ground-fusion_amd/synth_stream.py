@@ -1,0 +1,145 @@
+"""Seeded synthetic RGB-D + IMU + wheel stream of one ground-vehicle sequence: stationary lead-in (exercises the stationary
+initialisation, estimator.cpp:1604-1650), then forward motion with a yaw-rate sinusoid in front of the two-plane room of synth.render_room
+(near wall inside depth_threshold, far wall beyond it).  Camera 30 Hz (the back end takes every 2nd frame when multiple_thread=1), IMU 200 Hz,
+wheel odometer 50 Hz.  Body frame = camera frame (x right, y down, z forward; body_T_cam0 = I as in config/realsense/m2dgrp.yaml:75-82);
+the wheel frame is taken parallel to the body frame with a small lever arm.  Pure numpy."""
+import numpy as np
+
+import synth
+
+G_NORM = 9.805
+R0 = np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])  # body axes in the z-up world at zero yaw: z_b -> x_w, x_b -> -y_w, y_b -> -z_w
+TIO = np.array([0.02, 0.10, -0.05])
+RIO = np.eye(3)
+
+
+def rot_z(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+
+
+class Stream:
+    def __init__(self, seed, t_still=1.5, t_move=3.0, v_max=0.4, imu_hz=200.0, wheel_hz=50.0, cam_hz=30.0, noise=True, near_z=2.5, far_z=6.0, yaw0=0.0, yaw_turn=0.0, split_x=0.6, turn_delay=0.0):
+        rng = np.random.default_rng(2000 + seed)
+        self.seed, self.near_z, self.far_z, self.split_x = seed, near_z, far_z, split_x
+        T = t_still + t_move
+        h = 1e-4
+        t = np.arange(0, T + 0.2, h)
+        s = np.clip((t - t_still) / 0.8, 0, 1)
+        speed = v_max * (3 * s ** 2 - 2 * s ** 3)                                   # smooth ramp
+        amp, f, ph = rng.uniform(0.10, 0.25), rng.uniform(0.8, 1.6), rng.uniform(0, 6.28)
+        yaw_rate = np.where(t > t_still, amp * np.sin(f * (t - t_still) + ph) * (3 * s ** 2 - 2 * s ** 3), 0.0)
+        if yaw_turn != 0.0:   # plus a smooth turn by yaw_turn [rad] spread over the motion phase
+            t_on, t_len = t_still + turn_delay, max(t_move - turn_delay, 1e-9)
+            u = np.clip((t - t_on) / t_len, 0, 1)
+            yaw_rate = yaw_rate + yaw_turn * 6 * u * (1 - u) / t_len * (t > t_on)
+        psi = yaw0 + np.concatenate([[0], np.cumsum(0.5 * (yaw_rate[1:] + yaw_rate[:-1]) * h)])
+        vw = np.stack([speed * np.cos(psi), speed * np.sin(psi), np.zeros_like(t)], 1)
+        pw = np.concatenate([np.zeros((1, 3)), np.cumsum(0.5 * (vw[1:] + vw[:-1]) * h, 0)])
+        aw = np.gradient(vw, h, axis=0)
+        self._t, self._psi, self._pw, self._vw, self._aw, self._wz = t, psi, pw, vw, aw, yaw_rate
+        self.T = T
+        self.ba = rng.normal(0, 0.02, 3) if noise else np.zeros(3)
+        self.bg = rng.normal(0, 0.002, 3) if noise else np.zeros(3)
+        # IMU (acc = R^T (a_w + g), gyr = R^T w_w), m2dgrp.yaml noise levels
+        ti = np.arange(0, T + 0.1, 1.0 / imu_hz)
+        self.imu_t = ti
+        acc, gyr = np.zeros((len(ti), 3)), np.zeros((len(ti), 3))
+        for k, tk in enumerate(ti):
+            R = self.R_wb(tk)
+            acc[k] = R.T @ (self._at(self._aw, tk) + np.array([0, 0, G_NORM])) + self.ba
+            gyr[k] = R.T @ np.array([0, 0, self._at(self._wz, tk)]) + self.bg
+        if noise:
+            acc += rng.normal(0, 1.2374e-2, acc.shape)
+            gyr += rng.normal(0, 3.0033e-3, gyr.shape)
+        self.imu_acc, self.imu_gyr = acc, gyr
+        # wheel odometer in the wheel frame: v_o = R_io^T (R^T v_w + w_b x t_io)
+        tw = np.arange(0, T + 0.1, 1.0 / wheel_hz)
+        self.wheel_t = tw
+        vel, wg = np.zeros((len(tw), 3)), np.zeros((len(tw), 3))
+        for k, tk in enumerate(tw):
+            R = self.R_wb(tk)
+            wb = R.T @ np.array([0, 0, self._at(self._wz, tk)])
+            vel[k] = RIO.T @ (R.T @ self._at(self._vw, tk) + np.cross(wb, TIO))
+            wg[k] = RIO.T @ wb
+        if noise:
+            moving = (np.linalg.norm(vel, axis=1) > 1e-9)[:, None]
+            vel += rng.normal(0, 0.01, vel.shape) * moving     # an odometer at rest reports exact zeros
+            wg += rng.normal(0, 0.004, wg.shape) * moving
+        self.wheel_vel, self.wheel_gyr = vel, wg
+        self.cam_t = np.arange(0.05, T, 1.0 / cam_hz)
+        self._tex = None
+
+    def _at(self, arr, tk):
+        i = min(int(round(tk / 1e-4)), len(self._t) - 1)
+        return arr[i]
+
+    def R_wb(self, tk):
+        return rot_z(self._at(self._psi, tk)) @ R0
+
+    def p_wb(self, tk):
+        return self._at(self._pw, tk)
+
+    def image(self, k):
+        """(gray u8, depth u16 mm) of camera frame k"""
+        if self._tex is None:
+            self._tex = synth.make_texture(1000 + self.seed)
+        tk = self.cam_t[k]
+        R_rc = R0.T @ self.R_wb(tk)          # camera -> render world (x right, y down, z forward)
+        t_rc = R0.T @ self.p_wb(tk)
+        return synth.render_room(self._tex, R_rc, t_rc, near_z=self.near_z, far_z=self.far_z, split_x=self.split_x)
+
+    def feed(self, est, k, t_prev):
+        """push IMU / wheel samples with t_prev < t <= cam_t[k] + one sample of slack, as a ROS callback order would"""
+        t1 = self.cam_t[k] + 0.03
+        for i in np.nonzero((self.imu_t > t_prev) & (self.imu_t <= t1))[0]:
+            est.inputIMU(float(self.imu_t[i]), self.imu_acc[i], self.imu_gyr[i])
+        for i in np.nonzero((self.wheel_t > t_prev) & (self.wheel_t <= t1))[0]:
+            est.inputWheel(float(self.wheel_t[i]), self.wheel_vel[i], self.wheel_gyr[i])
+        return t1
+
+    # ---- feature frames without images (host-logic tests): project a seeded landmark cloud standing on the two walls
+    def _landmarks(self, n=400):
+        rng = np.random.default_rng(3000 + self.seed)
+        x = rng.uniform(-4.0, 6.0, n)          # render-world x (right)
+        y = rng.uniform(-2.0, 2.0, n)          # down
+        z = np.where(x < self.split_x, self.near_z, self.far_z)
+        return np.stack([x, y, z], 1) @ R0.T   # to the z-up world (render = R0^T world)
+
+    def feature_frame(self, k, pixel_noise=0.2):
+        """{id: (x_n, y_n, 1, u, v, vx, vy, depth)} of camera frame k, the layout FeatureTracker::trackImage returns (feature_tracker.cpp:344-368)"""
+        if not hasattr(self, "_lm"):
+            self._lm = self._landmarks()
+            self._pn = np.random.default_rng(4000 + self.seed).normal(0, 1.0, (len(self.cam_t), len(self._lm), 2))
+        out = {}
+        cur = self._project(k, pixel_noise)
+        prev = self._project(k - 1, pixel_noise) if k > 0 else {}
+        dt = self.cam_t[k] - self.cam_t[k - 1] if k > 0 else 1.0
+        for i, (xn, yn, u, v, d) in cur.items():
+            if i in prev:
+                vx, vy = (xn - prev[i][0]) / dt, (yn - prev[i][1]) / dt
+            else:
+                vx = vy = 0.0
+            out[i] = np.array([xn, yn, 1.0, u, v, vx, vy, d])
+        return out
+
+    def _project(self, k, pixel_noise):
+        tk = self.cam_t[k]
+        R, p = self.R_wb(tk), self.p_wb(tk)
+        Xc = (self._lm - p) @ R
+        # occlusion as in render_room: a far-wall point is seen only where its ray passes the near plane beyond the near wall's edge
+        Lr, Cr = self._lm @ R0, p @ R0                      # render-world coordinates (render = R0^T world)
+        far = Lr[:, 2] > self.near_z + 1e-9
+        with np.errstate(all="ignore"):
+            xn = Cr[0] + (Lr[:, 0] - Cr[0]) * (self.near_z - Cr[2]) / (Lr[:, 2] - Cr[2])
+        hidden = far & (xn < self.split_x)
+        out = {}
+        for i in range(len(Xc)):
+            if Xc[i, 2] < 0.3 or hidden[i]:
+                continue
+            u = synth.FX * Xc[i, 0] / Xc[i, 2] + synth.CX + pixel_noise * self._pn[k, i, 0]
+            v = synth.FY * Xc[i, 1] / Xc[i, 2] + synth.CY + pixel_noise * self._pn[k, i, 1]
+            if 2 <= u < synth.W - 2 and 2 <= v < synth.H - 2:
+                d = float(np.rint(Xc[i, 2] * 1000.0)) / 1000.0
+                out[i] = ((u - synth.CX) / synth.FX, (v - synth.CY) / synth.FY, u, v, d)
+        return out

@@ -210,6 +210,58 @@ int gf_imu_preintegrate(int n, const double* dt, const double* acc, const double
 int gf_wheel_preintegrate(int n, const double* dt, const double* vel, const double* gyr, const double* vel0, const double* gyr0, const double* lin,
                           const double* noise, double* delta_p, double* delta_q, double* jacobian, double* covariance, double* sum_dt);
 
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * Estimator: the call surface of Estimator::processImage and its bookkeeping, one handle per
+ * sequence.  Replaces, in vins_estimator/src/estimator/estimator.h: inputIMU :104, inputWheel :106, inputFeature :108,
+ * inputImage :105, processImage :110 (via processMeasurements :113), and the FeatureManager it owns (feature_manager.h:139-215).
+ * The dense work (Estimator::optimization, estimator.cpp:2890-3636) runs on the HIP back end behind gf_ba_*.
+ * Built: RGB-D + IMU (+ wheel) configuration, stationary / wheel-activated initialisation (estimator.cpp:1557-1682),
+ * MULTIPLE_THREAD 0/1 data flow (processed synchronously).  Not built: SfM initialisation, GNSS, line / plane / motion factors.
+ * ------------------------------------------------------------------------------------------------------------------------------ */
+typedef struct gf_estimator gf_estimator;
+
+typedef struct gf_estimator_cfg {
+    int window_size;        /* WINDOW_SIZE, parameters.h:24 */
+    int max_features;       /* NUM_OF_F, parameters.h:25 */
+    int max_visual;         /* capacity of visual factors per window */
+    int use_imu, use_wheel, depth;                              /* imu / wheel / depth, parameters.cpp:160-176 */
+    int estimate_extrinsic, estimate_wheel_extrinsic, estimate_wheel_intrinsic, estimate_td, estimate_td_wheel;
+    int use_mcc, wdetect, stationary_detect, only_initial_with_wheel, multiple_thread;
+    int num_iterations;     /* max_num_iterations */
+    int with_tracker;       /* own a FeatureTracker (gf_estimator_input_image); `tracker` below configures it */
+    double acc_n, gyr_n, acc_w, gyr_w, g_norm, wheel_vel_n, wheel_gyr_n;
+    double min_parallax_px; /* keyframe_parallax (pixels at FOCAL_LENGTH) */
+    double depth_threshold, init_depth, focal_length; /* depth_threshold; INIT_DEPTH parameters.cpp:478; FOCAL_LENGTH parameters.h:23 */
+    double td, td_wheel, sx, sy, sw;
+    double tic[3], ric[9], tio[3], rio[9];  /* body_T_cam0, body_T_wheel (row-major rotations) */
+    gf_tracker_cfg tracker;
+} gf_estimator_cfg;
+
+int gf_estimator_default_cfg(gf_estimator_cfg* cfg);   /* values of config/realsense/m2dgrp.yaml */
+int gf_estimator_create(const gf_estimator_cfg* cfg, gf_estimator** out);
+int gf_estimator_destroy(gf_estimator* h);
+int gf_estimator_input_imu(gf_estimator* h, double t, const double* acc, const double* gyr);
+int gf_estimator_input_wheel(gf_estimator* h, double t, const double* vel, const double* gyr);
+/* inputFeature + processMeasurements: one call = one processImage once IMU / wheel data cover the frame time */
+int gf_estimator_input_feature(gf_estimator* h, double t, const gf_feature_obs* obs, int n);
+/* inputImage: trackImage on the owned tracker, then inputFeature (every second frame when multiple_thread, estimator.cpp:226) */
+int gf_estimator_input_image(gf_estimator* h, double t, const uint8_t* gray, int stride, const uint16_t* depth, int dstride,
+                             gf_feature_obs* out, int cap, int* n_out);
+/* window state; arrays of (window_size+1) entries, any pointer may be NULL.  info[16]: frame_count, solver_flag, marginalization_flag,
+ * #features, prior valid, prior n, systemstationary, last iterations, last successful steps, #optimizations, openExWheelEstimation,
+ * last_track_num, long_track_num, new_feature_num, sum_of_back, sum_of_front.  extr[32]: tic 3, ric 9, tio 3, rio 9, sx, sy, sw, td,
+ * td_wheel, last initial cost, last final cost, last_average_parallax */
+int gf_estimator_get_state(gf_estimator* h, double* Ps, double* Rs, double* Vs, double* Bas, double* Bgs, double* Headers, int* info, double* extr);
+int gf_estimator_set_state(gf_estimator* h, int frame_count, int solver_flag, const double* Ps, const double* Rs, const double* Vs,
+                           const double* Bas, const double* Bgs);
+int gf_estimator_get_features(gf_estimator* h, int cap, int* id, int* start_frame, int* n_obs, double* estimated_depth, int* estimate_flag,
+                              int* solve_flag, int* n);
+/* predictPtsInNextFrame / removeOutliers feedback of the last processImage (estimator.cpp:1132-1136) */
+int gf_estimator_get_feedback(gf_estimator* h, int cap, int* predict_ids, double* predict_xyz, int* n_predict, int* remove_ids, int* n_remove);
+int gf_estimator_get_prior(gf_estimator* h, int cap_n, int cap_blocks, int* n, int* nblocks, int* block_id, double* J, double* r);
+/* single host-side steps by name (FeatureManager members, slideWindow, ...) for unit tests; see gf_estimator.hip */
+int gf_estimator_debug(gf_estimator* h, const char* op, const double* in, int n_in, double* out, int cap_out, int* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -456,9 +456,11 @@ struct Problem {
         n_e = n_cols;
         for (int i = 0; i <= w->W; i++) { add(bid(POSE, i)); add(bid(SPEEDBIAS, i)); }
         add(bid(EX_POSE, 0));
-        if (w->n_wheel > 0) { add(bid(EX_WHEEL, 0)); add(bid(SX, 0)); add(bid(SY, 0)); add(bid(SW, 0)); }
+        // wheel blocks take part when a wheel factor or the prior mentions them (Ceres drops parameter blocks without residuals)
+        auto in_prior = [&](int id) { for (int q = 0; q < w->prior_nblocks; q++) if (w->prior_block_id[q] == id) return true; return false; };
+        for (int id : {bid(EX_WHEEL, 0), bid(SX, 0), bid(SY, 0), bid(SW, 0)}) if (w->n_wheel > 0 || in_prior(id)) add(id);
         add(bid(TD, 0));
-        if (w->n_wheel > 0) add(bid(TD_WHEEL, 0));
+        if (w->n_wheel > 0 || in_prior(bid(TD_WHEEL, 0))) add(bid(TD_WHEEL, 0));
     }
     // Evaluates all residual blocks at s.  Returns cost = 1/2 sum rho(|r|^2).  If rows != null also the corrected residuals/Jacobians
     // of the free blocks (local parameterisation: first 6 columns of a 7-column pose Jacobian, pose_local_parameterization.cpp:30-36).

@@ -1,0 +1,184 @@
+"""Host half of the back end: FeatureManager and the processImage bookkeeping of libgroundfusion_hip.so
+(ground-fusion_amd/csrc/gf_estimator.hip) against the numpy restatement oracle/estimator_oracle.py.  None of these paths touches the GPU:
+the INITIAL fill phase and the single-step debug entry points never reach Estimator::optimization."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ground-fusion_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import gfamd  # noqa: E402
+import synth_stream as SS  # noqa: E402
+import estimator_oracle as EO  # noqa: E402
+
+
+def make_pair(seed, **kw):
+    st = SS.Stream(seed, t_still=kw.pop("t_still", 0.15), t_move=kw.pop("t_move", 1.6), v_max=0.8)
+    ocfg = dict(tio=SS.TIO, rio=SS.RIO, **kw)
+    est_o = EO.Estimator(ocfg)
+    est_p = gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(tio=SS.TIO, rio=SS.RIO, **kw))
+    return st, est_o, est_p
+
+
+STRIDE = 3   # every third 30 Hz camera frame reaches the estimator: ~1 s of motion inside one window
+
+
+def feed(st, ests, k, tp):
+    k = k * STRIDE
+    t1 = tp
+    for e in ests:
+        t1 = st.feed(e, k, tp)
+    frame = st.feature_frame(k)
+    for e in ests:
+        e.inputFeature(float(st.cam_t[k]), frame)
+    return t1
+
+
+def compare_features(est_o, est_p, tol=1e-12):
+    fo, fp = est_o.f_manager.feature, est_p.features()
+    assert [f.feature_id for f in fo] == list(fp["id"])
+    assert [f.start_frame for f in fo] == list(fp["start_frame"])
+    assert [len(f.feature_per_frame) for f in fo] == list(fp["n_obs"])
+    assert [f.estimate_flag for f in fo] == list(fp["estimate_flag"])
+    assert [f.solve_flag for f in fo] == list(fp["solve_flag"])
+    do = np.array([f.estimated_depth for f in fo])
+    np.testing.assert_allclose(fp["estimated_depth"], do, rtol=tol, atol=tol)
+
+
+def compare_state(est_o, est_p, tol=1e-12):
+    s = est_p.state()
+    assert s["frame_count"] == est_o.frame_count and s["solver_flag"] == est_o.solver_flag and s["marginalization_flag"] == est_o.marginalization_flag
+    assert bool(s["systemstationary"]) == bool(est_o.systemstationary)
+    np.testing.assert_allclose(s["Ps"], np.array(est_o.Ps), atol=tol)
+    np.testing.assert_allclose(s["Rs"], np.array(est_o.Rs), atol=tol)
+    np.testing.assert_allclose(s["Vs"], np.array(est_o.Vs), atol=tol)
+    np.testing.assert_allclose(s["Headers"], np.array(est_o.Headers), atol=0)
+    return s
+
+
+def fill_window(seed, **kw):
+    st, est_o, est_p = make_pair(seed, **kw)
+    tp = -1.0
+    k = 0
+    while est_o.frame_count < est_o.W:
+        tp = feed(st, (est_o, est_p), k, tp)
+        k += 1
+    # observations of the newest frame (index W) without running processImage, which would call the (GPU) optimisation
+    frame = st.feature_frame(k * STRIDE)
+    flat = [float(est_o.W), 0.0]
+    for fid in sorted(frame):
+        flat += [float(fid)] + list(frame[fid])
+    kf_p = est_p.debug("addFeature", flat)[0]
+    kf_o = est_o.f_manager.addFeatureCheckParallax(est_o.W, frame, 0.0)
+    assert bool(kf_p) == bool(kf_o)
+    st.window_times = list(est_o.Headers[:est_o.W]) + [float(st.cam_t[k * STRIDE])]
+    return st, est_o, est_p, k, tp
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fill_phase_matches_oracle(seed):
+    """INITIAL phase (estimator.cpp:1064-1073): keyframe votes, wheel dead-reckoning of Ps/Rs/Vs, feature list, stationarity votes."""
+    st, est_o, est_p = make_pair(seed)
+    tp = -1.0
+    for k in range(10):
+        tp = feed(st, (est_o, est_p), k, tp)
+        s = compare_state(est_o, est_p)
+        compare_features(est_o, est_p)
+        assert s["last_track_num"] == est_o.f_manager.last_track_num and s["long_track_num"] == est_o.f_manager.long_track_num
+        assert s["new_feature_num"] == est_o.f_manager.new_feature_num
+        assert abs(s["last_average_parallax"] - est_o.f_manager.last_average_parallax) < 1e-9
+    assert est_o.frame_count == 10 and np.linalg.norm(est_o.Ps[10]) > 0.05   # the vehicle moved: dead reckoning is exercised
+
+
+def _seed_truth(st, est_o, est_p):
+    """poses of the window frames from ground truth (what initialisation would deliver), NON_LINEAR"""
+    W = est_o.W
+    Ps = np.array([st.p_wb(t) for t in st.window_times])
+    Rs = np.array([st.R_wb(t) for t in st.window_times])
+    est_p.set_state(W, 1, Ps, Rs)
+    est_o.solver_flag = 1
+    est_o.Ps = [p.copy() for p in Ps]
+    est_o.Rs = [r.copy() for r in Rs]
+
+
+def test_triangulation_and_depth_bookkeeping():
+    """FeatureManager::triangulateWithDepth / triangulate / setDepth / getDepthVector / removeFailures (FM:249-302, :669-799)."""
+    st, est_o, est_p, k, tp = fill_window(3)
+    _seed_truth(st, est_o, est_p)
+    est_o.f_manager.triangulateWithDepth(est_o.Ps, est_o.Rs, est_o.tic, est_o.ric)
+    est_p.debug("triangulateWithDepth")
+    compare_features(est_o, est_p)
+    flags = np.array([f.estimate_flag for f in est_o.f_manager.feature])
+    assert (flags == 1).sum() > 20                     # near-wall points got a depth-camera depth
+    est_o.f_manager.triangulate(est_o.Ps, est_o.Rs, est_o.tic, est_o.ric)
+    est_p.debug("triangulate")
+    compare_features(est_o, est_p, tol=1e-8)           # SVD (LAPACK) vs one-sided Jacobi: agree to the conditioning of the 4-column system
+    flags = np.array([f.estimate_flag for f in est_o.f_manager.feature])
+    assert (flags == 2).sum() > 5                      # far-wall points were triangulated
+    dep_o = est_o.f_manager.getDepthVector()
+    dep_p = est_p.debug("getDepthVector")
+    np.testing.assert_allclose(dep_p, dep_o, rtol=1e-8)
+    assert int(est_p.debug("getFeatureCount")[0]) == est_o.f_manager.getFeatureCount() == len(dep_o)
+    x = dep_o.copy()
+    x[::7] *= -1.0                                     # some negative inverse depths -> solve_flag 2
+    est_o.f_manager.setDepth(x)
+    est_p.debug("setDepth", x)
+    compare_features(est_o, est_p, tol=1e-8)
+    est_o.f_manager.removeFailures()
+    est_p.debug("removeFailures")
+    compare_features(est_o, est_p, tol=1e-8)
+
+
+@pytest.mark.parametrize("flag", [0, 1])
+def test_slide_window_and_feedback(flag):
+    """slideWindow (EST:3638-3837) with removeBackShiftDepth / removeFront, movingConsistencyCheckW and predictPtsInNextFrame (EST:3862-3995)."""
+    st, est_o, est_p, k, tp = fill_window(4)
+    _seed_truth(st, est_o, est_p)
+    for e in (est_o.f_manager,):
+        e.triangulateWithDepth(est_o.Ps, est_o.Rs, est_o.tic, est_o.ric)
+        e.triangulate(est_o.Ps, est_o.Rs, est_o.tic, est_o.ric)
+    est_p.debug("triangulateWithDepth")
+    est_p.debug("triangulate")
+    # corrupt a few depths so the consistency check has something to reject
+    x = est_o.f_manager.getDepthVector()
+    x[::9] *= 6.0
+    est_o.f_manager.setDepth(x)
+    est_p.debug("setDepth", x)
+    rem_o = set()
+    est_o.movingConsistencyCheckW(rem_o)
+    rem_p = est_p.debug("movingConsistencyCheckW")
+    assert sorted(rem_o) == [int(v) for v in rem_p] and len(rem_o) > 3
+    est_o.predictPts = {}
+    est_o.predictPtsInNextFrame()
+    pp = est_p.debug("predictPtsInNextFrame").reshape(-1, 4)
+    assert [int(v) for v in pp[:, 0]] == sorted(est_o.predictPts) and len(pp) > 50
+    np.testing.assert_allclose(pp[:, 1:], np.array([est_o.predictPts[i] for i in sorted(est_o.predictPts)]), rtol=1e-9, atol=1e-9)
+    est_o.marginalization_flag = flag
+    est_o.slideWindow()
+    est_p.debug("slideWindow", [flag])
+    compare_features(est_o, est_p, tol=1e-8)
+    s = est_p.state()
+    np.testing.assert_allclose(s["Ps"], np.array(est_o.Ps), atol=1e-12)
+    np.testing.assert_allclose(s["Headers"], np.array(est_o.Headers), atol=0)
+    assert (s["sum_of_back"], s["sum_of_front"]) == (est_o.sum_of_back, est_o.sum_of_front)
+
+
+def test_remove_back_initial_phase():
+    """slideWindowOld in the INITIAL phase uses removeBack (FM:858-874), no depth shift."""
+    st, est_o, est_p, k, tp = fill_window(5)
+    est_o.f_manager.removeBack()
+    est_p.debug("removeBack")
+    compare_features(est_o, est_p)
+    est_o.f_manager.removeFront(est_o.W)
+    est_p.debug("removeFront", [est_o.W])
+    compare_features(est_o, est_p)
+
+
+def test_rejects_unbuilt_configurations():
+    with pytest.raises(gfamd.GfError):
+        gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(estimate_extrinsic=2))
+    with pytest.raises(gfamd.GfError):
+        gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(window_size=25))

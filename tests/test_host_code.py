@@ -44,13 +44,16 @@ def test_double2vector_keeps_yaw_and_position_of_pose0(oracle):
 
 
 def test_cpp_host_mirror_compiles_and_links(tmp_path):
-    """The C++ drop-in classes (host/feature_tracker.h, host/estimator_backend.h) compile against the C-ABI with plain g++."""
+    """The C++ drop-in classes (host/feature_tracker.h, host/estimator.h, host/estimator_backend.h) compile against the C-ABI with plain g++."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = tmp_path / "t.cpp"
-    src.write_text('#include <cmath>\n#include "ground-fusion_amd/host/feature_tracker.h"\n#include "ground-fusion_amd/host/estimator_backend.h"\n'
-                   'int main() { gf::FeatureTracker t; t.setIntrinsics(640, 480, 600, 600, 320, 240); (void)sizeof(gf::EstimatorBackend); return t.MAX_CNT == 150 ? 0 : 1; }\n')
+    src.write_text('#include <cmath>\n#include "ground-fusion_amd/host/feature_tracker.h"\n#include "ground-fusion_amd/host/estimator_backend.h"\n#include "ground-fusion_amd/host/estimator.h"\n'
+                   'int main() { gf::FeatureTracker t; t.setIntrinsics(640, 480, 600, 600, 320, 240); (void)sizeof(gf::EstimatorBackend);\n'
+                   '  gf::Estimator e; e.setParameter(); gf::Vec3 a{0, -9.8, 0}, w{0, 0, 0}; e.inputIMU(0.0, a, w); e.inputWheel(0.0, w, w);\n'
+                   '  gf::FeatureFrame f; e.inputFeature(1.0, f);   /* waits: IMU data do not cover t yet */\n'
+                   '  return (t.MAX_CNT == 150 && e.frame_count == 0 && (int)e.Ps.size() == 11) ? 0 : 1; }\n')
     exe = tmp_path / "t"
     lib = os.path.join(root, "ground-fusion_amd", "lib")
     subprocess.check_call(["g++", "-std=c++17", "-I", root, str(src), "-L", lib, "-lgroundfusion_hip", "-Wl,-rpath," + lib, "-o", str(exe)])
