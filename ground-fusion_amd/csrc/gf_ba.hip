@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -47,7 +48,7 @@ struct gf_ba {
     bool pending = false;   // an asynchronous solve is in flight
     int pending_iters = 0;
     gf_ba_stats stats{};
-    size_t step_lds = 0;
+    size_t step_lds = 0, sg_stride = 0, mg_stride = 0; bool big_step = false, big_marg = false;
     // inputs (host mirror + device)
     Buf<double> xs0;     // pristine states [B][XS] (for reset)
     Buf<double> xs;      // [2][B][XS]
@@ -56,7 +57,7 @@ struct gf_ba {
     Buf<SolverState> st, st0;
     // work
     Buf<double> imu_sqrt, wh_sqrt, pri_A, pri_b, pri_c, pri_H0, H, g, cost, efac;
-    Buf<double> scale, diag, grad, gn, step, u, Et, Es, ete, etb, rhs, yv;
+    Buf<double> scale, diag, grad, gn, step, u, Et, Es, ete, etb, rhs, yv, Sg, Mg;
     // marginalisation: column maps per mode (0 MARGIN_OLD, 1 MARGIN_SECOND_NEW), outputs
     Buf<int> mcolf[2], mcole[2], morder[2], mnorder[2], minfo[2];
     Buf<double> outJ, outr;
@@ -65,7 +66,7 @@ struct gf_ba {
     size_t marg_lds = 0; int marg_ncap = 0, last_marg_mode = -1;
     long long mfma_per_lin = 0;   // v_mfma_f64_16x16x4 instructions of one visual linearisation of the resident batch
     std::vector<Buf<double>*> dbl() { return {&xs0, &xs, &vis_data, &imu_data, &wh_data, &pri_J, &pri_r, &pri_x0, &imu_sqrt, &wh_sqrt, &pri_A, &pri_b, &pri_c, &pri_H0, &H, &g, &cost, &efac,
-                                              &scale, &diag, &grad, &gn, &step, &u, &Et, &Es, &ete, &etb, &rhs, &yv}; }
+                                              &scale, &diag, &grad, &gn, &step, &u, &Et, &Es, &ete, &etb, &rhs, &yv, &Sg, &Mg}; }
     std::vector<Buf<int>*> ints() { return {&colf, &cole, &nvis, &nimu, &nwh, &nfeat, &vis_feat, &vis_i, &vis_j, &order, &norder, &feat_ptr, &feat_fac, &imu_i, &wh_i, &pri_n, &pri_nb, &pri_bid}; }
     void release() {
         for (auto* b : dbl()) b->release();
@@ -92,7 +93,7 @@ struct gf_ba {
     StepBufs sbufs() {
         StepBufs s{};
         s.scale = scale.d; s.diag = diag.d; s.grad = grad.d; s.gn = gn.d; s.step = step.d; s.u = u.d; s.Et = Et.d; s.Es = Es.d; s.ete = ete.d; s.etb = etb.d;
-        s.rhs = rhs.d; s.yv = yv.d; s.VS = d.RP + d.FP; s.stamps = stamps.d;
+        s.rhs = rhs.d; s.yv = yv.d; s.VS = d.RP + d.FP; s.stamps = stamps.d; s.Sg = Sg.d; s.SgStride = sg_stride; s.Mg = Mg.d; s.MgStride = mg_stride;
         return s;
     }
     double G[3] = {0, 0, 9.805};
@@ -249,7 +250,7 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
             for (int id : keepb) { mc[fblk(id)] = mp + n; n += lsize_kind(id / 4096); }
             for (size_t q = 0; q < dropf.size(); q++) me[dropf[q] % 4096] = (int)q;
             if (mp + (int)dropf.size() == 0) valid = false;
-            if (valid && (n > h->marg_ncap || mp > 15 || mp + n > d.RP)) return gf::set_err(GF_ERR_CAPACITY, "window %d: marginalisation sizes mp=%d n=%d exceed this build (n <= %d)", b, mp, n, h->marg_ncap);
+            if (valid && (n > h->marg_ncap || mp > gfb::MPMAX || mp + n > d.RP)) return gf::set_err(GF_ERR_CAPACITY, "window %d: marginalisation sizes mp=%d n=%d exceed this build (n <= %d)", b, mp, n, h->marg_ncap);
             int* inf = h->minfo[mode].h + (size_t)b * 4;
             inf[0] = mp; inf[1] = (int)dropf.size(); inf[2] = n; inf[3] = valid ? 1 : 0;
             h->keep_ids[mode][b] = keepb;
@@ -325,7 +326,8 @@ int run_solve(gf_ba* h, int max_iters) {
     Win w = h->win();
     StepBufs sb = h->sbufs();
     for (int it = 0; it <= max_iters; it++) {
-        ba_step<<<dim3(d.B), 512, h->step_lds, h->stream>>>(w, sb, it == 0 ? 1 : 0, max_iters, it == max_iters ? 1 : 0);
+        if (h->big_step) ba_step<true><<<dim3(d.B), 512, 0, h->stream>>>(w, sb, it == 0 ? 1 : 0, max_iters, it == max_iters ? 1 : 0);
+        else ba_step<false><<<dim3(d.B), 512, h->step_lds, h->stream>>>(w, sb, it == 0 ? 1 : 0, max_iters, it == max_iters ? 1 : 0);
         HIPCHK(hipGetLastError());
         if (it < max_iters) {
             // candidate state lives in buffer (1 - cur) of each window: linearise both ... the kernels pick the right one per window
@@ -349,7 +351,8 @@ int run_marginalize(gf_ba* h, int mode) {
     ba_linearize_misc<<<dim3(1, d.B), 256, 0, h->stream>>>(wm, -1, -2, 0, 2, 2, 2 * d.W);
     ba_build_et<<<dim3(d.F, d.B), 64, 0, h->stream>>>(wm, h->sbufs(), -1, 1);
     MargOut mo{h->outJ.d, h->outr.d};
-    ba_marg_finish<<<dim3(d.B), 512, h->marg_lds, h->stream>>>(wm, h->sbufs(), reinterpret_cast<const MargInfo*>(h->minfo[mode].d), mo);
+    if (h->big_marg) ba_marg_finish<true><<<dim3(d.B), 512, 0, h->stream>>>(wm, h->sbufs(), reinterpret_cast<const MargInfo*>(h->minfo[mode].d), mo);
+    else ba_marg_finish<false><<<dim3(d.B), 512, h->marg_lds, h->stream>>>(wm, h->sbufs(), reinterpret_cast<const MargInfo*>(h->minfo[mode].d), mo);
     HIPCHK(hipGetLastError());
     return GF_OK;
 }
@@ -361,7 +364,7 @@ extern "C" {
 int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     if (!cfg || !out) return gf::set_err(GF_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (cfg->window_size < 2 || cfg->window_size > 19 || cfg->max_features < 1 || cfg->max_visual < 1 || cfg->batch < 1) return gf::set_err(GF_ERR_INVALID, "bad gf_ba_cfg");
+    if (cfg->window_size < 2 || cfg->window_size > 30 || cfg->max_features < 1 || cfg->max_visual < 1 || cfg->batch < 1) return gf::set_err(GF_ERR_INVALID, "bad gf_ba_cfg");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return gf::set_err(GF_ERR_NO_DEVICE, "no HIP device available; the HIP path has no CPU fallback");
     gf_ba* h = new gf_ba();
@@ -372,7 +375,8 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     const int Rmax = 15 * d.NP + 17;
     d.RP = (Rmax + 1 + 15) & ~15; /* one spare column: the Schur GEMM carries the right-hand side in column R */ d.XS = (16 * d.NP + 20 + d.F + 3) & ~3; d.NFB = 2 * d.NP + 7; d.FP = (d.F + 3) & ~3; d.NPRI = d.RP; d.ECW = (6 * d.NP + 8 + 15) & ~15;
     h->step_lds = (size_t)(Rmax + 1) * (Rmax + 2) / 2 * sizeof(double);  // packed lower S plus the right-hand-side row
-    if (h->step_lds + 8 * 1024 > 160 * 1024) { delete h; return gf::set_err(GF_ERR_INVALID, "window_size %d: reduced system (%d) does not fit the LDS-resident Cholesky of this build", d.W, Rmax); }
+    h->big_step = h->step_lds + 16 * 1024 > 160 * 1024 || getenv("GF_BA_FORCE_GLOBAL") != nullptr;   // reduced system too large for LDS: ba_step<true> keeps it in global memory
+    if (Rmax + 1 > 512) { delete h; return gf::set_err(GF_ERR_INVALID, "window_size %d: reduced system (%d) exceeds 511 columns", d.W, Rmax); }
 #define A_(x) do { if (int rc_ = (x)) { h->release(); delete h; return rc_; } } while (0)
 #define H_(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { gf::set_err(GF_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); h->release(); delete h; return GF_ERR_HIP; } } while (0)
     H_(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -400,10 +404,15 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     A_(h->rhs.alloc(B * d.RP, false)); A_(h->yv.alloc(B * VS, false));
     for (int m = 0; m < 2; m++) { A_(h->mcolf[m].alloc(B * d.NFB, true)); A_(h->mcole[m].alloc(B * d.F, true)); A_(h->morder[m].alloc(B * d.NVP, true)); A_(h->mnorder[m].alloc(B, true)); A_(h->minfo[m].alloc(B * 4, true)); }
     A_(h->outJ.alloc(B * (size_t)d.NPRI * d.NPRI, true)); A_(h->outr.alloc(B * d.NPRI, true)); A_(h->stamps.alloc(64, true));
-    h->marg_ncap = std::min(d.NPRI, 96);   // A and V of the kept system live in LDS
-    h->marg_lds = (size_t)2 * h->marg_ncap * h->marg_ncap * sizeof(double);
-    H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->step_lds));
-    H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_marg_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds));
+    // kept system of the marginalisation: 6 W poses + speed-bias + extrinsics ...; A and V live in LDS up to 92 columns, else in global memory
+    const int nkeep = 6 * d.W + 9 + 17;
+    h->big_marg = nkeep > 92 || getenv("GF_BA_FORCE_GLOBAL") != nullptr;
+    h->marg_ncap = h->big_marg ? std::min(d.NPRI, nkeep + 16) : 92;
+    h->marg_lds = h->big_marg ? 0 : (size_t)2 * h->marg_ncap * h->marg_ncap * sizeof(double);
+    if (h->big_step) { h->sg_stride = (h->step_lds / sizeof(double) + 15) & ~(size_t)15; A_(h->Sg.alloc(B * h->sg_stride, false)); }
+    if (h->big_marg) { h->mg_stride = (size_t)2 * h->marg_ncap * h->marg_ncap + 1024; A_(h->Mg.alloc(B * h->mg_stride, false)); }
+    if (!h->big_step) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_step<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->step_lds));
+    if (!h->big_marg) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_marg_finish<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds));
     H_(hipStreamSynchronize(h->stream));
 #undef A_
 #undef H_
@@ -546,7 +555,8 @@ int gf_ba_linearize(gf_ba* h, const gf_ba_window* w, int cap, double* Hout, doub
     HIPCHK(hipMemsetAsync(h->cost.d, 0, (size_t)2 * d.B * sizeof(double), h->stream));
     if (int rc = launch_linearize(h, 0, 0, 0, 0, false)) return rc;
     // run the accept/eliminated-column phase of ba_step once (finalize_only) to materialise ete / etb / Et
-    ba_step<<<dim3(d.B), 512, h->step_lds, h->stream>>>(h->win(), h->sbufs(), 1, 1, 1);
+    if (h->big_step) ba_step<true><<<dim3(d.B), 512, 0, h->stream>>>(h->win(), h->sbufs(), 1, 1, 1);
+    else ba_step<false><<<dim3(d.B), 512, h->step_lds, h->stream>>>(h->win(), h->sbufs(), 1, 1, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(h->H.down(h->stream)); HIPCHK(h->g.down(h->stream)); HIPCHK(h->cost.down(h->stream)); HIPCHK(h->Et.down(h->stream)); HIPCHK(h->ete.down(h->stream)); HIPCHK(h->etb.down(h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -685,6 +685,10 @@ struct StepBufs {  // per-window global scratch of ba_step
     double* etb;    // [B][FP]
     double* rhs;    // [B][RP]
     double* yv;     // [B][VS]
+    double* Sg;     // [B][SgStride] global home of the reduced system when it does not fit LDS (large windows); else null
+    size_t SgStride;
+    double* Mg;     // [B][MgStride] same for the kept system of the marginalisation
+    size_t MgStride;
     long long* stamps;  // optional phase timestamps of window 0 (builds with -DGF_PROFILE_STEP)
     int VS;
 };
@@ -728,13 +732,14 @@ __device__ __forceinline__ int tri_row(int t) {  // largest i with i(i+1)/2 <= t
     while ((i + 1) * (i + 2) / 2 <= t) i++;
     return i;
 }
+template <int QN, int EN>   // QN 64-column chunks of the reduced system (R <= 64 QN), EN chunks of the compact rows (ECW <= 64 EN)
 __device__ inline void quad_form(const double* H, const double* g, const double* Et, const double* ete, const double* etb, const double* u, const double* uc, int R,
                                  int NE, int RP, int ECW, double* sred, int tid, double& uHu, double& ug) {
     const int wave = tid >> 6, lane = tid & 63;
     double a = 0, c = 0;
-    double uk[3];
+    double uk[QN];
 #pragma unroll
-    for (int q = 0; q < 3; q++) uk[q] = (lane + 64 * q) < R ? u[lane + 64 * q] : 0.0;   // R <= 192
+    for (int q = 0; q < QN; q++) uk[q] = (lane + 64 * q) < R ? u[lane + 64 * q] : 0.0;
     for (int r0 = wave; r0 < R; r0 += 32) {
         double sv[4];
 #pragma unroll
@@ -744,13 +749,15 @@ __device__ inline void quad_form(const double* H, const double* g, const double*
             if (r < R) {
                 const double* row = H + (size_t)r * RP;
 #pragma unroll
-                for (int q = 0; q < 3; q++) { const int c = lane + 64 * q; if (c <= r) sv[m] += (c == r ? 1.0 : 2.0) * row[c] * uk[q]; }   // H holds its lower triangle
+                for (int q = 0; q < QN; q++) { const int c = lane + 64 * q; if (c <= r) sv[m] += (c == r ? 1.0 : 2.0) * row[c] * uk[q]; }   // H holds its lower triangle
             }
         }
 #pragma unroll
         for (int m = 0; m < 4; m++) if (r0 + 8 * m < R) a += u[r0 + 8 * m] * sv[m];
     }
-    const double ucl0 = lane < ECW ? uc[lane] : 0.0, ucl1 = (lane + 64) < ECW ? uc[lane + 64] : 0.0;   // ECW <= 128
+    double ucl[EN];
+#pragma unroll
+    for (int q = 0; q < EN; q++) ucl[q] = (lane + 64 * q) < ECW ? uc[lane + 64 * q] : 0.0;
     for (int e0 = wave; e0 < NE; e0 += 32) {
 #pragma unroll
         for (int m = 0; m < 4; m++) {
@@ -758,8 +765,8 @@ __device__ inline void quad_form(const double* H, const double* g, const double*
             if (e < NE) {
                 const double* row = Et + (size_t)e * ECW;
                 double sv = 0;
-                if (lane < ECW) sv += row[lane] * ucl0;
-                if (lane + 64 < ECW) sv += row[lane + 64] * ucl1;
+#pragma unroll
+                for (int q = 0; q < EN; q++) if (lane + 64 * q < ECW) sv += row[lane + 64 * q] * ucl[q];
                 a += 2.0 * u[RP + e] * sv;
             }
         }
@@ -877,21 +884,24 @@ __device__ inline bool wave_chol16_inv(double* s_L, double* s_inv, double* s_rdi
 // One 512-thread block per window: accept/reject of the previous candidate (trust_region_minimizer.cc), then the next
 // dogleg step (dogleg_strategy.cc): Jacobi scaling, Cauchy point, Gauss-Newton step through the Schur complement
 // (MFMA GEMM) and an LDS-resident blocked Cholesky, candidate point.  first: the call that follows the initial linearisation.
+// GS: the packed reduced system lives in global memory (sb.Sg) instead of LDS -- windows whose (R+1)(R+2)/2 doubles exceed 160 KB
+// (WINDOW_SIZE > 10); same code, the triangular solves then run out of L2.
+template <bool GS>
 __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, int max_iters, int finalize_only) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double sred[512];
     __shared__ double s_blk[16 * 17], s_inv[16 * 17];
     __shared__ double s_y[16];
     __shared__ int s_flag[4];
-    __shared__ int s_cmap[128];      // compact column -> reduced column (or -1), right-hand-side slot -> R
-    __shared__ double s_uc[128];     // a vector gathered to the compact layout
-    __shared__ double s_rd[208];     // reciprocals of the Cholesky diagonal
+    __shared__ int s_cmap[256];      // compact column -> reduced column (or -1), right-hand-side slot -> R
+    __shared__ double s_uc[256];     // a vector gathered to the compact layout
+    __shared__ double s_rd[512];     // reciprocals of the Cholesky diagonal
     const Dims d = w.d;
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     SolverState& st = w.st[b];
     if (st.done) return;
     const int R = st.R, NE = st.NE, RP = d.RP, VS = sb.VS, ECW = d.ECW;
-    double* S = smem;  // packed lower (R+1)(R+2)/2: row R carries the right-hand side
+    double* S = GS ? sb.Sg + (size_t)blockIdx.x * sb.SgStride : smem;  // packed lower (R+1)(R+2)/2: row R carries the right-hand side
     const int* colf = w.colf + (size_t)b * d.NFB;
     const int* cole = w.cole + (size_t)b * d.F;
     double* scale = sb.scale + (size_t)b * VS; double* diag = sb.diag + (size_t)b * VS; double* grad = sb.grad + (size_t)b * VS;
@@ -980,7 +990,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
         for (int e = tid; e < NE; e += 512) gsq += grad[RP + e] * grad[RP + e];
         gsq = block_sum(gsq, sred, tid, 512);
         double uHu, ug;
-        quad_form(H, g, Et, ete, etb, u, s_uc, R, NE, RP, ECW, sred, tid, uHu, ug);
+        quad_form<GS ? 8 : 3, GS ? 4 : 2>(H, g, Et, ete, etb, u, s_uc, R, NE, RP, ECW, sred, tid, uHu, ug);
         if (tid == 0) st.alpha = gsq / uHu;
         // ---------------- Gauss-Newton step: (J^T J + mu D^2) y = J^T r through the Schur complement, retry with larger mu on failure
         bool ok = false;
@@ -1204,7 +1214,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
         if (tid < ECW) { const int c = s_cmap[tid]; s_uc[tid] = (c >= 0 && c < R) ? u[c] : 0.0; }
         __syncthreads();
         double uHu, ug;
-        quad_form(H, g, Et, ete, etb, u, s_uc, R, NE, RP, ECW, sred, tid, uHu, ug);
+        quad_form<GS ? 8 : 3, GS ? 4 : 2>(H, g, Et, ete, etb, u, s_uc, R, NE, RP, ECW, sred, tid, uHu, ug);
         const double mcc = -(ug + 0.5 * uHu);
         if (tid == 0) st.model_cost_change = mcc;
         valid = mcc > 0.0;

@@ -98,14 +98,16 @@ __device__ inline void block_jacobi_eig(double* A, double* V, int n, double* s_c
     }
 }
 
+constexpr int MPMAX = 20;   // dropped pose + speed-bias (+ receiver clock blocks) columns
 struct MargOut { double* J; double* r; };  // [B][NPRI*NPRI], [B][NPRI]
 
 // One 512-thread block per window.  M = H[1-cur] (ld RP) holds the dropped-block + kept-block normal equations, g[1-cur] the
 // right-hand side, efac[1-cur] the per-factor products of the eliminated feature columns.
+template <bool GS>   // GS: A and V of the kept system live in global memory (sb.Mg) -- priors larger than 96 columns
 __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const MargInfo* info, MargOut out) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double sred[512];
-    __shared__ double sP[15 * 15], sPV[15 * 15], sPinv[15 * 15], sbp[16];
+    __shared__ double sP[MPMAX * MPMAX], sPV[MPMAX * MPMAX], sPinv[MPMAX * MPMAX], sbp[MPMAX];
     __shared__ double s_c[64], s_s[64];
     __shared__ int s_p[64], s_q[64], s_flag;
     const Dims d = w.d;
@@ -120,7 +122,7 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     const int ECW = d.ECW;
     const double* Et = sb.Et + ((size_t)o * d.B + b) * d.FP * ECW;   // compact rows built by ba_build_et
     double* Es = sb.Es + (size_t)b * d.FP * ECW;
-    __shared__ int s_cmap[128];
+    __shared__ int s_cmap[256];
     if (tid < ECW) s_cmap[tid] = compact_to_col(tid, w.colf + (size_t)b * d.NFB, d.NP, -1);   // marginalisation column map (swapped in by the caller)
     const double* ete = sb.ete + ((size_t)o * d.B + b) * d.FP; const double* etb = sb.etb + ((size_t)o * d.B + b) * d.FP;
     const double eps = 1e-8;
@@ -182,8 +184,8 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     __syncthreads();
     GF_MST(3);
     // ---- kept system: A_r = M_kk - M_kp Pinv M_pk (LDS), b_r = b_k - M_kp Pinv b_p
-    double* A = smem;            // n x n
-    double* V = smem + n * n;    // n x n
+    double* A = GS ? sb.Mg + (size_t)blockIdx.x * sb.MgStride : smem;   // n x n
+    double* V = A + n * n;       // n x n
     double* br = sb.rhs + (size_t)b * RP;
     double* T = V;   // T = Pinv * M_pk (mp x n), staged in the not-yet-used V area
     for (int i = tid; i < mp * n; i += 512) {
@@ -210,8 +212,8 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     // J^T r and |r|^2 enter Ceres), so a rank-revealing (diagonally pivoted) Cholesky with the same absolute threshold is used:
     // A_r = P L L^T P^T, J = L^T P^T (rows beyond the detected rank are zero), r = L^-1 P^T b (forward substitution rides along).
     int* perm = reinterpret_cast<int*>(V);          // n ints
-    double* zb = V + 64;                            // n doubles: permuted right-hand side being forward-substituted
-    int* sidx = reinterpret_cast<int*>(V + 64 + 128);   // 512 ints for the arg-max reduction
+    double* zb = V + 256;                           // n doubles: permuted right-hand side being forward-substituted
+    int* sidx = reinterpret_cast<int*>(V + 256 + 512);  // 512 ints for the arg-max reduction
     for (int i = tid; i < n; i += 512) { perm[i] = i; zb[i] = br[i]; }
     __syncthreads();
     int rank = n;

@@ -909,7 +909,7 @@ int gf_estimator_default_cfg(gf_estimator_cfg* c) {
 
 int gf_estimator_create(const gf_estimator_cfg* c, gf_estimator** out) {
     if (!c || !out) return gf::set_err(GF_ERR_INVALID, "null argument");
-    if (c->window_size < 2 || c->window_size > 19) return gf::set_err(GF_ERR_INVALID, "window_size must be in [2, 19]");
+    if (c->window_size < 2 || c->window_size > 30) return gf::set_err(GF_ERR_INVALID, "window_size must be in [2, 30]");
     if (!c->use_imu || !c->depth) return gf::set_err(GF_ERR_INVALID, "only the RGB-D + IMU configuration is built (USE_IMU=1, DEPTH=1)");
     if (c->estimate_extrinsic == 2) return gf::set_err(GF_ERR_INVALID, "ESTIMATE_EXTRINSIC=2 (online rotation calibration) is not built");
     gf_estimator* e = new gf_estimator(*c);

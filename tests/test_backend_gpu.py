@@ -125,7 +125,56 @@ def test_prior_chain_solve_with_gpu_prior(gf, oracle, seed):
     pg = est.marginalize([wg], 0)[0]
     w2o = SW.make_window(seed, oracle, frame0=1, prior=po)
     w2g = SW.make_window(seed, oracle, frame0=1, prior=pg)
+    w2x = SW.make_window(seed, oracle, frame0=1, prior=pg)
+    oracle.ba_solve(w2o, 8); est.solve([w2g], 8); oracle.ba_solve(w2x, 8)
+    # same (GPU-made) prior, HIP solve vs oracle solve: the solver bar
+    dp, dr = _pose_diff(w2x, w2g)
+    assert dp < 1e-6 and dr < 1e-6, (dp, dr)
+    # all-HIP chain vs all-oracle chain: additionally carries the prior's own rounding.  The Schur complement of the dropped block has a
+    # condition number of 1e6..1e7 on these windows, so the two priors agree to ~1e-10 relative only, and that difference moves with the
+    # order of the atomic accumulation (scripts/chain_flaky.py: 1e-7 .. 4e-6 on seed 12 from run to run) -- conditioning, not a defect
+    dp, dr = _pose_diff(w2o, w2g)
+    assert dp < 2e-5 and dr < 2e-5, (dp, dr)
+    est.close()
+
+
+@pytest.mark.parametrize("W,F", [(20, 500), (12, 200)])
+def test_large_window_matches_oracle(gf, oracle, W, F):
+    """BASELINE.json config 5 sizes (20-frame window, 500 features, ~9000 visual factors; without GNSS): the reduced system (332 columns)
+    no longer fits LDS, ba_step<true> / ba_marg_finish<true> keep it in global memory."""
+    est = gf.Estimator(W, F, F * W)
+    w = SW.make_window(1, oracle, W=W, n_landmarks=int(F * 1.5), max_features=F)
+    assert w["n_feature"] == F and w["n_visual"] > 8 * F
+    lo, lg = oracle.ba_linearize(w.copy(), cap=1024), est.linearize(w.copy(), cap=1024)
+    assert lo["n_f"] == lg["n_f"] == 15 * (W + 1) + 6 and lo["n_e"] == lg["n_e"]
+    assert abs(lo["cost"] - lg["cost"]) <= 1e-12 * lo["cost"]
+    assert np.abs(lo["H"] - lg["H"]).max() <= 1e-13 * np.abs(lo["H"]).max() and np.abs(lo["g"] - lg["g"]).max() <= 1e-13 * np.abs(lo["g"]).max()
+    wo, wg = w.copy(), w.copy()
+    so, sg = oracle.ba_solve(wo, 8), est.solve([wg], 8)[0]
+    assert (so["iterations"], so["successful_steps"]) == (sg["iterations"], sg["successful_steps"])
+    dp, dr = _pose_diff(wo, wg)
+    assert dp < 1e-6 and dr < 1e-6, (dp, dr)
+    po, pg = oracle.ba_marginalize(wo, 0, cap_n=512), est.marginalize([wo], 0, cap_n=512)[0]
+    assert pg["n"] == po["n"] == 6 * W + 9 + 17 and list(pg["block_id"]) == list(po["block_id"])
+    n = po["n"]
+    Ao, Ag = po["J"].reshape(n, n).T @ po["J"].reshape(n, n), pg["J"].reshape(n, n).T @ pg["J"].reshape(n, n)
+    assert np.abs(Ao - Ag).max() <= 1e-9 * np.abs(Ao).max()          # conditioning of the dropped block, see test_marginalization_matches_oracle
+    w2o = SW.make_window(1, oracle, W=W, n_landmarks=int(F * 1.5), max_features=F, frame0=1, prior=pg)
+    w2g = w2o.copy()
     oracle.ba_solve(w2o, 8); est.solve([w2g], 8)
     dp, dr = _pose_diff(w2o, w2g)
     assert dp < 1e-6 and dr < 1e-6, (dp, dr)
     est.close()
+
+
+def test_lds_and_global_reduced_system_agree(gf, oracle, monkeypatch):
+    """the global-memory variant of the step / marginalisation kernels on a window that also fits LDS"""
+    w = SW.make_window(4, oracle)
+    a, b = w.copy(), w.copy()
+    e1 = gf.Estimator(); e1.solve([a], 8); p1 = e1.marginalize([a], 0)[0]; e1.close()
+    monkeypatch.setenv("GF_BA_FORCE_GLOBAL", "1")
+    e2 = gf.Estimator(); e2.solve([b], 8); p2 = e2.marginalize([b], 0)[0]; e2.close()
+    dp, dr = _pose_diff(a, b)
+    assert dp < 1e-8 and dr < 1e-8
+    A1, A2 = p1["J"].reshape(p1["n"], -1), p2["J"].reshape(p2["n"], -1)
+    assert np.abs(A1.T @ A1 - A2.T @ A2).max() <= 1e-9 * np.abs(A1.T @ A1).max()

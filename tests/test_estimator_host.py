@@ -181,4 +181,4 @@ def test_rejects_unbuilt_configurations():
     with pytest.raises(gfamd.GfError):
         gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(estimate_extrinsic=2))
     with pytest.raises(gfamd.GfError):
-        gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(window_size=25))
+        gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(window_size=40))
