@@ -4,7 +4,7 @@ layout, by the test oracle.  Mirrors what Estimator::vector2double + the factor 
 import ctypes as C
 import numpy as np
 
-POSE, SPEEDBIAS, EX_POSE, EX_WHEEL, SX, SY, SW, TD, TD_WHEEL, FEATURE = range(10)
+POSE, SPEEDBIAS, EX_POSE, EX_WHEEL, SX, SY, SW, TD, TD_WHEEL, FEATURE, RCV_DT, RCV_DDT, YAW, ANC = range(14)
 
 
 def bid(kind, idx=0):
@@ -12,7 +12,7 @@ def bid(kind, idx=0):
 
 
 def gsize(kind):
-    return 7 if kind in (POSE, EX_POSE, EX_WHEEL) else 9 if kind == SPEEDBIAS else 1
+    return 7 if kind in (POSE, EX_POSE, EX_WHEEL) else 9 if kind == SPEEDBIAS else 3 if kind == ANC else 1
 
 
 def lsize(kind):
@@ -37,7 +37,11 @@ class WindowC(C.Structure):
                 ("imu_jacobian", PD), ("imu_covariance", PD),
                 ("wh_i", PI), ("wh_sum_dt", PD), ("wh_delta_p", PD), ("wh_delta_q", PD), ("wh_jacobian", PD), ("wh_covariance", PD), ("wh_lin", PD),
                 ("wh_lin_vel", PD), ("wh_lin_gyr", PD), ("wh_vel_1", PD), ("wh_gyr_1", PD),
-                ("prior_n", C.c_int), ("prior_nblocks", C.c_int), ("prior_block_id", PI), ("prior_J", PD), ("prior_r", PD), ("prior_x0", PD)]
+                ("prior_n", C.c_int), ("prior_nblocks", C.c_int), ("prior_block_id", PI), ("prior_J", PD), ("prior_r", PD), ("prior_x0", PD),
+                ("gnss_enabled", C.c_int), ("gnss_lowspeed", C.c_int), ("n_gnss", C.c_int), ("has_anchor", C.c_int),
+                ("para_rcv_dt", PD), ("para_rcv_ddt", PD), ("para_yaw_enu_local", PD), ("para_anc_ecef", PD),
+                ("gnss_ddt_weight", C.c_double), ("anchor_value", C.c_double * 7),
+                ("gnss_iono", PD), ("gnss_frame", PI), ("gnss_lower", PI), ("gnss_sys", PI), ("gnss_ratio", PD), ("gnss_data", PD), ("gnss_headers", PD)]
 
 
 class SummaryC(C.Structure):
@@ -48,11 +52,13 @@ class SummaryC(C.Structure):
 _F64 = ["para_Pose", "para_SpeedBias", "para_Ex_Pose", "para_Ex_Pose_wheel", "para_Ix", "para_Td", "para_Td_wheel", "para_Feature",
         "vis_pts_i", "vis_pts_j", "vis_vel_i", "vis_vel_j", "vis_td_i", "vis_td_j", "imu_sum_dt", "imu_delta_p", "imu_delta_q", "imu_delta_v",
         "imu_lin_ba", "imu_lin_bg", "imu_jacobian", "imu_covariance", "wh_sum_dt", "wh_delta_p", "wh_delta_q", "wh_jacobian", "wh_covariance",
-        "wh_lin", "wh_lin_vel", "wh_lin_gyr", "wh_vel_1", "wh_gyr_1", "prior_J", "prior_r", "prior_x0"]
-_I32 = ["vis_feature", "vis_i", "vis_j", "imu_i", "wh_i", "prior_block_id"]
+        "wh_lin", "wh_lin_vel", "wh_lin_gyr", "wh_vel_1", "wh_gyr_1", "prior_J", "prior_r", "prior_x0",
+        "para_rcv_dt", "para_rcv_ddt", "para_yaw_enu_local", "para_anc_ecef", "gnss_iono", "gnss_ratio", "gnss_data", "gnss_headers"]
+_I32 = ["vis_feature", "vis_i", "vis_j", "imu_i", "wh_i", "prior_block_id", "gnss_frame", "gnss_lower", "gnss_sys"]
 _SCALARS = ["W", "n_feature", "n_visual", "n_imu", "n_wheel", "fix_ex_pose", "fix_ex_wheel", "fix_ix", "fix_td", "fix_td_wheel", "fix_poses",
-            "vis_sqrt_info", "prior_n", "prior_nblocks"]
-STATE_KEYS = ["para_Pose", "para_SpeedBias", "para_Ex_Pose", "para_Ex_Pose_wheel", "para_Ix", "para_Td", "para_Td_wheel", "para_Feature"]
+            "vis_sqrt_info", "prior_n", "prior_nblocks", "gnss_enabled", "gnss_lowspeed", "n_gnss", "has_anchor", "gnss_ddt_weight"]
+STATE_KEYS = ["para_Pose", "para_SpeedBias", "para_Ex_Pose", "para_Ex_Pose_wheel", "para_Ix", "para_Td", "para_Td_wheel", "para_Feature",
+              "para_rcv_dt", "para_rcv_ddt", "para_yaw_enu_local", "para_anc_ecef"]
 
 
 class Window(dict):
@@ -77,6 +83,8 @@ class Window(dict):
         self["n_wheel"] = len(self["wh_i"])
         self["prior_n"] = len(self["prior_r"])
         self["prior_nblocks"] = len(self["prior_block_id"])
+        self["n_gnss"] = len(self["gnss_frame"])
+        self["anchor_value"] = np.ascontiguousarray(self.get("anchor_value", np.zeros(7)), np.float64)
         for k in _SCALARS:
             self.setdefault(k, 0)
         return self
@@ -89,6 +97,8 @@ class Window(dict):
             setattr(c, k, self[k])
         for i in range(3):
             c.G[i] = self["G"][i]
+        for i in range(7):
+            c.anchor_value[i] = self["anchor_value"][i]
         for k in _F64:
             a = self[k]
             setattr(c, k, a.ctypes.data_as(PD) if a.size else None)

@@ -69,7 +69,7 @@ class Trajectory:
 
 
 def make_window(seed, pre, W=10, n_landmarks=220, max_features=150, use_wheel=True, frame0=0, perturb=True, prior=None,
-                fix_ex_pose=1, fix_ex_wheel=0, fix_ix=1, fix_td=1, fix_td_wheel=1):
+                fix_ex_pose=1, fix_ex_wheel=0, fix_ix=1, fix_td=1, fix_td_wheel=1, gnss=False, gnss_lowspeed=0, anchor=False):
     """Window over frames frame0 .. frame0+W of trajectory `seed`."""
     rng = np.random.default_rng(seed * 7919 + 13 + frame0)
     traj = Trajectory(seed, T=(frame0 + W + 3) / 15.0 + 0.5)
@@ -176,5 +176,82 @@ def make_window(seed, pre, W=10, n_landmarks=220, max_features=150, use_wheel=Tr
     w["para_Ix"], w["para_Td"], w["para_Td_wheel"] = np.ones(3), np.zeros(1), np.zeros(1)
     w["fix_ex_pose"], w["fix_ex_wheel"], w["fix_ix"], w["fix_td"], w["fix_td_wheel"], w["fix_poses"] = fix_ex_pose, fix_ex_wheel, fix_ix, fix_td, fix_td_wheel, 0
     w["G"] = G
+    if gnss:
+        add_gnss(w, seed, traj, times, frame0, perturb, gnss_lowspeed)
+    if anchor:
+        w["has_anchor"] = 1
+        w["anchor_value"] = np.concatenate([Ps[0], quat_from_R(Rs[0])])
     w.set_prior(prior)
+    return w
+
+
+# ---------------------------------------------------------------- synthetic GNSS (config 5): measurement model in numpy, used only to make data
+C_LIGHT, OMG_E, WGS_A, WGS_E2 = 2.99792458e8, 7.2921151467e-5, 6378137.0, 6.69437999014e-3
+IONO = np.array([0.1118e-07, 0.2235e-07, -0.4172e-06, 0.6557e-06, 0.1249e+06, -0.4424e+06, 0.1507e+07, -0.2621e+06])   # m2dgrp.yaml gnss_iono_default_parameters
+
+
+def geo2ecef(lat_deg, lon_deg, alt):
+    lat, lon = np.radians(lat_deg), np.radians(lon_deg)
+    N = WGS_A / np.sqrt(1 - WGS_E2 * np.sin(lat) ** 2)
+    return np.array([(N + alt) * np.cos(lat) * np.cos(lon), (N + alt) * np.cos(lat) * np.sin(lon), (N * (1 - WGS_E2) + alt) * np.sin(lat)])
+
+
+def R_ecef_enu(lat_deg, lon_deg):
+    lat, lon = np.radians(lat_deg), np.radians(lon_deg)
+    return np.array([[-np.sin(lon), -np.sin(lat) * np.cos(lon), np.cos(lat) * np.cos(lon)], [np.cos(lon), -np.sin(lat) * np.sin(lon), np.cos(lat) * np.sin(lon)],
+                     [0, np.cos(lat), np.sin(lat)]])
+
+
+def add_gnss(w, seed, traj, times, frame0, perturb, lowspeed, sats_per_sys=3, lat=31.03, lon=121.44, alt=20.0, yaw=0.3):
+    """4 constellations x sats_per_sys satellites above 30 deg elevation, one pseudorange + Doppler pair per satellite and frame, observation epochs
+    a few ms off the frame stamps (so the interpolation ratio of estimator.cpp:3187-3198 is exercised).  Delays (iono / tropo) are left out of
+    the synthetic pseudoranges: they only shift the residuals by a few metres, which the clock states absorb."""
+    W = w["W"]
+    rng = np.random.default_rng(seed * 6007 + 11)      # constellation: fixed per seed
+    orng = np.random.default_rng(seed * 6011 + 17 + frame0)
+    anc = geo2ecef(lat, lon, alt)
+    Re = R_ecef_enu(lat, lon)
+    Ry = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1.0]])
+    R_el = Re @ Ry
+    sats = []
+    for sys in range(4):
+        for _ in range(sats_per_sys):
+            az, el, rg = rng.uniform(0, 2 * np.pi), rng.uniform(np.radians(32), np.radians(80)), rng.uniform(2.0e7, 2.5e7)
+            d_enu = np.array([np.sin(az) * np.cos(el), np.cos(az) * np.cos(el), np.sin(el)])
+            pos = anc + Re @ (d_enu * rg)
+            vel = Re @ (np.cross(d_enu, rng.normal(0, 1, 3)) * 1.5e3)
+            sats.append((sys, pos, vel, rng.uniform(-2e-4, 2e-4), rng.uniform(-1e-11, 1e-11), rng.uniform(-8e-9, 8e-9)))
+    dt_true = np.array([150.0, 180.0, 120.0, 200.0])   # receiver clock bias per constellation [m]
+    ddt_true = 2.0                                       # drift [m/s]
+    frames, lowers, syss, ratios, data = [], [], [], [], []
+    wl = C_LIGHT / 1575.42e6
+    for i in range(W + 1):
+        for (sys, pos, vel, svdt, svddt, tgd) in sats:
+            ts = times[i] + orng.uniform(-0.02, 0.02)
+            if times[i] > ts:
+                lower = 0 if i == 0 else i - 1
+            else:
+                lower = W - 1 if i == W else i
+            ratio = (times[lower + 1] - ts) / (times[lower + 1] - times[lower])
+            p, R, v, _, _ = traj.at(min(max(ts, traj.t[0]), traj.t[-1]))
+            sp = pos + vel * (ts - times[0])
+            P_e, V_e = R_el @ p + anc, R_el @ v
+            los = sp - P_e
+            rg = np.linalg.norm(los)
+            unit = los / rg
+            clk = dt_true[sys] + ddt_true * (ts - times[0] + frame0 / 15.0)
+            psr = rg + OMG_E * (sp[0] * P_e[1] - sp[1] * P_e[0]) / C_LIGHT + clk - svdt * C_LIGHT + tgd * C_LIGHT + orng.normal(0, 0.5)
+            dop_est = (vel - V_e) @ unit + OMG_E / C_LIGHT * (vel[0] * P_e[1] + sp[0] * V_e[1] - vel[1] * P_e[0] - sp[1] * V_e[0]) + ddt_true - svddt * C_LIGHT
+            dopp = -(dop_est + orng.normal(0, 0.05)) / wl
+            frames.append(i); lowers.append(lower); syss.append(sys); ratios.append(ratio)
+            data.append([*sp, *vel, svdt, svddt, tgd, 2.0, 2.0, psr, dopp, wl, 345600.0 + ts, 0.0])
+    w["gnss_enabled"], w["gnss_lowspeed"] = 1, lowspeed
+    w["gnss_frame"], w["gnss_lower"], w["gnss_sys"], w["gnss_ratio"], w["gnss_data"] = frames, lowers, syss, np.array(ratios), np.array(data)
+    w["gnss_iono"], w["gnss_headers"], w["gnss_ddt_weight"] = IONO.copy(), np.array(times), 10.0
+    prng = np.random.default_rng(seed * 6029 + 5 + frame0)
+    clk0 = np.array([[dt_true[q] + ddt_true * (times[i] - times[0] + frame0 / 15.0) for q in range(4)] for i in range(W + 1)])
+    w["para_rcv_dt"] = clk0 + (prng.normal(0, 3.0, clk0.shape) if perturb else 0.0)
+    w["para_rcv_ddt"] = np.full(W + 1, ddt_true) + (prng.normal(0, 0.2, W + 1) if perturb else 0.0)
+    w["para_yaw_enu_local"] = np.array([yaw])
+    w["para_anc_ecef"] = anc + (prng.normal(0, 0.5, 3) if perturb else 0.0)
     return w

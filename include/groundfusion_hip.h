@@ -120,7 +120,8 @@ int gf_pyramid_level(const uint8_t* img, int width, int height, int level, uint8
 typedef struct gf_ba gf_ba;
 
 /* parameter-block ids used by priors: kind * 4096 + index */
-enum { GF_POSE = 0, GF_SPEEDBIAS = 1, GF_EX_POSE = 2, GF_EX_WHEEL = 3, GF_SX = 4, GF_SY = 5, GF_SW = 6, GF_TD = 7, GF_TD_WHEEL = 8, GF_FEATURE = 9 };
+enum { GF_POSE = 0, GF_SPEEDBIAS = 1, GF_EX_POSE = 2, GF_EX_WHEEL = 3, GF_SX = 4, GF_SY = 5, GF_SW = 6, GF_TD = 7, GF_TD_WHEEL = 8, GF_FEATURE = 9,
+       GF_RCV_DT = 10, GF_RCV_DDT = 11, GF_YAW = 12, GF_ANC = 13 };
 
 typedef struct gf_ba_cfg {
     int window_size;   /* WINDOW_SIZE (parameters.h:24 fixes 10; here a runtime value) */
@@ -157,6 +158,24 @@ typedef struct gf_ba_window {
     /* MarginalizationFactor(last_marginalization_info): linearized_jacobians (n x n row-major), linearized_residuals, keep_block_data */
     int prior_n, prior_nblocks;
     const int* prior_block_id; const double* prior_J; const double* prior_r; const double* prior_x0;
+    /* GNSS (estimator.cpp:2904-2941, :3178-3229, :3390-3431): blocks and factors.  gnss_enabled = gnss_ready; the factors enter the solve
+     * unless gnss_lowspeed (estimator.cpp:3178), and enter the MARGIN_OLD marginalisation whenever gnss_enabled (:3390).
+     * gnss_data per factor (16 doubles): sv_pos 3, sv_vel 3, svdt, svddt, tgd, pr_uura, dp_uura, psr, dopp, wavelength, time of GPS week [s], 0.
+     * What GnssPsrDoppFactor's constructor derives from observation + ephemeris (gnss_psr_dopp_factor.cpp:3-47) is handed over precomputed. */
+    int gnss_enabled, gnss_lowspeed, n_gnss, has_anchor;
+    double* para_rcv_dt;         /* 4 (W+1), in/out */
+    double* para_rcv_ddt;        /* (W+1) */
+    double* para_yaw_enu_local;  /* 1 (held constant, estimator.cpp:2932) */
+    double* para_anc_ecef;       /* 3 */
+    double gnss_ddt_weight;      /* GNSS_DDT_WEIGHT, parameters.cpp:549 */
+    double anchor_value[7];      /* PoseAnchorFactor on Pose[0] (estimator.cpp:2943-2951), sqrt_info 120 */
+    const double* gnss_iono;     /* 8 Klobuchar parameters */
+    const int* gnss_frame;       /* i: the factor uses rcv_dt[4 i + sys] and rcv_ddt[i] */
+    const int* gnss_lower;       /* lower_idx: the factor sits on (Pose, SpeedBias)[lower_idx] and [lower_idx + 1] */
+    const int* gnss_sys;         /* sys_idx 0..3 */
+    const double* gnss_ratio;    /* ts_ratio */
+    const double* gnss_data;     /* n_gnss x 16 */
+    const double* gnss_headers;  /* Headers[0..W]: DtDdtFactor(Headers[i+1] - Headers[i]), estimator.cpp:3214-3223 */
 } gf_ba_window;
 
 typedef struct gf_ba_summary {

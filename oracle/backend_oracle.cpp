@@ -153,20 +153,22 @@ struct WheelPre {
 };
 
 // ------------------------------------------------------------------ parameter blocks
-enum Kind { POSE = 0, SPEEDBIAS = 1, EX_POSE = 2, EX_WHEEL = 3, SX = 4, SY = 5, SW = 6, TD = 7, TD_WHEEL = 8, FEATURE = 9 };
+enum Kind { POSE = 0, SPEEDBIAS = 1, EX_POSE = 2, EX_WHEEL = 3, SX = 4, SY = 5, SW = 6, TD = 7, TD_WHEEL = 8, FEATURE = 9, RCV_DT = 10, RCV_DDT = 11, YAW = 12, ANC = 13 };
 inline int bid(int kind, int idx) { return kind * 4096 + idx; }
-inline int gsize_of(int kind) { return (kind == POSE || kind == EX_POSE || kind == EX_WHEEL) ? 7 : kind == SPEEDBIAS ? 9 : 1; }
+inline int gsize_of(int kind) { return (kind == POSE || kind == EX_POSE || kind == EX_WHEEL) ? 7 : kind == SPEEDBIAS ? 9 : kind == ANC ? 3 : 1; }
 inline int lsize_of(int kind) { int g = gsize_of(kind); return g == 7 ? 6 : g; }
 
 struct State {  // values of every parameter block (copied from / to the window)
     int W, F;
     std::vector<double> pose, sb, feat;
     double ex[7], exw[7], ix[3], td, tdw;
+    std::vector<double> rcv_dt, rcv_ddt; double yaw = 0, anc[3] = {0, 0, 0}; bool gnss = false;
     double* ptr(int id) {
         int k = id / 4096, i = id % 4096;
         switch (k) {
             case POSE: return &pose[7 * i]; case SPEEDBIAS: return &sb[9 * i]; case EX_POSE: return ex; case EX_WHEEL: return exw;
             case SX: return &ix[0]; case SY: return &ix[1]; case SW: return &ix[2]; case TD: return &td; case TD_WHEEL: return &tdw;
+            case RCV_DT: return &rcv_dt[i]; case RCV_DDT: return &rcv_ddt[i]; case YAW: return &yaw; case ANC: return anc;
             default: return &feat[i];
         }
     }
@@ -176,11 +178,14 @@ struct State {  // values of every parameter block (copied from / to the window)
         pose.assign(w->para_Pose, w->para_Pose + 7 * (W + 1)); sb.assign(w->para_SpeedBias, w->para_SpeedBias + 9 * (W + 1));
         feat.assign(w->para_Feature, w->para_Feature + F);
         memcpy(ex, w->para_Ex_Pose, 56); memcpy(exw, w->para_Ex_Pose_wheel, 56); memcpy(ix, w->para_Ix, 24); td = w->para_Td[0]; tdw = w->para_Td_wheel[0];
+        gnss = w->gnss_enabled != 0;
+        if (gnss) { rcv_dt.assign(w->para_rcv_dt, w->para_rcv_dt + 4 * (W + 1)); rcv_ddt.assign(w->para_rcv_ddt, w->para_rcv_ddt + W + 1); yaw = w->para_yaw_enu_local[0]; memcpy(anc, w->para_anc_ecef, 24); }
     }
     void store(gfo_window* w) const {
         memcpy(w->para_Pose, pose.data(), pose.size() * 8); memcpy(w->para_SpeedBias, sb.data(), sb.size() * 8);
         if (F) memcpy(w->para_Feature, feat.data(), F * 8);
         memcpy(w->para_Ex_Pose, ex, 56); memcpy(w->para_Ex_Pose_wheel, exw, 56); memcpy(w->para_Ix, ix, 24); w->para_Td[0] = td; w->para_Td_wheel[0] = tdw;
+        if (gnss) { memcpy(w->para_rcv_dt, rcv_dt.data(), rcv_dt.size() * 8); memcpy(w->para_rcv_ddt, rcv_ddt.data(), rcv_ddt.size() * 8); w->para_yaw_enu_local[0] = yaw; memcpy(w->para_anc_ecef, anc, 24); }
     }
 };
 
@@ -403,6 +408,160 @@ static void eval_wheel(const gfo_window* w, int k, const double* const* p, Facto
 }
 
 // MarginalizationFactor::Evaluate, marginalization_factor.cpp:344-392.  Jacobian = columns of linearized_jacobians.
+
+// ------------------------------------------------------------------ GNSS factors (F4).  gnss_comm (un-vendored, unpinned git HEAD) supplies
+// ecef2geo / ecef2rotation / sat_azel / calculate_trop_delay / calculate_ion_delay to gnss_psr_dopp_factor.cpp:70-83.  Restated here from the
+// published algorithms gnss_comm takes them from (RTKLIB: Saastamoinen troposphere with standard atmosphere and 70 % humidity, Klobuchar broadcast
+// ionosphere; closed-form Bowring geodetic conversion, latitude / longitude in DEGREES).  Constants: gnss_comm/gnss_constant.hpp.
+static const double GN_C = 2.99792458e8, GN_OMG = 7.2921151467e-5, GN_A = 6378137.0, GN_E2 = 6.69437999014e-3, GN_PI = 3.14159265358979323846;
+static V3 gn_ecef2geo(const V3& xyz) {   // lat [deg], lon [deg], alt [m]
+    if (xyz[0] == 0 && xyz[1] == 0) return v3(0, 0, 0);
+    const double a = GN_A, a2 = a * a, b2 = a2 * (1 - GN_E2), b = std::sqrt(b2), ep2 = (a2 - b2) / b2, p = std::sqrt(xyz[0] * xyz[0] + xyz[1] * xyz[1]);
+    double s1 = xyz[2] * a, s2 = p * b, h = std::sqrt(s1 * s1 + s2 * s2);
+    const double sin_theta = s1 / h, cos_theta = s2 / h;
+    s1 = xyz[2] + ep2 * b * sin_theta * sin_theta * sin_theta;
+    s2 = p - a * GN_E2 * cos_theta * cos_theta * cos_theta;
+    h = std::sqrt(s1 * s1 + s2 * s2);
+    const double tan_lat = s1 / s2, sin_lat = s1 / h, cos_lat = s2 / h;
+    const double N = a2 / std::sqrt(a2 * cos_lat * cos_lat + b2 * sin_lat * sin_lat);
+    return v3(std::atan(tan_lat) * 180.0 / GN_PI, std::atan2(xyz[1], xyz[0]) * 180.0 / GN_PI, p / cos_lat - N);
+}
+static M3 gn_geo2rotation(const V3& lla) {   // R_ecef_enu
+    const double lat = lla[0] * GN_PI / 180.0, lon = lla[1] * GN_PI / 180.0, sl = std::sin(lat), cl = std::cos(lat), so = std::sin(lon), co = std::cos(lon);
+    M3 R;
+    R(0, 0) = -so; R(0, 1) = -sl * co; R(0, 2) = cl * co;
+    R(1, 0) = co;  R(1, 1) = -sl * so; R(1, 2) = cl * so;
+    R(2, 0) = 0;   R(2, 1) = cl;       R(2, 2) = sl;
+    return R;
+}
+static M3 gn_ecef2rotation(const V3& ecef) { return gn_geo2rotation(gn_ecef2geo(ecef)); }
+static void gn_sat_azel(const V3& rcv, const V3& sat, double azel[2]) {
+    V3 d = sat - rcv; d = d * (1.0 / d.norm());
+    const V3 enu = gn_ecef2rotation(rcv).T() * d;
+    azel[0] = (std::sqrt(d[0] * d[0] + d[1] * d[1]) < 1e-12) ? 0.0 : std::atan2(enu[0], enu[1]);
+    if (azel[0] < 0) azel[0] += 2 * GN_PI;
+    azel[1] = std::asin(enu[2]);
+}
+static double gn_trop_delay(const V3& lla, const double azel[2]) {   // Saastamoinen, standard atmosphere, relative humidity 0.7
+    if (lla[2] < -100.0 || 1e4 < lla[2] || azel[1] <= 0) return 0.0;
+    const double hgt = lla[2] < 0.0 ? 0.0 : lla[2];
+    const double pres = 1013.25 * std::pow(1.0 - 2.2557e-5 * hgt, 5.2568), temp = 15.0 - 6.5e-3 * hgt + 273.16;
+    const double e = 6.108 * 0.7 * std::exp((17.15 * temp - 4684.0) / (temp - 38.45)), z = GN_PI / 2.0 - azel[1];
+    const double trph = 0.0022768 * pres / (1.0 - 0.00266 * std::cos(2.0 * lla[0] * GN_PI / 180.0) - 0.00028 * hgt / 1e3) / std::cos(z);
+    const double trpw = 0.002277 * (1255.0 / temp + 0.05) * e / std::cos(z);
+    return trph + trpw;
+}
+static double gn_ion_delay(double tow, const double* ion_in, const V3& lla, const double azel[2]) {   // Klobuchar
+    static const double ion_default[8] = {0.1118e-07, -0.7451e-08, -0.5961e-07, 0.1192e-06, 0.1167e+06, -0.2294e+06, -0.1311e+06, 0.1049e+07};
+    if (lla[2] < -1e3 || azel[1] <= 0) return 0.0;
+    double nrm = 0; for (int i = 0; i < 8; i++) nrm += ion_in[i] * ion_in[i];
+    const double* ion = nrm <= 0.0 ? ion_default : ion_in;
+    const double psi = 0.0137 / (azel[1] / GN_PI + 0.11) - 0.022;
+    double phi = lla[0] / 180.0 + psi * std::cos(azel[0]);
+    if (phi > 0.416) phi = 0.416; else if (phi < -0.416) phi = -0.416;
+    const double lam = lla[1] / 180.0 + psi * std::sin(azel[0]) / std::cos(phi * GN_PI);
+    phi += 0.064 * std::cos((lam - 1.617) * GN_PI);
+    double tt = 43200.0 * lam + tow;
+    tt -= std::floor(tt / 86400.0) * 86400.0;
+    const double f = 1.0 + 16.0 * std::pow(0.53 - azel[1] / GN_PI, 3.0);
+    double amp = ion[0] + phi * (ion[1] + phi * (ion[2] + phi * ion[3])), per = ion[4] + phi * (ion[5] + phi * (ion[6] + phi * ion[7]));
+    amp = amp < 0.0 ? 0.0 : amp; per = per < 72000.0 ? 72000.0 : per;
+    const double x = 2.0 * GN_PI * (tt - 50400.0) / per;
+    return GN_C * f * (std::fabs(x) < 1.57 ? 5e-9 + amp * (1.0 + x * x * (-0.5 + x * x / 24.0)) : 5e-9);
+}
+// GnssPsrDoppFactor::Evaluate, gnss_psr_dopp_factor.cpp:49-208.  Blocks: Pose_i(7) SpeedBias_i(9) Pose_j(7) SpeedBias_j(9) rcv_dt(1) rcv_ddt(1) yaw(1) anc(3)
+static void eval_gnss(const gfo_window* w, int k, const double* const* p, FactorOut& o, bool jac) {
+    const double* d = w->gnss_data + (size_t)k * 16;
+    const V3 sv_pos = v3(d[0], d[1], d[2]), sv_vel = v3(d[3], d[4], d[5]);
+    const double svdt = d[6], svddt = d[7], tgd = d[8], pr_uura = d[9], dp_uura = d[10], psr = d[11], dopp = d[12], wavelength = d[13], tow = d[14];
+    const double ratio = w->gnss_ratio[k];
+    const V3 Pi = P_of(p[0]), Vi = v3(p[1][0], p[1][1], p[1][2]), Pj = P_of(p[2]), Vj = v3(p[3][0], p[3][1], p[3][2]);
+    const double rcv_dt = p[4][0], rcv_ddt = p[5][0], yaw_diff = p[6][0];
+    const V3 ref_ecef = v3(p[7][0], p[7][1], p[7][2]);
+    const V3 local_pos = Pi * ratio + Pj * (1.0 - ratio), local_vel = Vi * ratio + Vj * (1.0 - ratio);
+    const double sy = std::sin(yaw_diff), cy = std::cos(yaw_diff);
+    M3 R_enu_local; R_enu_local(0, 0) = cy; R_enu_local(0, 1) = -sy; R_enu_local(0, 2) = 0; R_enu_local(1, 0) = sy; R_enu_local(1, 1) = cy; R_enu_local(1, 2) = 0;
+    R_enu_local(2, 0) = 0; R_enu_local(2, 1) = 0; R_enu_local(2, 2) = 1;
+    const M3 R_ecef_enu = gn_ecef2rotation(ref_ecef), R_ecef_local = R_ecef_enu * R_enu_local;
+    const V3 P_ecef = R_ecef_local * local_pos + ref_ecef, V_ecef = R_ecef_local * local_vel;
+    double ion_delay = 0, tro_delay = 0, azel[2] = {0, GN_PI / 2.0};
+    if (P_ecef.norm() > 0) {
+        gn_sat_azel(P_ecef, sv_pos, azel);
+        const V3 lla = gn_ecef2geo(P_ecef);
+        tro_delay = gn_trop_delay(lla, azel);
+        ion_delay = gn_ion_delay(tow, w->gnss_iono, lla, azel);
+    }
+    const double sin_el = std::sin(azel[1]), sin_el_2 = sin_el * sin_el;
+    const double pr_weight = sin_el_2 / pr_uura * 10.0, dp_weight = sin_el_2 / dp_uura * 10.0 * 5.0;   // relative_sqrt_info 10, PSR_TO_DOPP_RATIO 5
+    const V3 rcv2sat = sv_pos - P_ecef;
+    const double rng = rcv2sat.norm();
+    const V3 unit = rcv2sat * (1.0 / rng);
+    const double psr_sagnac = GN_OMG * (sv_pos[0] * P_ecef[1] - sv_pos[1] * P_ecef[0]) / GN_C;
+    const double psr_est = rng + psr_sagnac + rcv_dt - svdt * GN_C + ion_delay + tro_delay + tgd * GN_C;
+    o.nres = 2;
+    o.r[0] = (psr_est - psr) * pr_weight;
+    const double dopp_sagnac = GN_OMG / GN_C * (sv_vel[0] * P_ecef[1] + sv_pos[0] * V_ecef[1] - sv_vel[1] * P_ecef[0] - sv_pos[1] * V_ecef[0]);
+    const double dopp_est = (sv_vel - V_ecef).dot(unit) + dopp_sagnac + rcv_ddt - svddt * GN_C;
+    o.r[1] = (dopp_est + dopp * wavelength) * dp_weight;
+    if (!jac) return;
+    o.J.assign(8, {});
+    const int gs[8] = {7, 9, 7, 9, 1, 1, 1, 3};
+    for (int b = 0; b < 8; b++) o.J[b].assign((size_t)2 * gs[b], 0.0);
+    const double norm3 = rng * rng * rng, norm2 = rcv2sat.dot(rcv2sat);
+    M3 u2p;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) u2p(i, j) = -((i == j) ? (norm2 - rcv2sat[i] * rcv2sat[i]) / norm3 : (-rcv2sat[i] * rcv2sat[j]) / norm3);
+    const V3 dv = sv_vel - V_ecef;
+    V3 row_pr, row_dp, row_v;   // unit^T R, (sv_vel - V)^T u2p R, unit^T R
+    for (int c = 0; c < 3; c++) {
+        double a = 0, bsum = 0;
+        for (int r = 0; r < 3; r++) { a += unit[r] * R_ecef_local(r, c); double t = 0; for (int q = 0; q < 3; q++) t += dv[q] * u2p(q, r); bsum += t * R_ecef_local(r, c); }
+        row_pr[c] = a; row_dp[c] = bsum; row_v[c] = a;
+    }
+    for (int c = 0; c < 3; c++) {
+        o.J[0][c] = -row_pr[c] * pr_weight * ratio;          o.J[0][7 + c] = row_dp[c] * dp_weight * ratio;
+        o.J[1][9 + c] = -row_v[c] * dp_weight * ratio;
+        o.J[2][c] = -row_pr[c] * pr_weight * (1.0 - ratio);  o.J[2][7 + c] = row_dp[c] * dp_weight * (1.0 - ratio);
+        o.J[3][9 + c] = -row_v[c] * dp_weight * (1.0 - ratio);
+        o.J[7][c] = -unit[c] * pr_weight;
+    }
+    o.J[4][0] = pr_weight; o.J[4][1] = 0;
+    o.J[5][0] = 0; o.J[5][1] = dp_weight;
+    M3 d_yaw; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) d_yaw(i, j) = 0;
+    d_yaw(0, 0) = -sy; d_yaw(0, 1) = -cy; d_yaw(1, 0) = cy; d_yaw(1, 1) = -sy;
+    o.J[6][0] = -unit.dot(R_ecef_enu * (d_yaw * local_pos)) * pr_weight;
+    o.J[6][1] = -unit.dot(R_ecef_enu * (d_yaw * local_vel)) * dp_weight;
+}
+// DtDdtFactor (gnss_dt_ddt_factor.cpp): blocks rcv_dt_i, rcv_dt_j, rcv_ddt_i, rcv_ddt_j; dt_info_coeff 50
+static void eval_dt_ddt(double delta_t, const double* const* p, FactorOut& o, bool jac) {
+    o.nres = 1;
+    o.r[0] = (p[1][0] - p[0][0] - 0.5 * (p[2][0] + p[3][0]) * delta_t) * 50.0;
+    if (!jac) return;
+    o.J.assign(4, std::vector<double>(1, 0.0));
+    o.J[0][0] = -50.0; o.J[1][0] = 50.0; o.J[2][0] = -0.5 * delta_t * 50.0; o.J[3][0] = -0.5 * delta_t * 50.0;
+}
+// DdtSmoothFactor (gnss_ddt_smooth_factor.cpp)
+static void eval_ddt_smooth(double weight, const double* const* p, FactorOut& o, bool jac) {
+    o.nres = 1;
+    o.r[0] = (p[0][0] - p[1][0]) * weight;
+    if (!jac) return;
+    o.J.assign(2, std::vector<double>(1, 0.0));
+    o.J[0][0] = weight; o.J[1][0] = -weight;
+}
+// PoseAnchorFactor (pose_anchor_factor.cpp), sqrt_info 120
+static void eval_anchor(const double* anchor, const double* const* p, FactorOut& o, bool jac) {
+    const double si = 120.0;
+    o.nres = 6;
+    for (int i = 0; i < 3; i++) o.r[i] = (p[0][i] - anchor[i]) * si;
+    const Quat cq = Q_of(p[0]), aq(anchor[6], anchor[3], anchor[4], anchor[5]);
+    const Quat ai = aq.inverse(), e = cq * ai;
+    o.r[3] = 2.0 * e.x * si; o.r[4] = 2.0 * e.y * si; o.r[5] = 2.0 * e.z * si;
+    if (!jac) return;
+    o.J.assign(1, std::vector<double>(42, 0.0));
+    for (int i = 0; i < 3; i++) o.J[0][(size_t)i * 7 + i] = 2.0 * si;
+    const double Jq[9] = {ai.w, ai.z, -ai.y, -ai.z, ai.w, ai.x, ai.y, -ai.x, ai.w};
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) o.J[0][(size_t)(3 + r) * 7 + 3 + c] = Jq[3 * r + c] * 2.0 * si;
+}
+
 static void prior_dx(const gfo_window* w, const State& s, std::vector<double>& dx) {
     dx.assign(w->prior_n, 0.0);
     int idx = 0, off0 = 0;
@@ -444,6 +603,8 @@ struct Problem {
             case EX_POSE: return w->fix_ex_pose != 0; case EX_WHEEL: return w->fix_ex_wheel != 0;
             case SX: case SY: case SW: return w->fix_ix != 0;
             case TD: return w->fix_td != 0; case TD_WHEEL: return w->fix_td_wheel != 0;
+            case YAW: return true;   // problem.SetParameterBlockConstant(para_yaw_enu_local), estimator.cpp:2932
+            case RCV_DT: case RCV_DDT: case ANC: return false;
             default: return w->feature_fixed && w->feature_fixed[i] != 0;
         }
     }
@@ -461,6 +622,14 @@ struct Problem {
         for (int id : {bid(EX_WHEEL, 0), bid(SX, 0), bid(SY, 0), bid(SW, 0)}) if (w->n_wheel > 0 || in_prior(id)) add(id);
         add(bid(TD, 0));
         if (w->n_wheel > 0 || in_prior(bid(TD_WHEEL, 0))) add(bid(TD_WHEEL, 0));
+        if (w->gnss_enabled) {   // receiver clock / anchor blocks that some residual block (or the prior) mentions
+            const bool fac = !w->gnss_lowspeed;
+            for (int i = 0; i <= w->W; i++) {
+                for (int q = 0; q < 4; q++) if (fac || in_prior(bid(RCV_DT, 4 * i + q))) add(bid(RCV_DT, 4 * i + q));
+                if (fac || in_prior(bid(RCV_DDT, i))) add(bid(RCV_DDT, i));
+            }
+            if ((fac && w->n_gnss > 0) || in_prior(bid(ANC, 0))) add(bid(ANC, 0));
+        }
     }
     // Evaluates all residual blocks at s.  Returns cost = 1/2 sum rho(|r|^2).  If rows != null also the corrected residuals/Jacobians
     // of the free blocks (local parameterisation: first 6 columns of a 7-column pose Jacobian, pose_local_parameterization.cpp:30-36).
@@ -503,6 +672,12 @@ struct Problem {
             if (rb.nb > 0) rows->push_back(std::move(rb));
         };
         const bool jac = rows != nullptr;
+        if (w->has_anchor) {  // estimator.cpp:2943-2951
+            const int fid[1] = {bid(POSE, 0)};
+            const double* p[1] = {s.ptr(fid[0])};
+            eval_anchor(w->anchor_value, p, o, jac);
+            emit(fid, 1, false);
+        }
         if (w->prior_n > 0) {  // estimator.cpp:3102-3108
             std::vector<double> dx;
             prior_dx(w, s, dx);
@@ -541,6 +716,29 @@ struct Problem {
             for (int q = 0; q < 7; q++) p[q] = s.ptr(fid[q]);
             eval_wheel(w, k, p, o, jac);
             emit(fid, 7, false);
+        }
+        if (w->gnss_enabled && !w->gnss_lowspeed) {  // estimator.cpp:3178-3229
+            for (int k = 0; k < w->n_gnss; k++) {
+                const int i = w->gnss_frame[k], l = w->gnss_lower[k];
+                const int fid[8] = {bid(POSE, l), bid(SPEEDBIAS, l), bid(POSE, l + 1), bid(SPEEDBIAS, l + 1), bid(RCV_DT, 4 * i + w->gnss_sys[k]), bid(RCV_DDT, i), bid(YAW, 0), bid(ANC, 0)};
+                const double* p[8];
+                for (int q = 0; q < 8; q++) p[q] = s.ptr(fid[q]);
+                eval_gnss(w, k, p, o, jac);
+                emit(fid, 8, false);
+            }
+            for (int q = 0; q < 4; q++)
+                for (int i = 0; i < w->W; i++) {
+                    const int fid[4] = {bid(RCV_DT, 4 * i + q), bid(RCV_DT, 4 * (i + 1) + q), bid(RCV_DDT, i), bid(RCV_DDT, i + 1)};
+                    const double* p[4] = {s.ptr(fid[0]), s.ptr(fid[1]), s.ptr(fid[2]), s.ptr(fid[3])};
+                    eval_dt_ddt(w->gnss_headers[i + 1] - w->gnss_headers[i], p, o, jac);
+                    emit(fid, 4, false);
+                }
+            for (int i = 0; i < w->W; i++) {
+                const int fid[2] = {bid(RCV_DDT, i), bid(RCV_DDT, i + 1)};
+                const double* p[2] = {s.ptr(fid[0]), s.ptr(fid[1])};
+                eval_ddt_smooth(w->gnss_ddt_weight, p, o, jac);
+                emit(fid, 2, false);
+            }
         }
         for (int k = 0; k < w->n_visual; k++) {  // estimator.cpp:3269-3297, Huber(1.0)
             const int fid[5] = {bid(POSE, w->vis_i[k]), bid(POSE, w->vis_j[k]), bid(EX_POSE, 0), bid(FEATURE, w->vis_feature[k]), bid(TD, 0)};
@@ -859,6 +1057,21 @@ static int marginalize(const gfo_window* w, int mode, int cap_n, int* out_n, int
             const double* p[7]; for (int q = 0; q < 7; q++) p[q] = s.ptr(fid[q]);
             eval_wheel(w, k, p, o, true); push(fid, 7, false, {0});
         }
+        if (w->gnss_enabled) {  // :3390-3431: whenever gnss_ready, also at low speed
+            for (int k = 0; k < w->n_gnss; k++) if (w->gnss_frame[k] == 0) {
+                const int fid[8] = {bid(POSE, 0), bid(SPEEDBIAS, 0), bid(POSE, 1), bid(SPEEDBIAS, 1), bid(RCV_DT, w->gnss_sys[k]), bid(RCV_DDT, 0), bid(YAW, 0), bid(ANC, 0)};
+                const double* p[8]; for (int q = 0; q < 8; q++) p[q] = s.ptr(fid[q]);
+                eval_gnss(w, k, p, o, true); push(fid, 8, false, {0, 1, 4, 5});
+            }
+            for (int q = 0; q < 4; q++) {
+                const int fid[4] = {bid(RCV_DT, q), bid(RCV_DT, 4 + q), bid(RCV_DDT, 0), bid(RCV_DDT, 1)};
+                const double* p[4] = {s.ptr(fid[0]), s.ptr(fid[1]), s.ptr(fid[2]), s.ptr(fid[3])};
+                eval_dt_ddt(w->gnss_headers[1] - w->gnss_headers[0], p, o, true); push(fid, 4, false, {0, 2});
+            }
+            const int fid[2] = {bid(RCV_DDT, 0), bid(RCV_DDT, 1)};
+            const double* p[2] = {s.ptr(fid[0]), s.ptr(fid[1])};
+            eval_ddt_smooth(w->gnss_ddt_weight, p, o, true); push(fid, 2, false, {0});
+        }
         for (int k = 0; k < w->n_visual; k++) if (w->vis_i[k] == 0) {  // :3433-3462 (features starting at frame 0)
             const int fid[5] = {bid(POSE, 0), bid(POSE, w->vis_j[k]), bid(EX_POSE, 0), bid(FEATURE, w->vis_feature[k]), bid(TD, 0)};
             const double* p[5]; for (int q = 0; q < 5; q++) p[q] = s.ptr(fid[q]);
@@ -926,9 +1139,12 @@ static int marginalize(const gfo_window* w, int mode, int cap_n, int* out_n, int
     int nb = 0, x0off = 0;
     for (int id : keep) {
         int kind = id / 4096, i = id % 4096, nid = id;
-        if (kind == POSE || kind == SPEEDBIAS) {
+        if (kind == POSE || kind == SPEEDBIAS || kind == RCV_DDT) {
             if (mode == 0) nid = bid(kind, i - 1);
             else nid = (i == W) ? bid(kind, W - 1) : id;
+        } else if (kind == RCV_DT) {
+            if (mode == 0) nid = bid(kind, i - 4);
+            else nid = (i / 4 == W) ? bid(kind, i - 4) : id;
         }
         out_block_id[nb++] = nid;
         const double* p = s.ptr(id);
@@ -955,10 +1171,16 @@ int gfo_factor_eval(const gfo_window* w, int kind, int k, double* residuals, dou
     if (kind == 0) { const int f[5] = {bid(POSE, w->vis_i[k]), bid(POSE, w->vis_j[k]), bid(EX_POSE, 0), bid(FEATURE, w->vis_feature[k]), bid(TD, 0)}; nb = 5; memcpy(fid, f, sizeof f); }
     else if (kind == 1) { const int i = w->imu_i[k]; const int f[4] = {bid(POSE, i), bid(SPEEDBIAS, i), bid(POSE, i + 1), bid(SPEEDBIAS, i + 1)}; nb = 4; memcpy(fid, f, sizeof f); }
     else if (kind == 2) { const int i = w->wh_i[k]; const int f[7] = {bid(POSE, i), bid(POSE, i + 1), bid(EX_WHEEL, 0), bid(SX, 0), bid(SY, 0), bid(SW, 0), bid(TD_WHEEL, 0)}; nb = 7; memcpy(fid, f, sizeof f); }
+    else if (kind == 3) { const int i = w->gnss_frame[k], l = w->gnss_lower[k]; const int f[8] = {bid(POSE, l), bid(SPEEDBIAS, l), bid(POSE, l + 1), bid(SPEEDBIAS, l + 1), bid(RCV_DT, 4 * i + w->gnss_sys[k]), bid(RCV_DDT, i), bid(YAW, 0), bid(ANC, 0)}; nb = 8; memcpy(fid, f, sizeof f); }
+    else if (kind == 4) { const int i = k / 4, q = k % 4; const int f[4] = {bid(RCV_DT, 4 * i + q), bid(RCV_DT, 4 * (i + 1) + q), bid(RCV_DDT, i), bid(RCV_DDT, i + 1)}; nb = 4; memcpy(fid, f, sizeof f); }
+    else if (kind == 5) { const int f[2] = {bid(RCV_DDT, k), bid(RCV_DDT, k + 1)}; nb = 2; memcpy(fid, f, sizeof f); }
+    else if (kind == 6) { fid[0] = bid(POSE, 0); nb = 1; }
     else return -1;
     const double* p[8];
     for (int q = 0; q < nb; q++) p[q] = s.ptr(fid[q]);
-    if (kind == 0) eval_visual(w, k, p, o, true); else if (kind == 1) eval_imu(w, k, p, o, true); else eval_wheel(w, k, p, o, true);
+    if (kind == 0) eval_visual(w, k, p, o, true); else if (kind == 1) eval_imu(w, k, p, o, true); else if (kind == 2) eval_wheel(w, k, p, o, true);
+    else if (kind == 3) eval_gnss(w, k, p, o, true); else if (kind == 4) eval_dt_ddt(w->gnss_headers[k / 4 + 1] - w->gnss_headers[k / 4], p, o, true);
+    else if (kind == 5) eval_ddt_smooth(w->gnss_ddt_weight, p, o, true); else eval_anchor(w->anchor_value, p, o, true);
     int cols = 0;
     for (int q = 0; q < nb; q++) cols += gsize_of(fid[q] / 4096);
     *nres = o.nres; *ncols = cols;

@@ -42,7 +42,8 @@ int gfo_good_features(const uint8_t* img, int w, int h, float* corners, int maxC
 extern "C" {
 #endif
 /* Parameter-block ids used by priors: kind * 4096 + index */
-enum { GFO_POSE = 0, GFO_SPEEDBIAS = 1, GFO_EX_POSE = 2, GFO_EX_WHEEL = 3, GFO_SX = 4, GFO_SY = 5, GFO_SW = 6, GFO_TD = 7, GFO_TD_WHEEL = 8, GFO_FEATURE = 9 };
+enum { GFO_POSE = 0, GFO_SPEEDBIAS = 1, GFO_EX_POSE = 2, GFO_EX_WHEEL = 3, GFO_SX = 4, GFO_SY = 5, GFO_SW = 6, GFO_TD = 7, GFO_TD_WHEEL = 8, GFO_FEATURE = 9,
+       GFO_RCV_DT = 10, GFO_RCV_DDT = 11, GFO_YAW = 12, GFO_ANC = 13 };
 
 typedef struct gfo_window {
     int W, n_feature, n_visual, n_imu, n_wheel;
@@ -60,6 +61,24 @@ typedef struct gfo_window {
     const double* wh_covariance; const double* wh_lin; const double* wh_lin_vel; const double* wh_lin_gyr; const double* wh_vel_1; const double* wh_gyr_1;
     int prior_n, prior_nblocks;
     const int* prior_block_id; const double* prior_J; const double* prior_r; const double* prior_x0;
+    /* GNSS (estimator.cpp:2904-2941, :3178-3229, :3390-3431): blocks and factors.  gnss_enabled = gnss_ready; the factors enter the solve
+     * unless gnss_lowspeed (estimator.cpp:3178), and enter the MARGIN_OLD marginalisation whenever gnss_enabled (:3390).
+     * gnss_data per factor (16 doubles): sv_pos 3, sv_vel 3, svdt, svddt, tgd, pr_uura, dp_uura, psr, dopp, wavelength, time of GPS week [s], 0.
+     * What GnssPsrDoppFactor's constructor derives from observation + ephemeris (gnss_psr_dopp_factor.cpp:3-47) is handed over precomputed. */
+    int gnss_enabled, gnss_lowspeed, n_gnss, has_anchor;
+    double* para_rcv_dt;         /* 4 (W+1), in/out */
+    double* para_rcv_ddt;        /* (W+1) */
+    double* para_yaw_enu_local;  /* 1 (held constant, estimator.cpp:2932) */
+    double* para_anc_ecef;       /* 3 */
+    double gnss_ddt_weight;      /* GNSS_DDT_WEIGHT, parameters.cpp:549 */
+    double anchor_value[7];      /* PoseAnchorFactor on Pose[0] (estimator.cpp:2943-2951), sqrt_info 120 */
+    const double* gnss_iono;     /* 8 Klobuchar parameters */
+    const int* gnss_frame;       /* i: the factor uses rcv_dt[4 i + sys] and rcv_ddt[i] */
+    const int* gnss_lower;       /* lower_idx: the factor sits on (Pose, SpeedBias)[lower_idx] and [lower_idx + 1] */
+    const int* gnss_sys;         /* sys_idx 0..3 */
+    const double* gnss_ratio;    /* ts_ratio */
+    const double* gnss_data;     /* n_gnss x 16 */
+    const double* gnss_headers;  /* Headers[0..W]: DtDdtFactor(Headers[i+1] - Headers[i]), estimator.cpp:3214-3223 */
 } gfo_window;
 
 typedef struct gfo_summary {
@@ -73,7 +92,7 @@ int gfo_ba_solve(gfo_window* w, int max_iters, gfo_summary* s);
 /* estimator.cpp:3334-3631: mode 0 = MARGIN_OLD, 1 = MARGIN_SECOND_NEW. Outputs the next prior (block ids already address-shifted). */
 int gfo_ba_marginalize(const gfo_window* w, int mode, int cap_n, int* out_n, int* out_nblocks, int* out_block_id, double* out_J, double* out_r,
                        double* out_x0, int* out_m);
-/* factor evaluation for unit tests: kind 0 visual k, 1 imu k, 2 wheel k, 3 prior; returns residuals and the dense Jacobian wrt the factor's
+/* factor evaluation for unit tests: kind 0 visual k, 1 imu k, 2 wheel k, 3 GnssPsrDopp k, 4 DtDdt (k = 4 i + sys), 5 DdtSmooth k, 6 PoseAnchor; returns residuals and the dense Jacobian wrt the factor's
  * parameter blocks in GLOBAL size (row-major, blocks concatenated), as ceres::CostFunction::Evaluate fills them */
 int gfo_factor_eval(const gfo_window* w, int kind, int k, double* residuals, double* jacobians, int* nres, int* ncols);
 /* IntegrationBase::push_back loop (integration_base.h:39-167); noise = ACC_N, GYR_N, ACC_W, GYR_W */

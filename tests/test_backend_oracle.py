@@ -156,3 +156,96 @@ def test_sym_eig_matches_numpy(oracle):
         assert np.abs(np.sort(np.linalg.eigvalsh(A)) - d).max() < 1e-9 * max(1, d.max())
         assert np.abs(V @ np.diag(d) @ V.T - A).max() < 1e-9 * max(1, d.max())
         assert np.abs(V.T @ V - np.eye(n)).max() < 1e-11
+
+
+# ---------------------------------------------------------------- GNSS factors
+def _gnss_blocks(kind, w, k):
+    if kind == 3:
+        i, l = int(w["gnss_frame"][k]), int(w["gnss_lower"][k])
+        return [gw.bid(gw.POSE, l), gw.bid(gw.SPEEDBIAS, l), gw.bid(gw.POSE, l + 1), gw.bid(gw.SPEEDBIAS, l + 1), gw.bid(gw.RCV_DT, 4 * i + int(w["gnss_sys"][k])),
+                gw.bid(gw.RCV_DDT, i), gw.bid(gw.YAW), gw.bid(gw.ANC)]
+    if kind == 4:
+        i, q = k // 4, k % 4
+        return [gw.bid(gw.RCV_DT, 4 * i + q), gw.bid(gw.RCV_DT, 4 * (i + 1) + q), gw.bid(gw.RCV_DDT, i), gw.bid(gw.RCV_DDT, i + 1)]
+    if kind == 5:
+        return [gw.bid(gw.RCV_DDT, k), gw.bid(gw.RCV_DDT, k + 1)]
+    return [gw.bid(gw.POSE, 0)]
+
+
+def _gview(w, b):
+    kind, i = b // 4096, b % 4096
+    if kind == gw.RCV_DT:
+        return w["para_rcv_dt"], i, 1
+    if kind == gw.RCV_DDT:
+        return w["para_rcv_ddt"], i, 1
+    if kind == gw.YAW:
+        return w["para_yaw_enu_local"], 0, 1
+    if kind == gw.ANC:
+        return w["para_anc_ecef"], 0, 3
+    return _view(w, b)
+
+
+def _gplus(w, b, d):
+    if b // 4096 >= gw.RCV_DT:
+        arr, off, g = _gview(w, b)
+        arr[off:off + g] += d[:g]
+    else:
+        _plus(w, b, d)
+
+
+@pytest.mark.parametrize("kind,name", [(3, "psr_dopp"), (4, "dt_ddt"), (5, "ddt_smooth"), (6, "pose_anchor")])
+def test_gnss_factor_jacobians(oracle, kind, name):
+    """GnssPsrDoppFactor's analytic Jacobian leaves out the delay models, the elevation weights and (for the anchor) the rotation's dependence on
+    the anchor ("approximation for simplicity", gnss_psr_dopp_factor.cpp:199): it matches central differences to ~1e-4 relative, not to rounding."""
+    w = SW.make_window(3, oracle, gnss=True, anchor=True)
+    w["para_Pose"][0:3] += [0.05, -0.02, 0.01]      # off the anchor so that the PoseAnchorFactor residual is not zero
+    for k in (0, 7):
+        r0, J = oracle.factor_eval(w, kind, k)
+        assert np.all(np.isfinite(r0)) and np.all(np.isfinite(J))
+        col = 0
+        for b in _gnss_blocks(kind, w, k):
+            g, l = gw.gsize(b // 4096), gw.lsize(b // 4096)
+            for c in range(l):
+                eps = 1e-3 if kind == 3 else 1e-6
+                wp, wm = w.copy(), w.copy()
+                d = np.zeros(9); d[c] = eps
+                _gplus(wp, b, d); _gplus(wm, b, -d)
+                num = (oracle.factor_eval(wp, kind, k)[0] - oracle.factor_eval(wm, kind, k)[0]) / (2 * eps)
+                scale = max(1.0, np.abs(J).max())
+                if kind == 6:
+                    # pose_anchor_factor.cpp:29 multiplies the whole Jacobian by 2 sqrt_info, the residual by sqrt_info: position rows are twice the slope
+                    # ... and the rotation block is the derivative with respect to the quaternion's (x, y, z), used as if it were d/d(theta): a
+                    # reference quirk (diagonal 2x the true slope), kept as is.  Only the position part is a derivative that can be checked.
+                    if c < 3:
+                        assert np.abs(num[:3] - 0.5 * J[:3, col + c]).max() / scale < 1e-6, (name, b, c)
+                        assert np.all(J[3:, col + c] == 0)
+                elif kind == 3 and b // 4096 in (gw.ANC, gw.YAW):
+                    assert np.abs(num - J[:, col + c]).max() / scale < 5e-2, (name, b, c)      # documented approximation
+                else:
+                    assert np.abs(num - J[:, col + c]).max() / scale < (2e-3 if kind == 3 else 1e-6), (name, k, b, c, num, J[:, col + c])
+            col += g
+
+
+def test_gnss_window_solves_and_marginalises(oracle):
+    """GNSS blocks (receiver clocks, anchor) take part in the solve and the MARGIN_OLD prior keeps the frame-1 clocks under frame-0 names."""
+    w = SW.make_window(2, oracle, gnss=True)
+    a = w.copy()
+    s = oracle.ba_solve(a, 8)
+    assert s["final_cost"] < 0.2 * s["initial_cost"] and s["successful_steps"] >= 3
+    assert np.abs(a["para_rcv_dt"] - w["para_rcv_dt"]).max() > 0.1 and np.abs(a["para_anc_ecef"] - w["para_anc_ecef"]).max() > 1e-3
+    assert a["para_yaw_enu_local"][0] == w["para_yaw_enu_local"][0]                    # held constant
+    p = oracle.ba_marginalize(a, 0)
+    ids = [int(i) for i in p["block_id"]]
+    for q in range(4):
+        assert gw.bid(gw.RCV_DT, q) in ids and gw.bid(gw.RCV_DT, 4 + q) not in ids       # frame 1 clocks renamed to frame 0; nothing else kept
+    assert gw.bid(gw.RCV_DDT, 0) in ids and gw.bid(gw.ANC) in ids and gw.bid(gw.YAW) in ids
+    assert p["n"] == 6 * 10 + 9 + 6 + 6 + 3 + 1 + 1 + 4 + 1 + 1 + 3
+    w2 = SW.make_window(2, oracle, frame0=1, gnss=True, prior=p)
+    s2 = oracle.ba_solve(w2, 8)
+    assert s2["final_cost"] < s2["initial_cost"]
+    lo = SW.make_window(2, oracle, gnss=True, gnss_lowspeed=1)
+    s3 = oracle.ba_solve(lo, 8)
+    nog = SW.make_window(2, oracle)
+    s4 = oracle.ba_solve(nog, 8)
+    assert abs(s3["final_cost"] - s4["final_cost"]) < 1e-9 * s4["final_cost"]            # low speed: GNSS factors stay out of the solve
+    assert oracle.ba_marginalize(lo, 0)["n"] == p["n"]                                    # ... but not out of the marginalisation
