@@ -16,6 +16,7 @@
 #include "../../include/groundfusion_hip.h"
 #include "gf_ba_kernels.hpp"
 #include "gf_ba_marg.hpp"
+#include "gf_ba_gnss.hpp"
 
 namespace gf { int set_err(int code, const char* fmt, ...); }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return gf::set_err(GF_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
@@ -57,7 +58,8 @@ struct gf_ba {
     Buf<SolverState> st, st0;
     // work
     Buf<double> imu_sqrt, wh_sqrt, pri_A, pri_b, pri_c, pri_H0, H, g, cost, efac;
-    Buf<double> scale, diag, grad, gn, step, u, Et, Es, ete, etb, rhs, yv, Sg, Mg;
+    Buf<double> scale, diag, grad, gn, step, u, Et, Es, ete, etb, rhs, yv, Sg, Mg, gn_data, gn_misc;
+    Buf<int> ngnss, gn_idx;
     // marginalisation: column maps per mode (0 MARGIN_OLD, 1 MARGIN_SECOND_NEW), outputs
     Buf<int> mcolf[2], mcole[2], morder[2], mnorder[2], minfo[2];
     Buf<double> outJ, outr;
@@ -66,8 +68,8 @@ struct gf_ba {
     size_t marg_lds = 0; int marg_ncap = 0, last_marg_mode = -1;
     long long mfma_per_lin = 0;   // v_mfma_f64_16x16x4 instructions of one visual linearisation of the resident batch
     std::vector<Buf<double>*> dbl() { return {&xs0, &xs, &vis_data, &imu_data, &wh_data, &pri_J, &pri_r, &pri_x0, &imu_sqrt, &wh_sqrt, &pri_A, &pri_b, &pri_c, &pri_H0, &H, &g, &cost, &efac,
-                                              &scale, &diag, &grad, &gn, &step, &u, &Et, &Es, &ete, &etb, &rhs, &yv, &Sg, &Mg}; }
-    std::vector<Buf<int>*> ints() { return {&colf, &cole, &nvis, &nimu, &nwh, &nfeat, &vis_feat, &vis_i, &vis_j, &order, &norder, &feat_ptr, &feat_fac, &imu_i, &wh_i, &pri_n, &pri_nb, &pri_bid}; }
+                                              &scale, &diag, &grad, &gn, &step, &u, &Et, &Es, &ete, &etb, &rhs, &yv, &Sg, &Mg, &gn_data, &gn_misc}; }
+    std::vector<Buf<int>*> ints() { return {&colf, &cole, &nvis, &nimu, &nwh, &nfeat, &vis_feat, &vis_i, &vis_j, &order, &norder, &feat_ptr, &feat_fac, &imu_i, &wh_i, &pri_n, &pri_nb, &pri_bid, &ngnss, &gn_idx}; }
     void release() {
         for (auto* b : dbl()) b->release();
         for (auto* b : ints()) b->release();
@@ -84,6 +86,7 @@ struct gf_ba {
         Win w{};
         w.d = d; w.xs = xs.d; w.colf = colf.d; w.cole = cole.d; w.nvis = nvis.d; w.nimu = nimu.d; w.nwh = nwh.d; w.nfeat = nfeat.d;
         w.vis_feat = vis_feat.d; w.vis_i = vis_i.d; w.vis_j = vis_j.d; w.vis_data = vis_data.d; w.order = order.d; w.norder = norder.d;
+        w.ngnss = ngnss.d; w.gn_idx = gn_idx.d; w.gn_data = gn_data.d; w.gn_misc = gn_misc.d;
         w.feat_ptr = feat_ptr.d; w.feat_fac = feat_fac.d; w.imu_i = imu_i.d; w.imu_data = imu_data.d; w.wh_i = wh_i.d; w.wh_data = wh_data.d;
         w.imu_sqrt = imu_sqrt.d; w.wh_sqrt = wh_sqrt.d; w.pri_n = pri_n.d; w.pri_nb = pri_nb.d; w.pri_bid = pri_bid.d; w.pri_J = pri_J.d; w.pri_r = pri_r.d;
         w.pri_x0 = pri_x0.d; w.pri_H0 = pri_H0.d; w.prior_preloaded = 1; w.pri_A = pri_A.d; w.pri_b = pri_b.d; w.pri_c = pri_c.d; w.H = H.d; w.g = g.d; w.cost = cost.d; w.efac = efac.d; w.st = st.d;
@@ -112,12 +115,35 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
         if (w.W != d.W) return gf::set_err(GF_ERR_INVALID, "window %d: W=%d, handle built for %d", b, w.W, d.W);
         if (w.n_feature > d.F || w.n_visual > d.NV || w.n_imu > d.W || w.n_wheel > d.W || w.prior_n > d.NPRI || w.prior_nblocks > 64)
             return gf::set_err(GF_ERR_CAPACITY, "window %d exceeds capacity (features %d/%d, visual %d/%d, prior %d/%d)", b, w.n_feature, d.F, w.n_visual, d.NV, w.prior_n, d.NPRI);
+        if (w.gnss_enabled && (!d.GO || w.n_gnss > d.NG)) return gf::set_err(GF_ERR_CAPACITY, "window %d: %d GNSS factors, handle built for %d (gf_ba_cfg.max_gnss)", b, w.n_gnss, d.NG);
+        if (w.gnss_enabled && (!w.para_rcv_dt || !w.para_rcv_ddt || !w.para_yaw_enu_local || !w.para_anc_ecef || !w.gnss_headers || !w.gnss_iono || (w.n_gnss > 0 && (!w.gnss_frame || !w.gnss_lower || !w.gnss_sys || !w.gnss_ratio || !w.gnss_data))))
+            return gf::set_err(GF_ERR_INVALID, "window %d: GNSS enabled but a GNSS array is null", b);
         if (b == 0) { h->G[0] = w.G[0]; h->G[1] = w.G[1]; h->G[2] = w.G[2]; h->vis_sqrt_info = w.vis_sqrt_info; }
         double* x = h->xs0.h + (size_t)b * d.XS;
         memset(x, 0, d.XS * sizeof(double));
         for (int i = 0; i < d.NP; i++) { memcpy(x + off_pose(i), w.para_Pose + 7 * i, 56); memcpy(x + off_sb(i), w.para_SpeedBias + 9 * i, 72); }
         memcpy(x + off_ex(d.NP), w.para_Ex_Pose, 56); memcpy(x + off_exw(d.NP), w.para_Ex_Pose_wheel, 56); memcpy(x + off_ix(d.NP), w.para_Ix, 24);
         x[off_td(d.NP)] = w.para_Td[0]; x[off_tdw(d.NP)] = w.para_Td_wheel[0];
+        if (d.GO) {
+            h->ngnss.h[b] = w.gnss_enabled ? w.n_gnss : 0;
+            double* ms = h->gn_misc.h + (size_t)b * (GN_MISC + d.NP);
+            memset(ms, 0, (GN_MISC + d.NP) * sizeof(double));
+            if (w.gnss_enabled) {
+                memcpy(x + d.GO, w.para_rcv_dt, 4 * d.NP * 8); memcpy(x + d.GO + 4 * d.NP, w.para_rcv_ddt, d.NP * 8); x[d.GO + 5 * d.NP] = w.para_yaw_enu_local[0];
+                memcpy(x + d.GO + 5 * d.NP + 1, w.para_anc_ecef, 24);
+                memcpy(ms, w.gnss_iono, 64); ms[8] = w.gnss_ddt_weight; ms[16] = 1.0; ms[17] = w.gnss_lowspeed ? 0.0 : 1.0;
+                memcpy(ms + GN_MISC, w.gnss_headers, d.NP * 8);
+                for (int k = 0; k < w.n_gnss; k++) {
+                    if (w.gnss_frame[k] < 0 || w.gnss_frame[k] > d.W || w.gnss_lower[k] < 0 || w.gnss_lower[k] >= d.W || w.gnss_sys[k] < 0 || w.gnss_sys[k] > 3)
+                        return gf::set_err(GF_ERR_INVALID, "window %d: GNSS factor %d has bad indices", b, k);
+                    int* ix = h->gn_idx.h + ((size_t)b * d.NG + k) * 4;
+                    ix[0] = w.gnss_frame[k]; ix[1] = w.gnss_lower[k]; ix[2] = w.gnss_sys[k]; ix[3] = 0;
+                    double* gd = h->gn_data.h + ((size_t)b * d.NG + k) * GN_STRIDE;
+                    memcpy(gd, w.gnss_data + 16 * (size_t)k, 128); gd[16] = w.gnss_ratio[k]; gd[17] = 0;
+                }
+            }
+            if (w.has_anchor) { memcpy(ms + 9, w.anchor_value, 56); ms[18] = 1.0; }
+        } else if (w.has_anchor) return gf::set_err(GF_ERR_INVALID, "window %d: PoseAnchorFactor needs a handle built with max_gnss > 0", b);
         for (int f = 0; f < w.n_feature; f++) x[off_feat(d.NP) + f] = w.para_Feature[f];
         if (w.fix_poses) for (int i = 0; i < d.NP; i++) x[off_sb(i)] = x[off_sb(i) + 1] = x[off_sb(i) + 2] = 0.0;  // estimator.cpp:3233-3246
         // column maps (canonical order: pose0, sb0, pose1, ..., ex, exw, sx, sy, sw, td, tdw)
@@ -132,6 +158,14 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
         for (int q = 0; q < 3; q++) add(fb_sx(d.NP) + q, !part((GF_SX + q) * 4096) || w.fix_ix, 1);
         add(fb_td(d.NP), w.fix_td != 0, 1);
         add(fb_tdw(d.NP), !part(GF_TD_WHEEL * 4096) || w.fix_td_wheel, 1);
+        if (d.GO) {   // receiver clocks / anchor: free when a residual block or the prior mentions them (estimator.cpp:2904-2941); yaw_enu_local is held constant (:2932)
+            auto inpri = [&](int id) { for (int q = 0; q < w.prior_nblocks; q++) if (w.prior_block_id[q] == id) return true; return false; };
+            const bool fac = w.gnss_enabled && !w.gnss_lowspeed;
+            for (int i = 0; i < d.NP; i++) for (int q = 0; q < 4; q++) add(fb_rcvdt(d.NP, 4 * i + q), !(w.gnss_enabled && (fac || inpri(GF_RCV_DT * 4096 + 4 * i + q))), 1);
+            for (int i = 0; i < d.NP; i++) add(fb_rcvddt(d.NP, i), !(w.gnss_enabled && (fac || inpri(GF_RCV_DDT * 4096 + i))), 1);
+            add(fb_yaw(d.NP), true, 1);
+            add(fb_anc(d.NP), !(w.gnss_enabled && ((fac && w.n_gnss > 0) || inpri(GF_ANC * 4096))), 3);
+        }
         if (!w.fix_ex_pose) h->any_ex = true;
         SolverState& st = h->st0.h[b];
         memset(&st, 0, sizeof st);
@@ -216,7 +250,7 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
             auto has = [](const std::vector<int>& v, int id) { return std::find(v.begin(), v.end(), id) != v.end(); };
             auto touch = [&](int id, bool dropped) {
                 if (id / 4096 == GF_FEATURE) { if (!has(dropf, id)) dropf.push_back(id); return; }
-                if (dropped) { if (!has(dropb, id)) dropb.push_back(id); }
+                if (dropped) { if (!has(dropb, id)) { dropb.push_back(id); auto it = std::find(keepb.begin(), keepb.end(), id); if (it != keepb.end()) keepb.erase(it); } }
                 else if (!has(keepb, id) && !has(dropb, id)) keepb.push_back(id);
             };
             bool valid = true;
@@ -226,6 +260,13 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
                 for (int k = 0; k < w.n_wheel; k++) if (w.wh_i[k] == 0 && w.wh_sum_dt[k] < 10.0) {
                     touch(GF_POSE * 4096, true); touch(GF_POSE * 4096 + 1, false); touch(GF_EX_WHEEL * 4096, false); touch(GF_SX * 4096, false); touch(GF_SY * 4096, false);
                     touch(GF_SW * 4096, false); touch(GF_TD_WHEEL * 4096, false);
+                }
+                if (d.GO && w.gnss_enabled) {   // estimator.cpp:3390-3431
+                    for (int k = 0; k < w.n_gnss; k++) if (w.gnss_frame[k] == 0) {
+                        touch(GF_POSE * 4096, true); touch(GF_SPEEDBIAS * 4096, true); touch(GF_POSE * 4096 + 1, false); touch(GF_SPEEDBIAS * 4096 + 1, false);
+                        touch(GF_RCV_DT * 4096 + w.gnss_sys[k], true); touch(GF_RCV_DDT * 4096, true); touch(GF_YAW * 4096, false); touch(GF_ANC * 4096, false);
+                    }
+                    for (int q = 0; q < 4; q++) { touch(GF_RCV_DT * 4096 + q, true); touch(GF_RCV_DT * 4096 + 4 + q, false); touch(GF_RCV_DDT * 4096, true); touch(GF_RCV_DDT * 4096 + 1, false); }
                 }
                 for (int k = 0; k < w.n_visual; k++) if (w.vis_i[k] == 0) {
                     touch(GF_POSE * 4096, true); touch(GF_POSE * 4096 + w.vis_j[k], false); touch(GF_EX_POSE * 4096, false); touch(GF_FEATURE * 4096 + w.vis_feature[k], true);
@@ -243,7 +284,8 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
             auto fblk = [&](int id) {
                 const int kind = id / 4096, i = id % 4096;
                 switch (kind) { case 0: return fb_pose(i); case 1: return fb_sb(i); case 2: return fb_ex(d.NP); case 3: return fb_exw(d.NP); case 4: return fb_sx(d.NP);
-                                case 5: return fb_sx(d.NP) + 1; case 6: return fb_sx(d.NP) + 2; case 7: return fb_td(d.NP); default: return fb_tdw(d.NP); }
+                                case 5: return fb_sx(d.NP) + 1; case 6: return fb_sx(d.NP) + 2; case 7: return fb_td(d.NP); case 10: return fb_rcvdt(d.NP, i); case 11: return fb_rcvddt(d.NP, i);
+                                case 12: return fb_yaw(d.NP); case 13: return fb_anc(d.NP); default: return fb_tdw(d.NP); }
             };
             int mp = 0, n = 0;
             for (int id : dropb) { mc[fblk(id)] = mp; mp += lsize_kind(id / 4096); }
@@ -283,6 +325,7 @@ int upload(gf_ba* h) {
                     &h->imu_i, &h->wh_i, &h->pri_n, &h->pri_nb, &h->pri_bid})
         HIPCHK(b->up(s));
     for (auto* b : {&h->vis_data, &h->imu_data, &h->wh_data, &h->pri_J, &h->pri_r, &h->pri_x0}) HIPCHK(b->up(s));
+    if (h->d.GO) { HIPCHK(h->ngnss.up(s)); HIPCHK(h->gn_idx.up(s)); HIPCHK(h->gn_data.up(s)); HIPCHK(h->gn_misc.up(s)); }
     for (int m = 0; m < 2; m++) for (auto* b : {&h->mcolf[m], &h->mcole[m], &h->morder[m], &h->mnorder[m], &h->minfo[m]}) HIPCHK(b->up(s));
     HIPCHK(hipMemcpyAsync(h->st0.d, h->st0.h, h->st0.n * sizeof(SolverState), hipMemcpyHostToDevice, s));
     ba_setup<<<dim3(h->d.B), 256, 0, s>>>(h->win());
@@ -310,6 +353,7 @@ int launch_linearize(gf_ba* h, int which, int which_state, int cost_only, int on
     HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
     ba_linearize_misc<<<dim3(2 * d.W, d.B), 64, 0, h->stream2>>>(w, which, which_state, cost_only, only_valid, 0, 0);
     ba_linearize_misc<<<dim3(1, d.B), 256, 0, h->stream2>>>(w, which, which_state, cost_only, only_valid, 0, 2 * d.W);
+    if (d.GO) ba_linearize_gnss<<<dim3((d.NG + 5 * d.W + 1 + 63) / 64, d.B), 64, 0, h->stream2>>>(w, which, which_state, cost_only, only_valid, 0);
     HIPCHK(hipEventRecord(h->ev_join, h->stream2));
     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
     HIPCHK(hipGetLastError());
@@ -348,6 +392,7 @@ int run_marginalize(gf_ba* h, int mode) {
     ba_zero_other<<<dim3(d.B), 256, 0, h->stream>>>(w);
     if (mode == 0) ba_linearize_visual<true><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(wm, -1, -2, 0, 2);
     if (mode == 0) ba_linearize_misc<<<dim3(2 * d.W, d.B), 64, 0, h->stream>>>(wm, -1, -2, 0, 2, 1, 0);
+    if (mode == 0 && d.GO) ba_linearize_gnss<<<dim3((d.NG + 5 * d.W + 1 + 63) / 64, d.B), 64, 0, h->stream>>>(wm, -1, -2, 0, 2, 1);
     ba_linearize_misc<<<dim3(1, d.B), 256, 0, h->stream>>>(wm, -1, -2, 0, 2, 2, 2 * d.W);
     ba_build_et<<<dim3(d.F, d.B), 64, 0, h->stream>>>(wm, h->sbufs(), -1, 1);
     MargOut mo{h->outJ.d, h->outr.d};
@@ -372,8 +417,10 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     Dims& d = h->d;
     d.B = cfg->batch; d.W = cfg->window_size; d.NP = d.W + 1; d.F = cfg->max_features; d.NV = cfg->max_visual;
     d.NVP = ((d.NV + d.NP * d.NP / 2 + 63) / 64) * 64;
-    const int Rmax = 15 * d.NP + 17;
-    d.RP = (Rmax + 1 + 15) & ~15; /* one spare column: the Schur GEMM carries the right-hand side in column R */ d.XS = (16 * d.NP + 20 + d.F + 3) & ~3; d.NFB = 2 * d.NP + 7; d.FP = (d.F + 3) & ~3; d.NPRI = d.RP; d.ECW = (6 * d.NP + 8 + 15) & ~15;
+    const bool gnss = cfg->max_gnss > 0;
+    d.NG = gnss ? ((cfg->max_gnss + 63) & ~63) : 0;
+    const int Rmax = 15 * d.NP + 17 + (gnss ? 5 * d.NP + 3 : 0);
+    d.RP = (Rmax + 1 + 15) & ~15; /* one spare column: the Schur GEMM carries the right-hand side in column R */ d.GO = gnss ? ((16 * d.NP + 20 + d.F + 3) & ~3) : 0; d.XS = gnss ? ((d.GO + 5 * d.NP + 4 + 3) & ~3) : ((16 * d.NP + 20 + d.F + 3) & ~3); d.NFB = 2 * d.NP + 7 + (gnss ? 5 * d.NP + 2 : 0); d.FP = (d.F + 3) & ~3; d.NPRI = d.RP; d.ECW = (6 * d.NP + 8 + 15) & ~15;
     h->step_lds = (size_t)(Rmax + 1) * (Rmax + 2) / 2 * sizeof(double);  // packed lower S plus the right-hand-side row
     h->big_step = h->step_lds + 16 * 1024 > 160 * 1024 || getenv("GF_BA_FORCE_GLOBAL") != nullptr;   // reduced system too large for LDS: ba_step<true> keeps it in global memory
     if (Rmax + 1 > 512) { delete h; return gf::set_err(GF_ERR_INVALID, "window_size %d: reduced system (%d) exceeds 511 columns", d.W, Rmax); }
@@ -402,10 +449,11 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     A_(h->scale.alloc(B * VS, false)); A_(h->diag.alloc(B * VS, false)); A_(h->grad.alloc(B * VS, false)); A_(h->gn.alloc(B * VS, false)); A_(h->step.alloc(B * VS, false));
     A_(h->u.alloc(B * VS, false)); A_(h->Et.alloc(2 * B * d.FP * d.ECW, true)); A_(h->Es.alloc(B * d.FP * d.ECW, false)); A_(h->ete.alloc(2 * B * d.FP, true)); A_(h->etb.alloc(2 * B * d.FP, true));
     A_(h->rhs.alloc(B * d.RP, false)); A_(h->yv.alloc(B * VS, false));
+    if (gnss) { A_(h->ngnss.alloc(B, true)); A_(h->gn_idx.alloc(B * d.NG * 4, true)); A_(h->gn_data.alloc(B * d.NG * GN_STRIDE, true)); A_(h->gn_misc.alloc(B * (GN_MISC + d.NP), true)); }
     for (int m = 0; m < 2; m++) { A_(h->mcolf[m].alloc(B * d.NFB, true)); A_(h->mcole[m].alloc(B * d.F, true)); A_(h->morder[m].alloc(B * d.NVP, true)); A_(h->mnorder[m].alloc(B, true)); A_(h->minfo[m].alloc(B * 4, true)); }
     A_(h->outJ.alloc(B * (size_t)d.NPRI * d.NPRI, true)); A_(h->outr.alloc(B * d.NPRI, true)); A_(h->stamps.alloc(64, true));
     // kept system of the marginalisation: 6 W poses + speed-bias + extrinsics ...; A and V live in LDS up to 92 columns, else in global memory
-    const int nkeep = 6 * d.W + 9 + 17;
+    const int nkeep = 6 * d.W + 9 + 17 + (gnss ? 9 : 0);
     h->big_marg = nkeep > 92 || getenv("GF_BA_FORCE_GLOBAL") != nullptr;
     h->marg_ncap = h->big_marg ? std::min(d.NPRI, nkeep + 16) : 92;
     h->marg_lds = h->big_marg ? 0 : (size_t)2 * h->marg_ncap * h->marg_ncap * sizeof(double);
@@ -495,6 +543,7 @@ int gf_ba_download(gf_ba* h, gf_ba_window* windows, int count, gf_ba_summary* su
             memcpy(w.para_Ex_Pose, x + off_ex(d.NP), 56); memcpy(w.para_Ex_Pose_wheel, x + off_exw(d.NP), 56); memcpy(w.para_Ix, x + off_ix(d.NP), 24);
             w.para_Td[0] = x[off_td(d.NP)]; w.para_Td_wheel[0] = x[off_tdw(d.NP)];
             for (int f = 0; f < w.n_feature; f++) w.para_Feature[f] = x[off_feat(d.NP) + f];
+            if (d.GO && w.gnss_enabled) { memcpy(w.para_rcv_dt, x + d.GO, 4 * d.NP * 8); memcpy(w.para_rcv_ddt, x + d.GO + 4 * d.NP, d.NP * 8); w.para_yaw_enu_local[0] = x[d.GO + 5 * d.NP]; memcpy(w.para_anc_ecef, x + d.GO + 5 * d.NP + 1, 24); }
         }
         if (priors) {
             gf_ba_prior& p = priors[b];
@@ -513,11 +562,13 @@ int gf_ba_download(gf_ba* h, gf_ba_window* windows, int count, gf_ba_summary* su
                 for (size_t q = 0; q < keep.size(); q++) {
                     const int id = keep[q], kind = id / 4096, i = id % 4096;
                     int nid = id;  // addr_shift (estimator.cpp:3471-3500 / :3583-3626)
-                    if (kind == GF_POSE || kind == GF_SPEEDBIAS) nid = mode == 0 ? kind * 4096 + i - 1 : (i == d.W ? kind * 4096 + d.W - 1 : id);
+                    if (kind == GF_POSE || kind == GF_SPEEDBIAS || kind == GF_RCV_DDT) nid = mode == 0 ? kind * 4096 + i - 1 : (i == d.W ? kind * 4096 + d.W - 1 : id);
+                    else if (kind == GF_RCV_DT) nid = mode == 0 ? id - 4 : (i / 4 == d.W ? id - 4 : id);
                     p.block_id[q] = nid;
                     int off;
                     switch (kind) { case 0: off = off_pose(i); break; case 1: off = off_sb(i); break; case 2: off = off_ex(d.NP); break; case 3: off = off_exw(d.NP); break;
                                     case 4: off = off_ix(d.NP); break; case 5: off = off_ix(d.NP) + 1; break; case 6: off = off_ix(d.NP) + 2; break; case 7: off = off_td(d.NP); break;
+                                    case 10: off = d.GO + i; break; case 11: off = d.GO + 4 * d.NP + i; break; case 12: off = d.GO + 5 * d.NP; break; case 13: off = d.GO + 5 * d.NP + 1; break;
                                     default: off = off_tdw(d.NP); }
                     for (int k = 0; k < gsize_kind(kind); k++) p.x0[xo++] = x[off + k];
                 }
@@ -582,6 +633,11 @@ int gf_ba_linearize(gf_ba* h, const gf_ba_window* w, int cap, double* Hout, doub
         for (int i = 0; i < d.NP; i++) { if (cf[fb_pose(i)] >= 0) for (int q = 0; q < 6; q++) col_block_id[cf[fb_pose(i)] + q] = GF_POSE * 4096 + i; if (cf[fb_sb(i)] >= 0) for (int q = 0; q < 9; q++) col_block_id[cf[fb_sb(i)] + q] = GF_SPEEDBIAS * 4096 + i; }
         const int kinds[7] = {GF_EX_POSE, GF_EX_WHEEL, GF_SX, GF_SY, GF_SW, GF_TD, GF_TD_WHEEL};
         for (int q = 0; q < 7; q++) { const int c0 = cf[2 * d.NP + q]; if (c0 >= 0) for (int k = 0; k < (q < 2 ? 6 : 1); k++) col_block_id[c0 + k] = kinds[q] * 4096; }
+        if (d.GO) {
+            for (int q = 0; q < 4 * d.NP; q++) if (cf[fb_rcvdt(d.NP, q)] >= 0) col_block_id[cf[fb_rcvdt(d.NP, q)]] = GF_RCV_DT * 4096 + q;
+            for (int i = 0; i < d.NP; i++) if (cf[fb_rcvddt(d.NP, i)] >= 0) col_block_id[cf[fb_rcvddt(d.NP, i)]] = GF_RCV_DDT * 4096 + i;
+            if (cf[fb_anc(d.NP)] >= 0) for (int k = 0; k < 3; k++) col_block_id[cf[fb_anc(d.NP)] + k] = GF_ANC * 4096;
+        }
         for (int f = 0; f < d.F; f++) if (h->cole.h[f] >= 0) col_block_id[R + h->cole.h[f]] = GF_FEATURE * 4096 + f;
     }
     return GF_OK;

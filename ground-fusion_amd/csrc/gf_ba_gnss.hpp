@@ -1,0 +1,232 @@
+// gf_ba_gnss.hpp — GNSS residual blocks of the sliding window on the device:
+//   GnssPsrDoppFactor  factor/gnss_psr_dopp_factor.cpp:49-208   pseudorange + Doppler of one satellite, interpolated between two frames
+//   DtDdtFactor        factor/gnss_dt_ddt_factor.cpp            receiver clock bias vs drift between consecutive frames (x4 constellations)
+//   DdtSmoothFactor    factor/gnss_ddt_smooth_factor.cpp        drift smoothness
+//   PoseAnchorFactor   factor/pose_anchor_factor.cpp            gauge anchor of Pose[0] at the first optimisation
+// One lane per residual block (they are independent and tiny: 2 x 17, 1 x 4, 1 x 2, 6 x 6); the blocks' J^T J / J^T r go to H / g with the same
+// lower-triangle atomics as the other factor kernels.  ECEF magnitudes are ~6.4e6 m, so everything stays FP64.
+// gnss_comm (not vendored by the reference) supplies ecef2geo / ecef2rotation / sat_azel / Saastamoinen / Klobuchar; restated from the published
+// algorithms (RTKLIB lineage), the same formulas as the CPU oracle -- both documented as "parity unpinned" against gnss_comm itself.
+#pragma once
+#include "gf_ba_kernels.hpp"
+
+namespace gfb {
+
+constexpr double GN_C = 2.99792458e8, GN_OMG = 7.2921151467e-5, GN_A = 6378137.0, GN_E2 = 6.69437999014e-3, GN_PI = 3.14159265358979323846;
+
+__device__ inline V3 gn_ecef2geo(V3 p) {   // latitude [deg], longitude [deg], height [m]
+    if (p.x == 0 && p.y == 0) return v3(0, 0, 0);
+    const double a = GN_A, a2 = a * a, b2 = a2 * (1 - GN_E2), b = sqrt(b2), ep2 = (a2 - b2) / b2, rho = sqrt(p.x * p.x + p.y * p.y);
+    double s1 = p.z * a, s2 = rho * b, h = sqrt(s1 * s1 + s2 * s2);
+    const double st = s1 / h, ct = s2 / h;
+    s1 = p.z + ep2 * b * st * st * st;
+    s2 = rho - a * GN_E2 * ct * ct * ct;
+    h = sqrt(s1 * s1 + s2 * s2);
+    const double sin_lat = s1 / h, cos_lat = s2 / h;
+    const double N = a2 / sqrt(a2 * cos_lat * cos_lat + b2 * sin_lat * sin_lat);
+    return v3(atan(s1 / s2) * 180.0 / GN_PI, atan2(p.y, p.x) * 180.0 / GN_PI, rho / cos_lat - N);
+}
+__device__ inline M3 gn_geo2rotation(V3 lla) {   // R_ecef_enu
+    const double lat = lla.x * GN_PI / 180.0, lon = lla.y * GN_PI / 180.0, sl = sin(lat), cl = cos(lat), so = sin(lon), co = cos(lon);
+    M3 R;
+    R.m[0] = -so; R.m[1] = -sl * co; R.m[2] = cl * co;
+    R.m[3] = co;  R.m[4] = -sl * so; R.m[5] = cl * so;
+    R.m[6] = 0;   R.m[7] = cl;       R.m[8] = sl;
+    return R;
+}
+__device__ inline void gn_sat_azel(V3 rcv, V3 sat, double& az, double& el) {
+    V3 dl = sat - rcv; dl = dl / sqrt(sqn(dl));
+    const V3 enu = transpose(gn_geo2rotation(gn_ecef2geo(rcv))) * dl;
+    az = (sqrt(dl.x * dl.x + dl.y * dl.y) < 1e-12) ? 0.0 : atan2(enu.x, enu.y);
+    if (az < 0) az += 2 * GN_PI;
+    el = asin(enu.z);
+}
+__device__ inline double gn_trop_delay(V3 lla, double el) {   // Saastamoinen, standard atmosphere, humidity 0.7
+    if (lla.z < -100.0 || 1e4 < lla.z || el <= 0) return 0.0;
+    const double hgt = lla.z < 0.0 ? 0.0 : lla.z;
+    const double pres = 1013.25 * pow(1.0 - 2.2557e-5 * hgt, 5.2568), temp = 15.0 - 6.5e-3 * hgt + 273.16;
+    const double e = 6.108 * 0.7 * exp((17.15 * temp - 4684.0) / (temp - 38.45)), z = GN_PI / 2.0 - el;
+    const double trph = 0.0022768 * pres / (1.0 - 0.00266 * cos(2.0 * lla.x * GN_PI / 180.0) - 0.00028 * hgt / 1e3) / cos(z);
+    const double trpw = 0.002277 * (1255.0 / temp + 0.05) * e / cos(z);
+    return trph + trpw;
+}
+__device__ inline double gn_ion_delay(double tow, const double* ion_in, V3 lla, double az, double el) {   // Klobuchar
+    const double ion_default[8] = {0.1118e-07, -0.7451e-08, -0.5961e-07, 0.1192e-06, 0.1167e+06, -0.2294e+06, -0.1311e+06, 0.1049e+07};
+    if (lla.z < -1e3 || el <= 0) return 0.0;
+    double nrm = 0;
+    for (int i = 0; i < 8; i++) nrm += ion_in[i] * ion_in[i];
+    double ion[8];
+    for (int i = 0; i < 8; i++) ion[i] = nrm <= 0.0 ? ion_default[i] : ion_in[i];
+    const double psi = 0.0137 / (el / GN_PI + 0.11) - 0.022;
+    double phi = lla.x / 180.0 + psi * cos(az);
+    if (phi > 0.416) phi = 0.416; else if (phi < -0.416) phi = -0.416;
+    const double lam = lla.y / 180.0 + psi * sin(az) / cos(phi * GN_PI);
+    phi += 0.064 * cos((lam - 1.617) * GN_PI);
+    double tt = 43200.0 * lam + tow;
+    tt -= floor(tt / 86400.0) * 86400.0;
+    const double f = 1.0 + 16.0 * pow(0.53 - el / GN_PI, 3.0);
+    double amp = ion[0] + phi * (ion[1] + phi * (ion[2] + phi * ion[3])), per = ion[4] + phi * (ion[5] + phi * (ion[6] + phi * ion[7]));
+    amp = amp < 0.0 ? 0.0 : amp; per = per < 72000.0 ? 72000.0 : per;
+    const double x = 2.0 * GN_PI * (tt - 50400.0) / per;
+    return GN_C * f * (fabs(x) < 1.57 ? 5e-9 + amp * (1.0 + x * x * (-0.5 + x * x / 24.0)) : 5e-9);
+}
+
+// One residual block: nres rows, ncol local columns with solver columns col[] (-1: constant), J row-major nres x ncol.  Adds 1/2 |r|^2 to the cost
+// and J^T J (lower triangle) / J^T r to H / g.
+template <int NR, int NC>
+__device__ inline void gn_accumulate(const double (&r)[NR], const double (&J)[NR * NC], const int (&col)[NC], double* H, double* g, double* cost, int RP, bool cost_only) {
+    double c = 0;
+#pragma unroll
+    for (int i = 0; i < NR; i++) c += r[i] * r[i];
+    atomicAdd(cost, 0.5 * c);
+    if (cost_only) return;
+    for (int a = 0; a < NC; a++) {
+        const int ca = col[a];
+        if (ca < 0) continue;
+        double gv = 0;
+#pragma unroll
+        for (int i = 0; i < NR; i++) gv += J[i * NC + a] * r[i];
+        if (gv != 0.0) atomicAdd(g + ca, gv);
+        for (int b2 = 0; b2 < NC; b2++) {
+            const int cb = col[b2];
+            if (cb < 0 || cb > ca) continue;
+            if (cb == ca && b2 > a) continue;   // (a, b2) and (b2, a) hit the same diagonal entry only when a == b2
+            double hv = 0;
+#pragma unroll
+            for (int i = 0; i < NR; i++) hv += J[i * NC + a] * J[i * NC + b2];
+            if (hv != 0.0) atomicAdd(H + (size_t)ca * RP + cb, hv);
+        }
+    }
+}
+
+// grid (ceil((NG + 5 W + 1) / 64), B), 64 threads, one residual block per lane: items [0, NG) GnssPsrDopp, [NG, NG + 4W) DtDdt (item = NG + 4 i + q),
+// [NG + 4W, NG + 5W) DdtSmooth, NG + 5W PoseAnchor.  frame_filter as in ba_linearize_misc: 1 = blocks of frame 0 only (MARGIN_OLD, taken whenever
+// GNSS is enabled, estimator.cpp:3390), 2 = none; 0 = the solve (only when in_solve, i.e. gnss_ready && !lowspeed, estimator.cpp:3178).
+__global__ void __launch_bounds__(64) ba_linearize_gnss(Win w, int which, int which_state, int cost_only, int only_cand_valid, int frame_filter) {
+    const Dims d = w.d;
+    const int b = blockIdx.y, item = blockIdx.x * 64 + threadIdx.x;
+    const SolverState& st = w.st[b];
+    if (st.done && only_cand_valid != 2) return;
+    if (only_cand_valid == 1 && !st.cand_valid) return;
+    if (frame_filter == 2) return;
+    if (which < 0) which = 1 - st.cur;
+    if (which_state == -2) which_state = st.cur; else if (which_state < 0) which_state = 1 - st.cur;
+    const double* misc = w.gn_misc + (size_t)b * (GN_MISC + d.NP);
+    const bool enabled = misc[16] != 0.0, in_solve = misc[17] != 0.0, has_anchor = misc[18] != 0.0;
+    const double* hdr = misc + GN_MISC;
+    const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
+    const int* colf = w.colf + (size_t)b * d.NFB;
+    double* H = w.H + ((size_t)which * d.B + b) * d.RP * d.RP;
+    double* g = w.g + ((size_t)which * d.B + b) * d.RP;
+    double* cost = w.cost + (size_t)which * d.B + b;
+    const int NP = d.NP, W = d.W;
+    auto cof = [&](int fb, int o) { const int c0 = colf[fb]; return c0 >= 0 ? c0 + o : -1; };
+    if (item == d.NG + 5 * W) {   // PoseAnchorFactor, sqrt_info 120 (pose_anchor_factor.h:19); only in the solve
+        if (frame_filter != 0 || !has_anchor) return;
+        const double* an = misc + 9;
+        const double* P = xs + off_pose(0);
+        const double si = 120.0;
+        double r[6], J[36];
+        int col[6];
+        for (int i = 0; i < 36; i++) J[i] = 0.0;
+        for (int i = 0; i < 3; i++) { r[i] = (P[i] - an[i]) * si; J[i * 6 + i] = 2.0 * si; }
+        const Q4 ai = qinverse(Q4{an[6], an[3], an[4], an[5]}), e = qmul(q_of(P), ai);
+        r[3] = 2.0 * e.x * si; r[4] = 2.0 * e.y * si; r[5] = 2.0 * e.z * si;
+        const double Jq[9] = {ai.w, ai.z, -ai.y, -ai.z, ai.w, ai.x, ai.y, -ai.x, ai.w};
+        for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) J[(3 + a) * 6 + 3 + c] = Jq[3 * a + c] * 2.0 * si;
+        for (int c = 0; c < 6; c++) col[c] = cof(fb_pose(0), c);
+        gn_accumulate<6, 6>(r, J, col, H, g, cost, d.RP, cost_only != 0);
+        return;
+    }
+    if (!enabled || (frame_filter == 0 && !in_solve)) return;
+    if (item >= d.NG + 4 * W && item < d.NG + 5 * W) {   // DdtSmoothFactor(GNSS_DDT_WEIGHT) on rcv_ddt[i], rcv_ddt[i+1]
+        const int i = item - d.NG - 4 * W;
+        if (frame_filter == 1 && i != 0) return;
+        const double wt = misc[8];
+        const double r[1] = {(xs[d.GO + 4 * NP + i] - xs[d.GO + 4 * NP + i + 1]) * wt};
+        const double J[2] = {wt, -wt};
+        const int col[2] = {cof(fb_rcvddt(NP, i), 0), cof(fb_rcvddt(NP, i + 1), 0)};
+        gn_accumulate<1, 2>(r, J, col, H, g, cost, d.RP, cost_only != 0);
+        return;
+    }
+    if (item >= d.NG && item < d.NG + 4 * W) {   // DtDdtFactor(Headers[i+1] - Headers[i]), dt_info_coeff 50
+        const int i = (item - d.NG) / 4, q = (item - d.NG) % 4;
+        if (frame_filter == 1 && i != 0) return;
+        const double delta_t = hdr[i + 1] - hdr[i];
+        const double r[1] = {(xs[d.GO + 4 * (i + 1) + q] - xs[d.GO + 4 * i + q] - 0.5 * (xs[d.GO + 4 * NP + i] + xs[d.GO + 4 * NP + i + 1]) * delta_t) * 50.0};
+        const double J[4] = {-50.0, 50.0, -0.5 * delta_t * 50.0, -0.5 * delta_t * 50.0};
+        const int col[4] = {cof(fb_rcvdt(NP, 4 * i + q), 0), cof(fb_rcvdt(NP, 4 * (i + 1) + q), 0), cof(fb_rcvddt(NP, i), 0), cof(fb_rcvddt(NP, i + 1), 0)};
+        gn_accumulate<1, 4>(r, J, col, H, g, cost, d.RP, cost_only != 0);
+        return;
+    }
+    if (item >= w.ngnss[b]) return;
+    // ---- GnssPsrDoppFactor
+    const int* ix = w.gn_idx + ((size_t)b * d.NG + item) * 4;
+    const int fi = ix[0], lo = ix[1], sys = ix[2];
+    if (frame_filter == 1 && fi != 0) return;
+    const double* dat = w.gn_data + ((size_t)b * d.NG + item) * GN_STRIDE;
+    const V3 sv_pos = v3(dat[0], dat[1], dat[2]), sv_vel = v3(dat[3], dat[4], dat[5]);
+    const double svdt = dat[6], svddt = dat[7], tgd = dat[8], pr_uura = dat[9], dp_uura = dat[10], psr = dat[11], dopp = dat[12], wavelength = dat[13], tow = dat[14];
+    const double ratio = dat[16];
+    const double* Pi_ = xs + off_pose(lo); const double* Pj_ = xs + off_pose(lo + 1);
+    const double* SBi = xs + off_sb(lo); const double* SBj = xs + off_sb(lo + 1);
+    const V3 Pi = p_of(Pi_), Pj = p_of(Pj_), Vi = v3(SBi[0], SBi[1], SBi[2]), Vj = v3(SBj[0], SBj[1], SBj[2]);
+    const double rcv_dt = xs[d.GO + 4 * fi + sys], rcv_ddt = xs[d.GO + 4 * NP + fi], yaw_diff = xs[d.GO + 5 * NP];
+    const V3 ref_ecef = v3(xs[d.GO + 5 * NP + 1], xs[d.GO + 5 * NP + 2], xs[d.GO + 5 * NP + 3]);
+    const V3 local_pos = Pi * ratio + Pj * (1.0 - ratio), local_vel = Vi * ratio + Vj * (1.0 - ratio);
+    const double sy = sin(yaw_diff), cy = cos(yaw_diff);
+    M3 R_enu_local = m3_zero();
+    R_enu_local.m[0] = cy; R_enu_local.m[1] = -sy; R_enu_local.m[3] = sy; R_enu_local.m[4] = cy; R_enu_local.m[8] = 1;
+    const M3 R_ecef_enu = gn_geo2rotation(gn_ecef2geo(ref_ecef)), R_ecef_local = R_ecef_enu * R_enu_local;
+    const V3 P_ecef = R_ecef_local * local_pos + ref_ecef, V_ecef = R_ecef_local * local_vel;
+    double ion_delay = 0, tro_delay = 0, az = 0, el = GN_PI / 2.0;
+    if (sqn(P_ecef) > 0) {
+        gn_sat_azel(P_ecef, sv_pos, az, el);
+        const V3 lla = gn_ecef2geo(P_ecef);
+        tro_delay = gn_trop_delay(lla, el);
+        ion_delay = gn_ion_delay(tow, misc, lla, az, el);
+    }
+    const double sin_el = sin(el), sin_el_2 = sin_el * sin_el;
+    const double pr_weight = sin_el_2 / pr_uura * 10.0, dp_weight = sin_el_2 / dp_uura * 10.0 * 5.0;   // relative_sqrt_info 10, PSR_TO_DOPP_RATIO 5
+    const V3 rcv2sat = sv_pos - P_ecef;
+    const double norm2 = sqn(rcv2sat), rng = sqrt(norm2);
+    const V3 unit = rcv2sat / rng;
+    const double psr_sagnac = GN_OMG * (sv_pos.x * P_ecef.y - sv_pos.y * P_ecef.x) / GN_C;
+    const double psr_est = rng + psr_sagnac + rcv_dt - svdt * GN_C + ion_delay + tro_delay + tgd * GN_C;
+    const double dopp_sagnac = GN_OMG / GN_C * (sv_vel.x * P_ecef.y + sv_pos.x * V_ecef.y - sv_vel.y * P_ecef.x - sv_pos.y * V_ecef.x);
+    const V3 dv = sv_vel - V_ecef;
+    const double dopp_est = dot(dv, unit) + dopp_sagnac + rcv_ddt - svddt * GN_C;
+    const double r[2] = {(psr_est - psr) * pr_weight, (dopp_est + dopp * wavelength) * dp_weight};
+    // local columns: 0-2 P_i, 3-5 V_i, 6-8 P_j, 9-11 V_j, 12 rcv_dt, 13 rcv_ddt, 14 yaw, 15-17 anc
+    double J[2 * 18];
+    int col[18];
+    for (int i = 0; i < 36; i++) J[i] = 0.0;
+    if (!cost_only) {
+        const double norm3 = rng * rng * rng;
+        const double rs[3] = {rcv2sat.x, rcv2sat.y, rcv2sat.z}, un[3] = {unit.x, unit.y, unit.z}, dvv[3] = {dv.x, dv.y, dv.z};
+        double t[3];   // (sv_vel - V)^T unit2rcv_pos, unit2rcv_pos = -(d unit / d rcv2sat)
+        for (int c = 0; c < 3; c++) { double a = 0; for (int q = 0; q < 3; q++) a += dvv[q] * -((q == c) ? (norm2 - rs[q] * rs[q]) / norm3 : (-rs[q] * rs[c]) / norm3); t[c] = a; }
+        for (int c = 0; c < 3; c++) {
+            double a = 0, bsum = 0;
+            for (int q = 0; q < 3; q++) { a += un[q] * R_ecef_local.m[3 * q + c]; bsum += t[q] * R_ecef_local.m[3 * q + c]; }
+            J[c] = -a * pr_weight * ratio;              J[18 + c] = bsum * dp_weight * ratio;
+            J[18 + 3 + c] = -a * dp_weight * ratio;
+            J[6 + c] = -a * pr_weight * (1.0 - ratio);  J[18 + 6 + c] = bsum * dp_weight * (1.0 - ratio);
+            J[18 + 9 + c] = -a * dp_weight * (1.0 - ratio);
+            J[15 + c] = -un[c] * pr_weight;
+        }
+        J[12] = pr_weight; J[18 + 13] = dp_weight;
+        M3 d_yaw = m3_zero();
+        d_yaw.m[0] = -sy; d_yaw.m[1] = -cy; d_yaw.m[3] = cy; d_yaw.m[4] = -sy;
+        J[14] = -dot(unit, R_ecef_enu * (d_yaw * local_pos)) * pr_weight;
+        J[18 + 14] = -dot(unit, R_ecef_enu * (d_yaw * local_vel)) * dp_weight;
+    }
+    for (int c = 0; c < 3; c++) {
+        col[c] = cof(fb_pose(lo), c); col[3 + c] = cof(fb_sb(lo), c); col[6 + c] = cof(fb_pose(lo + 1), c); col[9 + c] = cof(fb_sb(lo + 1), c);
+        col[15 + c] = cof(fb_anc(NP), c);
+    }
+    col[12] = cof(fb_rcvdt(NP, 4 * fi + sys), 0); col[13] = cof(fb_rcvddt(NP, fi), 0); col[14] = cof(fb_yaw(NP), 0);
+    gn_accumulate<2, 18>(r, J, col, H, g, cost, d.RP, cost_only != 0);
+}
+
+}  // namespace gfb

@@ -18,11 +18,13 @@ using namespace gfd;
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 struct Dims {
-    int B, W, NP, F, NV, NVP, RP, XS, NFB, FP, NPRI, ECW;
+    int B, W, NP, F, NV, NVP, RP, XS, NFB, FP, NPRI, ECW, GO, NG;
     // NP = W+1 poses; NVP = padded length of the pair-sorted factor order; RP = padded reduced dimension (multiple of 16);
     // XS = state vector stride; NFB = 2*NP + 7 non-feature parameter blocks; FP = F rounded up to 4; NPRI = prior capacity (= RP)
     // ECW = width of the compact rows of the eliminated columns: a feature only touches pose blocks, the camera extrinsic and td
     //       (compact column 6i+q = pose i, 6NP+q = ex_pose, 6NP+6 = td, 6NP+7 = right-hand-side slot), rounded up to 16
+    // GO  = offset of the GNSS states in the state vector (rcv_dt 4NP, rcv_ddt NP, yaw 1, anc_ecef 3), 0: handle built without GNSS
+    // NG  = capacity of GnssPsrDoppFactor per window
 };
 __host__ __device__ inline int off_pose(int i) { return 16 * i; }
 __host__ __device__ inline int off_sb(int i) { return 16 * i + 7; }
@@ -40,6 +42,11 @@ __host__ __device__ inline int fb_exw(int NP) { return 2 * NP + 1; }
 __host__ __device__ inline int fb_sx(int NP) { return 2 * NP + 2; }
 __host__ __device__ inline int fb_td(int NP) { return 2 * NP + 5; }
 __host__ __device__ inline int fb_tdw(int NP) { return 2 * NP + 6; }
+// GNSS f-blocks (only when Dims::GO > 0): rcv_dt[4 NP], rcv_ddt[NP], yaw (always constant in the solver), anc_ecef
+__host__ __device__ inline int fb_rcvdt(int NP, int idx) { return 2 * NP + 7 + idx; }
+__host__ __device__ inline int fb_rcvddt(int NP, int i) { return 6 * NP + 7 + i; }
+__host__ __device__ inline int fb_yaw(int NP) { return 7 * NP + 7; }
+__host__ __device__ inline int fb_anc(int NP) { return 7 * NP + 8; }
 
 struct SolverState {  // per window, lives in device memory
     double radius, mu, alpha, x_cost, cand_cost, model_cost_change, dogleg_step_norm, gmax, initial_cost, x_norm, step_norm;
@@ -75,7 +82,13 @@ struct Win {  // device view of the whole batch
     double G[3];
     double vis_sqrt_info;
     int prior_preloaded;      // 1: every H buffer starts as a copy of pri_H0, the prior kernel adds only g and cost
+    // GNSS (Dims::GO > 0)
+    const int* ngnss;         // [B]
+    const int* gn_idx;        // [B][NG][4]: frame i, lower_idx, sys_idx, 0
+    const double* gn_data;    // [B][NG][GN_STRIDE]: 16 values of gf_ba_window::gnss_data, ratio
+    const double* gn_misc;    // [B][GN_MISC]: iono 8, ddt_weight, anchor 7, enabled, in_solve (= !lowspeed), has_anchor, Headers[NP]
 };
+constexpr int GN_STRIDE = 18, GN_MISC = 20;   // gn_misc is GN_MISC + NP doubles per window
 constexpr int IMU_STRIDE = 16 + 225 + 225;  // sum_dt, dp3, dq4, dv3, lba3, lbg3(=17 used incl. sum_dt -> 0..16) jac, cov
 constexpr int IMU_JAC = 17, IMU_COV = 17 + 225;
 constexpr int IMU_STRIDE2 = 17 + 450;
@@ -330,7 +343,7 @@ __device__ inline void wave_inverse_spd_sqrt(double* M, double* T, int n, int la
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ int fblock_of(int id, int NP);
+__device__ __forceinline__ int fblock_of(int id, const Dims& d);
 __host__ __device__ inline int lsize_kind(int kind);
 __host__ __device__ inline int gsize_kind(int kind);
 
@@ -383,7 +396,7 @@ __global__ void __launch_bounds__(256) ba_setup(Win w) {
             int idx = 0;
             for (int q = 0; q < w.pri_nb[b]; q++) {
                 const int id = w.pri_bid[(size_t)b * 64 + q], kind = id / 4096;
-                const int fb = fblock_of(id, d.NP);
+                const int fb = fblock_of(id, d);
                 const int c0 = fb >= 0 ? w.colf[(size_t)b * d.NFB + fb] : -1;
                 for (int k2 = 0; k2 < lsize_kind(kind); k2++) s_pcol[idx++] = c0 >= 0 ? c0 + k2 : -1;
             }
@@ -513,31 +526,33 @@ __device__ inline void wheel_raw(const double* Pi_, const double* Pj_, const dou
 
 // dx of the marginalisation prior for one kept block (marginalization_factor.cpp:348-372)
 __device__ __forceinline__ void prior_block_dx(int kind, const double* x, const double* x0, double* dx) {
-    const int gs = (kind == 0 || kind == 2 || kind == 3) ? 7 : kind == 1 ? 9 : 1;
+    const int gs = gsize_kind(kind);
     if (gs != 7) { for (int i = 0; i < gs; i++) dx[i] = x[i] - x0[i]; return; }
     for (int i = 0; i < 3; i++) dx[i] = x[i] - x0[i];
     const Q4 dq = qmul(qinverse(Q4{x0[6], x0[3], x0[4], x0[5]}), Q4{x[6], x[3], x[4], x[5]});
     const double sgn = (dq.w >= 0) ? 2.0 : -2.0;
     dx[3] = sgn * dq.x; dx[4] = sgn * dq.y; dx[5] = sgn * dq.z;
 }
-__device__ __forceinline__ int state_off_of(int id, int NP) {
-    const int kind = id / 4096, i = id % 4096;
+__device__ __forceinline__ int state_off_of(int id, const Dims& d) {
+    const int kind = id / 4096, i = id % 4096, NP = d.NP;
     switch (kind) {
         case 0: return off_pose(i); case 1: return off_sb(i); case 2: return off_ex(NP); case 3: return off_exw(NP);
         case 4: return off_ix(NP); case 5: return off_ix(NP) + 1; case 6: return off_ix(NP) + 2; case 7: return off_td(NP); case 8: return off_tdw(NP);
+        case 10: return d.GO + i; case 11: return d.GO + 4 * NP + i; case 12: return d.GO + 5 * NP; case 13: return d.GO + 5 * NP + 1;
         default: return off_feat(NP) + i;
     }
 }
-__device__ __forceinline__ int fblock_of(int id, int NP) {
-    const int kind = id / 4096, i = id % 4096;
+__device__ __forceinline__ int fblock_of(int id, const Dims& d) {
+    const int kind = id / 4096, i = id % 4096, NP = d.NP;
     switch (kind) {
         case 0: return fb_pose(i); case 1: return fb_sb(i); case 2: return fb_ex(NP); case 3: return fb_exw(NP);
         case 4: return fb_sx(NP); case 5: return fb_sx(NP) + 1; case 6: return fb_sx(NP) + 2; case 7: return fb_td(NP); case 8: return fb_tdw(NP);
+        case 10: return d.GO ? fb_rcvdt(NP, i) : -1; case 11: return d.GO ? fb_rcvddt(NP, i) : -1; case 12: return d.GO ? fb_yaw(NP) : -1; case 13: return d.GO ? fb_anc(NP) : -1;
         default: return -1;
     }
 }
-__host__ __device__ inline int lsize_kind(int kind) { return (kind == 0 || kind == 2 || kind == 3) ? 6 : kind == 1 ? 9 : 1; }
-__host__ __device__ inline int gsize_kind(int kind) { return (kind == 0 || kind == 2 || kind == 3) ? 7 : kind == 1 ? 9 : 1; }
+__host__ __device__ inline int lsize_kind(int kind) { return (kind == 0 || kind == 2 || kind == 3) ? 6 : kind == 1 ? 9 : kind == 13 ? 3 : 1; }
+__host__ __device__ inline int gsize_kind(int kind) { return (kind == 0 || kind == 2 || kind == 3) ? 7 : kind == 1 ? 9 : kind == 13 ? 3 : 1; }
 
 // grid (2W + 1, B), 256 threads: block t < W evaluates IMU factor t (wavefront 0), W <= t < 2W wheel factor t - W, block 2W adds the prior.
 // frame_filter: 0 all factors; 1 only IMU/wheel factors starting at frame 0 (MARGIN_OLD); 2 no IMU/wheel factor (MARGIN_SECOND_NEW)
@@ -634,8 +649,8 @@ __global__ void __launch_bounds__(256) ba_linearize_misc(Win w, int which, int w
             for (int q = 0; q < (int)threadIdx.x; q++) { idx += lsize_kind(bid[q] / 4096); o0 += gsize_kind(bid[q] / 4096); }
             const int id = bid[threadIdx.x], kind = id / 4096;
             double dx[9];
-            prior_block_dx(kind, xs + state_off_of(id, d.NP), x0 + o0, dx);
-            const int fb = fblock_of(id, d.NP);
+            prior_block_dx(kind, xs + state_off_of(id, d), x0 + o0, dx);
+            const int fb = fblock_of(id, d);
             const int c0 = fb >= 0 ? colf[fb] : -1;
             for (int q = 0; q < lsize_kind(kind); q++) { sdx[idx + q] = dx[q]; sdx[256 + idx + q] = c0 >= 0 ? (double)(c0 + q) : -1.0; }
         }
@@ -1240,7 +1255,8 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
             if (blk < d.NFB) {
                 c0 = colf[blk];
                 if (blk < 2 * d.NP) { kind = (blk & 1) ? 1 : 0; off = (blk & 1) ? off_sb(blk >> 1) : off_pose(blk >> 1); }
-                else { const int q = blk - 2 * d.NP; kind = q == 0 ? 2 : q == 1 ? 3 : q <= 4 ? 4 : q == 5 ? 7 : 8; off = q == 0 ? off_ex(d.NP) : q == 1 ? off_exw(d.NP) : q <= 4 ? off_ix(d.NP) + (q - 2) : q == 5 ? off_td(d.NP) : off_tdw(d.NP); }
+                else if (blk < 2 * d.NP + 7) { const int q = blk - 2 * d.NP; kind = q == 0 ? 2 : q == 1 ? 3 : q <= 4 ? 4 : q == 5 ? 7 : 8; off = q == 0 ? off_ex(d.NP) : q == 1 ? off_exw(d.NP) : q <= 4 ? off_ix(d.NP) + (q - 2) : q == 5 ? off_td(d.NP) : off_tdw(d.NP); }
+                else { const int q = blk - (2 * d.NP + 7); kind = q < 5 * d.NP + 1 ? 10 : 13; off = d.GO + q; }   // rcv_dt, rcv_ddt, yaw: scalars in state order; then anc_ecef (3)
             } else {
                 const int f = blk - d.NFB;
                 if (f >= w.nfeat[b]) continue;

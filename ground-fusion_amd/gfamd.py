@@ -216,7 +216,7 @@ import gfwindow as _gw  # noqa: E402
 
 
 class BaCfg(C.Structure):
-    _fields_ = [("window_size", C.c_int), ("max_features", C.c_int), ("max_visual", C.c_int), ("batch", C.c_int)]
+    _fields_ = [("window_size", C.c_int), ("max_features", C.c_int), ("max_visual", C.c_int), ("batch", C.c_int), ("max_gnss", C.c_int)]
 
 
 class BaPriorC(C.Structure):
@@ -236,8 +236,8 @@ EXPORTS += ["gf_ba_create", "gf_ba_destroy", "gf_ba_solve", "gf_ba_marginalize",
 class Estimator:
     """Batched window solver: the Ceres problem of Estimator::optimization() (estimator.cpp:2890-3631) on the GPU."""
 
-    def __init__(self, window_size=10, max_features=150, max_visual=1500, batch=1):
-        self.cfg = BaCfg(window_size, max_features, max_visual, batch)
+    def __init__(self, window_size=10, max_features=150, max_visual=1500, batch=1, max_gnss=0):
+        self.cfg = BaCfg(window_size, max_features, max_visual, batch, max_gnss)
         self.h = C.c_void_p()
         _chk(lib().gf_ba_create(C.byref(self.cfg), C.byref(self.h)))
         self._keep = None

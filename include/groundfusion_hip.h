@@ -128,6 +128,7 @@ typedef struct gf_ba_cfg {
     int max_features;  /* capacity of para_Feature (NUM_OF_F, parameters.h:25) */
     int max_visual;    /* capacity of visual factors per window */
     int batch;         /* independent windows solved per call */
+    int max_gnss;      /* capacity of GnssPsrDoppFactor per window; 0 builds the handle without the GNSS blocks (gnss_enable: 0) */
 } gf_ba_cfg;
 
 typedef struct gf_ba_window {

@@ -624,10 +624,8 @@ struct Problem {
         if (w->n_wheel > 0 || in_prior(bid(TD_WHEEL, 0))) add(bid(TD_WHEEL, 0));
         if (w->gnss_enabled) {   // receiver clock / anchor blocks that some residual block (or the prior) mentions
             const bool fac = !w->gnss_lowspeed;
-            for (int i = 0; i <= w->W; i++) {
-                for (int q = 0; q < 4; q++) if (fac || in_prior(bid(RCV_DT, 4 * i + q))) add(bid(RCV_DT, 4 * i + q));
-                if (fac || in_prior(bid(RCV_DDT, i))) add(bid(RCV_DDT, i));
-            }
+            for (int i = 0; i <= w->W; i++) for (int q = 0; q < 4; q++) if (fac || in_prior(bid(RCV_DT, 4 * i + q))) add(bid(RCV_DT, 4 * i + q));
+            for (int i = 0; i <= w->W; i++) if (fac || in_prior(bid(RCV_DDT, i))) add(bid(RCV_DDT, i));
             if ((fac && w->n_gnss > 0) || in_prior(bid(ANC, 0))) add(bid(ANC, 0));
         }
     }

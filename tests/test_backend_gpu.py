@@ -178,3 +178,73 @@ def test_lds_and_global_reduced_system_agree(gf, oracle, monkeypatch):
     assert dp < 1e-8 and dr < 1e-8
     A1, A2 = p1["J"].reshape(p1["n"], -1), p2["J"].reshape(p2["n"], -1)
     assert np.abs(A1.T @ A1 - A2.T @ A2).max() <= 1e-9 * np.abs(A1.T @ A1).max()
+
+
+# ---------------------------------------------------------------- GNSS residual blocks on the device
+def _gnss_est(gf, W=10, F=150):
+    return gf.Estimator(W, F, F * W, 1, max_gnss=12 * (W + 1))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(anchor=True), dict(gnss_lowspeed=1)])
+def test_gnss_normal_equations_and_solve_match_oracle(gf, oracle, kw):
+    est = _gnss_est(gf)
+    w = SW.make_window(1, oracle, gnss=True, **kw)
+    lo, lg = oracle.ba_linearize(w.copy(), cap=1024), est.linearize(w.copy(), cap=1024)
+    assert list(lo["ids"]) == list(lg["ids"]) and lo["n_f"] == lg["n_f"]
+    if not kw.get("gnss_lowspeed"):
+        assert gw.bid(gw.RCV_DT, 7) in lo["ids"] and gw.bid(gw.RCV_DDT, 3) in lo["ids"] and gw.bid(gw.ANC) in lo["ids"] and gw.bid(gw.YAW) not in lo["ids"]
+    assert abs(lo["cost"] - lg["cost"]) <= 1e-12 * lo["cost"]
+    assert np.abs(lo["H"] - lg["H"]).max() <= 1e-12 * np.abs(lo["H"]).max() and np.abs(lo["g"] - lg["g"]).max() <= 1e-12 * np.abs(lo["g"]).max()
+    wo, wg = w.copy(), w.copy()
+    so, sg = oracle.ba_solve(wo, 8), est.solve([wg], 8)[0]
+    assert (so["iterations"], so["successful_steps"]) == (sg["iterations"], sg["successful_steps"])
+    dp, dr = _pose_diff(wo, wg)
+    assert dp < 1e-6 and dr < 1e-6, (dp, dr)
+    assert np.abs(wo["para_rcv_dt"] - wg["para_rcv_dt"]).max() < 1e-6 and np.abs(wo["para_rcv_ddt"] - wg["para_rcv_ddt"]).max() < 1e-6      # metres, m/s
+    assert np.abs(wo["para_anc_ecef"] - wg["para_anc_ecef"]).max() < 1e-6 and wg["para_yaw_enu_local"][0] == w["para_yaw_enu_local"][0]
+    est.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_gnss_marginalization_and_chain(gf, oracle, seed):
+    """MARGIN_OLD drops pose 0, speed-bias 0, the four frame-0 clock biases and the frame-0 drift (20 columns); the prior keeps the frame-1 clocks,
+    yaw_enu_local and the anchor; MARGIN_SECOND_NEW on the next window only renames the newest clocks."""
+    est = _gnss_est(gf)
+    w = SW.make_window(seed, oracle, gnss=True)
+    oracle.ba_solve(w, 8)
+    po, pg = oracle.ba_marginalize(w, 0), est.marginalize([w], 0)[0]
+    assert pg["m"] == po["m"] and pg["n"] == po["n"] == 95 and list(pg["block_id"]) == list(po["block_id"])
+    assert np.abs(pg["x0"] - po["x0"]).max() == 0
+    n = po["n"]
+    Ao, Ag = po["J"].reshape(n, n).T @ po["J"].reshape(n, n), pg["J"].reshape(n, n).T @ pg["J"].reshape(n, n)
+    bo, bg = po["J"].reshape(n, n).T @ po["r"], pg["J"].reshape(n, n).T @ pg["r"]
+    # the dropped block now also holds five receiver-clock columns: its pseudo-inverse is conditioned ~1e7, b carries that (see test_marginalisation_matches_oracle)
+    assert np.abs(Ao - Ag).max() <= 1e-9 * np.abs(Ao).max() and np.abs(bo - bg).max() <= 1e-4 * max(1.0, np.abs(bo).max())
+    w2 = SW.make_window(seed, oracle, gnss=True, frame0=1, prior=pg)
+    a, b = w2.copy(), w2.copy()
+    so, sg = oracle.ba_solve(a, 8), est.solve([b], 8)[0]
+    assert (so["iterations"], so["successful_steps"]) == (sg["iterations"], sg["successful_steps"])
+    dp, dr = _pose_diff(a, b)
+    assert dp < 1e-6 and dr < 1e-6 and np.abs(a["para_rcv_dt"] - b["para_rcv_dt"]).max() < 1e-6
+    p1o, p1g = oracle.ba_marginalize(a, 1), est.marginalize([a], 1)[0]
+    assert p1g["n"] == p1o["n"] == 89 and list(p1g["block_id"]) == list(p1o["block_id"])
+    n1 = p1o["n"]
+    A1o, A1g = p1o["J"].reshape(n1, n1).T @ p1o["J"].reshape(n1, n1), p1g["J"].reshape(n1, n1).T @ p1g["J"].reshape(n1, n1)
+    assert np.abs(A1o - A1g).max() <= 1e-9 * np.abs(A1o).max()
+    est.close()
+
+
+def test_config5_window_with_gnss(gf, oracle):
+    """BASELINE.json config 5: 20-frame window, 500 features, RGB-D + IMU + wheel + GNSS factors: 440 reduced columns, global-memory Cholesky."""
+    W, F = 20, 500
+    est = _gnss_est(gf, W, F)
+    w = SW.make_window(1, oracle, W=W, n_landmarks=750, max_features=F, gnss=True)
+    assert w["n_gnss"] == 12 * (W + 1) and w["n_feature"] == F
+    a, b = w.copy(), w.copy()
+    so, sg = oracle.ba_solve(a, 8), est.solve([b], 8)[0]
+    assert (so["iterations"], so["successful_steps"]) == (sg["iterations"], sg["successful_steps"])
+    dp, dr = _pose_diff(a, b)
+    assert dp < 1e-6 and dr < 1e-6, (dp, dr)
+    po, pg = oracle.ba_marginalize(a, 0, cap_n=512), est.marginalize([a], 0, cap_n=512)[0]
+    assert pg["n"] == po["n"] == 6 * W + 9 + 17 + 9 and list(pg["block_id"]) == list(po["block_id"])
+    est.close()
