@@ -102,20 +102,23 @@ __global__ void __launch_bounds__(256) scharr_kernel(const uint8_t* __restrict__
 // ---------------------------------------------------------------------------------------------
 // Wave-level exact integer sum.  Per-lane |v| < 2^28 so 8-lane partial sums fit int32; the eight group
 // sums are combined on the scalar unit in 64 bits.  Result is wave-uniform.
-__device__ __forceinline__ long long wave_sum_exact(int v) {
+// Exact sum of one int32 per lane over the wavefront (|sum| < 2^53): three DPP adds inside 8-lane groups (no overflow: 8 x 2^28), then eight
+// v_readlane + scalar 64-bit adds.  (Two v_mfma_f64_16x16x4_f64 against a matrix of ones give the same exact sum on the matrix pipe; measured
+// 15 % slower here -- the dependent MFMA latency sits on the per-iteration critical path.)
+__device__ __forceinline__ double wave_sum_exact(int v) {
     v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
     v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
     v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);  // row_half_mirror
     long long s = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) s += (long long)__builtin_amdgcn_readlane(v, k * 8);
-    return s;
+    return (double)s;
 }
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float unif(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 
-__device__ __forceinline__ float i64_to_f32(long long v) { return (float)(double)v; }  // exact then one rounding
+__device__ __forceinline__ float i64_to_f32(double v) { return (float)v; }  // v holds an exact integer: one rounding, as (float)(int64) in the reference build
 
 struct __attribute__((packed, aligned(4))) U4a { uint32_t x, y, z, w; };
 
@@ -206,7 +209,7 @@ __device__ __forceinline__ int lk_solve(const PyrGeom& G, const LkImages im, flo
                 a11 += __mul24(ix, ix); a12 += __mul24(ix, iy); a22 += __mul24(iy, iy);
             }
         }
-        const long long iA11 = wave_sum_exact(a11), iA12 = wave_sum_exact(a12), iA22 = wave_sum_exact(a22);
+        const double iA11 = wave_sum_exact(a11), iA12 = wave_sum_exact(a12), iA22 = wave_sum_exact(a22);
         const float FLT_SCALE = 1.f / (1 << 20);
         const float A11 = i64_to_f32(iA11) * FLT_SCALE, A12 = i64_to_f32(iA12) * FLT_SCALE, A22 = i64_to_f32(iA22) * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
@@ -249,17 +252,20 @@ __device__ __forceinline__ int lk_solve(const PyrGeom& G, const LkImages im, flo
             {
                 const int xo = inx - tx0 + 7 * s;
                 const int o = xo & 3;
-                const uint32_t* q0 = reinterpret_cast<const uint32_t*>(tile + (iny - ty0 + r) * kTileStride + (xo - o));
+                const uint32_t* q0 = reinterpret_cast<const uint32_t*>(tile + __mul24(iny - ty0 + r, kTileStride) + (xo - o));
                 const uint32_t* q1 = q0 + kTileStride / 4;
                 uint32_t l0, h0, l1, h1;
                 align8(q0[0], q0[1], q0[2], o, l0, h0);
                 align8(q1[0], q1[1], q1[2], o, l1, h1);
                 const uint32_t m0 = __builtin_amdgcn_alignbyte(h0, l0, 3), m1 = __builtin_amdgcn_alignbyte(h1, l1, 3);   // bytes 3..6 of each row
-                // weights split into 7-bit halves (w = 128 * wh + wl, wh <= 128): the 4-tap sum becomes two v_dot4_u32_u8
-                // iw11 = 2^14 - iw00 - iw01 - iw10 can come out as -1/-2 after the three roundings: keep that part out of the unsigned dots
-                const int iw11p = iw11 > 0 ? iw11 : 0, iw11n = iw11 < 0 ? iw11 : 0;
-                const uint32_t wh = (uint32_t)(iw00 >> 7) | ((uint32_t)(iw01 >> 7) << 8) | ((uint32_t)(iw10 >> 7) << 16) | ((uint32_t)(iw11p >> 7) << 24);
-                const uint32_t wl = (uint32_t)(iw00 & 127) | ((uint32_t)(iw01 & 127) << 8) | ((uint32_t)(iw10 & 127) << 16) | ((uint32_t)(iw11p & 127) << 24);
+                // weights split into 7-bit halves (w = 128 * wh + wl, wh <= 128): the 4-tap sum becomes two v_dot4_u32_u8.
+                // iw11 = 2^14 - iw00 - iw01 - iw10 is >= -1 (three roundings of at most 1/2 each): the unsigned dots take iw11 + 1 and the extra
+                // J[r+1][k+1] is subtracted again.  The weights are wave-uniform: pinned to SGPRs so that the packing runs on the scalar unit.
+                int sw00 = __builtin_amdgcn_readfirstlane(iw00), sw01 = __builtin_amdgcn_readfirstlane(iw01), sw10 = __builtin_amdgcn_readfirstlane(iw10),
+                    sw11 = __builtin_amdgcn_readfirstlane(iw11 + 1);
+                asm volatile("" : "+s"(sw00), "+s"(sw01), "+s"(sw10), "+s"(sw11));
+                const uint32_t wh = (uint32_t)(sw00 >> 7) | ((uint32_t)(sw01 >> 7) << 8) | ((uint32_t)(sw10 >> 7) << 16) | ((uint32_t)(sw11 >> 7) << 24);
+                const uint32_t wl = (uint32_t)(sw00 & 127) | ((uint32_t)(sw01 & 127) << 8) | ((uint32_t)(sw10 & 127) << 16) | ((uint32_t)(sw11 & 127) << 24);
 #pragma unroll
                 for (int k = 0; k < 7; k++) {
                     // p = { J[r][k], J[r][k+1], J[r+1][k], J[r+1][k+1] }
@@ -269,14 +275,13 @@ __device__ __forceinline__ int lk_solve(const PyrGeom& G, const LkImages im, flo
                     const uint32_t pq = __builtin_amdgcn_perm(s1, s0, sel);
                     const uint32_t hi = __builtin_amdgcn_udot4(pq, wh, 0u, false);
                     const uint32_t lo = __builtin_amdgcn_udot4(pq, wl, 256u, false);
-                    int raw = (int)((hi << 7) + lo);
-                    if (iw11n) raw += (int)(pq >> 24) * iw11n;   // wave-uniform, rare
+                    const int raw = (int)((hi << 7) + lo - (pq >> 24));
                     const int diff = (raw >> 9) - tI[k];
                     b1 = mad_i24(diff, tX[k], b1);
                     b2 = mad_i24(diff, tY[k], b2);
                 }
             }
-            const long long ib1 = wave_sum_exact(b1), ib2 = wave_sum_exact(b2);
+            const double ib1 = wave_sum_exact(b1), ib2 = wave_sum_exact(b2);
             const float fb1 = i64_to_f32(ib1) * FLT_SCALE, fb2 = i64_to_f32(ib2) * FLT_SCALE;
             const float dx = (A12 * fb2 - A22 * fb1) * D;
             const float dy = (A12 * fb1 - A11 * fb2) * D;
