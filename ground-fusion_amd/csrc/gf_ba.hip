@@ -351,8 +351,8 @@ int launch_linearize(gf_ba* h, int which, int which_state, int cost_only, int on
     if (!cost_only) ba_build_et<<<dim3(d.F, d.B), 64, 0, h->stream>>>(w, h->sbufs(), which, 0);
     // IMU / wheel / prior factors only share the atomically accumulated H, g, cost with the visual sweep: second stream
     HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-    ba_linearize_misc<<<dim3(2 * d.W, d.B), 64, 0, h->stream2>>>(w, which, which_state, cost_only, only_valid, 0, 0);
-    ba_linearize_misc<<<dim3(1, d.B), 256, 0, h->stream2>>>(w, which, which_state, cost_only, only_valid, 0, 2 * d.W);
+    ba_linearize_misc<false><<<dim3(2 * d.W, d.B), 64, 0, h->stream2>>>(w, which, which_state, cost_only, only_valid, 0, 0);
+    ba_linearize_misc<true><<<dim3(1, d.B), 256, 0, h->stream2>>>(w, which, which_state, cost_only, only_valid, 0, 2 * d.W);
     if (d.GO) ba_linearize_gnss<<<dim3((d.NG + 5 * d.W + 1 + 63) / 64, d.B), 64, 0, h->stream2>>>(w, which, which_state, cost_only, only_valid, 0);
     HIPCHK(hipEventRecord(h->ev_join, h->stream2));
     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
@@ -391,9 +391,9 @@ int run_marginalize(gf_ba* h, int mode) {
     wm.colf = h->mcolf[mode].d; wm.cole = h->mcole[mode].d; wm.order = h->morder[mode].d; wm.norder = h->mnorder[mode].d;
     ba_zero_other<<<dim3(d.B), 256, 0, h->stream>>>(w);
     if (mode == 0) ba_linearize_visual<true><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(wm, -1, -2, 0, 2);
-    if (mode == 0) ba_linearize_misc<<<dim3(2 * d.W, d.B), 64, 0, h->stream>>>(wm, -1, -2, 0, 2, 1, 0);
+    if (mode == 0) ba_linearize_misc<false><<<dim3(2 * d.W, d.B), 64, 0, h->stream>>>(wm, -1, -2, 0, 2, 1, 0);
     if (mode == 0 && d.GO) ba_linearize_gnss<<<dim3((d.NG + 5 * d.W + 1 + 63) / 64, d.B), 64, 0, h->stream>>>(wm, -1, -2, 0, 2, 1);
-    ba_linearize_misc<<<dim3(1, d.B), 256, 0, h->stream>>>(wm, -1, -2, 0, 2, 2, 2 * d.W);
+    ba_linearize_misc<true><<<dim3(1, d.B), 256, 0, h->stream>>>(wm, -1, -2, 0, 2, 2, 2 * d.W);
     ba_build_et<<<dim3(d.F, d.B), 64, 0, h->stream>>>(wm, h->sbufs(), -1, 1);
     MargOut mo{h->outJ.d, h->outr.d};
     if (h->big_marg) ba_marg_finish<true><<<dim3(d.B), 512, 0, h->stream>>>(wm, h->sbufs(), reinterpret_cast<const MargInfo*>(h->minfo[mode].d), mo);

@@ -556,14 +556,15 @@ __host__ __device__ inline int gsize_kind(int kind) { return (kind == 0 || kind 
 
 // grid (2W + 1, B), 256 threads: block t < W evaluates IMU factor t (wavefront 0), W <= t < 2W wheel factor t - W, block 2W adds the prior.
 // frame_filter: 0 all factors; 1 only IMU/wheel factors starting at frame 0 (MARGIN_OLD); 2 no IMU/wheel factor (MARGIN_SECOND_NEW)
-__global__ void __launch_bounds__(256) ba_linearize_misc(Win w, int which, int which_state, int cost_only, int only_cand_valid, int frame_filter, int task_base) {
-    __shared__ double sS[225];
-    __shared__ double sJ[450];
-    __shared__ double sSJ[450];
+template <bool PRIOR>   // PRIOR: the 256-thread prior task; else one 64-thread block per IMU / wheel factor (own register budget and LDS footprint)
+__global__ void __launch_bounds__(PRIOR ? 256 : 64, PRIOR ? 1 : 3) ba_linearize_misc(Win w, int which, int which_state, int cost_only, int only_cand_valid, int frame_filter, int task_base) {
+    __shared__ double sS[PRIOR ? 1 : 225];
+    __shared__ double sJ[PRIOR ? 1 : 450];
+    __shared__ double sSJ[PRIOR ? 1 : 450];
     __shared__ double sr[32];
     __shared__ int scol[32];
-    __shared__ double sdx[512];
-    __shared__ double sred[256];
+    __shared__ double sdx[PRIOR ? 512 : 1];
+    __shared__ double sred[PRIOR ? 256 : 1];
     const Dims d = w.d;
     const int b = blockIdx.y, task = task_base + blockIdx.x, lane = threadIdx.x & 63;   // factor tasks: 64-thread blocks; prior task: 256 threads
     const SolverState& st = w.st[b];
@@ -576,8 +577,8 @@ __global__ void __launch_bounds__(256) ba_linearize_misc(Win w, int which, int w
     double* H = w.H + ((size_t)which * d.B + b) * d.RP * d.RP;
     double* g = w.g + ((size_t)which * d.B + b) * d.RP;
     const int nimu = w.nimu[b], nwh = w.nwh[b];
-    if (task < 2 * d.W) {
-        if (threadIdx.x >= 64) return;   // one wavefront per factor
+    if (!PRIOR) {
+        if (task >= 2 * d.W) return;
         const bool is_imu = task < d.W;
         const int k = is_imu ? task : task - d.W;
         if (k >= (is_imu ? nimu : nwh) || frame_filter == 2) return;
@@ -848,6 +849,20 @@ __device__ __forceinline__ double bcast_lane(double v, int srclane) {  // srclan
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane), hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
     return __hiloint2double(hi, lo);
 }
+// value of lane J of the own 16-lane row, in every lane of the row: one v_mov_b32_dpp row_newbcast per half (no SGPR round trip)
+template <int J> __device__ __forceinline__ double row_bcast_c(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + J, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + J, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_bcast(double v, int j) {   // j must fold to a constant (unrolled loops)
+    switch (j) {
+        case 0: return row_bcast_c<0>(v); case 1: return row_bcast_c<1>(v); case 2: return row_bcast_c<2>(v); case 3: return row_bcast_c<3>(v);
+        case 4: return row_bcast_c<4>(v); case 5: return row_bcast_c<5>(v); case 6: return row_bcast_c<6>(v); case 7: return row_bcast_c<7>(v);
+        case 8: return row_bcast_c<8>(v); case 9: return row_bcast_c<9>(v); case 10: return row_bcast_c<10>(v); case 11: return row_bcast_c<11>(v);
+        case 12: return row_bcast_c<12>(v); case 13: return row_bcast_c<13>(v); case 14: return row_bcast_c<14>(v); default: return row_bcast_c<15>(v);
+    }
+}
 __device__ inline bool wave_chol16_inv(double* s_L, double* s_inv, double* s_rdiag, int lane) {
     const int r = lane & 15;   // the four 16-lane groups work redundantly on identical data, so lane j of the wavefront speaks for row j
     double a[16], rd[16];
@@ -856,7 +871,7 @@ __device__ inline bool wave_chol16_inv(double* s_L, double* s_inv, double* s_rdi
     bool good = true;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-        const double piv = bcast_lane(a[j], j);
+        const double piv = row_bcast(a[j], j);
         if (!(piv > 0.0)) good = false;
         double rs = __builtin_amdgcn_rsq(piv);          // ~2^-26 seed, two Newton steps
         rs = rs * (1.5 - 0.5 * piv * rs * rs);
@@ -865,7 +880,7 @@ __device__ inline bool wave_chol16_inv(double* s_L, double* s_inv, double* s_rdi
         const double l = (r == j) ? piv * rs : a[j] * rs;   // L_rj (rows r >= j)
         a[j] = l;
 #pragma unroll
-        for (int c = j + 1; c < 16; c++) a[c] -= l * bcast_lane(l, c);   // L_rj * L_cj
+        for (int c = j + 1; c < 16; c++) a[c] -= l * row_bcast(l, c);   // L_rj * L_cj
     }
     if (lane < 16) {
 #pragma unroll
@@ -1086,11 +1101,23 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
             for (int j0 = 0; j0 < R; j0 += 16) {
                 const int nb = min(16, R - j0);
                 if (wave == 0) {
+#ifdef GF_PROFILE_STEP
+                    const long long q0 = clock64();
+#endif
                     for (int i = lane; i < 256; i += 64) { const int r = i >> 4, c = i & 15; s_blk[r * 17 + c] = (r < nb && c < nb) ? S[pk(j0 + max(r, c), j0 + min(r, c))] : (r == c ? 1.0 : 0.0); }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+#ifdef GF_PROFILE_STEP
+                    const long long q1 = clock64();
+#endif
                     const bool good = wave_chol16_inv(s_blk, s_inv, s_rd + j0, lane);
                     if (!good && lane == 0) s_flag[1] = 0;
+#ifdef GF_PROFILE_STEP
+                    const long long q2 = clock64();
+#endif
                     for (int i = lane; i < nb * nb; i += 64) { const int r = i / nb, c = i % nb; if (c <= r) S[pk(j0 + r, j0 + c)] = s_blk[r * 17 + c]; }
+#ifdef GF_PROFILE_STEP
+                    if (blockIdx.x == 0 && tid == 0 && sb.stamps) { sb.stamps[16] += q1 - q0; sb.stamps[17] += q2 - q1; sb.stamps[18] += clock64() - q2; }
+#endif
                 }
                 __syncthreads();
                 GF_SUB(tA);

@@ -1,11 +1,11 @@
 import sys, ctypes as C
 sys.path.insert(0,'ground-fusion_amd')
 import numpy as np, gfamd, synth_window as SW
-est=gfamd.Estimator(batch=64)
-wins=[SW.make_window(1000+b, gfamd) for b in range(64)]
+est=gfamd.Estimator(batch=256)
+base=[SW.make_window(1000+b, gfamd) for b in range(8)]; wins=[base[b%8] for b in range(256)]
 est.upload(wins)
 for it in (1,2,3):
     est.solve_resident(it, -1, True)
     st=np.zeros(24, np.int64)
     gfamd._chk(gfamd.lib().gf_ba_debug_stamps(est.h, st.ctypes.data_as(C.POINTER(C.c_longlong)), 24))
-    d=np.diff(st[:15]); print(it, 'total', (st[14]-st[0]), 'phases', d.tolist(), 'chol diag/panel/trail', st[20:23].tolist())
+    d=np.diff(st[:15]); print(it, 'total', (st[14]-st[0]), 'phases', d.tolist(), 'chol diag/panel/trail', st[20:23].tolist(), 'diag copyin/factor+inv/copyout (accumulated)', st[16:19].tolist())
