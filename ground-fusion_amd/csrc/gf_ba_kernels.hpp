@@ -1114,7 +1114,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
 #ifdef GF_PROFILE_STEP
                     const long long q2 = clock64();
 #endif
-                    for (int i = lane; i < nb * nb; i += 64) { const int r = i / nb, c = i % nb; if (c <= r) S[pk(j0 + r, j0 + c)] = s_blk[r * 17 + c]; }
+                    for (int i = lane; i < 256; i += 64) { const int r = i >> 4, c = i & 15; if (c <= r && r < nb) S[pk(j0 + r, j0 + c)] = s_blk[r * 17 + c]; }
 #ifdef GF_PROFILE_STEP
                     if (blockIdx.x == 0 && tid == 0 && sb.stamps) { sb.stamps[16] += q1 - q0; sb.stamps[17] += q2 - q1; sb.stamps[18] += clock64() - q2; }
 #endif
@@ -1182,17 +1182,25 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                     const int nb = min(16, R - j0);
                     if (wave == 0) {
                         double z = lane < nb ? S[pk(R, j0 + lane)] : 0.0;
-                        for (int c = nb - 1; c >= 0; c--) {
-                            const double yc = bcast_lane(z, c) * s_rd[j0 + c];
-                            if (lane == c) z = yc;
-                            else if (lane < c) z -= S[pk(j0 + c, j0 + lane)] * yc;
+                        double lc[16], rdv[16];   // column `lane` of the diagonal block and the reciprocal pivots, fetched before the serial chain
+#pragma unroll
+                        for (int c = 0; c < 16; c++) { lc[c] = (c < nb && (lane & 15) < c) ? S[pk(j0 + c, j0 + (lane & 15))] : 0.0; rdv[c] = c < nb ? s_rd[j0 + c] : 0.0; }
+#pragma unroll
+                        for (int c = 15; c >= 0; c--) {
+                            const double yc = row_bcast(z, c) * rdv[c];
+                            if ((lane & 15) == c) z = yc; else z -= lc[c] * yc;
                         }
                         if (lane < nb) { s_y[lane] = z; yv[j0 + lane] = z; }
+                        if (lane >= nb && lane < 16) s_y[lane] = 0.0;
                     }
                     __syncthreads();
                     for (int r = tid; r < j0; r += 512) {
                         double sv = S[pk(R, r)];
-                        for (int c = 0; c < nb; c++) sv -= S[pk(j0 + c, r)] * s_y[c];
+                        double lv[16];
+#pragma unroll
+                        for (int c = 0; c < 16; c++) lv[c] = c < nb ? S[pk(j0 + c, r)] : 0.0;
+#pragma unroll
+                        for (int c = 0; c < 16; c++) sv -= lv[c] * s_y[c];
                         S[pk(R, r)] = sv;
                     }
                     __syncthreads();
@@ -1269,7 +1277,12 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
     {
         double* Hc = w.H + ((size_t)(1 - cur) * d.B + b) * RP * RP;
         const double* H0 = w.pri_H0 + (size_t)b * RP * RP;
-        for (int i = tid; i < RP * RP; i += 512) Hc[i] = H0[i];
+        // only the lower triangle of the first R rows is ever read or accumulated: copy that, two doubles per lane (rows are 128-B aligned)
+        for (int r = wave; r < R; r += 8) {
+            const double2* src = reinterpret_cast<const double2*>(H0 + (size_t)r * RP);
+            double2* dst = reinterpret_cast<double2*>(Hc + (size_t)r * RP);
+            for (int c2 = lane; 2 * c2 <= r; c2 += 64) dst[c2] = src[c2];
+        }
         double* gc = w.g + ((size_t)(1 - cur) * d.B + b) * RP;
         for (int i = tid; i < RP; i += 512) gc[i] = 0.0;
         if (tid == 0) w.cost[(size_t)(1 - cur) * d.B + b] = 0.0;
