@@ -863,6 +863,7 @@ __device__ __forceinline__ double row_bcast(double v, int j) {   // j must fold 
         case 12: return row_bcast_c<12>(v); case 13: return row_bcast_c<13>(v); case 14: return row_bcast_c<14>(v); default: return row_bcast_c<15>(v);
     }
 }
+template <bool INV = true>
 __device__ inline bool wave_chol16_inv(double* s_L, double* s_inv, double* s_rdiag, int lane) {
     const int r = lane & 15;   // the four 16-lane groups work redundantly on identical data, so lane j of the wavefront speaks for row j
     double a[16], rd[16];
@@ -892,7 +893,7 @@ __device__ inline bool wave_chol16_inv(double* s_L, double* s_inv, double* s_rdi
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
     // inverse: lane j solves L x = e_j (column j of L^-1); L is read as LDS broadcasts
-    {
+    if (INV) {
         const int j = r;
         double x[16];
 #pragma unroll
@@ -1098,29 +1099,38 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
 #else
 #define GF_SUB(acc) do { } while (0)
 #endif
+            // diagonal block j0: copy to s_blk, in-register factor + explicit inverse, copy the factor back (wavefront 0 only)
+            auto diag_block = [&](int j0) {
+                const int nb = min(16, R - j0);
+                for (int i = lane; i < 256; i += 64) { const int r = i >> 4, c = i & 15; s_blk[r * 17 + c] = (r < nb && c < nb) ? S[pk(j0 + max(r, c), j0 + min(r, c))] : (r == c ? 1.0 : 0.0); }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                const bool good = wave_chol16_inv(s_blk, s_inv, s_rd + j0, lane);
+                if (!good && lane == 0) s_flag[1] = 0;
+                for (int i = lane; i < 256; i += 64) { const int r = i >> 4, c = i & 15; if (c <= r && r < nb) S[pk(j0 + r, j0 + c)] = s_blk[r * 17 + c]; }
+            };
+            // one 16x16 tile (ti, tk) of the trailing update A22 -= L21 L21^T
+            auto trail_tile = [&](int j0, int nb, int r0, int ti, int tk) {
+                const int ra = r0 + 16 * ti + (lane & 15), rb = r0 + 16 * tk + (lane & 15);
+                const int ba_ = ra <= R ? pk(ra, j0) : -1, bb_ = rb < R ? pk(rb, j0) : -1;   // row R (rhs) never acts as a column
+                d4 acc = {0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int c = 4 * k + (lane >> 4);
+                    const double av = (ba_ >= 0 && c < nb) ? S[ba_ + c] : 0.0;
+                    const double bv2 = (bb_ >= 0 && c < nb) ? S[bb_ + c] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv2, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = r0 + 16 * ti + (lane >> 4) + 4 * r, col = r0 + 16 * tk + (lane & 15);
+                    if (row <= R && col <= row && col < R) S[pk(row, col)] -= acc[r];
+                }
+            };
+            if (wave == 0) diag_block(0);
+            __syncthreads();
+            GF_SUB(tA);
             for (int j0 = 0; j0 < R; j0 += 16) {
                 const int nb = min(16, R - j0);
-                if (wave == 0) {
-#ifdef GF_PROFILE_STEP
-                    const long long q0 = clock64();
-#endif
-                    for (int i = lane; i < 256; i += 64) { const int r = i >> 4, c = i & 15; s_blk[r * 17 + c] = (r < nb && c < nb) ? S[pk(j0 + max(r, c), j0 + min(r, c))] : (r == c ? 1.0 : 0.0); }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-#ifdef GF_PROFILE_STEP
-                    const long long q1 = clock64();
-#endif
-                    const bool good = wave_chol16_inv(s_blk, s_inv, s_rd + j0, lane);
-                    if (!good && lane == 0) s_flag[1] = 0;
-#ifdef GF_PROFILE_STEP
-                    const long long q2 = clock64();
-#endif
-                    for (int i = lane; i < 256; i += 64) { const int r = i >> 4, c = i & 15; if (c <= r && r < nb) S[pk(j0 + r, j0 + c)] = s_blk[r * 17 + c]; }
-#ifdef GF_PROFILE_STEP
-                    if (blockIdx.x == 0 && tid == 0 && sb.stamps) { sb.stamps[16] += q1 - q0; sb.stamps[17] += q2 - q1; sb.stamps[18] += clock64() - q2; }
-#endif
-                }
-                __syncthreads();
-                GF_SUB(tA);
                 if (!s_flag[1]) break;
                 // panel: X = A21 L11^-T for the rows below the block and the rhs row; 16-row tiles, X[i][c] = sum_k A[i][k] Linv[c][k]
                 const int r0 = j0 + nb;
@@ -1146,26 +1156,18 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                 }
                 __syncthreads();
                 GF_SUB(tB);
-                // trailing update A22 -= L21 L21^T (lower tiles)
+                // trailing update with look-ahead: wavefront 0 updates the next diagonal tile first and factors it (the serial part of the next
+                // block column) while wavefronts 1..7 update all other tiles
                 if (r0 <= R) {
                     const int nrows = R + 1 - r0, nt = (nrows + 15) / 16, ntiles = nt * (nt + 1) / 2;
-                    for (int t = wave; t < ntiles; t += 8) {
-                        const int ti = tri_row(t), tk = t - ti * (ti + 1) / 2;
-                        const int ra = r0 + 16 * ti + (lane & 15), rb = r0 + 16 * tk + (lane & 15);
-                        const int ba_ = ra <= R ? pk(ra, j0) : -1, bb_ = rb < R ? pk(rb, j0) : -1;   // row R (rhs) never acts as a column
-                        d4 acc = {0, 0, 0, 0};
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int c = 4 * k + (lane >> 4);
-                            const double av = (ba_ >= 0 && c < nb) ? S[ba_ + c] : 0.0;
-                            const double bv2 = (bb_ >= 0 && c < nb) ? S[bb_ + c] : 0.0;
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv2, acc, 0, 0, 0);
+                    if (wave == 0) {
+                        trail_tile(j0, nb, r0, 0, 0);
+                        if (r0 < R) {
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                            diag_block(r0);
                         }
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int row = r0 + 16 * ti + (lane >> 4) + 4 * r, col = r0 + 16 * tk + (lane & 15);
-                            if (row <= R && col <= row && col < R) S[pk(row, col)] -= acc[r];
-                        }
+                    } else {
+                        for (int t = wave; t < ntiles; t += 7) trail_tile(j0, nb, r0, tri_row(t), t - tri_row(t) * (tri_row(t) + 1) / 2);
                     }
                 }
                 __syncthreads();
