@@ -1013,6 +1013,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
             const double sc = scale[RP + e];
             const double dd = sqrt(fmin(fmax(sc * sc * ete[e], 1e-6), 1e32));
             diag[RP + e] = dd; grad[RP + e] = sc * etb[e] / dd; u[RP + e] = sc * (grad[RP + e] / dd);
+            gn[RP + e] = u[RP + e];   // the Cauchy direction's eliminated part survives in gn's tail until the back-substitution rewrites it
         }
         __syncthreads();
         if (tid < ECW) { const int c = s_cmap[tid]; s_uc[tid] = (c >= 0 && c < R) ? u[c] : 0.0; }
@@ -1020,9 +1021,14 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
         for (int c = tid; c < R; c += 512) gsq += grad[c] * grad[c];
         for (int e = tid; e < NE; e += 512) gsq += grad[RP + e] * grad[RP + e];
         gsq = block_sum(gsq, sred, tid, 512);
-        double uHu, ug;
-        quad_form<GS ? 8 : 3, GS ? 4 : 2>(H, g, Et, ete, etb, u, s_uc, R, NE, RP, ECW, sred, tid, uHu, ug);
-        if (tid == 0) st.alpha = gsq / uHu;
+        // alpha = |g~|^2 / (u^T H u) of the Cauchy point: the quadratic form is accumulated below, inside the passes that stream Et (Es build) and
+        // H (load of the reduced system) anyway, instead of a separate sweep over both
+        double uHu_acc = 0.0;
+        bool need_alpha = true;
+        constexpr int QN = GS ? 8 : 3;
+        double uk[QN];
+#pragma unroll
+        for (int q = 0; q < QN; q++) uk[q] = (lane + 64 * q) < R ? u[lane + 64 * q] : 0.0;
         // ---------------- Gauss-Newton step: (J^T J + mu D^2) y = J^T r through the Schur complement, retry with larger mu on failure
         bool ok = false;
         while (!ok) {
@@ -1039,25 +1045,70 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
             // compact Es[e][k] = f_e s_c Et[e][k] (c = reduced column of k); the right-hand-side slot carries etb~ / sqrt(ete~) so that the
             // GEMM also reduces the right-hand side
             const int NE4 = (NE + 3) & ~3;
-            for (int i = tid; i < NE4 * ECW; i += 512) {
-                const int e = i / ECW, k = i - e * ECW;
-                double v = 0.0;
-                if (e < NE) { const int c = s_cmap[k]; if (c >= 0 && c < R) v = u[RP + e] * scale[c] * Et[i]; else if (c == R) v = u[RP + e] * etb[e]; }
-                Es[i] = v;
+            // one wavefront per compact row, four rows in flight; lanes cover the ECW (<= 64 EN) columns
+            {
+                constexpr int EN = GS ? 4 : 2;
+                for (int e0 = wave; e0 < NE4; e0 += 32) {
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        const int e = e0 + 8 * m;
+                        if (e >= NE4) continue;
+                        const bool live = e < NE;
+                        const double fe = live ? u[RP + e] : 0.0, ue = (live && need_alpha) ? gn[RP + e] : 0.0, eb = live ? etb[e] : 0.0;
+                        const double* src = Et + (size_t)e * ECW;
+                        double* dst = Es + (size_t)e * ECW;
+                        double dotv = 0.0;
+#pragma unroll
+                        for (int q = 0; q < EN; q++) {
+                            const int k = lane + 64 * q;
+                            if (k < ECW) {
+                                const int c = s_cmap[k];
+                                double v = 0.0;
+                                if (live && c >= 0 && c < R) { const double etv = src[k]; v = fe * scale[c] * etv; dotv += etv * s_uc[k]; }
+                                else if (live && c == R) v = fe * eb;
+                                dst[k] = v;
+                            }
+                        }
+                        uHu_acc += 2.0 * ue * dotv;
+                    }
+                }
             }
             GF_STAMP(6);
             // reduced system in LDS (packed lower): S = s H s + mu D^2, row R = s g
-            for (int r = wave; r <= R; r += 8) {
-                const int base = pk(r, 0);
-                if (r < R) {
-                    const double sr = scale[r];
-                    const double* hr = H + (size_t)r * RP;
-                    for (int c = lane; c <= r; c += 64) {
-                        double v = sr * scale[c] * hr[c];
-                        if (c == r) { const double lm = diag[r] * sqrt(mu); v += lm * lm; }
-                        S[base + c] = v;
+            for (int r0 = wave; r0 <= R; r0 += 32) {   // four rows per wavefront in flight: all loads first, then the arithmetic
+                double hv[4][QN], srv[4], urv[4];
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const int r = r0 + 8 * m;
+                    srv[m] = r < R ? scale[r] : 0.0; urv[m] = r < R ? u[r] : 0.0;
+                    const double* hr = r < R ? H + (size_t)r * RP : g;   // row R: the right-hand side s g
+#pragma unroll
+                    for (int q = 0; q < QN; q++) { const int c = lane + 64 * q; hv[m][q] = (r <= R && c < R && (c <= r)) ? hr[c] : 0.0; }
+                }
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const int r = r0 + 8 * m;
+                    if (r > R) continue;
+                    const int base = pk(r, 0);
+#pragma unroll
+                    for (int q = 0; q < QN; q++) {
+                        const int c = lane + 64 * q;
+                        if (r < R) {
+                            if (c <= r) {
+                                double v = srv[m] * scale[c] * hv[m][q];
+                                if (c == r) { const double lm = diag[r] * sqrt(mu); v += lm * lm; }
+                                S[base + c] = v;
+                                uHu_acc += (c == r ? 1.0 : 2.0) * hv[m][q] * uk[q] * urv[m];   // H holds its lower triangle
+                            }
+                        } else if (c < R) S[base + c] = scale[c] * hv[m][q];
                     }
-                } else for (int c = lane; c < R; c += 64) S[base + c] = scale[c] * g[c];
+                }
+            }
+            if (need_alpha) {
+                for (int e = tid; e < NE; e += 512) { const double ue = gn[RP + e]; uHu_acc += ete[e] * ue * ue; }
+                const double uHu = block_sum(uHu_acc, sred, tid, 512);
+                if (tid == 0) st.alpha = gsq / uHu;
+                need_alpha = false;
             }
             __syncthreads();
             GF_STAMP(7);
