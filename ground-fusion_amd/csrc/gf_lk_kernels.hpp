@@ -53,8 +53,11 @@ __global__ void __launch_bounds__(256) pyr_level0_kernel(const uint8_t* __restri
     int py = t / qw, px = (t - py * qw) << 2;
     const uint8_t* src = raw + blockIdx.y * raw_seq_stride + (size_t)reflect101(py - kPad, g.h) * raw_stride;
     uint32_t v = 0;
+    if (px >= kPad && px + 3 < kPad + g.w && !((raw_stride | g.w) & 3)) v = *reinterpret_cast<const uint32_t*>(src + (px - kPad));   // interior: one aligned dword
+    else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) v |= (uint32_t)src[reflect101(px + k - kPad, g.w)] << (8 * k);
+        for (int k = 0; k < 4; k++) v |= (uint32_t)src[reflect101(px + k - kPad, g.w)] << (8 * k);
+    }
     uint8_t* dst = pyr + blockIdx.y * pyr_seq_stride + g.img_off - kPad * g.stride - kPad;
     *reinterpret_cast<uint32_t*>(dst + (size_t)py * g.stride + px) = v;
 }
@@ -97,6 +100,95 @@ __global__ void __launch_bounds__(256) scharr_kernel(const uint8_t* __restrict__
     int dx = ((a2 + c2) * 3 + b2 * 10) - ((a0 + c0) * 3 + b0 * 10);
     int dy = ((c2 - a2) + (c0 - a0)) * 3 + (c1 - a1) * 10;
     der[blockIdx.y * der_seq_stride + g.der_off + (size_t)y * g.stride + x] = (dx & 0xffff) | (dy << 16);
+}
+
+// Four-pixel-per-thread variants for level widths that are multiples of 4 (640 / 320 / 160 / 80): aligned dword loads instead of byte
+// loads, one dword / int4 store per thread.  Same integer arithmetic as the scalar kernels above.
+__device__ __forceinline__ int byte_of(uint32_t v, int k) { return (int)((v >> (8 * k)) & 0xffu); }
+
+// pyrDown, interior of level l+1 only (the border is filled by pyr_border_kernel): thread = 4 consecutive output pixels of one row
+__global__ void __launch_bounds__(256) pyr_down4_kernel(uint8_t* __restrict__ pyr, size_t pyr_seq_stride, LevelGeom s, LevelGeom d) {
+    const int qw = d.w >> 2;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= qw * d.h) return;
+    const int y = t / qw, x = (t - y * qw) << 2;
+    uint8_t* base = pyr + blockIdx.y * pyr_seq_stride;
+    const uint8_t* sp = base + s.img_off + (size_t)(2 * y - 2) * s.stride + 2 * x;   // 8-byte aligned
+    int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int dy = 0; dy < 5; dy++) {
+        const int ky = dy == 0 || dy == 4 ? 1 : (dy == 2 ? 6 : 4);
+        const uint32_t* r = reinterpret_cast<const uint32_t*>(sp + (size_t)dy * s.stride);
+        const uint32_t w0 = r[-1], w1 = r[0], w2 = r[1], w3 = r[2];   // source columns 2x-4 .. 2x+11
+        int p[12];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { p[k] = byte_of(w0, k); p[4 + k] = byte_of(w1, k); p[8 + k] = byte_of(w2, k); }
+        const int p12 = byte_of(w3, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {   // output i: source columns 2(x+i)-2 .. 2(x+i)+2 = p[2 + 2i] .. p[6 + 2i]
+            const int e = 6 + 2 * i < 12 ? p[(6 + 2 * i) < 12 ? 6 + 2 * i : 11] : p12;
+            acc[i] += ky * (p[2 + 2 * i] + 4 * p[3 + 2 * i] + 6 * p[4 + 2 * i] + 4 * p[5 + 2 * i] + e);
+        }
+    }
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) out |= (uint32_t)((acc[i] + 128) >> 8) << (8 * i);
+    *reinterpret_cast<uint32_t*>(base + d.img_off + (size_t)y * d.stride + x) = out;
+}
+
+// REFLECT_101 border of one level from its own interior: thread = 4 destination bytes of the padded domain, interior groups are skipped
+__global__ void __launch_bounds__(256) pyr_border_kernel(uint8_t* __restrict__ pyr, size_t pyr_seq_stride, LevelGeom g) {
+    const int pw = g.w + 2 * kPad, ph = g.h + 2 * kPad, qw = pw >> 2;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= qw * ph) return;
+    const int py = t / qw, px = (t - py * qw) << 2;
+    if (py >= kPad && py < kPad + g.h && px >= kPad && px + 3 < kPad + g.w) return;
+    uint8_t* base = pyr + blockIdx.y * pyr_seq_stride + g.img_off;
+    const uint8_t* src = base + (size_t)reflect101(py - kPad, g.h) * g.stride;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) v |= (uint32_t)src[reflect101(px + k - kPad, g.w)] << (8 * k);
+    *reinterpret_cast<uint32_t*>(base + (ptrdiff_t)(py - kPad) * g.stride + (px - kPad)) = v;
+}
+
+// Scharr derivative, thread = 4 consecutive pixels of one row; grid.y = sequence, grid.z = level
+__global__ void __launch_bounds__(256) scharr4_kernel(const uint8_t* __restrict__ pyr, size_t pyr_seq_stride, int* __restrict__ der, size_t der_seq_stride, PyrGeom G) {
+    const LevelGeom g = G.lv[blockIdx.z];
+    const int qw = g.w >> 2;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= qw * g.h) return;
+    const int y = t / qw, x = (t - y * qw) << 2;
+    const uint8_t* p = pyr + blockIdx.y * pyr_seq_stride + g.img_off + (size_t)y * g.stride + x;
+    int a[6], b[6], c[6];   // columns x-1 .. x+4 of rows y-1, y, y+1
+    {
+        const uint32_t* r = reinterpret_cast<const uint32_t*>(p - g.stride);
+        const uint32_t l = r[-1], m = r[0], h2 = r[1];
+        a[0] = byte_of(l, 3); a[5] = byte_of(h2, 0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) a[1 + k] = byte_of(m, k);
+    }
+    {
+        const uint32_t* r = reinterpret_cast<const uint32_t*>(p);
+        const uint32_t l = r[-1], m = r[0], h2 = r[1];
+        b[0] = byte_of(l, 3); b[5] = byte_of(h2, 0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) b[1 + k] = byte_of(m, k);
+    }
+    {
+        const uint32_t* r = reinterpret_cast<const uint32_t*>(p + g.stride);
+        const uint32_t l = r[-1], m = r[0], h2 = r[1];
+        c[0] = byte_of(l, 3); c[5] = byte_of(h2, 0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) c[1 + k] = byte_of(m, k);
+    }
+    int o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int dx = ((a[i + 2] + c[i + 2]) * 3 + b[i + 2] * 10) - ((a[i] + c[i]) * 3 + b[i] * 10);
+        const int dy = ((c[i + 2] - a[i + 2]) + (c[i] - a[i])) * 3 + (c[i + 1] - a[i + 1]) * 10;
+        o[i] = (dx & 0xffff) | (dy << 16);
+    }
+    *reinterpret_cast<int4*>(der + blockIdx.y * der_seq_stride + g.der_off + (size_t)y * g.stride + x) = make_int4(o[0], o[1], o[2], o[3]);
 }
 
 // ---------------------------------------------------------------------------------------------

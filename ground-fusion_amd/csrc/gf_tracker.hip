@@ -238,12 +238,20 @@ static int launch_pyramid(gf_tracker* h, const uint8_t* d_raw_frames) {
         const int n = ((g0.w + 2 * kPad) / 4) * (g0.h + 2 * kPad);
         pyr_level0_kernel<<<dim3((n + 255) / 256, h->B), 256, 0, h->stream>>>(d_raw_frames, (size_t)g0.w * g0.h, g0.w, img, seq_img, g0);
     }
+    bool vec = true;   // four-pixel kernels need level widths (and with them strides, offsets) that are multiples of 4
+    for (int l = 0; l < G.nlevels; l++) vec = vec && !(G.lv[l].w & 3) && !(G.lv[l].img_off & 3);
     for (int l = 1; l < G.nlevels; l++) {
         const LevelGeom d = G.lv[l];
-        const int n = (d.w + 2 * kPad) * (d.h + 2 * kPad);
-        pyr_down_kernel<<<dim3((n + 255) / 256, h->B), 256, 0, h->stream>>>(img, seq_img, G.lv[l - 1], d);
+        if (vec) {
+            pyr_down4_kernel<<<dim3(((d.w >> 2) * d.h + 255) / 256, h->B), 256, 0, h->stream>>>(img, seq_img, G.lv[l - 1], d);
+            pyr_border_kernel<<<dim3((((d.w + 2 * kPad) >> 2) * (d.h + 2 * kPad) + 255) / 256, h->B), 256, 0, h->stream>>>(img, seq_img, d);
+        } else {
+            const int n = (d.w + 2 * kPad) * (d.h + 2 * kPad);
+            pyr_down_kernel<<<dim3((n + 255) / 256, h->B), 256, 0, h->stream>>>(img, seq_img, G.lv[l - 1], d);
+        }
     }
-    scharr_kernel<<<dim3((g0.w * g0.h + 255) / 256, h->B, G.nlevels), 256, 0, h->stream>>>(img, seq_img, der, seq_der, G);
+    if (vec) scharr4_kernel<<<dim3(((g0.w >> 2) * g0.h + 255) / 256, h->B, G.nlevels), 256, 0, h->stream>>>(img, seq_img, der, seq_der, G);
+    else scharr_kernel<<<dim3((g0.w * g0.h + 255) / 256, h->B, G.nlevels), 256, 0, h->stream>>>(img, seq_img, der, seq_der, G);
     HIPCHK(hipGetLastError());
     return GF_OK;
 }
