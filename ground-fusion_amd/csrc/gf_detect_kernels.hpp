@@ -172,6 +172,31 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(DetectArgs A, DiskTab
             }
         }
     }
+    // setMask first: a tile without a single unmasked pixel contributes neither to the masked maximum nor a candidate, and with MAX_CNT tracks
+    // of radius MIN_DIST most of the image is masked -- such tiles stop here, before any arithmetic on the image
+    unsigned allow_bits = 0;
+    {
+        __syncthreads();   // n_dsk / dsk complete
+        const int nd0 = min(n_dsk, 512);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int li = tid + q * 256;
+            const int ly = li / kDT_W, lx = li - ly * kDT_W;
+            const int x = bx + lx, y = by + ly;
+            if (x >= g.w || y >= g.h) continue;
+            bool allowed;
+            if (A.mask) allowed = A.mask[b * A.mask_seq_stride + (size_t)y * g.w + x] != 0;
+            else {
+                allowed = true;
+                for (int k = 0; k < nd0; k++) {
+                    const int dy = abs(y - dsk[k].y), dx = abs(x - dsk[k].x);
+                    if (dy <= T.radius && dx <= T.hw[dy]) { allowed = false; break; }
+                }
+            }
+            if (allowed) allow_bits |= 1u << q;
+        }
+        if (!__syncthreads_or(allow_bits != 0)) return;
+    }
     const uint8_t* img = A.pyr + b * A.pyr_seq_stride + g.img_off;
     const float f1 = (float)(1.0 * (1.0 / (4.0 * 3.0 * 255.0))), f0 = (float)(2.0 * (1.0 / (4.0 * 3.0 * 255.0)));
     for (int t = tid; t < (kDT_W + 4) * (kDT_H + 4); t += 256) {
@@ -209,7 +234,6 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(DetectArgs A, DiskTab
         eg[ty][tx] = (a + c) - sqrtf((a - c) * (a - c) + bb * bb);
     }
     __syncthreads();
-    const int nd = min(n_dsk, 512);
     unsigned best = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -217,16 +241,7 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(DetectArgs A, DiskTab
         const int ly = li / kDT_W, lx = li - ly * kDT_W;
         const int x = bx + lx, y = by + ly;
         if (x >= g.w || y >= g.h) continue;
-        bool allowed;
-        if (A.mask) allowed = A.mask[b * A.mask_seq_stride + (size_t)y * g.w + x] != 0;
-        else {
-            allowed = true;
-            for (int k = 0; k < nd; k++) {
-                const int dy = abs(y - dsk[k].y), dx = abs(x - dsk[k].x);
-                if (dy <= T.radius && dx <= T.hw[dy]) { allowed = false; break; }
-            }
-        }
-        if (!allowed) continue;
+        if (!((allow_bits >> q) & 1u)) continue;
         const float v = eg[ly + 1][lx + 1];
         best = max(best, f32_orderable(v));
         if (x < 1 || y < 1 || x >= g.w - 1 || y >= g.h - 1 || v == 0.f) continue;
