@@ -78,6 +78,7 @@ def test_replay_feature_frames_matches_oracle():
     assert {(1, 0, 0), (1, 1, 0), (1, 1, 1)} <= seen                       # keyframes, non-keyframes and stationary frames all occurred
     assert np.linalg.norm(est_o.Ps[-1]) > 0.5                              # it really drove away
     assert any(f.estimate_flag == 2 for f in est_o.f_manager.feature)      # far-wall points were triangulated (free inverse depths)
+    print("feature-frame replay worst deviation", worst)
     assert worst["p"] < 1e-6 and worst["r"] < 1e-6, worst
 
 
@@ -106,6 +107,7 @@ def _image_replay(multiple_thread, t_move):
             continue
         compare_frame(est_o, est_p, worst, "image %d" % k)
     assert est_o.solver_flag == EO.NON_LINEAR and np.linalg.norm(est_o.Ps[-1]) > 0.3
+    print("image replay (multiple_thread=%d) worst deviation" % multiple_thread, worst)
     return worst
 
 
