@@ -820,13 +820,23 @@ __global__ void __launch_bounds__(64) ba_build_et(Win w, StepBufs sb, int which,
     const int p0 = w.feat_ptr[(size_t)b * (d.F + 1) + f], p1 = w.feat_ptr[(size_t)b * (d.F + 1) + f + 1];
     double acc = 0;
     int fi = 0;
-    for (int p = p0; p < p1; p++) {
-        const int k = w.feat_fac[(size_t)b * d.NV + p];
-        const double* ef = efac + (size_t)k * EF;
-        const size_t kk = (size_t)b * d.NV + k;
-        fi = w.vis_i[kk];
-        if (lane < 6 || (lane >= 12 && lane < 21)) acc += ef[lane];
-        else if (lane < 12) Et[6 * w.vis_j[kk] + lane - 6] = ef[lane];
+    for (int p = p0; p < p1; p += 4) {   // four factors in flight: index, frame and product loads are issued before any is consumed
+        int kq[4], jq[4];
+        double ev[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) kq[q] = p + q < p1 ? w.feat_fac[(size_t)b * d.NV + p + q] : -1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            jq[q] = kq[q] >= 0 ? w.vis_j[(size_t)b * d.NV + kq[q]] : 0;
+            ev[q] = (kq[q] >= 0 && lane < 21) ? efac[(size_t)kq[q] * EF + lane] : 0.0;
+        }
+        if (kq[0] >= 0) fi = w.vis_i[(size_t)b * d.NV + kq[0]];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (kq[q] < 0) continue;
+            if (lane < 6 || (lane >= 12 && lane < 21)) acc += ev[q];
+            else if (lane < 12) Et[6 * jq[q] + lane - 6] = ev[q];
+        }
     }
     if (lane < 6) Et[6 * fi + lane] = acc;
     else if (lane == 12) Et[6 * d.NP + 6] = acc;                    // td
