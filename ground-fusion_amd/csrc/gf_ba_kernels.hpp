@@ -53,6 +53,7 @@ struct SolverState {  // per window, lives in device memory
     int cur;            // which of the two state / normal-equation buffers is current
     int reuse, done, termination, iterations, successful, invalid_run, last_successful, have_scale, cand_valid;
     int R, NE;          // reduced dimension and number of eliminated (free inverse-depth) columns
+    double mu_solved;   // the mu of the Gauss-Newton solve that gn / yv currently hold
 };
 
 struct Win {  // device view of the whole batch
@@ -1292,7 +1293,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
         __syncthreads();
         if (ok) for (int c = tid; c < R; c += 512) gn[c] = -diag[c] * yv[c];
         __syncthreads();
-        if (tid == 0) st.reuse = 1;
+        if (tid == 0) { st.reuse = 1; st.mu_solved = st.mu; }
     } else if (tid == 0) s_flag[2] = 1;
     __syncthreads();
     bool valid = s_flag[2] != 0;
@@ -1322,12 +1323,14 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
         if (dsn < 0) dsn = sqrt(nn);
         if (tid == 0) st.dogleg_step_norm = dsn;
         GF_STAMP(12);
-        // model_cost_change = -(J s)^T (r + J s / 2) = -(u^T g + u^T H u / 2), u = scale .* step (trust_region_minimizer.cc)
+        // model_cost_change = -(J s)^T (r + J s / 2) = -(u^T g + u^T H u / 2), u = scale .* step (trust_region_minimizer.cc), without another
+        // sweep over H: u = ca uC + cb uG with uC the Cauchy direction and uG = -s y the Gauss-Newton step, and (s H s + mu D^2) y = s g gives
+        //   uC^T g = |g~|^2,  uG^T g = g~.gn,  uC^T H uC = |g~|^2 / alpha,  uC^T H uG = -|g~|^2 - mu g~.gn,  uG^T H uG = -g~.gn - mu |gn|^2
+        // (g~ = grad, gn in dogleg space; all three sums are already reduced above)
         __syncthreads();
-        if (tid < ECW) { const int c = s_cmap[tid]; s_uc[tid] = (c >= 0 && c < R) ? u[c] : 0.0; }
-        __syncthreads();
-        double uHu, ug;
-        quad_form<GS ? 8 : 3, GS ? 4 : 2>(H, g, Et, ete, etb, u, s_uc, R, NE, RP, ECW, sred, tid, uHu, ug);
+        const double mu_s = st.mu_solved;
+        const double ug = ca * v3[0] + cb * gdot;
+        const double uHu = ca * ca * (v3[0] / alpha) + 2.0 * ca * cb * (-v3[0] - mu_s * gdot) + cb * cb * (-gdot - mu_s * v3[1]);
         const double mcc = -(ug + 0.5 * uHu);
         if (tid == 0) st.model_cost_change = mcc;
         valid = mcc > 0.0;
