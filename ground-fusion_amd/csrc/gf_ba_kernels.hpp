@@ -740,61 +740,12 @@ __device__ __forceinline__ double block_max(double v, double* sred, int tid, int
     return t;
 }
 
-// u^T H u over reduced + eliminated columns: u_f^T Hff u_f + 2 u_e . (Et uc) + sum ete u_e^2, and u^T g.  Rows are streamed by wavefronts
-// (coalesced, four rows in flight), every lane keeps private partial sums, one block reduction at the end.  uc: u gathered to the compact
-// column layout of Et (LDS).
 __device__ __forceinline__ int tri_row(int t) {  // largest i with i(i+1)/2 <= t
     int i = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
     while (i * (i + 1) / 2 > t) i--;
     while ((i + 1) * (i + 2) / 2 <= t) i++;
     return i;
 }
-template <int QN, int EN>   // QN 64-column chunks of the reduced system (R <= 64 QN), EN chunks of the compact rows (ECW <= 64 EN)
-__device__ inline void quad_form(const double* H, const double* g, const double* Et, const double* ete, const double* etb, const double* u, const double* uc, int R,
-                                 int NE, int RP, int ECW, double* sred, int tid, double& uHu, double& ug) {
-    const int wave = tid >> 6, lane = tid & 63;
-    double a = 0, c = 0;
-    double uk[QN];
-#pragma unroll
-    for (int q = 0; q < QN; q++) uk[q] = (lane + 64 * q) < R ? u[lane + 64 * q] : 0.0;
-    for (int r0 = wave; r0 < R; r0 += 32) {
-        double sv[4];
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const int r = r0 + 8 * m;
-            sv[m] = 0;
-            if (r < R) {
-                const double* row = H + (size_t)r * RP;
-#pragma unroll
-                for (int q = 0; q < QN; q++) { const int c = lane + 64 * q; if (c <= r) sv[m] += (c == r ? 1.0 : 2.0) * row[c] * uk[q]; }   // H holds its lower triangle
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < 4; m++) if (r0 + 8 * m < R) a += u[r0 + 8 * m] * sv[m];
-    }
-    double ucl[EN];
-#pragma unroll
-    for (int q = 0; q < EN; q++) ucl[q] = (lane + 64 * q) < ECW ? uc[lane + 64 * q] : 0.0;
-    for (int e0 = wave; e0 < NE; e0 += 32) {
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const int e = e0 + 8 * m;
-            if (e < NE) {
-                const double* row = Et + (size_t)e * ECW;
-                double sv = 0;
-#pragma unroll
-                for (int q = 0; q < EN; q++) if (lane + 64 * q < ECW) sv += row[lane + 64 * q] * ucl[q];
-                a += 2.0 * u[RP + e] * sv;
-            }
-        }
-    }
-    for (int r = tid; r < R; r += 512) c += u[r] * g[r];
-    for (int e = tid; e < NE; e += 512) { const double ue = u[RP + e]; a += ete[e] * ue * ue; c += ue * etb[e]; }
-    double v2[2] = {a, c};
-    block_sum_n(v2, sred, tid);
-    uHu = v2[0]; ug = v2[1];
-}
-
 // PoseLocalParameterization::Plus (pose_local_parameterization.cpp:12-28)
 __device__ __forceinline__ void pose_plus(const double* x, const double* dl, double* out) {
     out[0] = x[0] + dl[0]; out[1] = x[1] + dl[1]; out[2] = x[2] + dl[2];
@@ -862,8 +813,8 @@ __device__ __forceinline__ double bcast_lane(double v, int srclane) {  // srclan
 }
 // value of lane J of the own 16-lane row, in every lane of the row: one v_mov_b32_dpp row_newbcast per half (no SGPR round trip)
 template <int J> __device__ __forceinline__ double row_bcast_c(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + J, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + J, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + J, 0xf, 0xf, true);   // every source lane is valid: no `old` operand to set up
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + J, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double row_bcast(double v, int j) {   // j must fold to a constant (unrolled loops)
@@ -908,11 +859,14 @@ __device__ inline bool wave_chol16_inv(double* s_L, double* s_inv, double* s_rdi
         const int j = r;
         double x[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            double sv = (i == j) ? 1.0 : 0.0;
+        for (int i = 0; i < 16; i++) x[i] = (i == j) ? 1.0 : 0.0;
+        // right-looking: once x[k] is final every later row takes its contribution -- 15 - k independent FMAs per step instead of one long
+        // dependent accumulation per row
 #pragma unroll
-            for (int k = 0; k < i; k++) sv -= s_L[i * 17 + k] * x[k];
-            x[i] = sv * rd[i];
+        for (int k = 0; k < 16; k++) {
+            x[k] *= rd[k];
+#pragma unroll
+            for (int i = k + 1; i < 16; i++) x[i] -= s_L[i * 17 + k] * x[k];
         }
         if (lane < 16) {
 #pragma unroll

@@ -1,4 +1,5 @@
 // micro-benchmark of the in-register 16x16 Cholesky + inverse of ba_step (one wavefront): cycles per call
+#pragma clang fp contract(fast)
 #include <cstdio>
 #include <vector>
 #include <hip/hip_runtime.h>
