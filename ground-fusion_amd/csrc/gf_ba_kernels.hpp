@@ -1298,10 +1298,24 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
         double* Hc = w.H + ((size_t)(1 - cur) * d.B + b) * RP * RP;
         const double* H0 = w.pri_H0 + (size_t)b * RP * RP;
         // only the lower triangle of the first R rows is ever read or accumulated: copy that, two doubles per lane (rows are 128-B aligned)
-        for (int r = wave; r < R; r += 8) {
-            const double2* src = reinterpret_cast<const double2*>(H0 + (size_t)r * RP);
-            double2* dst = reinterpret_cast<double2*>(Hc + (size_t)r * RP);
-            for (int c2 = lane; 2 * c2 <= r; c2 += 64) dst[c2] = src[c2];
+        constexpr int CQ = GS ? 4 : 2;   // 128-column chunks of a row
+        for (int r0 = wave; r0 < R; r0 += 32) {   // four rows per wavefront in flight
+            double2 v[4][CQ];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int r = r0 + 8 * m;
+                const double2* src = reinterpret_cast<const double2*>(H0 + (size_t)min(r, R - 1) * RP);
+#pragma unroll
+                for (int q = 0; q < CQ; q++) { const int c2 = lane + 64 * q; v[m][q] = (r < R && 2 * c2 <= r) ? src[c2] : make_double2(0.0, 0.0); }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int r = r0 + 8 * m;
+                if (r >= R) continue;
+                double2* dst = reinterpret_cast<double2*>(Hc + (size_t)r * RP);
+#pragma unroll
+                for (int q = 0; q < CQ; q++) { const int c2 = lane + 64 * q; if (2 * c2 <= r) dst[c2] = v[m][q]; }
+            }
         }
         double* gc = w.g + ((size_t)(1 - cur) * d.B + b) * RP;
         for (int i = tid; i < RP; i += 512) gc[i] = 0.0;
