@@ -211,42 +211,43 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     // dropped (marginalization_factor.cpp:294-302); any J with J^T J = A_r and J^T r = b_r is the same prior to the solver (only J^T J,
     // J^T r and |r|^2 enter Ceres), so a rank-revealing (diagonally pivoted) Cholesky with the same absolute threshold is used:
     // A_r = P L L^T P^T, J = L^T P^T (rows beyond the detected rank are zero), r = L^-1 P^T b (forward substitution rides along).
-    int* perm = reinterpret_cast<int*>(V);          // n ints
-    double* zb = V + 256;                           // n doubles: permuted right-hand side being forward-substituted
-    int* sidx = reinterpret_cast<int*>(V + 256 + 512);  // 512 ints for the arg-max reduction
-    for (int i = tid; i < n; i += 512) { perm[i] = i; zb[i] = br[i]; }
+    int* perm = reinterpret_cast<int*>(V);   // n ints
+    double* zb = V + 256;                    // n doubles: permuted right-hand side being forward-substituted
+    double* dg = V + 768;                    // current diagonal, by original index (pivot search reads only this)
+    double* dinvs = V + 1280;                // 1 / L_kk per accepted pivot
+    double* zr = V + 1792;                   // finished entries of the forward substitution
+    __shared__ double s_piv;
+    for (int i = tid; i < n; i += 512) { perm[i] = i; zb[i] = br[i]; dg[i] = A[i * n + i]; }
     __syncthreads();
     int rank = n;
     for (int k = 0; k < n; k++) {
-        double best = -1.0; int bi = k;
-        for (int i = k + tid; i < n; i += 512) { const double v = A[perm[i] * n + perm[i]]; if (v > best) { best = v; bi = i; } }
-        sred[tid] = best; sidx[tid] = bi;
-        __syncthreads();
-        for (int sft = 256; sft > 0; sft >>= 1) {
-            if (tid < sft && (sred[tid + sft] > sred[tid] || (sred[tid + sft] == sred[tid] && sidx[tid + sft] < sidx[tid]))) { sred[tid] = sred[tid + sft]; sidx[tid] = sidx[tid + sft]; }
-            __syncthreads();
+        // pivot search + swap by wavefront 0 alone (shuffles, no block-wide reduction): two barriers per pivot instead of ~15
+        if (wave == 0) {
+            double best = -1.0; int bi = k;
+            for (int i = k + lane; i < n; i += 64) { const double v = dg[perm[i]]; if (v > best) { best = v; bi = i; } }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (lane == 0) {
+                s_piv = best;
+                if (best > eps) { const int t = perm[k]; perm[k] = perm[bi]; perm[bi] = t; const double tz = zb[k]; zb[k] = zb[bi]; zb[bi] = tz; }
+            }
         }
-        const double piv = sred[0];
-        const int pi = sidx[0];
         __syncthreads();
+        const double piv = s_piv;
         if (!(piv > eps)) { rank = k; break; }
-        if (tid == 0) { const int t = perm[k]; perm[k] = perm[pi]; perm[pi] = t; const double tz = zb[k]; zb[k] = zb[pi]; zb[pi] = tz; }
-        __syncthreads();
         const int pk_ = perm[k];
-        const double dinv = 1.0 / sqrt(piv);
+        const double dinv = 1.0 / sqrt(piv), ipiv = 1.0 / piv;
         const double rk = zb[k] * dinv;
-        __syncthreads();
-        // column k of L: L[i][k] = A[perm[i]][pk_] / d (stored in place), forward substitution of the right-hand side
-        for (int i = k + tid; i < n; i += 512) {
-            if (i == k) { A[pk_ * n + pk_] = piv * dinv; zb[k] = rk; }
-            else { const double l = A[perm[i] * n + pk_] * dinv; A[perm[i] * n + pk_] = l; zb[i] -= l * rk; }
-        }
-        __syncthreads();
-        // trailing update on the symmetric full storage
+        if (tid == 0) { dinvs[k] = dinv; zr[k] = rk; }
+        // column k stays unscaled in A (it is only read from here on): L[i][k] = A[perm[i]][pk_] * dinv is applied where it is consumed
+        for (int i = k + 1 + tid; i < n; i += 512) { const double l = A[perm[i] * n + pk_] * dinv; zb[i] -= l * rk; dg[perm[i]] -= l * l; }
         const int m = n - k - 1;
         for (int e = tid; e < m * m; e += 512) {
             const int i = k + 1 + e / m, j = k + 1 + e % m;
-            A[perm[i] * n + perm[j]] -= A[perm[i] * n + pk_] * A[perm[j] * n + pk_];
+            A[perm[i] * n + perm[j]] -= A[perm[i] * n + pk_] * A[perm[j] * n + pk_] * ipiv;
         }
         __syncthreads();
     }
@@ -255,9 +256,11 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     double* rr = out.r + (size_t)b * d.NPRI;
     for (int i = tid; i < n * n; i += 512) {
         const int k = i / n, pos = i % n;   // J[k][perm[pos]] = L[pos][k] for pos >= k, k < rank
-        J[(size_t)k * n + perm[pos]] = (k < rank && pos >= k) ? A[perm[pos] * n + perm[k]] : 0.0;
+        double v = 0.0;
+        if (k < rank && pos >= k) v = pos == k ? 1.0 / dinvs[k] : A[perm[pos] * n + perm[k]] * dinvs[k];
+        J[(size_t)k * n + perm[pos]] = v;
     }
-    for (int k = tid; k < n; k += 512) rr[k] = k < rank ? zb[k] : 0.0;
+    for (int k = tid; k < n; k += 512) rr[k] = k < rank ? zr[k] : 0.0;
 }
 
 }  // namespace gfb
