@@ -1,0 +1,65 @@
+"""Committed golden vectors (tests/golden/oracle_golden.npz, made by tests/golden/make_golden.py): the oracle must reproduce them on the CPU,
+the HIP path must meet them on the GPU.  They pin this repo's oracle, not the reference (see the generator's header)."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = dict(np.load(os.path.join(HERE, "golden", "oracle_golden.npz")))
+
+
+def _gen():
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_oracle_reproduces_golden(oracle):
+    now = _gen().compute()
+    assert sorted(now) == sorted(GOLD)
+    for k, v in GOLD.items():
+        if k.startswith(("trk_", "lk_", "corners", "marg_ids")):
+            assert np.array_equal(now[k], v), k                                   # integer / float front-end results: bit-exact
+        else:
+            np.testing.assert_allclose(now[k], v, rtol=1e-9, atol=1e-9, err_msg=k)  # FP64 back end: libm differences only
+
+
+@pytest.mark.gpu
+def test_hip_front_end_meets_golden(gf):
+    import synth
+    frames = synth.tracker_sequence(4242, 3)
+    depth = np.full(frames[0].shape, 1500, np.uint16)
+    trk = gf.FeatureTracker(gf.default_cfg())
+    for k, f in enumerate(frames):
+        ids, obs = trk.trackImage(0.0666 * k, f, depth)
+        assert np.array_equal(ids, GOLD["trk_ids_%d" % k]) and np.array_equal(obs.view(np.uint64), GOLD["trk_obs_%d" % k].view(np.uint64)), k
+    trk.close()
+    pts = np.array([[100.25, 80.5], [320.0, 240.0], [500.75, 400.125]], np.float32)
+    nxt, st, _ = gf.lk_track(frames[0], frames[1], pts)
+    assert np.array_equal(nxt.view(np.uint32), GOLD["lk_next"].view(np.uint32)) and np.array_equal(st, GOLD["lk_status"])
+    assert np.array_equal(gf.good_features(frames[0], 40, min_dist=30), GOLD["corners"])
+
+
+@pytest.mark.gpu
+def test_hip_back_end_meets_golden(gf, oracle):
+    import synth_window as SW
+    w = SW.make_window(77, oracle, max_features=40, n_landmarks=60)
+    est = gf.Estimator(max_features=40, max_visual=400)
+    s = est.solve([w], 4)[0]
+    assert [s["iterations"], s["successful_steps"], s["termination"]] == [int(v) for v in GOLD["ba_summary"][:3]]
+    assert np.abs(w["para_Pose"] - GOLD["ba_pose"]).max() < 1e-6 and np.abs(w["para_SpeedBias"] - GOLD["ba_speedbias"]).max() < 1e-6
+    p = est.marginalize([w], 0)[0]
+    J = p["J"].reshape(p["n"], p["n"])
+    assert np.array_equal(p["block_id"], GOLD["marg_ids"])
+    assert np.abs(J.T @ J - GOLD["marg_JtJ"]).max() <= 1e-6 * np.abs(GOLD["marg_JtJ"]).max()   # the linearisation points already differ by the solver bar
+    est.close()
+    g = SW.make_window(78, oracle, max_features=30, n_landmarks=45, gnss=True, anchor=True)
+    eg = gf.Estimator(max_features=30, max_visual=300, max_gnss=12 * 11)
+    sg = eg.solve([g], 4)[0]
+    assert [sg["iterations"], sg["successful_steps"]] == [int(v) for v in GOLD["gnss_summary"][:2]]
+    assert np.abs(g["para_Pose"] - GOLD["gnss_pose"]).max() < 1e-6 and np.abs(g["para_rcv_dt"] - GOLD["gnss_rcv_dt"]).max() < 1e-6
+    assert np.abs(g["para_anc_ecef"] - GOLD["gnss_anc"]).max() < 1e-6
+    eg.close()
