@@ -7,6 +7,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "lib", "libgroundfusion_hip.so")
 SRCS = [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc"))) if f.endswith(".hip")]
 DEPS = [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))] + [os.path.join(HERE, "..", "include", "groundfusion_hip.h")]
+# the ROS-free replay tool (tools/gf_replay.cpp, host code on top of the C-ABI)
+TOOL = os.path.join(HERE, "..", "bin", "gf_replay")
+TOOL_SRC = os.path.join(HERE, "..", "tools", "gf_replay.cpp")
+TOOL_DEPS = [TOOL_SRC] + [os.path.join(HERE, "host", f) for f in os.listdir(os.path.join(HERE, "host"))]
 
 
 def needs_build():
@@ -16,7 +20,25 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
+def build_tool(force=False, verbose=False):
+    if not force and os.path.exists(TOOL) and all(os.path.getmtime(d) <= os.path.getmtime(TOOL) for d in TOOL_DEPS + [LIB]):
+        return TOOL
+    os.makedirs(os.path.dirname(TOOL), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O2", "-std=c++17", "-Wall", "-o", TOOL, TOOL_SRC, "-L" + os.path.dirname(LIB), "-lgroundfusion_hip", "-Wl,-rpath,$ORIGIN/../ground-fusion_amd/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return TOOL
+
+
 def build(force=False, verbose=False):
+    lib = build_lib(force, verbose)
+    build_tool(force, verbose)
+    return lib
+
+
+def build_lib(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)

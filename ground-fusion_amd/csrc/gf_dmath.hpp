@@ -56,6 +56,19 @@ GFD M3 qmat(Q4 q) {  // Eigen toRotationMatrix
     r.m[6] = txz - twy; r.m[7] = tyz + twx; r.m[8] = 1 - (txx + tyy);
     return r;
 }
+// Eigen::Quaterniond(Matrix3d)
+GFD Q4 rot_to_quat(const M3& Rm) {
+    const double* R = Rm.m;
+    double t = R[0] + R[4] + R[8], w, v[3];
+    if (t > 0) { t = sqrt(t + 1.0); w = 0.5 * t; t = 0.5 / t; v[0] = (R[7] - R[5]) * t; v[1] = (R[2] - R[6]) * t; v[2] = (R[3] - R[1]) * t; }
+    else {
+        int i = 0; if (R[4] > R[0]) i = 1; if (R[8] > R[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0); v[i] = 0.5 * t; t = 0.5 / t;
+        w = (R[3 * k + j] - R[3 * j + k]) * t; v[j] = (R[3 * j + i] + R[3 * i + j]) * t; v[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+    }
+    return Q4{w, v[0], v[1], v[2]};
+}
 GFD V3 qrot(Q4 q, V3 v) {  // Eigen _transformVector
     V3 u = qvec(q);
     V3 uv = cross(u, v);

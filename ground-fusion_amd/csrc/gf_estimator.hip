@@ -54,19 +54,6 @@ M3 ypr2R(V3 ypr) {
     Rx.m[0] = 1; Rx.m[4] = cos(r); Rx.m[5] = -sin(r); Rx.m[7] = sin(r); Rx.m[8] = cos(r);
     return Rz * Ry * Rx;
 }
-// Eigen::Quaterniond(Matrix3d)
-Q4 rot_to_quat(const M3& Rm) {
-    const double* R = Rm.m;
-    double t = R[0] + R[4] + R[8], w, v[3];
-    if (t > 0) { t = sqrt(t + 1.0); w = 0.5 * t; t = 0.5 / t; v[0] = (R[7] - R[5]) * t; v[1] = (R[2] - R[6]) * t; v[2] = (R[3] - R[1]) * t; }
-    else {
-        int i = 0; if (R[4] > R[0]) i = 1; if (R[8] > R[4 * i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0); v[i] = 0.5 * t; t = 0.5 / t;
-        w = (R[3 * k + j] - R[3 * j + k]) * t; v[j] = (R[3 * j + i] + R[3 * i + j]) * t; v[k] = (R[3 * k + i] + R[3 * i + k]) * t;
-    }
-    return Q4{w, v[0], v[1], v[2]};
-}
 // Utility::g2R (utility/utility.cpp:12-22) with Eigen's Quaterniond::FromTwoVectors (regular branch; the antiparallel branch needs g ≈ -z)
 M3 g2R(V3 g) {
     const V3 v0 = normalized(g), v1 = v3(0, 0, 1);
@@ -344,6 +331,7 @@ struct gf_estimator {
     // stationarity / anomaly votes (estimator.h, EST:26-35)
     bool wheelanomaly = false, visualstationary = false, wheelstationary = false, imustationary = false, systemstationary = false, varstationary = false,
          preintegrationstationary = false, is_imu_excited = false, Bas_calibok = false;
+    std::string result_path;   // VINS_RESULT_PATH ("" = no trajectory file)
     V3 dP_imu = v3(0, 0, 0), dP_wheel = v3(0, 0, 0);
     int openExEstimation = 0, openExWheelEstimation = 0, openIxEstimation = 0;
     M3 back_R0 = m3_identity(), last_R = m3_identity(), last_R0 = m3_identity(); V3 back_P0 = v3(0, 0, 0), last_P = v3(0, 0, 0), last_P0 = v3(0, 0, 0);
@@ -428,7 +416,17 @@ struct gf_estimator {
         }
         vel_0_wheel = linear_velocity; gyr_0_wheel = angular_velocity;
     }
-    int processMeasurements() {  // EST:526-709, single-thread form: one feature frame per call
+    // the processThread of multiple_thread: 1 (EST:209, :529-707) made deterministic: whenever an input arrives, take every queued frame
+    // whose IMU / wheel interval is complete.  Which samples a frame integrates depends only on time stamps, not on when it is taken.
+    int drain() {
+        for (;;) {
+            bool progressed = false;
+            if (int rc = processMeasurements(&progressed)) return rc;
+            if (!progressed) return GF_OK;
+        }
+    }
+    int processMeasurements(bool* progressed = nullptr) {  // EST:526-709, single-thread form: one feature frame per call
+        if (progressed) *progressed = false;
         if (featureBuf.empty()) return GF_OK;
         auto& feature = featureBuf.front();
         curTime = feature.first + td; curTime_wheel = curTime - td_wheel;
@@ -467,6 +465,10 @@ struct gf_estimator {
         }
         const int rc = processImage(image, header);
         prevTime = curTime; prevTime_wheel = curTime_wheel;
+        if (progressed) *progressed = true;
+        // pubOdometry(*this, header), EST:679 -> utility/visualization.cpp:287-357: the trajectory file gets a line once the window is live
+        if (rc == GF_OK && !result_path.empty() && (solver_flag == NON_LINEAR || is_imu_excited))
+            return gf_tum_append(result_path.c_str(), header, &Ps[WINDOW_SIZE].x, Rs[WINDOW_SIZE].m);
         return rc;
     }
 
@@ -921,15 +923,27 @@ int gf_estimator_create(const gf_estimator_cfg* c, gf_estimator** out) {
     return GF_OK;
 }
 int gf_estimator_destroy(gf_estimator* e) { delete e; return GF_OK; }
+int gf_estimator_set_result_path(gf_estimator* e, const char* vio_txt) {   // VINS_RESULT_PATH, created empty at start-up (parameters.cpp:347-352)
+    if (!e) return gf::set_err(GF_ERR_INVALID, "null handle");
+    e->result_path = vio_txt ? vio_txt : "";
+    if (!e->result_path.empty()) {
+        FILE* f = fopen(vio_txt, "w");
+        if (!f) { e->result_path.clear(); return gf::set_err(GF_ERR_INVALID, "cannot create %s", vio_txt); }
+        fclose(f);
+    }
+    return GF_OK;
+}
 
 int gf_estimator_input_imu(gf_estimator* e, double t, const double* acc, const double* gyr) {  // Estimator::inputIMU EST:330-346
     if (!e || !acc || !gyr) return gf::set_err(GF_ERR_INVALID, "null argument");
     e->accBuf.emplace_back(t, arr3(acc)); e->gyrBuf.emplace_back(t, arr3(gyr));
+    if (e->cfg.multiple_thread && !e->featureBuf.empty()) return e->drain();   // a frame was waiting for this sample ("wait for imu ...", EST:551-560)
     return GF_OK;
 }
 int gf_estimator_input_wheel(gf_estimator* e, double t, const double* vel, const double* gyr) {  // Estimator::inputWheel EST:347-360
     if (!e || !vel || !gyr) return gf::set_err(GF_ERR_INVALID, "null argument");
     e->wheelVelBuf.emplace_back(t, arr3(vel)); e->wheelGyrBuf.emplace_back(t, arr3(gyr));
+    if (e->cfg.multiple_thread && !e->featureBuf.empty()) return e->drain();   // "wait for wheel ...", EST:562-573
     return GF_OK;
 }
 // Estimator::inputFeature (EST:362-375) + processMeasurements: `obs` is the tracker's map flattened in id order
@@ -938,7 +952,7 @@ int gf_estimator_input_feature(gf_estimator* e, double t, const gf_feature_obs* 
     std::vector<gf_feature_obs> v(obs, obs + n);
     std::stable_sort(v.begin(), v.end(), [](const gf_feature_obs& a, const gf_feature_obs& b) { return a.id < b.id; });
     e->featureBuf.emplace_back(t, std::move(v));
-    return e->processMeasurements();
+    return e->cfg.multiple_thread ? e->drain() : e->processMeasurements();   // inline call of the non-threaded mode: one frame, EST:239
 }
 // Estimator::inputImage (EST:213-242): track, then (multiple_thread: every second frame) hand the features to the back end
 int gf_estimator_input_image(gf_estimator* e, double t, const uint8_t* gray, int stride, const uint16_t* depth, int dstride, gf_feature_obs* out, int cap, int* n_out) {

@@ -492,3 +492,37 @@ class SlidingWindowEstimator:
         n = C.c_int(0)
         _chk(lib().gf_estimator_debug(self.h, op.encode(), _p(a, C.c_double) if a.size else None, int(a.size), _p(out, C.c_double), cap, C.byref(n)))
         return out[:n.value].copy()
+
+
+# ------------------------------------------------------------------ ROS-free I/O (gf_io.hip): config files, trajectory output, raw frames
+def estimator_cfg_from_yaml(config_file):
+    """readParameters(config_file) (parameters.cpp:138-558) + the cam0_calib file -> EstimatorCfg with the tracker part filled."""
+    c = EstimatorCfg()
+    _chk(lib().gf_estimator_cfg_from_yaml(os.fsencode(config_file), C.byref(c)))
+    return c
+
+
+def tum_append(path, t, P, R):
+    """one `t x y z qx qy qz qw` line as pubOdometry writes it (visualization.cpp:346-357)"""
+    P, R = np.ascontiguousarray(P, np.float64), np.ascontiguousarray(R, np.float64)
+    _chk(lib().gf_tum_append(os.fsencode(path), C.c_double(t), _p(P, C.c_double), _p(R, C.c_double)))
+
+
+def read_pgm(path):
+    """binary PGM -> u8 (maxval <= 255) or u16 array [h, w]"""
+    w, h, mv = C.c_int(0), C.c_int(0), C.c_int(0)
+    fn = lib().gf_pgm_read
+    fn.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
+    _chk(fn(os.fsencode(path), C.byref(w), C.byref(h), C.byref(mv), None, 0))
+    img = np.zeros((h.value, w.value), np.uint16 if mv.value > 255 else np.uint8)
+    _chk(fn(os.fsencode(path), C.byref(w), C.byref(h), C.byref(mv), img.ctypes.data_as(C.c_void_p), img.nbytes))
+    return img
+
+
+def write_pgm(path, img):
+    """the inverse of read_pgm (numpy only; used by the dataset exporter and tests)"""
+    img = np.ascontiguousarray(img)
+    assert img.dtype in (np.uint8, np.uint16) and img.ndim == 2
+    with open(path, "wb") as f:
+        f.write(b"P5\n%d %d\n%d\n" % (img.shape[1], img.shape[0], 255 if img.dtype == np.uint8 else 65535))
+        f.write(img.tobytes() if img.dtype == np.uint8 else img.astype(">u2").tobytes())

@@ -49,6 +49,10 @@ class Estimator {
         refresh();
     }
     void clearState() { setParameter(); }          // estimator.cpp:51-174
+    // readParameters(config_file) (parameters.cpp:138-558) fills cfg, tracker part included; call setParameter() afterwards as main() does
+    void readParameters(const std::string& config_file) { check(gf_estimator_cfg_from_yaml(config_file.c_str(), &cfg)); }
+    // VINS_RESULT_PATH: pubOdometry's trajectory file (visualization.cpp:346-357), written by the library after every processed frame
+    void setResultPath(const std::string& vio_txt) { need(); check(gf_estimator_set_result_path(h_, vio_txt.c_str())); }
 
     void inputIMU(double t, const Vec3& linearAcceleration, const Vec3& angularVelocity) {
         need();

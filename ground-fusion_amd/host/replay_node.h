@@ -1,0 +1,153 @@
+// replay_node.h — the ROS node of the reference without ROS: the callbacks of vins_estimator/src/rosNodeTest.cpp
+// driven from recorded messages in time-stamp order, the way `rosbag play` delivers them.
+//   imu_callback   rosNodeTest.cpp:567-585     wheel_callback  :81-189 (the w_replace yaw-rate substitution included)
+//   img0_callback / img1_callback :59-71       sync_process    :290-470 (RGB / depth pairing within 3 ms, the non-YOLO branch)
+// Est is gf::Estimator (estimator.h) in the tool; the unit test substitutes a recorder.  Frames are read from binary PGM files
+// (8-bit gray = MONO8, 16-bit = MONO16 depth in mm) when their pair is formed, not when their message is queued.
+//
+// Dataset directory read by load():   imu.csv  t,ax,ay,az,gx,gy,gz     wheel.csv  t,vx,vy,vz,wx,wy,wz     (nav_msgs/Odometry twist)
+//                                     image0.csv  t,file               image1.csv  t,file                 (files relative to the directory)
+#pragma once
+#include <algorithm>
+#include <cstdio>
+#include <deque>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "estimator.h"
+
+namespace gf {
+
+struct ImuMsg { double t; Vec3 linear_acceleration, angular_velocity; };
+struct OdomMsg { double t; Vec3 linear, angular; };
+struct ImageMsg { double t; std::string file; };
+
+template <class Est> class ReplayNode {
+  public:
+    Est& estimator;
+    int w_replace = 0;                 // config key `w_replace` (parameters.cpp:178): take the wheel yaw rate from the IMU's -y gyro axis
+    std::deque<ImuMsg> imu_buf;
+    std::deque<ImageMsg> img0_buf, img1_buf;
+    long n_pairs = 0, n_thrown0 = 0, n_thrown1 = 0;
+
+    explicit ReplayNode(Est& e) : estimator(e) {}
+
+    void imu_callback(const ImuMsg& m) {
+        imu_buf.push_back(m);
+        estimator.inputIMU(m.t, m.linear_acceleration, m.angular_velocity);
+    }
+
+    void wheel_callback(const OdomMsg& m) {
+        const double t = m.t;
+        double rz_f = 0, rz_b = 0, t_f = 0, t_b = 0, final_z = 0;
+        while (!imu_buf.empty()) {
+            const int Bg_z = 0;        // `int Bg_z = 0.000000001;` in the reference, i.e. 0
+            double t_imu = imu_buf.front().t;
+            if (t - t_imu < 0.006 && t - t_imu > 0) {
+                rz_f = -imu_buf.front().angular_velocity[1];
+                t_f = t_imu;
+                imu_buf.pop_front();
+                if (!imu_buf.empty()) {
+                    rz_b = -imu_buf.front().angular_velocity[1];
+                    t_imu = imu_buf.front().t;
+                    t_b = t_imu;
+                    imu_buf.pop_front();
+                    final_z = rz_f + (rz_b - rz_f) / (t_b - t_f) * (t - t_f) - Bg_z;
+                }
+                break;
+            }
+            imu_buf.pop_front();
+        }
+        Vec3 gyr = m.angular;
+        if (final_z != 0 && w_replace) gyr[2] = final_z;
+        estimator.inputWheel(t, m.linear, gyr);
+    }
+
+    void img0_callback(const ImageMsg& m) { img0_buf.push_back(m); }
+    void img1_callback(const ImageMsg& m) { img1_buf.push_back(m); }
+
+    // one polling pass of the sync thread, repeated until it finds nothing to do
+    void sync_process(const std::string& dir) {
+        while (!img0_buf.empty() && !img1_buf.empty()) {
+            const double time0 = img0_buf.front().t, time1 = img1_buf.front().t;
+            if (time0 < time1 - 0.003) { img0_buf.pop_front(); n_thrown0++; continue; }
+            if (time0 > time1 + 0.003) { img1_buf.pop_front(); n_thrown1++; continue; }
+            const double time = time0;
+            load_pgm(dir + "/" + img0_buf.front().file, gray_, sizeof(uint8_t), gw_, gh_);
+            load_pgm(dir + "/" + img1_buf.front().file, depth_, sizeof(uint16_t), dw_, dh_);
+            img0_buf.pop_front(); img1_buf.pop_front();
+            if (gw_ != dw_ || gh_ != dh_) throw std::runtime_error("replay: gray and depth frames differ in size");
+            GrayImage g; g.data = gray_.data(); g.rows = gh_; g.cols = gw_; g.stride = gw_;
+            DepthImage d; d.data = (const uint16_t*)depth_.data(); d.rows = dh_; d.cols = dw_; d.stride = dw_;
+            estimator.inputImage(time, g, d);
+            n_pairs++;
+        }
+    }
+
+    // merge the four recorded topics by time stamp (ties: imu, wheel, image0, image1) and run the callbacks
+    void run(const std::string& dir) {
+        struct Ev { double t; int kind; size_t idx; };
+        std::vector<ImuMsg> imu; std::vector<OdomMsg> odom; std::vector<ImageMsg> im0, im1;
+        load(dir, imu, odom, im0, im1);
+        std::vector<Ev> ev;
+        for (size_t i = 0; i < imu.size(); i++) ev.push_back({imu[i].t, 0, i});
+        for (size_t i = 0; i < odom.size(); i++) ev.push_back({odom[i].t, 1, i});
+        for (size_t i = 0; i < im0.size(); i++) ev.push_back({im0[i].t, 2, i});
+        for (size_t i = 0; i < im1.size(); i++) ev.push_back({im1[i].t, 3, i});
+        std::stable_sort(ev.begin(), ev.end(), [](const Ev& a, const Ev& b) { return a.t < b.t || (a.t == b.t && a.kind < b.kind); });
+        for (const Ev& e : ev) {
+            if (e.kind == 0) imu_callback(imu[e.idx]);
+            else if (e.kind == 1) wheel_callback(odom[e.idx]);
+            else if (e.kind == 2) { img0_callback(im0[e.idx]); sync_process(dir); }
+            else { img1_callback(im1[e.idx]); sync_process(dir); }
+        }
+    }
+
+    static void load(const std::string& dir, std::vector<ImuMsg>& imu, std::vector<OdomMsg>& odom, std::vector<ImageMsg>& im0, std::vector<ImageMsg>& im1) {
+        for (auto& r : rows(dir + "/imu.csv", 7)) imu.push_back({num(r[0]), vec(r, 1), vec(r, 4)});
+        for (auto& r : rows(dir + "/wheel.csv", 7)) odom.push_back({num(r[0]), vec(r, 1), vec(r, 4)});
+        for (auto& r : rows(dir + "/image0.csv", 2)) im0.push_back({num(r[0]), r[1]});
+        for (auto& r : rows(dir + "/image1.csv", 2)) im1.push_back({num(r[0]), r[1]});
+    }
+
+  private:
+    std::vector<uint8_t> gray_, depth_;
+    int gw_ = 0, gh_ = 0, dw_ = 0, dh_ = 0;
+
+    static double num(const std::string& s) {
+        char* end = nullptr;
+        const double v = strtod(s.c_str(), &end);
+        if (end == s.c_str()) throw std::runtime_error("replay: bad number '" + s + "'");
+        return v;
+    }
+    static Vec3 vec(const std::vector<std::string>& r, int o) { Vec3 v; v[0] = num(r[o]); v[1] = num(r[o + 1]); v[2] = num(r[o + 2]); return v; }
+    static std::vector<std::vector<std::string>> rows(const std::string& path, size_t ncol) {
+        std::ifstream in(path);
+        if (!in) throw std::runtime_error("replay: cannot open " + path);
+        std::vector<std::vector<std::string>> out;
+        std::string line;
+        while (std::getline(in, line)) {
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (line.empty() || line[0] == '#') continue;
+            std::vector<std::string> f;
+            std::stringstream ss(line);
+            std::string tok;
+            while (std::getline(ss, tok, ',')) f.push_back(tok);
+            if (f.size() != ncol) throw std::runtime_error("replay: " + path + ": expected " + std::to_string(ncol) + " comma-separated fields: " + line);
+            out.push_back(f);
+        }
+        return out;
+    }
+    static void load_pgm(const std::string& path, std::vector<uint8_t>& buf, size_t bpp, int& w, int& h) {
+        int mv = 0;
+        if (gf_pgm_read(path.c_str(), &w, &h, &mv, nullptr, 0) != GF_OK) throw std::runtime_error(std::string("replay: ") + gf_last_error());
+        if ((mv > 255 ? 2u : 1u) != bpp) throw std::runtime_error("replay: " + path + ": expected a " + std::to_string(8 * bpp) + "-bit PGM");
+        buf.resize((size_t)w * h * bpp);
+        if (gf_pgm_read(path.c_str(), &w, &h, &mv, buf.data(), buf.size()) != GF_OK) throw std::runtime_error(std::string("replay: ") + gf_last_error());
+    }
+};
+
+}  // namespace gf

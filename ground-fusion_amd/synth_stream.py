@@ -143,3 +143,53 @@ class Stream:
                 d = float(np.rint(Xc[i, 2] * 1000.0)) / 1000.0
                 out[i] = ((u - synth.CX) / synth.FX, (v - synth.CY) / synth.FY, u, v, d)
         return out
+
+    # ---- the stream as files: what tools/gf_replay reads (host/replay_node.h) plus a configuration in the reference's own YAML dialect
+    def export(self, out_dir, n_frames=None, **cfg):
+        """writes imu.csv, wheel.csv, image0.csv, image1.csv, frames/*.pgm, config.yaml and cam.yaml; cfg overrides YAML keys"""
+        import os
+        import gfamd
+        os.makedirs(os.path.join(out_dir, "frames"), exist_ok=True)
+        n = len(self.cam_t) if n_frames is None else min(n_frames, len(self.cam_t))
+        t_end = self.cam_t[n - 1] + 0.05
+        with open(os.path.join(out_dir, "imu.csv"), "w") as f:
+            f.write("# t,ax,ay,az,gx,gy,gz\n")
+            for t, a, g in zip(self.imu_t, self.imu_acc, self.imu_gyr):
+                if t <= t_end:
+                    f.write(",".join(repr(float(v)) for v in (t, *a, *g)) + "\n")
+        with open(os.path.join(out_dir, "wheel.csv"), "w") as f:
+            f.write("# t,vx,vy,vz,wx,wy,wz\n")
+            for t, v, g in zip(self.wheel_t, self.wheel_vel, self.wheel_gyr):
+                if t <= t_end:
+                    f.write(",".join(repr(float(x)) for x in (t, *v, *g)) + "\n")
+        with open(os.path.join(out_dir, "image0.csv"), "w") as f0, open(os.path.join(out_dir, "image1.csv"), "w") as f1:
+            for k in range(n):
+                img, dep = self.image(k)
+                gfamd.write_pgm(os.path.join(out_dir, "frames", "%06d_gray.pgm" % k), img)
+                gfamd.write_pgm(os.path.join(out_dir, "frames", "%06d_depth.pgm" % k), dep)
+                f0.write("%r,frames/%06d_gray.pgm\n" % (float(self.cam_t[k]), k))
+                f1.write("%r,frames/%06d_depth.pgm\n" % (float(self.cam_t[k]), k))
+        keys = dict(imu=1, wheel=1, depth=1, gnss_enable=0, w_replace=0, wdetect=1, stationary_detect=1, use_motion=0, use_line=0, use_mcc=0, plane=0, use_yolo=0,
+                    num_of_cam=1, equalize=0, depth_threshold=3, output_path='"%s"' % out_dir, cam0_calib='"cam.yaml"', cam1_calib='"cam.yaml"',
+                    image_width=synth.W, image_height=synth.H, estimate_extrinsic=0, extrinsic_type=0, estimate_wheel_extrinsic=1, extrinsic_type_wheel=0,
+                    multiple_thread=1, max_cnt=150, min_dist=30, freq=10, F_threshold=1.0, show_track=0, flow_back=1, max_solver_time=0.04, max_num_iterations=8,
+                    keyframe_parallax=10.0, acc_n=1.2374091609523514e-02, gyr_n=3.0032654435730201e-03, acc_w=1.9218003442176448e-04, gyr_w=5.4692100664858005e-05,
+                    g_norm=G_NORM, wheel_gyro_noise_sigma=0.004, wheel_velocity_noise_sigma=0.01, estimate_wheel_intrinsic=0, sx=1.0, sy=1.0, sw=1.0,
+                    estimate_td=0, td=0.0, estimate_td_wheel=0, td_wheel=0.0)
+        keys.update(cfg)
+        T_io = np.eye(4)
+        T_io[:3, :3], T_io[:3, 3] = RIO, TIO
+
+        def mat(name, M):
+            rows = ",\n          ".join(", ".join(repr(float(v)) for v in r) for r in M)
+            return "%s: !!opencv-matrix\n   rows: %d\n   cols: %d\n   dt: d\n   data: [ %s ]\n" % (name, M.shape[0], M.shape[1], rows)
+
+        with open(os.path.join(out_dir, "config.yaml"), "w") as f:
+            f.write("%YAML:1.0\n\n# synthetic sequence, seed " + str(self.seed) + " (ground-fusion_amd/synth_stream.py)\n")
+            for k, v in keys.items():
+                f.write("%s: %s\n" % (k, v))
+            f.write("\n" + mat("body_T_cam0", np.eye(4)) + "\n" + mat("body_T_cam1", np.eye(4)) + "\n" + mat("body_T_wheel", T_io))
+        with open(os.path.join(out_dir, "cam.yaml"), "w") as f:
+            f.write("%%YAML:1.0\n---\nmodel_type: PINHOLE\ncamera_name: camera\nimage_width: %d\nimage_height: %d\ndistortion_parameters:\n   k1: 0.0\n   k2: 0.0\n"
+                    "   p1: 0.0\n   p2: 0.0\nprojection_parameters:\n   fx: %r\n   fy: %r\n   cx: %r\n   cy: %r\n" % (synth.W, synth.H, synth.FX, synth.FY, synth.CX, synth.CY))
+        return n

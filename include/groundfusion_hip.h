@@ -282,6 +282,24 @@ int gf_estimator_get_prior(gf_estimator* h, int cap_n, int cap_blocks, int* n, i
 /* single host-side steps by name (FeatureManager members, slideWindow, ...) for unit tests; see gf_estimator.hip */
 int gf_estimator_debug(gf_estimator* h, const char* op, const double* in, int n_in, double* out, int cap_out, int* n_out);
 
+/* ---- ROS-free I/O around the path: config files, trajectory output, raw frames ---------------------------------------- */
+/* readParameters(std::string config_file), vins_estimator/src/estimator/parameters.cpp:138-558, plus the cam0_calib file it names
+ * (PinholeCamera::Parameters::readFromYamlFile, camera_models/src/camera_models/PinholeCamera.cc:145-183; path relative to the config
+ * file's directory, parameters.cpp:436-443).  Same key names and cv::FileNode defaults (a missing numeric key reads as 0).  Fills the
+ * whole cfg including cfg->tracker and sets with_tracker = 1.  Options outside the built path (use_line, use_yolo, plane, equalize,
+ * gnss_enable, use_motion, num_of_cam 2, estimate_extrinsic 2, subset extrinsic_type) return GF_ERR_INVALID instead of being ignored. */
+int gf_estimator_cfg_from_yaml(const char* config_file, gf_estimator_cfg* cfg);
+/* the line pubOdometry appends to VINS_RESULT_PATH (utility/visualization.cpp:346-357): "t x y z qx qy qz qw", fixed, 9 decimals;
+ * P = Ps[WINDOW_SIZE], R = Rs[WINDOW_SIZE] (row-major), quaternion as Eigen::Quaterniond(R) */
+int gf_tum_append(const char* path, double t, const double* P, const double* R);
+/* VINS_RESULT_PATH (output_path + "/vio.txt", parameters.cpp:347-352): creates the file empty; from then on every processed frame appends
+ * its line as pubOdometry does (estimator.cpp:679 -> visualization.cpp:287-357: only once solver_flag == NON_LINEAR or the IMU was found
+ * excited).  NULL or "" switches the output off. */
+int gf_estimator_set_result_path(gf_estimator* h, const char* vio_txt);
+/* binary PGM (P5) reader standing in for sensor_msgs::Image + cv_bridge (rosNodeTest.cpp:229-287): maxval <= 255 -> u8 (MONO8),
+ * else u16 in host byte order (MONO16, depth in mm).  pixels == NULL only queries the header. */
+int gf_pgm_read(const char* path, int* width, int* height, int* maxval, void* pixels, size_t cap_bytes);
+
 #ifdef __cplusplus
 }
 #endif

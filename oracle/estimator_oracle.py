@@ -420,6 +420,7 @@ class Estimator:
         self.initial_timestamp = 0.0
         self.wheelanomaly = self.visualstationary = self.wheelstationary = self.imustationary = self.systemstationary = False
         self.varstationary = self.preintegrationstationary = self.is_imu_excited = self.Bas_calibok = False
+        self.trajectory = []
         self.dP_imu, self.dP_wheel = np.zeros(3), np.zeros(3)
         self.openExEstimation = self.openExWheelEstimation = self.openIxEstimation = 0
         self.prior = None
@@ -435,14 +436,25 @@ class Estimator:
     def inputIMU(self, t, acc, gyr):  # EST:330-346
         self.accBuf.append((t, np.array(acc, float)))
         self.gyrBuf.append((t, np.array(gyr, float)))
+        if self.cfg["multiple_thread"] and self.featureBuf:   # the waiting processThread ("wait for imu ...", EST:551-560), made deterministic
+            self._drain()
 
     def inputWheel(self, t, vel, gyr):  # EST:347-360
         self.wheelVelBuf.append((t, np.array(vel, float)))
         self.wheelGyrBuf.append((t, np.array(gyr, float)))
+        if self.cfg["multiple_thread"] and self.featureBuf:   # "wait for wheel ...", EST:562-573
+            self._drain()
 
     def inputFeature(self, t, image):  # EST:362-375
         self.featureBuf.append((t, image))
-        self.processMeasurements()
+        if self.cfg["multiple_thread"]:
+            self._drain()
+        else:
+            self.processMeasurements()
+
+    def _drain(self):
+        while self.processMeasurements():
+            pass
 
     def inputImage(self, t, img, depth=None):  # EST:213-242
         ids, obs = self.tracker.track(t, img, depth)
@@ -468,16 +480,16 @@ class Estimator:
             bv.append(b[0])
         return av, bv
 
-    def processMeasurements(self):  # EST:526-709 (MULTIPLE_THREAD 0 control flow: one frame per call)
+    def processMeasurements(self):  # EST:526-709, one frame per call; True when a frame was taken
         if not self.featureBuf:
-            return
+            return False
         t, image = self.featureBuf[0]
         self.curTime = t + self.td
         self.curTime_wheel = self.curTime - self.td_wheel
         if self.cfg["use_imu"] and not (self.accBuf and t + self.td <= self.accBuf[-1][0]):
-            return
+            return False
         if self.cfg["use_wheel"] and not (self.wheelVelBuf and t + self.td - self.td_wheel <= self.wheelVelBuf[-1][0]):
-            return
+            return False
         accV, gyrV = self._interval(self.accBuf, self.gyrBuf, self.prevTime, self.curTime) if self.cfg["use_imu"] else ([], [])
         self.featureBuf.pop(0)
         velV, wgyrV = self._interval(self.wheelVelBuf, self.wheelGyrBuf, self.prevTime_wheel, self.curTime_wheel) if self.cfg["use_wheel"] else ([], [])
@@ -499,6 +511,10 @@ class Estimator:
             self.preintegrationstationary = np.linalg.norm(self.dP_imu) < 0.001
         self.processImage(image, t)
         self.prevTime, self.prevTime_wheel = self.curTime, self.curTime_wheel
+        if self.solver_flag == NON_LINEAR or self.is_imu_excited:   # pubOdometry, EST:679 -> visualization.cpp:287-357 (what vio.txt receives)
+            W = self.W
+            self.trajectory.append((t, np.array(self.Ps[W], float), np.array(self.Rs[W], float)))
+        return True
 
     def initFirstIMUPose(self, accV):  # EST:710-731
         self.initFirstPoseFlag = True

@@ -1,0 +1,62 @@
+"""tools/gf_replay: the reference's YAML configuration + recorded IMU / wheel / RGB / depth messages in, the reference's
+trajectory file (vio.txt, TUM format) out -- against the CPU oracle pipeline fed with the same messages in the same (time-stamp) order."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ground-fusion_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import synth_stream as SS  # noqa: E402
+import estimator_oracle as EO  # noqa: E402
+import oracle_py as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def quat_xyzw(R):
+    """Eigen::Quaterniond(R) for trace > 0 (small rotations of a ground vehicle around the start attitude R0 keep it there or the test says so)"""
+    t = np.trace(R)
+    assert t > 0
+    s = np.sqrt(t + 1.0)
+    w = 0.5 * s
+    s = 0.5 / s
+    return np.array([(R[2, 1] - R[1, 2]) * s, (R[0, 2] - R[2, 0]) * s, (R[1, 0] - R[0, 1]) * s, w])
+
+
+def test_replay_tool_writes_the_oracle_trajectory(tmp_path):
+    st = SS.Stream(1, t_still=1.5, t_move=2.0, v_max=0.4, yaw0=0.0, yaw_turn=-0.6, split_x=1.8, turn_delay=0.8)
+    d = str(tmp_path)
+    n = st.export(d)
+    exe = os.path.join(ROOT, "bin", "gf_replay")
+    assert os.path.exists(exe), "bin/gf_replay is missing: run `python __graft_entry__.py` (build)"
+    out = subprocess.run([exe, os.path.join(d, "config.yaml"), d, os.path.join(d, "vio.txt")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    assert "%d RGB-D pairs (0 / 0 unpaired" % n in out.stdout and "solver_flag 1" in out.stdout
+    got = np.loadtxt(os.path.join(d, "vio.txt"))
+    # the oracle pipeline, messages in the order ReplayNode::run delivers them
+    est = EO.Estimator(dict(tio=SS.TIO, rio=SS.RIO, multiple_thread=1), tracker=O.Tracker())
+    t_end = st.cam_t[n - 1] + 0.05
+    ev = [(float(t), 0, i) for i, t in enumerate(st.imu_t) if t <= t_end] + [(float(t), 1, i) for i, t in enumerate(st.wheel_t) if t <= t_end] + \
+         [(float(st.cam_t[k]), 2, k) for k in range(n)]
+    for t, kind, i in sorted(ev):
+        if kind == 0:
+            est.inputIMU(t, st.imu_acc[i], st.imu_gyr[i])
+        elif kind == 1:
+            est.inputWheel(t, st.wheel_vel[i], st.wheel_gyr[i])
+        else:
+            est.inputImage(t, *st.image(i))
+    ref = est.trajectory
+    assert len(ref) > 20 and got.shape == (len(ref), 8)
+    dp = dq = 0.0
+    for row, (t, P, R) in zip(got, ref):
+        assert abs(row[0] - t) < 1e-9                    # 9 decimals in the file
+        q = quat_xyzw(R)
+        dp = max(dp, float(np.abs(row[1:4] - P).max()))
+        dq = max(dq, float(min(np.abs(row[4:] - q).max(), np.abs(row[4:] + q).max())))
+    print("gf_replay vs oracle: %d poses, worst |dp| %.2e, |dq| %.2e" % (len(ref), dp, dq))
+    assert dp < 1e-6 + 5e-10 and dq < 1e-6 + 5e-10        # the 1e-6 bar plus the file's rounding to 9 decimals
+    assert np.linalg.norm(ref[-1][1]) > 0.2               # it moved

@@ -1,0 +1,45 @@
+// gf_replay — `rosrun vins vins_node <config.yaml>` + `rosbag play` without ROS:
+//   gf_replay <config.yaml> <dataset dir> [<vio.txt>]
+// reads the reference's own YAML configuration (parameters.cpp key names), replays the recorded IMU / wheel / RGB / depth messages of
+// <dataset dir> (layout in host/replay_node.h) through FeatureTracker::trackImage and Estimator::processImage on the GPU, and writes the
+// trajectory file the reference writes (output_path/vio.txt, TUM format) — to <vio.txt> when given, else to `output_path` of the config.
+#include <cstdio>
+#include <fstream>
+#include <string>
+
+#include "../ground-fusion_amd/host/replay_node.h"
+
+static std::string yaml_string(const std::string& file, const std::string& key) {   // top-level string / scalar of the config, "" if absent
+    std::ifstream in(file);
+    std::string line;
+    while (std::getline(in, line)) {
+        if (line.compare(0, key.size() + 1, key + ":") != 0) continue;
+        std::string v = line.substr(key.size() + 1);
+        const size_t h = v.find(" #");
+        if (h != std::string::npos) v = v.substr(0, h);
+        const size_t a = v.find_first_not_of(" \t\""), b = v.find_last_not_of(" \t\"\r");
+        return a == std::string::npos ? std::string() : v.substr(a, b - a + 1);
+    }
+    return std::string();
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) { fprintf(stderr, "usage: %s <config.yaml> <dataset dir> [<vio.txt>]\n", argv[0]); return 2; }
+    try {
+        gf::Estimator estimator;
+        estimator.readParameters(argv[1]);
+        estimator.setParameter();
+        const std::string out = argc > 3 ? argv[3] : yaml_string(argv[1], "output_path") + "/vio.txt";
+        estimator.setResultPath(out);
+        gf::ReplayNode<gf::Estimator> node(estimator);
+        const std::string wr = yaml_string(argv[1], "w_replace");
+        node.w_replace = wr.empty() ? 0 : atoi(wr.c_str());
+        node.run(argv[2]);
+        printf("gf_replay: %ld RGB-D pairs (%ld / %ld unpaired frames thrown), solver_flag %d, trajectory in %s\n", node.n_pairs, node.n_thrown0, node.n_thrown1,
+               (int)estimator.solver_flag, out.c_str());
+    } catch (const std::exception& e) {
+        fprintf(stderr, "gf_replay: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
