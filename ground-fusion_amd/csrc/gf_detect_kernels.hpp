@@ -140,6 +140,9 @@ __global__ void __launch_bounds__(256) nms_collect_kernel(const float* __restric
 // around the kept points, tested analytically with OpenCV's midpoint-circle row table (no rasterised mask).
 // Tile: 64x16 outputs per 256-thread block (4 pixels per thread).
 constexpr int kDT_W = 64, kDT_H = 16;
+constexpr int kRawQ = (kDT_W + 8) / 4;   // dwords per row of the raw patch: bytes bx-4 .. bx+67
+static_assert(kDT_W % 4 == 0 && (kDT_W + 2) % 2 == 0 && (kDT_H + 2) % 3 == 0, "work-item shapes of detect_fused_kernel");
+__device__ __forceinline__ int byte8(uint32_t lo, uint32_t hi, int k) { return k < 4 ? (int)((lo >> (8 * k)) & 0xff) : (int)((hi >> (8 * (k - 4))) & 0xff); }
 struct DetectArgs {
     const uint8_t* pyr; size_t pyr_seq_stride; LevelGeom g;
     const uint8_t* mask; size_t mask_seq_stride;            // optional explicit mask (non-zero = allowed)
@@ -152,32 +155,43 @@ struct DetectArgs {
 __global__ void __launch_bounds__(256) detect_fused_kernel(DetectArgs A, DiskTable T) {
     __shared__ float cxx[kDT_H + 4][kDT_W + 5], cxy[kDT_H + 4][kDT_W + 5], cyy[kDT_H + 4][kDT_W + 5];
     __shared__ float eg[kDT_H + 2][kDT_W + 3];
-    __shared__ int2 dsk[512];
-    __shared__ int n_dsk, n_cand, cand_base;
+    __shared__ uint32_t raw[kDT_H + 6][kRawQ];
+    __shared__ unsigned long long rowmask[kDT_H];
+    __shared__ short s_hw[kMaxRadius + 1];
+    __shared__ int n_cand, cand_base;
     __shared__ unsigned blk_max;
     __shared__ unsigned long long ckeys[kDT_W * kDT_H];
     const int b = blockIdx.z;
     if (A.want[b] <= 0) return;
     const LevelGeom g = A.g;
     const int bx = blockIdx.x * kDT_W, by = blockIdx.y * kDT_H, tid = threadIdx.x;
-    if (tid == 0) { n_dsk = 0; n_cand = 0; blk_max = 0; }
+    if (tid == 0) { n_cand = 0; blk_max = 0; }
+    if (tid < kDT_H) rowmask[tid] = 0ull;
+    if (!A.mask && tid <= T.radius) s_hw[tid] = T.hw[tid];
     __syncthreads();
-    if (!A.mask) {  // disks whose bounding box touches this tile
+    // setMask first: a tile without a single unmasked pixel contributes neither to the masked maximum nor a candidate, and with MAX_CNT tracks
+    // of radius MIN_DIST most of the image is masked -- such tiles stop here, before any arithmetic on the image.
+    // The filled circles (OpenCV's midpoint-circle row table) are rasterised into one 64-bit word per tile row: a kept point whose bounding
+    // box touches the tile ORs its span of every row it crosses.
+    if (!A.mask) {
         const int n = A.n_centers[b];
         for (int i = tid; i < n; i += 256) {
             const int2 c = A.centers[(size_t)b * A.cap + i];
-            if (c.x + T.radius >= bx && c.x - T.radius < bx + kDT_W && c.y + T.radius >= by && c.y - T.radius < by + kDT_H) {
-                const int k = atomicAdd(&n_dsk, 1);
-                if (k < 512) dsk[k] = c;
+            if (c.x + T.radius < bx || c.x - T.radius >= bx + kDT_W || c.y + T.radius < by || c.y - T.radius >= by + kDT_H) continue;
+            const int l0 = max(0, c.y - T.radius - by), l1 = min(kDT_H - 1, c.y + T.radius - by);
+            for (int ly = l0; ly <= l1; ly++) {
+                const int hw = s_hw[abs(by + ly - c.y)];
+                const int x0 = max(c.x - hw, bx) - bx, x1 = min(c.x + hw, bx + kDT_W - 1) - bx;
+                if (x0 > x1) continue;
+                const int len = x1 - x0 + 1;
+                const unsigned long long bits = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << x0;
+                atomicOr(&rowmask[ly], bits);
             }
         }
+        __syncthreads();
     }
-    // setMask first: a tile without a single unmasked pixel contributes neither to the masked maximum nor a candidate, and with MAX_CNT tracks
-    // of radius MIN_DIST most of the image is masked -- such tiles stop here, before any arithmetic on the image
     unsigned allow_bits = 0;
     {
-        __syncthreads();   // n_dsk / dsk complete
-        const int nd0 = min(n_dsk, 512);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int li = tid + q * 256;
@@ -186,52 +200,89 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(DetectArgs A, DiskTab
             if (x >= g.w || y >= g.h) continue;
             bool allowed;
             if (A.mask) allowed = A.mask[b * A.mask_seq_stride + (size_t)y * g.w + x] != 0;
-            else {
-                allowed = true;
-                for (int k = 0; k < nd0; k++) {
-                    const int dy = abs(y - dsk[k].y), dx = abs(x - dsk[k].x);
-                    if (dy <= T.radius && dx <= T.hw[dy]) { allowed = false; break; }
-                }
-            }
+            else allowed = !((rowmask[ly] >> lx) & 1ull);
             if (allowed) allow_bits |= 1u << q;
         }
         if (!__syncthreads_or(allow_bits != 0)) return;
     }
     const uint8_t* img = A.pyr + b * A.pyr_seq_stride + g.img_off;
     const float f1 = (float)(1.0 * (1.0 / (4.0 * 3.0 * 255.0))), f0 = (float)(2.0 * (1.0 / (4.0 * 3.0 * 255.0)));
-    for (int t = tid; t < (kDT_W + 4) * (kDT_H + 4); t += 256) {
-        const int ty = t / (kDT_W + 4), tx = t - ty * (kDT_W + 4);
-        const int x = reflect101(bx + tx - 2, g.w), y = reflect101(by + ty - 2, g.h);
-        const uint8_t* p = img + (size_t)y * g.stride + x;
-        const int a0 = p[-g.stride - 1], a1 = p[-g.stride], a2 = p[-g.stride + 1];
-        const int m0 = p[-1], m2 = p[1];
-        const int c0 = p[g.stride - 1], c1 = p[g.stride], c2 = p[g.stride + 1];
-        const float t0 = (float)(a2 - a0), t1 = (float)(m2 - m0), t2 = (float)(c2 - c0);
-        const float dx = (t0 + t2) * f1 + t1 * f0;
-        float rt = f1 * (float)a0; rt += f0 * (float)a1; rt += f1 * (float)a2;
-        float rb = f1 * (float)c0; rb += f0 * (float)c1; rb += f1 * (float)c2;
-        const float dy = rb - rt;
-        cxx[ty][tx] = dx * dx; cxy[ty][tx] = dx * dy; cyy[ty][tx] = dy * dy;
+    // stage 1: the image patch behind the tile, rows by-3 .. by+18, bytes bx-4 .. bx+67, as dwords.  The pyramid level carries a
+    // REFLECT_101 border of kPad pixels (pyr_level0_kernel), so rows / columns just outside the image are plain reads.
+    {
+        const bool al = !((g.img_off | g.stride | (int)(A.pyr_seq_stride & 3)) & 3);
+        for (int t = tid; t < (kDT_H + 6) * kRawQ; t += 256) {
+            const int ry = t / kRawQ, rq = t - ry * kRawQ;
+            const int y = by - 3 + ry, x = bx - 4 + 4 * rq;
+            uint32_t v = 0;
+            if (x + 3 < g.w + kPad) {      // y <= h + 17 and x >= -4 always lie inside the border
+                const uint8_t* p = img + (ptrdiff_t)y * g.stride + x;
+                if (al) v = *reinterpret_cast<const uint32_t*>(p);
+                else v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+            }
+            raw[ry][rq] = v;
+        }
     }
     __syncthreads();
-    // eig on the tile + 1 halo.  NOTE cov halo entries were evaluated at REFLECT_101 coordinates, which is what the
-    // box filter needs for in-image pixels; eig halo entries outside the image are never consulted below.
-    for (int t = tid; t < (kDT_W + 2) * (kDT_H + 2); t += 256) {
-        const int ty = t / (kDT_W + 2), tx = t - ty * (kDT_W + 2);
-        // the box window of an in-image pixel next to the border must see cov(reflect(x+-1)); the LDS entry at tile
-        // offset -1 relative to an image edge holds cov(reflect(-1)) = cov(1) only if that entry's own coordinate was
-        // reflected — it was (see above) — so plain neighbour reads are correct for in-image centres.
-        double sa = 0, sb = 0, sc = 0;
+    // stage 2: Sobel products of the in-image pixels of the tile + 2 halo; one item = four consecutive pixels of one row (six dword reads)
+    for (int t = tid; t < (kDT_H + 4) * ((kDT_W + 4) / 4); t += 256) {
+        const int ty = t / ((kDT_W + 4) / 4), gq = t - ty * ((kDT_W + 4) / 4);
+        const int y = by - 2 + ty;
+        if (y < 0 || y >= g.h) continue;
+        const uint32_t al_ = raw[ty][gq], ah_ = raw[ty][gq + 1], ml_ = raw[ty + 1][gq], mh_ = raw[ty + 1][gq + 1], cl_ = raw[ty + 2][gq], ch_ = raw[ty + 2][gq + 1];
 #pragma unroll
-        for (int dy = 0; dy < 3; dy++)
+        for (int k = 0; k < 4; k++) {
+            const int tx = 4 * gq + k, x = bx - 2 + tx;
+            if (x < 0 || x >= g.w) continue;
+            // pixel x sits at byte 4 gq + k + 2 of the raw row
+            const int a0 = byte8(al_, ah_, k + 1), a1 = byte8(al_, ah_, k + 2), a2 = byte8(al_, ah_, k + 3);
+            const int m0 = byte8(ml_, mh_, k + 1), m2 = byte8(ml_, mh_, k + 3);
+            const int c0 = byte8(cl_, ch_, k + 1), c1 = byte8(cl_, ch_, k + 2), c2 = byte8(cl_, ch_, k + 3);
+            const float t0 = (float)(a2 - a0), t1 = (float)(m2 - m0), t2 = (float)(c2 - c0);
+            const float dx = (t0 + t2) * f1 + t1 * f0;
+            float rt = f1 * (float)a0; rt += f0 * (float)a1; rt += f1 * (float)a2;
+            float rb = f1 * (float)c0; rb += f0 * (float)c1; rb += f1 * (float)c2;
+            const float dy = rb - rt;
+            cxx[ty][tx] = dx * dx; cxy[ty][tx] = dx * dy; cyy[ty][tx] = dy * dy;
+        }
+    }
+    // the box filter's own border (BORDER_REFLECT_101 on the product images): entries one or two pixels outside the image take the value
+    // of their mirror pixel, which lies in this tile.  Only tiles on the image border have such entries.
+    if (bx < 2 || by < 2 || bx + kDT_W + 2 > g.w || by + kDT_H + 2 > g.h) {
+        __syncthreads();
+        for (int t = tid; t < (kDT_W + 4) * (kDT_H + 4); t += 256) {
+            const int ty = t / (kDT_W + 4), tx = t - ty * (kDT_W + 4);
+            const int x = bx - 2 + tx, y = by - 2 + ty;
+            if ((x >= 0 && x < g.w && y >= 0 && y < g.h) || x < -2 || x > g.w + 1 || y < -2 || y > g.h + 1) continue;
+            const int sx = reflect101(x, g.w) - (bx - 2), sy = reflect101(y, g.h) - (by - 2);
+            if (sx < 0 || sx >= kDT_W + 4 || sy < 0 || sy >= kDT_H + 4) continue;   // images narrower than the reflection reach: entry is never consulted
+            cxx[ty][tx] = cxx[sy][sx]; cxy[ty][tx] = cxy[sy][sx]; cyy[ty][tx] = cyy[sy][sx];
+        }
+    }
+    __syncthreads();
+    // stage 3: 3x3 box sums and the smaller eigenvalue on the tile + 1 halo.  One item = 2 columns x 3 rows: row sums of three columns are
+    // shared between the two columns and between the rows.  Sums run in double as in cv::boxFilter (ColumnSum<double, float>); nine float
+    // products spanning < 2^52 add exactly, so the order of additions is free.  Halo entries outside the image are never consulted below.
+    for (int t = tid; t < ((kDT_W + 2) / 2) * ((kDT_H + 2) / 3); t += 256) {
+        const int sg = t / ((kDT_W + 2) / 2), tx = 2 * (t - sg * ((kDT_W + 2) / 2)), ty0 = 3 * sg;
+        double ha[5][2], hb[5][2], hc[5][2];
 #pragma unroll
-            for (int dx = 0; dx < 3; dx++) {
-                sa += (double)cxx[ty + dy][tx + dx];
-                sb += (double)cxy[ty + dy][tx + dx];
-                sc += (double)cyy[ty + dy][tx + dx];
+        for (int rr = 0; rr < 5; rr++) {
+            const float* pa = &cxx[ty0 + rr][tx]; const float* pb = &cxy[ty0 + rr][tx]; const float* pc = &cyy[ty0 + rr][tx];
+            const double a1 = (double)pa[1] + (double)pa[2], b1 = (double)pb[1] + (double)pb[2], c1 = (double)pc[1] + (double)pc[2];
+            ha[rr][0] = (double)pa[0] + a1; ha[rr][1] = a1 + (double)pa[3];
+            hb[rr][0] = (double)pb[0] + b1; hb[rr][1] = b1 + (double)pb[3];
+            hc[rr][0] = (double)pc[0] + c1; hc[rr][1] = c1 + (double)pc[3];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++) {
+                const double sa = ha[rr][cc] + ha[rr + 1][cc] + ha[rr + 2][cc], sb = hb[rr][cc] + hb[rr + 1][cc] + hb[rr + 2][cc],
+                             sc = hc[rr][cc] + hc[rr + 1][cc] + hc[rr + 2][cc];
+                const float a = (float)sa * 0.5f, bb = (float)sb, c = (float)sc * 0.5f;
+                eg[ty0 + rr][tx + cc] = (a + c) - sqrtf((a - c) * (a - c) + bb * bb);
             }
-        const float a = (float)sa * 0.5f, bb = (float)sb, c = (float)sc * 0.5f;
-        eg[ty][tx] = (a + c) - sqrtf((a - c) * (a - c) + bb * bb);
     }
     __syncthreads();
     unsigned best = 0;
