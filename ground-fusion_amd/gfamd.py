@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libgroundfusion_hip.so")
+LIB_PATH = os.environ.get("GF_LIB_PATH") or os.path.join(HERE, "lib", "libgroundfusion_hip.so")   # override: profiling builds of the same sources
 _LIB = None
 
 
