@@ -69,7 +69,7 @@ def make_windows(gfamd, batch, seed0, features):
     return est, w1
 
 
-def cpu_baseline(frames_host, dt, wins, threads, ba_iters):
+def cpu_baseline(frames_host, dt, wins, threads, ba_iters, repeat=4):
     """CPU oracle (kind 'port') on a bounded sample of the same workload, `threads` sequences in parallel, each sequence
     single-threaded like the reference (Ceres num_threads = 1, estimator.cpp:3306).  Returns per-unit rates."""
     import threading
@@ -83,17 +83,18 @@ def cpu_baseline(frames_host, dt, wins, threads, ba_iters):
     n_ba = [0] * nseq
 
     def run(b):
-        tr = oracle_py.Tracker(oracle_py.default_cfg())
-        prev = set()
         t0 = time.perf_counter()
-        for k in range(n_frames):
-            ids, _ = tr.track(dt * k, frames_host[k, b], depth)
-            if k > 0:
-                counts[b] += len(prev & set(ids.tolist()))
-            prev = set(ids.tolist())
+        for _ in range(repeat):          # the same frames again through a fresh tracker: ~10 s of CPU work over all threads
+            tr = oracle_py.Tracker(oracle_py.default_cfg())
+            prev = set()
+            for k in range(n_frames):
+                ids, _ = tr.track(dt * k, frames_host[k, b], depth)
+                if k > 0:
+                    counts[b] += len(prev & set(ids.tolist()))
+                prev = set(ids.tolist())
         t_track[b] = time.perf_counter() - t0
         t0 = time.perf_counter()
-        for _ in range(max(1, n_frames // 4)):
+        for _ in range(repeat * max(1, n_frames // 4)):
             w = wins[b].copy()
             oracle_py.ba_solve(w, ba_iters)
             oracle_py.ba_marginalize(w, 0)
@@ -109,10 +110,10 @@ def cpu_baseline(frames_host, dt, wins, threads, ba_iters):
             th.join()
     el = time.perf_counter() - t0
     # time for one full step of one sequence on one core = tracker frame + solve; `threads` cores run in parallel
-    per_frame = sum(t_track) / (nseq * (n_frames - 1)) + 0.0
+    per_frame = sum(t_track) / (nseq * repeat * (n_frames - 1)) + 0.0
     per_solve = sum(t_ba) / sum(n_ba)
     steps_per_s = threads / (per_frame + per_solve)
-    return {"steps_per_s": steps_per_s, "tracked_features_per_s": threads * (sum(counts) / (nseq * (n_frames - 1))) / per_frame,
+    return {"steps_per_s": steps_per_s, "tracked_features_per_s": threads * (sum(counts) / (nseq * repeat * (n_frames - 1))) / per_frame, "repeat": repeat,
             "solves_only_per_s": threads / per_solve, "ms_track_frame_1core": 1e3 * per_frame, "ms_solve_marg_1core": 1e3 * per_solve, "wall_s": el}
 
 
@@ -252,8 +253,8 @@ def main():
             cb = cpu_baseline(fh, dt, wins[:nseq], cores, args.ba_iters)
             res["cpu_baseline"] = {"value": cb["steps_per_s"] if not args.no_backend else cb["tracked_features_per_s"],
                                    "unit": unit, "cores": cores, "kind": "port",
-                                   "sample": "%d sequences x %d frames (tracker) and %d solve+marginalise per sequence through the CPU oracle, %d threads, one sequence per thread; %.1f s wall"
-                                             % (nseq, fh.shape[0], max(1, fh.shape[0] // 4), cores, cb["wall_s"]),
+                                   "sample": "%d sequences x %d x %d frames (tracker) and %d solve+marginalise per sequence through the CPU oracle, %d threads, one sequence per thread; %.1f s wall, ~%.0f s of CPU work"
+                                             % (nseq, cb["repeat"], fh.shape[0], cb["repeat"] * max(1, fh.shape[0] // 4), cores, cb["wall_s"], cb["wall_s"] * cores),
                                    "detail": cb}
         print(json.dumps(res))
     trk.close()
