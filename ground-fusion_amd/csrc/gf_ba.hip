@@ -69,6 +69,7 @@ struct gf_ba {
     Buf<long long> stamps;
     std::vector<std::vector<int>> keep_ids[2];   // per window: kept block ids (before the address shift), in column order
     size_t marg_lds = 0; int marg_ncap = 0, last_marg_mode = -1;
+    size_t vwin_lds = 0;   // > 0: the window-level visual sweep (ba_linearize_visual_win) fits LDS; its dynamic size
     long long mfma_per_lin = 0;   // v_mfma_f64_16x16x4 instructions of one visual linearisation of the resident batch
     std::vector<Buf<double>*> dbl() { return {&xs0, &xs, &vis_data, &imu_data, &wh_data, &pri_J, &pri_r, &pri_x0, &imu_sqrt, &wh_sqrt, &pri_A, &pri_b, &pri_c, &pri_H0, &H, &g, &cost, &efac,
                                               &scale, &diag, &grad, &gn, &step, &u, &Et, &Es, &ete, &etb, &rhs, &yv, &Sg, &Mg, &gn_data, &gn_misc}; }
@@ -349,6 +350,7 @@ int launch_linearize(gf_ba* h, int which, int which_state, int cost_only, int on
     HIPCHK(hipEventRecord(h->ev_fork, h->stream));   // everything enqueued so far (state, zeroed buffers) precedes the forked work
     if (timed) HIPCHK(hipEventRecord(h->ev[2], h->stream));
     if (h->any_ex) ba_linearize_visual<true><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(w, which, which_state, cost_only, only_valid);
+    else if (h->vwin_lds) ba_linearize_visual_win<<<dim3(d.B), 64 * kVW, h->vwin_lds, h->stream>>>(w, which, which_state, cost_only, only_valid);
     else ba_linearize_visual<false><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(w, which, which_state, cost_only, only_valid);
     if (timed) HIPCHK(hipEventRecord(h->ev[3], h->stream));
     if (!cost_only) ba_build_et<<<dim3(d.F, d.B), 64, 0, h->stream>>>(w, h->sbufs(), which, 0);
@@ -463,6 +465,11 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     if (h->big_step) { h->sg_stride = (h->step_lds / sizeof(double) + 15) & ~(size_t)15; A_(h->Sg.alloc(B * h->sg_stride, false)); }
     if (h->big_marg) { h->mg_stride = (size_t)2 * h->marg_ncap * h->marg_ncap + 1024; A_(h->Mg.alloc(B * h->mg_stride, false)); }
     if (!h->big_step) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_step<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->step_lds));
+    {   // window-level visual sweep: staging areas of kVW wavefronts (static) + the compact visual system (dynamic)
+        const size_t nc = 6 * (size_t)d.NP + 2, dyn = nc * (nc + 1) / 2 * sizeof(double), stat = (size_t)kVW * kVHalf * sizeof(double) + kVW * 64 * sizeof(int) + 256;
+        h->vwin_lds = (dyn + stat <= 158 * 1024 && !getenv("GF_BA_CHUNKED_VISUAL")) ? dyn : 0;
+        if (h->vwin_lds) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_visual_win), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->vwin_lds));
+    }
     if (!h->big_marg) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_marg_finish<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds));
     H_(hipStreamSynchronize(h->stream));
 #undef A_

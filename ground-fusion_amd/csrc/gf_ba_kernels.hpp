@@ -168,32 +168,14 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// grid (NVP/64, B), 64 threads.  EX: the camera extrinsic block is free (second 16-column tile).
-// which: buffer (0/1) of H/g/cost/efac to fill; state read from xs[which_state].
+// One visual factor per lane: residual, Jacobians, Huber correction, zeroed columns of constant blocks, and the products the Schur
+// complement needs for a free inverse depth (stored to efac).  k < 0: padding lane (all zero).  Returns the factor's cost.
 template <bool EX>
-__global__ void __launch_bounds__(64) ba_linearize_visual(Win w, int which, int which_state, int cost_only, int only_cand_valid) {
-    constexpr int COLS = EX ? 32 : 16;
-    constexpr int LSTR = 2 * COLS + 1;  // odd stride: de-phases the per-lane writes
-    __shared__ double Jbuf[64 * LSTR];
-    __shared__ int s_pair[64];
-    const Dims d = w.d;
-    const int b = blockIdx.y, lane = threadIdx.x;
-    const SolverState& st = w.st[b];
-    if (st.done && only_cand_valid != 2) return;   // only_cand_valid == 2: marginalisation pass (runs on finished windows)
-    if (only_cand_valid == 1 && !st.cand_valid) return;
-    const int n_order = w.norder[b];
-    const int e0 = blockIdx.x * 64;
-    if (e0 >= n_order) return;
-    if (which < 0) which = 1 - st.cur;            // the candidate's buffers
-    if (which_state == -2) which_state = st.cur; else if (which_state < 0) which_state = 1 - st.cur;
-    const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
-    const int* colf = w.colf + (size_t)b * d.NFB;
-    const int entry = e0 + lane;
-    const int k = entry < n_order ? w.order[(size_t)b * d.NVP + entry] : -1;
+__device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int b, int which, int k, int cost_only, const double* xs, const int* colf,
+                                                VisEval& ev, int& fi, int& fj) {
     double cost = 0.0;
-    int fi = 0, fj = 0, feat = 0;
-    VisEval ev;
+    int feat = 0;
+    fi = 0; fj = 0;
 #pragma unroll
     for (int r = 0; r < 2; r++) { for (int c = 0; c < 22; c++) ev.row[r][c] = 0.0; ev.jd[r] = 0.0; }
     if (k >= 0) {
@@ -235,6 +217,35 @@ __global__ void __launch_bounds__(64) ba_linearize_visual(Win w, int which, int 
             }
         }
     }
+    return cost;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// grid (NVP/64, B), 64 threads.  EX: the camera extrinsic block is free (second 16-column tile).
+// which: buffer (0/1) of H/g/cost/efac to fill; state read from xs[which_state].
+template <bool EX>
+__global__ void __launch_bounds__(64) ba_linearize_visual(Win w, int which, int which_state, int cost_only, int only_cand_valid) {
+    constexpr int COLS = EX ? 32 : 16;
+    constexpr int LSTR = 2 * COLS + 1;  // odd stride: de-phases the per-lane writes
+    __shared__ double Jbuf[64 * LSTR];
+    __shared__ int s_pair[64];
+    const Dims d = w.d;
+    const int b = blockIdx.y, lane = threadIdx.x;
+    const SolverState& st = w.st[b];
+    if (st.done && only_cand_valid != 2) return;   // only_cand_valid == 2: marginalisation pass (runs on finished windows)
+    if (only_cand_valid == 1 && !st.cand_valid) return;
+    const int n_order = w.norder[b];
+    const int e0 = blockIdx.x * 64;
+    if (e0 >= n_order) return;
+    if (which < 0) which = 1 - st.cur;            // the candidate's buffers
+    if (which_state == -2) which_state = st.cur; else if (which_state < 0) which_state = 1 - st.cur;
+    const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
+    const int* colf = w.colf + (size_t)b * d.NFB;
+    const int entry = e0 + lane;
+    const int k = entry < n_order ? w.order[(size_t)b * d.NVP + entry] : -1;
+    int fi, fj;
+    VisEval ev;
+    double cost = vis_lane_eval<EX>(w, d, b, which, k, cost_only, xs, colf, ev, fi, fj);
     cost = wave_sum_f64(cost);
     if (lane == 0) atomicAdd(w.cost + (size_t)which * d.B + b, cost);
     if (cost_only) return;
@@ -746,6 +757,108 @@ __device__ __forceinline__ int tri_row(int t) {  // largest i with i(i+1)/2 <= t
     while ((i + 1) * (i + 2) / 2 <= t) i++;
     return i;
 }
+// ---------------------------------------------------------------------------------------------------------------
+// Window-level visual sweep (fixed camera extrinsic): one block of kVW wavefronts per window instead of one 64-thread block per 64
+// factors.  Every wavefront walks its share of the 64-factor chunks exactly like ba_linearize_visual, but the per-frame-pair MFMA tiles
+// are added into an LDS copy of the window's visual normal equations (compact columns 6 p + q of pose p, then td, then the right-hand
+// side; packed lower triangle), and only that copy -- one value per touched entry -- goes to H / g with global atomics at the end.
+// The chunked kernel issues ~100 global atomics per pair per chunk, most of them on the same few diagonal blocks; its run time is that
+// atomic traffic (103 us against 50 us for 256 windows of 1500 factors).  Dynamic LDS: (6 NP + 2)(6 NP + 3)/2 doubles.
+constexpr int kVW = 12;               // wavefronts per block (three per SIMD at the kernel's ~150 VGPRs)
+constexpr int kVHalf = 32 * 33;       // staging area of one wavefront: 32 factors x (2 rows x 16 columns + 1) doubles
+__global__ void __launch_bounds__(64 * kVW) ba_linearize_visual_win(Win w, int which, int which_state, int cost_only, int only_cand_valid) {
+    constexpr int LSTR = 33;
+    extern __shared__ __attribute__((aligned(16))) double v_acc[];   // packed lower triangle of the compact system
+    __shared__ double Jst[kVW * kVHalf];
+    __shared__ int s_pr[kVW][64];
+    __shared__ double s_cost[kVW];
+    const Dims d = w.d;
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const SolverState& st = w.st[b];
+    if (st.done && only_cand_valid != 2) return;
+    if (only_cand_valid == 1 && !st.cand_valid) return;
+    const int n_order = w.norder[b];
+    if (n_order <= 0) return;
+    if (which < 0) which = 1 - st.cur;
+    if (which_state == -2) which_state = st.cur; else if (which_state < 0) which_state = 1 - st.cur;
+    const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
+    const int* colf = w.colf + (size_t)b * d.NFB;
+    const int TD = 6 * d.NP, RHS = 6 * d.NP + 1, NT = (RHS + 1) * (RHS + 2) / 2;
+    if (!cost_only) for (int i = tid; i < NT; i += 64 * kVW) v_acc[i] = 0.0;
+    __syncthreads();
+    double* Jbuf = Jst + wave * kVHalf;
+    int* s_pair = s_pr[wave];
+    double cost = 0.0;
+    const int nchunks = (n_order + 63) / 64;
+    for (int ch = wave; ch < nchunks; ch += kVW) {
+        const int entry = ch * 64 + lane;
+        const int k = entry < n_order ? w.order[(size_t)b * d.NVP + entry] : -1;
+        int fi, fj;
+        VisEval ev;
+        cost += vis_lane_eval<false>(w, d, b, which, k, cost_only, xs, colf, ev, fi, fj);
+        if (cost_only) continue;
+        s_pair[lane] = k >= 0 ? fi * 64 + fj : -1;
+        d4 acc = {0, 0, 0, 0};
+        int cur_pair = -1;
+        auto flush = [&](int pair) {
+            if (pair < 0) return;
+            const int pi = pair >> 6, pj = pair & 63;   // pi < pj: a feature is observed in later frames than its start frame
+            auto cm = [&](int t) -> int { return t < 6 ? 6 * pi + t : t < 12 ? 6 * pj + t - 6 : t == 12 ? TD : t == 13 ? RHS : -1; };
+            const int cb = cm(lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int ca = cm((lane >> 4) + 4 * r);
+                const double v = acc[r];
+                if (ca >= 0 && cb >= 0 && cb <= ca && v != 0.0) atomicAdd(&v_acc[ca * (ca + 1) / 2 + cb], v);
+            }
+            acc = d4{0, 0, 0, 0};
+        };
+        // the 64 block rows go through the staging area in two halves of 32 factors (lanes 0-31, then 32-63)
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();   // the previous half's reads are done
+            if ((lane >> 5) == half) {
+                const int l = lane & 31;
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int c = 0; c < 16; c++) Jbuf[l * LSTR + r * 16 + c] = (c < 14) ? ev.row[r][c] : 0.0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+            for (int m = 0; m < 16; m++) {
+                const int pair = s_pair[32 * half + 2 * m];   // pairs are padded to even length: entries 2m and 2m+1 share the pair (or are padding)
+                if (pair < 0) continue;
+                if (pair != cur_pair) { flush(cur_pair); cur_pair = pair; }
+                const int e = 2 * m + (lane >> 5), r = (lane >> 4) & 1, c = lane & 15;
+                const double a0 = Jbuf[e * LSTR + r * 16 + c];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc, 0, 0, 0);
+            }
+        }
+        flush(cur_pair);
+    }
+    cost = wave_sum_f64(cost);
+    if (lane == 0) s_cost[wave] = cost;
+    __syncthreads();
+    if (tid == 0) { double c = 0; for (int q = 0; q < kVW; q++) c += s_cost[q]; atomicAdd(w.cost + (size_t)which * d.B + b, c); }
+    if (cost_only) return;
+    // ---- the window's visual normal equations -> H, g
+    double* H = w.H + ((size_t)which * d.B + b) * d.RP * d.RP;
+    double* g = w.g + ((size_t)which * d.B + b) * d.RP;
+    const int tdc = colf[fb_td(d.NP)];
+    for (int i = tid; i < NT; i += 64 * kVW) {
+        const double v = v_acc[i];
+        if (v == 0.0) continue;
+        const int a = tri_row(i), c2 = i - a * (a + 1) / 2;
+        if (c2 >= RHS) continue;                                  // r^T r
+        const int cb0 = c2 == TD ? tdc : colf[fb_pose(c2 / 6)], cb = cb0 < 0 ? -1 : c2 == TD ? cb0 : cb0 + c2 % 6;
+        if (cb < 0) continue;
+        if (a == RHS) { atomicAdd(g + cb, v); continue; }
+        const int ca0 = a == TD ? tdc : colf[fb_pose(a / 6)], ca = ca0 < 0 ? -1 : a == TD ? ca0 : ca0 + a % 6;
+        if (ca < 0) continue;
+        atomicAdd(H + (size_t)max(ca, cb) * d.RP + min(ca, cb), v);
+    }
+}
+
 // PoseLocalParameterization::Plus (pose_local_parameterization.cpp:12-28)
 __device__ __forceinline__ void pose_plus(const double* x, const double* dl, double* out) {
     out[0] = x[0] + dl[0]; out[1] = x[1] + dl[1]; out[2] = x[2] + dl[2];

@@ -10,7 +10,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--parse":
                 acc[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
         v = sorted(v)
-        print("%-40s grid %-8s wg %-4s calls %4d  median %8.1f us  total %8.1f ms" % (k[0], k[1], k[2], len(v), v[len(v) // 2] / 1e3, sum(v) / 1e6))
+        print("%-40s grid %-8s wg %-4s calls %4d  median %8.1f us  p90 %8.1f us  max %8.1f us  total %8.1f ms" % (k[0], k[1], k[2], len(v), v[len(v) // 2] / 1e3, v[len(v) * 9 // 10] / 1e3, v[-1] / 1e3, sum(v) / 1e6))
     sys.exit(0)
 sys.path.insert(0, 'ground-fusion_amd')
 import numpy as np, gfamd, synth_window as SW
