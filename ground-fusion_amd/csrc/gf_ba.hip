@@ -70,6 +70,7 @@ struct gf_ba {
     std::vector<std::vector<int>> keep_ids[2];   // per window: kept block ids (before the address shift), in column order
     size_t marg_lds = 0; int marg_ncap = 0, last_marg_mode = -1;
     size_t vwin_lds = 0;   // > 0: the window-level visual sweep (ba_linearize_visual_win) fits LDS; its dynamic size
+    size_t mwin_lds = 0;   // > 0: the window-level IMU / wheel sweep (ba_linearize_misc_win) fits LDS; its dynamic size
     long long mfma_per_lin = 0;   // v_mfma_f64_16x16x4 instructions of one visual linearisation of the resident batch
     std::vector<Buf<double>*> dbl() { return {&xs0, &xs, &vis_data, &imu_data, &wh_data, &pri_J, &pri_r, &pri_x0, &imu_sqrt, &wh_sqrt, &pri_A, &pri_b, &pri_c, &pri_H0, &H, &g, &cost, &efac,
                                               &scale, &diag, &grad, &gn, &step, &u, &Et, &Es, &ete, &etb, &rhs, &yv, &Sg, &Mg, &gn_data, &gn_misc}; }
@@ -356,7 +357,8 @@ int launch_linearize(gf_ba* h, int which, int which_state, int cost_only, int on
     if (!cost_only) ba_build_et<<<dim3(d.F, d.B), 64, 0, h->stream>>>(w, h->sbufs(), which, 0);
     // IMU / wheel / prior factors only share the atomically accumulated H, g, cost with the visual sweep: second stream
     HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-    ba_linearize_misc<false><<<dim3(2 * d.W, d.B), 64, 0, h->stream2>>>(w, which, which_state, cost_only, only_valid, 0, 0);
+    if (h->mwin_lds) ba_linearize_misc_win<<<dim3(d.B), 64 * kMW, h->mwin_lds, h->stream2>>>(w, which, which_state, cost_only, only_valid);
+    else ba_linearize_misc<false><<<dim3(2 * d.W, d.B), 64, 0, h->stream2>>>(w, which, which_state, cost_only, only_valid, 0, 0);
     ba_linearize_misc<true><<<dim3(1, d.B), 256, 0, h->stream2>>>(w, which, which_state, cost_only, only_valid, 0, 2 * d.W);
     if (d.GO) ba_linearize_gnss<<<dim3((d.NG + 5 * d.W + 1 + 63) / 64, d.B), 64, 0, h->stream2>>>(w, which, which_state, cost_only, only_valid, 0);
     HIPCHK(hipEventRecord(h->ev_join, h->stream2));
@@ -469,6 +471,9 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
         const size_t nc = 6 * (size_t)d.NP + 2, dyn = nc * (nc + 1) / 2 * sizeof(double), stat = (size_t)kVW * kVHalf * sizeof(double) + kVW * 64 * sizeof(int) + 256;
         h->vwin_lds = (dyn + stat <= 158 * 1024 && !getenv("GF_BA_CHUNKED_VISUAL")) ? dyn : 0;
         if (h->vwin_lds) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_visual_win), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->vwin_lds));
+        const size_t mdyn = misc_win_lds_doubles(d.W) * sizeof(double);
+        h->mwin_lds = (mdyn + 512 <= 158 * 1024 && !getenv("GF_BA_CHUNKED_MISC")) ? mdyn : 0;
+        if (h->mwin_lds) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_misc_win), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mwin_lds));
     }
     if (!h->big_marg) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_marg_finish<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds));
     H_(hipStreamSynchronize(h->stream));

@@ -424,8 +424,10 @@ __global__ void __launch_bounds__(256) ba_setup(Win w) {
 
 // IMUFactor::Evaluate (imu_factor.h:28-191) + IntegrationBase::evaluate (integration_base.h:169-195): raw (un-whitened) residual and Jacobian.
 // Jraw: 15 x 30 row-major in LDS, columns [pose_i 6 | speedbias_i 9 | pose_j 6 | speedbias_j 9].  Executed redundantly by every lane; lane 0 stores.
+// `writer`: this lane stores the raw residual (15) and the Jacobian blocks (15 x 30, row-major, into a zeroed Jraw); the arithmetic runs on
+// every lane.  The caller zeroes Jraw before and fences after.
 __device__ inline void imu_raw(const double* Pi_, const double* SBi, const double* Pj_, const double* SBj, const double* dat, const double* G_, double* rraw,
-                               double* Jraw, bool want_jac, int lane) {
+                               double* Jraw, bool want_jac, bool writer) {
     const V3 Pi = p_of(Pi_), Pj = p_of(Pj_), Vi = v3(SBi[0], SBi[1], SBi[2]), Bai = v3(SBi[3], SBi[4], SBi[5]), Bgi = v3(SBi[6], SBi[7], SBi[8]);
     const V3 Vj = v3(SBj[0], SBj[1], SBj[2]), Baj = v3(SBj[3], SBj[4], SBj[5]), Bgj = v3(SBj[6], SBj[7], SBj[8]);
     const Q4 Qi = q_of(Pi_), Qj = q_of(Pj_);
@@ -444,14 +446,12 @@ __device__ inline void imu_raw(const double* Pi_, const double* SBi, const doubl
     const V3 t_p = qrot(Qi_inv, G * (0.5 * sum_dt * sum_dt) + Pj - Pi - Vi * sum_dt);
     const V3 t_v = qrot(Qi_inv, G * sum_dt + Vj - Vi);
     const V3 rp = t_p - cdp, rq = qvec(qmul(qinverse(cdq), qmul(Qi_inv, Qj))) * 2.0, rv = t_v - cdv, rba = Baj - Bai, rbg = Bgj - Bgi;
-    if (lane == 0) {
+    if (writer) {
         rraw[0] = rp.x; rraw[1] = rp.y; rraw[2] = rp.z; rraw[3] = rq.x; rraw[4] = rq.y; rraw[5] = rq.z; rraw[6] = rv.x; rraw[7] = rv.y; rraw[8] = rv.z;
         rraw[9] = rba.x; rraw[10] = rba.y; rraw[11] = rba.z; rraw[12] = rbg.x; rraw[13] = rbg.y; rraw[14] = rbg.z;
     }
     if (!want_jac) return;
-    for (int i = lane; i < 450; i += 64) Jraw[i] = 0.0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
+    if (writer) {
         auto put = [&](int r0, int c0, const M3& m) { for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Jraw[(r0 + r) * 30 + c0 + c] = m.m[3 * r + c]; };
         const M3 Rit = qmat(Qi_inv);
         // pose_i (cols 0..5)
@@ -473,13 +473,13 @@ __device__ inline void imu_raw(const double* Pi_, const double* SBi, const doubl
         put(6, 21, Rit);
         put(9, 24, m3_identity()); put(12, 27, m3_identity());
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
 }
 
 // WheelFactor::Evaluate (wheel_factor.h:28-247) + WheelIntegrationBase::evaluate (wheel_integration_base.h:180-219).
 // Jraw: 6 x 22, columns [pose_i 6 | pose_j 6 | T_io 6 | sx | sy | sw | td_wheel].
+// same conventions as imu_raw: residual (6), Jacobian 6 x 22 into a zeroed Jraw
 __device__ inline void wheel_raw(const double* Pi_, const double* Pj_, const double* Ex, double sx, double sy, double sw, double td, const double* dat, double* rraw,
-                                 double* Jraw, bool want_jac, int lane) {
+                                 double* Jraw, bool want_jac, bool writer) {
     const V3 Pi = p_of(Pi_), Pj = p_of(Pj_), tio = p_of(Ex);
     const Q4 Qi = q_of(Pi_), Qj = q_of(Pj_), qio = q_of(Ex);
     const M3 sv = m3_diag(sx, sy, 1);
@@ -501,11 +501,9 @@ __device__ inline void wheel_raw(const double* Pi_, const double* Pj_, const dou
     const V3 rp = Rio_t * (Rj * tio + Pj - Ri * tio - Pi) - dp_time;
     const Q4 Qio = qmul(Qi, qio);
     const V3 rr = so3_log(qmul(qmul(qmul(qinverse(dq_time), qinverse(Qio)), Qj), qio));
-    if (lane == 0) { rraw[0] = rp.x; rraw[1] = rp.y; rraw[2] = rp.z; rraw[3] = rr.x; rraw[4] = rr.y; rraw[5] = rr.z; }
+    if (writer) { rraw[0] = rp.x; rraw[1] = rp.y; rraw[2] = rp.z; rraw[3] = rr.x; rraw[4] = rr.y; rraw[5] = rr.z; }
     if (!want_jac) return;
-    for (int i = lane; i < 132; i += 64) Jraw[i] = 0.0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
+    if (writer) {
         auto put = [&](int r0, int c0, const M3& m) { for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Jraw[(r0 + r) * 22 + c0 + c] = m.m[3 * r + c]; };
         auto putv = [&](int r0, int c0, V3 v) { Jraw[r0 * 22 + c0] = v.x; Jraw[(r0 + 1) * 22 + c0] = v.y; Jraw[(r0 + 2) * 22 + c0] = v.z; };
         const M3 Jr_inv = rightJacobianInvSO3(rr);
@@ -533,7 +531,6 @@ __device__ inline void wheel_raw(const double* Pi_, const double* Pj_, const dou
         putv(0, 21, -(Efw * (sv * lin_vel - Rcq * (sv * vel_1) + skew(Jrtd * lin_gyr * sw) * (fcv + cdp - Rcq * bcv))));
         putv(3, 21, -(Jr_inv * Em * (Ebw * Rcq_inv * (Jrtd * lin_gyr) * sw - Jr_mtd * gyr_1 * sw)));
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
 }
 
 // dx of the marginalisation prior for one kept block (marginalization_factor.cpp:348-372)
@@ -567,6 +564,67 @@ __host__ __device__ inline int lsize_kind(int kind) { return (kind == 0 || kind 
 __host__ __device__ inline int gsize_kind(int kind) { return (kind == 0 || kind == 2 || kind == 3) ? 7 : kind == 1 ? 9 : kind == 13 ? 3 : 1; }
 
 // grid (2W + 1, B), 256 threads: block t < W evaluates IMU factor t (wavefront 0), W <= t < 2W wheel factor t - W, block 2W adds the prior.
+// reduced-system column of every local column of an IMU factor (pose_i 6, speed-bias_i 9, pose_j 6, speed-bias_j 9) or a wheel factor
+// (pose_i 6, pose_j 6, wheel extrinsic 6, sx, sy, sw, td_wheel); -1: constant block
+__device__ __forceinline__ void misc_cols(bool is_imu, int i, const int* colf, int NP, int* scol, int lane) {
+    const int j = i + 1;
+    if (is_imu) {
+        if (lane < 30) {
+            const int blk = lane < 6 ? fb_pose(i) : lane < 15 ? fb_sb(i) : lane < 21 ? fb_pose(j) : fb_sb(j);
+            const int o = lane < 6 ? lane : lane < 15 ? lane - 6 : lane < 21 ? lane - 15 : lane - 21;
+            scol[lane] = colf[blk] >= 0 ? colf[blk] + o : -1;
+        }
+    } else if (lane < 22) {
+        const int blk = lane < 6 ? fb_pose(i) : lane < 12 ? fb_pose(j) : lane < 18 ? fb_exw(NP) : lane < 21 ? fb_sx(NP) + (lane - 18) : fb_tdw(NP);
+        const int o = lane < 6 ? lane : lane < 12 ? lane - 6 : lane < 18 ? lane - 12 : 0;
+        scol[lane] = colf[blk] >= 0 ? colf[blk] + o : -1;
+    }
+}
+
+// One wavefront: whiten a factor's raw residual / Jacobian with its upper-triangular square-root information S (imu_factor.h:73,
+// wheel_factor.h:85: residual = S r, J = S J), add J^T J and J^T r to H / g (lower triangle, global atomics), return the factor's cost.
+// sJ: NRES x NCOL raw Jacobian (LDS), rraw: raw residual (LDS); sS, sSJ, sr: this wavefront's scratch; scol from misc_cols.
+template <int NRES, int NCOL>
+__device__ __forceinline__ double misc_whiten_accumulate(const double* Sg, const double* rraw, const double* sJ, double* sS, double* sSJ, double* sr, const int* scol,
+                                                         double* H, double* g, int RP, int cost_only, int lane) {
+    for (int q = lane; q < NRES * NRES; q += 64) sS[q] = Sg[q];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    if (lane < NRES) {
+        double sv = 0;
+#pragma unroll 3
+        for (int k2 = 0; k2 < NRES; k2++) sv += sS[lane * NRES + k2] * rraw[k2];
+        sr[lane] = sv;   // whitened residual
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    double c = lane < NRES ? 0.5 * sr[lane] * sr[lane] : 0.0;
+    c = wave_sum_f64(c);
+    if (cost_only) return c;
+    for (int e = lane; e < NRES * NCOL; e += 64) {
+        const int r = e / NCOL, cc = e % NCOL;
+        double sv = 0;
+#pragma unroll 3
+        for (int k2 = 0; k2 < NRES; k2++) if (k2 >= r) sv += sS[r * NRES + k2] * sJ[k2 * NCOL + cc];  // S is upper triangular
+        sSJ[e] = sv;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < NCOL * NCOL; e += 64) {
+        const int a = e / NCOL, c2 = e % NCOL;
+        const int ca = scol[a], cb = scol[c2];
+        if (ca < 0 || cb < 0 || cb > ca) continue;   // lower triangle only
+        double sv = 0;
+#pragma unroll 3
+        for (int r = 0; r < NRES; r++) sv += sSJ[r * NCOL + a] * sSJ[r * NCOL + c2];
+        if (sv != 0.0) atomicAdd(H + (size_t)ca * RP + cb, sv);
+    }
+    if (lane < NCOL && scol[lane] >= 0) {
+        double sv = 0;
+#pragma unroll 3
+        for (int r = 0; r < NRES; r++) sv += sSJ[r * NCOL + lane] * sr[r];
+        atomicAdd(g + scol[lane], sv);
+    }
+    return c;
+}
+
 // frame_filter: 0 all factors; 1 only IMU/wheel factors starting at frame 0 (MARGIN_OLD); 2 no IMU/wheel factor (MARGIN_SECOND_NEW)
 template <bool PRIOR>   // PRIOR: the 256-thread prior task; else one 64-thread block per IMU / wheel factor (own register budget and LDS footprint)
 __global__ void __launch_bounds__(PRIOR ? 256 : 64, PRIOR ? 1 : 3) ba_linearize_misc(Win w, int which, int which_state, int cost_only, int only_cand_valid, int frame_filter, int task_base) {
@@ -596,56 +654,20 @@ __global__ void __launch_bounds__(PRIOR ? 256 : 64, PRIOR ? 1 : 3) ba_linearize_
         if (k >= (is_imu ? nimu : nwh) || frame_filter == 2) return;
         const int i = is_imu ? w.imu_i[(size_t)b * d.W + k] : w.wh_i[(size_t)b * d.W + k], j = i + 1;
         if (frame_filter == 1 && i != 0) return;
-        int nres, ncol;
-        const double* S;
+        double c;
         if (is_imu) {
-            imu_raw(xs + off_pose(i), xs + off_sb(i), xs + off_pose(j), xs + off_sb(j), w.imu_data + ((size_t)b * d.W + k) * IMU_STRIDE2, w.G, sr + 16, sJ, !cost_only, lane);
-            nres = 15; ncol = 30; S = w.imu_sqrt + ((size_t)b * d.W + k) * 225;
-            for (int q = lane; q < 225; q += 64) sS[q] = S[q];
-            if (lane < 30) {
-                const int blk = lane < 6 ? fb_pose(i) : lane < 15 ? fb_sb(i) : lane < 21 ? fb_pose(j) : fb_sb(j);
-                const int o = lane < 6 ? lane : lane < 15 ? lane - 6 : lane < 21 ? lane - 15 : lane - 21;
-                scol[lane] = colf[blk] >= 0 ? colf[blk] + o : -1;
-            }
+            if (!cost_only) { for (int q = lane; q < 450; q += 64) sJ[q] = 0.0; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+            imu_raw(xs + off_pose(i), xs + off_sb(i), xs + off_pose(j), xs + off_sb(j), w.imu_data + ((size_t)b * d.W + k) * IMU_STRIDE2, w.G, sr + 16, sJ, !cost_only, lane == 0);
+            misc_cols(true, i, colf, d.NP, scol, lane);
+            c = misc_whiten_accumulate<15, 30>(w.imu_sqrt + ((size_t)b * d.W + k) * 225, sr + 16, sJ, sS, sSJ, sr, scol, H, g, d.RP, cost_only, lane);
         } else {
+            if (!cost_only) { for (int q = lane; q < 132; q += 64) sJ[q] = 0.0; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
             wheel_raw(xs + off_pose(i), xs + off_pose(j), xs + off_exw(d.NP), xs[off_ix(d.NP)], xs[off_ix(d.NP) + 1], xs[off_ix(d.NP) + 2], xs[off_tdw(d.NP)],
-                      w.wh_data + ((size_t)b * d.W + k) * WH_STRIDE, sr + 16, sJ, !cost_only, lane);
-            nres = 6; ncol = 22; S = w.wh_sqrt + ((size_t)b * d.W + k) * 36;
-            if (lane < 36) sS[lane] = S[lane];
-            if (lane < 22) {
-                const int blk = lane < 6 ? fb_pose(i) : lane < 12 ? fb_pose(j) : lane < 18 ? fb_exw(d.NP) : lane < 21 ? fb_sx(d.NP) + (lane - 18) : fb_tdw(d.NP);
-                const int o = lane < 6 ? lane : lane < 12 ? lane - 6 : lane < 18 ? lane - 12 : 0;
-                scol[lane] = colf[blk] >= 0 ? colf[blk] + o : -1;
-            }
+                      w.wh_data + ((size_t)b * d.W + k) * WH_STRIDE, sr + 16, sJ, !cost_only, lane == 0);
+            misc_cols(false, i, colf, d.NP, scol, lane);
+            c = misc_whiten_accumulate<6, 22>(w.wh_sqrt + ((size_t)b * d.W + k) * 36, sr + 16, sJ, sS, sSJ, sr, scol, H, g, d.RP, cost_only, lane);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-        S = sS;
-        if (lane < nres) { double sv = 0; for (int k2 = 0; k2 < nres; k2++) sv += S[lane * nres + k2] * sr[16 + k2]; sr[lane] = sv; }   // whitened residual
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-        double c = lane < nres ? 0.5 * sr[lane] * sr[lane] : 0.0;
-        c = wave_sum_f64(c);
         if (lane == 0) atomicAdd(w.cost + (size_t)which * d.B + b, c);
-        if (cost_only) return;
-        for (int e = lane; e < nres * ncol; e += 64) {
-            const int r = e / ncol, cc = e % ncol;
-            double sv = 0;
-            for (int k2 = r; k2 < nres; k2++) sv += S[r * nres + k2] * sJ[k2 * ncol + cc];  // S is upper triangular
-            sSJ[e] = sv;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-        for (int e = lane; e < ncol * ncol; e += 64) {
-            const int a = e / ncol, c2 = e % ncol;
-            const int ca = scol[a], cb = scol[c2];
-            if (ca < 0 || cb < 0 || cb > ca) continue;   // lower triangle only
-            double sv = 0;
-            for (int r = 0; r < nres; r++) sv += sSJ[r * ncol + a] * sSJ[r * ncol + c2];
-            if (sv != 0.0) atomicAdd(H + (size_t)ca * d.RP + cb, sv);
-        }
-        if (lane < ncol && scol[lane] >= 0) {
-            double sv = 0;
-            for (int r = 0; r < nres; r++) sv += sSJ[r * ncol + lane] * sr[r];
-            atomicAdd(g + scol[lane], sv);
-        }
         return;
     }
     // ---- prior: r = r0 + J0 dx  =>  cost = 1/2 (c0 + 2 b0.dx + dx^T A dx), g += b0 + A dx, H += A   (marginalization_factor.cpp:344-392)
@@ -857,6 +879,71 @@ __global__ void __launch_bounds__(64 * kVW) ba_linearize_visual_win(Win w, int w
         if (ca < 0) continue;
         atomicAdd(H + (size_t)max(ca, cb) * d.RP + min(ca, cb), v);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Window-level IMU / wheel sweep: one block of kMW wavefronts per window.  The residual / Jacobian evaluation of a factor is a long
+// scalar program (quaternion algebra, SO(3) exp / log, right Jacobians): in ba_linearize_misc one whole wavefront runs it for one
+// factor, 63 of 64 lanes idle.  Here lane k of wavefront 0 evaluates IMU factor k and lane k of wavefront 1 wheel factor k -- all
+// factors of the window at the price of one -- into LDS; then the wavefronts share the factors for whitening and J^T J.
+// Dynamic LDS (doubles): W x (450 + 16) IMU Jacobians / residuals, W x (132 + 8) wheel, kMW x 724 scratch.
+constexpr int kMW = 8;
+constexpr int kMScr = 225 + 450 + 32 + 17;   // per wavefront: S, S J, residuals, column map (32 ints + pad)
+__host__ __device__ inline size_t misc_win_lds_doubles(int W) { return (size_t)W * (450 + 16 + 132 + 8) + (size_t)kMW * kMScr; }
+__global__ void __launch_bounds__(64 * kMW) ba_linearize_misc_win(Win w, int which, int which_state, int cost_only, int only_cand_valid) {
+    extern __shared__ __attribute__((aligned(16))) double m_lds[];
+    __shared__ double s_cost[kMW];
+    const Dims d = w.d;
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const SolverState& st = w.st[b];
+    if (st.done && only_cand_valid != 2) return;
+    if (only_cand_valid == 1 && !st.cand_valid) return;
+    if (which < 0) which = 1 - st.cur;
+    if (which_state == -2) which_state = st.cur; else if (which_state < 0) which_state = 1 - st.cur;
+    const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
+    const int* colf = w.colf + (size_t)b * d.NFB;
+    double* H = w.H + ((size_t)which * d.B + b) * d.RP * d.RP;
+    double* g = w.g + ((size_t)which * d.B + b) * d.RP;
+    const int nimu = w.nimu[b], nwh = w.nwh[b];
+    if (nimu + nwh <= 0) return;
+    double* sJi = m_lds;                       // [W][450]
+    double* sJw = sJi + (size_t)d.W * 450;     // [W][132]
+    double* sRi = sJw + (size_t)d.W * 132;     // [W][16]
+    double* sRw = sRi + (size_t)d.W * 16;      // [W][8]
+    double* scr = sRw + (size_t)d.W * 8 + (size_t)wave * kMScr;
+    double* sS = scr; double* sSJ = scr + 225; double* sr = scr + 675; int* scol = reinterpret_cast<int*>(scr + 707);
+    if (!cost_only) {
+        for (int q = tid; q < nimu * 450; q += 64 * kMW) sJi[q] = 0.0;
+        for (int q = tid; q < nwh * 132; q += 64 * kMW) sJw[q] = 0.0;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < nimu) {
+        const int k = lane, i = w.imu_i[(size_t)b * d.W + k], j = i + 1;
+        imu_raw(xs + off_pose(i), xs + off_sb(i), xs + off_pose(j), xs + off_sb(j), w.imu_data + ((size_t)b * d.W + k) * IMU_STRIDE2, w.G, sRi + 16 * k, sJi + 450 * k,
+                !cost_only, true);
+    }
+    if (wave == 1 && lane < nwh) {
+        const int k = lane, i = w.wh_i[(size_t)b * d.W + k], j = i + 1;
+        wheel_raw(xs + off_pose(i), xs + off_pose(j), xs + off_exw(d.NP), xs[off_ix(d.NP)], xs[off_ix(d.NP) + 1], xs[off_ix(d.NP) + 2], xs[off_tdw(d.NP)],
+                  w.wh_data + ((size_t)b * d.W + k) * WH_STRIDE, sRw + 8 * k, sJw + 132 * k, !cost_only, true);
+    }
+    __syncthreads();
+    double cost = 0.0;
+    for (int t = wave; t < nimu + nwh; t += kMW) {   // IMU factors (the dearer ones) first
+        if (t < nimu) {
+            const int k = t, i = w.imu_i[(size_t)b * d.W + k];
+            misc_cols(true, i, colf, d.NP, scol, lane);
+            cost += misc_whiten_accumulate<15, 30>(w.imu_sqrt + ((size_t)b * d.W + k) * 225, sRi + 16 * k, sJi + 450 * k, sS, sSJ, sr, scol, H, g, d.RP, cost_only, lane);
+        } else {
+            const int k = t - nimu, i = w.wh_i[(size_t)b * d.W + k];
+            misc_cols(false, i, colf, d.NP, scol, lane);
+            cost += misc_whiten_accumulate<6, 22>(w.wh_sqrt + ((size_t)b * d.W + k) * 36, sRw + 8 * k, sJw + 132 * k, sS, sSJ, sr, scol, H, g, d.RP, cost_only, lane);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();   // scratch is reused by the next factor
+    }
+    if (lane == 0) s_cost[wave] = cost;
+    __syncthreads();
+    if (tid == 0) { double c = 0; for (int q = 0; q < kMW; q++) c += s_cost[q]; atomicAdd(w.cost + (size_t)which * d.B + b, c); }
 }
 
 // PoseLocalParameterization::Plus (pose_local_parameterization.cpp:12-28)
