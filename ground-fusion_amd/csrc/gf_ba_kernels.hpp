@@ -426,8 +426,9 @@ __global__ void __launch_bounds__(256) ba_setup(Win w) {
 // Jraw: 15 x 30 row-major in LDS, columns [pose_i 6 | speedbias_i 9 | pose_j 6 | speedbias_j 9].  Executed redundantly by every lane; lane 0 stores.
 // `writer`: this lane stores the raw residual (15) and the Jacobian blocks (15 x 30, row-major, into a zeroed Jraw); the arithmetic runs on
 // every lane.  The caller zeroes Jraw before and fences after.
+// ld: row stride of Jraw (>= 30), rs: stride of rraw.
 __device__ inline void imu_raw(const double* Pi_, const double* SBi, const double* Pj_, const double* SBj, const double* dat, const double* G_, double* rraw,
-                               double* Jraw, bool want_jac, bool writer) {
+                               double* Jraw, bool want_jac, bool writer, int ld = 30, int rs = 1) {
     const V3 Pi = p_of(Pi_), Pj = p_of(Pj_), Vi = v3(SBi[0], SBi[1], SBi[2]), Bai = v3(SBi[3], SBi[4], SBi[5]), Bgi = v3(SBi[6], SBi[7], SBi[8]);
     const V3 Vj = v3(SBj[0], SBj[1], SBj[2]), Baj = v3(SBj[3], SBj[4], SBj[5]), Bgj = v3(SBj[6], SBj[7], SBj[8]);
     const Q4 Qi = q_of(Pi_), Qj = q_of(Pj_);
@@ -447,12 +448,13 @@ __device__ inline void imu_raw(const double* Pi_, const double* SBi, const doubl
     const V3 t_v = qrot(Qi_inv, G * sum_dt + Vj - Vi);
     const V3 rp = t_p - cdp, rq = qvec(qmul(qinverse(cdq), qmul(Qi_inv, Qj))) * 2.0, rv = t_v - cdv, rba = Baj - Bai, rbg = Bgj - Bgi;
     if (writer) {
-        rraw[0] = rp.x; rraw[1] = rp.y; rraw[2] = rp.z; rraw[3] = rq.x; rraw[4] = rq.y; rraw[5] = rq.z; rraw[6] = rv.x; rraw[7] = rv.y; rraw[8] = rv.z;
-        rraw[9] = rba.x; rraw[10] = rba.y; rraw[11] = rba.z; rraw[12] = rbg.x; rraw[13] = rbg.y; rraw[14] = rbg.z;
+        const double rr_[15] = {rp.x, rp.y, rp.z, rq.x, rq.y, rq.z, rv.x, rv.y, rv.z, rba.x, rba.y, rba.z, rbg.x, rbg.y, rbg.z};
+#pragma unroll
+        for (int q = 0; q < 15; q++) rraw[q * rs] = rr_[q];
     }
     if (!want_jac) return;
     if (writer) {
-        auto put = [&](int r0, int c0, const M3& m) { for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Jraw[(r0 + r) * 30 + c0 + c] = m.m[3 * r + c]; };
+        auto put = [&](int r0, int c0, const M3& m) { for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Jraw[(r0 + r) * ld + c0 + c] = m.m[3 * r + c]; };
         const M3 Rit = qmat(Qi_inv);
         // pose_i (cols 0..5)
         put(0, 0, -Rit);
@@ -479,7 +481,7 @@ __device__ inline void imu_raw(const double* Pi_, const double* SBi, const doubl
 // Jraw: 6 x 22, columns [pose_i 6 | pose_j 6 | T_io 6 | sx | sy | sw | td_wheel].
 // same conventions as imu_raw: residual (6), Jacobian 6 x 22 into a zeroed Jraw
 __device__ inline void wheel_raw(const double* Pi_, const double* Pj_, const double* Ex, double sx, double sy, double sw, double td, const double* dat, double* rraw,
-                                 double* Jraw, bool want_jac, bool writer) {
+                                 double* Jraw, bool want_jac, bool writer, int ld = 22, int rs = 1) {
     const V3 Pi = p_of(Pi_), Pj = p_of(Pj_), tio = p_of(Ex);
     const Q4 Qi = q_of(Pi_), Qj = q_of(Pj_), qio = q_of(Ex);
     const M3 sv = m3_diag(sx, sy, 1);
@@ -501,11 +503,11 @@ __device__ inline void wheel_raw(const double* Pi_, const double* Pj_, const dou
     const V3 rp = Rio_t * (Rj * tio + Pj - Ri * tio - Pi) - dp_time;
     const Q4 Qio = qmul(Qi, qio);
     const V3 rr = so3_log(qmul(qmul(qmul(qinverse(dq_time), qinverse(Qio)), Qj), qio));
-    if (writer) { rraw[0] = rp.x; rraw[1] = rp.y; rraw[2] = rp.z; rraw[3] = rr.x; rraw[4] = rr.y; rraw[5] = rr.z; }
+    if (writer) { rraw[0] = rp.x; rraw[rs] = rp.y; rraw[2 * rs] = rp.z; rraw[3 * rs] = rr.x; rraw[4 * rs] = rr.y; rraw[5 * rs] = rr.z; }
     if (!want_jac) return;
     if (writer) {
-        auto put = [&](int r0, int c0, const M3& m) { for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Jraw[(r0 + r) * 22 + c0 + c] = m.m[3 * r + c]; };
-        auto putv = [&](int r0, int c0, V3 v) { Jraw[r0 * 22 + c0] = v.x; Jraw[(r0 + 1) * 22 + c0] = v.y; Jraw[(r0 + 2) * 22 + c0] = v.z; };
+        auto put = [&](int r0, int c0, const M3& m) { for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Jraw[(r0 + r) * ld + c0 + c] = m.m[3 * r + c]; };
+        auto putv = [&](int r0, int c0, V3 v) { Jraw[r0 * ld + c0] = v.x; Jraw[(r0 + 1) * ld + c0] = v.y; Jraw[(r0 + 2) * ld + c0] = v.z; };
         const M3 Jr_inv = rightJacobianInvSO3(rr);
         const M3 Jr_drdsw = rightJacobianSO3(dq_dsw * (sw - lsw));
         const M3 Rcq = qmat(cdq);
@@ -623,6 +625,72 @@ __device__ __forceinline__ double misc_whiten_accumulate(const double* Sg, const
         atomicAdd(g + scol[lane], sv);
     }
     return c;
+}
+
+// The same on the matrix cores, for the window-level sweep.  sJp: the factor's padded block row [J | r] in LDS, 4*KS x 33 doubles, rows
+// >= NRES and columns > NCOL zero.  W' = S [J | r] (KS MFMA steps x 2 column tiles), then W'^T W' = [[J^T J, J^T r], [., r^T r]] whitened
+// (3 tiles): 20 MFMAs for an IMU factor instead of ~9000 LDS-latency-bound scalar multiply-adds.  sW: 4*KS x 33 scratch of this wavefront.
+template <int NRES, int NCOL>
+__device__ __forceinline__ double misc_mfma_accumulate(const double* Sg, const double* sJp, double* sW, const int* scol, double* H, double* g, int RP, int cost_only,
+                                                       int lane) {
+    constexpr int KS = (NRES + 3) / 4, LD = 33;
+    const int lr = lane & 15, lk = lane >> 4;
+    if (cost_only) {
+        double sv = 0;
+        if (lane < NRES)
+            for (int k2 = lane; k2 < NRES; k2++) sv += Sg[lane * NRES + k2] * sJp[k2 * LD + NCOL];
+        return wave_sum_f64(0.5 * sv * sv);
+    }
+    double sa[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) { const int k = 4 * kk + lk; sa[kk] = (lr < NRES && k < NRES) ? Sg[lr * NRES + k] : 0.0; }
+    d4 w0 = {0, 0, 0, 0}, w1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) {
+        const double* row = sJp + (4 * kk + lk) * LD + lr;
+        w0 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[kk], row[0], w0, 0, 0, 0);
+        w1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[kk], row[16], w1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = lk + 4 * r;
+        if (row < 4 * KS) { sW[row * LD + lr] = w0[r]; sW[row * LD + 16 + lr] = w1[r]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    d4 g00 = {0, 0, 0, 0}, g10 = {0, 0, 0, 0}, g11 = {0, 0, 0, 0};
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) {
+        const double* row = sW + (4 * kk + lk) * LD + lr;
+        const double a0 = row[0], a1 = row[16];
+        g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, g00, 0, 0, 0);
+        g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a0, g10, 0, 0, 0);
+        g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, g11, 0, 0, 0);
+    }
+    // element (a, b) of tile (ta, tb): local columns 16 ta + a, 16 tb + b; a = lk + 4 r, b = lr
+    const int cb0 = lr < NCOL ? scol[lr] : -1;                                    // tile column 0
+    const int cb1 = 16 + lr < NCOL ? scol[16 + lr] : -1;                          // tile column 1
+    double cost2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int a = lk + 4 * r;
+        // rows of tile row 0
+        const int ca0 = a < NCOL ? scol[a] : -1;
+        if (ca0 >= 0 && cb0 >= 0 && lr <= a && g00[r] != 0.0) atomicAdd(H + (size_t)max(ca0, cb0) * RP + min(ca0, cb0), g00[r]);
+        // rows of tile row 1: local column 16 + a
+        const int la = 16 + a;
+        if (la < NCOL) {
+            const int ca1 = scol[la];
+            if (ca1 >= 0) {
+                if (cb0 >= 0 && g10[r] != 0.0) atomicAdd(H + (size_t)max(ca1, cb0) * RP + min(ca1, cb0), g10[r]);
+                if (cb1 >= 0 && lr <= a && g11[r] != 0.0) atomicAdd(H + (size_t)max(ca1, cb1) * RP + min(ca1, cb1), g11[r]);
+            }
+        } else if (la == NCOL) {                                                   // the r column: J^T r and r^T r
+            if (cb0 >= 0) atomicAdd(g + cb0, g10[r]);
+            if (cb1 >= 0) atomicAdd(g + cb1, g11[r]);
+            if (16 + lr == NCOL) cost2 = g11[r];
+        }
+    }
+    return 0.5 * wave_sum_f64(cost2);
 }
 
 // frame_filter: 0 all factors; 1 only IMU/wheel factors starting at frame 0 (MARGIN_OLD); 2 no IMU/wheel factor (MARGIN_SECOND_NEW)
@@ -885,14 +953,16 @@ __global__ void __launch_bounds__(64 * kVW) ba_linearize_visual_win(Win w, int w
 // Window-level IMU / wheel sweep: one block of kMW wavefronts per window.  The residual / Jacobian evaluation of a factor is a long
 // scalar program (quaternion algebra, SO(3) exp / log, right Jacobians): in ba_linearize_misc one whole wavefront runs it for one
 // factor, 63 of 64 lanes idle.  Here lane k of wavefront 0 evaluates IMU factor k and lane k of wavefront 1 wheel factor k -- all
-// factors of the window at the price of one -- into LDS; then the wavefronts share the factors for whitening and J^T J.
-// Dynamic LDS (doubles): W x (450 + 16) IMU Jacobians / residuals, W x (132 + 8) wheel, kMW x 724 scratch.
+// factors of the window at the price of one -- into padded block rows [J | r] in LDS; whitening and J^T J of each factor then run on
+// the matrix cores (misc_mfma_accumulate), IMU factors as soon as wavefront 0 is through, wheel factors when wavefront 1 is.
+// Dynamic LDS (doubles): W x 16 x 33 IMU block rows, W x 8 x 33 wheel block rows, kMW x (16 x 33 + 16) scratch.
 constexpr int kMW = 8;
-constexpr int kMScr = 225 + 450 + 32 + 17;   // per wavefront: S, S J, residuals, column map (32 ints + pad)
-__host__ __device__ inline size_t misc_win_lds_doubles(int W) { return (size_t)W * (450 + 16 + 132 + 8) + (size_t)kMW * kMScr; }
+constexpr int kMJi = 16 * 33, kMJw = 8 * 33, kMScr = 16 * 33 + 16;   // scratch: W', column map (32 ints)
+__host__ __device__ inline size_t misc_win_lds_doubles(int W) { return (size_t)W * (kMJi + kMJw) + (size_t)kMW * kMScr; }
 __global__ void __launch_bounds__(64 * kMW) ba_linearize_misc_win(Win w, int which, int which_state, int cost_only, int only_cand_valid) {
     extern __shared__ __attribute__((aligned(16))) double m_lds[];
     __shared__ double s_cost[kMW];
+    __shared__ int s_ready[2];     // [0]: IMU block rows are in LDS, [1]: wheel block rows
     const Dims d = w.d;
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const SolverState& st = w.st[b];
@@ -906,40 +976,61 @@ __global__ void __launch_bounds__(64 * kMW) ba_linearize_misc_win(Win w, int whi
     double* g = w.g + ((size_t)which * d.B + b) * d.RP;
     const int nimu = w.nimu[b], nwh = w.nwh[b];
     if (nimu + nwh <= 0) return;
-    double* sJi = m_lds;                       // [W][450]
-    double* sJw = sJi + (size_t)d.W * 450;     // [W][132]
-    double* sRi = sJw + (size_t)d.W * 132;     // [W][16]
-    double* sRw = sRi + (size_t)d.W * 16;      // [W][8]
-    double* scr = sRw + (size_t)d.W * 8 + (size_t)wave * kMScr;
-    double* sS = scr; double* sSJ = scr + 225; double* sr = scr + 675; int* scol = reinterpret_cast<int*>(scr + 707);
-    if (!cost_only) {
-        for (int q = tid; q < nimu * 450; q += 64 * kMW) sJi[q] = 0.0;
-        for (int q = tid; q < nwh * 132; q += 64 * kMW) sJw[q] = 0.0;
-    }
+    double* sJi = m_lds;                          // [W][16][33]
+    double* sJw = sJi + (size_t)d.W * kMJi;       // [W][8][33]
+    double* scr = sJw + (size_t)d.W * kMJw + (size_t)wave * kMScr;
+    double* sW = scr; int* scol = reinterpret_cast<int*>(scr + 16 * 33);
+    for (int q = tid; q < nimu * kMJi; q += 64 * kMW) sJi[q] = 0.0;
+    for (int q = tid; q < nwh * kMJw; q += 64 * kMW) sJw[q] = 0.0;
+    if (tid < 2) s_ready[tid] = 0;
     __syncthreads();
-    if (wave == 0 && lane < nimu) {
-        const int k = lane, i = w.imu_i[(size_t)b * d.W + k], j = i + 1;
-        imu_raw(xs + off_pose(i), xs + off_sb(i), xs + off_pose(j), xs + off_sb(j), w.imu_data + ((size_t)b * d.W + k) * IMU_STRIDE2, w.G, sRi + 16 * k, sJi + 450 * k,
-                !cost_only, true);
-    }
-    if (wave == 1 && lane < nwh) {
-        const int k = lane, i = w.wh_i[(size_t)b * d.W + k], j = i + 1;
-        wheel_raw(xs + off_pose(i), xs + off_pose(j), xs + off_exw(d.NP), xs[off_ix(d.NP)], xs[off_ix(d.NP) + 1], xs[off_ix(d.NP) + 2], xs[off_tdw(d.NP)],
-                  w.wh_data + ((size_t)b * d.W + k) * WH_STRIDE, sRw + 8 * k, sJw + 132 * k, !cost_only, true);
-    }
-    __syncthreads();
-    double cost = 0.0;
-    for (int t = wave; t < nimu + nwh; t += kMW) {   // IMU factors (the dearer ones) first
-        if (t < nimu) {
-            const int k = t, i = w.imu_i[(size_t)b * d.W + k];
-            misc_cols(true, i, colf, d.NP, scol, lane);
-            cost += misc_whiten_accumulate<15, 30>(w.imu_sqrt + ((size_t)b * d.W + k) * 225, sRi + 16 * k, sJi + 450 * k, sS, sSJ, sr, scol, H, g, d.RP, cost_only, lane);
-        } else {
-            const int k = t - nimu, i = w.wh_i[(size_t)b * d.W + k];
-            misc_cols(false, i, colf, d.NP, scol, lane);
-            cost += misc_whiten_accumulate<6, 22>(w.wh_sqrt + ((size_t)b * d.W + k) * 36, sRw + 8 * k, sJw + 132 * k, sS, sSJ, sr, scol, H, g, d.RP, cost_only, lane);
+    if (wave == 0) {
+        if (lane < nimu) {
+            const int k = lane, i = w.imu_i[(size_t)b * d.W + k], j = i + 1;
+            imu_raw(xs + off_pose(i), xs + off_sb(i), xs + off_pose(j), xs + off_sb(j), w.imu_data + ((size_t)b * d.W + k) * IMU_STRIDE2, w.G, sJi + kMJi * k + 30,
+                    sJi + kMJi * k, !cost_only, true, 33, 33);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();   // scratch is reused by the next factor
+        __threadfence_block();
+        if (lane == 0) __hip_atomic_store(&s_ready[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (wave == 1) {
+        if (lane < nwh) {
+            const int k = lane, i = w.wh_i[(size_t)b * d.W + k], j = i + 1;
+            wheel_raw(xs + off_pose(i), xs + off_pose(j), xs + off_exw(d.NP), xs[off_ix(d.NP)], xs[off_ix(d.NP) + 1], xs[off_ix(d.NP) + 2], xs[off_tdw(d.NP)],
+                      w.wh_data + ((size_t)b * d.W + k) * WH_STRIDE, sJw + kMJw * k + 22, sJw + kMJw * k, !cost_only, true, 33, 33);
+        }
+        __threadfence_block();
+        if (lane == 0) __hip_atomic_store(&s_ready[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    auto wait_for = [&](int which_flag) {
+        while (__hip_atomic_load(&s_ready[which_flag], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(4);
+    };
+    double cost = 0.0;
+    // IMU factors: every wavefront but the one still busy with the wheel evaluation
+    {
+        const int slot = wave == 0 ? 0 : wave - 1;      // wavefronts 0, 2, 3, ... -> slots 0, 1, 2, ...
+        if (wave != 1 && nimu > 0) {
+            wait_for(0);
+            for (int k = slot; k < nimu; k += kMW - 1) {
+                const int i = w.imu_i[(size_t)b * d.W + k];
+                misc_cols(true, i, colf, d.NP, scol, lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                cost += misc_mfma_accumulate<15, 30>(w.imu_sqrt + ((size_t)b * d.W + k) * 225, sJi + kMJi * k, sW, scol, H, g, d.RP, cost_only, lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();   // scratch is reused by the next factor
+            }
+        }
+    }
+    // wheel factors: all wavefronts, wavefront 1 first in line
+    if (nwh > 0) {
+        wait_for(1);
+        const int slot = (wave + kMW - 1) % kMW;         // wavefront 1 -> slot 0
+        for (int k = slot; k < nwh; k += kMW) {
+            const int i = w.wh_i[(size_t)b * d.W + k];
+            misc_cols(false, i, colf, d.NP, scol, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+            cost += misc_mfma_accumulate<6, 22>(w.wh_sqrt + ((size_t)b * d.W + k) * 36, sJw + kMJw * k, sW, scol, H, g, d.RP, cost_only, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        }
     }
     if (lane == 0) s_cost[wave] = cost;
     __syncthreads();

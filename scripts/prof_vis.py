@@ -1,4 +1,3 @@
-"""stage clocks of one IMU and one wheel wavefront of ba_linearize_misc<false> (profiling build: python scripts/build_profile.py)"""
 import sys, ctypes as C
 sys.path.insert(0, 'ground-fusion_amd')
 import numpy as np, gfamd, synth_window as SW
@@ -6,10 +5,11 @@ est = gfamd.Estimator(batch=256)
 base = [SW.make_window(1000 + b, gfamd) for b in range(8)]
 wins = [base[b % 8] for b in range(256)]
 est.upload(wins)
-for it in (1, 2, 8):
+for it in (1, 8):
     est.solve_resident(it, -1, True)
     st = np.zeros(64, np.int64)
     gfamd._chk(gfamd.lib().gf_ba_debug_stamps(est.h, st.ctypes.data_as(C.POINTER(C.c_longlong)), 64))
-    for o, name in ((32, "imu"), (40, "wheel")):
-        v = st[o:o + 6]
-        print(it, name, "raw eval %d, whiten r + cost %d, S J %d, J^T J + atomics %d, drain %d  (cycles; total %d)" % (*np.diff(v).tolist(), v[5] - v[0]))
+    t0 = st[32]
+    for wv in range(4):
+        v = st[32 + 8 * wv: 32 + 8 * wv + 6] - t0
+        print(it, "wave", wv, "start %d | phase1 done %d | after sync %d | task1 done %d | task2 done %d | all tasks %d" % tuple(v.tolist()))
