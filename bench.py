@@ -139,6 +139,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # host bookkeeping threads of the tracker (default 4 per process): keep all ranks of the node within its cores
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    os.environ.setdefault("GF_HOST_THREADS", str(max(1, min(4, (os.cpu_count() or 4) // max(local_world, 1)))))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
