@@ -1,5 +1,7 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 300 python -m pytest tests/test_backend_gpu.py tests/test_golden.py -m gpu -x -q 2>&1 | tail -4
-rm -rf /tmp/p0; timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/p0 -- python scripts/prof_misc.py > /dev/null 2>&1
-python scripts/prof_misc.py --parse /tmp/p0 | head -8
-python scripts/timeline.py /tmp/p0 30 | tail -22
+cd $GRAFT_REPO_ROOT
+run() { echo "== $1"; env $1 timeout 200 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['gpu_ms_per_step'])"; }
+run "X=1"
+run "GF_BA_PRIO=1"
+run "GF_BA_PRIO=1 GF_TRK_PRIO=0"
+run "GF_TRK_PRIO=1"
+run "GF_BA_PRIO=0 GF_TRK_PRIO=1"

@@ -180,6 +180,21 @@ def test_lds_and_global_reduced_system_agree(gf, oracle, monkeypatch):
     assert np.abs(A1.T @ A1 - A2.T @ A2).max() <= 1e-9 * np.abs(A1.T @ A1).max()
 
 
+def test_window_level_and_chunked_sweeps_agree(gf, oracle, monkeypatch):
+    """ba_linearize_visual_win / ba_linearize_misc_win (one block per window, LDS accumulation, matrix-core whitening) against the chunked
+    kernels they replace in the solve (still used for marginalisation, a free camera extrinsic and long windows): same normal equations up to
+    the order of the additions, same solve"""
+    w = SW.make_window(9, oracle)
+    e1 = gf.Estimator(); l1 = e1.linearize(w); a = w.copy(); e1.solve([a], 8); e1.close()
+    monkeypatch.setenv("GF_BA_CHUNKED_VISUAL", "1")
+    monkeypatch.setenv("GF_BA_CHUNKED_MISC", "1")
+    e2 = gf.Estimator(); l2 = e2.linearize(w); b = w.copy(); e2.solve([b], 8); e2.close()
+    assert abs(l1["cost"] - l2["cost"]) <= 1e-13 * l2["cost"]
+    assert np.abs(l1["H"] - l2["H"]).max() <= 1e-13 * np.abs(l2["H"]).max() and np.abs(l1["g"] - l2["g"]).max() <= 1e-12 * np.abs(l2["g"]).max()
+    dp, dr = _pose_diff(a, b)
+    assert dp < 1e-8 and dr < 1e-8
+
+
 # ---------------------------------------------------------------- GNSS residual blocks on the device (SURVEY.md §8a row F4)
 def _gnss_est(gf, W=10, F=150):
     return gf.Estimator(W, F, F * W, 1, max_gnss=12 * (W + 1))
