@@ -47,7 +47,7 @@ struct gf_ba {
     int count = 0;       // windows currently resident
     bool any_ex = false; // some window estimates the camera extrinsic
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: IMU / wheel / prior linearisation, concurrent with the visual sweep
-    hipEvent_t ev[6] = {};
+    hipEvent_t ev[8] = {};   // 6, 7: around the second ba_step of a solve (the first full dogleg step)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool pending = false;   // an asynchronous solve is in flight
     int pending_iters = 0;
@@ -72,6 +72,7 @@ struct gf_ba {
     size_t vwin_lds = 0;   // > 0: the window-level visual sweep (ba_linearize_visual_win) fits LDS; its dynamic size
     size_t mwin_lds = 0;   // > 0: the window-level IMU / wheel sweep (ba_linearize_misc_win) fits LDS; its dynamic size
     long long mfma_per_lin = 0;   // v_mfma_f64_16x16x4 instructions of one visual linearisation of the resident batch
+    long long step_flops = 0;     // dense algebra of one ba_step over the resident batch: Schur SYRK NE*n_c^2 + Cholesky R^3/3 + substitutions 2 R^2
     std::vector<Buf<double>*> dbl() { return {&xs0, &xs, &vis_data, &imu_data, &wh_data, &pri_J, &pri_r, &pri_x0, &imu_sqrt, &wh_sqrt, &pri_A, &pri_b, &pri_c, &pri_H0, &H, &g, &cost, &efac,
                                               &scale, &diag, &grad, &gn, &step, &u, &Et, &Es, &ete, &etb, &rhs, &yv, &Sg, &Mg, &gn_data, &gn_misc}; }
     std::vector<Buf<int>*> ints() { return {&colf, &cole, &nvis, &nimu, &nwh, &nfeat, &vis_feat, &vis_i, &vis_j, &order, &norder, &feat_ptr, &feat_fac, &imu_i, &wh_i, &pri_n, &pri_nb, &pri_bid, &ngnss, &gn_idx}; }
@@ -114,7 +115,7 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
     const Dims& d = h->d;
     if (count < 1 || count > d.B) return gf::set_err(GF_ERR_INVALID, "count %d outside 1..%d", count, d.B);
     h->any_ex = false;
-    h->mfma_per_lin = 0;
+    h->mfma_per_lin = 0; h->step_flops = 0;
     for (int b = 0; b < d.B; b++) {
         const gf_ba_window& w = ws[std::min(b, count - 1)];  // unused slots replicate the last window (kernels run on the whole batch)
         if (w.W != d.W) return gf::set_err(GF_ERR_INVALID, "window %d: W=%d, handle built for %d", b, w.W, d.W);
@@ -193,6 +194,7 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
             h->cole.h[(size_t)b * d.F + f] = free_f ? ne++ : -1;
         }
         st.NE = ne;
+        if (b < count) { const double R = st.R, nc = 6.0 * d.NP + 8.0; h->step_flops += (long long)(ne * nc * nc + R * R * R / 3.0 + 2.0 * R * R); }
         h->nvis.h[b] = w.n_visual; h->nimu.h[b] = w.n_imu; h->nwh.h[b] = w.n_wheel; h->nfeat.h[b] = w.n_feature;
         {   // pair-sorted order with even padding (each MFMA consumes two factors of one frame pair)
             std::vector<int> idx(w.n_visual);
@@ -377,9 +379,12 @@ int run_solve(gf_ba* h, int max_iters) {
     Win w = h->win();
     StepBufs sb = h->sbufs();
     for (int it = 0; it <= max_iters; it++) {
+        const bool time_step = it == 1 && max_iters >= 1;
+        if (time_step) HIPCHK(hipEventRecord(h->ev[6], h->stream));
         if (h->big_step) ba_step<true><<<dim3(d.B), 512, 0, h->stream>>>(w, sb, it == 0 ? 1 : 0, max_iters, it == max_iters ? 1 : 0);
         else ba_step<false><<<dim3(d.B), 512, h->step_lds, h->stream>>>(w, sb, it == 0 ? 1 : 0, max_iters, it == max_iters ? 1 : 0);
         HIPCHK(hipGetLastError());
+        if (time_step) { HIPCHK(hipEventRecord(h->ev[7], h->stream)); h->stats.step_launches++; h->stats.step_flops += h->step_flops; }
         if (it < max_iters) {
             // candidate state lives in buffer (1 - cur) of each window: linearise both ... the kernels pick the right one per window
             if (int rc = launch_linearize(h, -1, -1, 0, 1, it == 0)) return rc;
@@ -526,6 +531,7 @@ int gf_ba_wait(gf_ba* h) {
     HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); h->stats.ms_solve += ms;
     HIPCHK(hipEventElapsedTime(&ms, h->ev[1], h->ev[4])); h->stats.ms_marginalize += ms;
     if (h->pending_iters > 0) { HIPCHK(hipEventElapsedTime(&ms, h->ev[2], h->ev[3])); h->stats.ms_jtj += ms; }
+    if (h->pending_iters > 0) { HIPCHK(hipEventElapsedTime(&ms, h->ev[6], h->ev[7])); h->stats.ms_step += ms; }
     return GF_OK;
 }
 

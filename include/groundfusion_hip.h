@@ -195,6 +195,8 @@ typedef struct gf_ba_stats {
     double ms_upload, ms_solve, ms_marginalize, ms_download;   /* hipEvent times accumulated over calls */
     double ms_jtj;                                             /* time inside the visual J^T J (MFMA) kernel */
     long long solves, jtj_launches, jtj_flops;                 /* jtj_flops: MFMA flops issued by that kernel */
+    double ms_step;                                            /* time inside ba_step (one full dogleg step per solve is timed) */
+    long long step_launches, step_flops;                       /* step_flops: Schur SYRK + Cholesky + substitutions of the timed launches */
 } gf_ba_stats;
 
 int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out);
