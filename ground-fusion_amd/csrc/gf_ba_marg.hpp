@@ -99,6 +99,42 @@ __device__ inline void block_jacobi_eig(double* A, double* V, int n, double* s_c
 }
 
 constexpr int MPMAX = 20;   // dropped pose + speed-bias (+ receiver clock blocks) columns
+// Inverse of a symmetric positive definite n x n block (n <= MPMAX) by Gauss-Jordan without pivoting, one wavefront.  T: n x 2n work
+// area.  Returns true and Ainv when every pivot is positive and 1 / |A^-1|_F > eps: then lambda_min(A) >= 1 / |A^-1|_2 > eps, no
+// eigenvalue falls under the reference's truncation threshold (marginalization_factor.cpp:279-283) and the pseudo-inverse it builds from
+// the eigen-decomposition is this inverse.  Otherwise the caller takes the eigen route.
+__device__ inline bool wave_spd_inverse(const double* A, double* T, double* Ainv, int n, double eps, int lane) {
+    constexpr int Q = (MPMAX * 2 * MPMAX + 63) / 64;
+    const int n2 = 2 * n, tot = n * n2;
+    for (int i = lane; i < tot; i += 64) { const int r = i / n2, c = i - r * n2; T[i] = c < n ? A[r * n + c] : (c - n == r ? 1.0 : 0.0); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    bool ok = true;
+    for (int k = 0; k < n && ok; k++) {
+        const double piv = T[k * n2 + k];
+        if (!(piv > 0.0)) { ok = false; break; }
+        const double dinv = 1.0 / piv;
+        double fr[Q], pv[Q], cur[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int i = lane + 64 * q;
+            if (i < tot) { const int r = i / n2, c = i - r * n2; fr[q] = T[r * n2 + k]; pv[q] = T[k * n2 + c]; cur[q] = T[i]; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int i = lane + 64 * q;
+            if (i < tot) { const int r = i / n2; T[i] = r == k ? cur[q] * dinv : cur[q] - fr[q] * dinv * pv[q]; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
+    if (!ok) return false;
+    double f2 = 0.0;
+    for (int i = lane; i < n * n; i += 64) { const int r = i / n, c = i - r * n; const double v = 0.5 * (T[r * n2 + n + c] + T[c * n2 + n + r]); Ainv[i] = v; f2 += v * v; }
+    f2 = wave_sum_f64(f2);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    return f2 > 0.0 && 1.0 / sqrt(f2) > eps;
+}
+
 struct MargOut { double* J; double* r; };  // [B][NPRI*NPRI], [B][NPRI]
 
 // One 512-thread block per window.  M = H[1-cur] (ld RP) holds the dropped-block + kept-block normal equations, g[1-cur] the
@@ -109,7 +145,7 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     __shared__ double sred[512];
     __shared__ double sP[MPMAX * MPMAX], sPV[MPMAX * MPMAX], sPinv[MPMAX * MPMAX], sbp[MPMAX];
     __shared__ double s_c[64], s_s[64];
-    __shared__ int s_p[64], s_q[64], s_flag;
+    __shared__ int s_p[64], s_q[64], s_flag, s_fastinv;
     const Dims d = w.d;
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const MargInfo mi = info[b];
@@ -171,15 +207,23 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     // ---- pseudo-inverse of the dropped pose / speed-bias block (eigenvalues <= eps are dropped)
     for (int i = tid; i < mp * mp; i += 512) { const int r = i / mp, c = i % mp; sP[i] = M[(size_t)max(r, c) * RP + min(r, c)]; }
     __syncthreads();
-    if (wave == 0) block_jacobi_eig<true>(sP, sPV, mp, s_c, s_s, s_p, s_q, &s_flag, lane, 64);
-    __syncthreads();
-    for (int i = tid; i < mp * mp; i += 512) {
-        const int r = i / mp, c = i % mp;
-        double v = 0;
-        for (int k = 0; k < mp; k++) { const double ev = sP[k * mp + k]; if (ev > eps) v += sPV[r * mp + k] * sPV[c * mp + k] / ev; }
-        sPinv[i] = v;
+    // well-conditioned block (the usual case): plain inverse; else eigen-decomposition with the truncation of the reference
+    if (wave == 0) {
+        const bool fast = wave_spd_inverse(sP, GS ? sb.Mg + (size_t)blockIdx.x * sb.MgStride : smem, sPinv, mp, eps, lane);
+        if (lane == 0) s_fastinv = fast ? 1 : 0;
     }
     __syncthreads();
+    if (!s_fastinv) {
+        if (wave == 0) block_jacobi_eig<true>(sP, sPV, mp, s_c, s_s, s_p, s_q, &s_flag, lane, 64);
+        __syncthreads();
+        for (int i = tid; i < mp * mp; i += 512) {
+            const int r = i / mp, c = i % mp;
+            double v = 0;
+            for (int k = 0; k < mp; k++) { const double ev = sP[k * mp + k]; if (ev > eps) v += sPV[r * mp + k] * sPV[c * mp + k] / ev; }
+            sPinv[i] = v;
+        }
+        __syncthreads();
+    }
     if (tid < mp) { double v = 0; for (int k = 0; k < mp; k++) v += sPinv[tid * mp + k] * bv[k]; sbp[tid] = v; }
     __syncthreads();
     GF_MST(3);
