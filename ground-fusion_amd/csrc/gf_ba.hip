@@ -70,6 +70,7 @@ struct gf_ba {
     std::vector<std::vector<int>> keep_ids[2];   // per window: kept block ids (before the address shift), in column order
     size_t marg_lds = 0; int marg_ncap = 0, last_marg_mode = -1;
     size_t vwin_lds = 0;   // > 0: the window-level visual sweep (ba_linearize_visual_win) fits LDS; its dynamic size
+    size_t vwinx_lds = 0;  // the same for the variant with camera-extrinsic columns (free extrinsic; MARGIN_OLD sweep)
     size_t mwin_lds = 0;   // > 0: the window-level IMU / wheel sweep (ba_linearize_misc_win) fits LDS; its dynamic size
     long long mfma_per_lin = 0;   // v_mfma_f64_16x16x4 instructions of one visual linearisation of the resident batch
     long long step_flops = 0;     // dense algebra of one ba_step over the resident batch: Schur SYRK NE*n_c^2 + Cholesky R^3/3 + substitutions 2 R^2
@@ -352,8 +353,9 @@ int launch_linearize(gf_ba* h, int which, int which_state, int cost_only, int on
     Win w = h->win();
     HIPCHK(hipEventRecord(h->ev_fork, h->stream));   // everything enqueued so far (state, zeroed buffers) precedes the forked work
     if (timed) HIPCHK(hipEventRecord(h->ev[2], h->stream));
-    if (h->any_ex) ba_linearize_visual<true><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(w, which, which_state, cost_only, only_valid);
-    else if (h->vwin_lds) ba_linearize_visual_win<<<dim3(d.B), 64 * kVW, h->vwin_lds, h->stream>>>(w, which, which_state, cost_only, only_valid);
+    if (h->any_ex && h->vwinx_lds) ba_linearize_visual_win<true, kVWX><<<dim3(d.B), 64 * kVWX, h->vwinx_lds, h->stream>>>(w, which, which_state, cost_only, only_valid);
+    else if (h->any_ex) ba_linearize_visual<true><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(w, which, which_state, cost_only, only_valid);
+    else if (h->vwin_lds) ba_linearize_visual_win<false, kVW><<<dim3(d.B), 64 * kVW, h->vwin_lds, h->stream>>>(w, which, which_state, cost_only, only_valid);
     else ba_linearize_visual<false><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(w, which, which_state, cost_only, only_valid);
     if (timed) HIPCHK(hipEventRecord(h->ev[3], h->stream));
     if (!cost_only) ba_build_et<<<dim3(d.F, d.B), 64, 0, h->stream>>>(w, h->sbufs(), which, 0);
@@ -402,7 +404,8 @@ int run_marginalize(gf_ba* h, int mode) {
     wm.prior_preloaded = 0;   // marginalisation columns differ from the solver's: the prior is added explicitly
     wm.colf = h->mcolf[mode].d; wm.cole = h->mcole[mode].d; wm.order = h->morder[mode].d; wm.norder = h->mnorder[mode].d;
     ba_zero_other<<<dim3(d.B), 256, 0, h->stream>>>(w);
-    if (mode == 0) ba_linearize_visual<true><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(wm, -1, -2, 0, 2);
+    if (mode == 0 && h->vwinx_lds) ba_linearize_visual_win<true, kVWX><<<dim3(d.B), 64 * kVWX, h->vwinx_lds, h->stream>>>(wm, -1, -2, 0, 2);
+    else if (mode == 0) ba_linearize_visual<true><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(wm, -1, -2, 0, 2);
     if (mode == 0) ba_linearize_misc<false><<<dim3(2 * d.W, d.B), 64, 0, h->stream>>>(wm, -1, -2, 0, 2, 1, 0);
     if (mode == 0 && d.GO) ba_linearize_gnss<<<dim3((d.NG + 5 * d.W + 1 + 63) / 64, d.B), 64, 0, h->stream>>>(wm, -1, -2, 0, 2, 1);
     ba_linearize_misc<true><<<dim3(1, d.B), 256, 0, h->stream>>>(wm, -1, -2, 0, 2, 2, 2 * d.W);
@@ -472,10 +475,14 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     if (h->big_step) { h->sg_stride = (h->step_lds / sizeof(double) + 15) & ~(size_t)15; A_(h->Sg.alloc(B * h->sg_stride, false)); }
     if (h->big_marg) { h->mg_stride = (size_t)2 * h->marg_ncap * h->marg_ncap + 1024; A_(h->Mg.alloc(B * h->mg_stride, false)); }
     if (!h->big_step) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_step<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->step_lds));
-    {   // window-level visual sweep: staging areas of kVW wavefronts (static) + the compact visual system (dynamic)
-        const size_t nc = 6 * (size_t)d.NP + 2, dyn = nc * (nc + 1) / 2 * sizeof(double), stat = (size_t)kVW * kVHalf * sizeof(double) + kVW * 64 * sizeof(int) + 256;
-        h->vwin_lds = (dyn + stat <= 158 * 1024 && !getenv("GF_BA_CHUNKED_VISUAL")) ? dyn : 0;
-        if (h->vwin_lds) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_visual_win), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->vwin_lds));
+    {   // window-level sweeps: staging areas of the wavefronts (static) + the compact visual system (dynamic)
+        const bool chunked = getenv("GF_BA_CHUNKED_VISUAL") != nullptr;
+        const size_t dyn = vwin_acc_doubles(d.NP, false) * sizeof(double), stat = (size_t)kVW * vwin_half(false) * sizeof(double) + kVW * 64 * sizeof(int) + 256;
+        h->vwin_lds = (dyn + stat <= 158 * 1024 && !chunked) ? dyn : 0;
+        if (h->vwin_lds) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_visual_win<false, kVW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->vwin_lds));
+        const size_t dynx = vwin_acc_doubles(d.NP, true) * sizeof(double), statx = (size_t)kVWX * vwin_half(true) * sizeof(double) + kVWX * 64 * sizeof(int) + 256;
+        h->vwinx_lds = (dynx + statx <= 158 * 1024 && !chunked) ? dynx : 0;
+        if (h->vwinx_lds) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_visual_win<true, kVWX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->vwinx_lds));
         const size_t mdyn = misc_win_lds_doubles(d.W) * sizeof(double);
         h->mwin_lds = (mdyn + 512 <= 158 * 1024 && !getenv("GF_BA_CHUNKED_MISC")) ? mdyn : 0;
         if (h->mwin_lds) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_misc_win), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mwin_lds));

@@ -854,18 +854,23 @@ __device__ __forceinline__ int tri_row(int t) {  // largest i with i(i+1)/2 <= t
 // side; packed lower triangle), and only that copy -- one value per touched entry -- goes to H / g with global atomics at the end.
 // The chunked kernel issues ~100 global atomics per pair per chunk, most of them on the same few diagonal blocks; its run time is that
 // atomic traffic (103 us against 50 us for 256 windows of 1500 factors).  Dynamic LDS: (6 NP + 2)(6 NP + 3)/2 doubles.
-constexpr int kVW = 12;               // wavefronts per block (three per SIMD at the kernel's ~150 VGPRs)
-constexpr int kVHalf = 32 * 33;       // staging area of one wavefront: 32 factors x (2 rows x 16 columns + 1) doubles
-__global__ void __launch_bounds__(64 * kVW) ba_linearize_visual_win(Win w, int which, int which_state, int cost_only, int only_cand_valid) {
-    constexpr int LSTR = 33;
+constexpr int kVW = 12;               // wavefronts per block, fixed extrinsic (three per SIMD at the kernel's ~150 VGPRs)
+constexpr int kVWX = 6;               // wavefronts per block when the camera extrinsic carries columns (twice the staging area per wavefront)
+__host__ __device__ constexpr int vwin_half(bool ex) { return 32 * (ex ? 65 : 33); }   // staging area of one wavefront: 32 factors x (2 rows x COLS + 1) doubles
+__host__ __device__ inline size_t vwin_acc_doubles(int NP, bool ex) { const size_t nc = 6 * (size_t)NP + (ex ? 8 : 2); return nc * (nc + 1) / 2; }
+// EX: the camera extrinsic block has columns (free in the solve, or a kept block of the marginalisation): second 16-column tile, compact
+// columns 6 NP .. 6 NP + 5 in front of td and the right-hand side.
+template <bool EX, int NW>
+__global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, int which, int which_state, int cost_only, int only_cand_valid) {
+    constexpr int COLS = EX ? 32 : 16, LSTR = 2 * COLS + 1, HALF = vwin_half(EX);
     extern __shared__ __attribute__((aligned(16))) double v_acc[];   // packed lower triangle of the compact system
-    __shared__ double Jst[kVW * kVHalf];
-    __shared__ int s_pr[kVW][64];
-    __shared__ double s_cost[kVW];
+    __shared__ double Jst[NW * HALF];
+    __shared__ int s_pr[NW][64];
+    __shared__ double s_cost[NW];
     const Dims d = w.d;
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const SolverState& st = w.st[b];
-    if (st.done && only_cand_valid != 2) return;
+    if (st.done && only_cand_valid != 2) return;   // only_cand_valid == 2: marginalisation pass (runs on finished windows)
     if (only_cand_valid == 1 && !st.cand_valid) return;
     const int n_order = w.norder[b];
     if (n_order <= 0) return;
@@ -873,35 +878,40 @@ __global__ void __launch_bounds__(64 * kVW) ba_linearize_visual_win(Win w, int w
     if (which_state == -2) which_state = st.cur; else if (which_state < 0) which_state = 1 - st.cur;
     const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
     const int* colf = w.colf + (size_t)b * d.NFB;
-    const int TD = 6 * d.NP, RHS = 6 * d.NP + 1, NT = (RHS + 1) * (RHS + 2) / 2;
-    if (!cost_only) for (int i = tid; i < NT; i += 64 * kVW) v_acc[i] = 0.0;
+    const int EXC = 6 * d.NP, TD = EXC + (EX ? 6 : 0), RHS = TD + 1, NT = (RHS + 1) * (RHS + 2) / 2;
+    if (!cost_only) for (int i = tid; i < NT; i += 64 * NW) v_acc[i] = 0.0;
     __syncthreads();
-    double* Jbuf = Jst + wave * kVHalf;
+    double* Jbuf = Jst + wave * HALF;
     int* s_pair = s_pr[wave];
     double cost = 0.0;
     const int nchunks = (n_order + 63) / 64;
-    for (int ch = wave; ch < nchunks; ch += kVW) {
+    for (int ch = wave; ch < nchunks; ch += NW) {
         const int entry = ch * 64 + lane;
         const int k = entry < n_order ? w.order[(size_t)b * d.NVP + entry] : -1;
         int fi, fj;
         VisEval ev;
-        cost += vis_lane_eval<false>(w, d, b, which, k, cost_only, xs, colf, ev, fi, fj);
+        cost += vis_lane_eval<EX>(w, d, b, which, k, cost_only, xs, colf, ev, fi, fj);
         if (cost_only) continue;
         s_pair[lane] = k >= 0 ? fi * 64 + fj : -1;
-        d4 acc = {0, 0, 0, 0};
+        d4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
         int cur_pair = -1;
+        auto add = [&](int ca, int cb, double v) { if (v != 0.0) atomicAdd(&v_acc[max(ca, cb) * (max(ca, cb) + 1) / 2 + min(ca, cb)], v); };
         auto flush = [&](int pair) {
             if (pair < 0) return;
-            const int pi = pair >> 6, pj = pair & 63;   // pi < pj: a feature is observed in later frames than its start frame
+            const int pi = pair >> 6, pj = pair & 63;
             auto cm = [&](int t) -> int { return t < 6 ? 6 * pi + t : t < 12 ? 6 * pj + t - 6 : t == 12 ? TD : t == 13 ? RHS : -1; };
-            const int cb = cm(lane & 15);
+            const int tb = lane & 15, cb = cm(tb);
+            const int cb1 = (EX && tb < 6) ? EXC + tb : -1;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int ca = cm((lane >> 4) + 4 * r);
-                const double v = acc[r];
-                if (ca >= 0 && cb >= 0 && cb <= ca && v != 0.0) atomicAdd(&v_acc[ca * (ca + 1) / 2 + cb], v);
+                const int ta = (lane >> 4) + 4 * r, ca = cm(ta);
+                if (ca >= 0 && cb >= 0 && tb <= ta) add(ca, cb, acc00[r]);          // tile 0 x tile 0: each unordered pair once
+                if (EX) {
+                    if (ca >= 0 && cb1 >= 0) add(ca, cb1, acc01[r]);                  // tile 0 x extrinsic: disjoint column sets
+                    if (ta < 6 && cb1 >= 0 && tb <= ta) add(EXC + ta, cb1, acc11[r]);
+                }
             }
-            acc = d4{0, 0, 0, 0};
+            acc00 = d4{0, 0, 0, 0}; acc01 = d4{0, 0, 0, 0}; acc11 = d4{0, 0, 0, 0};
         };
         // the 64 block rows go through the staging area in two halves of 32 factors (lanes 0-31, then 32-63)
 #pragma unroll
@@ -910,9 +920,14 @@ __global__ void __launch_bounds__(64 * kVW) ba_linearize_visual_win(Win w, int w
             if ((lane >> 5) == half) {
                 const int l = lane & 31;
 #pragma unroll
-                for (int r = 0; r < 2; r++)
+                for (int r = 0; r < 2; r++) {
 #pragma unroll
-                    for (int c = 0; c < 16; c++) Jbuf[l * LSTR + r * 16 + c] = (c < 14) ? ev.row[r][c] : 0.0;
+                    for (int c = 0; c < 16; c++) Jbuf[l * LSTR + r * COLS + c] = (c < 14) ? ev.row[r][c] : 0.0;
+                    if (EX) {
+#pragma unroll
+                        for (int c = 0; c < 16; c++) Jbuf[l * LSTR + r * COLS + 16 + c] = (c < 6) ? ev.row[r][16 + c] : 0.0;
+                    }
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
             for (int m = 0; m < 16; m++) {
@@ -920,8 +935,13 @@ __global__ void __launch_bounds__(64 * kVW) ba_linearize_visual_win(Win w, int w
                 if (pair < 0) continue;
                 if (pair != cur_pair) { flush(cur_pair); cur_pair = pair; }
                 const int e = 2 * m + (lane >> 5), r = (lane >> 4) & 1, c = lane & 15;
-                const double a0 = Jbuf[e * LSTR + r * 16 + c];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc, 0, 0, 0);
+                const double a0 = Jbuf[e * LSTR + r * COLS + c];
+                acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc00, 0, 0, 0);
+                if (EX) {
+                    const double a1 = Jbuf[e * LSTR + r * COLS + 16 + c];
+                    acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a1, acc01, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc11, 0, 0, 0);
+                }
             }
         }
         flush(cur_pair);
@@ -929,21 +949,24 @@ __global__ void __launch_bounds__(64 * kVW) ba_linearize_visual_win(Win w, int w
     cost = wave_sum_f64(cost);
     if (lane == 0) s_cost[wave] = cost;
     __syncthreads();
-    if (tid == 0) { double c = 0; for (int q = 0; q < kVW; q++) c += s_cost[q]; atomicAdd(w.cost + (size_t)which * d.B + b, c); }
+    if (tid == 0) { double c = 0; for (int q = 0; q < NW; q++) c += s_cost[q]; atomicAdd(w.cost + (size_t)which * d.B + b, c); }
     if (cost_only) return;
     // ---- the window's visual normal equations -> H, g
     double* H = w.H + ((size_t)which * d.B + b) * d.RP * d.RP;
     double* g = w.g + ((size_t)which * d.B + b) * d.RP;
-    const int tdc = colf[fb_td(d.NP)];
-    for (int i = tid; i < NT; i += 64 * kVW) {
+    auto gcol = [&](int c) -> int {   // compact column -> column of the reduced system (-1: constant block)
+        const int base = c < EXC ? colf[fb_pose(c / 6)] : c < TD ? colf[fb_ex(d.NP)] : colf[fb_td(d.NP)];
+        return base < 0 ? -1 : c < EXC ? base + c % 6 : c < TD ? base + (c - EXC) : base;
+    };
+    for (int i = tid; i < NT; i += 64 * NW) {
         const double v = v_acc[i];
         if (v == 0.0) continue;
         const int a = tri_row(i), c2 = i - a * (a + 1) / 2;
         if (c2 >= RHS) continue;                                  // r^T r
-        const int cb0 = c2 == TD ? tdc : colf[fb_pose(c2 / 6)], cb = cb0 < 0 ? -1 : c2 == TD ? cb0 : cb0 + c2 % 6;
+        const int cb = gcol(c2);
         if (cb < 0) continue;
         if (a == RHS) { atomicAdd(g + cb, v); continue; }
-        const int ca0 = a == TD ? tdc : colf[fb_pose(a / 6)], ca = ca0 < 0 ? -1 : a == TD ? ca0 : ca0 + a % 6;
+        const int ca = gcol(a);
         if (ca < 0) continue;
         atomicAdd(H + (size_t)max(ca, cb) * d.RP + min(ca, cb), v);
     }
