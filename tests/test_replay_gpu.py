@@ -32,6 +32,9 @@ def test_replay_tool_writes_the_oracle_trajectory(tmp_path):
     d = str(tmp_path)
     n = st.export(d)
     exe = os.path.join(ROOT, "bin", "gf_replay")
+    if not os.path.exists(exe):      # normally built by __graft_entry__.build(); same toolchain on the GPU box
+        import build as gfbuild
+        gfbuild.build_tool(verbose=True)
     assert os.path.exists(exe), "bin/gf_replay is missing: run `python __graft_entry__.py` (build)"
     out = subprocess.run([exe, os.path.join(d, "config.yaml"), d, os.path.join(d, "vio.txt")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr
