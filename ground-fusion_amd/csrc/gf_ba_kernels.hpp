@@ -695,7 +695,7 @@ __device__ __forceinline__ double misc_mfma_accumulate(const double* Sg, const d
 
 // frame_filter: 0 all factors; 1 only IMU/wheel factors starting at frame 0 (MARGIN_OLD); 2 no IMU/wheel factor (MARGIN_SECOND_NEW)
 template <bool PRIOR>   // PRIOR: the 256-thread prior task; else one 64-thread block per IMU / wheel factor (own register budget and LDS footprint)
-__global__ void __launch_bounds__(PRIOR ? 256 : 64, PRIOR ? 1 : 3) ba_linearize_misc(Win w, int which, int which_state, int cost_only, int only_cand_valid, int frame_filter, int task_base) {
+__global__ void __launch_bounds__(PRIOR ? 256 : 64, PRIOR ? 1 : 2) ba_linearize_misc(Win w, int which, int which_state, int cost_only, int only_cand_valid, int frame_filter, int task_base) {
     __shared__ double sS[PRIOR ? 1 : 225];
     __shared__ double sJ[PRIOR ? 1 : 450];
     __shared__ double sSJ[PRIOR ? 1 : 450];
@@ -1217,7 +1217,6 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
     double* scale = sb.scale + (size_t)b * VS; double* diag = sb.diag + (size_t)b * VS; double* grad = sb.grad + (size_t)b * VS;
     double* gn = sb.gn + (size_t)b * VS; double* stepv = sb.step + (size_t)b * VS; double* u = sb.u + (size_t)b * VS; double* yv = sb.yv + (size_t)b * VS;
     double* Es = sb.Es + (size_t)b * d.FP * ECW;
-    double* rhs = sb.rhs + (size_t)b * RP;
     if (tid < ECW) s_cmap[tid] = compact_to_col(tid, colf, d.NP, R);
     GF_STAMP(0);
     // ---------------- accept / reject the candidate of the previous iteration

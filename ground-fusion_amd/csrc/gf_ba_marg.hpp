@@ -142,7 +142,6 @@ struct MargOut { double* J; double* r; };  // [B][NPRI*NPRI], [B][NPRI]
 template <bool GS>   // GS: A and V of the kept system live in global memory (sb.Mg) -- priors larger than 96 columns
 __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const MargInfo* info, MargOut out) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ double sred[512];
     __shared__ double sP[MPMAX * MPMAX], sPV[MPMAX * MPMAX], sPinv[MPMAX * MPMAX], sbp[MPMAX];
     __shared__ double s_c[64], s_s[64];
     __shared__ int s_p[64], s_q[64], s_flag, s_fastinv;
@@ -152,7 +151,7 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     if (!mi.valid) return;
     const SolverState& st = w.st[b];
     const int o = 1 - st.cur, RP = d.RP;
-    const int mp = mi.mp, NE = mi.nfe, n = mi.n, R = mp + n;
+    const int mp = mi.mp, NE = mi.nfe, n = mi.n;
     double* M = w.H + ((size_t)o * d.B + b) * RP * RP;
     double* bv = w.g + ((size_t)o * d.B + b) * RP;
     const int ECW = d.ECW;

@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(256) min_eig_kernel(const uint8_t* __restrict_
         const int x = reflect101(bx + tx - 1, g.w), y = reflect101(by + ty - 1, g.h);
         const uint8_t* p = img + (size_t)y * g.stride + x;
         const int a0 = p[-g.stride - 1], a1 = p[-g.stride], a2 = p[-g.stride + 1];
-        const int m0 = p[-1], m1 = p[0], m2 = p[1];
+        const int m0 = p[-1], m2 = p[1];
         const int c0 = p[g.stride - 1], c1 = p[g.stride], c2 = p[g.stride + 1];
         const float t0 = (float)(a2 - a0), t1 = (float)(m2 - m0), t2 = (float)(c2 - c0);
         const float dx = (t0 + t2) * f1 + t1 * f0;

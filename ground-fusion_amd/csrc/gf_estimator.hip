@@ -674,7 +674,7 @@ struct gf_estimator {
     }
     int optimization() {  // EST:2890-3636
         if (!ba) {
-            gf_ba_cfg bc{WINDOW_SIZE, cfg.max_features, cfg.max_visual, 1};
+            gf_ba_cfg bc{WINDOW_SIZE, cfg.max_features, cfg.max_visual, 1, 0};   // no GNSS front matter in this handle
             if (int rc = gf_ba_create(&bc, &ba)) return rc;
         }
         vector2double();
