@@ -11,5 +11,5 @@ for k in range(0, kdump + 1):
     tp = st.feed(est_o, k, tp)
     if k % 2: continue
     est_o.inputFeature(float(st.cam_t[k]), st.feature_frame(k))
-pickle.dump(dict(est_o.last_window), open("scripts/data/win_dump.pkl", "wb"))
+pickle.dump(dict(est_o.last_window), open("/tmp/win_dump.pkl", "wb"))
 print(est_o.last_summary)
