@@ -1072,33 +1072,36 @@ __device__ __forceinline__ void pose_plus(const double* x, const double* dl, dou
 __global__ void __launch_bounds__(64) ba_build_et(Win w, StepBufs sb, int which, int ignore_done) {
     const Dims d = w.d;
     const int b = blockIdx.y, f = blockIdx.x, lane = threadIdx.x;
+    // the kernel is a chain of dependent global loads (74 % of its wave cycles are parked on them): everything the early exits and the
+    // factor loop need from the first level is fetched before any of it is tested
     const SolverState& st = w.st[b];
-    if (st.done && !ignore_done) return;
-    if (!ignore_done && which < 0 && !st.cand_valid) return;
-    if (f >= w.nfeat[b]) return;
+    const int st_done = st.done, st_valid = st.cand_valid, st_cur = st.cur, nfeat = w.nfeat[b];
     const int e = w.cole[(size_t)b * d.F + f];
-    if (e < 0) return;
-    if (which < 0) which = 1 - st.cur;
+    const int p0 = w.feat_ptr[(size_t)b * (d.F + 1) + f], p1 = w.feat_ptr[(size_t)b * (d.F + 1) + f + 1];
+    if (st_done && !ignore_done) return;
+    if (!ignore_done && which < 0 && !st_valid) return;
+    if (f >= nfeat || e < 0) return;
+    if (which < 0) which = 1 - st_cur;
     const double* efac = w.efac + ((size_t)which * d.B + b) * d.NV * EF;
     double* Et = sb.Et + (((size_t)which * d.B + b) * d.FP + e) * d.ECW;
     for (int c = lane; c < d.ECW; c += 64) Et[c] = 0.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-    const int p0 = w.feat_ptr[(size_t)b * (d.F + 1) + f], p1 = w.feat_ptr[(size_t)b * (d.F + 1) + f + 1];
     double acc = 0;
     int fi = 0;
-    for (int p = p0; p < p1; p += 4) {   // four factors in flight: index, frame and product loads are issued before any is consumed
-        int kq[4], jq[4];
-        double ev[4];
+    constexpr int NF = 12;   // factors in flight: index, frame and product loads are issued before any is consumed (a track spans <= W frames)
+    for (int p = p0; p < p1; p += NF) {
+        int kq[NF], jq[NF];
+        double ev[NF];
 #pragma unroll
-        for (int q = 0; q < 4; q++) kq[q] = p + q < p1 ? w.feat_fac[(size_t)b * d.NV + p + q] : -1;
+        for (int q = 0; q < NF; q++) kq[q] = p + q < p1 ? w.feat_fac[(size_t)b * d.NV + p + q] : -1;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < NF; q++) {
             jq[q] = kq[q] >= 0 ? w.vis_j[(size_t)b * d.NV + kq[q]] : 0;
             ev[q] = (kq[q] >= 0 && lane < 21) ? efac[(size_t)kq[q] * EF + lane] : 0.0;
         }
-        if (kq[0] >= 0) fi = w.vis_i[(size_t)b * d.NV + kq[0]];
+        if (p == p0 && kq[0] >= 0) fi = w.vis_i[(size_t)b * d.NV + kq[0]];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < NF; q++) {
             if (kq[q] < 0) continue;
             if (lane < 6 || (lane >= 12 && lane < 21)) acc += ev[q];
             else if (lane < 12) Et[6 * jq[q] + lane - 6] = ev[q];
