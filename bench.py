@@ -246,7 +246,7 @@ def main():
                                          "16-B/lane loads (MI355X_MICROARCH.md, HBM section); not re-collected inside this run",
                          "algorithmic_bytes_per_launch": alg_bytes / launches,
                          "points_per_launch": st["lk_points"] / launches, "iterations_per_launch": st["lk_iterations"] / launches},
-            "roofline_jtj": {"kernel": "ba_linearize_visual", "bound": "mfma", "achieved": jtj_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            "roofline_jtj": {"kernel": "ba_linearize_visual_win", "bound": "mfma", "achieved": jtj_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                              "frac": jtj_tf / FP64_MFMA_PEAK_TF, "launch_ms": jtj_ms, "mfma_flops_per_launch": bs["jtj_flops"] / max(bs["jtj_launches"], 1),
                              "note": "kernel time includes the per-factor residual/Jacobian evaluation (FP64 VALU) that feeds the MFMA contraction"},
             "roofline_step": {"kernel": "ba_step", "bound": "mfma", "achieved": step_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": step_tf / FP64_MFMA_PEAK_TF,
