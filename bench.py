@@ -117,9 +117,9 @@ def cpu_baseline(frames_host, dt, wins, threads, ba_iters, repeat=4):
             "solves_only_per_s": threads / per_solve, "ms_track_frame_1core": 1e3 * per_frame, "ms_solve_marg_1core": 1e3 * per_solve, "wall_s": el}
 
 
-# lk_track_kernel HBM-side traffic per tracked point from the PMC passes committed under profiles/ (r01_c): FETCH_SIZE 118 634 KB and WRITE_SIZE 237 KB
-# per launch of 4864 points; FETCH_SIZE doubled per the gfx950 note of the micro-architecture guide
-LK_PMC_BYTES_PER_POINT = (2 * 118634.0 + 237.0) * 1024.0 / 4864.0
+# lk_track_kernel HBM-side traffic per tracked point from the PMC passes committed under profiles/ (r01_k, the final kernel of the round): FETCH_SIZE
+# 120 878 KB and WRITE_SIZE 240 KB per launch of 4864 points; FETCH_SIZE doubled per the gfx950 note of the micro-architecture guide
+LK_PMC_BYTES_PER_POINT = (2 * 120878.0 + 240.0) * 1024.0 / 4864.0
 
 
 def main():
@@ -241,7 +241,7 @@ def main():
             "host_ms_per_step": {k: st[k] / K for k in ("ms_host_pre", "ms_wait_lk", "ms_host_mid", "ms_wait_detect", "ms_host_post")},
             "roofline": {"kernel": "lk_track_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": LK_PMC_BYTES_PER_POINT * st["lk_points"] / launches, "launch_ms": lk_ms,
-                         "traffic_note": "PMC, separate rocprofv3 --pmc passes of the torch-free driver scripts/pmc_lk.py (profiles/r01_c_tracker_pmc_*.csv, 4864 points "
+                         "traffic_note": "PMC, separate rocprofv3 --pmc passes of the torch-free driver scripts/pmc_lk.py (profiles/r01_k_tracker_pmc_*.csv, 4864 points "
                                          "per launch): (2 x FETCH_SIZE + WRITE_SIZE) per point x points of this launch; the x2 is the gfx950 FETCH_SIZE correction for "
                                          "16-B/lane loads (MI355X_MICROARCH.md, HBM section); not re-collected inside this run",
                          "algorithmic_bytes_per_launch": alg_bytes / launches,
