@@ -374,9 +374,12 @@ int launch_linearize(gf_ba* h, int which, int which_state, int cost_only, int on
 // The fixed launch schedule of one batch solve: initial linearisation, then max_iters x (step, linearise candidate), final accept.
 int run_solve(gf_ba* h, int max_iters) {
     const Dims& d = h->d;
-    HIPCHK(hipMemcpyAsync(h->H.d, h->pri_H0.d, (size_t)d.B * d.RP * d.RP * sizeof(double), hipMemcpyDeviceToDevice, h->stream));   // buffer 0 <- prior
-    HIPCHK(hipMemsetAsync(h->g.d, 0, (size_t)d.B * d.RP * sizeof(double), h->stream));
-    HIPCHK(hipMemsetAsync(h->cost.d, 0, (size_t)2 * d.B * sizeof(double), h->stream));
+    if (d.RP <= 512) ba_reset_first<<<dim3(d.B), 512, 0, h->stream>>>(h->win());   // buffer 0 <- prior, g, cost <- 0
+    else {
+        HIPCHK(hipMemcpyAsync(h->H.d, h->pri_H0.d, (size_t)d.B * d.RP * d.RP * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemsetAsync(h->g.d, 0, (size_t)d.B * d.RP * sizeof(double), h->stream));
+        HIPCHK(hipMemsetAsync(h->cost.d, 0, (size_t)2 * d.B * sizeof(double), h->stream));
+    }
     if (int rc = launch_linearize(h, 0, 0, 0, 0, false)) return rc;
     Win w = h->win();
     StepBufs sb = h->sbufs();

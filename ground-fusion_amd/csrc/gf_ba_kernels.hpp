@@ -1194,6 +1194,36 @@ __device__ inline bool wave_chol16_inv(double* s_L, double* s_inv, double* s_rdi
     return good;
 }
 
+// Start of a solve: buffer 0 of the normal equations <- the prior (lower triangle of the first R rows: nothing else is ever read or
+// accumulated), g <- 0, both costs <- 0.  Replaces a full RP x RP device copy per window (75 MB for 256 windows) and two memsets.
+__global__ void __launch_bounds__(512) ba_reset_first(Win w) {
+    const Dims d = w.d;
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, RP = d.RP;
+    const int R = w.st[b].R;
+    double* Hc = w.H + (size_t)b * RP * RP;
+    const double* H0 = w.pri_H0 + (size_t)b * RP * RP;
+    for (int r0 = wave; r0 < R; r0 += 32) {   // four rows per wavefront in flight, two doubles per lane (rows are 128-B aligned)
+        double2 v[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int r = r0 + 8 * m;
+            const double2* src = reinterpret_cast<const double2*>(H0 + (size_t)min(r, R - 1) * RP);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int c2 = lane + 64 * q; v[m][q] = (r < R && 2 * c2 <= r && 2 * c2 < RP) ? src[c2] : make_double2(0.0, 0.0); }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int r = r0 + 8 * m;
+            if (r >= R) continue;
+            double2* dst = reinterpret_cast<double2*>(Hc + (size_t)r * RP);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int c2 = lane + 64 * q; if (2 * c2 <= r && 2 * c2 < RP) dst[c2] = v[m][q]; }
+        }
+    }
+    for (int i = tid; i < RP; i += 512) w.g[(size_t)b * RP + i] = 0.0;
+    if (tid == 0) { w.cost[b] = 0.0; w.cost[(size_t)d.B + b] = 0.0; }
+}
+
 // One 512-thread block per window: accept/reject of the previous candidate (trust_region_minimizer.cc), then the next
 // dogleg step (dogleg_strategy.cc): Jacobi scaling, Cauchy point, Gauss-Newton step through the Schur complement
 // (MFMA GEMM) and an LDS-resident blocked Cholesky, candidate point.  first: the call that follows the initial linearisation.
