@@ -15,14 +15,18 @@
 //   FeatureManager::*                              FM:43-110, :198-302, :669-934, :978-1010
 // Unsupported switches are rejected at create time: ESTIMATE_EXTRINSIC==2, USE_LINE, USE_PLANE, USE_MOTION, GNSS_ENABLE, STEREO, !USE_IMU.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
 #include <deque>
 #include <list>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/groundfusion_hip.h"
@@ -303,6 +307,61 @@ struct ImageFrame {  // initial/initial_alignment.h ImageFrame: only what the no
 
 }  // namespace
 
+// ---------------------------------------------------------------- many sequences, one batched solver (not in the reference)
+// Estimators of a group run their processImage on one host thread each; when one reaches ceres::Solve or the marginalisation it hands
+// its window to this rendezvous and sleeps.  As soon as every member that is still busy with its frame is asleep here, all waiting
+// windows go to the device in one gf_ba_solve / gf_ba_marginalize call of the shared handle -- the batched kernels see B windows per
+// launch although each Estimator keeps the reference's single-sequence control flow.  A member outside a group step (a frame that
+// waited for IMU data and is taken by a later inputIMU) is simply a batch of one.
+struct BatchSolver {
+    struct Req { int kind; gf_ba_window* w; int iters, mode; gf_ba_summary* sum; gf_ba_prior* prior; int rc; bool done; std::string err; };
+    gf_ba* ba = nullptr;
+    std::mutex m;
+    std::condition_variable cv;
+    int active = 0;                 // members currently inside a frame of a group step
+    std::vector<Req*> pending;
+    long long batches = 0, windows = 0, largest = 0;
+
+    int submit(Req& r) {
+        std::unique_lock<std::mutex> lk(m);
+        pending.push_back(&r);
+        maybe_run();
+        cv.wait(lk, [&] { return r.done; });
+        if (r.rc != GF_OK) gf::set_err(r.rc, "%s", r.err.c_str());   // the batch may have run on another thread: carry its message over
+        return r.rc;
+    }
+    void leave() { std::unique_lock<std::mutex> lk(m); active--; maybe_run(); }
+    // with the lock held: run everything that waits once nobody is left computing on the host
+    void maybe_run() {
+        if (pending.empty() || (int)pending.size() < active) return;
+        std::vector<Req*> reqs;
+        reqs.swap(pending);
+        for (int pass = 0; pass < 3; pass++) {   // solves, MARGIN_OLD, MARGIN_SECOND_NEW
+            std::vector<Req*> grp;
+            for (Req* r : reqs) if ((pass == 0 && r->kind == 0) || (pass > 0 && r->kind == 1 && r->mode == pass - 1)) grp.push_back(r);
+            if (grp.empty()) continue;
+            // the shared handle takes its iteration count per call: group by it (members of one group share a configuration)
+            std::vector<gf_ba_window> wins(grp.size());
+            for (size_t i = 0; i < grp.size(); i++) wins[i] = *grp[i]->w;
+            int rc;
+            if (pass == 0) {
+                std::vector<gf_ba_summary> sums(grp.size());
+                rc = gf_ba_solve(ba, wins.data(), (int)grp.size(), grp[0]->iters, sums.data());
+                for (size_t i = 0; i < grp.size(); i++) if (rc == GF_OK) *grp[i]->sum = sums[i];
+            } else {
+                std::vector<gf_ba_prior> pri(grp.size());
+                for (size_t i = 0; i < grp.size(); i++) pri[i] = *grp[i]->prior;
+                rc = gf_ba_marginalize(ba, wins.data(), (int)grp.size(), pass - 1, pri.data());
+                for (size_t i = 0; i < grp.size(); i++) if (rc == GF_OK) *grp[i]->prior = pri[i];
+            }
+            const std::string err = rc == GF_OK ? std::string() : std::string(gf_last_error());
+            for (Req* r : grp) { r->rc = rc; r->err = err; r->done = true; }
+            batches++; windows += (long long)grp.size(); largest = std::max(largest, (long long)grp.size());
+        }
+        cv.notify_all();
+    }
+};
+
 // ---------------------------------------------------------------- Estimator
 struct gf_estimator {
     gf_estimator_cfg cfg;
@@ -311,6 +370,7 @@ struct gf_estimator {
     enum { MARGIN_OLD = 0, MARGIN_SECOND_NEW = 1 };
     FeatureManager f_manager;
     gf_ba* ba = nullptr;
+    BatchSolver* group = nullptr;      // member of a gf_estimator_group: solves go through the group's shared handle
     gf_tracker* tracker = nullptr;
     // measurement queues (estimator.h:182-190)
     std::deque<std::pair<double, V3>> accBuf, gyrBuf, wheelVelBuf, wheelGyrBuf;
@@ -673,7 +733,7 @@ struct gf_estimator {
         return GF_OK;
     }
     int optimization() {  // EST:2890-3636
-        if (!ba) {
+        if (!ba && !group) {
             gf_ba_cfg bc{WINDOW_SIZE, cfg.max_features, cfg.max_visual, 1, 0};   // no GNSS front matter in this handle
             if (int rc = gf_ba_create(&bc, &ba)) return rc;
         }
@@ -754,7 +814,10 @@ struct gf_estimator {
         w.wh_i = wh_i.data(); w.wh_sum_dt = wh_sum_dt.data(); w.wh_delta_p = wh_dp.data(); w.wh_delta_q = wh_dq.data(); w.wh_jacobian = wh_J.data(); w.wh_covariance = wh_P.data();
         w.wh_lin = wh_lin.data(); w.wh_lin_vel = wh_lv.data(); w.wh_lin_gyr = wh_lg.data(); w.wh_vel_1 = wh_v1.data(); w.wh_gyr_1 = wh_g1.data();
         if (prior_valid) { w.prior_n = prior_n; w.prior_nblocks = (int)prior_block_id.size(); w.prior_block_id = prior_block_id.data(); w.prior_J = prior_J.data(); w.prior_r = prior_r.data(); w.prior_x0 = prior_x0.data(); }
-        if (int rc = gf_ba_solve(ba, &w, 1, cfg.num_iterations, &last_summary)) return rc;   // ceres::Solve, EST:3303-3318
+        if (group) {   // ceres::Solve, EST:3303-3318
+            BatchSolver::Req rq{0, &w, cfg.num_iterations, 0, &last_summary, nullptr, GF_OK, false, std::string()};
+            if (int rc = group->submit(rq)) return rc;
+        } else if (int rc = gf_ba_solve(ba, &w, 1, cfg.num_iterations, &last_summary)) return rc;
         n_optimizations++;
         if (int rc = double2vector()) return rc;                                            // :3327
         if (frame_count < WINDOW_SIZE) { wheelanomaly = false; return GF_OK; }
@@ -770,7 +833,10 @@ struct gf_estimator {
             std::vector<double> pJ((size_t)cap_n * cap_n), pr(cap_n), px0(16 * (WINDOW_SIZE + 1) + 64); std::vector<int> pid(cap_b);
             gf_ba_prior p{};
             p.cap_n = cap_n; p.cap_blocks = cap_b; p.block_id = pid.data(); p.J = pJ.data(); p.r = pr.data(); p.x0 = px0.data();
-            if (int rc = gf_ba_marginalize(ba, &w, 1, marginalization_flag, &p)) return rc;
+            if (group) {
+                BatchSolver::Req rq{1, &w, 0, marginalization_flag, nullptr, &p, GF_OK, false, std::string()};
+                if (int rc = group->submit(rq)) return rc;
+            } else if (int rc = gf_ba_marginalize(ba, &w, 1, marginalization_flag, &p)) return rc;
             prior_valid = p.valid != 0;
             if (p.valid) {
                 prior_n = p.n;
@@ -1072,6 +1138,113 @@ int gf_estimator_debug(gf_estimator* e, const char* op, const double* in, int n_
     if (n_out) *n_out = (int)o.size();
     if ((int)o.size() > cap_out) return gf::set_err(GF_ERR_CAPACITY, "debug op '%s' returns %d values", op, (int)o.size());
     if (out) std::copy(o.begin(), o.end(), out);
+    return GF_OK;
+}
+
+// ---------------------------------------------------------------- group of sequences on one batched solver
+struct gf_estimator_group {
+    std::vector<gf_estimator*> mem;
+    BatchSolver solver;
+    int device = 0;
+    std::vector<std::thread> thr;
+    std::mutex m;
+    std::condition_variable cv_go, cv_done;
+    long long gen = 0;
+    int remaining = 0;
+    bool stop = false;
+    std::vector<char> has;
+    std::vector<double> t;
+    std::vector<std::vector<gf_feature_obs>> frames;
+    std::vector<int> rcs;
+    std::vector<std::string> errs;
+
+    void worker(int i) {
+        (void)hipSetDevice(device);   // the device is a per-thread setting; whichever member closes a rendezvous launches the batch
+        long long seen = 0;
+        for (;;) {
+            bool mine;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_go.wait(lk, [&] { return gen != seen || stop; });
+                if (stop) return;
+                seen = gen; mine = has[i] != 0;
+            }
+            if (!mine) continue;
+            const int rc = gf_estimator_input_feature(mem[i], t[i], frames[i].data(), (int)frames[i].size());
+            rcs[i] = rc;
+            if (rc != GF_OK) errs[i] = gf_last_error();
+            solver.leave();
+            std::unique_lock<std::mutex> lk(m);
+            if (--remaining == 0) cv_done.notify_all();
+        }
+    }
+    ~gf_estimator_group() {
+        { std::unique_lock<std::mutex> lk(m); stop = true; }
+        cv_go.notify_all();
+        for (auto& th : thr) if (th.joinable()) th.join();
+        for (gf_estimator* e : mem) delete e;
+        if (solver.ba) gf_ba_destroy(solver.ba);
+    }
+};
+
+int gf_estimator_group_create(const gf_estimator_cfg* c, int n, gf_estimator_group** out) {
+    if (!c || !out || n < 1 || n > 4096) return gf::set_err(GF_ERR_INVALID, "bad argument (1 <= n <= 4096)");
+    if (c->with_tracker) return gf::set_err(GF_ERR_INVALID, "group members take feature frames (cfg.with_tracker = 0); run one batched gf_tracker next to the group");
+    gf_estimator_group* g = new gf_estimator_group();
+    for (int i = 0; i < n; i++) {
+        gf_estimator* e = nullptr;
+        if (int rc = gf_estimator_create(c, &e)) { delete g; return rc; }
+        e->group = &g->solver;
+        g->mem.push_back(e);
+    }
+    gf_ba_cfg bc{c->window_size, c->max_features, c->max_visual, n, 0};
+    if (int rc = gf_ba_create(&bc, &g->solver.ba)) { delete g; return rc; }
+    (void)hipGetDevice(&g->device);
+    g->has.assign(n, 0); g->t.assign(n, 0.0); g->frames.resize(n); g->rcs.assign(n, GF_OK); g->errs.resize(n);
+    for (int i = 0; i < n; i++) g->thr.emplace_back([g, i] { g->worker(i); });
+    *out = g;
+    return GF_OK;
+}
+int gf_estimator_group_destroy(gf_estimator_group* g) { delete g; return GF_OK; }
+int gf_estimator_group_member(gf_estimator_group* g, int i, gf_estimator** out) {
+    if (!g || !out || i < 0 || i >= (int)g->mem.size()) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    *out = g->mem[i];
+    return GF_OK;
+}
+int gf_estimator_group_input_features(gf_estimator_group* g, int count, const int* seq, const double* t, const gf_feature_obs* obs, const int* n_obs) {
+    if (!g || count < 0 || (count > 0 && (!seq || !t || !n_obs))) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    if (count == 0) return GF_OK;
+    const int n = (int)g->mem.size();
+    std::vector<char> seen(n, 0);
+    size_t off = 0;
+    {
+        std::unique_lock<std::mutex> lk(g->m);
+        std::fill(g->has.begin(), g->has.end(), 0);
+        for (int k = 0; k < count; k++) {
+            const int i = seq[k];
+            if (i < 0 || i >= n || seen[i] || n_obs[k] < 0 || (n_obs[k] > 0 && !obs)) return gf::set_err(GF_ERR_INVALID, "sequence index %d out of range, listed twice, or without observations", i);
+            seen[i] = 1;
+            g->has[i] = 1; g->t[i] = t[k]; g->frames[i].assign(obs + off, obs + off + n_obs[k]); g->rcs[i] = GF_OK;
+            off += (size_t)n_obs[k];
+        }
+        { std::unique_lock<std::mutex> sl(g->solver.m); g->solver.active = count; }
+        g->remaining = count;
+        g->gen++;
+    }
+    g->cv_go.notify_all();
+    {
+        std::unique_lock<std::mutex> lk(g->m);
+        g->cv_done.wait(lk, [&] { return g->remaining == 0; });
+    }
+    for (int k = 0; k < count; k++) if (g->rcs[seq[k]] != GF_OK) return gf::set_err(g->rcs[seq[k]], "sequence %d: %s", seq[k], g->errs[seq[k]].c_str());
+    return GF_OK;
+}
+int gf_estimator_group_stats(gf_estimator_group* g, long long* batches, long long* windows, long long* largest) {
+    if (!g) return gf::set_err(GF_ERR_INVALID, "null handle");
+    std::unique_lock<std::mutex> lk(g->solver.m);
+    if (batches) *batches = g->solver.batches;
+    if (windows) *windows = g->solver.windows;
+    if (largest) *largest = g->solver.largest;
     return GF_OK;
 }
 

@@ -527,3 +527,55 @@ def write_pgm(path, img):
     with open(path, "wb") as f:
         f.write(b"P5\n%d %d\n%d\n" % (img.shape[1], img.shape[0], 255 if img.dtype == np.uint8 else 65535))
         f.write(img.tobytes() if img.dtype == np.uint8 else img.astype(">u2").tobytes())
+
+
+# ------------------------------------------------------------------ many sequences on one batched solver (gf_estimator_group_*)
+class EstimatorGroup:
+    """n Estimators sharing one batched back-end handle; members are SlidingWindowEstimator views (IMU / wheel input, state queries)."""
+
+    def __init__(self, cfg, n):
+        self.cfg, self.n = cfg, n
+        self.g = C.c_void_p()
+        _chk(lib().gf_estimator_group_create(C.byref(cfg), n, C.byref(self.g)))
+        self.members = []
+        for i in range(n):
+            m = SlidingWindowEstimator.__new__(SlidingWindowEstimator)
+            m.cfg, m.W, m.h = cfg, cfg.window_size, C.c_void_p()
+            _chk(lib().gf_estimator_group_member(self.g, i, C.byref(m.h)))
+            m.close = lambda: None          # owned by the group
+            self.members.append(m)
+
+    def close(self):
+        if getattr(self, "g", None):
+            for m in self.members:
+                m.h = None
+            lib().gf_estimator_group_destroy(self.g)
+            self.g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def inputFeatures(self, seqs, ts, images):
+        """one frame {feature_id: 8-vector} per listed sequence; all of them are processed concurrently, their solves as one batch"""
+        tot = sum(len(im) for im in images)
+        obs = (FeatureObs * max(tot, 1))()
+        k = 0
+        for im in images:
+            for i in sorted(im):
+                obs[k].id, obs[k].camera_id = int(i), 0
+                v = np.asarray(im[i], np.float64).reshape(-1)
+                for j in range(8):
+                    obs[k].v[j] = v[j]
+                k += 1
+        sq = np.ascontiguousarray(seqs, np.int32)
+        tt = np.ascontiguousarray(ts, np.float64)
+        no = np.ascontiguousarray([len(im) for im in images], np.int32)
+        _chk(lib().gf_estimator_group_input_features(self.g, len(sq), _p(sq, C.c_int), _p(tt, C.c_double), obs, _p(no, C.c_int)))
+
+    def stats(self):
+        b, w, l = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+        _chk(lib().gf_estimator_group_stats(self.g, C.byref(b), C.byref(w), C.byref(l)))
+        return {"batches": b.value, "windows": w.value, "largest_batch": l.value}

@@ -284,6 +284,18 @@ int gf_estimator_get_prior(gf_estimator* h, int cap_n, int cap_blocks, int* n, i
 /* single host-side steps by name (FeatureManager members, slideWindow, ...) for unit tests; see gf_estimator.hip */
 int gf_estimator_debug(gf_estimator* h, const char* op, const double* in, int n_in, double* out, int cap_out, int* n_out);
 
+/* ---- many sequences on one batched solver (not in the reference; the batched counterpart of gf_estimator_*) -------------------------------
+ * n Estimators that keep the reference's single-sequence control flow and share one gf_ba handle of batch n: whenever the members that
+ * are busy with a frame have all reached ceres::Solve or the marginalisation, their windows go to the device in one call.  Members take
+ * feature frames (run one batched gf_tracker next to the group); IMU / wheel samples and state queries go through the member handles. */
+typedef struct gf_estimator_group gf_estimator_group;
+int gf_estimator_group_create(const gf_estimator_cfg* cfg, int n, gf_estimator_group** out);
+int gf_estimator_group_destroy(gf_estimator_group* g);
+int gf_estimator_group_member(gf_estimator_group* g, int i, gf_estimator** out);   /* owned by the group */
+/* Estimator::inputFeature on each listed sequence, concurrently; obs = the frames back to back, n_obs[k] entries for seq[k] */
+int gf_estimator_group_input_features(gf_estimator_group* g, int count, const int* seq, const double* t, const gf_feature_obs* obs, const int* n_obs);
+int gf_estimator_group_stats(gf_estimator_group* g, long long* batches, long long* windows, long long* largest_batch);
+
 /* ---- ROS-free I/O around the path: config files, trajectory output, raw frames ---------------------------------------- */
 /* readParameters(std::string config_file), vins_estimator/src/estimator/parameters.cpp:138-558, plus the cam0_calib file it names
  * (PinholeCamera::Parameters::readFromYamlFile, camera_models/src/camera_models/PinholeCamera.cc:145-183; path relative to the config

@@ -123,3 +123,44 @@ def test_replay_images_with_tracker_feedback():
     roundings of poses that agree to ~1e-8 only."""
     worst = _image_replay(0, 2.0)
     assert worst["p"] < 1e-6 and worst["r"] < 1e-6, worst
+
+
+def test_group_of_sequences_on_one_batched_solver():
+    """gf_estimator_group_*: four sequences keep the reference's per-sequence control flow on host threads while their solves and
+    marginalisations reach the device as one batch; every member must end up where a stand-alone Estimator on the same inputs does."""
+    n = 4
+    streams = []
+    for s in range(n):
+        st = SS.Stream(1 + s, t_still=1.5, t_move=1.6, v_max=0.4, yaw0=0.0, yaw_turn=-0.4 + 0.2 * s, split_x=1.8, turn_delay=0.6)
+        st._lm = st._landmarks(900)
+        st._pn = np.random.default_rng(4100 + s).normal(0, 1.0, (len(st.cam_t), len(st._lm), 2))
+        streams.append(st)
+    cfg = gfamd.default_estimator_cfg(tio=SS.TIO, rio=SS.RIO, multiple_thread=1)
+    grp = gfamd.EstimatorGroup(cfg, n)
+    solo = [gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(tio=SS.TIO, rio=SS.RIO, multiple_thread=1)) for _ in range(n)]
+    tp = [-1.0] * n
+    nk = min(len(st.cam_t) for st in streams)
+    worst = 0.0
+    for k in range(nk):
+        for s, st in enumerate(streams):
+            st.feed(grp.members[s], k, tp[s])
+            tp[s] = st.feed(solo[s], k, tp[s])
+        if k % 2:
+            continue
+        frames = [st.feature_frame(k) for st in streams]
+        grp.inputFeatures(list(range(n)), [float(st.cam_t[k]) for st in streams], frames)
+        for s in range(n):
+            solo[s].inputFeature(float(streams[s].cam_t[k]), frames[s])
+            a, b = grp.members[s].state(), solo[s].state()
+            assert a["frame_count"] == b["frame_count"] and a["solver_flag"] == b["solver_flag"] and a["marginalization_flag"] == b["marginalization_flag"], (k, s)
+            assert a["iterations"] == b["iterations"] and a["successful_steps"] == b["successful_steps"], (k, s)
+            assert list(grp.members[s].features()["id"]) == list(solo[s].features()["id"]), (k, s)
+            worst = max(worst, float(np.abs(a["Ps"] - b["Ps"]).max()), rot_angle(a["Rs"], b["Rs"]))
+    st = grp.stats()
+    print("group of %d: worst deviation from stand-alone estimators %.2e; %s" % (n, worst, st))
+    assert all(m.state()["solver_flag"] == 1 for m in grp.members)
+    assert worst < 1e-6
+    assert st["largest_batch"] == n and st["windows"] > 2 * st["batches"]      # the solves really went out together
+    grp.close()
+    for e in solo:
+        e.close()
