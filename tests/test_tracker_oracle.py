@@ -116,6 +116,15 @@ def test_capi_library_exports_every_declared_symbol():
     assert set(gfamd.EXPORTS) <= declared
 
 
+def test_header_is_plain_c(tmp_path):
+    """the boundary is a C ABI: include/groundfusion_hip.h must compile as C99 (no C++, no torch types in the signatures)"""
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    src = tmp_path / "t.c"
+    src.write_text('#include "include/groundfusion_hip.h"\nint main(void) { gf_estimator_cfg c; gf_ba_window w; (void)c; (void)w; return 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", root, str(src)])
+
+
 def test_no_cpu_fallback_without_gpu():
     import gfamd
     if gfamd.device_count() > 0:
