@@ -182,3 +182,18 @@ def test_rejects_unbuilt_configurations():
         gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(estimate_extrinsic=2))
     with pytest.raises(gfamd.GfError):
         gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(window_size=40))
+
+
+def test_group_argument_checks_and_no_cpu_fallback():
+    """gf_estimator_group_*: argument errors are reported before any device work; without a GPU creation fails loudly (the shared
+    back-end handle needs the device), it never degrades to a host solver"""
+    with pytest.raises(gfamd.GfError) as e:
+        gfamd.EstimatorGroup(gfamd.default_estimator_cfg(), 0)
+    assert "1 <= n" in str(e.value)
+    with pytest.raises(gfamd.GfError) as e:
+        gfamd.EstimatorGroup(gfamd.default_estimator_cfg(with_tracker=1), 2)
+    assert "with_tracker" in str(e.value)
+    if gfamd.device_count() == 0:
+        with pytest.raises(gfamd.GfError) as e:
+            gfamd.EstimatorGroup(gfamd.default_estimator_cfg(), 2)
+        assert "no HIP device" in str(e.value) or "HIP" in str(e.value)
