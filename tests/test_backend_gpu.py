@@ -180,6 +180,31 @@ def test_lds_and_global_reduced_system_agree(gf, oracle, monkeypatch):
     assert np.abs(A1.T @ A1 - A2.T @ A2).max() <= 1e-9 * np.abs(A1.T @ A1).max()
 
 
+@pytest.mark.parametrize("drop", ["visual", "inertial"])
+def test_windows_without_a_factor_family(gf, oracle, drop):
+    """ragged inputs: a window without a single visual factor (vision failure: IMU + wheel only) and one without IMU / wheel factors
+    (sum_dt > 10 skips them, estimator.cpp:3114-3132): same solve and marginalisation as the oracle"""
+    w = SW.make_window(5, oracle)
+    keys = [k for k in w if isinstance(w[k], np.ndarray) and (k.startswith("vis_") if drop == "visual" else (k.startswith("imu_") or k.startswith("wh_")))]
+    for k in keys:
+        w[k] = w[k][:0]
+    if drop == "visual":
+        w["para_Feature"], w["feature_fixed"] = w["para_Feature"][:0], w["feature_fixed"][:0]
+    wo, wg = w.copy(), w.copy()
+    so = oracle.ba_solve(wo, 6)
+    est = gf.Estimator()
+    sg = est.solve([wg], 6)[0]
+    assert (sg["iterations"], sg["successful_steps"]) == (so["iterations"], so["successful_steps"])
+    assert abs(sg["final_cost"] - so["final_cost"]) <= 1e-7 * max(so["final_cost"], 1.0)
+    dp, dr = _pose_diff(wo, wg)
+    assert dp < 1e-6 and dr < 1e-6, (dp, dr)
+    po, pg = oracle.ba_marginalize(wo, 0), est.marginalize([wo.copy()], 0)[0]
+    assert pg is not None and list(pg["block_id"]) == list(po["block_id"]) and pg["n"] == po["n"]
+    Ao, Ag = po["J"].reshape(po["n"], -1), pg["J"].reshape(pg["n"], -1)
+    assert np.abs(Ao.T @ Ao - Ag.T @ Ag).max() <= 1e-6 * np.abs(Ao.T @ Ao).max()
+    est.close()
+
+
 def test_window_level_and_chunked_sweeps_agree(gf, oracle, monkeypatch):
     """ba_linearize_visual_win / ba_linearize_misc_win (one block per window, LDS accumulation, matrix-core whitening) against the chunked
     kernels they replace in the solve (still used for marginalisation, a free camera extrinsic and long windows): same normal equations up to
