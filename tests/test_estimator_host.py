@@ -197,3 +197,26 @@ def test_group_argument_checks_and_no_cpu_fallback():
         with pytest.raises(gfamd.GfError) as e:
             gfamd.EstimatorGroup(gfamd.default_estimator_cfg(), 2)
         assert "no HIP device" in str(e.value) or "HIP" in str(e.value)
+
+
+def test_empty_and_sparse_feature_frames():
+    """ragged inputs: frames without a single observation (vision failure) and frames with a handful of features, mixed into the fill
+    phase -- keyframe votes, track bookkeeping and propagated states stay equal to the oracle's"""
+    st, est_o, est_p = make_pair(4)
+    tp, k = -1.0, 0
+    while est_o.frame_count < est_o.W:
+        kk = k * STRIDE
+        for e in (est_o, est_p):
+            t1 = st.feed(e, kk, tp)
+        tp = t1
+        frame = st.feature_frame(kk)
+        if k in (2, 5):
+            frame = {}
+        elif k in (3, 6):
+            frame = {i: frame[i] for i in sorted(frame)[:3]}
+        for e in (est_o, est_p):
+            e.inputFeature(float(st.cam_t[kk]), frame)
+        compare_state(est_o, est_p)
+        compare_features(est_o, est_p)
+        k += 1
+    assert est_o.frame_count == est_o.W
