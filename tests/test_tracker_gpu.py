@@ -90,6 +90,26 @@ def test_good_features_degenerate_images(gf, oracle):
     assert len(gf.good_features(img, 50, mask=allmasked)) == 0 == len(oracle.good_features(img, 50, mask=allmasked))
 
 
+def test_track_image_through_featureless_and_saturated_frames(gf, oracle):
+    """empty inputs: frames without any corner (no track exists, LK runs on zero points), then texture, then a saturated frame whose tracks
+    the brightness test (> 250, feature_tracker.cpp:160-163) drops, then texture again -- ids and observations stay bit-exact"""
+    tex = _frames(1003, 3)
+    flat = np.full(tex[0].shape, 128, np.uint8)
+    white = np.full(tex[0].shape, 255, np.uint8)
+    seq = [flat, flat, tex[0], tex[1], white, tex[2], flat]
+    depth = np.full(flat.shape, 1500, np.uint16)
+    otr, gtr = oracle.Tracker(oracle.default_cfg()), gf.FeatureTracker(gf.default_cfg())
+    counts = []
+    for k, f in enumerate(seq):
+        oi, oo = otr.track(0.0666 * k, f, depth)
+        gi, go = gtr.trackImage(0.0666 * k, f, depth)
+        assert np.array_equal(oi, gi), "frame %d: feature id lists differ" % k
+        assert np.array_equal(oo.view(np.uint64), go.view(np.uint64)), "frame %d: observations differ" % k
+        counts.append(len(gi))
+    assert counts[0] == 0 and counts[1] == 0 and counts[2] > 100 and counts[3] > 100
+    gtr.close()
+
+
 @pytest.mark.parametrize("max_cnt,min_dist", [(150, 30), (300, 20), (500, 12)])
 def test_track_image_sequence_bit_exact_ids(gf, oracle, max_cnt, min_dist):
     frames = _frames(1000, 8)
