@@ -60,7 +60,7 @@ struct gf_ba {
     Buf<double> vis_data, imu_data, wh_data, pri_J, pri_r, pri_x0;
     Buf<SolverState> st, st0;
     // work
-    Buf<double> imu_sqrt, wh_sqrt, pri_A, pri_b, pri_c, pri_H0, H, g, cost, efac;
+    Buf<double> imu_sqrt, wh_sqrt, pri_A, pri_b, pri_c, H, g, Vc, vtile, wpar, cost, efac;
     Buf<double> scale, diag, grad, gn, step, u, Et, Es, ete, etb, rhs, yv, Sg, Mg, gn_data, gn_misc;
     Buf<int> ngnss, gn_idx;
     // marginalisation: column maps per mode (0 MARGIN_OLD, 1 MARGIN_SECOND_NEW), outputs
@@ -69,12 +69,14 @@ struct gf_ba {
     Buf<long long> stamps;
     std::vector<std::vector<int>> keep_ids[2];   // per window: kept block ids (before the address shift), in column order
     size_t marg_lds = 0; int marg_ncap = 0, last_marg_mode = -1;
-    size_t vwin_lds = 0;   // > 0: the window-level visual sweep (ba_linearize_visual_win) fits LDS; its dynamic size
+    size_t vwin_lds = 0;   // dynamic LDS of the visual sweep (its pair tiles); 0: the tiles live in global memory (vtile)
     size_t vwinx_lds = 0;  // the same for the variant with camera-extrinsic columns (free extrinsic; MARGIN_OLD sweep)
-    size_t mwin_lds = 0;   // > 0: the window-level IMU / wheel sweep (ba_linearize_misc_win) fits LDS; its dynamic size
+    size_t vtile_stride = 0;   // doubles per window in vtile (0: both variants keep their tiles in LDS)
+    size_t mwin_lds = 0;   // dynamic LDS of the prior / IMU / wheel sweep (ba_linearize_misc_win)
     long long mfma_per_lin = 0;   // v_mfma_f64_16x16x4 instructions of one visual linearisation of the resident batch
+    long long jtj_alg_flops = 0;  // algorithmic flops of the same: Nv * 2 * 2 * (12 * 13 / 2 + 12 + 1) per window
     long long step_flops = 0;     // dense algebra of one ba_step over the resident batch: Schur SYRK NE*n_c^2 + Cholesky R^3/3 + substitutions 2 R^2
-    std::vector<Buf<double>*> dbl() { return {&xs0, &xs, &vis_data, &imu_data, &wh_data, &pri_J, &pri_r, &pri_x0, &imu_sqrt, &wh_sqrt, &pri_A, &pri_b, &pri_c, &pri_H0, &H, &g, &cost, &efac,
+    std::vector<Buf<double>*> dbl() { return {&xs0, &xs, &vis_data, &imu_data, &wh_data, &pri_J, &pri_r, &pri_x0, &imu_sqrt, &wh_sqrt, &pri_A, &pri_b, &pri_c, &H, &g, &Vc, &vtile, &wpar, &cost, &efac,
                                               &scale, &diag, &grad, &gn, &step, &u, &Et, &Es, &ete, &etb, &rhs, &yv, &Sg, &Mg, &gn_data, &gn_misc}; }
     std::vector<Buf<int>*> ints() { return {&colf, &cole, &nvis, &nimu, &nwh, &nfeat, &vis_feat, &vis_i, &vis_j, &order, &norder, &feat_ptr, &feat_fac, &imu_i, &wh_i, &pri_n, &pri_nb, &pri_bid, &ngnss, &gn_idx}; }
     void release() {
@@ -96,8 +98,8 @@ struct gf_ba {
         w.ngnss = ngnss.d; w.gn_idx = gn_idx.d; w.gn_data = gn_data.d; w.gn_misc = gn_misc.d;
         w.feat_ptr = feat_ptr.d; w.feat_fac = feat_fac.d; w.imu_i = imu_i.d; w.imu_data = imu_data.d; w.wh_i = wh_i.d; w.wh_data = wh_data.d;
         w.imu_sqrt = imu_sqrt.d; w.wh_sqrt = wh_sqrt.d; w.pri_n = pri_n.d; w.pri_nb = pri_nb.d; w.pri_bid = pri_bid.d; w.pri_J = pri_J.d; w.pri_r = pri_r.d;
-        w.pri_x0 = pri_x0.d; w.pri_H0 = pri_H0.d; w.prior_preloaded = 1; w.pri_A = pri_A.d; w.pri_b = pri_b.d; w.pri_c = pri_c.d; w.H = H.d; w.g = g.d; w.cost = cost.d; w.efac = efac.d; w.st = st.d;
-        w.G[0] = G[0]; w.G[1] = G[1]; w.G[2] = G[2]; w.vis_sqrt_info = vis_sqrt_info;
+        w.pri_x0 = pri_x0.d; w.pri_A = pri_A.d; w.pri_b = pri_b.d; w.pri_c = pri_c.d; w.H = H.d; w.g = g.d; w.Vc = Vc.d; w.cost = cost.d; w.efac = efac.d; w.st = st.d;
+        w.wpar = wpar.d; w.vtile = nullptr; w.vtile_stride = vtile_stride;
         return w;
     }
     StepBufs sbufs() {
@@ -106,8 +108,6 @@ struct gf_ba {
         s.rhs = rhs.d; s.yv = yv.d; s.VS = d.RP + d.FP; s.stamps = stamps.d; s.Sg = Sg.d; s.SgStride = sg_stride; s.Mg = Mg.d; s.MgStride = mg_stride;
         return s;
     }
-    double G[3] = {0, 0, 9.805};
-    double vis_sqrt_info = 400.0;
 };
 
 namespace {
@@ -116,7 +116,7 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
     const Dims& d = h->d;
     if (count < 1 || count > d.B) return gf::set_err(GF_ERR_INVALID, "count %d outside 1..%d", count, d.B);
     h->any_ex = false;
-    h->mfma_per_lin = 0; h->step_flops = 0;
+    h->mfma_per_lin = 0; h->step_flops = 0; h->jtj_alg_flops = 0;
     for (int b = 0; b < d.B; b++) {
         const gf_ba_window& w = ws[std::min(b, count - 1)];  // unused slots replicate the last window (kernels run on the whole batch)
         if (w.W != d.W) return gf::set_err(GF_ERR_INVALID, "window %d: W=%d, handle built for %d", b, w.W, d.W);
@@ -125,7 +125,7 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
         if (w.gnss_enabled && (!d.GO || w.n_gnss > d.NG)) return gf::set_err(GF_ERR_CAPACITY, "window %d: %d GNSS factors, handle built for %d (gf_ba_cfg.max_gnss)", b, w.n_gnss, d.NG);
         if (w.gnss_enabled && (!w.para_rcv_dt || !w.para_rcv_ddt || !w.para_yaw_enu_local || !w.para_anc_ecef || !w.gnss_headers || !w.gnss_iono || (w.n_gnss > 0 && (!w.gnss_frame || !w.gnss_lower || !w.gnss_sys || !w.gnss_ratio || !w.gnss_data))))
             return gf::set_err(GF_ERR_INVALID, "window %d: GNSS enabled but a GNSS array is null", b);
-        if (b == 0) { h->G[0] = w.G[0]; h->G[1] = w.G[1]; h->G[2] = w.G[2]; h->vis_sqrt_info = w.vis_sqrt_info; }
+        { double* wp = h->wpar.h + 4 * (size_t)b; wp[0] = w.G[0]; wp[1] = w.G[1]; wp[2] = w.G[2]; wp[3] = w.vis_sqrt_info; }   // gravity and visual sqrt_info are per window (estimator.h `g`)
         double* x = h->xs0.h + (size_t)b * d.XS;
         memset(x, 0, d.XS * sizeof(double));
         for (int i = 0; i < d.NP; i++) { memcpy(x + off_pose(i), w.para_Pose + 7 * i, 56); memcpy(x + off_sb(i), w.para_SpeedBias + 9 * i, 72); }
@@ -181,7 +181,7 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
         std::vector<char> used(std::max(w.n_feature, 1), 0);
         for (int k = 0; k < w.n_visual; k++) {
             const size_t kk = (size_t)b * d.NV + k;
-            if (w.vis_feature[k] < 0 || w.vis_feature[k] >= w.n_feature || w.vis_i[k] < 0 || w.vis_i[k] > d.W || w.vis_j[k] < 0 || w.vis_j[k] > d.W)
+            if (w.vis_feature[k] < 0 || w.vis_feature[k] >= w.n_feature || w.vis_i[k] < 0 || w.vis_i[k] >= w.vis_j[k] || w.vis_j[k] > d.W)   // frame i is the feature's start frame: i < j
                 return gf::set_err(GF_ERR_INVALID, "window %d: visual factor %d has bad indices", b, k);
             h->vis_feat.h[kk] = w.vis_feature[k]; h->vis_i.h[kk] = w.vis_i[k]; h->vis_j.h[kk] = w.vis_j[k];
             double* vd = h->vis_data.h + kk * 12;
@@ -206,14 +206,14 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
             for (size_t p = 0; p < idx.size();) {
                 size_t q = p;
                 const int key = w.vis_i[idx[p]] * 64 + w.vis_j[idx[p]];
-                while (q < idx.size() && w.vis_i[idx[q]] * 64 + w.vis_j[idx[q]] == key) ord[n++] = idx[q++];
+                while (q < idx.size() && w.vis_i[idx[q]] * 64 + w.vis_j[idx[q]] == key) ord[n++] = (key << 16) | idx[q++];   // pair key (i * 64 + j) above the factor index
                 if ((q - p) & 1) ord[n++] = -1;
                 p = q;
             }
             if (n > d.NVP) return gf::set_err(GF_ERR_CAPACITY, "factor order overflow");
             h->norder.h[b] = n;
             for (int i = n; i < d.NVP; i++) ord[i] = -1;
-            if (b < count) h->mfma_per_lin += (long long)(n / 2) * (w.fix_ex_pose ? 1 : 3);
+            if (b < count) { h->mfma_per_lin += (long long)(n / 2) * (w.fix_ex_pose ? 1 : 3); h->jtj_alg_flops += (long long)w.n_visual * 4 * 91; }
         }
         {   // CSR feature -> factors
             int* fp = h->feat_ptr.h + (size_t)b * (d.F + 1);
@@ -313,7 +313,7 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
                 std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return w.vis_j[a] < w.vis_j[c]; });
                 for (size_t p = 0; p < idx.size();) {
                     size_t q = p;
-                    while (q < idx.size() && w.vis_j[idx[q]] == w.vis_j[idx[p]]) ord[no++] = idx[q++];
+                    while (q < idx.size() && w.vis_j[idx[q]] == w.vis_j[idx[p]]) ord[no++] = (w.vis_j[idx[p]] << 16) | idx[q++];   // pair (0, j)
                     if ((q - p) & 1) ord[no++] = -1;
                     p = q;
                 }
@@ -332,7 +332,7 @@ int upload(gf_ba* h) {
     for (auto* b : {&h->colf, &h->cole, &h->nvis, &h->nimu, &h->nwh, &h->nfeat, &h->vis_feat, &h->vis_i, &h->vis_j, &h->order, &h->norder, &h->feat_ptr, &h->feat_fac,
                     &h->imu_i, &h->wh_i, &h->pri_n, &h->pri_nb, &h->pri_bid})
         HIPCHK(b->up(s));
-    for (auto* b : {&h->vis_data, &h->imu_data, &h->wh_data, &h->pri_J, &h->pri_r, &h->pri_x0}) HIPCHK(b->up(s));
+    for (auto* b : {&h->vis_data, &h->imu_data, &h->wh_data, &h->pri_J, &h->pri_r, &h->pri_x0, &h->wpar}) HIPCHK(b->up(s));
     if (h->d.GO) { HIPCHK(h->ngnss.up(s)); HIPCHK(h->gn_idx.up(s)); HIPCHK(h->gn_data.up(s)); HIPCHK(h->gn_misc.up(s)); }
     for (int m = 0; m < 2; m++) for (auto* b : {&h->mcolf[m], &h->mcole[m], &h->morder[m], &h->mnorder[m], &h->minfo[m]}) HIPCHK(b->up(s));
     HIPCHK(hipMemcpyAsync(h->st0.d, h->st0.h, h->st0.n * sizeof(SolverState), hipMemcpyHostToDevice, s));
@@ -348,23 +348,29 @@ int reset_state(gf_ba* h) {
     return GF_OK;
 }
 
-int launch_linearize(gf_ba* h, int which, int which_state, int cost_only, int only_valid, bool timed) {
+// One linearisation of the resident batch at the state buffer `which_state` into the buffers `which` (-1: the candidate's).
+// Visual sweep (Vc, E^T F rows) on the main stream; prior / IMU / wheel (H, g) and the GNSS blocks on the second one.  Every buffer
+// has one writing kernel and every sum a fixed order: no zeroing or reset passes, no atomics.
+int launch_visual(gf_ba* h, Win w, bool ex, int which, int which_state, int only_valid) {
+    const Dims& d = h->d;
+    const size_t lds = ex ? h->vwinx_lds : h->vwin_lds;
+    w.vtile = lds ? nullptr : h->vtile.d;
+    if (ex) ba_linearize_visual_win<true, kVWX><<<dim3(d.B), 64 * kVWX, lds, h->stream>>>(w, h->sbufs(), which, which_state, only_valid);
+    else ba_linearize_visual_win<false, kVW><<<dim3(d.B), 64 * kVW, lds, h->stream>>>(w, h->sbufs(), which, which_state, only_valid);
+    HIPCHK(hipGetLastError());
+    return GF_OK;
+}
+
+int launch_linearize(gf_ba* h, int which, int which_state, int only_valid, bool timed) {
     const Dims& d = h->d;
     Win w = h->win();
-    HIPCHK(hipEventRecord(h->ev_fork, h->stream));   // everything enqueued so far (state, zeroed buffers) precedes the forked work
+    HIPCHK(hipEventRecord(h->ev_fork, h->stream));   // everything enqueued so far (the state) precedes the forked work
     if (timed) HIPCHK(hipEventRecord(h->ev[2], h->stream));
-    if (h->any_ex && h->vwinx_lds) ba_linearize_visual_win<true, kVWX><<<dim3(d.B), 64 * kVWX, h->vwinx_lds, h->stream>>>(w, which, which_state, cost_only, only_valid);
-    else if (h->any_ex) ba_linearize_visual<true><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(w, which, which_state, cost_only, only_valid);
-    else if (h->vwin_lds) ba_linearize_visual_win<false, kVW><<<dim3(d.B), 64 * kVW, h->vwin_lds, h->stream>>>(w, which, which_state, cost_only, only_valid);
-    else ba_linearize_visual<false><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(w, which, which_state, cost_only, only_valid);
+    if (int rc = launch_visual(h, w, h->any_ex, which, which_state, only_valid)) return rc;
     if (timed) HIPCHK(hipEventRecord(h->ev[3], h->stream));
-    if (!cost_only) ba_build_et<<<dim3(d.F, d.B), 64, 0, h->stream>>>(w, h->sbufs(), which, 0);
-    // IMU / wheel / prior factors only share the atomically accumulated H, g, cost with the visual sweep: second stream
     HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-    if (h->mwin_lds) ba_linearize_misc_win<<<dim3(d.B), 64 * kMW, h->mwin_lds, h->stream2>>>(w, which, which_state, cost_only, only_valid);
-    else ba_linearize_misc<false><<<dim3(2 * d.W, d.B), 64, 0, h->stream2>>>(w, which, which_state, cost_only, only_valid, 0, 0);
-    ba_linearize_misc<true><<<dim3(1, d.B), 256, 0, h->stream2>>>(w, which, which_state, cost_only, only_valid, 0, 2 * d.W);
-    if (d.GO) ba_linearize_gnss<<<dim3((d.NG + 5 * d.W + 1 + 63) / 64, d.B), 64, 0, h->stream2>>>(w, which, which_state, cost_only, only_valid, 0);
+    ba_linearize_misc_win<<<dim3(d.B), 64 * kMW, h->mwin_lds, h->stream2>>>(w, which, which_state, only_valid, 0);
+    if (d.GO) ba_linearize_gnss<<<dim3((d.NG + 5 * d.W + 1 + 63) / 64, d.B), 64, 0, h->stream2>>>(w, which, which_state, 0, only_valid, 0);
     HIPCHK(hipEventRecord(h->ev_join, h->stream2));
     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
     HIPCHK(hipGetLastError());
@@ -374,13 +380,7 @@ int launch_linearize(gf_ba* h, int which, int which_state, int cost_only, int on
 // The fixed launch schedule of one batch solve: initial linearisation, then max_iters x (step, linearise candidate), final accept.
 int run_solve(gf_ba* h, int max_iters) {
     const Dims& d = h->d;
-    if (d.RP <= 512) ba_reset_first<<<dim3(d.B), 512, 0, h->stream>>>(h->win());   // buffer 0 <- prior, g, cost <- 0
-    else {
-        HIPCHK(hipMemcpyAsync(h->H.d, h->pri_H0.d, (size_t)d.B * d.RP * d.RP * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemsetAsync(h->g.d, 0, (size_t)d.B * d.RP * sizeof(double), h->stream));
-        HIPCHK(hipMemsetAsync(h->cost.d, 0, (size_t)2 * d.B * sizeof(double), h->stream));
-    }
-    if (int rc = launch_linearize(h, 0, 0, 0, 0, false)) return rc;
+    if (int rc = launch_linearize(h, 0, 0, 0, false)) return rc;
     Win w = h->win();
     StepBufs sb = h->sbufs();
     for (int it = 0; it <= max_iters; it++) {
@@ -391,9 +391,9 @@ int run_solve(gf_ba* h, int max_iters) {
         HIPCHK(hipGetLastError());
         if (time_step) { HIPCHK(hipEventRecord(h->ev[7], h->stream)); h->stats.step_launches++; h->stats.step_flops += h->step_flops; }
         if (it < max_iters) {
-            // candidate state lives in buffer (1 - cur) of each window: linearise both ... the kernels pick the right one per window
-            if (int rc = launch_linearize(h, -1, -1, 0, 1, it == 0)) return rc;
-            if (it == 0) { h->stats.jtj_launches++; h->stats.jtj_flops += h->mfma_per_lin * 2048; }
+            // candidate state lives in buffer (1 - cur) of each window: the kernels pick the right one per window
+            if (int rc = launch_linearize(h, -1, -1, 1, it == 0)) return rc;
+            if (it == 0) { h->stats.jtj_launches++; h->stats.jtj_flops += h->mfma_per_lin * 2048; h->stats.jtj_alg_flops += h->jtj_alg_flops; }
         }
     }
     h->stats.solves += h->count;
@@ -403,19 +403,15 @@ int run_solve(gf_ba* h, int max_iters) {
 int run_marginalize(gf_ba* h, int mode) {
     const Dims& d = h->d;
     Win w = h->win();
-    Win wm = w;
-    wm.prior_preloaded = 0;   // marginalisation columns differ from the solver's: the prior is added explicitly
+    Win wm = w;   // marginalisation column maps: dropped blocks first, no block constant
     wm.colf = h->mcolf[mode].d; wm.cole = h->mcole[mode].d; wm.order = h->morder[mode].d; wm.norder = h->mnorder[mode].d;
-    ba_zero_other<<<dim3(d.B), 256, 0, h->stream>>>(w);
-    if (mode == 0 && h->vwinx_lds) ba_linearize_visual_win<true, kVWX><<<dim3(d.B), 64 * kVWX, h->vwinx_lds, h->stream>>>(wm, -1, -2, 0, 2);
-    else if (mode == 0) ba_linearize_visual<true><<<dim3(d.NVP / 64, d.B), 64, 0, h->stream>>>(wm, -1, -2, 0, 2);
-    if (mode == 0) ba_linearize_misc<false><<<dim3(2 * d.W, d.B), 64, 0, h->stream>>>(wm, -1, -2, 0, 2, 1, 0);
+    // the dropped frame's factors are linearised at the current state into the other buffer set
+    if (mode == 0) { if (int rc = launch_visual(h, wm, true, -1, -2, 2)) return rc; }
+    ba_linearize_misc_win<<<dim3(d.B), 64 * kMW, h->mwin_lds, h->stream>>>(wm, -1, -2, 2, mode == 0 ? 1 : 2);
     if (mode == 0 && d.GO) ba_linearize_gnss<<<dim3((d.NG + 5 * d.W + 1 + 63) / 64, d.B), 64, 0, h->stream>>>(wm, -1, -2, 0, 2, 1);
-    ba_linearize_misc<true><<<dim3(1, d.B), 256, 0, h->stream>>>(wm, -1, -2, 0, 2, 2, 2 * d.W);
-    ba_build_et<<<dim3(d.F, d.B), 64, 0, h->stream>>>(wm, h->sbufs(), -1, 1);
     MargOut mo{h->outJ.d, h->outr.d};
-    if (h->big_marg) ba_marg_finish<true><<<dim3(d.B), 512, 0, h->stream>>>(wm, h->sbufs(), reinterpret_cast<const MargInfo*>(h->minfo[mode].d), mo);
-    else ba_marg_finish<false><<<dim3(d.B), 512, h->marg_lds, h->stream>>>(wm, h->sbufs(), reinterpret_cast<const MargInfo*>(h->minfo[mode].d), mo);
+    if (h->big_marg) ba_marg_finish<true><<<dim3(d.B), 512, 0, h->stream>>>(wm, h->sbufs(), reinterpret_cast<const MargInfo*>(h->minfo[mode].d), mo, mode == 0 ? 1 : 0);
+    else ba_marg_finish<false><<<dim3(d.B), 512, h->marg_lds, h->stream>>>(wm, h->sbufs(), reinterpret_cast<const MargInfo*>(h->minfo[mode].d), mo, mode == 0 ? 1 : 0);
     HIPCHK(hipGetLastError());
     return GF_OK;
 }
@@ -438,10 +434,12 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     const bool gnss = cfg->max_gnss > 0;
     d.NG = gnss ? ((cfg->max_gnss + 63) & ~63) : 0;
     const int Rmax = 15 * d.NP + 17 + (gnss ? 5 * d.NP + 3 : 0);
-    d.RP = (Rmax + 1 + 15) & ~15; /* one spare column: the Schur GEMM carries the right-hand side in column R */ d.GO = gnss ? ((16 * d.NP + 20 + d.F + 3) & ~3) : 0; d.XS = gnss ? ((d.GO + 5 * d.NP + 4 + 3) & ~3) : ((16 * d.NP + 20 + d.F + 3) & ~3); d.NFB = 2 * d.NP + 7 + (gnss ? 5 * d.NP + 2 : 0); d.FP = (d.F + 3) & ~3; d.NPRI = d.RP; d.ECW = (6 * d.NP + 8 + 15) & ~15;
+    d.RP = (Rmax + 1 + 15) & ~15; /* one spare column: the Schur GEMM carries the right-hand side in column R */ d.GO = gnss ? ((16 * d.NP + 20 + d.F + 3) & ~3) : 0; d.XS = gnss ? ((d.GO + 5 * d.NP + 4 + 3) & ~3) : ((16 * d.NP + 20 + d.F + 3) & ~3); d.NFB = 2 * d.NP + 7 + (gnss ? 5 * d.NP + 2 : 0); d.FP = (d.F + 3) & ~3; d.NPRI = d.RP; d.ECW = (6 * d.NP + 8 + 15) & ~15; d.NC = 6 * d.NP + 8; d.NVC = (d.NC * (d.NC + 1) / 2 + 3) & ~3;
     h->step_lds = (size_t)(Rmax + 1) * (Rmax + 2) / 2 * sizeof(double);  // packed lower S plus the right-hand-side row
-    h->big_step = h->step_lds + 16 * 1024 > 160 * 1024 || getenv("GF_BA_FORCE_GLOBAL") != nullptr;   // reduced system too large for LDS: ba_step<true> keeps it in global memory
+    h->big_step = h->step_lds + 27 * 1024 > 160 * 1024 || getenv("GF_BA_FORCE_GLOBAL") != nullptr;   // reduced system too large for LDS: ba_step<true> keeps it in global memory
     if (Rmax + 1 > 512) { delete h; return gf::set_err(GF_ERR_INVALID, "window_size %d: reduced system (%d) exceeds 511 columns", d.W, Rmax); }
+    if (d.NV > 65535) { delete h; return gf::set_err(GF_ERR_INVALID, "max_visual %d exceeds 65535", d.NV); }
+    if (misc_win_lds_doubles(d.W) * sizeof(double) + 10 * 1024 > 160 * 1024) { delete h; return gf::set_err(GF_ERR_INVALID, "window_size %d: the IMU / wheel block rows exceed LDS (window_size <= 20 in this build)", d.W); }
 #define A_(x) do { if (int rc_ = (x)) { h->release(); delete h; return rc_; } } while (0)
 #define H_(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { gf::set_err(GF_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); h->release(); delete h; return GF_ERR_HIP; } } while (0)
     H_(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -463,7 +461,9 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     }
     h->st.n = h->st0.n = B;
     A_(h->imu_sqrt.alloc(B * d.W * 225, false)); A_(h->wh_sqrt.alloc(B * d.W * 36, false)); A_(h->pri_A.alloc(B * d.NPRI * d.NPRI, false)); A_(h->pri_b.alloc(B * d.NPRI, false));
-    A_(h->pri_c.alloc(B, false)); A_(h->pri_H0.alloc(B * d.RP * d.RP, false)); A_(h->H.alloc(2 * B * d.RP * d.RP, true)); A_(h->g.alloc(2 * B * d.RP, true)); A_(h->cost.alloc(2 * B, true)); A_(h->efac.alloc(2 * B * d.NV * EF, false));
+    A_(h->pri_c.alloc(B, false)); A_(h->H.alloc(2 * B * d.RP * d.RP, true)); A_(h->g.alloc(2 * B * d.RP, true)); A_(h->Vc.alloc(2 * B * d.NVC, true)); A_(h->wpar.alloc(B * 4, true));
+    A_(h->cost.alloc(6 * B, true)); A_(h->efac.alloc(2 * B * d.NV * EF, false));
+    H_(hipMemsetAsync(h->cost.d, 0, 6 * B * sizeof(double), h->stream));
     A_(h->scale.alloc(B * VS, false)); A_(h->diag.alloc(B * VS, false)); A_(h->grad.alloc(B * VS, false)); A_(h->gn.alloc(B * VS, false)); A_(h->step.alloc(B * VS, false));
     A_(h->u.alloc(B * VS, false)); A_(h->Et.alloc(2 * B * d.FP * d.ECW, true)); A_(h->Es.alloc(B * d.FP * d.ECW, false)); A_(h->ete.alloc(2 * B * d.FP, true)); A_(h->etb.alloc(2 * B * d.FP, true));
     A_(h->rhs.alloc(B * d.RP, false)); A_(h->yv.alloc(B * VS, false));
@@ -478,17 +478,17 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     if (h->big_step) { h->sg_stride = (h->step_lds / sizeof(double) + 15) & ~(size_t)15; A_(h->Sg.alloc(B * h->sg_stride, false)); }
     if (h->big_marg) { h->mg_stride = (size_t)2 * h->marg_ncap * h->marg_ncap + 1024; A_(h->Mg.alloc(B * h->mg_stride, false)); }
     if (!h->big_step) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_step<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->step_lds));
-    {   // window-level sweeps: staging areas of the wavefronts (static) + the compact visual system (dynamic)
-        const bool chunked = getenv("GF_BA_CHUNKED_VISUAL") != nullptr;
-        const size_t dyn = vwin_acc_doubles(d.NP, false) * sizeof(double), stat = (size_t)kVW * vwin_half(false) * sizeof(double) + kVW * 64 * sizeof(int) + 256;
-        h->vwin_lds = (dyn + stat <= 158 * 1024 && !chunked) ? dyn : 0;
+    {   // window-level sweeps: staging areas of the wavefronts (static LDS) + pair tiles / block rows (dynamic LDS, or global memory for long windows)
+        const bool glob = getenv("GF_BA_GLOBAL_TILES") != nullptr;   // test switch: pair tiles in global memory also where they fit LDS
+        const size_t dyn = vwin_slot_doubles(d.NP, false) * sizeof(double), stat = (size_t)kVW * vwin_sg(false) * vwin_lstr(false) * sizeof(double) + kVW * 64 * sizeof(int) + 512;
+        h->vwin_lds = (dyn + stat <= 160 * 1024 && !glob) ? dyn : 0;
         if (h->vwin_lds) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_visual_win<false, kVW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->vwin_lds));
-        const size_t dynx = vwin_acc_doubles(d.NP, true) * sizeof(double), statx = (size_t)kVWX * vwin_half(true) * sizeof(double) + kVWX * 64 * sizeof(int) + 256;
-        h->vwinx_lds = (dynx + statx <= 158 * 1024 && !chunked) ? dynx : 0;
+        const size_t dynx = vwin_slot_doubles(d.NP, true) * sizeof(double), statx = (size_t)kVWX * vwin_sg(true) * vwin_lstr(true) * sizeof(double) + kVWX * 64 * sizeof(int) + 512;
+        h->vwinx_lds = (dynx + statx <= 160 * 1024 && !glob) ? dynx : 0;
         if (h->vwinx_lds) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_visual_win<true, kVWX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->vwinx_lds));
-        const size_t mdyn = misc_win_lds_doubles(d.W) * sizeof(double);
-        h->mwin_lds = (mdyn + 512 <= 158 * 1024 && !getenv("GF_BA_CHUNKED_MISC")) ? mdyn : 0;
-        if (h->mwin_lds) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_misc_win), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mwin_lds));
+        if (!h->vwin_lds || !h->vwinx_lds) { h->vtile_stride = (vwin_slot_doubles(d.NP, true) + 3) & ~(size_t)3; A_(h->vtile.alloc(B * h->vtile_stride, false)); }
+        h->mwin_lds = misc_win_lds_doubles(d.W) * sizeof(double);
+        H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_misc_win), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mwin_lds));
     }
     if (!h->big_marg) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_marg_finish<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds));
     H_(hipStreamSynchronize(h->stream));
@@ -632,16 +632,15 @@ int gf_ba_linearize(gf_ba* h, const gf_ba_window* w, int cap, double* Hout, doub
     if (int rc = gf_ba_upload(h, w, 1)) return rc;
     if (int rc = reset_state(h)) return rc;
     const Dims& d = h->d;
-    HIPCHK(hipMemcpyAsync(h->H.d, h->pri_H0.d, (size_t)d.B * d.RP * d.RP * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(hipMemsetAsync(h->g.d, 0, (size_t)d.B * d.RP * sizeof(double), h->stream));
-    HIPCHK(hipMemsetAsync(h->cost.d, 0, (size_t)2 * d.B * sizeof(double), h->stream));
-    if (int rc = launch_linearize(h, 0, 0, 0, 0, false)) return rc;
-    // run the accept/eliminated-column phase of ba_step once (finalize_only) to materialise ete / etb / Et
-    if (h->big_step) ba_step<true><<<dim3(d.B), 512, 0, h->stream>>>(h->win(), h->sbufs(), 1, 1, 1);
-    else ba_step<false><<<dim3(d.B), 512, h->step_lds, h->stream>>>(h->win(), h->sbufs(), 1, 1, 1);
-    HIPCHK(hipGetLastError());
-    HIPCHK(h->H.down(h->stream)); HIPCHK(h->g.down(h->stream)); HIPCHK(h->cost.down(h->stream)); HIPCHK(h->Et.down(h->stream)); HIPCHK(h->ete.down(h->stream)); HIPCHK(h->etb.down(h->stream));
+    if (int rc = launch_linearize(h, 0, 0, 0, false)) return rc;
+    HIPCHK(h->H.down(h->stream)); HIPCHK(h->g.down(h->stream)); HIPCHK(h->Vc.down(h->stream)); HIPCHK(h->cost.down(h->stream)); HIPCHK(h->Et.down(h->stream)); HIPCHK(h->ete.down(h->stream)); HIPCHK(h->etb.down(h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    {   // H, g <- H + Vc, g + Vc's right-hand-side row: what ba_step assembles
+        const int RHSK = 6 * d.NP + 7;
+        auto ccol = [&](int k) -> int { const int* cf = h->colf.h; if (k < 6 * d.NP) { const int c0 = cf[fb_pose(k / 6)]; return c0 >= 0 ? c0 + k % 6 : -1; } if (k < 6 * d.NP + 6) { const int c0 = cf[fb_ex(d.NP)]; return c0 >= 0 ? c0 + k - 6 * d.NP : -1; } return cf[fb_td(d.NP)]; };
+        for (int ka = 0; ka < RHSK; ka++) for (int kb = 0; kb <= ka; kb++) { const int r = ccol(ka), c = ccol(kb); if (r >= 0 && c >= 0) h->H.h[(size_t)std::max(r, c) * d.RP + std::min(r, c)] += h->Vc.h[(size_t)ka * (ka + 1) / 2 + kb]; }
+        for (int kb = 0; kb < RHSK; kb++) { const int c = ccol(kb); if (c >= 0) h->g.h[c] += h->Vc.h[(size_t)RHSK * (RHSK + 1) / 2 + kb]; }
+    }
     const SolverState& st = h->st0.h[0];
     const int R = st.R, NE = st.NE, n = R + NE;
     if (n > cap) return gf::set_err(GF_ERR_CAPACITY, "capacity %d < %d columns", cap, n);
@@ -658,7 +657,7 @@ int gf_ba_linearize(gf_ba* h, const gf_ba_window* w, int cap, double* Hout, doub
             if (c >= 0) { Hout[(size_t)(R + e) * n + c] = h->Et.h[(size_t)e * d.ECW + k]; Hout[(size_t)c * n + R + e] = h->Et.h[(size_t)e * d.ECW + k]; }
         }
     }
-    *cost = h->cost.h[0]; *n_f = R; *n_e = NE;
+    *cost = (h->cost.h[0] + h->cost.h[2 * (size_t)d.B]) + h->cost.h[4 * (size_t)d.B]; *n_f = R; *n_e = NE;
     if (col_block_id) {
         const int* cf = h->colf.h;
         for (int i = 0; i < d.NP; i++) { if (cf[fb_pose(i)] >= 0) for (int q = 0; q < 6; q++) col_block_id[cf[fb_pose(i)] + q] = GF_POSE * 4096 + i; if (cf[fb_sb(i)] >= 0) for (int q = 0; q < 9; q++) col_block_id[cf[fb_sb(i)] + q] = GF_SPEEDBIAS * 4096 + i; }

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(64) ba_linearize_gnss(Win w, int which, int wh
     const int* colf = w.colf + (size_t)b * d.NFB;
     double* H = w.H + ((size_t)which * d.B + b) * d.RP * d.RP;
     double* g = w.g + ((size_t)which * d.B + b) * d.RP;
-    double* cost = w.cost + (size_t)which * d.B + b;
+    double* cost = cost_part(w, 2, which, b);
     const int NP = d.NP, W = d.W;
     auto cof = [&](int fb, int o) { const int c0 = colf[fb]; return c0 >= 0 ? c0 + o : -1; };
     if (item == d.NG + 5 * W) {   // PoseAnchorFactor, sqrt_info 120 (pose_anchor_factor.h:19); only in the solve

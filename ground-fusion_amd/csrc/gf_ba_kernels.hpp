@@ -1,11 +1,13 @@
 // gf_ba_kernels.hpp — gfx950 device code of the sliding-window back end (Estimator::optimization()).
 //
-// Batched over independent windows (grid.y / grid.x = window).  Per LM iteration:
-//   ba_linearize_visual : one lane per ProjectionTwoFrameOneCamFactor (residual, analytic Jacobian, Huber corrector),
-//                         block rows staged in LDS, J^T J / J^T r of each frame pair contracted with
-//                         v_mfma_f64_16x16x4_f64 and scattered into the dense normal equations
-//   ba_linearize_misc   : IMU / wheel factors (one wavefront each) and the marginalisation prior
-//   ba_step             : Jacobi scaling, dogleg (Cauchy point, Schur complement via MFMA, blocked Cholesky), candidate
+// Batched over independent windows (one block per window).  Per LM iteration:
+//   ba_linearize_visual_win : one lane per ProjectionTwoFrameOneCamFactor (residual, analytic Jacobian, Huber corrector), block rows staged
+//                             in LDS, J^T J / J^T r of each frame pair contracted with v_mfma_f64_16x16x4_f64 into per-pair tiles, tiles
+//                             reduced in a fixed order into the window's compact visual system Vc; E^T F rows of the free inverse depths
+//   ba_linearize_misc_win   : the marginalisation prior, IMU and wheel factors: the only writer of H / g (prior gathered, factor tiles
+//                             added in parity phases)
+//   ba_step                 : S = s (H + Vc) s, Jacobi scaling, dogleg (Cauchy point, Schur complement via MFMA, blocked Cholesky), candidate
+// Every sum has a fixed order (no floating-point atomics anywhere): two runs of the same input give bit-identical results.
 // Semantics: reference factors (file:line cited per function) + Ceres 1.14 trust_region_minimizer.cc / dogleg_strategy.cc.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -18,13 +20,15 @@ using namespace gfd;
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 struct Dims {
-    int B, W, NP, F, NV, NVP, RP, XS, NFB, FP, NPRI, ECW, GO, NG;
+    int B, W, NP, F, NV, NVP, RP, XS, NFB, FP, NPRI, ECW, GO, NG, NC, NVC;
     // NP = W+1 poses; NVP = padded length of the pair-sorted factor order; RP = padded reduced dimension (multiple of 16);
     // XS = state vector stride; NFB = 2*NP + 7 non-feature parameter blocks; FP = F rounded up to 4; NPRI = prior capacity (= RP)
     // ECW = width of the compact rows of the eliminated columns: a feature only touches pose blocks, the camera extrinsic and td
     //       (compact column 6i+q = pose i, 6NP+q = ex_pose, 6NP+6 = td, 6NP+7 = right-hand-side slot), rounded up to 16
     // GO  = offset of the GNSS states in the state vector (rcv_dt 4NP, rcv_ddt NP, yaw 1, anc_ecef 3), 0: handle built without GNSS
     // NG  = capacity of GnssPsrDoppFactor per window
+    // NC  = 6 NP + 8 compact columns of the visual system Vc (pose blocks, camera extrinsic, td, right-hand side: the layout of the compact
+    //       rows above); NVC = stride of one packed lower triangle NC (NC + 1) / 2 (entry (RHS, RHS) is unused: the cost travels separately)
 };
 __host__ __device__ inline int off_pose(int i) { return 16 * i; }
 __host__ __device__ inline int off_sb(int i) { return 16 * i + 7; }
@@ -74,15 +78,15 @@ struct Win {  // device view of the whole batch
     const int* pri_n; const int* pri_nb; const int* pri_bid;  // [B], [B], [B][64]
     const double* pri_J; const double* pri_r; const double* pri_x0;  // [B][NPRI*NPRI], [B][NPRI], [B][NPRI*2]
     double* pri_A; double* pri_b; double* pri_c;  // J0^T J0, J0^T r0, r0^T r0
-    double* pri_H0;           // [B][RP*RP] the prior's J0^T J0 scattered to the solver's columns (lower triangle): initial value of every H buffer
-    double* H;                // [2][B][RP*RP]
-    double* g;                // [2][B][RP]
-    double* cost;             // [2][B]
+    double* H;                // [2][B][RP*RP] prior + IMU + wheel (+ GNSS) part of the normal equations, lower triangle of the first R rows (ba_linearize_misc_win)
+    double* g;                // [2][B][RP]    the same part of J^T r
+    double* Vc;               // [2][B][NVC]   visual part, compact columns, packed lower triangle, row RHS = J^T r (ba_linearize_visual_win)
+    double* cost;             // [3][2][B]     cost parts: prior + IMU + wheel, visual, GNSS; added in this order
     double* efac;             // [2][B][NV][EF]
     SolverState* st;          // [B]
-    double G[3];
-    double vis_sqrt_info;
-    int prior_preloaded;      // 1: every H buffer starts as a copy of pri_H0, the prior kernel adds only g and cost
+    const double* wpar;       // [B][4] per window: gravity G (3), visual sqrt_info
+    double* vtile;            // global home of the visual sweep's pair tiles when they do not fit LDS ([B][vtile_stride]); else null
+    size_t vtile_stride;
     // GNSS (Dims::GO > 0)
     const int* ngnss;         // [B]
     const int* gn_idx;        // [B][NG][4]: frame i, lower_idx, sys_idx, 0
@@ -95,6 +99,8 @@ constexpr int IMU_JAC = 17, IMU_COV = 17 + 225;
 constexpr int IMU_STRIDE2 = 17 + 450;
 constexpr int WH_STRIDE = 1 + 3 + 4 + 18 + 36 + 4 + 12;  // sum_dt, dp, dq, jac(6x3), cov(6x6), lin(4), lin_vel, lin_gyr, vel_1, gyr_1
 constexpr int EF = 24;  // per-factor eliminated-column products: Jd^T[Ji(6) Jj(6) Jtd(1) Jex(6)] , Jd^T Jd, Jd^T r
+__device__ __forceinline__ double* cost_part(const Win& w, int part, int which, int b) { return w.cost + ((size_t)(part * 2 + which) * w.d.B + b); }
+__device__ __forceinline__ double cost_total(const Win& w, int which, int b) { return (*cost_part(w, 0, which, b) + *cost_part(w, 1, which, b)) + *cost_part(w, 2, which, b); }
 
 __device__ __forceinline__ Q4 q_of(const double* p) { return Q4{p[6], p[3], p[4], p[5]}; }
 __device__ __forceinline__ V3 p_of(const double* p) { return V3{p[0], p[1], p[2]}; }
@@ -171,8 +177,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // One visual factor per lane: residual, Jacobians, Huber correction, zeroed columns of constant blocks, and the products the Schur
 // complement needs for a free inverse depth (stored to efac).  k < 0: padding lane (all zero).  Returns the factor's cost.
 template <bool EX>
-__device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int b, int which, int k, int cost_only, const double* xs, const int* colf,
-                                                VisEval& ev, int& fi, int& fj) {
+__device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int b, int which, int k, const double* xs, const int* colf, VisEval& ev, int& fi, int& fj) {
     double cost = 0.0;
     int feat = 0;
     fi = 0; fj = 0;
@@ -182,129 +187,41 @@ __device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int
         const size_t kk = (size_t)b * d.NV + k;
         fi = w.vis_i[kk]; fj = w.vis_j[kk]; feat = w.vis_feat[kk];
         visual_eval(xs + off_pose(fi), xs + off_pose(fj), xs + off_ex(d.NP), xs[off_feat(d.NP) + feat], xs[off_td(d.NP)], w.vis_data + kk * 12,
-                    w.vis_sqrt_info, !cost_only, ev);
+                    w.wpar[4 * b + 3], true, ev);
         const double r0 = ev.row[0][13], r1 = ev.row[1][13];
         const double sq = r0 * r0 + r1 * r1;
         double rho0, sqrt_rho1, rs, asn;
         huber_corrector(sq, rho0, sqrt_rho1, rs, asn);
         cost = 0.5 * rho0;
-        if (!cost_only) {
-            // J = sqrt_rho1 * (J - alpha_sq_norm * r * (r^T J)), r *= residual_scaling
+        // J = sqrt_rho1 * (J - alpha_sq_norm * r * (r^T J)), r *= residual_scaling
 #pragma unroll
-            for (int c = 0; c < 22; c++) {
-                if (c == 13 || c == 14 || c == 15) continue;
-                const double rtj = r0 * ev.row[0][c] + r1 * ev.row[1][c];
-                ev.row[0][c] = sqrt_rho1 * (ev.row[0][c] - asn * r0 * rtj);
-                ev.row[1][c] = sqrt_rho1 * (ev.row[1][c] - asn * r1 * rtj);
-            }
-            const double rtj = r0 * ev.jd[0] + r1 * ev.jd[1];
-            ev.jd[0] = sqrt_rho1 * (ev.jd[0] - asn * r0 * rtj);
-            ev.jd[1] = sqrt_rho1 * (ev.jd[1] - asn * r1 * rtj);
-            ev.row[0][13] = r0 * rs; ev.row[1][13] = r1 * rs;
-            // constant blocks contribute no columns
-            if (colf[fb_pose(fi)] < 0) for (int c = 0; c < 6; c++) ev.row[0][c] = ev.row[1][c] = 0.0;
-            if (colf[fb_pose(fj)] < 0) for (int c = 6; c < 12; c++) ev.row[0][c] = ev.row[1][c] = 0.0;
-            if (colf[fb_td(d.NP)] < 0) ev.row[0][12] = ev.row[1][12] = 0.0;
-            // eliminated (free inverse depth) column: products needed by the Schur complement
-            if (w.cole[(size_t)b * d.F + feat] >= 0) {
-                double* ef = w.efac + (((size_t)which * d.B + b) * d.NV + k) * EF;
+        for (int c = 0; c < 22; c++) {
+            if (c == 13 || c == 14 || c == 15) continue;
+            const double rtj = r0 * ev.row[0][c] + r1 * ev.row[1][c];
+            ev.row[0][c] = sqrt_rho1 * (ev.row[0][c] - asn * r0 * rtj);
+            ev.row[1][c] = sqrt_rho1 * (ev.row[1][c] - asn * r1 * rtj);
+        }
+        const double rtj = r0 * ev.jd[0] + r1 * ev.jd[1];
+        ev.jd[0] = sqrt_rho1 * (ev.jd[0] - asn * r0 * rtj);
+        ev.jd[1] = sqrt_rho1 * (ev.jd[1] - asn * r1 * rtj);
+        ev.row[0][13] = r0 * rs; ev.row[1][13] = r1 * rs;
+        // constant blocks contribute no columns
+        if (colf[fb_pose(fi)] < 0) for (int c = 0; c < 6; c++) ev.row[0][c] = ev.row[1][c] = 0.0;
+        if (colf[fb_pose(fj)] < 0) for (int c = 6; c < 12; c++) ev.row[0][c] = ev.row[1][c] = 0.0;
+        if (colf[fb_td(d.NP)] < 0) ev.row[0][12] = ev.row[1][12] = 0.0;
+        if (EX && colf[fb_ex(d.NP)] < 0) for (int c = 16; c < 22; c++) ev.row[0][c] = ev.row[1][c] = 0.0;
+        // eliminated (free inverse depth) column: products needed by the Schur complement
+        if (w.cole[(size_t)b * d.F + feat] >= 0) {
+            double* ef = w.efac + (((size_t)which * d.B + b) * d.NV + k) * EF;
 #pragma unroll
-                for (int c = 0; c < 13; c++) ef[c] = ev.jd[0] * ev.row[0][c] + ev.jd[1] * ev.row[1][c];
+            for (int c = 0; c < 13; c++) ef[c] = ev.jd[0] * ev.row[0][c] + ev.jd[1] * ev.row[1][c];
 #pragma unroll
-                for (int c = 0; c < 6; c++) ef[13 + c] = EX ? ev.jd[0] * ev.row[0][16 + c] + ev.jd[1] * ev.row[1][16 + c] : 0.0;
-                ef[19] = ev.jd[0] * ev.jd[0] + ev.jd[1] * ev.jd[1];
-                ef[20] = ev.jd[0] * ev.row[0][13] + ev.jd[1] * ev.row[1][13];
-            }
+            for (int c = 0; c < 6; c++) ef[13 + c] = EX ? ev.jd[0] * ev.row[0][16 + c] + ev.jd[1] * ev.row[1][16 + c] : 0.0;
+            ef[19] = ev.jd[0] * ev.jd[0] + ev.jd[1] * ev.jd[1];
+            ef[20] = ev.jd[0] * ev.row[0][13] + ev.jd[1] * ev.row[1][13];
         }
     }
     return cost;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// grid (NVP/64, B), 64 threads.  EX: the camera extrinsic block is free (second 16-column tile).
-// which: buffer (0/1) of H/g/cost/efac to fill; state read from xs[which_state].
-template <bool EX>
-__global__ void __launch_bounds__(64) ba_linearize_visual(Win w, int which, int which_state, int cost_only, int only_cand_valid) {
-    constexpr int COLS = EX ? 32 : 16;
-    constexpr int LSTR = 2 * COLS + 1;  // odd stride: de-phases the per-lane writes
-    __shared__ double Jbuf[64 * LSTR];
-    __shared__ int s_pair[64];
-    const Dims d = w.d;
-    const int b = blockIdx.y, lane = threadIdx.x;
-    const SolverState& st = w.st[b];
-    if (st.done && only_cand_valid != 2) return;   // only_cand_valid == 2: marginalisation pass (runs on finished windows)
-    if (only_cand_valid == 1 && !st.cand_valid) return;
-    const int n_order = w.norder[b];
-    const int e0 = blockIdx.x * 64;
-    if (e0 >= n_order) return;
-    if (which < 0) which = 1 - st.cur;            // the candidate's buffers
-    if (which_state == -2) which_state = st.cur; else if (which_state < 0) which_state = 1 - st.cur;
-    const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
-    const int* colf = w.colf + (size_t)b * d.NFB;
-    const int entry = e0 + lane;
-    const int k = entry < n_order ? w.order[(size_t)b * d.NVP + entry] : -1;
-    int fi, fj;
-    VisEval ev;
-    double cost = vis_lane_eval<EX>(w, d, b, which, k, cost_only, xs, colf, ev, fi, fj);
-    cost = wave_sum_f64(cost);
-    if (lane == 0) atomicAdd(w.cost + (size_t)which * d.B + b, cost);
-    if (cost_only) return;
-    // ---- stage block rows in LDS
-    s_pair[lane] = k >= 0 ? fi * 64 + fj : -1;
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-#pragma unroll
-        for (int c = 0; c < 16; c++) Jbuf[lane * LSTR + r * COLS + c] = (c < 14) ? ev.row[r][c] : 0.0;
-        if (EX) {
-#pragma unroll
-            for (int c = 0; c < 16; c++) Jbuf[lane * LSTR + r * COLS + 16 + c] = (c < 6) ? ev.row[r][16 + c] : 0.0;
-        }
-    }
-    __syncthreads();
-    // ---- J^T J per frame pair on the matrix cores: D[a][b] += sum_k J[k][a] J[k][b], 4 rows (2 factors) per instruction
-    double* H = w.H + ((size_t)which * d.B + b) * d.RP * d.RP;
-    double* g = w.g + ((size_t)which * d.B + b) * d.RP;
-    const int exc = EX ? colf[fb_ex(d.NP)] : -1;
-    const int tdc = colf[fb_td(d.NP)];
-    d4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
-    int cur_pair = -1;
-    auto flush = [&](int pair) {
-        if (pair < 0) return;
-        const int pi = pair >> 6, pj = pair & 63;
-        const int ci = colf[fb_pose(pi)], cj = colf[fb_pose(pj)];
-        auto cmap = [&](int t) -> int { return t < 6 ? (ci >= 0 ? ci + t : -1) : t < 12 ? (cj >= 0 ? cj + t - 6 : -1) : t == 12 ? tdc : t == 13 ? -2 : -1; };
-        const int tb = lane & 15, cb = cmap(tb);
-        const int cb1 = (EX && tb < 6 && exc >= 0) ? exc + tb : -1;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int ta = (lane >> 4) + 4 * r, ca = cmap(ta);
-            const double v00 = acc00[r];
-            if (ca >= 0 && cb >= 0 && cb <= ca) atomicAdd(H + (size_t)ca * d.RP + cb, v00);   // lower triangle only (H is symmetric)
-            if (ca >= 0 && cb == -2) atomicAdd(g + ca, v00);
-            if (EX) {
-                const double v01 = acc01[r], v11 = acc11[r];
-                if (ca >= 0 && cb1 >= 0) atomicAdd(H + (size_t)max(ca, cb1) * d.RP + min(ca, cb1), v01);
-                if (ca == -2 && cb1 >= 0) atomicAdd(g + cb1, v01);
-                const int ca1 = (ta < 6 && exc >= 0) ? exc + ta : -1;
-                if (ca1 >= 0 && cb1 >= 0 && cb1 <= ca1) atomicAdd(H + (size_t)ca1 * d.RP + cb1, v11);
-            }
-        }
-        acc00 = d4{0, 0, 0, 0}; acc01 = d4{0, 0, 0, 0}; acc11 = d4{0, 0, 0, 0};
-    };
-    for (int m = 0; m < 32; m++) {
-        const int pair = s_pair[2 * m];  // pairs are padded to even length: entries 2m and 2m+1 share the pair (or are padding)
-        if (pair < 0) continue;
-        if (pair != cur_pair) { flush(cur_pair); cur_pair = pair; }
-        const int e = 2 * m + (lane >> 5), r = (lane >> 4) & 1, c = lane & 15;
-        const double a0 = Jbuf[e * LSTR + r * COLS + c];
-        acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc00, 0, 0, 0);
-        if (EX) {
-            const double a1 = Jbuf[e * LSTR + r * COLS + 16 + c];
-            acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a1, acc01, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc11, 0, 0, 0);
-        }
-    }
-    flush(cur_pair);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -396,29 +313,6 @@ __global__ void __launch_bounds__(256) ba_setup(Win w) {
         }
         for (int a = threadIdx.x; a < n; a += 256) { double s = 0; for (int k2 = 0; k2 < n; k2++) s += J[(size_t)k2 * n + a] * r[k2]; w.pri_b[(size_t)b * d.NPRI + a] = s; }
         if (threadIdx.x == 0) { double s = 0; for (int k2 = 0; k2 < n; k2++) s += r[k2] * r[k2]; w.pri_c[b] = s; }
-    }
-    // H0: zero, then the prior's A scattered to solver columns (lower triangle).  Every linearisation starts from a copy of it.
-    __syncthreads();
-    double* H0 = w.pri_H0 + (size_t)b * d.RP * d.RP;
-    for (int i = threadIdx.x; i < d.RP * d.RP; i += 256) H0[i] = 0.0;
-    __syncthreads();
-    if (n > 0) {
-        __shared__ int s_pcol[256];
-        if (threadIdx.x == 0) {
-            int idx = 0;
-            for (int q = 0; q < w.pri_nb[b]; q++) {
-                const int id = w.pri_bid[(size_t)b * 64 + q], kind = id / 4096;
-                const int fb = fblock_of(id, d);
-                const int c0 = fb >= 0 ? w.colf[(size_t)b * d.NFB + fb] : -1;
-                for (int k2 = 0; k2 < lsize_kind(kind); k2++) s_pcol[idx++] = c0 >= 0 ? c0 + k2 : -1;
-            }
-        }
-        __syncthreads();
-        const double* A = w.pri_A + (size_t)b * d.NPRI * d.NPRI;
-        for (int i = threadIdx.x; i < n * n; i += 256) {
-            const int ca = s_pcol[i / n], cb = s_pcol[i % n];
-            if (ca >= 0 && cb >= 0 && cb <= ca) H0[(size_t)ca * d.RP + cb] = A[i];
-        }
     }
 }
 
@@ -583,64 +477,34 @@ __device__ __forceinline__ void misc_cols(bool is_imu, int i, const int* colf, i
     }
 }
 
-// One wavefront: whiten a factor's raw residual / Jacobian with its upper-triangular square-root information S (imu_factor.h:73,
-// wheel_factor.h:85: residual = S r, J = S J), add J^T J and J^T r to H / g (lower triangle, global atomics), return the factor's cost.
-// sJ: NRES x NCOL raw Jacobian (LDS), rraw: raw residual (LDS); sS, sSJ, sr: this wavefront's scratch; scol from misc_cols.
-template <int NRES, int NCOL>
-__device__ __forceinline__ double misc_whiten_accumulate(const double* Sg, const double* rraw, const double* sJ, double* sS, double* sSJ, double* sr, const int* scol,
-                                                         double* H, double* g, int RP, int cost_only, int lane) {
-    for (int q = lane; q < NRES * NRES; q += 64) sS[q] = Sg[q];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-    if (lane < NRES) {
-        double sv = 0;
-#pragma unroll 3
-        for (int k2 = 0; k2 < NRES; k2++) sv += sS[lane * NRES + k2] * rraw[k2];
-        sr[lane] = sv;   // whitened residual
+// Plain read-modify-write of up to N distinct global addresses per lane: all loads are issued before the first store (the
+// targets of one call never alias).  Used where the summation order is fixed by phases instead of atomics.
+template <int N>
+struct RmwBatch {
+    double* p[N]; double v[N];
+    __device__ __forceinline__ void set(int i, double* ptr, double val) { p[i] = ptr; v[i] = val; }   // i must fold to a constant (unrolled loops)
+    __device__ __forceinline__ void commit() {
+        double o[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) o[i] = p[i] ? *p[i] : 0.0;
+#pragma unroll
+        for (int i = 0; i < N; i++) if (p[i]) *p[i] = o[i] + v[i];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-    double c = lane < NRES ? 0.5 * sr[lane] * sr[lane] : 0.0;
-    c = wave_sum_f64(c);
-    if (cost_only) return c;
-    for (int e = lane; e < NRES * NCOL; e += 64) {
-        const int r = e / NCOL, cc = e % NCOL;
-        double sv = 0;
-#pragma unroll 3
-        for (int k2 = 0; k2 < NRES; k2++) if (k2 >= r) sv += sS[r * NRES + k2] * sJ[k2 * NCOL + cc];  // S is upper triangular
-        sSJ[e] = sv;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-    for (int e = lane; e < NCOL * NCOL; e += 64) {
-        const int a = e / NCOL, c2 = e % NCOL;
-        const int ca = scol[a], cb = scol[c2];
-        if (ca < 0 || cb < 0 || cb > ca) continue;   // lower triangle only
-        double sv = 0;
-#pragma unroll 3
-        for (int r = 0; r < NRES; r++) sv += sSJ[r * NCOL + a] * sSJ[r * NCOL + c2];
-        if (sv != 0.0) atomicAdd(H + (size_t)ca * RP + cb, sv);
-    }
-    if (lane < NCOL && scol[lane] >= 0) {
-        double sv = 0;
-#pragma unroll 3
-        for (int r = 0; r < NRES; r++) sv += sSJ[r * NCOL + lane] * sr[r];
-        atomicAdd(g + scol[lane], sv);
-    }
-    return c;
-}
+};
 
-// The same on the matrix cores, for the window-level sweep.  sJp: the factor's padded block row [J | r] in LDS, 4*KS x 33 doubles, rows
-// >= NRES and columns > NCOL zero.  W' = S [J | r] (KS MFMA steps x 2 column tiles), then W'^T W' = [[J^T J, J^T r], [., r^T r]] whitened
-// (3 tiles): 20 MFMAs for an IMU factor instead of ~9000 LDS-latency-bound scalar multiply-adds.  sW: 4*KS x 33 scratch of this wavefront.
-template <int NRES, int NCOL>
-__device__ __forceinline__ double misc_mfma_accumulate(const double* Sg, const double* sJp, double* sW, const int* scol, double* H, double* g, int RP, int cost_only,
+// One wavefront: whiten a factor's block row with its upper-triangular square-root information S (imu_factor.h:73, wheel_factor.h:85:
+// residual = S r, J = S J) and form J^T J / J^T r on the matrix cores.  sJp: the factor's padded block row [J | r] in LDS, 4*KS x 33 doubles,
+// rows >= NRES and columns > NCOL zero.  W' = S [J | r] (KS MFMA steps x 2 column tiles), then W'^T W' = [[J^T J, J^T r], [., r^T r]]
+// (3 tiles): 20 MFMAs for an IMU factor.  sW: 4*KS x 33 scratch of this wavefront.
+// The products are ADDED to H / g with plain read-modify-writes: the caller runs factors that share columns in different phases
+// (separated by barriers), so every entry has one writer at a time and a fixed order of additions.  Local columns >= SH0 (the
+// blocks all wheel factors share: wheel extrinsic, sx, sy, sw, td_wheel) are not written but stashed in `stash` (packed lower
+// (NCOL - SH0) x (NCOL - SH0), then the NCOL - SH0 entries of J^T r) for an ordered reduction over the factors.  Returns the cost.
+template <int NRES, int NCOL, int SH0>
+__device__ __forceinline__ double misc_mfma_accumulate(const double* Sg, const double* sJp, double* sW, const int* scol, double* H, double* g, int RP, double* stash,
                                                        int lane) {
     constexpr int KS = (NRES + 3) / 4, LD = 33;
     const int lr = lane & 15, lk = lane >> 4;
-    if (cost_only) {
-        double sv = 0;
-        if (lane < NRES)
-            for (int k2 = lane; k2 < NRES; k2++) sv += Sg[lane * NRES + k2] * sJp[k2 * LD + NCOL];
-        return wave_sum_f64(0.5 * sv * sv);
-    }
     double sa[KS];
 #pragma unroll
     for (int kk = 0; kk < KS; kk++) { const int k = 4 * kk + lk; sa[kk] = (lr < NRES && k < NRES) ? Sg[lr * NRES + k] : 0.0; }
@@ -666,118 +530,36 @@ __device__ __forceinline__ double misc_mfma_accumulate(const double* Sg, const d
         g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a0, g10, 0, 0, 0);
         g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, g11, 0, 0, 0);
     }
-    // element (a, b) of tile (ta, tb): local columns 16 ta + a, 16 tb + b; a = lk + 4 r, b = lr
-    const int cb0 = lr < NCOL ? scol[lr] : -1;                                    // tile column 0
-    const int cb1 = 16 + lr < NCOL ? scol[16 + lr] : -1;                          // tile column 1
+    // element (a, b) of tile (ta, tb): local columns la = 16 ta + a, lb = 16 tb + b; a = lk + 4 r, b = lr.  Local column NCOL is the residual.
+    constexpr int NSH = NCOL - SH0;
+    RmwBatch<12> rm;
     double cost2 = 0.0;
+    auto put = [&](int la, int lb, double v) -> double* {   // la >= lb, both < NCOL: entry of J^T J; returns the global target or null
+        if (la >= SH0 && lb >= SH0) { stash[(la - SH0) * (la - SH0 + 1) / 2 + (lb - SH0)] = v; return nullptr; }
+        const int ca = scol[la], cb = scol[lb];
+        return (ca >= 0 && cb >= 0) ? H + (size_t)max(ca, cb) * RP + min(ca, cb) : nullptr;
+    };
+    auto putg = [&](int lb, double v) -> double* {          // entry of J^T r
+        if (lb >= SH0) { stash[NSH * (NSH + 1) / 2 + (lb - SH0)] = v; return nullptr; }
+        const int cb = scol[lb];
+        return cb >= 0 ? g + cb : nullptr;
+    };
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int a = lk + 4 * r;
-        // rows of tile row 0
-        const int ca0 = a < NCOL ? scol[a] : -1;
-        if (ca0 >= 0 && cb0 >= 0 && lr <= a && g00[r] != 0.0) atomicAdd(H + (size_t)max(ca0, cb0) * RP + min(ca0, cb0), g00[r]);
-        // rows of tile row 1: local column 16 + a
-        const int la = 16 + a;
-        if (la < NCOL) {
-            const int ca1 = scol[la];
-            if (ca1 >= 0) {
-                if (cb0 >= 0 && g10[r] != 0.0) atomicAdd(H + (size_t)max(ca1, cb0) * RP + min(ca1, cb0), g10[r]);
-                if (cb1 >= 0 && lr <= a && g11[r] != 0.0) atomicAdd(H + (size_t)max(ca1, cb1) * RP + min(ca1, cb1), g11[r]);
-            }
-        } else if (la == NCOL) {                                                   // the r column: J^T r and r^T r
-            if (cb0 >= 0) atomicAdd(g + cb0, g10[r]);
-            if (cb1 >= 0) atomicAdd(g + cb1, g11[r]);
-            if (16 + lr == NCOL) cost2 = g11[r];
-        }
+        const int a = lk + 4 * r, la = 16 + a;
+        // tile (0, 0): local (a, lr), lower triangle
+        rm.set(3 * r, (a < NCOL && lr <= a) ? put(a, lr, g00[r]) : nullptr, g00[r]);
+        // tile (1, 0): local (16 + a, lr); row NCOL is the residual: J^T r of the local columns lr
+        rm.set(3 * r + 1, la < NCOL ? put(la, lr, g10[r]) : la == NCOL ? putg(lr, g10[r]) : nullptr, g10[r]);
+        // tile (1, 1): local (16 + a, 16 + lr), lower triangle
+        double* t = nullptr;
+        if (la < NCOL && lr <= a) t = put(la, 16 + lr, g11[r]);
+        else if (la == NCOL && 16 + lr < NCOL) t = putg(16 + lr, g11[r]);
+        else if (la == NCOL && 16 + lr == NCOL) cost2 = g11[r];
+        rm.set(3 * r + 2, t, g11[r]);
     }
+    rm.commit();
     return 0.5 * wave_sum_f64(cost2);
-}
-
-// frame_filter: 0 all factors; 1 only IMU/wheel factors starting at frame 0 (MARGIN_OLD); 2 no IMU/wheel factor (MARGIN_SECOND_NEW)
-template <bool PRIOR>   // PRIOR: the 256-thread prior task; else one 64-thread block per IMU / wheel factor (own register budget and LDS footprint)
-__global__ void __launch_bounds__(PRIOR ? 256 : 64, PRIOR ? 1 : 2) ba_linearize_misc(Win w, int which, int which_state, int cost_only, int only_cand_valid, int frame_filter, int task_base) {
-    __shared__ double sS[PRIOR ? 1 : 225];
-    __shared__ double sJ[PRIOR ? 1 : 450];
-    __shared__ double sSJ[PRIOR ? 1 : 450];
-    __shared__ double sr[32];
-    __shared__ int scol[32];
-    __shared__ double sdx[PRIOR ? 512 : 1];
-    __shared__ double sred[PRIOR ? 256 : 1];
-    const Dims d = w.d;
-    const int b = blockIdx.y, task = task_base + blockIdx.x, lane = threadIdx.x & 63;   // factor tasks: 64-thread blocks; prior task: 256 threads
-    const SolverState& st = w.st[b];
-    if (st.done && only_cand_valid != 2) return;
-    if (only_cand_valid == 1 && !st.cand_valid) return;
-    if (which < 0) which = 1 - st.cur;
-    if (which_state == -2) which_state = st.cur; else if (which_state < 0) which_state = 1 - st.cur;
-    const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
-    const int* colf = w.colf + (size_t)b * d.NFB;
-    double* H = w.H + ((size_t)which * d.B + b) * d.RP * d.RP;
-    double* g = w.g + ((size_t)which * d.B + b) * d.RP;
-    const int nimu = w.nimu[b], nwh = w.nwh[b];
-    if (!PRIOR) {
-        if (task >= 2 * d.W) return;
-        const bool is_imu = task < d.W;
-        const int k = is_imu ? task : task - d.W;
-        if (k >= (is_imu ? nimu : nwh) || frame_filter == 2) return;
-        const int i = is_imu ? w.imu_i[(size_t)b * d.W + k] : w.wh_i[(size_t)b * d.W + k], j = i + 1;
-        if (frame_filter == 1 && i != 0) return;
-        double c;
-        if (is_imu) {
-            if (!cost_only) { for (int q = lane; q < 450; q += 64) sJ[q] = 0.0; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-            imu_raw(xs + off_pose(i), xs + off_sb(i), xs + off_pose(j), xs + off_sb(j), w.imu_data + ((size_t)b * d.W + k) * IMU_STRIDE2, w.G, sr + 16, sJ, !cost_only, lane == 0);
-            misc_cols(true, i, colf, d.NP, scol, lane);
-            c = misc_whiten_accumulate<15, 30>(w.imu_sqrt + ((size_t)b * d.W + k) * 225, sr + 16, sJ, sS, sSJ, sr, scol, H, g, d.RP, cost_only, lane);
-        } else {
-            if (!cost_only) { for (int q = lane; q < 132; q += 64) sJ[q] = 0.0; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-            wheel_raw(xs + off_pose(i), xs + off_pose(j), xs + off_exw(d.NP), xs[off_ix(d.NP)], xs[off_ix(d.NP) + 1], xs[off_ix(d.NP) + 2], xs[off_tdw(d.NP)],
-                      w.wh_data + ((size_t)b * d.W + k) * WH_STRIDE, sr + 16, sJ, !cost_only, lane == 0);
-            misc_cols(false, i, colf, d.NP, scol, lane);
-            c = misc_whiten_accumulate<6, 22>(w.wh_sqrt + ((size_t)b * d.W + k) * 36, sr + 16, sJ, sS, sSJ, sr, scol, H, g, d.RP, cost_only, lane);
-        }
-        if (lane == 0) atomicAdd(w.cost + (size_t)which * d.B + b, c);
-        return;
-    }
-    // ---- prior: r = r0 + J0 dx  =>  cost = 1/2 (c0 + 2 b0.dx + dx^T A dx), g += b0 + A dx, H += A   (marginalization_factor.cpp:344-392)
-    const int n = w.pri_n[b];
-    if (n <= 0) return;
-    double pc = 0.0;
-    {
-        const int nb = w.pri_nb[b];
-        const int* bid = w.pri_bid + (size_t)b * 64;
-        const double* x0 = w.pri_x0 + (size_t)b * d.NPRI * 2;
-        // sdx[0..n) = dx, sdx[256..256+n) = column map
-        if ((int)threadIdx.x < nb) {
-            int idx = 0, o0 = 0;
-            for (int q = 0; q < (int)threadIdx.x; q++) { idx += lsize_kind(bid[q] / 4096); o0 += gsize_kind(bid[q] / 4096); }
-            const int id = bid[threadIdx.x], kind = id / 4096;
-            double dx[9];
-            prior_block_dx(kind, xs + state_off_of(id, d), x0 + o0, dx);
-            const int fb = fblock_of(id, d);
-            const int c0 = fb >= 0 ? colf[fb] : -1;
-            for (int q = 0; q < lsize_kind(kind); q++) { sdx[idx + q] = dx[q]; sdx[256 + idx + q] = c0 >= 0 ? (double)(c0 + q) : -1.0; }
-        }
-        __syncthreads();
-        const double* A = w.pri_A + (size_t)b * d.NPRI * d.NPRI;
-        const double* b0 = w.pri_b + (size_t)b * d.NPRI;
-        for (int a = threadIdx.x; a < n; a += 256) {
-            double v = 0;
-            for (int c2 = 0; c2 < n; c2++) v += A[(size_t)a * n + c2] * sdx[c2];
-            pc += sdx[a] * (b0[a] + 0.5 * v);
-            const int ca = (int)sdx[256 + a];
-            if (!cost_only && ca >= 0) atomicAdd(g + ca, b0[a] + v);
-        }
-        if (!cost_only && !w.prior_preloaded)
-            for (int e = threadIdx.x; e < n * n; e += 256) {
-                const int ca = (int)sdx[256 + e / n], cb = (int)sdx[256 + e % n];
-                if (ca >= 0 && cb >= 0 && cb <= ca) atomicAdd(H + (size_t)ca * d.RP + cb, A[e]);
-            }
-        if (threadIdx.x == 0) pc += 0.5 * w.pri_c[b];
-    }
-    sred[threadIdx.x] = pc;
-    __syncthreads();
-    for (int sft = 128; sft > 0; sft >>= 1) { if ((int)threadIdx.x < sft) sred[threadIdx.x] += sred[threadIdx.x + sft]; __syncthreads(); }
-    if (threadIdx.x == 0) atomicAdd(w.cost + (size_t)which * d.B + b, sred[0]);
 }
 
 }  // namespace gfb
@@ -847,241 +629,10 @@ __device__ __forceinline__ int tri_row(int t) {  // largest i with i(i+1)/2 <= t
     while ((i + 1) * (i + 2) / 2 <= t) i++;
     return i;
 }
-// ---------------------------------------------------------------------------------------------------------------
-// Window-level visual sweep (fixed camera extrinsic): one block of kVW wavefronts per window instead of one 64-thread block per 64
-// factors.  Every wavefront walks its share of the 64-factor chunks exactly like ba_linearize_visual, but the per-frame-pair MFMA tiles
-// are added into an LDS copy of the window's visual normal equations (compact columns 6 p + q of pose p, then td, then the right-hand
-// side; packed lower triangle), and only that copy -- one value per touched entry -- goes to H / g with global atomics at the end.
-// The chunked kernel issues ~100 global atomics per pair per chunk, most of them on the same few diagonal blocks; its run time is that
-// atomic traffic (103 us against 50 us for 256 windows of 1500 factors).  Dynamic LDS: (6 NP + 2)(6 NP + 3)/2 doubles.
-constexpr int kVW = 12;               // wavefronts per block, fixed extrinsic (three per SIMD at the kernel's ~150 VGPRs)
-constexpr int kVWX = 6;               // wavefronts per block when the camera extrinsic carries columns (twice the staging area per wavefront)
-__host__ __device__ constexpr int vwin_half(bool ex) { return 32 * (ex ? 65 : 33); }   // staging area of one wavefront: 32 factors x (2 rows x COLS + 1) doubles
-__host__ __device__ inline size_t vwin_acc_doubles(int NP, bool ex) { const size_t nc = 6 * (size_t)NP + (ex ? 8 : 2); return nc * (nc + 1) / 2; }
-// EX: the camera extrinsic block has columns (free in the solve, or a kept block of the marginalisation): second 16-column tile, compact
-// columns 6 NP .. 6 NP + 5 in front of td and the right-hand side.
-template <bool EX, int NW>
-__global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, int which, int which_state, int cost_only, int only_cand_valid) {
-    constexpr int COLS = EX ? 32 : 16, LSTR = 2 * COLS + 1, HALF = vwin_half(EX);
-    extern __shared__ __attribute__((aligned(16))) double v_acc[];   // packed lower triangle of the compact system
-    __shared__ double Jst[NW * HALF];
-    __shared__ int s_pr[NW][64];
-    __shared__ double s_cost[NW];
-    const Dims d = w.d;
-    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const SolverState& st = w.st[b];
-    if (st.done && only_cand_valid != 2) return;   // only_cand_valid == 2: marginalisation pass (runs on finished windows)
-    if (only_cand_valid == 1 && !st.cand_valid) return;
-    const int n_order = w.norder[b];
-    if (n_order <= 0) return;
-    if (which < 0) which = 1 - st.cur;
-    if (which_state == -2) which_state = st.cur; else if (which_state < 0) which_state = 1 - st.cur;
-    const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
-    const int* colf = w.colf + (size_t)b * d.NFB;
-    const int EXC = 6 * d.NP, TD = EXC + (EX ? 6 : 0), RHS = TD + 1, NT = (RHS + 1) * (RHS + 2) / 2;
-    if (!cost_only) for (int i = tid; i < NT; i += 64 * NW) v_acc[i] = 0.0;
-    __syncthreads();
-    double* Jbuf = Jst + wave * HALF;
-    int* s_pair = s_pr[wave];
-    double cost = 0.0;
-    const int nchunks = (n_order + 63) / 64;
-    for (int ch = wave; ch < nchunks; ch += NW) {
-        const int entry = ch * 64 + lane;
-        const int k = entry < n_order ? w.order[(size_t)b * d.NVP + entry] : -1;
-        int fi, fj;
-        VisEval ev;
-        cost += vis_lane_eval<EX>(w, d, b, which, k, cost_only, xs, colf, ev, fi, fj);
-        if (cost_only) continue;
-        s_pair[lane] = k >= 0 ? fi * 64 + fj : -1;
-        d4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
-        int cur_pair = -1;
-        auto add = [&](int ca, int cb, double v) { if (v != 0.0) atomicAdd(&v_acc[max(ca, cb) * (max(ca, cb) + 1) / 2 + min(ca, cb)], v); };
-        auto flush = [&](int pair) {
-            if (pair < 0) return;
-            const int pi = pair >> 6, pj = pair & 63;
-            auto cm = [&](int t) -> int { return t < 6 ? 6 * pi + t : t < 12 ? 6 * pj + t - 6 : t == 12 ? TD : t == 13 ? RHS : -1; };
-            const int tb = lane & 15, cb = cm(tb);
-            const int cb1 = (EX && tb < 6) ? EXC + tb : -1;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int ta = (lane >> 4) + 4 * r, ca = cm(ta);
-                if (ca >= 0 && cb >= 0 && tb <= ta) add(ca, cb, acc00[r]);          // tile 0 x tile 0: each unordered pair once
-                if (EX) {
-                    if (ca >= 0 && cb1 >= 0) add(ca, cb1, acc01[r]);                  // tile 0 x extrinsic: disjoint column sets
-                    if (ta < 6 && cb1 >= 0 && tb <= ta) add(EXC + ta, cb1, acc11[r]);
-                }
-            }
-            acc00 = d4{0, 0, 0, 0}; acc01 = d4{0, 0, 0, 0}; acc11 = d4{0, 0, 0, 0};
-        };
-        // the 64 block rows go through the staging area in two halves of 32 factors (lanes 0-31, then 32-63)
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();   // the previous half's reads are done
-            if ((lane >> 5) == half) {
-                const int l = lane & 31;
-#pragma unroll
-                for (int r = 0; r < 2; r++) {
-#pragma unroll
-                    for (int c = 0; c < 16; c++) Jbuf[l * LSTR + r * COLS + c] = (c < 14) ? ev.row[r][c] : 0.0;
-                    if (EX) {
-#pragma unroll
-                        for (int c = 0; c < 16; c++) Jbuf[l * LSTR + r * COLS + 16 + c] = (c < 6) ? ev.row[r][16 + c] : 0.0;
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-            for (int m = 0; m < 16; m++) {
-                const int pair = s_pair[32 * half + 2 * m];   // pairs are padded to even length: entries 2m and 2m+1 share the pair (or are padding)
-                if (pair < 0) continue;
-                if (pair != cur_pair) { flush(cur_pair); cur_pair = pair; }
-                const int e = 2 * m + (lane >> 5), r = (lane >> 4) & 1, c = lane & 15;
-                const double a0 = Jbuf[e * LSTR + r * COLS + c];
-                acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc00, 0, 0, 0);
-                if (EX) {
-                    const double a1 = Jbuf[e * LSTR + r * COLS + 16 + c];
-                    acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a1, acc01, 0, 0, 0);
-                    acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc11, 0, 0, 0);
-                }
-            }
-        }
-        flush(cur_pair);
-    }
-    cost = wave_sum_f64(cost);
-    if (lane == 0) s_cost[wave] = cost;
-    __syncthreads();
-    if (tid == 0) { double c = 0; for (int q = 0; q < NW; q++) c += s_cost[q]; atomicAdd(w.cost + (size_t)which * d.B + b, c); }
-    if (cost_only) return;
-    // ---- the window's visual normal equations -> H, g
-    double* H = w.H + ((size_t)which * d.B + b) * d.RP * d.RP;
-    double* g = w.g + ((size_t)which * d.B + b) * d.RP;
-    auto gcol = [&](int c) -> int {   // compact column -> column of the reduced system (-1: constant block)
-        const int base = c < EXC ? colf[fb_pose(c / 6)] : c < TD ? colf[fb_ex(d.NP)] : colf[fb_td(d.NP)];
-        return base < 0 ? -1 : c < EXC ? base + c % 6 : c < TD ? base + (c - EXC) : base;
-    };
-    for (int i = tid; i < NT; i += 64 * NW) {
-        const double v = v_acc[i];
-        if (v == 0.0) continue;
-        const int a = tri_row(i), c2 = i - a * (a + 1) / 2;
-        if (c2 >= RHS) continue;                                  // r^T r
-        const int cb = gcol(c2);
-        if (cb < 0) continue;
-        if (a == RHS) { atomicAdd(g + cb, v); continue; }
-        const int ca = gcol(a);
-        if (ca < 0) continue;
-        atomicAdd(H + (size_t)max(ca, cb) * d.RP + min(ca, cb), v);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Window-level IMU / wheel sweep: one block of kMW wavefronts per window.  The residual / Jacobian evaluation of a factor is a long
-// scalar program (quaternion algebra, SO(3) exp / log, right Jacobians): in ba_linearize_misc one whole wavefront runs it for one
-// factor, 63 of 64 lanes idle.  Here lane k of wavefront 0 evaluates IMU factor k and lane k of wavefront 1 wheel factor k -- all
-// factors of the window at the price of one -- into padded block rows [J | r] in LDS; whitening and J^T J of each factor then run on
-// the matrix cores (misc_mfma_accumulate), IMU factors as soon as wavefront 0 is through, wheel factors when wavefront 1 is.
-// Dynamic LDS (doubles): W x 16 x 33 IMU block rows, W x 8 x 33 wheel block rows, kMW x (16 x 33 + 16) scratch.
-constexpr int kMW = 8;
-constexpr int kMJi = 16 * 33, kMJw = 8 * 33, kMScr = 16 * 33 + 16;   // scratch: W', column map (32 ints)
-__host__ __device__ inline size_t misc_win_lds_doubles(int W) { return (size_t)W * (kMJi + kMJw) + (size_t)kMW * kMScr; }
-__global__ void __launch_bounds__(64 * kMW) ba_linearize_misc_win(Win w, int which, int which_state, int cost_only, int only_cand_valid) {
-    extern __shared__ __attribute__((aligned(16))) double m_lds[];
-    __shared__ double s_cost[kMW];
-    __shared__ int s_ready[2];     // [0]: IMU block rows are in LDS, [1]: wheel block rows
-    const Dims d = w.d;
-    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const SolverState& st = w.st[b];
-    if (st.done && only_cand_valid != 2) return;
-    if (only_cand_valid == 1 && !st.cand_valid) return;
-    if (which < 0) which = 1 - st.cur;
-    if (which_state == -2) which_state = st.cur; else if (which_state < 0) which_state = 1 - st.cur;
-    const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
-    const int* colf = w.colf + (size_t)b * d.NFB;
-    double* H = w.H + ((size_t)which * d.B + b) * d.RP * d.RP;
-    double* g = w.g + ((size_t)which * d.B + b) * d.RP;
-    const int nimu = w.nimu[b], nwh = w.nwh[b];
-    if (nimu + nwh <= 0) return;
-    double* sJi = m_lds;                          // [W][16][33]
-    double* sJw = sJi + (size_t)d.W * kMJi;       // [W][8][33]
-    double* scr = sJw + (size_t)d.W * kMJw + (size_t)wave * kMScr;
-    double* sW = scr; int* scol = reinterpret_cast<int*>(scr + 16 * 33);
-    for (int q = tid; q < nimu * kMJi; q += 64 * kMW) sJi[q] = 0.0;
-    for (int q = tid; q < nwh * kMJw; q += 64 * kMW) sJw[q] = 0.0;
-    if (tid < 2) s_ready[tid] = 0;
-    __syncthreads();
-    if (wave == 0) {
-        if (lane < nimu) {
-            const int k = lane, i = w.imu_i[(size_t)b * d.W + k], j = i + 1;
-            imu_raw(xs + off_pose(i), xs + off_sb(i), xs + off_pose(j), xs + off_sb(j), w.imu_data + ((size_t)b * d.W + k) * IMU_STRIDE2, w.G, sJi + kMJi * k + 30,
-                    sJi + kMJi * k, !cost_only, true, 33, 33);
-        }
-        __threadfence_block();
-        if (lane == 0) __hip_atomic_store(&s_ready[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    if (wave == 1) {
-        if (lane < nwh) {
-            const int k = lane, i = w.wh_i[(size_t)b * d.W + k], j = i + 1;
-            wheel_raw(xs + off_pose(i), xs + off_pose(j), xs + off_exw(d.NP), xs[off_ix(d.NP)], xs[off_ix(d.NP) + 1], xs[off_ix(d.NP) + 2], xs[off_tdw(d.NP)],
-                      w.wh_data + ((size_t)b * d.W + k) * WH_STRIDE, sJw + kMJw * k + 22, sJw + kMJw * k, !cost_only, true, 33, 33);
-        }
-        __threadfence_block();
-        if (lane == 0) __hip_atomic_store(&s_ready[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    auto wait_for = [&](int which_flag) {
-        while (__hip_atomic_load(&s_ready[which_flag], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(4);
-    };
-    double cost = 0.0;
-    // IMU factors: every wavefront but the one still busy with the wheel evaluation
-    {
-        const int slot = wave == 0 ? 0 : wave - 1;      // wavefronts 0, 2, 3, ... -> slots 0, 1, 2, ...
-        if (wave != 1 && nimu > 0) {
-            wait_for(0);
-            for (int k = slot; k < nimu; k += kMW - 1) {
-                const int i = w.imu_i[(size_t)b * d.W + k];
-                misc_cols(true, i, colf, d.NP, scol, lane);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                cost += misc_mfma_accumulate<15, 30>(w.imu_sqrt + ((size_t)b * d.W + k) * 225, sJi + kMJi * k, sW, scol, H, g, d.RP, cost_only, lane);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();   // scratch is reused by the next factor
-            }
-        }
-    }
-    // wheel factors: all wavefronts, wavefront 1 first in line
-    if (nwh > 0) {
-        wait_for(1);
-        const int slot = (wave + kMW - 1) % kMW;         // wavefront 1 -> slot 0
-        for (int k = slot; k < nwh; k += kMW) {
-            const int i = w.wh_i[(size_t)b * d.W + k];
-            misc_cols(false, i, colf, d.NP, scol, lane);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-            cost += misc_mfma_accumulate<6, 22>(w.wh_sqrt + ((size_t)b * d.W + k) * 36, sJw + kMJw * k, sW, scol, H, g, d.RP, cost_only, lane);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-        }
-    }
-    if (lane == 0) s_cost[wave] = cost;
-    __syncthreads();
-    if (tid == 0) { double c = 0; for (int q = 0; q < kMW; q++) c += s_cost[q]; atomicAdd(w.cost + (size_t)which * d.B + b, c); }
-}
-
-// PoseLocalParameterization::Plus (pose_local_parameterization.cpp:12-28)
-__device__ __forceinline__ void pose_plus(const double* x, const double* dl, double* out) {
-    out[0] = x[0] + dl[0]; out[1] = x[1] + dl[1]; out[2] = x[2] + dl[2];
-    const Q4 q = qnormalized(qmul(Q4{x[6], x[3], x[4], x[5]}, deltaQ(v3(dl[3], dl[4], dl[5]))));
-    out[3] = q.x; out[4] = q.y; out[5] = q.z; out[6] = q.w;
-}
-
-// Compact rows of E^T F, ete, etb of the eliminated (free inverse-depth) columns: grid (F, B), one wavefront per feature.
-// Every factor of a feature shares its pose_i / ex / td entries (register sums); its pose_j entries are unique (direct stores).
-__global__ void __launch_bounds__(64) ba_build_et(Win w, StepBufs sb, int which, int ignore_done) {
-    const Dims d = w.d;
-    const int b = blockIdx.y, f = blockIdx.x, lane = threadIdx.x;
-    // the kernel is a chain of dependent global loads (74 % of its wave cycles are parked on them): everything the early exits and the
-    // factor loop need from the first level is fetched before any of it is tested
-    const SolverState& st = w.st[b];
-    const int st_done = st.done, st_valid = st.cand_valid, st_cur = st.cur, nfeat = w.nfeat[b];
-    const int e = w.cole[(size_t)b * d.F + f];
+// Compact rows of E^T F, ete, etb of one eliminated (free inverse-depth) column, by one wavefront: every factor of a feature shares its
+// pose_i / ex / td entries (register sums in the fixed order of the feature's factor list), its pose_j entries are unique (direct stores).
+__device__ __forceinline__ void et_row(const Win& w, const StepBufs& sb, const Dims& d, int b, int f, int e, int which, int lane) {
     const int p0 = w.feat_ptr[(size_t)b * (d.F + 1) + f], p1 = w.feat_ptr[(size_t)b * (d.F + 1) + f + 1];
-    if (st_done && !ignore_done) return;
-    if (!ignore_done && which < 0 && !st_valid) return;
-    if (f >= nfeat || e < 0) return;
-    if (which < 0) which = 1 - st_cur;
     const double* efac = w.efac + ((size_t)which * d.B + b) * d.NV * EF;
     double* Et = sb.Et + (((size_t)which * d.B + b) * d.FP + e) * d.ECW;
     for (int c = lane; c < d.ECW; c += 64) Et[c] = 0.0;
@@ -1113,6 +664,357 @@ __global__ void __launch_bounds__(64) ba_build_et(Win w, StepBufs sb, int which,
     else if (lane == 19) sb.ete[((size_t)which * d.B + b) * d.FP + e] = acc;
     else if (lane == 20) sb.etb[((size_t)which * d.B + b) * d.FP + e] = acc;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Window-level visual sweep: one block of NW wavefronts per window.  The pair-sorted factor list (gf_ba.hip packs it: factors of one
+// frame pair (i, j) are contiguous, pairs padded to even length) is cut into NW contiguous ranges of 64-factor chunks, one per wavefront.
+// A wavefront evaluates 64 factors at a time (one per lane), stages their block rows in LDS and contracts J^T J / J^T r of a frame pair on
+// the matrix cores; the tile of a pair stays in the accumulators across chunk boundaries and is stored -- not added -- once, when the
+// pair ends: into the pair's own slot, or, when the pair began in the previous wavefront's range, into this wavefront's continuation slot.
+// Afterwards the continuation slots are folded into the pair slots in wavefront order, and every entry of the window's compact visual
+// system Vc (columns 6 p + q of pose p, camera extrinsic, td, right-hand side; packed lower triangle) is summed by one thread over the
+// pair tiles that touch it, in frame order.  No floating-point atomics: the result does not depend on timing.
+// The kernel then builds the compact E^T F rows of the free inverse depths (et_row), which ba_step / ba_marg_finish eliminate.
+// Slots: NP (NP - 1) / 2 + NW tiles of 14 x 14 (EX: 20 x 20) packed lower triangles, in LDS when they fit (W = 10), else in w.vtile.
+constexpr int kVW = 12;               // wavefronts per block, fixed extrinsic (three per SIMD at the kernel's ~150 VGPRs)
+constexpr int kVWX = 6;               // wavefronts per block when the camera extrinsic carries columns
+__host__ __device__ constexpr int vwin_sg(bool ex) { return ex ? 16 : 32; }       // factors staged per pass
+__host__ __device__ constexpr int vwin_lstr(bool ex) { return ex ? 65 : 33; }     // staging row stride: 2 rows x COLS + 1
+__host__ __device__ constexpr int vwin_tn(bool ex) { return ex ? 210 : 105; }     // packed tile: 20 x 21 / 2, 14 x 15 / 2
+__host__ __device__ inline size_t vwin_slot_doubles(int NP, bool ex) { return ((size_t)NP * (NP - 1) / 2 + (ex ? kVWX : kVW)) * vwin_tn(ex); }
+// EX: the camera extrinsic block has columns (free in the solve, or a kept block of the marginalisation): second 16-column tile
+template <bool EX, int NW>
+__global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBufs sb, int which, int which_state, int only_cand_valid) {
+    constexpr int COLS = EX ? 32 : 16, LSTR = vwin_lstr(EX), SG = vwin_sg(EX), TN = vwin_tn(EX), NT = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) double v_dyn[];   // pair-tile slots (when they fit)
+    __shared__ double Jst[NW * SG * LSTR];
+    __shared__ int s_pr[NW][64];
+    __shared__ double s_cost[NW];
+    __shared__ int s_first[NW], s_last[NW], s_cont[NW];
+    const Dims d = w.d;
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, NP = d.NP;
+    const SolverState& st = w.st[b];
+    if (st.done && only_cand_valid != 2) return;   // only_cand_valid == 2: marginalisation pass (runs on finished windows)
+    if (only_cand_valid == 1 && !st.cand_valid) return;
+    const int n_order = w.norder[b];
+    if (which < 0) which = 1 - st.cur;
+    if (which_state == -2) which_state = st.cur; else if (which_state < 0) which_state = 1 - st.cur;
+    const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
+    const int* colf = w.colf + (size_t)b * d.NFB;
+    const int NPAIR = NP * (NP - 1) / 2;
+    double* slots = w.vtile ? w.vtile + (size_t)b * w.vtile_stride : v_dyn;
+    double* bnd = slots + (size_t)NPAIR * TN;
+    for (int i = tid; i < (NPAIR + NW) * TN; i += NT) slots[i] = 0.0;
+    // this wavefront's range of chunks, and the pair keys at its ends (a pair that straddles two ranges has a main and a continuation slot)
+    const int nchunks = (n_order + 63) / 64, cpw = (nchunks + NW - 1) / NW;
+    const int c_lo = min(nchunks, wave * cpw), c_hi = min(nchunks, c_lo + cpw);
+    const int* ord = w.order + (size_t)b * d.NVP;
+    {
+        int kf = -1, kl = -1;
+        if (c_lo < c_hi) {
+            const int e0 = 64 * c_lo + lane, e1 = 64 * (c_hi - 1) + lane;
+            const int o0 = e0 < n_order ? ord[e0] : -1, o1 = e1 < n_order ? ord[e1] : -1;
+            const unsigned long long m0 = __ballot(o0 >= 0), m1 = __ballot(o1 >= 0);
+            if (m0) kf = __shfl(o0, __ffsll((long long)m0) - 1) >> 16;
+            if (m1) kl = __shfl(o1, 63 - __clzll((long long)m1)) >> 16;
+        }
+        if (lane == 0) { s_first[wave] = kf; s_last[wave] = kl; }
+    }
+    __syncthreads();
+    const int first_key = s_first[wave];
+    const bool continuing = wave > 0 && first_key >= 0 && s_last[wave - 1] == first_key;
+    if (lane == 0) s_cont[wave] = continuing ? ((first_key & 63) * ((first_key & 63) - 1) / 2 + (first_key >> 6)) : -1;
+    double* Jbuf = Jst + wave * SG * LSTR;
+    int* s_pair = s_pr[wave];
+    double cost = 0.0;
+    d4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
+    int cur_pair = -1;
+    auto flush = [&](int pair) {   // store the finished tile of `pair` (local columns: 0-5 pose_i, 6-11 pose_j, 12 td, 13 residual, 14-19 extrinsic)
+        if (pair < 0) return;
+        const int pi = pair >> 6, pj = pair & 63;
+        double* dst = (continuing && pair == first_key) ? bnd + (size_t)wave * TN : slots + (size_t)(pj * (pj - 1) / 2 + pi) * TN;
+        const int tb = lane & 15;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int ta = (lane >> 4) + 4 * r;
+            if (ta < 14 && tb <= ta) dst[ta * (ta + 1) / 2 + tb] = acc00[r];
+            if (EX) {
+                if (ta < 14 && tb < 6) dst[(14 + tb) * (15 + tb) / 2 + ta] = acc01[r];          // extrinsic column tb x tile-0 column ta
+                if (ta < 6 && tb <= ta) dst[(14 + ta) * (15 + ta) / 2 + 14 + tb] = acc11[r];
+            }
+        }
+        acc00 = d4{0, 0, 0, 0}; acc01 = d4{0, 0, 0, 0}; acc11 = d4{0, 0, 0, 0};
+    };
+    for (int ch = c_lo; ch < c_hi; ch++) {
+        const int entry = ch * 64 + lane;
+        const int oe = entry < n_order ? ord[entry] : -1;
+        const int k = oe < 0 ? -1 : (oe & 0xffff);
+        int fi, fj;
+        VisEval ev;
+        cost += vis_lane_eval<EX>(w, d, b, which, k, xs, colf, ev, fi, fj);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();   // the previous chunk's reads of s_pair are done
+        s_pair[lane] = oe < 0 ? -1 : (oe >> 16);
+        // the 64 block rows go through the staging area SG factors at a time
+#pragma unroll
+        for (int part = 0; part < 64 / SG; part++) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();   // the previous part's reads are done
+            if (lane / SG == part) {
+                const int l = lane % SG;
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+#pragma unroll
+                    for (int c = 0; c < 16; c++) Jbuf[l * LSTR + r * COLS + c] = (c < 14) ? ev.row[r][c] : 0.0;
+                    if (EX) {
+#pragma unroll
+                        for (int c = 0; c < 16; c++) Jbuf[l * LSTR + r * COLS + 16 + c] = (c < 6) ? ev.row[r][16 + c] : 0.0;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+            for (int m = 0; m < SG / 2; m++) {
+                const int pair = s_pair[SG * part + 2 * m];   // pairs are padded to even length: entries 2m and 2m+1 share the pair (or are padding)
+                if (pair < 0) continue;
+                if (pair != cur_pair) { flush(cur_pair); cur_pair = pair; }
+                const int e = 2 * m + (lane >> 5), r = (lane >> 4) & 1, c = lane & 15;
+                const double a0 = Jbuf[e * LSTR + r * COLS + c];
+                acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc00, 0, 0, 0);
+                if (EX) {
+                    const double a1 = Jbuf[e * LSTR + r * COLS + 16 + c];
+                    acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a1, acc01, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc11, 0, 0, 0);
+                }
+            }
+        }
+    }
+    flush(cur_pair);
+    cost = wave_sum_f64(cost);
+    if (lane == 0) s_cost[wave] = cost;
+    __syncthreads();
+    if (tid == 0) { double c = 0; for (int q = 0; q < NW; q++) c += s_cost[q]; *cost_part(w, 1, which, b) = c; }
+    // ---- continuation slots -> pair slots, in wavefront order
+    for (int t = tid; t < TN; t += NT)
+        for (int ww = 1; ww < NW; ww++) { const int p = s_cont[ww]; if (p >= 0) slots[(size_t)p * TN + t] += bnd[(size_t)ww * TN + t]; }
+    __syncthreads();
+    // ---- the window's compact visual system: entry (ka >= kb) = sum over the pair tiles that hold both columns, in frame order
+    {
+        const int EXC = 6 * NP, TD = EXC + 6, RHS = EXC + 7, NCc = EXC + 8;
+        double* Vc = w.Vc + ((size_t)which * d.B + b) * d.NVC;
+        auto T = [&](int i, int j, int la, int lb) -> double {   // tile of pair (i < j), local entry (la, lb)
+            const int hi = max(la, lb), lo = min(la, lb);
+            return slots[(size_t)(j * (j - 1) / 2 + i) * TN + hi * (hi + 1) / 2 + lo];
+        };
+        auto loc_other = [&](int k) -> int { return k < TD ? (EX ? 14 + (k - EXC) : -1) : k == TD ? 12 : 13; };   // local index of a non-pose column
+        for (int idx = tid; idx < NCc * (NCc + 1) / 2; idx += NT) {
+            const int ka = tri_row(idx), kb = idx - ka * (ka + 1) / 2;
+            double s = 0.0;
+            if (ka < EXC) {                                   // pose x pose (kb <= ka: also a pose column)
+                const int fa = ka / 6, qa = ka - 6 * fa, fb = kb / 6, qb = kb - 6 * fb;
+                if (fa == fb) {
+                    for (int t = 0; t < NP; t++) {
+                        if (t == fa) continue;
+                        const int o = t > fa ? 0 : 6;          // fa is the pair's first frame (local 0-5) or its second (6-11)
+                        s += T(min(t, fa), max(t, fa), o + qa, o + qb);
+                    }
+                } else s = T(fb, fa, 6 + qa, qb);             // fa > fb: only the pair (fb, fa)
+            } else {
+                const int la = loc_other(ka);
+                if (la >= 0) {
+                    if (kb < EXC) {                           // extrinsic / td / rhs x pose
+                        const int fb = kb / 6, qb = kb - 6 * fb;
+                        for (int t = 0; t < NP; t++) {
+                            if (t == fb) continue;
+                            s += T(min(t, fb), max(t, fb), la, (t > fb ? 0 : 6) + qb);
+                        }
+                    } else {
+                        const int lb = loc_other(kb);
+                        if (lb >= 0 && !(ka == RHS && kb == RHS)) for (int j = 1; j < NP; j++) for (int i = 0; i < j; i++) s += T(i, j, la, lb);
+                    }
+                }
+            }
+            Vc[idx] = s;
+        }
+    }
+    // ---- compact E^T F rows of the free inverse depths (the factor products efac were written above by this block)
+    {
+        const int nfeat = w.nfeat[b];
+        const int* cole = w.cole + (size_t)b * d.F;
+        for (int f = wave; f < nfeat; f += NW) { const int e = cole[f]; if (e >= 0) et_row(w, sb, d, b, f, e, which, lane); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Window-level prior / IMU / wheel sweep: one block of kMW wavefronts per window, the only writer of H and g.
+//  phase 1  wavefront 0 evaluates the IMU factors (lane k = factor k: a factor evaluation is a ~10^4-instruction scalar program, so all
+//           factors of the window cost the latency of one), wavefront 1 the wheel factors, into padded block rows [J | r] in LDS;
+//           the other wavefronts meanwhile write the prior's part: H <- A gathered to this pass's columns (lower triangle of the
+//           first R rows), g <- b0 + A dx, prior cost (marginalization_factor.cpp:344-392: r = r0 + J0 dx).
+//  phase 2-5 whitening + J^T J of each factor on the matrix cores (misc_mfma_accumulate), added to H / g with plain read-modify-writes:
+//           IMU factors starting at even frames, then odd frames, then wheel factors even / odd -- factors of one phase share no column,
+//           so every entry sees its additions in one fixed order.
+//  phase 6  the block all wheel factors share (wheel extrinsic, sx, sy, sw, td_wheel) is summed over the factors in order by one
+//           thread per entry; costs are added in factor order.
+// frame_filter: 0 all factors; 1 only factors starting at frame 0 (MARGIN_OLD); 2 no IMU / wheel factor (MARGIN_SECOND_NEW).
+// Dynamic LDS (doubles): W x 16 x 33 IMU block rows, W x 9 x 33 wheel block rows, W x 66 shared-block stash, nscr x (16 x 33 + 16) scratch.
+constexpr int kMW = 8;
+constexpr int kMJi = 16 * 33, kMJw = 9 * 33, kMSh = 66, kMScr = 16 * 33 + 16;   // scratch: W', column map (32 ints)
+__host__ __device__ inline int misc_win_nscr(int W) { return W <= 12 ? kMW : 2; }   // whitening wavefronts (scratch areas): long windows leave room for two
+__host__ __device__ inline size_t misc_win_lds_doubles(int W) { return (size_t)W * (kMJi + kMJw + kMSh) + (size_t)misc_win_nscr(W) * kMScr; }
+__global__ void __launch_bounds__(64 * kMW) ba_linearize_misc_win(Win w, int which, int which_state, int only_cand_valid, int frame_filter) {
+    extern __shared__ __attribute__((aligned(16))) double m_lds[];
+    __shared__ double s_fcost[64];       // per-factor costs: IMU k at k, wheel k at 32 + k
+    __shared__ double s_wc[kMW];         // prior cost partials of the wavefronts
+    __shared__ double s_dx[512];
+    __shared__ int s_pcol[512], s_pidx[512], s_R;
+    const Dims d = w.d;
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, RP = d.RP;
+    const SolverState& st = w.st[b];
+    if (st.done && only_cand_valid != 2) return;
+    if (only_cand_valid == 1 && !st.cand_valid) return;
+    if (which < 0) which = 1 - st.cur;
+    if (which_state == -2) which_state = st.cur; else if (which_state < 0) which_state = 1 - st.cur;
+    const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
+    const int* colf = w.colf + (size_t)b * d.NFB;
+    double* H = w.H + ((size_t)which * d.B + b) * RP * RP;
+    double* g = w.g + ((size_t)which * d.B + b) * RP;
+    const int nimu = frame_filter == 2 ? 0 : w.nimu[b], nwh = frame_filter == 2 ? 0 : w.nwh[b];
+    const int nscr = misc_win_nscr(d.W);
+    double* sJi = m_lds;                          // [W][16][33]
+    double* sJw = sJi + (size_t)d.W * kMJi;       // [W][9][33]
+    double* sSh = sJw + (size_t)d.W * kMJw;       // [W][66]
+    double* scr = sSh + (size_t)d.W * kMSh + (size_t)min(wave, nscr - 1) * kMScr;
+    double* sW = scr; int* scol = reinterpret_cast<int*>(scr + 16 * 33);
+    const int* imu_i = w.imu_i + (size_t)b * d.W; const int* wh_i = w.wh_i + (size_t)b * d.W;
+    auto imu_on = [&](int k) -> bool { return frame_filter != 1 || imu_i[k] == 0; };
+    auto wh_on = [&](int k) -> bool { return frame_filter != 1 || wh_i[k] == 0; };
+    for (int q = tid; q < nimu * kMJi; q += 64 * kMW) sJi[q] = 0.0;
+    for (int q = tid; q < nwh * (kMJw + 0); q += 64 * kMW) sJw[q] = 0.0;
+    if (tid < 64) s_fcost[tid] = 0.0;
+    if (tid < kMW) s_wc[tid] = 0.0;
+    for (int q = tid; q < 512; q += 64 * kMW) { s_pidx[q] = -1; s_pcol[q] = -1; }
+    if (tid == 0) {   // number of columns of this pass: blocks with a column are laid out contiguously from 0
+        int R = 0;
+        for (int q = 0; q < d.NFB; q++) {
+            if (colf[q] < 0) continue;
+            const int ls = q < 2 * d.NP ? ((q & 1) ? 9 : 6) : q < 2 * d.NP + 2 ? 6 : (d.GO && q == fb_anc(d.NP)) ? 3 : 1;
+            R = max(R, colf[q] + ls);
+        }
+        s_R = R;
+    }
+    __syncthreads();
+    const int R = s_R, n = w.pri_n[b];
+    {   // prior: dx of every kept block (marginalization_factor.cpp:348-372), column of every local prior index, and the inverse map
+        const int nb = n > 0 ? w.pri_nb[b] : 0;
+        const int* bid = w.pri_bid + (size_t)b * 64;
+        const double* x0 = w.pri_x0 + (size_t)b * d.NPRI * 2;
+        if (tid < nb) {
+            int idx = 0, o0 = 0;
+            for (int q = 0; q < tid; q++) { idx += lsize_kind(bid[q] / 4096); o0 += gsize_kind(bid[q] / 4096); }
+            const int id = bid[tid], kind = id / 4096;
+            double dx[9];
+            prior_block_dx(kind, xs + state_off_of(id, d), x0 + o0, dx);
+            const int fb = fblock_of(id, d);
+            const int c0 = fb >= 0 ? colf[fb] : -1;
+            for (int q = 0; q < lsize_kind(kind); q++) { s_dx[idx + q] = dx[q]; s_pcol[idx + q] = c0 >= 0 ? c0 + q : -1; if (c0 >= 0) s_pidx[c0 + q] = idx + q; }
+        }
+    }
+    __syncthreads();
+    // ---- phase 1: factor evaluation (wavefronts 0, 1) next to the prior's part of H, g, cost (wavefronts 2..)
+    if (wave == 0) {
+        if (lane < nimu && imu_on(lane)) {
+            const int k = lane, i = imu_i[k], j = i + 1;
+            imu_raw(xs + off_pose(i), xs + off_sb(i), xs + off_pose(j), xs + off_sb(j), w.imu_data + ((size_t)b * d.W + k) * IMU_STRIDE2, w.wpar + 4 * b, sJi + kMJi * k + 30,
+                    sJi + kMJi * k, true, true, 33, 33);
+        }
+    } else if (wave == 1) {
+        if (lane < nwh && wh_on(lane)) {
+            const int k = lane, i = wh_i[k], j = i + 1;
+            wheel_raw(xs + off_pose(i), xs + off_pose(j), xs + off_exw(d.NP), xs[off_ix(d.NP)], xs[off_ix(d.NP) + 1], xs[off_ix(d.NP) + 2], xs[off_tdw(d.NP)],
+                      w.wh_data + ((size_t)b * d.W + k) * WH_STRIDE, sJw + kMJw * k + 22, sJw + kMJw * k, true, true, 33, 33);
+        }
+    } else {
+        const int t6 = tid - 128, NT6 = 64 * (kMW - 2);
+        const double* A = w.pri_A + (size_t)b * d.NPRI * d.NPRI;
+        const double* b0 = w.pri_b + (size_t)b * d.NPRI;
+        // g <- b0 + A dx at the prior's columns, 0 elsewhere; cost = 1/2 (c0 + 2 b0.dx + dx^T A dx)
+        double pc = 0.0;
+        for (int a = t6; a < n; a += NT6) {
+            double v = 0;
+            for (int c2 = 0; c2 < n; c2++) v += A[(size_t)a * n + c2] * s_dx[c2];
+            pc += s_dx[a] * (b0[a] + 0.5 * v);
+            if (s_pcol[a] >= 0) g[s_pcol[a]] = b0[a] + v;
+        }
+        for (int c = t6; c < R; c += NT6) if (s_pidx[c] < 0) g[c] = 0.0;
+        pc = wave_sum_f64(pc);
+        if (lane == 0) s_wc[wave] = pc;
+        // H <- A gathered to this pass's columns: lower triangle of the first R rows, four rows per wavefront in flight
+        for (int r0 = wave - 2; r0 < R; r0 += 4 * (kMW - 2)) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int r = r0 + (kMW - 2) * m;
+                if (r >= R) continue;
+                const int pr = s_pidx[r];
+                double* dst = H + (size_t)r * RP;
+                for (int c = lane; c <= r; c += 64) {
+                    const int pc2 = s_pidx[c];
+                    dst[c] = (pr >= 0 && pc2 >= 0) ? A[(size_t)pr * n + pc2] : 0.0;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phases 2-5: whitened J^T J / J^T r of the factors on the matrix cores, parity classes one after the other
+    double fcost = 0.0;   // lane-uniform per wavefront
+#pragma unroll 1
+    for (int ph = 0; ph < 4; ph++) {
+        const bool is_imu = ph < 2;
+        const int par = ph & 1, nf = is_imu ? nimu : nwh;
+        if (wave < nscr) {
+            int slot = 0;
+            for (int k = 0; k < nf; k++) {
+                const int i = is_imu ? imu_i[k] : wh_i[k];
+                if ((i & 1) != par || !(is_imu ? imu_on(k) : wh_on(k))) continue;
+                if ((slot++ % nscr) != wave) continue;
+                misc_cols(is_imu, i, colf, d.NP, scol, lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                double c;
+                if (is_imu) c = misc_mfma_accumulate<15, 30, 30>(w.imu_sqrt + ((size_t)b * d.W + k) * 225, sJi + kMJi * k, sW, scol, H, g, RP, nullptr, lane);
+                else c = misc_mfma_accumulate<6, 22, 12>(w.wh_sqrt + ((size_t)b * d.W + k) * 36, sJw + kMJw * k, sW, scol, H, g, RP, sSh + kMSh * k, lane);
+                if (lane == 0) s_fcost[(is_imu ? 0 : 32) + k] = c;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();   // scratch is reused by the next factor
+            }
+        }
+        __syncthreads();
+    }
+    // ---- phase 6: the block shared by all wheel factors (local columns 12-21: wheel extrinsic 6, sx, sy, sw, td_wheel), summed in factor order
+    if (tid < 65 && nwh > 0) {
+        int la = 0, lb = 0;   // entry tid < 55: (la >= lb) of the packed 10 x 10 block; else J^T r of local column tid - 55
+        if (tid < 55) { la = tri_row(tid); lb = tid - la * (la + 1) / 2; } else la = lb = tid - 55;
+        auto col_of = [&](int l) -> int { const int blk = l < 6 ? fb_exw(d.NP) : l < 9 ? fb_sx(d.NP) + (l - 6) : fb_tdw(d.NP); const int c0 = colf[blk]; return c0 >= 0 ? c0 + (l < 6 ? l : 0) : -1; };
+        const int ca = col_of(la), cb = col_of(lb);
+        if (ca >= 0 && cb >= 0) {
+            double* dst = tid < 55 ? H + (size_t)max(ca, cb) * RP + min(ca, cb) : g + ca;
+            double v = *dst;
+            for (int k = 0; k < nwh; k++) if (wh_on(k)) v += sSh[kMSh * k + tid];
+            *dst = v;
+        }
+    }
+    if (tid == 0) {
+        double c = 0.5 * w.pri_c[b] * (n > 0 ? 1.0 : 0.0);
+        for (int q = 2; q < kMW; q++) c += s_wc[q];
+        for (int k = 0; k < nimu; k++) c += s_fcost[k];
+        for (int k = 0; k < nwh; k++) c += s_fcost[32 + k];
+        *cost_part(w, 0, which, b) = c;
+        *cost_part(w, 2, which, b) = 0.0;   // the GNSS kernel (same stream, later) adds its part
+    }
+}
+
+// PoseLocalParameterization::Plus (pose_local_parameterization.cpp:12-28)
+__device__ __forceinline__ void pose_plus(const double* x, const double* dl, double* out) {
+    out[0] = x[0] + dl[0]; out[1] = x[1] + dl[1]; out[2] = x[2] + dl[2];
+    const Q4 q = qnormalized(qmul(Q4{x[6], x[3], x[4], x[5]}, deltaQ(v3(dl[3], dl[4], dl[5]))));
+    out[3] = q.x; out[4] = q.y; out[5] = q.z; out[6] = q.w;
+}
+
 // reduced column of compact column k (or -1); the right-hand-side slot maps to `rhs_col`
 __device__ __forceinline__ int compact_to_col(int k, const int* colf, int NP, int rhs_col) {
     if (k < 6 * NP) { const int c0 = colf[fb_pose(k / 6)]; return c0 >= 0 ? c0 + k % 6 : -1; }
@@ -1194,36 +1096,6 @@ __device__ inline bool wave_chol16_inv(double* s_L, double* s_inv, double* s_rdi
     return good;
 }
 
-// Start of a solve: buffer 0 of the normal equations <- the prior (lower triangle of the first R rows: nothing else is ever read or
-// accumulated), g <- 0, both costs <- 0.  Replaces a full RP x RP device copy per window (75 MB for 256 windows) and two memsets.
-__global__ void __launch_bounds__(512) ba_reset_first(Win w) {
-    const Dims d = w.d;
-    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, RP = d.RP;
-    const int R = w.st[b].R;
-    double* Hc = w.H + (size_t)b * RP * RP;
-    const double* H0 = w.pri_H0 + (size_t)b * RP * RP;
-    for (int r0 = wave; r0 < R; r0 += 32) {   // four rows per wavefront in flight, two doubles per lane (rows are 128-B aligned)
-        double2 v[4][4];
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const int r = r0 + 8 * m;
-            const double2* src = reinterpret_cast<const double2*>(H0 + (size_t)min(r, R - 1) * RP);
-#pragma unroll
-            for (int q = 0; q < 4; q++) { const int c2 = lane + 64 * q; v[m][q] = (r < R && 2 * c2 <= r && 2 * c2 < RP) ? src[c2] : make_double2(0.0, 0.0); }
-        }
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const int r = r0 + 8 * m;
-            if (r >= R) continue;
-            double2* dst = reinterpret_cast<double2*>(Hc + (size_t)r * RP);
-#pragma unroll
-            for (int q = 0; q < 4; q++) { const int c2 = lane + 64 * q; if (2 * c2 <= r && 2 * c2 < RP) dst[c2] = v[m][q]; }
-        }
-    }
-    for (int i = tid; i < RP; i += 512) w.g[(size_t)b * RP + i] = 0.0;
-    if (tid == 0) { w.cost[b] = 0.0; w.cost[(size_t)d.B + b] = 0.0; }
-}
-
 // One 512-thread block per window: accept/reject of the previous candidate (trust_region_minimizer.cc), then the next
 // dogleg step (dogleg_strategy.cc): Jacobi scaling, Cauchy point, Gauss-Newton step through the Schur complement
 // (MFMA GEMM) and an LDS-resident blocked Cholesky, candidate point.  first: the call that follows the initial linearisation.
@@ -1239,6 +1111,9 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
     __shared__ int s_cmap[256];      // compact column -> reduced column (or -1), right-hand-side slot -> R
     __shared__ double s_uc[256];     // a vector gathered to the compact layout
     __shared__ double s_rd[512];     // reciprocals of the Cholesky diagonal
+    __shared__ int s_rc[512];        // reduced column -> compact column of the visual system Vc (or -1)
+    __shared__ double s_hd[512];     // diagonal of H + Vc
+    __shared__ double s_gt[512];     // g + Vc's right-hand-side row
     const Dims d = w.d;
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     SolverState& st = w.st[b];
@@ -1251,16 +1126,19 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
     double* gn = sb.gn + (size_t)b * VS; double* stepv = sb.step + (size_t)b * VS; double* u = sb.u + (size_t)b * VS; double* yv = sb.yv + (size_t)b * VS;
     double* Es = sb.Es + (size_t)b * d.FP * ECW;
     if (tid < ECW) s_cmap[tid] = compact_to_col(tid, colf, d.NP, R);
+    s_rc[tid] = -1;
+    __syncthreads();
+    if (tid < 6 * d.NP + 7) { const int c = s_cmap[tid]; if (c >= 0 && c < R) s_rc[c] = tid; }
     GF_STAMP(0);
     // ---------------- accept / reject the candidate of the previous iteration
     if (tid == 0) {
         s_flag[0] = 0;
         if (first) {
-            st.x_cost = w.cost[(size_t)st.cur * d.B + b];
+            st.x_cost = cost_total(w, st.cur, b);
             st.initial_cost = st.x_cost;
             st.last_successful = 1;
         } else if (st.cand_valid) {
-            const double cand_cost = w.cost[(size_t)(1 - st.cur) * d.B + b];
+            const double cand_cost = cost_total(w, 1 - st.cur, b);
             st.cand_cost = cand_cost;
             if (st.step_norm <= 1e-8 * (st.x_norm + 1e-8)) { st.done = 1; st.termination = 2; }
             else if (fabs(st.x_cost - cand_cost) <= 1e-6 * st.x_cost) { st.done = 1; st.termination = 1; }
@@ -1285,18 +1163,28 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
     const double* Et = sb.Et + ((size_t)cur * d.B + b) * d.FP * ECW;
     const double* ete = sb.ete + ((size_t)cur * d.B + b) * d.FP;
     const double* etb = sb.etb + ((size_t)cur * d.B + b) * d.FP;
+    // the visual part of the normal equations lives in its own compact system Vc (ba_linearize_visual_win): diagonal and right-hand side of
+    // the sum, once per call
+    const double* Vc = w.Vc + ((size_t)cur * d.B + b) * d.NVC;
+    const int RHSK = 6 * d.NP + 7;
+    for (int c = tid; c < R; c += 512) {
+        const int k = s_rc[c];
+        s_hd[c] = H[(size_t)c * RP + c] + (k >= 0 ? Vc[pk(k, k)] : 0.0);
+        s_gt[c] = g[c] + (k >= 0 ? Vc[pk(RHSK, k)] : 0.0);
+    }
+    __syncthreads();
     GF_STAMP(1);
     if (!st.reuse) {
         // ---------------- Jacobi scaling from the initial Jacobian (trust_region_minimizer.cc: jacobian_scaling_)
         if (!st.have_scale) {
-            for (int c = tid; c < R; c += 512) scale[c] = 1.0 / (1.0 + sqrt(H[(size_t)c * RP + c]));
+            for (int c = tid; c < R; c += 512) scale[c] = 1.0 / (1.0 + sqrt(s_hd[c]));
             for (int e = tid; e < NE; e += 512) scale[RP + e] = 1.0 / (1.0 + sqrt(ete[e]));
             __syncthreads();
             if (tid == 0) st.have_scale = 1;
         }
         // unscaled gradient max norm (gradient tolerance)
         double gm = 0;
-        for (int c = tid; c < R; c += 512) gm = fmax(gm, fabs(g[c]));
+        for (int c = tid; c < R; c += 512) gm = fmax(gm, fabs(s_gt[c]));
         for (int e = tid; e < NE; e += 512) gm = fmax(gm, fabs(etb[e]));
         gm = block_max(gm, sred, tid, 512);
         if (tid == 0) st.gmax = gm;
@@ -1317,8 +1205,8 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
         GF_STAMP(4);
         // ---------------- dogleg diagonal, scaled gradient, Cauchy point
         for (int c = tid; c < R; c += 512) {
-            const double dd = sqrt(fmin(fmax(scale[c] * scale[c] * H[(size_t)c * RP + c], 1e-6), 1e32));
-            diag[c] = dd; grad[c] = scale[c] * g[c] / dd; u[c] = scale[c] * (grad[c] / dd);
+            const double dd = sqrt(fmin(fmax(scale[c] * scale[c] * s_hd[c], 1e-6), 1e32));
+            diag[c] = dd; grad[c] = scale[c] * s_gt[c] / dd; u[c] = scale[c] * (grad[c] / dd);
         }
         for (int e = tid; e < NE; e += 512) {
             const double sc = scale[RP + e];
@@ -1392,9 +1280,16 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                 for (int m = 0; m < 4; m++) {
                     const int r = r0 + 8 * m;
                     srv[m] = r < R ? scale[r] : 0.0; urv[m] = r < R ? u[r] : 0.0;
-                    const double* hr = r < R ? H + (size_t)r * RP : g;   // row R: the right-hand side s g
+                    const double* hr = H + (size_t)min(r, R - 1) * RP;
+                    const int kr = r < R ? s_rc[r] : -1;   // compact -> reduced is monotone: a lower-triangle entry (r, c) is the lower-triangle entry (kr, kc) of Vc
 #pragma unroll
-                    for (int q = 0; q < QN; q++) { const int c = lane + 64 * q; hv[m][q] = (r <= R && c < R && (c <= r)) ? hr[c] : 0.0; }
+                    for (int q = 0; q < QN; q++) {
+                        const int c = lane + 64 * q;
+                        double v = 0.0;
+                        if (r < R && c <= r) { const int kc = s_rc[c]; v = hr[c] + ((kr >= 0 && kc >= 0) ? Vc[pk(kr, kc)] : 0.0); }
+                        else if (r == R && c < R) v = s_gt[c];   // row R: the right-hand side s g
+                        hv[m][q] = v;
+                    }
                 }
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
@@ -1637,36 +1532,9 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
     }
     __syncthreads();
     GF_STAMP(13);
-    // ---------------- candidate point x (+) delta, delta = step .* scale = u ; zero the candidate's normal equations
+    // ---------------- candidate point x (+) delta, delta = step .* scale = u  (its normal equations are written, not accumulated, by the next sweeps)
     double* xc = w.xs + ((size_t)(1 - cur) * d.B + b) * d.XS;
     for (int i = tid; i < d.XS; i += 512) xc[i] = xs[i];
-    {
-        double* Hc = w.H + ((size_t)(1 - cur) * d.B + b) * RP * RP;
-        const double* H0 = w.pri_H0 + (size_t)b * RP * RP;
-        // only the lower triangle of the first R rows is ever read or accumulated: copy that, two doubles per lane (rows are 128-B aligned)
-        constexpr int CQ = GS ? 4 : 2;   // 128-column chunks of a row
-        for (int r0 = wave; r0 < R; r0 += 32) {   // four rows per wavefront in flight
-            double2 v[4][CQ];
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const int r = r0 + 8 * m;
-                const double2* src = reinterpret_cast<const double2*>(H0 + (size_t)min(r, R - 1) * RP);
-#pragma unroll
-                for (int q = 0; q < CQ; q++) { const int c2 = lane + 64 * q; v[m][q] = (r < R && 2 * c2 <= r) ? src[c2] : make_double2(0.0, 0.0); }
-            }
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const int r = r0 + 8 * m;
-                if (r >= R) continue;
-                double2* dst = reinterpret_cast<double2*>(Hc + (size_t)r * RP);
-#pragma unroll
-                for (int q = 0; q < CQ; q++) { const int c2 = lane + 64 * q; if (2 * c2 <= r) dst[c2] = v[m][q]; }
-            }
-        }
-        double* gc = w.g + ((size_t)(1 - cur) * d.B + b) * RP;
-        for (int i = tid; i < RP; i += 512) gc[i] = 0.0;
-        if (tid == 0) w.cost[(size_t)(1 - cur) * d.B + b] = 0.0;
-    }
     __syncthreads();
     double sn = 0, xn = 0;
     if (valid) {

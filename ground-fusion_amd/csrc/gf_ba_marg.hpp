@@ -1,7 +1,7 @@
 // gf_ba_marg.hpp — device side of the marginalisation prior (MarginalizationInfo::preMarginalize / marginalize,
 // factor/marginalization_factor.cpp:119-308, as driven by estimator.cpp:3334-3631).
 //
-// The dropped-frame factors are linearised by the same kernels as the solver (ba_linearize_visual / ba_linearize_misc)
+// The dropped-frame factors are linearised by the same kernels as the solver (ba_linearize_visual_win / ba_linearize_misc_win)
 // with a marginalisation column map: columns [0, mp) = dropped pose/speed-bias block(s), [mp, mp+n) = kept blocks,
 // eliminated columns = features starting at frame 0.  ba_marg_finish then forms the Schur complement and its
 // thresholded symmetric eigen-decomposition:
@@ -16,17 +16,6 @@
 namespace gfb {
 
 struct MargInfo { int mp, nfe, n, valid; };  // dropped non-feature dims, dropped features, kept dims
-
-__global__ void __launch_bounds__(256) ba_zero_other(Win w) {
-    const Dims d = w.d;
-    const int b = blockIdx.x;
-    const int o = 1 - w.st[b].cur;
-    double* H = w.H + ((size_t)o * d.B + b) * d.RP * d.RP;
-    for (int i = threadIdx.x; i < d.RP * d.RP; i += 256) H[i] = 0.0;
-    double* g = w.g + ((size_t)o * d.B + b) * d.RP;
-    for (int i = threadIdx.x; i < d.RP; i += 256) g[i] = 0.0;
-    if (threadIdx.x == 0) w.cost[(size_t)o * d.B + b] = 0.0;
-}
 
 // Cyclic Jacobi eigen-decomposition of the symmetric n x n matrix A (row-major, leading dim n) by `nthreads` threads of one block
 // (nthreads == 64: a single wavefront, barriers degrade to wave barriers).  V (n x n) receives the eigenvectors in its columns, the
@@ -137,10 +126,11 @@ __device__ inline bool wave_spd_inverse(const double* A, double* T, double* Ainv
 
 struct MargOut { double* J; double* r; };  // [B][NPRI*NPRI], [B][NPRI]
 
-// One 512-thread block per window.  M = H[1-cur] (ld RP) holds the dropped-block + kept-block normal equations, g[1-cur] the
-// right-hand side, efac[1-cur] the per-factor products of the eliminated feature columns.
+// One 512-thread block per window.  M = H[1-cur] (ld RP) holds the prior / IMU / wheel part of the dropped-block + kept-block normal
+// equations and g[1-cur] of the right-hand side (ba_linearize_misc_win with the marginalisation's column map), Vc[1-cur] the visual part
+// in compact columns (use_vc: MARGIN_OLD), Et / ete / etb[1-cur] the compact rows of the eliminated feature columns.
 template <bool GS>   // GS: A and V of the kept system live in global memory (sb.Mg) -- priors larger than 96 columns
-__global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const MargInfo* info, MargOut out) {
+__global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const MargInfo* info, MargOut out, int use_vc) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double sP[MPMAX * MPMAX], sPV[MPMAX * MPMAX], sPinv[MPMAX * MPMAX], sbp[MPMAX];
     __shared__ double s_c[64], s_s[64];
@@ -161,6 +151,18 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     if (tid < ECW) s_cmap[tid] = compact_to_col(tid, w.colf + (size_t)b * d.NFB, d.NP, -1);   // marginalisation column map (swapped in by the caller)
     const double* ete = sb.ete + ((size_t)o * d.B + b) * d.FP; const double* etb = sb.etb + ((size_t)o * d.B + b) * d.FP;
     const double eps = 1e-8;
+    __syncthreads();
+    if (use_vc) {   // M += visual part: every compact entry maps to its own entry of M (one writer each)
+        const double* Vc = w.Vc + ((size_t)o * d.B + b) * d.NVC;
+        const int RHSK = 6 * d.NP + 7;
+        for (int idx = tid; idx < RHSK * (RHSK + 1) / 2; idx += 512) {
+            const int ka = tri_row(idx), kb = idx - ka * (ka + 1) / 2;
+            const int r = s_cmap[ka], c = s_cmap[kb];
+            if (r >= 0 && c >= 0) M[(size_t)max(r, c) * RP + min(r, c)] += Vc[idx];
+        }
+        for (int kb = tid; kb < RHSK; kb += 512) { const int c = s_cmap[kb]; if (c >= 0) bv[c] += Vc[(size_t)RHSK * (RHSK + 1) / 2 + kb]; }
+        __syncthreads();
+    }
 #ifdef GF_PROFILE_STEP
 #define GF_MST(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && sb.stamps) sb.stamps[32 + (i)] = clock64(); } while (0)
 #else

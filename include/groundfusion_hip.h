@@ -197,6 +197,7 @@ typedef struct gf_ba_stats {
     long long solves, jtj_launches, jtj_flops;                 /* jtj_flops: MFMA flops issued by that kernel */
     double ms_step;                                            /* time inside ba_step (one full dogleg step per solve is timed) */
     long long step_launches, step_flops;                       /* step_flops: Schur SYRK + Cholesky + substitutions of the timed launches */
+    long long jtj_alg_flops;                                   /* algorithmic flops of the timed visual J^T J launches: Nv * 2 * 2 * 91 per window */
 } gf_ba_stats;
 
 int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out);

@@ -985,6 +985,9 @@ static int solve(gfo_window* w, int max_iters, gfo_summary* sum) {
 }
 
 // ------------------------------------------------------------------ marginalisation (marginalization_factor.cpp:119-308, estimator.cpp:3334-3631)
+// debug sink (tests only): when set, marginalize() copies the assembled system A (pos x pos, row-major), b, and the Schur complement A_r, b_r
+struct MargDebug { int cap; int pos, m, n; double* A; double* b; double* Ar; double* br; };
+static thread_local MargDebug* g_marg_debug = nullptr;
 static int marginalize(const gfo_window* w, int mode, int cap_n, int* out_n, int* out_nblocks, int* out_block_id, double* out_J, double* out_r, double* out_x0, int* out_m) {
     Problem P; P.w = w;  // only for evaluation helpers: in marginalisation NO block is constant (ResidualBlockInfo has no such notion)
     gfo_window wf = *w;
@@ -1103,6 +1106,10 @@ static int marginalize(const gfo_window* w, int mode, int cap_n, int* out_n, int
             for (int a = 0; a < li; a++) { double sacc = 0; for (int r = 0; r < f.nres; r++) sacc += f.J[i][(size_t)r * li + a] * f.r[r]; b[pi + a] += sacc; }
         }
     }
+    if (g_marg_debug && pos <= g_marg_debug->cap) {
+        MargDebug& dbg = *g_marg_debug; dbg.pos = pos; dbg.m = m; dbg.n = n;
+        for (int i = 0; i < pos; i++) { for (int j = 0; j < pos; j++) dbg.A[(size_t)i * pos + j] = A(i, j); dbg.b[i] = b[i]; }
+    }
     const double eps = 1e-8;
     DMat Amm(m, m), V(m, m);
     for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Amm(i, j) = 0.5 * (A(i, j) + A(j, i));
@@ -1120,6 +1127,10 @@ static int marginalize(const gfo_window* w, int mode, int cap_n, int* out_n, int
         double sb = b[m + i];
         for (int k = 0; k < m; k++) sb -= T(i, k) * b[k];
         br[i] = sb;
+    }
+    if (g_marg_debug && pos <= g_marg_debug->cap) {
+        MargDebug& dbg = *g_marg_debug;
+        for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) dbg.Ar[(size_t)i * n + j] = Ar(i, j); dbg.br[i] = br[i]; }
     }
     DMat V2(n, n);
     std::vector<double> ev2(n);
@@ -1161,6 +1172,17 @@ int gfo_ba_solve(gfo_window* w, int max_iters, gfo_summary* s) { return solve(w,
 int gfo_ba_marginalize(const gfo_window* w, int mode, int cap_n, int* out_n, int* out_nblocks, int* out_block_id, double* out_J, double* out_r, double* out_x0,
                        int* out_m) {
     return marginalize(w, mode, cap_n, out_n, out_nblocks, out_block_id, out_J, out_r, out_x0, out_m);
+}
+/* test helper: the assembled marginalisation system before the Schur complement (A pos x pos, b), and A_r, b_r as the oracle forms them */
+int gfo_ba_marg_system(const gfo_window* w, int mode, int cap, double* A, double* b, double* Ar, double* br, int* pos, int* m, int* n) {
+    MargDebug dbg{cap, 0, 0, 0, A, b, Ar, br};
+    g_marg_debug = &dbg;
+    std::vector<int> bidv(512); std::vector<double> J((size_t)cap * cap), r(cap), x0(2 * (size_t)cap);
+    int on = 0, onb = 0, om = 0;
+    const int rc = marginalize(w, mode, cap, &on, &onb, bidv.data(), J.data(), r.data(), x0.data(), &om);
+    g_marg_debug = nullptr;
+    *pos = dbg.pos; *m = dbg.m; *n = dbg.n;
+    return rc;
 }
 int gfo_factor_eval(const gfo_window* w, int kind, int k, double* residuals, double* jacobians, int* nres, int* ncols) {
     State s; s.load(w);

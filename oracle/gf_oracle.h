@@ -92,6 +92,8 @@ int gfo_ba_solve(gfo_window* w, int max_iters, gfo_summary* s);
 /* estimator.cpp:3334-3631: mode 0 = MARGIN_OLD, 1 = MARGIN_SECOND_NEW. Outputs the next prior (block ids already address-shifted). */
 int gfo_ba_marginalize(const gfo_window* w, int mode, int cap_n, int* out_n, int* out_nblocks, int* out_block_id, double* out_J, double* out_r,
                        double* out_x0, int* out_m);
+/* test helper: the marginalisation's assembled system A (pos x pos, row-major; dropped columns first), b and its Schur complement A_r, b_r */
+int gfo_ba_marg_system(const gfo_window* w, int mode, int cap, double* A, double* b, double* Ar, double* br, int* pos, int* m, int* n);
 /* factor evaluation for unit tests: kind 0 visual k, 1 imu k, 2 wheel k, 3 GnssPsrDopp k, 4 DtDdt (k = 4 i + sys), 5 DdtSmooth k, 6 PoseAnchor; returns residuals and the dense Jacobian wrt the factor's
  * parameter blocks in GLOBAL size (row-major, blocks concatenated), as ceres::CostFunction::Evaluate fills them */
 int gfo_factor_eval(const gfo_window* w, int kind, int k, double* residuals, double* jacobians, int* nres, int* ncols);

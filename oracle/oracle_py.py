@@ -174,6 +174,19 @@ def ba_marginalize(win, mode=0, cap_n=512):
     return {"block_id": ids, "J": J[:nn * nn].copy(), "r": r[:nn].copy(), "x0": x0[:gs].copy(), "m": m.value, "n": nn}
 
 
+def ba_marg_system(win, mode=0, cap=1024):
+    """assembled marginalisation system (A, b; dropped columns first) and the oracle's Schur complement (A_r, b_r)"""
+    _bind_backend()
+    c = win.to_c()
+    A = np.zeros(cap * cap); b = np.zeros(cap); Ar = np.zeros(cap * cap); br = np.zeros(cap)
+    pos, m, n = C.c_int(0), C.c_int(0), C.c_int(0)
+    rc = lib().gfo_ba_marg_system(C.byref(c), mode, cap, _p(A, C.c_double), _p(b, C.c_double), _p(Ar, C.c_double), _p(br, C.c_double),
+                                  C.byref(pos), C.byref(m), C.byref(n))
+    assert rc == 0
+    P, N = pos.value, n.value
+    return {"A": A[:P * P].reshape(P, P).copy(), "b": b[:P].copy(), "Ar": Ar[:N * N].reshape(N, N).copy(), "br": br[:N].copy(), "m": m.value, "n": N}
+
+
 def factor_eval(win, kind, k):
     _bind_backend()
     c = win.to_c()
