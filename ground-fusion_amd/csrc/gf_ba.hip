@@ -62,7 +62,8 @@ struct gf_ba {
     // work
     Buf<double> imu_sqrt, wh_sqrt, pri_A, pri_b, pri_c, H, g, Vc, vtile, wpar, cost, efac;
     Buf<double> scale, diag, grad, gn, step, u, Et, Es, ete, etb, rhs, yv, Sg, Mg, gn_data, gn_misc;
-    Buf<int> ngnss, gn_idx;
+    Buf<int> ngnss, gn_idx, gn_gptr, gn_gitem;
+    Buf<double> gn_rows;
     // marginalisation: column maps per mode (0 MARGIN_OLD, 1 MARGIN_SECOND_NEW), outputs
     Buf<int> mcolf[2], mcole[2], morder[2], mnorder[2], minfo[2];
     Buf<double> outJ, outr;
@@ -77,8 +78,8 @@ struct gf_ba {
     long long jtj_alg_flops = 0;  // algorithmic flops of the same: Nv * 2 * 2 * (12 * 13 / 2 + 12 + 1) per window
     long long step_flops = 0;     // dense algebra of one ba_step over the resident batch: Schur SYRK NE*n_c^2 + Cholesky R^3/3 + substitutions 2 R^2
     std::vector<Buf<double>*> dbl() { return {&xs0, &xs, &vis_data, &imu_data, &wh_data, &pri_J, &pri_r, &pri_x0, &imu_sqrt, &wh_sqrt, &pri_A, &pri_b, &pri_c, &H, &g, &Vc, &vtile, &wpar, &cost, &efac,
-                                              &scale, &diag, &grad, &gn, &step, &u, &Et, &Es, &ete, &etb, &rhs, &yv, &Sg, &Mg, &gn_data, &gn_misc}; }
-    std::vector<Buf<int>*> ints() { return {&colf, &cole, &nvis, &nimu, &nwh, &nfeat, &vis_feat, &vis_i, &vis_j, &order, &norder, &feat_ptr, &feat_fac, &imu_i, &wh_i, &pri_n, &pri_nb, &pri_bid, &ngnss, &gn_idx}; }
+                                              &scale, &diag, &grad, &gn, &step, &u, &Et, &Es, &ete, &etb, &rhs, &yv, &Sg, &Mg, &gn_data, &gn_misc, &gn_rows}; }
+    std::vector<Buf<int>*> ints() { return {&colf, &cole, &nvis, &nimu, &nwh, &nfeat, &vis_feat, &vis_i, &vis_j, &order, &norder, &feat_ptr, &feat_fac, &imu_i, &wh_i, &pri_n, &pri_nb, &pri_bid, &ngnss, &gn_idx, &gn_gptr, &gn_gitem}; }
     void release() {
         for (auto* b : dbl()) b->release();
         for (auto* b : ints()) b->release();
@@ -95,7 +96,7 @@ struct gf_ba {
         Win w{};
         w.d = d; w.xs = xs.d; w.colf = colf.d; w.cole = cole.d; w.nvis = nvis.d; w.nimu = nimu.d; w.nwh = nwh.d; w.nfeat = nfeat.d;
         w.vis_feat = vis_feat.d; w.vis_i = vis_i.d; w.vis_j = vis_j.d; w.vis_data = vis_data.d; w.order = order.d; w.norder = norder.d;
-        w.ngnss = ngnss.d; w.gn_idx = gn_idx.d; w.gn_data = gn_data.d; w.gn_misc = gn_misc.d;
+        w.ngnss = ngnss.d; w.gn_idx = gn_idx.d; w.gn_data = gn_data.d; w.gn_misc = gn_misc.d; w.gn_gptr = gn_gptr.d; w.gn_gitem = gn_gitem.d; w.gn_rows = gn_rows.d;
         w.feat_ptr = feat_ptr.d; w.feat_fac = feat_fac.d; w.imu_i = imu_i.d; w.imu_data = imu_data.d; w.wh_i = wh_i.d; w.wh_data = wh_data.d;
         w.imu_sqrt = imu_sqrt.d; w.wh_sqrt = wh_sqrt.d; w.pri_n = pri_n.d; w.pri_nb = pri_nb.d; w.pri_bid = pri_bid.d; w.pri_J = pri_J.d; w.pri_r = pri_r.d;
         w.pri_x0 = pri_x0.d; w.pri_A = pri_A.d; w.pri_b = pri_b.d; w.pri_c = pri_c.d; w.H = H.d; w.g = g.d; w.Vc = Vc.d; w.cost = cost.d; w.efac = efac.d; w.st = st.d;
@@ -135,6 +136,7 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
             h->ngnss.h[b] = w.gnss_enabled ? w.n_gnss : 0;
             double* ms = h->gn_misc.h + (size_t)b * (GN_MISC + d.NP);
             memset(ms, 0, (GN_MISC + d.NP) * sizeof(double));
+            h->gn_gptr.h[(size_t)b * (d.NGRP + 2) + d.NGRP + 1] = 0;
             if (w.gnss_enabled) {
                 memcpy(x + d.GO, w.para_rcv_dt, 4 * d.NP * 8); memcpy(x + d.GO + 4 * d.NP, w.para_rcv_ddt, d.NP * 8); x[d.GO + 5 * d.NP] = w.para_yaw_enu_local[0];
                 memcpy(x + d.GO + 5 * d.NP + 1, w.para_anc_ecef, 24);
@@ -147,6 +149,20 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
                     ix[0] = w.gnss_frame[k]; ix[1] = w.gnss_lower[k]; ix[2] = w.gnss_sys[k]; ix[3] = 0;
                     double* gd = h->gn_data.h + ((size_t)b * d.NG + k) * GN_STRIDE;
                     memcpy(gd, w.gnss_data + 16 * (size_t)k, 128); gd[16] = w.gnss_ratio[k]; gd[17] = 0;
+                }
+                {   // groups of factors that share their parameter blocks: same (frame, lower_idx), in ascending order; factors keep their order inside a group
+                    std::vector<int> idx(w.n_gnss);
+                    for (int k = 0; k < w.n_gnss; k++) idx[k] = k;
+                    auto key = [&](int k) { return w.gnss_frame[k] * 64 + w.gnss_lower[k]; };
+                    std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return key(a) < key(c); });
+                    int* gp = h->gn_gptr.h + (size_t)b * (d.NGRP + 2);
+                    int* gi = h->gn_gitem.h + (size_t)b * d.NG;
+                    int ngrp = 0;
+                    for (int p = 0; p < w.n_gnss; p++) {
+                        if (p == 0 || key(idx[p]) != key(idx[p - 1])) { if (ngrp >= d.NGRP) return gf::set_err(GF_ERR_CAPACITY, "window %d: more than %d (frame, lower_idx) groups of GNSS factors", b, d.NGRP); gp[ngrp++] = p; }
+                        gi[p] = idx[p];
+                    }
+                    gp[ngrp] = w.n_gnss; gp[d.NGRP + 1] = ngrp;
                 }
             }
             if (w.has_anchor) { memcpy(ms + 9, w.anchor_value, 56); ms[18] = 1.0; }
@@ -333,7 +349,7 @@ int upload(gf_ba* h) {
                     &h->imu_i, &h->wh_i, &h->pri_n, &h->pri_nb, &h->pri_bid})
         HIPCHK(b->up(s));
     for (auto* b : {&h->vis_data, &h->imu_data, &h->wh_data, &h->pri_J, &h->pri_r, &h->pri_x0, &h->wpar}) HIPCHK(b->up(s));
-    if (h->d.GO) { HIPCHK(h->ngnss.up(s)); HIPCHK(h->gn_idx.up(s)); HIPCHK(h->gn_data.up(s)); HIPCHK(h->gn_misc.up(s)); }
+    if (h->d.GO) { HIPCHK(h->ngnss.up(s)); HIPCHK(h->gn_idx.up(s)); HIPCHK(h->gn_data.up(s)); HIPCHK(h->gn_misc.up(s)); HIPCHK(h->gn_gptr.up(s)); HIPCHK(h->gn_gitem.up(s)); }
     for (int m = 0; m < 2; m++) for (auto* b : {&h->mcolf[m], &h->mcole[m], &h->morder[m], &h->mnorder[m], &h->minfo[m]}) HIPCHK(b->up(s));
     HIPCHK(hipMemcpyAsync(h->st0.d, h->st0.h, h->st0.n * sizeof(SolverState), hipMemcpyHostToDevice, s));
     ba_setup<<<dim3(h->d.B), 256, 0, s>>>(h->win());
@@ -370,7 +386,7 @@ int launch_linearize(gf_ba* h, int which, int which_state, int only_valid, bool 
     if (timed) HIPCHK(hipEventRecord(h->ev[3], h->stream));
     HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
     ba_linearize_misc_win<<<dim3(d.B), 64 * kMW, h->mwin_lds, h->stream2>>>(w, which, which_state, only_valid, 0);
-    if (d.GO) ba_linearize_gnss<<<dim3((d.NG + 5 * d.W + 1 + 63) / 64, d.B), 64, 0, h->stream2>>>(w, which, which_state, 0, only_valid, 0);
+    if (d.GO) ba_linearize_gnss<<<dim3(d.B), 256, 0, h->stream2>>>(w, which, which_state, only_valid, 0);
     HIPCHK(hipEventRecord(h->ev_join, h->stream2));
     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
     HIPCHK(hipGetLastError());
@@ -408,7 +424,7 @@ int run_marginalize(gf_ba* h, int mode) {
     // the dropped frame's factors are linearised at the current state into the other buffer set
     if (mode == 0) { if (int rc = launch_visual(h, wm, true, -1, -2, 2)) return rc; }
     ba_linearize_misc_win<<<dim3(d.B), 64 * kMW, h->mwin_lds, h->stream>>>(wm, -1, -2, 2, mode == 0 ? 1 : 2);
-    if (mode == 0 && d.GO) ba_linearize_gnss<<<dim3((d.NG + 5 * d.W + 1 + 63) / 64, d.B), 64, 0, h->stream>>>(wm, -1, -2, 0, 2, 1);
+    if (mode == 0 && d.GO) ba_linearize_gnss<<<dim3(d.B), 256, 0, h->stream>>>(wm, -1, -2, 2, 1);
     MargOut mo{h->outJ.d, h->outr.d};
     if (h->big_marg) ba_marg_finish<true><<<dim3(d.B), 512, 0, h->stream>>>(wm, h->sbufs(), reinterpret_cast<const MargInfo*>(h->minfo[mode].d), mo, mode == 0 ? 1 : 0);
     else ba_marg_finish<false><<<dim3(d.B), 512, h->marg_lds, h->stream>>>(wm, h->sbufs(), reinterpret_cast<const MargInfo*>(h->minfo[mode].d), mo, mode == 0 ? 1 : 0);
@@ -432,7 +448,7 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     d.B = cfg->batch; d.W = cfg->window_size; d.NP = d.W + 1; d.F = cfg->max_features; d.NV = cfg->max_visual;
     d.NVP = ((d.NV + d.NP * d.NP / 2 + 63) / 64) * 64;
     const bool gnss = cfg->max_gnss > 0;
-    d.NG = gnss ? ((cfg->max_gnss + 63) & ~63) : 0;
+    d.NG = gnss ? ((cfg->max_gnss + 63) & ~63) : 0; d.NGRP = gnss ? 4 * d.NP : 0;
     const int Rmax = 15 * d.NP + 17 + (gnss ? 5 * d.NP + 3 : 0);
     d.RP = (Rmax + 1 + 15) & ~15; /* one spare column: the Schur GEMM carries the right-hand side in column R */ d.GO = gnss ? ((16 * d.NP + 20 + d.F + 3) & ~3) : 0; d.XS = gnss ? ((d.GO + 5 * d.NP + 4 + 3) & ~3) : ((16 * d.NP + 20 + d.F + 3) & ~3); d.NFB = 2 * d.NP + 7 + (gnss ? 5 * d.NP + 2 : 0); d.FP = (d.F + 3) & ~3; d.NPRI = d.RP; d.ECW = (6 * d.NP + 8 + 15) & ~15; d.NC = 6 * d.NP + 8; d.NVC = (d.NC * (d.NC + 1) / 2 + 3) & ~3;
     h->step_lds = (size_t)(Rmax + 1) * (Rmax + 2) / 2 * sizeof(double);  // packed lower S plus the right-hand-side row
@@ -467,7 +483,7 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     A_(h->scale.alloc(B * VS, false)); A_(h->diag.alloc(B * VS, false)); A_(h->grad.alloc(B * VS, false)); A_(h->gn.alloc(B * VS, false)); A_(h->step.alloc(B * VS, false));
     A_(h->u.alloc(B * VS, false)); A_(h->Et.alloc(2 * B * d.FP * d.ECW, true)); A_(h->Es.alloc(B * d.FP * d.ECW, false)); A_(h->ete.alloc(2 * B * d.FP, true)); A_(h->etb.alloc(2 * B * d.FP, true));
     A_(h->rhs.alloc(B * d.RP, false)); A_(h->yv.alloc(B * VS, false));
-    if (gnss) { A_(h->ngnss.alloc(B, true)); A_(h->gn_idx.alloc(B * d.NG * 4, true)); A_(h->gn_data.alloc(B * d.NG * GN_STRIDE, true)); A_(h->gn_misc.alloc(B * (GN_MISC + d.NP), true)); }
+    if (gnss) { A_(h->ngnss.alloc(B, true)); A_(h->gn_idx.alloc(B * d.NG * 4, true)); A_(h->gn_data.alloc(B * d.NG * GN_STRIDE, true)); A_(h->gn_misc.alloc(B * (GN_MISC + d.NP), true)); A_(h->gn_gptr.alloc(B * (d.NGRP + 2), true)); A_(h->gn_gitem.alloc(B * d.NG, true)); A_(h->gn_rows.alloc(B * d.NG * GN_ROW, false)); }
     for (int m = 0; m < 2; m++) { A_(h->mcolf[m].alloc(B * d.NFB, true)); A_(h->mcole[m].alloc(B * d.F, true)); A_(h->morder[m].alloc(B * d.NVP, true)); A_(h->mnorder[m].alloc(B, true)); A_(h->minfo[m].alloc(B * 4, true)); }
     A_(h->outJ.alloc(B * (size_t)d.NPRI * d.NPRI, true)); A_(h->outr.alloc(B * d.NPRI, true)); A_(h->stamps.alloc(64, true));
     // kept system of the marginalisation: 6 W poses + speed-bias + extrinsics ...; A and V live in LDS up to 92 columns, else in global memory

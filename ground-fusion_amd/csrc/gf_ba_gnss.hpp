@@ -3,8 +3,8 @@
 //   DtDdtFactor        factor/gnss_dt_ddt_factor.cpp            receiver clock bias vs drift between consecutive frames (x4 constellations)
 //   DdtSmoothFactor    factor/gnss_ddt_smooth_factor.cpp        drift smoothness
 //   PoseAnchorFactor   factor/pose_anchor_factor.cpp            gauge anchor of Pose[0] at the first optimisation
-// One lane per residual block (they are independent and tiny: 2 x 17, 1 x 4, 1 x 2, 6 x 6); the blocks' J^T J / J^T r go to H / g with the same
-// lower-triangle atomics as the other factor kernels.  ECEF magnitudes are ~6.4e6 m, so everything stays FP64.
+// The blocks are tiny (2 x 18, 1 x 4, 1 x 2, 6 x 6): one thread evaluates a GnssPsrDoppFactor, and J^T J / J^T r of the factors that share
+// parameter blocks are summed per entry in a fixed order (ba_linearize_gnss below).  ECEF magnitudes are ~6.4e6 m, so everything stays FP64.
 // gnss_comm (not vendored by the reference) supplies ecef2geo / ecef2rotation / sat_azel / Saastamoinen / Klobuchar; restated from the published
 // algorithms (RTKLIB lineage), the same formulas as the CPU oracle -- both documented as "parity unpinned" against gnss_comm itself.
 #pragma once
@@ -71,100 +71,10 @@ __device__ inline double gn_ion_delay(double tow, const double* ion_in, V3 lla, 
     return GN_C * f * (fabs(x) < 1.57 ? 5e-9 + amp * (1.0 + x * x * (-0.5 + x * x / 24.0)) : 5e-9);
 }
 
-// One residual block: nres rows, ncol local columns with solver columns col[] (-1: constant), J row-major nres x ncol.  Adds 1/2 |r|^2 to the cost
-// and J^T J (lower triangle) / J^T r to H / g.
-template <int NR, int NC>
-__device__ inline void gn_accumulate(const double (&r)[NR], const double (&J)[NR * NC], const int (&col)[NC], double* H, double* g, double* cost, int RP, bool cost_only) {
-    double c = 0;
-#pragma unroll
-    for (int i = 0; i < NR; i++) c += r[i] * r[i];
-    atomicAdd(cost, 0.5 * c);
-    if (cost_only) return;
-    for (int a = 0; a < NC; a++) {
-        const int ca = col[a];
-        if (ca < 0) continue;
-        double gv = 0;
-#pragma unroll
-        for (int i = 0; i < NR; i++) gv += J[i * NC + a] * r[i];
-        if (gv != 0.0) atomicAdd(g + ca, gv);
-        for (int b2 = 0; b2 < NC; b2++) {
-            const int cb = col[b2];
-            if (cb < 0 || cb > ca) continue;
-            if (cb == ca && b2 > a) continue;   // (a, b2) and (b2, a) hit the same diagonal entry only when a == b2
-            double hv = 0;
-#pragma unroll
-            for (int i = 0; i < NR; i++) hv += J[i * NC + a] * J[i * NC + b2];
-            if (hv != 0.0) atomicAdd(H + (size_t)ca * RP + cb, hv);
-        }
-    }
-}
-
-// grid (ceil((NG + 5 W + 1) / 64), B), 64 threads, one residual block per lane: items [0, NG) GnssPsrDopp, [NG, NG + 4W) DtDdt (item = NG + 4 i + q),
-// [NG + 4W, NG + 5W) DdtSmooth, NG + 5W PoseAnchor.  frame_filter as in ba_linearize_misc: 1 = blocks of frame 0 only (MARGIN_OLD, taken whenever
-// GNSS is enabled, estimator.cpp:3390), 2 = none; 0 = the solve (only when in_solve, i.e. gnss_ready && !lowspeed, estimator.cpp:3178).
-__global__ void __launch_bounds__(64) ba_linearize_gnss(Win w, int which, int which_state, int cost_only, int only_cand_valid, int frame_filter) {
-    const Dims d = w.d;
-    const int b = blockIdx.y, item = blockIdx.x * 64 + threadIdx.x;
-    const SolverState& st = w.st[b];
-    if (st.done && only_cand_valid != 2) return;
-    if (only_cand_valid == 1 && !st.cand_valid) return;
-    if (frame_filter == 2) return;
-    if (which < 0) which = 1 - st.cur;
-    if (which_state == -2) which_state = st.cur; else if (which_state < 0) which_state = 1 - st.cur;
-    const double* misc = w.gn_misc + (size_t)b * (GN_MISC + d.NP);
-    const bool enabled = misc[16] != 0.0, in_solve = misc[17] != 0.0, has_anchor = misc[18] != 0.0;
-    const double* hdr = misc + GN_MISC;
-    const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
-    const int* colf = w.colf + (size_t)b * d.NFB;
-    double* H = w.H + ((size_t)which * d.B + b) * d.RP * d.RP;
-    double* g = w.g + ((size_t)which * d.B + b) * d.RP;
-    double* cost = cost_part(w, 2, which, b);
-    const int NP = d.NP, W = d.W;
-    auto cof = [&](int fb, int o) { const int c0 = colf[fb]; return c0 >= 0 ? c0 + o : -1; };
-    if (item == d.NG + 5 * W) {   // PoseAnchorFactor, sqrt_info 120 (pose_anchor_factor.h:19); only in the solve
-        if (frame_filter != 0 || !has_anchor) return;
-        const double* an = misc + 9;
-        const double* P = xs + off_pose(0);
-        const double si = 120.0;
-        double r[6], J[36];
-        int col[6];
-        for (int i = 0; i < 36; i++) J[i] = 0.0;
-        for (int i = 0; i < 3; i++) { r[i] = (P[i] - an[i]) * si; J[i * 6 + i] = 2.0 * si; }
-        const Q4 ai = qinverse(Q4{an[6], an[3], an[4], an[5]}), e = qmul(q_of(P), ai);
-        r[3] = 2.0 * e.x * si; r[4] = 2.0 * e.y * si; r[5] = 2.0 * e.z * si;
-        const double Jq[9] = {ai.w, ai.z, -ai.y, -ai.z, ai.w, ai.x, ai.y, -ai.x, ai.w};
-        for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) J[(3 + a) * 6 + 3 + c] = Jq[3 * a + c] * 2.0 * si;
-        for (int c = 0; c < 6; c++) col[c] = cof(fb_pose(0), c);
-        gn_accumulate<6, 6>(r, J, col, H, g, cost, d.RP, cost_only != 0);
-        return;
-    }
-    if (!enabled || (frame_filter == 0 && !in_solve)) return;
-    if (item >= d.NG + 4 * W && item < d.NG + 5 * W) {   // DdtSmoothFactor(GNSS_DDT_WEIGHT) on rcv_ddt[i], rcv_ddt[i+1]
-        const int i = item - d.NG - 4 * W;
-        if (frame_filter == 1 && i != 0) return;
-        const double wt = misc[8];
-        const double r[1] = {(xs[d.GO + 4 * NP + i] - xs[d.GO + 4 * NP + i + 1]) * wt};
-        const double J[2] = {wt, -wt};
-        const int col[2] = {cof(fb_rcvddt(NP, i), 0), cof(fb_rcvddt(NP, i + 1), 0)};
-        gn_accumulate<1, 2>(r, J, col, H, g, cost, d.RP, cost_only != 0);
-        return;
-    }
-    if (item >= d.NG && item < d.NG + 4 * W) {   // DtDdtFactor(Headers[i+1] - Headers[i]), dt_info_coeff 50
-        const int i = (item - d.NG) / 4, q = (item - d.NG) % 4;
-        if (frame_filter == 1 && i != 0) return;
-        const double delta_t = hdr[i + 1] - hdr[i];
-        const double r[1] = {(xs[d.GO + 4 * (i + 1) + q] - xs[d.GO + 4 * i + q] - 0.5 * (xs[d.GO + 4 * NP + i] + xs[d.GO + 4 * NP + i + 1]) * delta_t) * 50.0};
-        const double J[4] = {-50.0, 50.0, -0.5 * delta_t * 50.0, -0.5 * delta_t * 50.0};
-        const int col[4] = {cof(fb_rcvdt(NP, 4 * i + q), 0), cof(fb_rcvdt(NP, 4 * (i + 1) + q), 0), cof(fb_rcvddt(NP, i), 0), cof(fb_rcvddt(NP, i + 1), 0)};
-        gn_accumulate<1, 4>(r, J, col, H, g, cost, d.RP, cost_only != 0);
-        return;
-    }
-    if (item >= w.ngnss[b]) return;
-    // ---- GnssPsrDoppFactor
-    const int* ix = w.gn_idx + ((size_t)b * d.NG + item) * 4;
-    const int fi = ix[0], lo = ix[1], sys = ix[2];
-    if (frame_filter == 1 && fi != 0) return;
-    const double* dat = w.gn_data + ((size_t)b * d.NG + item) * GN_STRIDE;
+// GnssPsrDoppFactor::Evaluate (gnss_psr_dopp_factor.cpp:49-208) of one satellite observation: residual r (2) and Jacobian J (2 x 18, row-major).
+// local columns: 0-2 P_lo, 3-5 V_lo, 6-8 P_hi, 9-11 V_hi, 12 rcv_dt, 13 rcv_ddt, 14 yaw_enu_local, 15-17 anc_ecef
+__device__ inline void gn_psr_dopp(const Dims& d, const double* xs, const double* misc, const double* dat, int fi, int lo, int sys, double* r, double* J) {
+    const int NP = d.NP;
     const V3 sv_pos = v3(dat[0], dat[1], dat[2]), sv_vel = v3(dat[3], dat[4], dat[5]);
     const double svdt = dat[6], svddt = dat[7], tgd = dat[8], pr_uura = dat[9], dp_uura = dat[10], psr = dat[11], dopp = dat[12], wavelength = dat[13], tow = dat[14];
     const double ratio = dat[16];
@@ -196,37 +106,174 @@ __global__ void __launch_bounds__(64) ba_linearize_gnss(Win w, int which, int wh
     const double dopp_sagnac = GN_OMG / GN_C * (sv_vel.x * P_ecef.y + sv_pos.x * V_ecef.y - sv_vel.y * P_ecef.x - sv_pos.y * V_ecef.x);
     const V3 dv = sv_vel - V_ecef;
     const double dopp_est = dot(dv, unit) + dopp_sagnac + rcv_ddt - svddt * GN_C;
-    const double r[2] = {(psr_est - psr) * pr_weight, (dopp_est + dopp * wavelength) * dp_weight};
-    // local columns: 0-2 P_i, 3-5 V_i, 6-8 P_j, 9-11 V_j, 12 rcv_dt, 13 rcv_ddt, 14 yaw, 15-17 anc
-    double J[2 * 18];
-    int col[18];
+    r[0] = (psr_est - psr) * pr_weight; r[1] = (dopp_est + dopp * wavelength) * dp_weight;
     for (int i = 0; i < 36; i++) J[i] = 0.0;
-    if (!cost_only) {
-        const double norm3 = rng * rng * rng;
-        const double rs[3] = {rcv2sat.x, rcv2sat.y, rcv2sat.z}, un[3] = {unit.x, unit.y, unit.z}, dvv[3] = {dv.x, dv.y, dv.z};
-        double t[3];   // (sv_vel - V)^T unit2rcv_pos, unit2rcv_pos = -(d unit / d rcv2sat)
-        for (int c = 0; c < 3; c++) { double a = 0; for (int q = 0; q < 3; q++) a += dvv[q] * -((q == c) ? (norm2 - rs[q] * rs[q]) / norm3 : (-rs[q] * rs[c]) / norm3); t[c] = a; }
-        for (int c = 0; c < 3; c++) {
-            double a = 0, bsum = 0;
-            for (int q = 0; q < 3; q++) { a += un[q] * R_ecef_local.m[3 * q + c]; bsum += t[q] * R_ecef_local.m[3 * q + c]; }
-            J[c] = -a * pr_weight * ratio;              J[18 + c] = bsum * dp_weight * ratio;
-            J[18 + 3 + c] = -a * dp_weight * ratio;
-            J[6 + c] = -a * pr_weight * (1.0 - ratio);  J[18 + 6 + c] = bsum * dp_weight * (1.0 - ratio);
-            J[18 + 9 + c] = -a * dp_weight * (1.0 - ratio);
-            J[15 + c] = -un[c] * pr_weight;
-        }
-        J[12] = pr_weight; J[18 + 13] = dp_weight;
-        M3 d_yaw = m3_zero();
-        d_yaw.m[0] = -sy; d_yaw.m[1] = -cy; d_yaw.m[3] = cy; d_yaw.m[4] = -sy;
-        J[14] = -dot(unit, R_ecef_enu * (d_yaw * local_pos)) * pr_weight;
-        J[18 + 14] = -dot(unit, R_ecef_enu * (d_yaw * local_vel)) * dp_weight;
-    }
+    const double norm3 = rng * rng * rng;
+    const double rs[3] = {rcv2sat.x, rcv2sat.y, rcv2sat.z}, un[3] = {unit.x, unit.y, unit.z}, dvv[3] = {dv.x, dv.y, dv.z};
+    double t[3];   // (sv_vel - V)^T unit2rcv_pos, unit2rcv_pos = -(d unit / d rcv2sat)
+    for (int c = 0; c < 3; c++) { double a = 0; for (int q = 0; q < 3; q++) a += dvv[q] * -((q == c) ? (norm2 - rs[q] * rs[q]) / norm3 : (-rs[q] * rs[c]) / norm3); t[c] = a; }
     for (int c = 0; c < 3; c++) {
-        col[c] = cof(fb_pose(lo), c); col[3 + c] = cof(fb_sb(lo), c); col[6 + c] = cof(fb_pose(lo + 1), c); col[9 + c] = cof(fb_sb(lo + 1), c);
-        col[15 + c] = cof(fb_anc(NP), c);
+        double a = 0, bsum = 0;
+        for (int q = 0; q < 3; q++) { a += un[q] * R_ecef_local.m[3 * q + c]; bsum += t[q] * R_ecef_local.m[3 * q + c]; }
+        J[c] = -a * pr_weight * ratio;              J[18 + c] = bsum * dp_weight * ratio;
+        J[18 + 3 + c] = -a * dp_weight * ratio;
+        J[6 + c] = -a * pr_weight * (1.0 - ratio);  J[18 + 6 + c] = bsum * dp_weight * (1.0 - ratio);
+        J[18 + 9 + c] = -a * dp_weight * (1.0 - ratio);
+        J[15 + c] = -un[c] * pr_weight;
     }
-    col[12] = cof(fb_rcvdt(NP, 4 * fi + sys), 0); col[13] = cof(fb_rcvddt(NP, fi), 0); col[14] = cof(fb_yaw(NP), 0);
-    gn_accumulate<2, 18>(r, J, col, H, g, cost, d.RP, cost_only != 0);
+    J[12] = pr_weight; J[18 + 13] = dp_weight;
+    M3 d_yaw = m3_zero();
+    d_yaw.m[0] = -sy; d_yaw.m[1] = -cy; d_yaw.m[3] = cy; d_yaw.m[4] = -sy;
+    J[14] = -dot(unit, R_ecef_enu * (d_yaw * local_pos)) * pr_weight;
+    J[18 + 14] = -dot(unit, R_ecef_enu * (d_yaw * local_vel)) * dp_weight;
+}
+
+// One 256-thread block per window, launched behind ba_linearize_misc_win on the same stream: ADDS the GNSS blocks to H / g (plain
+// read-modify-writes, one owner per entry and phase) and writes their cost.  No atomics: every sum runs in a fixed order.
+//  A  one thread per GnssPsrDoppFactor: residual and Jacobian rows to the scratch w.gn_rows ([B][NG][38]).
+//  B  the factors are grouped by (frame, lower_idx) on the host (gf_ba.hip: gn_gptr / gn_gitem; all factors of a group share their
+//     parameter blocks up to the constellation's clock): per group, thread (a >= b) sums J^T J of the group's 21 local columns
+//     [P_lo 3, V_lo 3, P_hi 3, V_hi 3, rcv_dt x 4, rcv_ddt, yaw, anc 3] over the group's factors in list order and adds it; groups one
+//     after the other (consecutive groups share pose blocks).
+//  C  DtDdtFactor x 4 and DdtSmoothFactor of frame pair (i, i + 1): 10 local columns [dt_i x 4, dt_i+1 x 4, ddt_i, ddt_i+1], even i, then odd i.
+//  D  PoseAnchorFactor.
+// frame_filter as in ba_linearize_misc_win: 1 = blocks of frame 0 only (MARGIN_OLD, taken whenever GNSS is enabled, estimator.cpp:3390),
+// 2 = none; 0 = the solve (only when in_solve, i.e. gnss_ready && !lowspeed, estimator.cpp:3178).
+constexpr int GN_ROW = 38;
+__global__ void __launch_bounds__(256) ba_linearize_gnss(Win w, int which, int which_state, int only_cand_valid, int frame_filter) {
+    __shared__ double s_cst[256];
+    __shared__ int s_gcol[24];
+    const Dims d = w.d;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const SolverState& st = w.st[b];
+    if (st.done && only_cand_valid != 2) return;
+    if (only_cand_valid == 1 && !st.cand_valid) return;
+    if (which < 0) which = 1 - st.cur;
+    if (which_state == -2) which_state = st.cur; else if (which_state < 0) which_state = 1 - st.cur;
+    const double* misc = w.gn_misc + (size_t)b * (GN_MISC + d.NP);
+    const bool enabled = misc[16] != 0.0, in_solve = misc[17] != 0.0, has_anchor = misc[18] != 0.0;
+    const double* hdr = misc + GN_MISC;
+    const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
+    const int* colf = w.colf + (size_t)b * d.NFB;
+    const int RP = d.RP, NP = d.NP, W = d.W;
+    double* H = w.H + ((size_t)which * d.B + b) * RP * RP;
+    double* g = w.g + ((size_t)which * d.B + b) * RP;
+    auto cof = [&](int fb, int o) { const int c0 = colf[fb]; return c0 >= 0 ? c0 + o : -1; };
+    const bool on = frame_filter != 2 && enabled && (frame_filter != 0 || in_solve);
+    const int ng = on ? w.ngnss[b] : 0;
+    double* rows = w.gn_rows + (size_t)b * d.NG * GN_ROW;
+    double cst = 0.0;   // cost terms owned by this thread, added in a fixed order below
+    // ---- A
+    for (int item = tid; item < ng; item += 256) {
+        const int* ix = w.gn_idx + ((size_t)b * d.NG + item) * 4;
+        if (frame_filter == 1 && ix[0] != 0) continue;
+        double r[2], J[36];
+        gn_psr_dopp(d, xs, misc, w.gn_data + ((size_t)b * d.NG + item) * GN_STRIDE, ix[0], ix[1], ix[2], r, J);
+        double* dst = rows + (size_t)item * GN_ROW;
+        dst[0] = r[0]; dst[1] = r[1];
+        for (int i = 0; i < 36; i++) dst[2 + i] = J[i];
+    }
+    __syncthreads();
+    // ---- B
+    {
+        const int* gptr = w.gn_gptr + (size_t)b * (d.NGRP + 2);
+        const int* gitem = w.gn_gitem + (size_t)b * d.NG;
+        const int ngrp = on ? gptr[d.NGRP + 1] : 0;   // the last slot holds the number of groups
+        int la = 0, lb = 0;                       // this thread's entry of the 21 x 21 group tile (tid < 231: J^T J lower triangle; 231..251: J^T r)
+        if (tid < 231) { la = tri_row(tid); lb = tid - la * (la + 1) / 2; } else if (tid < 252) la = lb = tid - 231;
+        auto item_local = [&](int gl, int sys) -> int { return gl < 12 ? gl : gl < 16 ? (gl - 12 == sys ? 12 : -1) : gl == 16 ? 13 : gl == 17 ? 14 : gl - 3; };
+        for (int gi = 0; gi < ngrp; gi++) {
+            const int p0 = gptr[gi], p1 = gptr[gi + 1];
+            const int* ix0 = w.gn_idx + ((size_t)b * d.NG + gitem[p0]) * 4;
+            const int fi = ix0[0], lo = ix0[1];
+            if (frame_filter == 1 && fi != 0) continue;   // uniform over the block
+            if (tid < 21) {
+                const int gl = tid;
+                s_gcol[gl] = gl < 3 ? cof(fb_pose(lo), gl) : gl < 6 ? cof(fb_sb(lo), gl - 3) : gl < 9 ? cof(fb_pose(lo + 1), gl - 6) : gl < 12 ? cof(fb_sb(lo + 1), gl - 9)
+                           : gl < 16 ? cof(fb_rcvdt(NP, 4 * fi + gl - 12), 0) : gl == 16 ? cof(fb_rcvddt(NP, fi), 0) : gl == 17 ? cof(fb_yaw(NP), 0) : cof(fb_anc(NP), gl - 18);
+            }
+            __syncthreads();
+            if (tid < 252) {
+                const int ca = s_gcol[la], cb = s_gcol[lb];
+                if (ca >= 0 && cb >= 0) {
+                    double sum = 0.0;
+                    for (int p = p0; p < p1; p++) {
+                        const int item = gitem[p];
+                        const int sys = w.gn_idx[((size_t)b * d.NG + item) * 4 + 2];
+                        const double* rw = rows + (size_t)item * GN_ROW;
+                        const int ia = item_local(la, sys);
+                        if (ia < 0) continue;
+                        if (tid < 231) { const int ib = item_local(lb, sys); if (ib >= 0) sum += rw[2 + ia] * rw[2 + ib] + rw[20 + ia] * rw[20 + ib]; }
+                        else sum += rw[2 + ia] * rw[0] + rw[20 + ia] * rw[1];
+                    }
+                    double* dst = tid < 231 ? H + (size_t)max(ca, cb) * RP + min(ca, cb) : g + ca;
+                    *dst += sum;
+                }
+            } else if (tid == 255) {
+                for (int p = p0; p < p1; p++) { const double* rw = rows + (size_t)gitem[p] * GN_ROW; cst += 0.5 * (rw[0] * rw[0] + rw[1] * rw[1]); }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- C: clock factors of frame pair (i, i + 1); local columns 0-3 dt_i, 4-7 dt_i+1, 8 ddt_i, 9 ddt_i+1; rows q = 0..3 DtDdt, 4 DdtSmooth
+    if (on) {
+        const double wt = misc[8];
+        for (int par = 0; par < 2; par++) {
+            for (int t = tid; t < 65 * W; t += 256) {
+                const int i = t / 65, e = t - 65 * i;
+                if ((i & 1) != par || (frame_filter == 1 && i != 0)) continue;
+                int la, lb;
+                if (e < 55) { la = tri_row(e); lb = e - la * (la + 1) / 2; } else la = lb = e - 55;
+                auto colc = [&](int l) -> int { return l < 4 ? cof(fb_rcvdt(NP, 4 * i + l), 0) : l < 8 ? cof(fb_rcvdt(NP, 4 * (i + 1) + l - 4), 0) : cof(fb_rcvddt(NP, i + l - 8), 0); };
+                const int ca = colc(la), cb = colc(lb);
+                const double delta_t = hdr[i + 1] - hdr[i];
+                const double ddi = xs[d.GO + 4 * NP + i], ddj = xs[d.GO + 4 * NP + i + 1];
+                auto jac = [&](int row, int l) -> double {   // d residual(row) / d local column l
+                    if (row < 4) return l == row ? -50.0 : l == 4 + row ? 50.0 : l >= 8 ? -0.5 * delta_t * 50.0 : 0.0;
+                    return l == 8 ? wt : l == 9 ? -wt : 0.0;
+                };
+                auto res = [&](int row) -> double {
+                    if (row < 4) return (xs[d.GO + 4 * (i + 1) + row] - xs[d.GO + 4 * i + row] - 0.5 * (ddi + ddj) * delta_t) * 50.0;
+                    return (ddi - ddj) * wt;
+                };
+                if (ca >= 0 && cb >= 0) {
+                    double sum = 0.0;
+                    for (int row = 0; row < 5; row++) sum += e < 55 ? jac(row, la) * jac(row, lb) : jac(row, la) * res(row);
+                    double* dst = e < 55 ? H + (size_t)max(ca, cb) * RP + min(ca, cb) : g + ca;
+                    *dst += sum;
+                }
+                if (e == 64) { double c = 0; for (int row = 0; row < 5; row++) c += 0.5 * res(row) * res(row); cst += c; }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- D: PoseAnchorFactor, sqrt_info 120 (pose_anchor_factor.h:19); only in the solve
+    if (frame_filter == 0 && has_anchor && tid < 27) {
+        const double* an = misc + 9;
+        const double* P = xs + off_pose(0);
+        const double si = 120.0;
+        double r[6], J[36];
+        for (int i = 0; i < 36; i++) J[i] = 0.0;
+        for (int i = 0; i < 3; i++) { r[i] = (P[i] - an[i]) * si; J[i * 6 + i] = 2.0 * si; }
+        const Q4 ai = qinverse(Q4{an[6], an[3], an[4], an[5]}), e = qmul(q_of(P), ai);
+        r[3] = 2.0 * e.x * si; r[4] = 2.0 * e.y * si; r[5] = 2.0 * e.z * si;
+        const double Jq[9] = {ai.w, ai.z, -ai.y, -ai.z, ai.w, ai.x, ai.y, -ai.x, ai.w};
+        for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) J[(3 + a) * 6 + 3 + c] = Jq[3 * a + c] * 2.0 * si;
+        int la, lb;
+        if (tid < 21) { la = tri_row(tid); lb = tid - la * (la + 1) / 2; } else la = lb = tid - 21;
+        const int ca = cof(fb_pose(0), la), cb = cof(fb_pose(0), lb);
+        if (ca >= 0 && cb >= 0) {
+            double sum = 0.0;
+            for (int i = 0; i < 6; i++) sum += tid < 21 ? J[i * 6 + la] * J[i * 6 + lb] : J[i * 6 + la] * r[i];
+            double* dst = tid < 21 ? H + (size_t)max(ca, cb) * RP + min(ca, cb) : g + ca;
+            *dst += sum;
+        }
+        if (tid == 26) { double c = 0; for (int i = 0; i < 6; i++) c += 0.5 * r[i] * r[i]; cst += c; }
+    }
+    // ---- cost: the threads' terms in thread order
+    s_cst[tid] = cst;
+    __syncthreads();
+    if (tid == 0) { double c = 0; for (int i = 0; i < 256; i++) c += s_cst[i]; *cost_part(w, 2, which, b) = c; }
 }
 
 }  // namespace gfb

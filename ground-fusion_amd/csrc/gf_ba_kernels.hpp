@@ -20,13 +20,13 @@ using namespace gfd;
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 struct Dims {
-    int B, W, NP, F, NV, NVP, RP, XS, NFB, FP, NPRI, ECW, GO, NG, NC, NVC;
+    int B, W, NP, F, NV, NVP, RP, XS, NFB, FP, NPRI, ECW, GO, NG, NC, NVC, NGRP;
     // NP = W+1 poses; NVP = padded length of the pair-sorted factor order; RP = padded reduced dimension (multiple of 16);
     // XS = state vector stride; NFB = 2*NP + 7 non-feature parameter blocks; FP = F rounded up to 4; NPRI = prior capacity (= RP)
     // ECW = width of the compact rows of the eliminated columns: a feature only touches pose blocks, the camera extrinsic and td
     //       (compact column 6i+q = pose i, 6NP+q = ex_pose, 6NP+6 = td, 6NP+7 = right-hand-side slot), rounded up to 16
     // GO  = offset of the GNSS states in the state vector (rcv_dt 4NP, rcv_ddt NP, yaw 1, anc_ecef 3), 0: handle built without GNSS
-    // NG  = capacity of GnssPsrDoppFactor per window
+    // NG  = capacity of GnssPsrDoppFactor per window; NGRP = capacity of (frame, lower_idx) groups of them
     // NC  = 6 NP + 8 compact columns of the visual system Vc (pose blocks, camera extrinsic, td, right-hand side: the layout of the compact
     //       rows above); NVC = stride of one packed lower triangle NC (NC + 1) / 2 (entry (RHS, RHS) is unused: the cost travels separately)
 };
@@ -92,6 +92,9 @@ struct Win {  // device view of the whole batch
     const int* gn_idx;        // [B][NG][4]: frame i, lower_idx, sys_idx, 0
     const double* gn_data;    // [B][NG][GN_STRIDE]: 16 values of gf_ba_window::gnss_data, ratio
     const double* gn_misc;    // [B][GN_MISC]: iono 8, ddt_weight, anchor 7, enabled, in_solve (= !lowspeed), has_anchor, Headers[NP]
+    const int* gn_gptr;       // [B][NGRP + 2]: GnssPsrDoppFactors grouped by (frame, lower_idx): start of each group in gn_gitem; last slot = number of groups
+    const int* gn_gitem;      // [B][NG] factor indices in group order
+    double* gn_rows;          // [B][NG][38] scratch: residual (2) and Jacobian rows (2 x 18) of every GnssPsrDoppFactor
 };
 constexpr int GN_STRIDE = 18, GN_MISC = 20;   // gn_misc is GN_MISC + NP doubles per window
 constexpr int IMU_STRIDE = 16 + 225 + 225;  // sum_dt, dp3, dq4, dv3, lba3, lbg3(=17 used incl. sum_dt -> 0..16) jac, cov

@@ -76,6 +76,17 @@ def _prior_invariants(p):
     return J.T @ J, J.T @ p["r"], float(p["r"] @ p["r"])
 
 
+def _assert_prior_close(Ao, bo, Ag, bg, b_tol=1e-8):
+    """J^T J within 1e-9 of its largest entry and J^T r within 1e-8 (relative).  Entry by entry, scaled by sqrt(A_ii A_jj), the bound is
+    5e-7: that is the rounding noise of the ORACLE's own route (eigen pseudo-inverse of the whole dropped block, marginalization_factor.cpp:278-283;
+    scripts/marg_precision.py measures 4e-8 .. 2e-7 for it against a 60-digit Schur complement, and 3e-9 .. 8e-9 for the block elimination the
+    kernel uses).  The HIP side itself is reproducible to the bit (test_runs_are_bit_identical)."""
+    assert np.abs(Ao - Ag).max() <= 1e-9 * np.abs(Ao).max()
+    sc = np.sqrt(np.outer(np.diag(Ao), np.diag(Ao))) + 1e-6 * np.abs(Ao).max()
+    assert (np.abs(Ao - Ag) / sc).max() < 5e-7
+    assert np.abs(bo - bg).max() <= b_tol * np.abs(bo).max()
+
+
 @pytest.mark.parametrize("seed,kw", [(4, {}), (7, {"use_wheel": False})])
 def test_marginalisation_matches_oracle(gf, oracle, seed, kw):
     """prior built on the GPU == prior built by the oracle, compared through the basis-independent J^T J, J^T r
@@ -89,12 +100,7 @@ def test_marginalisation_matches_oracle(gf, oracle, seed, kw):
     assert np.array_equal(po["x0"], pg["x0"])
     Ao, bo, co = _prior_invariants(po)
     Ag, bg, cg = _prior_invariants(pg)
-    # The Schur complement through the dropped pose/speed-bias block is ill-conditioned (cond ~1e6-1e7: biases vs positions), so
-    # rounding-level differences of the accumulation order (atomics) show up at ~1e-6..1e-5 in a few weak entries; the bound that
-    # matters — poses of the next solve within 1e-6 — is asserted below and in test_prior_chain_solve_with_gpu_prior.
-    sc = np.sqrt(np.outer(np.diag(Ao), np.diag(Ao))) + 1e-6 * np.abs(Ao).max()
-    assert (np.abs(Ao - Ag) / sc).max() < 1e-4
-    assert np.abs(bo - bg).max() <= 1e-5 * np.abs(bo).max()
+    _assert_prior_close(Ao, bo, Ag, bg)
     # second window: solve with that prior on both sides, then both marginalisation modes
     w2 = SW.make_window(seed, oracle, frame0=1, prior=po, **kw)
     wo, wg = w2.copy(), w2.copy()
@@ -108,9 +114,7 @@ def test_marginalisation_matches_oracle(gf, oracle, seed, kw):
         assert np.array_equal(p1o["block_id"], p1g["block_id"]) and p1o["m"] == p1g["m"]
         Ao, bo, co = _prior_invariants(p1o)
         Ag, bg, cg = _prior_invariants(p1g)
-        sc = np.sqrt(np.outer(np.diag(Ao), np.diag(Ao))) + 1e-6 * np.abs(Ao).max()
-        assert (np.abs(Ao - Ag) / sc).max() < 1e-4, mode
-        assert np.abs(bo - bg).max() <= 1e-5 * np.abs(bo).max(), mode
+        _assert_prior_close(Ao, bo, Ag, bg)
     est.close()
 
 
@@ -130,11 +134,62 @@ def test_prior_chain_solve_with_gpu_prior(gf, oracle, seed):
     # same (GPU-made) prior, HIP solve vs oracle solve: the solver bar
     dp, dr = _pose_diff(w2x, w2g)
     assert dp < 1e-6 and dr < 1e-6, (dp, dr)
-    # all-HIP chain vs all-oracle chain: additionally carries the prior's own rounding.  The Schur complement of the dropped block has a
-    # condition number of 1e6..1e7 on these windows, so the two priors agree to ~1e-10 relative only, and that difference moves with the
-    # order of the atomic accumulation (scripts/chain_flaky.py: 1e-7 .. 3e-5 on seed 12 from run to run) -- conditioning, not a defect
+    # all-HIP chain (HIP solve -> HIP prior -> HIP solve) vs all-oracle chain: the bar of BASELINE.json (observed 3e-8 .. 5e-8; the oracle moves
+    # by 3e-8 .. 1.3e-7 against itself when its solved state is perturbed in the last bit, scripts/gnss_chain_sensitivity.py)
     dp, dr = _pose_diff(w2o, w2g)
-    assert dp < 1e-4 and dr < 1e-4, (dp, dr)
+    assert dp < 1e-6 and dr < 1e-6, (dp, dr)
+    est.close()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(gnss=True)])
+def test_runs_are_bit_identical(gf, oracle, kw):
+    """no floating-point atomics: every sum of the back end has a fixed order, so two handles give the same bits -- states after the solve,
+    both kinds of prior, and a batch slot gives what a single-window handle gives"""
+    mk = (lambda b=1: _gnss_est(gf, batch=b)) if kw else (lambda b=1: gf.Estimator(batch=b))
+    w = SW.make_window(12, oracle, **kw)
+    outs = []
+    for rep in range(3):
+        est = mk(4 if rep == 2 else 1)
+        a = w.copy()
+        wins = [SW.make_window(20 + q, oracle, **kw) for q in range(2)] + [a] if rep == 2 else [a]
+        s = est.solve(wins, 8)[-1]
+        p0 = est.marginalize(wins, 0)[-1]
+        p1 = None
+        if not kw:
+            w2 = SW.make_window(12, oracle, frame0=1, prior=p0); est.solve([w2], 8); p1 = est.marginalize([w2], 1)[0]
+        outs.append((a, s, p0, p1))
+        est.close()
+    for a, s, p0, p1 in outs[1:]:
+        for k in gw.STATE_KEYS:
+            assert np.array_equal(a[k], outs[0][0][k]), k
+        assert s == outs[0][1]
+        assert np.array_equal(p0["J"], outs[0][2]["J"]) and np.array_equal(p0["r"], outs[0][2]["r"])
+        if p1 is not None:
+            assert np.array_equal(p1["J"], outs[0][3]["J"]) and np.array_equal(p1["r"], outs[0][3]["r"])
+
+
+def test_batch_with_different_gravity_and_flags(gf, oracle):
+    """gravity and the visual sqrt_info are per window (each Estimator has its own `g` after initialStructure, estimator.cpp:1630-1650), as are the
+    constant-block decisions: a batch of windows that differ in all of them against the oracle's solo solves"""
+    kws = [dict(), dict(use_wheel=False), dict(fix_td=0, fix_ex_wheel=1), dict()]
+    wins = [SW.make_window(30 + q, oracle, **kw) for q, kw in enumerate(kws)]
+    for q, g in enumerate([[0.0, 0.0, 9.805], [0.35, -0.2, 9.7966], [-0.5, 0.1, 9.7917], [0.0, 0.0, 9.81]]):
+        wins[q]["G"] = np.array(g)
+    wins[3]["vis_sqrt_info"] = 460.0 / 1.5
+    ref = [w.copy() for w in wins]
+    sums_o = [oracle.ba_solve(w, 8) for w in ref]
+    est = gf.Estimator(batch=4)
+    sums = est.solve(wins, 8)
+    for w, r, so, sg in zip(wins, ref, sums_o, sums):
+        assert (sg["iterations"], sg["successful_steps"]) == (so["iterations"], so["successful_steps"])
+        dp, dr = _pose_diff(w, r)
+        assert dp < 1e-6 and dr < 1e-6, (dp, dr)
+    pg = est.marginalize(ref, 0)
+    for w, p in zip(ref, pg):
+        po = oracle.ba_marginalize(w, 0)
+        Ao, bo, _ = _prior_invariants(po)
+        Ag, bg, _ = _prior_invariants(p)
+        _assert_prior_close(Ao, bo, Ag, bg)
     est.close()
 
 
@@ -175,9 +230,9 @@ def test_lds_and_global_reduced_system_agree(gf, oracle, monkeypatch):
     monkeypatch.setenv("GF_BA_FORCE_GLOBAL", "1")
     e2 = gf.Estimator(); e2.solve([b], 8); p2 = e2.marginalize([b], 0)[0]; e2.close()
     dp, dr = _pose_diff(a, b)
-    assert dp < 1e-8 and dr < 1e-8
+    assert dp < 1e-9 and dr < 1e-9
     A1, A2 = p1["J"].reshape(p1["n"], -1), p2["J"].reshape(p2["n"], -1)
-    assert np.abs(A1.T @ A1 - A2.T @ A2).max() <= 1e-9 * np.abs(A1.T @ A1).max()
+    assert np.abs(A1.T @ A1 - A2.T @ A2).max() <= 1e-11 * np.abs(A1.T @ A1).max()
 
 
 @pytest.mark.parametrize("drop", ["visual", "inertial"])
@@ -201,7 +256,7 @@ def test_windows_without_a_factor_family(gf, oracle, drop):
     po, pg = oracle.ba_marginalize(wo, 0), est.marginalize([wo.copy()], 0)[0]
     assert pg is not None and list(pg["block_id"]) == list(po["block_id"]) and pg["n"] == po["n"]
     Ao, Ag = po["J"].reshape(po["n"], -1), pg["J"].reshape(pg["n"], -1)
-    assert np.abs(Ao.T @ Ao - Ag.T @ Ag).max() <= 1e-6 * np.abs(Ao.T @ Ao).max()
+    assert np.abs(Ao.T @ Ao - Ag.T @ Ag).max() <= 2e-8 * np.abs(Ao.T @ Ao).max()   # no visual information: the oracle's eigen route carries the 1e9 dynamic range of IMU vs wheel blocks
     est.close()
 
 
@@ -217,8 +272,8 @@ def test_pair_tiles_in_lds_and_in_global_memory_agree(gf, oracle, monkeypatch):
 
 
 # ---------------------------------------------------------------- GNSS residual blocks on the device
-def _gnss_est(gf, W=10, F=150):
-    return gf.Estimator(W, F, F * W, 1, max_gnss=12 * (W + 1))
+def _gnss_est(gf, W=10, F=150, batch=1):
+    return gf.Estimator(W, F, F * W, batch, max_gnss=12 * (W + 1))
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(anchor=True), dict(gnss_lowspeed=1)])
@@ -254,15 +309,25 @@ def test_gnss_marginalization_and_chain(gf, oracle, seed):
     n = po["n"]
     Ao, Ag = po["J"].reshape(n, n).T @ po["J"].reshape(n, n), pg["J"].reshape(n, n).T @ pg["J"].reshape(n, n)
     bo, bg = po["J"].reshape(n, n).T @ po["r"], pg["J"].reshape(n, n).T @ pg["r"]
-    # the dropped block now also holds five receiver-clock columns: its pseudo-inverse is conditioned ~1e7, b carries that (see test_marginalisation_matches_oracle)
-    # b_r = b_k - M_kp P^+ b_p cancels ~3 digits on these windows: the prior's right-hand side agrees to ~1e-4 relative from run to run
-    assert np.abs(Ao - Ag).max() <= 1e-9 * np.abs(Ao).max() and np.abs(bo - bg).max() <= 1e-3 * max(1.0, np.abs(bo).max())
+    # With GNSS the kept system has eigenvalues right at the truncation threshold (1e-8 .. 1e-6 against 1e8 at the top: yaw_enu_local, the ECEF anchor)
+    # whose right-hand-side components are rounding noise of the 6.4e6-m ECEF arithmetic: J^T r is defined to ~1e-7 only -- the oracle moves by
+    # 2e-8 .. 9e-8 against itself when its input state is perturbed in the last bit (scripts/gnss_chain_sensitivity.py); observed here 2e-8 .. 4e-7
+    _assert_prior_close(Ao, bo, Ag, bg, b_tol=2e-6)
     w2 = SW.make_window(seed, oracle, gnss=True, frame0=1, prior=pg)
     a, b = w2.copy(), w2.copy()
     so, sg = oracle.ba_solve(a, 8), est.solve([b], 8)[0]
     assert (so["iterations"], so["successful_steps"]) == (sg["iterations"], sg["successful_steps"])
     dp, dr = _pose_diff(a, b)
     assert dp < 1e-6 and dr < 1e-6 and np.abs(a["para_rcv_dt"] - b["para_rcv_dt"]).max() < 1e-6
+    # all-HIP chain against the all-oracle chain.  Rotations and the window's shape meet the bar; its absolute position is observed through
+    # pseudoranges only and inherits the prior's noise above: the oracle's own chain moves by 2e-6 .. 4e-5 m under last-bit perturbations
+    wgpu = SW.make_window(seed, oracle, gnss=True); est.solve([wgpu], 8); pgg = est.marginalize([wgpu], 0)[0]
+    w2g = SW.make_window(seed, oracle, gnss=True, frame0=1, prior=pgg); est.solve([w2g], 8)
+    w2o = SW.make_window(seed, oracle, gnss=True, frame0=1, prior=po); oracle.ba_solve(w2o, 8)
+    Pg, Po = w2g["para_Pose"].reshape(-1, 7), w2o["para_Pose"].reshape(-1, 7)
+    dp, dr = _pose_diff(w2o, w2g)
+    shape = np.abs((Pg[:, :3] - Pg[0, :3]) - (Po[:, :3] - Po[0, :3])).max()
+    assert dr < 1e-6 and shape < 1e-6 and dp < 2e-4, (dp, dr, shape)
     p1o, p1g = oracle.ba_marginalize(a, 1), est.marginalize([a], 1)[0]
     assert p1g["n"] == p1o["n"] == 89 and list(p1g["block_id"]) == list(p1o["block_id"])
     n1 = p1o["n"]
