@@ -56,7 +56,7 @@ struct gf_ba {
     // inputs (host mirror + device)
     Buf<double> xs0;     // pristine states [B][XS] (for reset)
     Buf<double> xs;      // [2][B][XS]
-    Buf<int> colf, cole, nvis, nimu, nwh, nfeat, vis_feat, vis_i, vis_j, order, norder, feat_ptr, feat_fac, imu_i, wh_i, pri_n, pri_nb, pri_bid;
+    Buf<int> colf, cole, nvis, nimu, nwh, nfeat, vis_feat, vis_i, vis_j, order, norder, feat_ptr, feat_fac, vis_pos, imu_i, wh_i, pri_n, pri_nb, pri_bid;
     Buf<double> vis_data, imu_data, wh_data, pri_J, pri_r, pri_x0;
     Buf<SolverState> st, st0;
     // work
@@ -79,7 +79,7 @@ struct gf_ba {
     long long step_flops = 0;     // dense algebra of one ba_step over the resident batch: Schur SYRK NE*n_c^2 + Cholesky R^3/3 + substitutions 2 R^2
     std::vector<Buf<double>*> dbl() { return {&xs0, &xs, &vis_data, &imu_data, &wh_data, &pri_J, &pri_r, &pri_x0, &imu_sqrt, &wh_sqrt, &pri_A, &pri_b, &pri_c, &H, &g, &Vc, &vtile, &wpar, &cost, &efac,
                                               &scale, &diag, &grad, &gn, &step, &u, &Et, &Es, &ete, &etb, &rhs, &yv, &Sg, &Mg, &gn_data, &gn_misc, &gn_rows}; }
-    std::vector<Buf<int>*> ints() { return {&colf, &cole, &nvis, &nimu, &nwh, &nfeat, &vis_feat, &vis_i, &vis_j, &order, &norder, &feat_ptr, &feat_fac, &imu_i, &wh_i, &pri_n, &pri_nb, &pri_bid, &ngnss, &gn_idx, &gn_gptr, &gn_gitem}; }
+    std::vector<Buf<int>*> ints() { return {&colf, &cole, &nvis, &nimu, &nwh, &nfeat, &vis_feat, &vis_i, &vis_j, &order, &norder, &feat_ptr, &feat_fac, &vis_pos, &imu_i, &wh_i, &pri_n, &pri_nb, &pri_bid, &ngnss, &gn_idx, &gn_gptr, &gn_gitem}; }
     void release() {
         for (auto* b : dbl()) b->release();
         for (auto* b : ints()) b->release();
@@ -97,10 +97,10 @@ struct gf_ba {
         w.d = d; w.xs = xs.d; w.colf = colf.d; w.cole = cole.d; w.nvis = nvis.d; w.nimu = nimu.d; w.nwh = nwh.d; w.nfeat = nfeat.d;
         w.vis_feat = vis_feat.d; w.vis_i = vis_i.d; w.vis_j = vis_j.d; w.vis_data = vis_data.d; w.order = order.d; w.norder = norder.d;
         w.ngnss = ngnss.d; w.gn_idx = gn_idx.d; w.gn_data = gn_data.d; w.gn_misc = gn_misc.d; w.gn_gptr = gn_gptr.d; w.gn_gitem = gn_gitem.d; w.gn_rows = gn_rows.d;
-        w.feat_ptr = feat_ptr.d; w.feat_fac = feat_fac.d; w.imu_i = imu_i.d; w.imu_data = imu_data.d; w.wh_i = wh_i.d; w.wh_data = wh_data.d;
+        w.feat_ptr = feat_ptr.d; w.feat_fac = feat_fac.d; w.vis_pos = vis_pos.d; w.imu_i = imu_i.d; w.imu_data = imu_data.d; w.wh_i = wh_i.d; w.wh_data = wh_data.d;
         w.imu_sqrt = imu_sqrt.d; w.wh_sqrt = wh_sqrt.d; w.pri_n = pri_n.d; w.pri_nb = pri_nb.d; w.pri_bid = pri_bid.d; w.pri_J = pri_J.d; w.pri_r = pri_r.d;
         w.pri_x0 = pri_x0.d; w.pri_A = pri_A.d; w.pri_b = pri_b.d; w.pri_c = pri_c.d; w.H = H.d; w.g = g.d; w.Vc = Vc.d; w.cost = cost.d; w.efac = efac.d; w.st = st.d;
-        w.wpar = wpar.d; w.vtile = nullptr; w.vtile_stride = vtile_stride;
+        w.wpar = wpar.d; w.vtile = nullptr; w.vtile_stride = vtile_stride; w.stamps = stamps.d;
         return w;
     }
     StepBufs sbufs() {
@@ -238,7 +238,7 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
             fp[0] = 0;
             for (int f = 0; f < d.F; f++) fp[f + 1] = fp[f] + cnt[f + 1];
             std::vector<int> cur(fp, fp + d.F);
-            for (int k = 0; k < w.n_visual; k++) h->feat_fac.h[(size_t)b * d.NV + cur[w.vis_feature[k]]++] = k;
+            for (int k = 0; k < w.n_visual; k++) { const int pos = cur[w.vis_feature[k]]++; h->feat_fac.h[(size_t)b * d.NV + pos] = k; h->vis_pos.h[(size_t)b * d.NV + k] = pos; }
         }
         for (int k = 0; k < w.n_imu; k++) {
             h->imu_i.h[(size_t)b * d.W + k] = w.imu_i[k];
@@ -345,7 +345,7 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
 int upload(gf_ba* h) {
     hipStream_t s = h->stream;
     HIPCHK(h->xs0.up(s));
-    for (auto* b : {&h->colf, &h->cole, &h->nvis, &h->nimu, &h->nwh, &h->nfeat, &h->vis_feat, &h->vis_i, &h->vis_j, &h->order, &h->norder, &h->feat_ptr, &h->feat_fac,
+    for (auto* b : {&h->colf, &h->cole, &h->nvis, &h->nimu, &h->nwh, &h->nfeat, &h->vis_feat, &h->vis_i, &h->vis_j, &h->order, &h->norder, &h->feat_ptr, &h->feat_fac, &h->vis_pos,
                     &h->imu_i, &h->wh_i, &h->pri_n, &h->pri_nb, &h->pri_bid})
         HIPCHK(b->up(s));
     for (auto* b : {&h->vis_data, &h->imu_data, &h->wh_data, &h->pri_J, &h->pri_r, &h->pri_x0, &h->wpar}) HIPCHK(b->up(s));
@@ -467,7 +467,7 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     A_(h->xs0.alloc(B * d.XS, true)); A_(h->xs.alloc(2 * B * d.XS, true));
     A_(h->colf.alloc(B * d.NFB, true)); A_(h->cole.alloc(B * d.F, true)); A_(h->nvis.alloc(B, true)); A_(h->nimu.alloc(B, true)); A_(h->nwh.alloc(B, true)); A_(h->nfeat.alloc(B, true));
     A_(h->vis_feat.alloc(B * d.NV, true)); A_(h->vis_i.alloc(B * d.NV, true)); A_(h->vis_j.alloc(B * d.NV, true)); A_(h->vis_data.alloc(B * d.NV * 12, true));
-    A_(h->order.alloc(B * d.NVP, true)); A_(h->norder.alloc(B, true)); A_(h->feat_ptr.alloc(B * (d.F + 1), true)); A_(h->feat_fac.alloc(B * d.NV, true));
+    A_(h->order.alloc(B * d.NVP, true)); A_(h->norder.alloc(B, true)); A_(h->feat_ptr.alloc(B * (d.F + 1), true)); A_(h->feat_fac.alloc(B * d.NV, true)); A_(h->vis_pos.alloc(B * d.NV, true));
     A_(h->imu_i.alloc(B * d.W, true)); A_(h->imu_data.alloc(B * d.W * IMU_STRIDE2, true)); A_(h->wh_i.alloc(B * d.W, true)); A_(h->wh_data.alloc(B * d.W * WH_STRIDE, true));
     A_(h->pri_n.alloc(B, true)); A_(h->pri_nb.alloc(B, true)); A_(h->pri_bid.alloc(B * 64, true)); A_(h->pri_J.alloc(B * d.NPRI * d.NPRI, true));
     A_(h->pri_r.alloc(B * d.NPRI, true)); A_(h->pri_x0.alloc(B * d.NPRI * 2, true));
@@ -485,7 +485,7 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     A_(h->rhs.alloc(B * d.RP, false)); A_(h->yv.alloc(B * VS, false));
     if (gnss) { A_(h->ngnss.alloc(B, true)); A_(h->gn_idx.alloc(B * d.NG * 4, true)); A_(h->gn_data.alloc(B * d.NG * GN_STRIDE, true)); A_(h->gn_misc.alloc(B * (GN_MISC + d.NP), true)); A_(h->gn_gptr.alloc(B * (d.NGRP + 2), true)); A_(h->gn_gitem.alloc(B * d.NG, true)); A_(h->gn_rows.alloc(B * d.NG * GN_ROW, false)); }
     for (int m = 0; m < 2; m++) { A_(h->mcolf[m].alloc(B * d.NFB, true)); A_(h->mcole[m].alloc(B * d.F, true)); A_(h->morder[m].alloc(B * d.NVP, true)); A_(h->mnorder[m].alloc(B, true)); A_(h->minfo[m].alloc(B * 4, true)); }
-    A_(h->outJ.alloc(B * (size_t)d.NPRI * d.NPRI, true)); A_(h->outr.alloc(B * d.NPRI, true)); A_(h->stamps.alloc(64, true));
+    A_(h->outJ.alloc(B * (size_t)d.NPRI * d.NPRI, true)); A_(h->outr.alloc(B * d.NPRI, true)); A_(h->stamps.alloc(128, true));
     // kept system of the marginalisation: 6 W poses + speed-bias + extrinsics ...; A and V live in LDS up to 92 columns, else in global memory
     const int nkeep = 6 * d.W + 9 + 17 + (gnss ? 9 : 0);
     h->big_marg = nkeep > 92 || getenv("GF_BA_FORCE_GLOBAL") != nullptr;
@@ -496,10 +496,10 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     if (!h->big_step) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_step<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->step_lds));
     {   // window-level sweeps: staging areas of the wavefronts (static LDS) + pair tiles / block rows (dynamic LDS, or global memory for long windows)
         const bool glob = getenv("GF_BA_GLOBAL_TILES") != nullptr;   // test switch: pair tiles in global memory also where they fit LDS
-        const size_t dyn = vwin_slot_doubles(d.NP, false) * sizeof(double), stat = (size_t)kVW * vwin_sg(false) * vwin_lstr(false) * sizeof(double) + kVW * 64 * sizeof(int) + 512;
+        const size_t dyn = vwin_slot_doubles(d.NP, false) * sizeof(double), stat = (size_t)kVW * vwin_sg(false) * vwin_lstr(false) * sizeof(double) + kVW * 64 * sizeof(int) + 512 + 2048;
         h->vwin_lds = (dyn + stat <= 160 * 1024 && !glob) ? dyn : 0;
         if (h->vwin_lds) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_visual_win<false, kVW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->vwin_lds));
-        const size_t dynx = vwin_slot_doubles(d.NP, true) * sizeof(double), statx = (size_t)kVWX * vwin_sg(true) * vwin_lstr(true) * sizeof(double) + kVWX * 64 * sizeof(int) + 512;
+        const size_t dynx = vwin_slot_doubles(d.NP, true) * sizeof(double), statx = (size_t)kVWX * vwin_sg(true) * vwin_lstr(true) * sizeof(double) + kVWX * 64 * sizeof(int) + 512 + 2048;
         h->vwinx_lds = (dynx + statx <= 160 * 1024 && !glob) ? dynx : 0;
         if (h->vwinx_lds) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_visual_win<true, kVWX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->vwinx_lds));
         if (!h->vwin_lds || !h->vwinx_lds) { h->vtile_stride = (vwin_slot_doubles(d.NP, true) + 3) & ~(size_t)3; A_(h->vtile.alloc(B * h->vtile_stride, false)); }
@@ -690,7 +690,7 @@ int gf_ba_linearize(gf_ba* h, const gf_ba_window* w, int cap, double* Hout, doub
 }
 
 int gf_ba_debug_stamps(gf_ba* h, long long* out, int n) {  // phase timestamps of the last ba_step launch (profiling builds)
-    if (!h || !out || n > 64) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    if (!h || !out || n > 128) return gf::set_err(GF_ERR_INVALID, "bad argument");
     HIPCHK(hipMemcpy(out, h->stamps.d, n * sizeof(long long), hipMemcpyDeviceToHost));
     return GF_OK;
 }

@@ -72,6 +72,7 @@ struct Win {  // device view of the whole batch
     const int* norder;        // [B]
     const int* feat_ptr;      // [B][F+1] CSR: factors of each feature
     const int* feat_fac;      // [B][NV]
+    const int* vis_pos;       // [B][NV] position of every factor in its feature's list (inverse of feat_fac): row of efac
     const int* imu_i; const double* imu_data;   // [B][W], [B][W][IMU_STRIDE]
     const int* wh_i; const double* wh_data;     // [B][W], [B][W][WH_STRIDE]
     double* imu_sqrt; double* wh_sqrt;          // [B][W][225], [B][W][36]
@@ -82,9 +83,10 @@ struct Win {  // device view of the whole batch
     double* g;                // [2][B][RP]    the same part of J^T r
     double* Vc;               // [2][B][NVC]   visual part, compact columns, packed lower triangle, row RHS = J^T r (ba_linearize_visual_win)
     double* cost;             // [3][2][B]     cost parts: prior + IMU + wheel, visual, GNSS; added in this order
-    double* efac;             // [2][B][NV][EF]
+    double* efac;             // [2][B][NV][EF] per-factor products of the eliminated column, rows in feature-list order (vis_pos)
     SolverState* st;          // [B]
     const double* wpar;       // [B][4] per window: gravity G (3), visual sqrt_info
+    long long* stamps;        // optional phase timestamps of window 0 (profiling builds, -DGF_PROFILE_STEP)
     double* vtile;            // global home of the visual sweep's pair tiles when they do not fit LDS ([B][vtile_stride]); else null
     size_t vtile_stride;
     // GNSS (Dims::GO > 0)
@@ -101,7 +103,14 @@ constexpr int IMU_STRIDE = 16 + 225 + 225;  // sum_dt, dp3, dq4, dv3, lba3, lbg3
 constexpr int IMU_JAC = 17, IMU_COV = 17 + 225;
 constexpr int IMU_STRIDE2 = 17 + 450;
 constexpr int WH_STRIDE = 1 + 3 + 4 + 18 + 36 + 4 + 12;  // sum_dt, dp, dq, jac(6x3), cov(6x6), lin(4), lin_vel, lin_gyr, vel_1, gyr_1
-constexpr int EF = 24;  // per-factor eliminated-column products: Jd^T[Ji(6) Jj(6) Jtd(1) Jex(6)] , Jd^T Jd, Jd^T r
+constexpr int EF = 24;  // per-factor eliminated-column products: Jd^T[Ji(6) Jj(6) Jtd(1) Jex(6)] , Jd^T Jd, Jd^T r, then the factor's frames i, j (as doubles)
+#ifdef GF_PROFILE_STEP
+#define GF_WSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && w.stamps) w.stamps[i] = clock64(); } while (0)
+#define GF_WSTAMP_T(t, i) do { if (blockIdx.x == 0 && threadIdx.x == (t) && w.stamps) w.stamps[i] = clock64(); } while (0)
+#else
+#define GF_WSTAMP(i) do { } while (0)
+#define GF_WSTAMP_T(t, i) do { } while (0)
+#endif
 __device__ __forceinline__ double* cost_part(const Win& w, int part, int which, int b) { return w.cost + ((size_t)(part * 2 + which) * w.d.B + b); }
 __device__ __forceinline__ double cost_total(const Win& w, int which, int b) { return (*cost_part(w, 0, which, b) + *cost_part(w, 1, which, b)) + *cost_part(w, 2, which, b); }
 
@@ -215,13 +224,14 @@ __device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int
         if (EX && colf[fb_ex(d.NP)] < 0) for (int c = 16; c < 22; c++) ev.row[0][c] = ev.row[1][c] = 0.0;
         // eliminated (free inverse depth) column: products needed by the Schur complement
         if (w.cole[(size_t)b * d.F + feat] >= 0) {
-            double* ef = w.efac + (((size_t)which * d.B + b) * d.NV + k) * EF;
+            double* ef = w.efac + (((size_t)which * d.B + b) * d.NV + w.vis_pos[kk]) * EF;   // the factors of a feature are contiguous
 #pragma unroll
             for (int c = 0; c < 13; c++) ef[c] = ev.jd[0] * ev.row[0][c] + ev.jd[1] * ev.row[1][c];
 #pragma unroll
             for (int c = 0; c < 6; c++) ef[13 + c] = EX ? ev.jd[0] * ev.row[0][16 + c] + ev.jd[1] * ev.row[1][16 + c] : 0.0;
             ef[19] = ev.jd[0] * ev.jd[0] + ev.jd[1] * ev.jd[1];
             ef[20] = ev.jd[0] * ev.row[0][13] + ev.jd[1] * ev.row[1][13];
+            ef[21] = (double)fi; ef[22] = (double)fj;
         }
     }
     return cost;
@@ -480,32 +490,13 @@ __device__ __forceinline__ void misc_cols(bool is_imu, int i, const int* colf, i
     }
 }
 
-// Plain read-modify-write of up to N distinct global addresses per lane: all loads are issued before the first store (the
-// targets of one call never alias).  Used where the summation order is fixed by phases instead of atomics.
-template <int N>
-struct RmwBatch {
-    double* p[N]; double v[N];
-    __device__ __forceinline__ void set(int i, double* ptr, double val) { p[i] = ptr; v[i] = val; }   // i must fold to a constant (unrolled loops)
-    __device__ __forceinline__ void commit() {
-        double o[N];
-#pragma unroll
-        for (int i = 0; i < N; i++) o[i] = p[i] ? *p[i] : 0.0;
-#pragma unroll
-        for (int i = 0; i < N; i++) if (p[i]) *p[i] = o[i] + v[i];
-    }
-};
-
 // One wavefront: whiten a factor's block row with its upper-triangular square-root information S (imu_factor.h:73, wheel_factor.h:85:
-// residual = S r, J = S J) and form J^T J / J^T r on the matrix cores.  sJp: the factor's padded block row [J | r] in LDS, 4*KS x 33 doubles,
-// rows >= NRES and columns > NCOL zero.  W' = S [J | r] (KS MFMA steps x 2 column tiles), then W'^T W' = [[J^T J, J^T r], [., r^T r]]
-// (3 tiles): 20 MFMAs for an IMU factor.  sW: 4*KS x 33 scratch of this wavefront.
-// The products are ADDED to H / g with plain read-modify-writes: the caller runs factors that share columns in different phases
-// (separated by barriers), so every entry has one writer at a time and a fixed order of additions.  Local columns >= SH0 (the
-// blocks all wheel factors share: wheel extrinsic, sx, sy, sw, td_wheel) are not written but stashed in `stash` (packed lower
-// (NCOL - SH0) x (NCOL - SH0), then the NCOL - SH0 entries of J^T r) for an ordered reduction over the factors.  Returns the cost.
-template <int NRES, int NCOL, int SH0>
-__device__ __forceinline__ double misc_mfma_accumulate(const double* Sg, const double* sJp, double* sW, const int* scol, double* H, double* g, int RP, double* stash,
-                                                       int lane) {
+// residual = S r, J = S J) and form [J | r]^T [J | r] on the matrix cores.  sJp: the factor's padded block row [J | r] in LDS, 4*KS x 33
+// doubles, rows >= NRES and columns > NCOL zero.  W' = S [J | r] (KS MFMA steps x 2 column tiles), then W'^T W' (3 tiles): 20 MFMAs for an
+// IMU factor.  sW: 4*KS x 33 scratch of this wavefront.  The result -- the packed lower triangle of the (NCOL + 1) x (NCOL + 1) tile
+// [[J^T J, .], [r^T J, r^T r]], local column NCOL being the residual -- overwrites the block row in sJp.  Returns the factor's cost.
+template <int NRES, int NCOL>
+__device__ __forceinline__ double misc_mfma_tile(const double* Sg, double* sJp, double* sW, int lane) {
     constexpr int KS = (NRES + 3) / 4, LD = 33;
     const int lr = lane & 15, lk = lane >> 4;
     double sa[KS];
@@ -523,7 +514,7 @@ __device__ __forceinline__ double misc_mfma_accumulate(const double* Sg, const d
         const int row = lk + 4 * r;
         if (row < 4 * KS) { sW[row * LD + lr] = w0[r]; sW[row * LD + 16 + lr] = w1[r]; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();   // W' complete: the block row in sJp is dead
     d4 g00 = {0, 0, 0, 0}, g10 = {0, 0, 0, 0}, g11 = {0, 0, 0, 0};
 #pragma unroll
     for (int kk = 0; kk < KS; kk++) {
@@ -533,35 +524,18 @@ __device__ __forceinline__ double misc_mfma_accumulate(const double* Sg, const d
         g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a0, g10, 0, 0, 0);
         g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, g11, 0, 0, 0);
     }
-    // element (a, b) of tile (ta, tb): local columns la = 16 ta + a, lb = 16 tb + b; a = lk + 4 r, b = lr.  Local column NCOL is the residual.
-    constexpr int NSH = NCOL - SH0;
-    RmwBatch<12> rm;
+    // element (a, b) of tile (ta, tb): local columns 16 ta + a, 16 tb + b; a = lk + 4 r, b = lr
     double cost2 = 0.0;
-    auto put = [&](int la, int lb, double v) -> double* {   // la >= lb, both < NCOL: entry of J^T J; returns the global target or null
-        if (la >= SH0 && lb >= SH0) { stash[(la - SH0) * (la - SH0 + 1) / 2 + (lb - SH0)] = v; return nullptr; }
-        const int ca = scol[la], cb = scol[lb];
-        return (ca >= 0 && cb >= 0) ? H + (size_t)max(ca, cb) * RP + min(ca, cb) : nullptr;
-    };
-    auto putg = [&](int lb, double v) -> double* {          // entry of J^T r
-        if (lb >= SH0) { stash[NSH * (NSH + 1) / 2 + (lb - SH0)] = v; return nullptr; }
-        const int cb = scol[lb];
-        return cb >= 0 ? g + cb : nullptr;
-    };
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int a = lk + 4 * r, la = 16 + a;
-        // tile (0, 0): local (a, lr), lower triangle
-        rm.set(3 * r, (a < NCOL && lr <= a) ? put(a, lr, g00[r]) : nullptr, g00[r]);
-        // tile (1, 0): local (16 + a, lr); row NCOL is the residual: J^T r of the local columns lr
-        rm.set(3 * r + 1, la < NCOL ? put(la, lr, g10[r]) : la == NCOL ? putg(lr, g10[r]) : nullptr, g10[r]);
-        // tile (1, 1): local (16 + a, 16 + lr), lower triangle
-        double* t = nullptr;
-        if (la < NCOL && lr <= a) t = put(la, 16 + lr, g11[r]);
-        else if (la == NCOL && 16 + lr < NCOL) t = putg(16 + lr, g11[r]);
-        else if (la == NCOL && 16 + lr == NCOL) cost2 = g11[r];
-        rm.set(3 * r + 2, t, g11[r]);
+        if (lr <= a) sJp[a * (a + 1) / 2 + lr] = g00[r];
+        if (la <= NCOL) {
+            sJp[la * (la + 1) / 2 + lr] = g10[r];
+            if (lr <= a) sJp[la * (la + 1) / 2 + 16 + lr] = g11[r];
+            if (la == NCOL && 16 + lr == NCOL) cost2 = g11[r];
+        }
     }
-    rm.commit();
     return 0.5 * wave_sum_f64(cost2);
 }
 
@@ -632,40 +606,44 @@ __device__ __forceinline__ int tri_row(int t) {  // largest i with i(i+1)/2 <= t
     while ((i + 1) * (i + 2) / 2 <= t) i++;
     return i;
 }
-// Compact rows of E^T F, ete, etb of one eliminated (free inverse-depth) column, by one wavefront: every factor of a feature shares its
-// pose_i / ex / td entries (register sums in the fixed order of the feature's factor list), its pose_j entries are unique (direct stores).
-__device__ __forceinline__ void et_row(const Win& w, const StepBufs& sb, const Dims& d, int b, int f, int e, int which, int lane) {
-    const int p0 = w.feat_ptr[(size_t)b * (d.F + 1) + f], p1 = w.feat_ptr[(size_t)b * (d.F + 1) + f + 1];
+// Compact rows of E^T F, ete, etb of one eliminated (free inverse-depth) column, by 16 lanes (four features per wavefront): every factor of
+// a feature shares its pose_i / ex / td entries (summed in the fixed order of the feature's factor list), its pose_j entries are unique.
+// The factor products sit in efac in feature-list order, frames included: no index chasing, one contiguous read per feature.
+__device__ __forceinline__ void et_rows4(const Win& w, const StepBufs& sb, const Dims& d, int b, int f0, int nfeat, const int* cole, const int* fptr, int which, int lane) {
+    const int sub = lane & 15, f = f0 + (lane >> 4);
+    const int e = f < nfeat ? cole[f] : -1;
+    const int p0 = e >= 0 ? fptr[f] : 0, p1 = e >= 0 ? fptr[f + 1] : 0;
     const double* efac = w.efac + ((size_t)which * d.B + b) * d.NV * EF;
-    double* Et = sb.Et + (((size_t)which * d.B + b) * d.FP + e) * d.ECW;
-    for (int c = lane; c < d.ECW; c += 64) Et[c] = 0.0;
+    double* Et = sb.Et + (((size_t)which * d.B + b) * d.FP + max(e, 0)) * d.ECW;
+    if (e >= 0) for (int c = sub; c < d.ECW; c += 16) Et[c] = 0.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-    double acc = 0;
+    // lane `sub` owns products sub (0-5 pose_i, 6-11 pose_j, 12 td, 13-15 ex 0-2) and 16 + sub (ex 3-5, ete, etb) of every factor
+    double acc0 = 0.0, acc1 = 0.0;
     int fi = 0;
-    constexpr int NF = 12;   // factors in flight: index, frame and product loads are issued before any is consumed (a track spans <= W frames)
-    for (int p = p0; p < p1; p += NF) {
-        int kq[NF], jq[NF];
-        double ev[NF];
-#pragma unroll
-        for (int q = 0; q < NF; q++) kq[q] = p + q < p1 ? w.feat_fac[(size_t)b * d.NV + p + q] : -1;
+    constexpr int NF = 10;   // factors in flight: every load of a batch is issued before the first store (a track spans <= W frames)
+    for (int pb = p0; pb < p1; pb += NF) {
+        double v0[NF], v1[NF], fjd[NF], fid[NF];
 #pragma unroll
         for (int q = 0; q < NF; q++) {
-            jq[q] = kq[q] >= 0 ? w.vis_j[(size_t)b * d.NV + kq[q]] : 0;
-            ev[q] = (kq[q] >= 0 && lane < 21) ? efac[(size_t)kq[q] * EF + lane] : 0.0;
+            const bool on = pb + q < p1;
+            const double* row = efac + (size_t)(on ? pb + q : p0) * EF;
+            v0[q] = on ? row[sub] : 0.0; v1[q] = (on && sub < 5) ? row[16 + sub] : 0.0; fid[q] = row[21]; fjd[q] = row[22];
         }
-        if (p == p0 && kq[0] >= 0) fi = w.vis_i[(size_t)b * d.NV + kq[0]];
+        fi = (int)fid[0];
 #pragma unroll
         for (int q = 0; q < NF; q++) {
-            if (kq[q] < 0) continue;
-            if (lane < 6 || (lane >= 12 && lane < 21)) acc += ev[q];
-            else if (lane < 12) Et[6 * jq[q] + lane - 6] = ev[q];
+            if (pb + q >= p1) continue;
+            if (sub >= 6 && sub < 12) Et[6 * (int)fjd[q] + sub - 6] = v0[q]; else acc0 += v0[q];
+            acc1 += v1[q];
         }
     }
-    if (lane < 6) Et[6 * fi + lane] = acc;
-    else if (lane == 12) Et[6 * d.NP + 6] = acc;                    // td
-    else if (lane >= 13 && lane < 19) Et[6 * d.NP + lane - 13] = acc;  // ex_pose
-    else if (lane == 19) sb.ete[((size_t)which * d.B + b) * d.FP + e] = acc;
-    else if (lane == 20) sb.etb[((size_t)which * d.B + b) * d.FP + e] = acc;
+    if (e < 0) return;
+    if (sub < 6) Et[6 * fi + sub] = acc0;
+    else if (sub == 12) Et[6 * d.NP + 6] = acc0;                       // td
+    else if (sub >= 13) Et[6 * d.NP + sub - 13] = acc0;                // ex 0-2
+    if (sub < 3) Et[6 * d.NP + 3 + sub] = acc1;                        // ex 3-5
+    else if (sub == 3) sb.ete[((size_t)which * d.B + b) * d.FP + e] = acc1;
+    else if (sub == 4) sb.etb[((size_t)which * d.B + b) * d.FP + e] = acc1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -681,6 +659,7 @@ __device__ __forceinline__ void et_row(const Win& w, const StepBufs& sb, const D
 // Slots: NP (NP - 1) / 2 + NW tiles of 14 x 14 (EX: 20 x 20) packed lower triangles, in LDS when they fit (W = 10), else in w.vtile.
 constexpr int kVW = 12;               // wavefronts per block, fixed extrinsic (three per SIMD at the kernel's ~150 VGPRs)
 constexpr int kVWX = 6;               // wavefronts per block when the camera extrinsic carries columns
+constexpr int kVFP = 511;             // feature lists up to this many features are staged in LDS
 __host__ __device__ constexpr int vwin_sg(bool ex) { return ex ? 16 : 32; }       // factors staged per pass
 __host__ __device__ constexpr int vwin_lstr(bool ex) { return ex ? 65 : 33; }     // staging row stride: 2 rows x COLS + 1
 __host__ __device__ constexpr int vwin_tn(bool ex) { return ex ? 210 : 105; }     // packed tile: 20 x 21 / 2, 14 x 15 / 2
@@ -694,6 +673,7 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
     __shared__ int s_pr[NW][64];
     __shared__ double s_cost[NW];
     __shared__ int s_first[NW], s_last[NW], s_cont[NW];
+    __shared__ int s_fptr[kVFP + 1];     // the features' factor lists (feat_ptr) when they fit
     const Dims d = w.d;
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, NP = d.NP;
     const SolverState& st = w.st[b];
@@ -707,7 +687,9 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
     const int NPAIR = NP * (NP - 1) / 2;
     double* slots = w.vtile ? w.vtile + (size_t)b * w.vtile_stride : v_dyn;
     double* bnd = slots + (size_t)NPAIR * TN;
+    GF_WSTAMP(80);
     for (int i = tid; i < (NPAIR + NW) * TN; i += NT) slots[i] = 0.0;
+    if (d.F <= kVFP) for (int i = tid; i <= d.F; i += NT) s_fptr[i] = w.feat_ptr[(size_t)b * (d.F + 1) + i];
     // this wavefront's range of chunks, and the pair keys at its ends (a pair that straddles two ranges has a main and a continuation slot)
     const int nchunks = (n_order + 63) / 64, cpw = (nchunks + NW - 1) / NW;
     const int c_lo = min(nchunks, wave * cpw), c_hi = min(nchunks, c_lo + cpw);
@@ -727,6 +709,7 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
     const int first_key = s_first[wave];
     const bool continuing = wave > 0 && first_key >= 0 && s_last[wave - 1] == first_key;
     if (lane == 0) s_cont[wave] = continuing ? ((first_key & 63) * ((first_key & 63) - 1) / 2 + (first_key >> 6)) : -1;
+    GF_WSTAMP(81);
     double* Jbuf = Jst + wave * SG * LSTR;
     int* s_pair = s_pr[wave];
     double cost = 0.0;
@@ -790,14 +773,17 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
         }
     }
     flush(cur_pair);
+    GF_WSTAMP(82);
     cost = wave_sum_f64(cost);
     if (lane == 0) s_cost[wave] = cost;
     __syncthreads();
+    GF_WSTAMP(83);
     if (tid == 0) { double c = 0; for (int q = 0; q < NW; q++) c += s_cost[q]; *cost_part(w, 1, which, b) = c; }
     // ---- continuation slots -> pair slots, in wavefront order
     for (int t = tid; t < TN; t += NT)
         for (int ww = 1; ww < NW; ww++) { const int p = s_cont[ww]; if (p >= 0) slots[(size_t)p * TN + t] += bnd[(size_t)ww * TN + t]; }
     __syncthreads();
+    GF_WSTAMP(84);
     // ---- the window's compact visual system: entry (ka >= kb) = sum over the pair tiles that hold both columns, in frame order
     {
         const int EXC = 6 * NP, TD = EXC + 6, RHS = EXC + 7, NCc = EXC + 8;
@@ -837,12 +823,15 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
             Vc[idx] = s;
         }
     }
+    GF_WSTAMP(85);
     // ---- compact E^T F rows of the free inverse depths (the factor products efac were written above by this block)
     {
         const int nfeat = w.nfeat[b];
         const int* cole = w.cole + (size_t)b * d.F;
-        for (int f = wave; f < nfeat; f += NW) { const int e = cole[f]; if (e >= 0) et_row(w, sb, d, b, f, e, which, lane); }
+        const int* fptr = d.F <= kVFP ? s_fptr : w.feat_ptr + (size_t)b * (d.F + 1);
+        for (int f0 = 4 * wave; f0 < nfeat; f0 += 4 * NW) et_rows4(w, sb, d, b, f0, nfeat, cole, fptr, which, lane);
     }
+    GF_WSTAMP(86);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -851,25 +840,26 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
 //           factors of the window cost the latency of one), wavefront 1 the wheel factors, into padded block rows [J | r] in LDS;
 //           the other wavefronts meanwhile write the prior's part: H <- A gathered to this pass's columns (lower triangle of the
 //           first R rows), g <- b0 + A dx, prior cost (marginalization_factor.cpp:344-392: r = r0 + J0 dx).
-//  phase 2-5 whitening + J^T J of each factor on the matrix cores (misc_mfma_accumulate), added to H / g with plain read-modify-writes:
-//           IMU factors starting at even frames, then odd frames, then wheel factors even / odd -- factors of one phase share no column,
-//           so every entry sees its additions in one fixed order.
-//  phase 6  the block all wheel factors share (wheel extrinsic, sx, sy, sw, td_wheel) is summed over the factors in order by one
-//           thread per entry; costs are added in factor order.
+//  phase 2  whitening + [J | r]^T [J | r] of each factor on the matrix cores (misc_mfma_tile): one packed tile per factor, in LDS.
+//  phase 3  every entry of H / g inside the band the factors touch (per frame: the 15 x 15 pose / speed-bias block and its coupling
+//           to the next frame; the block all wheel factors share: wheel extrinsic, sx, sy, sw, td_wheel, and its rows against the poses)
+//           is written by one thread as prior + the tiles that hold it, in factor order.  Costs are added in factor order.
+// No floating-point atomics, no read-modify-write: every entry has one final writer and a fixed order of additions.
 // frame_filter: 0 all factors; 1 only factors starting at frame 0 (MARGIN_OLD); 2 no IMU / wheel factor (MARGIN_SECOND_NEW).
-// Dynamic LDS (doubles): W x 16 x 33 IMU block rows, W x 9 x 33 wheel block rows, W x 66 shared-block stash, nscr x (16 x 33 + 16) scratch.
+// Dynamic LDS (doubles): W x 16 x 33 IMU block rows / tiles, W x 9 x 33 wheel block rows / tiles, nscr x 16 x 33 scratch.
 constexpr int kMW = 8;
-constexpr int kMJi = 16 * 33, kMJw = 9 * 33, kMSh = 66, kMScr = 16 * 33 + 16;   // scratch: W', column map (32 ints)
-__host__ __device__ inline int misc_win_nscr(int W) { return W <= 12 ? kMW : 2; }   // whitening wavefronts (scratch areas): long windows leave room for two
-__host__ __device__ inline size_t misc_win_lds_doubles(int W) { return (size_t)W * (kMJi + kMJw + kMSh) + (size_t)misc_win_nscr(W) * kMScr; }
+constexpr int kMJi = 16 * 33, kMJw = 9 * 33, kMScr = 16 * 33;
+__host__ __device__ inline int misc_win_nscr(int W) { return W <= 12 ? kMW : 4; }   // whitening wavefronts (scratch areas)
+__host__ __device__ inline size_t misc_win_lds_doubles(int W) { return (size_t)W * (kMJi + kMJw) + (size_t)misc_win_nscr(W) * kMScr; }
 __global__ void __launch_bounds__(64 * kMW) ba_linearize_misc_win(Win w, int which, int which_state, int only_cand_valid, int frame_filter) {
     extern __shared__ __attribute__((aligned(16))) double m_lds[];
     __shared__ double s_fcost[64];       // per-factor costs: IMU k at k, wheel k at 32 + k
     __shared__ double s_wc[kMW];         // prior cost partials of the wavefronts
-    __shared__ double s_dx[512];
+    __shared__ double s_dx[512], s_pg[512];   // prior: dx, b0 + A dx by local prior index
     __shared__ int s_pcol[512], s_pidx[512], s_R;
+    __shared__ int s_imu_at[32], s_wh_at[32];   // factor starting at frame f (or -1)
     const Dims d = w.d;
-    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, RP = d.RP;
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, RP = d.RP, NP = d.NP;
     const SolverState& st = w.st[b];
     if (st.done && only_cand_valid != 2) return;
     if (only_cand_valid == 1 && !st.cand_valid) return;
@@ -883,22 +873,22 @@ __global__ void __launch_bounds__(64 * kMW) ba_linearize_misc_win(Win w, int whi
     const int nscr = misc_win_nscr(d.W);
     double* sJi = m_lds;                          // [W][16][33]
     double* sJw = sJi + (size_t)d.W * kMJi;       // [W][9][33]
-    double* sSh = sJw + (size_t)d.W * kMJw;       // [W][66]
-    double* scr = sSh + (size_t)d.W * kMSh + (size_t)min(wave, nscr - 1) * kMScr;
-    double* sW = scr; int* scol = reinterpret_cast<int*>(scr + 16 * 33);
+    double* sW = sJw + (size_t)d.W * kMJw + (size_t)min(wave, nscr - 1) * kMScr;
     const int* imu_i = w.imu_i + (size_t)b * d.W; const int* wh_i = w.wh_i + (size_t)b * d.W;
     auto imu_on = [&](int k) -> bool { return frame_filter != 1 || imu_i[k] == 0; };
     auto wh_on = [&](int k) -> bool { return frame_filter != 1 || wh_i[k] == 0; };
+    GF_WSTAMP(64);
     for (int q = tid; q < nimu * kMJi; q += 64 * kMW) sJi[q] = 0.0;
-    for (int q = tid; q < nwh * (kMJw + 0); q += 64 * kMW) sJw[q] = 0.0;
+    for (int q = tid; q < nwh * kMJw; q += 64 * kMW) sJw[q] = 0.0;
     if (tid < 64) s_fcost[tid] = 0.0;
     if (tid < kMW) s_wc[tid] = 0.0;
+    if (tid < 32) { s_imu_at[tid] = -1; s_wh_at[tid] = -1; }
     for (int q = tid; q < 512; q += 64 * kMW) { s_pidx[q] = -1; s_pcol[q] = -1; }
     if (tid == 0) {   // number of columns of this pass: blocks with a column are laid out contiguously from 0
         int R = 0;
         for (int q = 0; q < d.NFB; q++) {
             if (colf[q] < 0) continue;
-            const int ls = q < 2 * d.NP ? ((q & 1) ? 9 : 6) : q < 2 * d.NP + 2 ? 6 : (d.GO && q == fb_anc(d.NP)) ? 3 : 1;
+            const int ls = q < 2 * NP ? ((q & 1) ? 9 : 6) : q < 2 * NP + 2 ? 6 : (d.GO && q == fb_anc(NP)) ? 3 : 1;
             R = max(R, colf[q] + ls);
         }
         s_R = R;
@@ -919,8 +909,12 @@ __global__ void __launch_bounds__(64 * kMW) ba_linearize_misc_win(Win w, int whi
             const int c0 = fb >= 0 ? colf[fb] : -1;
             for (int q = 0; q < lsize_kind(kind); q++) { s_dx[idx + q] = dx[q]; s_pcol[idx + q] = c0 >= 0 ? c0 + q : -1; if (c0 >= 0) s_pidx[c0 + q] = idx + q; }
         }
+        if (tid >= 64 && tid < 64 + nimu && imu_on(tid - 64)) s_imu_at[imu_i[tid - 64]] = tid - 64;
+        if (tid >= 128 && tid < 128 + nwh && wh_on(tid - 128)) s_wh_at[wh_i[tid - 128]] = tid - 128;
     }
     __syncthreads();
+    GF_WSTAMP(65);
+    const double* A = w.pri_A + (size_t)b * d.NPRI * d.NPRI;
     // ---- phase 1: factor evaluation (wavefronts 0, 1) next to the prior's part of H, g, cost (wavefronts 2..)
     if (wave == 0) {
         if (lane < nimu && imu_on(lane)) {
@@ -928,15 +922,16 @@ __global__ void __launch_bounds__(64 * kMW) ba_linearize_misc_win(Win w, int whi
             imu_raw(xs + off_pose(i), xs + off_sb(i), xs + off_pose(j), xs + off_sb(j), w.imu_data + ((size_t)b * d.W + k) * IMU_STRIDE2, w.wpar + 4 * b, sJi + kMJi * k + 30,
                     sJi + kMJi * k, true, true, 33, 33);
         }
+        GF_WSTAMP_T(0, 66);
     } else if (wave == 1) {
         if (lane < nwh && wh_on(lane)) {
             const int k = lane, i = wh_i[k], j = i + 1;
-            wheel_raw(xs + off_pose(i), xs + off_pose(j), xs + off_exw(d.NP), xs[off_ix(d.NP)], xs[off_ix(d.NP) + 1], xs[off_ix(d.NP) + 2], xs[off_tdw(d.NP)],
+            wheel_raw(xs + off_pose(i), xs + off_pose(j), xs + off_exw(NP), xs[off_ix(NP)], xs[off_ix(NP) + 1], xs[off_ix(NP) + 2], xs[off_tdw(NP)],
                       w.wh_data + ((size_t)b * d.W + k) * WH_STRIDE, sJw + kMJw * k + 22, sJw + kMJw * k, true, true, 33, 33);
         }
+        GF_WSTAMP_T(64, 67);
     } else {
         const int t6 = tid - 128, NT6 = 64 * (kMW - 2);
-        const double* A = w.pri_A + (size_t)b * d.NPRI * d.NPRI;
         const double* b0 = w.pri_b + (size_t)b * d.NPRI;
         // g <- b0 + A dx at the prior's columns, 0 elsewhere; cost = 1/2 (c0 + 2 b0.dx + dx^T A dx)
         double pc = 0.0;
@@ -944,11 +939,13 @@ __global__ void __launch_bounds__(64 * kMW) ba_linearize_misc_win(Win w, int whi
             double v = 0;
             for (int c2 = 0; c2 < n; c2++) v += A[(size_t)a * n + c2] * s_dx[c2];
             pc += s_dx[a] * (b0[a] + 0.5 * v);
+            s_pg[a] = b0[a] + v;
             if (s_pcol[a] >= 0) g[s_pcol[a]] = b0[a] + v;
         }
         for (int c = t6; c < R; c += NT6) if (s_pidx[c] < 0) g[c] = 0.0;
         pc = wave_sum_f64(pc);
         if (lane == 0) s_wc[wave] = pc;
+        GF_WSTAMP_T(128, 68);
         // H <- A gathered to this pass's columns: lower triangle of the first R rows, four rows per wavefront in flight
         for (int r0 = wave - 2; r0 < R; r0 += 4 * (kMW - 2)) {
 #pragma unroll
@@ -963,42 +960,102 @@ __global__ void __launch_bounds__(64 * kMW) ba_linearize_misc_win(Win w, int whi
                 }
             }
         }
+        GF_WSTAMP_T(128, 69);
     }
     __syncthreads();
-    // ---- phases 2-5: whitened J^T J / J^T r of the factors on the matrix cores, parity classes one after the other
-    double fcost = 0.0;   // lane-uniform per wavefront
-#pragma unroll 1
-    for (int ph = 0; ph < 4; ph++) {
-        const bool is_imu = ph < 2;
-        const int par = ph & 1, nf = is_imu ? nimu : nwh;
-        if (wave < nscr) {
-            int slot = 0;
-            for (int k = 0; k < nf; k++) {
-                const int i = is_imu ? imu_i[k] : wh_i[k];
-                if ((i & 1) != par || !(is_imu ? imu_on(k) : wh_on(k))) continue;
-                if ((slot++ % nscr) != wave) continue;
-                misc_cols(is_imu, i, colf, d.NP, scol, lane);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                double c;
-                if (is_imu) c = misc_mfma_accumulate<15, 30, 30>(w.imu_sqrt + ((size_t)b * d.W + k) * 225, sJi + kMJi * k, sW, scol, H, g, RP, nullptr, lane);
-                else c = misc_mfma_accumulate<6, 22, 12>(w.wh_sqrt + ((size_t)b * d.W + k) * 36, sJw + kMJw * k, sW, scol, H, g, RP, sSh + kMSh * k, lane);
-                if (lane == 0) s_fcost[(is_imu ? 0 : 32) + k] = c;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();   // scratch is reused by the next factor
-            }
+    GF_WSTAMP(70);
+    // ---- phase 2: one tile per factor on the matrix cores (the tile replaces the factor's block row)
+    if (wave < nscr) {
+        int slot = 0;
+        for (int k = 0; k < nimu; k++) {
+            if (!imu_on(k) || (slot++ % nscr) != wave) continue;
+            const double c = misc_mfma_tile<15, 30>(w.imu_sqrt + ((size_t)b * d.W + k) * 225, sJi + kMJi * k, sW, lane);
+            if (lane == 0) s_fcost[k] = c;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();   // scratch is reused by the next factor
         }
-        __syncthreads();
+        for (int k = 0; k < nwh; k++) {
+            if (!wh_on(k) || (slot++ % nscr) != wave) continue;
+            const double c = misc_mfma_tile<6, 22>(w.wh_sqrt + ((size_t)b * d.W + k) * 36, sJw + kMJw * k, sW, lane);
+            if (lane == 0) s_fcost[32 + k] = c;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        }
     }
-    // ---- phase 6: the block shared by all wheel factors (local columns 12-21: wheel extrinsic 6, sx, sy, sw, td_wheel), summed in factor order
-    if (tid < 65 && nwh > 0) {
-        int la = 0, lb = 0;   // entry tid < 55: (la >= lb) of the packed 10 x 10 block; else J^T r of local column tid - 55
-        if (tid < 55) { la = tri_row(tid); lb = tid - la * (la + 1) / 2; } else la = lb = tid - 55;
-        auto col_of = [&](int l) -> int { const int blk = l < 6 ? fb_exw(d.NP) : l < 9 ? fb_sx(d.NP) + (l - 6) : fb_tdw(d.NP); const int c0 = colf[blk]; return c0 >= 0 ? c0 + (l < 6 ? l : 0) : -1; };
-        const int ca = col_of(la), cb = col_of(lb);
-        if (ca >= 0 && cb >= 0) {
-            double* dst = tid < 55 ? H + (size_t)max(ca, cb) * RP + min(ca, cb) : g + ca;
-            double v = *dst;
-            for (int k = 0; k < nwh; k++) if (wh_on(k)) v += sSh[kMSh * k + tid];
-            *dst = v;
+    __syncthreads();
+    GF_WSTAMP(71);
+    // ---- phase 3: the band.  Local tile indices: IMU factor at frame i: comp c (0-5 pose, 6-14 speed-bias) of frame i -> c, of frame i + 1 -> 15 + c,
+    // residual 30; wheel factor at frame i: pose comp q of frame i -> q, of frame i + 1 -> 6 + q, shared column s (wheel extrinsic 0-5, sx, sy, sw,
+    // td_wheel) -> 12 + s, residual 22.
+    {
+        auto TI = [&](int k, int la, int lb) -> double { const int hi = max(la, lb), lo = min(la, lb); return sJi[kMJi * k + hi * (hi + 1) / 2 + lo]; };
+        auto TW = [&](int k, int la, int lb) -> double { const int hi = max(la, lb), lo = min(la, lb); return sJw[kMJw * k + hi * (hi + 1) / 2 + lo]; };
+        auto fcol = [&](int f, int c) -> int { const int c0 = colf[c < 6 ? fb_pose(f) : fb_sb(f)]; return c0 >= 0 ? c0 + (c < 6 ? c : c - 6) : -1; };
+        auto scol = [&](int s2) -> int { const int blk = s2 < 6 ? fb_exw(NP) : s2 < 9 ? fb_sx(NP) + (s2 - 6) : fb_tdw(NP); const int c0 = colf[blk]; return c0 >= 0 ? c0 + (s2 < 6 ? s2 : 0) : -1; };
+        auto prior = [&](int r, int c) -> double { const int pr = s_pidx[r], pc2 = s_pidx[c]; return (pr >= 0 && pc2 >= 0) ? A[(size_t)pr * n + pc2] : 0.0; };
+        auto put = [&](int r, int c, double v) { H[(size_t)max(r, c) * RP + min(r, c)] = v; };
+        const int n1 = NP * 120, n2 = (NP - 1) * 225, n3 = NP * 60, n4 = 55, n5 = NP * 15 + 10;
+        for (int t = tid; t < n1 + n2 + n3 + n4 + n5; t += 64 * kMW) {
+            if (t < n1) {                                             // diagonal block of frame f, entry (a >= c2)
+                const int f = t / 120, e = t - 120 * f, a = tri_row(e), c2 = e - a * (a + 1) / 2;
+                const int r = fcol(f, a), c = fcol(f, c2);
+                if (r < 0 || c < 0) continue;
+                double v = prior(r, c);
+                const int kp = f > 0 ? s_imu_at[f - 1] : -1, kc = s_imu_at[f];
+                if (kp >= 0) v += TI(kp, 15 + a, 15 + c2);
+                if (kc >= 0) v += TI(kc, a, c2);
+                if (a < 6) {
+                    const int wp = f > 0 ? s_wh_at[f - 1] : -1, wc = s_wh_at[f];
+                    if (wp >= 0) v += TW(wp, 6 + a, 6 + c2);
+                    if (wc >= 0) v += TW(wc, a, c2);
+                }
+                put(r, c, v);
+            } else if (t < n1 + n2) {                                 // coupling of frame f + 1 (row comp a) with frame f (column comp c2)
+                const int u = t - n1, f = u / 225, e = u - 225 * f, a = e / 15, c2 = e - 15 * a;
+                const int r = fcol(f + 1, a), c = fcol(f, c2);
+                if (r < 0 || c < 0) continue;
+                double v = prior(r, c);
+                const int kc = s_imu_at[f], wc = s_wh_at[f];
+                if (kc >= 0) v += TI(kc, 15 + a, c2);
+                if (a < 6 && c2 < 6 && wc >= 0) v += TW(wc, 6 + a, c2);
+                put(r, c, v);
+            } else if (t < n1 + n2 + n3) {                            // shared column s2 against pose comp q of frame f
+                const int u = t - n1 - n2, f = u / 60, e = u - 60 * f, s2 = e / 6, q = e - 6 * s2;
+                const int r = scol(s2), c = fcol(f, q);
+                if (r < 0 || c < 0) continue;
+                double v = prior(r, c);
+                const int wp = f > 0 ? s_wh_at[f - 1] : -1, wc = s_wh_at[f];
+                if (wp >= 0) v += TW(wp, 12 + s2, 6 + q);
+                if (wc >= 0) v += TW(wc, 12 + s2, q);
+                put(r, c, v);
+            } else if (t < n1 + n2 + n3 + n4) {                       // shared x shared: all wheel factors, in factor order
+                const int e = t - n1 - n2 - n3, a = tri_row(e), c2 = e - a * (a + 1) / 2;
+                const int r = scol(a), c = scol(c2);
+                if (r < 0 || c < 0) continue;
+                double v = prior(r, c);
+                for (int k = 0; k < nwh; k++) if (wh_on(k)) v += TW(k, 12 + a, 12 + c2);
+                put(r, c, v);
+            } else {                                                  // right-hand side
+                const int e = t - n1 - n2 - n3 - n4;
+                if (e < NP * 15) {
+                    const int f = e / 15, a = e - 15 * f, c = fcol(f, a);
+                    if (c < 0) continue;
+                    double v = s_pidx[c] >= 0 ? s_pg[s_pidx[c]] : 0.0;
+                    const int kp = f > 0 ? s_imu_at[f - 1] : -1, kc = s_imu_at[f];
+                    if (kp >= 0) v += TI(kp, 30, 15 + a);
+                    if (kc >= 0) v += TI(kc, 30, a);
+                    if (a < 6) {
+                        const int wp = f > 0 ? s_wh_at[f - 1] : -1, wc = s_wh_at[f];
+                        if (wp >= 0) v += TW(wp, 22, 6 + a);
+                        if (wc >= 0) v += TW(wc, 22, a);
+                    }
+                    g[c] = v;
+                } else {
+                    const int s2 = e - NP * 15, c = scol(s2);
+                    if (c < 0) continue;
+                    double v = s_pidx[c] >= 0 ? s_pg[s_pidx[c]] : 0.0;
+                    for (int k = 0; k < nwh; k++) if (wh_on(k)) v += TW(k, 22, 12 + s2);
+                    g[c] = v;
+                }
+            }
         }
     }
     if (tid == 0) {
@@ -1009,6 +1066,7 @@ __global__ void __launch_bounds__(64 * kMW) ba_linearize_misc_win(Win w, int whi
         *cost_part(w, 0, which, b) = c;
         *cost_part(w, 2, which, b) = 0.0;   // the GNSS kernel (same stream, later) adds its part
     }
+    GF_WSTAMP(75);
 }
 
 // PoseLocalParameterization::Plus (pose_local_parameterization.cpp:12-28)
@@ -1076,7 +1134,7 @@ __device__ inline bool wave_chol16_inv(double* s_L, double* s_inv, double* s_rdi
         for (int c = 0; c < 16; c++) s_rdiag[c] = rd[c];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-    // inverse: lane j solves L x = e_j (column j of L^-1); L is read as LDS broadcasts
+    // inverse: lane j solves L x = e_j (column j of L^-1); L is read as LDS broadcasts (DPP row broadcasts of the register copy measured slower)
     if (INV) {
         const int j = r;
         double x[16];
