@@ -6,7 +6,10 @@ independent 640x480 RGBD+IMU+wheel sequences owned by this GPU advances by one f
   front end  FeatureTracker::trackImage   (HIP pyramid + Scharr + LK forward/reverse + Shi-Tomasi top-up), and
   back end   Estimator::optimization()    (8 dogleg iterations of the 10-frame / 150-feature window + MARGIN_OLD prior).
 One process per GPU.  Sequences are independent, so they are sharded across ranks with no data-path collective (weak
-scaling); after the timed region the newest pose of every sequence is gathered over RCCL (north_star's pose gather).
+scaling); the one exchange north_star names -- the gather of the newest pose of every sequence over RCCL -- is part of every
+timed step.  After the timed region the three roofline kernels are timed again on an otherwise idle GPU (tracker alone, back
+end alone), and rank 0 at N = 1 runs two bounded side measurements: the end-to-end drop-in path (trackImage -> inputFeature ->
+processImage -> solve -> marginalise through gf_estimator_group_*) and the CPU oracle.
 """
 import argparse
 import json
@@ -117,9 +120,68 @@ def cpu_baseline(frames_host, dt, wins, threads, ba_iters, repeat=4):
             "solves_only_per_s": threads / per_solve, "ms_track_frame_1core": 1e3 * per_frame, "ms_solve_marg_1core": 1e3 * per_solve, "wall_s": el}
 
 
-# lk_track_kernel HBM-side traffic per tracked point from the PMC passes committed under profiles/ (r01_k, the final kernel of the round): FETCH_SIZE
-# 120 878 KB and WRITE_SIZE 240 KB per launch of 4864 points; FETCH_SIZE doubled per the gfx950 note of the micro-architecture guide
-LK_PMC_BYTES_PER_POINT = (2 * 120878.0 + 240.0) * 1024.0 / 4864.0
+def pmc_summary():
+    """counter-derived figures of the roofline kernels, collected by separate rocprofv3 --pmc passes (scripts/pmc_collect.sh) and kept
+    under profiles/ -- never hard-coded here.  Missing file: the fields that need it are null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_summary.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist):
+    """The drop-in path on a bounded sample: `nseq` sequences (one seeded synthetic RGB-D + IMU + wheel stream, replicated) through the batched
+    tracker (trackImage on every camera frame) and gf_estimator_group_* (inputFeature -> processImage -> batched solve + marginalisation on
+    every second frame, the reference's MULTIPLE_THREAD flow): the back end is fed by the tracker's own output.  Returns window-solves/s over
+    the frames on which the windows are live (NON_LINEAR), wall-clock including the tracker, host bookkeeping, uploads and downloads."""
+    import ctypes as C
+    import synth_stream as SS
+    st = SS.Stream(1, t_still=1.5, t_move=1.5, v_max=0.4, yaw0=0.0, yaw_turn=-0.6, split_x=1.8, turn_delay=0.8)
+    cfg = gfamd.default_estimator_cfg(tio=SS.TIO, rio=SS.RIO, multiple_thread=1)
+    grp = gfamd.EstimatorGroup(cfg, nseq)
+    trk = gfamd.FeatureTracker(gfamd.default_cfg(batch=nseq, max_cnt=max_cnt, min_dist=min_dist))
+    frames, cache = [], {}
+    for k in range(len(st.cam_t)):      # rendering is input synthesis, outside the timed part; identical poses (the stationary lead-in) share a frame
+        key = (tuple(np.round(st.p_wb(st.cam_t[k]), 9)), round(float(st._at(st._psi, st.cam_t[k])), 9))
+        if key not in cache:
+            img, dep = st.image(k)
+            cache[key] = (torch.from_numpy(img).to(dev), torch.from_numpy(dep.view(np.int16)).to(dev))
+        frames.append(cache[key])
+    sq = np.arange(nseq, dtype=np.int32)
+    tp, t_live, solves, frames_live = -1.0, 0.0, 0, 0
+    live = False
+    for k in range(len(st.cam_t)):
+        for m in grp.members:
+            t1 = st.feed(m, k, tp)
+        tp = t1
+        g = frames[k][0].unsqueeze(0).expand(nseq, -1, -1).contiguous()
+        d = frames[k][1].unsqueeze(0).expand(nseq, -1, -1).contiguous()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = trk.trackImageBatchDevice([float(st.cam_t[k])] * nseq, g.data_ptr(), d.data_ptr(), unpack=False)
+        if k % 2 == 0:
+            out = trk._out
+            obs = np.ascontiguousarray(out[np.arange(out.shape[1])[None, :] < n[:, None]])   # per-sequence frames back to back
+            tt = np.full(nseq, float(st.cam_t[k]))
+            no = np.ascontiguousarray(n, np.int32)
+            gfamd._chk(gfamd.lib().gf_estimator_group_input_features(grp.g, nseq, sq.ctypes.data_as(C.POINTER(C.c_int)), tt.ctypes.data_as(C.POINTER(C.c_double)),
+                                                                     obs.ctypes.data_as(C.c_void_p), no.ctypes.data_as(C.POINTER(C.c_int))))
+        dt = time.perf_counter() - t0
+        if live:
+            t_live += dt
+            frames_live += 1
+            if k % 2 == 0:
+                solves += nseq
+        live = grp.members[0].state()["solver_flag"] == 1
+    stt = grp.stats()
+    pos = float(np.linalg.norm(grp.members[0].state()["Ps"][-1]))
+    grp.close(); trk.close()
+    return {"window_solves_per_s": solves / max(t_live, 1e-9), "sequences": nseq, "live_camera_frames": frames_live, "window_solves": solves, "wall_s": t_live,
+            "ms_per_backend_frame": 1e3 * t_live / max(solves // max(nseq, 1), 1), "group_batches": stt["batches"], "largest_batch": stt["largest_batch"],
+            "newest_position_norm_m": pos,
+            "path": "gf_tracker_track_batch_device -> gf_estimator_group_input_features (inputFeature -> processImage -> gf_ba solve + marginalise, "
+                    "windows packed / uploaded / downloaded every frame)"}
 
 
 def main():
@@ -134,6 +196,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frontend", action="store_true")
     ap.add_argument("--no-backend", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the bounded end-to-end (drop-in path) sample")
+    ap.add_argument("--e2e-seqs", type=int, default=64)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -156,7 +220,7 @@ def main():
     gfamd._chk(gfamd.lib().gf_set_device(local_rank))
     B, K, Wm = args.batch, args.steps, args.warmup
     dt = 1.0 / 15.0
-    n_frames = Wm + K + 1
+    n_frames = Wm + K + 1 + 4   # + the frames of the isolated tracker passes after the timed region
     seq0 = shard.first_sequence(rank, B)  # global sequence ids [seq0, seq0 + B)
     frames, depth = make_frames(n_frames, B, 1000 + seq0, dev)
     torch.cuda.synchronize()
@@ -168,16 +232,22 @@ def main():
     est.upload(wins)
     step = [0]
 
-    def do_step():
-        k = step[0]
+    newest = torch.zeros((B, 7), dtype=torch.float64, device=dev)   # payload of the pose gather
+    gathered = [None]
+
+    def do_step(exchange=True):
+        k = step[0] % n_frames
         # the back end of this step is enqueued first and runs on its own stream while the tracker (GPU kernels + host bookkeeping)
-        # proceeds — the reference runs processImage and trackImage on separate threads as well (estimator.cpp:209, rosNodeTest.cpp:713)
+        # proceeds -- the reference runs processImage and trackImage on separate threads as well (estimator.cpp:209, rosNodeTest.cpp:713)
         if not args.no_backend:
             est.solve_resident_async(args.ba_iters, 0, True)
         if not args.no_frontend:
             trk.trackImageBatchDevice([dt * k] * B, frames.data_ptr() + k * frame_bytes, depth.data_ptr(), unpack=False)
         if not args.no_backend:
             est.wait()
+            if exchange:   # north_star's only exchange: the newest pose of every sequence, all_gather over RCCL (56 B per sequence, latency-bound)
+                est.export_newest_poses(newest.data_ptr(), B)
+                gathered[0] = shard.gather_poses(newest, dist, world)
         step[0] += 1
 
     for _ in range(Wm + 1):  # frame 0 only detects; it is part of the warm-up
@@ -198,11 +268,23 @@ def main():
     el = time.perf_counter() - t0
     st = trk.stats()
     bs = est.stats()
+    sums = est.download(wins) if not args.no_backend else [None]
 
-    # north_star: gather the newest pose of every sequence on rank 0 (7 doubles per sequence, latency-bound)
-    sums = est.download(wins)
-    newest = torch.tensor(np.stack([w["para_Pose"].reshape(-1, 7)[-1] for w in wins]), dtype=torch.float64, device=dev)
-    gathered = shard.gather_poses(newest, dist, world)
+    # the roofline kernels once more on an otherwise idle GPU: their hipEvent times without the other half's kernels in between
+    iso = {}
+    if not args.no_frontend and not args.no_backend:
+        trk.reset_stats(); est.reset_stats()
+        for _ in range(4):
+            trk.trackImageBatchDevice([dt * (step[0] % n_frames)] * B, frames.data_ptr() + (step[0] % n_frames) * frame_bytes, depth.data_ptr(), unpack=False)
+            step[0] += 1
+        torch.cuda.synchronize()
+        for _ in range(3):
+            est.solve_resident(args.ba_iters, 0, True)
+        ti, bi = trk.stats(), est.stats()
+        iso = {"lk_ms": ti["ms_lk"] / max(ti["lk_launches"], 1), "lk_alg_bytes": (484.0 * 5.0 * ti["lk_level_passes"] + 484.0 * ti["lk_iterations"]) / max(ti["lk_launches"], 1),
+               "pyramid_ms": ti["ms_pyramid"] / 4, "detect_ms": ti["ms_detect"] / 4,
+               "jtj_ms": bi["ms_jtj"] / max(bi["jtj_launches"], 1), "step_ms": bi["ms_step"] / max(bi["step_launches"], 1),
+               "ba_solve_ms": bi["ms_solve"] / 3, "ba_marginalize_ms": bi["ms_marginalize"] / 3}
 
     tot = torch.tensor([el, float(st["tracked_features"]), float(st["output_features"]), float(bs["solves"])], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -213,8 +295,10 @@ def main():
         el_max, tracked, outf, solves = el, st["tracked_features"], st["output_features"], bs["solves"]
 
     if rank == 0:
-        assert gathered.shape == (B * world, 7) and bool(torch.isfinite(gathered).all())
-        # roofline of the dominant kernel (lk_track_kernel): algorithmic bytes per SURVEY.md §8(d):
+        if not args.no_backend:
+            assert gathered[0].shape == (B * world, 7) and bool(torch.isfinite(gathered[0]).all())
+        pmc = pmc_summary()
+        # roofline of the dominant front-end kernel (lk_track_kernel): algorithmic bytes per SURVEY.md 8(d):
         #   484*(1+4) B per (point, level pass) [u8 window + s16x2 derivative window] + 484 B per iteration [moving window]
         launches = max(st["lk_launches"], 1)
         alg_bytes = 484.0 * 5.0 * st["lk_level_passes"] + 484.0 * st["lk_iterations"]
@@ -222,8 +306,14 @@ def main():
         achieved = alg_bytes / launches / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
         jtj_ms = bs["ms_jtj"] / max(bs["jtj_launches"], 1)
         step_ms = bs["ms_step"] / max(bs["step_launches"], 1)
-        step_tf = bs["step_flops"] / max(bs["step_launches"], 1) / (step_ms * 1e-3) / 1e12 if step_ms > 0 else 0.0
-        jtj_tf = bs["jtj_flops"] / max(bs["jtj_launches"], 1) / (jtj_ms * 1e-3) / 1e12 if jtj_ms > 0 else 0.0
+        step_flops = bs["step_flops"] / max(bs["step_launches"], 1)
+        jtj_alg = bs["jtj_alg_flops"] / max(bs["jtj_launches"], 1)
+        jtj_issued = bs["jtj_flops"] / max(bs["jtj_launches"], 1)
+        jtj_t = iso.get("jtj_ms", jtj_ms)      # kernel time on an idle GPU when available (the in-region span includes waiting for CUs held by tracker kernels)
+        step_t = iso.get("step_ms", step_ms)
+        tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        lk_pmc = pmc.get("lk_track_kernel", {})
+        traffic = lk_pmc.get("hbm_bytes_per_point")
         unit = "window-solves/s (each with its tracker frame)" if not (args.no_frontend or args.no_backend) else ("tracked-features/s" if args.no_backend else "window-solves/s")
         value = (tracked / el_max) if args.no_backend else (solves / el_max)
         res = {
@@ -232,29 +322,38 @@ def main():
             "ms_per_step": 1e3 * el_max / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "front end u8/s16 fixed point + f32; back end f64", "data": "synthetic",
             "config": {"workload": "configs[1] (150 features, 10-frame window, visual+IMU+wheel+prior factors, 8 dogleg iterations + MARGIN_OLD marginalisation; "
-                                   "LK 21x21 3 levels + flow-back, Shi-Tomasi top-up) run as %d independent 640x480 RGBD sequences per GPU (the per-GPU share of configs[3])" % B,
+                                   "LK 21x21 3 levels + flow-back, Shi-Tomasi top-up) run as %d independent 640x480 RGBD sequences per GPU (the per-GPU share of configs[3]); "
+                                   "every step ends with the all_gather of the newest poses" % B,
                        "sequences_per_gpu": B, "window": 10, "features": args.max_cnt, "ba_iterations": args.ba_iters},
             "solves_per_s": solves / el_max, "tracked_features_per_s": tracked / el_max, "frames_per_s": B * world * K / el_max,
             "output_features_per_s": outf / el_max,
             "gpu_ms_per_step": {"pyramid": st["ms_pyramid"] / K, "lk": st["ms_lk"] / K, "detect": st["ms_detect"] / K, "tracker_total": st["ms_total_gpu"] / K,
                                 "ba_solve": bs["ms_solve"] / K, "ba_marginalize": bs["ms_marginalize"] / K},
+            "gpu_ms_isolated": iso,
             "host_ms_per_step": {k: st[k] / K for k in ("ms_host_pre", "ms_wait_lk", "ms_host_mid", "ms_wait_detect", "ms_host_post")},
             "roofline": {"kernel": "lk_track_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": LK_PMC_BYTES_PER_POINT * st["lk_points"] / launches, "launch_ms": lk_ms,
-                         "traffic_note": "PMC, separate rocprofv3 --pmc passes of the torch-free driver scripts/pmc_lk.py (profiles/r01_k_tracker_pmc_*.csv, 4864 points "
-                                         "per launch): (2 x FETCH_SIZE + WRITE_SIZE) per point x points of this launch; the x2 is the gfx950 FETCH_SIZE correction for "
-                                         "16-B/lane loads (MI355X_MICROARCH.md, HBM section); not re-collected inside this run",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": (traffic * st["lk_points"] / launches) if traffic else None, "launch_ms": lk_ms,
+                         "launch_ms_isolated": iso.get("lk_ms"),
+                         "frac_isolated": (iso["lk_alg_bytes"] / (iso["lk_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if iso.get("lk_ms") else None,
+                         "traffic_note": lk_pmc.get("note", "no PMC summary under profiles/"),
                          "algorithmic_bytes_per_launch": alg_bytes / launches,
                          "points_per_launch": st["lk_points"] / launches, "iterations_per_launch": st["lk_iterations"] / launches},
-            "roofline_jtj": {"kernel": "ba_linearize_visual_win", "bound": "mfma", "achieved": jtj_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                             "frac": jtj_tf / FP64_MFMA_PEAK_TF, "launch_ms": jtj_ms, "mfma_flops_per_launch": bs["jtj_flops"] / max(bs["jtj_launches"], 1),
-                             "note": "kernel time includes the per-factor residual/Jacobian evaluation (FP64 VALU) that feeds the MFMA contraction"},
-            "roofline_step": {"kernel": "ba_step", "bound": "mfma", "achieved": step_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": step_tf / FP64_MFMA_PEAK_TF,
-                              "launch_ms": step_ms, "flops_per_launch": bs["step_flops"] / max(bs["step_launches"], 1),
+            "roofline_jtj": {"kernel": "ba_linearize_visual_win", "bound": "mfma", "achieved": tf(jtj_alg, jtj_t), "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                             "frac": tf(jtj_alg, jtj_t) / FP64_MFMA_PEAK_TF, "launch_ms": jtj_t, "launch_ms_in_timed_region": jtj_ms,
+                             "algorithmic_flops_per_launch": jtj_alg, "issued_mfma_flops_per_launch": jtj_issued, "frac_issued": tf(jtj_issued, jtj_t) / FP64_MFMA_PEAK_TF,
+                             "mfma_utilisation_pmc": pmc.get("ba_linearize_visual_win", {}).get("mfma_utilisation"),
+                             "note": "algorithmic flops = Nv*2*2*91 per window (SURVEY.md 8d); issued = 2048 per v_mfma_f64_16x16x4_f64 (16-column tiles, 13 used); the kernel also "
+                                     "evaluates every factor's residual / Jacobian (FP64 VALU), reduces the pair tiles and builds the E^T F rows; " + pmc.get("ba_linearize_visual_win", {}).get("note", "")},
+            "roofline_step": {"kernel": "ba_step", "bound": "mfma", "achieved": tf(step_flops, step_t), "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf(step_flops, step_t) / FP64_MFMA_PEAK_TF,
+                              "launch_ms": step_t, "launch_ms_in_timed_region": step_ms, "flops_per_launch": step_flops,
+                              "mfma_utilisation_pmc": pmc.get("ba_step", {}).get("mfma_utilisation"),
                               "note": "largest kernel by time; algorithmic flops = Schur SYRK NE*n_c^2 + Cholesky R^3/3 + substitutions 2R^2 per window; one block per window, "
                                       "bound by the latency of R/16 sequential 16x16 factor+inverse blocks, not by MFMA issue"},
             "ba_summary_seq0": sums[0],
         }
+        if world == 1 and not args.no_e2e and not (args.no_frontend or args.no_backend):
+            trk.close(); trk = None
+            res["end_to_end"] = end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist)
         if not args.no_cpu_baseline:
             nseq = min(8, B)
             cores = min(os.cpu_count() or 1, nseq)
@@ -266,7 +365,8 @@ def main():
                                              % (nseq, cb["repeat"], fh.shape[0], cb["repeat"] * max(1, fh.shape[0] // 4), cores, cb["wall_s"], cb["wall_s"] * cores),
                                    "detail": cb}
         print(json.dumps(res))
-    trk.close()
+    if trk is not None:
+        trk.close()
     est.close()
     if dist is not None:
         dist.barrier()

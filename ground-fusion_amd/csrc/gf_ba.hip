@@ -689,6 +689,22 @@ int gf_ba_linearize(gf_ba* h, const gf_ba_window* w, int cap, double* Hout, doub
     return GF_OK;
 }
 
+// north_star's pose exchange: the newest pose (px py pz qx qy qz qw) of every resident window, straight from the current state buffer into a
+// caller-provided DEVICE array [count][7] (what the RCCL all_gather of bench.py / shard.py sends); returns when the copy has completed.
+__global__ void ba_export_newest(gfb::Win w, double* out, int count) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= count) return;
+    const double* x = w.xs + ((size_t)w.st[b].cur * w.d.B + b) * w.d.XS + gfb::off_pose(w.d.W);
+    for (int q = 0; q < 7; q++) out[(size_t)b * 7 + q] = x[q];
+}
+int gf_ba_export_newest_poses(gf_ba* h, void* d_out, int count) {
+    if (!h || !d_out || count < 1 || count > h->count) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    ba_export_newest<<<dim3((count + 63) / 64), 64, 0, h->stream>>>(h->win(), static_cast<double*>(d_out), count);
+    HIPCHK(hipGetLastError());
+    if (!h->pending) HIPCHK(hipStreamSynchronize(h->stream));
+    return GF_OK;
+}
+
 int gf_ba_debug_stamps(gf_ba* h, long long* out, int n) {  // phase timestamps of the last ba_step launch (profiling builds)
     if (!h || !out || n > 128) return gf::set_err(GF_ERR_INVALID, "bad argument");
     HIPCHK(hipMemcpy(out, h->stamps.d, n * sizeof(long long), hipMemcpyDeviceToHost));

@@ -275,6 +275,10 @@ class Estimator:
     def solve_resident(self, max_iters=8, marginalize_mode=-1, reset=True):
         _chk(lib().gf_ba_solve_resident(self.h, max_iters, marginalize_mode, int(reset)))
 
+    def export_newest_poses(self, d_ptr, count):
+        """newest pose of every resident window into a device array [count][7] (d_ptr: integer device address)"""
+        _chk(lib().gf_ba_export_newest_poses(self.h, C.c_void_p(d_ptr), count))
+
     def solve_resident_async(self, max_iters=8, marginalize_mode=-1, reset=True):
         _chk(lib().gf_ba_solve_resident_async(self.h, max_iters, marginalize_mode, int(reset)))
 

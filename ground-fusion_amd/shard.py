@@ -1,15 +1,8 @@
-"""Multi-GPU sharding of independent sequences: sequence k lives on rank k // per_gpu; there is no
-data-path collective.  The only exchange is the gather of the newest pose of every sequence (7 doubles each) onto rank 0,
-over RCCL on GPUs (torch.distributed backend "nccl") or gloo in the CPU tests."""
+"""Multi-GPU sharding of independent sequences: sequences are dealt to ranks in contiguous shards; there is no
+data-path collective.  The only exchange is the gather of the newest pose of every sequence (7 doubles each), over RCCL on GPUs
+(torch.distributed backend "nccl") or gloo in the CPU tests.  Shards may be uneven (n_sequences % world != 0): the gather pads
+every rank's block to the largest shard and strips the padding again."""
 import torch
-
-
-def first_sequence(rank, per_gpu):
-    return rank * per_gpu
-
-
-def owner_of(seq, per_gpu):
-    return seq // per_gpu
 
 
 def partition(n_sequences, world):
@@ -23,11 +16,50 @@ def partition(n_sequences, world):
     return out
 
 
-def gather_poses(newest, dist, world):
-    """newest: [per_gpu, 7] float64 tensor on this rank's device. Returns [world*per_gpu, 7] on every rank (all_gather keeps
-    ranks symmetric; 56 B per sequence, latency-bound — one collective per step at most)."""
+class Plan:
+    """who owns which sequence; every helper derives from the one partition table"""
+
+    def __init__(self, n_sequences, world):
+        self.n, self.world = n_sequences, world
+        self.parts = partition(n_sequences, world)
+
+    def first(self, rank):
+        return self.parts[rank][0]
+
+    def count(self, rank):
+        return self.parts[rank][1]
+
+    def counts(self):
+        return [c for _, c in self.parts]
+
+    def owner_of(self, seq):
+        for r, (f, c) in enumerate(self.parts):
+            if f <= seq < f + c:
+                return r
+        raise IndexError("sequence %d outside 0..%d" % (seq, self.n - 1))
+
+
+def first_sequence(rank, per_gpu):
+    """uniform shards of per_gpu sequences (weak scaling: the bench's layout)"""
+    return rank * per_gpu
+
+
+def owner_of(seq, per_gpu):
+    return seq // per_gpu
+
+
+def gather_poses(newest, dist, world, counts=None):
+    """newest: [count(rank), 7] float64 tensor on this rank's device.  Returns [sum(counts), 7] on every rank, sequences in global
+    order (all_gather keeps ranks symmetric; 56 B per sequence, latency-bound -- one collective per step).  counts: sequences per
+    rank when the shards are uneven (Plan.counts()); None = every rank holds newest.shape[0]."""
     if dist is None or world == 1:
         return newest.clone()
-    out = [torch.empty_like(newest) for _ in range(world)]
-    dist.all_gather(out, newest.contiguous())
-    return torch.cat(out, 0)
+    if counts is None:
+        counts = [newest.shape[0]] * world
+    cmax = max(counts)
+    mine = newest.contiguous()
+    if mine.shape[0] < cmax:   # pad to the largest shard: all_gather needs equal shapes
+        mine = torch.cat([mine, torch.zeros((cmax - mine.shape[0], mine.shape[1]), dtype=mine.dtype, device=mine.device)], 0)
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return torch.cat([o[:c] for o, c in zip(out, counts)], 0)

@@ -213,6 +213,10 @@ int gf_ba_solve_resident(gf_ba* h, int max_iters, int marginalize_mode /* -1: no
 int gf_ba_solve_resident_async(gf_ba* h, int max_iters, int marginalize_mode, int reset_state);
 int gf_ba_wait(gf_ba* h);
 int gf_ba_download(gf_ba* h, gf_ba_window* windows, int count, gf_ba_summary* summaries, gf_ba_prior* priors);
+/* the newest pose (para_Pose[W]: px py pz qx qy qz qw) of the first `count` resident windows into a DEVICE array [count][7] -- the payload of the
+ * per-step pose gather across GPUs (north_star; there is no counterpart in the single-process reference).  Enqueued behind a pending
+ * asynchronous solve (complete after gf_ba_wait); otherwise complete on return. */
+int gf_ba_export_newest_poses(gf_ba* h, void* d_out, int count);
 int gf_ba_get_stats(gf_ba* h, gf_ba_stats* out);
 int gf_ba_debug_stamps(gf_ba* h, long long* out, int n); /* per-phase clock stamps of ba_step (profiling builds, -DGF_PROFILE_STEP) */
 int gf_ba_reset_stats(gf_ba* h);

@@ -10,6 +10,40 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _uneven_worker(rank, world, port, n_seq, q):
+    sys.path.insert(0, os.path.join(ROOT, "ground-fusion_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import shard
+    plan = shard.Plan(n_seq, world)
+    mine = torch.tensor([[float(k)] * 7 for k in range(plan.first(rank), plan.first(rank) + plan.count(rank))], dtype=torch.float64).reshape(-1, 7)
+    g = shard.gather_poses(mine, dist, world, plan.counts())
+    if rank == 0:
+        q.put(g.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_uneven_shards_gather_in_global_order():
+    """5 sequences on 2 ranks (3 + 2): the owner table and the padded gather agree with the partition"""
+    sys.path.insert(0, os.path.join(ROOT, "ground-fusion_amd"))
+    import shard
+    plan = shard.Plan(5, 2)
+    assert plan.parts == [(0, 3), (3, 2)] and [plan.owner_of(k) for k in range(5)] == [0, 0, 0, 1, 1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_uneven_worker, args=(r, 2, port, 5, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got.shape == (5, 7) and np.array_equal(got[:, 0], np.arange(5.0))
+
+
 def _worker(rank, world, port, per_gpu, q):
     for p in (ROOT, os.path.join(ROOT, "ground-fusion_amd"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
