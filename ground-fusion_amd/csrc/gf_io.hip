@@ -235,7 +235,11 @@ int gf_pgm_read(const char* path, int* width, int* height, int* maxval, void* pi
         if (isspace(ch)) continue;
         if (!isdigit(ch)) { fclose(f); return gf::set_err(GF_ERR_INVALID, "%s: malformed PGM header", path); }
         int v = 0;
-        while (ch != EOF && isdigit(ch)) { v = v * 10 + (ch - '0'); ch = fgetc(f); }
+        while (ch != EOF && isdigit(ch)) {
+            v = v * 10 + (ch - '0');
+            if (v > (1 << 24)) { fclose(f); return gf::set_err(GF_ERR_INVALID, "%s: malformed PGM header (number too large)", path); }   // no header field of a frame comes near: stop before the int overflows
+            ch = fgetc(f);
+        }
         vals[nv++] = v;          // the single whitespace byte after maxval has just been consumed
     }
     if (nv < 3 || vals[0] <= 0 || vals[1] <= 0 || vals[2] <= 0 || vals[2] > 65535) { fclose(f); return gf::set_err(GF_ERR_INVALID, "%s: malformed PGM header", path); }

@@ -513,13 +513,16 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
         s.prev_pts = s.cur_pts; s.prev_un_pts = s.cur_un_pts; s.prev_un_pts_map.swap(s.cur_un_pts_map); s.prev_time = s.cur_time;
         s.hasPrediction = false;
         const int n = (int)s.ids.size();
+        // depth_cam set but no depth image: neither packing loop of the reference runs (feature_tracker.cpp:320 `depth_cam == 0`, :344 `!_img1.empty()`):
+        // the returned featureFrame is empty, the tracker state has advanced all the same
+        if (h->cfg.depth_cam && !d_depth) { n_out[b] = 0; return; }
         if (n > cap_out) { a_overflow = n; n_out[b] = 0; return; }
         gf_feature_obs* o = out + (size_t)b * cap_out;
         for (int i = 0; i < n; i++) {
             o[i].id = s.ids[i]; o[i].camera_id = 0;
             o[i].v[0] = s.cur_un_pts[i].x; o[i].v[1] = s.cur_un_pts[i].y; o[i].v[2] = 1; o[i].v[3] = s.cur_pts[i].x; o[i].v[4] = s.cur_pts[i].y;
             o[i].v[5] = s.pts_velocity[i].x; o[i].v[6] = s.pts_velocity[i].y;
-            o[i].v[7] = (h->cfg.depth_cam && d_depth) ? (double)(int)s.cur_depth[i] / 1000 : -2.4;
+            o[i].v[7] = h->cfg.depth_cam ? (double)(int)s.cur_depth[i] / 1000 : -2.4;
         }
         n_out[b] = n;
         a_out += n;

@@ -521,6 +521,7 @@ struct Tracker {
         prev_img = cur_img; prev_pts = cur_pts; prev_un_pts = cur_un_pts; prev_un_pts_map = cur_un_pts_map;
         prev_time = cur_time; hasPrediction = false;
         int n = (int)ids.size();
+        if (cfg.depth_cam && !depth) return 0;   // FT:320 (`depth_cam == 0`) and FT:344 (`!_img1.empty()`) both false: empty featureFrame
         for (int i = 0; i < n && i < cap; i++) {  // FT:322-368
             double* o = out_obs + (size_t)i * 8;
             out_ids[i] = ids[i];

@@ -180,6 +180,16 @@ def test_exported_dataset_config_round_trips(tmp_path):
     assert len(open(tmp_path / "image0.csv").read().split()) == 2
 
 
+def test_pgm_header_with_absurd_numbers_is_rejected(tmp_path):
+    """a garbage header must fail cleanly, not overflow the parser's accumulator"""
+    for hdr in (b"P5\n99999999999999999999 480\n255\n", b"P5\n640 480\n70000\n", b"P5\n640 -3\n255\n"):
+        q = str(tmp_path / "bad.pgm")
+        with open(q, "wb") as f:
+            f.write(hdr + b"\0" * 64)
+        with pytest.raises(gfamd.GfError):
+            gfamd.read_pgm(q)
+
+
 def test_tum_line_and_pgm(tmp_path):
     p = str(tmp_path / "vio.txt")
     a = 0.3

@@ -133,8 +133,8 @@ def test_track_image_sequence_bit_exact_ids(gf, oracle, max_cnt, min_dist):
 def test_track_image_prediction_and_outlier_feedback(gf, oracle):
     """setPrediction / removeOutliers path (feature_tracker.cpp:118-133, :1006-1045), incl. the <10 fallback."""
     frames = _frames(1003, 6)
-    otr = oracle.Tracker(oracle.default_cfg())
-    gtr = gf.FeatureTracker(gf.default_cfg())
+    otr = oracle.Tracker(oracle.default_cfg(depth_cam=0))
+    gtr = gf.FeatureTracker(gf.default_cfg(depth_cam=0))
     rng = np.random.default_rng(9)
     for k, f in enumerate(frames):
         t = 0.0666 * k
@@ -154,11 +154,56 @@ def test_track_image_prediction_and_outlier_feedback(gf, oracle):
     gtr.close()
 
 
+def test_depth_camera_without_depth_image_returns_an_empty_frame(gf, oracle):
+    """depth_cam = 1 and no depth image: neither packing loop of trackImage runs (feature_tracker.cpp:320, :344) -- the featureFrame is empty
+    while ids / track_cnt / prev_pts advance as usual; the next frame with a depth image reports the aged tracks"""
+    frames = _frames(1004, 4)
+    depth = np.full(frames[0].shape, 1500, np.uint16)
+    otr, gtr = oracle.Tracker(oracle.default_cfg()), gf.FeatureTracker(gf.default_cfg())
+    for k, f in enumerate(frames):
+        d = None if k in (1, 2) else depth
+        oi, oo = otr.track(0.05 * k, f, d)
+        gi, go = gtr.trackImage(0.05 * k, f, d)
+        assert np.array_equal(oi, gi) and np.array_equal(oo.view(np.uint64), go.view(np.uint64))
+        assert (len(gi) == 0) == (d is None)
+        os_, gs_ = otr.state(), gtr.state()
+        assert len(gs_[0]) > 100 and all(np.array_equal(a, b) for a, b in zip(os_, gs_))
+    assert gs_[1].max() == 4     # tracked through the frames without output
+    gtr.close()
+
+
+def test_track_image_with_lens_distortion(gf, oracle):
+    """SURVEY.md row T8 with non-zero distortion (config/realsense/idc_cam.yaml): undistortedPts -> PinholeCamera::liftProjective's 8 fixed-point
+    iterations (PinholeCamera.cc:450-510), ptsVelocity on the undistorted plane, setPrediction -> spaceToPlane with distortion (:520-542)"""
+    K = dict(fx=6.2097277909374247e+02, fy=6.2212293397677581e+02, cx=3.1175896455154810e+02, cy=2.4718077836114819e+02,
+             k1=1.4865749308203452e-01, k2=-4.6815685578576460e-01, p1=1.6205585303208318e-03, p2=-8.9101576735577930e-03)
+    ocfg, gcfg = oracle.default_cfg(), gf.default_cfg()
+    for k, v in K.items():
+        setattr(ocfg, k, v); setattr(gcfg, k, v)
+    frames = _frames(1005, 6)
+    depth = np.full(frames[0].shape, 2100, np.uint16)
+    otr, gtr = oracle.Tracker(ocfg), gf.FeatureTracker(gcfg)
+    rng = np.random.default_rng(3)
+    for k, f in enumerate(frames):
+        oi, oo = otr.track(0.0666 * k, f, depth)
+        gi, go = gtr.trackImage(0.0666 * k, f, depth)
+        assert np.array_equal(oi, gi), "frame %d: ids differ" % k
+        assert np.array_equal(oo.view(np.uint64), go.view(np.uint64)), "frame %d: observations differ" % k
+        # the undistorted coordinates really differ from the pinhole ones
+        pin = np.stack([(go[:, 3] - K["cx"]) / K["fx"], (go[:, 4] - K["cy"]) / K["fy"]], 1)
+        assert np.abs(pin - go[:, :2]).max() > 1e-3
+        ids, _, pts = otr.state()
+        sel = rng.random(len(ids)) < 0.6
+        xyz = np.stack([go[sel, 0] * 2.0, go[sel, 1] * 2.0, np.full(sel.sum(), 2.0)], 1) + rng.normal(0, 0.002, (sel.sum(), 3))
+        otr.set_prediction(ids[sel], xyz); gtr.setPrediction(ids[sel], xyz)
+    gtr.close()
+
+
 def test_batched_sequences_match_individual_runs(gf, oracle):
     B = 3
     seqs = [_frames(1000 + b, 4) for b in range(B)]
-    gtr = gf.FeatureTracker(gf.default_cfg(batch=B))
-    otrs = [oracle.Tracker(oracle.default_cfg()) for _ in range(B)]
+    gtr = gf.FeatureTracker(gf.default_cfg(batch=B, depth_cam=0))
+    otrs = [oracle.Tracker(oracle.default_cfg(depth_cam=0)) for _ in range(B)]
     for k in range(4):
         res = gtr.trackImageBatch([0.05 * k] * B, [seqs[b][k] for b in range(B)], None)
         for b in range(B):
