@@ -507,6 +507,7 @@ class Estimator:
                 self.processWheel(velV[i][0], dt, velV[i][1], wgyrV[i][1])
             if np.linalg.norm(self.dP_wheel - self.dP_imu) > 0.02 and self.cfg["wdetect"]:
                 self.wheelanomaly = True
+                self.n_wheel_anomaly = getattr(self, "n_wheel_anomaly", 0) + 1   # test bookkeeping
             self.wheelstationary = np.linalg.norm(self.dP_wheel) < 0.001
             self.preintegrationstationary = np.linalg.norm(self.dP_imu) < 0.001
         self.processImage(image, t)

@@ -222,6 +222,34 @@ def test_large_window_matches_oracle(gf, oracle, W, F):
     est.close()
 
 
+def test_config3_300_features_matches_oracle(gf, oracle):
+    """BASELINE.json configs[2]: 10-frame window, 300 features (3000 visual factors): solve, MARGIN_OLD, next solve, MARGIN_SECOND_NEW"""
+    F = 300
+    est = gf.Estimator(10, F, F * 10)
+    w = SW.make_window(3, oracle, n_landmarks=int(F * 1.5), max_features=F)
+    assert w["n_feature"] == F and w["n_visual"] > 2000
+    wo, wg = w.copy(), w.copy()
+    so, sg = oracle.ba_solve(wo, 8), est.solve([wg], 8)[0]
+    assert (so["iterations"], so["successful_steps"], so["termination"]) == (sg["iterations"], sg["successful_steps"], sg["termination"])
+    dp, dr = _pose_diff(wo, wg)
+    assert dp < 1e-6 and dr < 1e-6, (dp, dr)
+    po, pg = oracle.ba_marginalize(wo, 0, cap_n=512), est.marginalize([wo], 0, cap_n=512)[0]
+    assert list(pg["block_id"]) == list(po["block_id"]) and pg["m"] == po["m"]
+    Ao, bo, _ = _prior_invariants(po)
+    Ag, bg, _ = _prior_invariants(pg)
+    _assert_prior_close(Ao, bo, Ag, bg)
+    w2o = SW.make_window(3, oracle, n_landmarks=int(F * 1.5), max_features=F, frame0=1, prior=po)
+    w2g = SW.make_window(3, oracle, n_landmarks=int(F * 1.5), max_features=F, frame0=1, prior=pg)
+    oracle.ba_solve(w2o, 8); est.solve([w2g], 8)
+    dp, dr = _pose_diff(w2o, w2g)
+    assert dp < 1e-6 and dr < 1e-6, (dp, dr)
+    p1o, p1g = oracle.ba_marginalize(w2o, 1, cap_n=512), est.marginalize([w2o], 1, cap_n=512)[0]
+    Ao, bo, _ = _prior_invariants(p1o)
+    Ag, bg, _ = _prior_invariants(p1g)
+    _assert_prior_close(Ao, bo, Ag, bg)
+    est.close()
+
+
 def test_lds_and_global_reduced_system_agree(gf, oracle, monkeypatch):
     """the global-memory variant of the step / marginalisation kernels on a window that also fits LDS"""
     w = SW.make_window(4, oracle)

@@ -82,6 +82,49 @@ def test_replay_feature_frames_matches_oracle():
     assert worst["p"] < 1e-6 and worst["r"] < 1e-6, worst
 
 
+@pytest.mark.parametrize("variant", ["use_mcc", "estimate_td", "wheel_slip"])
+def test_replay_configurations_of_the_other_shipped_yaml_files(variant):
+    """what the m2dgrp.yaml replays leave untouched: use_mcc: 1 (groundchallenge.yaml:10, idc_rs.yaml:13 -- the consistency check's outliers now reach
+    removeOutlier and the tracker feedback, estimator.cpp:1104-1134), estimate_td: 1 (td becomes a free block once the vehicle moves, :3097-3100), and
+    a wheel-slip segment (`wdetect`: |dP_wheel - dP_imu| > 0.02 raises wheelanomaly, the wheel factors of that frame are skipped in the solve and in
+    the marginalisation, :633, :3132-3136, :3370).  Same bars as the other replays."""
+    st = make_stream(2)
+    st._lm = st._landmarks(1600)
+    st._pn = np.random.default_rng(4002).normal(0, 1.0, (len(st.cam_t), len(st._lm), 2))
+    kw = dict(tio=SS.TIO, rio=SS.RIO, multiple_thread=1)
+    if variant == "use_mcc":
+        kw["use_mcc"] = 1
+    if variant == "estimate_td":
+        kw["estimate_td"] = 1
+    if variant == "wheel_slip":      # the odometer over-reports for 0.5 s in the middle of the drive (wheel spin)
+        sel = (st.wheel_t > 3.0) & (st.wheel_t < 3.5)
+        st.wheel_vel[sel] *= 1.6
+    est_p = gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(**kw))
+    est_o = EO.Estimator(dict(kw))
+    tp, worst, td_free = -1.0, dict(p=0.0, r=0.0, v=0.0), 0
+    for k in range(len(st.cam_t)):
+        for e in (est_o, est_p):
+            t1 = st.feed(e, k, tp)
+        tp = t1
+        if k % 2:
+            continue
+        frame = st.feature_frame(k)
+        est_p.inputFeature(float(st.cam_t[k]), frame)
+        est_o.inputFeature(float(st.cam_t[k]), frame)
+        compare_frame(est_o, est_p, worst, "%s frame %d" % (variant, k))
+        s = est_p.state()
+        assert abs(s["td"] - est_o.td) < 1e-6      # seconds; observed 7e-9 on a td of 12 ms
+        td_free += int(abs(est_o.td) > 0)
+    assert est_o.solver_flag == EO.NON_LINEAR and est_o.n_optimizations > 30
+    if variant == "estimate_td":
+        assert td_free > 5          # td really was estimated
+    if variant == "wheel_slip":
+        assert getattr(est_o, "n_wheel_anomaly", 0) > 0   # the slip was detected and wheel factors were dropped
+    print("replay %s worst deviation" % variant, worst)
+    assert worst["p"] < 1e-6 and worst["r"] < 1e-6, worst
+    est_p.close()
+
+
 def _image_replay(multiple_thread, t_move):
     st = make_stream(1, t_move)
     cfg = gfamd.default_estimator_cfg(tio=SS.TIO, rio=SS.RIO, multiple_thread=multiple_thread, with_tracker=1)

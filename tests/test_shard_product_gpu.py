@@ -1,0 +1,68 @@
+"""The product path with world_size 2: two processes (gloo rendezvous, both on device 0 of the one-GPU test box) each own half of the
+sequences, solve + marginalise them on the HIP back end, export the newest poses on the device and all_gather them; the result must be
+bit-identical to the single-process batch (every sum of the back end has a fixed order, so the batch split cannot change a bit)."""
+import os
+import sys
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+N_SEQ, ITERS = 6, 6
+
+
+def _windows(gfamd, first, count):
+    import synth_window as SW
+    return [SW.make_window(200 + k, gfamd, max_features=80, n_landmarks=120) for k in range(first, first + count)]
+
+
+def _solve_newest(gfamd, wins):
+    est = gfamd.Estimator(10, 80, 800, len(wins))
+    est.upload(wins)
+    est.solve_resident(ITERS, 0, True)
+    out = torch.zeros((len(wins), 7), dtype=torch.float64, device="cuda:0")
+    est.export_newest_poses(out.data_ptr(), len(wins))
+    torch.cuda.synchronize()
+    est.download(wins)
+    host = np.stack([w["para_Pose"].reshape(-1, 7)[-1] for w in wins])
+    est.close()
+    return out, host
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "ground-fusion_amd")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gfamd
+    import shard
+    plan = shard.Plan(N_SEQ, world)
+    dev, host = _solve_newest(gfamd, _windows(gfamd, plan.first(rank), plan.count(rank)))
+    assert np.array_equal(dev.cpu().numpy(), host)          # the device export is the downloaded state
+    g = shard.gather_poses(dev.cpu(), dist, world, plan.counts())   # gloo moves host tensors; on the 8-GPU node the same call runs over RCCL on device tensors
+    if rank == 0:
+        q.put(g.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_on_the_product_path_match_one():
+    for p in (ROOT, os.path.join(ROOT, "ground-fusion_amd")):
+        sys.path.insert(0, p)
+    import gfamd
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    _, ref = _solve_newest(gfamd, _windows(gfamd, 0, N_SEQ))
+    assert got.shape == (N_SEQ, 7) and np.array_equal(got, ref)
