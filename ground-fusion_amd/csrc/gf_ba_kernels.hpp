@@ -1142,11 +1142,20 @@ __device__ inline bool wave_chol16_inv(double* s_L, double* s_inv, double* s_rdi
         for (int i = 0; i < 16; i++) x[i] = (i == j) ? 1.0 : 0.0;
         // right-looking: once x[k] is final every later row takes its contribution -- 15 - k independent FMAs per step instead of one long
         // dependent accumulation per row
+        // column k of L is fetched from LDS (broadcast reads) one step ahead of its use: the 16 steps are a dependent chain, an LDS round trip
+        // per step would double it
+        double lc[16], ln[16];
+#pragma unroll
+        for (int i = 1; i < 16; i++) lc[i] = s_L[i * 17];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
+#pragma unroll
+            for (int i = k + 2; i < 16; i++) ln[i] = s_L[i * 17 + k + 1];
             x[k] *= rd[k];
 #pragma unroll
-            for (int i = k + 1; i < 16; i++) x[i] -= s_L[i * 17 + k] * x[k];
+            for (int i = k + 1; i < 16; i++) x[i] -= lc[i] * x[k];
+#pragma unroll
+            for (int i = k + 2; i < 16; i++) lc[i] = ln[i];
         }
         if (lane < 16) {
 #pragma unroll

@@ -170,8 +170,9 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
 #endif
     GF_MST(0);
     // ---- eliminate the features: M -= sum_f w_f^T w_f / d_f, bv -= sum_f w_f b_f / d_f  (d_f <= eps: no information, dropped)
-    double* fe = sb.u + (size_t)b * sb.VS;   // per-feature 1/sqrt(d_f) (0: dropped) and b_f/sqrt(d_f)
-    for (int e = tid; e < NE; e += 512) { const double df = ete[e]; const double f = df > eps ? 1.0 / sqrt(df) : 0.0; fe[e] = f; fe[d.FP + e] = f * etb[e]; }
+    double* fe = sb.u + (size_t)b * sb.VS;   // per-feature 1/sqrt(d_f) (0: dropped)
+    double* feb = sb.yv + (size_t)b * sb.VS;  // per-feature b_f/sqrt(d_f)  (two scratch vectors of VS = RP + FP entries each: F entries fit either, not both in one)
+    for (int e = tid; e < NE; e += 512) { const double df = ete[e]; const double f = df > eps ? 1.0 / sqrt(df) : 0.0; fe[e] = f; feb[e] = f * etb[e]; }
     __syncthreads();
     for (int i = tid; i < ((NE + 3) & ~3) * ECW; i += 512) {
         const int e = i / ECW, k = i - e * ECW;
@@ -182,7 +183,7 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
         const int c = s_cmap[k];
         if (c < 0) continue;
         double v = bv[c];
-        for (int e = 0; e < NE; e++) v -= Es[(size_t)e * ECW + k] * fe[d.FP + e];
+        for (int e = 0; e < NE; e++) v -= Es[(size_t)e * ECW + k] * feb[e];
         bv[c] = v;
     }
     GF_MST(1);
