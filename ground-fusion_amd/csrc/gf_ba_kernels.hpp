@@ -1134,36 +1134,35 @@ __device__ inline bool wave_chol16_inv(double* s_L, double* s_inv, double* s_rdi
         for (int c = 0; c < 16; c++) s_rdiag[c] = rd[c];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-    // inverse: lane j solves L x = e_j (column j of L^-1); L is read as LDS broadcasts (DPP row broadcasts of the register copy measured slower)
-    if (INV) {
-        const int j = r;
-        double x[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) x[i] = (i == j) ? 1.0 : 0.0;
-        // right-looking: once x[k] is final every later row takes its contribution -- 15 - k independent FMAs per step instead of one long
-        // dependent accumulation per row
-        // column k of L is fetched from LDS (broadcast reads) one step ahead of its use: the 16 steps are a dependent chain, an LDS round trip
-        // per step would double it
-        double lc[16], ln[16];
-#pragma unroll
-        for (int i = 1; i < 16; i++) lc[i] = s_L[i * 17];
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-#pragma unroll
-            for (int i = k + 2; i < 16; i++) ln[i] = s_L[i * 17 + k + 1];
-            x[k] *= rd[k];
-#pragma unroll
-            for (int i = k + 1; i < 16; i++) x[i] -= lc[i] * x[k];
-#pragma unroll
-            for (int i = k + 2; i < 16; i++) lc[i] = ln[i];
-        }
-        if (lane < 16) {
-#pragma unroll
-            for (int i = 0; i < 16; i++) s_inv[i * 17 + j] = x[i];
-        }
-    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
     return good;
+}
+
+// Explicit inverse of the 16x16 lower-triangular factor in s_L (reciprocal diagonal in s_rdiag): lane j solves L x = e_j (column j of L^-1);
+// L is read as LDS broadcasts, one column ahead of its use (the 16 steps are a dependent chain).  All 64 lanes must call it.
+__device__ inline void wave_tri_inv16(const double* s_L, double* s_inv, const double* s_rdiag, int lane) {
+    const int j = lane & 15;
+    double x[16], lc[16], ln[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 1; i < 16; i++) lc[i] = s_L[i * 17];
+    // right-looking: once x[k] is final every later row takes its contribution -- 15 - k independent FMAs per step
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+#pragma unroll
+        for (int i = k + 2; i < 16; i++) ln[i] = s_L[i * 17 + k + 1];
+        x[k] *= s_rdiag[k];
+#pragma unroll
+        for (int i = k + 1; i < 16; i++) x[i] -= lc[i] * x[k];
+#pragma unroll
+        for (int i = k + 2; i < 16; i++) lc[i] = ln[i];
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s_inv[i * 17 + j] = x[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
 }
 
 // One 512-thread block per window: accept/reject of the previous candidate (trust_region_minimizer.cc), then the next
@@ -1422,6 +1421,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
             __syncthreads();
 #ifdef GF_PROFILE_STEP
             long long tA = 0, tB = 0, tC = 0, t0c = clock64();
+            if (blockIdx.x == 0 && tid == 0 && sb.stamps) { sb.stamps[24] = sb.stamps[25] = sb.stamps[26] = sb.stamps[27] = 0; }
 #define GF_SUB(acc) do { const long long n_ = clock64(); acc += n_ - t0c; t0c = n_; } while (0)
 #else
 #define GF_SUB(acc) do { } while (0)
@@ -1429,11 +1429,22 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
             // diagonal block j0: copy to s_blk, in-register factor + explicit inverse, copy the factor back (wavefront 0 only)
             auto diag_block = [&](int j0) {
                 const int nb = min(16, R - j0);
+#ifdef GF_PROFILE_STEP
+                long long d0 = clock64();
+#define GF_DSUB(i) do { const long long n_ = clock64(); if (blockIdx.x == 0 && tid == 0 && sb.stamps) sb.stamps[i] += n_ - d0; d0 = n_; } while (0)
+#else
+#define GF_DSUB(i) do { } while (0)
+#endif
                 for (int i = lane; i < 256; i += 64) { const int r = i >> 4, c = i & 15; s_blk[r * 17 + c] = (r < nb && c < nb) ? S[pk(j0 + max(r, c), j0 + min(r, c))] : (r == c ? 1.0 : 0.0); }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                const bool good = wave_chol16_inv(s_blk, s_inv, s_rd + j0, lane);
+                GF_DSUB(24);
+                const bool good = wave_chol16_inv<false>(s_blk, s_inv, s_rd + j0, lane);
+                GF_DSUB(25);
+                wave_tri_inv16(s_blk, s_inv, s_rd + j0, lane);
+                GF_DSUB(26);
                 if (!good && lane == 0) s_flag[1] = 0;
                 for (int i = lane; i < 256; i += 64) { const int r = i >> 4, c = i & 15; if (c <= r && r < nb) S[pk(j0 + r, j0 + c)] = s_blk[r * 17 + c]; }
+                GF_DSUB(27);
             };
             // one 16x16 tile (ti, tk) of the trailing update A22 -= L21 L21^T
             auto trail_tile = [&](int j0, int nb, int r0, int ti, int tk) {

@@ -823,4 +823,57 @@ int gf_good_features(const uint8_t* img, int width, int height, const uint8_t* m
     return rc;
 }
 
+
+// ---- calibration of the rocprofv3 FETCH_SIZE counter for the front end's access patterns (profiling aid, scripts/pmc_collect.sh).
+// Known byte counts over a buffer far larger than the Infinity Cache, three patterns:
+//   mode 0  streaming: every lane reads 16 contiguous bytes (the pattern MI355X_MICROARCH.md calibrates: FETCH_SIZE = 1/2 of the bytes)
+//   mode 1  LK tile, aligned: a wavefront reads a 32 x 32 u8 tile, two 16-byte lanes per row (the refill of lk_solve), every 32-byte row segment
+//           inside its own 64-byte line, tiles disjoint
+//   mode 2  LK tile at an odd 4-byte phase: every row segment straddles two 64-byte lines
+namespace gf {
+__global__ void __launch_bounds__(256) calib_stream_kernel(const uint4* __restrict__ src, size_t n16, unsigned* __restrict__ sink) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned acc = 0;
+    for (; i < n16; i += (size_t)gridDim.x * blockDim.x) { const uint4 v = src[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+__global__ void __launch_bounds__(256) calib_tile_kernel(const uint8_t* __restrict__ src, size_t row_stride, int tiles_per_row, size_t n_tiles, int phase, unsigned* __restrict__ sink) {
+    const size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tiles) return;
+    const int lane = threadIdx.x & 63, trow = lane >> 1, thalf = lane & 1;
+    const size_t ty = t / tiles_per_row, tx = t % tiles_per_row;
+    const uint8_t* p = src + (ty * 32 + trow) * row_stride + tx * 128 + phase + thalf * 16;
+    const U4a v = *reinterpret_cast<const U4a*>(p);
+    if ((v.x ^ v.y ^ v.z ^ v.w) == 0x12345678u) sink[0] = v.x;
+}
+}  // namespace gf
+int gf_calib_fetch(int mode, size_t buffer_bytes, double* requested_bytes, double* lines64, double* ms) {
+    if (mode < 0 || mode > 2 || buffer_bytes < (1u << 20)) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    uint8_t* buf = nullptr; unsigned* sink = nullptr;
+    if (hipMalloc((void**)&buf, buffer_bytes) != hipSuccess || hipMalloc((void**)&sink, 64) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipMalloc failed");
+    (void)hipMemset(buf, 1, buffer_bytes); (void)hipMemset(sink, 0, 64);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0, 0);
+    if (mode == 0) {
+        const size_t n16 = buffer_bytes / 16;
+        gf::calib_stream_kernel<<<dim3(256 * 8), 256>>>(reinterpret_cast<const uint4*>(buf), n16, sink);
+        if (requested_bytes) *requested_bytes = (double)n16 * 16; if (lines64) *lines64 = (double)n16 / 4;
+    } else {
+        const size_t row_stride = 1u << 16;                 // a 64 KiB wide "image": 512 tile columns of 128 bytes
+        const int tiles_per_row = 511;
+        const size_t tile_rows = buffer_bytes / row_stride / 32, n_tiles = tile_rows * tiles_per_row;
+        const int phase = mode == 1 ? 0 : 44;                // 44: bytes 44..75 of the 128-byte slot -> both halves of the segment in different 64-byte lines
+        gf::calib_tile_kernel<<<dim3((unsigned)((n_tiles + 3) / 4)), 256>>>(buf, row_stride, tiles_per_row, n_tiles, phase, sink);
+        if (requested_bytes) *requested_bytes = (double)n_tiles * 1024; if (lines64) *lines64 = (double)n_tiles * 32 * (mode == 1 ? 1 : 2);
+    }
+    (void)hipEventRecord(e1, 0);
+    const hipError_t err = hipDeviceSynchronize();
+    float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
+    if (ms) *ms = t;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(buf); (void)hipFree(sink);
+    if (err != hipSuccess) return gf::set_err(GF_ERR_HIP, "calibration kernel failed: %s", hipGetErrorString(err));
+    return GF_OK;
+}
+
 }  // extern "C"

@@ -112,6 +112,12 @@ int gf_min_eigen_val(const uint8_t* img, int width, int height, float* eig);
 int gf_pyramid_level(const uint8_t* img, int width, int height, int level, uint8_t* out, int16_t* deriv_xy);
 
 
+/* profiling aid (no counterpart in the reference): kernels with a known byte count in the front end's access patterns, to calibrate rocprofv3's
+ * FETCH_SIZE (scripts/pmc_collect.sh).  mode 0 streaming 16 B/lane, 1 LK 32x32 tile refill with 64-byte-aligned row segments, 2 the same straddling
+ * two 64-byte lines.  Outputs: bytes the lanes requested, distinct 64-byte lines touched, kernel time. */
+int gf_calib_fetch(int mode, size_t buffer_bytes, double* requested_bytes, double* lines64, double* ms);
+
+
 /* ------------------------------------------------------------------ back end: Estimator::optimization() */
 /* Replaces the Ceres problem built and solved in Estimator::optimization() (vins_estimator/src/estimator/estimator.cpp:2890-3327:
  * vector2double -> ceres::Solve(DENSE_SCHUR, DOGLEG, max_num_iterations) ) and the construction of the next marginalisation prior

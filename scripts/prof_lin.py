@@ -12,7 +12,7 @@ for it in (1, 2, 3):
     st = np.zeros(128, np.int64)
     gfamd._chk(gfamd.lib().gf_ba_debug_stamps(est.h, st.ctypes.data_as(C.POINTER(C.c_longlong)), 128))
     print("iters", it)
-    print("  ba_step   total %d phases %s | chol diag/panel/trail %s" % (st[14] - st[0], np.diff(st[:15]).tolist(), st[20:23].tolist()))
+    print("  ba_step   total %d phases %s | chol diag/panel/trail %s | diag block copy-in/factor/inverse/write-back (sum over blocks) %s" % (st[14] - st[0], np.diff(st[:15]).tolist(), st[20:23].tolist(), st[24:28].tolist()))
     m = st[64:76]
     print("  misc_win  total %d | zero+tables %d | imu eval end +%d wheel eval end +%d prior g/cost end +%d H gather end +%d | barrier %d | tiles %d | band gather %d" % (
         m[11] - m[0], m[1] - m[0], m[2] - m[1], m[3] - m[1], m[4] - m[1], m[5] - m[1], m[6] - m[1], m[7] - m[6], m[11] - m[7]))
