@@ -133,8 +133,10 @@ def pmc_summary():
 def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist):
     """The drop-in path on a bounded sample: `nseq` sequences (one seeded synthetic RGB-D + IMU + wheel stream, replicated) through the batched
     tracker (trackImage on every camera frame) and gf_estimator_group_* (inputFeature -> processImage -> batched solve + marginalisation on
-    every second frame, the reference's MULTIPLE_THREAD flow): the back end is fed by the tracker's own output.  Returns window-solves/s over
-    the frames on which the windows are live (NON_LINEAR), wall-clock including the tracker, host bookkeeping, uploads and downloads."""
+    every second frame, the reference's MULTIPLE_THREAD flow): the back end is fed by the tracker's own output; as in the reference the tracker
+    (sync_process thread) and the estimators (processThread) run concurrently, one frame apart.  Returns window-solves/s over the frames on
+    which the windows are live (NON_LINEAR): wall-clock including the tracker, host bookkeeping, uploads and downloads, excluding only the
+    Python loop that hands the IMU / wheel samples to the members."""
     import ctypes as C
     import synth_stream as SS
     st = SS.Stream(1, t_still=1.5, t_move=1.5, v_max=0.4, yaw0=0.0, yaw_turn=-0.6, split_x=1.8, turn_delay=0.8)
@@ -149,31 +151,54 @@ def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist):
             cache[key] = (torch.from_numpy(img).to(dev), torch.from_numpy(dep.view(np.int16)).to(dev))
         frames.append(cache[key])
     sq = np.arange(nseq, dtype=np.int32)
-    tp, t_live, solves, frames_live = -1.0, 0.0, 0, 0
-    live = False
+    import threading
+    state = {"thread": None, "err": None}
+
+    def group_step(tk, obs, no):   # inputFeature -> processImage -> solve -> marginalise of all sequences (the reference's processThread, estimator.cpp:209)
+        try:
+            tt = np.full(nseq, tk)
+            gfamd._chk(gfamd.lib().gf_estimator_group_input_features(grp.g, nseq, sq.ctypes.data_as(C.POINTER(C.c_int)), tt.ctypes.data_as(C.POINTER(C.c_double)),
+                                                                     obs.ctypes.data_as(C.c_void_p), no.ctypes.data_as(C.POINTER(C.c_int))))
+        except Exception as e:   # noqa: BLE001
+            state["err"] = e
+
+    def join():
+        if state["thread"] is not None:
+            state["thread"].join()
+            state["thread"] = None
+        if state["err"] is not None:
+            raise state["err"]
+
+    tp, solves, frames_live, t_feed_live = -1.0, 0, 0, 0.0
+    live, t_start = False, None
     for k in range(len(st.cam_t)):
-        for m in grp.members:
-            t1 = st.feed(m, k, tp)
-        tp = t1
         g = frames[k][0].unsqueeze(0).expand(nseq, -1, -1).contiguous()
         d = frames[k][1].unsqueeze(0).expand(nseq, -1, -1).contiguous()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        # the tracker of this frame runs while the estimators still work on the previous back-end frame (separate threads in the reference too: rosNodeTest.cpp:713)
         n = trk.trackImageBatchDevice([float(st.cam_t[k])] * nseq, g.data_ptr(), d.data_ptr(), unpack=False)
         if k % 2 == 0:
             out = trk._out
-            obs = np.ascontiguousarray(out[np.arange(out.shape[1])[None, :] < n[:, None]])   # per-sequence frames back to back
-            tt = np.full(nseq, float(st.cam_t[k]))
-            no = np.ascontiguousarray(n, np.int32)
-            gfamd._chk(gfamd.lib().gf_estimator_group_input_features(grp.g, nseq, sq.ctypes.data_as(C.POINTER(C.c_int)), tt.ctypes.data_as(C.POINTER(C.c_double)),
-                                                                     obs.ctypes.data_as(C.c_void_p), no.ctypes.data_as(C.POINTER(C.c_int))))
-        dt = time.perf_counter() - t0
-        if live:
-            t_live += dt
-            frames_live += 1
-            if k % 2 == 0:
+            obs = np.ascontiguousarray(out[np.arange(out.shape[1])[None, :] < n[:, None]])   # per-sequence frames back to back (a copy: the tracker reuses its buffer)
+            no = np.ascontiguousarray(n, np.int32).copy()
+            join()
+            now_live = grp.members[0].state()["solver_flag"] == 1
+            if now_live and not live:
+                live, t_start = True, time.perf_counter()
+            t0 = time.perf_counter()
+            for kk in (k - 1, k):          # IMU / wheel samples up to this frame: input marshalling through Python, not part of the measured path
+                if kk >= 0:
+                    for m in grp.members:
+                        t1 = st.feed(m, kk, tp)
+                    tp = t1
+            if live:
+                t_feed_live += time.perf_counter() - t0
                 solves += nseq
-        live = grp.members[0].state()["solver_flag"] == 1
+                frames_live += 2
+            state["thread"] = threading.Thread(target=group_step, args=(float(st.cam_t[k]), obs, no))
+            state["thread"].start()
+    join()
+    t_live = (time.perf_counter() - t_start - t_feed_live) if t_start is not None else 0.0
     stt = grp.stats()
     pos = float(np.linalg.norm(grp.members[0].state()["Ps"][-1]))
     grp.close(); trk.close()

@@ -13,7 +13,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/groundfusion_hip.h"
@@ -37,6 +40,12 @@ template <class T> struct Buf {  // device buffer + pinned host mirror
     }
     void release() { if (d) (void)hipFree(d); if (h) (void)hipHostFree(h); d = nullptr; h = nullptr; }
     hipError_t up(hipStream_t s) { return hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, s); }
+    // `rows` rows of `pitch` elements, only the first `used` of each are live: one strided copy of what the kernels read
+    hipError_t up2d(hipStream_t s, size_t rows, size_t pitch, size_t used) {
+        if (used == 0 || rows == 0) return hipSuccess;
+        if (used >= pitch) return hipMemcpyAsync(d, h, rows * pitch * sizeof(T), hipMemcpyHostToDevice, s);
+        return hipMemcpy2DAsync(d, pitch * sizeof(T), h, pitch * sizeof(T), used * sizeof(T), rows, hipMemcpyHostToDevice, s);
+    }
     hipError_t down(hipStream_t s) { return hipMemcpyAsync(h, d, n * sizeof(T), hipMemcpyDeviceToHost, s); }
 };
 }  // namespace
@@ -74,6 +83,8 @@ struct gf_ba {
     size_t vwinx_lds = 0;  // the same for the variant with camera-extrinsic columns (free extrinsic; MARGIN_OLD sweep)
     size_t vtile_stride = 0;   // doubles per window in vtile (0: both variants keep their tiles in LDS)
     size_t mwin_lds = 0;   // dynamic LDS of the prior / IMU / wheel sweep (ba_linearize_misc_win)
+    int max_vis = 0, max_order = 0, max_prior = 0;   // largest n_visual / factor-order length / prior size of the resident batch (what the uploads copy)
+    std::vector<const gf_ba_window*> resident;       // the caller's window behind every resident slot (gf_ba_marginalize_resident)
     long long mfma_per_lin = 0;   // v_mfma_f64_16x16x4 instructions of one visual linearisation of the resident batch
     long long jtj_alg_flops = 0;  // algorithmic flops of the same: Nv * 2 * 2 * (12 * 13 / 2 + 12 + 1) per window
     long long step_flops = 0;     // dense algebra of one ba_step over the resident batch: Schur SYRK NE*n_c^2 + Cholesky R^3/3 + substitutions 2 R^2
@@ -118,7 +129,10 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
     if (count < 1 || count > d.B) return gf::set_err(GF_ERR_INVALID, "count %d outside 1..%d", count, d.B);
     h->any_ex = false;
     h->mfma_per_lin = 0; h->step_flops = 0; h->jtj_alg_flops = 0;
-    for (int b = 0; b < d.B; b++) {
+    std::atomic<bool> a_any_ex{false};
+    std::atomic<long long> a_mfma{0}, a_step{0}, a_jtj{0};
+    std::atomic<int> a_maxvis{0}, a_maxord{0}, a_maxpri{0};
+    auto pack_one = [&](int b) -> int {
         const gf_ba_window& w = ws[std::min(b, count - 1)];  // unused slots replicate the last window (kernels run on the whole batch)
         if (w.W != d.W) return gf::set_err(GF_ERR_INVALID, "window %d: W=%d, handle built for %d", b, w.W, d.W);
         if (w.n_feature > d.F || w.n_visual > d.NV || w.n_imu > d.W || w.n_wheel > d.W || w.prior_n > d.NPRI || w.prior_nblocks > 64)
@@ -189,7 +203,7 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
             add(fb_yaw(d.NP), true, 1);
             add(fb_anc(d.NP), !(w.gnss_enabled && ((fac && w.n_gnss > 0) || inpri(GF_ANC * 4096))), 3);
         }
-        if (!w.fix_ex_pose) h->any_ex = true;
+        if (!w.fix_ex_pose) a_any_ex = true;
         SolverState& st = h->st0.h[b];
         memset(&st, 0, sizeof st);
         st.radius = 1e4; st.mu = 1e-8; st.R = col; st.last_successful = 1;
@@ -211,7 +225,9 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
             h->cole.h[(size_t)b * d.F + f] = free_f ? ne++ : -1;
         }
         st.NE = ne;
-        if (b < count) { const double R = st.R, nc = 6.0 * d.NP + 8.0; h->step_flops += (long long)(ne * nc * nc + R * R * R / 3.0 + 2.0 * R * R); }
+        if (b < count) { const double R = st.R, nc = 6.0 * d.NP + 8.0; a_step += (long long)(ne * nc * nc + R * R * R / 3.0 + 2.0 * R * R); }
+        { int v = a_maxvis.load(); while (w.n_visual > v && !a_maxvis.compare_exchange_weak(v, w.n_visual)) {} }
+        { int v = a_maxpri.load(); while (w.prior_n > v && !a_maxpri.compare_exchange_weak(v, w.prior_n)) {} }
         h->nvis.h[b] = w.n_visual; h->nimu.h[b] = w.n_imu; h->nwh.h[b] = w.n_wheel; h->nfeat.h[b] = w.n_feature;
         {   // pair-sorted order with even padding (each MFMA consumes two factors of one frame pair)
             std::vector<int> idx(w.n_visual);
@@ -229,7 +245,8 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
             if (n > d.NVP) return gf::set_err(GF_ERR_CAPACITY, "factor order overflow");
             h->norder.h[b] = n;
             for (int i = n; i < d.NVP; i++) ord[i] = -1;
-            if (b < count) { h->mfma_per_lin += (long long)(n / 2) * (w.fix_ex_pose ? 1 : 3); h->jtj_alg_flops += (long long)w.n_visual * 4 * 91; }
+            if (b < count) { a_mfma += (long long)(n / 2) * (w.fix_ex_pose ? 1 : 3); a_jtj += (long long)w.n_visual * 4 * 91; }
+            { int v = a_maxord.load(); while (n > v && !a_maxord.compare_exchange_weak(v, n)) {} }
         }
         {   // CSR feature -> factors
             int* fp = h->feat_ptr.h + (size_t)b * (d.F + 1);
@@ -264,11 +281,12 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
             memcpy(h->pri_r.h + (size_t)b * d.NPRI, w.prior_r, (size_t)w.prior_n * 8);
             memcpy(h->pri_x0.h + (size_t)b * d.NPRI * 2, w.prior_x0, (size_t)gs * 8);
         }
-    }
+        return GF_OK;
+    };
     // ---- marginalisation layouts (first-appearance order of the blocks over [prior, IMU0, wheel0, visual factors from frame 0])
-    for (int mode = 0; mode < 2; mode++) {
-        h->keep_ids[mode].assign(d.B, {});
-        for (int b = 0; b < d.B; b++) {
+    for (int mode = 0; mode < 2; mode++) h->keep_ids[mode].assign(d.B, {});
+    auto pack_marg = [&](int b) -> int {
+        for (int mode = 0; mode < 2; mode++) {
             const gf_ba_window& w = ws[std::min(b, count - 1)];
             std::vector<int> dropb, keepb, dropf;
             auto has = [](const std::vector<int>& v, int id) { return std::find(v.begin(), v.end(), id) != v.end(); };
@@ -337,20 +355,50 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
             h->mnorder[mode].h[b] = no;
             for (int i = no; i < d.NVP; i++) ord[i] = -1;
         }
+        return GF_OK;
+    };
+    // the windows are independent: pack them on a few host threads (the estimator group hands over hundreds per call)
+    {
+        const int nt = std::max(1, std::min({d.B / 4, (int)std::thread::hardware_concurrency(), 16}));
+        std::atomic<int> next{0}, failed{GF_OK};
+        std::mutex em; std::string emsg;
+        auto work = [&]() {
+            for (int b = next++; b < d.B; b = next++) {
+                int rc = pack_one(b);
+                if (rc == GF_OK) rc = pack_marg(b);
+                if (rc != GF_OK) { std::lock_guard<std::mutex> lk(em); if (failed == GF_OK) { failed = rc; emsg = gf_last_error(); } }
+            }
+        };
+        std::vector<std::thread> ths;
+        for (int t = 1; t < nt; t++) ths.emplace_back(work);
+        work();
+        for (auto& t : ths) t.join();
+        if (failed != GF_OK) return gf::set_err(failed, "%s", emsg.c_str());
     }
+    h->any_ex = a_any_ex; h->mfma_per_lin = a_mfma; h->step_flops = a_step; h->jtj_alg_flops = a_jtj;
+    h->max_vis = a_maxvis; h->max_order = a_maxord; h->max_prior = a_maxpri;
     h->count = count;
     return GF_OK;
 }
 
 int upload(gf_ba* h) {
     hipStream_t s = h->stream;
+    const Dims& d = h->d;
+    const size_t B = d.B, nv = (size_t)h->max_vis, no = (size_t)std::max(h->max_order, 1), np2 = (size_t)h->max_prior * h->max_prior;
     HIPCHK(h->xs0.up(s));
-    for (auto* b : {&h->colf, &h->cole, &h->nvis, &h->nimu, &h->nwh, &h->nfeat, &h->vis_feat, &h->vis_i, &h->vis_j, &h->order, &h->norder, &h->feat_ptr, &h->feat_fac, &h->vis_pos,
-                    &h->imu_i, &h->wh_i, &h->pri_n, &h->pri_nb, &h->pri_bid})
+    for (auto* b : {&h->colf, &h->cole, &h->nvis, &h->nimu, &h->nwh, &h->nfeat, &h->norder, &h->feat_ptr, &h->imu_i, &h->wh_i, &h->pri_n, &h->pri_nb, &h->pri_bid})
         HIPCHK(b->up(s));
-    for (auto* b : {&h->vis_data, &h->imu_data, &h->wh_data, &h->pri_J, &h->pri_r, &h->pri_x0, &h->wpar}) HIPCHK(b->up(s));
+    // per-window tables are laid out for the handle's capacity; only what this batch fills is copied
+    for (auto* b : {&h->vis_feat, &h->vis_i, &h->vis_j, &h->feat_fac, &h->vis_pos}) HIPCHK(b->up2d(s, B, d.NV, nv));
+    HIPCHK(h->order.up2d(s, B, d.NVP, no));
+    HIPCHK(h->vis_data.up2d(s, B, (size_t)d.NV * 12, nv * 12));
+    HIPCHK(h->pri_J.up2d(s, B, (size_t)d.NPRI * d.NPRI, np2));
+    for (auto* b : {&h->imu_data, &h->wh_data, &h->pri_r, &h->pri_x0, &h->wpar}) HIPCHK(b->up(s));
     if (h->d.GO) { HIPCHK(h->ngnss.up(s)); HIPCHK(h->gn_idx.up(s)); HIPCHK(h->gn_data.up(s)); HIPCHK(h->gn_misc.up(s)); HIPCHK(h->gn_gptr.up(s)); HIPCHK(h->gn_gitem.up(s)); }
-    for (int m = 0; m < 2; m++) for (auto* b : {&h->mcolf[m], &h->mcole[m], &h->morder[m], &h->mnorder[m], &h->minfo[m]}) HIPCHK(b->up(s));
+    for (int m = 0; m < 2; m++) {
+        for (auto* b : {&h->mcolf[m], &h->mcole[m], &h->mnorder[m], &h->minfo[m]}) HIPCHK(b->up(s));
+        HIPCHK(h->morder[m].up2d(s, B, d.NVP, no));
+    }
     HIPCHK(hipMemcpyAsync(h->st0.d, h->st0.h, h->st0.n * sizeof(SolverState), hipMemcpyHostToDevice, s));
     ba_setup<<<dim3(h->d.B), 256, 0, s>>>(h->win());
     HIPCHK(hipGetLastError());
@@ -525,6 +573,8 @@ int gf_ba_upload(gf_ba* h, const gf_ba_window* windows, int count) {
     if (!h || !windows) return gf::set_err(GF_ERR_INVALID, "null argument");
     if (int rc = gf_ba_wait(h)) return rc;
     if (int rc = pack_windows(h, windows, count)) return rc;
+    h->resident.assign(count, nullptr);
+    for (int b = 0; b < count; b++) h->resident[b] = windows + b;
     HIPCHK(hipEventRecord(h->ev[0], h->stream));
     if (int rc = upload(h)) return rc;
     HIPCHK(hipEventRecord(h->ev[1], h->stream));
@@ -641,6 +691,70 @@ int gf_ba_marginalize(gf_ba* h, const gf_ba_window* windows, int count, int mode
     if (int rc = gf_ba_upload(h, windows, count)) return rc;
     if (int rc = gf_ba_solve_resident(h, 0, mode, 1)) return rc;
     return gf_ba_download(h, nullptr, count, nullptr, priors);
+}
+
+// MARGIN_OLD / MARGIN_SECOND_NEW on windows that are already resident (the preceding gf_ba_solve / gf_ba_upload of the same structures): only
+// the parameter blocks are packed and uploaded again -- Estimator::optimization() runs double2vector (the gauge fix) and vector2double between
+// ceres::Solve and the marginalisation (estimator.cpp:3327, :3337), so the states differ from what the solve left on the device, the factors do
+// not.  slots[i] = position of windows[i] in the resident batch.  Slots not listed are marginalised too (the kernels run on the whole batch);
+// their results are not fetched.
+int gf_ba_marginalize_resident(gf_ba* h, const int* slots, const gf_ba_window* windows, int n, int mode, gf_ba_prior* priors) {
+    if (!h || !slots || !windows || !priors || n < 1 || mode < 0 || mode > 1) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    if (int rc = gf_ba_wait(h)) return rc;
+    const Dims& d = h->d;
+    for (int i = 0; i < n; i++) {
+        const int b = slots[i];
+        if (b < 0 || b >= h->count) return gf::set_err(GF_ERR_INVALID, "slot %d outside the %d resident windows", b, h->count);
+        const gf_ba_window& w = windows[i];
+        if (w.W != d.W || w.n_feature > d.F) return gf::set_err(GF_ERR_INVALID, "window %d does not match the resident structure", i);
+        double* x = h->xs0.h + (size_t)b * d.XS;
+        for (int k = 0; k < d.NP; k++) { memcpy(x + off_pose(k), w.para_Pose + 7 * k, 56); memcpy(x + off_sb(k), w.para_SpeedBias + 9 * k, 72); }
+        memcpy(x + off_ex(d.NP), w.para_Ex_Pose, 56); memcpy(x + off_exw(d.NP), w.para_Ex_Pose_wheel, 56); memcpy(x + off_ix(d.NP), w.para_Ix, 24);
+        x[off_td(d.NP)] = w.para_Td[0]; x[off_tdw(d.NP)] = w.para_Td_wheel[0];
+        for (int f = 0; f < w.n_feature; f++) x[off_feat(d.NP) + f] = w.para_Feature[f];
+        if (d.GO && w.gnss_enabled) { memcpy(x + d.GO, w.para_rcv_dt, 4 * d.NP * 8); memcpy(x + d.GO + 4 * d.NP, w.para_rcv_ddt, d.NP * 8); x[d.GO + 5 * d.NP] = w.para_yaw_enu_local[0]; memcpy(x + d.GO + 5 * d.NP + 1, w.para_anc_ecef, 24); }
+        if (w.fix_poses) for (int k = 0; k < d.NP; k++) x[off_sb(k)] = x[off_sb(k) + 1] = x[off_sb(k) + 2] = 0.0;
+    }
+    HIPCHK(h->xs0.up(h->stream));
+    if (int rc = gf_ba_solve_resident(h, 0, mode, 1)) return rc;
+    // priors of the listed slots: n x n of J, n of r (the rest of the capacity-sized slots stays on the device)
+    const int* inf0 = h->minfo[mode].h;
+    int nmax = 0;
+    for (int i = 0; i < n; i++) if (inf0[(size_t)slots[i] * 4 + 3]) nmax = std::max(nmax, inf0[(size_t)slots[i] * 4 + 2]);
+    if (nmax > 0) {
+        HIPCHK(hipMemcpy2DAsync(h->outJ.h, (size_t)d.NPRI * d.NPRI * 8, h->outJ.d, (size_t)d.NPRI * d.NPRI * 8, (size_t)nmax * nmax * 8, h->count, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpy2DAsync(h->outr.h, (size_t)d.NPRI * 8, h->outr.d, (size_t)d.NPRI * 8, (size_t)nmax * 8, h->count, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; i++) {
+        const int b = slots[i];
+        gf_ba_prior& p = priors[i];
+        const int* inf = inf0 + (size_t)b * 4;
+        p.valid = inf[3]; p.m = inf[0] + inf[1]; p.n = 0; p.nblocks = 0;
+        if (!inf[3]) continue;
+        const int nn = inf[2];
+        const std::vector<int>& keep = h->keep_ids[mode][b];
+        if (nn > p.cap_n || (int)keep.size() > p.cap_blocks) return gf::set_err(GF_ERR_CAPACITY, "prior capacity too small (n=%d, blocks=%zu)", nn, keep.size());
+        p.n = nn; p.nblocks = (int)keep.size();
+        memcpy(p.J, h->outJ.h + (size_t)b * d.NPRI * d.NPRI, (size_t)nn * nn * sizeof(double));
+        memcpy(p.r, h->outr.h + (size_t)b * d.NPRI, (size_t)nn * sizeof(double));
+        const double* x = h->xs0.h + (size_t)b * d.XS;   // the linearisation point of the prior = the states just uploaded
+        int xo = 0;
+        for (size_t q = 0; q < keep.size(); q++) {
+            const int id = keep[q], kind = id / 4096, k = id % 4096;
+            int nid = id;  // addr_shift (estimator.cpp:3471-3500 / :3583-3626)
+            if (kind == GF_POSE || kind == GF_SPEEDBIAS || kind == GF_RCV_DDT) nid = mode == 0 ? kind * 4096 + k - 1 : (k == d.W ? kind * 4096 + d.W - 1 : id);
+            else if (kind == GF_RCV_DT) nid = mode == 0 ? id - 4 : (k / 4 == d.W ? id - 4 : id);
+            p.block_id[q] = nid;
+            int off;
+            switch (kind) { case 0: off = off_pose(k); break; case 1: off = off_sb(k); break; case 2: off = off_ex(d.NP); break; case 3: off = off_exw(d.NP); break;
+                            case 4: off = off_ix(d.NP); break; case 5: off = off_ix(d.NP) + 1; break; case 6: off = off_ix(d.NP) + 2; break; case 7: off = off_td(d.NP); break;
+                            case 10: off = d.GO + k; break; case 11: off = d.GO + 4 * d.NP + k; break; case 12: off = d.GO + 5 * d.NP; break; case 13: off = d.GO + 5 * d.NP + 1; break;
+                            default: off = off_tdw(d.NP); }
+            for (int c = 0; c < gsize_kind(kind); c++) p.x0[xo++] = x[off + c];
+        }
+    }
+    return GF_OK;
 }
 
 int gf_ba_linearize(gf_ba* h, const gf_ba_window* w, int cap, double* Hout, double* gout, double* cost, int* n_f, int* n_e, int* col_block_id) {

@@ -16,9 +16,13 @@
 // Unsupported switches are rejected at create time: ESTIMATE_EXTRINSIC==2, USE_LINE, USE_PLANE, USE_MOTION, GNSS_ENABLE, STEREO, !USE_IMU.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstring>
+#include <ctime>
 #include <deque>
 #include <list>
 #include <map>
@@ -31,6 +35,7 @@
 
 #include "../../include/groundfusion_hip.h"
 #include "gf_dmath.hpp"
+#include "gf_preint.hpp"
 
 namespace gf { int set_err(int code, const char* fmt, ...); }
 using namespace gfd;
@@ -269,16 +274,21 @@ struct ImuPre {  // integration_base.h:22-62: linearized_acc/gyr, linearized_ba/
     std::vector<double> dt, acc, gyr;
     double sum_dt = 0, delta_p[3] = {0, 0, 0}, delta_q[4] = {1, 0, 0, 0}, delta_v[3] = {0, 0, 0};
     std::vector<double> jacobian, covariance;
-    bool dirty = true;
+    bool dirty = true, restart = true;
+    gf::ImuPreState st;   // state after st.n_done samples: appended samples are integrated on top (same operations as starting over)
     ImuPre(V3 a0, V3 g0, V3 ba, V3 bg) : acc0(a0), gyr0(g0), lin_ba(ba), lin_bg(bg), jacobian(225), covariance(225) {}
     void push_back(double t, V3 a, V3 g) { dt.push_back(t); acc.insert(acc.end(), {a.x, a.y, a.z}); gyr.insert(gyr.end(), {g.x, g.y, g.z}); dirty = true; }
-    void repropagate(V3 ba, V3 bg) { lin_ba = ba; lin_bg = bg; dirty = true; }  // integration_base.h:51-62
+    void repropagate(V3 ba, V3 bg) { lin_ba = ba; lin_bg = bg; dirty = true; restart = true; }  // integration_base.h:51-62
     int eval(const double* noise) {
         if (!dirty) return GF_OK;
         const double a0[3] = {acc0.x, acc0.y, acc0.z}, g0[3] = {gyr0.x, gyr0.y, gyr0.z}, ba[3] = {lin_ba.x, lin_ba.y, lin_ba.z}, bg[3] = {lin_bg.x, lin_bg.y, lin_bg.z};
-        const int rc = gf_imu_preintegrate((int)dt.size(), dt.data(), acc.data(), gyr.data(), a0, g0, ba, bg, noise, delta_p, delta_q, delta_v, jacobian.data(), covariance.data(), &sum_dt);
-        dirty = rc != GF_OK;
-        return rc;
+        if (restart || st.n_done > (int)dt.size()) { gf::imu_preint_reset(st, a0, g0); restart = false; }
+        gf::imu_preint_range(st, ba, bg, noise, dt.data(), acc.data(), gyr.data(), st.n_done, (int)dt.size());
+        memcpy(delta_p, st.dp, 24); memcpy(delta_q, st.dq, 32); memcpy(delta_v, st.dv, 24);
+        memcpy(jacobian.data(), st.J, 225 * 8); memcpy(covariance.data(), st.P, 225 * 8);
+        sum_dt = st.sum_dt;
+        dirty = false;
+        return GF_OK;
     }
 };
 struct WheelPre {  // wheel_integration_base.h:23-60
@@ -321,6 +331,8 @@ struct BatchSolver {
     int active = 0;                 // members currently inside a frame of a group step
     std::vector<Req*> pending;
     long long batches = 0, windows = 0, largest = 0;
+    std::vector<gf_ba_window*> resident;   // the members' windows behind the slots of the last solve (their marginalisations reuse the device copy)
+    double t_solve = 0, t_marg = 0;        // wall time inside the batched calls [s] (GF_GROUP_TIMING=1 prints them when the group is destroyed)
 
     int submit(Req& r) {
         std::unique_lock<std::mutex> lk(m);
@@ -344,16 +356,28 @@ struct BatchSolver {
             std::vector<gf_ba_window> wins(grp.size());
             for (size_t i = 0; i < grp.size(); i++) wins[i] = *grp[i]->w;
             int rc;
+            const auto tc0 = std::chrono::steady_clock::now();
             if (pass == 0) {
                 std::vector<gf_ba_summary> sums(grp.size());
                 rc = gf_ba_solve(ba, wins.data(), (int)grp.size(), grp[0]->iters, sums.data());
                 for (size_t i = 0; i < grp.size(); i++) if (rc == GF_OK) *grp[i]->sum = sums[i];
+                resident.clear();
+                if (rc == GF_OK) for (Req* r : grp) resident.push_back(r->w);
             } else {
                 std::vector<gf_ba_prior> pri(grp.size());
                 for (size_t i = 0; i < grp.size(); i++) pri[i] = *grp[i]->prior;
-                rc = gf_ba_marginalize(ba, wins.data(), (int)grp.size(), pass - 1, pri.data());
+                // the windows of this step's solve are still on the device: only their states (double2vector's gauge fix sits in between) go up again
+                std::vector<int> slots(grp.size(), -1);
+                bool all = !resident.empty();
+                for (size_t i = 0; i < grp.size() && all; i++) {
+                    const auto it = std::find(resident.begin(), resident.end(), grp[i]->w);
+                    if (it == resident.end()) all = false; else slots[i] = (int)(it - resident.begin());
+                }
+                if (all) rc = gf_ba_marginalize_resident(ba, slots.data(), wins.data(), (int)grp.size(), pass - 1, pri.data());
+                else { rc = gf_ba_marginalize(ba, wins.data(), (int)grp.size(), pass - 1, pri.data()); resident.clear(); }
                 for (size_t i = 0; i < grp.size(); i++) if (rc == GF_OK) *grp[i]->prior = pri[i];
             }
+            (pass == 0 ? t_solve : t_marg) += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
             const std::string err = rc == GF_OK ? std::string() : std::string(gf_last_error());
             for (Req* r : grp) { r->rc = rc; r->err = err; r->done = true; }
             batches++; windows += (long long)grp.size(); largest = std::max(largest, (long long)grp.size());
@@ -403,7 +427,22 @@ struct gf_estimator {
     std::vector<int> prior_block_id; std::vector<double> prior_J, prior_r, prior_x0;
     // feedback to the tracker (EST:1132-1136)
     std::vector<int> predict_ids, remove_ids; std::vector<double> predict_xyz;
+    struct WinScratch {
+        std::vector<int> imu_i, wh_i, vf, vi, vj;
+        std::vector<double> imu_sum_dt, imu_dp, imu_dq, imu_dv, imu_ba, imu_bg, imu_J, imu_P, wh_sum_dt, wh_dp, wh_dq, wh_J, wh_P, wh_lin, wh_lv, wh_lg, wh_v1, wh_g1, vpi, vpj, vvi, vvj, vti, vtj;
+        std::vector<unsigned char> fixed;
+        void clear() {
+            for (auto* v : {&imu_i, &wh_i, &vf, &vi, &vj}) v->clear();
+            for (auto* v : {&imu_sum_dt, &imu_dp, &imu_dq, &imu_dv, &imu_ba, &imu_bg, &imu_J, &imu_P, &wh_sum_dt, &wh_dp, &wh_dq, &wh_J, &wh_P, &wh_lin, &wh_lv, &wh_lg, &wh_v1, &wh_g1, &vpi, &vpj, &vvi, &vvj, &vti, &vtj}) v->clear();
+            fixed.clear();
+        }
+    } scratch;
     gf_ba_summary last_summary{};
+    std::vector<double> marg_J, marg_r, marg_x0; std::vector<int> marg_id;   // receive buffers of gf_ba_marginalize
+    double t_sect[6] = {0, 0, 0, 0, 0, 0};   // host wall time [s]: before optimization(), window build, waiting for the solve, between solve and marginalisation, waiting for it, after
+    double t_mark = 0;   // CPU time of the member's thread (not wall: the members of a group share the host's cores)
+    static double cpu_now() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+    void lap(int i) { const double n = cpu_now(); t_sect[i] += n - t_mark; t_mark = n; }
     long long n_optimizations = 0;
     double imu_noise[4], wheel_noise[2];
     std::string err;
@@ -737,6 +776,7 @@ struct gf_estimator {
             gf_ba_cfg bc{WINDOW_SIZE, cfg.max_features, cfg.max_visual, 1, 0};   // no GNSS front matter in this handle
             if (int rc = gf_ba_create(&bc, &ba)) return rc;
         }
+        lap(0);
         vector2double();
         gf_ba_window w;
         memset(&w, 0, sizeof(w));
@@ -751,8 +791,10 @@ struct gf_estimator {
         w.fix_td = (!cfg.estimate_td || norm(Vs[0]) < 0.2) ? 1 : 0;                                                                                      // :3097-3100
         w.fix_td_wheel = (!cfg.estimate_td_wheel || norm(Vs[0]) < 0.2) ? 1 : 0;
         // IMU factors :3109-3119
-        std::vector<int> imu_i, wh_i;
-        std::vector<double> imu_sum_dt, imu_dp, imu_dq, imu_dv, imu_ba, imu_bg, imu_J, imu_P;
+        // the window's tables live in vectors of the estimator that keep their capacity from frame to frame (no allocation in the steady state)
+        WinScratch& S_ = scratch; S_.clear();
+        std::vector<int>&imu_i = S_.imu_i, &wh_i = S_.wh_i;
+        std::vector<double>&imu_sum_dt = S_.imu_sum_dt, &imu_dp = S_.imu_dp, &imu_dq = S_.imu_dq, &imu_dv = S_.imu_dv, &imu_ba = S_.imu_ba, &imu_bg = S_.imu_bg, &imu_J = S_.imu_J, &imu_P = S_.imu_P;
         for (int i = 0; i < frame_count; i++) {
             ImuPre& p = *pre_integrations[i + 1];
             if (int rc = p.eval(imu_noise)) return rc;
@@ -763,7 +805,7 @@ struct gf_estimator {
             imu_J.insert(imu_J.end(), p.jacobian.begin(), p.jacobian.end()); imu_P.insert(imu_P.end(), p.covariance.begin(), p.covariance.end());
         }
         // wheel factors :3120-3151
-        std::vector<double> wh_sum_dt, wh_dp, wh_dq, wh_J, wh_P, wh_lin, wh_lv, wh_lg, wh_v1, wh_g1;
+        std::vector<double>&wh_sum_dt = S_.wh_sum_dt, &wh_dp = S_.wh_dp, &wh_dq = S_.wh_dq, &wh_J = S_.wh_J, &wh_P = S_.wh_P, &wh_lin = S_.wh_lin, &wh_lv = S_.wh_lv, &wh_lg = S_.wh_lg, &wh_v1 = S_.wh_v1, &wh_g1 = S_.wh_g1;
         if (wheel_on)
             for (int i = 0; i < frame_count; i++) {
                 WheelPre& p = *pre_integrations_wheel[i + 1];
@@ -783,7 +825,7 @@ struct gf_estimator {
             w.fix_poses = 1;
         }
         // visual factors :3262-3297
-        std::vector<int> vf, vi, vj; std::vector<double> vpi, vpj, vvi, vvj, vti, vtj; std::vector<unsigned char> fixed;
+        std::vector<int>&vf = S_.vf, &vi = S_.vi, &vj = S_.vj; std::vector<double>&vpi = S_.vpi, &vpj = S_.vpj, &vvi = S_.vvi, &vvj = S_.vvj, &vti = S_.vti, &vtj = S_.vtj; std::vector<unsigned char>& fixed = S_.fixed;
         int feature_index = -1;
         for (auto& it : f_manager.feature) {
             it.used_num = (int)it.feature_per_frame.size();
@@ -814,10 +856,12 @@ struct gf_estimator {
         w.wh_i = wh_i.data(); w.wh_sum_dt = wh_sum_dt.data(); w.wh_delta_p = wh_dp.data(); w.wh_delta_q = wh_dq.data(); w.wh_jacobian = wh_J.data(); w.wh_covariance = wh_P.data();
         w.wh_lin = wh_lin.data(); w.wh_lin_vel = wh_lv.data(); w.wh_lin_gyr = wh_lg.data(); w.wh_vel_1 = wh_v1.data(); w.wh_gyr_1 = wh_g1.data();
         if (prior_valid) { w.prior_n = prior_n; w.prior_nblocks = (int)prior_block_id.size(); w.prior_block_id = prior_block_id.data(); w.prior_J = prior_J.data(); w.prior_r = prior_r.data(); w.prior_x0 = prior_x0.data(); }
+        lap(1);
         if (group) {   // ceres::Solve, EST:3303-3318
             BatchSolver::Req rq{0, &w, cfg.num_iterations, 0, &last_summary, nullptr, GF_OK, false, std::string()};
             if (int rc = group->submit(rq)) return rc;
         } else if (int rc = gf_ba_solve(ba, &w, 1, cfg.num_iterations, &last_summary)) return rc;
+        lap(2);
         n_optimizations++;
         if (int rc = double2vector()) return rc;                                            // :3327
         if (frame_count < WINDOW_SIZE) { wheelanomaly = false; return GF_OK; }
@@ -830,13 +874,17 @@ struct gf_estimator {
             vector2double();                                                                // :3337 / :3543
             if (systemstationary && cfg.stationary_detect) { /* para_SpeedBias already refreshed from Vs by vector2double */ }
             const int cap_n = 16 * (WINDOW_SIZE + 1) + 64, cap_b = 2 * (WINDOW_SIZE + 1) + 16;
-            std::vector<double> pJ((size_t)cap_n * cap_n), pr(cap_n), px0(16 * (WINDOW_SIZE + 1) + 64); std::vector<int> pid(cap_b);
+            // receive buffers of the prior: members of the estimator, sized once (half a megabyte of zero-filled std::vector per frame and sequence otherwise)
+            if (marg_J.size() != (size_t)cap_n * cap_n) { marg_J.assign((size_t)cap_n * cap_n, 0.0); marg_r.assign(cap_n, 0.0); marg_x0.assign(16 * (WINDOW_SIZE + 1) + 64, 0.0); marg_id.assign(cap_b, 0); }
+            std::vector<double>&pJ = marg_J, &pr = marg_r, &px0 = marg_x0; std::vector<int>& pid = marg_id;
             gf_ba_prior p{};
             p.cap_n = cap_n; p.cap_blocks = cap_b; p.block_id = pid.data(); p.J = pJ.data(); p.r = pr.data(); p.x0 = px0.data();
+            lap(3);
             if (group) {
                 BatchSolver::Req rq{1, &w, 0, marginalization_flag, nullptr, &p, GF_OK, false, std::string()};
                 if (int rc = group->submit(rq)) return rc;
             } else if (int rc = gf_ba_marginalize(ba, &w, 1, marginalization_flag, &p)) return rc;
+            lap(4);
             prior_valid = p.valid != 0;
             if (p.valid) {
                 prior_n = p.n;
@@ -1150,6 +1198,7 @@ struct gf_estimator_group {
     std::mutex m;
     std::condition_variable cv_go, cv_done;
     long long gen = 0;
+    double t_input = 0;   // wall time inside gf_estimator_group_input_features [s]
     int remaining = 0;
     bool stop = false;
     std::vector<char> has;
@@ -1170,7 +1219,9 @@ struct gf_estimator_group {
                 seen = gen; mine = has[i] != 0;
             }
             if (!mine) continue;
+            mem[i]->t_mark = gf_estimator::cpu_now();
             const int rc = gf_estimator_input_feature(mem[i], t[i], frames[i].data(), (int)frames[i].size());
+            mem[i]->lap(5);
             rcs[i] = rc;
             if (rc != GF_OK) errs[i] = gf_last_error();
             solver.leave();
@@ -1205,7 +1256,19 @@ int gf_estimator_group_create(const gf_estimator_cfg* c, int n, gf_estimator_gro
     *out = g;
     return GF_OK;
 }
-int gf_estimator_group_destroy(gf_estimator_group* g) { delete g; return GF_OK; }
+int gf_estimator_group_destroy(gf_estimator_group* g) {
+    if (g && getenv("GF_GROUP_TIMING")) {
+        double ts[6] = {0, 0, 0, 0, 0, 0};
+        for (gf_estimator* e : g->mem) for (int q = 0; q < 6; q++) ts[q] += e->t_sect[q];
+        fprintf(stderr, "gf_estimator_group members, CPU time summed over %zu threads [ms]: before optimization %.1f, window build %.1f, waiting for the solve %.1f, double2vector .. marginalisation request %.1f, "
+                        "waiting for the marginalisation %.1f, rest of the frame %.1f\n", g->mem.size(), 1e3 * ts[0], 1e3 * ts[1], 1e3 * ts[2], 1e3 * ts[3], 1e3 * ts[4], 1e3 * ts[5]);
+    }
+    if (g && getenv("GF_GROUP_TIMING"))
+        fprintf(stderr, "gf_estimator_group: %lld batches, %lld windows; %.1f ms inside batched solves, %.1f ms inside batched marginalisations, %.1f ms inside input_features\n",
+                g->solver.batches, g->solver.windows, 1e3 * g->solver.t_solve, 1e3 * g->solver.t_marg, 1e3 * g->t_input);
+    delete g;
+    return GF_OK;
+}
 int gf_estimator_group_member(gf_estimator_group* g, int i, gf_estimator** out) {
     if (!g || !out || i < 0 || i >= (int)g->mem.size()) return gf::set_err(GF_ERR_INVALID, "bad argument");
     *out = g->mem[i];
@@ -1214,6 +1277,7 @@ int gf_estimator_group_member(gf_estimator_group* g, int i, gf_estimator** out) 
 int gf_estimator_group_input_features(gf_estimator_group* g, int count, const int* seq, const double* t, const gf_feature_obs* obs, const int* n_obs) {
     if (!g || count < 0 || (count > 0 && (!seq || !t || !n_obs))) return gf::set_err(GF_ERR_INVALID, "bad argument");
     if (count == 0) return GF_OK;
+    const auto tc0 = std::chrono::steady_clock::now();
     const int n = (int)g->mem.size();
     std::vector<char> seen(n, 0);
     size_t off = 0;
@@ -1236,6 +1300,7 @@ int gf_estimator_group_input_features(gf_estimator_group* g, int count, const in
         std::unique_lock<std::mutex> lk(g->m);
         g->cv_done.wait(lk, [&] { return g->remaining == 0; });
     }
+    g->t_input += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
     for (int k = 0; k < count; k++) if (g->rcs[seq[k]] != GF_OK) return gf::set_err(g->rcs[seq[k]], "sequence %d: %s", seq[k], g->errs[seq[k]].c_str());
     return GF_OK;
 }

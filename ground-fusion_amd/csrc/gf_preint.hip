@@ -5,21 +5,22 @@
 #include <vector>
 #include "../../include/groundfusion_hip.h"
 #include "gf_dmath.hpp"
+#include "gf_preint.hpp"
 
 namespace gf { int set_err(int code, const char* fmt, ...); }
 using namespace gfd;
 
 namespace {
-struct DM {  // tiny dense row-major matrix
-    int r, c; std::vector<double> a;
-    DM(int r_, int c_) : r(r_), c(c_), a((size_t)r_ * c_, 0.0) {}
-    double& operator()(int i, int j) { return a[(size_t)i * c + j]; }
-    double operator()(int i, int j) const { return a[(size_t)i * c + j]; }
+template <int R, int C> struct DM {  // tiny dense row-major matrix on the stack (the estimator group calls this from hundreds of host threads: no heap traffic)
+    double a[R * C];
+    DM() { for (int i = 0; i < R * C; i++) a[i] = 0.0; }
+    double& operator()(int i, int j) { return a[i * C + j]; }
+    double operator()(int i, int j) const { return a[i * C + j]; }
     void set3(int r0, int c0, const M3& m) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) (*this)(r0 + i, c0 + j) = m.m[3 * i + j]; }
 };
-DM mul(const DM& x, const DM& y) { DM o(x.r, y.c); for (int i = 0; i < x.r; i++) for (int k = 0; k < x.c; k++) { const double v = x(i, k); if (v != 0.0) for (int j = 0; j < y.c; j++) o(i, j) += v * y(k, j); } return o; }
-DM tr(const DM& x) { DM o(x.c, x.r); for (int i = 0; i < x.r; i++) for (int j = 0; j < x.c; j++) o(j, i) = x(i, j); return o; }
-DM add(const DM& x, const DM& y) { DM o(x.r, x.c); for (size_t i = 0; i < o.a.size(); i++) o.a[i] = x.a[i] + y.a[i]; return o; }
+template <int R, int K, int C> DM<R, C> mul(const DM<R, K>& x, const DM<K, C>& y) { DM<R, C> o; for (int i = 0; i < R; i++) for (int k = 0; k < K; k++) { const double v = x(i, k); if (v != 0.0) for (int j = 0; j < C; j++) o(i, j) += v * y(k, j); } return o; }
+template <int R, int C> DM<C, R> tr(const DM<R, C>& x) { DM<C, R> o; for (int i = 0; i < R; i++) for (int j = 0; j < C; j++) o(j, i) = x(i, j); return o; }
+template <int R, int C> DM<R, C> add(const DM<R, C>& x, const DM<R, C>& y) { DM<R, C> o; for (int i = 0; i < R * C; i++) o.a[i] = x.a[i] + y.a[i]; return o; }
 V3 arr(const double* p) { return v3(p[0], p[1], p[2]); }
 }  // namespace
 
@@ -70,19 +71,28 @@ int gf_ba_double2vector(int W, const double* R0_before, const double* P0_before,
     return GF_OK;
 }
 
-int gf_imu_preintegrate(int n, const double* dt, const double* acc, const double* gyr, const double* acc0, const double* gyr0, const double* ba, const double* bg,
-                        const double* noise, double* delta_p, double* delta_q, double* delta_v, double* jacobian, double* covariance, double* sum_dt) {
-    if (n < 0 || !acc0 || !gyr0 || !ba || !bg || !noise) return gf::set_err(GF_ERR_INVALID, "bad argument");
-    V3 acc_0 = arr(acc0), gyr_0 = arr(gyr0), lba = arr(ba), lbg = arr(bg), dp = v3(0, 0, 0), dv = v3(0, 0, 0);
-    Q4 dq{1, 0, 0, 0};
-    DM J(15, 15), P(15, 15), N(18, 18);
-    for (int i = 0; i < 15; i++) J(i, i) = 1;
+}  // extern "C"
+
+namespace gf {
+// IntegrationBase::push_back for samples [s0, s1) on top of the running state `st` (the estimator appends samples to an interval frame after
+// frame; integrating only the new ones is the same sequence of operations as starting over, bit for bit)
+void imu_preint_reset(ImuPreState& st, const double* acc0, const double* gyr0) {
+    memset(&st, 0, sizeof st);
+    for (int i = 0; i < 3; i++) { st.acc_0[i] = acc0[i]; st.gyr_0[i] = gyr0[i]; }
+    st.dq[0] = 1;
+    for (int i = 0; i < 15; i++) st.J[i * 15 + i] = 1;
+}
+void imu_preint_range(ImuPreState& st, const double* ba, const double* bg, const double* noise, const double* dt, const double* acc, const double* gyr, int s0, int s1) {
+    V3 acc_0 = arr(st.acc_0), gyr_0 = arr(st.gyr_0), lba = arr(ba), lbg = arr(bg), dp = arr(st.dp), dv = arr(st.dv);
+    Q4 dq{st.dq[0], st.dq[1], st.dq[2], st.dq[3]};
+    DM<15, 15> J, P; DM<18, 18> N;
+    memcpy(J.a, st.J, sizeof J.a); memcpy(P.a, st.P, sizeof P.a);
     for (int i = 0; i < 3; i++) {
         N(i, i) = noise[0] * noise[0]; N(3 + i, 3 + i) = noise[1] * noise[1]; N(6 + i, 6 + i) = noise[0] * noise[0]; N(9 + i, 9 + i) = noise[1] * noise[1];
         N(12 + i, 12 + i) = noise[2] * noise[2]; N(15 + i, 15 + i) = noise[3] * noise[3];
     }
-    double sdt = 0;
-    for (int s = 0; s < n; s++) {
+    double sdt = st.sum_dt;
+    for (int s = s0; s < s1; s++) {
         const double t = dt[s];
         const V3 acc_1 = arr(acc + 3 * s), gyr_1 = arr(gyr + 3 * s);
         const V3 un_acc_0 = qrot(dq, acc_0 - lba);
@@ -92,7 +102,7 @@ int gf_imu_preintegrate(int n, const double* dt, const double* acc, const double
         const V3 un_acc = (un_acc_0 + un_acc_1) * 0.5;
         const V3 rp = dp + dv * t + un_acc * (0.5 * t * t), rv = dv + un_acc * t;
         const M3 Rwx = skew(un_gyr), Ra0 = skew(acc_0 - lba), Ra1 = skew(acc_1 - lba), Rd = qmat(dq), Rr = qmat(rq), I = m3_identity();
-        DM F(15, 15), V(15, 18);
+        DM<15, 15> F; DM<15, 18> V;
         F.set3(0, 0, I);
         F.set3(0, 3, Rd * Ra0 * (-0.25 * t * t) + Rr * Ra1 * (I - Rwx * t) * (-0.25 * t * t));
         F.set3(0, 6, I * t);
@@ -118,10 +128,24 @@ int gf_imu_preintegrate(int n, const double* dt, const double* acc, const double
         dp = rp; dq = qnormalized(rq); dv = rv;
         sdt += t; acc_0 = acc_1; gyr_0 = gyr_1;
     }
-    delta_p[0] = dp.x; delta_p[1] = dp.y; delta_p[2] = dp.z; delta_v[0] = dv.x; delta_v[1] = dv.y; delta_v[2] = dv.z;
-    delta_q[0] = dq.w; delta_q[1] = dq.x; delta_q[2] = dq.y; delta_q[3] = dq.z;
-    memcpy(jacobian, J.a.data(), 225 * 8); memcpy(covariance, P.a.data(), 225 * 8);
-    *sum_dt = sdt;
+    st.dp[0] = dp.x; st.dp[1] = dp.y; st.dp[2] = dp.z; st.dv[0] = dv.x; st.dv[1] = dv.y; st.dv[2] = dv.z;
+    st.dq[0] = dq.w; st.dq[1] = dq.x; st.dq[2] = dq.y; st.dq[3] = dq.z;
+    st.acc_0[0] = acc_0.x; st.acc_0[1] = acc_0.y; st.acc_0[2] = acc_0.z; st.gyr_0[0] = gyr_0.x; st.gyr_0[1] = gyr_0.y; st.gyr_0[2] = gyr_0.z;
+    memcpy(st.J, J.a, sizeof J.a); memcpy(st.P, P.a, sizeof P.a);
+    st.sum_dt = sdt; st.n_done = s1;
+}
+}  // namespace gf
+
+extern "C" {
+int gf_imu_preintegrate(int n, const double* dt, const double* acc, const double* gyr, const double* acc0, const double* gyr0, const double* ba, const double* bg,
+                        const double* noise, double* delta_p, double* delta_q, double* delta_v, double* jacobian, double* covariance, double* sum_dt) {
+    if (n < 0 || !acc0 || !gyr0 || !ba || !bg || !noise) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    gf::ImuPreState st;
+    gf::imu_preint_reset(st, acc0, gyr0);
+    gf::imu_preint_range(st, ba, bg, noise, dt, acc, gyr, 0, n);
+    memcpy(delta_p, st.dp, 24); memcpy(delta_q, st.dq, 32); memcpy(delta_v, st.dv, 24);
+    memcpy(jacobian, st.J, 225 * 8); memcpy(covariance, st.P, 225 * 8);
+    *sum_dt = st.sum_dt;
     return GF_OK;
 }
 
@@ -131,7 +155,7 @@ int gf_wheel_preintegrate(int n, const double* dt, const double* vel, const doub
     V3 vel_0 = arr(vel0), gyr_0 = arr(gyr0), dp = v3(0, 0, 0);
     Q4 dq{1, 0, 0, 0};
     const double sx = lin[0], sy = lin[1], sw = lin[2];
-    DM Jm(6, 3), P(6, 6), N(12, 12);
+    DM<6, 3> Jm; DM<6, 6> P; DM<12, 12> N;
     for (int i = 0; i < 3; i++) { N(i, i) = noise[0] * noise[0]; N(3 + i, 3 + i) = noise[1] * noise[1]; N(6 + i, 6 + i) = noise[0] * noise[0]; N(9 + i, 9 + i) = noise[1] * noise[1]; }
     double sdt = 0;
     const M3 sv = m3_diag(sx, sy, 1), I = m3_identity(), I1 = m3_diag(1, 0, 0), I2 = m3_diag(0, 1, 0);
@@ -145,7 +169,7 @@ int gf_wheel_preintegrate(int n, const double* dt, const double* vel, const doub
         const V3 un_vel_1 = qrot(rq, sv * vel_1);
         const V3 rp = dp + (un_vel_0 + un_vel_1) * 0.5 * t;
         const M3 Rv0 = skew(sv * vel_0), Rv1 = skew(sv * vel_1), Rd = qmat(dq), Rr = qmat(rq), Rdd = qmat(ddq);
-        DM F(6, 6), V(6, 12);
+        DM<6, 6> F; DM<6, 12> V;
         F.set3(0, 0, I);
         F.set3(0, 3, (Rd * Rv0 + Rr * Rv1 * transpose(Rdd)) * (-0.5 * t));
         F.set3(3, 3, transpose(Rdd));
@@ -171,7 +195,7 @@ int gf_wheel_preintegrate(int n, const double* dt, const double* vel, const doub
     }
     delta_p[0] = dp.x; delta_p[1] = dp.y; delta_p[2] = dp.z;
     delta_q[0] = dq.w; delta_q[1] = dq.x; delta_q[2] = dq.y; delta_q[3] = dq.z;
-    memcpy(jacobian, Jm.a.data(), 18 * 8); memcpy(covariance, P.a.data(), 36 * 8);
+    memcpy(jacobian, Jm.a, 18 * 8); memcpy(covariance, P.a, 36 * 8);
     *sum_dt = sdt;
     return GF_OK;
 }

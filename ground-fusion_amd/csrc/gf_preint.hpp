@@ -1,0 +1,11 @@
+// gf_preint.hpp -- running state of an IMU pre-integration (IntegrationBase, factor/integration_base.h:22-62) for the host code that appends samples
+// to an interval frame after frame (gf_estimator.hip): integrating only the new samples repeats exactly the operations of starting over.
+#pragma once
+namespace gf {
+struct ImuPreState {
+    double acc_0[3], gyr_0[3], dp[3], dq[4], dv[3], J[225], P[225], sum_dt;
+    int n_done;
+};
+void imu_preint_reset(ImuPreState& st, const double* acc0, const double* gyr0);
+void imu_preint_range(ImuPreState& st, const double* ba, const double* bg, const double* noise, const double* dt, const double* acc, const double* gyr, int s0, int s1);
+}  // namespace gf
