@@ -1285,6 +1285,9 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
         }
         __syncthreads();
         if (tid < ECW) { const int c = s_cmap[tid]; s_uc[tid] = (c >= 0 && c < R) ? u[c] : 0.0; }
+        // the passes below read the column scaling and the Cauchy direction once per matrix entry: LDS copies (s_hd and s_rd are free until the
+        // next call / the Cholesky)
+        for (int c = tid; c < R; c += 512) { s_hd[c] = scale[c]; s_rd[c] = u[c]; }
         double gsq = 0;
         for (int c = tid; c < R; c += 512) gsq += grad[c] * grad[c];
         for (int e = tid; e < NE; e += 512) gsq += grad[RP + e] * grad[RP + e];
@@ -1317,13 +1320,20 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
             {
                 constexpr int EN = GS ? 4 : 2;
                 for (int e0 = wave; e0 < NE4; e0 += 32) {
+                    double fe[4], ue[4], eb[4], etv[4][EN];
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {   // every load of the four rows is issued before the first store
+                        const int e = e0 + 8 * m;
+                        const bool live = e < NE;
+                        fe[m] = live ? u[RP + e] : 0.0; ue[m] = (live && need_alpha) ? gn[RP + e] : 0.0; eb[m] = live ? etb[e] : 0.0;
+                        const double* src = Et + (size_t)min(e, max(NE - 1, 0)) * ECW;
+#pragma unroll
+                        for (int q = 0; q < EN; q++) { const int k = lane + 64 * q; etv[m][q] = (live && k < ECW) ? src[k] : 0.0; }
+                    }
 #pragma unroll
                     for (int m = 0; m < 4; m++) {
                         const int e = e0 + 8 * m;
                         if (e >= NE4) continue;
-                        const bool live = e < NE;
-                        const double fe = live ? u[RP + e] : 0.0, ue = (live && need_alpha) ? gn[RP + e] : 0.0, eb = live ? etb[e] : 0.0;
-                        const double* src = Et + (size_t)e * ECW;
                         double* dst = Es + (size_t)e * ECW;
                         double dotv = 0.0;
 #pragma unroll
@@ -1332,51 +1342,59 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                             if (k < ECW) {
                                 const int c = s_cmap[k];
                                 double v = 0.0;
-                                if (live && c >= 0 && c < R) { const double etv = src[k]; v = fe * scale[c] * etv; dotv += etv * s_uc[k]; }
-                                else if (live && c == R) v = fe * eb;
+                                if (c >= 0 && c < R) { v = fe[m] * s_hd[c] * etv[m][q]; dotv += etv[m][q] * s_uc[k]; }
+                                else if (c == R) v = fe[m] * eb[m];
                                 dst[k] = v;
                             }
                         }
-                        uHu_acc += 2.0 * ue * dotv;
+                        uHu_acc += 2.0 * ue[m] * dotv;
                     }
                 }
             }
             GF_STAMP(6);
-            // reduced system in LDS (packed lower): S = s H s + mu D^2, row R = s g
+            // reduced system in LDS (packed lower): S = s (H + Vc) s + mu D^2, row R = s g.  First the H part, row by row ...
             for (int r0 = wave; r0 <= R; r0 += 32) {   // four rows per wavefront in flight: all loads first, then the arithmetic
-                double hv[4][QN], srv[4], urv[4];
+                double hv[4][QN];
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
                     const int r = r0 + 8 * m;
-                    srv[m] = r < R ? scale[r] : 0.0; urv[m] = r < R ? u[r] : 0.0;
                     const double* hr = H + (size_t)min(r, R - 1) * RP;
-                    const int kr = r < R ? s_rc[r] : -1;   // compact -> reduced is monotone: a lower-triangle entry (r, c) is the lower-triangle entry (kr, kc) of Vc
 #pragma unroll
-                    for (int q = 0; q < QN; q++) {
-                        const int c = lane + 64 * q;
-                        double v = 0.0;
-                        if (r < R && c <= r) { const int kc = s_rc[c]; v = hr[c] + ((kr >= 0 && kc >= 0) ? Vc[pk(kr, kc)] : 0.0); }
-                        else if (r == R && c < R) v = s_gt[c];   // row R: the right-hand side s g
-                        hv[m][q] = v;
-                    }
+                    for (int q = 0; q < QN; q++) { const int c = lane + 64 * q; hv[m][q] = (r < R && c <= r) ? hr[c] : 0.0; }
                 }
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
                     const int r = r0 + 8 * m;
                     if (r > R) continue;
                     const int base = pk(r, 0);
+                    const double sr = r < R ? s_hd[r] : 1.0, ur = r < R ? s_rd[r] : 0.0;
 #pragma unroll
                     for (int q = 0; q < QN; q++) {
                         const int c = lane + 64 * q;
                         if (r < R) {
                             if (c <= r) {
-                                double v = srv[m] * scale[c] * hv[m][q];
+                                double v = sr * s_hd[c] * hv[m][q];
                                 if (c == r) { const double lm = diag[r] * sqrt(mu); v += lm * lm; }
                                 S[base + c] = v;
-                                uHu_acc += (c == r ? 1.0 : 2.0) * hv[m][q] * uk[q] * urv[m];   // H holds its lower triangle
+                                uHu_acc += (c == r ? 1.0 : 2.0) * hv[m][q] * uk[q] * ur;   // H holds its lower triangle
                             }
-                        } else if (c < R) S[base + c] = scale[c] * hv[m][q];
+                        } else if (c < R) S[base + c] = s_hd[c] * s_gt[c];   // row R: the right-hand side s g (visual part included in s_gt)
                     }
+                }
+            }
+            __syncthreads();
+            // ... then the visual part, compact row by compact row: entry (ka >= kb) of Vc lands on its own entry (r >= c) of S
+            for (int ka = wave; ka < 6 * d.NP + 7; ka += 8) {
+                const int r = s_cmap[ka];
+                if (r < 0 || r >= R) continue;
+                const double* vrow = Vc + pk(ka, 0);
+                const double sr = s_hd[r], ur = s_rd[r];
+                for (int kb = lane; kb <= ka; kb += 64) {
+                    const int c = s_cmap[kb];
+                    if (c < 0) continue;
+                    const double v = vrow[kb];
+                    S[pk(r, c)] += sr * s_hd[c] * v;
+                    uHu_acc += (c == r ? 1.0 : 2.0) * v * ur * s_rd[c];
                 }
             }
             if (need_alpha) {
