@@ -1319,10 +1319,11 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
             // one wavefront per compact row, four rows in flight; lanes cover the ECW (<= 64 EN) columns
             {
                 constexpr int EN = GS ? 4 : 2;
-                for (int e0 = wave; e0 < NE4; e0 += 32) {
-                    double fe[4], ue[4], eb[4], etv[4][EN];
+                constexpr int ER = GS ? 4 : 8;   // rows per wavefront in flight
+                for (int e0 = wave; e0 < NE4; e0 += 8 * ER) {
+                    double fe[ER], ue[ER], eb[ER], etv[ER][EN];
 #pragma unroll
-                    for (int m = 0; m < 4; m++) {   // every load of the four rows is issued before the first store
+                    for (int m = 0; m < ER; m++) {   // every load of these rows is issued before the first store
                         const int e = e0 + 8 * m;
                         const bool live = e < NE;
                         fe[m] = live ? u[RP + e] : 0.0; ue[m] = (live && need_alpha) ? gn[RP + e] : 0.0; eb[m] = live ? etb[e] : 0.0;
@@ -1331,7 +1332,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                         for (int q = 0; q < EN; q++) { const int k = lane + 64 * q; etv[m][q] = (live && k < ECW) ? src[k] : 0.0; }
                     }
 #pragma unroll
-                    for (int m = 0; m < 4; m++) {
+                    for (int m = 0; m < ER; m++) {
                         const int e = e0 + 8 * m;
                         if (e >= NE4) continue;
                         double* dst = Es + (size_t)e * ECW;

@@ -24,6 +24,8 @@ void gfo_tracker_set_prediction(void* h, const int* ids, const double* xyz, int 
 void gfo_tracker_remove_outliers(void* h, const int* ids, int n);
 int gfo_tracker_state(void* h, int* ids, int* track_cnt, float* prev_pts, int cap);
 long long gfo_tracker_lk_iters(void* h);
+/* 0: int64 LK sums (parity mode); 1: float-lane accumulation of an x86 OpenCV build (sensitivity measurement only, see tracker_oracle.cpp) */
+void gfo_set_lk_accum(int mode);
 
 void gfo_pyr_down(const uint8_t* src, int w, int h, uint8_t* dst);
 void gfo_scharr(const uint8_t* src, int w, int h, int16_t* dst);

@@ -84,6 +84,11 @@ class Tracker:
         return int(lib().gfo_tracker_lk_iters(self.h))
 
 
+def set_lk_accum(mode):
+    """0: int64 sums (parity mode); 1: float-lane accumulation of an x86 OpenCV build (sensitivity measurement only)"""
+    lib().gfo_set_lk_accum(int(mode))
+
+
 def pyr_down(img):
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape

@@ -148,6 +148,13 @@ static const int W_BITS = 14;
 static const float FLT_SCALE = 1.f / (1 << 20);
 
 static inline float i64_to_f32(int64_t v) { return (float)(double)v; }  // |v| < 2^53: single rounding
+// Accumulation mode of the LK sums.  0 (the parity mode, what the HIP kernels implement): int64, exact.  1: the float accumulation of an x86
+// build of OpenCV 4.2 (`typedef float acctype`), in the manner of LKTrackerInvoker's SSE2 path as far as it can be restated without the source
+// at hand: structure tensor -- four float lanes over x (x = 0..19), products formed in float, scalar float tail for x = 20; mismatch vector --
+// int32 products converted to float and added into the lanes of two registers (pixels 0/4, 1/5 | 2/6, 3/7 of every group of eight, x = 0..15),
+// scalar float tail x = 16..20; lanes added horizontally at the end.  Mode 1 exists to MEASURE how much the documented int64 choice can
+// change feature ids / status flags / coordinates (tests/test_tracker_oracle.py); it does not pin anything.
+static int g_lk_accum = 0;
 
 // lkpyramid.cpp LKTrackerInvoker::operator() for one pyramid level, all points.
 static void lk_level(const Img8& I, const Deriv& dI, const Img8& J, const P2f* prevPts, P2f* nextPts,
@@ -177,6 +184,7 @@ static void lk_level(const Img8& I, const Deriv& dI, const Img8& J, const P2f* p
         int iw10 = cvRoundf((1.f - a) * b * (1 << W_BITS));
         int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
         int64_t iA11 = 0, iA12 = 0, iA22 = 0;
+        float qA11[4] = {0, 0, 0, 0}, qA12[4] = {0, 0, 0, 0}, qA22[4] = {0, 0, 0, 0}, fA11 = 0, fA12 = 0, fA22 = 0;
         for (int y = 0; y < win; y++) {
             const uint8_t* src = I.ptr(y + ipy) + ipx;
             const int16_t* dsrc = dI.ptr(y + ipy) + ipx * 2;
@@ -188,9 +196,18 @@ static void lk_level(const Img8& I, const Deriv& dI, const Img8& J, const P2f* p
                 int iyval = GF_DESCALE(dsrc[1] * iw00 + dsrc[3] * iw01 + dsrc[dstep + 1] * iw10 + dsrc[dstep + 3] * iw11, W_BITS);
                 Ip[x] = (int16_t)ival; dp[0] = (int16_t)ixval; dp[1] = (int16_t)iyval;
                 iA11 += (int64_t)(ixval * ixval); iA12 += (int64_t)(ixval * iyval); iA22 += (int64_t)(iyval * iyval);
+                if (g_lk_accum == 1) {
+                    const int16_t sx = (int16_t)ixval, sy = (int16_t)iyval;
+                    if (x < 20) { const float fx = (float)sx, fy = (float)sy; qA11[x & 3] += fx * fx; qA12[x & 3] += fx * fy; qA22[x & 3] += fy * fy; }
+                    else { fA11 += (float)(sx * sx); fA12 += (float)(sx * sy); fA22 += (float)(sy * sy); }
+                }
             }
         }
         float A11 = i64_to_f32(iA11) * FLT_SCALE, A12 = i64_to_f32(iA12) * FLT_SCALE, A22 = i64_to_f32(iA22) * FLT_SCALE;
+        if (g_lk_accum == 1) {
+            fA11 += qA11[0] + qA11[1] + qA11[2] + qA11[3]; fA12 += qA12[0] + qA12[1] + qA12[2] + qA12[3]; fA22 += qA22[0] + qA22[1] + qA22[2] + qA22[3];
+            A11 = fA11 * FLT_SCALE; A12 = fA12 * FLT_SCALE; A22 = fA22 * FLT_SCALE;
+        }
         float D = A11 * A22 - A12 * A12;
         float minEig = (A22 + A11 - std::sqrt((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * win * win);
         if (minEig < minEigThreshold || D < FLT_EPSILON) {
@@ -213,6 +230,7 @@ static void lk_level(const Img8& I, const Deriv& dI, const Img8& J, const P2f* p
             iw10 = cvRoundf((1.f - a) * b * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
             int64_t ib1 = 0, ib2 = 0;
+            float qb0[4] = {0, 0, 0, 0}, qb1[4] = {0, 0, 0, 0}, fb1 = 0, fb2 = 0;
             for (int y = 0; y < win; y++) {
                 const uint8_t* Jp = J.ptr(y + iny) + inx;
                 const int16_t* Ip = &Ibuf[y * win];
@@ -220,9 +238,19 @@ static void lk_level(const Img8& I, const Deriv& dI, const Img8& J, const P2f* p
                 for (int x = 0; x < win; x++, dp += 2) {
                     int diff = GF_DESCALE(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + stepJ] * iw10 + Jp[x + stepJ + 1] * iw11, W_BITS - 5) - Ip[x];
                     ib1 += (int64_t)(diff * dp[0]); ib2 += (int64_t)(diff * dp[1]);
+                    if (g_lk_accum == 1) {
+                        const int16_t sd = (int16_t)diff;
+                        if (x < 16) { float* q = (x & 2) ? qb1 : qb0; const int l = 2 * (x & 1); q[l] += (float)(sd * dp[0]); q[l + 1] += (float)(sd * dp[1]); }
+                        else { fb1 += (float)(sd * dp[0]); fb2 += (float)(sd * dp[1]); }
+                    }
                 }
             }
             float b1 = i64_to_f32(ib1) * FLT_SCALE, b2 = i64_to_f32(ib2) * FLT_SCALE;
+            if (g_lk_accum == 1) {
+                const float s0 = qb0[0] + qb1[0], s1 = qb0[1] + qb1[1], s2 = qb0[2] + qb1[2], s3 = qb0[3] + qb1[3];
+                fb1 += s0 + s2; fb2 += s1 + s3;
+                b1 = fb1 * FLT_SCALE; b2 = fb2 * FLT_SCALE;
+            }
             P2f delta = {(float)((A12 * b2 - A22 * b1) * D), (float)((A12 * b1 - A11 * b2) * D)};
             nextPt.x += delta.x; nextPt.y += delta.y;
             nextPts[p] = {nextPt.x + half, nextPt.y + half};
@@ -574,6 +602,7 @@ int gfo_tracker_state(void* h, int* ids, int* track_cnt, float* prev_pts, int ca
     return n;
 }
 long long gfo_tracker_lk_iters(void* h) { return ((Tracker*)h)->lk_iters; }
+void gfo_set_lk_accum(int mode) { g_lk_accum = mode; }
 
 void gfo_pyr_down(const uint8_t* src, int w, int h, uint8_t* dst) {
     Img8 s, d; s.create(h, w, 0);

@@ -135,3 +135,17 @@ def test_no_cpu_fallback_without_gpu():
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("tracker creation must fail loudly without a HIP device")
+
+
+def test_int64_accumulation_against_float_lane_accumulation():
+    """DESIGN.md section 2, arithmetic choice A: the LK sums are accumulated in int64 (exact), an x86 build of OpenCV 4.2 accumulates them in float lanes.
+    Oracle mode 1 restates that float accumulation; this bounds what the choice can change on the tracker fixture: the same feature ids at every
+    frame, sub-pixel positions within a fraction of LK's own 0.01 px termination threshold.  (A sensitivity measurement, not a pin.)"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lk_accum_sensitivity", os.path.join(root, "scripts", "lk_accum_sensitivity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = mod.compare(dict(max_cnt=150, min_dist=30), seed=1000, nframes=6)
+    assert r["frames_with_different_id_lists"] == 0 and r["ids_in_both"] == r["observations"]
+    assert 0 < r["coordinates_changed"] and r["largest_pixel_change"] < 0.01
