@@ -437,6 +437,17 @@ struct gf_estimator {
             fixed.clear();
         }
     } scratch;
+    // GNSS (estimator.h:293-331): epoch queue, per-frame measurement buffers, receiver clock / anchor / yaw states
+    std::deque<std::pair<double, std::vector<gf_gnss_obs>>> GNSSBuf;
+    std::vector<gf_gnss_obs> gnss_msg;                       // member of the reference too: the last epoch taken stays until the next one (EST:503-508, :656)
+    std::vector<std::vector<gf_gnss_obs>> gnss_meas_buf;     // [WINDOW_SIZE + 1]
+    std::map<int, int> sat_track_status;
+    bool gnss_ready = false, first_optimization = true, lowspeed = false, align_pending = false;
+    double diff_t_gnss_local = 0, yaw_enu_local = 0;
+    double align_anc[3] = {0, 0, 0}, align_yaw = 0, align_dt[4] = {0, 0, 0, 0}, align_ddt = 0;
+    V3 anc_ecef = v3(0, 0, 0), ecef_pos = v3(0, 0, 0), enu_pos = v3(0, 0, 0); M3 R_ecef_enu = m3_identity();
+    std::vector<double> para_rcv_dt, para_rcv_ddt, gnss_iono; double para_yaw_enu_local[1] = {0}, para_anc_ecef[3] = {0, 0, 0};
+    std::vector<int> gn_frame, gn_lower, gn_sys; std::vector<double> gn_ratio, gn_data;
     gf_ba_summary last_summary{};
     std::vector<double> marg_J, marg_r, marg_x0; std::vector<int> marg_id;   // receive buffers of gf_ba_marginalize
     double t_sect[6] = {0, 0, 0, 0, 0, 0};   // host wall time [s]: before optimization(), window build, waiting for the solve, between solve and marginalisation, waiting for it, after
@@ -458,6 +469,9 @@ struct gf_estimator {
         wheel_noise[0] = c.wheel_vel_n; wheel_noise[1] = c.wheel_gyr_n;
         f_manager.WINDOW_SIZE = WINDOW_SIZE; f_manager.FOCAL_LENGTH = c.focal_length; f_manager.MIN_PARALLAX = c.min_parallax_px / c.focal_length;
         f_manager.INIT_DEPTH = c.init_depth; f_manager.depth_threshold = c.depth_threshold;
+        gnss_meas_buf.assign(NP, {}); para_rcv_dt.assign(4 * NP, 0.0); para_rcv_ddt.assign(NP, 0.0);
+        gnss_iono.assign(c.gnss_iono, c.gnss_iono + 8);      // clearState EST:147-149
+        diff_t_gnss_local = c.gnss_local_time_diff;          // rosNodeTest.cpp:703-708 hands GNSS_LOCAL_TIME_DIFF over at start-up
     }
     ~gf_estimator() { if (ba) gf_ba_destroy(ba); if (tracker) gf_tracker_destroy(tracker); }
 
@@ -471,6 +485,79 @@ struct gf_estimator {
         if (!a.empty()) { av.push_back(a.front()); bv.push_back(b.front()); }
         return true;
     }
+    // ------------------------------------------------------------ GNSS intake
+    bool getGNSSInterval(double /*t0*/, double t1) {  // EST:476-510: stale epochs are thrown away, then the front epoch is taken whatever its age
+        if (GNSSBuf.empty()) return false;
+        while (!GNSSBuf.empty() && GNSSBuf.front().second[0].time < t1 + diff_t_gnss_local - 0.1 /* MAX_GNSS_CAMERA_DELAY */) {
+            GNSSBuf.pop_front();
+            if (GNSSBuf.empty()) return false;
+        }
+        gnss_msg = std::move(GNSSBuf.front().second);
+        GNSSBuf.pop_front();
+        return true;
+    }
+    static V3 ecef2geo(V3 p) {   // gnss_comm ecef2geo: latitude [deg], longitude [deg], height [m] (the formulas of gf_ba_gnss.hpp, on the host)
+        if (p.x == 0 && p.y == 0) return v3(0, 0, 0);
+        const double a = 6378137.0, e2 = 6.69437999014e-3, a2 = a * a, b2 = a2 * (1 - e2), b = sqrt(b2), ep2 = (a2 - b2) / b2, rho = sqrt(p.x * p.x + p.y * p.y);
+        double s1 = p.z * a, s2 = rho * b, h = sqrt(s1 * s1 + s2 * s2);
+        const double st = s1 / h, ct = s2 / h;
+        s1 = p.z + ep2 * b * st * st * st; s2 = rho - a * e2 * ct * ct * ct; h = sqrt(s1 * s1 + s2 * s2);
+        const double sin_lat = s1 / h, cos_lat = s2 / h, N = a2 / sqrt(a2 * cos_lat * cos_lat + b2 * sin_lat * sin_lat);
+        return v3(atan(s1 / s2) * 180.0 / M_PI, atan2(p.y, p.x) * 180.0 / M_PI, rho / cos_lat - N);
+    }
+    static M3 ecef2rotation(V3 p) {   // gnss_comm ecef2rotation = geo2rotation(ecef2geo(p)): R_ecef_enu
+        const V3 lla = ecef2geo(p);
+        const double lat = lla.x * M_PI / 180.0, lon = lla.y * M_PI / 180.0, sl = sin(lat), cl = cos(lat), so = sin(lon), co = cos(lon);
+        M3 R;
+        R.m[0] = -so; R.m[1] = -sl * co; R.m[2] = cl * co; R.m[3] = co; R.m[4] = -sl * so; R.m[5] = cl * so; R.m[6] = 0; R.m[7] = cl; R.m[8] = sl;
+        return R;
+    }
+    static double sat_elevation(V3 rcv, V3 sat) {   // gnss_comm sat_azel, elevation only
+        V3 dl = sat - rcv; dl = dl / norm(dl);
+        return asin((transpose(ecef2rotation(rcv)) * dl).z);
+    }
+    void processGNSS(const std::vector<gf_gnss_obs>& gnss_meas) {  // EST:1455-1535; ephemeris look-up and L1 selection happen before the C boundary (gf_gnss_obs)
+        std::vector<gf_gnss_obs> valid_meas;
+        for (const gf_gnss_obs& obs : gnss_meas) {
+            if (obs.sys < 0 || obs.sys > 3) continue;                                             // :1463-1465
+            if (obs.psr_std > cfg.gnss_psr_std_thres || obs.dopp_std > cfg.gnss_dopp_std_thres) { sat_track_status[obs.sat] = 0; continue; }   // :1499-1504
+            ++sat_track_status[obs.sat];                                                          // :1505-1510
+            if (sat_track_status[obs.sat] < cfg.gnss_track_num_thres) continue;                   // :1511-1512
+            if (gnss_ready && sat_elevation(ecef_pos, arr3(obs.sv_pos)) < cfg.gnss_elevation_thres * M_PI / 180.0) continue;   // :1515-1526
+            valid_meas.push_back(obs);
+        }
+        gnss_meas_buf[frame_count] = std::move(valid_meas);
+    }
+    bool GNSSVIAlign() {  // EST:1928-2043 with the initialiser's result handed in (gf_estimator_set_gnss_alignment)
+        if (!is_imu_excited && solver_flag == INITIAL) return false;
+        if (gnss_ready) return true;
+        double ax = 0, ay = 0;
+        for (int i = 0; i <= WINDOW_SIZE; i++) { ax += fabs(Vs[i].x); ay += fabs(Vs[i].y); }
+        ax /= WINDOW_SIZE + 1; ay /= WINDOW_SIZE + 1;
+        if (sqrt(ax * ax + ay * ay) < 0.3) return false;
+        if (!align_pending) return false;   // where coarse_localization / yaw_alignment / anchor_refinement would fail
+        int one_observed_sys = -1;
+        for (int k = 0; k < 4; k++) if (align_dt[k] != 0) { one_observed_sys = k; break; }
+        for (int i = 0; i <= WINDOW_SIZE; i++) {   // :2015-2036 (the drift is multiplied by the frame index, not by a time)
+            para_rcv_ddt[i] = align_ddt;
+            for (int k = 0; k < 4; k++) para_rcv_dt[4 * i + k] = (align_dt[k] == 0 ? (one_observed_sys < 0 ? 0.0 : align_dt[one_observed_sys]) : align_dt[k]) + align_ddt * i;
+        }
+        anc_ecef = arr3(align_anc); R_ecef_enu = ecef2rotation(anc_ecef); yaw_enu_local = align_yaw;
+        align_pending = false;
+        return true;
+    }
+    void updateGNSSStatistics() {  // EST:2045-2058
+        const double c = cos(yaw_enu_local), s = sin(yaw_enu_local);
+        const V3 p = Ps[WINDOW_SIZE];
+        enu_pos = v3(c * p.x - s * p.y, s * p.x + c * p.y, p.z);
+        ecef_pos = anc_ecef + R_ecef_enu * enu_pos;
+    }
+    void afterOptimizationGNSS() {  // EST:945-956, :1014-1025, :1113-1123
+        if (!cfg.gnss_enable) return;
+        if (!gnss_ready) gnss_ready = GNSSVIAlign();
+        if (gnss_ready) updateGNSSStatistics();
+    }
+
     void initFirstIMUPose(const std::vector<std::pair<double, V3>>& accVector) {  // EST:710-731
         initFirstPoseFlag = true;
         V3 averAcc = v3(0, 0, 0);
@@ -536,6 +623,7 @@ struct gf_estimator {
         const double header = feature.first;
         std::vector<gf_feature_obs> image = std::move(feature.second);
         featureBuf.pop_front();
+        if (cfg.gnss_enable) getGNSSInterval(prevTime, curTime);   // EST:584-587
         if (cfg.use_wheel) getInterval(wheelVelBuf, wheelGyrBuf, prevTime_wheel, curTime_wheel, velWheelVector, gyrWheelVector);
         if (cfg.use_imu) {
             dP_imu = v3(0, 0, 0);
@@ -562,6 +650,7 @@ struct gf_estimator {
             wheelstationary = norm(dP_wheel) < 0.001;
             preintegrationstationary = norm(dP_imu) < 0.001;
         }
+        if (cfg.gnss_enable && !gnss_msg.empty()) processGNSS(gnss_msg);   // EST:656-660
         const int rc = processImage(image, header);
         prevTime = curTime; prevTime_wheel = curTime_wheel;
         if (progressed) *progressed = true;
@@ -702,6 +791,7 @@ struct gf_estimator {
                     for (int k = 0; k <= WINDOW_SIZE; k++) pre_integrations[k]->repropagate(v3(0, 0, 0), Bgs[k]);
                     solver_flag = NON_LINEAR;
                     if (int rc = optimization()) return rc;
+                    afterOptimizationGNSS();
                     slideWindow();
                 } else {
                     if (int rc = optimization()) return rc;
@@ -719,6 +809,7 @@ struct gf_estimator {
             std::set<int> removeIndex;
             if (cfg.use_mcc) { movingConsistencyCheckW(removeIndex); f_manager.removeOutlier(removeIndex); }
             if (int rc = optimization()) return rc;
+            afterOptimizationGNSS();
             if (!cfg.use_mcc) { std::set<int> inner; movingConsistencyCheckW(inner); f_manager.removeOutlier(inner); }  // shadowing set, SURVEY.md quirk 13
             if (!cfg.multiple_thread) {
                 remove_ids.assign(removeIndex.begin(), removeIndex.end());
@@ -756,6 +847,7 @@ struct gf_estimator {
         if (dep.size() > para_Feature.size()) para_Feature.resize(dep.size());
         std::copy(dep.begin(), dep.end(), para_Feature.begin());
         para_Td[0] = td; para_Td_wheel[0] = td_wheel;
+        if (gnss_ready) { para_yaw_enu_local[0] = yaw_enu_local; para_anc_ecef[0] = anc_ecef.x; para_anc_ecef[1] = anc_ecef.y; para_anc_ecef[2] = anc_ecef.z; }   // :2347-2352
     }
     int double2vector() {  // EST:2440-2569
         std::vector<double> R(9 * (WINDOW_SIZE + 1)), P(3 * (WINDOW_SIZE + 1)), V(P.size()), Ba(P.size()), Bg(P.size());
@@ -769,11 +861,12 @@ struct gf_estimator {
         }
         f_manager.setDepth(para_Feature.data());
         td = para_Td[0];
+        if (gnss_ready) { yaw_enu_local = para_yaw_enu_local[0]; anc_ecef = arr3(para_anc_ecef); R_ecef_enu = ecef2rotation(anc_ecef); }   // :2562-2568
         return GF_OK;
     }
     int optimization() {  // EST:2890-3636
         if (!ba && !group) {
-            gf_ba_cfg bc{WINDOW_SIZE, cfg.max_features, cfg.max_visual, 1, 0};   // no GNSS front matter in this handle
+            gf_ba_cfg bc{WINDOW_SIZE, cfg.max_features, cfg.max_visual, 1, cfg.gnss_enable ? cfg.max_gnss_per_frame * (WINDOW_SIZE + 1) : 0};
             if (int rc = gf_ba_create(&bc, &ba)) return rc;
         }
         lap(0);
@@ -790,6 +883,34 @@ struct gf_estimator {
         } else { w.fix_ex_wheel = 1; w.fix_ix = 1; }
         w.fix_td = (!cfg.estimate_td || norm(Vs[0]) < 0.2) ? 1 : 0;                                                                                      // :3097-3100
         w.fix_td_wheel = (!cfg.estimate_td_wheel || norm(Vs[0]) < 0.2) ? 1 : 0;
+        if (gnss_ready) {   // :2904-2941: the GNSS blocks; yaw_enu_local is held constant, lowspeed drops the factors of this solve
+            double ax = 0, ay = 0;
+            for (int i = 0; i <= WINDOW_SIZE; i++) { ax += fabs(Vs[i].x); ay += fabs(Vs[i].y); }
+            ax /= WINDOW_SIZE + 1; ay /= WINDOW_SIZE + 1;
+            lowspeed = sqrt(ax * ax + ay * ay) < 0.3;
+        }
+        if (first_optimization && cfg.gnss_enable) {   // :2943-2951 PoseAnchorFactor on the values of para_Pose[0]
+            w.has_anchor = 1; memcpy(w.anchor_value, para_Pose.data(), 56);
+            first_optimization = false;
+        }
+        if (cfg.gnss_enable) {
+            gn_frame.clear(); gn_lower.clear(); gn_sys.clear(); gn_ratio.clear(); gn_data.clear();
+            if (gnss_ready)   // :3178-3210 (built whenever gnss_ready: the MARGIN_OLD marginalisation takes the factors of frame 0 even when lowspeed, :3398)
+                for (int i = 0; i <= WINDOW_SIZE; i++)
+                    for (const gf_gnss_obs& o : gnss_meas_buf[i]) {
+                        const double obs_local_ts = o.time - diff_t_gnss_local;
+                        const int lower_idx = Headers[i] > obs_local_ts ? (i == 0 ? 0 : i - 1) : (i == WINDOW_SIZE ? WINDOW_SIZE - 1 : i);
+                        const double lower_ts = Headers[lower_idx], upper_ts = Headers[lower_idx + 1];
+                        gn_frame.push_back(i); gn_lower.push_back(lower_idx); gn_sys.push_back(o.sys); gn_ratio.push_back((upper_ts - obs_local_ts) / (upper_ts - lower_ts));
+                        gn_data.insert(gn_data.end(), {o.sv_pos[0], o.sv_pos[1], o.sv_pos[2], o.sv_vel[0], o.sv_vel[1], o.sv_vel[2], o.svdt, o.svddt, o.tgd, o.pr_uura, o.dp_uura,
+                                                       o.psr, o.dopp, o.wavelength, o.tow, 0.0});
+                    }
+            w.gnss_enabled = gnss_ready ? 1 : 0; w.gnss_lowspeed = lowspeed ? 1 : 0; w.n_gnss = (int)gn_frame.size();
+            w.para_rcv_dt = para_rcv_dt.data(); w.para_rcv_ddt = para_rcv_ddt.data(); w.para_yaw_enu_local = para_yaw_enu_local; w.para_anc_ecef = para_anc_ecef;
+            w.gnss_ddt_weight = 1.0 / cfg.gnss_ddt_sigma; w.gnss_iono = gnss_iono.data();
+            w.gnss_frame = gn_frame.data(); w.gnss_lower = gn_lower.data(); w.gnss_sys = gn_sys.data(); w.gnss_ratio = gn_ratio.data(); w.gnss_data = gn_data.data();
+            w.gnss_headers = Headers.data();
+        }
         // IMU factors :3109-3119
         // the window's tables live in vectors of the estimator that keep their capacity from frame to frame (no allocation in the steady state)
         WinScratch& S_ = scratch; S_.clear();
@@ -863,6 +984,8 @@ struct gf_estimator {
         } else if (int rc = gf_ba_solve(ba, &w, 1, cfg.num_iterations, &last_summary)) return rc;
         lap(2);
         n_optimizations++;
+        while (para_yaw_enu_local[0] > M_PI) para_yaw_enu_local[0] -= 2.0 * M_PI;           // :3322-3325
+        while (para_yaw_enu_local[0] < -M_PI) para_yaw_enu_local[0] += 2.0 * M_PI;
         if (int rc = double2vector()) return rc;                                            // :3327
         if (frame_count < WINDOW_SIZE) { wheelanomaly = false; return GF_OK; }
         bool run_marg = marginalization_flag == MARGIN_OLD;
@@ -873,9 +996,10 @@ struct gf_estimator {
         if (run_marg) {
             vector2double();                                                                // :3337 / :3543
             if (systemstationary && cfg.stationary_detect) { /* para_SpeedBias already refreshed from Vs by vector2double */ }
-            const int cap_n = 16 * (WINDOW_SIZE + 1) + 64, cap_b = 2 * (WINDOW_SIZE + 1) + 16;
+            const int gx = cfg.gnss_enable ? 5 * (WINDOW_SIZE + 1) + 4 : 0;
+            const int cap_n = 16 * (WINDOW_SIZE + 1) + 64 + gx, cap_b = 2 * (WINDOW_SIZE + 1) + 16 + gx;
             // receive buffers of the prior: members of the estimator, sized once (half a megabyte of zero-filled std::vector per frame and sequence otherwise)
-            if (marg_J.size() != (size_t)cap_n * cap_n) { marg_J.assign((size_t)cap_n * cap_n, 0.0); marg_r.assign(cap_n, 0.0); marg_x0.assign(16 * (WINDOW_SIZE + 1) + 64, 0.0); marg_id.assign(cap_b, 0); }
+            if (marg_J.size() != (size_t)cap_n * cap_n) { marg_J.assign((size_t)cap_n * cap_n, 0.0); marg_r.assign(cap_n, 0.0); marg_x0.assign(16 * (WINDOW_SIZE + 1) + 64 + gx, 0.0); marg_id.assign(cap_b, 0); }
             std::vector<double>&pJ = marg_J, &pr = marg_r, &px0 = marg_x0; std::vector<int>& pid = marg_id;
             gf_ba_prior p{};
             p.cap_n = cap_n; p.cap_blocks = cap_b; p.block_id = pid.data(); p.J = pJ.data(); p.r = pr.data(); p.x0 = px0.data();
@@ -891,7 +1015,7 @@ struct gf_estimator {
                 prior_block_id.assign(pid.begin(), pid.begin() + p.nblocks);
                 prior_J.assign(pJ.begin(), pJ.begin() + (size_t)p.n * p.n); prior_r.assign(pr.begin(), pr.begin() + p.n);
                 int gs = 0;
-                for (int id : prior_block_id) { const int k = id / 4096; gs += (k == GF_POSE || k == GF_EX_POSE || k == GF_EX_WHEEL) ? 7 : k == GF_SPEEDBIAS ? 9 : 1; }
+                for (int id : prior_block_id) { const int k = id / 4096; gs += (k == GF_POSE || k == GF_EX_POSE || k == GF_EX_WHEEL) ? 7 : k == GF_SPEEDBIAS ? 9 : k == GF_ANC ? 3 : 1; }
                 prior_x0.assign(px0.begin(), px0.begin() + gs);
             }
         }
@@ -911,7 +1035,13 @@ struct gf_estimator {
                 std::swap(pre_integrations[i], pre_integrations[i + 1]);
                 std::swap(Vs[i], Vs[i + 1]); std::swap(Bas[i], Bas[i + 1]); std::swap(Bgs[i], Bgs[i + 1]);
                 if (cfg.use_wheel) std::swap(pre_integrations_wheel[i], pre_integrations_wheel[i + 1]);
+                if (cfg.gnss_enable) {   // :3674-3681
+                    gnss_meas_buf[i].swap(gnss_meas_buf[i + 1]);
+                    for (int k = 0; k < 4; k++) para_rcv_dt[4 * i + k] = para_rcv_dt[4 * (i + 1) + k];
+                    para_rcv_ddt[i] = para_rcv_ddt[i + 1];
+                }
             }
+            if (cfg.gnss_enable) gnss_meas_buf[WINDOW_SIZE].clear();   // :3700-3704
             Headers[WINDOW_SIZE] = Headers[WINDOW_SIZE - 1]; Ps[WINDOW_SIZE] = Ps[WINDOW_SIZE - 1]; Rs[WINDOW_SIZE] = Rs[WINDOW_SIZE - 1];
             Vs[WINDOW_SIZE] = Vs[WINDOW_SIZE - 1]; Bas[WINDOW_SIZE] = Bas[WINDOW_SIZE - 1]; Bgs[WINDOW_SIZE] = Bgs[WINDOW_SIZE - 1];
             pre_integrations[WINDOW_SIZE] = std::make_shared<ImuPre>(acc_0, gyr_0, Bas[WINDOW_SIZE], Bgs[WINDOW_SIZE]);
@@ -936,6 +1066,12 @@ struct gf_estimator {
                     for (size_t i = 0; i < src.dt.size(); i++) dst.push_back(src.dt[i], arr3(&src.vel[3 * i]), arr3(&src.gyr[3 * i]));
                 }
                 pre_integrations_wheel[WINDOW_SIZE] = std::make_shared<WheelPre>(vel_0_wheel, gyr_0_wheel, sx, sy, sw, td_wheel);
+            }
+            {   // :3761-3768
+                gnss_meas_buf[frame_count - 1] = gnss_meas_buf[frame_count];
+                for (int k = 0; k < 4; k++) para_rcv_dt[4 * (frame_count - 1) + k] = para_rcv_dt[4 * frame_count + k];
+                para_rcv_ddt[frame_count - 1] = para_rcv_ddt[frame_count];
+                gnss_meas_buf[frame_count].clear();
             }
             sum_of_front++;
             f_manager.removeFront(frame_count);   // slideWindowNew, EST:3792-3802
@@ -1020,6 +1156,11 @@ int gf_estimator_default_cfg(gf_estimator_cfg* c) {
     const double rio[9] = {0.352551, -0.935764, -0.00734672, 0.0145238, 0.0133214, -0.999806, 0.93568, 0.352375, 0.0182873};   // body_T_wheel, m2dgrp.yaml:107-114
     const double tio[3] = {0.0497956, 1.06332, -0.037465};
     memcpy(c->rio, rio, sizeof(rio)); memcpy(c->tio, tio, sizeof(tio));
+    // GNSS off, thresholds as in m2dgrp.yaml:7, :38-48
+    c->gnss_enable = 0; c->gnss_track_num_thres = 5; c->max_gnss_per_frame = 32;
+    c->gnss_elevation_thres = 30.0; c->gnss_psr_std_thres = 2.0; c->gnss_dopp_std_thres = 2.0; c->gnss_ddt_sigma = 0.1; c->gnss_local_time_diff = 18.0;
+    const double iono[8] = {0.1118e-07, 0.2235e-07, -0.4172e-06, 0.6557e-06, 0.1249e+06, -0.4424e+06, 0.1507e+07, -0.2621e+06};
+    memcpy(c->gnss_iono, iono, sizeof(iono));
     return GF_OK;
 }
 
@@ -1028,6 +1169,7 @@ int gf_estimator_create(const gf_estimator_cfg* c, gf_estimator** out) {
     if (c->window_size < 2 || c->window_size > 30) return gf::set_err(GF_ERR_INVALID, "window_size must be in [2, 30]");
     if (!c->use_imu || !c->depth) return gf::set_err(GF_ERR_INVALID, "only the RGB-D + IMU configuration is built (USE_IMU=1, DEPTH=1)");
     if (c->estimate_extrinsic == 2) return gf::set_err(GF_ERR_INVALID, "ESTIMATE_EXTRINSIC=2 (online rotation calibration) is not built");
+    if (c->gnss_enable && (c->max_gnss_per_frame < 1 || !(c->gnss_ddt_sigma > 0))) return gf::set_err(GF_ERR_INVALID, "gnss_enable needs max_gnss_per_frame >= 1 and gnss_ddt_sigma > 0");
     gf_estimator* e = new gf_estimator(*c);
     if (c->with_tracker) {
         gf_tracker_cfg tc = c->tracker; tc.batch = 1;
@@ -1058,6 +1200,40 @@ int gf_estimator_input_wheel(gf_estimator* e, double t, const double* vel, const
     if (!e || !vel || !gyr) return gf::set_err(GF_ERR_INVALID, "null argument");
     e->wheelVelBuf.emplace_back(t, arr3(vel)); e->wheelGyrBuf.emplace_back(t, arr3(gyr));
     if (e->cfg.multiple_thread && !e->featureBuf.empty()) return e->drain();   // "wait for wheel ...", EST:562-573
+    return GF_OK;
+}
+int gf_estimator_input_gnss(gf_estimator* e, double t, const gf_gnss_obs* obs, int n) {  // Estimator::inputGNSS EST:397-404
+    if (!e || !obs || n < 1) return gf::set_err(GF_ERR_INVALID, "an epoch needs at least one observation (getGNSSInterval reads the first one's time, EST:489)");
+    if (!e->cfg.gnss_enable) return gf::set_err(GF_ERR_INVALID, "estimator was created with gnss_enable 0");
+    if (n > e->cfg.max_gnss_per_frame) return gf::set_err(GF_ERR_CAPACITY, "epoch with %d observations, max_gnss_per_frame %d", n, e->cfg.max_gnss_per_frame);
+    e->GNSSBuf.emplace_back(t, std::vector<gf_gnss_obs>(obs, obs + n));
+    return GF_OK;
+}
+int gf_estimator_input_gnss_time_diff(gf_estimator* e, double t_diff) {  // EST:1450-1453
+    if (!e) return gf::set_err(GF_ERR_INVALID, "null handle");
+    e->diff_t_gnss_local = t_diff;
+    return GF_OK;
+}
+int gf_estimator_input_iono_params(gf_estimator* e, const double* p) {  // EST:1438-1448
+    if (!e || !p) return gf::set_err(GF_ERR_INVALID, "null argument");
+    e->gnss_iono.assign(p, p + 8);
+    return GF_OK;
+}
+int gf_estimator_set_gnss_alignment(gf_estimator* e, const double* anc_ecef, double yaw, const double* rcv_dt4, double rcv_ddt) {
+    if (!e || !anc_ecef || !rcv_dt4) return gf::set_err(GF_ERR_INVALID, "null argument");
+    if (!e->cfg.gnss_enable) return gf::set_err(GF_ERR_INVALID, "estimator was created with gnss_enable 0");
+    memcpy(e->align_anc, anc_ecef, 24); memcpy(e->align_dt, rcv_dt4, 32); e->align_yaw = yaw; e->align_ddt = rcv_ddt; e->align_pending = true;
+    return GF_OK;
+}
+int gf_estimator_get_gnss_state(gf_estimator* e, int* gnss, double* rcv_dt, double* rcv_ddt, double* yaw, double* anc, double* ecef, double* enu) {
+    if (!e) return gf::set_err(GF_ERR_INVALID, "null handle");
+    if (gnss) { const int v[8] = {e->gnss_ready ? 1 : 0, e->lowspeed ? 1 : 0, (int)e->gnss_meas_buf[e->WINDOW_SIZE].size(), e->first_optimization ? 1 : 0, (int)e->GNSSBuf.size(), 0, 0, 0}; memcpy(gnss, v, sizeof(v)); }
+    if (rcv_dt) memcpy(rcv_dt, e->para_rcv_dt.data(), e->para_rcv_dt.size() * 8);
+    if (rcv_ddt) memcpy(rcv_ddt, e->para_rcv_ddt.data(), e->para_rcv_ddt.size() * 8);
+    if (yaw) *yaw = e->yaw_enu_local;
+    if (anc) memcpy(anc, &e->anc_ecef.x, 24);
+    if (ecef) memcpy(ecef, &e->ecef_pos.x, 24);
+    if (enu) memcpy(enu, &e->enu_pos.x, 24);
     return GF_OK;
 }
 // Estimator::inputFeature (EST:362-375) + processMeasurements: `obs` is the tracker's map flattened in id order
@@ -1175,6 +1351,10 @@ int gf_estimator_debug(gf_estimator* e, const char* op, const double* in, int n_
     else if (s == "getDepthVector") e->f_manager.getDepthVector(o);
     else if (s == "getFeatureCount") o.push_back(e->f_manager.getFeatureCount());
     else if (s == "checkvisual") o.push_back(e->checkvisual() ? 1 : 0);
+    else if (s == "gnss_meas_buf") {   // per frame: count, then the satellite numbers (gnss_meas_buf[i], estimator.h:296)
+        for (auto& b : e->gnss_meas_buf) { o.push_back((double)b.size()); for (auto& m : b) o.push_back(m.sat); }
+    }
+    else if (s == "sat_track_status") for (auto& kv : e->sat_track_status) { o.push_back(kv.first); o.push_back(kv.second); }
     else if (s == "addFeature" && n_in >= 2 && (n_in - 2) % 9 == 0) {
         const int n = (n_in - 2) / 9;
         std::vector<gf_feature_obs> v(n);
@@ -1248,7 +1428,7 @@ int gf_estimator_group_create(const gf_estimator_cfg* c, int n, gf_estimator_gro
         e->group = &g->solver;
         g->mem.push_back(e);
     }
-    gf_ba_cfg bc{c->window_size, c->max_features, c->max_visual, n, 0};
+    gf_ba_cfg bc{c->window_size, c->max_features, c->max_visual, n, c->gnss_enable ? c->max_gnss_per_frame * (c->window_size + 1) : 0};
     if (int rc = gf_ba_create(&bc, &g->solver.ba)) { delete g; return rc; }
     (void)hipGetDevice(&g->device);
     g->has.assign(n, 0); g->t.assign(n, 0.0); g->frames.resize(n); g->rcs.assign(n, GF_OK); g->errs.resize(n);

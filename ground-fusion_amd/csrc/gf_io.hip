@@ -150,7 +150,7 @@ int gf_estimator_cfg_from_yaml(const char* config_file, gf_estimator_cfg* c) {
     std::string err;
     if (!parse_yaml(config_file, y, err)) return gf::set_err(GF_ERR_INVALID, "%s: %s", config_file, err.c_str());
     // what the build does not carry fails here, loudly, instead of being silently ignored
-    const char* unsupported[] = {"use_line", "use_yolo", "plane", "equalize", "gnss_enable", "use_motion"};
+    const char* unsupported[] = {"use_line", "use_yolo", "plane", "equalize", "use_motion"};
     for (const char* k : unsupported)
         if (y.integer(k) != 0) return gf::set_err(GF_ERR_INVALID, "%s: `%s: %d` is outside the built path (DESIGN.md, out of scope)", config_file, k, y.integer(k));
     if (y.integer("num_of_cam") != 1) return gf::set_err(GF_ERR_INVALID, "%s: num_of_cam must be 1 (RGB-D), got %d", config_file, y.integer("num_of_cam"));
@@ -189,6 +189,21 @@ int gf_estimator_cfg_from_yaml(const char* config_file, gf_estimator_cfg* c) {
     c->td = y.real("td"); c->estimate_td = y.integer("estimate_td");
     c->td_wheel = y.real("td_wheel"); c->estimate_td_wheel = y.integer("estimate_td_wheel");
     if (!c->use_imu) { c->estimate_extrinsic = 0; c->estimate_td = 0; }      // parameters.cpp:508-513
+    c->gnss_enable = y.integer("gnss_enable") != 0;                           // parameters.cpp:519-552 (the reference reads these keys only when enabled)
+    c->max_gnss_per_frame = 32;
+    {
+        auto it = y.mat.find("gnss_iono_default_parameters");
+        const bool have = it != y.mat.end() && it->second.data.size() == 8;
+        if (have) memcpy(c->gnss_iono, it->second.data.data(), 64);
+        else if (c->gnss_enable) return gf::set_err(GF_ERR_INVALID, "%s: gnss_iono_default_parameters must be a 1 x 8 matrix", config_file);
+        if (c->gnss_enable && y.integer("gnss_local_online_sync") != 0)
+            return gf::set_err(GF_ERR_INVALID, "%s: gnss_local_online_sync: 1 (trigger-message time sync) is not built; give gnss_local_time_diff", config_file);
+        c->gnss_local_time_diff = y.real("gnss_local_time_diff");
+        c->gnss_elevation_thres = y.real("gnss_elevation_thres"); c->gnss_ddt_sigma = y.real("gnss_ddt_sigma");
+        c->gnss_psr_std_thres = y.real("gnss_psr_std_thres"); c->gnss_dopp_std_thres = y.real("gnss_dopp_std_thres");
+        c->gnss_track_num_thres = (int)(unsigned)y.real("gnss_track_num_thres");   // static_cast<uint32_t>(double), parameters.cpp:547-548
+        if (c->gnss_enable && !(c->gnss_ddt_sigma > 0)) return gf::set_err(GF_ERR_INVALID, "%s: gnss_ddt_sigma must be positive", config_file);
+    }
     // front end
     gf_tracker_cfg& t = c->tracker;
     t.height = y.integer("image_height"); t.width = y.integer("image_width");   // ROW / COL

@@ -378,14 +378,23 @@ class EstimatorCfg(C.Structure):
                                        "stationary_detect", "only_initial_with_wheel", "multiple_thread", "num_iterations", "with_tracker")] + \
                [(k, C.c_double) for k in ("acc_n", "gyr_n", "acc_w", "gyr_w", "g_norm", "wheel_vel_n", "wheel_gyr_n", "min_parallax_px", "depth_threshold",
                                           "init_depth", "focal_length", "td", "td_wheel", "sx", "sy", "sw")] + \
-               [("tic", C.c_double * 3), ("ric", C.c_double * 9), ("tio", C.c_double * 3), ("rio", C.c_double * 9), ("tracker", TrackerCfg)]
+               [("tic", C.c_double * 3), ("ric", C.c_double * 9), ("tio", C.c_double * 3), ("rio", C.c_double * 9), ("tracker", TrackerCfg)] + \
+               [(k, C.c_int) for k in ("gnss_enable", "gnss_track_num_thres", "max_gnss_per_frame")] + \
+               [(k, C.c_double) for k in ("gnss_elevation_thres", "gnss_psr_std_thres", "gnss_dopp_std_thres", "gnss_ddt_sigma", "gnss_local_time_diff")] + \
+               [("gnss_iono", C.c_double * 8)]
+
+
+class GnssObs(C.Structure):
+    """gf_gnss_obs: one L1 observation of an epoch with the satellite state its ephemeris gives (include/groundfusion_hip.h)"""
+    _fields_ = [("sat", C.c_int), ("sys", C.c_int)] + [(k, C.c_double) for k in ("time", "psr", "dopp", "psr_std", "dopp_std", "wavelength")] + \
+               [("sv_pos", C.c_double * 3), ("sv_vel", C.c_double * 3)] + [(k, C.c_double) for k in ("svdt", "svddt", "tgd", "pr_uura", "dp_uura", "tow")]
 
 
 def default_estimator_cfg(**kw):
     c = EstimatorCfg()
     _chk(lib().gf_estimator_default_cfg(C.byref(c)))
     for k, v in kw.items():
-        if k in ("tic", "ric", "tio", "rio"):
+        if k in ("tic", "ric", "tio", "rio", "gnss_iono"):
             a = np.asarray(v, np.float64).reshape(-1)
             for i in range(len(a)):
                 getattr(c, k)[i] = a[i]
@@ -432,6 +441,39 @@ class SlidingWindowEstimator:
             for j in range(8):
                 obs[k].v[j] = v[j]
         _chk(lib().gf_estimator_input_feature(self.h, C.c_double(t), obs, len(ids)))
+
+    def inputGNSS(self, t, epoch):
+        """epoch: list of dicts with the fields of gf_gnss_obs (Estimator::inputGNSS, estimator.cpp:397)"""
+        obs = (GnssObs * max(len(epoch), 1))()
+        for k, o in enumerate(epoch):
+            for name, _ in GnssObs._fields_:
+                if name in ("sv_pos", "sv_vel"):
+                    for j in range(3):
+                        getattr(obs[k], name)[j] = float(o[name][j])
+                else:
+                    setattr(obs[k], name, o[name])
+        _chk(lib().gf_estimator_input_gnss(self.h, C.c_double(t), obs, len(epoch)))
+
+    def inputGNSSTimeDiff(self, t_diff):
+        _chk(lib().gf_estimator_input_gnss_time_diff(self.h, C.c_double(t_diff)))
+
+    def inputIonoParams(self, params):
+        a = np.ascontiguousarray(params, np.float64)
+        assert a.size == 8
+        _chk(lib().gf_estimator_input_iono_params(self.h, _p(a, C.c_double)))
+
+    def setGNSSAlignment(self, anc_ecef, yaw_enu_local, rcv_dt, rcv_ddt):
+        a, d = np.ascontiguousarray(anc_ecef, np.float64), np.ascontiguousarray(rcv_dt, np.float64)
+        assert a.size == 3 and d.size == 4
+        _chk(lib().gf_estimator_set_gnss_alignment(self.h, _p(a, C.c_double), C.c_double(yaw_enu_local), _p(d, C.c_double), C.c_double(rcv_ddt)))
+
+    def gnss_state(self):
+        N = self.W + 1
+        info, dt, ddt, yaw, anc, ecef, enu = np.zeros(8, np.int32), np.zeros((N, 4)), np.zeros(N), C.c_double(0), np.zeros(3), np.zeros(3), np.zeros(3)
+        _chk(lib().gf_estimator_get_gnss_state(self.h, _p(info, C.c_int), _p(dt, C.c_double), _p(ddt, C.c_double), C.byref(yaw), _p(anc, C.c_double),
+                                               _p(ecef, C.c_double), _p(enu, C.c_double)))
+        return dict(gnss_ready=int(info[0]), lowspeed=int(info[1]), n_newest=int(info[2]), first_optimization=int(info[3]), queued=int(info[4]),
+                    rcv_dt=dt, rcv_ddt=ddt, yaw_enu_local=yaw.value, anc_ecef=anc, ecef_pos=ecef, enu_pos=enu)
 
     def inputImage(self, t, img, depth=None):
         img = np.ascontiguousarray(img, np.uint8)

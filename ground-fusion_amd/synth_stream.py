@@ -19,7 +19,7 @@ def rot_z(a):
 
 
 class Stream:
-    def __init__(self, seed, t_still=1.5, t_move=3.0, v_max=0.4, imu_hz=200.0, wheel_hz=50.0, cam_hz=30.0, noise=True, near_z=2.5, far_z=6.0, yaw0=0.0, yaw_turn=0.0, split_x=0.6, turn_delay=0.0):
+    def __init__(self, seed, t_still=1.5, t_move=3.0, v_max=0.4, imu_hz=200.0, wheel_hz=50.0, cam_hz=30.0, noise=True, near_z=2.5, far_z=6.0, yaw0=0.0, yaw_turn=0.0, split_x=0.6, turn_delay=0.0, slow_tail=0.0, v_tail=0.15):
         rng = np.random.default_rng(2000 + seed)
         self.seed, self.near_z, self.far_z, self.split_x = seed, near_z, far_z, split_x
         T = t_still + t_move
@@ -27,6 +27,9 @@ class Stream:
         t = np.arange(0, T + 0.2, h)
         s = np.clip((t - t_still) / 0.8, 0, 1)
         speed = v_max * (3 * s ** 2 - 2 * s ** 3)                                   # smooth ramp
+        if slow_tail > 0.0:                                                         # ... and down to v_tail over the last slow_tail seconds (crawling, not stopping)
+            e = np.clip((t - (T - slow_tail)) / (0.6 * slow_tail), 0, 1)
+            speed = speed - (v_max - v_tail) * (3 * e ** 2 - 2 * e ** 3) * (t > t_still + 0.8)
         amp, f, ph = rng.uniform(0.10, 0.25), rng.uniform(0.8, 1.6), rng.uniform(0, 6.28)
         yaw_rate = np.where(t > t_still, amp * np.sin(f * (t - t_still) + ph) * (3 * s ** 2 - 2 * s ** 3), 0.0)
         if yaw_turn != 0.0:   # plus a smooth turn by yaw_turn [rad] spread over the motion phase
@@ -144,6 +147,55 @@ class Stream:
                 out[i] = ((u - synth.CX) / synth.FX, (v - synth.CY) / synth.FY, u, v, d)
         return out
 
+    # ---- GNSS: raw measurements of a receiver riding on the body origin (the measurement model of synth_window.add_gnss)
+    def gnss_setup(self, sats_per_sys=3, n_low=2, lat=31.03, lon=121.44, alt=20.0, alpha=0.3, time_diff=18.0):
+        """constellation (4 systems x sats_per_sys above 32 deg, plus n_low GPS satellites at 8..22 deg that the elevation gate of
+        Estimator::processGNSS has to drop once gnss_ready), receiver clock and the ENU <- world yaw alpha."""
+        import synth_window as SW
+        rng = np.random.default_rng(7000 + self.seed)
+        anc, Re = SW.geo2ecef(lat, lon, alt), SW.R_ecef_enu(lat, lon)
+        sats = []
+        for sys in range(4):
+            for q in range(sats_per_sys + (n_low if sys == 0 else 0)):
+                low = q >= sats_per_sys
+                az, rg = rng.uniform(0, 2 * np.pi), rng.uniform(2.0e7, 2.5e7)
+                el = rng.uniform(np.radians(8), np.radians(22)) if low else rng.uniform(np.radians(32), np.radians(80))
+                d_enu = np.array([np.sin(az) * np.cos(el), np.cos(az) * np.cos(el), np.sin(el)])
+                sats.append(dict(sat=100 * sys + q + 1, sys=sys, pos=anc + Re @ (d_enu * rg), vel=Re @ (np.cross(d_enu, rng.normal(0, 1, 3)) * 1.5e3),
+                                 svdt=rng.uniform(-2e-4, 2e-4), svddt=rng.uniform(-1e-11, 1e-11), tgd=rng.uniform(-8e-9, 8e-9)))
+        R0w = self.R_wb(self.cam_t[0])
+        theta0 = float(np.arctan2(R0w[1, 0], R0w[0, 0]))          # the estimator's local frame is the world turned by -theta0 about z (initFirstIMUPose zeroes the yaw)
+        self._gnss = dict(anc=anc, Re=Re, R_ew=Re @ rot_z(alpha), sats=sats, dt=np.array([150.0, 180.0, 120.0, 200.0]), ddt=2.0, time_diff=time_diff,
+                          yaw_enu_local=alpha + theta0, noise=np.random.default_rng(7100 + self.seed))
+        return self._gnss
+
+    def gnss_epoch(self, t_local, flaky_sat=None):
+        """(gps time, list of gf_gnss_obs-like dicts) of the epoch received at local time t_local; flaky_sat: this satellite reports psr_std 5 m"""
+        import synth_window as SW
+        G = self._gnss
+        rng = G["noise"]
+        p, v = G["anc"] + G["R_ew"] @ self.p_wb(t_local), G["R_ew"] @ self._at(self._vw, t_local)
+        wl = SW.C_LIGHT / 1575.42e6
+        out = []
+        for sv in G["sats"]:
+            sp = sv["pos"] + sv["vel"] * t_local
+            los = sp - p
+            rg = np.linalg.norm(los)
+            unit = los / rg
+            clk = G["dt"][sv["sys"]] + G["ddt"] * t_local
+            psr = rg + SW.OMG_E * (sp[0] * p[1] - sp[1] * p[0]) / SW.C_LIGHT + clk - sv["svdt"] * SW.C_LIGHT + sv["tgd"] * SW.C_LIGHT + rng.normal(0, 0.5)
+            dop = (sv["vel"] - v) @ unit + SW.OMG_E / SW.C_LIGHT * (sv["vel"][0] * p[1] + sp[0] * v[1] - sv["vel"][1] * p[0] - sp[1] * v[0]) + G["ddt"] - sv["svddt"] * SW.C_LIGHT
+            bad = flaky_sat is not None and sv["sat"] == flaky_sat
+            out.append(dict(sat=sv["sat"], sys=sv["sys"], time=t_local + G["time_diff"], psr=float(psr), dopp=float(-(dop + rng.normal(0, 0.05)) / wl),
+                            psr_std=5.0 if bad else 0.6, dopp_std=0.3, wavelength=wl, sv_pos=sp.copy(), sv_vel=sv["vel"].copy(), svdt=sv["svdt"], svddt=sv["svddt"],
+                            tgd=sv["tgd"], pr_uura=2.0, dp_uura=2.0, tow=345600.0 + t_local))
+        return t_local + G["time_diff"], out
+
+    def gnss_alignment(self, t_oldest, anchor_error=(0.4, -0.3, 0.2), yaw_error=0.002, clock_error=2.0):
+        """a GNSSVIAlign result of realistic quality for a window whose oldest frame is at t_oldest: anchor, yaw, clock biases of that frame, drift"""
+        G = self._gnss
+        return G["anc"] + np.array(anchor_error), G["yaw_enu_local"] + yaw_error, G["dt"] + G["ddt"] * t_oldest + clock_error, G["ddt"] + 0.1
+
     # ---- the stream as files: what tools/gf_replay reads (host/replay_node.h) plus a configuration in the reference's own YAML dialect
     def export(self, out_dir, n_frames=None, **cfg):
         """writes imu.csv, wheel.csv, image0.csv, image1.csv, frames/*.pgm, config.yaml and cam.yaml; cfg overrides YAML keys"""
@@ -175,7 +227,8 @@ class Stream:
                     multiple_thread=1, max_cnt=150, min_dist=30, freq=10, F_threshold=1.0, show_track=0, flow_back=1, max_solver_time=0.04, max_num_iterations=8,
                     keyframe_parallax=10.0, acc_n=1.2374091609523514e-02, gyr_n=3.0032654435730201e-03, acc_w=1.9218003442176448e-04, gyr_w=5.4692100664858005e-05,
                     g_norm=G_NORM, wheel_gyro_noise_sigma=0.004, wheel_velocity_noise_sigma=0.01, estimate_wheel_intrinsic=0, sx=1.0, sy=1.0, sw=1.0,
-                    estimate_td=0, td=0.0, estimate_td_wheel=0, td_wheel=0.0)
+                    estimate_td=0, td=0.0, estimate_td_wheel=0, td_wheel=0.0, gnss_elevation_thres=30, gnss_psr_std_thres=2.0, gnss_dopp_std_thres=2.0,
+                    gnss_track_num_thres=5, gnss_ddt_sigma=0.1, gnss_local_online_sync=0, gnss_local_time_diff=18.0)
         keys.update(cfg)
         T_io = np.eye(4)
         T_io[:3, :3], T_io[:3, 3] = RIO, TIO
@@ -189,6 +242,8 @@ class Stream:
             for k, v in keys.items():
                 f.write("%s: %s\n" % (k, v))
             f.write("\n" + mat("body_T_cam0", np.eye(4)) + "\n" + mat("body_T_cam1", np.eye(4)) + "\n" + mat("body_T_wheel", T_io))
+            import synth_window as SW
+            f.write("\n" + mat("gnss_iono_default_parameters", SW.IONO.reshape(1, 8)))
         with open(os.path.join(out_dir, "cam.yaml"), "w") as f:
             f.write("%%YAML:1.0\n---\nmodel_type: PINHOLE\ncamera_name: camera\nimage_width: %d\nimage_height: %d\ndistortion_parameters:\n   k1: 0.0\n   k2: 0.0\n"
                     "   p1: 0.0\n   p2: 0.0\nprojection_parameters:\n   fx: %r\n   fy: %r\n   cx: %r\n   cy: %r\n" % (synth.W, synth.H, synth.FX, synth.FY, synth.CX, synth.CY))

@@ -251,8 +251,10 @@ int gf_wheel_preintegrate(int n, const double* dt, const double* vel, const doub
  * sequence.  Replaces, in vins_estimator/src/estimator/estimator.h: inputIMU :104, inputWheel :106, inputFeature :108,
  * inputImage :105, processImage :110 (via processMeasurements :113), and the FeatureManager it owns (feature_manager.h:139-215).
  * The dense work (Estimator::optimization, estimator.cpp:2890-3636) runs on the HIP back end behind gf_ba_*.
- * Built: RGB-D + IMU (+ wheel) configuration, stationary / wheel-activated initialisation (estimator.cpp:1557-1682),
- * MULTIPLE_THREAD 0/1 data flow (processed synchronously).  Not built: SfM initialisation, GNSS, line / plane / motion factors.
+ * Built: RGB-D + IMU (+ wheel) (+ GNSS) configuration, stationary / wheel-activated initialisation (estimator.cpp:1557-1682),
+ * MULTIPLE_THREAD 0/1 data flow (processed synchronously); GNSS: measurement gating, clock / anchor / yaw states, factors in the solve and the
+ * marginalisation, with satellite states and the GNSS-VI alignment handed in (gf_gnss_obs, gf_estimator_set_gnss_alignment).
+ * Not built: SfM initialisation, ephemeris decoding and GNSSVIAlign's own initialiser, line / plane / motion factors.
  * ------------------------------------------------------------------------------------------------------------------------------ */
 typedef struct gf_estimator gf_estimator;
 
@@ -271,13 +273,41 @@ typedef struct gf_estimator_cfg {
     double td, td_wheel, sx, sy, sw;
     double tic[3], ric[9], tio[3], rio[9];  /* body_T_cam0, body_T_wheel (row-major rotations) */
     gf_tracker_cfg tracker;
+    /* GNSS (parameters.cpp:519-552): gnss_enable; thresholds of processGNSS (estimator.cpp:1497-1523); GNSS_DDT_WEIGHT = 1 / gnss_ddt_sigma;
+     * max_gnss_per_frame: capacity of gnss_meas_buf[i]; gnss_iono[8]: gnss_iono_default_parameters */
+    int gnss_enable, gnss_track_num_thres, max_gnss_per_frame;
+    double gnss_elevation_thres, gnss_psr_std_thres, gnss_dopp_std_thres, gnss_ddt_sigma, gnss_local_time_diff;
+    double gnss_iono[8];
 } gf_estimator_cfg;
+
+/* One L1 observation of a GNSS epoch as Estimator::inputGNSS receives it (ObsPtr), together with what GnssPsrDoppFactor's constructor derives from
+ * the matching ephemeris (gnss_psr_dopp_factor.cpp:3-47 via gnss_comm eph2pos / geph2pos / eph2svdt: not part of this build):
+ * the satellite state at transmission time. */
+typedef struct gf_gnss_obs {
+    int sat;                 /* satellite number (tracking statistics, estimator.cpp:1497-1511) */
+    int sys;                 /* constellation index 0 GPS, 1 GLO, 2 GAL, 3 BDS (gnss_comm::sys2idx); < 0: any other system, dropped (estimator.cpp:1463-1465) */
+    double time;             /* time2sec(obs->time) [s] */
+    double psr, dopp, psr_std, dopp_std, wavelength;   /* L1 pseudorange [m], Doppler [Hz], their standard deviations, carrier wavelength [m] */
+    double sv_pos[3], sv_vel[3], svdt, svddt, tgd, pr_uura, dp_uura, tow;
+} gf_gnss_obs;
 
 int gf_estimator_default_cfg(gf_estimator_cfg* cfg);   /* values of config/realsense/m2dgrp.yaml */
 int gf_estimator_create(const gf_estimator_cfg* cfg, gf_estimator** out);
 int gf_estimator_destroy(gf_estimator* h);
 int gf_estimator_input_imu(gf_estimator* h, double t, const double* acc, const double* gyr);
 int gf_estimator_input_wheel(gf_estimator* h, double t, const double* vel, const double* gyr);
+/* Estimator::inputGNSS (estimator.h:99, estimator.cpp:397): one epoch; inputGNSSTimeDiff (estimator.cpp:1450); inputIonoParams (estimator.h:98) */
+int gf_estimator_input_gnss(gf_estimator* h, double t, const gf_gnss_obs* obs, int n);
+int gf_estimator_input_gnss_time_diff(gf_estimator* h, double diff_t_gnss_local);
+int gf_estimator_input_iono_params(gf_estimator* h, const double* params8);
+/* What GNSSVIAlign (estimator.cpp:1928-2043: coarse SPP localisation, yaw alignment, anchor refinement) would find: supplied by the caller in this build
+ * (the initialiser needs gnss_comm's psr_pos).  The estimator applies it at the point where the reference runs GNSSVIAlign and
+ * under its preconditions (visual-inertial part initialised, mean horizontal speed of the window >= 0.3 m/s): refined_xyzt = anc_ecef + rcv_dt[4],
+ * aligned yaw and clock drift. */
+int gf_estimator_set_gnss_alignment(gf_estimator* h, const double* anc_ecef, double yaw_enu_local, const double* rcv_dt4, double rcv_ddt);
+/* gnss[8]: gnss_ready, lowspeed, #valid measurements of the newest frame, first_optimization, then 4 reserved; any pointer may be NULL.
+ * rcv_dt 4 (W+1), rcv_ddt (W+1), anc_ecef 3, ecef_pos 3, enu_pos 3 (updateGNSSStatistics, estimator.cpp:2045-2058) */
+int gf_estimator_get_gnss_state(gf_estimator* h, int* gnss, double* rcv_dt, double* rcv_ddt, double* yaw_enu_local, double* anc_ecef, double* ecef_pos, double* enu_pos);
 /* inputFeature + processMeasurements: one call = one processImage once IMU / wheel data cover the frame time */
 int gf_estimator_input_feature(gf_estimator* h, double t, const gf_feature_obs* obs, int n);
 /* inputImage: trackImage on the owned tracker, then inputFeature (every second frame when multiple_thread, estimator.cpp:226) */

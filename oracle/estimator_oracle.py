@@ -28,7 +28,47 @@ def default_cfg():
                 gyr_w=5.4692100664858005e-05, g_norm=9.805, wheel_vel_n=0.01, wheel_gyr_n=0.004, min_parallax_px=10.0, depth_threshold=3.0, init_depth=5.0,
                 focal_length=600.0, td=0.0, td_wheel=0.0, sx=1.0, sy=1.0, sw=1.0, tic=np.zeros(3), ric=np.eye(3),
                 tio=np.array([0.0497956, 1.06332, -0.037465]),
-                rio=np.array([[0.352551, -0.935764, -0.00734672], [0.0145238, 0.0133214, -0.999806], [0.93568, 0.352375, 0.0182873]]))
+                rio=np.array([[0.352551, -0.935764, -0.00734672], [0.0145238, 0.0133214, -0.999806], [0.93568, 0.352375, 0.0182873]]),
+                gnss_enable=0, gnss_track_num_thres=5, gnss_elevation_thres=30.0, gnss_psr_std_thres=2.0, gnss_dopp_std_thres=2.0, gnss_ddt_sigma=0.1,
+                gnss_local_time_diff=18.0,
+                gnss_iono=np.array([0.1118e-07, 0.2235e-07, -0.4172e-06, 0.6557e-06, 0.1249e+06, -0.4424e+06, 0.1507e+07, -0.2621e+06]))
+
+
+# ---------------------------------------------------------------- gnss_comm helpers the estimator itself calls (ecef2geo, ecef2rotation, sat_azel; RTKLIB lineage)
+def ecef2geo(p):
+    """latitude [deg], longitude [deg], height [m] (gnss_comm gnss_utility.cpp ecef2geo: Bowring's closed form)"""
+    x, y, z = (float(v) for v in p)
+    if x == 0 and y == 0:
+        return np.zeros(3)
+    a, e2 = 6378137.0, 6.69437999014e-3
+    a2 = a * a
+    b2 = a2 * (1 - e2)
+    b = math.sqrt(b2)
+    ep2 = (a2 - b2) / b2
+    rho = math.sqrt(x * x + y * y)
+    s1, s2 = z * a, rho * b
+    h = math.sqrt(s1 * s1 + s2 * s2)
+    st, ct = s1 / h, s2 / h
+    s1 = z + ep2 * b * st ** 3
+    s2 = rho - a * e2 * ct ** 3
+    h = math.sqrt(s1 * s1 + s2 * s2)
+    sin_lat, cos_lat = s1 / h, s2 / h
+    N = a2 / math.sqrt(a2 * cos_lat * cos_lat + b2 * sin_lat * sin_lat)
+    return np.array([math.degrees(math.atan(s1 / s2)), math.degrees(math.atan2(y, x)), rho / cos_lat - N])
+
+
+def ecef2rotation(p):
+    """R_ecef_enu at p"""
+    lla = ecef2geo(p)
+    lat, lon = math.radians(lla[0]), math.radians(lla[1])
+    sl, cl, so, co = math.sin(lat), math.cos(lat), math.sin(lon), math.cos(lon)
+    return np.array([[-so, -sl * co, cl * co], [co, -sl * so, cl * so], [0.0, cl, sl]])
+
+
+def sat_elevation(rcv, sat):
+    dl = np.asarray(sat, float) - np.asarray(rcv, float)
+    dl = dl / np.linalg.norm(dl)
+    return math.asin((ecef2rotation(rcv).T @ dl)[2])
 
 
 # ---------------------------------------------------------------- small rotation helpers (utility/utility.h)
@@ -431,6 +471,95 @@ class Estimator:
         self.n_optimizations = 0
         self.sum_of_back = self.sum_of_front = 0
         self.back_R0, self.back_P0 = np.eye(3), np.zeros(3)
+        # GNSS (estimator.h:293-331)
+        self.GNSSBuf, self.gnss_msg = [], []
+        self.gnss_meas_buf = [[] for _ in range(W + 1)]
+        self.sat_track_status = {}
+        self.gnss_ready, self.first_optimization, self.lowspeed = False, True, False
+        self.diff_t_gnss_local = c["gnss_local_time_diff"]
+        self.latest_gnss_iono_params = np.array(c["gnss_iono"], float)
+        self.para_rcv_dt, self.para_rcv_ddt = np.zeros((W + 1, 4)), np.zeros(W + 1)
+        self.yaw_enu_local, self.anc_ecef, self.R_ecef_enu = 0.0, np.zeros(3), np.eye(3)
+        self.ecef_pos, self.enu_pos = np.zeros(3), np.zeros(3)
+        self.alignment = None
+
+    # ---- GNSS
+    def inputGNSS(self, t, epoch):  # EST:397-404; epoch: list of dicts with the fields of gf_gnss_obs
+        assert len(epoch) >= 1
+        self.GNSSBuf.append((t, [dict(o) for o in epoch]))
+
+    def inputGNSSTimeDiff(self, t_diff):  # EST:1450-1453
+        self.diff_t_gnss_local = t_diff
+
+    def inputIonoParams(self, params):  # EST:1438-1448
+        self.latest_gnss_iono_params = np.array(params, float)
+
+    def setGNSSAlignment(self, anc_ecef, yaw_enu_local, rcv_dt, rcv_ddt):
+        """what GNSSVIInitializer would return (coarse_localization + yaw_alignment + anchor_refinement, EST:1972-2013); not restated"""
+        self.alignment = (np.array(anc_ecef, float), float(yaw_enu_local), np.array(rcv_dt, float), float(rcv_ddt))
+
+    def getGNSSInterval(self, t0, t1):  # EST:476-510
+        if not self.GNSSBuf:
+            return False
+        while self.GNSSBuf and self.GNSSBuf[0][1][0]["time"] < t1 + self.diff_t_gnss_local - 0.1:
+            self.GNSSBuf.pop(0)
+            if not self.GNSSBuf:
+                return False
+        self.gnss_msg = self.GNSSBuf.pop(0)[1]
+        return True
+
+    def processGNSS(self, gnss_meas):  # EST:1455-1535
+        c, valid = self.cfg, []
+        for obs in gnss_meas:
+            if not 0 <= obs["sys"] <= 3:
+                continue
+            if obs["psr_std"] > c["gnss_psr_std_thres"] or obs["dopp_std"] > c["gnss_dopp_std_thres"]:
+                self.sat_track_status[obs["sat"]] = 0
+                continue
+            self.sat_track_status[obs["sat"]] = self.sat_track_status.get(obs["sat"], 0) + 1
+            if self.sat_track_status[obs["sat"]] < c["gnss_track_num_thres"]:
+                continue
+            if self.gnss_ready and sat_elevation(self.ecef_pos, obs["sv_pos"]) < math.radians(c["gnss_elevation_thres"]):
+                continue
+            valid.append(obs)
+        self.gnss_meas_buf[self.frame_count] = valid
+
+    def _avg_hor_vel(self):
+        return np.linalg.norm(np.mean([np.abs(v[0:2]) for v in self.Vs], axis=0))
+
+    def GNSSVIAlign(self):  # EST:1928-2043
+        if not self.is_imu_excited and self.solver_flag == INITIAL:
+            return False
+        if self.gnss_ready:
+            return True
+        if self._avg_hor_vel() < 0.3:
+            return False
+        if self.alignment is None:
+            return False
+        anc, yaw, dt4, ddt = self.alignment
+        observed = [k for k in range(4) if dt4[k] != 0]
+        for i in range(self.W + 1):
+            self.para_rcv_ddt[i] = ddt
+            for k in range(4):
+                base = dt4[k] if dt4[k] != 0 else (dt4[observed[0]] if observed else 0.0)
+                self.para_rcv_dt[i, k] = base + ddt * i
+        self.anc_ecef, self.R_ecef_enu, self.yaw_enu_local = anc.copy(), ecef2rotation(anc), yaw
+        self.alignment = None
+        return True
+
+    def updateGNSSStatistics(self):  # EST:2045-2058
+        c, s = math.cos(self.yaw_enu_local), math.sin(self.yaw_enu_local)
+        p = self.Ps[self.W]
+        self.enu_pos = np.array([c * p[0] - s * p[1], s * p[0] + c * p[1], p[2]])
+        self.ecef_pos = self.anc_ecef + self.R_ecef_enu @ self.enu_pos
+
+    def _after_optimization_gnss(self):  # EST:945-956, :1014-1025, :1113-1123
+        if not self.cfg["gnss_enable"]:
+            return
+        if not self.gnss_ready:
+            self.gnss_ready = self.GNSSVIAlign()
+        if self.gnss_ready:
+            self.updateGNSSStatistics()
 
     # ---- intake
     def inputIMU(self, t, acc, gyr):  # EST:330-346
@@ -492,6 +621,8 @@ class Estimator:
             return False
         accV, gyrV = self._interval(self.accBuf, self.gyrBuf, self.prevTime, self.curTime) if self.cfg["use_imu"] else ([], [])
         self.featureBuf.pop(0)
+        if self.cfg["gnss_enable"]:
+            self.getGNSSInterval(self.prevTime, self.curTime)
         velV, wgyrV = self._interval(self.wheelVelBuf, self.wheelGyrBuf, self.prevTime_wheel, self.curTime_wheel) if self.cfg["use_wheel"] else ([], [])
         if self.cfg["use_imu"]:
             self.dP_imu = np.zeros(3)
@@ -510,6 +641,8 @@ class Estimator:
                 self.n_wheel_anomaly = getattr(self, "n_wheel_anomaly", 0) + 1   # test bookkeeping
             self.wheelstationary = np.linalg.norm(self.dP_wheel) < 0.001
             self.preintegrationstationary = np.linalg.norm(self.dP_imu) < 0.001
+        if self.cfg["gnss_enable"] and self.gnss_msg:
+            self.processGNSS(self.gnss_msg)
         self.processImage(image, t)
         self.prevTime, self.prevTime_wheel = self.curTime, self.curTime_wheel
         if self.solver_flag == NON_LINEAR or self.is_imu_excited:   # pubOdometry, EST:679 -> visualization.cpp:287-357 (what vio.txt receives)
@@ -679,6 +812,8 @@ class Estimator:
                         self.pre_integrations[i].repropagate(np.zeros(3), self.Bgs[i])
                     self.solver_flag = NON_LINEAR
                 self.optimization()
+                if result:
+                    self._after_optimization_gnss()
                 self.slideWindow()
             if self.frame_count < self.W:
                 self.frame_count += 1
@@ -692,6 +827,7 @@ class Estimator:
                 self.movingConsistencyCheckW(removeIndex)
                 self.f_manager.removeOutlier(removeIndex)
             self.optimization()
+            self._after_optimization_gnss()
             if not self.cfg["use_mcc"]:
                 inner = set()
                 self.movingConsistencyCheckW(inner)
@@ -722,6 +858,9 @@ class Estimator:
         st["para_Td"], st["para_Td_wheel"] = np.array([self.td], float), np.array([self.td_wheel], float)
         with np.errstate(all="ignore"):
             st["para_Feature"] = self.f_manager.getDepthVector()
+        if self.cfg["gnss_enable"]:   # para_rcv_dt / para_rcv_ddt ARE the state (estimator.h:305-308); yaw and anchor are copied when gnss_ready (:2347-2352)
+            st["para_rcv_dt"], st["para_rcv_ddt"] = self.para_rcv_dt.reshape(-1).copy(), self.para_rcv_ddt.copy()
+            st["para_yaw_enu_local"], st["para_anc_ecef"] = np.array([self.yaw_enu_local]), self.anc_ecef.copy()
         return st
 
     def double2vector(self, w):  # EST:2440-2569
@@ -742,6 +881,10 @@ class Estimator:
         with np.errstate(all="ignore"):
             self.f_manager.setDepth(w["para_Feature"])
         self.td = float(w["para_Td"][0])
+        if self.gnss_ready:  # :2562-2568 (the clock states live in para_rcv_dt / para_rcv_ddt themselves)
+            self.para_rcv_dt, self.para_rcv_ddt = w["para_rcv_dt"].reshape(-1, 4).copy(), w["para_rcv_ddt"].copy()
+            self.yaw_enu_local, self.anc_ecef = float(w["para_yaw_enu_local"][0]), w["para_anc_ecef"].copy()
+            self.R_ecef_enu = ecef2rotation(self.anc_ecef)
 
     def build_window(self):  # EST:2890-3297
         c, W, fc = self.cfg, self.W, self.frame_count
@@ -768,6 +911,32 @@ class Estimator:
         still = np.linalg.norm(self.Vs[0]) < 0.2
         w["fix_td"] = 1 if (not c["estimate_td"] or still) else 0
         w["fix_td_wheel"] = 1 if (not c["estimate_td_wheel"] or still) else 0
+        if self.gnss_ready:  # :2904-2941
+            self.lowspeed = bool(self._avg_hor_vel() < 0.3)
+        if self.first_optimization and c["gnss_enable"]:  # :2943-2951
+            w["has_anchor"], w["anchor_value"] = 1, w["para_Pose"][0].copy()
+            self.first_optimization = False
+        if c["gnss_enable"]:
+            gn = {k: [] for k in ("frame", "lower", "sys", "ratio", "data")}
+            if self.gnss_ready:  # :3178-3210; the factors of frame 0 also feed the MARGIN_OLD marginalisation (:3398-3418), lowspeed or not
+                for i in range(W + 1):
+                    for o in self.gnss_meas_buf[i]:
+                        obs_local_ts = o["time"] - self.diff_t_gnss_local
+                        if self.Headers[i] > obs_local_ts:
+                            lower = 0 if i == 0 else i - 1
+                        else:
+                            lower = W - 1 if i == W else i
+                        lower_ts, upper_ts = self.Headers[lower], self.Headers[lower + 1]
+                        gn["frame"].append(i)
+                        gn["lower"].append(lower)
+                        gn["sys"].append(o["sys"])
+                        gn["ratio"].append((upper_ts - obs_local_ts) / (upper_ts - lower_ts))
+                        gn["data"].append([*o["sv_pos"], *o["sv_vel"], o["svdt"], o["svddt"], o["tgd"], o["pr_uura"], o["dp_uura"], o["psr"], o["dopp"],
+                                           o["wavelength"], o["tow"], 0.0])
+            w["gnss_enabled"], w["gnss_lowspeed"] = int(self.gnss_ready), int(self.lowspeed)
+            w["gnss_frame"], w["gnss_lower"], w["gnss_sys"] = (np.array(gn[k], np.int32) for k in ("frame", "lower", "sys"))
+            w["gnss_ratio"], w["gnss_data"] = np.array(gn["ratio"], float), np.array(gn["data"], float).reshape(-1)
+            w["gnss_iono"], w["gnss_headers"], w["gnss_ddt_weight"] = self.latest_gnss_iono_params.copy(), np.array(self.Headers, float), 1.0 / c["gnss_ddt_sigma"]
         imu = {k: [] for k in ("i", "sum_dt", "delta_p", "delta_q", "delta_v", "lin_ba", "lin_bg", "jacobian", "covariance")}
         for i in range(fc):
             p = self.pre_integrations[i + 1]
@@ -830,6 +999,11 @@ class Estimator:
         self.last_window = w.copy()
         self.last_summary = O.ba_solve(w, self.cfg["num_iterations"])
         self.n_optimizations += 1
+        if self.cfg["gnss_enable"]:  # :3322-3325
+            while w["para_yaw_enu_local"][0] > math.pi:
+                w["para_yaw_enu_local"][0] -= 2.0 * math.pi
+            while w["para_yaw_enu_local"][0] < -math.pi:
+                w["para_yaw_enu_local"][0] += 2.0 * math.pi
         self.double2vector(w)
         if self.frame_count < self.W:
             self.wheelanomaly = False
@@ -840,6 +1014,7 @@ class Estimator:
         if run:
             w.update(self.vector2double())
             w.finalize()
+            self.last_marg_window = w.copy()   # test bookkeeping
             self.prior = O.ba_marginalize(w, self.marginalization_flag)
         self.wheelanomaly = False
 
@@ -855,6 +1030,11 @@ class Estimator:
                 lst.append(lst.pop(0))  # the chain of swaps rotates the oldest entry to the back
             if self.cfg["use_wheel"]:
                 self.pre_integrations_wheel.append(self.pre_integrations_wheel.pop(0))
+            if self.cfg["gnss_enable"]:  # :3674-3681, :3700-3704: buffers swap along, the clock states are copied down (the newest keeps its value)
+                self.gnss_meas_buf.append(self.gnss_meas_buf.pop(0))
+                self.gnss_meas_buf[W] = []
+                self.para_rcv_dt[0:W] = self.para_rcv_dt[1:W + 1].copy()
+                self.para_rcv_ddt[0:W] = self.para_rcv_ddt[1:W + 1].copy()
             self.Headers[W] = self.Headers[W - 1]
             for lst in (self.Ps, self.Rs, self.Vs, self.Bas, self.Bgs):
                 lst[W] = lst[W - 1].copy()
@@ -888,6 +1068,10 @@ class Estimator:
                     for dt, v, g_ in zip(src.dt, src.vel, src.gyr):
                         dst.push_back(dt, v, g_)
                 self.pre_integrations_wheel[W] = WheelPre(self.vel_0_wheel, self.gyr_0_wheel, self.sx, self.sy, self.sw, self.td_wheel, self.wheel_noise)
+            self.gnss_meas_buf[fc - 1] = self.gnss_meas_buf[fc]  # :3761-3768
+            self.gnss_meas_buf[fc] = []
+            self.para_rcv_dt[fc - 1] = self.para_rcv_dt[fc].copy()
+            self.para_rcv_ddt[fc - 1] = self.para_rcv_ddt[fc]
             self.sum_of_front += 1
             self.f_manager.removeFront(fc)
 

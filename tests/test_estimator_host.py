@@ -220,3 +220,54 @@ def test_empty_and_sparse_feature_frames():
         compare_features(est_o, est_p)
         k += 1
     assert est_o.frame_count == est_o.W
+
+
+def test_gnss_intake_during_the_fill_phase_matches_oracle():
+    """Estimator::inputGNSS / getGNSSInterval / processGNSS (estimator.cpp:397-404, :476-510, :1455-1535) while the window fills (no optimisation, no
+    GPU): epochs older than the frame by more than 0.1 s are thrown away, the front epoch is taken whatever its age, the last taken epoch is
+    processed again for every frame that finds the queue empty (gnss_msg is a member), satellites are admitted after gnss_track_num_thres good
+    epochs in a row and fall back to zero on one bad psr_std, other constellations are dropped."""
+    kw = dict(gnss_enable=1, gnss_track_num_thres=2, gnss_local_time_diff=18.0)
+    st, est_o, est_p = make_pair(4, **kw)
+    st.gnss_setup(sats_per_sys=2, n_low=1)
+    rng = np.random.default_rng(5)
+    tp, stale = -1.0, 0
+    for k in range(10):
+        tk = float(st.cam_t[k * STRIDE])
+        epochs = []
+        if k == 0:                                      # two epochs from long before the first frame: thrown away (EST:489-497)
+            epochs += [st.gnss_epoch(tk - 0.9), st.gnss_epoch(tk - 0.5)]
+        if k not in (3, 4, 8):                          # frames 3, 4 and 8 find the queue empty and reuse the previous epoch (EST:656-660)
+            epochs.append(st.gnss_epoch(tk + rng.uniform(-0.03, 0.03), flaky_sat=101 if k == 5 else None))
+        if k == 6:
+            epochs[-1][1].append(dict(epochs[-1][1][0], sat=900, sys=-1))   # a QZSS / SBAS satellite: filtered by system (EST:1463-1465)
+        for tg, ep in epochs:
+            est_o.inputGNSS(tg, ep)
+            est_p.inputGNSS(tg, ep)
+        if k == 7:
+            est_o.inputGNSSTimeDiff(18.0)
+            est_p.inputGNSSTimeDiff(18.0)
+        tp = feed(st, (est_o, est_p), k, tp)
+        buf = est_p.debug("gnss_meas_buf")
+        got, q = [], 0
+        for _ in range(est_o.W + 1):
+            n = int(buf[q])
+            got.append([int(x) for x in buf[q + 1:q + 1 + n]])
+            q += 1 + n
+        assert got == [[o["sat"] for o in b] for b in est_o.gnss_meas_buf], k
+        ts = est_p.debug("sat_track_status")
+        assert {int(a): int(b) for a, b in zip(ts[0::2], ts[1::2])} == est_o.sat_track_status, k
+        assert est_p.gnss_state()["queued"] == len(est_o.GNSSBuf)
+        stale += int(k in (3, 4, 8))
+    sizes = [len(b) for b in est_o.gnss_meas_buf]
+    assert sizes[0] == 0 and sizes[1] > 0 and sizes[3] == sizes[2] and max(sizes) == 9   # admitted from the second epoch on; reused epochs fill frames 3, 4, 8
+    assert est_o.sat_track_status[101] < est_o.sat_track_status[102]                 # the flaky satellite started over
+    assert 900 not in est_o.sat_track_status and not est_p.gnss_state()["gnss_ready"]
+    # inputs the boundary refuses
+    with pytest.raises(gfamd.GfError):
+        est_p.inputGNSS(1.0, [])
+    plain = gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg())
+    with pytest.raises(gfamd.GfError):
+        plain.inputGNSS(*st.gnss_epoch(0.5))
+    with pytest.raises(gfamd.GfError):
+        gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(gnss_enable=1, gnss_ddt_sigma=0.0))

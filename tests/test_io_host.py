@@ -114,8 +114,34 @@ def test_yaml_reader_follows_read_parameters(tmp_path):
     assert (t.fx, t.fy, t.cx, t.cy, t.k1, t.k2, t.p1, t.p2) == (611.5, 610.25, 320.5, 241.0, -0.01, 0.002, 1.0e-4, -2.0e-4)
 
 
+GNSS_KEYS = """gnss_local_online_sync: 0
+gnss_local_time_diff: 18.0
+gnss_elevation_thres: 30
+gnss_psr_std_thres: 2.0
+gnss_dopp_std_thres: 2.5
+gnss_track_num_thres: 20
+gnss_ddt_sigma: 0.1
+gnss_iono_default_parameters: !!opencv-matrix
+  rows: 1
+  cols: 8
+  dt: d
+  data: [0.1118E-07,  0.2235E-07, -0.4172E-06,  0.6557E-06,
+         0.1249E+06, -0.4424E+06,  0.1507E+07, -0.2621E+06]
+"""
+
+
+def test_yaml_reader_takes_the_gnss_keys(tmp_path):
+    # parameters.cpp:519-552
+    c = gfamd.estimator_cfg_from_yaml(write_cfg(tmp_path, CFG.replace("gnss_enable: 0", "gnss_enable: 1\n" + GNSS_KEYS)))
+    assert (c.gnss_enable, c.gnss_track_num_thres, c.gnss_local_time_diff, c.gnss_elevation_thres) == (1, 20, 18.0, 30.0)
+    assert (c.gnss_psr_std_thres, c.gnss_dopp_std_thres, c.gnss_ddt_sigma) == (2.0, 2.5, 0.1)
+    assert list(c.gnss_iono) == [0.1118e-07, 0.2235e-07, -0.4172e-06, 0.6557e-06, 0.1249e+06, -0.4424e+06, 0.1507e+07, -0.2621e+06]
+    assert gfamd.estimator_cfg_from_yaml(write_cfg(tmp_path)).gnss_enable == 0
+
+
 @pytest.mark.parametrize("edit,needle", [
-    (("gnss_enable: 0", "gnss_enable: 1"), "gnss_enable"),
+    (("gnss_enable: 0", "gnss_enable: 1"), "gnss_iono_default_parameters"),
+    (("gnss_enable: 0", "gnss_enable: 1\n" + GNSS_KEYS.replace("gnss_local_online_sync: 0", "gnss_local_online_sync: 1")), "gnss_local_online_sync"),
     (("num_of_cam: 1", "num_of_cam: 2"), "num_of_cam"),
     (("estimate_extrinsic: 1", "estimate_extrinsic: 2"), "estimate_extrinsic"),
     (("extrinsic_type: 0", "extrinsic_type: 3"), "extrinsic_type"),
@@ -149,7 +175,9 @@ def test_shipped_configs_parse_and_match_the_defaults():
         if k in ("tracker", "with_tracker"):
             continue
         a, b = getattr(c, k), getattr(d, k)
-        if k in ("tic", "ric", "tio", "rio"):
+        if k == "gnss_iono":
+            assert list(a) == list(b), k
+        elif k in ("tic", "ric", "tio", "rio"):
             assert np.allclose(list(a), list(b), atol=1e-6), k      # the yaml's body_T_wheel is orthonormal to 6 digits only; both are normalised
         else:
             assert a == b, k
@@ -170,7 +198,7 @@ def test_exported_dataset_config_round_trips(tmp_path):
         a, b = getattr(c, k), getattr(d, k)
         if k == "tracker":
             assert all(getattr(a, f) == getattr(b, f) for f, _ in gfamd.TrackerCfg._fields_)
-        elif k in ("tic", "ric", "tio", "rio"):
+        elif k in ("tic", "ric", "tio", "rio", "gnss_iono"):
             assert list(a) == list(b), k
         else:
             assert a == b, k
