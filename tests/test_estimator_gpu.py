@@ -234,7 +234,9 @@ def test_replay_with_gnss_matches_oracle(window_size):
     est_p = gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(**kw))
     est_o = EO.Estimator(dict(kw))
     tp, worst, orng = -1.0, dict(p=0.0, r=0.0, v=0.0, clk=0.0, anc=0.0, ecef=0.0, anc_low=0.0, ecef_low=0.0), np.random.default_rng(99)
-    seen, ready_frames, admitted = set(), 0, set()
+    seen, ready_frames, admitted, ate = set(), 0, set(), []
+    R0w = st.R_wb(st.cam_t[0])
+    theta0 = float(np.arctan2(R0w[1, 0], R0w[0, 0]))
     for k in range(len(st.cam_t)):
         for e in (est_o, est_p):
             t1 = st.feed(e, k, tp)
@@ -260,6 +262,9 @@ def test_replay_with_gnss_matches_oracle(window_size):
             q += 1 + n
         assert got == [[o["sat"] for o in b] for b in est_o.gnss_meas_buf], k
         seen.add((int(est_o.gnss_ready), int(est_o.lowspeed), est_o.marginalization_flag))
+        if est_o.solver_flag == EO.NON_LINEAR:   # absolute trajectory error of the product's newest pose against the stream's ground truth, in the estimator's local frame
+            s_ = est_p.state()
+            ate.append(np.linalg.norm(s_["Ps"][W] - SS.rot_z(-theta0) @ st.p_wb(s_["Headers"][W])))
         admitted |= {s for b in got for s in b}
         if est_o.gnss_ready:
             ready_frames += 1
@@ -275,7 +280,9 @@ def test_replay_with_gnss_matches_oracle(window_size):
     assert low <= admitted and not (low & {o["sat"] for o in est_o.gnss_meas_buf[W - 1]})   # admitted before the alignment, dropped by the elevation gate afterwards
     truth = G["anc"] + G["R_ew"] @ st.p_wb(est_o.Headers[W])
     assert np.linalg.norm(est_o.ecef_pos - truth) < 15.0                     # metres: a sane fix (the synthetic ranges carry no iono / tropo delay, the factor removes a modelled one)
-    print("gnss replay W=%d worst deviation" % W, worst)
+    rmse = float(np.sqrt(np.mean(np.square(ate))))
+    print("gnss replay W=%d worst deviation" % W, worst, "ATE rmse %.4f m over %d frames" % (rmse, len(ate)))
+    assert rmse < 0.05                                                       # 1.4 m of driving; observed 0.01
     assert worst["p"] < 1e-6 and worst["r"] < 1e-6, worst
     assert worst["clk"] < 1e-4 and worst["anc"] < 1e-4 and worst["ecef"] < 1e-4, worst
     assert worst["anc_low"] < 2e-3 and worst["ecef_low"] < 2e-3, worst
