@@ -25,14 +25,12 @@ struct LevelGeom {
     int w, h;          // interior size
     int stride;        // bytes per padded image row ( = w + 2*kPad )
     int img_off;       // byte offset of interior pixel (0,0) inside one image pyramid
-    int der_off;       // int32 (= short2) element offset of interior pixel (0,0) inside one derivative pyramid
 };
 
 struct PyrGeom {
     LevelGeom lv[kMaxLevels];
     int nlevels;
     size_t img_bytes;  // bytes of one image pyramid
-    size_t der_elems;  // short2 elements of one derivative pyramid
 };
 
 __device__ __forceinline__ int reflect101(int p, int len) {
@@ -63,7 +61,7 @@ __global__ void __launch_bounds__(256) pyr_level0_kernel(const uint8_t* __restri
 }
 
 // pyrDown (5-tap [1 4 6 4 1] separable, (s+128)>>8) from level l to l+1, written over the whole padded
-// domain of level l+1 (border pixels are the REFLECT_101 images of interior ones, recomputed in place).
+// domain of level l+1 (border pixels are the REFLECT_101 images of interior ones, recomputed in place).  Any level size.
 __global__ void __launch_bounds__(256) pyr_down_kernel(uint8_t* __restrict__ pyr, size_t pyr_seq_stride, LevelGeom s, LevelGeom d) {
     const int pw = d.w + 2 * kPad, ph = d.h + 2 * kPad;
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -83,42 +81,18 @@ __global__ void __launch_bounds__(256) pyr_down_kernel(uint8_t* __restrict__ pyr
     base[d.img_off + (py - kPad) * d.stride + (px - kPad)] = (uint8_t)((acc + 128) >> 8);
 }
 
-// Scharr derivative of every level: out = (dI/dx, dI/dy) as short2, kernels (3,10,3) x (-1,0,1).
-// grid.y = sequence, grid.z = level.  The derivative border stays zero (BORDER_CONSTANT).
-__global__ void __launch_bounds__(256) scharr_kernel(const uint8_t* __restrict__ pyr, size_t pyr_seq_stride, int* __restrict__ der,
-                                                     size_t der_seq_stride, PyrGeom G) {
-    const LevelGeom g = G.lv[blockIdx.z];
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= g.w * g.h) return;
-    int y = t / g.w, x = t - y * g.w;
-    const uint8_t* p = pyr + blockIdx.y * pyr_seq_stride + g.img_off + (size_t)y * g.stride + x;
-    const uint8_t* r0 = p - g.stride;
-    const uint8_t* r2 = p + g.stride;
-    int a0 = r0[-1], a1 = r0[0], a2 = r0[1];
-    int b0 = p[-1], b2 = p[1];
-    int c0 = r2[-1], c1 = r2[0], c2 = r2[1];
-    int dx = ((a2 + c2) * 3 + b2 * 10) - ((a0 + c0) * 3 + b0 * 10);
-    int dy = ((c2 - a2) + (c0 - a0)) * 3 + (c1 - a1) * 10;
-    der[blockIdx.y * der_seq_stride + g.der_off + (size_t)y * g.stride + x] = (dx & 0xffff) | (dy << 16);
-}
-
 // Four-pixel-per-thread variants for level widths that are multiples of 4 (640 / 320 / 160 / 80): aligned dword loads instead of byte
-// loads, one dword / int4 store per thread.  Same integer arithmetic as the scalar kernels above.
+// loads, one dword store per thread.  Same integer arithmetic as the scalar kernel above.
 __device__ __forceinline__ int byte_of(uint32_t v, int k) { return (int)((v >> (8 * k)) & 0xffu); }
 
-// pyrDown, interior of level l+1 only (the border is filled by pyr_border_kernel): thread = 4 consecutive output pixels of one row
-__global__ void __launch_bounds__(256) pyr_down4_kernel(uint8_t* __restrict__ pyr, size_t pyr_seq_stride, LevelGeom s, LevelGeom d) {
-    const int qw = d.w >> 2;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= qw * d.h) return;
-    const int y = t / qw, x = (t - y * qw) << 2;
-    uint8_t* base = pyr + blockIdx.y * pyr_seq_stride;
-    const uint8_t* sp = base + s.img_off + (size_t)(2 * y - 2) * s.stride + 2 * x;   // 8-byte aligned
+// four consecutive interior pixels (y, x .. x+3) of level d from level s (x a multiple of 4), packed into one dword
+__device__ __forceinline__ uint32_t pyr_down_quad(const uint8_t* __restrict__ base, const LevelGeom& s, int y, int x) {
+    const uint8_t* sp = base + s.img_off + (ptrdiff_t)(2 * y - 2) * s.stride + 2 * x;   // 8-byte aligned
     int acc[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int dy = 0; dy < 5; dy++) {
         const int ky = dy == 0 || dy == 4 ? 1 : (dy == 2 ? 6 : 4);
-        const uint32_t* r = reinterpret_cast<const uint32_t*>(sp + (size_t)dy * s.stride);
+        const uint32_t* r = reinterpret_cast<const uint32_t*>(sp + (ptrdiff_t)dy * s.stride);
         const uint32_t w0 = r[-1], w1 = r[0], w2 = r[1], w3 = r[2];   // source columns 2x-4 .. 2x+11
         int p[12];
 #pragma unroll
@@ -133,62 +107,124 @@ __global__ void __launch_bounds__(256) pyr_down4_kernel(uint8_t* __restrict__ py
     uint32_t out = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) out |= (uint32_t)((acc[i] + 128) >> 8) << (8 * i);
-    *reinterpret_cast<uint32_t*>(base + d.img_off + (size_t)y * d.stride + x) = out;
+    return out;
 }
-
-// REFLECT_101 border of one level from its own interior: thread = 4 destination bytes of the padded domain, interior groups are skipped
-__global__ void __launch_bounds__(256) pyr_border_kernel(uint8_t* __restrict__ pyr, size_t pyr_seq_stride, LevelGeom g) {
-    const int pw = g.w + 2 * kPad, ph = g.h + 2 * kPad, qw = pw >> 2;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= qw * ph) return;
-    const int py = t / qw, px = (t - py * qw) << 2;
-    if (py >= kPad && py < kPad + g.h && px >= kPad && px + 3 < kPad + g.w) return;
-    uint8_t* base = pyr + blockIdx.y * pyr_seq_stride + g.img_off;
-    const uint8_t* src = base + (size_t)reflect101(py - kPad, g.h) * g.stride;
-    uint32_t v = 0;
+// one pixel of level d at interior coordinates (y, x)
+__device__ __forceinline__ uint32_t pyr_down_one(const uint8_t* __restrict__ base, const LevelGeom& s, int y, int x) {
+    const uint8_t* sp = base + s.img_off + (ptrdiff_t)(2 * y - 2) * s.stride + (2 * x - 2);
+    int acc = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) v |= (uint32_t)src[reflect101(px + k - kPad, g.w)] << (8 * k);
-    *reinterpret_cast<uint32_t*>(base + (ptrdiff_t)(py - kPad) * g.stride + (px - kPad)) = v;
+    for (int dy = 0; dy < 5; dy++) {
+        const int ky = dy == 0 || dy == 4 ? 1 : (dy == 2 ? 6 : 4);
+        const uint8_t* r = sp + (ptrdiff_t)dy * s.stride;
+        acc += ky * (r[0] + 4 * r[1] + 6 * r[2] + 4 * r[3] + r[4]);
+    }
+    return (uint32_t)((acc + 128) >> 8);
 }
 
-// Scharr derivative, thread = 4 consecutive pixels of one row; grid.y = sequence, grid.z = level
-__global__ void __launch_bounds__(256) scharr4_kernel(const uint8_t* __restrict__ pyr, size_t pyr_seq_stride, int* __restrict__ der, size_t der_seq_stride, PyrGeom G) {
-    const LevelGeom g = G.lv[blockIdx.z];
-    const int qw = g.w >> 2;
+// Level l+1 from level l, interior AND its REFLECT_101 border in one pass: thread = four consecutive interior pixels (one dword).  A pixel within
+// kPad of an edge is also the source of border pixels (its mirror images across that edge, and across the corner): the thread that computed it
+// stores them too -- row mirrors as dwords, column mirrors as bytes (their dword would straddle an alignment boundary).  No pixel is filtered
+// twice and nothing is read back.  Needs d.w, d.h > kPad (one reflection reaches every border pixel) and d.w a multiple of 4.
+__global__ void __launch_bounds__(256) pyr_down_pad4_kernel(uint8_t* __restrict__ pyr, size_t pyr_seq_stride, LevelGeom s, LevelGeom d) {
+    const int qw = d.w >> 2;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= qw * g.h) return;
+    if (t >= qw * d.h) return;
     const int y = t / qw, x = (t - y * qw) << 2;
-    const uint8_t* p = pyr + blockIdx.y * pyr_seq_stride + g.img_off + (size_t)y * g.stride + x;
-    int a[6], b[6], c[6];   // columns x-1 .. x+4 of rows y-1, y, y+1
-    {
-        const uint32_t* r = reinterpret_cast<const uint32_t*>(p - g.stride);
-        const uint32_t l = r[-1], m = r[0], h2 = r[1];
-        a[0] = byte_of(l, 3); a[5] = byte_of(h2, 0);
+    uint8_t* base = pyr + blockIdx.y * pyr_seq_stride;
+    const uint32_t v = pyr_down_quad(base, s, y, x);
+    uint8_t* img = base + d.img_off;
+    // rows this pixel row is mirrored to: y itself, -y (1 <= y <= kPad), 2(h-1)-y (h-1-kPad <= y <= h-2)
+    int rows[3], nr = 0;
+    rows[nr++] = y;
+    if (y >= 1 && y <= kPad) rows[nr++] = -y;
+    if (y >= d.h - 1 - kPad && y <= d.h - 2) rows[nr++] = 2 * (d.h - 1) - y;
+    const bool left = x <= kPad, right = x + 3 >= d.w - 1 - kPad;   // some pixel of the quad has a column mirror
+    for (int q = 0; q < nr; q++) {
+        uint8_t* row = img + (ptrdiff_t)rows[q] * d.stride;
+        *reinterpret_cast<uint32_t*>(row + x) = v;
+        if (left) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) a[1 + k] = byte_of(m, k);
-    }
-    {
-        const uint32_t* r = reinterpret_cast<const uint32_t*>(p);
-        const uint32_t l = r[-1], m = r[0], h2 = r[1];
-        b[0] = byte_of(l, 3); b[5] = byte_of(h2, 0);
+            for (int k = 0; k < 4; k++) { const int c = x + k; if (c >= 1 && c <= kPad) row[-c] = (uint8_t)(v >> (8 * k)); }
+        }
+        if (right) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) b[1 + k] = byte_of(m, k);
+            for (int k = 0; k < 4; k++) { const int c = x + k; if (c >= d.w - 1 - kPad && c <= d.w - 2) row[2 * (d.w - 1) - c] = (uint8_t)(v >> (8 * k)); }
+        }
     }
-    {
-        const uint32_t* r = reinterpret_cast<const uint32_t*>(p + g.stride);
-        const uint32_t l = r[-1], m = r[0], h2 = r[1];
-        c[0] = byte_of(l, 3); c[5] = byte_of(h2, 0);
+}
+
+__device__ __forceinline__ int reflect_once(int p, int len) { return p < 0 ? -p : (p >= len ? 2 * len - 2 - p : p); }   // |overshoot| < len
+
+// one pixel of the next level from rows [row0, ...) of level s held in LDS without borders (REFLECT_101 by index)
+__device__ __forceinline__ uint32_t pyr_down_one_lds(const uint8_t* __restrict__ src, int sw, int sh, int row0, int y, int x) {
+    const int c0 = reflect_once(2 * x - 2, sw), c1 = reflect_once(2 * x - 1, sw), c2 = 2 * x, c3 = reflect_once(2 * x + 1, sw), c4 = reflect_once(2 * x + 2, sw);
+    int acc = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) c[1 + k] = byte_of(m, k);
+    for (int dy = 0; dy < 5; dy++) {
+        const int ky = dy == 0 || dy == 4 ? 1 : (dy == 2 ? 6 : 4);
+        const uint8_t* r = src + (reflect_once(2 * y - 2 + dy, sh) - row0) * sw;
+        acc += ky * (r[c0] + 4 * r[c1] + 6 * r[c2] + 4 * r[c3] + r[c4]);
     }
-    int o[4];
+    return (uint32_t)((acc + 128) >> 8);
+}
+
+// padded rows [ra, rb) of a level from their interior pixels in LDS (rows stored from row0), each also written to the border rows it mirrors to
+__device__ __forceinline__ void write_padded_rows(uint8_t* __restrict__ base, const LevelGeom& d, const uint8_t* __restrict__ lds, int row0, int ra, int rb) {
+    const int pw = d.w + 2 * kPad, qw = pw >> 2;
+    for (int t = threadIdx.x; t < qw * (rb - ra); t += blockDim.x) {
+        const int yy = t / qw, px = (t - yy * qw) << 2, y = ra + yy;
+        const uint8_t* src = lds + (y - row0) * d.w;
+        uint32_t v;
+        if (px >= kPad && px < kPad + d.w) v = *reinterpret_cast<const uint32_t*>(src + (px - kPad));
+        else {
+            v = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int dx = ((a[i + 2] + c[i + 2]) * 3 + b[i + 2] * 10) - ((a[i] + c[i]) * 3 + b[i] * 10);
-        const int dy = ((c[i + 2] - a[i + 2]) + (c[i] - a[i])) * 3 + (c[i + 1] - a[i + 1]) * 10;
-        o[i] = (dx & 0xffff) | (dy << 16);
+            for (int k = 0; k < 4; k++) v |= (uint32_t)src[reflect_once(px + k - kPad, d.w)] << (8 * k);
+        }
+        uint8_t* col = base + d.img_off + (px - kPad);
+        *reinterpret_cast<uint32_t*>(col + (ptrdiff_t)y * d.stride) = v;
+        if (y >= 1 && y <= kPad) *reinterpret_cast<uint32_t*>(col - (ptrdiff_t)y * d.stride) = v;
+        if (y >= d.h - 1 - kPad && y <= d.h - 2) *reinterpret_cast<uint32_t*>(col + (ptrdiff_t)(2 * (d.h - 1) - y) * d.stride) = v;
     }
-    *reinterpret_cast<int4*>(der + blockIdx.y * der_seq_stride + g.der_off + (size_t)y * g.stride + x) = make_int4(o[0], o[1], o[2], o[3]);
+}
+
+// The two small levels (160x120 and 80x60 at VGA) in ONE launch.  grid = (parts, sequences): a block owns a band of rows of level first+1 and
+// the rows of level `first` under it.  It filters the rows of level `first` it needs (band + 2 halo rows, 1.1x the work) from global memory into
+// LDS, writes its own rows of that level with their borders, filters its band of the next level from LDS and writes that with its borders.
+// Global memory is only written, never read back: no fence between the phases (a device-scope fence writes the whole L2 back: 250 us per launch).
+__global__ void __launch_bounds__(512) pyr_down_tail_kernel(uint8_t* __restrict__ pyr, size_t pyr_seq_stride, PyrGeom G, int first) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t pyr_sm[];
+    uint8_t* base = pyr + blockIdx.y * pyr_seq_stride;
+    const LevelGeom s = G.lv[first - 1], d = G.lv[first];
+    const bool two = first + 1 < G.nlevels;
+    const LevelGeom e = G.lv[two ? first + 1 : first];
+    const int parts = gridDim.x, p = blockIdx.x;
+    // band of the coarser level (or, without one, of level `first` in units of two rows)
+    const int nb = two ? e.h : (d.h + 1) / 2;
+    const int r0 = (int)((long long)nb * p / parts), r1 = (int)((long long)nb * (p + 1) / parts);
+    const int oa = min(d.h, 2 * r0), ob = p == parts - 1 ? d.h : min(d.h, 2 * r1);         // rows of level `first` this block writes
+    const int a = max(0, min(oa, 2 * r0 - 2)), b = min(d.h, max(ob, 2 * r1 + 1));           // rows it needs in LDS
+    uint8_t* ldsA = pyr_sm;
+    uint8_t* ldsB = pyr_sm + (size_t)(b - a) * d.w;
+    const int qi = d.w >> 2;
+    for (int t = threadIdx.x; t < qi * (b - a); t += blockDim.x) {
+        const int yy = t / qi, x = (t - yy * qi) << 2;
+        *reinterpret_cast<uint32_t*>(ldsA + yy * d.w + x) = pyr_down_quad(base, s, a + yy, x);
+    }
+    __syncthreads();
+    write_padded_rows(base, d, ldsA, a, oa, ob);
+    if (!two) return;
+    const int qe = e.w >> 2;
+    for (int t = threadIdx.x; t < qe * (r1 - r0); t += blockDim.x) {
+        const int yy = t / qe, x = (t - yy * qe) << 2;
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) v |= pyr_down_one_lds(ldsA, d.w, d.h, a, r0 + yy, x + k) << (8 * k);
+        *reinterpret_cast<uint32_t*>(ldsB + yy * e.w + x) = v;
+    }
+    __syncthreads();
+    write_padded_rows(base, e, ldsB, r0, r0, r1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -232,9 +268,52 @@ __device__ __forceinline__ int byte_of(uint32_t lo, uint32_t hi, int k) {
 
 struct LkImages {
     const uint8_t* I;   // template image pyramid (base of one pyramid)
-    const int* dI;      // its derivative pyramid (short2 packed in int)
     const uint8_t* J;   // moving image pyramid
 };
+
+// ---------------------------------------------------------------------------------------------
+// Scharr derivative (calcSharrDeriv, lkpyramid.cpp: kernels (3,10,3) x (-1,0,1)) evaluated where LK needs it, in packed 16-bit lanes.
+// A lane holds ten consecutive pixels of four image rows as u16 pairs (c0,c1)(c2,c3)...(c8,c9); from three rows it gets dI/dx and dI/dy of
+// the eight inner columns as s16 pairs (d1,d2)(d3,d4)(d5,d6)(d7,d8).  |3(a+c)+10b| <= 4080 and |d| <= 4080: nothing leaves 16 bits.
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2u as_v2u(uint32_t v) { return __builtin_bit_cast(v2u, v); }
+__device__ __forceinline__ v2s as_v2s(uint32_t v) { return __builtin_bit_cast(v2s, v); }
+__device__ __forceinline__ uint32_t as_u32(v2s v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t as_u32(v2u v) { return __builtin_bit_cast(uint32_t, v); }
+
+// ten pixels starting at byte o (0..3) of the 16 bytes at p (4-byte aligned), widened to five u16 pairs
+__device__ __forceinline__ void load_row10(const uint8_t* p, int o, uint32_t (&E)[5]) {
+    const U4a w = *reinterpret_cast<const U4a*>(p);
+    const uint32_t e0 = __builtin_amdgcn_alignbyte(w.y, w.x, o), e1 = __builtin_amdgcn_alignbyte(w.z, w.y, o), e2 = __builtin_amdgcn_alignbyte(w.w, w.z, o);
+    E[0] = __builtin_amdgcn_perm(0u, e0, 0x0c010c00u); E[1] = __builtin_amdgcn_perm(0u, e0, 0x0c030c02u);
+    E[2] = __builtin_amdgcn_perm(0u, e1, 0x0c010c00u); E[3] = __builtin_amdgcn_perm(0u, e1, 0x0c030c02u);
+    E[4] = __builtin_amdgcn_perm(0u, e2, 0x0c010c00u);
+}
+// rows A (y-1), B (y), C (y+1) -> derivative pairs of columns 1..8
+__device__ __forceinline__ void scharr8(const uint32_t (&A)[5], const uint32_t (&B)[5], const uint32_t (&C)[5], uint32_t (&DX)[4], uint32_t (&DY)[4]) {
+    v2u V[5]; v2s H[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        V[j] = (as_v2u(A[j]) + as_v2u(C[j])) * (unsigned short)3 + as_v2u(B[j]) * (unsigned short)10;   // 3 (a + c) + 10 b per column
+        H[j] = as_v2s(C[j]) - as_v2s(A[j]);                                                             // c - a per column
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        DX[m] = as_u32(__builtin_bit_cast(v2s, V[m + 1]) - __builtin_bit_cast(v2s, V[m]));             // V[x+1] - V[x-1] for x = 2m+1, 2m+2
+        const v2s Hodd = as_v2s(__builtin_amdgcn_alignbit(as_u32(H[m + 1]), as_u32(H[m]), 16));        // (H[2m+1], H[2m+2])
+        DY[m] = as_u32((H[m] + H[m + 1]) * (short)3 + Hodd * (short)10);                              // 3 (H[x-1] + H[x+1]) + 10 H[x]
+    }
+}
+// acc += a.lo * w.lo + a.hi * w.hi (signed 16-bit halves); w wave-uniform
+__device__ __forceinline__ int dot2_acc(int acc, uint32_t w, uint32_t a) {
+    asm("v_dot2c_i32_i16 %0, %1, %2" : "+v"(acc) : "s"(w), "v"(a));
+    return acc;
+}
+// the pair (p[k], p[k+1]) out of pairs P[m] = (p[2m], p[2m+1])
+__device__ __forceinline__ uint32_t pair_at(const uint32_t* P, int k) {
+    return (k & 1) ? __builtin_amdgcn_alignbit(P[(k + 1) >> 1], P[k >> 1], 16) : P[k >> 1];
+}
 
 // One pyramidal LK solve for one point by one wavefront.  All control flow is wave-uniform.
 // Lane l < 63 owns window row r = l/3 and the 7-pixel run starting at column 7*(l%3).
@@ -269,33 +348,36 @@ __device__ __forceinline__ int lk_solve(const PyrGeom& G, const LkImages im, flo
         int iw10 = uni(__float2int_rn((1.f - a) * b * 16384.f));
         int iw11 = 16384 - iw00 - iw01 - iw10;
 
-        // ---- template: bilinear I (5 fractional bits) and its derivative for this lane's 7 pixels
+        // ---- template: bilinear I (5 fractional bits) and bilinear Scharr derivative for this lane's 7 pixels.  The derivative is evaluated here
+        // from four image rows (16 B each) instead of being read from a derivative pyramid (32 B per row and pixel run, plus the pass that wrote it).
         int tI[7], tX[7], tY[7];
         int a11 = 0, a12 = 0, a22 = 0;
         {
-            const int x0 = ipx + 7 * s;
-            const uint8_t* irow = im.I + g.img_off + (ptrdiff_t)(ipy + r) * g.stride;
-            const int o = x0 & 3;
-            const uint32_t* q0 = reinterpret_cast<const uint32_t*>(irow + (x0 - o));
-            const uint32_t* q1 = reinterpret_cast<const uint32_t*>(irow + g.stride + (x0 - o));
-            uint32_t l0, h0, l1, h1;
-            align8(q0[0], q0[1], q0[2], o, l0, h0);
-            align8(q1[0], q1[1], q1[2], o, l1, h1);
-            const int* d0 = im.dI + g.der_off + (ptrdiff_t)(ipy + r) * g.stride + x0;
-            const int* d1 = d0 + g.stride;
-            U4a da0 = *reinterpret_cast<const U4a*>(d0), da1 = *reinterpret_cast<const U4a*>(d0 + 4);
-            U4a db0 = *reinterpret_cast<const U4a*>(d1), db1 = *reinterpret_cast<const U4a*>(d1 + 4);
-            const int top[8] = {(int)da0.x, (int)da0.y, (int)da0.z, (int)da0.w, (int)da1.x, (int)da1.y, (int)da1.z, (int)da1.w};
-            const int bot[8] = {(int)db0.x, (int)db0.y, (int)db0.z, (int)db0.w, (int)db1.x, (int)db1.y, (int)db1.z, (int)db1.w};
+            const int x0 = ipx + 7 * s, xb = x0 - 1, o = xb & 3;
+            const uint8_t* irow = im.I + g.img_off + (ptrdiff_t)(ipy + r - 1) * g.stride + (xb - o);
+            uint32_t R0[5], R1[5], R2[5], R3[5];   // image rows ipy+r-1 .. ipy+r+2, columns x0-1 .. x0+8
+            load_row10(irow, o, R0); load_row10(irow + g.stride, o, R1); load_row10(irow + 2 * g.stride, o, R2); load_row10(irow + 3 * g.stride, o, R3);
+            uint32_t XT[4], YT[4], XB[4], YB[4];   // derivative pairs of rows ipy+r (top) and ipy+r+1 (bottom), columns x0 .. x0+7
+            scharr8(R0, R1, R2, XT, YT);
+            scharr8(R1, R2, R3, XB, YB);
+            if (!(ipx >= 0 && ipy >= 0 && ipx + kWin < g.w && ipy + kWin < g.h)) {
+                // the window leaves the image: the derivative image is zero outside the interior (copyMakeBorder BORDER_CONSTANT in the reference)
+                const int yt = ipy + r;
+                const uint32_t mt = (yt >= 0 && yt < g.h) ? 0xffffffffu : 0u, mb = (yt + 1 >= 0 && yt + 1 < g.h) ? 0xffffffffu : 0u;
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const int xa = x0 + 2 * m;
+                    const uint32_t mx = ((xa >= 0 && xa < g.w) ? 0x0000ffffu : 0u) | ((xa + 1 >= 0 && xa + 1 < g.w) ? 0xffff0000u : 0u);
+                    XT[m] &= mx & mt; YT[m] &= mx & mt; XB[m] &= mx & mb; YB[m] &= mx & mb;
+                }
+            }
+            // bilinear weights as s16 pairs (iw11 >= -1): two v_dot2c per interpolation
+            const uint32_t w0 = ((uint32_t)iw00 & 0xffffu) | ((uint32_t)iw01 << 16), w1 = ((uint32_t)iw10 & 0xffffu) | ((uint32_t)iw11 << 16);
 #pragma unroll
             for (int k = 0; k < 7; k++) {
-                int i00 = byte_of(l0, h0, k), i01 = byte_of(l0, h0, k + 1), i10 = byte_of(l1, h1, k), i11 = byte_of(l1, h1, k + 1);
-                int iv = (__mul24(i00, iw00) + __mul24(i01, iw01) + __mul24(i10, iw10) + __mul24(i11, iw11) + (1 << 8)) >> 9;   // all operands < 2^15
-                int x00 = (short)(top[k] & 0xffff), x01 = (short)(top[k + 1] & 0xffff), x10 = (short)(bot[k] & 0xffff), x11 = (short)(bot[k + 1] & 0xffff);
-                int y00 = top[k] >> 16, y01 = top[k + 1] >> 16, y10 = bot[k] >> 16, y11 = bot[k + 1] >> 16;
-                int ix = (__mul24(x00, iw00) + __mul24(x01, iw01) + __mul24(x10, iw10) + __mul24(x11, iw11) + (1 << 13)) >> 14;
-                int iy = (__mul24(y00, iw00) + __mul24(y01, iw01) + __mul24(y10, iw10) + __mul24(y11, iw11) + (1 << 13)) >> 14;
-                ix = (short)ix; iy = (short)iy; iv = (short)iv;
+                int iv = dot2_acc(dot2_acc(1 << 8, w0, pair_at(R1, k + 1)), w1, pair_at(R2, k + 1)) >> 9;
+                int ix = dot2_acc(dot2_acc(1 << 13, w0, pair_at(XT, k)), w1, pair_at(XB, k)) >> 14;
+                int iy = dot2_acc(dot2_acc(1 << 13, w0, pair_at(YT, k)), w1, pair_at(YB, k)) >> 14;
                 if (!live) { ix = 0; iy = 0; iv = 0; }
                 tI[k] = iv; tX[k] = ix; tY[k] = iy;
                 a11 += __mul24(ix, ix); a12 += __mul24(ix, iy); a22 += __mul24(iy, iy);
@@ -397,7 +479,6 @@ __device__ __forceinline__ int lk_solve(const PyrGeom& G, const LkImages im, flo
 
 struct LkBatchArgs {
     const uint8_t* img;   // [batch][2 slots] image pyramids
-    const int* der;       // [batch][2 slots] derivative pyramids
     int prev_slot;        // slot holding the previous frame; cur = 1 - prev_slot
     int cap;              // per-sequence capacity of the point arrays
     const int* n_pts;     // [batch]
@@ -433,8 +514,6 @@ __global__ void __launch_bounds__(256, 8) lk_track_kernel(PyrGeom G, LkBatchArgs
     pp.x = unif(pp.x); pp.y = unif(pp.y);
     const uint8_t* prevI = A.img + ((size_t)b * 2 + A.prev_slot) * G.img_bytes;
     const uint8_t* curI = A.img + ((size_t)b * 2 + (1 - A.prev_slot)) * G.img_bytes;
-    const int* prevD = A.der + ((size_t)b * 2 + A.prev_slot) * G.der_elems;
-    const int* curD = A.der + ((size_t)b * 2 + (1 - A.prev_slot)) * G.der_elems;
     unsigned n_levels = 0, n_iters = 0;
     float cx, cy;
     int st;
@@ -442,12 +521,12 @@ __global__ void __launch_bounds__(256, 8) lk_track_kernel(PyrGeom G, LkBatchArgs
         const float2 ip = A.init_pts[pi];
         cx = unif(ip.x); cy = unif(ip.y);
     } else { cx = 0.f; cy = 0.f; }
-    st = lk_solve(G, LkImages{prevI, prevD, curI}, pp.x, pp.y, cx, cy, min(A.fwd_max_level, G.nlevels - 1), A.fwd_use_init != 0, tile, lane,
+    st = lk_solve(G, LkImages{prevI, curI}, pp.x, pp.y, cx, cy, min(A.fwd_max_level, G.nlevels - 1), A.fwd_use_init != 0, tile, lane,
                   n_levels, n_iters);
     const int fwd_st = st;
     if (A.flow_back && st) {
         float rx = pp.x, ry = pp.y;
-        int rst = lk_solve(G, LkImages{curI, curD, prevI}, cx, cy, rx, ry, min(1, G.nlevels - 1), true, tile, lane, n_levels, n_iters);
+        int rst = lk_solve(G, LkImages{curI, prevI}, cx, cy, rx, ry, min(1, G.nlevels - 1), true, tile, lane, n_levels, n_iters);
         const double ddx = (double)(pp.x - rx), ddy = (double)(pp.y - ry);
         st = (rst && sqrt(ddx * ddx + ddy * ddy) <= 0.5) ? 1 : 0;
     }
@@ -475,6 +554,25 @@ __global__ void __launch_bounds__(256, 8) lk_track_kernel(PyrGeom G, LkBatchArgs
         A.counters[2 * pi] = n_levels;
         A.counters[2 * pi + 1] = n_iters;
     }
+}
+
+// The derivative image of one level as lk_solve evaluates it (same device functions), for gf_pyramid_level's parity check against calcSharrDeriv:
+// thread = eight consecutive pixels of one row; out[y][x] = (dx, dy) as s16 pairs.
+__global__ void __launch_bounds__(256) deriv_probe_kernel(const uint8_t* __restrict__ pyr, LevelGeom g, int* __restrict__ out) {
+    const int q = (g.w + 7) >> 3;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= q * g.h) return;
+    const int y = t / q, x0 = (t - y * q) << 3, xb = x0 - 1, o = xb & 3;
+    const uint8_t* irow = pyr + g.img_off + (ptrdiff_t)(y - 1) * g.stride + (xb - o);
+    uint32_t R0[5], R1[5], R2[5], DX[4], DY[4];
+    load_row10(irow, o, R0); load_row10(irow + g.stride, o, R1); load_row10(irow + 2 * g.stride, o, R2);
+    scharr8(R0, R1, R2, DX, DY);
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (x0 + k < g.w) {
+            const uint32_t dx = (DX[k >> 1] >> (16 * (k & 1))) & 0xffffu, dy = (DY[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+            out[(size_t)y * g.w + x0 + k] = (int)(dx | (dy << 16));
+        }
 }
 
 }  // namespace gf

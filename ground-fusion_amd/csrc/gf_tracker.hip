@@ -135,7 +135,6 @@ static int build_geom(int w, int h, PyrGeom& G) {
         g.w = lw; g.h = lh; g.stride = lw + 2 * kPad;
         const size_t rows = lh + 2 * kPad;
         g.img_off = (int)(off + (size_t)kPad * g.stride + kPad);
-        g.der_off = g.img_off;
         off += rows * g.stride;
         off = (off + 255) & ~(size_t)255;
         lw = (lw + 1) / 2; lh = (lh + 1) / 2;
@@ -143,7 +142,6 @@ static int build_geom(int w, int h, PyrGeom& G) {
     }
     G.nlevels = level;
     G.img_bytes = off;
-    G.der_elems = off;
     return GF_OK;
 }
 
@@ -164,7 +162,7 @@ struct gf_tracker {
     HostPool* pool = nullptr;
     // device
     DevBuf<uint8_t> d_img, d_raw, d_mask, d_status, d_fwd_status, d_seqmask;
-    DevBuf<int> d_der, d_npts, d_cand_count, d_want, d_ncenters, d_out_n;
+    DevBuf<int> d_npts, d_cand_count, d_want, d_ncenters, d_out_n;
     DevBuf<uint16_t> d_depth, d_depth_out, d_out_depth;
     DevBuf<float2> d_prev_pts, d_init_pts, d_cur_pts, d_out_pts;
     DevBuf<unsigned> d_counters, d_maxkey;
@@ -182,7 +180,7 @@ struct gf_tracker {
     size_t select_lds = 0;
 
     void release() {
-        d_img.release(); d_raw.release(); d_mask.release(); d_status.release(); d_fwd_status.release(); d_seqmask.release(); d_der.release(); d_npts.release();
+        d_img.release(); d_raw.release(); d_mask.release(); d_status.release(); d_fwd_status.release(); d_seqmask.release(); d_npts.release();
         d_cand_count.release(); d_want.release(); d_ncenters.release(); d_out_n.release(); d_depth.release(); d_depth_out.release();
         d_out_depth.release(); d_prev_pts.release(); d_init_pts.release(); d_cur_pts.release(); d_out_pts.release(); d_counters.release();
         d_maxkey.release(); d_eig.release(); d_cand.release(); d_centers.release();
@@ -228,11 +226,12 @@ template <class V> static void reduce_vector(std::vector<V>& v, const uint8_t* s
     v.resize(j);
 }
 
+// buildOpticalFlowPyramid in three launches: level 0 (copy + REFLECT_101 border), level 1 (interior + border in one pass), and one kernel for
+// all remaining levels.  There is no derivative pyramid: lk_solve evaluates the Scharr derivative of the template window itself.
 static int launch_pyramid(gf_tracker* h, const uint8_t* d_raw_frames) {
     const PyrGeom& G = h->G;
-    const size_t seq_img = 2 * G.img_bytes, seq_der = 2 * G.der_elems;
+    const size_t seq_img = 2 * G.img_bytes;
     uint8_t* img = h->d_img.p + (size_t)h->cur_slot * G.img_bytes;
-    int* der = h->d_der.p + (size_t)h->cur_slot * G.der_elems;
     const LevelGeom g0 = G.lv[0];
     {
         const int n = ((g0.w + 2 * kPad) / 4) * (g0.h + 2 * kPad);
@@ -240,18 +239,28 @@ static int launch_pyramid(gf_tracker* h, const uint8_t* d_raw_frames) {
     }
     bool vec = true;   // four-pixel kernels need level widths (and with them strides, offsets) that are multiples of 4
     for (int l = 0; l < G.nlevels; l++) vec = vec && !(G.lv[l].w & 3) && !(G.lv[l].img_off & 3);
-    for (int l = 1; l < G.nlevels; l++) {
-        const LevelGeom d = G.lv[l];
-        if (vec) {
-            pyr_down4_kernel<<<dim3(((d.w >> 2) * d.h + 255) / 256, h->B), 256, 0, h->stream>>>(img, seq_img, G.lv[l - 1], d);
-            pyr_border_kernel<<<dim3((((d.w + 2 * kPad) >> 2) * (d.h + 2 * kPad) + 255) / 256, h->B), 256, 0, h->stream>>>(img, seq_img, d);
-        } else {
+    for (int l = 1; l < G.nlevels; l++) vec = vec && G.lv[l].w > kPad + 1 && G.lv[l].h > kPad + 1;   // one reflection reaches every border pixel
+    if (vec) {
+        auto down = [&](int l) {
+            const LevelGeom d = G.lv[l];
+            pyr_down_pad4_kernel<<<dim3(((d.w >> 2) * d.h + 255) / 256, h->B), 256, 0, h->stream>>>(img, seq_img, G.lv[l - 1], d);
+        };
+        if (G.nlevels > 1) down(1);
+        if (G.nlevels > 2) {
+            const int parts = 4, last = std::min(G.nlevels - 1, 3);
+            const LevelGeom d = G.lv[2], e = G.lv[last];
+            const int band = last > 2 ? (e.h + parts - 1) / parts + 1 : ((d.h + 1) / 2 + parts - 1) / parts + 1;
+            const size_t lds = (size_t)(2 * band + 4) * d.w + (last > 2 ? (size_t)band * e.w : 0);
+            if (G.nlevels <= 4 && lds <= 64 * 1024) pyr_down_tail_kernel<<<dim3(parts, h->B), 512, lds, h->stream>>>(img, seq_img, G, 2);
+            else for (int l = 2; l < G.nlevels; l++) down(l);
+        }
+    } else {
+        for (int l = 1; l < G.nlevels; l++) {
+            const LevelGeom d = G.lv[l];
             const int n = (d.w + 2 * kPad) * (d.h + 2 * kPad);
             pyr_down_kernel<<<dim3((n + 255) / 256, h->B), 256, 0, h->stream>>>(img, seq_img, G.lv[l - 1], d);
         }
     }
-    if (vec) scharr4_kernel<<<dim3(((g0.w >> 2) * g0.h + 255) / 256, h->B, G.nlevels), 256, 0, h->stream>>>(img, seq_img, der, seq_der, G);
-    else scharr_kernel<<<dim3((g0.w * g0.h + 255) / 256, h->B, G.nlevels), 256, 0, h->stream>>>(img, seq_img, der, seq_der, G);
     HIPCHK(hipGetLastError());
     return GF_OK;
 }
@@ -259,7 +268,7 @@ static int launch_pyramid(gf_tracker* h, const uint8_t* d_raw_frames) {
 static LkBatchArgs lk_args(gf_tracker* h, int fwd_max_level, int use_init, int flow_back, int post_checks, const uint8_t* seqmask,
                            const uint16_t* d_depth) {
     LkBatchArgs A{};
-    A.img = h->d_img.p; A.der = h->d_der.p; A.prev_slot = 1 - h->cur_slot; A.cap = h->cap;
+    A.img = h->d_img.p; A.prev_slot = 1 - h->cur_slot; A.cap = h->cap;
     A.n_pts = h->d_npts.p; A.prev_pts = h->d_prev_pts.p; A.init_pts = h->d_init_pts.p; A.cur_pts = h->d_cur_pts.p;
     A.status = h->d_status.p; A.fwd_status = h->d_fwd_status.p; A.depth_out = h->d_depth_out.p; A.depth = d_depth;
     A.depth_seq_stride = (size_t)h->cfg.width * h->cfg.height; A.depth_stride = h->cfg.width;
@@ -588,7 +597,6 @@ int gf_tracker_create(const gf_tracker_cfg* cfg, gf_tracker** out) {
     H_(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (auto& e : h->ev) H_(hipEventCreate(&e));
     A_(h->d_img.alloc((size_t)B * 2 * h->G.img_bytes));
-    A_(h->d_der.alloc((size_t)B * 2 * h->G.der_elems));
     A_(h->d_raw.alloc((size_t)B * W * H));
     A_(h->d_depth.alloc((size_t)B * W * H));
     A_(h->d_mask.alloc(h->mask_stride));  // explicit masks exist only in the gf_good_features building block
@@ -604,7 +612,6 @@ int gf_tracker_create(const gf_tracker_cfg* cfg, gf_tracker** out) {
     A_(h->h_status.alloc((size_t)B * cap)); A_(h->h_fwd_status.alloc((size_t)B * cap)); A_(h->h_seqmask.alloc(2 * (size_t)B)); A_(h->h_depth_out.alloc((size_t)B * cap)); A_(h->h_out_depth.alloc((size_t)B * cap));
     A_(h->h_counters.alloc((size_t)B * cap * 2)); A_(h->h_centers.alloc((size_t)B * cap));
     H_(hipMemsetAsync(h->d_img.p, 0, h->d_img.n, h->stream));
-    H_(hipMemsetAsync(h->d_der.p, 0, h->d_der.n * sizeof(int), h->stream));  // derivative borders stay zero for ever
     H_(hipFuncSetAttribute(reinterpret_cast<const void*>(gf::select_corners_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->select_lds));
     H_(hipStreamSynchronize(h->stream));
 #undef A_
@@ -757,7 +764,15 @@ int gf_pyramid_level(const uint8_t* img, int width, int height, int level, uint8
         HIPCHK(hipStreamSynchronize(h->stream));
         const gf::LevelGeom g = h->G.lv[level];
         if (out) HIPCHK(hipMemcpy2D(out, g.w, h->d_img.p + g.img_off, g.stride, g.w, g.h, hipMemcpyDeviceToHost));
-        if (deriv_xy) HIPCHK(hipMemcpy2D(deriv_xy, (size_t)g.w * 4, h->d_der.p + g.der_off, (size_t)g.stride * 4, (size_t)g.w * 4, g.h, hipMemcpyDeviceToHost));
+        if (deriv_xy) {   // the derivative as lk_solve evaluates it (deriv_probe_kernel calls the same device functions)
+            gf::DevBuf<int> d;
+            if (int r = d.alloc((size_t)g.w * g.h)) return r;
+            gf::deriv_probe_kernel<<<dim3((((g.w + 7) >> 3) * g.h + 255) / 256), 256, 0, h->stream>>>(h->d_img.p, g, d.p);
+            HIPCHK(hipGetLastError());
+            const hipError_t e = hipMemcpy(deriv_xy, d.p, (size_t)g.w * g.h * 4, hipMemcpyDeviceToHost);
+            d.release();
+            HIPCHK(e);
+        }
         return GF_OK;
     };
     int rc = body();
