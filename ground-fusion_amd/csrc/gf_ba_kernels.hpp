@@ -1105,12 +1105,23 @@ __device__ __forceinline__ double row_bcast(double v, int j) {   // j must fold 
         case 12: return row_bcast_c<12>(v); case 13: return row_bcast_c<13>(v); case 14: return row_bcast_c<14>(v); default: return row_bcast_c<15>(v);
     }
 }
-template <bool INV = true>
-__device__ inline bool wave_chol16_inv(double* s_L, double* s_inv, double* s_rdiag, int lane) {
-    const int r = lane & 15;   // the four 16-lane groups work redundantly on identical data, so lane j of the wavefront speaks for row j
-    double a[16], rd[16];
+// Factor and explicit inverse of a 16x16 block in ONE sweep of 16 dependent steps (the serial part of ba_step's blocked Cholesky).
+// Lane (g, r) = (lane >> 4, lane & 15) holds row r of the block -- the four 16-lane groups factor redundantly, which keeps every broadcast inside a
+// DPP row -- and the entries W[r][4m + g], m = 0..3, of W = L^-1: the groups split the columns of the inverse between them.
+//   W[r][c] = (delta_rc - sum_{k<r} L[r][k] W[k][c]) / L[r][r]
+// Step j knows column j of L and (scaling by 1 / L_jj) row j of W; it removes their product from the accumulators t_r[c] of the rows below.
+// Against factor + separate forward substitution (two chains of 16 steps, the second one fed by LDS broadcasts): 10.2 k -> ~5 k cycles per block.
+// The block is read straight from the packed lower triangle S (rows / columns j0 .. j0 + nb - 1, padded with the identity); the inverse goes to s_inv
+// (operand of the panel product) and, packed, back into S in place of the block -- the factor itself is not needed again.
+template <class SPtr>
+__device__ inline bool wave_chol16_fused(SPtr S, int j0, int nb, double* s_inv, double* s_rdiag, int lane) {
+    const int r = lane & 15, g = lane >> 4;
+    double a[16], rd[16], t[4];
 #pragma unroll
-    for (int c = 0; c < 16; c++) a[c] = s_L[r * 17 + c];
+    for (int c = 0; c < 16; c++) a[c] = (r < nb && c < nb) ? S[pk(j0 + max(r, c), j0 + min(r, c))] : (r == c ? 1.0 : 0.0);
+#pragma unroll
+    for (int m = 0; m < 4; m++) t[m] = (4 * m + g == r) ? 1.0 : 0.0;
+    double rd_own = 0.0;
     bool good = true;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
@@ -1122,47 +1133,29 @@ __device__ inline bool wave_chol16_inv(double* s_L, double* s_inv, double* s_rdi
         rd[j] = rs;                                         // 1 / L_jj
         const double l = (r == j) ? piv * rs : a[j] * rs;   // L_rj (rows r >= j)
         a[j] = l;
+        if (r == j) rd_own = rs;
+        const double lm = (r > j) ? l : 0.0;
+#pragma unroll
+        for (int m = 0; 4 * m <= j; m++) {                  // columns 4m + g <= j carry something; a larger column index has t = 0 in row j
+            const double wjc = row_bcast(t[m], j) * rs;     // W[j][4m + g]
+            t[m] -= lm * wjc;
+        }
 #pragma unroll
         for (int c = j + 1; c < 16; c++) a[c] -= l * row_bcast(l, c);   // L_rj * L_cj
-    }
-    if (lane < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; c++) s_L[r * 17 + c] = (c <= r) ? a[c] : 0.0;
     }
     if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < 16; c++) s_rdiag[c] = rd[c];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const int c = 4 * m + g;
+        const double w = t[m] * rd_own;
+        s_inv[r * 17 + c] = w;
+        if (c <= r && r < nb) S[pk(j0 + r, j0 + c)] = w;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
     return good;
-}
-
-// Explicit inverse of the 16x16 lower-triangular factor in s_L (reciprocal diagonal in s_rdiag): lane j solves L x = e_j (column j of L^-1);
-// L is read as LDS broadcasts, one column ahead of its use (the 16 steps are a dependent chain).  All 64 lanes must call it.
-__device__ inline void wave_tri_inv16(const double* s_L, double* s_inv, const double* s_rdiag, int lane) {
-    const int j = lane & 15;
-    double x[16], lc[16], ln[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) x[i] = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-    for (int i = 1; i < 16; i++) lc[i] = s_L[i * 17];
-    // right-looking: once x[k] is final every later row takes its contribution -- 15 - k independent FMAs per step
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-#pragma unroll
-        for (int i = k + 2; i < 16; i++) ln[i] = s_L[i * 17 + k + 1];
-        x[k] *= s_rdiag[k];
-#pragma unroll
-        for (int i = k + 1; i < 16; i++) x[i] -= lc[i] * x[k];
-#pragma unroll
-        for (int i = k + 2; i < 16; i++) lc[i] = ln[i];
-    }
-    if (lane < 16) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) s_inv[i * 17 + j] = x[i];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
 }
 
 // One 512-thread block per window: accept/reject of the previous candidate (trust_region_minimizer.cc), then the next
@@ -1174,7 +1167,7 @@ template <bool GS>
 __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, int max_iters, int finalize_only) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double sred[512];
-    __shared__ double s_blk[16 * 17], s_inv[16 * 17];
+    __shared__ double s_inv[16 * 17];
     __shared__ double s_y[16];
     __shared__ int s_flag[4];
     __shared__ int s_cmap[256];      // compact column -> reduced column (or -1), right-hand-side slot -> R
@@ -1445,7 +1438,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
 #else
 #define GF_SUB(acc) do { } while (0)
 #endif
-            // diagonal block j0: copy to s_blk, in-register factor + explicit inverse, copy the factor back (wavefront 0 only)
+            // diagonal block j0: in-register factor + explicit inverse (wavefront 0 only)
             auto diag_block = [&](int j0) {
                 const int nb = min(16, R - j0);
 #ifdef GF_PROFILE_STEP
@@ -1454,15 +1447,13 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
 #else
 #define GF_DSUB(i) do { } while (0)
 #endif
-                for (int i = lane; i < 256; i += 64) { const int r = i >> 4, c = i & 15; s_blk[r * 17 + c] = (r < nb && c < nb) ? S[pk(j0 + max(r, c), j0 + min(r, c))] : (r == c ? 1.0 : 0.0); }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
                 GF_DSUB(24);
-                const bool good = wave_chol16_inv<false>(s_blk, s_inv, s_rd + j0, lane);
+                // the diagonal block of S receives the INVERSE of its factor: the panel below is multiplied with it (MFMA), and the backward
+                // substitution becomes a 16x16 product per block instead of a chain of 16 dependent steps
+                const bool good = wave_chol16_fused(S, j0, nb, s_inv, s_rd + j0, lane);
                 GF_DSUB(25);
-                wave_tri_inv16(s_blk, s_inv, s_rd + j0, lane);
                 GF_DSUB(26);
                 if (!good && lane == 0) s_flag[1] = 0;
-                for (int i = lane; i < 256; i += 64) { const int r = i >> 4, c = i & 15; if (c <= r && r < nb) S[pk(j0 + r, j0 + c)] = s_blk[r * 17 + c]; }
                 GF_DSUB(27);
             };
             // one 16x16 tile (ti, tk) of the trailing update A22 -= L21 L21^T
@@ -1541,14 +1532,14 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                     const int nb = min(16, R - j0);
                     if (wave == 0) {
                         double z = lane < nb ? S[pk(R, j0 + lane)] : 0.0;
-                        double lc[16], rdv[16];   // column `lane` of the diagonal block and the reciprocal pivots, fetched before the serial chain
+                        const int cc = lane & 15;
+                        double wc[16];   // column cc of the block's inverse factor (stored in place of the factor): y_c = sum_{r >= c} Linv[r][c] z_r
 #pragma unroll
-                        for (int c = 0; c < 16; c++) { lc[c] = (c < nb && (lane & 15) < c) ? S[pk(j0 + c, j0 + (lane & 15))] : 0.0; rdv[c] = c < nb ? s_rd[j0 + c] : 0.0; }
+                        for (int rr = 0; rr < 16; rr++) wc[rr] = (rr < nb && cc <= rr) ? S[pk(j0 + rr, j0 + cc)] : 0.0;
+                        double y0 = 0.0, y1 = 0.0;
 #pragma unroll
-                        for (int c = 15; c >= 0; c--) {
-                            const double yc = row_bcast(z, c) * rdv[c];
-                            if ((lane & 15) == c) z = yc; else z -= lc[c] * yc;
-                        }
+                        for (int rr = 0; rr < 16; rr += 2) { y0 += wc[rr] * row_bcast(z, rr); y1 += wc[rr + 1] * row_bcast(z, rr + 1); }
+                        z = y0 + y1;
                         if (lane < nb) { s_y[lane] = z; yv[j0 + lane] = z; }
                         if (lane >= nb && lane < 16) s_y[lane] = 0.0;
                     }

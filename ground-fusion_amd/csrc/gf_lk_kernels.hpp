@@ -305,10 +305,9 @@ __device__ __forceinline__ void scharr8(const uint32_t (&A)[5], const uint32_t (
         DY[m] = as_u32((H[m] + H[m + 1]) * (short)3 + Hodd * (short)10);                              // 3 (H[x-1] + H[x+1]) + 10 H[x]
     }
 }
-// acc += a.lo * w.lo + a.hi * w.hi (signed 16-bit halves); w wave-uniform
+// acc + a.lo * w.lo + a.hi * w.hi (signed 16-bit halves): v_dot2c_i32_i16
 __device__ __forceinline__ int dot2_acc(int acc, uint32_t w, uint32_t a) {
-    asm("v_dot2c_i32_i16 %0, %1, %2" : "+v"(acc) : "s"(w), "v"(a));
-    return acc;
+    return __builtin_amdgcn_sdot2(as_v2s(a), as_v2s(w), acc, false);
 }
 // the pair (p[k], p[k+1]) out of pairs P[m] = (p[2m], p[2m+1])
 __device__ __forceinline__ uint32_t pair_at(const uint32_t* P, int k) {
@@ -379,7 +378,8 @@ __device__ __forceinline__ int lk_solve(const PyrGeom& G, const LkImages im, flo
                 int ix = dot2_acc(dot2_acc(1 << 13, w0, pair_at(XT, k)), w1, pair_at(XB, k)) >> 14;
                 int iy = dot2_acc(dot2_acc(1 << 13, w0, pair_at(YT, k)), w1, pair_at(YB, k)) >> 14;
                 if (!live) { ix = 0; iy = 0; iv = 0; }
-                tI[k] = iv; tX[k] = ix; tY[k] = iy;
+                tI[k] = (1 << 8) - (iv << 9);   // the iteration's accumulator start: (raw >> 9) - iv == (raw - (iv << 9)) >> 9
+                tX[k] = ix; tY[k] = iy;
                 a11 += __mul24(ix, ix); a12 += __mul24(ix, iy); a22 += __mul24(iy, iy);
             }
         }
@@ -428,29 +428,21 @@ __device__ __forceinline__ int lk_solve(const PyrGeom& G, const LkImages im, flo
                 const int o = xo & 3;
                 const uint32_t* q0 = reinterpret_cast<const uint32_t*>(tile + __mul24(iny - ty0 + r, kTileStride) + (xo - o));
                 const uint32_t* q1 = q0 + kTileStride / 4;
-                uint32_t l0, h0, l1, h1;
+                uint32_t l0, h0, l1, h1;   // bytes 0..7 of the lane's run in window rows r and r + 1
                 align8(q0[0], q0[1], q0[2], o, l0, h0);
                 align8(q1[0], q1[1], q1[2], o, l1, h1);
-                const uint32_t m0 = __builtin_amdgcn_alignbyte(h0, l0, 3), m1 = __builtin_amdgcn_alignbyte(h1, l1, 3);   // bytes 3..6 of each row
-                // weights split into 7-bit halves (w = 128 * wh + wl, wh <= 128): the 4-tap sum becomes two v_dot4_u32_u8.
-                // iw11 = 2^14 - iw00 - iw01 - iw10 is >= -1 (three roundings of at most 1/2 each): the unsigned dots take iw11 + 1 and the extra
-                // J[r+1][k+1] is subtracted again.  The weights are wave-uniform: pinned to SGPRs so that the packing runs on the scalar unit.
-                int sw00 = __builtin_amdgcn_readfirstlane(iw00), sw01 = __builtin_amdgcn_readfirstlane(iw01), sw10 = __builtin_amdgcn_readfirstlane(iw10),
-                    sw11 = __builtin_amdgcn_readfirstlane(iw11 + 1);
-                asm volatile("" : "+s"(sw00), "+s"(sw01), "+s"(sw10), "+s"(sw11));
-                const uint32_t wh = (uint32_t)(sw00 >> 7) | ((uint32_t)(sw01 >> 7) << 8) | ((uint32_t)(sw10 >> 7) << 16) | ((uint32_t)(sw11 >> 7) << 24);
-                const uint32_t wl = (uint32_t)(sw00 & 127) | ((uint32_t)(sw01 & 127) << 8) | ((uint32_t)(sw10 & 127) << 16) | ((uint32_t)(sw11 & 127) << 24);
+                // (J[k], J[k+1]) as u16 pairs, k = 0..6, for both rows; the bilinear sample is two v_dot2c_i32_i16 against the s16 weight pairs
+                // (iw11 = 2^14 - iw00 - iw01 - iw10 >= -1), started from 2^8 - (I << 9) of the template pixel
+                const uint32_t w0 = ((uint32_t)iw00 & 0xffffu) | ((uint32_t)iw01 << 16), w1 = ((uint32_t)iw10 & 0xffffu) | ((uint32_t)iw11 << 16);
+                const uint32_t T[7] = {__builtin_amdgcn_perm(0u, l0, 0x0c010c00u), __builtin_amdgcn_perm(0u, l0, 0x0c020c01u), __builtin_amdgcn_perm(0u, l0, 0x0c030c02u),
+                                       __builtin_amdgcn_perm(h0, l0, 0x0c040c03u), __builtin_amdgcn_perm(0u, h0, 0x0c010c00u), __builtin_amdgcn_perm(0u, h0, 0x0c020c01u),
+                                       __builtin_amdgcn_perm(0u, h0, 0x0c030c02u)};
+                const uint32_t Bt[7] = {__builtin_amdgcn_perm(0u, l1, 0x0c010c00u), __builtin_amdgcn_perm(0u, l1, 0x0c020c01u), __builtin_amdgcn_perm(0u, l1, 0x0c030c02u),
+                                        __builtin_amdgcn_perm(h1, l1, 0x0c040c03u), __builtin_amdgcn_perm(0u, h1, 0x0c010c00u), __builtin_amdgcn_perm(0u, h1, 0x0c020c01u),
+                                        __builtin_amdgcn_perm(0u, h1, 0x0c030c02u)};
 #pragma unroll
                 for (int k = 0; k < 7; k++) {
-                    // p = { J[r][k], J[r][k+1], J[r+1][k], J[r+1][k+1] }
-                    const uint32_t s0 = k < 3 ? l0 : k == 3 ? m0 : h0, s1 = k < 3 ? l1 : k == 3 ? m1 : h1;
-                    const int kb = k < 3 ? k : k == 3 ? 0 : k - 4;
-                    const uint32_t sel = (uint32_t)kb | ((uint32_t)(kb + 1) << 8) | ((uint32_t)(4 + kb) << 16) | ((uint32_t)(5 + kb) << 24);
-                    const uint32_t pq = __builtin_amdgcn_perm(s1, s0, sel);
-                    const uint32_t hi = __builtin_amdgcn_udot4(pq, wh, 0u, false);
-                    const uint32_t lo = __builtin_amdgcn_udot4(pq, wl, 256u, false);
-                    const int raw = (int)((hi << 7) + lo - (pq >> 24));
-                    const int diff = (raw >> 9) - tI[k];
+                    const int diff = dot2_acc(dot2_acc(tI[k], w0, T[k]), w1, Bt[k]) >> 9;
                     b1 = mad_i24(diff, tX[k], b1);
                     b2 = mad_i24(diff, tY[k], b2);
                 }

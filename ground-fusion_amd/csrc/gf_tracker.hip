@@ -768,8 +768,9 @@ int gf_pyramid_level(const uint8_t* img, int width, int height, int level, uint8
             gf::DevBuf<int> d;
             if (int r = d.alloc((size_t)g.w * g.h)) return r;
             gf::deriv_probe_kernel<<<dim3((((g.w + 7) >> 3) * g.h + 255) / 256), 256, 0, h->stream>>>(h->d_img.p, g, d.p);
-            HIPCHK(hipGetLastError());
-            const hipError_t e = hipMemcpy(deriv_xy, d.p, (size_t)g.w * g.h * 4, hipMemcpyDeviceToHost);
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e == hipSuccess) e = hipMemcpy(deriv_xy, d.p, (size_t)g.w * g.h * 4, hipMemcpyDeviceToHost);
             d.release();
             HIPCHK(e);
         }

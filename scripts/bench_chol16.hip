@@ -6,19 +6,18 @@
 #include "../ground-fusion_amd/csrc/gf_ba_kernels.hpp"
 using namespace gfb;
 template <int MODE> __global__ void k(const double* A, double* out, long long* cyc, int reps) {
-    __shared__ double s_L[16 * 17], s_inv[16 * 17], s_rd[16];
+    __shared__ double s_P[136], s_inv[16 * 17], s_rd[16];
     const int lane = threadIdx.x;
     long long t = 0;
     double acc = 0;
     for (int it = 0; it < reps; it++) {
-        for (int i = lane; i < 256; i += 64) s_L[(i >> 4) * 17 + (i & 15)] = A[i] + (i % 17 == 0 ? it * 1e-9 : 0.0);
+        for (int i = lane; i < 256; i += 64) if ((i & 15) <= (i >> 4)) s_P[pk(i >> 4, i & 15)] = A[i] + (i % 17 == 0 ? it * 1e-9 : 0.0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
         const long long t0 = clock64();
         bool good;
-        if (MODE == 0) good = wave_chol16_inv(s_L, s_inv, s_rd, lane);
-        else good = wave_chol16_inv<false>(s_L, s_inv, s_rd, lane);
+        good = wave_chol16_fused(s_P, 0, 16, s_inv, s_rd, lane);
         t += clock64() - t0;
-        acc += s_L[lane % 16 * 17 + lane / 16] + (good ? 1 : 0) + (MODE == 0 ? s_inv[lane % 16 * 17 + 3] : 0.0);
+        acc += s_P[lane] + (good ? 1 : 0) + s_inv[lane % 16 * 17 + 3];
     }
     out[lane] = acc;
     if (lane == 0) cyc[blockIdx.x] = t / reps;
@@ -34,6 +33,6 @@ int main() {
         k<0><<<1, 64>>>(dA, dout, dc, 100); hipMemcpy(&c[0], dc, 8, hipMemcpyDeviceToHost);
         k<1><<<1, 64>>>(dA, dout, dc, 100); hipMemcpy(&c[1], dc, 8, hipMemcpyDeviceToHost);
     }
-    printf("cycles per 16x16 block: factor+inverse %lld, factor only %lld\n", c[0], c[1]);
+    printf("cycles per 16x16 block (fused factor + inverse): %lld / %lld\n", c[0], c[1]);
     return 0;
 }
