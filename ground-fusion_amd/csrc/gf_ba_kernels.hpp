@@ -1114,9 +1114,9 @@ __device__ __forceinline__ double row_bcast(double v, int j) {   // j must fold 
 // The block is read straight from the packed lower triangle S (rows / columns j0 .. j0 + nb - 1, padded with the identity); the inverse goes to s_inv
 // (operand of the panel product) and, packed, back into S in place of the block -- the factor itself is not needed again.
 template <class SPtr>
-__device__ inline bool wave_chol16_fused(SPtr S, int j0, int nb, double* s_inv, double* s_rdiag, int lane) {
+__device__ inline bool wave_chol16_fused(SPtr S, int j0, int nb, double* s_inv, int lane) {
     const int r = lane & 15, g = lane >> 4;
-    double a[16], rd[16], t[4];
+    double a[16], t[4];
 #pragma unroll
     for (int c = 0; c < 16; c++) a[c] = (r < nb && c < nb) ? S[pk(j0 + max(r, c), j0 + min(r, c))] : (r == c ? 1.0 : 0.0);
 #pragma unroll
@@ -1130,8 +1130,7 @@ __device__ inline bool wave_chol16_fused(SPtr S, int j0, int nb, double* s_inv, 
         double rs = __builtin_amdgcn_rsq(piv);          // ~2^-26 seed, two Newton steps
         rs = rs * (1.5 - 0.5 * piv * rs * rs);
         rs = rs * (1.5 - 0.5 * piv * rs * rs);
-        rd[j] = rs;                                         // 1 / L_jj
-        const double l = (r == j) ? piv * rs : a[j] * rs;   // L_rj (rows r >= j)
+        const double l = (r == j) ? piv * rs : a[j] * rs;   // L_rj (rows r >= j); rs = 1 / L_jj
         a[j] = l;
         if (r == j) rd_own = rs;
         const double lm = (r > j) ? l : 0.0;
@@ -1142,10 +1141,6 @@ __device__ inline bool wave_chol16_fused(SPtr S, int j0, int nb, double* s_inv, 
         }
 #pragma unroll
         for (int c = j + 1; c < 16; c++) a[c] -= l * row_bcast(l, c);   // L_rj * L_cj
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int c = 0; c < 16; c++) s_rdiag[c] = rd[c];
     }
 #pragma unroll
     for (int m = 0; m < 4; m++) {
@@ -1172,7 +1167,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
     __shared__ int s_flag[4];
     __shared__ int s_cmap[256];      // compact column -> reduced column (or -1), right-hand-side slot -> R
     __shared__ double s_uc[256];     // a vector gathered to the compact layout
-    __shared__ double s_rd[512];     // reciprocals of the Cholesky diagonal
+    __shared__ double s_rd[512];     // scratch: the Cauchy direction during the Schur pass, the solution during the backward substitution
     __shared__ int s_rc[512];        // reduced column -> compact column of the visual system Vc (or -1)
     __shared__ double s_hd[512];     // diagonal of H + Vc
     __shared__ double s_gt[512];     // g + Vc's right-hand-side row
@@ -1450,7 +1445,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                 GF_DSUB(24);
                 // the diagonal block of S receives the INVERSE of its factor: the panel below is multiplied with it (MFMA), and the backward
                 // substitution becomes a 16x16 product per block instead of a chain of 16 dependent steps
-                const bool good = wave_chol16_fused(S, j0, nb, s_inv, s_rd + j0, lane);
+                const bool good = wave_chol16_fused(S, j0, nb, s_inv, lane);
                 GF_DSUB(25);
                 GF_DSUB(26);
                 if (!good && lane == 0) s_flag[1] = 0;

@@ -15,7 +15,7 @@ template <int MODE> __global__ void k(const double* A, double* out, long long* c
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
         const long long t0 = clock64();
         bool good;
-        good = wave_chol16_fused(s_P, 0, 16, s_inv, s_rd, lane);
+        good = wave_chol16_fused(s_P, 0, 16, s_inv, lane);
         t += clock64() - t0;
         acc += s_P[lane] + (good ? 1 : 0) + s_inv[lane % 16 * 17 + 3];
     }
