@@ -1114,11 +1114,15 @@ __device__ __forceinline__ double row_bcast(double v, int j) {   // j must fold 
 // The block is read straight from the packed lower triangle S (rows / columns j0 .. j0 + nb - 1, padded with the identity); the inverse goes to s_inv
 // (operand of the panel product) and, packed, back into S in place of the block -- the factor itself is not needed again.
 template <class SPtr>
-__device__ inline bool wave_chol16_fused(SPtr S, int j0, int nb, double* s_inv, int lane) {
+__device__ __forceinline__ bool wave_chol16_fused(SPtr S, int j0, int nb, double* s_inv, int lane) {
     const int r = lane & 15, g = lane >> 4;
     double a[16], t[4];
 #pragma unroll
-    for (int c = 0; c < 16; c++) a[c] = (r < nb && c < nb) ? S[pk(j0 + max(r, c), j0 + min(r, c))] : (r == c ? 1.0 : 0.0);
+    for (int c = 0; c < 16; c++) {   // unconditional loads (indices clamped into the block), masked afterwards: no branch per element
+        const int rl = min(r, nb - 1), cl = min(c, nb - 1);
+        const double v = S[pk(j0 + max(rl, cl), j0 + min(rl, cl))];
+        a[c] = (r < nb && c < nb) ? v : (r == c ? 1.0 : 0.0);
+    }
 #pragma unroll
     for (int m = 0; m < 4; m++) t[m] = (4 * m + g == r) ? 1.0 : 0.0;
     double rd_own = 0.0;
@@ -1127,9 +1131,12 @@ __device__ inline bool wave_chol16_fused(SPtr S, int j0, int nb, double* s_inv, 
     for (int j = 0; j < 16; j++) {
         const double piv = row_bcast(a[j], j);
         if (!(piv > 0.0)) good = false;
-        double rs = __builtin_amdgcn_rsq(piv);          // ~2^-26 seed, two Newton steps
-        rs = rs * (1.5 - 0.5 * piv * rs * rs);
-        rs = rs * (1.5 - 0.5 * piv * rs * rs);
+        // 1 / sqrt(piv): hardware seed (~2^-26) and two Newton steps y += y (1/2 - (piv/2) y^2), written with explicit fused multiply-adds
+        // (this file is compiled without contraction; on the serial chain of the factorisation every dependent operation counts)
+        const double hp = 0.5 * piv;
+        double rs = __builtin_amdgcn_rsq(piv);
+        rs = __builtin_fma(rs, __builtin_fma(-(hp * rs), rs, 0.5), rs);
+        rs = __builtin_fma(rs, __builtin_fma(-(hp * rs), rs, 0.5), rs);
         const double l = (r == j) ? piv * rs : a[j] * rs;   // L_rj (rows r >= j); rs = 1 / L_jj
         a[j] = l;
         if (r == j) rd_own = rs;
@@ -1137,10 +1144,10 @@ __device__ inline bool wave_chol16_fused(SPtr S, int j0, int nb, double* s_inv, 
 #pragma unroll
         for (int m = 0; 4 * m <= j; m++) {                  // columns 4m + g <= j carry something; a larger column index has t = 0 in row j
             const double wjc = row_bcast(t[m], j) * rs;     // W[j][4m + g]
-            t[m] -= lm * wjc;
+            t[m] = __builtin_fma(-lm, wjc, t[m]);
         }
 #pragma unroll
-        for (int c = j + 1; c < 16; c++) a[c] -= l * row_bcast(l, c);   // L_rj * L_cj
+        for (int c = j + 1; c < 16; c++) a[c] = __builtin_fma(-l, row_bcast(l, c), a[c]);   // - L_rj * L_cj
     }
 #pragma unroll
     for (int m = 0; m < 4; m++) {
@@ -1428,7 +1435,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
             __syncthreads();
 #ifdef GF_PROFILE_STEP
             long long tA = 0, tB = 0, tC = 0, t0c = clock64();
-            if (blockIdx.x == 0 && tid == 0 && sb.stamps) { sb.stamps[24] = sb.stamps[25] = sb.stamps[26] = sb.stamps[27] = 0; }
+            if (blockIdx.x == 0 && tid == 0 && sb.stamps) { sb.stamps[24] = sb.stamps[25] = sb.stamps[26] = sb.stamps[27] = sb.stamps[28] = 0; }
 #define GF_SUB(acc) do { const long long n_ = clock64(); acc += n_ - t0c; t0c = n_; } while (0)
 #else
 #define GF_SUB(acc) do { } while (0)
@@ -1504,7 +1511,13 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                 if (r0 <= R) {
                     const int nrows = R + 1 - r0, nt = (nrows + 15) / 16, ntiles = nt * (nt + 1) / 2;
                     if (wave == 0) {
+#ifdef GF_PROFILE_STEP
+                        const long long q0 = clock64();
+#endif
                         trail_tile(j0, nb, r0, 0, 0);
+#ifdef GF_PROFILE_STEP
+                        if (blockIdx.x == 0 && tid == 0 && sb.stamps) sb.stamps[28] += clock64() - q0;
+#endif
                         if (r0 < R) {
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
                             diag_block(r0);

@@ -6,6 +6,6 @@ base=[SW.make_window(1000+b, gfamd) for b in range(8)]; wins=[base[b%8] for b in
 est.upload(wins)
 for it in (1,2,3):
     est.solve_resident(it, -1, True)
-    st=np.zeros(24, np.int64)
-    gfamd._chk(gfamd.lib().gf_ba_debug_stamps(est.h, st.ctypes.data_as(C.POINTER(C.c_longlong)), 24))
-    d=np.diff(st[:15]); print(it, 'total', (st[14]-st[0]), 'phases', d.tolist(), 'chol diag/panel/trail', st[20:23].tolist(), 'diag copyin/factor+inv/copyout (accumulated)', st[16:19].tolist())
+    st=np.zeros(32, np.int64)
+    gfamd._chk(gfamd.lib().gf_ba_debug_stamps(est.h, st.ctypes.data_as(C.POINTER(C.c_longlong)), 32))
+    d=np.diff(st[:15]); print(it, 'total', (st[14]-st[0]), 'phases', d.tolist(), 'chol diag/panel/trail', st[20:23].tolist(), 'diag sub-phases (accumulated over the blocks after the first)', st[24:29].tolist())
