@@ -32,6 +32,10 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <climits>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include "../../include/groundfusion_hip.h"
 #include "gf_dmath.hpp"
@@ -323,11 +327,20 @@ struct ImageFrame {  // initial/initial_alignment.h ImageFrame: only what the no
 // windows go to the device in one gf_ba_solve / gf_ba_marginalize call of the shared handle -- the batched kernels see B windows per
 // launch although each Estimator keeps the reference's single-sequence control flow.  A member outside a group step (a frame that
 // waited for IMU data and is taken by a later inputIMU) is simply a batch of one.
+// A generation counter many threads sleep on (futex): bump() wakes them all at once and none of them has to take a lock to find out why it woke.
+// (A condition variable makes 256 sleepers queue up on its mutex one after the other -- milliseconds per rendezvous at this group size.)
+struct Gate {
+    std::atomic<int> gen{0};
+    int now() const { return gen.load(std::memory_order_acquire); }
+    void wait_while(int seen) { syscall(SYS_futex, reinterpret_cast<int*>(&gen), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0); }   // returns at once if gen != seen
+    void bump() { gen.fetch_add(1, std::memory_order_acq_rel); syscall(SYS_futex, reinterpret_cast<int*>(&gen), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0); }
+};
+
 struct BatchSolver {
-    struct Req { int kind; gf_ba_window* w; int iters, mode; gf_ba_summary* sum; gf_ba_prior* prior; int rc; bool done; std::string err; };
+    struct Req { int kind; gf_ba_window* w; int iters, mode; gf_ba_summary* sum; gf_ba_prior* prior; int rc; std::atomic<bool> done; std::string err; };
     gf_ba* ba = nullptr;
     std::mutex m;
-    std::condition_variable cv;
+    Gate finished;                  // bumped after every batch
     int active = 0;                 // members currently inside a frame of a group step
     std::vector<Req*> pending;
     long long batches = 0, windows = 0, largest = 0;
@@ -335,10 +348,16 @@ struct BatchSolver {
     double t_solve = 0, t_marg = 0;        // wall time inside the batched calls [s] (GF_GROUP_TIMING=1 prints them when the group is destroyed)
 
     int submit(Req& r) {
-        std::unique_lock<std::mutex> lk(m);
-        pending.push_back(&r);
-        maybe_run();
-        cv.wait(lk, [&] { return r.done; });
+        {
+            std::unique_lock<std::mutex> lk(m);
+            pending.push_back(&r);
+            maybe_run();
+        }
+        for (;;) {
+            const int seen = finished.now();
+            if (r.done.load(std::memory_order_acquire)) break;
+            finished.wait_while(seen);
+        }
         if (r.rc != GF_OK) gf::set_err(r.rc, "%s", r.err.c_str());   // the batch may have run on another thread: carry its message over
         return r.rc;
     }
@@ -379,10 +398,10 @@ struct BatchSolver {
             }
             (pass == 0 ? t_solve : t_marg) += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
             const std::string err = rc == GF_OK ? std::string() : std::string(gf_last_error());
-            for (Req* r : grp) { r->rc = rc; r->err = err; r->done = true; }
+            for (Req* r : grp) { r->rc = rc; r->err = err; r->done.store(true, std::memory_order_release); }
             batches++; windows += (long long)grp.size(); largest = std::max(largest, (long long)grp.size());
         }
-        cv.notify_all();
+        finished.bump();
     }
 };
 
@@ -1376,11 +1395,10 @@ struct gf_estimator_group {
     int device = 0;
     std::vector<std::thread> thr;
     std::mutex m;
-    std::condition_variable cv_go, cv_done;
-    long long gen = 0;
+    Gate go, all_done;    // a new step for the workers; the last worker of a step
     double t_input = 0;   // wall time inside gf_estimator_group_input_features [s]
-    int remaining = 0;
-    bool stop = false;
+    std::atomic<int> remaining{0};
+    std::atomic<bool> stop{false};
     std::vector<char> has;
     std::vector<double> t;
     std::vector<std::vector<gf_feature_obs>> frames;
@@ -1389,29 +1407,24 @@ struct gf_estimator_group {
 
     void worker(int i) {
         (void)hipSetDevice(device);   // the device is a per-thread setting; whichever member closes a rendezvous launches the batch
-        long long seen = 0;
+        int seen = 0;   // go starts at generation 0 and is only bumped by input_features / the destructor
         for (;;) {
-            bool mine;
-            {
-                std::unique_lock<std::mutex> lk(m);
-                cv_go.wait(lk, [&] { return gen != seen || stop; });
-                if (stop) return;
-                seen = gen; mine = has[i] != 0;
-            }
-            if (!mine) continue;
+            while (go.now() == seen && !stop.load(std::memory_order_acquire)) go.wait_while(seen);
+            if (stop.load(std::memory_order_acquire)) return;
+            seen = go.now();   // one step at a time: input_features does not return before every listed member is done
+            if (!has[i]) continue;
             mem[i]->t_mark = gf_estimator::cpu_now();
             const int rc = gf_estimator_input_feature(mem[i], t[i], frames[i].data(), (int)frames[i].size());
             mem[i]->lap(5);
             rcs[i] = rc;
             if (rc != GF_OK) errs[i] = gf_last_error();
             solver.leave();
-            std::unique_lock<std::mutex> lk(m);
-            if (--remaining == 0) cv_done.notify_all();
+            if (remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) all_done.bump();
         }
     }
     ~gf_estimator_group() {
-        { std::unique_lock<std::mutex> lk(m); stop = true; }
-        cv_go.notify_all();
+        stop.store(true, std::memory_order_release);
+        go.bump();
         for (auto& th : thr) if (th.joinable()) th.join();
         for (gf_estimator* e : mem) delete e;
         if (solver.ba) gf_ba_destroy(solver.ba);
@@ -1472,13 +1485,13 @@ int gf_estimator_group_input_features(gf_estimator_group* g, int count, const in
             off += (size_t)n_obs[k];
         }
         { std::unique_lock<std::mutex> sl(g->solver.m); g->solver.active = count; }
-        g->remaining = count;
-        g->gen++;
+        g->remaining.store(count, std::memory_order_release);
     }
-    g->cv_go.notify_all();
-    {
-        std::unique_lock<std::mutex> lk(g->m);
-        g->cv_done.wait(lk, [&] { return g->remaining == 0; });
+    g->go.bump();
+    for (;;) {
+        const int seen = g->all_done.now();
+        if (g->remaining.load(std::memory_order_acquire) == 0) break;
+        g->all_done.wait_while(seen);
     }
     g->t_input += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
     for (int k = 0; k < count; k++) if (g->rcs[seq[k]] != GF_OK) return gf::set_err(g->rcs[seq[k]], "sequence %d: %s", seq[k], g->errs[seq[k]].c_str());
