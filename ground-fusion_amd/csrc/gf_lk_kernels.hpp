@@ -493,7 +493,7 @@ struct LkBatchArgs {
 // grid.x = ceil(cap/4) blocks of 4 wavefronts, grid.y = sequence.  Forward LK (feature_tracker.cpp:118-135),
 // reverse LK and flow-back test (:138-153), inBorder and the brightness test with the reference's swapped
 // row/column indexing (:155-168).
-__global__ void __launch_bounds__(256, 8) lk_track_kernel(PyrGeom G, LkBatchArgs A) {
+__global__ void __launch_bounds__(256, 7) lk_track_kernel(PyrGeom G, LkBatchArgs A) {
     __shared__ __attribute__((aligned(16))) uint8_t tiles[4 * kTileBytes];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y;
