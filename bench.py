@@ -324,7 +324,9 @@ def main():
             assert gathered[0].shape == (B * world, 7) and bool(torch.isfinite(gathered[0]).all())
         pmc = pmc_summary()
         # roofline of the dominant front-end kernel (lk_track_kernel): algorithmic bytes per SURVEY.md 8(d):
-        #   484*(1+4) B per (point, level pass) [u8 window + s16x2 derivative window] + 484 B per iteration [moving window]
+        #   484*(1+4) B per (point, level pass) [u8 window + s16x2 derivative window] + 484 B per iteration [moving window].
+        # The formula is the survey's and is kept as the numerator; since round 2 the kernel does not read derivative windows any more (it evaluates the
+        # Scharr derivative from four u8 rows of 16 B per lane): `bytes_loaded_by_design` below is what its loads request.
         launches = max(st["lk_launches"], 1)
         alg_bytes = 484.0 * 5.0 * st["lk_level_passes"] + 484.0 * st["lk_iterations"]
         lk_ms = st["ms_lk"] / launches
@@ -362,6 +364,8 @@ def main():
                          "frac_isolated": (iso["lk_alg_bytes"] / (iso["lk_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if iso.get("lk_ms") else None,
                          "traffic_note": lk_pmc.get("note", "no PMC summary under profiles/"),
                          "algorithmic_bytes_per_launch": alg_bytes / launches,
+                         "bytes_loaded_by_design_per_launch": (63.0 * 64.0 * st["lk_level_passes"] + 1024.0 * st["lk_tile_refills"]) / launches if "lk_tile_refills" in st else (63.0 * 64.0 * st["lk_level_passes"]) / launches,
+                         "bytes_loaded_by_design_note": "template phase: 63 lanes x 4 rows x 16 B per (point, level pass); moving image: 32 x 32 B tile refills on top (not counted by the kernel)",
                          "points_per_launch": st["lk_points"] / launches, "iterations_per_launch": st["lk_iterations"] / launches},
             "roofline_jtj": {"kernel": "ba_linearize_visual_win", "bound": "mfma", "achieved": tf(jtj_alg, jtj_t), "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                              "frac": tf(jtj_alg, jtj_t) / FP64_MFMA_PEAK_TF, "launch_ms": jtj_t, "launch_ms_in_timed_region": jtj_ms,
