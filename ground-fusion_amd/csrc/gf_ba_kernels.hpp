@@ -1380,17 +1380,38 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
             }
             __syncthreads();
             // ... then the visual part, compact row by compact row: entry (ka >= kb) of Vc lands on its own entry (r >= c) of S
-            for (int ka = wave; ka < 6 * d.NP + 7; ka += 8) {
-                const int r = s_cmap[ka];
-                if (r < 0 || r >= R) continue;
-                const double* vrow = Vc + pk(ka, 0);
-                const double sr = s_hd[r], ur = s_rd[r];
-                for (int kb = lane; kb <= ka; kb += 64) {
-                    const int c = s_cmap[kb];
-                    if (c < 0) continue;
-                    const double v = vrow[kb];
-                    S[pk(r, c)] += sr * s_hd[c] * v;
-                    uHu_acc += (c == r ? 1.0 : 2.0) * v * ur * s_rd[c];
+            //     (four compact rows per wavefront in flight: every load is issued before the first use -- one row at a time this pass was a chain of
+            //     8-9 dependent global loads per wavefront)
+            {
+                const int nka = 6 * d.NP + 7;
+                constexpr int VQ = GS ? 3 : 2;   // 64-column pieces of a compact row (<= 6 NP + 8 columns)
+                for (int ka0 = wave; ka0 < nka; ka0 += 32) {
+                    double vv[4][VQ];
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        const int ka = ka0 + 8 * m;
+                        const double* vrow = Vc + pk(min(ka, nka - 1), 0);
+#pragma unroll
+                        for (int q = 0; q < VQ; q++) { const int kb = lane + 64 * q; vv[m][q] = (ka < nka && kb <= ka) ? vrow[kb] : 0.0; }
+                    }
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        const int ka = ka0 + 8 * m;
+                        if (ka >= nka) continue;
+                        const int r = s_cmap[ka];
+                        if (r < 0 || r >= R) continue;
+                        const double sr = s_hd[r], ur = s_rd[r];
+#pragma unroll
+                        for (int q = 0; q < VQ; q++) {
+                            const int kb = lane + 64 * q;
+                            if (kb > ka) continue;
+                            const int c = s_cmap[kb];
+                            if (c < 0) continue;
+                            const double v = vv[m][q];
+                            S[pk(r, c)] += sr * s_hd[c] * v;
+                            uHu_acc += (c == r ? 1.0 : 2.0) * v * ur * s_rd[c];
+                        }
+                    }
                 }
             }
             if (need_alpha) {
