@@ -64,6 +64,17 @@ class Estimator {
         const double v[3] = {linearVelocity[0], linearVelocity[1], linearVelocity[2]}, g[3] = {angularVelocity[0], angularVelocity[1], angularVelocity[2]};
         check(gf_estimator_input_wheel(h_, t, v, g));
     }
+    // inputGNSS (estimator.h:99): one epoch of L1 observations with the satellite states their ephemerides give (gf_gnss_obs); inputGNSSTimeDiff (:100);
+    // setGNSSAlignment: the result of GNSSVIInitializer, applied by the library where the reference runs GNSSVIAlign (estimator.cpp:1928-2043)
+    gf_estimator* handle() { need(); return h_; }   // for the C entry points this class does not wrap (gf_estimator_get_gnss_state, _get_features, ...)
+    void inputGNSS(double t, const std::vector<gf_gnss_obs>& meas) { need(); check(gf_estimator_input_gnss(h_, t, meas.data(), (int)meas.size())); }
+    void inputGNSSTimeDiff(double t_diff) { need(); check(gf_estimator_input_gnss_time_diff(h_, t_diff)); }
+    void inputIonoParams(double /*ts*/, const std::vector<double>& iono_params) { need(); if (iono_params.size() != 8) return; check(gf_estimator_input_iono_params(h_, iono_params.data())); }
+    void setGNSSAlignment(const Vec3& anc_ecef, double yaw_enu_local, const double rcv_dt[4], double rcv_ddt) {
+        need();
+        const double a[3] = {anc_ecef[0], anc_ecef[1], anc_ecef[2]};
+        check(gf_estimator_set_gnss_alignment(h_, a, yaw_enu_local, rcv_dt, rcv_ddt));
+    }
     void inputFeature(double t, const FeatureFrame& featureFrame) {   // + processMeasurements -> processImage
         need();
         std::vector<gf_feature_obs> obs;

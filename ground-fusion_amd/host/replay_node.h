@@ -7,6 +7,10 @@
 //
 // Dataset directory read by load():   imu.csv  t,ax,ay,az,gx,gy,gz     wheel.csv  t,vx,vy,vz,wx,wy,wz     (nav_msgs/Odometry twist)
 //                                     image0.csv  t,file               image1.csv  t,file                 (files relative to the directory)
+// optional (gnss_enable: 1):          gnss.csv   t_msg,sat,sys,time,psr,dopp,psr_std,dopp_std,wavelength,sx,sy,sz,vx,vy,vz,svdt,svddt,tgd,pr_uura,dp_uura,tow
+//                                                one row per L1 observation (gf_gnss_obs); consecutive rows with the same t_msg are one GnssMeasMsg
+//                                                (gnss_meas_callback, rosNodeTest.cpp:213-236), delivered at local time t_msg - gnss_local_time_diff
+//                                     gnss_align.csv  t,ax,ay,az,yaw,dt0,dt1,dt2,dt3,ddt   a GNSS-VI alignment result on offer from local time t on
 #pragma once
 #include <algorithm>
 #include <cstdio>
@@ -24,6 +28,8 @@ namespace gf {
 struct ImuMsg { double t; Vec3 linear_acceleration, angular_velocity; };
 struct OdomMsg { double t; Vec3 linear, angular; };
 struct ImageMsg { double t; std::string file; };
+struct GnssMsg { double t; std::vector<gf_gnss_obs> meas; };
+struct GnssAlignMsg { double t; Vec3 anc; double yaw, dt[4], ddt; };
 
 template <class Est> class ReplayNode {
   public:
@@ -31,7 +37,8 @@ template <class Est> class ReplayNode {
     int w_replace = 0;                 // config key `w_replace` (parameters.cpp:178): take the wheel yaw rate from the IMU's -y gyro axis
     std::deque<ImuMsg> imu_buf;
     std::deque<ImageMsg> img0_buf, img1_buf;
-    long n_pairs = 0, n_thrown0 = 0, n_thrown1 = 0;
+    long n_pairs = 0, n_thrown0 = 0, n_thrown1 = 0, n_gnss = 0;
+    double gnss_local_time_diff = 0;   // config key `gnss_local_time_diff`: GNSS messages are merged at their local time
 
     explicit ReplayNode(Est& e) : estimator(e) {}
 
@@ -66,6 +73,8 @@ template <class Est> class ReplayNode {
         estimator.inputWheel(t, m.linear, gyr);
     }
 
+    void gnss_meas_callback(const GnssMsg& m) { estimator.inputGNSS(m.t, m.meas); n_gnss++; }           // rosNodeTest.cpp:213-236 (time_diff_valid: offline value)
+    void gnss_align_callback(const GnssAlignMsg& m) { estimator.setGNSSAlignment(m.anc, m.yaw, m.dt, m.ddt); }
     void img0_callback(const ImageMsg& m) { img0_buf.push_back(m); }
     void img1_callback(const ImageMsg& m) { img1_buf.push_back(m); }
 
@@ -87,23 +96,50 @@ template <class Est> class ReplayNode {
         }
     }
 
-    // merge the four recorded topics by time stamp (ties: imu, wheel, image0, image1) and run the callbacks
+    // merge the recorded topics by time stamp (ties: GNSS alignment, GNSS, imu, wheel, image0, image1) and run the callbacks
     void run(const std::string& dir) {
         struct Ev { double t; int kind; size_t idx; };
         std::vector<ImuMsg> imu; std::vector<OdomMsg> odom; std::vector<ImageMsg> im0, im1;
         load(dir, imu, odom, im0, im1);
+        std::vector<GnssMsg> gn; std::vector<GnssAlignMsg> al;
+        load_gnss(dir, gn, al);
         std::vector<Ev> ev;
+        for (size_t i = 0; i < al.size(); i++) ev.push_back({al[i].t, -2, i});
+        for (size_t i = 0; i < gn.size(); i++) ev.push_back({gn[i].t - gnss_local_time_diff, -1, i});
         for (size_t i = 0; i < imu.size(); i++) ev.push_back({imu[i].t, 0, i});
         for (size_t i = 0; i < odom.size(); i++) ev.push_back({odom[i].t, 1, i});
         for (size_t i = 0; i < im0.size(); i++) ev.push_back({im0[i].t, 2, i});
         for (size_t i = 0; i < im1.size(); i++) ev.push_back({im1[i].t, 3, i});
         std::stable_sort(ev.begin(), ev.end(), [](const Ev& a, const Ev& b) { return a.t < b.t || (a.t == b.t && a.kind < b.kind); });
         for (const Ev& e : ev) {
-            if (e.kind == 0) imu_callback(imu[e.idx]);
+            if (e.kind == -2) gnss_align_callback(al[e.idx]);
+            else if (e.kind == -1) gnss_meas_callback(gn[e.idx]);
+            else if (e.kind == 0) imu_callback(imu[e.idx]);
             else if (e.kind == 1) wheel_callback(odom[e.idx]);
             else if (e.kind == 2) { img0_callback(im0[e.idx]); sync_process(dir); }
             else { img1_callback(im1[e.idx]); sync_process(dir); }
         }
+    }
+    // gnss.csv / gnss_align.csv are optional: a dataset without them replays as before
+    static void load_gnss(const std::string& dir, std::vector<GnssMsg>& gn, std::vector<GnssAlignMsg>& al) {
+        if (std::ifstream(dir + "/gnss.csv"))
+            for (auto& r : rows(dir + "/gnss.csv", 21)) {
+                gf_gnss_obs o{};
+                const double t = num(r[0]);
+                o.sat = (int)num(r[1]); o.sys = (int)num(r[2]); o.time = num(r[3]); o.psr = num(r[4]); o.dopp = num(r[5]); o.psr_std = num(r[6]); o.dopp_std = num(r[7]);
+                o.wavelength = num(r[8]);
+                for (int k = 0; k < 3; k++) { o.sv_pos[k] = num(r[9 + k]); o.sv_vel[k] = num(r[12 + k]); }
+                o.svdt = num(r[15]); o.svddt = num(r[16]); o.tgd = num(r[17]); o.pr_uura = num(r[18]); o.dp_uura = num(r[19]); o.tow = num(r[20]);
+                if (gn.empty() || gn.back().t != t) gn.push_back({t, {}});
+                gn.back().meas.push_back(o);
+            }
+        if (std::ifstream(dir + "/gnss_align.csv"))
+            for (auto& r : rows(dir + "/gnss_align.csv", 10)) {
+                GnssAlignMsg m; m.t = num(r[0]); m.anc = vec(r, 1); m.yaw = num(r[4]);
+                for (int k = 0; k < 4; k++) m.dt[k] = num(r[5 + k]);
+                m.ddt = num(r[9]);
+                al.push_back(m);
+            }
     }
 
     static void load(const std::string& dir, std::vector<ImuMsg>& imu, std::vector<OdomMsg>& odom, std::vector<ImageMsg>& im0, std::vector<ImageMsg>& im1) {

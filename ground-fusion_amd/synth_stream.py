@@ -244,6 +244,21 @@ class Stream:
             f.write("\n" + mat("body_T_cam0", np.eye(4)) + "\n" + mat("body_T_cam1", np.eye(4)) + "\n" + mat("body_T_wheel", T_io))
             import synth_window as SW
             f.write("\n" + mat("gnss_iono_default_parameters", SW.IONO.reshape(1, 8)))
+        if getattr(self, "_gnss", None) is not None and keys.get("gnss_enable"):
+            # one epoch per back-end frame (every second camera frame) a few ms off the frame stamp, and an alignment on offer at every such frame
+            orng = np.random.default_rng(99)
+            W = int(cfg.get("window_size", 10))
+            with open(os.path.join(out_dir, "gnss.csv"), "w") as fg, open(os.path.join(out_dir, "gnss_align.csv"), "w") as fa:
+                fg.write("# t_msg,sat,sys,time,psr,dopp,psr_std,dopp_std,wavelength,sx,sy,sz,vx,vy,vz,svdt,svddt,tgd,pr_uura,dp_uura,tow\n")
+                fa.write("# t,ax,ay,az,yaw,dt0,dt1,dt2,dt3,ddt\n")
+                for k in range(0, n, 2):
+                    tk = float(self.cam_t[k])
+                    tg, epoch = self.gnss_epoch(tk + orng.uniform(-0.02, 0.02), flaky_sat=2 if (k // 2) % 6 == 5 else None)
+                    for o in epoch:
+                        fg.write(",".join(repr(float(v)) for v in (tg, o["sat"], o["sys"], o["time"], o["psr"], o["dopp"], o["psr_std"], o["dopp_std"], o["wavelength"], *o["sv_pos"],
+                                                                   *o["sv_vel"], o["svdt"], o["svddt"], o["tgd"], o["pr_uura"], o["dp_uura"], o["tow"])) + "\n")
+                    anc, yaw, dt4, ddt = self.gnss_alignment(tk - W / 15.0)
+                    fa.write(",".join(repr(float(v)) for v in (tk - 0.03, *anc, yaw, *dt4, ddt)) + "\n")
         with open(os.path.join(out_dir, "cam.yaml"), "w") as f:
             f.write("%%YAML:1.0\n---\nmodel_type: PINHOLE\ncamera_name: camera\nimage_width: %d\nimage_height: %d\ndistortion_parameters:\n   k1: 0.0\n   k2: 0.0\n"
                     "   p1: 0.0\n   p2: 0.0\nprojection_parameters:\n   fx: %r\n   fy: %r\n   cx: %r\n   cy: %r\n" % (synth.W, synth.H, synth.FX, synth.FY, synth.CX, synth.CY))

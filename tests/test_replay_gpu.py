@@ -63,3 +63,59 @@ def test_replay_tool_writes_the_oracle_trajectory(tmp_path):
     print("gf_replay vs oracle: %d poses, worst |dp| %.2e, |dq| %.2e" % (len(ref), dp, dq))
     assert dp < 1e-6 + 5e-10 and dq < 1e-6 + 5e-10        # the 1e-6 bar plus the file's rounding to 9 decimals
     assert np.linalg.norm(ref[-1][1]) > 0.2               # it moved
+
+
+def test_replay_tool_with_gnss_messages(tmp_path):
+    """the same tool on a dataset that also carries GNSS raw measurements (gnss.csv: one GnssMeasMsg per back-end frame) and alignment offers
+    (gnss_align.csv) with `gnss_enable: 1` in its config: trajectory against the oracle pipeline fed in ReplayNode::run's order, and the closing
+    line's anchor / ECEF position against the oracle's states (2e-3 m: tests/test_estimator_gpu.py explains the GNSS bars)."""
+    st = SS.Stream(3, t_still=1.5, t_move=3.2, v_max=0.4, yaw0=0.0, yaw_turn=-0.6, split_x=1.8, turn_delay=0.8)
+    G = st.gnss_setup()
+    d = str(tmp_path)
+    n = st.export(d, gnss_enable=1, gnss_track_num_thres=3)
+    exe = os.path.join(ROOT, "bin", "gf_replay")
+    if not os.path.exists(exe):
+        import build as gfbuild
+        gfbuild.build_tool(verbose=True)
+    out = subprocess.run([exe, os.path.join(d, "config.yaml"), d, os.path.join(d, "vio.txt")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr
+    n_epochs = len(range(0, n, 2))
+    assert "%d RGB-D pairs (0 / 0 unpaired" % n in out.stdout and "%d GNSS epochs" % n_epochs in out.stdout and "gnss_ready 1" in out.stdout, out.stdout
+    got = np.loadtxt(os.path.join(d, "vio.txt"))
+    # oracle pipeline in the tool's message order: read the GNSS messages back from the files the tool read
+    gn, al = {}, []
+    for line in open(os.path.join(d, "gnss.csv")):
+        if line.startswith("#"):
+            continue
+        v = [float(x) for x in line.split(",")]
+        gn.setdefault(v[0], []).append(dict(sat=int(v[1]), sys=int(v[2]), time=v[3], psr=v[4], dopp=v[5], psr_std=v[6], dopp_std=v[7], wavelength=v[8], sv_pos=np.array(v[9:12]),
+                                            sv_vel=np.array(v[12:15]), svdt=v[15], svddt=v[16], tgd=v[17], pr_uura=v[18], dp_uura=v[19], tow=v[20]))
+    for line in open(os.path.join(d, "gnss_align.csv")):
+        if not line.startswith("#"):
+            v = [float(x) for x in line.split(",")]
+            al.append((v[0], np.array(v[1:4]), v[4], np.array(v[5:9]), v[9]))
+    est = EO.Estimator(dict(tio=SS.TIO, rio=SS.RIO, multiple_thread=1, gnss_enable=1, gnss_track_num_thres=3, gnss_local_time_diff=G["time_diff"]), tracker=O.Tracker())
+    t_end = st.cam_t[n - 1] + 0.05
+    ev = [(a[0], -2, i) for i, a in enumerate(al)] + [(t - G["time_diff"], -1, t) for t in gn] + [(float(t), 0, i) for i, t in enumerate(st.imu_t) if t <= t_end] + \
+         [(float(t), 1, i) for i, t in enumerate(st.wheel_t) if t <= t_end] + [(float(st.cam_t[k]), 2, k) for k in range(n)]
+    for t, kind, i in sorted(ev, key=lambda e: (e[0], e[1])):
+        if kind == -2:
+            est.setGNSSAlignment(*al[i][1:])
+        elif kind == -1:
+            est.inputGNSS(i, gn[i])
+        elif kind == 0:
+            est.inputIMU(t, st.imu_acc[i], st.imu_gyr[i])
+        elif kind == 1:
+            est.inputWheel(t, st.wheel_vel[i], st.wheel_gyr[i])
+        else:
+            est.inputImage(t, *st.image(i))
+    assert est.gnss_ready
+    ref = est.trajectory
+    assert len(ref) > 20 and got.shape == (len(ref), 8)
+    dp = max(float(np.abs(row[1:4] - P).max()) for row, (t, P, R) in zip(got, ref))
+    line = [l for l in out.stdout.splitlines() if "gnss_ready" in l][0].replace(",", " ").split()
+    anc = np.array([float(x) for x in line[line.index("anchor") + 1:line.index("anchor") + 4]])
+    ecef = np.array([float(x) for x in line[line.index("ecef") + 1:line.index("ecef") + 4]])
+    print("gf_replay with GNSS vs oracle: %d poses, worst |dp| %.2e, anchor %.2e, ecef %.2e" % (len(ref), dp, np.abs(anc - est.anc_ecef).max(), np.abs(ecef - est.ecef_pos).max()))
+    assert dp < 1e-6 + 5e-10
+    assert np.abs(anc - est.anc_ecef).max() < 2e-3 and np.abs(ecef - est.ecef_pos).max() < 2e-3     # printed with 4 decimals; observed 6e-4 (weak prior directions, see above)

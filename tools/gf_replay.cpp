@@ -34,9 +34,15 @@ int main(int argc, char** argv) {
         gf::ReplayNode<gf::Estimator> node(estimator);
         const std::string wr = yaml_string(argv[1], "w_replace");
         node.w_replace = wr.empty() ? 0 : atoi(wr.c_str());
+        node.gnss_local_time_diff = estimator.cfg.gnss_enable ? estimator.cfg.gnss_local_time_diff : 0.0;   // rosNodeTest.cpp:703-708
         node.run(argv[2]);
-        printf("gf_replay: %ld RGB-D pairs (%ld / %ld unpaired frames thrown), solver_flag %d, trajectory in %s\n", node.n_pairs, node.n_thrown0, node.n_thrown1,
-               (int)estimator.solver_flag, out.c_str());
+        printf("gf_replay: %ld RGB-D pairs (%ld / %ld unpaired frames thrown), %ld GNSS epochs, solver_flag %d, trajectory in %s\n", node.n_pairs, node.n_thrown0,
+               node.n_thrown1, node.n_gnss, (int)estimator.solver_flag, out.c_str());
+        if (estimator.cfg.gnss_enable) {   // gnss_result.txt of the reference carries the ECEF / ENU position; here as one closing line
+            int gi[8]; double yaw, anc[3], ecef[3], enu[3];
+            if (gf_estimator_get_gnss_state(estimator.handle(), gi, nullptr, nullptr, &yaw, anc, ecef, enu) == GF_OK)
+                printf("gf_replay: gnss_ready %d, anchor %.4f %.4f %.4f, ecef %.4f %.4f %.4f\n", gi[0], anc[0], anc[1], anc[2], ecef[0], ecef[1], ecef[2]);
+        }
     } catch (const std::exception& e) {
         fprintf(stderr, "gf_replay: %s\n", e.what());
         return 1;
