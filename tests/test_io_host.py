@@ -254,11 +254,15 @@ struct Rec {   // stands in for gf::Estimator
     void inputIMU(double t, const gf::Vec3&, const gf::Vec3&) { imu_t.push_back(t); }
     void inputWheel(double t, const gf::Vec3&, const gf::Vec3& g) { wheel_t.push_back(t); wheel_gz.push_back(g[2]); }
     void inputImage(double t, const gf::GrayImage& g, const gf::DepthImage& d) { img_t.push_back(t); img_px.push_back(g.data[1] + d.data[1]); }
+    std::vector<double> gnss_t; std::vector<int> gnss_n; int n_align = 0;
+    void inputGNSS(double t, const std::vector<gf_gnss_obs>& m) { gnss_t.push_back(t); gnss_n.push_back((int)m.size()); }
+    void setGNSSAlignment(const gf::Vec3&, double, const double*, double) { n_align++; }
 };
 int main(int argc, char** argv) {
     Rec r; gf::ReplayNode<Rec> n(r); n.w_replace = atoi(argv[2]);
     n.run(argv[1]);
     printf("imu %zu wheel %zu pairs %ld thrown %ld %ld\n", r.imu_t.size(), r.wheel_t.size(), n.n_pairs, n.n_thrown0, n.n_thrown1);
+    for (size_t i = 0; i < r.gnss_t.size(); i++) printf("g %.9f %d\n", r.gnss_t[i], r.gnss_n[i]);
     for (size_t i = 0; i < r.wheel_t.size(); i++) printf("w %.9f %.12f\n", r.wheel_t[i], r.wheel_gz[i]);
     for (size_t i = 0; i < r.img_t.size(); i++) printf("i %.9f %d\n", r.img_t[i], r.img_px[i]);
     return 0;
@@ -305,3 +309,9 @@ def test_replay_node_callbacks(tmp_path):
     assert imgs == [["0.040000000", str(11 + 1001)], ["0.090000000", str(13 + 1003)]]
     _, wheel0, _ = run(0)
     assert [w[1] for w in wheel0] == [0.7] * 4
+    # optional GNSS topic: rows of one message share t_msg; the message reaches inputGNSS with its own stamp and all its observations
+    row = "%r,%d,0,%r,2.2e7,100.0,0.5,0.3,0.19,1e7,1e7,1e7,100,200,300,1e-5,1e-12,1e-9,2,2,345600.5"
+    (d / "gnss.csv").write_text("# header\n" + "\n".join([row % (18.02, 1, 18.02), row % (18.02, 2, 18.02), row % (18.09, 1, 18.09)]) + "\n")
+    (d / "gnss_align.csv").write_text("0.015,1,2,3,0.3,10,20,30,40,2.0\n")
+    out = subprocess.check_output([str(exe), str(d), "1"]).decode().splitlines()
+    assert [l for l in out if l.startswith("g ")] == ["g 18.020000000 2", "g 18.090000000 1"]
