@@ -535,6 +535,176 @@ struct gf_estimator {
         V3 dl = sat - rcv; dl = dl / norm(dl);
         return asin((transpose(ecef2rotation(rcv)) * dl).z);
     }
+    // ---- GNSSVIInitializer (initial/gnss_vi_initializer.cpp) on the satellite states carried by gf_gnss_obs.  Its three gnss_comm callees -- psr_pos, psr_res,
+    // dopp_res (gnss_spp.cpp; gnss_comm is not vendored by the reference) -- are restated from their published form with the measurement model of
+    // GnssPsrDoppFactor::Evaluate (gnss_psr_dopp_factor.cpp:76-101): unweighted residuals, Jacobian rows [-unit(rcv -> sat), 1 on the system's clock].
+    static double trop_delay(V3 lla, double el) {   // Saastamoinen, standard atmosphere, humidity 0.7 (as gf_ba_gnss.hpp)
+        if (lla.z < -100.0 || 1e4 < lla.z || el <= 0) return 0.0;
+        const double hgt = lla.z < 0.0 ? 0.0 : lla.z;
+        const double pres = 1013.25 * pow(1.0 - 2.2557e-5 * hgt, 5.2568), temp = 15.0 - 6.5e-3 * hgt + 273.16;
+        const double e = 6.108 * 0.7 * exp((17.15 * temp - 4684.0) / (temp - 38.45)), z = M_PI / 2.0 - el;
+        return 0.0022768 * pres / (1.0 - 0.00266 * cos(2.0 * lla.x * M_PI / 180.0) - 0.00028 * hgt / 1e3) / cos(z) + 0.002277 * (1255.0 / temp + 0.05) * e / cos(z);
+    }
+    static double ion_delay(double tow, const double* ion_in, V3 lla, double az, double el) {   // Klobuchar (as gf_ba_gnss.hpp)
+        const double ion_default[8] = {0.1118e-07, -0.7451e-08, -0.5961e-07, 0.1192e-06, 0.1167e+06, -0.2294e+06, -0.1311e+06, 0.1049e+07};
+        if (lla.z < -1e3 || el <= 0) return 0.0;
+        double nrm = 0;
+        for (int i = 0; i < 8; i++) nrm += ion_in[i] * ion_in[i];
+        double ion[8];
+        for (int i = 0; i < 8; i++) ion[i] = nrm <= 0.0 ? ion_default[i] : ion_in[i];
+        const double psi = 0.0137 / (el / M_PI + 0.11) - 0.022;
+        double phi = lla.x / 180.0 + psi * cos(az);
+        if (phi > 0.416) phi = 0.416; else if (phi < -0.416) phi = -0.416;
+        const double lam = lla.y / 180.0 + psi * sin(az) / cos(phi * M_PI);
+        phi += 0.064 * cos((lam - 1.617) * M_PI);
+        double tt = 43200.0 * lam + tow;
+        tt -= floor(tt / 86400.0) * 86400.0;
+        const double f = 1.0 + 16.0 * pow(0.53 - el / M_PI, 3.0);
+        double amp = ion[0] + phi * (ion[1] + phi * (ion[2] + phi * ion[3])), per = ion[4] + phi * (ion[5] + phi * (ion[6] + phi * ion[7]));
+        amp = amp < 0.0 ? 0.0 : amp; per = per < 72000.0 ? 72000.0 : per;
+        const double x = 2.0 * M_PI * (tt - 50400.0) / per;
+        return 2.99792458e8 * f * (fabs(x) < 1.57 ? 5e-9 + amp * (1.0 + x * x * (-0.5 + x * x / 24.0)) : 5e-9);
+    }
+    static constexpr double kC = 2.99792458e8, kOmg = 7.2921151467e-5;
+    // psr_res: residual and Jacobian row (7: position 3, clock bias per system 4) of every observation of an epoch at receiver state xyzt
+    void psr_res(const double* xyzt, const std::vector<gf_gnss_obs>& meas, std::vector<double>& res, std::vector<double>& J) const {
+        const V3 rcv = arr3(xyzt);
+        for (const gf_gnss_obs& o : meas) {
+            const V3 sv = arr3(o.sv_pos);
+            double ion = 0, tro = 0;
+            if (norm(rcv) > 0) {
+                const V3 lla = ecef2geo(rcv);
+                V3 dl = sv - rcv; dl = dl / norm(dl);
+                const V3 enu = transpose(ecef2rotation(rcv)) * dl;
+                double az = sqrt(dl.x * dl.x + dl.y * dl.y) < 1e-12 ? 0.0 : atan2(enu.x, enu.y);
+                if (az < 0) az += 2 * M_PI;
+                const double el = asin(enu.z);
+                tro = trop_delay(lla, el); ion = ion_delay(o.tow, gnss_iono.data(), lla, az, el);
+            }
+            const V3 r2s = sv - rcv;
+            const double rg = norm(r2s);
+            const double est = rg + kOmg * (sv.x * rcv.y - sv.y * rcv.x) / kC + xyzt[3 + o.sys] - o.svdt * kC + ion + tro + o.tgd * kC;
+            res.push_back(est - o.psr);
+            double row[7] = {-r2s.x / rg, -r2s.y / rg, -r2s.z / rg, 0, 0, 0, 0};
+            row[3 + o.sys] = 1.0;
+            J.insert(J.end(), row, row + 7);
+        }
+    }
+    // dopp_res: residual and Jacobian row (4: ECEF velocity 3, clock drift) of every observation of an epoch
+    static void dopp_res(const double* vel_ddt, V3 rcv, const std::vector<gf_gnss_obs>& meas, std::vector<double>& res, std::vector<double>& J) {
+        const V3 vel = arr3(vel_ddt);
+        for (const gf_gnss_obs& o : meas) {
+            const V3 sv = arr3(o.sv_pos), svv = arr3(o.sv_vel);
+            const V3 r2s = sv - rcv;
+            const V3 unit = r2s / norm(r2s);
+            const double sag = kOmg / kC * (svv.x * rcv.y + sv.x * vel.y - svv.y * rcv.x - sv.y * vel.x);
+            const double est = dot(svv - vel, unit) + vel_ddt[3] + sag - o.svddt * kC;
+            res.push_back(est + o.dopp * o.wavelength);
+            J.insert(J.end(), {-unit.x, -unit.y, -unit.z, 1.0});
+        }
+    }
+    // dx = -(G^T G)^-1 G^T b for an m x n system (n <= 7), Gaussian elimination with partial pivoting on the normal equations
+    static bool normal_solve(const std::vector<double>& G, const std::vector<double>& b, int n, double* dx) {
+        const int m = (int)b.size();
+        double A[7][8];
+        for (int i = 0; i < n; i++) {
+            for (int j = 0; j < n; j++) { double a = 0; for (int r = 0; r < m; r++) a += G[(size_t)r * n + i] * G[(size_t)r * n + j]; A[i][j] = a; }
+            double g = 0; for (int r = 0; r < m; r++) g += G[(size_t)r * n + i] * b[r];
+            A[i][n] = -g;
+        }
+        for (int c = 0; c < n; c++) {
+            int p = c;
+            for (int r = c + 1; r < n; r++) if (fabs(A[r][c]) > fabs(A[p][c])) p = r;
+            if (!(fabs(A[p][c]) > 0)) return false;
+            if (p != c) for (int j = 0; j <= n; j++) std::swap(A[p][j], A[c][j]);
+            for (int r = c + 1; r < n; r++) { const double f = A[r][c] / A[c][c]; for (int j = c; j <= n; j++) A[r][j] -= f * A[c][j]; }
+        }
+        for (int i = n - 1; i >= 0; i--) { double v = A[i][n]; for (int j = i + 1; j < n; j++) v -= A[i][j] * dx[j]; dx[i] = v / A[i][i]; }
+        return true;
+    }
+    // GNSSVIAlign's three stages (EST:1972-2013) on gnss_meas_buf[0..W]: false = one of them failed
+    bool gnssViInitialize(double* refined_xyzt, double* rough_xyzt, double& aligned_yaw, double& aligned_ddt) const {
+        const int NPW = WINDOW_SIZE + 1;
+        size_t num_all = 0;
+        for (int i = 0; i < NPW; i++) num_all += gnss_meas_buf[i].size();
+        // 1. coarse_localization = psr_pos on all measurements of the window at one receiver position (gnss_vi_initializer.cpp:16-41)
+        {
+            std::vector<gf_gnss_obs> accum;
+            for (int i = 0; i < NPW; i++) accum.insert(accum.end(), gnss_meas_buf[i].begin(), gnss_meas_buf[i].end());
+            if (accum.size() < 4) return false;
+            double xyzt[7] = {0, 0, 0, 0, 0, 0, 0};
+            bool seen[4] = {false, false, false, false};
+            for (auto& o : accum) seen[o.sys] = true;
+            double dxn = 1.0; int it = 0;
+            while (it < 10 && dxn > 1e-4) {
+                std::vector<double> b, G;
+                psr_res(xyzt, accum, b, G);
+                for (int k = 0; k < 4; k++) if (!seen[k]) { double row[7] = {0, 0, 0, 0, 0, 0, 0}; row[3 + k] = 1.0; G.insert(G.end(), row, row + 7); b.push_back(0.0); }   // pin unobserved clocks
+                double dx[7];
+                if (!normal_solve(G, b, 7, dx)) return false;
+                dxn = 0; for (int k = 0; k < 7; k++) { xyzt[k] += dx[k]; dxn += dx[k] * dx[k]; }
+                dxn = sqrt(dxn); it++;
+            }
+            if (it == 10 && dxn > 1e-4) return false;
+            if (norm(arr3(xyzt)) == 0 || std::isnan(xyzt[0])) return false;
+            for (int k = 0; k < 4; k++) if (fabs(xyzt[3 + k]) < 1) xyzt[3 + k] = 0;   // not observed yet
+            memcpy(rough_xyzt, xyzt, sizeof(xyzt));
+        }
+        // 2. yaw_alignment (gnss_vi_initializer.cpp:43-104)
+        {
+            const V3 anchor = arr3(rough_xyzt);
+            const M3 Ree = ecef2rotation(anchor);
+            double est_yaw = 0, est_ddt = 0, dxn = 1.0; int it = 0;
+            while (it < 10 && dxn > 1e-5) {
+                std::vector<double> G, b;
+                const double cy = cos(est_yaw), sy_ = sin(est_yaw);
+                for (int i = 0; i < NPW; i++) {
+                    const V3 v = Vs[i];
+                    const V3 ve = Ree * v3(cy * v.x - sy_ * v.y, sy_ * v.x + cy * v.y, v.z);
+                    const double vd[4] = {ve.x, ve.y, ve.z, est_ddt};
+                    std::vector<double> r, Jd;
+                    dopp_res(vd, anchor, gnss_meas_buf[i], r, Jd);
+                    const V3 dv = Ree * v3(-sy_ * v.x - cy * v.y, cy * v.x - sy_ * v.y, 0.0);   // R_ecef_enu * tmp_M * local_v
+                    for (size_t q = 0; q < r.size(); q++) { G.push_back(Jd[4 * q] * dv.x + Jd[4 * q + 1] * dv.y + Jd[4 * q + 2] * dv.z); G.push_back(1.0); b.push_back(r[q]); }
+                }
+                double dx[2];
+                if (!normal_solve(G, b, 2, dx)) return false;
+                est_yaw += dx[0]; est_ddt += dx[1]; dxn = sqrt(dx[0] * dx[0] + dx[1] * dx[1]); it++;
+            }
+            aligned_yaw = est_yaw;
+            if (aligned_yaw > M_PI) aligned_yaw -= floor(est_yaw / (2.0 * M_PI) + 0.5) * (2.0 * M_PI);
+            else if (aligned_yaw < -M_PI) aligned_yaw -= ceil(est_yaw / (2.0 * M_PI) - 0.5) * (2.0 * M_PI);
+            aligned_ddt = est_ddt;
+        }
+        // 3. anchor_refinement (gnss_vi_initializer.cpp:106-172)
+        {
+            V3 anchor = arr3(rough_xyzt);
+            double dt4[4] = {rough_xyzt[3], rough_xyzt[4], rough_xyzt[5], rough_xyzt[6]};
+            const double cy = cos(aligned_yaw), sy_ = sin(aligned_yaw);
+            double dxn = 1.0; int it = 0;
+            while (it < 10 && dxn > 1e-5) {
+                std::vector<double> G, b;
+                const M3 Ree = ecef2rotation(anchor);
+                for (int i = 0; i < NPW; i++) {
+                    const V3 p = Ps[i];
+                    const V3 pe = Ree * v3(cy * p.x - sy_ * p.y, sy_ * p.x + cy * p.y, p.z) + anchor;
+                    const double st[7] = {pe.x, pe.y, pe.z, dt4[0] + aligned_ddt * i, dt4[1] + aligned_ddt * i, dt4[2] + aligned_ddt * i, dt4[3] + aligned_ddt * i};
+                    psr_res(st, gnss_meas_buf[i], b, G);
+                }
+                for (int k = 0; k < 4; k++) if (rough_xyzt[3 + k] == 0) { double row[7] = {0, 0, 0, 0, 0, 0, 0}; row[3 + k] = 1.0; G.insert(G.end(), row, row + 7); b.push_back(0.0); }
+                double dx[7];
+                if (!normal_solve(G, b, 7, dx)) return false;
+                anchor = anchor + arr3(dx);
+                dxn = 0; for (int k = 0; k < 7; k++) dxn += dx[k] * dx[k];
+                for (int k = 0; k < 4; k++) dt4[k] += dx[3 + k];
+                dxn = sqrt(dxn); it++;
+            }
+            refined_xyzt[0] = anchor.x; refined_xyzt[1] = anchor.y; refined_xyzt[2] = anchor.z;
+            for (int k = 0; k < 4; k++) refined_xyzt[3 + k] = dt4[k];
+        }
+        (void)num_all;
+        return true;
+    }
     void processGNSS(const std::vector<gf_gnss_obs>& gnss_meas) {  // EST:1455-1535; ephemeris look-up and L1 selection happen before the C boundary (gf_gnss_obs)
         std::vector<gf_gnss_obs> valid_meas;
         for (const gf_gnss_obs& obs : gnss_meas) {
@@ -554,15 +724,18 @@ struct gf_estimator {
         for (int i = 0; i <= WINDOW_SIZE; i++) { ax += fabs(Vs[i].x); ay += fabs(Vs[i].y); }
         ax /= WINDOW_SIZE + 1; ay /= WINDOW_SIZE + 1;
         if (sqrt(ax * ax + ay * ay) < 0.3) return false;
-        if (!align_pending) return false;   // where coarse_localization / yaw_alignment / anchor_refinement would fail
+        double refined[7], rough[7], yaw = 0, ddt = 0;
+        if (align_pending) {   // the caller ran its own initialiser (gf_estimator_set_gnss_alignment): take its result
+            memcpy(refined, align_anc, 24); memcpy(refined + 3, align_dt, 32); memcpy(rough, refined, sizeof(rough)); yaw = align_yaw; ddt = align_ddt;
+            align_pending = false;
+        } else if (!gnssViInitialize(refined, rough, yaw, ddt)) return false;   // :1972-2013
         int one_observed_sys = -1;
-        for (int k = 0; k < 4; k++) if (align_dt[k] != 0) { one_observed_sys = k; break; }
+        for (int k = 0; k < 4; k++) if (rough[3 + k] != 0) { one_observed_sys = k; break; }
         for (int i = 0; i <= WINDOW_SIZE; i++) {   // :2015-2036 (the drift is multiplied by the frame index, not by a time)
-            para_rcv_ddt[i] = align_ddt;
-            for (int k = 0; k < 4; k++) para_rcv_dt[4 * i + k] = (align_dt[k] == 0 ? (one_observed_sys < 0 ? 0.0 : align_dt[one_observed_sys]) : align_dt[k]) + align_ddt * i;
+            para_rcv_ddt[i] = ddt;
+            for (int k = 0; k < 4; k++) para_rcv_dt[4 * i + k] = (rough[3 + k] == 0 ? (one_observed_sys < 0 ? 0.0 : refined[3 + one_observed_sys]) : refined[3 + k]) + ddt * i;
         }
-        anc_ecef = arr3(align_anc); R_ecef_enu = ecef2rotation(anc_ecef); yaw_enu_local = align_yaw;
-        align_pending = false;
+        anc_ecef = arr3(refined); R_ecef_enu = ecef2rotation(anc_ecef); yaw_enu_local = yaw;
         return true;
     }
     void updateGNSSStatistics() {  // EST:2045-2058

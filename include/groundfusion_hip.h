@@ -253,8 +253,8 @@ int gf_wheel_preintegrate(int n, const double* dt, const double* vel, const doub
  * The dense work (Estimator::optimization, estimator.cpp:2890-3636) runs on the HIP back end behind gf_ba_*.
  * Built: RGB-D + IMU (+ wheel) (+ GNSS) configuration, stationary / wheel-activated initialisation (estimator.cpp:1557-1682),
  * MULTIPLE_THREAD 0/1 data flow (processed synchronously); GNSS: measurement gating, clock / anchor / yaw states, factors in the solve and the
- * marginalisation, with satellite states and the GNSS-VI alignment handed in (gf_gnss_obs, gf_estimator_set_gnss_alignment).
- * Not built: SfM initialisation, ephemeris decoding and GNSSVIAlign's own initialiser, line / plane / motion factors.
+ * marginalisation, GNSSVIAlign with its initialiser; satellite states are handed in (gf_gnss_obs).
+ * Not built: SfM initialisation, ephemeris decoding (gnss_comm), line / plane / motion factors.
  * ------------------------------------------------------------------------------------------------------------------------------ */
 typedef struct gf_estimator gf_estimator;
 
@@ -300,10 +300,10 @@ int gf_estimator_input_wheel(gf_estimator* h, double t, const double* vel, const
 int gf_estimator_input_gnss(gf_estimator* h, double t, const gf_gnss_obs* obs, int n);
 int gf_estimator_input_gnss_time_diff(gf_estimator* h, double diff_t_gnss_local);
 int gf_estimator_input_iono_params(gf_estimator* h, const double* params8);
-/* What GNSSVIAlign (estimator.cpp:1928-2043: coarse SPP localisation, yaw alignment, anchor refinement) would find: supplied by the caller in this build
- * (the initialiser needs gnss_comm's psr_pos).  The estimator applies it at the point where the reference runs GNSSVIAlign and
- * under its preconditions (visual-inertial part initialised, mean horizontal speed of the window >= 0.3 m/s): refined_xyzt = anc_ecef + rcv_dt[4],
- * aligned yaw and clock drift. */
+/* GNSSVIAlign (estimator.cpp:1928-2043) runs inside the library: GNSSVIInitializer (initial/gnss_vi_initializer.cpp: coarse SPP localisation of the
+ * window's measurements, yaw alignment on the Doppler residuals, anchor refinement) on the satellite states of gf_gnss_obs, under the reference's
+ * preconditions (visual-inertial part initialised, mean horizontal speed of the window >= 0.3 m/s).  A caller that has its own fix may hand it in
+ * instead: the next alignment attempt then takes refined_xyzt = anc_ecef + rcv_dt[4], yaw and clock drift from here (rcv_dt[k] = 0: system k unobserved). */
 int gf_estimator_set_gnss_alignment(gf_estimator* h, const double* anc_ecef, double yaw_enu_local, const double* rcv_dt4, double rcv_ddt);
 /* gnss[8]: gnss_ready, lowspeed, #valid measurements of the newest frame, first_optimization, then 4 reserved; any pointer may be NULL.
  * rcv_dt 4 (W+1), rcv_ddt (W+1), anc_ecef 3, ecef_pos 3, enu_pos 3 (updateGNSSStatistics, estimator.cpp:2045-2058) */

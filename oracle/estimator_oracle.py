@@ -65,6 +65,92 @@ def ecef2rotation(p):
     return np.array([[-so, -sl * co, cl * co], [co, -sl * so, cl * so], [0.0, cl, sl]])
 
 
+C_LIGHT, OMG_E = 2.99792458e8, 7.2921151467e-5
+
+
+def sat_azel(rcv, sat):
+    dl = np.asarray(sat, float) - np.asarray(rcv, float)
+    dl = dl / np.linalg.norm(dl)
+    enu = ecef2rotation(rcv).T @ dl
+    az = 0.0 if math.hypot(dl[0], dl[1]) < 1e-12 else math.atan2(enu[0], enu[1])
+    if az < 0:
+        az += 2 * math.pi
+    return az, math.asin(enu[2])
+
+
+def trop_delay(lla, el):
+    """Saastamoinen, standard atmosphere, relative humidity 0.7 (gnss_comm calculate_trop_delay; RTKLIB tropmodel)"""
+    if lla[2] < -100.0 or 1e4 < lla[2] or el <= 0:
+        return 0.0
+    hgt = 0.0 if lla[2] < 0.0 else lla[2]
+    pres = 1013.25 * (1.0 - 2.2557e-5 * hgt) ** 5.2568
+    temp = 15.0 - 6.5e-3 * hgt + 273.16
+    e = 6.108 * 0.7 * math.exp((17.15 * temp - 4684.0) / (temp - 38.45))
+    z = math.pi / 2.0 - el
+    trph = 0.0022768 * pres / (1.0 - 0.00266 * math.cos(2.0 * math.radians(lla[0])) - 0.00028 * hgt / 1e3) / math.cos(z)
+    return trph + 0.002277 * (1255.0 / temp + 0.05) * e / math.cos(z)
+
+
+def ion_delay(tow, ion_in, lla, az, el):
+    """Klobuchar (gnss_comm calculate_ion_delay; RTKLIB ionmodel)"""
+    ion_default = [0.1118e-07, -0.7451e-08, -0.5961e-07, 0.1192e-06, 0.1167e+06, -0.2294e+06, -0.1311e+06, 0.1049e+07]
+    if lla[2] < -1e3 or el <= 0:
+        return 0.0
+    ion = list(ion_in) if float(np.dot(ion_in, ion_in)) > 0.0 else ion_default
+    psi = 0.0137 / (el / math.pi + 0.11) - 0.022
+    phi = lla[0] / 180.0 + psi * math.cos(az)
+    phi = 0.416 if phi > 0.416 else (-0.416 if phi < -0.416 else phi)
+    lam = lla[1] / 180.0 + psi * math.sin(az) / math.cos(phi * math.pi)
+    phi += 0.064 * math.cos((lam - 1.617) * math.pi)
+    tt = 43200.0 * lam + tow
+    tt -= math.floor(tt / 86400.0) * 86400.0
+    f = 1.0 + 16.0 * (0.53 - el / math.pi) ** 3
+    amp = ion[0] + phi * (ion[1] + phi * (ion[2] + phi * ion[3]))
+    per = ion[4] + phi * (ion[5] + phi * (ion[6] + phi * ion[7]))
+    amp = 0.0 if amp < 0.0 else amp
+    per = 72000.0 if per < 72000.0 else per
+    x = 2.0 * math.pi * (tt - 50400.0) / per
+    return C_LIGHT * f * (5e-9 + amp * (1.0 + x * x * (-0.5 + x * x / 24.0)) if abs(x) < 1.57 else 5e-9)
+
+
+def psr_res(xyzt, meas, iono):
+    """gnss_comm psr_res restated with the measurement model of GnssPsrDoppFactor::Evaluate (gnss_psr_dopp_factor.cpp:76-97): residuals and rows
+    [-unit(rcv -> sat), 1 on the clock of the satellite's system]"""
+    rcv = np.asarray(xyzt[0:3], float)
+    res, J = [], []
+    for o in meas:
+        sv = np.asarray(o["sv_pos"], float)
+        ion = tro = 0.0
+        if np.linalg.norm(rcv) > 0:
+            lla = ecef2geo(rcv)
+            az, el = sat_azel(rcv, sv)
+            tro, ion = trop_delay(lla, el), ion_delay(o["tow"], iono, lla, az, el)
+        r2s = sv - rcv
+        rg = np.linalg.norm(r2s)
+        est = rg + OMG_E * (sv[0] * rcv[1] - sv[1] * rcv[0]) / C_LIGHT + xyzt[3 + o["sys"]] - o["svdt"] * C_LIGHT + ion + tro + o["tgd"] * C_LIGHT
+        res.append(est - o["psr"])
+        row = np.zeros(7)
+        row[0:3] = -r2s / rg
+        row[3 + o["sys"]] = 1.0
+        J.append(row)
+    return np.array(res), np.array(J).reshape(-1, 7)
+
+
+def dopp_res(vel_ddt, rcv, meas):
+    """gnss_comm dopp_res with the Doppler model of the same factor (:99-101)"""
+    vel, rcv = np.asarray(vel_ddt[0:3], float), np.asarray(rcv, float)
+    res, J = [], []
+    for o in meas:
+        sv, svv = np.asarray(o["sv_pos"], float), np.asarray(o["sv_vel"], float)
+        r2s = sv - rcv
+        unit = r2s / np.linalg.norm(r2s)
+        sag = OMG_E / C_LIGHT * (svv[0] * rcv[1] + sv[0] * vel[1] - svv[1] * rcv[0] - sv[1] * vel[0])
+        est = (svv - vel) @ unit + vel_ddt[3] + sag - o["svddt"] * C_LIGHT
+        res.append(est + o["dopp"] * o["wavelength"])
+        J.append(np.array([-unit[0], -unit[1], -unit[2], 1.0]))
+    return np.array(res), np.array(J).reshape(-1, 4)
+
+
 def sat_elevation(rcv, sat):
     dl = np.asarray(sat, float) - np.asarray(rcv, float)
     dl = dl / np.linalg.norm(dl)
@@ -534,18 +620,101 @@ class Estimator:
             return True
         if self._avg_hor_vel() < 0.3:
             return False
-        if self.alignment is None:
-            return False
-        anc, yaw, dt4, ddt = self.alignment
-        observed = [k for k in range(4) if dt4[k] != 0]
-        for i in range(self.W + 1):
+        if self.alignment is not None:   # the caller's own initialiser result
+            anc, yaw, dt4, ddt = self.alignment
+            refined = rough = np.concatenate([anc, dt4])
+            self.alignment = None
+        else:
+            out = self.gnssViInitialize()
+            if out is None:
+                return False
+            refined, rough, yaw, ddt = out
+        observed = [k for k in range(4) if rough[3 + k] != 0]
+        for i in range(self.W + 1):   # :2015-2036
             self.para_rcv_ddt[i] = ddt
             for k in range(4):
-                base = dt4[k] if dt4[k] != 0 else (dt4[observed[0]] if observed else 0.0)
+                base = refined[3 + k] if rough[3 + k] != 0 else (refined[3 + observed[0]] if observed else 0.0)
                 self.para_rcv_dt[i, k] = base + ddt * i
-        self.anc_ecef, self.R_ecef_enu, self.yaw_enu_local = anc.copy(), ecef2rotation(anc), yaw
-        self.alignment = None
+        self.anc_ecef, self.yaw_enu_local = np.array(refined[0:3], float), float(yaw)
+        self.R_ecef_enu = ecef2rotation(self.anc_ecef)
         return True
+
+    def gnssViInitialize(self):
+        """GNSSVIInitializer (initial/gnss_vi_initializer.cpp): coarse_localization (= gnss_comm psr_pos on all measurements of the window),
+        yaw_alignment, anchor_refinement; None where one of them fails"""
+        W, iono = self.W, self.latest_gnss_iono_params
+        accum = [o for b in self.gnss_meas_buf for o in b]
+        if len(accum) < 4:
+            return None
+        solve = lambda G, b: -np.linalg.solve(G.T @ G, G.T @ b)
+        xyzt = np.zeros(7)
+        seen = {o["sys"] for o in accum}
+        pins = [k for k in range(4) if k not in seen]
+        dxn, it = 1.0, 0
+        while it < 10 and dxn > 1e-4:   # psr_pos: Gauss-Newton from the Earth's centre, unobserved clocks pinned to zero
+            b, G = psr_res(xyzt, accum, iono)
+            for k in pins:
+                row = np.zeros(7)
+                row[3 + k] = 1.0
+                G, b = np.vstack([G, row]), np.append(b, 0.0)
+            dx = solve(G, b)
+            xyzt = xyzt + dx
+            dxn = float(np.linalg.norm(dx))
+            it += 1
+        if (it == 10 and dxn > 1e-4) or np.linalg.norm(xyzt[0:3]) == 0 or math.isnan(xyzt[0]):
+            return None
+        for k in range(4):
+            if abs(xyzt[3 + k]) < 1:
+                xyzt[3 + k] = 0.0
+        rough = xyzt.copy()
+        anchor = rough[0:3].copy()
+        Ree = ecef2rotation(anchor)
+        est_yaw, est_ddt, dxn, it = 0.0, 0.0, 1.0, 0
+        while it < 10 and dxn > 1e-5:   # yaw_alignment
+            G, b = [], []
+            cy, sy = math.cos(est_yaw), math.sin(est_yaw)
+            for i in range(W + 1):
+                v = self.Vs[i]
+                ve = Ree @ np.array([cy * v[0] - sy * v[1], sy * v[0] + cy * v[1], v[2]])
+                r, Jd = dopp_res([*ve, est_ddt], anchor, self.gnss_meas_buf[i])
+                dv = Ree @ np.array([-sy * v[0] - cy * v[1], cy * v[0] - sy * v[1], 0.0])
+                for q in range(len(r)):
+                    G.append([Jd[q, 0:3] @ dv, 1.0])
+                    b.append(r[q])
+            dx = solve(np.array(G), np.array(b))
+            est_yaw += dx[0]
+            est_ddt += dx[1]
+            dxn = float(np.linalg.norm(dx))
+            it += 1
+        yaw = est_yaw
+        if yaw > math.pi:
+            yaw -= math.floor(est_yaw / (2.0 * math.pi) + 0.5) * (2.0 * math.pi)
+        elif yaw < -math.pi:
+            yaw -= math.ceil(est_yaw / (2.0 * math.pi) - 0.5) * (2.0 * math.pi)
+        dt4 = rough[3:7].copy()
+        cy, sy = math.cos(yaw), math.sin(yaw)
+        dxn, it = 1.0, 0
+        while it < 10 and dxn > 1e-5:   # anchor_refinement
+            Gs, bs = [], []
+            Ree = ecef2rotation(anchor)
+            for i in range(W + 1):
+                p = self.Ps[i]
+                pe = Ree @ np.array([cy * p[0] - sy * p[1], sy * p[0] + cy * p[1], p[2]]) + anchor
+                r, J = psr_res(np.concatenate([pe, dt4 + est_ddt * i]), self.gnss_meas_buf[i], iono)
+                Gs.append(J)
+                bs.append(r)
+            for k in range(4):
+                if rough[3 + k] == 0:
+                    row = np.zeros((1, 7))
+                    row[0, 3 + k] = 1.0
+                    Gs.append(row)
+                    bs.append(np.zeros(1))
+            dx = solve(np.vstack(Gs), np.concatenate(bs))
+            anchor = anchor + dx[0:3]
+            dt4 = dt4 + dx[3:7]
+            dxn = float(np.linalg.norm(dx))
+            it += 1
+        return np.concatenate([anchor, dt4]), rough, yaw, est_ddt
 
     def updateGNSSStatistics(self):  # EST:2045-2058
         c, s = math.cos(self.yaw_enu_local), math.sin(self.yaw_enu_local)

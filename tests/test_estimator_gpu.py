@@ -209,8 +209,8 @@ def test_group_of_sequences_on_one_batched_solver():
         e.close()
 
 
-@pytest.mark.parametrize("window_size", [10, 20])
-def test_replay_with_gnss_matches_oracle(window_size):
+@pytest.mark.parametrize("window_size,own_initialiser", [(10, False), (20, False), (10, True)])
+def test_replay_with_gnss_matches_oracle(window_size, own_initialiser):
     """GNSS raw measurements through the estimator: inputGNSS -> getGNSSInterval -> processGNSS gating
     (estimator.cpp:476-510, :1455-1535), the PoseAnchorFactor of the first optimisation (:2943-2951), GNSS-VI alignment under the reference's
     preconditions (:1928-1962; the initialiser's result is handed in), receiver-clock / anchor / yaw blocks and GnssPsrDoppFactor, DtDdtFactor,
@@ -226,7 +226,9 @@ def test_replay_with_gnss_matches_oracle(window_size):
     reference's own truncation (marginalization_factor.cpp:276-282 zeroes eigenvalues below 1e-8): in the W = 20 replay the wheel blocks enter
     the prior with eigenvalues 2.7e-8 and 4.4e-8 -- next to the cut -- and the anchor of the two pipelines then differs by 5e-4 m for the rest
     of the crawl (scripts/gnss_replay.py --w20 --single: identical solves to 1 ulp, identical priors to 1e-9 before that frame).  Bar 2e-3 m
-    for the anchor / ECEF position of `lowspeed` frames; every local quantity keeps the 1e-6 bar."""
+    for the anchor / ECEF position of `lowspeed` frames; every local quantity keeps the 1e-6 bar.
+    own_initialiser: nobody hands an alignment in; the library runs GNSSVIInitializer itself (initial/gnss_vi_initializer.cpp: SPP fix of the window's
+    measurements, yaw alignment on the Doppler residuals, anchor refinement) and must arrive where the numpy restatement does."""
     W = window_size
     st = SS.Stream(3, t_still=1.5, t_move=4.5 if W == 10 else 5.7, v_max=0.4 if W == 10 else 0.35, yaw0=0.0, yaw_turn=-0.6, split_x=1.8, turn_delay=0.8, slow_tail=1.5)
     st._lm = st._landmarks(1600)
@@ -251,7 +253,8 @@ def test_replay_with_gnss_matches_oracle(window_size):
         frame = st.feature_frame(k)
         for e in (est_o, est_p):
             e.inputGNSS(tg, epoch)
-            e.setGNSSAlignment(*al)          # a receiver-side SPP / alignment result is on offer at every frame; the estimator takes it when GNSSVIAlign's conditions hold
+            if not own_initialiser:
+                e.setGNSSAlignment(*al)      # a receiver-side SPP / alignment result is on offer at every frame; the estimator takes it when GNSSVIAlign's conditions hold
             e.inputFeature(tk, frame)
         compare_frame(est_o, est_p, worst, "gnss frame %d" % k)
         g = est_p.gnss_state()
@@ -274,7 +277,9 @@ def test_replay_with_gnss_matches_oracle(window_size):
             key = "_low" if est_o.lowspeed else ""
             worst["anc" + key] = max(worst["anc" + key], float(np.abs(g["anc_ecef"] - est_o.anc_ecef).max()))
             worst["ecef" + key] = max(worst["ecef" + key], float(np.abs(g["ecef_pos"] - est_o.ecef_pos).max()), float(np.abs(g["enu_pos"] - est_o.enu_pos).max()))
-            assert g["yaw_enu_local"] == est_o.yaw_enu_local                 # held constant (estimator.cpp:2930)
+            assert abs(g["yaw_enu_local"] - est_o.yaw_enu_local) <= (1e-9 if own_initialiser else 0.0)   # held constant (estimator.cpp:2930)
+            if own_initialiser:
+                assert abs(est_o.yaw_enu_local - G["yaw_enu_local"]) < 0.05     # the Doppler alignment found the true ENU <- local yaw (0.05 rad: 0.4 m/s of speed, 5 cm/s of Doppler noise)
             # what the measurements see: modelled range + receiver clock of every admitted satellite of the newest frame, from either pipeline's states
             # (frame W - 1: the slide has already emptied the newest slot)
             s_ = est_p.state()
@@ -296,6 +301,6 @@ def test_replay_with_gnss_matches_oracle(window_size):
     print("gnss replay W=%d worst deviation" % W, worst, "ATE rmse %.4f m over %d frames" % (rmse, len(ate)))
     assert rmse < 0.05                                                       # 1.4 m of driving; observed 0.01
     assert worst["p"] < 1e-6 and worst["r"] < 1e-6, worst
-    assert worst["clk"] < 1e-3 and worst["anc"] < 1e-3 and worst["ecef"] < 1e-3 and worst["rho"] < 1e-3, worst
-    assert worst["anc_low"] < 2e-3 and worst["ecef_low"] < 2e-3, worst
+    assert worst["clk"] < 1e-3 and worst["anc"] < 1e-3 and worst["ecef"] < 1e-3, worst
+    assert worst["anc_low"] < 2e-3 and worst["ecef_low"] < 2e-3 and worst["rho"] < 2e-3, worst      # rho runs over the `lowspeed` frames too
     est_p.close()
