@@ -327,6 +327,93 @@ struct ImageFrame {  // initial/initial_alignment.h ImageFrame: only what the no
 // windows go to the device in one gf_ba_solve / gf_ba_marginalize call of the shared handle -- the batched kernels see B windows per
 // launch although each Estimator keeps the reference's single-sequence control flow.  A member outside a group step (a frame that
 // waited for IMU data and is taken by a later inputIMU) is simply a batch of one.
+// ---------------------------------------------------------------- broadcast ephemerides -> satellite state (gnss_comm eph2pos / geph2pos / eph2svdt / eph2vel,
+// not vendored by the reference: restated from the published broadcast-orbit algorithms, RTKLIB ephemeris.c lineage)
+namespace gnss_eph {
+constexpr double kC = 2.99792458e8;
+constexpr double MU_GPS = 3.9860050e14, MU_GAL = 3.986004418e14, MU_CMP = 3.986004418e14, OMGE_GPS = 7.2921151467e-5, OMGE_GAL = 7.2921151467e-5, OMGE_CMP = 7.292115e-5;
+constexpr double MU_GLO = 3.9860044e14, J2_GLO = 1.0826257e-3, OMGE_GLO = 7.292115e-5, RE_GLO = 6378136.0, TSTEP = 60.0;
+constexpr double SIN_5 = -0.0871557427476582, COS_5 = 0.9961946980917456;   // sin(-5 deg), cos(-5 deg): BeiDou GEO frame
+inline double eph2svdt(double t, const gf_gnss_ephem& e) {   // eph2clk
+    double tk = t - e.toc;
+    for (int i = 0; i < 2; i++) tk -= e.af0 + e.af1 * tk + e.af2 * tk * tk;
+    return e.af0 + e.af1 * tk + e.af2 * tk * tk;
+}
+inline V3 eph2pos(double t, const gf_gnss_ephem& e, double* svdt) {   // IS-GPS-200 table 20-IV; BeiDou GEO satellites in their inclined frame
+    const double mu = e.sys == 2 ? MU_GAL : e.sys == 3 ? MU_CMP : MU_GPS, omge = e.sys == 2 ? OMGE_GAL : e.sys == 3 ? OMGE_CMP : OMGE_GPS;
+    double tk = t - e.toe;
+    const double M = e.M0 + (sqrt(mu / (e.A * e.A * e.A)) + e.delta_n) * tk;
+    double E = M, Ek = 0;
+    for (int n = 0; fabs(E - Ek) > 1e-13 && n < 30; n++) { Ek = E; E -= (E - e.e * sin(E) - M) / (1.0 - e.e * cos(E)); }
+    const double sinE = sin(E), cosE = cos(E);
+    double u = atan2(sqrt(1.0 - e.e * e.e) * sinE, cosE - e.e) + e.omg, r = e.A * (1.0 - e.e * cosE), i = e.i0 + e.i_dot * tk;
+    const double sin2u = sin(2.0 * u), cos2u = cos(2.0 * u);
+    u += e.cus * sin2u + e.cuc * cos2u; r += e.crs * sin2u + e.crc * cos2u; i += e.cis * sin2u + e.cic * cos2u;
+    const double x = r * cos(u), y = r * sin(u), cosi = cos(i);
+    V3 rs;
+    if (e.sys == 3 && (e.prn <= 5 || e.prn >= 59)) {
+        const double O = e.OMG0 + e.OMG_dot * tk - omge * e.toe_tow, sinO = sin(O), cosO = cos(O);
+        const double xg = x * cosO - y * cosi * sinO, yg = x * sinO + y * cosi * cosO, zg = y * sin(i), sino = sin(omge * tk), coso = cos(omge * tk);
+        rs = v3(xg * coso + yg * sino * COS_5 + zg * sino * SIN_5, -xg * sino + yg * coso * COS_5 + zg * coso * SIN_5, -yg * SIN_5 + zg * COS_5);
+    } else {
+        const double O = e.OMG0 + (e.OMG_dot - omge) * tk - omge * e.toe_tow, sinO = sin(O), cosO = cos(O);
+        rs = v3(x * cosO - y * cosi * sinO, x * sinO + y * cosi * cosO, y * sin(i));
+    }
+    if (svdt) { tk = t - e.toc; *svdt = e.af0 + e.af1 * tk + e.af2 * tk * tk - 2.0 * sqrt(mu * e.A) * e.e * sinE / (kC * kC); }
+    return rs;
+}
+inline void glo_deq(const double* x, double* xdot, const double* acc) {
+    const double r2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2], r3 = r2 * sqrt(r2), omg2 = OMGE_GLO * OMGE_GLO;
+    const double a = 1.5 * J2_GLO * MU_GLO * RE_GLO * RE_GLO / r2 / r3, b = 5.0 * x[2] * x[2] / r2, c = -MU_GLO / r3 - a * (1.0 - b);
+    xdot[0] = x[3]; xdot[1] = x[4]; xdot[2] = x[5];
+    xdot[3] = (c + omg2) * x[0] + 2.0 * OMGE_GLO * x[4] + acc[0];
+    xdot[4] = (c + omg2) * x[1] - 2.0 * OMGE_GLO * x[3] + acc[1];
+    xdot[5] = (c - 2.0 * a) * x[2] + acc[2];
+}
+inline void glorbit(double t, double* x, const double* acc) {   // one Runge-Kutta step
+    double k1[6], k2[6], k3[6], k4[6], w[6];
+    glo_deq(x, k1, acc); for (int i = 0; i < 6; i++) w[i] = x[i] + k1[i] * t / 2.0;
+    glo_deq(w, k2, acc); for (int i = 0; i < 6; i++) w[i] = x[i] + k2[i] * t / 2.0;
+    glo_deq(w, k3, acc); for (int i = 0; i < 6; i++) w[i] = x[i] + k3[i] * t;
+    glo_deq(w, k4, acc);
+    for (int i = 0; i < 6; i++) x[i] += (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]) * t / 6.0;
+}
+inline double geph2svdt(double t, const gf_gnss_glo_ephem& g) {   // geph2clk
+    double tk = t - g.toe;
+    for (int i = 0; i < 2; i++) tk -= -g.tau_n + g.gamma * tk;
+    return -g.tau_n + g.gamma * tk;
+}
+inline V3 geph2pos(double t, const gf_gnss_glo_ephem& g, double* svdt) {
+    double tk = t - g.toe;
+    if (svdt) *svdt = -g.tau_n + g.gamma * tk;
+    double x[6] = {g.pos[0], g.pos[1], g.pos[2], g.vel[0], g.vel[1], g.vel[2]};
+    for (double tt = tk < 0.0 ? -TSTEP : TSTEP; fabs(tk) > 1e-9; tk -= tt) { if (fabs(tk) < TSTEP) tt = tk; glorbit(tt, x, g.acc); }
+    return v3(x[0], x[1], x[2]);
+}
+// GnssPsrDoppFactor's constructor (gnss_psr_dopp_factor.cpp:3-47)
+inline void sat_state(const gf_gnss_raw_obs& r, const gf_gnss_ephem* e, const gf_gnss_glo_ephem* g, gf_gnss_obs* o) {
+    memset(o, 0, sizeof(*o));
+    o->sat = r.sat; o->sys = r.sys; o->time = r.time; o->psr = r.psr; o->dopp = r.dopp; o->psr_std = r.psr_std; o->dopp_std = r.dopp_std; o->wavelength = kC / r.freq; o->tow = r.tow;
+    double sv_tx = r.time - r.psr / kC, svdt, svddt, d1, d2;
+    V3 p, p2;
+    const double tt = 1e-3;   // eph2vel / geph2vel: difference quotient over 1 ms, position and clock alike
+    if (g) {
+        svdt = geph2svdt(sv_tx, *g); sv_tx -= svdt;
+        p = geph2pos(sv_tx, *g, &d1); p2 = geph2pos(sv_tx + tt, *g, &d2);
+        o->tgd = 0.0; o->pr_uura = 2.0 * (r.psr_std / 0.16); o->dp_uura = 2.0 * (r.dopp_std / 0.256);
+    } else {
+        svdt = eph2svdt(sv_tx, *e); sv_tx -= svdt;
+        p = eph2pos(sv_tx, *e, &d1); p2 = eph2pos(sv_tx + tt, *e, &d2);
+        o->tgd = e->tgd0;
+        const double k = e->sys == 2 ? e->ura - 2.0 : e->ura - 1.0;
+        o->pr_uura = k * (r.psr_std / 0.16); o->dp_uura = k * (r.dopp_std / 0.256);
+    }
+    svdt = d1; svddt = (d2 - d1) / tt;
+    const V3 v = (p2 - p) / tt;
+    o->sv_pos[0] = p.x; o->sv_pos[1] = p.y; o->sv_pos[2] = p.z; o->sv_vel[0] = v.x; o->sv_vel[1] = v.y; o->sv_vel[2] = v.z; o->svdt = svdt; o->svddt = svddt;
+}
+}  // namespace gnss_eph
+
 // A generation counter many threads sleep on (futex): bump() wakes them all at once and none of them has to take a lock to find out why it woke.
 // (A condition variable makes 256 sleepers queue up on its mutex one after the other -- milliseconds per rendezvous at this group size.)
 struct Gate {
@@ -457,8 +544,12 @@ struct gf_estimator {
         }
     } scratch;
     // GNSS (estimator.h:293-331): epoch queue, per-frame measurement buffers, receiver clock / anchor / yaw states
-    std::deque<std::pair<double, std::vector<gf_gnss_obs>>> GNSSBuf;
-    std::vector<gf_gnss_obs> gnss_msg;                       // member of the reference too: the last epoch taken stays until the next one (EST:503-508, :656)
+    struct GMsgObs { gf_gnss_obs o; gf_gnss_raw_obs raw; bool is_raw; };   // an observation of a queued message: with its satellite state, or raw (ephemeris resolved in processGNSS)
+    std::deque<std::pair<double, std::vector<GMsgObs>>> GNSSBuf;
+    std::vector<GMsgObs> gnss_msg;                           // member of the reference too: the last epoch taken stays until the next one (EST:503-508, :656)
+    // inputEphem (EST:1428-1437): per satellite the ephemerides in arrival order and toe -> index; GLONASS in its own table
+    std::map<int, std::vector<gf_gnss_ephem>> sat2ephem; std::map<int, std::vector<gf_gnss_glo_ephem>> sat2gephem;
+    std::map<int, std::map<double, size_t>> sat2time_index;
     std::vector<std::vector<gf_gnss_obs>> gnss_meas_buf;     // [WINDOW_SIZE + 1]
     std::map<int, int> sat_track_status;
     bool gnss_ready = false, first_optimization = true, lowspeed = false, align_pending = false;
@@ -507,7 +598,7 @@ struct gf_estimator {
     // ------------------------------------------------------------ GNSS intake
     bool getGNSSInterval(double /*t0*/, double t1) {  // EST:476-510: stale epochs are thrown away, then the front epoch is taken whatever its age
         if (GNSSBuf.empty()) return false;
-        while (!GNSSBuf.empty() && GNSSBuf.front().second[0].time < t1 + diff_t_gnss_local - 0.1 /* MAX_GNSS_CAMERA_DELAY */) {
+        while (!GNSSBuf.empty() && GNSSBuf.front().second[0].o.time < t1 + diff_t_gnss_local - 0.1 /* MAX_GNSS_CAMERA_DELAY */) {
             GNSSBuf.pop_front();
             if (GNSSBuf.empty()) return false;
         }
@@ -705,15 +796,29 @@ struct gf_estimator {
         (void)num_all;
         return true;
     }
-    void processGNSS(const std::vector<gf_gnss_obs>& gnss_meas) {  // EST:1455-1535; ephemeris look-up and L1 selection happen before the C boundary (gf_gnss_obs)
+    void processGNSS(const std::vector<GMsgObs>& gnss_meas) {  // EST:1455-1535 (L1 selection happens before the C boundary)
         std::vector<gf_gnss_obs> valid_meas;
-        for (const gf_gnss_obs& obs : gnss_meas) {
+        for (const GMsgObs& m : gnss_meas) {
+            const gf_gnss_obs& obs = m.o;
             if (obs.sys < 0 || obs.sys > 3) continue;                                             // :1463-1465
+            const gf_gnss_ephem* eph = nullptr; const gf_gnss_glo_ephem* geph = nullptr;
+            if (m.is_raw) {                                                                       // :1467-1495: the satellite's ephemeris nearest in toe, within EPH_VALID_SECONDS
+                const auto ti = sat2time_index.find(obs.sat);
+                if (ti == sat2time_index.end()) continue;
+                double ephem_time = 7200.0; size_t ephem_index = 0;
+                for (const auto& kv : ti->second) if (fabs(kv.first - obs.time) < ephem_time) { ephem_time = fabs(kv.first - obs.time); ephem_index = kv.second; }
+                if (ephem_time >= 7200.0) continue;
+                if (obs.sys == 1) geph = &sat2gephem.at(obs.sat)[ephem_index]; else eph = &sat2ephem.at(obs.sat)[ephem_index];
+            }
             if (obs.psr_std > cfg.gnss_psr_std_thres || obs.dopp_std > cfg.gnss_dopp_std_thres) { sat_track_status[obs.sat] = 0; continue; }   // :1499-1504
             ++sat_track_status[obs.sat];                                                          // :1505-1510
             if (sat_track_status[obs.sat] < cfg.gnss_track_num_thres) continue;                   // :1511-1512
-            if (gnss_ready && sat_elevation(ecef_pos, arr3(obs.sv_pos)) < cfg.gnss_elevation_thres * M_PI / 180.0) continue;   // :1515-1526
-            valid_meas.push_back(obs);
+            if (gnss_ready) {                                                                     // :1515-1526: the satellite at the reception time when the ephemeris is here
+                const V3 sat_ecef = m.is_raw ? (geph ? gnss_eph::geph2pos(obs.time, *geph, nullptr) : gnss_eph::eph2pos(obs.time, *eph, nullptr)) : arr3(obs.sv_pos);
+                if (sat_elevation(ecef_pos, sat_ecef) < cfg.gnss_elevation_thres * M_PI / 180.0) continue;
+            }
+            if (m.is_raw) { gf_gnss_obs st; gnss_eph::sat_state(m.raw, eph, geph, &st); valid_meas.push_back(st); }   // what the factor's constructor derives (gnss_psr_dopp_factor.cpp:3-47)
+            else valid_meas.push_back(obs);
         }
         gnss_meas_buf[frame_count] = std::move(valid_meas);
     }
@@ -1398,7 +1503,52 @@ int gf_estimator_input_gnss(gf_estimator* e, double t, const gf_gnss_obs* obs, i
     if (!e || !obs || n < 1) return gf::set_err(GF_ERR_INVALID, "an epoch needs at least one observation (getGNSSInterval reads the first one's time, EST:489)");
     if (!e->cfg.gnss_enable) return gf::set_err(GF_ERR_INVALID, "estimator was created with gnss_enable 0");
     if (n > e->cfg.max_gnss_per_frame) return gf::set_err(GF_ERR_CAPACITY, "epoch with %d observations, max_gnss_per_frame %d", n, e->cfg.max_gnss_per_frame);
-    e->GNSSBuf.emplace_back(t, std::vector<gf_gnss_obs>(obs, obs + n));
+    std::vector<gf_estimator::GMsgObs> v(n);
+    for (int i = 0; i < n; i++) { v[i].o = obs[i]; v[i].is_raw = false; }
+    e->GNSSBuf.emplace_back(t, std::move(v));
+    return GF_OK;
+}
+int gf_estimator_input_gnss_raw(gf_estimator* e, double t, const gf_gnss_raw_obs* obs, int n) {  // Estimator::inputGNSS with the observations as they come off the receiver
+    if (!e || !obs || n < 1) return gf::set_err(GF_ERR_INVALID, "an epoch needs at least one observation (getGNSSInterval reads the first one's time, EST:489)");
+    if (!e->cfg.gnss_enable) return gf::set_err(GF_ERR_INVALID, "estimator was created with gnss_enable 0");
+    if (n > e->cfg.max_gnss_per_frame) return gf::set_err(GF_ERR_CAPACITY, "epoch with %d observations, max_gnss_per_frame %d", n, e->cfg.max_gnss_per_frame);
+    std::vector<gf_estimator::GMsgObs> v(n);
+    for (int i = 0; i < n; i++) {
+        if (!(obs[i].freq > 0)) return gf::set_err(GF_ERR_INVALID, "observation %d: carrier frequency must be positive", i);
+        memset(&v[i].o, 0, sizeof(v[i].o));
+        v[i].raw = obs[i]; v[i].is_raw = true;
+        v[i].o.sat = obs[i].sat; v[i].o.sys = obs[i].sys; v[i].o.time = obs[i].time; v[i].o.psr_std = obs[i].psr_std; v[i].o.dopp_std = obs[i].dopp_std;
+    }
+    e->GNSSBuf.emplace_back(t, std::move(v));
+    return GF_OK;
+}
+int gf_estimator_input_ephem(gf_estimator* e, const gf_gnss_ephem* eph) {  // Estimator::inputEphem EST:1428-1437: a (satellite, toe) pair is taken once
+    if (!e || !eph) return gf::set_err(GF_ERR_INVALID, "null argument");
+    if (eph->sys != 0 && eph->sys != 2 && eph->sys != 3) return gf::set_err(GF_ERR_INVALID, "gf_gnss_ephem is for GPS (0), Galileo (2) and BeiDou (3); GLONASS goes through gf_estimator_input_glo_ephem");
+    if (!(eph->A > 0)) return gf::set_err(GF_ERR_INVALID, "semi-major axis must be positive");
+    auto& idx = e->sat2time_index[eph->sat];
+    if (idx.count(eph->toe)) return GF_OK;
+    e->sat2ephem[eph->sat].push_back(*eph);
+    idx.emplace(eph->toe, e->sat2ephem[eph->sat].size() - 1);
+    return GF_OK;
+}
+int gf_estimator_input_glo_ephem(gf_estimator* e, const gf_gnss_glo_ephem* g) {
+    if (!e || !g) return gf::set_err(GF_ERR_INVALID, "null argument");
+    auto& idx = e->sat2time_index[g->sat];
+    if (idx.count(g->toe)) return GF_OK;
+    e->sat2gephem[g->sat].push_back(*g);
+    idx.emplace(g->toe, e->sat2gephem[g->sat].size() - 1);
+    return GF_OK;
+}
+int gf_gnss_obs_from_ephem(const gf_gnss_raw_obs* raw, const gf_gnss_ephem* eph, const gf_gnss_glo_ephem* geph, gf_gnss_obs* out) {
+    if (!raw || !out || (eph == nullptr) == (geph == nullptr) || !(raw->freq > 0)) return gf::set_err(GF_ERR_INVALID, "bad argument (exactly one ephemeris, positive frequency)");
+    gnss_eph::sat_state(*raw, eph, geph, out);
+    return GF_OK;
+}
+int gf_gnss_eph2pos(double t, const gf_gnss_ephem* eph, const gf_gnss_glo_ephem* geph, double* pos3, double* svdt) {
+    if (!pos3 || (eph == nullptr) == (geph == nullptr)) return gf::set_err(GF_ERR_INVALID, "bad argument (exactly one ephemeris)");
+    const V3 p = eph ? gnss_eph::eph2pos(t, *eph, svdt) : gnss_eph::geph2pos(t, *geph, svdt);
+    pos3[0] = p.x; pos3[1] = p.y; pos3[2] = p.z;
     return GF_OK;
 }
 int gf_estimator_input_gnss_time_diff(gf_estimator* e, double t_diff) {  // EST:1450-1453

@@ -384,6 +384,50 @@ class EstimatorCfg(C.Structure):
                [("gnss_iono", C.c_double * 8)]
 
 
+class GnssEphem(C.Structure):
+    """gf_gnss_ephem"""
+    _fields_ = [("sat", C.c_int), ("sys", C.c_int), ("prn", C.c_int)] + [(k, C.c_double) for k in (
+        "toe", "toc", "toe_tow", "A", "e", "i0", "OMG0", "omg", "M0", "delta_n", "OMG_dot", "i_dot", "cuc", "cus", "crc", "crs", "cic", "cis", "af0", "af1", "af2", "tgd0", "ura")]
+
+
+class GnssGloEphem(C.Structure):
+    """gf_gnss_glo_ephem"""
+    _fields_ = [("sat", C.c_int), ("toe", C.c_double), ("pos", C.c_double * 3), ("vel", C.c_double * 3), ("acc", C.c_double * 3), ("tau_n", C.c_double), ("gamma", C.c_double)]
+
+
+class GnssRawObs(C.Structure):
+    """gf_gnss_raw_obs"""
+    _fields_ = [("sat", C.c_int), ("sys", C.c_int)] + [(k, C.c_double) for k in ("time", "psr", "dopp", "psr_std", "dopp_std", "freq", "tow")]
+
+
+def _fill(cs, d):
+    for name, ct in cs._fields_:
+        if name in ("pos", "vel", "acc", "sv_pos", "sv_vel"):
+            for j in range(3):
+                getattr(cs, name)[j] = float(d[name][j])
+        else:
+            setattr(cs, name, d[name])
+    return cs
+
+
+def gnss_obs_from_ephem(raw, eph=None, geph=None):
+    """gf_gnss_obs_from_ephem: dict with the fields of gf_gnss_obs"""
+    out = GnssObs()
+    r = _fill(GnssRawObs(), raw)
+    e = C.byref(_fill(GnssEphem(), eph)) if eph is not None else None
+    g = C.byref(_fill(GnssGloEphem(), geph)) if geph is not None else None
+    _chk(lib().gf_gnss_obs_from_ephem(C.byref(r), e, g, C.byref(out)))
+    return {name: (np.array(getattr(out, name)[:]) if name in ("sv_pos", "sv_vel") else getattr(out, name)) for name, _ in GnssObs._fields_}
+
+
+def gnss_eph2pos(t, eph=None, geph=None):
+    pos, dts = np.zeros(3), C.c_double(0)
+    e = C.byref(_fill(GnssEphem(), eph)) if eph is not None else None
+    g = C.byref(_fill(GnssGloEphem(), geph)) if geph is not None else None
+    _chk(lib().gf_gnss_eph2pos(C.c_double(t), e, g, _p(pos, C.c_double), C.byref(dts)))
+    return pos, dts.value
+
+
 class GnssObs(C.Structure):
     """gf_gnss_obs: one L1 observation of an epoch with the satellite state its ephemeris gives (include/groundfusion_hip.h)"""
     _fields_ = [("sat", C.c_int), ("sys", C.c_int)] + [(k, C.c_double) for k in ("time", "psr", "dopp", "psr_std", "dopp_std", "wavelength")] + \
@@ -443,7 +487,9 @@ class SlidingWindowEstimator:
         _chk(lib().gf_estimator_input_feature(self.h, C.c_double(t), obs, len(ids)))
 
     def inputGNSS(self, t, epoch):
-        """epoch: list of dicts with the fields of gf_gnss_obs (Estimator::inputGNSS, estimator.cpp:397)"""
+        """epoch: list of dicts with the fields of gf_gnss_obs (Estimator::inputGNSS, estimator.cpp:397), or of gf_gnss_raw_obs (no "sv_pos")"""
+        if epoch and "sv_pos" not in epoch[0]:
+            return self.inputGNSSRaw(t, epoch)
         obs = (GnssObs * max(len(epoch), 1))()
         for k, o in enumerate(epoch):
             for name, _ in GnssObs._fields_:
@@ -453,6 +499,20 @@ class SlidingWindowEstimator:
                 else:
                     setattr(obs[k], name, o[name])
         _chk(lib().gf_estimator_input_gnss(self.h, C.c_double(t), obs, len(epoch)))
+
+    def inputGNSSRaw(self, t, epoch):
+        """epoch: list of dicts with the fields of gf_gnss_raw_obs; ephemerides through inputEphem"""
+        obs = (GnssRawObs * max(len(epoch), 1))()
+        for k, o in enumerate(epoch):
+            _fill(obs[k], o)
+        _chk(lib().gf_estimator_input_gnss_raw(self.h, C.c_double(t), obs, len(epoch)))
+
+    def inputEphem(self, eph):
+        """a dict with the fields of gf_gnss_ephem, or of gf_gnss_glo_ephem (recognised by its key "tau_n")"""
+        if "tau_n" in eph:
+            _chk(lib().gf_estimator_input_glo_ephem(self.h, C.byref(_fill(GnssGloEphem(), eph))))
+        else:
+            _chk(lib().gf_estimator_input_ephem(self.h, C.byref(_fill(GnssEphem(), eph))))
 
     def inputGNSSTimeDiff(self, t_diff):
         _chk(lib().gf_estimator_input_gnss_time_diff(self.h, C.c_double(t_diff)))

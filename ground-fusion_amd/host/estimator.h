@@ -68,6 +68,9 @@ class Estimator {
     // setGNSSAlignment: the result of GNSSVIInitializer, applied by the library where the reference runs GNSSVIAlign (estimator.cpp:1928-2043)
     gf_estimator* handle() { need(); return h_; }   // for the C entry points this class does not wrap (gf_estimator_get_gnss_state, _get_features, ...)
     void inputGNSS(double t, const std::vector<gf_gnss_obs>& meas) { need(); check(gf_estimator_input_gnss(h_, t, meas.data(), (int)meas.size())); }
+    void inputGNSSRaw(double t, const std::vector<gf_gnss_raw_obs>& meas) { need(); check(gf_estimator_input_gnss_raw(h_, t, meas.data(), (int)meas.size())); }
+    void inputEphem(const gf_gnss_ephem& eph) { need(); check(gf_estimator_input_ephem(h_, &eph)); }                 // estimator.h:97 (GPS / Galileo / BeiDou)
+    void inputEphem(const gf_gnss_glo_ephem& geph) { need(); check(gf_estimator_input_glo_ephem(h_, &geph)); }      // (GLONASS)
     void inputGNSSTimeDiff(double t_diff) { need(); check(gf_estimator_input_gnss_time_diff(h_, t_diff)); }
     void inputIonoParams(double /*ts*/, const std::vector<double>& iono_params) { need(); if (iono_params.size() != 8) return; check(gf_estimator_input_iono_params(h_, iono_params.data())); }
     void setGNSSAlignment(const Vec3& anc_ecef, double yaw_enu_local, const double rcv_dt[4], double rcv_ddt) {

@@ -148,13 +148,43 @@ class Stream:
         return out
 
     # ---- GNSS: raw measurements of a receiver riding on the body origin (the measurement model of synth_window.add_gnss)
-    def gnss_setup(self, sats_per_sys=3, n_low=2, lat=31.03, lon=121.44, alt=20.0, alpha=0.3, time_diff=18.0):
+    def gnss_setup(self, sats_per_sys=3, n_low=2, lat=31.03, lon=121.44, alt=20.0, alpha=0.3, time_diff=18.0, orbits=None):
         """constellation (4 systems x sats_per_sys above 32 deg, plus n_low GPS satellites at 8..22 deg that the elevation gate of
-        Estimator::processGNSS has to drop once gnss_ready), receiver clock and the ENU <- world yaw alpha."""
+        Estimator::processGNSS has to drop once gnss_ready), receiver clock and the ENU <- world yaw alpha.
+        orbits: an object with eph2pos(t, eph) / geph2pos(t, geph) (position, clock bias).  Then every satellite flies a broadcast orbit (Kepler elements
+        for GPS / Galileo / BeiDou, a PZ-90 state vector for GLONASS), gnss_epoch() returns RAW observations (gf_gnss_raw_obs) and self._gnss["ephems"]
+        lists the ephemerides to hand to inputEphem."""
         import synth_window as SW
         rng = np.random.default_rng(7000 + self.seed)
         anc, Re = SW.geo2ecef(lat, lon, alt), SW.R_ecef_enu(lat, lon)
         sats = []
+        if orbits is not None:
+            toe, t_mid = time_diff - 900.0, time_diff + 3.0
+            A_sys = {0: 26560e3, 1: 25510e3, 2: 29600e3, 3: 27906e3}
+            for sys in range(4):
+                for q in range(sats_per_sys + (n_low if sys == 0 else 0)):
+                    low = q >= sats_per_sys
+                    for _ in range(20000):   # draw orbits until the satellite stands in the wanted elevation band over the anchor
+                        e = dict(sat=100 * sys + q + 1, sys=sys if sys != 1 else 0, prn=10 + q, toe=toe, toc=toe, toe_tow=345600.0 - 900.0, A=A_sys[sys], e=rng.uniform(0.001, 0.01),
+                                 i0=1.131 if sys == 1 else 0.96, OMG0=rng.uniform(0, 2 * np.pi), omg=rng.uniform(0, 2 * np.pi), M0=rng.uniform(0, 2 * np.pi), delta_n=rng.uniform(3e-9, 5e-9),
+                                 OMG_dot=-8e-9, i_dot=1e-10, cuc=rng.normal(0, 1e-6), cus=rng.normal(0, 1e-6), crc=rng.normal(0, 100.0), crs=rng.normal(0, 100.0), cic=rng.normal(0, 1e-7),
+                                 cis=rng.normal(0, 1e-7), af0=rng.uniform(-2e-4, 2e-4), af1=rng.uniform(-1e-11, 1e-11), af2=0.0, tgd0=rng.uniform(-8e-9, 8e-9), ura=3.0)   # ura 2 would zero the Galileo weights (gnss_psr_dopp_factor.cpp:36: ura - 2)
+                        d = Re.T @ (orbits.eph2pos(t_mid, e)[0] - anc)
+                        el = np.degrees(np.arcsin(d[2] / np.linalg.norm(d)))
+                        if (8 < el < 22) if low else (32 < el < 80):
+                            break
+                    else:
+                        raise RuntimeError("no visible orbit found")
+                    if sys == 1:   # GLONASS: the same orbit as a PZ-90 state vector at toe (velocity by a difference quotient in the rotating frame)
+                        e["sys"] = 0
+                        p0, p1 = orbits.eph2pos(toe, e)[0], orbits.eph2pos(toe + 1e-3, e)[0]
+                        e = dict(sat=e["sat"], toe=toe, pos=p0, vel=(p1 - p0) / 1e-3, acc=rng.normal(0, 1e-6, 3), tau_n=rng.uniform(-2e-4, 2e-4), gamma=rng.uniform(-1e-11, 1e-11))
+                    sats.append(dict(sat=100 * sys + q + 1, sys=sys, eph=e))
+            R0w = self.R_wb(self.cam_t[0])
+            theta0 = float(np.arctan2(R0w[1, 0], R0w[0, 0]))
+            self._gnss = dict(anc=anc, Re=Re, R_ew=Re @ rot_z(alpha), sats=sats, dt=np.array([150.0, 180.0, 120.0, 200.0]), ddt=2.0, time_diff=time_diff,
+                              yaw_enu_local=alpha + theta0, noise=np.random.default_rng(7100 + self.seed), orbits=orbits, ephems=[sv["eph"] for sv in sats])
+            return self._gnss
         for sys in range(4):
             for q in range(sats_per_sys + (n_low if sys == 0 else 0)):
                 low = q >= sats_per_sys
@@ -177,6 +207,28 @@ class Stream:
         p, v = G["anc"] + G["R_ew"] @ self.p_wb(t_local), G["R_ew"] @ self._at(self._vw, t_local)
         wl = SW.C_LIGHT / 1575.42e6
         out = []
+        if G.get("orbits") is not None:   # raw observations of satellites on broadcast orbits
+            O, T = G["orbits"], t_local + G["time_diff"]
+            freq = {0: 1575.42e6, 1: 1602.0e6, 2: 1575.42e6, 3: 1561.098e6}
+            for sv in G["sats"]:
+                f = O.geph2pos if sv["sys"] == 1 else O.eph2pos
+                tof = 0.075
+                for _ in range(3):   # transmission time from the light time
+                    sp, svdt = f(T - tof, sv["eph"])
+                    tof = np.linalg.norm(sp - p) / SW.C_LIGHT
+                sp2, svdt2 = f(T - tof + 1e-3, sv["eph"])
+                svel, svddt = (sp2 - sp) / 1e-3, (svdt2 - svdt) / 1e-3
+                los = sp - p
+                rg = np.linalg.norm(los)
+                unit = los / rg
+                clk = G["dt"][sv["sys"]] + G["ddt"] * t_local
+                tgd = sv["eph"].get("tgd0", 0.0)
+                psr = rg + SW.OMG_E * (sp[0] * p[1] - sp[1] * p[0]) / SW.C_LIGHT + clk - svdt * SW.C_LIGHT + tgd * SW.C_LIGHT + rng.normal(0, 0.5)
+                dop = (svel - v) @ unit + SW.OMG_E / SW.C_LIGHT * (svel[0] * p[1] + sp[0] * v[1] - svel[1] * p[0] - sp[1] * v[0]) + G["ddt"] - svddt * SW.C_LIGHT
+                bad = flaky_sat is not None and sv["sat"] == flaky_sat
+                out.append(dict(sat=sv["sat"], sys=sv["sys"], time=T, psr=float(psr), dopp=float(-(dop + rng.normal(0, 0.05)) * freq[sv["sys"]] / SW.C_LIGHT),
+                                psr_std=5.0 if bad else 0.6, dopp_std=0.3, freq=freq[sv["sys"]], tow=345600.0 + t_local))
+            return T, out
         for sv in G["sats"]:
             sp = sv["pos"] + sv["vel"] * t_local
             los = sp - p

@@ -253,8 +253,8 @@ int gf_wheel_preintegrate(int n, const double* dt, const double* vel, const doub
  * The dense work (Estimator::optimization, estimator.cpp:2890-3636) runs on the HIP back end behind gf_ba_*.
  * Built: RGB-D + IMU (+ wheel) (+ GNSS) configuration, stationary / wheel-activated initialisation (estimator.cpp:1557-1682),
  * MULTIPLE_THREAD 0/1 data flow (processed synchronously); GNSS: measurement gating, clock / anchor / yaw states, factors in the solve and the
- * marginalisation, GNSSVIAlign with its initialiser; satellite states are handed in (gf_gnss_obs).
- * Not built: SfM initialisation, ephemeris decoding (gnss_comm), line / plane / motion factors.
+ * marginalisation, GNSSVIAlign with its initialiser, broadcast ephemerides -> satellite states (gf_estimator_input_ephem + gf_estimator_input_gnss_raw;
+ * or states handed in, gf_gnss_obs).  Not built: SfM initialisation, line / plane / motion factors.
  * ------------------------------------------------------------------------------------------------------------------------------ */
 typedef struct gf_estimator gf_estimator;
 
@@ -296,8 +296,37 @@ int gf_estimator_create(const gf_estimator_cfg* cfg, gf_estimator** out);
 int gf_estimator_destroy(gf_estimator* h);
 int gf_estimator_input_imu(gf_estimator* h, double t, const double* acc, const double* gyr);
 int gf_estimator_input_wheel(gf_estimator* h, double t, const double* vel, const double* gyr);
+/* Broadcast ephemerides as Estimator::inputEphem receives them (estimator.h:97, estimator.cpp:1428-1437; gnss_comm::Ephem / GloEphem) and the L1 entry of an
+ * observation (gnss_comm::Obs).  gtime_t fields are seconds (time2sec).  With these the library derives the satellite state itself, the way
+ * GnssPsrDoppFactor's constructor does (gnss_psr_dopp_factor.cpp:3-47: transmission time, eph2svdt / eph2pos / eph2vel or their GLONASS counterparts);
+ * gnss_comm is not vendored by the reference, so eph2pos etc. are restated from the published broadcast-orbit algorithms (IS-GPS-200 Kepler model, BeiDou
+ * GEO rotation, GLONASS ICD Runge-Kutta with 60 s steps; velocities and clock drifts by the 1 ms difference quotient RTKLIB uses). */
+typedef struct gf_gnss_ephem {
+    int sat, sys, prn;       /* satellite number, constellation index (0 GPS, 2 GAL, 3 BDS), PRN within it (BeiDou GEO: prn <= 5 or >= 59) */
+    double toe, toc, toe_tow; /* time2sec(toe), time2sec(toc), toe as seconds of the constellation's week */
+    double A, e, i0, OMG0, omg, M0, delta_n, OMG_dot, i_dot, cuc, cus, crc, crs, cic, cis, af0, af1, af2, tgd0, ura;
+} gf_gnss_ephem;
+typedef struct gf_gnss_glo_ephem {
+    int sat;
+    double toe;              /* time2sec(toe) */
+    double pos[3], vel[3], acc[3], tau_n, gamma;   /* PZ-90 state at toe [m, m/s, m/s^2], clock bias [s] and relative frequency bias */
+} gf_gnss_glo_ephem;
+typedef struct gf_gnss_raw_obs {
+    int sat, sys;            /* as in gf_gnss_obs; sys 1 = GLONASS */
+    double time, psr, dopp, psr_std, dopp_std, freq, tow;   /* reception time [s], L1 pseudorange [m], Doppler [Hz], their deviations, carrier frequency [Hz], time of week */
+} gf_gnss_raw_obs;
+/* the satellite state of one observation from its ephemeris (exactly one of eph / geph non-NULL): what gf_estimator_input_gnss_raw does per observation */
+int gf_gnss_obs_from_ephem(const gf_gnss_raw_obs* raw, const gf_gnss_ephem* eph, const gf_gnss_glo_ephem* geph, gf_gnss_obs* out);
+/* satellite position [m] and clock bias [s] at time t (eph2pos / geph2pos): building block entry for tests */
+int gf_gnss_eph2pos(double t, const gf_gnss_ephem* eph, const gf_gnss_glo_ephem* geph, double* pos3, double* svdt);
+
 /* Estimator::inputGNSS (estimator.h:99, estimator.cpp:397): one epoch; inputGNSSTimeDiff (estimator.cpp:1450); inputIonoParams (estimator.h:98) */
 int gf_estimator_input_gnss(gf_estimator* h, double t, const gf_gnss_obs* obs, int n);
+/* the same with raw observations: processGNSS then picks, per observation, the ephemeris of its satellite nearest in toe within EPH_VALID_SECONDS (7200 s)
+ * (estimator.cpp:1467-1495; observations without one are skipped), evaluates the elevation gate at the reception time and derives the satellite state */
+int gf_estimator_input_gnss_raw(gf_estimator* h, double t, const gf_gnss_raw_obs* obs, int n);
+int gf_estimator_input_ephem(gf_estimator* h, const gf_gnss_ephem* eph);            /* Estimator::inputEphem, estimator.cpp:1428-1437 */
+int gf_estimator_input_glo_ephem(gf_estimator* h, const gf_gnss_glo_ephem* geph);
 int gf_estimator_input_gnss_time_diff(gf_estimator* h, double diff_t_gnss_local);
 int gf_estimator_input_iono_params(gf_estimator* h, const double* params8);
 /* GNSSVIAlign (estimator.cpp:1928-2043) runs inside the library: GNSSVIInitializer (initial/gnss_vi_initializer.cpp: coarse SPP localisation of the

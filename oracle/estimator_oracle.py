@@ -151,6 +151,106 @@ def dopp_res(vel_ddt, rcv, meas):
     return np.array(res), np.array(J).reshape(-1, 4)
 
 
+# ---- broadcast ephemerides -> satellite state (gnss_comm eph2pos / geph2pos / eph2svdt / eph2vel; RTKLIB ephemeris.c lineage: IS-GPS-200 Kepler model,
+# BeiDou GEO frame, GLONASS ICD Runge-Kutta at 60 s steps, velocities and clock drift by the 1 ms difference quotient).  Ephemerides are dicts with the
+# field names of gf_gnss_ephem / gf_gnss_glo_ephem.
+MU = {0: 3.9860050e14, 2: 3.986004418e14, 3: 3.986004418e14}
+OMGE = {0: 7.2921151467e-5, 2: 7.2921151467e-5, 3: 7.292115e-5}
+MU_GLO, J2_GLO, OMGE_GLO, RE_GLO, TSTEP = 3.9860044e14, 1.0826257e-3, 7.292115e-5, 6378136.0, 60.0
+SIN_5, COS_5 = -0.0871557427476582, 0.9961946980917456
+
+
+def eph2svdt(t, e):
+    tk = t - e["toc"]
+    for _ in range(2):
+        tk -= e["af0"] + e["af1"] * tk + e["af2"] * tk * tk
+    return e["af0"] + e["af1"] * tk + e["af2"] * tk * tk
+
+
+def eph2pos(t, e):
+    """(position, clock bias incl. the relativistic term)"""
+    mu, omge = MU[e["sys"]], OMGE[e["sys"]]
+    tk = t - e["toe"]
+    M = e["M0"] + (math.sqrt(mu / e["A"] ** 3) + e["delta_n"]) * tk
+    E, Ek, n = M, 0.0, 0
+    while abs(E - Ek) > 1e-13 and n < 30:
+        Ek = E
+        E -= (E - e["e"] * math.sin(E) - M) / (1.0 - e["e"] * math.cos(E))
+        n += 1
+    sinE, cosE = math.sin(E), math.cos(E)
+    u = math.atan2(math.sqrt(1.0 - e["e"] ** 2) * sinE, cosE - e["e"]) + e["omg"]
+    r = e["A"] * (1.0 - e["e"] * cosE)
+    i = e["i0"] + e["i_dot"] * tk
+    s2, c2 = math.sin(2.0 * u), math.cos(2.0 * u)
+    u += e["cus"] * s2 + e["cuc"] * c2
+    r += e["crs"] * s2 + e["crc"] * c2
+    i += e["cis"] * s2 + e["cic"] * c2
+    x, y, cosi = r * math.cos(u), r * math.sin(u), math.cos(i)
+    if e["sys"] == 3 and (e["prn"] <= 5 or e["prn"] >= 59):
+        O = e["OMG0"] + e["OMG_dot"] * tk - omge * e["toe_tow"]
+        sO, cO = math.sin(O), math.cos(O)
+        xg, yg, zg = x * cO - y * cosi * sO, x * sO + y * cosi * cO, y * math.sin(i)
+        so, co = math.sin(omge * tk), math.cos(omge * tk)
+        rs = np.array([xg * co + yg * so * COS_5 + zg * so * SIN_5, -xg * so + yg * co * COS_5 + zg * co * SIN_5, -yg * SIN_5 + zg * COS_5])
+    else:
+        O = e["OMG0"] + (e["OMG_dot"] - omge) * tk - omge * e["toe_tow"]
+        sO, cO = math.sin(O), math.cos(O)
+        rs = np.array([x * cO - y * cosi * sO, x * sO + y * cosi * cO, y * math.sin(i)])
+    tk = t - e["toc"]
+    return rs, e["af0"] + e["af1"] * tk + e["af2"] * tk * tk - 2.0 * math.sqrt(mu * e["A"]) * e["e"] * sinE / C_LIGHT ** 2
+
+
+def _glo_deq(x, acc):
+    r2 = float(x[0:3] @ x[0:3])
+    r3, omg2 = r2 * math.sqrt(r2), OMGE_GLO ** 2
+    a = 1.5 * J2_GLO * MU_GLO * RE_GLO ** 2 / r2 / r3
+    b = 5.0 * x[2] * x[2] / r2
+    c = -MU_GLO / r3 - a * (1.0 - b)
+    return np.array([x[3], x[4], x[5], (c + omg2) * x[0] + 2.0 * OMGE_GLO * x[4] + acc[0], (c + omg2) * x[1] - 2.0 * OMGE_GLO * x[3] + acc[1], (c - 2.0 * a) * x[2] + acc[2]])
+
+
+def geph2svdt(t, g):
+    tk = t - g["toe"]
+    for _ in range(2):
+        tk -= -g["tau_n"] + g["gamma"] * tk
+    return -g["tau_n"] + g["gamma"] * tk
+
+
+def geph2pos(t, g):
+    tk = t - g["toe"]
+    dts = -g["tau_n"] + g["gamma"] * tk
+    x, acc = np.array([*g["pos"], *g["vel"]], float), np.asarray(g["acc"], float)
+    tt = -TSTEP if tk < 0.0 else TSTEP
+    while abs(tk) > 1e-9:
+        if abs(tk) < TSTEP:
+            tt = tk
+        k1 = _glo_deq(x, acc)
+        k2 = _glo_deq(x + k1 * tt / 2.0, acc)
+        k3 = _glo_deq(x + k2 * tt / 2.0, acc)
+        k4 = _glo_deq(x + k3 * tt, acc)
+        x = x + (k1 + 2.0 * k2 + 2.0 * k3 + k4) * tt / 6.0
+        tk -= tt
+    return x[0:3].copy(), dts
+
+
+def sat_state(raw, eph=None, geph=None):
+    """GnssPsrDoppFactor's constructor (gnss_psr_dopp_factor.cpp:3-47): a raw L1 observation + its ephemeris -> the fields of gf_gnss_obs"""
+    o = dict(sat=raw["sat"], sys=raw["sys"], time=raw["time"], psr=raw["psr"], dopp=raw["dopp"], psr_std=raw["psr_std"], dopp_std=raw["dopp_std"],
+             wavelength=C_LIGHT / raw["freq"], tow=raw["tow"])
+    sv_tx, tt = raw["time"] - raw["psr"] / C_LIGHT, 1e-3
+    if geph is not None:
+        sv_tx -= geph2svdt(sv_tx, geph)
+        (p, d1), (p2, d2) = geph2pos(sv_tx, geph), geph2pos(sv_tx + tt, geph)
+        o.update(tgd=0.0, pr_uura=2.0 * (raw["psr_std"] / 0.16), dp_uura=2.0 * (raw["dopp_std"] / 0.256))
+    else:
+        sv_tx -= eph2svdt(sv_tx, eph)
+        (p, d1), (p2, d2) = eph2pos(sv_tx, eph), eph2pos(sv_tx + tt, eph)
+        k = eph["ura"] - 2.0 if eph["sys"] == 2 else eph["ura"] - 1.0
+        o.update(tgd=eph["tgd0"], pr_uura=k * (raw["psr_std"] / 0.16), dp_uura=k * (raw["dopp_std"] / 0.256))
+    o.update(sv_pos=p, sv_vel=(p2 - p) / tt, svdt=d1, svddt=(d2 - d1) / tt)
+    return o
+
+
 def sat_elevation(rcv, sat):
     dl = np.asarray(sat, float) - np.asarray(rcv, float)
     dl = dl / np.linalg.norm(dl)
@@ -559,6 +659,7 @@ class Estimator:
         self.back_R0, self.back_P0 = np.eye(3), np.zeros(3)
         # GNSS (estimator.h:293-331)
         self.GNSSBuf, self.gnss_msg = [], []
+        self.sat2ephem, self.sat2time_index = {}, {}
         self.gnss_meas_buf = [[] for _ in range(W + 1)]
         self.sat_track_status = {}
         self.gnss_ready, self.first_optimization, self.lowspeed = False, True, False
@@ -570,9 +671,15 @@ class Estimator:
         self.alignment = None
 
     # ---- GNSS
-    def inputGNSS(self, t, epoch):  # EST:397-404; epoch: list of dicts with the fields of gf_gnss_obs
+    def inputGNSS(self, t, epoch):  # EST:397-404; epoch: list of dicts with the fields of gf_gnss_obs, or raw observations (key "freq", no "sv_pos")
         assert len(epoch) >= 1
         self.GNSSBuf.append((t, [dict(o) for o in epoch]))
+
+    def inputEphem(self, eph):  # EST:1428-1437 (GLONASS ephemerides carry "tau_n")
+        idx = self.sat2time_index.setdefault(eph["sat"], {})
+        if eph["toe"] not in idx:
+            self.sat2ephem.setdefault(eph["sat"], []).append(dict(eph))
+            idx[eph["toe"]] = len(self.sat2ephem[eph["sat"]]) - 1
 
     def inputGNSSTimeDiff(self, t_diff):  # EST:1450-1453
         self.diff_t_gnss_local = t_diff
@@ -599,15 +706,28 @@ class Estimator:
         for obs in gnss_meas:
             if not 0 <= obs["sys"] <= 3:
                 continue
+            raw, eph = "sv_pos" not in obs, None
+            if raw:   # :1467-1495
+                if obs["sat"] not in self.sat2time_index:
+                    continue
+                ephem_time, ephem_index = 7200.0, None
+                for toe in sorted(self.sat2time_index[obs["sat"]]):   # std::map order
+                    if abs(toe - obs["time"]) < ephem_time:
+                        ephem_time, ephem_index = abs(toe - obs["time"]), self.sat2time_index[obs["sat"]][toe]
+                if ephem_time >= 7200.0:
+                    continue
+                eph = self.sat2ephem[obs["sat"]][ephem_index]
             if obs["psr_std"] > c["gnss_psr_std_thres"] or obs["dopp_std"] > c["gnss_dopp_std_thres"]:
                 self.sat_track_status[obs["sat"]] = 0
                 continue
             self.sat_track_status[obs["sat"]] = self.sat_track_status.get(obs["sat"], 0) + 1
             if self.sat_track_status[obs["sat"]] < c["gnss_track_num_thres"]:
                 continue
-            if self.gnss_ready and sat_elevation(self.ecef_pos, obs["sv_pos"]) < math.radians(c["gnss_elevation_thres"]):
-                continue
-            valid.append(obs)
+            if self.gnss_ready:   # :1515-1526 (the satellite at the reception time)
+                sat_ecef = obs["sv_pos"] if not raw else (geph2pos(obs["time"], eph)[0] if "tau_n" in eph else eph2pos(obs["time"], eph)[0])
+                if sat_elevation(self.ecef_pos, sat_ecef) < math.radians(c["gnss_elevation_thres"]):
+                    continue
+            valid.append(obs if not raw else (sat_state(obs, geph=eph) if "tau_n" in eph else sat_state(obs, eph=eph)))
         self.gnss_meas_buf[self.frame_count] = valid
 
     def _avg_hor_vel(self):
