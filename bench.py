@@ -233,16 +233,22 @@ def main():
     os.environ.setdefault("GF_HOST_THREADS", str(max(1, min(4, (os.cpu_count() or 4) // max(local_world, 1)))))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # GF_BENCH_SINGLE_DEVICE=1 (tests only): every rank on device 0 with the gloo backend, to run the N > 1 path on a one-GPU box
+    single = os.environ.get("GF_BENCH_SINGLE_DEVICE") == "1"
+    device_index = 0 if single else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if single:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     import gfamd
     import shard
-    gfamd._chk(gfamd.lib().gf_set_device(local_rank))
+    gfamd._chk(gfamd.lib().gf_set_device(device_index))
     B, K, Wm = args.batch, args.steps, args.warmup
     dt = 1.0 / 15.0
     n_frames = Wm + K + 1 + 4   # + the frames of the isolated tracker passes after the timed region

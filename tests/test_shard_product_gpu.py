@@ -66,3 +66,26 @@ def test_two_processes_on_the_product_path_match_one():
         assert p.exitcode == 0
     _, ref = _solve_newest(gfamd, _windows(gfamd, 0, N_SEQ))
     assert got.shape == (N_SEQ, 7) and np.array_equal(got, ref)
+
+
+def test_bench_runs_with_two_ranks(tmp_path):
+    """bench.py's N > 1 path (launch contract of the driver: torch.distributed.run, one rank per GPU, barrier + max-over-ranks timing, pose all_gather in
+    every step, whole-job value on rank 0) on this one-GPU box: GF_BENCH_SINGLE_DEVICE=1 puts both ranks on device 0 and swaps RCCL for gloo -- everything
+    else is the code the 8-GPU run executes."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, GF_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 prints ONE JSON line
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak" and r["value"] > 0
+    assert abs(r["solves_per_s"] * r["ms_per_step"] * 1e-3 - 2 * 8) < 1e-6      # whole-job value: both ranks' sequences per step time
+    assert "roofline" in r and "end_to_end" not in r          # the drop-in sample and the CPU baseline run at N = 1 only
