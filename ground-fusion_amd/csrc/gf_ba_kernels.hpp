@@ -609,41 +609,45 @@ __device__ __forceinline__ int tri_row(int t) {  // largest i with i(i+1)/2 <= t
 // Compact rows of E^T F, ete, etb of one eliminated (free inverse-depth) column, by 16 lanes (four features per wavefront): every factor of
 // a feature shares its pose_i / ex / td entries (summed in the fixed order of the feature's factor list), its pose_j entries are unique.
 // The factor products sit in efac in feature-list order, frames included: no index chasing, one contiguous read per feature.
-__device__ __forceinline__ void et_rows4(const Win& w, const StepBufs& sb, const Dims& d, int b, int f0, int nfeat, const int* cole, const int* fptr, int which, int lane) {
-    const int sub = lane & 15, f = f0 + (lane >> 4);
+// eight features per wavefront, eight lanes per feature (sixteen lanes per feature made 3.1 rounds of ~15 k cycles each at 150 features and 12 wavefronts:
+// the rounds are load-latency bound, so fewer and fuller ones win)
+__device__ __forceinline__ void et_rows8(const Win& w, const StepBufs& sb, const Dims& d, int b, int f0, int nfeat, const int* cole, const int* fptr, int which, int lane) {
+    const int sub = lane & 7, f = f0 + (lane >> 3);
     const int e = f < nfeat ? cole[f] : -1;
     const int p0 = e >= 0 ? fptr[f] : 0, p1 = e >= 0 ? fptr[f + 1] : 0;
     const double* efac = w.efac + ((size_t)which * d.B + b) * d.NV * EF;
     double* Et = sb.Et + (((size_t)which * d.B + b) * d.FP + max(e, 0)) * d.ECW;
-    if (e >= 0) for (int c = sub; c < d.ECW; c += 16) Et[c] = 0.0;
+    if (e >= 0) for (int c = sub; c < d.ECW; c += 8) Et[c] = 0.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-    // lane `sub` owns products sub (0-5 pose_i, 6-11 pose_j, 12 td, 13-15 ex 0-2) and 16 + sub (ex 3-5, ete, etb) of every factor
-    double acc0 = 0.0, acc1 = 0.0;
+    // lane `sub` owns the products sub (0-5 pose_i, 6-7 pose_j), 8 + sub (8-11 pose_j, 12 td, 13-15 ex 0-2) and 16 + sub (16-18 ex 3-5, 19 ete, 20 etb) of every factor
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
     int fi = 0;
     constexpr int NF = 10;   // factors in flight: every load of a batch is issued before the first store (a track spans <= W frames)
     for (int pb = p0; pb < p1; pb += NF) {
-        double v0[NF], v1[NF], fjd[NF], fid[NF];
+        double v0[NF], v1[NF], v2[NF], fjd[NF], fid[NF];
 #pragma unroll
         for (int q = 0; q < NF; q++) {
             const bool on = pb + q < p1;
             const double* row = efac + (size_t)(on ? pb + q : p0) * EF;
-            v0[q] = on ? row[sub] : 0.0; v1[q] = (on && sub < 5) ? row[16 + sub] : 0.0; fid[q] = row[21]; fjd[q] = row[22];
+            v0[q] = on ? row[sub] : 0.0; v1[q] = on ? row[8 + sub] : 0.0; v2[q] = (on && sub < 5) ? row[16 + sub] : 0.0; fid[q] = row[21]; fjd[q] = row[22];
         }
         fi = (int)fid[0];
 #pragma unroll
         for (int q = 0; q < NF; q++) {
             if (pb + q >= p1) continue;
-            if (sub >= 6 && sub < 12) Et[6 * (int)fjd[q] + sub - 6] = v0[q]; else acc0 += v0[q];
-            acc1 += v1[q];
+            const int fj6 = 6 * (int)fjd[q];
+            if (sub >= 6) Et[fj6 + sub - 6] = v0[q]; else acc0 += v0[q];
+            if (sub < 4) Et[fj6 + 2 + sub] = v1[q]; else acc1 += v1[q];
+            acc2 += v2[q];
         }
     }
     if (e < 0) return;
     if (sub < 6) Et[6 * fi + sub] = acc0;
-    else if (sub == 12) Et[6 * d.NP + 6] = acc0;                       // td
-    else if (sub >= 13) Et[6 * d.NP + sub - 13] = acc0;                // ex 0-2
-    if (sub < 3) Et[6 * d.NP + 3 + sub] = acc1;                        // ex 3-5
-    else if (sub == 3) sb.ete[((size_t)which * d.B + b) * d.FP + e] = acc1;
-    else if (sub == 4) sb.etb[((size_t)which * d.B + b) * d.FP + e] = acc1;
+    if (sub == 4) Et[6 * d.NP + 6] = acc1;                             // td
+    else if (sub >= 5) Et[6 * d.NP + sub - 5] = acc1;                  // ex 0-2
+    if (sub < 3) Et[6 * d.NP + 3 + sub] = acc2;                        // ex 3-5
+    else if (sub == 3) sb.ete[((size_t)which * d.B + b) * d.FP + e] = acc2;
+    else if (sub == 4) sb.etb[((size_t)which * d.B + b) * d.FP + e] = acc2;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -829,7 +833,7 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
         const int nfeat = w.nfeat[b];
         const int* cole = w.cole + (size_t)b * d.F;
         const int* fptr = d.F <= kVFP ? s_fptr : w.feat_ptr + (size_t)b * (d.F + 1);
-        for (int f0 = 4 * wave; f0 < nfeat; f0 += 4 * NW) et_rows4(w, sb, d, b, f0, nfeat, cole, fptr, which, lane);
+        for (int f0 = 8 * wave; f0 < nfeat; f0 += 8 * NW) et_rows8(w, sb, d, b, f0, nfeat, cole, fptr, which, lane);
     }
     GF_WSTAMP(86);
 }
