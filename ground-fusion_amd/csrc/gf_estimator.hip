@@ -1586,6 +1586,13 @@ int gf_estimator_input_feature(gf_estimator* e, double t, const gf_feature_obs* 
     e->featureBuf.emplace_back(t, std::move(v));
     return e->cfg.multiple_thread ? e->drain() : e->processMeasurements();   // inline call of the non-threaded mode: one frame, EST:239
 }
+int gf_estimator_process_image(gf_estimator* e, double header, const gf_feature_obs* obs, int n) {  // Estimator::processImage, estimator.h:110
+    if (!e || (n > 0 && !obs) || n < 0) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    if (e->cfg.use_imu && !e->first_imu) return gf::set_err(GF_ERR_INVALID, "processImage before any IMU sample was processed (the reference dereferences a null pre-integration here)");
+    std::vector<gf_feature_obs> v(obs, obs + n);
+    std::stable_sort(v.begin(), v.end(), [](const gf_feature_obs& a, const gf_feature_obs& b) { return a.id < b.id; });
+    return e->processImage(v, header);
+}
 // Estimator::inputImage (EST:213-242): track, then (multiple_thread: every second frame) hand the features to the back end
 int gf_estimator_input_image(gf_estimator* e, double t, const uint8_t* gray, int stride, const uint16_t* depth, int dstride, gf_feature_obs* out, int cap, int* n_out) {
     if (!e || !e->tracker) return gf::set_err(GF_ERR_INVALID, "estimator was created without a tracker (cfg.with_tracker)");

@@ -3,11 +3,13 @@
 //   estimator.inputIMU(t, acc, gyr)      estimator.h:104        estimator.inputWheel(t, vel, gyr)   :106
 //   estimator.inputImage(t, img, depth)  :105                   estimator.inputFeature(t, frame)    :108
 // and the publishers of utility/visualization.cpp keep reading Ps, Rs, Vs, Bas, Bgs, tic, ric, tio, rio, sx, sy, sw, td, td_wheel,
-// Headers, solver_flag, marginalization_flag, which are refreshed after every call.
+// Headers, solver_flag, marginalization_flag, key_poses and (gnss_enable) gnss_ready, anc_ecef, ecef_pos, enu_pos, R_enu_local, para_rcv_dt, which are
+// refreshed after every call.
 // Build with -DGF_WITH_EIGEN / -DGF_WITH_OPENCV to get the Eigen / cv::Mat signatures (absent in this container: std::array / gf::ImageView).
 // Errors: a failing C-ABI call throws std::runtime_error(gf_last_error()) instead of the reference's log-and-continue.
 #pragma once
 #include <array>
+#include <cmath>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -37,6 +39,14 @@ class Estimator {
     Vec3 tic[1], tio; Mat3 ric[1], rio;
     double td = 0, td_wheel = 0, sx = 1, sy = 1, sw = 1;
     bool systemstationary = false;
+    std::vector<Vec3> key_poses;                  // estimator.h:290: the window's positions after a NON_LINEAR frame
+    // GNSS members read by pubGnssResult (utility/visualization.cpp:454-545); refreshed when cfg.gnss_enable
+    bool gnss_ready = false;
+    Vec3 anc_ecef{}, ecef_pos{}, enu_pos{};
+    Mat3 R_enu_local{};
+    double yaw_enu_local = 0;
+    std::vector<double> para_rcv_dt, para_rcv_ddt;   // (WINDOW_SIZE + 1) * 4, (WINDOW_SIZE + 1)
+    std::vector<std::pair<double, Vec3>> wheelxyztBuf;   // estimator.h:204
 
     Estimator() { gf_estimator_default_cfg(&cfg); }
     ~Estimator() { if (h_) gf_estimator_destroy(h_); }
@@ -77,6 +87,19 @@ class Estimator {
         need();
         const double a[3] = {anc_ecef[0], anc_ecef[1], anc_ecef[2]};
         check(gf_estimator_set_gnss_alignment(h_, a, yaw_enu_local, rcv_dt, rcv_ddt));
+    }
+    void inputrawodom(double t, const Vec3& wheel_xyz) { wheelxyztBuf.emplace_back(t, wheel_xyz); }   // estimator.h:116, estimator.cpp:388-395: queued, never consumed (as in the reference)
+    void processImage(const FeatureFrame& image, double header) {   // estimator.h:110: the frame directly, without the measurement queues
+        need();
+        std::vector<gf_feature_obs> obs;
+        for (auto& kv : image) {
+            gf_feature_obs o;
+            o.id = kv.first; o.camera_id = kv.second[0].first;
+            for (int k = 0; k < 8; k++) o.v[k] = kv.second[0].second[k];
+            obs.push_back(o);
+        }
+        check(gf_estimator_process_image(h_, header, obs.data(), (int)obs.size()));
+        refresh();
     }
     void inputFeature(double t, const FeatureFrame& featureFrame) {   // + processMeasurements -> processImage
         need();
@@ -130,6 +153,16 @@ class Estimator {
         frame_count = info[0]; solver_flag = info[1] ? NON_LINEAR : INITIAL; marginalization_flag = info[2] ? MARGIN_SECOND_NEW : MARGIN_OLD; systemstationary = info[6] != 0;
         tic[0] = v3(extr); ric[0] = m3(extr + 3); tio = v3(extr + 12); rio = m3(extr + 15);
         sx = extr[24]; sy = extr[25]; sw = extr[26]; td = extr[27]; td_wheel = extr[28];
+        if (solver_flag == NON_LINEAR) key_poses = Ps;     // estimator.cpp:1153-1155 (what pubKeyPoses reads)
+        if (cfg.gnss_enable) {                              // what pubGnssResult reads (visualization.cpp:454-545)
+            int gi[8]; double anc[3], ecef[3], enu[3];
+            para_rcv_dt.assign(4 * N, 0.0); para_rcv_ddt.assign(N, 0.0);
+            check(gf_estimator_get_gnss_state(h_, gi, para_rcv_dt.data(), para_rcv_ddt.data(), &yaw_enu_local, anc, ecef, enu));
+            gnss_ready = gi[0] != 0; anc_ecef = v3(anc); ecef_pos = v3(ecef); enu_pos = v3(enu);
+            const double c = std::cos(yaw_enu_local), s_ = std::sin(yaw_enu_local);
+            const double Rz[9] = {c, -s_, 0, s_, c, 0, 0, 0, 1};
+            R_enu_local = m3(Rz);
+        }
     }
 };
 

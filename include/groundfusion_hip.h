@@ -339,6 +339,10 @@ int gf_estimator_set_gnss_alignment(gf_estimator* h, const double* anc_ecef, dou
 int gf_estimator_get_gnss_state(gf_estimator* h, int* gnss, double* rcv_dt, double* rcv_ddt, double* yaw_enu_local, double* anc_ecef, double* ecef_pos, double* enu_pos);
 /* inputFeature + processMeasurements: one call = one processImage once IMU / wheel data cover the frame time */
 int gf_estimator_input_feature(gf_estimator* h, double t, const gf_feature_obs* obs, int n);
+/* Estimator::processImage(image, header) (estimator.h:110, estimator.cpp:843-1163) called directly, as the reference's public method allows: the frame
+ * goes through the keyframe vote, initialisation / optimisation and the window shift with whatever processIMU / processWheel have integrated so far
+ * (inputFeature does this for the frames it takes off the queue).  Needs at least one processed IMU sample when use_imu is set. */
+int gf_estimator_process_image(gf_estimator* h, double header, const gf_feature_obs* obs, int n);
 /* inputImage: trackImage on the owned tracker, then inputFeature (every second frame when multiple_thread, estimator.cpp:226) */
 int gf_estimator_input_image(gf_estimator* h, double t, const uint8_t* gray, int stride, const uint16_t* depth, int dstride,
                              gf_feature_obs* out, int cap, int* n_out);

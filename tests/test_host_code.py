@@ -53,7 +53,16 @@ def test_cpp_host_mirror_compiles_and_links(tmp_path):
                    'int main() { gf::FeatureTracker t; t.setIntrinsics(640, 480, 600, 600, 320, 240); (void)sizeof(gf::EstimatorBackend);\n'
                    '  gf::Estimator e; e.setParameter(); gf::Vec3 a{0, -9.8, 0}, w{0, 0, 0}; e.inputIMU(0.0, a, w); e.inputWheel(0.0, w, w);\n'
                    '  gf::FeatureFrame f; e.inputFeature(1.0, f);   /* waits: IMU data do not cover t yet */\n'
-                   '  return (t.MAX_CNT == 150 && e.frame_count == 0 && (int)e.Ps.size() == 11) ? 0 : 1; }\n')
+                   '  e.inputrawodom(0.5, w);                          /* estimator.h:116: queued, never consumed */\n'
+                   '  bool threw = false; try { gf::Estimator fresh; fresh.setParameter(); fresh.processImage(f, 0.1); } catch (const std::runtime_error&) { threw = true; }   /* no IMU sample yet */\n'
+                   '  gf::Estimator g; g.cfg.gnss_enable = 1; g.setParameter();   /* the GNSS surface: estimator.h:97-100, members read by visualization.cpp:454-545 */\n'
+                   '  gf_gnss_obs o{}; o.sat = 3; o.sys = 0; o.time = 18.1; o.psr = 2.2e7; o.psr_std = 0.5; o.dopp_std = 0.3; o.wavelength = 0.19; o.sv_pos[0] = 2.6e7;\n'
+                   '  g.inputGNSS(18.1, std::vector<gf_gnss_obs>{o}); g.inputGNSSTimeDiff(18.0); g.inputIonoParams(0.0, std::vector<double>(8, 1e-8));\n'
+                   '  gf_gnss_ephem eph{}; eph.sat = 3; eph.sys = 0; eph.A = 2.656e7; eph.toe = 0.0; g.inputEphem(eph);\n'
+                   '  gf_gnss_raw_obs r{}; r.sat = 3; r.sys = 0; r.time = 18.2; r.psr = 2.2e7; r.freq = 1575.42e6; g.inputGNSSRaw(18.2, std::vector<gf_gnss_raw_obs>{r});\n'
+                   '  g.inputIMU(0.0, a, w);                          /* refresh() pulls the GNSS members */\n'
+                   '  const bool gn = !g.gnss_ready && (int)g.para_rcv_dt.size() == 44 && g.key_poses.empty() && g.R_enu_local[0] == 1.0 && g.anc_ecef[0] == 0.0;\n'
+                   '  return (t.MAX_CNT == 150 && e.frame_count == 0 && (int)e.Ps.size() == 11 && e.wheelxyztBuf.size() == 1 && threw && gn) ? 0 : 1; }\n')
     exe = tmp_path / "t"
     lib = os.path.join(root, "ground-fusion_amd", "lib")
     subprocess.check_call(["g++", "-std=c++17", "-I", root, str(src), "-L", lib, "-lgroundfusion_hip", "-Wl,-rpath," + lib, "-o", str(exe)])
