@@ -85,6 +85,7 @@ struct gf_ba {
     size_t mwin_lds = 0;   // dynamic LDS of the prior / IMU / wheel sweep (ba_linearize_misc_win)
     int max_vis = 0, max_order = 0, max_prior = 0;   // largest n_visual / factor-order length / prior size of the resident batch (what the uploads copy)
     std::vector<const gf_ba_window*> resident;       // the caller's window behind every resident slot (gf_ba_marginalize_resident)
+    double max_solver_time = 0.0;   // ceres::Solver::Options::max_solver_time_in_seconds; 0 = not honoured (the fixed schedule runs without host round trips)
     long long mfma_per_lin = 0;   // v_mfma_f64_16x16x4 instructions of one visual linearisation of the resident batch
     long long jtj_alg_flops = 0;  // algorithmic flops of the same: Nv * 2 * 2 * (12 * 13 / 2 + 12 + 1) per window
     long long step_flops = 0;     // dense algebra of one ba_step over the resident batch: Schur SYRK NE*n_c^2 + Cholesky R^3/3 + substitutions 2 R^2
@@ -444,10 +445,17 @@ int launch_linearize(gf_ba* h, int which, int which_state, int only_valid, bool 
 // The fixed launch schedule of one batch solve: initial linearisation, then max_iters x (step, linearise candidate), final accept.
 int run_solve(gf_ba* h, int max_iters) {
     const Dims& d = h->d;
+    const auto t_begin = std::chrono::steady_clock::now();
     if (int rc = launch_linearize(h, 0, 0, 0, false)) return rc;
     Win w = h->win();
     StepBufs sb = h->sbufs();
     for (int it = 0; it <= max_iters; it++) {
+        if (h->max_solver_time > 0.0 && it > 0 && it < max_iters) {
+            // trust_region_minimizer.cc checks total_solver_time >= max_solver_time_in_seconds at the top of every iteration: with the option on, the host
+            // waits for the iterations enqueued so far and, once over the limit, enqueues only the closing step (accept / reject of the last candidate)
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() >= h->max_solver_time) it = max_iters;
+        }
         const bool time_step = it == 1 && max_iters >= 1;
         if (time_step) HIPCHK(hipEventRecord(h->ev[6], h->stream));
         if (h->big_step) ba_step<true><<<dim3(d.B), 512, 0, h->stream>>>(w, sb, it == 0 ? 1 : 0, max_iters, it == max_iters ? 1 : 0);
@@ -825,6 +833,11 @@ int gf_ba_debug_stamps(gf_ba* h, long long* out, int n) {  // phase timestamps o
     return GF_OK;
 }
 
+int gf_ba_set_max_solver_time(gf_ba* h, double seconds) {
+    if (!h || !(seconds >= 0.0)) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    h->max_solver_time = seconds;
+    return GF_OK;
+}
 int gf_ba_get_stats(gf_ba* h, gf_ba_stats* out) { if (!h || !out) return gf::set_err(GF_ERR_INVALID, "null argument"); *out = h->stats; return GF_OK; }
 int gf_ba_reset_stats(gf_ba* h) { if (!h) return gf::set_err(GF_ERR_INVALID, "null handle"); h->stats = gf_ba_stats{}; return GF_OK; }
 

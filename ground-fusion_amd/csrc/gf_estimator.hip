@@ -1275,6 +1275,7 @@ struct gf_estimator {
         w.wh_lin = wh_lin.data(); w.wh_lin_vel = wh_lv.data(); w.wh_lin_gyr = wh_lg.data(); w.wh_vel_1 = wh_v1.data(); w.wh_gyr_1 = wh_g1.data();
         if (prior_valid) { w.prior_n = prior_n; w.prior_nblocks = (int)prior_block_id.size(); w.prior_block_id = prior_block_id.data(); w.prior_J = prior_J.data(); w.prior_r = prior_r.data(); w.prior_x0 = prior_x0.data(); }
         lap(1);
+        if (!group && cfg.max_solver_time > 0) gf_ba_set_max_solver_time(ba, marginalization_flag == MARGIN_OLD ? cfg.max_solver_time * 4.0 / 5.0 : cfg.max_solver_time);   // EST:3312-3315
         if (group) {   // ceres::Solve, EST:3303-3318
             BatchSolver::Req rq{0, &w, cfg.num_iterations, 0, &last_summary, nullptr, GF_OK, false, std::string()};
             if (int rc = group->submit(rq)) return rc;

@@ -166,6 +166,7 @@ int gf_estimator_cfg_from_yaml(const char* config_file, gf_estimator_cfg* c) {
     c->depth_threshold = y.integer("depth_threshold");                       // an `int` in the reference, parameters.cpp:172
     c->multiple_thread = y.integer("multiple_thread");
     c->num_iterations = y.integer("max_num_iterations");
+    c->max_solver_time = y.real("max_solver_time");                          // SOLVER_TIME, parameters.cpp:343
     c->min_parallax_px = y.real("keyframe_parallax");
     if (c->use_imu) { c->acc_n = y.real("acc_n"); c->acc_w = y.real("acc_w"); c->gyr_n = y.real("gyr_n"); c->gyr_w = y.real("gyr_w"); c->g_norm = y.real("g_norm"); }
     const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};

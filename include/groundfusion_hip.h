@@ -226,6 +226,9 @@ int gf_ba_download(gf_ba* h, gf_ba_window* windows, int count, gf_ba_summary* su
  * per-step pose gather across GPUs (north_star; there is no counterpart in the single-process reference).  Enqueued behind a pending
  * asynchronous solve (complete after gf_ba_wait); otherwise complete on return. */
 int gf_ba_export_newest_poses(gf_ba* h, void* d_out, int count);
+/* ceres::Solver::Options::max_solver_time_in_seconds (estimator.cpp:3312-3315) for the following gf_ba_solve / gf_ba_solve_resident calls; 0 (default) = not
+ * honoured: the iterations are enqueued back to back.  With a limit the host synchronises before every iteration, as Ceres checks its clock there. */
+int gf_ba_set_max_solver_time(gf_ba* h, double seconds);
 int gf_ba_get_stats(gf_ba* h, gf_ba_stats* out);
 int gf_ba_debug_stamps(gf_ba* h, long long* out, int n); /* per-phase clock stamps of ba_step (profiling builds, -DGF_PROFILE_STEP) */
 int gf_ba_reset_stats(gf_ba* h);
@@ -278,6 +281,9 @@ typedef struct gf_estimator_cfg {
     int gnss_enable, gnss_track_num_thres, max_gnss_per_frame;
     double gnss_elevation_thres, gnss_psr_std_thres, gnss_dopp_std_thres, gnss_ddt_sigma, gnss_local_time_diff;
     double gnss_iono[8];
+    /* SOLVER_TIME (`max_solver_time`, parameters.cpp:343): the solve gets 4/5 of it when the oldest frame will be marginalised, all of it otherwise
+     * (estimator.cpp:3312-3315).  0 = not honoured (parity runs: the oracle counts iterations only). */
+    double max_solver_time;
 } gf_estimator_cfg;
 
 /* One L1 observation of a GNSS epoch as Estimator::inputGNSS receives it (ObsPtr), together with what GnssPsrDoppFactor's constructor derives from

@@ -378,3 +378,25 @@ def test_config5_window_with_gnss(gf, oracle):
     po, pg = oracle.ba_marginalize(a, 0, cap_n=512), est.marginalize([a], 0, cap_n=512)[0]
     assert pg["n"] == po["n"] == 6 * W + 9 + 17 + 9 and list(pg["block_id"]) == list(po["block_id"])
     est.close()
+
+
+def test_max_solver_time_is_optional_and_stops_the_schedule(gf):
+    """ceres::Solver::Options::max_solver_time_in_seconds (estimator.cpp:3312-3315): off by default (fixed schedule, no host round trip); with a generous cap
+    the result is bit-identical to the uncapped solve; with a cap that is already spent after the first iteration the solve ends early -- fewer iterations,
+    a higher final cost -- and still hands back a consistent, accepted state"""
+    import ctypes as C
+    est = gf.Estimator(batch=1)
+    base = SW.make_window(1004, gf)
+    free, capped, cut = base.copy(), base.copy(), base.copy()
+    s_free = est.solve([free], 8)[0]
+    gf._chk(gf.lib().gf_ba_set_max_solver_time(est.h, C.c_double(30.0)))
+    s_cap = est.solve([capped], 8)[0]
+    assert s_cap == s_free and all(np.array_equal(free[k], capped[k]) for k in gw.STATE_KEYS if k in free)
+    gf._chk(gf.lib().gf_ba_set_max_solver_time(est.h, C.c_double(1e-9)))
+    s_cut = est.solve([cut], 8)[0]
+    assert 1 <= s_cut["iterations"] < s_free["iterations"] and s_cut["final_cost"] > s_free["final_cost"] and s_cut["final_cost"] < s_cut["initial_cost"]
+    gf._chk(gf.lib().gf_ba_set_max_solver_time(est.h, C.c_double(0.0)))
+    again = base.copy()
+    assert est.solve([again], 8)[0] == s_free
+    with pytest.raises(gf.GfError):
+        gf._chk(gf.lib().gf_ba_set_max_solver_time(est.h, C.c_double(-1.0)))

@@ -4,6 +4,7 @@
 // <dataset dir> (layout in host/replay_node.h) through FeatureTracker::trackImage and Estimator::processImage on the GPU, and writes the
 // trajectory file the reference writes (output_path/vio.txt, TUM format) — to <vio.txt> when given, else to `output_path` of the config.
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <string>
 
@@ -28,6 +29,8 @@ int main(int argc, char** argv) {
     try {
         gf::Estimator estimator;
         estimator.readParameters(argv[1]);
+        // `max_solver_time` (a wall-clock cap on ceres::Solve) makes a replay depend on the machine and on what else it is doing: honoured only on request
+        if (!getenv("GF_HONOUR_SOLVER_TIME")) estimator.cfg.max_solver_time = 0.0;
         estimator.setParameter();
         const std::string out = argc > 3 ? argv[3] : yaml_string(argv[1], "output_path") + "/vio.txt";
         estimator.setResultPath(out);
