@@ -309,3 +309,53 @@ def test_replay_with_gnss_matches_oracle(window_size, own_initialiser, raw):
     assert worst["clk"] < 1e-3 and worst["anc"] < 1e-3 and worst["ecef"] < 1e-3, worst
     assert worst["anc_low"] < 2e-3 and worst["ecef_low"] < 2e-3 and worst["rho"] < 2e-3, worst      # rho runs over the `lowspeed` frames too
     est_p.close()
+
+
+def test_group_with_gnss_members():
+    """gf_estimator_group_* with gnss_enable: the shared back-end handle carries the GNSS blocks (max_gnss), members take their GNSS epochs through their own
+    handles and align themselves (GNSSVIInitializer inside the library); each member must end up where a stand-alone Estimator on the same inputs does --
+    local poses, receiver clocks, anchor -- while solves, marginalisations on the resident windows and the GNSS kernels run as one batch."""
+    n = 3
+    streams, G = [], []
+    for s in range(n):
+        st = SS.Stream(3 + s, t_still=1.5, t_move=3.4, v_max=0.4, yaw0=0.0, yaw_turn=-0.5 + 0.3 * s, split_x=1.8, turn_delay=0.8)
+        st._lm = st._landmarks(1200)
+        st._pn = np.random.default_rng(4200 + s).normal(0, 1.0, (len(st.cam_t), len(st._lm), 2))
+        G.append(st.gnss_setup(alpha=0.3 + 0.4 * s))
+        streams.append(st)
+    kw = dict(tio=SS.TIO, rio=SS.RIO, multiple_thread=1, gnss_enable=1, gnss_track_num_thres=3, gnss_local_time_diff=G[0]["time_diff"])
+    grp = gfamd.EstimatorGroup(gfamd.default_estimator_cfg(**kw), n)
+    solo = [gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(**kw)) for _ in range(n)]
+    tp, orng = [-1.0] * n, [np.random.default_rng(50 + s) for s in range(n)]
+    nk = min(len(st.cam_t) for st in streams)
+    worst, ready = dict(p=0.0, clk=0.0, anc=0.0), 0
+    for k in range(nk):
+        for s, st in enumerate(streams):
+            st.feed(grp.members[s], k, tp[s])
+            tp[s] = st.feed(solo[s], k, tp[s])
+        if k % 2:
+            continue
+        frames = [st.feature_frame(k) for st in streams]
+        for s, st in enumerate(streams):
+            tg, epoch = st.gnss_epoch(float(st.cam_t[k]) + orng[s].uniform(-0.02, 0.02))
+            grp.members[s].inputGNSS(tg, epoch)
+            solo[s].inputGNSS(tg, epoch)
+        grp.inputFeatures(list(range(n)), [float(st.cam_t[k]) for st in streams], frames)
+        for s in range(n):
+            solo[s].inputFeature(float(streams[s].cam_t[k]), frames[s])
+            a, b = grp.members[s].state(), solo[s].state()
+            ga, gb = grp.members[s].gnss_state(), solo[s].gnss_state()
+            assert a["frame_count"] == b["frame_count"] and a["solver_flag"] == b["solver_flag"] and a["iterations"] == b["iterations"], (k, s)
+            assert (ga["gnss_ready"], ga["lowspeed"], ga["n_newest"]) == (gb["gnss_ready"], gb["lowspeed"], gb["n_newest"]), (k, s)
+            worst["p"] = max(worst["p"], float(np.abs(a["Ps"] - b["Ps"]).max()))
+            worst["clk"] = max(worst["clk"], float(np.abs(ga["rcv_dt"] - gb["rcv_dt"]).max()))
+            worst["anc"] = max(worst["anc"], float(np.abs(ga["anc_ecef"] - gb["anc_ecef"]).max()))
+            ready += ga["gnss_ready"]
+    assert ready > 3 * 10
+    assert abs(solo[1].gnss_state()["yaw_enu_local"] - G[1]["yaw_enu_local"]) < 0.08          # each member found its own ENU <- local yaw
+    st_ = grp.stats()
+    assert st_["largest_batch"] == n
+    print("GNSS group vs stand-alone worst deviation", worst)
+    # the batch and the single-window launches run the same arithmetic (bit-identical states in tests/test_backend_gpu.py); the members' host threads change nothing
+    assert worst["p"] < 1e-9 and worst["clk"] < 1e-9 and worst["anc"] < 1e-9, worst
+    grp.close()
