@@ -257,53 +257,79 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     // dropped (marginalization_factor.cpp:294-302); any J with J^T J = A_r and J^T r = b_r is the same prior to the solver (only J^T J,
     // J^T r and |r|^2 enter Ceres), so a rank-revealing (diagonally pivoted) Cholesky with the same absolute threshold is used:
     // A_r = P L L^T P^T, J = L^T P^T (rows beyond the detected rank are zero), r = L^-1 P^T b (forward substitution rides along).
-    int* perm = reinterpret_cast<int*>(V);   // n ints
+    // Rows and columns are swapped PHYSICALLY when a pivot is chosen (one pass over the two rows / columns), so that everything after it addresses
+    // A[i][j] directly.  The matrix is kept full and symmetric: the pivot column is read as the pivot ROW (contiguous), the trailing update
+    // A[i][j] -= l_i l_j runs on a 2-D thread grid without index indirection, and every wavefront finds the pivot for itself (DPP row maxima + four
+    // scalar reads), so a pivot step costs one block barrier, two when rows have to be swapped (the version that addressed A[perm[i]][perm[j]],
+    // searched on one wavefront with shuffles and took an IEEE square root cost 4.8 k cycles per pivot).
+    int* perm = reinterpret_cast<int*>(V);   // n ints: original index of the row / column now at position i
     double* zb = V + 256;                    // n doubles: permuted right-hand side being forward-substituted
-    double* dg = V + 768;                    // current diagonal, by original index (pivot search reads only this)
     double* dinvs = V + 1280;                // 1 / L_kk per accepted pivot
     double* zr = V + 1792;                   // finished entries of the forward substitution
-    __shared__ double s_piv;
-    for (int i = tid; i < n; i += 512) { perm[i] = i; zb[i] = br[i]; dg[i] = A[i * n + i]; }
+    for (int i = tid; i < n; i += 512) { perm[i] = i; zb[i] = br[i]; }
     __syncthreads();
     int rank = n;
+    const int tx = tid & 31, ty = tid >> 5;   // 32 x 16 thread grid of the trailing update
     for (int k = 0; k < n; k++) {
-        // pivot search + swap by wavefront 0 alone (shuffles, no block-wide reduction): two barriers per pivot instead of ~15
-        if (wave == 0) {
-            double best = -1.0; int bi = k;
-            for (int i = k + lane; i < n; i += 64) { const double v = dg[perm[i]]; if (v > best) { best = v; bi = i; } }
+        // pivot: largest remaining diagonal entry, the lowest lane that holds it on ties (every wavefront computes the same answer)
+        double best = -1.0; int bi = k;
+        for (int i = k + lane; i < n; i += 64) { const double v = A[i * n + i]; if (v > best) { best = v; bi = i; } }
+        double m = best;
+#define GF_DPP_MAX(ctrl) do { const int lo_ = __builtin_amdgcn_mov_dpp(__double2loint(m), ctrl, 0xf, 0xf, true), hi_ = __builtin_amdgcn_mov_dpp(__double2hiint(m), ctrl, 0xf, 0xf, true); \
+                              m = fmax(m, __hiloint2double(hi_, lo_)); } while (0)
+        GF_DPP_MAX(0xB1); GF_DPP_MAX(0x4E); GF_DPP_MAX(0x141); GF_DPP_MAX(0x140);   // quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+#undef GF_DPP_MAX
+        double piv = -1.0;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-            }
-            if (lane == 0) {
-                s_piv = best;
-                if (best > eps) { const int t = perm[k]; perm[k] = perm[bi]; perm[bi] = t; const double tz = zb[k]; zb[k] = zb[bi]; zb[bi] = tz; }
-            }
-        }
-        __syncthreads();
-        const double piv = s_piv;
+        for (int q = 0; q < 4; q++) piv = fmax(piv, __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m), 16 * q), __builtin_amdgcn_readlane(__double2loint(m), 16 * q)));
+        const unsigned long long hit = __ballot(best == piv);
+        const int p = __builtin_amdgcn_readlane(bi, __ffsll((long long)hit) - 1);
         if (!(piv > eps)) { rank = k; break; }
-        const int pk_ = perm[k];
-        const double dinv = 1.0 / sqrt(piv), ipiv = 1.0 / piv;
-        const double rk = zb[k] * dinv;
-        if (tid == 0) { dinvs[k] = dinv; zr[k] = rk; }
-        // column k stays unscaled in A (it is only read from here on): L[i][k] = A[perm[i]][pk_] * dinv is applied where it is consumed
-        for (int i = k + 1 + tid; i < n; i += 512) { const double l = A[perm[i] * n + pk_] * dinv; zb[i] -= l * rk; dg[perm[i]] -= l * l; }
-        const int m = n - k - 1;
-        for (int e = tid; e < m * m; e += 512) {
-            const int i = k + 1 + e / m, j = k + 1 + e % m;
-            A[perm[i] * n + perm[j]] -= A[perm[i] * n + pk_] * A[perm[j] * n + pk_] * ipiv;
+        if (p != k) {   // symmetric swap k <-> p of the full matrix in one pass: thread t moves the four entries that involve t; the 2 x 2 corner by thread 0
+            for (int t = tid; t < n; t += 512) {
+                if (t == k || t == p) continue;
+                const double a0 = A[k * n + t], a1 = A[p * n + t]; A[k * n + t] = a1; A[p * n + t] = a0;
+                const double b0 = A[t * n + k], b1 = A[t * n + p]; A[t * n + k] = b1; A[t * n + p] = b0;
+            }
+            if (tid == 0) {
+                const double dk = A[k * n + k]; A[k * n + k] = A[p * n + p]; A[p * n + p] = dk;   // A[k][p] == A[p][k] stay where they are
+                const int tp = perm[k]; perm[k] = perm[p]; perm[p] = tp;
+                const double tz = zb[k]; zb[k] = zb[p]; zb[p] = tz;
+            }
+            __syncthreads();
         }
+#ifdef GF_MARG_IEEE_SQRT   // conditioning experiments (scripts/gnss_replay_sensitivity.py): the arithmetically equivalent, correctly rounded variant
+        double dinv = 1.0 / sqrt(piv);
+#else
+        // 1 / sqrt(piv): hardware seed, one plain Newton step, one with the residual 1 - piv y^2 formed exactly (product split by an fma), which leaves
+        // the final rounding as the only error (an IEEE sqrt and a division cost ~500 cycles per pivot).  Accuracy matters here: a relative error d of 1 / L_kk
+        // puts 2 d |l_i l_j| ~ 1e-7 (entries of 1e9) into the trailing block, which is the size of the weak GNSS directions the prior has to carry
+        double dinv = __builtin_amdgcn_rsq(piv);
+        dinv = dinv * (1.5 - 0.5 * piv * dinv * dinv);
+        {
+            const double h = piv * dinv, hl = __builtin_fma(piv, dinv, -h);
+            const double e = __builtin_fma(-h, dinv, 1.0) - hl * dinv;
+            dinv = __builtin_fma(0.5 * dinv, e, dinv);
+        }
+#endif
+        const double rk = zb[k] * dinv;
+        const double* rowk = A + (size_t)k * n;   // = column k (symmetric; rows > k are what the update below writes, row k is final)
+        for (int i = k + 1 + ty; i < n; i += 16) {
+            const double li = rowk[i] * dinv;
+            double* row = A + (size_t)i * n;
+            for (int j = k + 1 + tx; j < n; j += 32) row[j] = __builtin_fma(-li, rowk[j] * dinv, row[j]);
+        }
+        for (int i = k + 1 + tid; i < n; i += 512) zb[i] = __builtin_fma(-(rowk[i] * dinv), rk, zb[i]);
+        if (tid == 0) { dinvs[k] = dinv; zr[k] = rk; }
         __syncthreads();
     }
     GF_MST(5);
     double* J = out.J + (size_t)b * d.NPRI * d.NPRI;
     double* rr = out.r + (size_t)b * d.NPRI;
     for (int i = tid; i < n * n; i += 512) {
-        const int k = i / n, pos = i % n;   // J[k][perm[pos]] = L[pos][k] for pos >= k, k < rank
+        const int k = i / n, pos = i % n;   // J[k][perm[pos]] = L[pos][k] for pos >= k, k < rank (column k of A below the diagonal is still unscaled)
         double v = 0.0;
-        if (k < rank && pos >= k) v = pos == k ? 1.0 / dinvs[k] : A[perm[pos] * n + perm[k]] * dinvs[k];
+        if (k < rank && pos >= k) v = pos == k ? 1.0 / dinvs[k] : A[k * n + pos] * dinvs[k];   // row k right of the diagonal = column k below it
         J[(size_t)k * n + perm[pos]] = v;
     }
     for (int k = tid; k < n; k += 512) rr[k] = k < rank ? zr[k] : 0.0;

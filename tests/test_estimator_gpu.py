@@ -217,16 +217,14 @@ def test_replay_with_gnss_matches_oracle(window_size, own_initialiser, raw):
     DdtSmoothFactor in the solve (:2904-2941, :3178-3230) and in the MARGIN_OLD marginalisation (:3398-3434), the `lowspeed` switch while the
     vehicle crawls at the end, the clock shifts of both slideWindow branches (:3674-3681, :3761-3768), updateGNSSStatistics (:2045-2058).
     Bars: identical decisions (gnss_ready, lowspeed, admitted satellites per frame, keyframes, iteration counts) at every frame; window poses within
-    1e-6 m / 1e-6 rad; anchor, receiver clocks, ECEF position and the modelled range + clock of every admitted satellite within 1e-3 m.  The
-    GNSS states carry ECEF-sized numbers (6.4e6 m) and hang on weak directions of the marginalisation prior (eigenvalues ~1e-5 against 1e9 at the
-    top: a 1e-8 difference in the prior's right-hand side -- the parity level of two correct factorisations -- moves them by up to 1e-3 m).  Two
-    builds of THIS library that differ only in the summation order of the Cholesky diagonal blocks gave 1.3e-5 and 1.5e-4 m against the oracle,
-    with identical local poses (5e-8 m); the pseudoranges carry 0.5 m of noise.  DESIGN.md, "GNSS chains".
-    While `lowspeed` keeps the GNSS factors out of the solve the anchor hangs on the prior alone, and the prior is only defined up to the
-    reference's own truncation (marginalization_factor.cpp:276-282 zeroes eigenvalues below 1e-8): in the W = 20 replay the wheel blocks enter
-    the prior with eigenvalues 2.7e-8 and 4.4e-8 -- next to the cut -- and the anchor of the two pipelines then differs by 5e-4 m for the rest
-    of the crawl (scripts/gnss_replay.py --w20 --single: identical solves to 1 ulp, identical priors to 1e-9 before that frame).  Bar 2e-3 m
-    for the anchor / ECEF position of `lowspeed` frames; every local quantity keeps the 1e-6 bar.
+    1e-6 m / 1e-6 rad; anchor, receiver clocks, ECEF position and the modelled range + clock of every admitted satellite within 5e-4 m
+    (observed 1e-7 ... 1.1e-4).  The GNSS states carry ECEF-sized numbers (6.4e6 m) and hang on weak directions of the marginalisation prior
+    (eigenvalues 1e-8 ... 1e-5 against 1e9 at the top): what the prior says about them is what is left of entries of 1e9 after the strong pivots
+    have been eliminated, so every relative error of 1e-16 in the factorisation shows at the 1e-7 level there.  Measured: with 1 / L_kk from a
+    plain Newton iteration (2-3 ulp) the same replays sat 1.2e-3 m (W = 10, raw) and 1.5e-3 m (W = 20, `lowspeed` anchor) from the oracle, with
+    the correctly rounded reciprocal root 1e-4 and 2e-7 m -- local poses identical (5e-8 m) either way; the pseudoranges carry 0.5 m of noise.
+    DESIGN.md, "GNSS chains".  While `lowspeed` keeps the GNSS factors out of the solve the anchor hangs on the prior alone (anc_low / ecef_low,
+    same bar).
     own_initialiser: nobody hands an alignment in; the library runs GNSSVIInitializer itself (initial/gnss_vi_initializer.cpp: SPP fix of the window's
     measurements, yaw alignment on the Doppler residuals, anchor refinement) and must arrive where the numpy restatement does.
     raw: the satellites fly broadcast orbits; the estimators receive ephemerides (inputEphem) and raw observations and derive the satellite states
@@ -306,8 +304,8 @@ def test_replay_with_gnss_matches_oracle(window_size, own_initialiser, raw):
     print("gnss replay W=%d worst deviation" % W, worst, "ATE rmse %.4f m over %d frames" % (rmse, len(ate)))
     assert rmse < 0.05                                                       # 1.4 m of driving; observed 0.01
     assert worst["p"] < 1e-6 and worst["r"] < 1e-6, worst
-    assert worst["clk"] < 1e-3 and worst["anc"] < 1e-3 and worst["ecef"] < 1e-3, worst
-    assert worst["anc_low"] < 2e-3 and worst["ecef_low"] < 2e-3 and worst["rho"] < 2e-3, worst      # rho runs over the `lowspeed` frames too
+    assert worst["clk"] < 5e-4 and worst["anc"] < 5e-4 and worst["ecef"] < 5e-4, worst
+    assert worst["anc_low"] < 5e-4 and worst["ecef_low"] < 5e-4 and worst["rho"] < 5e-4, worst      # rho runs over the `lowspeed` frames too
     est_p.close()
 
 
