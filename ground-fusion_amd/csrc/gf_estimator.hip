@@ -40,6 +40,7 @@
 #include "../../include/groundfusion_hip.h"
 #include "gf_dmath.hpp"
 #include "gf_preint.hpp"
+#include "gf_init_sfm.hpp"
 
 namespace gf { int set_err(int code, const char* fmt, ...); }
 using namespace gfd;
@@ -177,6 +178,7 @@ struct FeatureManager {
             it.solve_flag = it.estimated_depth < 0 ? 2 : 1;
         }
     }
+    void clearDepth() { for (auto& it : feature) it.estimated_depth = -1; }  // FM:280-284
     void removeFailures() { for (auto it = feature.begin(); it != feature.end();) it = it->solve_flag == 2 ? feature.erase(it) : std::next(it); }  // FM:269-278
     void getDepthVector(std::vector<double>& dep) {  // FM:286-302
         dep.clear();
@@ -312,8 +314,10 @@ struct WheelPre {  // wheel_integration_base.h:23-60
         return rc;
     }
 };
-struct ImageFrame {  // initial/initial_alignment.h ImageFrame: only what the non-SfM paths read
+struct ImageFrame {  // initial/initial_alignment.h:25-40
     M3 R = m3_identity(); V3 T = v3(0, 0, 0);
+    std::vector<gf_feature_obs> points;   // the frame's observations in id order (std::map order), for the per-frame solvePnP of initialStructure
+    bool is_key_frame = false;
     std::shared_ptr<ImuPre> pre_integration;
     std::shared_ptr<WheelPre> pre_integration_wheel;
     bool pre_deleted = false;  // the reference deletes the pointer of the oldest frame but keeps the map entry (EST:3722-3726)
@@ -1025,7 +1029,125 @@ struct gf_estimator {
         for (int i = 0; i <= WINDOW_SIZE; i++) Bgs[i] = Bgs[i] + delta_bg;
         for (auto fi = all_image_frame.begin(); std::next(fi) != all_image_frame.end(); ++fi) std::next(fi)->second.pre_integration->repropagate(v3(0, 0, 0), Bgs[0]);
     }
-    bool initialStructure() {  // EST:1557-1682; the SfM / PnP path (EST:1684-1847) is not built -> false
+    // EST:2087-2124: solveRelativeRT_PNP returns true whatever cv::solvePnPRansac found, so the first frame with more than 20 correspondences is taken
+    // and the parallax test below it is never reached.  -1: no frame; -2: solvePnPRansac found no model (the reference would read unset matrices)
+    int relativePoseWithDepth(M3& relative_R, V3& relative_T) {
+        for (int i = 0; i < WINDOW_SIZE; i++) {
+            const std::vector<double> c = f_manager.getCorrespondingWithDepth(i, WINDOW_SIZE);
+            if ((int)c.size() / 6 > 20) {
+                std::vector<std::array<double, 6>> corres(c.size() / 6);
+                for (size_t k = 0; k < corres.size(); k++) for (int a = 0; a < 6; a++) corres[k][a] = c[6 * k + a];
+                double T[3];
+                if (!gfinit::solve_relative_rt_pnp(corres, relative_R.m, T)) return -2;
+                relative_T = arr3(T);
+                return i;
+            }
+        }
+        return -1;
+    }
+    bool visualInitialAlign() {  // EST:1849-1926; VisualIMUAlignment initial_aligment.cpp:640-653 (depth variants)
+        solveGyroscopeBias();
+        std::vector<gfinit::AlignFrame> fr;
+        for (auto& kv : all_image_frame) {
+            gfinit::AlignFrame a{};
+            for (int k = 0; k < 9; k++) a.R[k] = kv.second.R.m[k];
+            a.T[0] = kv.second.T.x; a.T[1] = kv.second.T.y; a.T[2] = kv.second.T.z;
+            if (!fr.empty()) {   // the first frame's pre-integration is never read
+                kv.second.pre_integration->eval(imu_noise);
+                a.sum_dt = kv.second.pre_integration->sum_dt;
+                for (int k = 0; k < 3; k++) { a.delta_p[k] = kv.second.pre_integration->delta_p[k]; a.delta_v[k] = kv.second.pre_integration->delta_v[k]; }
+                if (cfg.use_wheel) { kv.second.pre_integration_wheel->eval(wheel_noise); for (int k = 0; k < 3; k++) a.wheel_delta_p[k] = kv.second.pre_integration_wheel->delta_p[k]; }
+            }
+            fr.push_back(a);
+        }
+        const double TICa[3] = {tic.x, tic.y, tic.z}, TIOa[3] = {tio.x, tio.y, tio.z};
+        double ga[3];
+        std::vector<double> x;
+        if (!gfinit::linear_alignment(fr, TICa, cfg.g_norm, cfg.use_wheel != 0, rio.m, TIOa, ga, x)) return false;
+        g = init_g = arr3(ga);
+        for (int i = 0; i <= frame_count; i++) {
+            ImageFrame& f = all_image_frame[Headers[i]];
+            Ps[i] = f.T; Rs[i] = f.R; f.is_key_frame = true;
+        }
+        const double s = init_s = x.back();   // EST:1871: the last entry of x -- in the depth variants a gravity-refinement component, not a scale
+        for (int i = 0; i <= WINDOW_SIZE; i++) pre_integrations[i]->repropagate(v3(0, 0, 0), Bgs[i]);
+        const V3 P0 = Ps[0];
+        for (int i = frame_count; i >= 0; i--) Ps[i] = Ps[i] * s - Rs[i] * tic - (P0 * s - Rs[0] * tic);
+        int kv = -1;
+        for (auto& f : all_image_frame)
+            if (f.second.is_key_frame) { kv++; Vs[kv] = f.second.R * v3(x[3 * kv], x[3 * kv + 1], x[3 * kv + 2]); }
+        M3 R0 = g2R(g);
+        const double yaw = R2ypr(R0 * Rs[0]).x;
+        R0 = ypr2R(v3(-yaw, 0, 0)) * R0;
+        g = R0 * g;
+        for (int i = 0; i <= frame_count; i++) { Ps[i] = R0 * Ps[i]; Rs[i] = R0 * Rs[i]; Vs[i] = R0 * Vs[i]; }
+        f_manager.clearDepth();
+        f_manager.triangulateWithDepth(Ps.data(), Rs.data(), tic, ric);
+        f_manager.triangulate(Ps.data(), Rs.data(), tic, ric);
+        return true;
+    }
+    bool debug_skip_solve = false;
+    int init_rc = GF_OK, init_l = -1, init_points = 0; double init_s = 0; V3 init_g = v3(0, 0, 0);   // what the SfM branch did (debug / tests)
+    bool initialStructureSfM(V3 aver_g) {  // EST:1684-1847
+        if (!cfg.depth) { init_rc = gf::set_err(GF_ERR_INVALID, "initialStructure: the monocular SfM path (construct / relativePose) is outside the RGB-D scope"); return false; }
+        std::vector<gfinit::SfmFeature> sfm_f;
+        for (auto& it : f_manager.feature) {
+            gfinit::SfmFeature f;
+            f.id = it.feature_id;
+            int j = it.start_frame - 1;
+            for (auto& pf : it.feature_per_frame) { j++; f.observation.push_back({j, {pf.point.x, pf.point.y}}); f.depth.push_back(pf.depth); }
+            sfm_f.push_back(f);
+        }
+        M3 relative_R; V3 relative_T;
+        const int l = relativePoseWithDepth(relative_R, relative_T);
+        if (l == -2) { init_rc = gf::set_err(GF_ERR_INVALID, "initialStructure: solvePnPRansac found no model (the reference reads unset matrices here)"); return false; }
+        if (l < 0) return false;
+        std::vector<std::array<double, 4>> Q;
+        std::vector<gfinit::P3> T;
+        std::map<int, gfinit::P3> tracked;
+        const double rT[3] = {relative_T.x, relative_T.y, relative_T.z};
+        if (!gfinit::construct_with_depth(frame_count + 1, l, relative_R.m, rT, sfm_f, Q, T, tracked)) { marginalization_flag = MARGIN_OLD; return false; }
+        init_l = l; init_points = (int)tracked.size();
+        int i = 0;
+        for (auto& kv : all_image_frame) {   // solve pnp for all frame, :1749-1813
+            ImageFrame& fr = kv.second;
+            M3 Ri;
+            gfinit::quat_rot(Q[i].data(), Ri.m);
+            if (kv.first == Headers[i]) {
+                fr.is_key_frame = true;
+                fr.R = Ri * transpose(ric);
+                fr.T = v3(T[i][0], T[i][1], T[i][2]);
+                i++;
+                continue;
+            }
+            if (kv.first > Headers[i]) { i++; gfinit::quat_rot(Q[i].data(), Ri.m); }
+            const M3 R_initial = transpose(Ri);
+            const V3 P_initial = (R_initial * v3(T[i][0], T[i][1], T[i][2])) * -1.0;
+            fr.is_key_frame = false;
+            std::vector<gfinit::P3> X; std::vector<gfinit::P2> uv;
+            for (auto& o : fr.points) {
+                auto it = tracked.find(o.id);
+                if (it != tracked.end()) { X.push_back(it->second); uv.push_back({o.v[0], o.v[1]}); }
+            }
+            if (X.size() < 6) return false;
+            double rv[3], tv[3] = {P_initial.x, P_initial.y, P_initial.z};
+            gfinit::rodrigues_inv(R_initial.m, rv);
+            if (!gfinit::solve_pnp_iterative(X, uv, rv, tv, true)) return false;
+            M3 r;
+            gfinit::rodrigues(rv, r.m);
+            const M3 R_pnp = transpose(r);
+            fr.R = R_pnp * transpose(ric);
+            fr.T = R_pnp * (arr3(tv) * -1.0);
+        }
+        if (visualInitialAlign()) {
+            const V3 G = v3(0, 0, cfg.g_norm);
+            const V3 tmp_Bas = aver_g - transpose(g2R(aver_g)) * G;
+            for (int k = 0; k <= WINDOW_SIZE; k++) Bas[k] = tmp_Bas;
+            return true;
+        }
+        return false;
+    }
+    bool initialStructure() {  // EST:1557-1682 here; the SfM / PnP branch (EST:1684-1847) in initialStructureSfM
         V3 aver_g;
         {
             const int n = (int)all_image_frame.size() - 1;
@@ -1059,15 +1181,16 @@ struct gf_estimator {
             for (int i = 0; i <= frame_count; i++) { Ps[i] = R0 * Ps[i]; Rs[i] = R0 * Rs[i]; Vs[i] = R0 * Vs[i]; }
             return true;
         }
-        return false;
+        return initialStructureSfM(aver_g);
     }
 
     // ------------------------------------------------------------ processImage
-    int processImage(const std::vector<gf_feature_obs>& image, double header) {  // EST:843-1163
+    void processImageHead(const std::vector<gf_feature_obs>& image, double header) {  // EST:843-905: everything before the solver_flag switch
         marginalization_flag = f_manager.addFeatureCheckParallax(frame_count, image.data(), (int)image.size(), td) ? MARGIN_OLD : MARGIN_SECOND_NEW;
         Headers[frame_count] = header;
         ImageFrame imageframe;
         imageframe.pre_integration = tmp_pre_integration; imageframe.pre_integration_wheel = tmp_wheel_pre_integration;
+        if (solver_flag == INITIAL) imageframe.points = image;   // read by initialStructure only
         all_image_frame.insert(std::make_pair(header, imageframe));
         tmp_pre_integration = std::make_shared<ImuPre>(acc_0, gyr_0, Bas[frame_count], Bgs[frame_count]);
         tmp_wheel_pre_integration = std::make_shared<WheelPre>(vel_0_wheel, gyr_0_wheel, sx, sy, sw, td_wheel);
@@ -1076,13 +1199,16 @@ struct gf_estimator {
         if (checkvisual()) visualstationary = true;
         systemstationary = (imustationary && wheelstationary) || (visualstationary && wheelstationary) || (imustationary && visualstationary);
         predict_ids.clear(); predict_xyz.clear(); remove_ids.clear();
-
+    }
+    int processImage(const std::vector<gf_feature_obs>& image, double header) {  // EST:843-1163
+        processImageHead(image, header);
         if (solver_flag == INITIAL) {
             if (frame_count == WINDOW_SIZE) {  // DEPTH && USE_IMU branch, EST:967-1037
                 int i = 0;
                 for (auto& kv : all_image_frame) { if (i <= WINDOW_SIZE) { kv.second.R = Rs[i]; kv.second.T = Ps[i]; } i++; }
                 bool result = false;
                 if (header - initial_timestamp > 0.1) { result = initialStructure(); initial_timestamp = header; }
+                if (init_rc != GF_OK) return init_rc;
                 if (result) {
                     solveGyroscopeBias();
                     for (int k = 0; k <= WINDOW_SIZE; k++) pre_integrations[k]->repropagate(v3(0, 0, 0), Bgs[k]);
@@ -1162,6 +1288,7 @@ struct gf_estimator {
         return GF_OK;
     }
     int optimization() {  // EST:2890-3636
+        if (debug_skip_solve) return GF_OK;
         if (!ba && !group) {
             gf_ba_cfg bc{WINDOW_SIZE, cfg.max_features, cfg.max_visual, 1, cfg.gnss_enable ? cfg.max_gnss_per_frame * (WINDOW_SIZE + 1) : 0};
             if (int rc = gf_ba_create(&bc, &ba)) return rc;
@@ -1323,6 +1450,7 @@ struct gf_estimator {
 
     // ------------------------------------------------------------ window bookkeeping
     void slideWindow() {  // EST:3638-3790
+        if (debug_skip_solve) return;
         if (marginalization_flag == MARGIN_OLD) {
             const double t_0 = Headers[0];
             back_R0 = Rs[0]; back_P0 = Ps[0];
@@ -1705,6 +1833,24 @@ int gf_estimator_debug(gf_estimator* e, const char* op, const double* in, int n_
         for (auto& b : e->gnss_meas_buf) { o.push_back((double)b.size()); for (auto& m : b) o.push_back(m.sat); }
     }
     else if (s == "sat_track_status") for (auto& kv : e->sat_track_status) { o.push_back(kv.first); o.push_back(kv.second); }
+    else if (s == "solveRelativeRT_PNP" && n_in >= 6 && n_in % 6 == 0) {   // in: correspondences (6 values each); out: ok, Rotation (9), Translation (3)
+        std::vector<std::array<double, 6>> corres(n_in / 6);
+        for (size_t k = 0; k < corres.size(); k++) for (int a = 0; a < 6; a++) corres[k][a] = in[6 * k + a];
+        double R[9] = {0}, T[3] = {0};
+        const bool ok = gfinit::solve_relative_rt_pnp(corres, R, T);
+        o.push_back(ok ? 1.0 : 0.0); o.insert(o.end(), R, R + 9); o.insert(o.end(), T, T + 3);
+    }
+    else if (s == "solvePnP" && n_in >= 8 && (n_in - 8) % 5 == 0) {   // in: n, use_guess, rvec, tvec, then (X, Y, Z, u, v) per point; out: ok, rvec, tvec
+        const int n = (int)in[0];
+        if (n_in != 8 + 5 * n) return gf::set_err(GF_ERR_INVALID, "solvePnP: %d values for %d points", n_in, n);
+        std::vector<gfinit::P3> X(n); std::vector<gfinit::P2> uv(n);
+        for (int k = 0; k < n; k++) { X[k] = {in[8 + 5 * k], in[9 + 5 * k], in[10 + 5 * k]}; uv[k] = {in[11 + 5 * k], in[12 + 5 * k]}; }
+        double rv[3] = {in[2], in[3], in[4]}, tv[3] = {in[5], in[6], in[7]};
+        const bool ok = gfinit::solve_pnp_iterative(X, uv, rv, tv, in[1] != 0);
+        o.push_back(ok ? 1.0 : 0.0); o.insert(o.end(), rv, rv + 3); o.insert(o.end(), tv, tv + 3);
+    }
+    else if (s == "skip_solve" && n_in >= 1) e->debug_skip_solve = in[0] != 0;   // optimization() and slideWindow() become no-ops: host-only parity tests of initialStructure
+    else if (s == "init_info") o = {(double)e->init_l, (double)e->init_points, e->init_s, e->init_g.x, e->init_g.y, e->init_g.z, (double)e->init_rc, e->g.x, e->g.y, e->g.z};
     else if (s == "addFeature" && n_in >= 2 && (n_in - 2) % 9 == 0) {
         const int n = (n_in - 2) / 9;
         std::vector<gf_feature_obs> v(n);

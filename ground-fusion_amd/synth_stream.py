@@ -19,14 +19,14 @@ def rot_z(a):
 
 
 class Stream:
-    def __init__(self, seed, t_still=1.5, t_move=3.0, v_max=0.4, imu_hz=200.0, wheel_hz=50.0, cam_hz=30.0, noise=True, near_z=2.5, far_z=6.0, yaw0=0.0, yaw_turn=0.0, split_x=0.6, turn_delay=0.0, slow_tail=0.0, v_tail=0.15):
+    def __init__(self, seed, t_still=1.5, t_move=3.0, v_max=0.4, imu_hz=200.0, wheel_hz=50.0, cam_hz=30.0, noise=True, near_z=2.5, far_z=6.0, yaw0=0.0, yaw_turn=0.0, split_x=0.6, turn_delay=0.0, slow_tail=0.0, v_tail=0.15, v_start=0.0):
         rng = np.random.default_rng(2000 + seed)
         self.seed, self.near_z, self.far_z, self.split_x = seed, near_z, far_z, split_x
         T = t_still + t_move
         h = 1e-4
         t = np.arange(0, T + 0.2, h)
         s = np.clip((t - t_still) / 0.8, 0, 1)
-        speed = v_max * (3 * s ** 2 - 2 * s ** 3)                                   # smooth ramp
+        speed = v_start + (v_max - v_start) * (3 * s ** 2 - 2 * s ** 3)             # smooth ramp (v_start > 0 with t_still = 0: the recording begins in motion)
         if slow_tail > 0.0:                                                         # ... and down to v_tail over the last slow_tail seconds (crawling, not stopping)
             e = np.clip((t - (T - slow_tail)) / (0.6 * slow_tail), 0, 1)
             speed = speed - (v_max - v_tail) * (3 * e ** 2 - 2 * e ** 3) * (t > t_still + 0.8)

@@ -15,6 +15,7 @@ sys.path.insert(0, _HERE)
 sys.path.insert(0, os.path.join(_HERE, "..", "ground-fusion_amd"))
 import oracle_py as O  # noqa: E402
 import gfwindow as gw  # noqa: E402
+import init_oracle as IO  # noqa: E402
 
 INITIAL, NON_LINEAR = 0, 1
 MARGIN_OLD, MARGIN_SECOND_NEW = 0, 1
@@ -309,6 +310,15 @@ def qmul(a, b):
                      a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3], a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1]])
 
 
+def ypr2R_deg_free(r):
+    """Rx(r0) Ry(r1) Rz(r2), angles in radians: what Sophus::SO3(double rot_x, double rot_y, double rot_z) of the non-templated Sophus builds"""
+    cx, sx, cy, sy, cz, sz = math.cos(r[0]), math.sin(r[0]), math.cos(r[1]), math.sin(r[1]), math.cos(r[2]), math.sin(r[2])
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rx @ Ry @ Rz
+
+
 def deltaQ_R(theta):  # Utility::deltaQ(theta).toRotationMatrix()
     q = np.array([1.0, theta[0] / 2, theta[1] / 2, theta[2] / 2])
     q = q / np.linalg.norm(q)
@@ -459,6 +469,10 @@ class FeatureManager:
         for k, f in enumerate(self.used()):
             f.estimated_depth = 1.0 / x[k] if x[k] != 0 else math.copysign(math.inf, x[k])
             f.solve_flag = 2 if f.estimated_depth < 0 else 1
+
+    def clearDepth(self):  # FM:280-284
+        for f in self.feature:
+            f.estimated_depth = -1.0
 
     def removeFailures(self):  # FM:269-278
         self.feature = [f for f in self.feature if f.solve_flag != 2]
@@ -611,8 +625,9 @@ class WheelPre:
 
 
 class ImageFrame:
-    def __init__(self, pre, pre_w):
+    def __init__(self, pre, pre_w, points=None):  # initial/initial_alignment.h:25-40
         self.R, self.T, self.pre_integration, self.pre_integration_wheel = np.eye(3), np.zeros(3), pre, pre_w
+        self.points, self.is_key_frame = dict(points or {}), False
 
 
 # ---------------------------------------------------------------- Estimator
@@ -1068,7 +1083,117 @@ class Estimator:
             for i in range(self.frame_count + 1):
                 self.Ps[i], self.Rs[i], self.Vs[i] = R0 @ self.Ps[i], R0 @ self.Rs[i], R0 @ self.Vs[i]
             return True
+        return self._initialStructureSfM(aver_g)
+
+    def relativePoseWithDepth(self):  # EST:2087-2124 with MotionEstimator::solveRelativeRT_PNP (initial/solve_5pts.cpp:244-277)
+        W = self.W
+
+        def rt_pnp(corres):
+            X = [a for a, b in corres if a[2] > 0 and b[2] > 0]
+            uv = [b[:2] / b[2] for a, b in corres if a[2] > 0 and b[2] > 0]
+            r = IO.solve_pnp_ransac(np.array(X), np.array(uv))
+            if r is None:            # cv::solvePnPRansac left rvec / tvec empty: the reference would read unset matrices; refused here
+                raise RuntimeError("solvePnPRansac found no model")
+            rv, tv = r[0], r[1]
+            rota = ypr2R_deg_free(rv)   # Sophus::SO3(rot_x, rot_y, rot_z) of the non-templated Sophus: Rx(rot_x) Ry(rot_y) Rz(rot_z), NOT the Rodrigues vector
+            return rota.T, -rota.T @ tv
+
+        for i in range(W):
+            corres = self.f_manager.getCorrespondingWithDepth(i, W)
+            if len(corres) > 20:
+                R, T = rt_pnp(corres)   # solveRelativeRT_PNP returns true unconditionally: the parallax test below it is never reached
+                return R, T, i
+        return None
+
+    def _initialStructureSfM(self, aver_g):  # EST:1684-1847
+        fc = self.frame_count
+        sfm_f = []
+        for f in self.f_manager.feature:
+            sf = IO.SFMFeature(f.feature_id)
+            for k, fpf in enumerate(f.feature_per_frame):
+                sf.observation.append((f.start_frame + k, fpf.point[:2].copy()))
+                sf.observation_depth.append((f.start_frame + k, fpf.depth))
+            sfm_f.append(sf)
+        rel = self.relativePoseWithDepth()
+        if rel is None:
+            return False
+        relative_R, relative_T, l = rel
+        r = IO.construct_with_depth(fc + 1, l, relative_R, relative_T, sfm_f)
+        if r is None:
+            self.marginalization_flag = MARGIN_OLD
+            return False
+        Q, T, tracked = r
+        self.init_debug = dict(l=l, relative_R=relative_R, relative_T=relative_T, Q=np.array(Q), T=np.array(T), n_tracked=len(tracked))
+        ric = self.ric
+        i = 0
+        for key in sorted(self.all_image_frame):   # solve pnp for all frame, :1749-1813
+            fr = self.all_image_frame[key]
+            if key == self.Headers[i]:
+                fr.is_key_frame = True
+                fr.R = quat_to_R(*Q[i]) @ ric.T
+                fr.T = T[i].copy()
+                i += 1
+                continue
+            if key > self.Headers[i]:
+                i += 1
+            qi = np.array([Q[i][0], -Q[i][1], -Q[i][2], -Q[i][3]]) / float(Q[i] @ Q[i])
+            R_initial = quat_to_R(*qi)
+            P_initial = -R_initial @ T[i]
+            fr.is_key_frame = False
+            X, uv = [], []
+            for fid in sorted(fr.points):
+                if fid in tracked:
+                    X.append(tracked[fid]); uv.append(np.asarray(fr.points[fid][:2], float))
+            if len(X) < 6:
+                return False
+            rt = IO.solve_pnp_iterative(np.array(X), np.array(uv), (IO.rodrigues_inv(R_initial), P_initial))
+            if rt is None:
+                return False
+            R_pnp = IO.rodrigues(rt[0]).T
+            fr.R = R_pnp @ ric.T
+            fr.T = R_pnp @ (-rt[1])
+        if self.visualInitialAlign():
+            G = np.array([0, 0, self.cfg["g_norm"]], float)
+            tmp = aver_g - g2R(aver_g).T @ G
+            self.Bas = [tmp.copy() for _ in range(self.W + 1)]
+            return True
         return False
+
+    def visualInitialAlign(self):  # EST:1849-1926, VisualIMUAlignment initial_aligment.cpp:640-653
+        c, fc = self.cfg, self.frame_count
+        self.solveGyroscopeBias()
+        if not c["depth"]:
+            raise NotImplementedError("monocular alignment (LinearAlignment / LinearAlignmentWithWheel) is outside the RGB-D scope")
+        r = IO.linear_alignment(self._frames(), self.tic, c["g_norm"], bool(c["use_wheel"]), self.rio, self.tio)
+        if r is None:
+            return False
+        self.g, x = r
+        self.init_debug.update(g_c0=self.g.copy(), x=x.copy())
+        for i in range(fc + 1):
+            fr = self.all_image_frame[self.Headers[i]]
+            self.Ps[i], self.Rs[i] = fr.T.copy(), fr.R.copy()
+            fr.is_key_frame = True
+        s = float(x[-1])
+        for i in range(self.W + 1):
+            self.pre_integrations[i].repropagate(np.zeros(3), self.Bgs[i])
+        P0 = self.Ps[0].copy()
+        for i in range(fc, -1, -1):
+            self.Ps[i] = s * self.Ps[i] - self.Rs[i] @ self.tic - (s * P0 - self.Rs[0] @ self.tic)
+        kv = -1
+        for fr in self._frames():
+            if fr.is_key_frame:
+                kv += 1
+                self.Vs[kv] = fr.R @ x[3 * kv:3 * kv + 3]
+        R0 = g2R(self.g)
+        yaw = R2ypr(R0 @ self.Rs[0])[0]
+        R0 = ypr2R(np.array([-yaw, 0, 0])) @ R0
+        self.g = R0 @ self.g
+        for i in range(fc + 1):
+            self.Ps[i], self.Rs[i], self.Vs[i] = R0 @ self.Ps[i], R0 @ self.Rs[i], R0 @ self.Vs[i]
+        self.f_manager.clearDepth()
+        self.f_manager.triangulateWithDepth(self.Ps, self.Rs, self.tic, self.ric)
+        self.f_manager.triangulate(self.Ps, self.Rs, self.tic, self.ric)
+        return True
 
     # ---- processImage
     def processImage(self, image, header):  # EST:843-1163
@@ -1076,7 +1201,7 @@ class Estimator:
         self.marginalization_flag = MARGIN_OLD if self.f_manager.addFeatureCheckParallax(fc, image, self.td) else MARGIN_SECOND_NEW
         self.Headers[fc] = header
         if header not in self.all_image_frame:  # std::map::insert keeps an existing key
-            self.all_image_frame[header] = ImageFrame(self.tmp_pre_integration, self.tmp_wheel_pre_integration)
+            self.all_image_frame[header] = ImageFrame(self.tmp_pre_integration, self.tmp_wheel_pre_integration, image)
         self.tmp_pre_integration = ImuPre(self.acc_0, self.gyr_0, self.Bas[fc], self.Bgs[fc], self.imu_noise)
         self.tmp_wheel_pre_integration = WheelPre(self.vel_0_wheel, self.gyr_0_wheel, self.sx, self.sy, self.sw, self.td_wheel, self.wheel_noise)
         self.checkimu()
