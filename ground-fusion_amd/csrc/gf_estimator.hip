@@ -7,7 +7,7 @@
 //   Estimator::processMeasurements                 EST:526-709   Estimator::processMeasurements
 //   Estimator::processIMU / processWheel           EST:743-842   Estimator::processIMU / processWheel
 //   Estimator::processImage                        EST:843-1163  Estimator::processImage
-//   Estimator::initialStructure (stationary and wheel-activated shortcuts only, EST:1557-1682; the SfM path is SURVEY.md §8(f)1)
+//   Estimator::initialStructure (stationary and wheel-activated shortcuts EST:1557-1682; SfM branch EST:1684-1847 with visualInitialAlign, numerics in gf_init_sfm.hpp)
 //   Estimator::vector2double / double2vector       EST:2276-2353, :2440-2569
 //   Estimator::optimization                        EST:2890-3636 (problem construction -> one gf_ba_window)
 //   Estimator::slideWindow / slideWindowNew / Old  EST:3638-3837

@@ -8,7 +8,7 @@
 // RANSACPointSetRegistrator runs it (cv::RNG multiply-with-carry, 5-point subsets, iteration count from the inlier ratio), EPnP (Lepetit, Moreno-Noguer,
 // Fua 2009) as its kernel, the DLT start and the Levenberg-Marquardt refinement of cvFindExtrinsicCameraParams2 with CvLevMarq's lambda schedule, and
 // Ceres' trust-region loop with the Levenberg-Marquardt strategy and a Schur complement over the points.  Choices OpenCV leaves to rounding (basis inside a
-// null space, eigenvector signs) are made canonically; planar point sets (OpenCV: homography start) are refused.  DESIGN.md 7.
+// null space, eigenvector signs) are made canonically; for planar point sets the homography start is the normalised DLT without OpenCV's refinement of H.  DESIGN.md 7.
 #pragma once
 #include <algorithm>
 #include <array>
@@ -312,7 +312,63 @@ inline bool pnp_refine(const std::vector<P3>& X, const std::vector<P2>& m, doubl
     return std::isfinite(param[0] + param[1] + param[2] + param[3] + param[4] + param[5]);
 }
 
-// cvFindExtrinsicCameraParams2 without a guess, non-planar branch; false for a planar point set
+// cv::findHomography(src, dst, 0): the normalised DLT of HomographyEstimatorCallback::runKernel (fundam.cpp); its Levenberg-Marquardt passes over H are not
+// restated (H only starts the pose refinement that follows)
+inline bool homography_dlt(const std::vector<P2>& src, const std::vector<P2>& dst, double* H) {
+    const int n = (int)src.size();
+    double cM[2] = {0, 0}, cm[2] = {0, 0}, sM[2] = {0, 0}, sm[2] = {0, 0};
+    for (int i = 0; i < n; i++) for (int k = 0; k < 2; k++) { cM[k] += src[i][k]; cm[k] += dst[i][k]; }
+    for (int k = 0; k < 2; k++) { cM[k] /= n; cm[k] /= n; }
+    for (int i = 0; i < n; i++) for (int k = 0; k < 2; k++) { sM[k] += fabs(src[i][k] - cM[k]); sm[k] += fabs(dst[i][k] - cm[k]); }
+    if (std::min(std::min(sM[0], sM[1]), std::min(sm[0], sm[1])) < DBL_EPSILON) return false;
+    for (int k = 0; k < 2; k++) { sM[k] = n / sM[k]; sm[k] = n / sm[k]; }
+    Mat A(2 * n, 9);
+    for (int i = 0; i < n; i++) {
+        const double x = (dst[i][0] - cm[0]) * sm[0], y = (dst[i][1] - cm[1]) * sm[1], Xn = (src[i][0] - cM[0]) * sM[0], Yn = (src[i][1] - cM[1]) * sM[1];
+        const double r0[9] = {Xn, Yn, 1, 0, 0, 0, -x * Xn, -x * Yn, -x}, r1[9] = {0, 0, 0, Xn, Yn, 1, -y * Xn, -y * Yn, -y};
+        for (int k = 0; k < 9; k++) { A(2 * i, k) = r0[k]; A(2 * i + 1, k) = r1[k]; }
+    }
+    std::vector<double> w; Mat V;
+    sym_eig(AtA(A), w, V);
+    double H0[9];
+    for (int k = 0; k < 9; k++) H0[k] = V(k, 0);
+    const double inv_norm[9] = {1.0 / sm[0], 0, cm[0], 0, 1.0 / sm[1], cm[1], 0, 0, 1}, norm2[9] = {sM[0], 0, -cM[0] * sM[0], 0, sM[1], -cM[1] * sM[1], 0, 0, 1};
+    m3mul(inv_norm, H0, H); m3mul(H, norm2, H);
+    const double h22 = H[8];
+    for (int k = 0; k < 9; k++) H[k] /= h22;
+    return true;
+}
+// cvFindExtrinsicCameraParams2 without a guess, planar branch; w, V: eigen-decomposition (ascending) of the scatter of X
+inline void pnp_planar(const std::vector<P3>& X, const std::vector<P2>& uv, const double* mean, const Mat& V, double* rvec, double* tvec) {
+    double Rt[9];
+    for (int j = 0; j < 3; j++) { Rt[j] = V(j, 2); Rt[3 + j] = V(j, 1); Rt[6 + j] = V(j, 0); }
+    if (Rt[2] * Rt[2] + Rt[5] * Rt[5] < 1e-10) for (int i = 0; i < 9; i++) Rt[i] = (i % 4 == 0);
+    if (m3det(Rt) < 0) for (int i = 0; i < 9; i++) Rt[i] = -Rt[i];
+    double tt[3];
+    m3v(Rt, mean, tt);
+    for (int k = 0; k < 3; k++) tt[k] = -tt[k];
+    std::vector<P2> Mxy(X.size());
+    for (size_t i = 0; i < X.size(); i++) { double p[3]; m3v(Rt, X[i].data(), p); Mxy[i] = {p[0] + tt[0], p[1] + tt[1]}; }
+    double H[9];
+    bool fin = homography_dlt(Mxy, uv, H);
+    for (int k = 0; k < 9 && fin; k++) fin = std::isfinite(H[k]);
+    for (int k = 0; k < 3; k++) rvec[k] = tvec[k] = 0;
+    if (!fin) return;
+    const double n1 = sqrt(H[0] * H[0] + H[3] * H[3] + H[6] * H[6]), n2 = sqrt(H[1] * H[1] + H[4] * H[4] + H[7] * H[7]);
+    const double h1[3] = {H[0] / std::max(n1, DBL_EPSILON), H[3] / std::max(n1, DBL_EPSILON), H[6] / std::max(n1, DBL_EPSILON)};
+    const double h2[3] = {H[1] / std::max(n2, DBL_EPSILON), H[4] / std::max(n2, DBL_EPSILON), H[7] / std::max(n2, DBL_EPSILON)};
+    const double f = 2.0 / std::max(n1 + n2, DBL_EPSILON), t[3] = {H[2] * f, H[5] * f, H[8] * f};
+    double h3[3];
+    cross3(h1, h2, h3);
+    const double Mh[9] = {h1[0], h2[0], h3[0], h1[1], h2[1], h3[1], h1[2], h2[2], h3[2]};
+    double Rh[9], R[9], Rtt[3];
+    if (!polar_rotation(Mh, Rh)) return;
+    m3mul(Rh, Rt, R);
+    rodrigues_inv(R, rvec);
+    m3v(Rh, tt, Rtt);
+    for (int k = 0; k < 3; k++) tvec[k] = Rtt[k] + t[k];
+}
+// cvFindExtrinsicCameraParams2 without a guess: DLT for a non-planar point set, homography for a planar one
 inline bool pnp_dlt(const std::vector<P3>& X, const std::vector<P2>& uv, double* rvec, double* tvec) {
     const int n = (int)X.size();
     double mean[3] = {0, 0, 0};
@@ -322,7 +378,7 @@ inline bool pnp_dlt(const std::vector<P3>& X, const std::vector<P2>& uv, double*
     for (auto& p : X) for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) MM(i, j) += (p[i] - mean[i]) * (p[j] - mean[j]);
     std::vector<double> w; Mat V;
     sym_eig(MM, w, V);
-    if (w[0] / w[1] < 1e-3) return false;
+    if (w[0] / w[1] < 1e-3) { pnp_planar(X, uv, mean, V, rvec, tvec); return true; }
     Mat L(2 * n, 12);
     for (int i = 0; i < n; i++) {
         const double x = -uv[i][0], y = -uv[i][1];

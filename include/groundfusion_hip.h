@@ -254,10 +254,11 @@ int gf_wheel_preintegrate(int n, const double* dt, const double* vel, const doub
  * sequence.  Replaces, in vins_estimator/src/estimator/estimator.h: inputIMU :104, inputWheel :106, inputFeature :108,
  * inputImage :105, processImage :110 (via processMeasurements :113), and the FeatureManager it owns (feature_manager.h:139-215).
  * The dense work (Estimator::optimization, estimator.cpp:2890-3636) runs on the HIP back end behind gf_ba_*.
- * Built: RGB-D + IMU (+ wheel) (+ GNSS) configuration, stationary / wheel-activated initialisation (estimator.cpp:1557-1682),
+ * Built: RGB-D + IMU (+ wheel) (+ GNSS) configuration, stationary / wheel-activated initialisation (estimator.cpp:1557-1682) and the SfM branch behind
+ * them for recordings that begin in motion (estimator.cpp:1684-1926; relativePoseWithDepth, GlobalSFM::constructWithDepth, visualInitialAlign),
  * MULTIPLE_THREAD 0/1 data flow (processed synchronously); GNSS: measurement gating, clock / anchor / yaw states, factors in the solve and the
  * marginalisation, GNSSVIAlign with its initialiser, broadcast ephemerides -> satellite states (gf_estimator_input_ephem + gf_estimator_input_gnss_raw;
- * or states handed in, gf_gnss_obs).  Not built: SfM initialisation, line / plane / motion factors.
+ * or states handed in, gf_gnss_obs).  Not built: monocular (DEPTH 0) initialisation, line / plane / motion factors.
  * ------------------------------------------------------------------------------------------------------------------------------ */
 typedef struct gf_estimator gf_estimator;
 

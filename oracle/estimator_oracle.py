@@ -1060,7 +1060,7 @@ class Estimator:
         for fj in fr[1:]:
             fj.pre_integration.repropagate(np.zeros(3), self.Bgs[0])
 
-    def initialStructure(self):  # EST:1557-1682 (SfM branch not restated: returns False)
+    def initialStructure(self):  # EST:1557-1682; the SfM branch in _initialStructureSfM
         aver_g, var = self._gvar()
         if not (var < 0.35):
             self.is_imu_excited = True

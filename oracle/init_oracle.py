@@ -12,8 +12,8 @@ PARITY UNPINNED.  Three pieces of this path live in third-party code that the re
   * ceres::Solve with DENSE_SCHUR and the default LEVENBERG_MARQUARDT strategy (Ceres 1.14 trust_region_minimizer.cc,
     levenberg_marquardt_strategy.cc) for the structure-from-motion bundle adjustment; the wall-clock cap (0.2 s) is not restated.
 Where the outcome of the third-party code is decided by rounding (the basis OpenCV's SVD returns inside the null space of EPnP's 12 x 12 system
-with 5 points, the sign of eigenvectors), a canonical choice is made here and in the product so that the two can be compared; planar point sets
-(OpenCV switches to a homography start) are refused.  The reference's own arithmetic -- including that the `scale' read from the last entry of
+with 5 points, the sign of eigenvectors), a canonical choice is made here and in the product so that the two can be compared; for planar point sets
+the homography start is the normalised DLT without OpenCV's refinement of H (it only starts the pose refinement).  The reference's own arithmetic -- including that the `scale' read from the last entry of
 the alignment vector is a gravity-refinement component in the depth variants (initial_aligment.cpp:427-497, estimator.cpp:1871) -- is followed
 literally."""
 import math
@@ -184,13 +184,56 @@ def pnp_refine(X, uv, rvec, tvec, max_iter=20, eps=1.1920928955078125e-07):
         prev_err = en
 
 
-def pnp_dlt(X, uv):
-    """cvFindExtrinsicCameraParams2 without a guess, non-planar branch (calibration.cpp: 2N x 12 system, smallest right singular vector, rotation
-    made orthogonal, translation rescaled).  Planar point sets (third singular value of the scatter below 1e-3 of the second) -> None."""
-    Xc = X - X.mean(axis=0)
-    w = np.linalg.eigvalsh(Xc.T @ Xc)          # ascending
-    if w[0] / w[1] < 1e-3:
+def homography_dlt(src, dst):
+    """cv::findHomography(src, dst, 0): the normalised DLT of HomographyEstimatorCallback::runKernel (fundam.cpp: centroids, mean absolute deviation
+    scaling, smallest eigenvector of the 9 x 9 normal matrix, H[2][2] = 1).  Its 10 Levenberg-Marquardt passes over H are not restated: H only
+    starts the pose refinement that follows."""
+    n = len(src)
+    cM, cm = src.mean(axis=0), dst.mean(axis=0)
+    sM, sm = np.abs(src - cM).sum(axis=0), np.abs(dst - cm).sum(axis=0)
+    if min(sM.min(), sm.min()) < 2.220446049250313e-16:
         return None
+    sM, sm = n / sM, n / sm
+    A = np.zeros((2 * n, 9))
+    x, y = (dst[:, 0] - cm[0]) * sm[0], (dst[:, 1] - cm[1]) * sm[1]
+    Xn, Yn = (src[:, 0] - cM[0]) * sM[0], (src[:, 1] - cM[1]) * sM[1]
+    A[0::2] = np.stack([Xn, Yn, np.ones(n), np.zeros(n), np.zeros(n), np.zeros(n), -x * Xn, -x * Yn, -x], axis=1)
+    A[1::2] = np.stack([np.zeros(n), np.zeros(n), np.zeros(n), Xn, Yn, np.ones(n), -y * Xn, -y * Yn, -y], axis=1)
+    _, V = sym_eig(A.T @ A)
+    H0 = V[:, 0].reshape(3, 3)
+    inv_norm = np.array([[1.0 / sm[0], 0, cm[0]], [0, 1.0 / sm[1], cm[1]], [0, 0, 1]])
+    norm2 = np.array([[sM[0], 0, -cM[0] * sM[0]], [0, sM[1], -cM[1] * sM[1]], [0, 0, 1]])
+    H = inv_norm @ H0 @ norm2
+    return H / H[2, 2]
+
+
+def pnp_planar(X, uv, w, V):
+    """cvFindExtrinsicCameraParams2 without a guess, planar branch (calibration.cpp): the points in the coordinates of their plane, a homography to the
+    image, its first two columns made a rotation.  w, V: eigen-decomposition (ascending) of the scatter of X."""
+    Rt = np.stack([V[:, 2], V[:, 1], V[:, 0]], axis=0)      # rows: principal axes, largest spread first (V^T of cvSVD)
+    if Rt[0, 2] ** 2 + Rt[1, 2] ** 2 < 1e-10:
+        Rt = np.eye(3)
+    if np.linalg.det(Rt) < 0:
+        Rt = -Rt
+    tt = -Rt @ X.mean(axis=0)
+    Mxy = (X @ Rt.T + tt)[:, :2]
+    H = homography_dlt(Mxy, uv)
+    if H is None or not np.all(np.isfinite(H)):
+        return np.zeros(3), np.zeros(3)
+    n1, n2 = math.sqrt(float(H[:, 0] @ H[:, 0])), math.sqrt(float(H[:, 1] @ H[:, 1]))
+    h1, h2 = H[:, 0] / max(n1, 2.220446049250313e-16), H[:, 1] / max(n2, 2.220446049250313e-16)
+    t = H[:, 2] * (2.0 / max(n1 + n2, 2.220446049250313e-16))
+    Rh = polar_rotation(np.stack([h1, h2, np.cross(h1, h2)], axis=1))     # cvRodrigues2 there and back: the nearest rotation
+    return rodrigues_inv(Rh @ Rt), Rh @ tt + t
+
+
+def pnp_dlt(X, uv):
+    """cvFindExtrinsicCameraParams2 without a guess (calibration.cpp).  Non-planar: 2N x 12 system, smallest right singular vector, rotation
+    made orthogonal, translation rescaled.  Planar (third singular value of the scatter below 1e-3 of the second): pnp_planar."""
+    Xc = X - X.mean(axis=0)
+    w, Vs = sym_eig(Xc.T @ Xc)                 # ascending
+    if w[0] / w[1] < 1e-3:
+        return pnp_planar(X, uv, w, Vs)
     n = len(X)
     L = np.zeros((2 * n, 12))
     L[0::2, 0:3], L[0::2, 3] = X, 1.0

@@ -82,6 +82,42 @@ def test_replay_feature_frames_matches_oracle():
     assert worst["p"] < 1e-6 and worst["r"] < 1e-6, worst
 
 
+@pytest.mark.parametrize("use_wheel", [1, 0])
+def test_replay_from_a_moving_start_initialises_through_sfm(use_wheel):
+    """the recording begins in motion at constant speed, so neither the stationary nor the wheel-activated shortcut of initialStructure fires
+    (estimator.cpp:1604-1682) and the window is initialised by the SfM branch (:1684-1847: solveRelativeRT_PNP, GlobalSFM::constructWithDepth, solvePnP per
+    frame, visualInitialAlign; tests/test_init_sfm_host.py covers the pieces).  From there the replay is the usual closed loop: decisions identical, poses
+    within 1e-6 of the oracle pipeline at every frame -- and, since the reference's alignment leaves the positions collapsed (`s' of estimator.cpp:1871) and,
+    with the wheel, the velocities near zero, the optimisation has to pull the window back to the driven track, which it does."""
+    st = SS.Stream(5, t_still=0.0, t_move=4.0, v_max=0.5, v_start=0.5, yaw_turn=0.4)
+    st._lm = st._landmarks(1600)
+    st._pn = np.random.default_rng(4005).normal(0, 1.0, (len(st.cam_t), len(st._lm), 2))
+    kw = dict(tio=SS.TIO, rio=SS.RIO, multiple_thread=1, use_wheel=use_wheel, wdetect=use_wheel)
+    est_p = gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(**kw))
+    est_o = EO.Estimator(dict(kw))
+    tp, worst, chord = -1.0, dict(p=0.0, r=0.0, v=0.0), []
+    for k in range(len(st.cam_t)):
+        for e in (est_o, est_p):
+            t1 = st.feed(e, k, tp)
+        tp = t1
+        if k % 3:
+            continue
+        frame = st.feature_frame(k)
+        est_p.inputFeature(float(st.cam_t[k]), frame)
+        est_o.inputFeature(float(st.cam_t[k]), frame)
+        compare_frame(est_o, est_p, worst, "frame %d" % k)
+        if est_o.solver_flag == EO.NON_LINEAR:
+            W = est_o.W
+            chord.append(abs(np.linalg.norm(est_o.Ps[W - 1] - est_o.Ps[0]) - np.linalg.norm(st.p_wb(est_o.Headers[W - 1]) - st.p_wb(est_o.Headers[0]))))
+    info = est_p.debug("init_info")
+    assert est_o.solver_flag == EO.NON_LINEAR and not est_o.is_imu_excited and est_o.init_debug["n_tracked"] == int(info[1]) > 60 and int(info[6]) == 0
+    assert est_o.n_optimizations > 25
+    print("moving-start replay (use_wheel %d) worst deviation" % use_wheel, worst, "window chord error first / last %.3f / %.3f m" % (chord[0], chord[-1]))
+    assert worst["p"] < 1e-6 and worst["r"] < 1e-6, worst
+    assert chord[-1] < 0.05 and chord[-1] < chord[0]          # 0.5 m of chord: the window has found the driven track again
+    est_p.close()
+
+
 @pytest.mark.parametrize("variant", ["use_mcc", "estimate_td", "wheel_slip"])
 def test_replay_configurations_of_the_other_shipped_yaml_files(variant):
     """what the m2dgrp.yaml replays leave untouched: use_mcc: 1 (groundchallenge.yaml:10, idc_rs.yaml:13 -- the consistency check's outliers now reach
