@@ -285,6 +285,12 @@ struct ImuPre {  // integration_base.h:22-62: linearized_acc/gyr, linearized_ba/
     ImuPre(V3 a0, V3 g0, V3 ba, V3 bg) : acc0(a0), gyr0(g0), lin_ba(ba), lin_bg(bg), jacobian(225), covariance(225) {}
     void push_back(double t, V3 a, V3 g) { dt.push_back(t); acc.insert(acc.end(), {a.x, a.y, a.z}); gyr.insert(gyr.end(), {g.x, g.y, g.z}); dirty = true; }
     void repropagate(V3 ba, V3 bg) { lin_ba = ba; lin_bg = bg; dirty = true; restart = true; }  // integration_base.h:51-62
+    void adopt() {   // st was filled by the batched device kernel (bit-identical to the host loop over all samples)
+        memcpy(delta_p, st.dp, 24); memcpy(delta_q, st.dq, 32); memcpy(delta_v, st.dv, 24);
+        memcpy(jacobian.data(), st.J, 225 * 8); memcpy(covariance.data(), st.P, 225 * 8);
+        sum_dt = st.sum_dt;
+        dirty = false; restart = false;
+    }
     int eval(const double* noise) {
         if (!dirty) return GF_OK;
         const double a0[3] = {acc0.x, acc0.y, acc0.z}, g0[3] = {gyr0.x, gyr0.y, gyr0.z}, ba[3] = {lin_ba.x, lin_ba.y, lin_ba.z}, bg[3] = {lin_bg.x, lin_bg.y, lin_bg.z};
@@ -428,8 +434,11 @@ struct Gate {
 };
 
 struct BatchSolver {
-    struct Req { int kind; gf_ba_window* w; int iters, mode; gf_ba_summary* sum; gf_ba_prior* prior; int rc; std::atomic<bool> done; std::string err; };
+    struct Req { int kind; gf_ba_window* w; int iters, mode; gf_ba_summary* sum; gf_ba_prior* prior; int rc; std::atomic<bool> done; std::string err;
+                 std::vector<ImuPre*> pres; const double* noise; };   // kind 0 solve, 1 marginalise, 2 IMU pre-integrations of this frame
     gf_ba* ba = nullptr;
+    gf::PreintBatch* pre = nullptr;   // GF_GROUP_DEVICE_PREINT=1: the members' pending pre-integrations run as one launch per camera frame
+    double t_pre = 0; long long pre_batches = 0, pre_intervals = 0;
     std::mutex m;
     Gate finished;                  // bumped after every batch
     int active = 0;                 // members currently inside a frame of a group step
@@ -458,6 +467,25 @@ struct BatchSolver {
         if (pending.empty() || (int)pending.size() < active) return;
         std::vector<Req*> reqs;
         reqs.swap(pending);
+        {   // pre-integrations first: nothing else of the same step can be pending next to them
+            std::vector<Req*> grp;
+            for (Req* r : reqs) if (r->kind == 2) grp.push_back(r);
+            if (!grp.empty()) {
+                const auto tc0 = std::chrono::steady_clock::now();
+                std::vector<gf::PreintJob> jobs;
+                for (Req* r : grp)
+                    for (ImuPre* p : r->pres) {
+                        gf::PreintJob j{&p->st, &p->lin_ba.x, &p->lin_bg.x, p->dt.data(), p->acc.data(), p->gyr.data(), (int)p->dt.size(), {p->acc0.x, p->acc0.y, p->acc0.z}, {p->gyr0.x, p->gyr0.y, p->gyr0.z}};
+                        jobs.push_back(j);
+                    }
+                const int rc = gf::preint_batch_run(pre, jobs, grp[0]->noise);
+                if (rc == GF_OK) for (Req* r : grp) for (ImuPre* p : r->pres) p->adopt();
+                const std::string err = rc == GF_OK ? std::string() : std::string(gf_last_error());
+                for (Req* r : grp) { r->rc = rc; r->err = err; r->done.store(true, std::memory_order_release); }
+                t_pre += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
+                pre_batches++; pre_intervals += (long long)jobs.size();
+            }
+        }
         for (int pass = 0; pass < 3; pass++) {   // solves, MARGIN_OLD, MARGIN_SECOND_NEW
             std::vector<Req*> grp;
             for (Req* r : reqs) if ((pass == 0 && r->kind == 0) || (pass > 0 && r->kind == 1 && r->mode == pass - 1)) grp.push_back(r);
@@ -1087,6 +1115,7 @@ struct gf_estimator {
         return true;
     }
     bool debug_skip_solve = false;
+    int head_rc = GF_OK;   // batched pre-integration of this frame (estimator groups)
     int init_rc = GF_OK, init_l = -1, init_points = 0; double init_s = 0; V3 init_g = v3(0, 0, 0);   // what the SfM branch did (debug / tests)
     bool initialStructureSfM(V3 aver_g) {  // EST:1684-1847
         if (!cfg.depth) { init_rc = gf::set_err(GF_ERR_INVALID, "initialStructure: the monocular SfM path (construct / relativePose) is outside the RGB-D scope"); return false; }
@@ -1194,6 +1223,15 @@ struct gf_estimator {
         all_image_frame.insert(std::make_pair(header, imageframe));
         tmp_pre_integration = std::make_shared<ImuPre>(acc_0, gyr_0, Bas[frame_count], Bgs[frame_count]);
         tmp_wheel_pre_integration = std::make_shared<WheelPre>(vel_0_wheel, gyr_0_wheel, sx, sy, sw, td_wheel);
+        if (group && group->pre) {   // this frame's IMU intervals (the frame's own and the window's) join the group's batched launch; a failure leaves them to the host loop
+            BatchSolver::Req r{};
+            r.kind = 2; r.noise = imu_noise; r.rc = GF_OK;
+            std::set<ImuPre*> uniq;
+            auto want = [&](const std::shared_ptr<ImuPre>& p) { if (p && p->dirty && uniq.insert(p.get()).second) r.pres.push_back(p.get()); };
+            want(all_image_frame[header].pre_integration);
+            for (int i = 0; i <= frame_count; i++) want(pre_integrations[i]);
+            head_rc = group->submit(r);
+        }
         checkimu();
         imustationary = varstationary && preintegrationstationary;
         if (checkvisual()) visualstationary = true;
@@ -1202,6 +1240,7 @@ struct gf_estimator {
     }
     int processImage(const std::vector<gf_feature_obs>& image, double header) {  // EST:843-1163
         processImageHead(image, header);
+        if (head_rc != GF_OK) return head_rc;
         if (solver_flag == INITIAL) {
             if (frame_count == WINDOW_SIZE) {  // DEPTH && USE_IMU branch, EST:967-1037
                 int i = 0;
@@ -1905,6 +1944,7 @@ struct gf_estimator_group {
         for (auto& th : thr) if (th.joinable()) th.join();
         for (gf_estimator* e : mem) delete e;
         if (solver.ba) gf_ba_destroy(solver.ba);
+        if (solver.pre) gf::preint_batch_destroy(solver.pre);
     }
 };
 
@@ -1921,6 +1961,7 @@ int gf_estimator_group_create(const gf_estimator_cfg* c, int n, gf_estimator_gro
     gf_ba_cfg bc{c->window_size, c->max_features, c->max_visual, n, c->gnss_enable ? c->max_gnss_per_frame * (c->window_size + 1) : 0};
     if (int rc = gf_ba_create(&bc, &g->solver.ba)) { delete g; return rc; }
     (void)hipGetDevice(&g->device);
+    if (const char* e = getenv("GF_GROUP_DEVICE_PREINT")) if (atoi(e) != 0) if (int rc = gf::preint_batch_create(&g->solver.pre)) { delete g; return rc; }
     g->has.assign(n, 0); g->t.assign(n, 0.0); g->frames.resize(n); g->rcs.assign(n, GF_OK); g->errs.resize(n);
     for (int i = 0; i < n; i++) g->thr.emplace_back([g, i] { g->worker(i); });
     *out = g;
@@ -1933,10 +1974,19 @@ int gf_estimator_group_destroy(gf_estimator_group* g) {
         fprintf(stderr, "gf_estimator_group members, CPU time summed over %zu threads [ms]: before optimization %.1f, window build %.1f, waiting for the solve %.1f, double2vector .. marginalisation request %.1f, "
                         "waiting for the marginalisation %.1f, rest of the frame %.1f\n", g->mem.size(), 1e3 * ts[0], 1e3 * ts[1], 1e3 * ts[2], 1e3 * ts[3], 1e3 * ts[4], 1e3 * ts[5]);
     }
+    if (g && getenv("GF_GROUP_TIMING") && g->solver.pre)
+        fprintf(stderr, "gf_estimator_group: %lld batched pre-integration launches, %lld intervals, %.1f ms inside them\n", g->solver.pre_batches, g->solver.pre_intervals, 1e3 * g->solver.t_pre);
     if (g && getenv("GF_GROUP_TIMING"))
         fprintf(stderr, "gf_estimator_group: %lld batches, %lld windows; %.1f ms inside batched solves, %.1f ms inside batched marginalisations, %.1f ms inside input_features\n",
                 g->solver.batches, g->solver.windows, 1e3 * g->solver.t_solve, 1e3 * g->solver.t_marg, 1e3 * g->t_input);
     delete g;
+    return GF_OK;
+}
+int gf_estimator_group_set_device_preint(gf_estimator_group* g, int on) {
+    if (!g) return gf::set_err(GF_ERR_INVALID, "null handle");
+    std::unique_lock<std::mutex> lk(g->solver.m);
+    if (on && !g->solver.pre) return gf::preint_batch_create(&g->solver.pre);
+    if (!on && g->solver.pre) { gf::preint_batch_destroy(g->solver.pre); g->solver.pre = nullptr; }
     return GF_OK;
 }
 int gf_estimator_group_member(gf_estimator_group* g, int i, gf_estimator** out) {

@@ -1,8 +1,10 @@
-// gf_preint.hip — host-side pre-integration (SURVEY.md row B2 stays on the host: ~40 kFLOP per IMU sample).
+// gf_preint.hip — pre-integration: the host loops (~40 kFLOP per IMU sample) and the batched device kernel for the IMU intervals (8(f)4).
 // IntegrationBase::push_back/propagate/midPointIntegration (factor/integration_base.h:39-167) and
 // WheelIntegrationBase (factor/wheel_integration_base.h:41-178), restated on the small matrix type below.
+#include <algorithm>
 #include <cstring>
 #include <vector>
+#include <hip/hip_runtime.h>
 #include "../../include/groundfusion_hip.h"
 #include "gf_dmath.hpp"
 #include "gf_preint.hpp"
@@ -135,6 +137,234 @@ void imu_preint_range(ImuPreState& st, const double* ba, const double* bg, const
     st.sum_dt = sdt; st.n_done = s1;
 }
 }  // namespace gf
+
+// ---------------------------------------------------------------- many intervals at once on the device (SURVEY.md 8(f)4, row B2 on the GPU)
+// One wavefront per interval; the lanes own the entries of the 15 x 15 results and evaluate each as the host code does -- the same products in the same
+// order, no contraction, structural zeros skipped the way mul() skips them -- so that a device interval is bit-identical to gf::imu_preint_range of the same
+// samples (tests/test_preint_gpu.py).  The 3-vector / quaternion part of a sample and the 3 x 3 blocks of F and V are evaluated by every lane (uniform).
+namespace gf {
+struct PreintJobDev { int s0, s1; double acc0[3], gyr0[3], ba[3], bg[3]; };
+constexpr int PREINT_OUT = 16 + 225 + 225;   // dp 3, dq 4, dv 3, sum_dt, pad 5 | jacobian | covariance
+
+__global__ __launch_bounds__(64) void imu_preint_batch_kernel(int n, const PreintJobDev* __restrict__ jobs, const double* __restrict__ dt, const double* __restrict__ acc,
+                                                              const double* __restrict__ gyr, double n0, double n1, double n2, double n3, double* __restrict__ out) {
+    __shared__ double sJ[225], sP[225], sF[225], sV[270], sT[225], sVN[270];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= n) return;
+    const PreintJobDev jb = jobs[b];
+    for (int e = lane; e < 225; e += 64) { sJ[e] = (e % 16 == 0) ? 1.0 : 0.0; sP[e] = 0.0; }
+    V3 acc_0 = v3(jb.acc0[0], jb.acc0[1], jb.acc0[2]), gyr_0 = v3(jb.gyr0[0], jb.gyr0[1], jb.gyr0[2]);
+    const V3 lba = v3(jb.ba[0], jb.ba[1], jb.ba[2]), lbg = v3(jb.bg[0], jb.bg[1], jb.bg[2]);
+    V3 dp = v3(0, 0, 0), dv = v3(0, 0, 0);
+    Q4 dq{1, 0, 0, 0};
+    double sdt = 0;
+    const double Nd[6] = {n0 * n0, n1 * n1, n0 * n0, n1 * n1, n2 * n2, n3 * n3};   // diagonal of the 18 x 18 noise matrix, 3 entries each
+    __syncthreads();
+    for (int s = jb.s0; s < jb.s1; s++) {
+        const double t = dt[s];
+        const V3 acc_1 = v3(acc[3 * s], acc[3 * s + 1], acc[3 * s + 2]), gyr_1 = v3(gyr[3 * s], gyr[3 * s + 1], gyr[3 * s + 2]);
+        const V3 un_acc_0 = qrot(dq, acc_0 - lba);
+        const V3 un_gyr = (gyr_0 + gyr_1) * 0.5 - lbg;
+        const Q4 rq = qmul(dq, Q4{1, un_gyr.x * t / 2, un_gyr.y * t / 2, un_gyr.z * t / 2});
+        const V3 un_acc_1 = qrot(rq, acc_1 - lba);
+        const V3 un_acc = (un_acc_0 + un_acc_1) * 0.5;
+        const V3 rp = dp + dv * t + un_acc * (0.5 * t * t), rv = dv + un_acc * t;
+        for (int e = lane; e < 225; e += 64) sF[e] = 0.0;
+        for (int e = lane; e < 270; e += 64) sV[e] = 0.0;
+        __syncthreads();
+        {   // the 3 x 3 blocks of F and V: evaluated by every lane (uniform, the host's expressions), entry p of each block written by lane p
+            const M3 Rwx = skew(un_gyr), Ra0 = skew(acc_0 - lba), Ra1 = skew(acc_1 - lba), Rd = qmat(dq), Rr = qmat(rq), I = m3_identity();
+            const M3 A = Rd * Ra0, B = Rr * Ra1, Cm = B * (I - Rwx * t), nB = (-Rr) * Ra1, RdRr = Rd + Rr;
+            const M3 f03 = A * (-0.25 * t * t) + Cm * (-0.25 * t * t), f06 = I * t, f09 = RdRr * (-0.25 * t * t), f012 = B * (-0.25 * t * t * -t), f33 = I - Rwx * t,
+                     f312 = I * (-1.0 * t), f63 = A * (-0.5 * t) + Cm * (-0.5 * t), f69 = RdRr * (-0.5 * t), f612 = B * (-0.5 * t * -t);
+            const M3 v00 = Rd * (0.25 * t * t), v03 = nB * (0.25 * t * t * 0.5 * t), v06 = Rr * (0.25 * t * t), v33 = I * (0.5 * t), v60 = Rd * (0.5 * t),
+                     v63 = nB * (0.5 * t * 0.5 * t), v66 = Rr * (0.5 * t), v912 = I * t;
+            if (lane < 9) {
+                const int i = lane / 3, j = lane % 3;
+                auto pick = [&](const M3& m) { double r = m.m[0]; for (int q = 1; q < 9; q++) r = lane == q ? m.m[q] : r; return r; };
+                auto putF = [&](int r0, int c0, const M3& m) { sF[(r0 + i) * 15 + c0 + j] = pick(m); };
+                auto putV = [&](int r0, int c0, const M3& m) { sV[(r0 + i) * 18 + c0 + j] = pick(m); };
+                putF(0, 0, I); putF(0, 3, f03); putF(0, 6, f06); putF(0, 9, f09); putF(0, 12, f012);
+                putF(3, 3, f33); putF(3, 12, f312);
+                putF(6, 3, f63); putF(6, 6, I); putF(6, 9, f69); putF(6, 12, f612);
+                putF(9, 9, I); putF(12, 12, I);
+                putV(0, 0, v00); putV(0, 3, v03); putV(0, 6, v06); putV(0, 9, v03);
+                putV(3, 3, v33); putV(3, 9, v33);
+                putV(6, 0, v60); putV(6, 3, v63); putV(6, 6, v66); putV(6, 9, v63);
+                putV(9, 12, v912); putV(12, 15, v912);
+            }
+        }
+        __syncthreads();
+        // J' = F J and T = F P (entries owned by lanes; sums in k order, zero factors of the left matrix skipped as mul() does)
+        double jn[4], pn[4];
+        for (int q = 0; q < 4; q++) {
+            const int e = lane + 64 * q;
+            if (e < 225) {
+                const int i = e / 15, j = e % 15;
+                double a = 0.0, c = 0.0;
+#pragma unroll
+                for (int k = 0; k < 15; k++) { const double v = sF[i * 15 + k], a1 = a + v * sJ[k * 15 + j], c1 = c + v * sP[k * 15 + j]; a = v != 0.0 ? a1 : a; c = v != 0.0 ? c1 : c; }
+                jn[q] = a; sT[e] = c;
+            }
+        }
+        for (int e = lane; e < 270; e += 64) { const double v = sV[e]; sVN[e] = v != 0.0 ? v * Nd[(e % 18) / 3] : 0.0; }   // V N, N diagonal
+        __syncthreads();
+        for (int q = 0; q < 4; q++) {
+            const int e = lane + 64 * q;
+            if (e < 225) {
+                const int i = e / 15, j = e % 15;
+                double a = 0.0, c = 0.0;
+#pragma unroll
+                for (int k = 0; k < 15; k++) { const double v = sT[i * 15 + k], a1 = a + v * sF[j * 15 + k]; a = v != 0.0 ? a1 : a; }      // (F P) F^T
+#pragma unroll
+                for (int k = 0; k < 18; k++) { const double v = sVN[i * 18 + k], c1 = c + v * sV[j * 18 + k]; c = v != 0.0 ? c1 : c; }    // (V N) V^T
+                pn[q] = a + c;
+            }
+        }
+        __syncthreads();
+        for (int q = 0; q < 4; q++) { const int e = lane + 64 * q; if (e < 225) { sJ[e] = jn[q]; sP[e] = pn[q]; } }
+        dp = rp; dq = qnormalized(rq); dv = rv;
+        sdt += t; acc_0 = acc_1; gyr_0 = gyr_1;
+        __syncthreads();
+    }
+    double* o = out + (size_t)b * PREINT_OUT;
+    if (lane == 0) {
+        o[0] = dp.x; o[1] = dp.y; o[2] = dp.z; o[3] = dq.w; o[4] = dq.x; o[5] = dq.y; o[6] = dq.z; o[7] = dv.x; o[8] = dv.y; o[9] = dv.z; o[10] = sdt;
+        o[11] = acc_0.x; o[12] = acc_0.y; o[13] = acc_0.z;
+    }
+    for (int e = lane; e < 225; e += 64) { o[16 + e] = sJ[e]; o[16 + 225 + e] = sP[e]; }
+}
+
+struct PreintBatch {
+    hipStream_t stream = nullptr;
+    PreintJobDev* d_jobs = nullptr; double *d_dt = nullptr, *d_acc = nullptr, *d_gyr = nullptr, *d_out = nullptr;
+    PreintJobDev* h_jobs = nullptr; double *h_dt = nullptr, *h_acc = nullptr, *h_gyr = nullptr, *h_out = nullptr;   // pinned
+    int cap_jobs = 0, cap_samples = 0;
+    double t_kernel_ms = 0; long long launches = 0, intervals = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    ~PreintBatch() {
+        (void)hipFree(d_jobs); (void)hipFree(d_dt); (void)hipFree(d_acc); (void)hipFree(d_gyr); (void)hipFree(d_out);
+        (void)hipHostFree(h_jobs); (void)hipHostFree(h_dt); (void)hipHostFree(h_acc); (void)hipHostFree(h_gyr); (void)hipHostFree(h_out);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+#define GF_PRE_HIP(x) do { const hipError_t e_ = (x); if (e_ != hipSuccess) return gf::set_err(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? GF_ERR_NO_DEVICE : GF_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+int preint_batch_create(PreintBatch** out) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return gf::set_err(GF_ERR_NO_DEVICE, "no HIP device: batched pre-integration has no CPU fallback (use gf_imu_preintegrate on the host)");
+    PreintBatch* b = new PreintBatch();
+    if (hipStreamCreate(&b->stream) != hipSuccess || hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) { delete b; return gf::set_err(GF_ERR_HIP, "hipStreamCreate / hipEventCreate failed"); }
+    *out = b;
+    return GF_OK;
+}
+void preint_batch_destroy(PreintBatch* b) { delete b; }
+static int preint_reserve(PreintBatch* b, int jobs, int samples) {
+    if (jobs > b->cap_jobs) {
+        const int c = std::max(jobs, 2 * b->cap_jobs);
+        (void)hipFree(b->d_jobs); (void)hipFree(b->d_out); (void)hipHostFree(b->h_jobs); (void)hipHostFree(b->h_out);
+        b->d_jobs = nullptr; b->d_out = nullptr; b->h_jobs = nullptr; b->h_out = nullptr; b->cap_jobs = 0;
+        GF_PRE_HIP(hipMalloc(&b->d_jobs, sizeof(PreintJobDev) * c)); GF_PRE_HIP(hipMalloc(&b->d_out, sizeof(double) * PREINT_OUT * c));
+        GF_PRE_HIP(hipHostMalloc(&b->h_jobs, sizeof(PreintJobDev) * c)); GF_PRE_HIP(hipHostMalloc(&b->h_out, sizeof(double) * PREINT_OUT * c));
+        b->cap_jobs = c;
+    }
+    if (samples > b->cap_samples) {
+        const int c = std::max(samples, 2 * b->cap_samples);
+        (void)hipFree(b->d_dt); (void)hipFree(b->d_acc); (void)hipFree(b->d_gyr); (void)hipHostFree(b->h_dt); (void)hipHostFree(b->h_acc); (void)hipHostFree(b->h_gyr);
+        b->d_dt = b->d_acc = b->d_gyr = nullptr; b->h_dt = b->h_acc = b->h_gyr = nullptr; b->cap_samples = 0;
+        GF_PRE_HIP(hipMalloc(&b->d_dt, sizeof(double) * c)); GF_PRE_HIP(hipMalloc(&b->d_acc, sizeof(double) * 3 * c)); GF_PRE_HIP(hipMalloc(&b->d_gyr, sizeof(double) * 3 * c));
+        GF_PRE_HIP(hipHostMalloc(&b->h_dt, sizeof(double) * c)); GF_PRE_HIP(hipHostMalloc(&b->h_acc, sizeof(double) * 3 * c)); GF_PRE_HIP(hipHostMalloc(&b->h_gyr, sizeof(double) * 3 * c));
+        b->cap_samples = c;
+    }
+    return GF_OK;
+}
+// every job from scratch over its samples [0, n): fills st as imu_preint_reset + imu_preint_range(st, ..., 0, n) would
+int preint_batch_run(PreintBatch* b, const std::vector<PreintJob>& jobs, const double* noise) {
+    const int n = (int)jobs.size();
+    if (n == 0) return GF_OK;
+    int total = 0;
+    for (auto& j : jobs) total += j.n;
+    if (int rc = preint_reserve(b, n, std::max(total, 1))) return rc;
+    int off = 0;
+    for (int i = 0; i < n; i++) {
+        const PreintJob& j = jobs[i];
+        PreintJobDev& d = b->h_jobs[i];
+        d.s0 = off; d.s1 = off + j.n;
+        for (int k = 0; k < 3; k++) { d.acc0[k] = j.acc0[k]; d.gyr0[k] = j.gyr0[k]; d.ba[k] = j.ba[k]; d.bg[k] = j.bg[k]; }
+        if (j.n > 0) { memcpy(b->h_dt + off, j.dt, sizeof(double) * j.n); memcpy(b->h_acc + 3 * off, j.acc, sizeof(double) * 3 * j.n); memcpy(b->h_gyr + 3 * off, j.gyr, sizeof(double) * 3 * j.n); }
+        off += j.n;
+    }
+    GF_PRE_HIP(hipMemcpyAsync(b->d_jobs, b->h_jobs, sizeof(PreintJobDev) * n, hipMemcpyHostToDevice, b->stream));
+    if (total > 0) {
+        GF_PRE_HIP(hipMemcpyAsync(b->d_dt, b->h_dt, sizeof(double) * total, hipMemcpyHostToDevice, b->stream));
+        GF_PRE_HIP(hipMemcpyAsync(b->d_acc, b->h_acc, sizeof(double) * 3 * total, hipMemcpyHostToDevice, b->stream));
+        GF_PRE_HIP(hipMemcpyAsync(b->d_gyr, b->h_gyr, sizeof(double) * 3 * total, hipMemcpyHostToDevice, b->stream));
+    }
+    GF_PRE_HIP(hipEventRecord(b->ev0, b->stream));
+    hipLaunchKernelGGL(imu_preint_batch_kernel, dim3(n), dim3(64), 0, b->stream, n, b->d_jobs, b->d_dt, b->d_acc, b->d_gyr, noise[0], noise[1], noise[2], noise[3], b->d_out);
+    GF_PRE_HIP(hipGetLastError());
+    GF_PRE_HIP(hipEventRecord(b->ev1, b->stream));
+    GF_PRE_HIP(hipMemcpyAsync(b->h_out, b->d_out, sizeof(double) * PREINT_OUT * n, hipMemcpyDeviceToHost, b->stream));
+    GF_PRE_HIP(hipStreamSynchronize(b->stream));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess) b->t_kernel_ms += ms;
+    b->launches++; b->intervals += n;
+    for (int i = 0; i < n; i++) {
+        ImuPreState& st = *jobs[i].st;
+        const double* o = b->h_out + (size_t)i * PREINT_OUT;
+        memcpy(st.dp, o, 24); memcpy(st.dq, o + 3, 32); memcpy(st.dv, o + 7, 24);
+        st.sum_dt = o[10];
+        const int last = jobs[i].n - 1;
+        for (int k = 0; k < 3; k++) { st.acc_0[k] = last >= 0 ? jobs[i].acc[3 * last + k] : jobs[i].acc0[k]; st.gyr_0[k] = last >= 0 ? jobs[i].gyr[3 * last + k] : jobs[i].gyr0[k]; }
+        memcpy(st.J, o + 16, 225 * 8); memcpy(st.P, o + 16 + 225, 225 * 8);
+        st.n_done = jobs[i].n;
+    }
+    return GF_OK;
+}
+}  // namespace gf
+
+extern "C" {
+struct gf_preint { gf::PreintBatch* b; };
+int gf_preint_create(gf_preint** out) {
+    if (!out) return gf::set_err(GF_ERR_INVALID, "null argument");
+    gf::PreintBatch* b = nullptr;
+    if (int rc = gf::preint_batch_create(&b)) return rc;
+    *out = new gf_preint{b};
+    return GF_OK;
+}
+int gf_preint_destroy(gf_preint* h) { if (h) { gf::preint_batch_destroy(h->b); delete h; } return GF_OK; }
+int gf_imu_preintegrate_batch(gf_preint* h, int n, const int* first, const double* dt, const double* acc, const double* gyr, const double* acc0, const double* gyr0,
+                              const double* ba, const double* bg, const double* noise, double* delta_p, double* delta_q, double* delta_v, double* jacobian, double* covariance,
+                              double* sum_dt) {
+    if (!h || n < 0 || (n > 0 && (!first || !acc0 || !gyr0 || !ba || !bg || !noise || !delta_p || !delta_q || !delta_v || !jacobian || !covariance || !sum_dt)))
+        return gf::set_err(GF_ERR_INVALID, "bad argument");
+    std::vector<gf::ImuPreState> st(n);
+    std::vector<gf::PreintJob> jobs(n);
+    for (int i = 0; i < n; i++) {
+        if (first[i + 1] < first[i]) return gf::set_err(GF_ERR_INVALID, "interval %d: first[] must not decrease", i);
+        gf::PreintJob& j = jobs[i];
+        j.st = &st[i]; j.n = first[i + 1] - first[i];
+        j.dt = dt + first[i]; j.acc = acc + 3 * (size_t)first[i]; j.gyr = gyr + 3 * (size_t)first[i];
+        j.ba = ba + 3 * i; j.bg = bg + 3 * i;
+        for (int k = 0; k < 3; k++) { j.acc0[k] = acc0[3 * i + k]; j.gyr0[k] = gyr0[3 * i + k]; }
+    }
+    if (int rc = gf::preint_batch_run(h->b, jobs, noise)) return rc;
+    for (int i = 0; i < n; i++) {
+        memcpy(delta_p + 3 * i, st[i].dp, 24); memcpy(delta_q + 4 * i, st[i].dq, 32); memcpy(delta_v + 3 * i, st[i].dv, 24);
+        memcpy(jacobian + 225 * (size_t)i, st[i].J, 225 * 8); memcpy(covariance + 225 * (size_t)i, st[i].P, 225 * 8);
+        sum_dt[i] = st[i].sum_dt;
+    }
+    return GF_OK;
+}
+int gf_preint_stats(gf_preint* h, long long* launches, long long* intervals, double* kernel_ms) {
+    if (!h) return gf::set_err(GF_ERR_INVALID, "null handle");
+    if (launches) *launches = h->b->launches;
+    if (intervals) *intervals = h->b->intervals;
+    if (kernel_ms) *kernel_ms = h->b->t_kernel_ms;
+    return GF_OK;
+}
+}  // extern "C"
 
 extern "C" {
 int gf_imu_preintegrate(int n, const double* dt, const double* acc, const double* gyr, const double* acc0, const double* gyr0, const double* ba, const double* bg,

@@ -231,7 +231,8 @@ class BaStats(C.Structure):
 
 
 EXPORTS += ["gf_ba_create", "gf_ba_destroy", "gf_ba_solve", "gf_ba_marginalize", "gf_ba_upload", "gf_ba_solve_resident", "gf_ba_download", "gf_ba_get_stats",
-            "gf_ba_reset_stats", "gf_ba_linearize", "gf_ba_solve_resident_async", "gf_ba_wait", "gf_ba_debug_stamps", "gf_imu_preintegrate", "gf_wheel_preintegrate", "gf_ba_double2vector"]
+            "gf_ba_reset_stats", "gf_ba_linearize", "gf_ba_solve_resident_async", "gf_ba_wait", "gf_ba_debug_stamps", "gf_imu_preintegrate", "gf_wheel_preintegrate", "gf_ba_double2vector",
+            "gf_preint_create", "gf_preint_destroy", "gf_imu_preintegrate_batch", "gf_preint_stats"]
 
 
 class Estimator:
@@ -348,6 +349,43 @@ def imu_preintegrate(dt, acc, gyr, acc0, gyr0, ba, bg, noise):
                                    _p(out["delta_v"], C.c_double), _p(out["jacobian"], C.c_double), _p(out["covariance"], C.c_double), C.byref(sd)))
     out["sum_dt"] = sd.value
     return out
+
+
+class PreintBatch:
+    """gf_preint_*: IMU pre-integration of many intervals in one launch; no CPU fallback"""
+
+    def __init__(self):
+        self.h = C.c_void_p()
+        _chk(lib().gf_preint_create(C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().gf_preint_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, first, dt, acc, gyr, acc0, gyr0, ba, bg, noise):
+        f = lambda a: np.ascontiguousarray(a, np.float64)
+        first = np.ascontiguousarray(first, np.int32)
+        n = len(first) - 1
+        dt, acc, gyr, acc0, gyr0, ba, bg, noise = map(f, (dt, acc, gyr, acc0, gyr0, ba, bg, noise))
+        out = {"delta_p": np.zeros((n, 3)), "delta_q": np.zeros((n, 4)), "delta_v": np.zeros((n, 3)), "jacobian": np.zeros((n, 225)), "covariance": np.zeros((n, 225)),
+               "sum_dt": np.zeros(n)}
+        _chk(lib().gf_imu_preintegrate_batch(self.h, n, _p(first, C.c_int), _p(dt, C.c_double), _p(acc, C.c_double), _p(gyr, C.c_double), _p(acc0, C.c_double),
+                                             _p(gyr0, C.c_double), _p(ba, C.c_double), _p(bg, C.c_double), _p(noise, C.c_double), _p(out["delta_p"], C.c_double),
+                                             _p(out["delta_q"], C.c_double), _p(out["delta_v"], C.c_double), _p(out["jacobian"], C.c_double),
+                                             _p(out["covariance"], C.c_double), _p(out["sum_dt"], C.c_double)))
+        return out
+
+    def stats(self):
+        a, b, ms = C.c_longlong(0), C.c_longlong(0), C.c_double(0)
+        _chk(lib().gf_preint_stats(self.h, C.byref(a), C.byref(b), C.byref(ms)))
+        return dict(launches=a.value, intervals=b.value, kernel_ms=ms.value)
 
 
 def wheel_preintegrate(dt, vel, gyr, vel0, gyr0, lin, noise):
@@ -639,10 +677,12 @@ def write_pgm(path, img):
 class EstimatorGroup:
     """n Estimators sharing one batched back-end handle; members are SlidingWindowEstimator views (IMU / wheel input, state queries)."""
 
-    def __init__(self, cfg, n):
+    def __init__(self, cfg, n, device_preint=None):
         self.cfg, self.n = cfg, n
         self.g = C.c_void_p()
         _chk(lib().gf_estimator_group_create(C.byref(cfg), n, C.byref(self.g)))
+        if device_preint is not None:   # SURVEY.md 8(f)4: one pre-integration launch per step instead of the members' host loops
+            _chk(lib().gf_estimator_group_set_device_preint(self.g, int(bool(device_preint))))
         self.members = []
         for i in range(n):
             m = SlidingWindowEstimator.__new__(SlidingWindowEstimator)

@@ -245,6 +245,16 @@ int gf_ba_double2vector(int W, const double* R0_before, const double* P0_before,
 int gf_imu_preintegrate(int n, const double* dt, const double* acc, const double* gyr, const double* acc0, const double* gyr0, const double* ba,
                         const double* bg, const double* noise, double* delta_p, double* delta_q, double* delta_v, double* jacobian,
                         double* covariance, double* sum_dt);
+/* The same loop for many intervals at once ON THE DEVICE (row B2 batched): interval i owns the samples first[i] .. first[i+1]-1 of dt / acc / gyr
+ * and row i of acc0 / gyr0 / ba / bg (n x 3) and of the outputs (delta_p n x 3, delta_q n x 4 as w x y z, delta_v n x 3, jacobian / covariance n x 225, sum_dt n).
+ * One wavefront per interval; every result is bit-identical to gf_imu_preintegrate on the same samples.  No CPU fallback: GF_ERR_NO_DEVICE without a GPU. */
+typedef struct gf_preint gf_preint;
+int gf_preint_create(gf_preint** out);
+int gf_preint_destroy(gf_preint* h);
+int gf_imu_preintegrate_batch(gf_preint* h, int n, const int* first, const double* dt, const double* acc, const double* gyr, const double* acc0, const double* gyr0,
+                              const double* ba, const double* bg, const double* noise, double* delta_p, double* delta_q, double* delta_v, double* jacobian,
+                              double* covariance, double* sum_dt);
+int gf_preint_stats(gf_preint* h, long long* launches, long long* intervals, double* kernel_ms); /* kernel_ms: hipEvent time of the kernel alone, summed */
 /* WheelIntegrationBase::push_back loop (factor/wheel_integration_base.h:41-178); noise = VEL_N_wheel, GYR_N_wheel; lin = sx, sy, sw */
 int gf_wheel_preintegrate(int n, const double* dt, const double* vel, const double* gyr, const double* vel0, const double* gyr0, const double* lin,
                           const double* noise, double* delta_p, double* delta_q, double* jacobian, double* covariance, double* sum_dt);
@@ -375,6 +385,10 @@ int gf_estimator_debug(gf_estimator* h, const char* op, const double* in, int n_
 typedef struct gf_estimator_group gf_estimator_group;
 int gf_estimator_group_create(const gf_estimator_cfg* cfg, int n, gf_estimator_group** out);
 int gf_estimator_group_destroy(gf_estimator_group* g);
+/* the IMU intervals a camera frame completes (the frame's own IntegrationBase and the window's, estimator.cpp:760-768, :866-869) are integrated
+ * by one device launch per group step (gf_imu_preintegrate_batch's kernel) instead of on the members' host threads; results are bit-identical either way.
+ * Off by default (environment GF_GROUP_DEVICE_PREINT=1 turns it on at creation): it pays on hosts with few cores, DESIGN.md section 8. */
+int gf_estimator_group_set_device_preint(gf_estimator_group* g, int on);
 int gf_estimator_group_member(gf_estimator_group* g, int i, gf_estimator** out);   /* owned by the group */
 /* Estimator::inputFeature on each listed sequence, concurrently; obs = the frames back to back, n_obs[k] entries for seq[k] */
 int gf_estimator_group_input_features(gf_estimator_group* g, int count, const int* seq, const double* t, const gf_feature_obs* obs, const int* n_obs);

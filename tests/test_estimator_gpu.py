@@ -204,9 +204,12 @@ def test_replay_images_with_tracker_feedback():
     assert worst["p"] < 1e-6 and worst["r"] < 1e-6, worst
 
 
-def test_group_of_sequences_on_one_batched_solver():
+@pytest.mark.parametrize("device_preint", [False, True])
+def test_group_of_sequences_on_one_batched_solver(device_preint):
     """gf_estimator_group_*: four sequences keep the reference's per-sequence control flow on host threads while their solves and
-    marginalisations reach the device as one batch; every member must end up where a stand-alone Estimator on the same inputs does."""
+    marginalisations reach the device as one batch; every member must end up where a stand-alone Estimator on the same inputs does.
+    device_preint: the IMU intervals of a step are integrated by one device launch instead of on the members' threads -- bit-identical
+    intervals (tests/test_preint_gpu.py), so the members must land on exactly the same bits as without it."""
     n = 4
     streams = []
     for s in range(n):
@@ -215,7 +218,7 @@ def test_group_of_sequences_on_one_batched_solver():
         st._pn = np.random.default_rng(4100 + s).normal(0, 1.0, (len(st.cam_t), len(st._lm), 2))
         streams.append(st)
     cfg = gfamd.default_estimator_cfg(tio=SS.TIO, rio=SS.RIO, multiple_thread=1)
-    grp = gfamd.EstimatorGroup(cfg, n)
+    grp = gfamd.EstimatorGroup(cfg, n, device_preint=device_preint)
     solo = [gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(tio=SS.TIO, rio=SS.RIO, multiple_thread=1)) for _ in range(n)]
     tp = [-1.0] * n
     nk = min(len(st.cam_t) for st in streams)
@@ -238,7 +241,7 @@ def test_group_of_sequences_on_one_batched_solver():
     st = grp.stats()
     print("group of %d: worst deviation from stand-alone estimators %.2e; %s" % (n, worst, st))
     assert all(m.state()["solver_flag"] == 1 for m in grp.members)
-    assert worst < 1e-6
+    assert worst == 0.0                                                        # same kernels, same order of operations, same bits
     assert st["largest_batch"] == n and st["windows"] > 2 * st["batches"]      # the solves really went out together
     grp.close()
     for e in solo:
