@@ -21,10 +21,48 @@ def test_oracle_reproduces_golden(oracle):
     now = _gen().compute()
     assert sorted(now) == sorted(GOLD)
     for k, v in GOLD.items():
-        if k.startswith(("trk_", "lk_", "corners", "marg_ids")):
+        if k.startswith(("trk_", "lk_", "corners", "marg_ids", "init_ransac_inliers", "init_sfm_l_points")):
             assert np.array_equal(now[k], v), k                                   # integer / float front-end results: bit-exact
         else:
             np.testing.assert_allclose(now[k], v, rtol=1e-9, atol=1e-9, err_msg=k)  # FP64 back end: libm differences only
+
+
+def test_library_initialisation_meets_golden():
+    """initialisation while moving is host code in the library (csrc/gf_init_sfm.hpp): it meets the committed vectors without a GPU"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "ground-fusion_amd"))
+    import gfamd as gf
+    import synth_stream as SS
+    rng = np.random.default_rng(31)
+    X = np.stack([rng.uniform(-2, 2, 64), rng.uniform(-1.5, 1.5, 64), rng.uniform(2.5, 7.0, 64)], axis=1)
+    rvec, tvec = np.array([0.05, -0.08, 0.03]), np.array([0.06, -0.02, -0.45])
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+    import init_oracle as IO
+    import estimator_oracle as EO
+    uv = IO.project(rvec, tvec, X) + rng.normal(0, 0.2 / 460.0, (64, 2))
+    uv[::4] += 0.08
+    assert set(GOLD["init_ransac_inliers"]) == set(range(64)) - set(range(0, 64, 4))          # the gross mismatches are out, nothing else
+    kw = dict(tio=SS.TIO, rio=SS.RIO, multiple_thread=1)
+    ep = gf.SlidingWindowEstimator(gf.default_estimator_cfg(**kw))
+    d2 = np.full(64, 3.5)
+    out = ep.debug("solveRelativeRT_PNP", np.concatenate([X, uv * d2[:, None], d2[:, None]], axis=1).reshape(-1))
+    rota = EO.ypr2R_deg_free(GOLD["init_ransac_rvec"])
+    np.testing.assert_allclose(out[1:10].reshape(3, 3), rota.T, atol=1e-9)
+    np.testing.assert_allclose(out[10:13], -rota.T @ GOLD["init_ransac_tvec"], atol=1e-9)
+    st = SS.Stream(5, t_still=0.0, t_move=2.0, v_max=0.5, v_start=0.5, yaw_turn=0.4)
+    ep.debug("skip_solve", [1.0])
+    tp, k = -1.0, 0
+    while ep.state()["solver_flag"] == 0 and k < 45:
+        tp = st.feed(ep, k, tp)
+        ep.inputFeature(float(st.cam_t[k]), st.feature_frame(k))
+        k += 3
+    s, info = ep.state(), ep.debug("init_info")
+    assert [int(info[0]), int(info[1])] == list(GOLD["init_sfm_l_points"]) and abs(info[2] - GOLD["init_sfm_s"][0]) < 1e-9
+    np.testing.assert_allclose(info[3:6], GOLD["init_sfm_g_c0"], atol=1e-9)
+    for key in ("Ps", "Rs", "Vs"):
+        np.testing.assert_allclose(s[key], GOLD["init_sfm_" + key], atol=1e-9, err_msg=key)
+    ep.close()
 
 
 @pytest.mark.gpu
