@@ -60,6 +60,28 @@ __global__ void __launch_bounds__(256) pyr_level0_kernel(const uint8_t* __restri
     *reinterpret_cast<uint32_t*>(dst + (size_t)py * g.stride + px) = v;
 }
 
+// The same with 16 destination bytes per thread, for frames whose width, row pitch and base address are multiples of 16 (640 x 480: every interior group
+// is one aligned 16-byte load and one aligned 16-byte store; the 2 x 2 border groups of a row gather their mirror bytes).
+__global__ void __launch_bounds__(256) pyr_level0_vec16_kernel(const uint8_t* __restrict__ raw, size_t raw_seq_stride, int raw_stride,
+                                                               uint8_t* __restrict__ pyr, size_t pyr_seq_stride, LevelGeom g) {
+    const int pw = g.w + 2 * kPad, ph = g.h + 2 * kPad;
+    const int qw = pw >> 4;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= qw * ph) return;
+    const int py = t / qw, px = (t - py * qw) << 4;
+    const uint8_t* src = raw + blockIdx.y * raw_seq_stride + (size_t)reflect101(py - kPad, g.h) * raw_stride;
+    uint4 v;
+    if (px >= kPad && px + 15 < kPad + g.w) v = *reinterpret_cast<const uint4*>(src + (px - kPad));
+    else {
+        uint32_t w4[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 16; k++) w4[k >> 2] |= (uint32_t)src[reflect101(px + k - kPad, g.w)] << (8 * (k & 3));
+        v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+    }
+    uint8_t* dst = pyr + blockIdx.y * pyr_seq_stride + g.img_off - kPad * g.stride - kPad;
+    *reinterpret_cast<uint4*>(dst + (size_t)py * g.stride + px) = v;
+}
+
 // pyrDown (5-tap [1 4 6 4 1] separable, (s+128)>>8) from level l to l+1, written over the whole padded
 // domain of level l+1 (border pixels are the REFLECT_101 images of interior ones, recomputed in place).  Any level size.
 __global__ void __launch_bounds__(256) pyr_down_kernel(uint8_t* __restrict__ pyr, size_t pyr_seq_stride, LevelGeom s, LevelGeom d) {

@@ -233,7 +233,12 @@ static int launch_pyramid(gf_tracker* h, const uint8_t* d_raw_frames) {
     const size_t seq_img = 2 * G.img_bytes;
     uint8_t* img = h->d_img.p + (size_t)h->cur_slot * G.img_bytes;
     const LevelGeom g0 = G.lv[0];
-    {
+    const bool v16 = !((g0.w | g0.stride | (int)(((size_t)g0.w * g0.h) & 15) | (int)(seq_img & 15) | (int)((g0.img_off - kPad * g0.stride - kPad) & 15)) & 15) &&
+                     !((reinterpret_cast<uintptr_t>(d_raw_frames) | reinterpret_cast<uintptr_t>(img)) & 15);
+    if (v16) {
+        const int n = ((g0.w + 2 * kPad) / 16) * (g0.h + 2 * kPad);
+        pyr_level0_vec16_kernel<<<dim3((n + 255) / 256, h->B), 256, 0, h->stream>>>(d_raw_frames, (size_t)g0.w * g0.h, g0.w, img, seq_img, g0);
+    } else {
         const int n = ((g0.w + 2 * kPad) / 4) * (g0.h + 2 * kPad);
         pyr_level0_kernel<<<dim3((n + 255) / 256, h->B), 256, 0, h->stream>>>(d_raw_frames, (size_t)g0.w * g0.h, g0.w, img, seq_img, g0);
     }
