@@ -1501,6 +1501,48 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                     if (row <= R && col <= row && col < R) S[pk(row, col)] -= acc[r];
                 }
             };
+            // two tiles at a time for the wavefronts that own several: all panel loads first, the two MFMA chains interleaved, then the read-modify-writes
+            // (one tile after the other is a chain of LDS round trips with nothing in between)
+            auto trail_pair = [&](int j0, int nb, int r0, int t0, int t1) {
+                int tiv[2], tkv[2], ba_[2], bb_[2];
+                const bool two = t1 >= 0;
+                tiv[0] = tri_row(t0); tkv[0] = t0 - tiv[0] * (tiv[0] + 1) / 2;
+                tiv[1] = two ? tri_row(t1) : tiv[0]; tkv[1] = two ? t1 - tiv[1] * (tiv[1] + 1) / 2 : tkv[0];
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const int ra = r0 + 16 * tiv[p] + (lane & 15), rb = r0 + 16 * tkv[p] + (lane & 15);
+                    ba_[p] = ra <= R ? pk(ra, j0) : -1; bb_[p] = rb < R ? pk(rb, j0) : -1;
+                }
+                double av[2][4], bv2[2][4];
+#pragma unroll
+                for (int p = 0; p < 2; p++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int c = 4 * k + (lane >> 4);
+                        av[p][k] = (ba_[p] >= 0 && c < nb) ? S[ba_[p] + c] : 0.0;
+                        bv2[p][k] = (bb_[p] >= 0 && c < nb) ? S[bb_[p] + c] : 0.0;
+                    }
+                d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][k], bv2[0][k], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][k], bv2[1][k], acc1, 0, 0, 0);
+                }
+                double cur[2][4]; int idx[2][4];
+#pragma unroll
+                for (int p = 0; p < 2; p++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int row = r0 + 16 * tiv[p] + (lane >> 4) + 4 * r, col = r0 + 16 * tkv[p] + (lane & 15);
+                        idx[p][r] = (row <= R && col <= row && col < R && (p == 0 || two)) ? pk(row, col) : -1;
+                        cur[p][r] = idx[p][r] >= 0 ? S[idx[p][r]] : 0.0;
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (idx[0][r] >= 0) S[idx[0][r]] = cur[0][r] - acc0[r];
+                    if (idx[1][r] >= 0) S[idx[1][r]] = cur[1][r] - acc1[r];
+                }
+            };
             if (wave == 0) diag_block(0);
             __syncthreads();
             GF_SUB(tA);
@@ -1548,7 +1590,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                             diag_block(r0);
                         }
                     } else {
-                        for (int t = wave; t < ntiles; t += 7) trail_tile(j0, nb, r0, tri_row(t), t - tri_row(t) * (tri_row(t) + 1) / 2);
+                        for (int t = wave; t < ntiles; t += 14) trail_pair(j0, nb, r0, t, t + 7 < ntiles ? t + 7 : -1);
                     }
                 }
                 __syncthreads();

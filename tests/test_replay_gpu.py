@@ -27,8 +27,14 @@ def quat_xyzw(R):
     return np.array([(R[2, 1] - R[1, 2]) * s, (R[0, 2] - R[2, 0]) * s, (R[1, 0] - R[0, 1]) * s, w])
 
 
-def test_replay_tool_writes_the_oracle_trajectory(tmp_path):
-    st = SS.Stream(1, t_still=1.5, t_move=2.0, v_max=0.4, yaw0=0.0, yaw_turn=-0.6, split_x=1.8, turn_delay=0.8)
+@pytest.mark.parametrize("moving_start", [False, True])
+def test_replay_tool_writes_the_oracle_trajectory(tmp_path, moving_start):
+    """moving_start: the recording begins at constant speed, so the window is initialised by the SfM branch of initialStructure -- here with
+    the tracker's own features (sub-pixel noise, lost tracks, depth from the depth image) instead of projected landmarks."""
+    if moving_start:
+        st = SS.Stream(5, t_still=0.0, t_move=3.0, v_max=0.5, v_start=0.5, yaw0=0.0, yaw_turn=0.4, split_x=1.8)
+    else:
+        st = SS.Stream(1, t_still=1.5, t_move=2.0, v_max=0.4, yaw0=0.0, yaw_turn=-0.6, split_x=1.8, turn_delay=0.8)
     d = str(tmp_path)
     n = st.export(d)
     exe = os.path.join(ROOT, "bin", "gf_replay")
@@ -63,6 +69,8 @@ def test_replay_tool_writes_the_oracle_trajectory(tmp_path):
     print("gf_replay vs oracle: %d poses, worst |dp| %.2e, |dq| %.2e" % (len(ref), dp, dq))
     assert dp < 1e-6 + 5e-10 and dq < 1e-6 + 5e-10        # the 1e-6 bar plus the file's rounding to 9 decimals
     assert np.linalg.norm(ref[-1][1]) > 0.2               # it moved
+    if moving_start:
+        assert not est.is_imu_excited and est.init_debug["n_tracked"] > 40      # NON_LINEAR was reached through the SfM branch, on the tracker's features
 
 
 def test_replay_tool_with_gnss_messages(tmp_path):
