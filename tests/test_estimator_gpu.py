@@ -248,6 +248,39 @@ def test_group_of_sequences_on_one_batched_solver(device_preint):
         e.close()
 
 
+def test_group_members_initialise_through_sfm():
+    """three recordings that begin in motion as members of one group: each member's SfM initialisation (host code on its own thread) and the batched solves
+    behind it must land on the bits a stand-alone estimator produces"""
+    n = 3
+    streams = []
+    for s in range(n):
+        st = SS.Stream(5 + s, t_still=0.0, t_move=2.4, v_max=0.5, v_start=0.5, yaw_turn=0.4 - 0.3 * s)
+        st._lm = st._landmarks(1200)
+        st._pn = np.random.default_rng(4300 + s).normal(0, 1.0, (len(st.cam_t), len(st._lm), 2))
+        streams.append(st)
+    kw = dict(tio=SS.TIO, rio=SS.RIO, multiple_thread=1)
+    grp = gfamd.EstimatorGroup(gfamd.default_estimator_cfg(**kw), n)
+    solo = [gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(**kw)) for _ in range(n)]
+    tp = [-1.0] * n
+    for k in range(0, min(len(st.cam_t) for st in streams), 3):
+        for s, st in enumerate(streams):
+            st.feed(grp.members[s], k, tp[s])
+            tp[s] = st.feed(solo[s], k, tp[s])
+        frames = [st.feature_frame(k) for st in streams]
+        grp.inputFeatures(list(range(n)), [float(st.cam_t[k]) for st in streams], frames)
+        for s in range(n):
+            solo[s].inputFeature(float(streams[s].cam_t[k]), frames[s])
+            a, b = grp.members[s].state(), solo[s].state()
+            assert a["solver_flag"] == b["solver_flag"] and a["frame_count"] == b["frame_count"], (k, s)
+            assert np.array_equal(a["Ps"], b["Ps"]) and np.array_equal(a["Rs"], b["Rs"]) and np.array_equal(a["Vs"], b["Vs"]), (k, s)
+    for s in range(n):
+        info = grp.members[s].debug("init_info")
+        assert grp.members[s].state()["solver_flag"] == 1 and int(info[1]) > 60 and int(info[6]) == 0     # reached through the SfM branch
+    grp.close()
+    for e in solo:
+        e.close()
+
+
 @pytest.mark.parametrize("window_size,own_initialiser,raw", [(10, False, False), (20, False, False), (10, True, False), (10, True, True)])
 def test_replay_with_gnss_matches_oracle(window_size, own_initialiser, raw):
     """GNSS raw measurements through the estimator: inputGNSS -> getGNSSInterval -> processGNSS gating
