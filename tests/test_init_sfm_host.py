@@ -73,6 +73,36 @@ def test_epnp_and_iterative_pnp_recover_a_known_pose(est):
     assert np.abs(rg[0] - rvec).max() < 1e-6 and np.abs(rg[1] - tvec).max() < 1e-6
 
 
+def test_analytic_jacobians_against_finite_differences():
+    """independent of both implementations: the projection Jacobian of the pose refinement (d/d rvec through the derivative of the exponential map, d/d tvec)
+    and the local Jacobian of the bundle adjustment's residual (quaternion perturbed on the left, as ceres::QuaternionParameterization::Plus does)"""
+    X, uv, rvec, tvec = scene(6, n=12)
+    _, J = IO.project(rvec, tvec, X, jac=True)
+    h = 1e-6
+    for k in range(6):
+        d = np.zeros(6); d[k] = h
+        num = (IO.project(rvec + d[:3], tvec + d[3:], X) - IO.project(rvec - d[:3], tvec - d[3:], X)).reshape(-1) / (2 * h)
+        np.testing.assert_allclose(J[:, k], num, rtol=1e-6, atol=1e-8)
+    q = np.asarray(EO.R_to_quat(IO.rodrigues(rvec)), float)
+    p = X[0]
+
+    def res(qq, tt, pp):
+        v = IO.quat_rot(qq) @ pp + tt
+        return np.array([v[0] / v[2], v[1] / v[2]])
+
+    Rx = IO.quat_rot(q) @ p
+    v = Rx + tvec
+    D = np.array([[1 / v[2], 0, -v[0] / v[2] ** 2], [0, 1 / v[2], -v[1] / v[2] ** 2]])
+    for k in range(3):
+        d = np.zeros(3); d[k] = h
+        num_r = (res(IO.quat_plus(q, d), tvec, p) - res(IO.quat_plus(q, -d), tvec, p)) / (2 * h)
+        np.testing.assert_allclose((D @ (-2.0 * IO.skew(Rx)))[:, k], num_r, rtol=1e-6, atol=1e-8)
+        num_t = (res(q, tvec + d, p) - res(q, tvec - d, p)) / (2 * h)
+        np.testing.assert_allclose(D[:, k], num_t, rtol=1e-6, atol=1e-8)
+        num_p = (res(q, tvec, p + d) - res(q, tvec, p - d)) / (2 * h)
+        np.testing.assert_allclose((D @ IO.quat_rot(q))[:, k], num_p, rtol=1e-6, atol=1e-8)
+
+
 def test_planar_point_sets_start_from_a_homography(est):
     X, uv, rvec, tvec = scene(2, planar=True)           # a wall: cvFindExtrinsicCameraParams2 starts from a homography instead of the DLT
     ro = IO.solve_pnp_iterative(X, uv)
