@@ -88,7 +88,10 @@ def test_replay_from_a_moving_start_initialises_through_sfm(use_wheel):
     (estimator.cpp:1604-1682) and the window is initialised by the SfM branch (:1684-1847: solveRelativeRT_PNP, GlobalSFM::constructWithDepth, solvePnP per
     frame, visualInitialAlign; tests/test_init_sfm_host.py covers the pieces).  From there the replay is the usual closed loop: decisions identical, poses
     within 1e-6 of the oracle pipeline at every frame -- and, since the reference's alignment leaves the positions collapsed (`s' of estimator.cpp:1871) and,
-    with the wheel, the velocities near zero, the optimisation has to pull the window back to the driven track, which it does."""
+    with the wheel, the velocities near zero, the optimisation has to pull the window back to the driven track, which it does.
+    (Over 17 seeded recordings of this kind, scripts/sfm_init_sweep.py, the two pipelines stay within 6e-7 on 16 and end 5e-6 apart on one: the first
+    marginalisation after such an initialisation is ill-determined in double precision, two eigen-solvers on the reference's own route differ by more there --
+    DESIGN.md section 2.)"""
     st = SS.Stream(5, t_still=0.0, t_move=4.0, v_max=0.5, v_start=0.5, yaw_turn=0.4)
     st._lm = st._landmarks(1600)
     st._pn = np.random.default_rng(4005).normal(0, 1.0, (len(st.cam_t), len(st._lm), 2))
