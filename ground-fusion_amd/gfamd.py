@@ -232,7 +232,8 @@ class BaStats(C.Structure):
 
 EXPORTS += ["gf_ba_create", "gf_ba_destroy", "gf_ba_solve", "gf_ba_marginalize", "gf_ba_upload", "gf_ba_solve_resident", "gf_ba_download", "gf_ba_get_stats",
             "gf_ba_reset_stats", "gf_ba_linearize", "gf_ba_solve_resident_async", "gf_ba_wait", "gf_ba_debug_stamps", "gf_imu_preintegrate", "gf_wheel_preintegrate", "gf_ba_double2vector",
-            "gf_preint_create", "gf_preint_destroy", "gf_imu_preintegrate_batch", "gf_preint_stats"]
+            "gf_preint_create", "gf_preint_destroy", "gf_imu_preintegrate_batch", "gf_preint_stats",
+            "gf_featsweep_create", "gf_featsweep_destroy", "gf_triangulate_with_depth_batch", "gf_moving_consistency_batch", "gf_featsweep_stats"]
 
 
 class Estimator:
@@ -386,6 +387,61 @@ class PreintBatch:
         a, b, ms = C.c_longlong(0), C.c_longlong(0), C.c_double(0)
         _chk(lib().gf_preint_stats(self.h, C.byref(a), C.byref(b), C.byref(ms)))
         return dict(launches=a.value, intervals=b.value, kernel_ms=ms.value)
+
+
+class FeatureSweeps:
+    """gf_featsweep_*: triangulateWithDepth / movingConsistencyCheckW of many windows in one launch each; no CPU fallback.
+    windows: list of dicts with Rs ((W+1) x 3 x 3), Ps ((W+1) x 3), tic, ric, start_frame [F], obs (list of [n_f x 4] arrays), estimated_depth [F], estimate_flag [F]."""
+
+    def __init__(self):
+        self.h = C.c_void_p()
+        _chk(lib().gf_featsweep_create(C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().gf_featsweep_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _pack(windows):
+        W = len(windows[0]["Ps"]) - 1
+        f64 = lambda a: np.ascontiguousarray(a, np.float64)
+        Rs, Ps = f64([w["Rs"] for w in windows]), f64([w["Ps"] for w in windows])
+        tic, ric = f64([w["tic"] for w in windows]), f64([w["ric"] for w in windows])
+        ff = np.concatenate([[0], np.cumsum([len(w["start_frame"]) for w in windows])]).astype(np.int32)
+        sf = np.ascontiguousarray(np.concatenate([w["start_frame"] for w in windows]), np.int32)
+        nobs = [len(o) for w in windows for o in w["obs"]]
+        fo = np.concatenate([[0], np.cumsum(nobs)]).astype(np.int32)
+        obs = f64(np.concatenate([np.asarray(o, float).reshape(-1, 4) for w in windows for o in w["obs"]]))
+        dep = f64(np.concatenate([w["estimated_depth"] for w in windows]))
+        return W, Rs, Ps, tic, ric, ff, sf, fo, obs, dep
+
+    def triangulate_with_depth(self, windows, depth_threshold, init_depth):
+        W, Rs, Ps, tic, ric, ff, sf, fo, obs, dep = self._pack(windows)
+        flag = np.ascontiguousarray(np.concatenate([w["estimate_flag"] for w in windows]), np.int32)
+        d = C.c_double
+        _chk(lib().gf_triangulate_with_depth_batch(self.h, len(windows), W, _p(Rs, d), _p(Ps, d), _p(tic, d), _p(ric, d), _p(ff, C.c_int), _p(sf, C.c_int), _p(fo, C.c_int),
+                                                   _p(obs, d), d(depth_threshold), d(init_depth), _p(dep, d), _p(flag, C.c_int)))
+        return [(dep[ff[b]:ff[b + 1]].copy(), flag[ff[b]:ff[b + 1]].copy()) for b in range(len(windows))]
+
+    def moving_consistency(self, windows, focal_length):
+        W, Rs, Ps, tic, ric, ff, sf, fo, obs, dep = self._pack(windows)
+        rem = np.zeros(len(sf), np.int32)
+        d = C.c_double
+        _chk(lib().gf_moving_consistency_batch(self.h, len(windows), W, _p(Rs, d), _p(Ps, d), _p(tic, d), _p(ric, d), _p(ff, C.c_int), _p(sf, C.c_int), _p(fo, C.c_int),
+                                               _p(obs, d), _p(dep, d), d(focal_length), _p(rem, C.c_int)))
+        return [rem[ff[b]:ff[b + 1]].copy() for b in range(len(windows))]
+
+    def stats(self):
+        a, b, ms = C.c_longlong(0), C.c_longlong(0), C.c_double(0)
+        _chk(lib().gf_featsweep_stats(self.h, C.byref(a), C.byref(b), C.byref(ms)))
+        return dict(launches=a.value, features=b.value, kernel_ms=ms.value)
 
 
 def wheel_preintegrate(dt, vel, gyr, vel0, gyr0, lin, noise):

@@ -255,6 +255,21 @@ int gf_imu_preintegrate_batch(gf_preint* h, int n, const int* first, const doubl
                               const double* ba, const double* bg, const double* noise, double* delta_p, double* delta_q, double* delta_v, double* jacobian,
                               double* covariance, double* sum_dt);
 int gf_preint_stats(gf_preint* h, long long* launches, long long* intervals, double* kernel_ms); /* kernel_ms: hipEvent time of the kernel alone, summed */
+/* The per-feature sweeps of the measurement side for many windows at once ON THE DEVICE, one thread per feature, decisions and depths
+ * bit-identical to the host loops of the estimator:
+ *   gf_triangulate_with_depth_batch  FeatureManager::triangulateWithDepth, feature_manager.cpp:726-799 (estimated_depth / estimate_flag updated in place)
+ *   gf_moving_consistency_batch      Estimator::movingConsistencyCheckW, estimator.cpp:3955-3995 (remove[f] = 1 for the ids the reference puts into removeIndex)
+ * Window b: Rs / Ps ((W+1) x 9 row-major / (W+1) x 3), tic (3), ric (9), features first_feature[b] .. first_feature[b+1]-1 (feature_manager's list order);
+ * feature f: start_frame[f], observations first_obs[f] .. first_obs[f+1]-1, each x, y, z of the normalised point and the depth-camera depth. */
+typedef struct gf_featsweep gf_featsweep;
+int gf_featsweep_create(gf_featsweep** out);
+int gf_featsweep_destroy(gf_featsweep* h);
+int gf_triangulate_with_depth_batch(gf_featsweep* h, int B, int W, const double* Rs, const double* Ps, const double* tic, const double* ric, const int* first_feature,
+                                    const int* start_frame, const int* first_obs, const double* obs, double depth_threshold, double init_depth,
+                                    double* estimated_depth, int* estimate_flag);
+int gf_moving_consistency_batch(gf_featsweep* h, int B, int W, const double* Rs, const double* Ps, const double* tic, const double* ric, const int* first_feature,
+                                const int* start_frame, const int* first_obs, const double* obs, const double* estimated_depth, double focal_length, int* remove);
+int gf_featsweep_stats(gf_featsweep* h, long long* launches, long long* features, double* kernel_ms);
 /* WheelIntegrationBase::push_back loop (factor/wheel_integration_base.h:41-178); noise = VEL_N_wheel, GYR_N_wheel; lin = sx, sy, sw */
 int gf_wheel_preintegrate(int n, const double* dt, const double* vel, const double* gyr, const double* vel0, const double* gyr0, const double* lin,
                           const double* noise, double* delta_p, double* delta_q, double* jacobian, double* covariance, double* sum_dt);
