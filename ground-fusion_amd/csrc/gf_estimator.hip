@@ -1876,8 +1876,10 @@ int gf_estimator_debug(gf_estimator* e, const char* op, const double* in, int n_
         std::vector<std::array<double, 6>> corres(n_in / 6);
         for (size_t k = 0; k < corres.size(); k++) for (int a = 0; a < 6; a++) corres[k][a] = in[6 * k + a];
         double R[9] = {0}, T[3] = {0};
-        const bool ok = gfinit::solve_relative_rt_pnp(corres, R, T);
+        std::vector<int> inl;
+        const bool ok = gfinit::solve_relative_rt_pnp(corres, R, T, &inl);
         o.push_back(ok ? 1.0 : 0.0); o.insert(o.end(), R, R + 9); o.insert(o.end(), T, T + 3);
+        for (int i : inl) o.push_back(i);   // RANSAC inliers (indices into the correspondences with both depths positive)
     }
     else if (s == "solvePnP" && n_in >= 8 && (n_in - 8) % 5 == 0) {   // in: n, use_guess, rvec, tvec, then (X, Y, Z, u, v) per point; out: ok, rvec, tvec
         const int n = (int)in[0];

@@ -15,6 +15,8 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <utility>
 #include <vector>
@@ -579,6 +581,7 @@ inline bool solve_pnp_ransac(const std::vector<P3>& X_in, const std::vector<P2>&
             mask[i] = e <= thr;
             good += mask[i];
         }
+        if (getenv("GF_INIT_DEBUG")) fprintf(stderr, "ransac it %d subset %d %d %d %d %d good %d rv %.12g %.12g %.12g tv %.12g %.12g %.12g\n", it, idx[0], idx[1], idx[2], idx[3], idx[4], good, rv[0], rv[1], rv[2], tv[0], tv[1], tv[2]);
         if (good > std::max(best, mp - 1)) {
             best = good; best_mask = mask;
             niters = ransac_update_num_iters(0.99, (double)(n - good) / n, mp, niters);
@@ -592,12 +595,12 @@ inline bool solve_pnp_ransac(const std::vector<P3>& X_in, const std::vector<P2>&
 
 // MotionEstimator::solveRelativeRT_PNP, solve_5pts.cpp:244-277.  corres: (x, y, z) in frame l and in the newest frame, both scaled by their depth.
 // The rotation is built as Rx(r0) Ry(r1) Rz(r2) from the Rodrigues vector, as the SO3(double, double, double) constructor of the non-templated Sophus does.
-inline bool solve_relative_rt_pnp(const std::vector<std::array<double, 6>>& corres, double* Rot, double* Tr) {
+inline bool solve_relative_rt_pnp(const std::vector<std::array<double, 6>>& corres, double* Rot, double* Tr, std::vector<int>* inliers = nullptr) {
     std::vector<P3> X; std::vector<P2> uv;
     for (auto& c : corres)
         if (c[2] > 0 && c[5] > 0) { X.push_back({c[0], c[1], c[2]}); uv.push_back({c[3] / c[5], c[4] / c[5]}); }
     double rv[3], tv[3];
-    if (!solve_pnp_ransac(X, uv, rv, tv)) return false;
+    if (!solve_pnp_ransac(X, uv, rv, tv, inliers)) return false;
     const double cx = cos(rv[0]), sx = sin(rv[0]), cy = cos(rv[1]), sy = sin(rv[1]), cz = cos(rv[2]), sz = sin(rv[2]);
     const double Rx[9] = {1, 0, 0, 0, cx, -sx, 0, sx, cx}, Ry[9] = {cy, 0, sy, 0, 1, 0, -sy, 0, cy}, Rz[9] = {cz, -sz, 0, sz, cz, 0, 0, 0, 1};
     double rota[9];

@@ -21,6 +21,9 @@ import math
 import numpy as np
 
 
+_DEBUG = False
+
+
 def f32(a):
     """cv::Point2f / cv::Point3f storage: values pass through float"""
     return np.asarray(a, np.float32).astype(np.float64)
@@ -411,6 +414,8 @@ def solve_pnp_ransac(X, uv, iterations=100, reproj=1.0 / 460, confidence=0.99):
             err = d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]
         mask = err <= thr
         good = int(mask.sum())
+        if _DEBUG:
+            print("ransac it %d subset %s good %d rv %.12g %.12g %.12g tv %.12g %.12g %.12g" % (it - 1, " ".join(str(i) for i in idx), good, *m[0], *m[1]))
         if good > max(best_count, mp - 1):
             best_count, best_mask = good, mask
             niters = ransac_update_num_iters(confidence, (n - good) / n, mp, niters)

@@ -163,10 +163,27 @@ def test_bundle_adjustment_restores_perturbed_cameras_and_points():
     assert max(np.abs(a - b).max() for a, b in zip(t1, ts)) < 1e-5 and max(np.abs(a - b).max() for a, b in zip(p1, pts)) < 1e-4
 
 
+def test_ransac_hypotheses_of_near_degenerate_subsets_are_noise_driven():
+    """W = 20: after 2 s of driving only the frame next to the newest one shares more than 20 tracks with it (l = 19, 21 correspondences, on the two walls of the
+    scene), and the 5-point subsets of such a set are close to coplanar: EPnP's control points degenerate, its 12 x 12 eigenproblem and 6 x 4 least squares are
+    ill-conditioned (1e12), and two implementations of the same algorithm -- numpy / LAPACK here, Jacobi + Householder in the library; OpenCV's would be a third --
+    return hypotheses 1e-4 ... 1e-2 apart (scripts: GF_INIT_DEBUG=1 prints them).  Which hypothesis first reaches the best inlier count, hence which single point
+    stays out, is then rounding's choice, and the poses differ at 3e-4.  Everything discrete that does not depend on it agrees; the bar of this case is 2e-3, and
+    DESIGN.md section 2 lists the regime."""
+    st, eo, ep = run_to_init(5, 0.4, window_size=20)
+    s, info, d = ep.state(), ep.debug("init_info"), eo.init_debug
+    assert s["solver_flag"] == EO.NON_LINEAR and (int(info[0]), int(info[6])) == (d["l"], 0) and d["l"] == eo.W - 1
+    assert abs(int(info[1]) - d["n_tracked"]) <= 3
+    np.testing.assert_allclose(info[3:6], d["g_c0"], atol=2e-2)
+    np.testing.assert_allclose(s["Rs"], np.array(eo.Rs), atol=2e-3)
+    np.testing.assert_allclose(s["Ps"], np.array(eo.Ps), atol=2e-3)
+    ep.close()
+
+
 def run_to_init(seed, yaw_turn, **kw):
     """a recording that begins in motion at constant speed: neither the stationary nor the wheel-activated shortcut fires, the window fills, initialStructure
     takes the SfM branch.  Both pipelines run it with the optimisation behind it switched off."""
-    st = SS.Stream(seed, t_still=0.0, t_move=2.0, v_max=0.5, v_start=0.5, yaw_turn=yaw_turn)
+    st = SS.Stream(seed, t_still=0.0, t_move=2.0 if kw.get("window_size", 10) <= 10 else 3.2, v_max=0.5, v_start=0.5, yaw_turn=yaw_turn)
     cfg = dict(tio=SS.TIO, rio=SS.RIO, multiple_thread=1, **kw)
     eo = EO.Estimator(dict(cfg))
     ep = gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(**cfg))
@@ -183,7 +200,7 @@ def run_to_init(seed, yaw_turn, **kw):
         for e in (eo, ep):
             e.inputFeature(float(st.cam_t[k]), frame)
         k += 3
-        assert k < 45, "initialStructure never succeeded"
+        assert k < 4.5 * (eo.W + 1) and k < len(st.cam_t), "initialStructure never succeeded"
     return st, eo, ep
 
 
