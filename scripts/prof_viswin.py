@@ -1,0 +1,11 @@
+"""stage clocks of ba_linearize_visual_win (profiling build, scripts/build_profile.py): stamps 80..86 of block 0"""
+import sys, ctypes as C
+sys.path.insert(0, 'ground-fusion_amd')
+import numpy as np, gfamd, synth_window as SW
+est = gfamd.Estimator(batch=256)
+base = [SW.make_window(1000 + b, gfamd) for b in range(8)]
+est.upload([base[b % 8] for b in range(256)])
+est.solve_resident(2, -1, True)
+st = np.zeros(128, np.int64)
+gfamd._chk(gfamd.lib().gf_ba_debug_stamps(est.h, st.ctypes.data_as(C.POINTER(C.c_longlong)), 128))
+print("stamps 80..86 relative to 80:", (st[80:87] - st[80]).tolist())
