@@ -174,16 +174,39 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     double* feb = sb.yv + (size_t)b * sb.VS;  // per-feature b_f/sqrt(d_f)  (two scratch vectors of VS = RP + FP entries each: F entries fit either, not both in one)
     for (int e = tid; e < NE; e += 512) { const double df = ete[e]; const double f = df > eps ? 1.0 / sqrt(df) : 0.0; fe[e] = f; feb[e] = f * etb[e]; }
     __syncthreads();
-    for (int i = tid; i < ((NE + 3) & ~3) * ECW; i += 512) {
-        const int e = i / ECW, k = i - e * ECW;
-        Es[i] = (e < NE && s_cmap[k] >= 0) ? Et[i] * fe[e] : 0.0;
+    {   // Es = diag(fe) Et on the kept compact columns: one wavefront per row, eight rows in flight (every load issued before the first store)
+        const int NE4 = (NE + 3) & ~3;
+        constexpr int EN = GS ? 4 : 2;   // 64-column pieces of a compact row
+        for (int e0 = wave; e0 < NE4; e0 += 64) {
+            double ev[8][EN], fv[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int e = e0 + 8 * m;
+                fv[m] = e < NE ? fe[e] : 0.0;
+#pragma unroll
+                for (int q = 0; q < EN; q++) { const int k = lane + 64 * q; ev[m][q] = (e < NE && k < ECW) ? Et[(size_t)e * ECW + k] : 0.0; }
+            }
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int e = e0 + 8 * m;
+                if (e >= NE4) continue;
+#pragma unroll
+                for (int q = 0; q < EN; q++) { const int k = lane + 64 * q; if (k < ECW) Es[(size_t)e * ECW + k] = (e < NE && s_cmap[k] >= 0) ? ev[m][q] * fv[m] : 0.0; }
+            }
+        }
     }
     __syncthreads();
-    for (int k = tid; k < ECW; k += 512) {
+    for (int k = tid; k < ECW; k += 512) {   // bv -= Es^T feb: the sum runs in row order as before, the loads of eight rows at a time are issued together
         const int c = s_cmap[k];
         if (c < 0) continue;
         double v = bv[c];
-        for (int e = 0; e < NE; e++) v -= Es[(size_t)e * ECW + k] * feb[e];
+        for (int e0 = 0; e0 < NE; e0 += 8) {
+            double a[8], f[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) { const int e = min(e0 + m, NE - 1); a[m] = Es[(size_t)e * ECW + k]; f[m] = feb[e]; }
+#pragma unroll
+            for (int m = 0; m < 8; m++) if (e0 + m < NE) v -= a[m] * f[m];
+        }
         bv[c] = v;
     }
     GF_MST(1);
