@@ -705,7 +705,10 @@ int gf_ba_marginalize_resident(gf_ba* h, const int* slots, const gf_ba_window* w
         const int b = slots[i];
         if (b < 0 || b >= h->count) return gf::set_err(GF_ERR_INVALID, "slot %d outside the %d resident windows", b, h->count);
         const gf_ba_window& w = windows[i];
-        if (w.W != d.W || w.n_feature > d.F) return gf::set_err(GF_ERR_INVALID, "window %d does not match the resident structure", i);
+        // the factor tables, orders and the prior of slot b stay as the last upload / solve left them: the window handed in must be that one
+        if (w.W != d.W || w.n_feature != h->nfeat.h[b] || w.n_visual != h->nvis.h[b] || w.n_imu != h->nimu.h[b] || w.n_wheel != h->nwh.h[b] || w.prior_n != h->pri_n.h[b])
+            return gf::set_err(GF_ERR_INVALID, "window %d does not match the structure resident in slot %d (features %d/%d, visual %d/%d, imu %d/%d, wheel %d/%d, prior %d/%d)", i, b,
+                               w.n_feature, h->nfeat.h[b], w.n_visual, h->nvis.h[b], w.n_imu, h->nimu.h[b], w.n_wheel, h->nwh.h[b], w.prior_n, h->pri_n.h[b]);
         double* x = h->xs0.h + (size_t)b * d.XS;
         for (int k = 0; k < d.NP; k++) { memcpy(x + off_pose(k), w.para_Pose + 7 * k, 56); memcpy(x + off_sb(k), w.para_SpeedBias + 9 * k, 72); }
         memcpy(x + off_ex(d.NP), w.para_Ex_Pose, 56); memcpy(x + off_exw(d.NP), w.para_Ex_Pose_wheel, 56); memcpy(x + off_ix(d.NP), w.para_Ix, 24);
@@ -814,7 +817,9 @@ int gf_ba_export_newest_poses(gf_ba* h, void* d_out, int count) {
     if (!h || !d_out || count < 1 || count > h->count) return gf::set_err(GF_ERR_INVALID, "bad argument");
     ba_export_newest<<<dim3((count + 63) / 64), 64, 0, h->stream>>>(h->win(), static_cast<double*>(d_out), count);
     HIPCHK(hipGetLastError());
-    if (!h->pending) HIPCHK(hipStreamSynchronize(h->stream));
+    // Always synchronise: the caller hands d_out to a collective on ANOTHER stream right after this returns.  (With a solve in flight this also
+    // waits for the solve -- the exported pose is the solved one; gf_ba_wait afterwards only collects the statistics.)
+    HIPCHK(hipStreamSynchronize(h->stream));
     return GF_OK;
 }
 

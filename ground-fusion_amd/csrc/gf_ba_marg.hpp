@@ -135,6 +135,7 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     __shared__ double sP[MPMAX * MPMAX], sPV[MPMAX * MPMAX], sPinv[MPMAX * MPMAX], sbp[MPMAX];
     __shared__ double s_c[64], s_s[64];
     __shared__ int s_p[64], s_q[64], s_flag, s_fastinv;
+    __shared__ double s_dg[2][256];   // diagonal of the kept system during the pivoted factorisation (n <= 256: checked by the host)
     const Dims d = w.d;
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const MargInfo mi = info[b];
@@ -289,14 +290,20 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     double* zb = V + 256;                    // n doubles: permuted right-hand side being forward-substituted
     double* dinvs = V + 1280;                // 1 / L_kk per accepted pivot
     double* zr = V + 1792;                   // finished entries of the forward substitution
-    for (int i = tid; i < n; i += 512) { perm[i] = i; zb[i] = br[i]; }
+    // The pivot search reads the diagonal from a double-buffered copy in LDS: step k searches s_dg[k & 1], the trailing update of step k writes the
+    // new diagonal into s_dg[(k + 1) & 1].  A wavefront that is through with its search may therefore start swapping / updating A while a slower one is
+    // still searching -- what the slower one reads is never written in the same step -- and all wavefronts agree on the pivot without a barrier
+    // between search and swap (reading A[i][i] itself there was a race: round-2 advisor finding).
+    for (int i = tid; i < n; i += 512) { perm[i] = i; zb[i] = br[i]; s_dg[0][i] = A[i * n + i]; }
     __syncthreads();
     int rank = n;
     const int tx = tid & 31, ty = tid >> 5;   // 32 x 16 thread grid of the trailing update
     for (int k = 0; k < n; k++) {
         // pivot: largest remaining diagonal entry, the lowest lane that holds it on ties (every wavefront computes the same answer)
         double best = -1.0; int bi = k;
-        for (int i = k + lane; i < n; i += 64) { const double v = A[i * n + i]; if (v > best) { best = v; bi = i; } }
+        const double* dgo = s_dg[k & 1];
+        double* dgn = s_dg[(k + 1) & 1];
+        for (int i = k + lane; i < n; i += 64) { const double v = dgo[i]; if (v > best) { best = v; bi = i; } }
         double m = best;
 #define GF_DPP_MAX(ctrl) do { const int lo_ = __builtin_amdgcn_mov_dpp(__double2loint(m), ctrl, 0xf, 0xf, true), hi_ = __builtin_amdgcn_mov_dpp(__double2hiint(m), ctrl, 0xf, 0xf, true); \
                               m = fmax(m, __hiloint2double(hi_, lo_)); } while (0)
@@ -340,7 +347,7 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
         for (int i = k + 1 + ty; i < n; i += 16) {
             const double li = rowk[i] * dinv;
             double* row = A + (size_t)i * n;
-            for (int j = k + 1 + tx; j < n; j += 32) row[j] = __builtin_fma(-li, rowk[j] * dinv, row[j]);
+            for (int j = k + 1 + tx; j < n; j += 32) { const double nv = __builtin_fma(-li, rowk[j] * dinv, row[j]); row[j] = nv; if (j == i) dgn[i] = nv; }
         }
         for (int i = k + 1 + tid; i < n; i += 512) zb[i] = __builtin_fma(-(rowk[i] * dinv), rk, zb[i]);
         if (tid == 0) { dinvs[k] = dinv; zr[k] = rk; }

@@ -467,9 +467,12 @@ struct BatchSolver {
         if (pending.empty() || (int)pending.size() < active) return;
         std::vector<Req*> reqs;
         reqs.swap(pending);
+        // Partition by a snapshot of kind / mode BEFORE anything runs, and publish `done` only after the last pass: a submitter that sees done == true
+        // returns and destroys its stack-allocated Req, so no request may be looked at again once any flag of this batch is up.
+        std::vector<Req*> groups[4];   // pre-integrations, solves, MARGIN_OLD, MARGIN_SECOND_NEW
+        for (Req* r : reqs) groups[r->kind == 2 ? 0 : r->kind == 0 ? 1 : 2 + (r->mode != 0)].push_back(r);
         {   // pre-integrations first: nothing else of the same step can be pending next to them
-            std::vector<Req*> grp;
-            for (Req* r : reqs) if (r->kind == 2) grp.push_back(r);
+            const std::vector<Req*>& grp = groups[0];
             if (!grp.empty()) {
                 const auto tc0 = std::chrono::steady_clock::now();
                 std::vector<gf::PreintJob> jobs;
@@ -481,14 +484,13 @@ struct BatchSolver {
                 const int rc = gf::preint_batch_run(pre, jobs, grp[0]->noise);
                 if (rc == GF_OK) for (Req* r : grp) for (ImuPre* p : r->pres) p->adopt();
                 const std::string err = rc == GF_OK ? std::string() : std::string(gf_last_error());
-                for (Req* r : grp) { r->rc = rc; r->err = err; r->done.store(true, std::memory_order_release); }
+                for (Req* r : grp) { r->rc = rc; r->err = err; }
                 t_pre += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
                 pre_batches++; pre_intervals += (long long)jobs.size();
             }
         }
         for (int pass = 0; pass < 3; pass++) {   // solves, MARGIN_OLD, MARGIN_SECOND_NEW
-            std::vector<Req*> grp;
-            for (Req* r : reqs) if ((pass == 0 && r->kind == 0) || (pass > 0 && r->kind == 1 && r->mode == pass - 1)) grp.push_back(r);
+            const std::vector<Req*>& grp = groups[1 + pass];
             if (grp.empty()) continue;
             // the shared handle takes its iteration count per call: group by it (members of one group share a configuration)
             std::vector<gf_ba_window> wins(grp.size());
@@ -517,9 +519,10 @@ struct BatchSolver {
             }
             (pass == 0 ? t_solve : t_marg) += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
             const std::string err = rc == GF_OK ? std::string() : std::string(gf_last_error());
-            for (Req* r : grp) { r->rc = rc; r->err = err; r->done.store(true, std::memory_order_release); }
+            for (Req* r : grp) { r->rc = rc; r->err = err; }
             batches++; windows += (long long)grp.size(); largest = std::max(largest, (long long)grp.size());
         }
+        for (Req* r : reqs) r->done.store(true, std::memory_order_release);   // last touch of every request
         finished.bump();
     }
 };
@@ -1917,7 +1920,7 @@ struct gf_estimator_group {
     double t_input = 0;   // wall time inside gf_estimator_group_input_features [s]
     std::atomic<int> remaining{0};
     std::atomic<bool> stop{false};
-    std::vector<char> has;
+    std::unique_ptr<std::atomic<int>[]> job_gen;   // generation of `go` in which member i has a frame to process (0 = never)
     std::vector<double> t;
     std::vector<std::vector<gf_feature_obs>> frames;
     std::vector<int> rcs;
@@ -1930,7 +1933,10 @@ struct gf_estimator_group {
             while (go.now() == seen && !stop.load(std::memory_order_acquire)) go.wait_while(seen);
             if (stop.load(std::memory_order_acquire)) return;
             seen = go.now();   // one step at a time: input_features does not return before every listed member is done
-            if (!has[i]) continue;
+            // The work list is published per generation: job_gen[i] == seen means "member i is listed in the step this thread just woke for" and, by the
+            // release / acquire pair on it, that t[i] / frames[i] are completely written.  A thread that was not listed in step k and only gets here while
+            // step k + 1 is being set up sees job_gen[i] == k + 1 != seen, goes round the loop, picks up generation k + 1 and runs its frame exactly once.
+            if (job_gen[i].load(std::memory_order_acquire) != seen) continue;
             mem[i]->t_mark = gf_estimator::cpu_now();
             const int rc = gf_estimator_input_feature(mem[i], t[i], frames[i].data(), (int)frames[i].size());
             mem[i]->lap(5);
@@ -1953,6 +1959,7 @@ struct gf_estimator_group {
 int gf_estimator_group_create(const gf_estimator_cfg* c, int n, gf_estimator_group** out) {
     if (!c || !out || n < 1 || n > 4096) return gf::set_err(GF_ERR_INVALID, "bad argument (1 <= n <= 4096)");
     if (c->with_tracker) return gf::set_err(GF_ERR_INVALID, "group members take feature frames (cfg.with_tracker = 0); run one batched gf_tracker next to the group");
+    if (c->max_solver_time > 0) return gf::set_err(GF_ERR_INVALID, "max_solver_time %.3g s: the wall-clock cut of ceres::Solve is per solve, not per batch; set it to 0 for a group (iteration cap only)", c->max_solver_time);
     gf_estimator_group* g = new gf_estimator_group();
     for (int i = 0; i < n; i++) {
         gf_estimator* e = nullptr;
@@ -1964,7 +1971,8 @@ int gf_estimator_group_create(const gf_estimator_cfg* c, int n, gf_estimator_gro
     if (int rc = gf_ba_create(&bc, &g->solver.ba)) { delete g; return rc; }
     (void)hipGetDevice(&g->device);
     if (const char* e = getenv("GF_GROUP_DEVICE_PREINT")) if (atoi(e) != 0) if (int rc = gf::preint_batch_create(&g->solver.pre)) { delete g; return rc; }
-    g->has.assign(n, 0); g->t.assign(n, 0.0); g->frames.resize(n); g->rcs.assign(n, GF_OK); g->errs.resize(n);
+    g->job_gen.reset(new std::atomic<int>[n]); for (int i = 0; i < n; i++) g->job_gen[i].store(0, std::memory_order_relaxed);
+    g->t.assign(n, 0.0); g->frames.resize(n); g->rcs.assign(n, GF_OK); g->errs.resize(n);
     for (int i = 0; i < n; i++) g->thr.emplace_back([g, i] { g->worker(i); });
     *out = g;
     return GF_OK;
@@ -2005,12 +2013,16 @@ int gf_estimator_group_input_features(gf_estimator_group* g, int count, const in
     size_t off = 0;
     {
         std::unique_lock<std::mutex> lk(g->m);
-        std::fill(g->has.begin(), g->has.end(), 0);
-        for (int k = 0; k < count; k++) {
+        for (int k = 0; k < count; k++) {   // validate first: nothing is published for a call that is refused
             const int i = seq[k];
             if (i < 0 || i >= n || seen[i] || n_obs[k] < 0 || (n_obs[k] > 0 && !obs)) return gf::set_err(GF_ERR_INVALID, "sequence index %d out of range, listed twice, or without observations", i);
             seen[i] = 1;
-            g->has[i] = 1; g->t[i] = t[k]; g->frames[i].assign(obs + off, obs + off + n_obs[k]); g->rcs[i] = GF_OK;
+        }
+        const int next = g->go.now() + 1;   // only this function (serialised by g->m) and the destructor bump `go`
+        for (int k = 0; k < count; k++) {
+            const int i = seq[k];
+            g->t[i] = t[k]; g->frames[i].assign(obs + off, obs + off + n_obs[k]); g->rcs[i] = GF_OK;
+            g->job_gen[i].store(next, std::memory_order_release);
             off += (size_t)n_obs[k];
         }
         { std::unique_lock<std::mutex> sl(g->solver.m); g->solver.active = count; }

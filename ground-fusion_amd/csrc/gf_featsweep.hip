@@ -132,6 +132,7 @@ struct gf_featsweep {
 static int upload_common(gf_featsweep* h, SweepArgs& A, int B, int W, const double* Rs, const double* Ps, const double* tic, const double* ric, const int* first_feature,
                          const int* start_frame, const int* first_obs, const double* obs, const double* estimated_depth) {
     const int F = first_feature[B];
+    if (F < 0 || (F > 0 && (!start_frame || !first_obs || !obs))) return gf::set_err(GF_ERR_INVALID, "%d features listed but start_frame / first_obs / obs is null", F);
     const size_t O = F > 0 ? (size_t)first_obs[F] : 0;
     for (int b = 0; b < B; b++) if (first_feature[b + 1] < first_feature[b]) return gf::set_err(GF_ERR_INVALID, "first_feature must not decrease");
     for (int f = 0; f < F; f++) {

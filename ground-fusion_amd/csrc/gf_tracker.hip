@@ -871,7 +871,8 @@ __global__ void __launch_bounds__(256) calib_tile_kernel(const uint8_t* __restri
 int gf_calib_fetch(int mode, size_t buffer_bytes, double* requested_bytes, double* lines64, double* ms) {
     if (mode < 0 || mode > 2 || buffer_bytes < (1u << 20)) return gf::set_err(GF_ERR_INVALID, "bad argument");
     uint8_t* buf = nullptr; unsigned* sink = nullptr;
-    if (hipMalloc((void**)&buf, buffer_bytes) != hipSuccess || hipMalloc((void**)&sink, 64) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipMalloc failed");
+    if (hipMalloc((void**)&buf, buffer_bytes) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipMalloc failed");
+    if (hipMalloc((void**)&sink, 64) != hipSuccess) { (void)hipFree(buf); return gf::set_err(GF_ERR_HIP, "hipMalloc failed"); }
     (void)hipMemset(buf, 1, buffer_bytes); (void)hipMemset(sink, 0, 64);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipDeviceSynchronize();

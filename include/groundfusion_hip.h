@@ -308,7 +308,8 @@ typedef struct gf_estimator_cfg {
     double gnss_elevation_thres, gnss_psr_std_thres, gnss_dopp_std_thres, gnss_ddt_sigma, gnss_local_time_diff;
     double gnss_iono[8];
     /* SOLVER_TIME (`max_solver_time`, parameters.cpp:343): the solve gets 4/5 of it when the oldest frame will be marginalised, all of it otherwise
-     * (estimator.cpp:3312-3315).  0 = not honoured (parity runs: the oracle counts iterations only). */
+     * (estimator.cpp:3312-3315).  0 = not honoured (parity runs: the oracle counts iterations only).  A wall-clock cut makes the members of one
+     * batch end after different iteration counts depending on who shares the batch, so gf_estimator_group_create refuses a value > 0. */
     double max_solver_time;
 } gf_estimator_cfg;
 
@@ -413,8 +414,9 @@ int gf_estimator_group_stats(gf_estimator_group* g, long long* batches, long lon
 /* readParameters(std::string config_file), vins_estimator/src/estimator/parameters.cpp:138-558, plus the cam0_calib file it names
  * (PinholeCamera::Parameters::readFromYamlFile, camera_models/src/camera_models/PinholeCamera.cc:145-183; path relative to the config
  * file's directory, parameters.cpp:436-443).  Same key names and cv::FileNode defaults (a missing numeric key reads as 0).  Fills the
- * whole cfg including cfg->tracker and sets with_tracker = 1.  Options outside the built path (use_line, use_yolo, plane, equalize,
- * gnss_enable, use_motion, num_of_cam 2, estimate_extrinsic 2, subset extrinsic_type) return GF_ERR_INVALID instead of being ignored. */
+ * whole cfg including cfg->tracker and sets with_tracker = 1 (gnss_enable and its gnss_* keys are read, parameters.cpp:519-552).  Options
+ * outside the built path (use_line, use_yolo, plane, equalize, use_motion, num_of_cam 2, estimate_extrinsic 2, subset extrinsic_type,
+ * gnss_local_online_sync) return GF_ERR_INVALID instead of being ignored. */
 int gf_estimator_cfg_from_yaml(const char* config_file, gf_estimator_cfg* cfg);
 /* the line pubOdometry appends to VINS_RESULT_PATH (utility/visualization.cpp:346-357): "t x y z qx qy qz qw", fixed, 9 decimals;
  * P = Ps[WINDOW_SIZE], R = Rs[WINDOW_SIZE] (row-major), quaternion as Eigen::Quaterniond(R) */
