@@ -59,24 +59,32 @@ def make_frames(n_frames, batch, seed0, device):
     return frames, depth
 
 
-def make_windows(gfamd, batch, seed0, features):
+def make_windows(gfamd, batch, seed0, features, window=10, gnss=False, distinct=None):
     """Steady-state windows (with a marginalisation prior) for `batch` sequences: window 0 is solved and marginalised on the
-    GPU with the product path itself, the resulting prior feeds window 1 which is what the bench solves."""
+    GPU with the product path itself, the resulting prior feeds window 1 which is what the bench solves.  `distinct` < batch: only that
+    many seeded windows are generated (host synthesis of a 500-feature window takes seconds) and dealt round-robin to the sequences."""
     import synth_window as SW
-    est = gfamd.Estimator(window_size=10, max_features=features, max_visual=features * 10, batch=batch)
-    w0 = [SW.make_window(seed0 + b, gfamd, max_features=features, n_landmarks=int(features * 1.5)) for b in range(batch)]
+    nd = batch if not distinct else min(batch, distinct)
+    est = gfamd.Estimator(window_size=window, max_features=features, max_visual=features * window, batch=batch, max_gnss=12 * (window + 1) if gnss else 0)
+    kw = dict(W=window, max_features=features, n_landmarks=int(features * 1.5), gnss=gnss)
+    w0 = [SW.make_window(seed0 + b, gfamd, **kw) for b in range(nd)]
+    w0 = [w0[b % nd] if b < nd else w0[b % nd].copy() for b in range(batch)]
     est.upload(w0)
     est.solve_resident(8, 0, True)
     _, priors = est.download(w0, True)
-    w1 = [SW.make_window(seed0 + b, gfamd, frame0=1, prior=priors[b], max_features=features, n_landmarks=int(features * 1.5)) for b in range(batch)]
+    w1 = [SW.make_window(seed0 + b, gfamd, frame0=1, prior=priors[b], **kw) for b in range(nd)]
+    w1 = [w1[b % nd] if b < nd else w1[b % nd].copy() for b in range(batch)]
     return est, w1
 
 
-def cpu_baseline(frames_host, dt, wins, threads, ba_iters, repeat=4):
-    """CPU oracle (kind 'port') on a bounded sample of the same workload, `threads` sequences in parallel, each sequence
-    single-threaded like the reference (Ceres num_threads = 1, estimator.cpp:3306).  Returns per-unit rates."""
+def cpu_baseline(frames_host, dt, wins, threads, ba_iters, max_cnt, min_dist, repeat=4):
+    """CPU oracle (kind 'port', built -O3 -march=native on this box: BASELINE.md section 2) on a bounded sample of the same workload.
+    Variant (a): every sequence single-threaded like the reference's solver (Ceres num_threads = 1, estimator.cpp:3306); `threads` sequences run side by
+    side, one per core, which is the most favourable way to use the cores for THROUGHPUT.  Variant (b): one sequence at a time with the reference's own
+    intra-sequence parallelism (OpenCV parallel_for_ over the LK points on all cores, 4 marginalisation threads, marginalization_factor.h:22)."""
     import threading
     import oracle_py
+    native = oracle_py.use_native()
     oracle_py.lib()
     n_frames, nseq = frames_host.shape[0], frames_host.shape[1]
     depth = np.full((H, W), 1800, np.uint16)
@@ -85,10 +93,10 @@ def cpu_baseline(frames_host, dt, wins, threads, ba_iters, repeat=4):
     t_ba = [0.0] * nseq
     n_ba = [0] * nseq
 
-    def run(b):
+    def run(b, rep=repeat):
         t0 = time.perf_counter()
-        for _ in range(repeat):          # the same frames again through a fresh tracker: ~10 s of CPU work over all threads
-            tr = oracle_py.Tracker(oracle_py.default_cfg())
+        for _ in range(rep):          # the same frames again through a fresh tracker: ~10 s of CPU work over all threads
+            tr = oracle_py.Tracker(oracle_py.default_cfg(max_cnt=max_cnt, min_dist=min_dist))
             prev = set()
             for k in range(n_frames):
                 ids, _ = tr.track(dt * k, frames_host[k, b], depth)
@@ -97,7 +105,7 @@ def cpu_baseline(frames_host, dt, wins, threads, ba_iters, repeat=4):
                 prev = set(ids.tolist())
         t_track[b] = time.perf_counter() - t0
         t0 = time.perf_counter()
-        for _ in range(repeat * max(1, n_frames // 4)):
+        for _ in range(rep * max(1, n_frames // 4)):
             w = wins[b].copy()
             oracle_py.ba_solve(w, ba_iters)
             oracle_py.ba_marginalize(w, 0)
@@ -116,8 +124,23 @@ def cpu_baseline(frames_host, dt, wins, threads, ba_iters, repeat=4):
     per_frame = sum(t_track) / (nseq * repeat * (n_frames - 1)) + 0.0
     per_solve = sum(t_ba) / sum(n_ba)
     steps_per_s = threads / (per_frame + per_solve)
-    return {"steps_per_s": steps_per_s, "tracked_features_per_s": threads * (sum(counts) / (nseq * repeat * (n_frames - 1))) / per_frame, "repeat": repeat,
-            "solves_only_per_s": threads / per_solve, "ms_track_frame_1core": 1e3 * per_frame, "ms_solve_marg_1core": 1e3 * per_solve, "wall_s": el}
+    tracked_per_frame = sum(counts) / (nseq * repeat * (n_frames - 1))
+    # variant (b): sequence 0 alone, LK over all cores + 4 marginalisation threads
+    ncpu = os.cpu_count() or 1
+    oracle_py.set_threads(ncpu)
+    t_track[0] = t_ba[0] = 0.0; n_ba[0] = 0; counts[0] = 0
+    tb0 = time.perf_counter()
+    run(0, 1)
+    tb = time.perf_counter() - tb0
+    oracle_py.set_threads(1)
+    b_frame, b_solve = t_track[0] / (n_frames - 1), t_ba[0] / max(n_ba[0], 1)
+    return {"steps_per_s": steps_per_s, "tracked_features_per_s": threads * tracked_per_frame / per_frame, "repeat": repeat,
+            "solves_only_per_s": threads / per_solve, "ms_track_frame_1core": 1e3 * per_frame, "ms_solve_marg_1core": 1e3 * per_solve, "wall_s": el + tb,
+            "build": "g++ -O3 -march=native -ffp-contract=off (built on this box)" if native else "g++ -O3 -ffp-contract=off (portable build: the native build failed on this box)",
+            "variant_a_one_core_steps_per_s": 1.0 / (per_frame + per_solve),
+            "variant_b": {"threads_lk": ncpu, "threads_marginalisation": 4, "ms_track_frame": 1e3 * b_frame, "ms_solve_marg": 1e3 * b_solve,
+                          "steps_per_s": 1.0 / (b_frame + b_solve), "tracked_features_per_s": (counts[0] / (n_frames - 1)) / b_frame,
+                          "note": "one sequence at a time, the reference's own intra-sequence parallelism; Ceres itself stays single-threaded (estimator.cpp:3306)"}}
 
 
 def pmc_summary():
@@ -214,9 +237,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="independent sequences per GPU")
-    ap.add_argument("--max-cnt", type=int, default=150)
-    ap.add_argument("--min-dist", type=int, default=30)
+    ap.add_argument("--config", type=int, default=1, choices=(1, 2, 4),
+                    help="index into BASELINE.json configs: 1 = 150 features, W = 10 (the configuration the metric is quoted on; default); 2 = 300 features / min_dist 20, "
+                         "W = 10, full HIP path; 4 = 500 features / min_dist 12, W = 20, wheel + GNSS factors (reduced system and kept system in global memory)")
+    ap.add_argument("--batch", type=int, default=None, help="independent sequences per GPU (default 256; 64 for --config 4)")
+    ap.add_argument("--strong", type=int, default=0, help="strong scaling: this many sequences IN TOTAL, split over the ranks (BASELINE.json configs[3]: 64)")
+    ap.add_argument("--distinct", type=int, default=None, help="number of distinct seeded windows (dealt round-robin to the sequences); default all (16 for --config 4)")
+    ap.add_argument("--max-cnt", type=int, default=None)
+    ap.add_argument("--min-dist", type=int, default=None)
     ap.add_argument("--ba-iters", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frontend", action="store_true")
@@ -250,6 +278,18 @@ def main():
     import gfamd
     import shard
     gfamd._chk(gfamd.lib().gf_set_device(device_index))
+    CFG = {1: dict(max_cnt=150, min_dist=30, window=10, gnss=False, batch=256, distinct=None),
+           2: dict(max_cnt=300, min_dist=20, window=10, gnss=False, batch=256, distinct=None),
+           4: dict(max_cnt=500, min_dist=12, window=20, gnss=True, batch=64, distinct=16)}[args.config]
+    args.max_cnt = args.max_cnt or CFG["max_cnt"]
+    args.min_dist = args.min_dist or CFG["min_dist"]
+    args.batch = args.batch or CFG["batch"]
+    args.distinct = args.distinct if args.distinct is not None else CFG["distinct"]
+    WIN, GNSS = CFG["window"], CFG["gnss"]
+    if args.strong:
+        if args.strong % world:
+            raise SystemExit("--strong %d does not divide over %d ranks" % (args.strong, world))
+        args.batch = args.strong // world
     B, K, Wm = args.batch, args.steps, args.warmup
     dt = 1.0 / 15.0
     n_frames = Wm + K + 1 + 4   # + the frames of the isolated tracker passes after the timed region
@@ -260,7 +300,7 @@ def main():
 
     trk = gfamd.FeatureTracker(gfamd.default_cfg(batch=B, max_cnt=args.max_cnt, min_dist=args.min_dist))
     trk.set_profiling(True)
-    est, wins = make_windows(gfamd, B, 1000 + seq0, args.max_cnt)
+    est, wins = make_windows(gfamd, B, 1000 + seq0, args.max_cnt, WIN, GNSS, args.distinct)
     est.upload(wins)
     step = [0]
 
@@ -353,12 +393,16 @@ def main():
         res = {
             "metric": "sliding-window solves/sec + tracked-features/sec, 640x480x10-frame window",
             "value": value, "unit": unit, "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": 1e3 * el_max / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * el_max / K, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "front end u8/s16 fixed point + f32; back end f64", "data": "synthetic",
-            "config": {"workload": "configs[1] (150 features, 10-frame window, visual+IMU+wheel+prior factors, 8 dogleg iterations + MARGIN_OLD marginalisation; "
-                                   "LK 21x21 3 levels + flow-back, Shi-Tomasi top-up) run as %d independent 640x480 RGBD sequences per GPU (the per-GPU share of configs[3]); "
-                                   "every step ends with the all_gather of the newest poses" % B,
-                       "sequences_per_gpu": B, "window": 10, "features": args.max_cnt, "ba_iterations": args.ba_iters},
+            "config": {"workload": "configs[%d] (%d features / min_dist %d, %d-frame window, visual+IMU+wheel%s+prior factors, %d dogleg iterations + MARGIN_OLD marginalisation; "
+                                   "LK 21x21 3 levels + flow-back, Shi-Tomasi top-up) run as %s; every step ends with the all_gather of the newest poses"
+                                   % (args.config, args.max_cnt, args.min_dist, WIN, "+GNSS" if GNSS else "", args.ba_iters,
+                                      ("%d independent 640x480 RGBD sequences in total, %d per GPU (strong scaling)" % (args.strong, B)) if args.strong
+                                      else ("%d independent 640x480 RGBD sequences per GPU (weak scaling)" % B)),
+                       "baseline_config_index": args.config, "sequences_per_gpu": B, "sequences_total": B * world, "window": WIN, "features": args.max_cnt, "min_dist": args.min_dist,
+                       "gnss": GNSS, "distinct_windows": args.distinct or B, "ba_iterations": args.ba_iters,
+                       "reduced_system_in": "global memory (ba_step<true>)" if WIN > 10 or GNSS else "LDS (ba_step<false>)"},
             "solves_per_s": solves / el_max, "tracked_features_per_s": tracked / el_max, "frames_per_s": B * world * K / el_max,
             "output_features_per_s": outf / el_max,
             "gpu_ms_per_step": {"pyramid": st["ms_pyramid"] / K, "lk": st["ms_lk"] / K, "detect": st["ms_detect"] / K, "tracker_total": st["ms_total_gpu"] / K,
@@ -387,7 +431,7 @@ def main():
                                       "bound by the latency of R/16 sequential 16x16 factor+inverse blocks, not by MFMA issue"},
             "ba_summary_seq0": sums[0],
         }
-        if world == 1 and not args.no_e2e and not (args.no_frontend or args.no_backend):
+        if world == 1 and not args.no_e2e and not args.strong and args.config == 1 and not (args.no_frontend or args.no_backend):
             trk.close(); trk = None
             cold = end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist)
             res["end_to_end"] = end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist)   # second pass: host allocations and worker threads warm, as in a running service
@@ -400,11 +444,14 @@ def main():
             nseq = min(8, B)
             cores = min(os.cpu_count() or 1, nseq)
             fh = frames[: min(n_frames, 13), :nseq].cpu().numpy()
-            cb = cpu_baseline(fh, dt, wins[:nseq], cores, args.ba_iters)
+            if args.config != 1:   # heavier windows: bound the sample
+                fh = fh[:5]
+            cb = cpu_baseline(fh, dt, wins[:nseq], cores, args.ba_iters, args.max_cnt, args.min_dist, repeat=4 if args.config == 1 else 1)
             res["cpu_baseline"] = {"value": cb["steps_per_s"] if not args.no_backend else cb["tracked_features_per_s"],
                                    "unit": unit, "cores": cores, "kind": "port",
-                                   "sample": "%d sequences x %d x %d frames (tracker) and %d solve+marginalise per sequence through the CPU oracle, %d threads, one sequence per thread; %.1f s wall, ~%.0f s of CPU work"
-                                             % (nseq, cb["repeat"], fh.shape[0], cb["repeat"] * max(1, fh.shape[0] // 4), cores, cb["wall_s"], cb["wall_s"] * cores),
+                                   "sample": "%d sequences x %d x %d frames (tracker) and %d solve+marginalise per sequence through the CPU oracle (%s), %d threads, one sequence per thread "
+                                             "(variant a x %d cores); then sequence 0 once more as variant b; %.1f s wall, ~%.0f s of CPU work; box has %d host cores"
+                                             % (nseq, cb["repeat"], fh.shape[0], cb["repeat"] * max(1, fh.shape[0] // 4), cb["build"], cores, cores, cb["wall_s"], cb["wall_s"] * cores, os.cpu_count() or 1),
                                    "detail": cb}
         print(json.dumps(res))
     if trk is not None:

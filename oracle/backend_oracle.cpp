@@ -25,10 +25,12 @@
 #include <cfloat>
 #include <cstdio>
 #include <map>
+#include <thread>
 #include <vector>
 
 #include "gf_math.h"
 #include "gf_oracle.h"
+
 
 using namespace gfm;
 
@@ -1091,11 +1093,13 @@ static int marginalize(const gfo_window* w, int mode, int cap_n, int* out_n, int
     if (n > cap_n) return -1;
     DMat A(pos, pos);
     std::vector<double> b(pos, 0.0);
-    for (auto& f : facs) {
+    auto construct = [&](DMat& A, std::vector<double>& b, size_t first, size_t stride) {
+    for (size_t fi = first; fi < facs.size(); fi += stride) {
+        auto& f = facs[fi];
         for (int i = 0; i < f.nb; i++) {
-            const int pi = pos_of[f.id[i]], li = lsize_of(f.id[i] / 4096);
+            const int pi = pos_of.at(f.id[i]), li = lsize_of(f.id[i] / 4096);
             for (int j = i; j < f.nb; j++) {
-                const int pj = pos_of[f.id[j]], lj = lsize_of(f.id[j] / 4096);
+                const int pj = pos_of.at(f.id[j]), lj = lsize_of(f.id[j] / 4096);
                 for (int a = 0; a < li; a++) for (int c = 0; c < lj; c++) {
                     double sacc = 0;
                     for (int r = 0; r < f.nres; r++) sacc += f.J[i][(size_t)r * li + a] * f.J[j][(size_t)r * lj + c];
@@ -1106,6 +1110,16 @@ static int marginalize(const gfo_window* w, int mode, int cap_n, int* out_n, int
             for (int a = 0; a < li; a++) { double sacc = 0; for (int r = 0; r < f.nres; r++) sacc += f.J[i][(size_t)r * li + a] * f.r[r]; b[pi + a] += sacc; }
         }
     }
+    };
+    if (gfo_get_threads() > 1) {   // MARG:232-262: NUM_THREADS = 4 pthreads, factor k to thread k % 4, A += A_thread in thread order
+        const int NT = 4;
+        std::vector<DMat> At; std::vector<std::vector<double>> bt(NT, std::vector<double>(pos, 0.0));
+        for (int t = 0; t < NT; t++) At.emplace_back(pos, pos);
+        std::vector<std::thread> th;
+        for (int t = 0; t < NT; t++) th.emplace_back([&, t] { construct(At[t], bt[t], (size_t)t, (size_t)NT); });
+        for (auto& x : th) x.join();
+        for (int t = 0; t < NT; t++) { for (size_t i = 0; i < A.a.size(); i++) A.a[i] += At[t].a[i]; for (int i = 0; i < pos; i++) b[i] += bt[t][i]; }
+    } else construct(A, b, 0, 1);
     if (g_marg_debug && pos <= g_marg_debug->cap) {
         MargDebug& dbg = *g_marg_debug; dbg.pos = pos; dbg.m = m; dbg.n = n;
         for (int i = 0; i < pos; i++) { for (int j = 0; j < pos; j++) dbg.A[(size_t)i * pos + j] = A(i, j); dbg.b[i] = b[i]; }

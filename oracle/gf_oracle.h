@@ -26,6 +26,11 @@ int gfo_tracker_state(void* h, int* ids, int* track_cnt, float* prev_pts, int ca
 long long gfo_tracker_lk_iters(void* h);
 /* 0: int64 LK sums (parity mode); 1: float-lane accumulation of an x86 OpenCV build (sensitivity measurement only, see tracker_oracle.cpp) */
 void gfo_set_lk_accum(int mode);
+/* CPU-baseline variant (b) of BASELINE.md section 2: n > 1 runs the LK point loop on n threads (OpenCV's parallel_for_ over points; results unchanged)
+ * and the marginalisation's A / b construction on 4 threads, factors dealt round-robin and the four partial systems added in thread order
+ * (marginalization_factor.cpp:150-181, :232-262).  n = 1 (default): one thread, factors summed in list order. */
+void gfo_set_threads(int n);
+int gfo_get_threads(void);
 
 void gfo_pyr_down(const uint8_t* src, int w, int h, uint8_t* dst);
 void gfo_scharr(const uint8_t* src, int w, int h, int16_t* dst);

@@ -31,6 +31,27 @@ def lib():
     return _LIB
 
 
+def use_native():
+    """bench.py's cpu_baseline leg only: switch to the -O3 -march=native build, compiled on THIS machine by `make native`.
+    Returns True when the native library is loaded, False (portable build kept) when it cannot be built here."""
+    global _LIB
+    p = os.path.join(_HERE, "libgf_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "native"], stderr=subprocess.DEVNULL)
+        nat = C.CDLL(p)
+    except (OSError, subprocess.CalledProcessError):
+        return False
+    nat.gfo_tracker_create.restype = C.c_void_p
+    nat.gfo_tracker_lk_iters.restype = C.c_longlong
+    _LIB = nat
+    return True
+
+
+def set_threads(n):
+    """CPU-baseline variant (b): per-point parallel LK on n threads + 4 marginalisation threads (gf_oracle.h)"""
+    lib().gfo_set_threads(int(n))
+
+
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 

@@ -155,14 +155,22 @@ static inline float i64_to_f32(int64_t v) { return (float)(double)v; }  // |v| <
 // scalar float tail x = 16..20; lanes added horizontally at the end.  Mode 1 exists to MEASURE how much the documented int64 choice can
 // change feature ids / status flags / coordinates (tests/test_tracker_oracle.py); it does not pin anything.
 static int g_lk_accum = 0;
+int g_threads = 1;   // gfo_set_threads: per-point parallel LK here, 4 marginalisation threads in backend_oracle.cpp (CPU-baseline variant (b))
 
 // lkpyramid.cpp LKTrackerInvoker::operator() for one pyramid level, all points.
 static void lk_level(const Img8& I, const Deriv& dI, const Img8& J, const P2f* prevPts, P2f* nextPts,
                      uint8_t* status, int npts, int win, int maxCount, double epsilon, int level,
                      int maxLevel, bool useInitialFlow, float minEigThreshold, int64_t* iters_out) {
     const float half = (win - 1) * 0.5f;
-    std::vector<int16_t> Ibuf(win * win), dbuf(win * win * 2);
     const int stepI = I.stride, stepJ = J.stride, dstep = dI.stride;
+    int64_t iters_total = 0;
+    // OpenCV runs this loop as parallel_for_ over the points (lkpyramid.cpp: LKTrackerInvoker); points are independent, so the thread count
+    // (gfo_set_threads, CPU-baseline variant (b) of BASELINE.md section 2; default 1) cannot change a result.
+#pragma omp parallel num_threads(g_threads) if (g_threads > 1) reduction(+ : iters_total)
+    {
+    std::vector<int16_t> Ibuf(win * win), dbuf(win * win * 2);
+    int64_t* iters_out_l = iters_out ? &iters_total : nullptr;
+#pragma omp for schedule(dynamic, 4)
     for (int p = 0; p < npts; p++) {
         P2f prevPt = {prevPts[p].x * (float)(1. / (1 << level)), prevPts[p].y * (float)(1. / (1 << level))};
         P2f nextPt;
@@ -223,7 +231,7 @@ static void lk_level(const Img8& I, const Deriv& dI, const Img8& J, const P2f* p
                 if (level == 0) status[p] = 0;
                 break;
             }
-            if (iters_out) (*iters_out)++;
+            if (iters_out_l) (*iters_out_l)++;
             a = nextPt.x - inx; b = nextPt.y - iny;
             iw00 = cvRoundf((1.f - a) * (1.f - b) * (1 << W_BITS));
             iw01 = cvRoundf(a * (1.f - b) * (1 << W_BITS));
@@ -269,6 +277,8 @@ static void lk_level(const Img8& I, const Deriv& dI, const Img8& J, const P2f* p
             if (inx < -win || inx >= J.cols || iny < -win || iny >= J.rows) status[p] = 0;
         }
     }
+    }
+    if (iters_out) *iters_out += iters_total;
 }
 
 // lkpyramid.cpp SparsePyrLKOpticalFlowImpl::calc, winSize 21x21, minEigThreshold 1e-4
@@ -603,6 +613,8 @@ int gfo_tracker_state(void* h, int* ids, int* track_cnt, float* prev_pts, int ca
 }
 long long gfo_tracker_lk_iters(void* h) { return ((Tracker*)h)->lk_iters; }
 void gfo_set_lk_accum(int mode) { g_lk_accum = mode; }
+void gfo_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int gfo_get_threads(void) { return g_threads; }
 
 void gfo_pyr_down(const uint8_t* src, int w, int h, uint8_t* dst) {
     Img8 s, d; s.create(h, w, 0);

@@ -432,3 +432,24 @@ def test_group_with_gnss_members():
     # the batch and the single-window launches run the same arithmetic (bit-identical states in tests/test_backend_gpu.py); the members' host threads change nothing
     assert worst["p"] < 1e-9 and worst["clk"] < 1e-9 and worst["anc"] < 1e-9, worst
     grp.close()
+
+
+def test_config4_replay_images_w20_gnss():
+    """BASELINE.json configs[4] as one run: 640x480 RGB-D images through the HIP tracker at max_cnt 500 / min_dist 12 into a 20-frame
+    window with IMU + wheel + GNSS factors (raw measurements + broadcast ephemerides, the library's own GNSSVIInitializer), against the oracle pipeline on
+    the same stream (scripts/config4_replay.py).  Up to ~900 tracks live in the FeatureManager and ~9 500 visual factors in a window, which puts the reduced
+    system (440 columns) and the kept system of the marginalisation (155) in global memory (ba_step<true>, ba_marg_finish<true>).  Bars: tracker ids and
+    observations bit-exact at every image, identical decisions / iteration counts at every back-end frame, window poses within 1e-6 m / 1e-6 rad, GNSS
+    states within the bar of test_replay_with_gnss_matches_oracle; the absolute trajectory error against the stream's ground truth is printed."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import config4_replay as C4
+    r = C4.run(product=True, t_move=4.5)
+    w = r["worst"]
+    print("configs[4] replay: %d images, %d back-end frames (%d with gnss_ready), <= %d features / %d visual factors per window, worst deviation %s, "
+          "ATE rmse %.4f m over %.2f m of driving; oracle pipeline %.1f s, HIP pipeline %.1f s (one sequence, synchronous calls)"
+          % (r["images"], r["frames"], r["ready_frames"], r["n_feat_max"], r["n_visual_max"], w, r["ate_rmse"], r["moved_m"], r["t_oracle"], r["t_product"]))
+    assert r["solver_flag"] == EO.NON_LINEAR and r["ready_frames"] >= 15 and r["n_visual_max"] > 5000
+    assert {s[:3] for s in r["seen"]} >= {(1, 0, 0), (1, 0, 1)}, r["seen"]      # aligned windows of both marginalisation kinds were solved
+    assert r["ate_rmse"] < 0.05
+    assert w["p"] < 1e-6 and w["r"] < 1e-6, w
+    assert w["clk"] < 5e-4 and w["anc"] < 5e-4 and w["ecef"] < 5e-4, w

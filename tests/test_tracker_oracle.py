@@ -149,3 +149,31 @@ def test_int64_accumulation_against_float_lane_accumulation():
     r = mod.compare(dict(max_cnt=150, min_dist=30), seed=1000, nframes=6)
     assert r["frames_with_different_id_lists"] == 0 and r["ids_in_both"] == r["observations"]
     assert 0 < r["coordinates_changed"] and r["largest_pixel_change"] < 0.01
+
+
+def test_thread_count_of_the_cpu_baseline_variant_does_not_change_results(oracle):
+    """BASELINE.md section 2 variant (b): per-point parallel LK (OpenCV's parallel_for_ over points) gives the same bits as one thread; the four
+    marginalisation threads (marginalization_factor.cpp:232-262: factor k to thread k % 4, partial systems added in thread order) give the same
+    prior up to the summation order of A and b."""
+    import synth_window as SW
+    frames = synth.tracker_sequence(1003, 4)
+    depth = np.full(frames[0].shape, 1500, np.uint16)
+    out = []
+    for n in (1, 4):
+        oracle.set_threads(n)
+        try:
+            tr = oracle.Tracker(oracle.default_cfg())
+            res = [tr.track(0.0666 * k, f, depth) for k, f in enumerate(frames)]
+            w = SW.make_window(5, oracle)
+            oracle.ba_solve(w, 4)
+            pr = oracle.ba_marginalize(w, 0)
+        finally:
+            oracle.set_threads(1)
+        out.append((res, pr))
+    for (i1, o1), (i4, o4) in zip(out[0][0], out[1][0]):
+        assert np.array_equal(i1, i4) and np.array_equal(o1.view(np.uint64), o4.view(np.uint64))
+    p1, p4 = out[0][1], out[1][1]
+    n = p1["n"]
+    assert p4["n"] == n and list(p1["block_id"]) == list(p4["block_id"])
+    H1, H4 = p1["J"].reshape(n, n).T @ p1["J"].reshape(n, n), p4["J"].reshape(n, n).T @ p4["J"].reshape(n, n)
+    assert np.abs(H1 - H4).max() <= 1e-9 * np.abs(H1).max()
