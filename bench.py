@@ -126,7 +126,7 @@ def cpu_baseline(frames_host, dt, wins, threads, ba_iters, max_cnt, min_dist, re
     steps_per_s = threads / (per_frame + per_solve)
     tracked_per_frame = sum(counts) / (nseq * repeat * (n_frames - 1))
     # variant (b): sequence 0 alone, LK over all cores + 4 marginalisation threads
-    ncpu = os.cpu_count() or 1
+    ncpu = min(os.cpu_count() or 1, 8)   # "per-point parallel LK over all 8 cores"; 150-500 points do not feed more threads than that
     oracle_py.set_threads(ncpu)
     t_track[0] = t_ba[0] = 0.0; n_ba[0] = 0; counts[0] = 0
     tb0 = time.perf_counter()
@@ -358,6 +358,11 @@ def main():
                "jtj_ms": bi["ms_jtj"] / max(bi["jtj_launches"], 1), "step_ms": bi["ms_step"] / max(bi["step_launches"], 1),
                "ba_solve_ms": bi["ms_solve"] / 3, "ba_marginalize_ms": bi["ms_marginalize"] / 3}
 
+    # the gather keeps the global sequence order: this rank's block of the gathered poses is what it exported
+    own_block_ok = True
+    if not args.no_backend:
+        own_block_ok = bool(torch.equal(gathered[0][rank * B:(rank + 1) * B], newest))
+        assert own_block_ok, "rank %d: its block of the gathered poses differs from what it exported" % rank
     tot = torch.tensor([el, float(st["tracked_features"]), float(st["output_features"]), float(bs["solves"])], dtype=torch.float64, device=dev)
     if dist is not None:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -403,6 +408,9 @@ def main():
                        "baseline_config_index": args.config, "sequences_per_gpu": B, "sequences_total": B * world, "window": WIN, "features": args.max_cnt, "min_dist": args.min_dist,
                        "gnss": GNSS, "distinct_windows": args.distinct or B, "ba_iterations": args.ba_iters,
                        "reduced_system_in": "global memory (ba_step<true>)" if WIN > 10 or GNSS else "LDS (ba_step<false>)"},
+            "pose_gather": {"rows": int(gathered[0].shape[0]) if gathered[0] is not None else 0, "bytes_per_step": 56 * B * world, "own_block_matches_export": own_block_ok,
+                            "backend": "none (1 rank)" if dist is None else ("gloo (GF_BENCH_SINGLE_DEVICE test mode)" if single else "nccl (RCCL)")},
+            "host_threads_per_rank": int(os.environ["GF_HOST_THREADS"]),
             "solves_per_s": solves / el_max, "tracked_features_per_s": tracked / el_max, "frames_per_s": B * world * K / el_max,
             "output_features_per_s": outf / el_max,
             "gpu_ms_per_step": {"pyramid": st["ms_pyramid"] / K, "lk": st["ms_lk"] / K, "detect": st["ms_detect"] / K, "tracker_total": st["ms_total_gpu"] / K,

@@ -549,6 +549,12 @@ struct gf_estimator {
     int frame_count = 0, solver_flag = INITIAL, marginalization_flag = MARGIN_OLD, sum_of_back = 0, sum_of_front = 0;
     bool first_imu = false, first_wheel = false, initFirstPoseFlag = false;
     V3 acc_0 = v3(0, 0, 0), gyr_0 = v3(0, 0, 0), vel_0_wheel = v3(0, 0, 0), gyr_0_wheel = v3(0, 0, 0), latest_vel_wheel_0 = v3(0, 0, 0);
+    // IMU- / wheel-rate propagation of the newest state (estimator.h:239-242, :354-356): what pubLatestOdometry / pubWheelLatestOdometry publish.
+    // Uninitialised in the reference until the first updateLatestStates (UB): zero / identity here.  Rotations are kept as matrices.
+    double latest_time = 0, latest_time_wheel = 0, latest_sx = 1, latest_sy = 1, latest_sw = 1;
+    V3 latest_P = v3(0, 0, 0), latest_V = v3(0, 0, 0), latest_Ba = v3(0, 0, 0), latest_Bg = v3(0, 0, 0), latest_acc_0 = v3(0, 0, 0), latest_gyr_0 = v3(0, 0, 0);
+    V3 latest_P_wheel = v3(0, 0, 0), latest_V_wheel = v3(0, 0, 0), latest_gyr_wheel_0 = v3(0, 0, 0);
+    M3 latest_Q = m3_identity(), latest_Q_wheel = m3_identity();
     std::vector<std::shared_ptr<ImuPre>> pre_integrations; std::vector<std::shared_ptr<WheelPre>> pre_integrations_wheel;
     std::shared_ptr<ImuPre> tmp_pre_integration; std::shared_ptr<WheelPre> tmp_wheel_pre_integration;
     std::map<double, ImageFrame> all_image_frame;
@@ -914,6 +920,42 @@ struct gf_estimator {
         }
         acc_0 = linear_acceleration; gyr_0 = angular_velocity;
     }
+    void fastPredictIMU(double t, V3 linear_acceleration, V3 angular_velocity) {  // EST:4014-4028
+        const double dt = t - latest_time;
+        latest_time = t;
+        const V3 un_acc_0 = latest_Q * (latest_acc_0 - latest_Ba) - g;
+        const V3 un_gyr = (latest_gyr_0 + angular_velocity) * 0.5 - latest_Bg;
+        latest_Q = latest_Q * qmat(deltaQ(un_gyr * dt));
+        const V3 un_acc_1 = latest_Q * (linear_acceleration - latest_Ba) - g;
+        const V3 un_acc = (un_acc_0 + un_acc_1) * 0.5;
+        latest_P = latest_P + latest_V * dt + un_acc * (0.5 * dt * dt);
+        latest_V = latest_V + un_acc * dt;
+        latest_acc_0 = linear_acceleration; latest_gyr_0 = angular_velocity;
+    }
+    void fastPredictWheel(double t, V3 linear_velocity, V3 angular_velocity) {  // EST:4079-4093 (un_gyr from the IMU's latest_gyr_0, as written there)
+        const double dt = t - latest_time_wheel;
+        latest_time_wheel = t;
+        const V3 un_gyr = (latest_gyr_0 + angular_velocity) * (0.5 * latest_sw);
+        const V3 un_vel_0 = latest_Q_wheel * latest_vel_wheel_0;
+        latest_Q_wheel = latest_Q_wheel * qmat(deltaQ(un_gyr * dt));
+        const V3 s = latest_Q_wheel * linear_velocity + un_vel_0;
+        latest_V_wheel = v3(0.5 * latest_sx * s.x, 0.5 * latest_sy * s.y, 0.5 * s.z);
+        latest_P_wheel = latest_P_wheel + latest_V_wheel * dt;
+        latest_vel_wheel_0 = linear_velocity; latest_gyr_wheel_0 = angular_velocity;   // shared with processWheel (SURVEY.md 8a quirk list, DESIGN.md: quirk 15)
+    }
+    void updateLatestStates() {  // EST:4141-4198
+        const int fc = frame_count;
+        latest_time = Headers[fc] + td;
+        latest_P = Ps[fc]; latest_Q = Rs[fc]; latest_V = Vs[fc]; latest_Ba = Bas[fc]; latest_Bg = Bgs[fc];
+        latest_acc_0 = acc_0; latest_gyr_0 = gyr_0;
+        for (size_t i = 0; i < accBuf.size() && i < gyrBuf.size(); i++) fastPredictIMU(accBuf[i].first, accBuf[i].second, gyrBuf[i].second);
+        latest_time_wheel = Headers[fc] + td - td_wheel;
+        latest_Q_wheel = Rs[fc] * rio;
+        latest_P_wheel = Rs[fc] * tio + Ps[fc];
+        latest_sx = sx; latest_sy = sy; latest_sw = sw;
+        latest_vel_wheel_0 = vel_0_wheel; latest_gyr_wheel_0 = gyr_0_wheel;
+        for (size_t i = 0; i < wheelVelBuf.size() && i < wheelGyrBuf.size(); i++) fastPredictWheel(wheelVelBuf[i].first, wheelVelBuf[i].second, wheelGyrBuf[i].second);
+    }
     void processWheel(double t, double dt, V3 linear_velocity, V3 angular_velocity) {  // EST:786-842
         if (!first_wheel) { first_wheel = true; vel_0_wheel = linear_velocity; gyr_0_wheel = angular_velocity; }
         if (!pre_integrations_wheel[frame_count]) pre_integrations_wheel[frame_count] = std::make_shared<WheelPre>(vel_0_wheel, gyr_0_wheel, sx, sy, sw, td_wheel);
@@ -921,6 +963,7 @@ struct gf_estimator {
             pre_integrations_wheel[frame_count]->push_back(dt, linear_velocity, angular_velocity);
             tmp_wheel_pre_integration->push_back(dt, linear_velocity, angular_velocity);
             const int j = frame_count;
+            latest_time_wheel = t;
             const V3 un_gyr = (gyr_0_wheel + angular_velocity) * 0.5;
             const V3 un_vel_0 = Rs[j] * latest_vel_wheel_0;
             if (!systemstationary) {
@@ -929,7 +972,7 @@ struct gf_estimator {
                 Ps[j] = Ps[j] + Vs[j] * dt;
             }
             if (systemstationary) Vs[j] = v3(0, 0, 0);
-            latest_vel_wheel_0 = linear_velocity;
+            latest_vel_wheel_0 = linear_velocity; latest_gyr_wheel_0 = angular_velocity;
             dP_wheel.x -= dt * Vs[j].y; dP_wheel.y += dt * Vs[j].x; dP_wheel.z -= dt * Vs[j].z;
         }
         vel_0_wheel = linear_velocity; gyr_0_wheel = angular_velocity;
@@ -1261,6 +1304,7 @@ struct gf_estimator {
                 } else {
                     if (int rc = optimization()) return rc;
                     slideWindow();
+                    updateLatestStates();   // EST:1030-1033: only on the branch without a successful initialisation
                 }
             }
             if (frame_count < WINDOW_SIZE) {
@@ -1287,6 +1331,7 @@ struct gf_estimator {
             slideWindow();
             f_manager.removeFailures();
             last_R = Rs[WINDOW_SIZE]; last_P = Ps[WINDOW_SIZE]; last_R0 = Rs[0]; last_P0 = Ps[0];
+            updateLatestStates();   // EST:1161
         }
         return GF_OK;
     }
@@ -1661,12 +1706,14 @@ int gf_estimator_set_result_path(gf_estimator* e, const char* vio_txt) {   // VI
 int gf_estimator_input_imu(gf_estimator* e, double t, const double* acc, const double* gyr) {  // Estimator::inputIMU EST:330-346
     if (!e || !acc || !gyr) return gf::set_err(GF_ERR_INVALID, "null argument");
     e->accBuf.emplace_back(t, arr3(acc)); e->gyrBuf.emplace_back(t, arr3(gyr));
+    e->fastPredictIMU(t, arr3(acc), arr3(gyr));   // EST:332: latest_P / latest_Q / latest_V for pubLatestOdometry (gf_estimator_get_latest)
     if (e->cfg.multiple_thread && !e->featureBuf.empty()) return e->drain();   // a frame was waiting for this sample ("wait for imu ...", EST:551-560)
     return GF_OK;
 }
 int gf_estimator_input_wheel(gf_estimator* e, double t, const double* vel, const double* gyr) {  // Estimator::inputWheel EST:347-360
     if (!e || !vel || !gyr) return gf::set_err(GF_ERR_INVALID, "null argument");
     e->wheelVelBuf.emplace_back(t, arr3(vel)); e->wheelGyrBuf.emplace_back(t, arr3(gyr));
+    e->fastPredictWheel(t, arr3(vel), arr3(gyr));   // EST:363-366
     if (e->cfg.multiple_thread && !e->featureBuf.empty()) return e->drain();   // "wait for wheel ...", EST:562-573
     return GF_OK;
 }
@@ -1800,6 +1847,12 @@ int gf_estimator_get_state(gf_estimator* e, double* Ps, double* Rs, double* Vs, 
     }
     return GF_OK;
 }
+int gf_estimator_get_latest(gf_estimator* e, double* imu, double* wheel) {
+    if (!e) return gf::set_err(GF_ERR_INVALID, "null handle");
+    if (imu) { imu[0] = e->latest_time; memcpy(imu + 1, &e->latest_P.x, 24); memcpy(imu + 4, e->latest_Q.m, 72); memcpy(imu + 13, &e->latest_V.x, 24); }
+    if (wheel) { wheel[0] = e->latest_time_wheel; memcpy(wheel + 1, &e->latest_P_wheel.x, 24); memcpy(wheel + 4, e->latest_Q_wheel.m, 72); memcpy(wheel + 13, &e->latest_V_wheel.x, 24); }
+    return GF_OK;
+}
 int gf_estimator_set_state(gf_estimator* e, int frame_count, int solver_flag, const double* Ps, const double* Rs, const double* Vs, const double* Bas, const double* Bgs) {
     if (!e || frame_count < 0 || frame_count > e->WINDOW_SIZE) return gf::set_err(GF_ERR_INVALID, "bad argument");
     e->frame_count = frame_count; e->solver_flag = solver_flag;
@@ -1858,6 +1911,7 @@ int gf_estimator_debug(gf_estimator* e, const char* op, const double* in, int n_
     if (s == "triangulate") e->f_manager.triangulate(e->Ps.data(), e->Rs.data(), e->tic, e->ric);
     else if (s == "triangulateWithDepth") e->f_manager.triangulateWithDepth(e->Ps.data(), e->Rs.data(), e->tic, e->ric);
     else if (s == "removeBack") e->f_manager.removeBack();
+    else if (s == "updateLatestStates") e->updateLatestStates();
     else if (s == "removeFront" && n_in >= 1) e->f_manager.removeFront((int)in[0]);
     else if (s == "removeFailures") e->f_manager.removeFailures();
     else if (s == "removeBackShiftDepth" && n_in >= 24) e->f_manager.removeBackShiftDepth(arr9(in), arr3(in + 9), arr9(in + 12), arr3(in + 21));

@@ -621,6 +621,13 @@ class SlidingWindowEstimator:
         assert a.size == 3 and d.size == 4
         _chk(lib().gf_estimator_set_gnss_alignment(self.h, _p(a, C.c_double), C.c_double(yaw_enu_local), _p(d, C.c_double), C.c_double(rcv_ddt)))
 
+    def latest(self):
+        """latest_time / latest_P / latest_Q / latest_V and the wheel counterparts (estimator.h:239-242, :354-356)"""
+        a, b = np.zeros(16), np.zeros(16)
+        _chk(lib().gf_estimator_get_latest(self.h, _p(a, C.c_double), _p(b, C.c_double)))
+        return dict(time=a[0], P=a[1:4].copy(), Q=a[4:13].reshape(3, 3).copy(), V=a[13:16].copy(),
+                    time_wheel=b[0], P_wheel=b[1:4].copy(), Q_wheel=b[4:13].reshape(3, 3).copy(), V_wheel=b[13:16].copy())
+
     def gnss_state(self):
         N = self.W + 1
         info, dt, ddt, yaw, anc, ecef, enu = np.zeros(8, np.int32), np.zeros((N, 4)), np.zeros(N), C.c_double(0), np.zeros(3), np.zeros(3), np.zeros(3)

@@ -47,6 +47,24 @@ class Estimator {
     double yaw_enu_local = 0;
     std::vector<double> para_rcv_dt, para_rcv_ddt;   // (WINDOW_SIZE + 1) * 4, (WINDOW_SIZE + 1)
     std::vector<std::pair<double, Vec3>> wheelxyztBuf;   // estimator.h:204
+    // IMU- / wheel-rate state for pubLatestOdometry / pubWheelLatestOdometry (estimator.h:239-242, :354-356; fastPredictIMU estimator.cpp:4014-4028,
+    // fastPredictWheel :4079-4093, updateLatestStates :4141-4198): refreshed after every inputIMU / inputWheel and after every frame
+    double latest_time = 0, latest_time_wheel = 0;
+    Vec3 latest_P{}, latest_V{}, latest_P_wheel{}, latest_V_wheel{};
+#ifdef GF_WITH_EIGEN
+    Eigen::Quaterniond latest_Q{1, 0, 0, 0}, latest_Q_wheel{1, 0, 0, 0};
+#else
+    Mat3 latest_Q{{1, 0, 0, 0, 1, 0, 0, 0, 1}}, latest_Q_wheel{{1, 0, 0, 0, 1, 0, 0, 0, 1}};   // rotation matrices, row-major
+#endif
+    // plane parameters (estimator.h:216-217): only initPlane (USE_PLANE, estimator.cpp:1537-1554) and the plane factor write them; `plane: 1` is outside the
+    // built path (gf_estimator_cfg_from_yaml refuses it), so they keep the values clearState gives them (estimator.cpp:123-124) for the publishers that read them
+#ifdef GF_WITH_EIGEN
+    Mat3 rpw = Mat3::Identity();
+#else
+    Mat3 rpw{{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+#endif
+    double zpw = 0;
+    double diff_t_gnss_local = 0;                        // estimator.h:310: set by inputGNSSTimeDiff / cfg.gnss_local_time_diff
 
     Estimator() { gf_estimator_default_cfg(&cfg); }
     ~Estimator() { if (h_) gf_estimator_destroy(h_); }
@@ -68,11 +86,13 @@ class Estimator {
         need();
         const double a[3] = {linearAcceleration[0], linearAcceleration[1], linearAcceleration[2]}, g[3] = {angularVelocity[0], angularVelocity[1], angularVelocity[2]};
         check(gf_estimator_input_imu(h_, t, a, g));
+        refreshLatest();     // estimator.cpp:332-335: the caller publishes latest_P / latest_Q / latest_V right after
     }
     void inputWheel(double t, const Vec3& linearVelocity, const Vec3& angularVelocity) {
         need();
         const double v[3] = {linearVelocity[0], linearVelocity[1], linearVelocity[2]}, g[3] = {angularVelocity[0], angularVelocity[1], angularVelocity[2]};
         check(gf_estimator_input_wheel(h_, t, v, g));
+        refreshLatest();     // estimator.cpp:363-366
     }
     // inputGNSS (estimator.h:99): one epoch of L1 observations with the satellite states their ephemerides give (gf_gnss_obs); inputGNSSTimeDiff (:100);
     // setGNSSAlignment: the result of GNSSVIInitializer, applied by the library where the reference runs GNSSVIAlign (estimator.cpp:1928-2043)
@@ -81,7 +101,7 @@ class Estimator {
     void inputGNSSRaw(double t, const std::vector<gf_gnss_raw_obs>& meas) { need(); check(gf_estimator_input_gnss_raw(h_, t, meas.data(), (int)meas.size())); }
     void inputEphem(const gf_gnss_ephem& eph) { need(); check(gf_estimator_input_ephem(h_, &eph)); }                 // estimator.h:97 (GPS / Galileo / BeiDou)
     void inputEphem(const gf_gnss_glo_ephem& geph) { need(); check(gf_estimator_input_glo_ephem(h_, &geph)); }      // (GLONASS)
-    void inputGNSSTimeDiff(double t_diff) { need(); check(gf_estimator_input_gnss_time_diff(h_, t_diff)); }
+    void inputGNSSTimeDiff(double t_diff) { need(); check(gf_estimator_input_gnss_time_diff(h_, t_diff)); diff_t_gnss_local = t_diff; }
     void inputIonoParams(double /*ts*/, const std::vector<double>& iono_params) { need(); if (iono_params.size() != 8) return; check(gf_estimator_input_iono_params(h_, iono_params.data())); }
     void setGNSSAlignment(const Vec3& anc_ecef, double yaw_enu_local, const double rcv_dt[4], double rcv_ddt) {
         need();
@@ -142,7 +162,19 @@ class Estimator {
 #endif
         return m;
     }
+    void refreshLatest() {
+        double a[16], b[16];
+        check(gf_estimator_get_latest(h_, a, b));
+        latest_time = a[0]; latest_P = v3(a + 1); latest_V = v3(a + 13); latest_time_wheel = b[0]; latest_P_wheel = v3(b + 1); latest_V_wheel = v3(b + 13);
+#ifdef GF_WITH_EIGEN
+        latest_Q = Eigen::Quaterniond(m3(a + 4)); latest_Q_wheel = Eigen::Quaterniond(m3(b + 4));
+#else
+        latest_Q = m3(a + 4); latest_Q_wheel = m3(b + 4);
+#endif
+    }
     void refresh() {
+        refreshLatest();
+        if (cfg.gnss_enable && diff_t_gnss_local == 0) diff_t_gnss_local = cfg.gnss_local_time_diff;
         const int N = cfg.window_size + 1;
         std::vector<double> P(3 * N), R(9 * N), V(3 * N), Ba(3 * N), Bg(3 * N);
         Headers.assign(N, 0.0);

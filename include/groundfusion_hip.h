@@ -388,6 +388,12 @@ int gf_estimator_set_state(gf_estimator* h, int frame_count, int solver_flag, co
                            const double* Bas, const double* Bgs);
 int gf_estimator_get_features(gf_estimator* h, int cap, int* id, int* start_frame, int* n_obs, double* estimated_depth, int* estimate_flag,
                               int* solve_flag, int* n);
+/* latest_time, latest_P, latest_Q, latest_V (estimator.h:354-356) and their wheel counterparts (estimator.h:239-242): the newest window state propagated
+ * through every IMU / wheel sample received since (fastPredictIMU estimator.cpp:4014-4028 inside inputIMU :332, fastPredictWheel :4079-4093 inside inputWheel :363,
+ * re-anchored by updateLatestStates :4141-4198 after every optimised frame) -- what pubLatestOdometry / pubWheelLatestOdometry publish at sensor rate.
+ * imu / wheel: 16 doubles each = time, P[3], rotation matrix [9] (row-major), V[3]; either may be NULL.  Before the first optimised frame the reference
+ * publishes uninitialised members; here they start at zero / identity. */
+int gf_estimator_get_latest(gf_estimator* h, double* imu, double* wheel);
 /* predictPtsInNextFrame / removeOutliers feedback of the last processImage (estimator.cpp:1132-1136) */
 int gf_estimator_get_feedback(gf_estimator* h, int cap, int* predict_ids, double* predict_xyz, int* n_predict, int* remove_ids, int* n_remove);
 int gf_estimator_get_prior(gf_estimator* h, int cap_n, int cap_blocks, int* n, int* nblocks, int* block_id, double* J, double* r);

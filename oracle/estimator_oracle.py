@@ -654,6 +654,11 @@ class Estimator:
         self.frame_count, self.solver_flag, self.marginalization_flag = 0, INITIAL, MARGIN_OLD
         self.first_imu = self.first_wheel = self.initFirstPoseFlag = False
         self.acc_0, self.gyr_0, self.vel_0_wheel, self.gyr_0_wheel, self.latest_vel_wheel_0 = (np.zeros(3) for _ in range(5))
+        self.latest_time = self.latest_time_wheel = 0.0
+        self.latest_P, self.latest_V, self.latest_Ba, self.latest_Bg, self.latest_acc_0, self.latest_gyr_0 = (np.zeros(3) for _ in range(6))
+        self.latest_P_wheel, self.latest_V_wheel, self.latest_gyr_wheel_0 = (np.zeros(3) for _ in range(3))
+        self.latest_Q, self.latest_Q_wheel = np.eye(3), np.eye(3)
+        self.latest_sx = self.latest_sy = self.latest_sw = 1.0
         self.pre_integrations = [None] * (W + 1)
         self.pre_integrations_wheel = [None] * (W + 1)
         self.tmp_pre_integration = self.tmp_wheel_pre_integration = None
@@ -869,12 +874,14 @@ class Estimator:
     def inputIMU(self, t, acc, gyr):  # EST:330-346
         self.accBuf.append((t, np.array(acc, float)))
         self.gyrBuf.append((t, np.array(gyr, float)))
+        self.fastPredictIMU(t, np.array(acc, float), np.array(gyr, float))   # what pubLatestOdometry publishes at IMU rate (EST:332-335)
         if self.cfg["multiple_thread"] and self.featureBuf:   # the waiting processThread ("wait for imu ...", EST:551-560), made deterministic
             self._drain()
 
     def inputWheel(self, t, vel, gyr):  # EST:347-360
         self.wheelVelBuf.append((t, np.array(vel, float)))
         self.wheelGyrBuf.append((t, np.array(gyr, float)))
+        self.fastPredictWheel(t, np.array(vel, float), np.array(gyr, float))   # EST:363-366; shares latest_vel_wheel_0 with processWheel (quirk 15)
         if self.cfg["multiple_thread"] and self.featureBuf:   # "wait for wheel ...", EST:562-573
             self._drain()
 
@@ -981,6 +988,47 @@ class Estimator:
             self.dP_imu = self.dP_imu + dt * self.Vs[fc] + 0.5 * dt * dt * un_acc
         self.acc_0, self.gyr_0 = acc.copy(), gyr.copy()
 
+    # ---- IMU- / wheel-rate propagation of the newest state for the odometry publishers (EST:4014-4028, :4079-4093, :4141-4198).  The members are
+    # uninitialised in the reference until the first updateLatestStates (UB); zero / identity here.
+    def fastPredictIMU(self, t, acc, gyr):  # EST:4014-4028
+        dt = t - self.latest_time
+        self.latest_time = t
+        un_acc_0 = self.latest_Q @ (self.latest_acc_0 - self.latest_Ba) - self.g
+        un_gyr = 0.5 * (self.latest_gyr_0 + gyr) - self.latest_Bg
+        self.latest_Q = self.latest_Q @ deltaQ_R(un_gyr * dt)
+        un_acc_1 = self.latest_Q @ (acc - self.latest_Ba) - self.g
+        un_acc = 0.5 * (un_acc_0 + un_acc_1)
+        self.latest_P = self.latest_P + dt * self.latest_V + 0.5 * dt * dt * un_acc
+        self.latest_V = self.latest_V + dt * un_acc
+        self.latest_acc_0, self.latest_gyr_0 = acc.copy(), gyr.copy()
+
+    def fastPredictWheel(self, t, vel, gyr):  # EST:4079-4093 (un_gyr is built from the IMU's latest_gyr_0, as written there)
+        dt = t - self.latest_time_wheel
+        self.latest_time_wheel = t
+        un_gyr = 0.5 * self.latest_sw * (self.latest_gyr_0 + gyr)
+        un_vel_0 = self.latest_Q_wheel @ self.latest_vel_wheel_0
+        sv = np.array([self.latest_sx, self.latest_sy, 1.0])
+        self.latest_Q_wheel = self.latest_Q_wheel @ deltaQ_R(un_gyr * dt)
+        self.latest_V_wheel = 0.5 * sv * (self.latest_Q_wheel @ vel + un_vel_0)
+        self.latest_P_wheel = self.latest_P_wheel + dt * self.latest_V_wheel
+        self.latest_vel_wheel_0, self.latest_gyr_wheel_0 = vel.copy(), gyr.copy()
+
+    def updateLatestStates(self):  # EST:4141-4198
+        fc = self.frame_count
+        self.latest_time = self.Headers[fc] + self.td
+        self.latest_P, self.latest_Q, self.latest_V = self.Ps[fc].copy(), self.Rs[fc].copy(), self.Vs[fc].copy()
+        self.latest_Ba, self.latest_Bg = self.Bas[fc].copy(), self.Bgs[fc].copy()
+        self.latest_acc_0, self.latest_gyr_0 = self.acc_0.copy(), self.gyr_0.copy()
+        for (t, a), (_, w) in zip(list(self.accBuf), list(self.gyrBuf)):
+            self.fastPredictIMU(t, a, w)
+        self.latest_time_wheel = self.Headers[fc] + self.td - self.td_wheel
+        self.latest_Q_wheel = self.Rs[fc] @ self.rio
+        self.latest_P_wheel = self.Rs[fc] @ self.tio + self.Ps[fc]
+        self.latest_sx, self.latest_sy, self.latest_sw = self.sx, self.sy, self.sw
+        self.latest_vel_wheel_0, self.latest_gyr_wheel_0 = self.vel_0_wheel.copy(), self.gyr_0_wheel.copy()
+        for (t, v), (_, w) in zip(list(self.wheelVelBuf), list(self.wheelGyrBuf)):
+            self.fastPredictWheel(t, v, w)
+
     def processWheel(self, t, dt, vel, gyr):  # EST:786-842
         if not self.first_wheel:
             self.first_wheel = True
@@ -991,6 +1039,7 @@ class Estimator:
         if fc != 0:
             self.pre_integrations_wheel[fc].push_back(dt, vel, gyr)
             self.tmp_wheel_pre_integration.push_back(dt, vel, gyr)
+            self.latest_time_wheel = t
             un_gyr = 0.5 * (self.gyr_0_wheel + gyr)
             un_vel_0 = self.Rs[fc] @ self.latest_vel_wheel_0
             if not self.systemstationary:
@@ -999,7 +1048,7 @@ class Estimator:
                 self.Ps[fc] = self.Ps[fc] + dt * self.Vs[fc]
             else:
                 self.Vs[fc] = np.zeros(3)
-            self.latest_vel_wheel_0 = vel.copy()
+            self.latest_vel_wheel_0, self.latest_gyr_wheel_0 = vel.copy(), gyr.copy()
             V = self.Vs[fc]
             self.dP_wheel = self.dP_wheel + np.array([-dt * V[1], dt * V[0], -dt * V[2]])
         self.vel_0_wheel, self.gyr_0_wheel = vel.copy(), gyr.copy()
@@ -1229,6 +1278,8 @@ class Estimator:
                 if result:
                     self._after_optimization_gnss()
                 self.slideWindow()
+                if not result:
+                    self.updateLatestStates()   # EST:1030-1033: only on the branch without a successful initialisation
             if self.frame_count < self.W:
                 self.frame_count += 1
                 k = self.frame_count
@@ -1255,6 +1306,7 @@ class Estimator:
                     self.tracker.set_prediction(pid, np.array([self.predictPts[i] for i in pid], float).reshape(-1, 3))
             self.slideWindow()
             self.f_manager.removeFailures()
+            self.updateLatestStates()   # EST:1161
 
     # ---- optimisation
     def vector2double(self):  # EST:2276-2353

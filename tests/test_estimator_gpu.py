@@ -52,6 +52,13 @@ def compare_frame(est_o, est_p, worst, tag):
     worst["p"] = max(worst["p"], float(np.abs(s["Ps"] - np.array(est_o.Ps)).max()))
     worst["r"] = max(worst["r"], rot_angle(s["Rs"], est_o.Rs))
     worst["v"] = max(worst["v"], float(np.abs(s["Vs"] - np.array(est_o.Vs)).max()))
+    # what pubLatestOdometry / pubWheelLatestOdometry read (updateLatestStates estimator.cpp:4141-4198 after the frame, fastPredictIMU / fastPredictWheel per sample)
+    lt = est_p.latest()
+    assert abs(lt["time"] - est_o.latest_time) < 1e-12 and abs(lt["time_wheel"] - est_o.latest_time_wheel) < 1e-12, tag
+    dl = max(float(np.abs(lt["P"] - est_o.latest_P).max()), float(np.abs(lt["V"] - est_o.latest_V).max()), float(np.abs(lt["Q"] - est_o.latest_Q).max()),
+             float(np.abs(lt["P_wheel"] - est_o.latest_P_wheel).max()), float(np.abs(lt["V_wheel"] - est_o.latest_V_wheel).max()), float(np.abs(lt["Q_wheel"] - est_o.latest_Q_wheel).max()))
+    worst["latest"] = max(worst.get("latest", 0.0), dl)
+    assert dl < 2e-6, (tag, dl)
     return s
 
 

@@ -271,3 +271,40 @@ def test_gnss_intake_during_the_fill_phase_matches_oracle():
         plain.inputGNSS(*st.gnss_epoch(0.5))
     with pytest.raises(gfamd.GfError):
         gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(gnss_enable=1, gnss_ddt_sigma=0.0))
+
+
+def _compare_latest(est_o, est_p, tol):
+    l = est_p.latest()
+    for k, v in (("time", est_o.latest_time), ("P", est_o.latest_P), ("Q", est_o.latest_Q), ("V", est_o.latest_V), ("time_wheel", est_o.latest_time_wheel),
+                 ("P_wheel", est_o.latest_P_wheel), ("Q_wheel", est_o.latest_Q_wheel), ("V_wheel", est_o.latest_V_wheel)):
+        np.testing.assert_allclose(l[k], v, rtol=0, atol=tol * max(1.0, float(np.abs(v).max())), err_msg=k)
+
+
+def test_latest_states_at_sensor_rate_match_oracle():
+    """latest_P / latest_Q / latest_V and the wheel counterparts (estimator.h:239-242, :354-356): fastPredictIMU inside inputIMU (estimator.cpp:332, :4014-4028),
+    fastPredictWheel inside inputWheel (:363, :4079-4093; it integrates the IMU's latest_gyr_0, as written there) and the re-anchoring of
+    updateLatestStates (:4141-4198: newest window state, then every sample still queued), checked after EVERY sample the way pubLatestOdometry would read them."""
+    st, est_o, est_p, k, tp = fill_window(5)
+    _seed_truth(st, est_o, est_p)
+    est_o.updateLatestStates()
+    est_p.debug("updateLatestStates")
+    _compare_latest(est_o, est_p, 1e-13)
+    assert est_o.latest_time == est_o.accBuf[-1][0] and est_o.latest_time_wheel == est_o.wheelVelBuf[-1][0]   # propagated through the queued samples
+    ev = [(float(t), 0, i) for i, t in enumerate(st.imu_t) if tp < t <= tp + 0.3] + [(float(t), 1, i) for i, t in enumerate(st.wheel_t) if tp < t <= tp + 0.3]
+    n = 0
+    for t, kind, i in sorted(ev):
+        for e in (est_o, est_p):
+            if kind == 0:
+                e.inputIMU(t, st.imu_acc[i], st.imu_gyr[i])
+            else:
+                e.inputWheel(t, st.wheel_vel[i], st.wheel_gyr[i])
+        _compare_latest(est_o, est_p, 1e-12)
+        n += 1
+    assert n > 60 and np.linalg.norm(est_o.latest_P - est_o.Ps[est_o.frame_count]) > 1e-3 and np.linalg.norm(est_o.latest_P_wheel) > 0
+    # the samples received since are still queued: re-anchoring replays them and lands on the same state
+    before = est_p.latest()
+    est_o.updateLatestStates()
+    est_p.debug("updateLatestStates")
+    _compare_latest(est_o, est_p, 1e-12)
+    np.testing.assert_allclose(est_p.latest()["P"], before["P"], atol=1e-9)
+    est_p.close()

@@ -62,7 +62,11 @@ def test_cpp_host_mirror_compiles_and_links(tmp_path):
                    '  gf_gnss_raw_obs r{}; r.sat = 3; r.sys = 0; r.time = 18.2; r.psr = 2.2e7; r.freq = 1575.42e6; g.inputGNSSRaw(18.2, std::vector<gf_gnss_raw_obs>{r});\n'
                    '  g.inputIMU(0.0, a, w);                          /* refresh() pulls the GNSS members */\n'
                    '  const bool gn = !g.gnss_ready && (int)g.para_rcv_dt.size() == 44 && g.key_poses.empty() && g.R_enu_local[0] == 1.0 && g.anc_ecef[0] == 0.0;\n'
-                   '  return (t.MAX_CNT == 150 && e.frame_count == 0 && (int)e.Ps.size() == 11 && e.wheelxyztBuf.size() == 1 && threw && gn) ? 0 : 1; }\n')
+                   '  /* the callbacks of rosNodeTest.cpp read these right after inputIMU / inputWheel (estimator.cpp:332-335, :363-366) and visualization.cpp reads rpw / zpw */\n'
+                   '  gf::Vec3 a2{0.1, -9.8, 0.2}; e.inputIMU(0.005, a2, w); const double lp = e.latest_P[0] + e.latest_V[1] + e.latest_Q[0] + e.latest_P_wheel[2] + e.latest_Q_wheel[4];\n'
+                   '  g.inputGNSSTimeDiff(18.0);\n'
+                   '  const bool lat = e.latest_time == 0.005 && e.latest_time_wheel == 0.0 && std::isfinite(lp) && e.rpw[0] == 1.0 && e.rpw[1] == 0.0 && e.zpw == 0.0 && g.diff_t_gnss_local == 18.0;\n'
+                   '  return (t.MAX_CNT == 150 && e.frame_count == 0 && (int)e.Ps.size() == 11 && e.wheelxyztBuf.size() == 1 && threw && gn && lat) ? 0 : 1; }\n')
     exe = tmp_path / "t"
     lib = os.path.join(root, "ground-fusion_amd", "lib")
     subprocess.check_call(["g++", "-std=c++17", "-I", root, str(src), "-L", lib, "-lgroundfusion_hip", "-Wl,-rpath," + lib, "-o", str(exe)])

@@ -89,3 +89,29 @@ def test_bench_runs_with_two_ranks(tmp_path):
     assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak" and r["value"] > 0
     assert abs(r["solves_per_s"] * r["ms_per_step"] * 1e-3 - 2 * 8) < 1e-6      # whole-job value: both ranks' sequences per step time
     assert "roofline" in r and "end_to_end" not in r          # the drop-in sample and the CPU baseline run at N = 1 only
+
+
+def test_bench_strong_scaling_of_configs3_with_eight_ranks():
+    """BASELINE.json configs[3] as the driver would launch it on an 8-GPU node: 64 sequences IN TOTAL over 8 ranks (`--strong 64`: 8 per rank), on this
+    one-GPU box with all ranks on device 0 and gloo in place of RCCL.  One JSON line, whole-job value, 64 gathered poses in global order (every rank
+    checks its own block inside bench.py), strong scaling declared, host threads per rank capped so that 8 ranks fit the node."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, GF_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    env.pop("GF_HOST_THREADS", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--strong", "64", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["scaling"] == "strong" and r["config"]["sequences_total"] == 64 and r["config"]["sequences_per_gpu"] == 8
+    assert r["pose_gather"]["rows"] == 64 and r["pose_gather"]["own_block_matches_export"] and r["pose_gather"]["bytes_per_step"] == 64 * 56
+    assert abs(r["solves_per_s"] * r["ms_per_step"] * 1e-3 - 64) < 1e-6       # whole-job value: all 64 sequences per step time
+    assert 1 <= r["host_threads_per_rank"] <= max(1, (os.cpu_count() or 8) // 8) and r["host_threads_per_rank"] <= 4
+    assert "end_to_end" not in r and "cpu_baseline" not in r
