@@ -180,10 +180,26 @@ __device__ __forceinline__ void visual_eval(const double* Pi_, const double* Pj_
     }
 }
 
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// Sums over lanes without LDS round trips (__shfl_xor on a double is two ds_bpermute per step, six dependent steps per sum): four DPP steps inside each
+// 16-lane row (xor 1, xor 2, half mirror, mirror -- every lane of the row ends with the row's sum), then the four row sums through v_readlane.  The order
+// of the additions is fixed, so the result does not depend on timing; every lane returns the same value.
+template <int CTRL> __device__ __forceinline__ double dpp_add_f64(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_sum16_f64(double v) {
+    v = dpp_add_f64<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+    v = dpp_add_f64<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+    v = dpp_add_f64<0x141>(v);   // row_half_mirror
+    v = dpp_add_f64<0x140>(v);   // row_mirror
     return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v = row_sum16_f64(v);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0)), r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32)), r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // One visual factor per lane: residual, Jacobians, Huber correction, zeroed columns of constant blocks, and the products the Schur
@@ -571,6 +587,10 @@ struct StepBufs {  // per-window global scratch of ba_step
 };
 
 __device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }  // packed lower, i >= j
+// A value every lane of the wavefront holds anyway (loaded from per-window state): tell the compiler, so that it lives in scalar registers, loop bounds and
+// branches on it are scalar, and pointers derived from it stay out of the vector register file (ba_step sits at the 256-VGPR limit).
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v))); }
 
 // 512-thread block reductions through wavefront shuffles + 8 LDS partials (sred >= 64 doubles)
 template <int NV_>
@@ -1109,31 +1129,41 @@ __device__ __forceinline__ double row_bcast(double v, int j) {   // j must fold 
         case 12: return row_bcast_c<12>(v); case 13: return row_bcast_c<13>(v); case 14: return row_bcast_c<14>(v); default: return row_bcast_c<15>(v);
     }
 }
+// acc += x[lane J of the own 16-lane row] * own, in ONE instruction: v_fmac_f64 takes its first source through DPP (64-bit DPP on gfx90a+ knows exactly one
+// control, row_newbcast, which is the one needed here).  The compiler does not combine a 64-bit DPP move into its user, so this is inline assembly; the
+// wait states a DPP read needs after the VALU write of its source (2) are the caller's business: dpp_fence() on the source before the first use.
+template <int J> __device__ __forceinline__ void fmac_bcast_c(double& acc, double x, double own) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(own), "n"(J));
+}
+// two wait states between the instruction that produced x and whatever reads x next (the data dependence through the operand keeps the order)
+__device__ __forceinline__ void dpp_fence(double& x) { asm("s_nop 1" : "+v"(x)); }
+// 64-bit row broadcast as one v_mov_b64_dpp (the 32-bit pair of row_bcast_c costs two instructions)
+template <int J> __device__ __forceinline__ double row_bcast64_c(double v) { return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0xf, true); }
 // Factor and explicit inverse of a 16x16 block in ONE sweep of 16 dependent steps (the serial part of ba_step's blocked Cholesky).
 // Lane (g, r) = (lane >> 4, lane & 15) holds row r of the block -- the four 16-lane groups factor redundantly, which keeps every broadcast inside a
 // DPP row -- and the entries W[r][4m + g], m = 0..3, of W = L^-1: the groups split the columns of the inverse between them.
 //   W[r][c] = (delta_rc - sum_{k<r} L[r][k] W[k][c]) / L[r][r]
 // Step j knows column j of L and (scaling by 1 / L_jj) row j of W; it removes their product from the accumulators t_r[c] of the rows below.
 // Against factor + separate forward substitution (two chains of 16 steps, the second one fed by LDS broadcasts): 10.2 k -> ~5 k cycles per block.
+// The sweep is bound by instruction issue (1 300 VALU instructions, 27 % of them the 32-bit halves of DPP broadcasts: disassembly of scripts/bench_chol16.hip),
+// not by the latency of its chain; round 3 folds every broadcast into the multiply-add that consumes it (v_fmac_f64_dpp row_newbcast): 176 broadcasts of
+// 2 + 1 (+ 1) instructions become 176 single instructions.
 // The block is read straight from the packed lower triangle S (rows / columns j0 .. j0 + nb - 1, padded with the identity); the inverse goes to s_inv
 // (operand of the panel product) and, packed, back into S in place of the block -- the factor itself is not needed again.
-template <class SPtr>
-__device__ __forceinline__ bool wave_chol16_fused(SPtr S, int j0, int nb, double* s_inv, int lane) {
-    const int r = lane & 15, g = lane >> 4;
-    double a[16], t[4];
-#pragma unroll
-    for (int c = 0; c < 16; c++) {   // unconditional loads (indices clamped into the block), masked afterwards: no branch per element
-        const int rl = min(r, nb - 1), cl = min(c, nb - 1);
-        const double v = S[pk(j0 + max(rl, cl), j0 + min(rl, cl))];
-        a[c] = (r < nb && c < nb) ? v : (r == c ? 1.0 : 0.0);
-    }
-#pragma unroll
-    for (int m = 0; m < 4; m++) t[m] = (4 * m + g == r) ? 1.0 : 0.0;
-    double rd_own = 0.0;
-    bool good = true;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const double piv = row_bcast(a[j], j);
+// the 16 steps as template recursion: every lane index of a DPP control and every index into a[] / t[] is a compile-time constant
+template <int J, int C> struct Chol16A {   // a_r[c] -= L_cj * L_rj for the columns c > j
+    static __device__ __forceinline__ void run(double (&a)[16], double nl, double l) { fmac_bcast_c<C>(a[C], nl, l); Chol16A<J, C + 1>::run(a, nl, l); }
+};
+template <int J> struct Chol16A<J, 16> { static __device__ __forceinline__ void run(double (&)[16], double, double) {} };
+template <int J, int M> struct Chol16W {   // t_r[4m + g] += t_j[4m + g] * nlw for the accumulators whose column can be <= j
+    static __device__ __forceinline__ void fence(double (&t)[4]) { if (4 * M <= J) { dpp_fence(t[M]); Chol16W<J, M + 1>::fence(t); } }
+    static __device__ __forceinline__ void run(double (&t)[4], double nlw) { if (4 * M <= J) { fmac_bcast_c<J>(t[M], t[M], nlw); Chol16W<J, M + 1>::run(t, nlw); } }
+};
+template <int J> struct Chol16W<J, 4> { static __device__ __forceinline__ void fence(double (&)[4]) {} static __device__ __forceinline__ void run(double (&)[4], double) {} };
+template <int J> struct Chol16Step {
+    static __device__ __forceinline__ void run(double (&a)[16], double (&t)[4], int& r, double& rd_own, bool& good) {
+        dpp_fence(a[J]);                                    // a[J] was last written by the previous step's DPP multiply-add
+        const double piv = row_bcast64_c<J>(a[J]);
         if (!(piv > 0.0)) good = false;
         // 1 / sqrt(piv): hardware seed (~2^-26) and two Newton steps y += y (1/2 - (piv/2) y^2), written with explicit fused multiply-adds
         // (this file is compiled without contraction; on the serial chain of the factorisation every dependent operation counts)
@@ -1141,18 +1171,46 @@ __device__ __forceinline__ bool wave_chol16_fused(SPtr S, int j0, int nb, double
         double rs = __builtin_amdgcn_rsq(piv);
         rs = __builtin_fma(rs, __builtin_fma(-(hp * rs), rs, 0.5), rs);
         rs = __builtin_fma(rs, __builtin_fma(-(hp * rs), rs, 0.5), rs);
-        const double l = (r == j) ? piv * rs : a[j] * rs;   // L_rj (rows r >= j); rs = 1 / L_jj
-        a[j] = l;
-        if (r == j) rd_own = rs;
-        const double lm = (r > j) ? l : 0.0;
-#pragma unroll
-        for (int m = 0; 4 * m <= j; m++) {                  // columns 4m + g <= j carry something; a larger column index has t = 0 in row j
-            const double wjc = row_bcast(t[m], j) * rs;     // W[j][4m + g]
-            t[m] = __builtin_fma(-lm, wjc, t[m]);
+        const double l = a[J] * rs;                         // L_rj (rows r >= j; on row j itself a[J] IS the pivot, so this is sqrt(piv)); rs = 1 / L_jj
+        a[J] = l;
+        // the row masks are formed here, one v_cmp each: hoisted out of the sweep they are 32 SGPR pairs, which the kernel does not have (they were being
+        // spilled into VGPR lanes and read back with v_readlane in every step)
+        asm("" : "+v"(r));
+        if (r == J) rd_own = rs;
+        // W: t_r[c] -= L_rj * (t_j[c] / L_jj) for the rows below j, as t_r[c] += t_j[c] * (-(L_rj / L_jj)): one DPP multiply-add per accumulator
+        const double nlw = (r > J) ? -(l * rs) : 0.0;
+        if (J > 0) Chol16W<J, 0>::fence(t);
+        Chol16W<J, 0>::run(t, nlw);
+        if (J < 15) {
+            double nl = -l;
+            dpp_fence(nl);
+            Chol16A<J, J + 1>::run(a, nl, l);
         }
-#pragma unroll
-        for (int c = j + 1; c < 16; c++) a[c] = __builtin_fma(-l, row_bcast(l, c), a[c]);   // - L_rj * L_cj
+        Chol16Step<J + 1>::run(a, t, r, rd_own, good);
     }
+};
+template <> struct Chol16Step<16> { static __device__ __forceinline__ void run(double (&)[16], double (&)[4], int&, double&, bool&) {} };
+template <class SPtr>
+__device__ __forceinline__ bool wave_chol16_fused(SPtr S, int j0, int nb, double* s_inv, int lane) {
+    int r = lane & 15;
+    const int g = lane >> 4;
+    double a[16], t[4];
+    {   // lane r reads 16 consecutive entries of row j0 + r of the packed triangle from column j0 on: one base address, 16 loads that issue back to back.
+        // Entries right of the diagonal (c > r) belong to the rows behind and are never looked at: row r only ever uses a[c] for c <= r (its own
+        // part of column c), and what it computes into a[c > r] feeds nothing but itself.
+        const int base = pk(j0 + min(r, nb - 1), j0);
+#pragma unroll
+        for (int c = 0; c < 16; c++) a[c] = S[base + c];
+        if (nb < 16) {   // last block of the system: pad with the identity (wave-uniform branch)
+#pragma unroll
+            for (int c = 0; c < 16; c++) a[c] = (r < nb && c < nb) ? a[c] : (r == c ? 1.0 : 0.0);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) t[m] = (4 * m + g == r) ? 1.0 : 0.0;
+    double rd_own = 0.0;
+    bool good = true;
+    Chol16Step<0>::run(a, t, r, rd_own, good);
 #pragma unroll
     for (int m = 0; m < 4; m++) {
         const int c = 4 * m + g;
@@ -1177,7 +1235,8 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
     __shared__ double s_y[16];
     __shared__ int s_flag[4];
     __shared__ int s_cmap[256];      // compact column -> reduced column (or -1), right-hand-side slot -> R
-    __shared__ double s_uc[256];     // a vector gathered to the compact layout
+    __shared__ double s_uc[256];     // a vector gathered to the compact layout (the Gauss-Newton solution during the back-substitution)
+    __shared__ double s_ucc[256];    // the Cauchy direction in the compact layout (kept for the quadratic form u^T H u)
     __shared__ double s_rd[512];     // scratch: the Cauchy direction during the Schur pass, the solution during the backward substitution
     __shared__ int s_rc[512];        // reduced column -> compact column of the visual system Vc (or -1)
     __shared__ double s_hd[512];     // diagonal of H + Vc
@@ -1185,8 +1244,8 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
     const Dims d = w.d;
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     SolverState& st = w.st[b];
-    if (st.done) return;
-    const int R = st.R, NE = st.NE, RP = d.RP, VS = sb.VS, ECW = d.ECW;
+    if (uni(st.done)) return;
+    const int R = uni(st.R), NE = uni(st.NE), RP = d.RP, VS = sb.VS, ECW = d.ECW;
     double* S = GS ? sb.Sg + (size_t)blockIdx.x * sb.SgStride : smem;  // packed lower (R+1)(R+2)/2: row R carries the right-hand side
     const int* colf = w.colf + (size_t)b * d.NFB;
     const int* cole = w.cole + (size_t)b * d.F;
@@ -1223,8 +1282,8 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
         }
     }
     __syncthreads();
-    if (st.done) return;
-    const int cur = st.cur;
+    if (uni(st.done)) return;
+    const int cur = uni(st.cur);
     double* H = w.H + ((size_t)cur * d.B + b) * RP * RP;
     double* g = w.g + ((size_t)cur * d.B + b) * RP;
     const double* xs = w.xs + ((size_t)cur * d.B + b) * d.XS;
@@ -1242,7 +1301,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
     }
     __syncthreads();
     GF_STAMP(1);
-    if (!st.reuse) {
+    if (!uni(st.reuse)) {
         // ---------------- Jacobi scaling from the initial Jacobian (trust_region_minimizer.cc: jacobian_scaling_)
         if (!st.have_scale) {
             for (int c = tid; c < R; c += 512) scale[c] = 1.0 / (1.0 + sqrt(s_hd[c]));
@@ -1267,9 +1326,9 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
     }
     __syncthreads();
     GF_STAMP(3);
-    if (st.done || finalize_only) return;
+    if (uni(st.done) || finalize_only) return;
 
-    if (!st.reuse) {
+    if (!uni(st.reuse)) {
         GF_STAMP(4);
         // ---------------- dogleg diagonal, scaled gradient, Cauchy point
         for (int c = tid; c < R; c += 512) {
@@ -1283,7 +1342,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
             gn[RP + e] = u[RP + e];   // the Cauchy direction's eliminated part survives in gn's tail until the back-substitution rewrites it
         }
         __syncthreads();
-        if (tid < ECW) { const int c = s_cmap[tid]; s_uc[tid] = (c >= 0 && c < R) ? u[c] : 0.0; }
+        if (tid < ECW) { const int c = s_cmap[tid]; s_ucc[tid] = (c >= 0 && c < R) ? u[c] : 0.0; }
         // the passes below read the column scaling and the Cauchy direction once per matrix entry: LDS copies (s_hd and s_rd are free until the
         // next call / the Cholesky)
         for (int c = tid; c < R; c += 512) { s_hd[c] = scale[c]; s_rd[c] = u[c]; }
@@ -1294,7 +1353,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
         // alpha = |g~|^2 / (u^T H u) of the Cauchy point: the quadratic form is accumulated below, inside the passes that stream Et (Es build) and
         // H (load of the reduced system) anyway, instead of a separate sweep over both
         double uHu_acc = 0.0;
-        bool need_alpha = true;
+        bool need_alpha = true, asm_alpha_done = false;
         constexpr int QN = GS ? 8 : 3;
         double uk[QN];
 #pragma unroll
@@ -1302,7 +1361,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
         // ---------------- Gauss-Newton step: (J^T J + mu D^2) y = J^T r through the Schur complement, retry with larger mu on failure
         bool ok = false;
         while (!ok) {
-            const double mu = st.mu;
+            const double mu = uni(st.mu);
             if (!(mu < 1.0)) break;
             GF_STAMP(5);
             // eliminated columns: ete~ = s_e^2 ete + mu D_e^2 (kept in yv's tail), row factor f_e = s_e / sqrt(ete~) (in u's tail)
@@ -1312,45 +1371,10 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                 yv[RP + e] = et; u[RP + e] = sc / sqrt(et);
             }
             __syncthreads();
-            // compact Es[e][k] = f_e s_c Et[e][k] (c = reduced column of k); the right-hand-side slot carries etb~ / sqrt(ete~) so that the
-            // GEMM also reduces the right-hand side
+            // The scaled compact rows Es[e][k] = f_e s_c Et[e][k] (c = reduced column of k; the right-hand-side slot carries f_e etb_e so that the GEMM also
+            // reduces the right-hand side) are not materialised any more: the Schur GEMM and the back-substitution of the eliminated columns scale the
+            // rows of Et as they load them (same products in the same order, so the same bits as the stored copy; 78 KB written and read back per call saved).
             const int NE4 = (NE + 3) & ~3;
-            // one wavefront per compact row, four rows in flight; lanes cover the ECW (<= 64 EN) columns
-            {
-                constexpr int EN = GS ? 4 : 2;
-                constexpr int ER = GS ? 4 : 8;   // rows per wavefront in flight
-                for (int e0 = wave; e0 < NE4; e0 += 8 * ER) {
-                    double fe[ER], ue[ER], eb[ER], etv[ER][EN];
-#pragma unroll
-                    for (int m = 0; m < ER; m++) {   // every load of these rows is issued before the first store
-                        const int e = e0 + 8 * m;
-                        const bool live = e < NE;
-                        fe[m] = live ? u[RP + e] : 0.0; ue[m] = (live && need_alpha) ? gn[RP + e] : 0.0; eb[m] = live ? etb[e] : 0.0;
-                        const double* src = Et + (size_t)min(e, max(NE - 1, 0)) * ECW;
-#pragma unroll
-                        for (int q = 0; q < EN; q++) { const int k = lane + 64 * q; etv[m][q] = (live && k < ECW) ? src[k] : 0.0; }
-                    }
-#pragma unroll
-                    for (int m = 0; m < ER; m++) {
-                        const int e = e0 + 8 * m;
-                        if (e >= NE4) continue;
-                        double* dst = Es + (size_t)e * ECW;
-                        double dotv = 0.0;
-#pragma unroll
-                        for (int q = 0; q < EN; q++) {
-                            const int k = lane + 64 * q;
-                            if (k < ECW) {
-                                const int c = s_cmap[k];
-                                double v = 0.0;
-                                if (c >= 0 && c < R) { v = fe[m] * s_hd[c] * etv[m][q]; dotv += etv[m][q] * s_uc[k]; }
-                                else if (c == R) v = fe[m] * eb[m];
-                                dst[k] = v;
-                            }
-                        }
-                        uHu_acc += 2.0 * ue[m] * dotv;
-                    }
-                }
-            }
             GF_STAMP(6);
             // reduced system in LDS (packed lower): S = s (H + Vc) s + mu D^2, row R = s g.  First the H part, row by row ...
             for (int r0 = wave; r0 <= R; r0 += 32) {   // four rows per wavefront in flight: all loads first, then the arithmetic
@@ -1376,7 +1400,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                                 double v = sr * s_hd[c] * hv[m][q];
                                 if (c == r) { const double lm = diag[r] * sqrt(mu); v += lm * lm; }
                                 S[base + c] = v;
-                                uHu_acc += (c == r ? 1.0 : 2.0) * hv[m][q] * uk[q] * ur;   // H holds its lower triangle
+                                if (!asm_alpha_done) uHu_acc += (c == r ? 1.0 : 2.0) * hv[m][q] * uk[q] * ur;   // H holds its lower triangle
                             }
                         } else if (c < R) S[base + c] = s_hd[c] * s_gt[c];   // row R: the right-hand side s g (visual part included in s_gt)
                     }
@@ -1413,37 +1437,68 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                             if (c < 0) continue;
                             const double v = vv[m][q];
                             S[pk(r, c)] += sr * s_hd[c] * v;
-                            uHu_acc += (c == r ? 1.0 : 2.0) * v * ur * s_rd[c];
+                            if (!asm_alpha_done) uHu_acc += (c == r ? 1.0 : 2.0) * v * ur * s_rd[c];
                         }
                     }
                 }
             }
-            if (need_alpha) {
+            if (need_alpha && !asm_alpha_done) {   // the eliminated columns' share of u^T H u (E^T F u and E^T E) follows in the back-substitution pass below, which streams Et anyway
                 for (int e = tid; e < NE; e += 512) { const double ue = gn[RP + e]; uHu_acc += ete[e] * ue * ue; }
-                const double uHu = block_sum(uHu_acc, sred, tid, 512);
-                if (tid == 0) st.alpha = gsq / uHu;
-                need_alpha = false;
+                asm_alpha_done = true;
             }
             __syncthreads();
             GF_STAMP(7);
             // S -= Es^T Es on the matrix cores over the COMPACT columns (poses, ex, td, rhs slot; speed-bias / wheel columns are structurally
             // zero): 16x16 tiles of the compact lower triangle, K = eliminated columns (4 per MFMA), scattered into the packed S.
             {
-                const int nt = ECW / 16, ntiles = nt * (nt + 1) / 2, nk = NE4 / 4;
+                constexpr int GB = 4;   // k-steps per batch: two batches of GB loads x 2 operands live at a time (the kernel sits at the 256-VGPR limit: eight spilled)
+                const int nt = ECW / 16, ntiles = nt * (nt + 1) / 2, nk = NE4 / 4, nbat = (nk + GB - 1) / GB;
+                // f_e = s_e / sqrt(ete~) and f_e etb_e per eliminated column: staged in LDS (sred is free between the reductions) when they fit, else read from global
+                const bool fe_lds = NE4 <= 256;
+                if (fe_lds) {
+                    for (int e = tid; e < NE4; e += 512) { const double f = e < NE ? u[RP + e] : 0.0; sred[e] = f; sred[256 + e] = e < NE ? f * etb[e] : 0.0; }
+                    __syncthreads();
+                }
                 for (int t = wave; t < ntiles; t += 8) {
                     const int ti = tri_row(t), tk = t - ti * (ti + 1) / 2;
-                    const double* pa = Es + (size_t)(lane >> 4) * ECW + 16 * ti + (lane & 15);
-                    const double* pb = Es + (size_t)(lane >> 4) * ECW + 16 * tk + (lane & 15);
+                    const int ka = 16 * ti + (lane & 15), kb = 16 * tk + (lane & 15), eg = lane >> 4;
+                    const int ca = s_cmap[ka], cb = s_cmap[kb];
+                    // per-lane column factors: s_c for a reduced column, the right-hand-side slot takes f_e etb_e instead of f_e s_c Et
+                    const double sca = (ca >= 0 && ca < R) ? s_hd[ca] : 0.0, scb = (cb >= 0 && cb < R) ? s_hd[cb] : 0.0;
+                    const bool rha = ca == R, rhb = cb == R;
+                    const double* pa = Et + (size_t)eg * ECW + ka;
+                    const double* pb = Et + (size_t)eg * ECW + kb;
                     d4 acc = {0, 0, 0, 0};
-                    int k = 0;
-                    for (; k + 8 <= nk; k += 8) {
-                        double av[8], bv2[8];
+                    // batches of GB k-steps (4 GB eliminated columns), double-buffered: the loads of batch n + 1 are issued before the matrix products of batch n
+                    auto load = [&](int bat, double (&av)[GB], double (&bv2)[GB]) {
 #pragma unroll
-                        for (int q = 0; q < 8; q++) { av[q] = pa[(size_t)4 * (k + q) * ECW]; bv2[q] = pb[(size_t)4 * (k + q) * ECW]; }
+                        for (int q = 0; q < GB; q++) {
+                            const int kk = GB * bat + q, e = 4 * kk + eg;
+                            const bool live = e < NE;
+                            av[q] = live ? pa[(size_t)4 * kk * ECW] : 0.0; bv2[q] = live ? pb[(size_t)4 * kk * ECW] : 0.0;
+                        }
+                    };
+                    auto mma = [&](int bat, const double (&av)[GB], const double (&bv2)[GB]) {
 #pragma unroll
-                        for (int q = 0; q < 8; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv2[q], acc, 0, 0, 0);
+                        for (int q = 0; q < GB; q++) {
+                            const int e = 4 * (GB * bat + q) + eg;
+                            double fe, feb;
+                            if (fe_lds) { fe = e < NE4 ? sred[e] : 0.0; feb = e < NE4 ? sred[256 + e] : 0.0; }
+                            else { fe = e < NE ? u[RP + e] : 0.0; feb = (e < NE && (rha || rhb)) ? fe * etb[e] : 0.0; }
+                            const double a0 = rha ? feb : fe * sca * av[q], b0 = rhb ? feb : fe * scb * bv2[q];   // = the former Es entries
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+                        }
+                    };
+                    double avA[GB], bvA[GB], avB[GB], bvB[GB];
+                    if (nbat > 0) load(0, avA, bvA);
+                    for (int bat = 0; bat < nbat; bat += 2) {
+                        if (bat + 1 < nbat) load(bat + 1, avB, bvB);
+                        mma(bat, avA, bvA);
+                        if (bat + 1 < nbat) {
+                            if (bat + 2 < nbat) load(bat + 2, avA, bvA);
+                            mma(bat + 1, avB, bvB);
+                        }
                     }
-                    for (; k < nk; k++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(size_t)4 * k * ECW], pb[(size_t)4 * k * ECW], acc, 0, 0, 0);
                     const int col = s_cmap[16 * tk + (lane & 15)];
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
@@ -1543,12 +1598,14 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                     if (idx[1][r] >= 0) S[idx[1][r]] = cur[1][r] - acc1[r];
                 }
             };
-            if (wave == 0) diag_block(0);
+            // wavefront 0 runs the serial part (next diagonal tile, then its factor + inverse) next to wavefront 4 on the same SIMD, which is busy with
+            // trailing tiles at that time: without priority the two alternate and the serial part takes twice its stand-alone time (3.5 k -> 6.4 k cycles)
+            if (wave == 0) { __builtin_amdgcn_s_setprio(3); diag_block(0); __builtin_amdgcn_s_setprio(0); }
             __syncthreads();
             GF_SUB(tA);
             for (int j0 = 0; j0 < R; j0 += 16) {
                 const int nb = min(16, R - j0);
-                if (!s_flag[1]) break;
+                if (!uni(s_flag[1])) break;
                 // panel: X = A21 L11^-T for the rows below the block and the rhs row; 16-row tiles, X[i][c] = sum_k A[i][k] Linv[c][k]
                 const int r0 = j0 + nb;
                 {
@@ -1578,6 +1635,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                 if (r0 <= R) {
                     const int nrows = R + 1 - r0, nt = (nrows + 15) / 16, ntiles = nt * (nt + 1) / 2;
                     if (wave == 0) {
+                        __builtin_amdgcn_s_setprio(3);
 #ifdef GF_PROFILE_STEP
                         const long long q0 = clock64();
 #endif
@@ -1589,6 +1647,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
                             diag_block(r0);
                         }
+                        __builtin_amdgcn_s_setprio(0);
                     } else {
                         for (int t = wave; t < ntiles; t += 14) trail_pair(j0, nb, r0, t, t + 7 < ntiles ? t + 7 : -1);
                     }
@@ -1599,7 +1658,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
 #ifdef GF_PROFILE_STEP
             if (blockIdx.x == 0 && tid == 0 && sb.stamps) { sb.stamps[20] = tA; sb.stamps[21] = tB; sb.stamps[22] = tC; }
 #endif
-            ok = s_flag[1] != 0;
+            ok = uni(s_flag[1]) != 0;
             if (ok) {
                 GF_STAMP(9);
                 // backward substitution L^T y = z (z = row R), 16-column blocks from the bottom: in-block solve by wavefront 0
@@ -1636,14 +1695,50 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                 for (int c = tid; c < R; c += 512) if (!isfinite(yv[c])) bad = 1;
                 if (tid < ECW) { const int c = s_cmap[tid]; s_uc[tid] = (c >= 0 && c < R) ? yv[c] : 0.0; }
                 __syncthreads();
-                for (int e = tid; e < NE; e += 512) {   // compact rows are short (ECW entries): one thread per eliminated column
-                    const double* row = Es + (size_t)e * ECW;
-                    double acc = 0;
-                    for (int k = 0; k < ECW; k++) acc += row[k] * s_uc[k];
-                    const double et = yv[RP + e];
-                    const double ye = (scale[RP + e] * etb[e] - acc * sqrt(et)) / et;
-                    gn[RP + e] = -diag[RP + e] * ye;
-                    if (!isfinite(ye)) bad = 1;
+                {   // sixteen lanes per eliminated column (four columns per wavefront instruction, two such groups in flight): acc_e = sum_k Es[e][k] y_k with
+                    // Es = f_e s_c Et scaled on the fly (the right-hand-side slot does not take part: its y entry is zero), and -- once per call -- the Cauchy
+                    // direction's dot product with the unscaled row; both reduced inside the 16-lane row by DPP
+                    constexpr int EM = GS ? 9 : 5;   // compact columns per lane: ECW <= 16 EM (6 (W + 1) + 8 padded to 16; W <= 10 in LDS, <= 20 in global memory)
+                    const int sub = lane & 15, grp = lane >> 4;
+                    for (int e0 = 4 * wave + grp; e0 < NE; e0 += 64) {
+                        double etv[2][EM], fe[2];
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const int e = e0 + 32 * h;
+                            const bool live = e < NE;
+                            fe[h] = live ? u[RP + e] : 0.0;
+                            const double* src = Et + (size_t)min(e, NE - 1) * ECW;
+#pragma unroll
+                            for (int q = 0; q < EM; q++) { const int k = sub + 16 * q; etv[h][q] = (live && k < ECW) ? src[k] : 0.0; }
+                        }
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const int e = e0 + 32 * h;
+                            double accy = 0.0, accu = 0.0;
+#pragma unroll
+                            for (int q = 0; q < EM; q++) {
+                                const int k = sub + 16 * q;
+                                if (k < ECW) {
+                                    const int c = s_cmap[k];
+                                    if (c >= 0 && c < R) { accy += (fe[h] * s_hd[c] * etv[h][q]) * s_uc[k]; accu += etv[h][q] * s_ucc[k]; }
+                                }
+                            }
+                            accy = row_sum16_f64(accy);
+                            if (need_alpha) accu = row_sum16_f64(accu);
+                            if (sub == 0 && e < NE) {
+                                const double et = yv[RP + e];
+                                const double ye = (scale[RP + e] * etb[e] - accy * sqrt(et)) / et;
+                                if (need_alpha) uHu_acc += 2.0 * gn[RP + e] * accu;   // gn's tail still holds the Cauchy direction's eliminated part here
+                                gn[RP + e] = -diag[RP + e] * ye;
+                                if (!isfinite(ye)) bad = 1;
+                            }
+                        }
+                    }
+                }
+                if (need_alpha) {
+                    const double uHu = block_sum(uHu_acc, sred, tid, 512);
+                    if (tid == 0) st.alpha = gsq / uHu;
+                    need_alpha = false;
                 }
                 bad = block_max(bad, sred, tid, 512);
                 if (bad > 0) ok = false;
