@@ -525,7 +525,7 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     h->st.n = h->st0.n = B;
     A_(h->imu_sqrt.alloc(B * d.W * 225, false)); A_(h->wh_sqrt.alloc(B * d.W * 36, false)); A_(h->pri_A.alloc(B * d.NPRI * d.NPRI, false)); A_(h->pri_b.alloc(B * d.NPRI, false));
     A_(h->pri_c.alloc(B, false)); A_(h->H.alloc(2 * B * d.RP * d.RP, true)); A_(h->g.alloc(2 * B * d.RP, true)); A_(h->Vc.alloc(2 * B * d.NVC, true)); A_(h->wpar.alloc(B * 4, true));
-    A_(h->cost.alloc(6 * B, true)); A_(h->efac.alloc(2 * B * d.NV * EF, false));
+    A_(h->cost.alloc(6 * B, true)); A_(h->efac.alloc(B * d.NV * EF, false));
     H_(hipMemsetAsync(h->cost.d, 0, 6 * B * sizeof(double), h->stream));
     A_(h->scale.alloc(B * VS, false)); A_(h->diag.alloc(B * VS, false)); A_(h->grad.alloc(B * VS, false)); A_(h->gn.alloc(B * VS, false)); A_(h->step.alloc(B * VS, false));
     A_(h->u.alloc(B * VS, false)); A_(h->Et.alloc(2 * B * d.FP * d.ECW, true)); A_(h->Es.alloc(B * d.FP * d.ECW, false)); A_(h->ete.alloc(2 * B * d.FP, true)); A_(h->etb.alloc(2 * B * d.FP, true));

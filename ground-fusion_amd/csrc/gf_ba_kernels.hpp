@@ -103,7 +103,13 @@ constexpr int IMU_STRIDE = 16 + 225 + 225;  // sum_dt, dp3, dq4, dv3, lba3, lbg3
 constexpr int IMU_JAC = 17, IMU_COV = 17 + 225;
 constexpr int IMU_STRIDE2 = 17 + 450;
 constexpr int WH_STRIDE = 1 + 3 + 4 + 18 + 36 + 4 + 12;  // sum_dt, dp, dq, jac(6x3), cov(6x6), lin(4), lin_vel, lin_gyr, vel_1, gyr_1
-constexpr int EF = 24;  // per-factor eliminated-column products: Jd^T[Ji(6) Jj(6) Jtd(1) Jex(6)] , Jd^T Jd, Jd^T r, then the factor's frames i, j (as doubles)
+// per-factor eliminated-column products, one scratch buffer per batch (written and consumed inside one ba_linearize_visual_win launch).
+//   EX (camera extrinsic carries columns): 24 doubles = Jd^T[Ji(6) Jj(6) Jtd(1) Jex(6)], Jd^T Jd, Jd^T r, then the factor's frames i, j (as doubles)
+//   else: 16 doubles = ONE 128-byte line: Jd^T[Ji(6) Jj(6) Jtd(1)], Jd^T Jd, Jd^T r, frames (i, j) as two ints in the last slot.
+// The sweeps are bound by memory traffic as much as by arithmetic (all 256 windows of a launch move their tables at once: ~3.7 TB/s over the launch); the
+// products were 2 x 73 MB (double-buffered, 192 B per factor) against a 256 MB Infinity Cache; now 49 MB.
+constexpr int EF = 24;
+template <bool EX> __host__ __device__ constexpr int ef_stride() { return EX ? 24 : 16; }
 #ifdef GF_PROFILE_STEP
 #define GF_WSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && w.stamps) w.stamps[i] = clock64(); } while (0)
 #define GF_WSTAMP_T(t, i) do { if (blockIdx.x == 0 && threadIdx.x == (t) && w.stamps) w.stamps[i] = clock64(); } while (0)
@@ -240,14 +246,15 @@ __device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int
         if (EX && colf[fb_ex(d.NP)] < 0) for (int c = 16; c < 22; c++) ev.row[0][c] = ev.row[1][c] = 0.0;
         // eliminated (free inverse depth) column: products needed by the Schur complement
         if (w.cole[(size_t)b * d.F + feat] >= 0) {
-            double* ef = w.efac + (((size_t)which * d.B + b) * d.NV + w.vis_pos[kk]) * EF;   // the factors of a feature are contiguous
+            double* ef = w.efac + ((size_t)b * d.NV * EF + (size_t)w.vis_pos[kk] * ef_stride<EX>());   // the factors of a feature are contiguous
 #pragma unroll
             for (int c = 0; c < 13; c++) ef[c] = ev.jd[0] * ev.row[0][c] + ev.jd[1] * ev.row[1][c];
+            const double ete_f = ev.jd[0] * ev.jd[0] + ev.jd[1] * ev.jd[1], etb_f = ev.jd[0] * ev.row[0][13] + ev.jd[1] * ev.row[1][13];
+            if (EX) {
 #pragma unroll
-            for (int c = 0; c < 6; c++) ef[13 + c] = EX ? ev.jd[0] * ev.row[0][16 + c] + ev.jd[1] * ev.row[1][16 + c] : 0.0;
-            ef[19] = ev.jd[0] * ev.jd[0] + ev.jd[1] * ev.jd[1];
-            ef[20] = ev.jd[0] * ev.row[0][13] + ev.jd[1] * ev.row[1][13];
-            ef[21] = (double)fi; ef[22] = (double)fj;
+                for (int c = 0; c < 6; c++) ef[13 + c] = ev.jd[0] * ev.row[0][16 + c] + ev.jd[1] * ev.row[1][16 + c];
+                ef[19] = ete_f; ef[20] = etb_f; ef[21] = (double)fi; ef[22] = (double)fj;
+            } else { ef[13] = ete_f; ef[14] = etb_f; ef[15] = __hiloint2double(fj, fi); }
         }
     }
     return cost;
@@ -403,8 +410,11 @@ __device__ inline void imu_raw(const double* Pi_, const double* SBi, const doubl
 // WheelFactor::Evaluate (wheel_factor.h:28-247) + WheelIntegrationBase::evaluate (wheel_integration_base.h:180-219).
 // Jraw: 6 x 22, columns [pose_i 6 | pose_j 6 | T_io 6 | sx | sy | sw | td_wheel].
 // same conventions as imu_raw: residual (6), Jacobian 6 x 22 into a zeroed Jraw
+// want_ix / want_td: the intrinsic (sx, sy, sw) and time-offset columns are asked for.  They are constant blocks in the shipped configurations
+// (estimate_wheel_intrinsic: 0, estimate_td_wheel: 0), and their Jacobians are half of the factor's arithmetic (four right Jacobians, five exponentials):
+// a pass whose column map drops them skips that half (the marginalisation passes, where no block is constant, evaluate everything).
 __device__ inline void wheel_raw(const double* Pi_, const double* Pj_, const double* Ex, double sx, double sy, double sw, double td, const double* dat, double* rraw,
-                                 double* Jraw, bool want_jac, bool writer, int ld = 22, int rs = 1) {
+                                 double* Jraw, bool want_jac, bool writer, int ld = 22, int rs = 1, bool want_ix = true, bool want_td = true) {
     const V3 Pi = p_of(Pi_), Pj = p_of(Pj_), tio = p_of(Ex);
     const Q4 Qi = q_of(Pi_), Qj = q_of(Pj_), qio = q_of(Ex);
     const M3 sv = m3_diag(sx, sy, 1);
@@ -444,17 +454,24 @@ __device__ inline void wheel_raw(const double* Pi_, const double* Pj_, const dou
         put(0, 12, Rqio_inv * (Rj - Ri));
         put(0, 15, skew(qrot(qinverse(Qio), qrot(Qj, tio) + Pj - qrot(Qi, tio) - Pi)));
         put(3, 15, Jr_inv * (m3_identity() - qmat(qmul(qmul(qinverse(qmul(Qj, qio)), Qi), qio))));
-        const V3 fcw = lin_gyr * (sw * dtd), fcv = sv * lin_vel * dtd, bcv = sv * vel_1 * dtd, bcw = gyr_1 * (sw * dtd);
-        const M3 Jrtd = rightJacobianSO3(fcw), Jr_mtd = rightJacobianSO3(-fcw);
-        const M3 I1 = m3_diag(1, 0, 0), I2 = m3_diag(0, 1, 0);
-        const M3 Efv = qmat(so3_exp(fcv)), Efw = qmat(so3_exp(fcw));   // wheel_factor.h:199,211 use exp(forward_compensate_v): kept as is
-        putv(0, 18, -(Efv * (I1 * lin_vel * dtd + dp_dsx - Rcq * (I1 * vel_1) * dtd)));
-        putv(0, 19, -(Efv * (I2 * lin_vel * dtd + dp_dsy - Rcq * (I2 * vel_1) * dtd)));
-        putv(0, 20, -(Efw * (dp_dsw - Rcq * skew(Jr_drdsw * dq_dsw) * (sv * vel_1) * dtd + skew(Jrtd * lin_gyr * dtd) * (fcv + cdp - qrot(cdq, bcv)))));
-        const M3 Em = qmat(so3_exp(-rr)), Ebw = qmat(so3_exp(bcw)), Rcq_inv = qmat(qinverse(cdq));
-        putv(3, 20, -(Jr_inv * Em * Ebw * (Rcq_inv * (Jrtd * lin_gyr) * dtd + Jr_drdsw * dq_dsw)));
-        putv(0, 21, -(Efw * (sv * lin_vel - Rcq * (sv * vel_1) + skew(Jrtd * lin_gyr * sw) * (fcv + cdp - Rcq * bcv))));
-        putv(3, 21, -(Jr_inv * Em * (Ebw * Rcq_inv * (Jrtd * lin_gyr) * sw - Jr_mtd * gyr_1 * sw)));
+        if (want_ix || want_td) {
+            const V3 fcw = lin_gyr * (sw * dtd), fcv = sv * lin_vel * dtd, bcv = sv * vel_1 * dtd, bcw = gyr_1 * (sw * dtd);
+            const M3 Jrtd = rightJacobianSO3(fcw), Jr_mtd = rightJacobianSO3(-fcw);
+            const M3 I1 = m3_diag(1, 0, 0), I2 = m3_diag(0, 1, 0);
+            const M3 Efw = qmat(so3_exp(fcw));
+            const M3 Em = qmat(so3_exp(-rr)), Ebw = qmat(so3_exp(bcw)), Rcq_inv = qmat(qinverse(cdq));
+            if (want_ix) {
+                const M3 Efv = qmat(so3_exp(fcv));   // wheel_factor.h:199,211 use exp(forward_compensate_v): kept as is
+                putv(0, 18, -(Efv * (I1 * lin_vel * dtd + dp_dsx - Rcq * (I1 * vel_1) * dtd)));
+                putv(0, 19, -(Efv * (I2 * lin_vel * dtd + dp_dsy - Rcq * (I2 * vel_1) * dtd)));
+                putv(0, 20, -(Efw * (dp_dsw - Rcq * skew(Jr_drdsw * dq_dsw) * (sv * vel_1) * dtd + skew(Jrtd * lin_gyr * dtd) * (fcv + cdp - qrot(cdq, bcv)))));
+                putv(3, 20, -(Jr_inv * Em * Ebw * (Rcq_inv * (Jrtd * lin_gyr) * dtd + Jr_drdsw * dq_dsw)));
+            }
+            if (want_td) {
+                putv(0, 21, -(Efw * (sv * lin_vel - Rcq * (sv * vel_1) + skew(Jrtd * lin_gyr * sw) * (fcv + cdp - Rcq * bcv))));
+                putv(3, 21, -(Jr_inv * Em * (Ebw * Rcq_inv * (Jrtd * lin_gyr) * sw - Jr_mtd * gyr_1 * sw)));
+            }
+        }
     }
 }
 
@@ -631,43 +648,54 @@ __device__ __forceinline__ int tri_row(int t) {  // largest i with i(i+1)/2 <= t
 // The factor products sit in efac in feature-list order, frames included: no index chasing, one contiguous read per feature.
 // eight features per wavefront, eight lanes per feature (sixteen lanes per feature made 3.1 rounds of ~15 k cycles each at 150 features and 12 wavefronts:
 // the rounds are load-latency bound, so fewer and fuller ones win)
+template <bool EX>
 __device__ __forceinline__ void et_rows8(const Win& w, const StepBufs& sb, const Dims& d, int b, int f0, int nfeat, const int* cole, const int* fptr, int which, int lane) {
+    constexpr int EFS = ef_stride<EX>();
     const int sub = lane & 7, f = f0 + (lane >> 3);
     const int e = f < nfeat ? cole[f] : -1;
     const int p0 = e >= 0 ? fptr[f] : 0, p1 = e >= 0 ? fptr[f + 1] : 0;
-    const double* efac = w.efac + ((size_t)which * d.B + b) * d.NV * EF;
+    const double* efac = w.efac + (size_t)b * d.NV * EF;
     double* Et = sb.Et + (((size_t)which * d.B + b) * d.FP + max(e, 0)) * d.ECW;
     if (e >= 0) for (int c = sub; c < d.ECW; c += 8) Et[c] = 0.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-    // lane `sub` owns the products sub (0-5 pose_i, 6-7 pose_j), 8 + sub (8-11 pose_j, 12 td, 13-15 ex 0-2) and 16 + sub (16-18 ex 3-5, 19 ete, 20 etb) of every factor
+    // EX:   lane `sub` owns the products sub (0-5 pose_i, 6-7 pose_j), 8 + sub (8-11 pose_j, 12 td, 13-15 ex 0-2) and 16 + sub (16-18 ex 3-5, 19 ete, 20 etb) of every factor
+    // else: lane `sub` owns the products sub (0-5 pose_i, 6-7 pose_j) and 8 + sub (8-11 pose_j, 12 td, 13 ete, 14 etb, 15 the frames) -- one 128-byte line per factor
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
     int fi = 0;
     constexpr int NF = 10;   // factors in flight: every load of a batch is issued before the first store (a track spans <= W frames)
     for (int pb = p0; pb < p1; pb += NF) {
-        double v0[NF], v1[NF], v2[NF], fjd[NF], fid[NF];
+        double v0[NF], v1[NF], v2[NF], fr[NF], fid[NF];
 #pragma unroll
         for (int q = 0; q < NF; q++) {
             const bool on = pb + q < p1;
-            const double* row = efac + (size_t)(on ? pb + q : p0) * EF;
-            v0[q] = on ? row[sub] : 0.0; v1[q] = on ? row[8 + sub] : 0.0; v2[q] = (on && sub < 5) ? row[16 + sub] : 0.0; fid[q] = row[21]; fjd[q] = row[22];
+            const double* row = efac + (size_t)(on ? pb + q : p0) * EFS;
+            v0[q] = on ? row[sub] : 0.0; v1[q] = on ? row[8 + sub] : 0.0;
+            if (EX) { v2[q] = (on && sub < 5) ? row[16 + sub] : 0.0; fid[q] = row[21]; fr[q] = row[22]; }
+            else { v2[q] = 0.0; fid[q] = 0.0; fr[q] = row[15]; }
         }
-        fi = (int)fid[0];
+        fi = EX ? (int)fid[0] : __double2loint(fr[0]);
 #pragma unroll
         for (int q = 0; q < NF; q++) {
             if (pb + q >= p1) continue;
-            const int fj6 = 6 * (int)fjd[q];
+            const int fj6 = 6 * (EX ? (int)fr[q] : __double2hiint(fr[q]));
             if (sub >= 6) Et[fj6 + sub - 6] = v0[q]; else acc0 += v0[q];
-            if (sub < 4) Et[fj6 + 2 + sub] = v1[q]; else acc1 += v1[q];
+            if (sub < 4) Et[fj6 + 2 + sub] = v1[q]; else if (EX || sub < 7) acc1 += v1[q];
             acc2 += v2[q];
         }
     }
     if (e < 0) return;
     if (sub < 6) Et[6 * fi + sub] = acc0;
-    if (sub == 4) Et[6 * d.NP + 6] = acc1;                             // td
-    else if (sub >= 5) Et[6 * d.NP + sub - 5] = acc1;                  // ex 0-2
-    if (sub < 3) Et[6 * d.NP + 3 + sub] = acc2;                        // ex 3-5
-    else if (sub == 3) sb.ete[((size_t)which * d.B + b) * d.FP + e] = acc2;
-    else if (sub == 4) sb.etb[((size_t)which * d.B + b) * d.FP + e] = acc2;
+    if (EX) {
+        if (sub == 4) Et[6 * d.NP + 6] = acc1;                             // td
+        else if (sub >= 5) Et[6 * d.NP + sub - 5] = acc1;                  // ex 0-2
+        if (sub < 3) Et[6 * d.NP + 3 + sub] = acc2;                        // ex 3-5
+        else if (sub == 3) sb.ete[((size_t)which * d.B + b) * d.FP + e] = acc2;
+        else if (sub == 4) sb.etb[((size_t)which * d.B + b) * d.FP + e] = acc2;
+    } else {
+        if (sub == 4) Et[6 * d.NP + 6] = acc1;                             // td
+        else if (sub == 5) sb.ete[((size_t)which * d.B + b) * d.FP + e] = acc1;
+        else if (sub == 6) sb.etb[((size_t)which * d.B + b) * d.FP + e] = acc1;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -853,7 +881,7 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
         const int nfeat = w.nfeat[b];
         const int* cole = w.cole + (size_t)b * d.F;
         const int* fptr = d.F <= kVFP ? s_fptr : w.feat_ptr + (size_t)b * (d.F + 1);
-        for (int f0 = 8 * wave; f0 < nfeat; f0 += 8 * NW) et_rows8(w, sb, d, b, f0, nfeat, cole, fptr, which, lane);
+        for (int f0 = 8 * wave; f0 < nfeat; f0 += 8 * NW) et_rows8<EX>(w, sb, d, b, f0, nfeat, cole, fptr, which, lane);
     }
     GF_WSTAMP(86);
 }
@@ -951,7 +979,8 @@ __global__ void __launch_bounds__(64 * kMW) ba_linearize_misc_win(Win w, int whi
         if (lane < nwh && wh_on(lane)) {
             const int k = lane, i = wh_i[k], j = i + 1;
             wheel_raw(xs + off_pose(i), xs + off_pose(j), xs + off_exw(NP), xs[off_ix(NP)], xs[off_ix(NP) + 1], xs[off_ix(NP) + 2], xs[off_tdw(NP)],
-                      w.wh_data + ((size_t)b * d.W + k) * WH_STRIDE, sJw + kMJw * k + 22, sJw + kMJw * k, true, true, 33, 33);
+                      w.wh_data + ((size_t)b * d.W + k) * WH_STRIDE, sJw + kMJw * k + 22, sJw + kMJw * k, true, true, 33, 33,
+                      colf[fb_sx(NP)] >= 0 || colf[fb_sx(NP) + 1] >= 0 || colf[fb_sx(NP) + 2] >= 0, colf[fb_tdw(NP)] >= 0);
         }
         GF_WSTAMP_T(64, 67);
     } else {
