@@ -84,6 +84,9 @@ struct gf_ba {
     size_t mwin_lds = 0;   // dynamic LDS of the prior / IMU / wheel sweep (ba_linearize_misc_win)
     int max_vis = 0, max_order = 0, max_prior = 0;   // largest n_visual / factor-order length / prior size of the resident batch (what the uploads copy)
     std::vector<const gf_ba_window*> resident;       // the caller's window behind every resident slot (gf_ba_marginalize_resident)
+    // what packing a window into slot b found out about it; reduced over the batch when the batch is closed (pack_slot may run on one thread per slot)
+    struct SlotMeta { bool any_ex = false; long long mfma = 0, step = 0, jtj = 0; int nvis = 0, norder = 0, npri = 0; };
+    std::vector<SlotMeta> meta;
     double max_solver_time = 0.0;   // ceres::Solver::Options::max_solver_time_in_seconds; 0 = not honoured (the fixed schedule runs without host round trips)
     long long mfma_per_lin = 0;   // v_mfma_f64_16x16x4 instructions of one visual linearisation of the resident batch
     long long jtj_alg_flops = 0;  // algorithmic flops of the same: Nv * 2 * 2 * (12 * 13 / 2 + 12 + 1) per window
@@ -121,16 +124,13 @@ struct gf_ba {
 
 namespace {
 
-int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
+// One window into slot b of the pinned staging tables (everything the kernels read about it, both marginalisation layouts included).  Touches only
+// slot b: any number of slots may be packed concurrently, one thread per slot.
+int pack_slot(gf_ba* h, int b, const gf_ba_window& w) {
     const Dims& d = h->d;
-    if (count < 1 || count > d.B) return gf::set_err(GF_ERR_INVALID, "count %d outside 1..%d", count, d.B);
-    h->any_ex = false;
-    h->mfma_per_lin = 0; h->step_flops = 0; h->jtj_alg_flops = 0;
-    std::atomic<bool> a_any_ex{false};
-    std::atomic<long long> a_mfma{0}, a_step{0}, a_jtj{0};
-    std::atomic<int> a_maxvis{0}, a_maxord{0}, a_maxpri{0};
-    auto pack_one = [&](int b) -> int {
-        const gf_ba_window& w = ws[std::min(b, count - 1)];  // unused slots replicate the last window (kernels run on the whole batch)
+    gf_ba::SlotMeta& M = h->meta[b];
+    M = gf_ba::SlotMeta{};
+    {
         if (w.W != d.W) return gf::set_err(GF_ERR_INVALID, "window %d: W=%d, handle built for %d", b, w.W, d.W);
         if (w.n_feature > d.F || w.n_visual > d.NV || w.n_imu > d.W || w.n_wheel > d.W || w.prior_n > d.NPRI || w.prior_nblocks > 64)
             return gf::set_err(GF_ERR_CAPACITY, "window %d exceeds capacity (features %d/%d, visual %d/%d, prior %d/%d)", b, w.n_feature, d.F, w.n_visual, d.NV, w.prior_n, d.NPRI);
@@ -200,7 +200,7 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
             add(fb_yaw(d.NP), true, 1);
             add(fb_anc(d.NP), !(w.gnss_enabled && ((fac && w.n_gnss > 0) || inpri(GF_ANC * 4096))), 3);
         }
-        if (!w.fix_ex_pose) a_any_ex = true;
+        if (!w.fix_ex_pose) M.any_ex = true;
         SolverState& st = h->st0.h[b];
         memset(&st, 0, sizeof st);
         st.radius = 1e4; st.mu = 1e-8; st.R = col; st.last_successful = 1;
@@ -222,9 +222,8 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
             h->cole.h[(size_t)b * d.F + f] = free_f ? ne++ : -1;
         }
         st.NE = ne;
-        if (b < count) { const double R = st.R, nc = 6.0 * d.NP + 8.0; a_step += (long long)(ne * nc * nc + R * R * R / 3.0 + 2.0 * R * R); }
-        { int v = a_maxvis.load(); while (w.n_visual > v && !a_maxvis.compare_exchange_weak(v, w.n_visual)) {} }
-        { int v = a_maxpri.load(); while (w.prior_n > v && !a_maxpri.compare_exchange_weak(v, w.prior_n)) {} }
+        { const double R = st.R, nc = 6.0 * d.NP + 8.0; M.step = (long long)(ne * nc * nc + R * R * R / 3.0 + 2.0 * R * R); }
+        M.nvis = w.n_visual; M.npri = w.prior_n;
         h->nvis.h[b] = w.n_visual; h->nimu.h[b] = w.n_imu; h->nwh.h[b] = w.n_wheel; h->nfeat.h[b] = w.n_feature;
         {   // pair-sorted order with even padding (each MFMA consumes two factors of one frame pair)
             std::vector<int> idx(w.n_visual);
@@ -242,8 +241,7 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
             if (n > d.NVP) return gf::set_err(GF_ERR_CAPACITY, "factor order overflow");
             h->norder.h[b] = n;
             for (int i = n; i < d.NVP; i++) ord[i] = -1;
-            if (b < count) { a_mfma += (long long)(n / 2) * (w.fix_ex_pose ? 1 : 3); a_jtj += (long long)w.n_visual * 4 * 91; }
-            { int v = a_maxord.load(); while (n > v && !a_maxord.compare_exchange_weak(v, n)) {} }
+            M.mfma = (long long)(n / 2) * (w.fix_ex_pose ? 1 : 3); M.jtj = (long long)w.n_visual * 4 * 91; M.norder = n;
         }
         {   // CSR feature -> factors
             int* fp = h->feat_ptr.h + (size_t)b * (d.F + 1);
@@ -278,13 +276,10 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
             memcpy(h->pri_r.h + (size_t)b * d.NPRI, w.prior_r, (size_t)w.prior_n * 8);
             memcpy(h->pri_x0.h + (size_t)b * d.NPRI * 2, w.prior_x0, (size_t)gs * 8);
         }
-        return GF_OK;
-    };
+    }
     // ---- marginalisation layouts (first-appearance order of the blocks over [prior, IMU0, wheel0, visual factors from frame 0])
-    for (int mode = 0; mode < 2; mode++) h->keep_ids[mode].assign(d.B, {});
-    auto pack_marg = [&](int b) -> int {
+    {
         for (int mode = 0; mode < 2; mode++) {
-            const gf_ba_window& w = ws[std::min(b, count - 1)];
             std::vector<int> dropb, keepb, dropf;
             auto has = [](const std::vector<int>& v, int id) { return std::find(v.begin(), v.end(), id) != v.end(); };
             auto touch = [&](int id, bool dropped) {
@@ -352,8 +347,27 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
             h->mnorder[mode].h[b] = no;
             for (int i = no; i < d.NVP; i++) ord[i] = -1;
         }
-        return GF_OK;
-    };
+    }
+    return GF_OK;
+}
+
+// closes a batch of packed slots: what the launches need to know about the batch as a whole (slots listed in `active`, or 0 .. count - 1)
+void finalize_pack(gf_ba* h, const int* active, int n_active, int count) {
+    const Dims& d = h->d;
+    bool any_ex = false; long long mfma = 0, step = 0, jtj = 0; int mv = 0, mo = 0, mp = 0;
+    for (int q = 0; q < n_active; q++) {
+        const gf_ba::SlotMeta& M = h->meta[active ? active[q] : q];
+        any_ex |= M.any_ex; mfma += M.mfma; step += M.step; jtj += M.jtj; mv = std::max(mv, M.nvis); mo = std::max(mo, M.norder); mp = std::max(mp, M.npri);
+    }
+    h->any_ex = any_ex; h->mfma_per_lin = mfma; h->step_flops = step; h->jtj_alg_flops = jtj;
+    h->max_vis = mv; h->max_order = mo; h->max_prior = mp;
+    h->count = count;
+    (void)d;
+}
+
+int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
+    const Dims& d = h->d;
+    if (count < 1 || count > d.B) return gf::set_err(GF_ERR_INVALID, "count %d outside 1..%d", count, d.B);
     // the windows are independent: pack them on a few host threads (the estimator group hands over hundreds per call)
     {
         const int nt = std::max(1, std::min({d.B / 4, (int)std::thread::hardware_concurrency(), 16}));
@@ -361,8 +375,7 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
         std::mutex em; std::string emsg;
         auto work = [&]() {
             for (int b = next++; b < d.B; b = next++) {
-                int rc = pack_one(b);
-                if (rc == GF_OK) rc = pack_marg(b);
+                const int rc = pack_slot(h, b, ws[std::min(b, count - 1)]);   // unused slots replicate the last window (kernels run on the whole batch)
                 if (rc != GF_OK) { std::lock_guard<std::mutex> lk(em); if (failed == GF_OK) { failed = rc; emsg = gf_last_error(); } }
             }
         };
@@ -372,9 +385,7 @@ int pack_windows(gf_ba* h, const gf_ba_window* ws, int count) {
         for (auto& t : ths) t.join();
         if (failed != GF_OK) return gf::set_err(failed, "%s", emsg.c_str());
     }
-    h->any_ex = a_any_ex; h->mfma_per_lin = a_mfma; h->step_flops = a_step; h->jtj_alg_flops = a_jtj;
-    h->max_vis = a_maxvis; h->max_order = a_maxord; h->max_prior = a_maxpri;
-    h->count = count;
+    finalize_pack(h, nullptr, count, count);
     return GF_OK;
 }
 
@@ -400,6 +411,26 @@ int upload(gf_ba* h) {
     ba_setup<<<dim3(h->d.B), 256, 0, s>>>(h->win());
     HIPCHK(hipGetLastError());
     return GF_OK;
+}
+
+// the solved state and the solver summary of slot b, from the host mirrors the last download filled, into the caller's window (either may be null)
+void unpack_state(gf_ba* h, int b, gf_ba_window* wp, gf_ba_summary* sp) {
+    const Dims& d = h->d;
+    const SolverState& st = h->st.h[b];
+    if (wp) {
+        gf_ba_window& w = *wp;
+        const double* x = h->xs.h + ((size_t)st.cur * d.B + b) * d.XS;
+        for (int i = 0; i < d.NP; i++) { memcpy(w.para_Pose + 7 * i, x + off_pose(i), 56); memcpy(w.para_SpeedBias + 9 * i, x + off_sb(i), 72); }
+        memcpy(w.para_Ex_Pose, x + off_ex(d.NP), 56); memcpy(w.para_Ex_Pose_wheel, x + off_exw(d.NP), 56); memcpy(w.para_Ix, x + off_ix(d.NP), 24);
+        w.para_Td[0] = x[off_td(d.NP)]; w.para_Td_wheel[0] = x[off_tdw(d.NP)];
+        for (int f = 0; f < w.n_feature; f++) w.para_Feature[f] = x[off_feat(d.NP) + f];
+        if (d.GO && w.gnss_enabled) { memcpy(w.para_rcv_dt, x + d.GO, 4 * d.NP * 8); memcpy(w.para_rcv_ddt, x + d.GO + 4 * d.NP, d.NP * 8); w.para_yaw_enu_local[0] = x[d.GO + 5 * d.NP]; memcpy(w.para_anc_ecef, x + d.GO + 5 * d.NP + 1, 24); }
+    }
+    if (sp) {
+        gf_ba_summary& s = *sp;
+        s.iterations = st.iterations; s.successful_steps = st.successful; s.termination = st.termination; s.initial_cost = st.initial_cost; s.final_cost = st.x_cost;
+        s.radius = st.radius;
+    }
 }
 
 int reset_state(gf_ba* h) {
@@ -536,6 +567,8 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     // kept system of the marginalisation: 6 W poses + speed-bias + extrinsics ...; A and V live in LDS up to 92 columns, else in global memory
     const int nkeep = 6 * d.W + 9 + 17 + (gnss ? 9 : 0);
     h->big_marg = nkeep > 92 || getenv("GF_BA_FORCE_GLOBAL") != nullptr;
+    h->meta.assign(d.B, gf_ba::SlotMeta{});
+    for (int mode = 0; mode < 2; mode++) h->keep_ids[mode].assign(d.B, {});
     h->marg_ncap = h->big_marg ? std::min(d.NPRI, nkeep + 16) : 92;
     h->marg_lds = h->big_marg ? 0 : (size_t)2 * h->marg_ncap * h->marg_ncap * sizeof(double);
     if (h->big_step) { h->sg_stride = (h->step_lds / sizeof(double) + 15) & ~(size_t)15; A_(h->Sg.alloc(B * h->sg_stride, false)); }
@@ -632,15 +665,7 @@ int gf_ba_download(gf_ba* h, gf_ba_window* windows, int count, gf_ba_summary* su
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); h->stats.ms_download += ms;
     for (int b = 0; b < count; b++) {
         const SolverState& st = h->st.h[b];
-        if (windows) {
-            gf_ba_window& w = windows[b];
-            const double* x = h->xs.h + ((size_t)st.cur * d.B + b) * d.XS;
-            for (int i = 0; i < d.NP; i++) { memcpy(w.para_Pose + 7 * i, x + off_pose(i), 56); memcpy(w.para_SpeedBias + 9 * i, x + off_sb(i), 72); }
-            memcpy(w.para_Ex_Pose, x + off_ex(d.NP), 56); memcpy(w.para_Ex_Pose_wheel, x + off_exw(d.NP), 56); memcpy(w.para_Ix, x + off_ix(d.NP), 24);
-            w.para_Td[0] = x[off_td(d.NP)]; w.para_Td_wheel[0] = x[off_tdw(d.NP)];
-            for (int f = 0; f < w.n_feature; f++) w.para_Feature[f] = x[off_feat(d.NP) + f];
-            if (d.GO && w.gnss_enabled) { memcpy(w.para_rcv_dt, x + d.GO, 4 * d.NP * 8); memcpy(w.para_rcv_ddt, x + d.GO + 4 * d.NP, d.NP * 8); w.para_yaw_enu_local[0] = x[d.GO + 5 * d.NP]; memcpy(w.para_anc_ecef, x + d.GO + 5 * d.NP + 1, 24); }
-        }
+        unpack_state(h, b, windows ? windows + b : nullptr, summaries ? summaries + b : nullptr);
         if (priors) {
             gf_ba_prior& p = priors[b];
             const int mode = h->last_marg_mode;
@@ -670,12 +695,39 @@ int gf_ba_download(gf_ba* h, gf_ba_window* windows, int count, gf_ba_summary* su
                 }
             }
         }
-        if (summaries) {
-            gf_ba_summary& s = summaries[b];
-            s.iterations = st.iterations; s.successful_steps = st.successful; s.termination = st.termination; s.initial_cost = st.initial_cost; s.final_cost = st.x_cost;
-            s.radius = st.radius;
-        }
     }
+    return GF_OK;
+}
+
+// ---- packed slots: callers that own many windows on many threads (gf_estimator_group) pack every window on its owner's thread, one call closes the
+// batch (upload, solve, one download of all states), and every owner unpacks its own slot again.  The serial part of a batched solve shrinks to the
+// transfers and the kernels (packing 256 windows on one call's 16 threads took longer than solving them).
+int gf_ba_pack_slot(gf_ba* h, int slot, const gf_ba_window* window) {
+    if (!h || !window || slot < 0 || slot >= h->d.B) return gf::set_err(GF_ERR_INVALID, "bad argument (0 <= slot < batch)");
+    if (h->pending) return gf::set_err(GF_ERR_INVALID, "a solve is in flight: call gf_ba_wait first");
+    return pack_slot(h, slot, *window);
+}
+int gf_ba_solve_packed(gf_ba* h, const int* slots, int n, int max_iters) {
+    if (!h || !slots || n < 1 || n > h->d.B) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    if (int rc = gf_ba_wait(h)) return rc;
+    const Dims& d = h->d;
+    std::vector<char> on(d.B, 0);
+    for (int q = 0; q < n; q++) { if (slots[q] < 0 || slots[q] >= d.B || on[slots[q]]) return gf::set_err(GF_ERR_INVALID, "slot %d out of range or listed twice", slots[q]); on[slots[q]] = 1; }
+    for (int b = 0; b < d.B; b++)
+        if (!on[b]) h->st0.h[b].done = 1;   // slots that sit this batch out: the solver kernels leave finished windows alone (their tables, the marginalisation
+                                            // layouts included, stay what their owner packed last: a marginalisation of such a slot may still follow)
+    finalize_pack(h, slots, n, d.B);
+    h->resident.assign(d.B, nullptr);
+    if (int rc = upload(h)) return rc;
+    if (int rc = gf_ba_solve_resident_async(h, max_iters, -1, 1)) return rc;
+    HIPCHK(h->xs.down(h->stream));
+    HIPCHK(hipMemcpyAsync(h->st.h, h->st.d, (size_t)d.B * sizeof(SolverState), hipMemcpyDeviceToHost, h->stream));
+    return gf_ba_wait(h);
+}
+int gf_ba_unpack_slot(gf_ba* h, int slot, gf_ba_window* window, gf_ba_summary* summary) {
+    if (!h || slot < 0 || slot >= h->d.B) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    if (h->pending) return gf::set_err(GF_ERR_INVALID, "a solve is in flight: call gf_ba_wait first");
+    unpack_state(h, slot, window, summary);
     return GF_OK;
 }
 

@@ -435,7 +435,9 @@ struct Gate {
 
 struct BatchSolver {
     struct Req { int kind; gf_ba_window* w; int iters, mode; gf_ba_summary* sum; gf_ba_prior* prior; int rc; std::atomic<bool> done; std::string err;
-                 std::vector<ImuPre*> pres; const double* noise; };   // kind 0 solve, 1 marginalise, 2 IMU pre-integrations of this frame
+                 std::vector<ImuPre*> pres; const double* noise; int slot = -1; };   // kind 0 solve, 1 marginalise, 2 IMU pre-integrations of this frame
+    // slot: the member's own slot of the shared handle.  A solve request arrives with its window already packed into that slot by the member's thread
+    // (gf_ba_pack_slot), and the member unpacks its result itself: the batching thread only uploads, launches and downloads.
     gf_ba* ba = nullptr;
     gf::PreintBatch* pre = nullptr;   // GF_GROUP_DEVICE_PREINT=1: the members' pending pre-integrations run as one launch per camera frame
     double t_pre = 0; long long pre_batches = 0, pre_intervals = 0;
@@ -444,7 +446,8 @@ struct BatchSolver {
     int active = 0;                 // members currently inside a frame of a group step
     std::vector<Req*> pending;
     long long batches = 0, windows = 0, largest = 0;
-    std::vector<gf_ba_window*> resident;   // the members' windows behind the slots of the last solve (their marginalisations reuse the device copy)
+    std::vector<gf_ba_window*> resident;   // per slot: the member's window its last solve left on the device (the marginalisation reuses the device copy)
+    size_t mem_count = 0;
     double t_solve = 0, t_marg = 0;        // wall time inside the batched calls [s] (GF_GROUP_TIMING=1 prints them when the group is destroyed)
 
     int submit(Req& r) {
@@ -462,6 +465,7 @@ struct BatchSolver {
         return r.rc;
     }
     void leave() { std::unique_lock<std::mutex> lk(m); active--; maybe_run(); }
+    void leave_with_error() {}   // a member that fails before its request ends its frame with the error; the worker's leave() takes it out of the rendezvous
     // with the lock held: run everything that waits once nobody is left computing on the host
     void maybe_run() {
         if (pending.empty() || (int)pending.size() < active) return;
@@ -493,28 +497,24 @@ struct BatchSolver {
             const std::vector<Req*>& grp = groups[1 + pass];
             if (grp.empty()) continue;
             // the shared handle takes its iteration count per call: group by it (members of one group share a configuration)
-            std::vector<gf_ba_window> wins(grp.size());
-            for (size_t i = 0; i < grp.size(); i++) wins[i] = *grp[i]->w;
             int rc;
             const auto tc0 = std::chrono::steady_clock::now();
+            std::vector<int> slots(grp.size());
+            for (size_t i = 0; i < grp.size(); i++) slots[i] = grp[i]->slot;
             if (pass == 0) {
-                std::vector<gf_ba_summary> sums(grp.size());
-                rc = gf_ba_solve(ba, wins.data(), (int)grp.size(), grp[0]->iters, sums.data());
-                for (size_t i = 0; i < grp.size(); i++) if (rc == GF_OK) *grp[i]->sum = sums[i];
-                resident.clear();
-                if (rc == GF_OK) for (Req* r : grp) resident.push_back(r->w);
+                rc = gf_ba_solve_packed(ba, slots.data(), (int)grp.size(), grp[0]->iters);
+                if (resident.size() != mem_count) resident.assign(mem_count, nullptr);
+                if (rc == GF_OK) for (Req* r : grp) resident[r->slot] = r->w;   // this member's window is what its slot holds now
             } else {
+                std::vector<gf_ba_window> wins(grp.size());
+                for (size_t i = 0; i < grp.size(); i++) wins[i] = *grp[i]->w;
                 std::vector<gf_ba_prior> pri(grp.size());
                 for (size_t i = 0; i < grp.size(); i++) pri[i] = *grp[i]->prior;
                 // the windows of this step's solve are still on the device: only their states (double2vector's gauge fix sits in between) go up again
-                std::vector<int> slots(grp.size(), -1);
-                bool all = !resident.empty();
-                for (size_t i = 0; i < grp.size() && all; i++) {
-                    const auto it = std::find(resident.begin(), resident.end(), grp[i]->w);
-                    if (it == resident.end()) all = false; else slots[i] = (int)(it - resident.begin());
-                }
+                bool all = resident.size() == mem_count;
+                for (size_t i = 0; i < grp.size() && all; i++) all = resident[grp[i]->slot] == grp[i]->w;
                 if (all) rc = gf_ba_marginalize_resident(ba, slots.data(), wins.data(), (int)grp.size(), pass - 1, pri.data());
-                else { rc = gf_ba_marginalize(ba, wins.data(), (int)grp.size(), pass - 1, pri.data()); resident.clear(); }
+                else rc = gf::set_err(GF_ERR_INVALID, "marginalisation of a window that is not resident in its member's slot");
                 for (size_t i = 0; i < grp.size(); i++) if (rc == GF_OK) *grp[i]->prior = pri[i];
             }
             (pass == 0 ? t_solve : t_marg) += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
@@ -536,6 +536,7 @@ struct gf_estimator {
     FeatureManager f_manager;
     gf_ba* ba = nullptr;
     BatchSolver* group = nullptr;      // member of a gf_estimator_group: solves go through the group's shared handle
+    int group_slot = -1;               // ... in this slot of it
     gf_tracker* tracker = nullptr;
     // measurement queues (estimator.h:182-190)
     std::deque<std::pair<double, V3>> accBuf, gyrBuf, wheelVelBuf, wheelGyrBuf;
@@ -1491,8 +1492,13 @@ struct gf_estimator {
         lap(1);
         if (!group && cfg.max_solver_time > 0) gf_ba_set_max_solver_time(ba, marginalization_flag == MARGIN_OLD ? cfg.max_solver_time * 4.0 / 5.0 : cfg.max_solver_time);   // EST:3312-3315
         if (group) {   // ceres::Solve, EST:3303-3318
+            // this thread packs its own window into the shared staging tables, the rendezvous only uploads and launches, and the result is unpacked here again
+            const int prc = gf_ba_pack_slot(group->ba, group_slot, &w);
             BatchSolver::Req rq{0, &w, cfg.num_iterations, 0, &last_summary, nullptr, GF_OK, false, std::string()};
+            rq.slot = group_slot;
+            if (prc != GF_OK) { const std::string msg = gf_last_error(); group->leave_with_error(); return gf::set_err(prc, "%s", msg.c_str()); }
             if (int rc = group->submit(rq)) return rc;
+            if (int rc = gf_ba_unpack_slot(group->ba, group_slot, &w, &last_summary)) return rc;
         } else if (int rc = gf_ba_solve(ba, &w, 1, cfg.num_iterations, &last_summary)) return rc;
         lap(2);
         n_optimizations++;
@@ -1518,6 +1524,7 @@ struct gf_estimator {
             lap(3);
             if (group) {
                 BatchSolver::Req rq{1, &w, 0, marginalization_flag, nullptr, &p, GF_OK, false, std::string()};
+                rq.slot = group_slot;
                 if (int rc = group->submit(rq)) return rc;
             } else if (int rc = gf_ba_marginalize(ba, &w, 1, marginalization_flag, &p)) return rc;
             lap(4);
@@ -2018,11 +2025,12 @@ int gf_estimator_group_create(const gf_estimator_cfg* c, int n, gf_estimator_gro
     for (int i = 0; i < n; i++) {
         gf_estimator* e = nullptr;
         if (int rc = gf_estimator_create(c, &e)) { delete g; return rc; }
-        e->group = &g->solver;
+        e->group = &g->solver; e->group_slot = i;
         g->mem.push_back(e);
     }
     gf_ba_cfg bc{c->window_size, c->max_features, c->max_visual, n, c->gnss_enable ? c->max_gnss_per_frame * (c->window_size + 1) : 0};
     if (int rc = gf_ba_create(&bc, &g->solver.ba)) { delete g; return rc; }
+    g->solver.mem_count = (size_t)n;
     (void)hipGetDevice(&g->device);
     if (const char* e = getenv("GF_GROUP_DEVICE_PREINT")) if (atoi(e) != 0) if (int rc = gf::preint_batch_create(&g->solver.pre)) { delete g; return rc; }
     g->job_gen.reset(new std::atomic<int>[n]); for (int i = 0; i < n; i++) g->job_gen[i].store(0, std::memory_order_relaxed);

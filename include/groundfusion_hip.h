@@ -226,6 +226,14 @@ int gf_ba_download(gf_ba* h, gf_ba_window* windows, int count, gf_ba_summary* su
  * per-step pose gather across GPUs (north_star; there is no counterpart in the single-process reference).  Enqueued behind a pending
  * asynchronous solve (complete after gf_ba_wait); otherwise complete on return. */
 int gf_ba_export_newest_poses(gf_ba* h, void* d_out, int count);
+/* The same solve for callers that own many windows on many threads (gf_estimator_group_*; no counterpart in the reference, whose Estimator owns one
+ * window): gf_ba_pack_slot packs one window into slot `slot` of the handle's staging tables -- callable concurrently for different slots, one thread per
+ * slot --, gf_ba_solve_packed closes the batch (upload, ceres::Solve on the listed slots -- slots not listed sit this batch out --, one download of all
+ * states) and gf_ba_unpack_slot copies the solved state and the summary of a slot back into its owner's window (again callable concurrently for
+ * different slots).  Results are identical to gf_ba_solve on the same windows.  gf_ba_marginalize_resident then takes the same slot numbers. */
+int gf_ba_pack_slot(gf_ba* h, int slot, const gf_ba_window* window);
+int gf_ba_solve_packed(gf_ba* h, const int* slots, int n, int max_iters);
+int gf_ba_unpack_slot(gf_ba* h, int slot, gf_ba_window* window, gf_ba_summary* summary);
 /* ceres::Solver::Options::max_solver_time_in_seconds (estimator.cpp:3312-3315) for the following gf_ba_solve / gf_ba_solve_resident calls; 0 (default) = not
  * honoured: the iterations are enqueued back to back.  With a limit the host synchronises before every iteration, as Ceres checks its clock there. */
 int gf_ba_set_max_solver_time(gf_ba* h, double seconds);
