@@ -73,7 +73,7 @@ struct gf_ba {
     Buf<int> ngnss, gn_idx, gn_gptr, gn_gitem;
     Buf<double> gn_rows;
     // marginalisation: column maps per mode (0 MARGIN_OLD, 1 MARGIN_SECOND_NEW), outputs
-    Buf<int> mcolf[2], mcole[2], morder[2], mnorder[2], minfo[2];
+    Buf<int> mcolf[2], mcole[2], morder[2], mnorder[2], minfo[2], minfo_stage;
     Buf<double> outJ, outr;
     Buf<long long> stamps;
     std::vector<std::vector<int>> keep_ids[2];   // per window: kept block ids (before the address shift), in column order
@@ -98,6 +98,7 @@ struct gf_ba {
         for (auto* b : dbl()) b->release();
         for (auto* b : ints()) b->release();
         for (int m = 0; m < 2; m++) { mcolf[m].release(); mcole[m].release(); morder[m].release(); mnorder[m].release(); minfo[m].release(); }
+        minfo_stage.release();
         outJ.release(); outr.release(); stamps.release();
         st.release(); st0.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -563,6 +564,7 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     A_(h->rhs.alloc(B * d.RP, false)); A_(h->yv.alloc(B * VS, false));
     if (gnss) { A_(h->ngnss.alloc(B, true)); A_(h->gn_idx.alloc(B * d.NG * 4, true)); A_(h->gn_data.alloc(B * d.NG * GN_STRIDE, true)); A_(h->gn_misc.alloc(B * (GN_MISC + d.NP), true)); A_(h->gn_gptr.alloc(B * (d.NGRP + 2), true)); A_(h->gn_gitem.alloc(B * d.NG, true)); A_(h->gn_rows.alloc(B * d.NG * GN_ROW, false)); }
     for (int m = 0; m < 2; m++) { A_(h->mcolf[m].alloc(B * d.NFB, true)); A_(h->mcole[m].alloc(B * d.F, true)); A_(h->morder[m].alloc(B * d.NVP, true)); A_(h->mnorder[m].alloc(B, true)); A_(h->minfo[m].alloc(B * 4, true)); }
+    A_(h->minfo_stage.alloc(B * 4, true));
     A_(h->outJ.alloc(B * (size_t)d.NPRI * d.NPRI, true)); A_(h->outr.alloc(B * d.NPRI, true)); A_(h->stamps.alloc(128, true));
     // kept system of the marginalisation: 6 W poses + speed-bias + extrinsics ...; A and V live in LDS up to 92 columns, else in global memory
     const int nkeep = 6 * d.W + 9 + 17 + (gnss ? 9 : 0);
@@ -749,8 +751,8 @@ int gf_ba_marginalize(gf_ba* h, const gf_ba_window* windows, int count, int mode
 // ceres::Solve and the marginalisation (estimator.cpp:3327, :3337), so the states differ from what the solve left on the device, the factors do
 // not.  slots[i] = position of windows[i] in the resident batch.  Slots not listed are marginalised too (the kernels run on the whole batch);
 // their results are not fetched.
-int gf_ba_marginalize_resident(gf_ba* h, const int* slots, const gf_ba_window* windows, int n, int mode, gf_ba_prior* priors) {
-    if (!h || !slots || !windows || !priors || n < 1 || mode < 0 || mode > 1) return gf::set_err(GF_ERR_INVALID, "bad argument");
+int gf_ba_marginalize_resident(gf_ba* h, const int* slots, const gf_ba_window* windows, int n, int mode, gf_ba_prior* priors) {   // priors == NULL: fetch them with gf_ba_unpack_prior_slot
+    if (!h || !slots || !windows || n < 1 || mode < 0 || mode > 1) return gf::set_err(GF_ERR_INVALID, "bad argument");
     if (int rc = gf_ba_wait(h)) return rc;
     const Dims& d = h->d;
     for (int i = 0; i < n; i++) {
@@ -770,6 +772,13 @@ int gf_ba_marginalize_resident(gf_ba* h, const int* slots, const gf_ba_window* w
         if (w.fix_poses) for (int k = 0; k < d.NP; k++) x[off_sb(k)] = x[off_sb(k) + 1] = x[off_sb(k) + 2] = 0.0;
     }
     HIPCHK(h->xs0.up(h->stream));
+    {   // only the listed slots are marginalised: the others keep whatever prior their last marginalisation left in the output buffers (their owners may
+        // not have fetched it yet -- two marginalisation kinds of one batch run back to back), so the kernels see them as invalid for this launch
+        std::vector<char> on(d.B, 0);
+        for (int i = 0; i < n; i++) on[slots[i]] = 1;
+        for (int b = 0; b < d.B; b++) { for (int q = 0; q < 4; q++) h->minfo_stage.h[(size_t)b * 4 + q] = h->minfo[mode].h[(size_t)b * 4 + q]; if (!on[b]) h->minfo_stage.h[(size_t)b * 4 + 3] = 0; }
+        HIPCHK(hipMemcpyAsync(h->minfo[mode].d, h->minfo_stage.h, (size_t)d.B * 4 * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    }
     if (int rc = gf_ba_solve_resident(h, 0, mode, 1)) return rc;
     // priors of the listed slots: n x n of J, n of r (the rest of the capacity-sized slots stays on the device)
     const int* inf0 = h->minfo[mode].h;
@@ -780,12 +789,22 @@ int gf_ba_marginalize_resident(gf_ba* h, const int* slots, const gf_ba_window* w
         HIPCHK(hipMemcpy2DAsync(h->outr.h, (size_t)d.NPRI * 8, h->outr.d, (size_t)d.NPRI * 8, (size_t)nmax * 8, h->count, hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
-    for (int i = 0; i < n; i++) {
-        const int b = slots[i];
-        gf_ba_prior& p = priors[i];
-        const int* inf = inf0 + (size_t)b * 4;
+    h->last_marg_mode = mode;
+    if (priors) for (int i = 0; i < n; i++) if (int rc = gf_ba_unpack_prior_slot(h, slots[i], mode, &priors[i])) return rc;
+    return GF_OK;
+}
+
+// the prior gf_ba_marginalize_resident left for slot `slot` in the host mirrors (kept block ids after the address shift, J, r, linearisation point): callable
+// concurrently for different slots -- the owners of the windows copy their own 60 KB each instead of one thread copying 15 MB for all of them
+int gf_ba_unpack_prior_slot(gf_ba* h, int slot, int mode, gf_ba_prior* prior) {
+    if (!h || !prior || slot < 0 || slot >= h->d.B || mode < 0 || mode > 1) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    const Dims& d = h->d;
+    const int b = slot;
+    gf_ba_prior& p = *prior;
+    {
+        const int* inf = h->minfo[mode].h + (size_t)b * 4;
         p.valid = inf[3]; p.m = inf[0] + inf[1]; p.n = 0; p.nblocks = 0;
-        if (!inf[3]) continue;
+        if (!inf[3]) return GF_OK;
         const int nn = inf[2];
         const std::vector<int>& keep = h->keep_ids[mode][b];
         if (nn > p.cap_n || (int)keep.size() > p.cap_blocks) return gf::set_err(GF_ERR_CAPACITY, "prior capacity too small (n=%d, blocks=%zu)", nn, keep.size());

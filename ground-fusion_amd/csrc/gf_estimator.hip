@@ -508,14 +508,12 @@ struct BatchSolver {
             } else {
                 std::vector<gf_ba_window> wins(grp.size());
                 for (size_t i = 0; i < grp.size(); i++) wins[i] = *grp[i]->w;
-                std::vector<gf_ba_prior> pri(grp.size());
-                for (size_t i = 0; i < grp.size(); i++) pri[i] = *grp[i]->prior;
-                // the windows of this step's solve are still on the device: only their states (double2vector's gauge fix sits in between) go up again
+                // the windows of this step's solve are still on the device: only their states (double2vector's gauge fix sits in between) go up again;
+                // every member then copies its own prior out of the handle's host mirrors (gf_ba_unpack_prior_slot on its own thread)
                 bool all = resident.size() == mem_count;
                 for (size_t i = 0; i < grp.size() && all; i++) all = resident[grp[i]->slot] == grp[i]->w;
-                if (all) rc = gf_ba_marginalize_resident(ba, slots.data(), wins.data(), (int)grp.size(), pass - 1, pri.data());
+                if (all) rc = gf_ba_marginalize_resident(ba, slots.data(), wins.data(), (int)grp.size(), pass - 1, nullptr);
                 else rc = gf::set_err(GF_ERR_INVALID, "marginalisation of a window that is not resident in its member's slot");
-                for (size_t i = 0; i < grp.size(); i++) if (rc == GF_OK) *grp[i]->prior = pri[i];
             }
             (pass == 0 ? t_solve : t_marg) += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
             const std::string err = rc == GF_OK ? std::string() : std::string(gf_last_error());
@@ -1526,6 +1524,7 @@ struct gf_estimator {
                 BatchSolver::Req rq{1, &w, 0, marginalization_flag, nullptr, &p, GF_OK, false, std::string()};
                 rq.slot = group_slot;
                 if (int rc = group->submit(rq)) return rc;
+                if (int rc = gf_ba_unpack_prior_slot(group->ba, group_slot, marginalization_flag, &p)) return rc;
             } else if (int rc = gf_ba_marginalize(ba, &w, 1, marginalization_flag, &p)) return rc;
             lap(4);
             prior_valid = p.valid != 0;
@@ -1983,7 +1982,7 @@ struct gf_estimator_group {
     std::atomic<bool> stop{false};
     std::unique_ptr<std::atomic<int>[]> job_gen;   // generation of `go` in which member i has a frame to process (0 = never)
     std::vector<double> t;
-    std::vector<std::vector<gf_feature_obs>> frames;
+    std::vector<const gf_feature_obs*> frame_ptr; std::vector<int> frame_n;   // this step's frame of member i inside the caller's buffer (no copy)
     std::vector<int> rcs;
     std::vector<std::string> errs;
 
@@ -1999,7 +1998,7 @@ struct gf_estimator_group {
             // step k + 1 is being set up sees job_gen[i] == k + 1 != seen, goes round the loop, picks up generation k + 1 and runs its frame exactly once.
             if (job_gen[i].load(std::memory_order_acquire) != seen) continue;
             mem[i]->t_mark = gf_estimator::cpu_now();
-            const int rc = gf_estimator_input_feature(mem[i], t[i], frames[i].data(), (int)frames[i].size());
+            const int rc = gf_estimator_input_feature(mem[i], t[i], frame_ptr[i], frame_n[i]);   // the caller's buffer: input_features does not return before this is done
             mem[i]->lap(5);
             rcs[i] = rc;
             if (rc != GF_OK) errs[i] = gf_last_error();
@@ -2034,7 +2033,7 @@ int gf_estimator_group_create(const gf_estimator_cfg* c, int n, gf_estimator_gro
     (void)hipGetDevice(&g->device);
     if (const char* e = getenv("GF_GROUP_DEVICE_PREINT")) if (atoi(e) != 0) if (int rc = gf::preint_batch_create(&g->solver.pre)) { delete g; return rc; }
     g->job_gen.reset(new std::atomic<int>[n]); for (int i = 0; i < n; i++) g->job_gen[i].store(0, std::memory_order_relaxed);
-    g->t.assign(n, 0.0); g->frames.resize(n); g->rcs.assign(n, GF_OK); g->errs.resize(n);
+    g->t.assign(n, 0.0); g->frame_ptr.assign(n, nullptr); g->frame_n.assign(n, 0); g->rcs.assign(n, GF_OK); g->errs.resize(n);
     for (int i = 0; i < n; i++) g->thr.emplace_back([g, i] { g->worker(i); });
     *out = g;
     return GF_OK;
@@ -2083,7 +2082,7 @@ int gf_estimator_group_input_features(gf_estimator_group* g, int count, const in
         const int next = g->go.now() + 1;   // only this function (serialised by g->m) and the destructor bump `go`
         for (int k = 0; k < count; k++) {
             const int i = seq[k];
-            g->t[i] = t[k]; g->frames[i].assign(obs + off, obs + off + n_obs[k]); g->rcs[i] = GF_OK;
+            g->t[i] = t[k]; g->frame_ptr[i] = n_obs[k] > 0 ? obs + off : nullptr; g->frame_n[i] = n_obs[k]; g->rcs[i] = GF_OK;
             g->job_gen[i].store(next, std::memory_order_release);
             off += (size_t)n_obs[k];
         }

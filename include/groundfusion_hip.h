@@ -215,6 +215,8 @@ int gf_ba_marginalize(gf_ba* h, const gf_ba_window* windows, int count, int mode
 /* the same on windows that the preceding gf_ba_solve / gf_ba_upload left resident: only the parameter blocks (changed by double2vector's gauge fix,
  * estimator.cpp:3327-3337) are uploaded again, only the priors' n x n blocks come back.  slots[i]: position of windows[i] in the resident batch */
 int gf_ba_marginalize_resident(gf_ba* h, const int* slots, const gf_ba_window* windows, int n, int mode, gf_ba_prior* priors);
+/* priors == NULL above: the priors stay in the handle's host mirrors and every owner fetches its own (callable concurrently for different slots) */
+int gf_ba_unpack_prior_slot(gf_ba* h, int slot, int mode, gf_ba_prior* prior);
 /* throughput path: windows stay resident in HBM between calls */
 int gf_ba_upload(gf_ba* h, const gf_ba_window* windows, int count);
 int gf_ba_solve_resident(gf_ba* h, int max_iters, int marginalize_mode /* -1: none */, int reset_state);
