@@ -30,6 +30,7 @@ namespace gf { int set_err(int code, const char* fmt, ...); }
 using namespace gfb;
 
 namespace {
+std::atomic<long long> g_up_bytes{0}, g_up_calls{0};   // host -> device traffic of this process (GF_GROUP_TIMING prints it)
 template <class T> struct Buf {  // device buffer + pinned host mirror
     T* d = nullptr; T* h = nullptr; size_t n = 0;
     int alloc(size_t count, bool host) {
@@ -39,10 +40,11 @@ template <class T> struct Buf {  // device buffer + pinned host mirror
         return GF_OK;
     }
     void release() { if (d) (void)hipFree(d); if (h) (void)hipHostFree(h); d = nullptr; h = nullptr; }
-    hipError_t up(hipStream_t s) { return hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, s); }
+    hipError_t up(hipStream_t s) { g_up_bytes += (long long)(n * sizeof(T)); g_up_calls++; return hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, s); }
     // `rows` rows of `pitch` elements, only the first `used` of each are live: one strided copy of what the kernels read
     hipError_t up2d(hipStream_t s, size_t rows, size_t pitch, size_t used) {
         if (used == 0 || rows == 0) return hipSuccess;
+        g_up_bytes += (long long)(rows * std::min(used, pitch) * sizeof(T)); g_up_calls++;
         if (used >= pitch) return hipMemcpyAsync(d, h, rows * pitch * sizeof(T), hipMemcpyHostToDevice, s);
         return hipMemcpy2DAsync(d, pitch * sizeof(T), h, pitch * sizeof(T), used * sizeof(T), rows, hipMemcpyHostToDevice, s);
     }
@@ -56,7 +58,8 @@ struct gf_ba {
     int count = 0;       // windows currently resident
     bool any_ex = false; // some window estimates the camera extrinsic
     hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};   // 6, 7: around the second ba_step of a solve (the first full dogleg step)
+    hipEvent_t ev[10] = {};   // 6, 7: around the second ba_step of a solve (the first full dogleg step); 8, 9: around the upload of gf_ba_solve_packed
+    bool packed_upload_timed = false;
     bool pending = false;   // an asynchronous solve is in flight
     int pending_iters = 0;
     gf_ba_stats stats{};
@@ -65,7 +68,7 @@ struct gf_ba {
     Buf<double> xs0;     // pristine states [B][XS] (for reset)
     Buf<double> xs;      // [2][B][XS]
     Buf<int> colf, cole, nvis, nimu, nwh, nfeat, vis_feat, vis_i, vis_j, order, norder, feat_ptr, feat_fac, vis_pos, imu_i, wh_i, pri_n, pri_nb, pri_bid;
-    Buf<double> vis_data, imu_data, wh_data, pri_J, pri_r, pri_x0;
+    Buf<double> vis_data, feat_obs, imu_data, wh_data, pri_J, pri_r, pri_x0;
     Buf<SolverState> st, st0;
     // work
     Buf<double> imu_sqrt, wh_sqrt, pri_A, pri_b, pri_c, H, g, Vc, vtile, wpar, cost, efac;
@@ -82,16 +85,20 @@ struct gf_ba {
     size_t vwinx_lds = 0;  // the same for the variant with camera-extrinsic columns (free extrinsic; MARGIN_OLD sweep)
     size_t vtile_stride = 0;   // doubles per window in vtile (0: both variants keep their tiles in LDS)
     size_t mwin_lds = 0;   // dynamic LDS of the prior / IMU / wheel sweep (ba_linearize_misc_win)
-    int max_vis = 0, max_order = 0, max_prior = 0;   // largest n_visual / factor-order length / prior size of the resident batch (what the uploads copy)
+    int max_vis = 0, max_order = 0, max_prior = 0, max_feat = 0;   // largest n_visual / factor-order length / prior size of the resident batch (what the uploads copy)
     std::vector<const gf_ba_window*> resident;       // the caller's window behind every resident slot (gf_ba_marginalize_resident)
     // what packing a window into slot b found out about it; reduced over the batch when the batch is closed (pack_slot may run on one thread per slot)
-    struct SlotMeta { bool any_ex = false; long long mfma = 0, step = 0, jtj = 0; int nvis = 0, norder = 0, npri = 0; };
+    struct SlotMeta { bool any_ex = false, pri_res = false; long long mfma = 0, step = 0, jtj = 0; int nvis = 0, norder = 0, npri = 0, nfeat = 0; };
     std::vector<SlotMeta> meta;
+    // device-resident priors (gf_ba_pack_slot with prior_n > 0 and prior_J == NULL): outJ_n[b] = size of the prior the last gf_ba_marginalize_resident left in
+    // the output buffer of slot b (0: none); the next solve of that slot copies it device to device into the prior table instead of taking it from the host
+    std::vector<int> outJ_n, active;
+    bool all_pri_res = false, any_pri_res = false, outJ_host_stale = false;
     double max_solver_time = 0.0;   // ceres::Solver::Options::max_solver_time_in_seconds; 0 = not honoured (the fixed schedule runs without host round trips)
     long long mfma_per_lin = 0;   // v_mfma_f64_16x16x4 instructions of one visual linearisation of the resident batch
     long long jtj_alg_flops = 0;  // algorithmic flops of the same: Nv * 2 * 2 * (12 * 13 / 2 + 12 + 1) per window
     long long step_flops = 0;     // dense algebra of one ba_step over the resident batch: Schur SYRK NE*n_c^2 + Cholesky R^3/3 + substitutions 2 R^2
-    std::vector<Buf<double>*> dbl() { return {&xs0, &xs, &vis_data, &imu_data, &wh_data, &pri_J, &pri_r, &pri_x0, &imu_sqrt, &wh_sqrt, &pri_A, &pri_b, &pri_c, &H, &g, &Vc, &vtile, &wpar, &cost, &efac,
+    std::vector<Buf<double>*> dbl() { return {&xs0, &xs, &vis_data, &feat_obs, &imu_data, &wh_data, &pri_J, &pri_r, &pri_x0, &imu_sqrt, &wh_sqrt, &pri_A, &pri_b, &pri_c, &H, &g, &Vc, &vtile, &wpar, &cost, &efac,
                                               &scale, &diag, &grad, &gn, &step, &u, &Et, &Es, &ete, &etb, &rhs, &yv, &Sg, &Mg, &gn_data, &gn_misc, &gn_rows}; }
     std::vector<Buf<int>*> ints() { return {&colf, &cole, &nvis, &nimu, &nwh, &nfeat, &vis_feat, &vis_i, &vis_j, &order, &norder, &feat_ptr, &feat_fac, &vis_pos, &imu_i, &wh_i, &pri_n, &pri_nb, &pri_bid, &ngnss, &gn_idx, &gn_gptr, &gn_gitem}; }
     void release() {
@@ -107,7 +114,7 @@ struct gf_ba {
     Win win() {
         Win w{};
         w.d = d; w.xs = xs.d; w.colf = colf.d; w.cole = cole.d; w.nvis = nvis.d; w.nimu = nimu.d; w.nwh = nwh.d; w.nfeat = nfeat.d;
-        w.vis_feat = vis_feat.d; w.vis_i = vis_i.d; w.vis_j = vis_j.d; w.vis_data = vis_data.d; w.order = order.d; w.norder = norder.d;
+        w.vis_feat = vis_feat.d; w.vis_i = vis_i.d; w.vis_j = vis_j.d; w.vis_data = vis_data.d; w.feat_obs = feat_obs.d; w.order = order.d; w.norder = norder.d;
         w.ngnss = ngnss.d; w.gn_idx = gn_idx.d; w.gn_data = gn_data.d; w.gn_misc = gn_misc.d; w.gn_gptr = gn_gptr.d; w.gn_gitem = gn_gitem.d; w.gn_rows = gn_rows.d;
         w.feat_ptr = feat_ptr.d; w.feat_fac = feat_fac.d; w.vis_pos = vis_pos.d; w.imu_i = imu_i.d; w.imu_data = imu_data.d; w.wh_i = wh_i.d; w.wh_data = wh_data.d;
         w.imu_sqrt = imu_sqrt.d; w.wh_sqrt = wh_sqrt.d; w.pri_n = pri_n.d; w.pri_nb = pri_nb.d; w.pri_bid = pri_bid.d; w.pri_J = pri_J.d; w.pri_r = pri_r.d;
@@ -212,9 +219,14 @@ int pack_slot(gf_ba* h, int b, const gf_ba_window& w) {
             if (w.vis_feature[k] < 0 || w.vis_feature[k] >= w.n_feature || w.vis_i[k] < 0 || w.vis_i[k] >= w.vis_j[k] || w.vis_j[k] > d.W)   // frame i is the feature's start frame: i < j
                 return gf::set_err(GF_ERR_INVALID, "window %d: visual factor %d has bad indices", b, k);
             h->vis_feat.h[kk] = w.vis_feature[k]; h->vis_i.h[kk] = w.vis_i[k]; h->vis_j.h[kk] = w.vis_j[k];
-            double* vd = h->vis_data.h + kk * 12;
-            memcpy(vd, w.vis_pts_i + 3 * k, 24); memcpy(vd + 3, w.vis_pts_j + 3 * k, 24); memcpy(vd + 6, w.vis_vel_i + 2 * k, 16); memcpy(vd + 8, w.vis_vel_j + 2 * k, 16);
-            vd[10] = w.vis_td_i[k]; vd[11] = w.vis_td_j[k];
+            double* vd = h->vis_data.h + kk * 6;
+            memcpy(vd, w.vis_pts_j + 3 * k, 24); memcpy(vd + 3, w.vis_vel_j + 2 * k, 16); vd[5] = w.vis_td_j[k];
+            // the observation in the start frame is stored once per feature: every factor of a feature must bring the same one (they are built from
+            // feature_per_frame[0], estimator.cpp:3276-3290)
+            double* fo = h->feat_obs.h + ((size_t)b * d.F + w.vis_feature[k]) * 6;
+            double me[6]; memcpy(me, w.vis_pts_i + 3 * k, 24); memcpy(me + 3, w.vis_vel_i + 2 * k, 16); me[5] = w.vis_td_i[k];
+            if (!used[w.vis_feature[k]]) memcpy(fo, me, 48);
+            else if (memcmp(fo, me, 48) != 0) return gf::set_err(GF_ERR_INVALID, "window %d: visual factor %d brings a start-frame observation that differs from the other factors of feature %d", b, k, w.vis_feature[k]);
             used[w.vis_feature[k]] = 1;
         }
         int ne = 0;
@@ -224,7 +236,7 @@ int pack_slot(gf_ba* h, int b, const gf_ba_window& w) {
         }
         st.NE = ne;
         { const double R = st.R, nc = 6.0 * d.NP + 8.0; M.step = (long long)(ne * nc * nc + R * R * R / 3.0 + 2.0 * R * R); }
-        M.nvis = w.n_visual; M.npri = w.prior_n;
+        M.nvis = w.n_visual; M.npri = w.prior_n; M.nfeat = w.n_feature;
         h->nvis.h[b] = w.n_visual; h->nimu.h[b] = w.n_imu; h->nwh.h[b] = w.n_wheel; h->nfeat.h[b] = w.n_feature;
         {   // pair-sorted order with even padding (each MFMA consumes two factors of one frame pair)
             std::vector<int> idx(w.n_visual);
@@ -273,7 +285,11 @@ int pack_slot(gf_ba* h, int b, const gf_ba_window& w) {
         if (w.prior_n > 0) {
             int gs = 0;
             for (int q = 0; q < w.prior_nblocks; q++) { h->pri_bid.h[(size_t)b * 64 + q] = w.prior_block_id[q]; gs += gsize_kind(w.prior_block_id[q] / 4096); }
-            memcpy(h->pri_J.h + (size_t)b * d.NPRI * d.NPRI, w.prior_J, (size_t)w.prior_n * w.prior_n * 8);
+            if (w.prior_J) memcpy(h->pri_J.h + (size_t)b * d.NPRI * d.NPRI, w.prior_J, (size_t)w.prior_n * w.prior_n * 8);
+            else {   // resident prior: what this slot's last marginalisation left on the device
+                if (h->outJ_n[b] != w.prior_n) return gf::set_err(GF_ERR_INVALID, "window %d: prior_J is null but slot %d holds no marginalisation output of %d columns (it holds %d)", b, b, w.prior_n, h->outJ_n[b]);
+                M.pri_res = true;
+            }
             memcpy(h->pri_r.h + (size_t)b * d.NPRI, w.prior_r, (size_t)w.prior_n * 8);
             memcpy(h->pri_x0.h + (size_t)b * d.NPRI * 2, w.prior_x0, (size_t)gs * 8);
         }
@@ -355,13 +371,16 @@ int pack_slot(gf_ba* h, int b, const gf_ba_window& w) {
 // closes a batch of packed slots: what the launches need to know about the batch as a whole (slots listed in `active`, or 0 .. count - 1)
 void finalize_pack(gf_ba* h, const int* active, int n_active, int count) {
     const Dims& d = h->d;
-    bool any_ex = false; long long mfma = 0, step = 0, jtj = 0; int mv = 0, mo = 0, mp = 0;
+    bool any_ex = false; long long mfma = 0, step = 0, jtj = 0; int mv = 0, mo = 0, mp = 0, mf = 0;
+    h->active.clear(); h->all_pri_res = n_active > 0; h->any_pri_res = false;
     for (int q = 0; q < n_active; q++) {
         const gf_ba::SlotMeta& M = h->meta[active ? active[q] : q];
-        any_ex |= M.any_ex; mfma += M.mfma; step += M.step; jtj += M.jtj; mv = std::max(mv, M.nvis); mo = std::max(mo, M.norder); mp = std::max(mp, M.npri);
+        h->active.push_back(active ? active[q] : q);
+        if (M.npri > 0) { h->all_pri_res &= M.pri_res; h->any_pri_res |= M.pri_res; }
+        any_ex |= M.any_ex; mfma += M.mfma; step += M.step; jtj += M.jtj; mv = std::max(mv, M.nvis); mo = std::max(mo, M.norder); mp = std::max(mp, M.npri); mf = std::max(mf, M.nfeat);
     }
     h->any_ex = any_ex; h->mfma_per_lin = mfma; h->step_flops = step; h->jtj_alg_flops = jtj;
-    h->max_vis = mv; h->max_order = mo; h->max_prior = mp;
+    h->max_vis = mv; h->max_order = mo; h->max_prior = mp; h->max_feat = mf;
     h->count = count;
     (void)d;
 }
@@ -394,20 +413,36 @@ int upload(gf_ba* h) {
     hipStream_t s = h->stream;
     const Dims& d = h->d;
     const size_t B = d.B, nv = (size_t)h->max_vis, no = (size_t)std::max(h->max_order, 1), np2 = (size_t)h->max_prior * h->max_prior;
-    HIPCHK(h->xs0.up(s));
-    for (auto* b : {&h->colf, &h->cole, &h->nvis, &h->nimu, &h->nwh, &h->nfeat, &h->norder, &h->feat_ptr, &h->imu_i, &h->wh_i, &h->pri_n, &h->pri_nb, &h->pri_bid})
+    static const bool dbg = getenv("GF_BA_UPLOAD_DEBUG") != nullptr;
+    long long mark = g_up_bytes; int stage = 0;
+    auto lapb = [&](const char* what) { if (dbg) { fprintf(stderr, "upload %d %-28s %8.2f MB\n", stage++, what, (g_up_bytes - mark) / 1e6); mark = g_up_bytes; } };
+    HIPCHK(h->xs0.up(s)); lapb("xs0");
+    const size_t nf = (size_t)std::max(h->max_feat, 1);
+    for (auto* b : {&h->colf, &h->nvis, &h->nimu, &h->nwh, &h->nfeat, &h->norder, &h->imu_i, &h->wh_i, &h->pri_n, &h->pri_nb, &h->pri_bid})
         HIPCHK(b->up(s));
+    HIPCHK(h->cole.up2d(s, B, d.F, (size_t)d.F));   // whole rows: entries beyond n_feature are -1 markers the kernels rely on
+    HIPCHK(h->feat_ptr.up2d(s, B, (size_t)d.F + 1, (size_t)d.F + 1)); lapb("small tables, cole, feat_ptr");
     // per-window tables are laid out for the handle's capacity; only what this batch fills is copied
     for (auto* b : {&h->vis_feat, &h->vis_i, &h->vis_j, &h->feat_fac, &h->vis_pos}) HIPCHK(b->up2d(s, B, d.NV, nv));
-    HIPCHK(h->order.up2d(s, B, d.NVP, no));
-    HIPCHK(h->vis_data.up2d(s, B, (size_t)d.NV * 12, nv * 12));
-    HIPCHK(h->pri_J.up2d(s, B, (size_t)d.NPRI * d.NPRI, np2));
+    lapb("vis int tables x5");
+    HIPCHK(h->order.up2d(s, B, d.NVP, no)); lapb("order");
+    HIPCHK(h->vis_data.up2d(s, B, (size_t)d.NV * 6, nv * 6));
+    HIPCHK(h->feat_obs.up2d(s, B, (size_t)d.F * 6, nf * 6)); lapb("vis_data + feat_obs");
+    if (!(h->any_pri_res && h->all_pri_res)) HIPCHK(h->pri_J.up2d(s, B, (size_t)d.NPRI * d.NPRI, np2));
+    if (h->any_pri_res) {   // device-resident priors: marginalisation output -> prior table, without the round trip through the host
+        const size_t pitch = (size_t)d.NPRI * d.NPRI * 8;
+        if (h->all_pri_res) HIPCHK(hipMemcpy2DAsync(h->pri_J.d, pitch, h->outJ.d, pitch, np2 * 8, B, hipMemcpyDeviceToDevice, s));
+        else for (int b : h->active) if (h->meta[b].pri_res) HIPCHK(hipMemcpyAsync(h->pri_J.d + (size_t)b * d.NPRI * d.NPRI, h->outJ.d + (size_t)b * d.NPRI * d.NPRI, (size_t)h->meta[b].npri * h->meta[b].npri * 8, hipMemcpyDeviceToDevice, s));
+    }
+    lapb("pri_J");
     for (auto* b : {&h->imu_data, &h->wh_data, &h->pri_r, &h->pri_x0, &h->wpar}) HIPCHK(b->up(s));
+    lapb("imu, wheel, pri_r, pri_x0, wpar");
     if (h->d.GO) { HIPCHK(h->ngnss.up(s)); HIPCHK(h->gn_idx.up(s)); HIPCHK(h->gn_data.up(s)); HIPCHK(h->gn_misc.up(s)); HIPCHK(h->gn_gptr.up(s)); HIPCHK(h->gn_gitem.up(s)); }
     for (int m = 0; m < 2; m++) {
         for (auto* b : {&h->mcolf[m], &h->mcole[m], &h->mnorder[m], &h->minfo[m]}) HIPCHK(b->up(s));
         HIPCHK(h->morder[m].up2d(s, B, d.NVP, no));
     }
+    lapb("gnss + marg layouts");
     HIPCHK(hipMemcpyAsync(h->st0.d, h->st0.h, h->st0.n * sizeof(SolverState), hipMemcpyHostToDevice, s));
     ba_setup<<<dim3(h->d.B), 256, 0, s>>>(h->win());
     HIPCHK(hipGetLastError());
@@ -545,7 +580,7 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     const size_t B = d.B, VS = d.RP + d.FP;
     A_(h->xs0.alloc(B * d.XS, true)); A_(h->xs.alloc(2 * B * d.XS, true));
     A_(h->colf.alloc(B * d.NFB, true)); A_(h->cole.alloc(B * d.F, true)); A_(h->nvis.alloc(B, true)); A_(h->nimu.alloc(B, true)); A_(h->nwh.alloc(B, true)); A_(h->nfeat.alloc(B, true));
-    A_(h->vis_feat.alloc(B * d.NV, true)); A_(h->vis_i.alloc(B * d.NV, true)); A_(h->vis_j.alloc(B * d.NV, true)); A_(h->vis_data.alloc(B * d.NV * 12, true));
+    A_(h->vis_feat.alloc(B * d.NV, true)); A_(h->vis_i.alloc(B * d.NV, true)); A_(h->vis_j.alloc(B * d.NV, true)); A_(h->vis_data.alloc(B * d.NV * 6, true)); A_(h->feat_obs.alloc(B * d.F * 6, true));
     A_(h->order.alloc(B * d.NVP, true)); A_(h->norder.alloc(B, true)); A_(h->feat_ptr.alloc(B * (d.F + 1), true)); A_(h->feat_fac.alloc(B * d.NV, true)); A_(h->vis_pos.alloc(B * d.NV, true));
     A_(h->imu_i.alloc(B * d.W, true)); A_(h->imu_data.alloc(B * d.W * IMU_STRIDE2, true)); A_(h->wh_i.alloc(B * d.W, true)); A_(h->wh_data.alloc(B * d.W * WH_STRIDE, true));
     A_(h->pri_n.alloc(B, true)); A_(h->pri_nb.alloc(B, true)); A_(h->pri_bid.alloc(B * 64, true)); A_(h->pri_J.alloc(B * d.NPRI * d.NPRI, true));
@@ -569,7 +604,7 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     // kept system of the marginalisation: 6 W poses + speed-bias + extrinsics ...; A and V live in LDS up to 92 columns, else in global memory
     const int nkeep = 6 * d.W + 9 + 17 + (gnss ? 9 : 0);
     h->big_marg = nkeep > 92 || getenv("GF_BA_FORCE_GLOBAL") != nullptr;
-    h->meta.assign(d.B, gf_ba::SlotMeta{});
+    h->meta.assign(d.B, gf_ba::SlotMeta{}); h->outJ_n.assign(d.B, 0);
     for (int mode = 0; mode < 2; mode++) h->keep_ids[mode].assign(d.B, {});
     h->marg_ncap = h->big_marg ? std::min(d.NPRI, nkeep + 16) : 92;
     h->marg_lds = h->big_marg ? 0 : (size_t)2 * h->marg_ncap * h->marg_ncap * sizeof(double);
@@ -606,6 +641,7 @@ int gf_ba_destroy(gf_ba* h) {
 int gf_ba_upload(gf_ba* h, const gf_ba_window* windows, int count) {
     if (!h || !windows) return gf::set_err(GF_ERR_INVALID, "null argument");
     if (int rc = gf_ba_wait(h)) return rc;
+    std::fill(h->outJ_n.begin(), h->outJ_n.end(), 0);   // whole-batch uploads do not track per-slot marginalisation outputs
     if (int rc = pack_windows(h, windows, count)) return rc;
     h->resident.assign(count, nullptr);
     for (int b = 0; b < count; b++) h->resident[b] = windows + b;
@@ -720,11 +756,15 @@ int gf_ba_solve_packed(gf_ba* h, const int* slots, int n, int max_iters) {
                                             // layouts included, stay what their owner packed last: a marginalisation of such a slot may still follow)
     finalize_pack(h, slots, n, d.B);
     h->resident.assign(d.B, nullptr);
+    HIPCHK(hipEventRecord(h->ev[8], h->stream));
     if (int rc = upload(h)) return rc;
+    HIPCHK(hipEventRecord(h->ev[9], h->stream));
     if (int rc = gf_ba_solve_resident_async(h, max_iters, -1, 1)) return rc;
     HIPCHK(h->xs.down(h->stream));
     HIPCHK(hipMemcpyAsync(h->st.h, h->st.d, (size_t)d.B * sizeof(SolverState), hipMemcpyDeviceToHost, h->stream));
-    return gf_ba_wait(h);
+    if (int rc = gf_ba_wait(h)) return rc;
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, h->ev[8], h->ev[9])); h->stats.ms_upload += ms;
+    return GF_OK;
 }
 int gf_ba_unpack_slot(gf_ba* h, int slot, gf_ba_window* window, gf_ba_summary* summary) {
     if (!h || slot < 0 || slot >= h->d.B) return gf::set_err(GF_ERR_INVALID, "bad argument");
@@ -784,8 +824,10 @@ int gf_ba_marginalize_resident(gf_ba* h, const int* slots, const gf_ba_window* w
     const int* inf0 = h->minfo[mode].h;
     int nmax = 0;
     for (int i = 0; i < n; i++) if (inf0[(size_t)slots[i] * 4 + 3]) nmax = std::max(nmax, inf0[(size_t)slots[i] * 4 + 2]);
+    for (int i = 0; i < n; i++) h->outJ_n[slots[i]] = inf0[(size_t)slots[i] * 4 + 3] ? inf0[(size_t)slots[i] * 4 + 2] : 0;
+    h->outJ_host_stale = priors == nullptr;   // the owners take J from the device (resident priors) or fetch it one by one (gf_ba_unpack_prior_slot with a J buffer)
     if (nmax > 0) {
-        HIPCHK(hipMemcpy2DAsync(h->outJ.h, (size_t)d.NPRI * d.NPRI * 8, h->outJ.d, (size_t)d.NPRI * d.NPRI * 8, (size_t)nmax * nmax * 8, h->count, hipMemcpyDeviceToHost, h->stream));
+        if (priors) HIPCHK(hipMemcpy2DAsync(h->outJ.h, (size_t)d.NPRI * d.NPRI * 8, h->outJ.d, (size_t)d.NPRI * d.NPRI * 8, (size_t)nmax * nmax * 8, h->count, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpy2DAsync(h->outr.h, (size_t)d.NPRI * 8, h->outr.d, (size_t)d.NPRI * 8, (size_t)nmax * 8, h->count, hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -809,7 +851,10 @@ int gf_ba_unpack_prior_slot(gf_ba* h, int slot, int mode, gf_ba_prior* prior) {
         const std::vector<int>& keep = h->keep_ids[mode][b];
         if (nn > p.cap_n || (int)keep.size() > p.cap_blocks) return gf::set_err(GF_ERR_CAPACITY, "prior capacity too small (n=%d, blocks=%zu)", nn, keep.size());
         p.n = nn; p.nblocks = (int)keep.size();
-        memcpy(p.J, h->outJ.h + (size_t)b * d.NPRI * d.NPRI, (size_t)nn * nn * sizeof(double));
+        if (p.J) {   // J == NULL: the prior's J stays on the device (the slot's next gf_ba_pack_slot passes prior_J = NULL)
+            if (h->outJ_host_stale) HIPCHK(hipMemcpy(h->outJ.h + (size_t)b * d.NPRI * d.NPRI, h->outJ.d + (size_t)b * d.NPRI * d.NPRI, (size_t)nn * nn * sizeof(double), hipMemcpyDeviceToHost));
+            memcpy(p.J, h->outJ.h + (size_t)b * d.NPRI * d.NPRI, (size_t)nn * nn * sizeof(double));
+        }
         memcpy(p.r, h->outr.h + (size_t)b * d.NPRI, (size_t)nn * sizeof(double));
         const double* x = h->xs0.h + (size_t)b * d.XS;   // the linearisation point of the prior = the states just uploaded
         int xo = 0;
@@ -827,6 +872,15 @@ int gf_ba_unpack_prior_slot(gf_ba* h, int slot, int mode, gf_ba_prior* prior) {
             for (int c = 0; c < gsize_kind(kind); c++) p.x0[xo++] = x[off + c];
         }
     }
+    return GF_OK;
+}
+
+int gf_ba_debug_upload_bytes(long long* bytes, long long* calls) { if (bytes) *bytes = g_up_bytes; if (calls) *calls = g_up_calls; return GF_OK; }
+int gf_ba_fetch_resident_prior(gf_ba* h, int slot, int n, double* J) {
+    if (!h || !J || slot < 0 || slot >= h->d.B) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    if (n < 1 || h->outJ_n[slot] != n) return gf::set_err(GF_ERR_INVALID, "slot %d holds a marginalisation output of %d columns, not %d", slot, h->outJ_n[slot], n);
+    if (int rc = gf_ba_wait(h)) return rc;
+    HIPCHK(hipMemcpy(J, h->outJ.d + (size_t)slot * h->d.NPRI * h->d.NPRI, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost));
     return GF_OK;
 }
 

@@ -67,7 +67,10 @@ struct Win {  // device view of the whole batch
     const int* cole;          // [B][F]   index of each free feature among the eliminated columns or -1
     const int* nvis; const int* nimu; const int* nwh; const int* nfeat;   // [B]
     const int* vis_feat; const int* vis_i; const int* vis_j;              // [B][NV]
-    const double* vis_data;   // [B][NV][12] pts_i(3) pts_j(3) vel_i(2) vel_j(2) td_i td_j
+    const double* vis_data;   // [B][NV][6] per factor: pts_j(3) vel_j(2) td_j -- the observation in frame j
+    const double* feat_obs;   // [B][F][6] per feature: pts_i(3) vel_i(2) td_i -- the observation in the start frame, shared by all factors of the feature
+                              // (ProjectionTwoFrameOneCamFactor is built from feature_per_frame[0], estimator.cpp:3276-3290): 96 -> 48 bytes per factor to
+                              // upload and to stream in every sweep
     const int* order;         // [B][NVP] factor index sorted by (i,j) pair, pairs padded to even length with -1
     const int* norder;        // [B]
     const int* feat_ptr;      // [B][F+1] CSR: factors of each feature
@@ -220,7 +223,12 @@ __device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int
     if (k >= 0) {
         const size_t kk = (size_t)b * d.NV + k;
         fi = w.vis_i[kk]; fj = w.vis_j[kk]; feat = w.vis_feat[kk];
-        visual_eval(xs + off_pose(fi), xs + off_pose(fj), xs + off_ex(d.NP), xs[off_feat(d.NP) + feat], xs[off_td(d.NP)], w.vis_data + kk * 12,
+        double vd[12];
+        {
+            const double* fj6 = w.vis_data + kk * 6; const double* fi6 = w.feat_obs + ((size_t)b * d.F + feat) * 6;
+            vd[0] = fi6[0]; vd[1] = fi6[1]; vd[2] = fi6[2]; vd[3] = fj6[0]; vd[4] = fj6[1]; vd[5] = fj6[2]; vd[6] = fi6[3]; vd[7] = fi6[4]; vd[8] = fj6[3]; vd[9] = fj6[4]; vd[10] = fi6[5]; vd[11] = fj6[5];
+        }
+        visual_eval(xs + off_pose(fi), xs + off_pose(fj), xs + off_ex(d.NP), xs[off_feat(d.NP) + feat], xs[off_td(d.NP)], vd,
                     w.wpar[4 * b + 3], true, ev);
         const double r0 = ev.row[0][13], r1 = ev.row[1][13];
         const double sq = r0 * r0 + r1 * r1;

@@ -569,7 +569,7 @@ struct gf_estimator {
     std::vector<double> para_Pose, para_SpeedBias, para_Feature;
     double para_Ex_Pose[7], para_Ex_Pose_wheel[7], para_Ix[3], para_Td[1], para_Td_wheel[1];
     // last_marginalization_info in C-ABI form
-    bool prior_valid = false; int prior_n = 0;
+    bool prior_valid = false, prior_resident = false; int prior_n = 0;   // prior_resident: J lives in the group's shared handle (slot group_slot), prior_J is empty
     std::vector<int> prior_block_id; std::vector<double> prior_J, prior_r, prior_x0;
     // feedback to the tracker (EST:1132-1136)
     std::vector<int> predict_ids, remove_ids; std::vector<double> predict_xyz;
@@ -1486,7 +1486,7 @@ struct gf_estimator {
         w.imu_lin_ba = imu_ba.data(); w.imu_lin_bg = imu_bg.data(); w.imu_jacobian = imu_J.data(); w.imu_covariance = imu_P.data();
         w.wh_i = wh_i.data(); w.wh_sum_dt = wh_sum_dt.data(); w.wh_delta_p = wh_dp.data(); w.wh_delta_q = wh_dq.data(); w.wh_jacobian = wh_J.data(); w.wh_covariance = wh_P.data();
         w.wh_lin = wh_lin.data(); w.wh_lin_vel = wh_lv.data(); w.wh_lin_gyr = wh_lg.data(); w.wh_vel_1 = wh_v1.data(); w.wh_gyr_1 = wh_g1.data();
-        if (prior_valid) { w.prior_n = prior_n; w.prior_nblocks = (int)prior_block_id.size(); w.prior_block_id = prior_block_id.data(); w.prior_J = prior_J.data(); w.prior_r = prior_r.data(); w.prior_x0 = prior_x0.data(); }
+        if (prior_valid) { w.prior_n = prior_n; w.prior_nblocks = (int)prior_block_id.size(); w.prior_block_id = prior_block_id.data(); w.prior_J = prior_resident ? nullptr : prior_J.data(); w.prior_r = prior_r.data(); w.prior_x0 = prior_x0.data(); }
         lap(1);
         if (!group && cfg.max_solver_time > 0) gf_ba_set_max_solver_time(ba, marginalization_flag == MARGIN_OLD ? cfg.max_solver_time * 4.0 / 5.0 : cfg.max_solver_time);   // EST:3312-3315
         if (group) {   // ceres::Solve, EST:3303-3318
@@ -1518,7 +1518,7 @@ struct gf_estimator {
             if (marg_J.size() != (size_t)cap_n * cap_n) { marg_J.assign((size_t)cap_n * cap_n, 0.0); marg_r.assign(cap_n, 0.0); marg_x0.assign(16 * (WINDOW_SIZE + 1) + 64 + gx, 0.0); marg_id.assign(cap_b, 0); }
             std::vector<double>&pJ = marg_J, &pr = marg_r, &px0 = marg_x0; std::vector<int>& pid = marg_id;
             gf_ba_prior p{};
-            p.cap_n = cap_n; p.cap_blocks = cap_b; p.block_id = pid.data(); p.J = pJ.data(); p.r = pr.data(); p.x0 = px0.data();
+            p.cap_n = cap_n; p.cap_blocks = cap_b; p.block_id = pid.data(); p.J = group ? nullptr : pJ.data(); p.r = pr.data(); p.x0 = px0.data();   // group: J stays on the device
             lap(3);
             if (group) {
                 BatchSolver::Req rq{1, &w, 0, marginalization_flag, nullptr, &p, GF_OK, false, std::string()};
@@ -1531,7 +1531,9 @@ struct gf_estimator {
             if (p.valid) {
                 prior_n = p.n;
                 prior_block_id.assign(pid.begin(), pid.begin() + p.nblocks);
-                prior_J.assign(pJ.begin(), pJ.begin() + (size_t)p.n * p.n); prior_r.assign(pr.begin(), pr.begin() + p.n);
+                prior_resident = group != nullptr;
+                if (prior_resident) prior_J.clear(); else prior_J.assign(pJ.begin(), pJ.begin() + (size_t)p.n * p.n);
+                prior_r.assign(pr.begin(), pr.begin() + p.n);
                 int gs = 0;
                 for (int id : prior_block_id) { const int k = id / 4096; gs += (k == GF_POSE || k == GF_EX_POSE || k == GF_EX_WHEEL) ? 7 : k == GF_SPEEDBIAS ? 9 : k == GF_ANC ? 3 : 1; }
                 prior_x0.assign(px0.begin(), px0.begin() + gs);
@@ -1656,6 +1658,7 @@ struct gf_estimator {
 };
 
 // ---------------------------------------------------------------- C-ABI
+extern "C" int gf_ba_debug_upload_bytes(long long* bytes, long long* calls);
 extern "C" {
 
 int gf_estimator_default_cfg(gf_estimator_cfg* c) {
@@ -1901,7 +1904,10 @@ int gf_estimator_get_prior(gf_estimator* e, int cap_n, int cap_blocks, int* n, i
     *n = e->prior_valid ? e->prior_n : 0; *nblocks = e->prior_valid ? (int)e->prior_block_id.size() : 0;
     if (*n > cap_n || *nblocks > cap_blocks) return gf::set_err(GF_ERR_CAPACITY, "prior is %d x %d with %d blocks", *n, *n, *nblocks);
     if (block_id) std::copy(e->prior_block_id.begin(), e->prior_block_id.begin() + *nblocks, block_id);
-    if (J && *n) std::copy(e->prior_J.begin(), e->prior_J.begin() + (size_t)*n * *n, J);
+    if (J && *n) {
+        if (e->prior_resident && e->group) { if (int rc = gf_ba_fetch_resident_prior(e->group->ba, e->group_slot, *n, J)) return rc; }   // a group member's J lives on the device
+        else std::copy(e->prior_J.begin(), e->prior_J.begin() + (size_t)*n * *n, J);
+    }
     if (r && *n) std::copy(e->prior_r.begin(), e->prior_r.begin() + *n, r);
     return GF_OK;
 }
@@ -2047,6 +2053,13 @@ int gf_estimator_group_destroy(gf_estimator_group* g) {
     }
     if (g && getenv("GF_GROUP_TIMING") && g->solver.pre)
         fprintf(stderr, "gf_estimator_group: %lld batched pre-integration launches, %lld intervals, %.1f ms inside them\n", g->solver.pre_batches, g->solver.pre_intervals, 1e3 * g->solver.t_pre);
+    if (g && getenv("GF_GROUP_TIMING") && g->solver.ba) {
+        gf_ba_stats bs{};
+        if (gf_ba_get_stats(g->solver.ba, &bs) == GF_OK)
+            fprintf(stderr, "gf_estimator_group: device time of the shared handle [ms]: upload %.1f, solve %.1f, marginalise %.1f\n", bs.ms_upload, bs.ms_solve, bs.ms_marginalize);
+        long long ub = 0, uc = 0; gf_ba_debug_upload_bytes(&ub, &uc);
+        fprintf(stderr, "gf_estimator_group: %.1f MB host -> device in %lld copies since process start\n", ub / 1e6, uc);
+    }
     if (g && getenv("GF_GROUP_TIMING"))
         fprintf(stderr, "gf_estimator_group: %lld batches, %lld windows; %.1f ms inside batched solves, %.1f ms inside batched marginalisations, %.1f ms inside input_features\n",
                 g->solver.batches, g->solver.windows, 1e3 * g->solver.t_solve, 1e3 * g->solver.t_marg, 1e3 * g->t_input);

@@ -233,7 +233,11 @@ int gf_ba_export_newest_poses(gf_ba* h, void* d_out, int count);
  * slot --, gf_ba_solve_packed closes the batch (upload, ceres::Solve on the listed slots -- slots not listed sit this batch out --, one download of all
  * states) and gf_ba_unpack_slot copies the solved state and the summary of a slot back into its owner's window (again callable concurrently for
  * different slots).  Results are identical to gf_ba_solve on the same windows.  gf_ba_marginalize_resident then takes the same slot numbers. */
+/* Device-resident priors: a prior fetched with gf_ba_unpack_prior_slot(..., prior->J == NULL) leaves its n x n factor on the device; the slot's next window says
+ * so with prior_n > 0 and prior_J == NULL (block ids, r and x0 as usual) and the solve copies it device to device -- 60 KB per window and frame that cross the
+ * bus in neither direction.  gf_ba_fetch_resident_prior reads it back for whoever wants to look at it. */
 int gf_ba_pack_slot(gf_ba* h, int slot, const gf_ba_window* window);
+int gf_ba_fetch_resident_prior(gf_ba* h, int slot, int n, double* J);
 int gf_ba_solve_packed(gf_ba* h, const int* slots, int n, int max_iters);
 int gf_ba_unpack_slot(gf_ba* h, int slot, gf_ba_window* window, gf_ba_summary* summary);
 /* ceres::Solver::Options::max_solver_time_in_seconds (estimator.cpp:3312-3315) for the following gf_ba_solve / gf_ba_solve_resident calls; 0 (default) = not
