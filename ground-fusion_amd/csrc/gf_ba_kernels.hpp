@@ -146,17 +146,20 @@ __device__ __forceinline__ void visual_eval(const double* Pi_, const double* Pj_
     const V3 pts_i = v3(vd[0], vd[1], vd[2]), pts_j = v3(vd[3], vd[4], vd[5]), vel_i = v3(vd[6], vd[7], 0), vel_j = v3(vd[8], vd[9], 0);
     const double td_i = vd[10], td_j = vd[11];
     const V3 pts_i_td = pts_i - vel_i * (td - td_i), pts_j_td = pts_j - vel_j * (td - td_j);
-    const V3 pts_camera_i = pts_i_td / inv_dep_i;
+    // One reciprocal per denominator (inverse depth, depth in frame j) and multiplications from there on: an IEEE double division costs ~25 instructions and this
+    // function divided twelve times by one of these two numbers (a quarter of the sweep's arithmetic).  The results move by an ulp; the parity bars are tolerances.
+    const double dep_i = 1.0 / inv_dep_i;
+    const V3 pts_camera_i = pts_i_td * dep_i;
     const V3 pts_imu_i = qrot(qic, pts_camera_i) + tic;
     const V3 pts_w = qrot(Qi, pts_imu_i) + Pi;
     const V3 pts_imu_j = qrot(qinverse(Qj), pts_w - Pj);
     const V3 pts_camera_j = qrot(qinverse(qic), pts_imu_j - tic);
-    const double dep_j = pts_camera_j.z;
-    o.row[0][13] = si * (pts_camera_j.x / dep_j - pts_j_td.x);
-    o.row[1][13] = si * (pts_camera_j.y / dep_j - pts_j_td.y);
+    const double idj = 1.0 / pts_camera_j.z;
+    o.row[0][13] = si * (pts_camera_j.x * idj - pts_j_td.x);
+    o.row[1][13] = si * (pts_camera_j.y * idj - pts_j_td.y);
     if (!want_jac) return;
     const M3 Ri = qmat(Qi), Rj = qmat(Qj), ric = qmat(qic);
-    const double r00 = si / dep_j, r02 = -si * pts_camera_j.x / (dep_j * dep_j), r11 = si / dep_j, r12 = -si * pts_camera_j.y / (dep_j * dep_j);
+    const double r00 = si * idj, r02 = -si * pts_camera_j.x * (idj * idj), r11 = r00, r12 = -si * pts_camera_j.y * (idj * idj);
     auto red = [&](const M3& m, int c, double& o0, double& o1) { o0 = r00 * m.m[c] + r02 * m.m[6 + c]; o1 = r11 * m.m[3 + c] + r12 * m.m[6 + c]; };
     auto redv = [&](V3 v, double& o0, double& o1) { o0 = r00 * v.x + r02 * v.z; o1 = r11 * v.y + r12 * v.z; };
     const M3 A = transpose(ric) * transpose(Rj);
@@ -181,11 +184,11 @@ __device__ __forceinline__ void visual_eval(const double* Pi_, const double* Pj_
     {
         double a0, a1;
         redv(tmp_r * pts_i_td, a0, a1);
-        const double f = -1.0 / (inv_dep_i * inv_dep_i);
+        const double f = -(dep_i * dep_i);
         o.jd[0] = a0 * f; o.jd[1] = a1 * f;
         redv(tmp_r * vel_i, a0, a1);
-        o.row[0][12] = a0 / inv_dep_i * -1.0 + si * vel_j.x;
-        o.row[1][12] = a1 / inv_dep_i * -1.0 + si * vel_j.y;
+        o.row[0][12] = a0 * dep_i * -1.0 + si * vel_j.x;
+        o.row[1][12] = a1 * dep_i * -1.0 + si * vel_j.y;
     }
 }
 
@@ -232,21 +235,24 @@ __device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int
                     w.wpar[4 * b + 3], true, ev);
         const double r0 = ev.row[0][13], r1 = ev.row[1][13];
         const double sq = r0 * r0 + r1 * r1;
-        double rho0, sqrt_rho1, rs, asn;
-        huber_corrector(sq, rho0, sqrt_rho1, rs, asn);
-        cost = 0.5 * rho0;
-        // J = sqrt_rho1 * (J - alpha_sq_norm * r * (r^T J)), r *= residual_scaling
+        cost = 0.5 * sq;   // inlier (s <= 1): rho = s, rho' = 1, rho'' = 0 -- the corrector is the identity (sqrt_rho1 = residual_scaling = 1, alpha = 0)
+        if (sq > 1.0) {    // outliers only: square roots, divisions and the rank-one correction of 22 columns (a converged window has next to none)
+            double rho0, sqrt_rho1, rs, asn;
+            huber_corrector(sq, rho0, sqrt_rho1, rs, asn);
+            cost = 0.5 * rho0;
+            // J = sqrt_rho1 * (J - alpha_sq_norm * r * (r^T J)), r *= residual_scaling
 #pragma unroll
-        for (int c = 0; c < 22; c++) {
-            if (c == 13 || c == 14 || c == 15) continue;
-            const double rtj = r0 * ev.row[0][c] + r1 * ev.row[1][c];
-            ev.row[0][c] = sqrt_rho1 * (ev.row[0][c] - asn * r0 * rtj);
-            ev.row[1][c] = sqrt_rho1 * (ev.row[1][c] - asn * r1 * rtj);
+            for (int c = 0; c < 22; c++) {
+                if (c == 13 || c == 14 || c == 15) continue;
+                const double rtj = r0 * ev.row[0][c] + r1 * ev.row[1][c];
+                ev.row[0][c] = sqrt_rho1 * (ev.row[0][c] - asn * r0 * rtj);
+                ev.row[1][c] = sqrt_rho1 * (ev.row[1][c] - asn * r1 * rtj);
+            }
+            const double rtj = r0 * ev.jd[0] + r1 * ev.jd[1];
+            ev.jd[0] = sqrt_rho1 * (ev.jd[0] - asn * r0 * rtj);
+            ev.jd[1] = sqrt_rho1 * (ev.jd[1] - asn * r1 * rtj);
+            ev.row[0][13] = r0 * rs; ev.row[1][13] = r1 * rs;
         }
-        const double rtj = r0 * ev.jd[0] + r1 * ev.jd[1];
-        ev.jd[0] = sqrt_rho1 * (ev.jd[0] - asn * r0 * rtj);
-        ev.jd[1] = sqrt_rho1 * (ev.jd[1] - asn * r1 * rtj);
-        ev.row[0][13] = r0 * rs; ev.row[1][13] = r1 * rs;
         // constant blocks contribute no columns
         if (colf[fb_pose(fi)] < 0) for (int c = 0; c < 6; c++) ev.row[0][c] = ev.row[1][c] = 0.0;
         if (colf[fb_pose(fj)] < 0) for (int c = 6; c < 12; c++) ev.row[0][c] = ev.row[1][c] = 0.0;
