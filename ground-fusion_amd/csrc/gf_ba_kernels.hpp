@@ -221,9 +221,17 @@ __device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int
     double cost = 0.0;
     int feat = 0;
     fi = 0; fj = 0;
+    // a padding lane (k < 0) evaluates factor 0 like everybody else and is masked where it would leave a trace (cost, efac; the caller zeroes its staged rows):
+    // cheaper than zero-filling 46 doubles in every lane and running the evaluation under an exec mask
+    const bool live = k >= 0;
+    k = max(k, 0);
 #pragma unroll
-    for (int r = 0; r < 2; r++) { for (int c = 0; c < 22; c++) ev.row[r][c] = 0.0; ev.jd[r] = 0.0; }
-    if (k >= 0) {
+    for (int c = 14; c < 16; c++) { ev.row[0][c] = 0.0; ev.row[1][c] = 0.0; }
+    if (!EX) {
+#pragma unroll
+        for (int c = 16; c < 22; c++) { ev.row[0][c] = 0.0; ev.row[1][c] = 0.0; }
+    }
+    {
         const size_t kk = (size_t)b * d.NV + k;
         fi = w.vis_i[kk]; fj = w.vis_j[kk]; feat = w.vis_feat[kk];
         double vd[12];
@@ -235,11 +243,11 @@ __device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int
                     w.wpar[4 * b + 3], true, ev);
         const double r0 = ev.row[0][13], r1 = ev.row[1][13];
         const double sq = r0 * r0 + r1 * r1;
-        cost = 0.5 * sq;   // inlier (s <= 1): rho = s, rho' = 1, rho'' = 0 -- the corrector is the identity (sqrt_rho1 = residual_scaling = 1, alpha = 0)
+        cost = live ? 0.5 * sq : 0.0;   // inlier (s <= 1): rho = s, rho' = 1, rho'' = 0 -- the corrector is the identity (sqrt_rho1 = residual_scaling = 1, alpha = 0)
         if (sq > 1.0) {    // outliers only: square roots, divisions and the rank-one correction of 22 columns (a converged window has next to none)
             double rho0, sqrt_rho1, rs, asn;
             huber_corrector(sq, rho0, sqrt_rho1, rs, asn);
-            cost = 0.5 * rho0;
+            cost = live ? 0.5 * rho0 : 0.0;
             // J = sqrt_rho1 * (J - alpha_sq_norm * r * (r^T J)), r *= residual_scaling
 #pragma unroll
             for (int c = 0; c < 22; c++) {
@@ -259,7 +267,7 @@ __device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int
         if (colf[fb_td(d.NP)] < 0) ev.row[0][12] = ev.row[1][12] = 0.0;
         if (EX && colf[fb_ex(d.NP)] < 0) for (int c = 16; c < 22; c++) ev.row[0][c] = ev.row[1][c] = 0.0;
         // eliminated (free inverse depth) column: products needed by the Schur complement
-        if (w.cole[(size_t)b * d.F + feat] >= 0) {
+        if (live && w.cole[(size_t)b * d.F + feat] >= 0) {
             double* ef = w.efac + ((size_t)b * d.NV * EF + (size_t)w.vis_pos[kk] * ef_stride<EX>());   // the factors of a feature are contiguous
 #pragma unroll
             for (int c = 0; c < 13; c++) ef[c] = ev.jd[0] * ev.row[0][c] + ev.jd[1] * ev.row[1][c];
@@ -815,16 +823,16 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
 #pragma unroll
-                    for (int c = 0; c < 16; c++) Jbuf[l * LSTR + r * COLS + c] = (c < 14) ? ev.row[r][c] : 0.0;
+                    for (int c = 0; c < 16; c++) Jbuf[l * LSTR + r * COLS + c] = (c < 14 && k >= 0) ? ev.row[r][c] : 0.0;
                     if (EX) {
 #pragma unroll
-                        for (int c = 0; c < 16; c++) Jbuf[l * LSTR + r * COLS + 16 + c] = (c < 6) ? ev.row[r][16 + c] : 0.0;
+                        for (int c = 0; c < 16; c++) Jbuf[l * LSTR + r * COLS + 16 + c] = (c < 6 && k >= 0) ? ev.row[r][16 + c] : 0.0;
                     }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
             for (int m = 0; m < SG / 2; m++) {
-                const int pair = s_pair[SG * part + 2 * m];   // pairs are padded to even length: entries 2m and 2m+1 share the pair (or are padding)
+                const int pair = uni(s_pair[SG * part + 2 * m]);   // pairs are padded to even length: entries 2m and 2m+1 share the pair (or are padding); the same in every lane
                 if (pair < 0) continue;
                 if (pair != cur_pair) { flush(cur_pair); cur_pair = pair; }
                 const int e = 2 * m + (lane >> 5), r = (lane >> 4) & 1, c = lane & 15;
