@@ -10,6 +10,7 @@
 // Every sum has a fixed order (no floating-point atomics anywhere): two runs of the same input give bit-identical results.
 // Semantics: reference factors (file:line cited per function) + Ceres 1.14 trust_region_minimizer.cc / dogleg_strategy.cc.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "gf_dmath.hpp"
@@ -1283,7 +1284,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double sred[512];
     __shared__ double s_inv[16 * 17];
-    __shared__ double s_y[16];
+    __shared__ double s_y[32];   // the solution of the current block of the backward substitution, double-buffered
     __shared__ int s_flag[4];
     __shared__ int s_cmap[256];      // compact column -> reduced column (or -1), right-hand-side slot -> R
     __shared__ double s_uc[256];     // a vector gathered to the compact layout (the Gauss-Newton solution during the back-substitution)
@@ -1566,7 +1567,7 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
             __syncthreads();
 #ifdef GF_PROFILE_STEP
             long long tA = 0, tB = 0, tC = 0, t0c = clock64();
-            if (blockIdx.x == 0 && tid == 0 && sb.stamps) { sb.stamps[24] = sb.stamps[25] = sb.stamps[26] = sb.stamps[27] = sb.stamps[28] = 0; }
+            if (blockIdx.x == 0 && tid == 0 && sb.stamps) { sb.stamps[24] = sb.stamps[25] = sb.stamps[26] = sb.stamps[27] = sb.stamps[28] = sb.stamps[29] = sb.stamps[30] = sb.stamps[31] = 0; }
 #define GF_SUB(acc) do { const long long n_ = clock64(); acc += n_ - t0c; t0c = n_; } while (0)
 #else
 #define GF_SUB(acc) do { } while (0)
@@ -1590,15 +1591,18 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                 GF_DSUB(27);
             };
             // one 16x16 tile (ti, tk) of the trailing update A22 -= L21 L21^T
-            auto trail_tile = [&](int j0, int nb, int r0, int ti, int tk) {
+            // `full` (a std::true_type / false_type tag): the block column has all 16 columns -- every block but the last.  Conditions on the block width are
+            // uniform, and the compiler turned each of them into a branch with its own wait; the full-width instances carry none.
+            auto trail_tile = [&](auto full, int j0, int nb, int r0, int ti, int tk) {
+                constexpr bool FULL = decltype(full)::value;
                 const int ra = r0 + 16 * ti + (lane & 15), rb = r0 + 16 * tk + (lane & 15);
                 const int ba_ = ra <= R ? pk(ra, j0) : -1, bb_ = rb < R ? pk(rb, j0) : -1;   // row R (rhs) never acts as a column
                 d4 acc = {0, 0, 0, 0};
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int c = 4 * k + (lane >> 4);
-                    const double av = (ba_ >= 0 && c < nb) ? S[ba_ + c] : 0.0;
-                    const double bv2 = (bb_ >= 0 && c < nb) ? S[bb_ + c] : 0.0;
+                    const double av = (ba_ >= 0 && (FULL || c < nb)) ? S[ba_ + c] : 0.0;
+                    const double bv2 = (bb_ >= 0 && (FULL || c < nb)) ? S[bb_ + c] : 0.0;
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv2, acc, 0, 0, 0);
                 }
 #pragma unroll
@@ -1609,7 +1613,8 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
             };
             // two tiles at a time for the wavefronts that own several: all panel loads first, the two MFMA chains interleaved, then the read-modify-writes
             // (one tile after the other is a chain of LDS round trips with nothing in between)
-            auto trail_pair = [&](int j0, int nb, int r0, int t0, int t1) {
+            auto trail_pair = [&](auto full, int j0, int nb, int r0, int t0, int t1) {
+                constexpr bool FULL = decltype(full)::value;
                 int tiv[2], tkv[2], ba_[2], bb_[2];
                 const bool two = t1 >= 0;
                 tiv[0] = tri_row(t0); tkv[0] = t0 - tiv[0] * (tiv[0] + 1) / 2;
@@ -1625,8 +1630,8 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const int c = 4 * k + (lane >> 4);
-                        av[p][k] = (ba_[p] >= 0 && c < nb) ? S[ba_[p] + c] : 0.0;
-                        bv2[p][k] = (bb_[p] >= 0 && c < nb) ? S[bb_[p] + c] : 0.0;
+                        av[p][k] = (ba_[p] >= 0 && (FULL || c < nb)) ? S[ba_[p] + c] : 0.0;
+                        bv2[p][k] = (bb_[p] >= 0 && (FULL || c < nb)) ? S[bb_[p] + c] : 0.0;
                     }
                 d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 #pragma unroll
@@ -1659,15 +1664,17 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                 if (!uni(s_flag[1])) break;
                 // panel: X = A21 L11^-T for the rows below the block and the rhs row; 16-row tiles, X[i][c] = sum_k A[i][k] Linv[c][k]
                 const int r0 = j0 + nb;
-                {
+                auto panel = [&](auto full) {
+                    constexpr bool FULL = decltype(full)::value;
                     const int nrows = R + 1 - r0, nt = (nrows + 15) / 16;
                     for (int t = wave; t < nt; t += 8) {
                         const int ra = r0 + 16 * t + (lane & 15);
+                        const int rb_ = pk(min(ra, R), j0);
                         d4 acc = {0, 0, 0, 0};
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
                             const int kc = 4 * k + (lane >> 4);
-                            const double av = (ra <= R && kc < nb) ? S[pk(ra, j0 + kc)] : 0.0;
+                            const double av = (ra <= R && (FULL || kc < nb)) ? S[rb_ + kc] : 0.0;
                             const double bv2 = s_inv[(lane & 15) * 17 + kc];          // B[k][c] = Linv[c][k]
                             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv2, acc, 0, 0, 0);
                         }
@@ -1675,22 +1682,26 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             const int row = r0 + 16 * t + (lane >> 4) + 4 * r, c = lane & 15;
-                            if (row <= R && c < nb) S[pk(row, j0 + c)] = acc[r];
+                            if (row <= R && (FULL || c < nb)) S[pk(row, j0 + c)] = acc[r];
                         }
                     }
-                }
+                };
+                if (nb == 16) panel(std::true_type{}); else panel(std::false_type{});
                 __syncthreads();
                 GF_SUB(tB);
                 // trailing update with look-ahead: wavefront 0 updates the next diagonal tile first and factors it (the serial part of the next
                 // block column) while wavefronts 1..7 update all other tiles
                 if (r0 <= R) {
                     const int nrows = R + 1 - r0, nt = (nrows + 15) / 16, ntiles = nt * (nt + 1) / 2;
+#ifdef GF_PROFILE_STEP
+                    const long long w0c = clock64();
+#endif
                     if (wave == 0) {
                         __builtin_amdgcn_s_setprio(3);
 #ifdef GF_PROFILE_STEP
                         const long long q0 = clock64();
 #endif
-                        trail_tile(j0, nb, r0, 0, 0);
+                        if (nb == 16) trail_tile(std::true_type{}, j0, nb, r0, 0, 0); else trail_tile(std::false_type{}, j0, nb, r0, 0, 0);
 #ifdef GF_PROFILE_STEP
                         if (blockIdx.x == 0 && tid == 0 && sb.stamps) sb.stamps[28] += clock64() - q0;
 #endif
@@ -1700,8 +1711,12 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                         }
                         __builtin_amdgcn_s_setprio(0);
                     } else {
-                        for (int t = wave; t < ntiles; t += 14) trail_pair(j0, nb, r0, t, t + 7 < ntiles ? t + 7 : -1);
+                        if (nb == 16) { for (int t = wave; t < ntiles; t += 14) trail_pair(std::true_type{}, j0, nb, r0, t, t + 7 < ntiles ? t + 7 : -1); }
+                        else { for (int t = wave; t < ntiles; t += 14) trail_pair(std::false_type{}, j0, nb, r0, t, t + 7 < ntiles ? t + 7 : -1); }
                     }
+#ifdef GF_PROFILE_STEP
+                    if (blockIdx.x == 0 && sb.stamps && (tid == 0 || tid == 64 || tid == 256) && j0 / 16 < 12) sb.stamps[(tid == 0 ? 40 : tid == 64 ? 56 : 72) + j0 / 16] = clock64() - w0c;
+#endif
                 }
                 __syncthreads();
                 GF_SUB(tC);
@@ -1712,34 +1727,81 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
             ok = uni(s_flag[1]) != 0;
             if (ok) {
                 GF_STAMP(9);
-                // backward substitution L^T y = z (z = row R), 16-column blocks from the bottom: in-block solve by wavefront 0
-                for (int j0 = ((R - 1) / 16) * 16; j0 >= 0; j0 -= 16) {
+                // backward substitution L^T y = z (z = row R), 16-column blocks from the bottom.  Wavefront 0 runs the serial chain alone: it completes the
+                // block's right-hand side, solves inside the block (the diagonal block holds the inverse of its factor: a 16 x 16 product), and applies the
+                // block's solution to the NEXT block's sixteen entries itself; the other wavefronts apply it to everything below that, one block behind
+                // and into an accumulator of their own (s_rd), so that no entry is updated from both sides.  One barrier per block instead of two, and the
+                // chain no longer waits for the wide update (11 x 3.8 k -> 11 x ~1.7 k cycles).
+                for (int r = tid; r < R; r += 512) s_rd[r] = 0.0;
+                __syncthreads();
+                for (int j0 = ((R - 1) / 16) * 16, par = 0; j0 >= 0; j0 -= 16, par ^= 1) {
                     const int nb = min(16, R - j0);
+#ifdef GF_PROFILE_STEP
+                    const long long bq0 = clock64();
+#endif
                     if (wave == 0) {
-                        double z = lane < nb ? S[pk(R, j0 + lane)] : 0.0;
-                        const int cc = lane & 15;
+                        __builtin_amdgcn_s_setprio(3);
+                        // every load below is unconditional, from an index clamped into the block, and masked afterwards: predicated loads compiled into a branch each
+                        // (700 instructions per block for ~150 of arithmetic)
+                        const int cc = lane & 15, lz = min(lane, nb - 1);
+                        double z = S[pk(R, j0 + lz)] + s_rd[j0 + lz];
+                        z = lane < nb ? z : 0.0;
                         double wc[16];   // column cc of the block's inverse factor (stored in place of the factor): y_c = sum_{r >= c} Linv[r][c] z_r
+                        double lnext[16];   // rows of the block at the columns of the next block: L[j0 + c][j0 - 16 + lane]; rows beyond the block meet a zero solution entry
+                        const int rn = max(j0 - 16, 0) + cc;
+                        if (nb == 16) {   // every block but the last one of the system: no condition on a uniform value inside (each one became a branch with its own wait)
 #pragma unroll
-                        for (int rr = 0; rr < 16; rr++) wc[rr] = (rr < nb && cc <= rr) ? S[pk(j0 + rr, j0 + cc)] : 0.0;
+                            for (int rr = 0; rr < 16; rr++) { const double v = S[pk(j0 + rr, j0) + min(cc, rr)]; wc[rr] = cc <= rr ? v : 0.0; }
+#pragma unroll
+                            for (int c = 0; c < 16; c++) lnext[c] = S[pk(j0 + c, 0) + rn];
+                        } else {
+#pragma unroll
+                            for (int rr = 0; rr < 16; rr++) {
+                                const int rl = min(rr, nb - 1);
+                                const double v = S[pk(j0 + rl, j0 + min(cc, rl))];
+                                wc[rr] = (rr < nb && cc <= rr) ? v : 0.0;
+                            }
+#pragma unroll
+                            for (int c = 0; c < 16; c++) lnext[c] = S[pk(j0 + min(c, nb - 1), rn)];
+                        }
+                        const double zn = S[pk(R, rn)];
                         double y0 = 0.0, y1 = 0.0;
 #pragma unroll
                         for (int rr = 0; rr < 16; rr += 2) { y0 += wc[rr] * row_bcast(z, rr); y1 += wc[rr + 1] * row_bcast(z, rr + 1); }
                         z = y0 + y1;
-                        if (lane < nb) { s_y[lane] = z; yv[j0 + lane] = z; }
-                        if (lane >= nb && lane < 16) s_y[lane] = 0.0;
-                    }
-                    __syncthreads();
-                    for (int r = tid; r < j0; r += 512) {
-                        double sv = S[pk(R, r)];
-                        double lv[16];
+                        if (lane < nb) { s_y[16 * par + lane] = z; yv[j0 + lane] = z; }
+                        if (lane >= nb && lane < 16) s_y[16 * par + lane] = 0.0;
+                        if (j0 > 0) {
+                            double sv = zn;
 #pragma unroll
-                        for (int c = 0; c < 16; c++) lv[c] = c < nb ? S[pk(j0 + c, r)] : 0.0;
-#pragma unroll
-                        for (int c = 0; c < 16; c++) sv -= lv[c] * s_y[c];
-                        S[pk(R, r)] = sv;
+                            for (int c = 0; c < 16; c++) sv -= lnext[c] * row_bcast(z, c);
+                            if (lane < 16) S[pk(R, rn)] = sv;
+                        }
+                        __builtin_amdgcn_s_setprio(0);
                     }
+#ifdef GF_PROFILE_STEP
+                    const long long bq1 = clock64();
+#endif
                     __syncthreads();
+#ifdef GF_PROFILE_STEP
+                    const long long bq2 = clock64();
+                    if (blockIdx.x == 0 && tid == 0 && sb.stamps) { sb.stamps[29] += bq1 - bq0; sb.stamps[30] += bq2 - bq1; }
+                    if (blockIdx.x == 0 && tid == 64 && sb.stamps) { sb.stamps[31] += bq2 - bq1; }
+#endif
+                    if (wave > 0) {
+                        const double* yb = s_y + 16 * par;
+                        for (int r = tid - 64; r < j0 - 16; r += 448) {
+                            double lv[16];
+#pragma unroll
+                            for (int c = 0; c < 16; c++) lv[c] = c < nb ? S[pk(j0 + c, r)] : 0.0;
+                            double acc = 0.0;
+#pragma unroll
+                            for (int c = 0; c < 16; c++) acc += lv[c] * yb[c];
+                            s_rd[r] -= acc;
+                        }
+                    }
                 }
+                __syncthreads();
                 GF_STAMP(10);
                 // back-substitute the eliminated columns (one wavefront per row), check finiteness
                 double bad = 0;

@@ -15,5 +15,9 @@ for k in sorted(acc):
         per = collections.defaultdict(float)   # one dispatch may be reported in several rows: sum rows of the same dispatch
         for d, v in acc[k][c]:
             per[d] += v
-        vals = list(per.values())
-        print("%s,%s,%d,%.1f,%.1f,%.1f,%.0f" % (k.replace(",", ";"), c, len(vals), sum(vals) / len(vals), min(vals), max(vals), sum(dur[k].values()) / len(dur[k])))
+        # launches that exit at once (finished windows, the finalising ba_step of a solve) are not what a roofline is about: keep the dispatches that ran at
+        # least a quarter as long as the longest one of the kernel
+        dmax = max(dur[k].values())
+        keep = [d for d in per if dur[k][d] >= 0.25 * dmax]
+        vals = [per[d] for d in keep]
+        print("%s,%s,%d,%.1f,%.1f,%.1f,%.0f" % (k.replace(",", ";"), c, len(vals), sum(vals) / len(vals), min(vals), max(vals), sum(dur[k][d] for d in keep) / len(keep)))

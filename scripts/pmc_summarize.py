@@ -13,6 +13,10 @@ def load(name):
 def info(name):
     return open(os.path.join(G, "%s_pmc_%s.info" % (tag, name))).read()
 cal, tf, tw, tsq, bsq, bsq2 = load("calib_fetch"), load("tracker_fetch"), load("tracker_write"), load("tracker_sq"), load("backend_sq"), load("backend_sq2")
+try:
+    bf, bw = load("backend_fetch"), load("backend_write")
+except OSError:
+    bf, bw = {}, {}
 ci = {int(m.group(1)): (float(m.group(2)), float(m.group(3))) for m in re.finditer(r"calib mode (\d) requested_bytes (\d+) lines64 (\d+)", info("calib_fetch"))}
 kb = 1024.0
 stream = cal["calib_stream_kernel"]["FETCH_SIZE"][0] * kb / ci[0][0]
@@ -55,13 +59,17 @@ for k, name in (("gfb::ba_linearize_visual_win<false; 12>", "ba_linearize_visual
         d.update({c: v[0] for c, v in bsq2.get(k, {}).items()})
         d["mfma_utilisation"] = util(d)
         d["wave_cycle_split"] = {"parked": d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"], "issue_stalled": d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"], "issuing": d["SQ_ACTIVE_INST_ANY"] / d["SQ_WAVE_CYCLES"]}
+        if k in bf and k in bw:   # HBM-side traffic of the launch (256 windows): FETCH_SIZE counts 64 B per request (see the calibration), so reads lie between 1x and 2x
+            f, wv = bf[k]["FETCH_SIZE"][0] * kb, bw[k]["WRITE_SIZE"][0] * kb
+            d.update({"FETCH_SIZE_bytes": f, "WRITE_SIZE_bytes": wv, "hbm_bytes_lower": f + wv, "hbm_bytes_upper": 2 * f + wv,
+                      "hbm_GBps_lower": (f + wv) / (d["duration_us_profiled"] * 1e-6) / 1e9, "hbm_GBps_upper": (2 * f + wv) / (d["duration_us_profiled"] * 1e-6) / 1e9})
         d["note"] = "counter-derived MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (profiled kernel duration x 2.4 GHz x 1024 SIMDs), profiles/%s_pmc_backend_sq.csv" % tag
         S[name] = d
 for k, name in (("gf::lk_track_kernel", "lk_track_kernel_sq"), ("gf::detect_fused_kernel", "detect_fused_kernel_sq")):
     if k in tsq:
         S[name] = sq(tsq, k)
 json.dump(S, open(os.path.join(R, "profiles", "pmc_summary.json"), "w"), indent=1)
-for n in ("calib_fetch", "tracker_fetch", "tracker_write", "tracker_sq", "backend_sq", "backend_sq2"):
+for n in ("calib_fetch", "tracker_fetch", "tracker_write", "tracker_sq", "backend_sq", "backend_sq2") + (("backend_fetch", "backend_write") if bf else ()):
     for ext in ("csv", "info"):
         shutil.copy(os.path.join(G, "%s_pmc_%s.%s" % (tag, n, ext)), os.path.join(R, "profiles", "%s_pmc_%s.%s" % (tag, n, ext)))
 print(json.dumps({k: S[k] for k in ("fetch_size_calibration",)}, indent=1))
