@@ -1590,77 +1590,61 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                 if (!good && lane == 0) s_flag[1] = 0;
                 GF_DSUB(27);
             };
-            // one 16x16 tile (ti, tk) of the trailing update A22 -= L21 L21^T
-            // `full` (a std::true_type / false_type tag): the block column has all 16 columns -- every block but the last.  Conditions on the block width are
-            // uniform, and the compiler turned each of them into a branch with its own wait; the full-width instances carry none.
-            auto trail_tile = [&](auto full, int j0, int nb, int r0, int ti, int tk) {
-                constexpr bool FULL = decltype(full)::value;
-                const int ra = r0 + 16 * ti + (lane & 15), rb = r0 + 16 * tk + (lane & 15);
-                const int ba_ = ra <= R ? pk(ra, j0) : -1, bb_ = rb < R ? pk(rb, j0) : -1;   // row R (rhs) never acts as a column
-                d4 acc = {0, 0, 0, 0};
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int c = 4 * k + (lane >> 4);
-                    const double av = (ba_ >= 0 && (FULL || c < nb)) ? S[ba_ + c] : 0.0;
-                    const double bv2 = (bb_ >= 0 && (FULL || c < nb)) ? S[bb_ + c] : 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv2, acc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int row = r0 + 16 * ti + (lane >> 4) + 4 * r, col = r0 + 16 * tk + (lane & 15);
-                    if (row <= R && col <= row && col < R) S[pk(row, col)] -= acc[r];
-                }
-            };
-            // two tiles at a time for the wavefronts that own several: all panel loads first, the two MFMA chains interleaved, then the read-modify-writes
-            // (one tile after the other is a chain of LDS round trips with nothing in between)
-            auto trail_pair = [&](auto full, int j0, int nb, int r0, int t0, int t1) {
-                constexpr bool FULL = decltype(full)::value;
-                int tiv[2], tkv[2], ba_[2], bb_[2];
-                const bool two = t1 >= 0;
-                tiv[0] = tri_row(t0); tkv[0] = t0 - tiv[0] * (tiv[0] + 1) / 2;
-                tiv[1] = two ? tri_row(t1) : tiv[0]; tkv[1] = two ? t1 - tiv[1] * (tiv[1] + 1) / 2 : tkv[0];
-#pragma unroll
-                for (int p = 0; p < 2; p++) {
-                    const int ra = r0 + 16 * tiv[p] + (lane & 15), rb = r0 + 16 * tkv[p] + (lane & 15);
-                    ba_[p] = ra <= R ? pk(ra, j0) : -1; bb_[p] = rb < R ? pk(rb, j0) : -1;
-                }
-                double av[2][4], bv2[2][4];
-#pragma unroll
-                for (int p = 0; p < 2; p++)
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int c = 4 * k + (lane >> 4);
-                        av[p][k] = (ba_[p] >= 0 && (FULL || c < nb)) ? S[ba_[p] + c] : 0.0;
-                        bv2[p][k] = (bb_[p] >= 0 && (FULL || c < nb)) ? S[bb_[p] + c] : 0.0;
-                    }
+            // ---- left-looking blocked Cholesky.  Block column j first receives ALL its updates -- tile (i, j) -= sum_{k < j} L_ik L_jk^T, accumulated on the
+            // matrix cores over the 16 k columns to its left and subtracted ONCE --, then its diagonal block is factored (+ inverted) and the tiles below it
+            // are multiplied with the inverse.  Against the right-looking form used before (every block column updated every tile of the trailing matrix:
+            // one LDS read-modify-write pass per tile and block column, 15 k cycles for the first columns on seven wavefronts next to a serial wavefront that
+            // needed 8 k) every tile is written twice in total, the operands of an update are plain loads, and the serial wavefront only waits for its own
+            // diagonal tile: it updates that one itself and goes straight on to factor it while the others update the rest of the column.
+            const int NT = (R + 16) / 16;   // tile rows: rows 0 .. R (row R carries the right-hand side)
+            auto upd_tile = [&](int ti, int tj, int k0, int k1) {   // tile (ti, tj), ti >= tj, minus the products of the block rows ti and tj over the block columns k0 .. k1 - 1 (< tj)
+                const int ra = 16 * ti + (lane & 15), rb = 16 * tj + (lane & 15), kq = lane >> 4;
+                const bool va = ra <= R, vb = rb < R;   // row R (rhs) never acts as a column
+                const int base_a = pk(min(ra, R), 0) + kq, base_b = pk(min(rb, R - 1), 0) + kq;
                 d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+                if (k0 >= k1) return;
+#pragma unroll 2
+                for (int k = k0; k < k1; k++) {
+                    double av[4], bv2[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][k], bv2[0][k], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][k], bv2[1][k], acc1, 0, 0, 0);
+                    for (int q = 0; q < 4; q++) { av[q] = S[base_a + 16 * k + 4 * q]; bv2[q] = S[base_b + 16 * k + 4 * q]; }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { av[q] = va ? av[q] : 0.0; bv2[q] = vb ? bv2[q] : 0.0; }
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv2[0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv2[1], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv2[2], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv2[3], acc1, 0, 0, 0);
                 }
-                double cur[2][4]; int idx[2][4];
-#pragma unroll
-                for (int p = 0; p < 2; p++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int row = r0 + 16 * tiv[p] + (lane >> 4) + 4 * r, col = r0 + 16 * tkv[p] + (lane & 15);
-                        idx[p][r] = (row <= R && col <= row && col < R && (p == 0 || two)) ? pk(row, col) : -1;
-                        cur[p][r] = idx[p][r] >= 0 ? S[idx[p][r]] : 0.0;
-                    }
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    if (idx[0][r] >= 0) S[idx[0][r]] = cur[0][r] - acc0[r];
-                    if (idx[1][r] >= 0) S[idx[1][r]] = cur[1][r] - acc1[r];
+                    const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tj + (lane & 15);
+                    if (row <= R && col <= row && col < R) S[pk(row, col)] -= acc0[r] + acc1[r];
                 }
             };
-            // wavefront 0 runs the serial part (next diagonal tile, then its factor + inverse) next to wavefront 4 on the same SIMD, which is busy with
-            // trailing tiles at that time: without priority the two alternate and the serial part takes twice its stand-alone time (3.5 k -> 6.4 k cycles)
-            if (wave == 0) { __builtin_amdgcn_s_setprio(3); diag_block(0); __builtin_amdgcn_s_setprio(0); }
-            __syncthreads();
-            GF_SUB(tA);
             for (int j0 = 0; j0 < R; j0 += 16) {
-                const int nb = min(16, R - j0);
+                const int nb = min(16, R - j0), jb = j0 >> 4;
+#ifdef GF_PROFILE_STEP
+                const long long w0c = clock64();
+#endif
+                // wavefront 0 runs the serial part (its diagonal tile, then the factor + inverse) next to wavefront 4 on the same SIMD: without priority the two
+                // alternate and the serial part takes twice its stand-alone time (3.5 k -> 6.4 k cycles)
+                // The diagonal tile of the NEXT block column takes everything that is final already (block columns 0 .. jb - 1) from wavefront 7 during this
+                // step -- it has the fewest tiles of the column, none in the later steps where this job is longest --, so that the serial wavefront only adds
+                // the last block column (the one whose panel is not done yet) before it factors: its share per step no longer grows with the column index.
+                if (wave == 0) {
+                    __builtin_amdgcn_s_setprio(3);
+                    if (jb > 0) { upd_tile(jb, jb, jb - 1, jb); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+                    diag_block(j0);
+                    __builtin_amdgcn_s_setprio(0);
+                } else {
+                    if (jb > 0) for (int t = wave; t < NT - jb; t += 7) upd_tile(jb + t, jb, 0, jb);
+                    if (wave == 7 && jb + 1 < NT && 16 * (jb + 1) < R) upd_tile(jb + 1, jb + 1, 0, jb);
+                }
+#ifdef GF_PROFILE_STEP
+                if (blockIdx.x == 0 && sb.stamps && (tid == 0 || tid == 64 || tid == 256) && jb < 12) sb.stamps[(tid == 0 ? 40 : tid == 64 ? 56 : 72) + jb] = clock64() - w0c;
+#endif
+                __syncthreads();
+                GF_SUB(tC);
                 if (!uni(s_flag[1])) break;
                 // panel: X = A21 L11^-T for the rows below the block and the rhs row; 16-row tiles, X[i][c] = sum_k A[i][k] Linv[c][k]
                 const int r0 = j0 + nb;
@@ -1689,37 +1673,6 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
                 if (nb == 16) panel(std::true_type{}); else panel(std::false_type{});
                 __syncthreads();
                 GF_SUB(tB);
-                // trailing update with look-ahead: wavefront 0 updates the next diagonal tile first and factors it (the serial part of the next
-                // block column) while wavefronts 1..7 update all other tiles
-                if (r0 <= R) {
-                    const int nrows = R + 1 - r0, nt = (nrows + 15) / 16, ntiles = nt * (nt + 1) / 2;
-#ifdef GF_PROFILE_STEP
-                    const long long w0c = clock64();
-#endif
-                    if (wave == 0) {
-                        __builtin_amdgcn_s_setprio(3);
-#ifdef GF_PROFILE_STEP
-                        const long long q0 = clock64();
-#endif
-                        if (nb == 16) trail_tile(std::true_type{}, j0, nb, r0, 0, 0); else trail_tile(std::false_type{}, j0, nb, r0, 0, 0);
-#ifdef GF_PROFILE_STEP
-                        if (blockIdx.x == 0 && tid == 0 && sb.stamps) sb.stamps[28] += clock64() - q0;
-#endif
-                        if (r0 < R) {
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                            diag_block(r0);
-                        }
-                        __builtin_amdgcn_s_setprio(0);
-                    } else {
-                        if (nb == 16) { for (int t = wave; t < ntiles; t += 14) trail_pair(std::true_type{}, j0, nb, r0, t, t + 7 < ntiles ? t + 7 : -1); }
-                        else { for (int t = wave; t < ntiles; t += 14) trail_pair(std::false_type{}, j0, nb, r0, t, t + 7 < ntiles ? t + 7 : -1); }
-                    }
-#ifdef GF_PROFILE_STEP
-                    if (blockIdx.x == 0 && sb.stamps && (tid == 0 || tid == 64 || tid == 256) && j0 / 16 < 12) sb.stamps[(tid == 0 ? 40 : tid == 64 ? 56 : 72) + j0 / 16] = clock64() - w0c;
-#endif
-                }
-                __syncthreads();
-                GF_SUB(tC);
             }
 #ifdef GF_PROFILE_STEP
             if (blockIdx.x == 0 && tid == 0 && sb.stamps) { sb.stamps[20] = tA; sb.stamps[21] = tB; sb.stamps[22] = tC; }
