@@ -59,6 +59,8 @@ struct SolverState {  // per window, lives in device memory
     int reuse, done, termination, iterations, successful, invalid_run, last_successful, have_scale, cand_valid;
     int R, NE;          // reduced dimension and number of eliminated (free inverse-depth) columns
     double mu_solved;   // the mu of the Gauss-Newton solve that gn / yv currently hold
+    int h_prior[2];     // buffer set q holds the prior's part of H for this solve's column map (written by its first linearisation: the part outside the band
+                        // the IMU / wheel factors touch does not depend on the state, and rewriting 150 KB per window and iteration made the sweep write-bound)
 };
 
 struct Win {  // device view of the whole batch
@@ -127,6 +129,10 @@ __device__ __forceinline__ double cost_total(const Win& w, int which, int b) { r
 __device__ __forceinline__ Q4 q_of(const double* p) { return Q4{p[6], p[3], p[4], p[5]}; }
 __device__ __forceinline__ V3 p_of(const double* p) { return V3{p[0], p[1], p[2]}; }
 
+// A value every lane of the wavefront holds anyway (loaded from per-window state): tell the compiler, so that it lives in scalar registers, loop bounds and
+// branches on it are scalar, and pointers derived from it stay out of the vector register file (ba_step sits at the 256-VGPR limit).
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v))); }
 // Huber(1.0) + ceres Corrector (loss_function.h / corrector.cc; same arithmetic at marginalization_factor.cpp:27-57)
 __device__ __forceinline__ void huber_corrector(double sq, double& rho0, double& sqrt_rho1, double& residual_scaling, double& alpha_sq_norm) {
     double rho1, rho2;
@@ -627,10 +633,6 @@ struct StepBufs {  // per-window global scratch of ba_step
 };
 
 __device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }  // packed lower, i >= j
-// A value every lane of the wavefront holds anyway (loaded from per-window state): tell the compiler, so that it lives in scalar registers, loop bounds and
-// branches on it are scalar, and pointers derived from it stay out of the vector register file (ba_step sits at the 256-VGPR limit).
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ double uni(double v) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v))); }
 
 // 512-thread block reductions through wavefront shuffles + 8 LDS partials (sred >= 64 doubles)
 template <int NV_>
@@ -752,11 +754,12 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
     const Dims d = w.d;
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, NP = d.NP;
     const SolverState& st = w.st[b];
-    if (st.done && only_cand_valid != 2) return;   // only_cand_valid == 2: marginalisation pass (runs on finished windows)
-    if (only_cand_valid == 1 && !st.cand_valid) return;
-    const int n_order = w.norder[b];
-    if (which < 0) which = 1 - st.cur;
-    if (which_state == -2) which_state = st.cur; else if (which_state < 0) which_state = 1 - st.cur;
+    const int st_cur = uni(st.cur);   // per-window scalars: uniform by construction, kept in scalar registers
+    if (uni(st.done) && only_cand_valid != 2) return;   // only_cand_valid == 2: marginalisation pass (runs on finished windows)
+    if (only_cand_valid == 1 && !uni(st.cand_valid)) return;
+    const int n_order = uni(w.norder[b]);
+    if (which < 0) which = 1 - st_cur;
+    if (which_state == -2) which_state = st_cur; else if (which_state < 0) which_state = 1 - st_cur;
     const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
     const int* colf = w.colf + (size_t)b * d.NFB;
     const int NPAIR = NP * (NP - 1) / 2;
@@ -901,7 +904,7 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
     GF_WSTAMP(85);
     // ---- compact E^T F rows of the free inverse depths (the factor products efac were written above by this block)
     {
-        const int nfeat = w.nfeat[b];
+        const int nfeat = uni(w.nfeat[b]);
         const int* cole = w.cole + (size_t)b * d.F;
         const int* fptr = d.F <= kVFP ? s_fptr : w.feat_ptr + (size_t)b * (d.F + 1);
         for (int f0 = 8 * wave; f0 < nfeat; f0 += 8 * NW) et_rows8<EX>(w, sb, d, b, f0, nfeat, cole, fptr, which, lane);
@@ -936,15 +939,19 @@ __global__ void __launch_bounds__(64 * kMW) ba_linearize_misc_win(Win w, int whi
     const Dims d = w.d;
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, RP = d.RP, NP = d.NP;
     const SolverState& st = w.st[b];
-    if (st.done && only_cand_valid != 2) return;
-    if (only_cand_valid == 1 && !st.cand_valid) return;
-    if (which < 0) which = 1 - st.cur;
-    if (which_state == -2) which_state = st.cur; else if (which_state < 0) which_state = 1 - st.cur;
+    const int st_cur = uni(st.cur);
+    if (uni(st.done) && only_cand_valid != 2) return;
+    if (only_cand_valid == 1 && !uni(st.cand_valid)) return;
+    if (which < 0) which = 1 - st_cur;
+    if (which_state == -2) which_state = st_cur; else if (which_state < 0) which_state = 1 - st_cur;
     const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
     const int* colf = w.colf + (size_t)b * d.NFB;
     double* H = w.H + ((size_t)which * d.B + b) * RP * RP;
     double* g = w.g + ((size_t)which * d.B + b) * RP;
-    const int nimu = frame_filter == 2 ? 0 : w.nimu[b], nwh = frame_filter == 2 ? 0 : w.nwh[b];
+    const int nimu = frame_filter == 2 ? 0 : uni(w.nimu[b]), nwh = frame_filter == 2 ? 0 : uni(w.nwh[b]);
+    // the prior's part of H outside the band is already in this buffer set (see SolverState::h_prior); not with GNSS blocks, whose kernel adds into H
+    const bool h_keeps = only_cand_valid != 2 && frame_filter == 0 && d.GO == 0;
+    const bool h_have = h_keeps && uni(w.st[b].h_prior[which]) != 0;
     const int nscr = misc_win_nscr(d.W);
     double* sJi = m_lds;                          // [W][16][33]
     double* sJw = sJi + (size_t)d.W * kMJi;       // [W][9][33]
@@ -969,7 +976,7 @@ __global__ void __launch_bounds__(64 * kMW) ba_linearize_misc_win(Win w, int whi
         s_R = R;
     }
     __syncthreads();
-    const int R = s_R, n = w.pri_n[b];
+    const int R = uni(s_R), n = uni(w.pri_n[b]);
     {   // prior: dx of every kept block (marginalization_factor.cpp:348-372), column of every local prior index, and the inverse map
         const int nb = n > 0 ? w.pri_nb[b] : 0;
         const int* bid = w.pri_bid + (size_t)b * 64;
@@ -1022,8 +1029,10 @@ __global__ void __launch_bounds__(64 * kMW) ba_linearize_misc_win(Win w, int whi
         pc = wave_sum_f64(pc);
         if (lane == 0) s_wc[wave] = pc;
         GF_WSTAMP_T(128, 68);
-        // H <- A gathered to this pass's columns: lower triangle of the first R rows, four rows per wavefront in flight
-        for (int r0 = wave - 2; r0 < R; r0 += 4 * (kMW - 2)) {
+        // H <- A gathered to this pass's columns: lower triangle of the first R rows, four rows per wavefront in flight.  Outside the band of phase 3 the
+        // entries are the prior's alone and constant over the solve: each of the two buffer sets receives them once (marginalisation passes always: their
+        // column map is another one).
+        if (!h_have) for (int r0 = wave - 2; r0 < R; r0 += 4 * (kMW - 2)) {
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 const int r = r0 + (kMW - 2) * m;
@@ -1141,6 +1150,7 @@ __global__ void __launch_bounds__(64 * kMW) ba_linearize_misc_win(Win w, int whi
         for (int k = 0; k < nwh; k++) c += s_fcost[32 + k];
         *cost_part(w, 0, which, b) = c;
         *cost_part(w, 2, which, b) = 0.0;   // the GNSS kernel (same stream, later) adds its part
+        w.st[b].h_prior[which] = h_keeps ? 1 : 0;
     }
     GF_WSTAMP(75);
 }

@@ -139,10 +139,10 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     const Dims d = w.d;
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const MargInfo mi = info[b];
-    if (!mi.valid) return;
+    if (!uni(mi.valid)) return;
     const SolverState& st = w.st[b];
-    const int o = 1 - st.cur, RP = d.RP;
-    const int mp = mi.mp, NE = mi.nfe, n = mi.n;
+    const int o = 1 - uni(st.cur), RP = d.RP;
+    const int mp = uni(mi.mp), NE = uni(mi.nfe), n = uni(mi.n);   // per-window scalars: scalar registers, scalar loop bounds
     double* M = w.H + ((size_t)o * d.B + b) * RP * RP;
     double* bv = w.g + ((size_t)o * d.B + b) * RP;
     const int ECW = d.ECW;
