@@ -392,7 +392,7 @@ def main():
         step_t = iso.get("step_ms", step_ms)
         tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         lk_pmc = pmc.get("lk_track_kernel", {})
-        traffic = lk_pmc.get("hbm_bytes_per_point")
+        traffic = lk_pmc.get("hbm_bytes_per_point")   # per point: the same kernel at any batch
         unit = "window-solves/s (each with its tracker frame)" if not (args.no_frontend or args.no_backend) else ("tracked-features/s" if args.no_backend else "window-solves/s")
         value = (tracked / el_max) if args.no_backend else (solves / el_max)
         res = {
@@ -429,12 +429,12 @@ def main():
             "roofline_jtj": {"kernel": "ba_linearize_visual_win", "bound": "mfma", "achieved": tf(jtj_alg, jtj_t), "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                              "frac": tf(jtj_alg, jtj_t) / FP64_MFMA_PEAK_TF, "launch_ms": jtj_t, "launch_ms_in_timed_region": jtj_ms,
                              "algorithmic_flops_per_launch": jtj_alg, "issued_mfma_flops_per_launch": jtj_issued, "frac_issued": tf(jtj_issued, jtj_t) / FP64_MFMA_PEAK_TF,
-                             "mfma_utilisation_pmc": pmc.get("ba_linearize_visual_win", {}).get("mfma_utilisation"),
+                             "mfma_utilisation_pmc": pmc.get("ba_linearize_visual_win", {}).get("mfma_utilisation") if args.config == 1 and B == 256 else None,   # the PMC passes ran configs[1] at 256 windows
                              "note": "algorithmic flops = Nv*2*2*91 per window (SURVEY.md 8d); issued = 2048 per v_mfma_f64_16x16x4_f64 (16-column tiles, 13 used); the kernel also "
                                      "evaluates every factor's residual / Jacobian (FP64 VALU), reduces the pair tiles and builds the E^T F rows; " + pmc.get("ba_linearize_visual_win", {}).get("note", "")},
             "roofline_step": {"kernel": "ba_step", "bound": "mfma", "achieved": tf(step_flops, step_t), "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf(step_flops, step_t) / FP64_MFMA_PEAK_TF,
                               "launch_ms": step_t, "launch_ms_in_timed_region": step_ms, "flops_per_launch": step_flops,
-                              "mfma_utilisation_pmc": pmc.get("ba_step", {}).get("mfma_utilisation"),
+                              "mfma_utilisation_pmc": pmc.get("ba_step", {}).get("mfma_utilisation") if args.config == 1 and B == 256 else None,
                               "note": "largest kernel by time; algorithmic flops = Schur SYRK NE*n_c^2 + Cholesky R^3/3 + substitutions 2R^2 per window; one block per window, "
                                       "bound by the latency of R/16 sequential 16x16 factor+inverse blocks, not by MFMA issue"},
             "ba_summary_seq0": sums[0],

@@ -160,7 +160,8 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(DetectArgs A, DiskTab
     __shared__ short s_hw[kMaxRadius + 1];
     __shared__ int n_cand, cand_base;
     __shared__ unsigned blk_max;
-    __shared__ unsigned long long ckeys[kDT_W * kDT_H];
+    constexpr int kCK = 320;   // local maxima of a 64 x 16 tile staged in LDS (a 3 x 3 maximum excludes its neighbours: <= 256 + plateaus); the rest goes out one by one
+    __shared__ unsigned long long ckeys[kCK];
     const int b = blockIdx.z;
     if (A.want[b] <= 0) return;
     const LevelGeom g = A.g;
@@ -299,8 +300,13 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(DetectArgs A, DiskTab
         const bool ismax = v >= eg[ly][lx] && v >= eg[ly][lx + 1] && v >= eg[ly][lx + 2] && v >= eg[ly + 1][lx] && v >= eg[ly + 1][lx + 2] &&
                            v >= eg[ly + 2][lx] && v >= eg[ly + 2][lx + 1] && v >= eg[ly + 2][lx + 2];
         if (ismax) {
+            const unsigned long long key = ((unsigned long long)f32_orderable(v) << 32) | (unsigned)(y * g.w + x);
             const int k = atomicAdd(&n_cand, 1);
-            ckeys[k] = ((unsigned long long)f32_orderable(v) << 32) | (unsigned)(y * g.w + x);
+            if (k < kCK) ckeys[k] = key;
+            else {   // plateau-ridden tile: straight to the sequence's list (the order of candidates is settled by the sort that follows)
+                const int slot = atomicAdd(A.cand_count + b, 1);
+                if (slot < A.cand_cap) A.cand[b * A.cand_seq_stride + slot] = key;
+            }
         }
     }
 #pragma unroll
@@ -309,6 +315,7 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(DetectArgs A, DiskTab
     __syncthreads();
     if (tid == 0) {
         if (blk_max) atomicMax(A.maxkey + b, blk_max);
+        n_cand = min(n_cand, kCK);
         cand_base = n_cand ? atomicAdd(A.cand_count + b, n_cand) : 0;
     }
     __syncthreads();
