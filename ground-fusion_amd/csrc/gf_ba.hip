@@ -52,6 +52,20 @@ template <class T> struct Buf {  // device buffer + pinned host mirror
 };
 }  // namespace
 
+// per slot: rows 1 .. W - 1 move up by one when the window slid (flag), then the staged rows go to their positions
+__global__ void ba_imu_patch(double* tab, const double* patch, const int* pinfo, int W) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int* pi = pinfo + (size_t)b * (W + 2);
+    double* t = tab + (size_t)b * W * IMU_STRIDE2;
+    if (pi[0]) for (int k = 0; k + 1 < W; k++) {
+        for (int i = tid; i < IMU_STRIDE2; i += 256) t[(size_t)k * IMU_STRIDE2 + i] = t[(size_t)(k + 1) * IMU_STRIDE2 + i];
+        __syncthreads();
+    }
+    const double* p = patch + (size_t)b * W * IMU_STRIDE2;
+    for (int q = 0; q < pi[1]; q++)
+        for (int i = tid; i < IMU_STRIDE2; i += 256) t[(size_t)pi[2 + q] * IMU_STRIDE2 + i] = p[(size_t)q * IMU_STRIDE2 + i];
+}
+
 struct gf_ba {
     gf_ba_cfg cfg;
     Dims d;
@@ -88,11 +102,18 @@ struct gf_ba {
     int max_vis = 0, max_order = 0, max_prior = 0, max_feat = 0;   // largest n_visual / factor-order length / prior size of the resident batch (what the uploads copy)
     std::vector<const gf_ba_window*> resident;       // the caller's window behind every resident slot (gf_ba_marginalize_resident)
     // what packing a window into slot b found out about it; reduced over the batch when the batch is closed (pack_slot may run on one thread per slot)
-    struct SlotMeta { bool any_ex = false, pri_res = false; long long mfma = 0, step = 0, jtj = 0; int nvis = 0, norder = 0, npri = 0, nfeat = 0; };
+    struct SlotMeta { bool any_ex = false, pri_res = false; long long mfma = 0, step = 0, jtj = 0; int nvis = 0, norder = 0, npri = 0, nfeat = 0, imu_dirty = 0; };
     std::vector<SlotMeta> meta;
     // device-resident priors (gf_ba_pack_slot with prior_n > 0 and prior_J == NULL): outJ_n[b] = size of the prior the last gf_ba_marginalize_resident left in
     // the output buffer of slot b (0: none); the next solve of that slot copies it device to device into the prior table instead of taking it from the host
     std::vector<int> outJ_n, active;
+    // IMU tables that stay on the device: a window's pre-integrations change little from frame to frame (a new interval at the end; after a MARGIN_OLD slide
+    // everything moves up by one).  pack_slot compares the rows it is handed with what the slot's table holds (bytes), finds "same position" or "moved up by one",
+    // and stages only the rows that are new; the upload sends those (imu_patch) and a small kernel moves / patches the slot's table.  imu_dev[b]: the device table
+    // of slot b equals its host mirror (set by an upload that covered the slot).
+    Buf<double> imu_patch; Buf<int> imu_pinfo;   // [B][W][IMU_STRIDE2] rows to write, [B][W + 2]: moved-up flag, number of rows, their positions
+    std::vector<char> imu_dev;
+    int max_imu_dirty = 0;
     bool all_pri_res = false, any_pri_res = false, outJ_host_stale = false;
     double max_solver_time = 0.0;   // ceres::Solver::Options::max_solver_time_in_seconds; 0 = not honoured (the fixed schedule runs without host round trips)
     long long mfma_per_lin = 0;   // v_mfma_f64_16x16x4 instructions of one visual linearisation of the resident batch
@@ -105,7 +126,7 @@ struct gf_ba {
         for (auto* b : dbl()) b->release();
         for (auto* b : ints()) b->release();
         for (int m = 0; m < 2; m++) { mcolf[m].release(); mcole[m].release(); morder[m].release(); mnorder[m].release(); minfo[m].release(); }
-        minfo_stage.release();
+        minfo_stage.release(); imu_patch.release(); imu_pinfo.release();
         outJ.release(); outr.release(); stamps.release();
         st.release(); st0.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -265,13 +286,32 @@ int pack_slot(gf_ba* h, int b, const gf_ba_window& w) {
             std::vector<int> cur(fp, fp + d.F);
             for (int k = 0; k < w.n_visual; k++) { const int pos = cur[w.vis_feature[k]]++; h->feat_fac.h[(size_t)b * d.NV + pos] = k; h->vis_pos.h[(size_t)b * d.NV + k] = pos; }
         }
-        for (int k = 0; k < w.n_imu; k++) {
-            h->imu_i.h[(size_t)b * d.W + k] = w.imu_i[k];
-            double* dd = h->imu_data.h + ((size_t)b * d.W + k) * IMU_STRIDE2;
-            dd[0] = w.imu_sum_dt[k];
-            memcpy(dd + 1, w.imu_delta_p + 3 * k, 24); memcpy(dd + 4, w.imu_delta_q + 4 * k, 32); memcpy(dd + 8, w.imu_delta_v + 3 * k, 24);
-            memcpy(dd + 11, w.imu_lin_ba + 3 * k, 24); memcpy(dd + 14, w.imu_lin_bg + 3 * k, 24);
-            memcpy(dd + IMU_JAC, w.imu_jacobian + 225 * k, 225 * 8); memcpy(dd + IMU_COV, w.imu_covariance + 225 * k, 225 * 8);
+        {   // IMU rows: build them, compare with the slot's table, stage what is new (see gf_ba::imu_patch)
+            std::vector<double> rows((size_t)std::max(w.n_imu, 1) * IMU_STRIDE2);
+            for (int k = 0; k < w.n_imu; k++) {
+                h->imu_i.h[(size_t)b * d.W + k] = w.imu_i[k];
+                double* dd = rows.data() + (size_t)k * IMU_STRIDE2;
+                dd[0] = w.imu_sum_dt[k];
+                memcpy(dd + 1, w.imu_delta_p + 3 * k, 24); memcpy(dd + 4, w.imu_delta_q + 4 * k, 32); memcpy(dd + 8, w.imu_delta_v + 3 * k, 24);
+                memcpy(dd + 11, w.imu_lin_ba + 3 * k, 24); memcpy(dd + 14, w.imu_lin_bg + 3 * k, 24);
+                memcpy(dd + IMU_JAC, w.imu_jacobian + 225 * k, 225 * 8); memcpy(dd + IMU_COV, w.imu_covariance + 225 * k, 225 * 8);
+            }
+            double* tab = h->imu_data.h + (size_t)b * d.W * IMU_STRIDE2;
+            int* pi = h->imu_pinfo.h + (size_t)b * (d.W + 2);
+            const size_t RB = (size_t)IMU_STRIDE2 * sizeof(double);
+            auto same = [&](int k, int old_k) { return old_k < d.W && memcmp(rows.data() + (size_t)k * IMU_STRIDE2, tab + (size_t)old_k * IMU_STRIDE2, RB) == 0; };
+            int shift = 0;
+            if (h->imu_dev[b] && w.n_imu > 0) {
+                int m0 = 0, m1 = 0;
+                for (int k = 0; k < w.n_imu; k++) { m0 += same(k, k); m1 += same(k, k + 1); }
+                shift = m1 > m0 ? 1 : 0;
+            }
+            int nd = 0;
+            for (int k = 0; k < w.n_imu; k++)
+                if (!(h->imu_dev[b] && same(k, k + shift))) { memcpy(h->imu_patch.h + ((size_t)b * d.W + nd) * IMU_STRIDE2, rows.data() + (size_t)k * IMU_STRIDE2, RB); pi[2 + nd++] = k; }
+            pi[0] = shift; pi[1] = nd;
+            M.imu_dirty = nd;
+            memcpy(tab, rows.data(), (size_t)w.n_imu * RB);   // the mirror of what the device table holds after the patch (rows beyond n_imu are never read)
         }
         for (int k = 0; k < w.n_wheel; k++) {
             h->wh_i.h[(size_t)b * d.W + k] = w.wh_i[k];
@@ -381,6 +421,8 @@ void finalize_pack(gf_ba* h, const int* active, int n_active, int count) {
     }
     h->any_ex = any_ex; h->mfma_per_lin = mfma; h->step_flops = step; h->jtj_alg_flops = jtj;
     h->max_vis = mv; h->max_order = mo; h->max_prior = mp; h->max_feat = mf;
+    h->max_imu_dirty = 0;
+    for (int q = 0; q < n_active; q++) h->max_imu_dirty = std::max(h->max_imu_dirty, h->meta[active ? active[q] : q].imu_dirty);
     h->count = count;
     (void)d;
 }
@@ -435,7 +477,18 @@ int upload(gf_ba* h) {
         else for (int b : h->active) if (h->meta[b].pri_res) HIPCHK(hipMemcpyAsync(h->pri_J.d + (size_t)b * d.NPRI * d.NPRI, h->outJ.d + (size_t)b * d.NPRI * d.NPRI, (size_t)h->meta[b].npri * h->meta[b].npri * 8, hipMemcpyDeviceToDevice, s));
     }
     lapb("pri_J");
-    for (auto* b : {&h->imu_data, &h->wh_data, &h->pri_r, &h->pri_x0, &h->wpar}) HIPCHK(b->up(s));
+    {   // IMU tables: everything when many rows are new (first frames, whole-batch uploads), else the new rows + one small kernel that moves / patches the slots' tables
+        bool all_dev = true;
+        for (int b : h->active) all_dev &= h->imu_dev[b] != 0;
+        if (all_dev && (int)h->active.size() == d.B && h->max_imu_dirty <= d.W / 2) {
+            if (h->max_imu_dirty > 0) HIPCHK(h->imu_patch.up2d(s, B, (size_t)d.W * IMU_STRIDE2, (size_t)h->max_imu_dirty * IMU_STRIDE2));
+            HIPCHK(h->imu_pinfo.up(s));
+            ba_imu_patch<<<dim3(d.B), 256, 0, s>>>(h->imu_data.d, h->imu_patch.d, h->imu_pinfo.d, d.W);
+            HIPCHK(hipGetLastError());
+        } else HIPCHK(h->imu_data.up(s));
+        for (int b = 0; b < d.B; b++) h->imu_dev[b] = 1;   // the full upload covers every slot with its mirror; the patch path required it before
+    }
+    for (auto* b : {&h->wh_data, &h->pri_r, &h->pri_x0, &h->wpar}) HIPCHK(b->up(s));
     lapb("imu, wheel, pri_r, pri_x0, wpar");
     if (h->d.GO) { HIPCHK(h->ngnss.up(s)); HIPCHK(h->gn_idx.up(s)); HIPCHK(h->gn_data.up(s)); HIPCHK(h->gn_misc.up(s)); HIPCHK(h->gn_gptr.up(s)); HIPCHK(h->gn_gitem.up(s)); }
     for (int m = 0; m < 2; m++) {
@@ -604,7 +657,8 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     // kept system of the marginalisation: 6 W poses + speed-bias + extrinsics ...; A and V live in LDS up to 92 columns, else in global memory
     const int nkeep = 6 * d.W + 9 + 17 + (gnss ? 9 : 0);
     h->big_marg = nkeep > 92 || getenv("GF_BA_FORCE_GLOBAL") != nullptr;
-    h->meta.assign(d.B, gf_ba::SlotMeta{}); h->outJ_n.assign(d.B, 0);
+    h->meta.assign(d.B, gf_ba::SlotMeta{}); h->outJ_n.assign(d.B, 0); h->imu_dev.assign(d.B, 0);
+    A_(h->imu_patch.alloc(B * d.W * IMU_STRIDE2, true)); A_(h->imu_pinfo.alloc(B * (d.W + 2), true));
     for (int mode = 0; mode < 2; mode++) h->keep_ids[mode].assign(d.B, {});
     h->marg_ncap = h->big_marg ? std::min(d.NPRI, nkeep + 16) : 92;
     h->marg_lds = h->big_marg ? 0 : (size_t)2 * h->marg_ncap * h->marg_ncap * sizeof(double);
