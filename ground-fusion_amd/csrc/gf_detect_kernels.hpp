@@ -14,23 +14,6 @@ constexpr int kMaxRadius = 128;  // largest MIN_DIST supported by the disk table
 
 struct DiskTable { short hw[kMaxRadius + 1]; int radius; };  // half-width of row |dy| of OpenCV's filled midpoint circle
 
-// grid.x = kept point, grid.y = sequence; one thread per disk row.
-__global__ void __launch_bounds__(256) mask_disks_kernel(uint8_t* __restrict__ mask, size_t mask_seq_stride, int w, int h,
-                                                         const int2* __restrict__ centers, const int* __restrict__ n_centers, int cap,
-                                                         DiskTable T) {
-    const int b = blockIdx.y, i = blockIdx.x;
-    if (i >= n_centers[b]) return;
-    const int dy = (int)threadIdx.x - T.radius;
-    if (dy > T.radius) return;
-    const int2 c = centers[(size_t)b * cap + i];
-    const int y = c.y + dy;
-    if ((unsigned)y >= (unsigned)h) return;
-    const int hw = T.hw[dy < 0 ? -dy : dy];
-    int x1 = max(c.x - hw, 0), x2 = min(c.x + hw, w - 1);
-    uint8_t* row = mask + b * mask_seq_stride + (size_t)y * w;
-    for (int x = x1; x <= x2; x++) row[x] = 0;
-}
-
 // cornerMinEigenVal(block 3, Sobel 3): 32x8 output tile per 256-thread block, 34x10 covariance halo in LDS
 // evaluated at REFLECT_101 coordinates (the box filter's border mode), image read from the padded level 0.
 __global__ void __launch_bounds__(256) min_eig_kernel(const uint8_t* __restrict__ pyr, size_t pyr_seq_stride, LevelGeom g,
@@ -83,66 +66,12 @@ __host__ __device__ __forceinline__ float f32_from_orderable(unsigned k) {
 #endif
 }
 
-// masked maximum (cv::minMaxLoc(eig, 0, &maxVal, 0, 0, mask)); result as orderable uint, 0 == "no pixel"
-__global__ void __launch_bounds__(256) masked_max_kernel(const float* __restrict__ eig, size_t eig_seq_stride, const uint8_t* __restrict__ mask,
-                                                         size_t mask_seq_stride, int n, unsigned* __restrict__ out) {
-    const int b = blockIdx.y;
-    const float* e = eig + b * eig_seq_stride;
-    const uint8_t* m = mask + b * mask_seq_stride;
-    unsigned best = 0;
-    for (int i = (blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += gridDim.x * 1024) {
-        if (i + 3 < n) {
-            const float4 v = *reinterpret_cast<const float4*>(e + i);
-            const uchar4 k = *reinterpret_cast<const uchar4*>(m + i);
-            if (k.x) best = max(best, f32_orderable(v.x));
-            if (k.y) best = max(best, f32_orderable(v.y));
-            if (k.z) best = max(best, f32_orderable(v.z));
-            if (k.w) best = max(best, f32_orderable(v.w));
-        } else {
-            for (int q = i; q < n; q++) if (m[q]) best = max(best, f32_orderable(e[q]));
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o));
-    if ((threadIdx.x & 63) == 0 && best) atomicMax(out + b, best);
-}
-
-// threshold(TOZERO at 0.01*max) + 3x3 dilate non-maximum suppression + mask; survivors are appended as
-// 64-bit keys (value bits << 32 | pixel offset) — descending key order == OpenCV's greaterThanPtr order.
-__global__ void __launch_bounds__(256) nms_collect_kernel(const float* __restrict__ eig, size_t eig_seq_stride, const uint8_t* __restrict__ mask,
-                                                          size_t mask_seq_stride, int w, int h, const unsigned* __restrict__ maxkey,
-                                                          unsigned long long* __restrict__ cand, size_t cand_seq_stride, int cand_cap,
-                                                          int* __restrict__ cand_count, const int* __restrict__ want) {
-    const int b = blockIdx.y;
-    if (want[b] <= 0) return;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int y = 1 + t / (w - 2), x = 1 + t % (w - 2);
-    if (y >= h - 1) return;
-    const unsigned mk = maxkey[b];
-    const double maxVal = mk ? (double)f32_from_orderable(mk) : 0.0;
-    const float thresh = (float)(maxVal * 0.01);
-    const float* e = eig + b * eig_seq_stride + (size_t)y * w + x;
-    const float v = e[0];
-    if (!(v > thresh) || v == 0.f) return;
-    if (!mask[b * mask_seq_stride + (size_t)y * w + x]) return;
-    bool ismax = v >= e[-w - 1] && v >= e[-w] && v >= e[-w + 1] && v >= e[-1] && v >= e[1] && v >= e[w - 1] && v >= e[w] && v >= e[w + 1];
-    if (!ismax) return;
-    const int slot = atomicAdd(cand_count + b, 1);
-    if (slot < cand_cap)
-        cand[b * cand_seq_stride + slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(y * w + x);
-}
-
 
 // ---------------------------------------------------------------------------------------------
 // Fused Shi-Tomasi pass: image tile -> covariance (LDS) -> min-eigenvalue (LDS) -> masked maximum and
 // 3x3 local-maximum candidates.  The response image never touches HBM.  The mask is either an explicit
 // u8 image (building-block entry point) or, in trackImage, the union of filled circles of radius MIN_DIST
 // around the kept points, tested analytically with OpenCV's midpoint-circle row table (no rasterised mask).
-// Tile: 64x16 outputs per 256-thread block (4 pixels per thread).
-constexpr int kDT_W = 64, kDT_H = 16;
-constexpr int kRawQ = (kDT_W + 8) / 4;   // dwords per row of the raw patch: bytes bx-4 .. bx+67
-static_assert(kDT_W % 4 == 0 && (kDT_W + 2) % 2 == 0 && (kDT_H + 2) % 3 == 0, "work-item shapes of detect_fused_kernel");
-__device__ __forceinline__ int byte8(uint32_t lo, uint32_t hi, int k) { return k < 4 ? (int)((lo >> (8 * k)) & 0xff) : (int)((hi >> (8 * (k - 4))) & 0xff); }
 struct DetectArgs {
     const uint8_t* pyr; size_t pyr_seq_stride; LevelGeom g;
     const uint8_t* mask; size_t mask_seq_stride;            // optional explicit mask (non-zero = allowed)
@@ -152,175 +81,165 @@ struct DetectArgs {
     unsigned long long* cand; size_t cand_seq_stride; int cand_cap; int* cand_count;
 };
 
-__global__ void __launch_bounds__(256) detect_fused_kernel(DetectArgs A, DiskTable T) {
-    __shared__ float cxx[kDT_H + 4][kDT_W + 5], cxy[kDT_H + 4][kDT_W + 5], cyy[kDT_H + 4][kDT_W + 5];
-    __shared__ float eg[kDT_H + 2][kDT_W + 3];
-    __shared__ uint32_t raw[kDT_H + 6][kRawQ];
-    __shared__ unsigned long long rowmask[kDT_H];
+// One wavefront walks a strip of R image rows top to bottom, lane l on column X0 - 2 + l, and keeps everything
+// a 3 x 3 neighbourhood needs in registers -- the horizontal parts of the Sobel rows of the last three raw rows, the horizontal box sums of the last three
+// product rows (double, exact), the last three eigenvalue rows and their horizontal maxima.  Horizontal neighbours come over DPP wavefront shifts; lanes 2..61
+// (60 columns) and rows Y0 .. Y0 + R - 1 are outputs, the rest is halo recomputed by the neighbouring strips.  Per pixel the arithmetic is the one of
+// min_eig_kernel above (same operations in the same order; the box sums are exact -- nine float products spanning < 2^52 -- so their order is free).
+constexpr int kDS_W = 60;   // output columns per wavefront
+constexpr int kDS_R = 30;   // rows per strip in trackImage: 36 raw rows for 30 output rows (16: 0.31 ms, 30: 0.27 ms, 32: 0.27 ms per 256 VGA frames)
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+__device__ __forceinline__ float dpp_from_left(float v) {   // lane l <- lane l - 1
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));   // lane 0 reads 0: halo, never used
+}
+__device__ __forceinline__ float dpp_from_right(float v) {  // lane l <- lane l + 1
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
+}
+
+// the strip's staged candidates -> the sequence's list (one atomic per call); rare inside a strip, so kept out of line
+__device__ __noinline__ void strip_flush(unsigned long long* cand, int* count, int cap, const unsigned long long* ckeys, int n, int lane) {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(count, n);
+    base = __builtin_amdgcn_readfirstlane(base);
+    for (int k = lane; k < n; k += 64)
+        if (base + k < cap) cand[base + k] = ckeys[k];
+}
+
+template <int R>
+__global__ void __launch_bounds__(64) detect_strip_kernel(DetectArgs A, DiskTable T) {
+    static_assert(R >= 1 && R <= 32, "one allow bit per strip row");
+    constexpr int NS = R + 6;   // raw rows Y0 - 3 .. Y0 + R + 2
+    constexpr int kCap = 320;   // candidates staged per strip (3 x 3 maxima exclude their neighbours: <= 60 R / 4 without plateaus); flushed early when a row might not fit
+    __shared__ unsigned long long ckeys[kCap];
     __shared__ short s_hw[kMaxRadius + 1];
-    __shared__ int n_cand, cand_base;
-    __shared__ unsigned blk_max;
-    constexpr int kCK = 320;   // local maxima of a 64 x 16 tile staged in LDS (a 3 x 3 maximum excludes its neighbours: <= 256 + plateaus); the rest goes out one by one
-    __shared__ unsigned long long ckeys[kCK];
     const int b = blockIdx.z;
     if (A.want[b] <= 0) return;
     const LevelGeom g = A.g;
-    const int bx = blockIdx.x * kDT_W, by = blockIdx.y * kDT_H, tid = threadIdx.x;
-    if (tid == 0) { n_cand = 0; blk_max = 0; }
-    if (tid < kDT_H) rowmask[tid] = 0ull;
-    if (!A.mask && tid <= T.radius) s_hw[tid] = T.hw[tid];
-    __syncthreads();
-    // setMask first: a tile without a single unmasked pixel contributes neither to the masked maximum nor a candidate, and with MAX_CNT tracks
-    // of radius MIN_DIST most of the image is masked -- such tiles stop here, before any arithmetic on the image.
-    // The filled circles (OpenCV's midpoint-circle row table) are rasterised into one 64-bit word per tile row: a kept point whose bounding
-    // box touches the tile ORs its span of every row it crosses.
-    if (!A.mask) {
+    const int lane = threadIdx.x;
+    const int X0 = blockIdx.x * kDS_W, Y0 = blockIdx.y * R;
+    const int x = X0 - 2 + lane;
+    const bool col_out = lane >= 2 && lane < 62 && x < g.w;
+    const int nrows = min(R, g.h - Y0);
+    const uint32_t rows_all = nrows >= 32 ? ~0u : (1u << nrows) - 1u;
+    // ---- setMask for this strip: bit r of `allow` = pixel (x, Y0 + r) lies in no kept point's filled circle.  The circle table is symmetric in dx <-> dy and
+    // monotone (midpoint circle), so a centre covers a contiguous run of rows of one column: |y - cy| <= hw[|x - cx|].
+    uint32_t allow = 0;
+    if (A.mask) {
+        if (col_out)
+            for (int r = 0; r < nrows; r++)
+                if (A.mask[b * A.mask_seq_stride + (size_t)(Y0 + r) * g.w + x]) allow |= 1u << r;
+    } else {
+#pragma unroll
+        for (int q = 0; q < (kMaxRadius + 64) / 64; q++)
+            if (lane + 64 * q <= T.radius) s_hw[lane + 64 * q] = T.hw[lane + 64 * q];
+        __syncthreads();
+        uint32_t covered = 0;
         const int n = A.n_centers[b];
-        for (int i = tid; i < n; i += 256) {
-            const int2 c = A.centers[(size_t)b * A.cap + i];
-            if (c.x + T.radius < bx || c.x - T.radius >= bx + kDT_W || c.y + T.radius < by || c.y - T.radius >= by + kDT_H) continue;
-            const int l0 = max(0, c.y - T.radius - by), l1 = min(kDT_H - 1, c.y + T.radius - by);
-            for (int ly = l0; ly <= l1; ly++) {
-                const int hw = s_hw[abs(by + ly - c.y)];
-                const int x0 = max(c.x - hw, bx) - bx, x1 = min(c.x + hw, bx + kDT_W - 1) - bx;
-                if (x0 > x1) continue;
-                const int len = x1 - x0 + 1;
-                const unsigned long long bits = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << x0;
-                atomicOr(&rowmask[ly], bits);
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            int2 c = make_int2(-(1 << 20), -(1 << 20));
+            if (i0 + lane < n) c = A.centers[(size_t)b * A.cap + i0 + lane];
+            const bool hit = c.x + T.radius >= X0 && c.x - T.radius < X0 + kDS_W && c.y + T.radius >= Y0 && c.y - T.radius < Y0 + R;
+            unsigned long long hb = __ballot(hit);
+            while (hb) {
+                const int j = __builtin_ctzll(hb);
+                hb &= hb - 1;
+                const int cx = __builtin_amdgcn_readlane(c.x, j), cy = __builtin_amdgcn_readlane(c.y, j);
+                const int dx = abs(x - cx);
+                if (dx <= T.radius) {
+                    const int k = s_hw[dx];
+                    const int lo = max(cy - k - Y0, 0), hi = min(cy + k - Y0, R - 1);
+                    if (lo <= hi) covered |= (hi - lo >= 31 ? ~0u : ((1u << (hi - lo + 1)) - 1u)) << lo;
+                }
             }
         }
-        __syncthreads();
+        if (col_out) allow = ~covered & rows_all;
     }
-    unsigned allow_bits = 0;
-    {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int li = tid + q * 256;
-            const int ly = li / kDT_W, lx = li - ly * kDT_W;
-            const int x = bx + lx, y = by + ly;
-            if (x >= g.w || y >= g.h) continue;
-            bool allowed;
-            if (A.mask) allowed = A.mask[b * A.mask_seq_stride + (size_t)y * g.w + x] != 0;
-            else allowed = !((rowmask[ly] >> lx) & 1ull);
-            if (allowed) allow_bits |= 1u << q;
-        }
-        if (!__syncthreads_or(allow_bits != 0)) return;
-    }
+    if (!__ballot(allow != 0)) return;   // nothing of this strip may hold a corner: no contribution to the masked maximum, no candidate
+
     const uint8_t* img = A.pyr + b * A.pyr_seq_stride + g.img_off;
     const float f1 = (float)(1.0 * (1.0 / (4.0 * 3.0 * 255.0))), f0 = (float)(2.0 * (1.0 / (4.0 * 3.0 * 255.0)));
-    // stage 1: the image patch behind the tile, rows by-3 .. by+18, bytes bx-4 .. bx+67, as dwords.  The pyramid level carries a
-    // REFLECT_101 border of kPad pixels (pyr_level0_kernel), so rows / columns just outside the image are plain reads.
+    // every raw row of the strip in flight at once: bytes x - 1 .. x + 2 of rows Y0 - 3 ..; columns / rows past the ones an output needs are clamped into the border
+    uint32_t raw[NS];
     {
-        const bool al = !((g.img_off | g.stride | (int)(A.pyr_seq_stride & 3)) & 3);
-        for (int t = tid; t < (kDT_H + 6) * kRawQ; t += 256) {
-            const int ry = t / kRawQ, rq = t - ry * kRawQ;
-            const int y = by - 3 + ry, x = bx - 4 + 4 * rq;
-            uint32_t v = 0;
-            if (x + 3 < g.w + kPad) {      // y <= h + 17 and x >= -4 always lie inside the border
-                const uint8_t* p = img + (ptrdiff_t)y * g.stride + x;
-                if (al) v = *reinterpret_cast<const uint32_t*>(p);
-                else v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-            }
-            raw[ry][rq] = v;
+        const int xl = min(x, g.w + 1) - 1;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const int y = min(Y0 - 3 + s, g.h + 1);
+            raw[s] = *reinterpret_cast<const u32_unaligned*>(img + (ptrdiff_t)y * g.stride + xl);
         }
     }
-    __syncthreads();
-    // stage 2: Sobel products of the in-image pixels of the tile + 2 halo; one item = four consecutive pixels of one row (six dword reads)
-    for (int t = tid; t < (kDT_H + 4) * ((kDT_W + 4) / 4); t += 256) {
-        const int ty = t / ((kDT_W + 4) / 4), gq = t - ty * ((kDT_W + 4) / 4);
-        const int y = by - 2 + ty;
-        if (y < 0 || y >= g.h) continue;
-        const uint32_t al_ = raw[ty][gq], ah_ = raw[ty][gq + 1], ml_ = raw[ty + 1][gq], mh_ = raw[ty + 1][gq + 1], cl_ = raw[ty + 2][gq], ch_ = raw[ty + 2][gq + 1];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int tx = 4 * gq + k, x = bx - 2 + tx;
-            if (x < 0 || x >= g.w) continue;
-            // pixel x sits at byte 4 gq + k + 2 of the raw row
-            const int a0 = byte8(al_, ah_, k + 1), a1 = byte8(al_, ah_, k + 2), a2 = byte8(al_, ah_, k + 3);
-            const int m0 = byte8(ml_, mh_, k + 1), m2 = byte8(ml_, mh_, k + 3);
-            const int c0 = byte8(cl_, ch_, k + 1), c1 = byte8(cl_, ch_, k + 2), c2 = byte8(cl_, ch_, k + 3);
-            const float t0 = (float)(a2 - a0), t1 = (float)(m2 - m0), t2 = (float)(c2 - c0);
-            const float dx = (t0 + t2) * f1 + t1 * f0;
-            float rt = f1 * (float)a0; rt += f0 * (float)a1; rt += f1 * (float)a2;
-            float rb = f1 * (float)c0; rb += f0 * (float)c1; rb += f1 * (float)c2;
-            const float dy = rb - rt;
-            cxx[ty][tx] = dx * dx; cxy[ty][tx] = dx * dy; cyy[ty][tx] = dy * dy;
-        }
-    }
-    // the box filter's own border (BORDER_REFLECT_101 on the product images): entries one or two pixels outside the image take the value
-    // of their mirror pixel, which lies in this tile.  Only tiles on the image border have such entries.
-    if (bx < 2 || by < 2 || bx + kDT_W + 2 > g.w || by + kDT_H + 2 > g.h) {
-        __syncthreads();
-        for (int t = tid; t < (kDT_W + 4) * (kDT_H + 4); t += 256) {
-            const int ty = t / (kDT_W + 4), tx = t - ty * (kDT_W + 4);
-            const int x = bx - 2 + tx, y = by - 2 + ty;
-            if ((x >= 0 && x < g.w && y >= 0 && y < g.h) || x < -2 || x > g.w + 1 || y < -2 || y > g.h + 1) continue;
-            const int sx = reflect101(x, g.w) - (bx - 2), sy = reflect101(y, g.h) - (by - 2);
-            if (sx < 0 || sx >= kDT_W + 4 || sy < 0 || sy >= kDT_H + 4) continue;   // images narrower than the reflection reach: entry is never consulted
-            cxx[ty][tx] = cxx[sy][sx]; cxy[ty][tx] = cxy[sy][sx]; cyy[ty][tx] = cyy[sy][sx];
-        }
-    }
-    __syncthreads();
-    // stage 3: 3x3 box sums and the smaller eigenvalue on the tile + 1 halo.  One item = 2 columns x 3 rows: row sums of three columns are
-    // shared between the two columns and between the rows.  Sums run in double as in cv::boxFilter (ColumnSum<double, float>); nine float
-    // products spanning < 2^52 add exactly, so the order of additions is free.  Halo entries outside the image are never consulted below.
-    for (int t = tid; t < ((kDT_W + 2) / 2) * ((kDT_H + 2) / 3); t += 256) {
-        const int sg = t / ((kDT_W + 2) / 2), tx = 2 * (t - sg * ((kDT_W + 2) / 2)), ty0 = 3 * sg;
-        double ha[5][2], hb[5][2], hc[5][2];
-#pragma unroll
-        for (int rr = 0; rr < 5; rr++) {
-            const float* pa = &cxx[ty0 + rr][tx]; const float* pb = &cxy[ty0 + rr][tx]; const float* pc = &cyy[ty0 + rr][tx];
-            const double a1 = (double)pa[1] + (double)pa[2], b1 = (double)pb[1] + (double)pb[2], c1 = (double)pc[1] + (double)pc[2];
-            ha[rr][0] = (double)pa[0] + a1; ha[rr][1] = a1 + (double)pa[3];
-            hb[rr][0] = (double)pb[0] + b1; hb[rr][1] = b1 + (double)pb[3];
-            hc[rr][0] = (double)pc[0] + c1; hc[rr][1] = c1 + (double)pc[3];
-        }
-#pragma unroll
-        for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-            for (int cc = 0; cc < 2; cc++) {
-                const double sa = ha[rr][cc] + ha[rr + 1][cc] + ha[rr + 2][cc], sb = hb[rr][cc] + hb[rr + 1][cc] + hb[rr + 2][cc],
-                             sc = hc[rr][cc] + hc[rr + 1][cc] + hc[rr + 2][cc];
-                const float a = (float)sa * 0.5f, bb = (float)sb, c = (float)sc * 0.5f;
-                eg[ty0 + rr][tx + cc] = (a + c) - sqrtf((a - c) * (a - c) + bb * bb);
-            }
-    }
-    __syncthreads();
+    // the box filter's own border (BORDER_REFLECT_101 on the product images): column -1 takes the products of column 1, column w those of column w - 2
+    const bool fix_h = X0 == 0 || X0 - 2 + 63 >= g.w;
+    int fix_src = lane;
+    if (x == -1) fix_src = lane + (g.w > 1 ? 2 : 1);
+    if (x == g.w) fix_src = lane - (g.w > 1 ? 2 : 1);
+    const bool fix_v = Y0 == 0 || Y0 + R >= g.h;
+
+    float hd[3] = {0.f, 0.f, 0.f}, hm[3] = {0.f, 0.f, 0.f};                      // per raw row: (float)(p[x+1] - p[x-1]) and the [f1 f0 f1] row sum
+    double hxx[3] = {0, 0, 0}, hxy[3] = {0, 0, 0}, hyy[3] = {0, 0, 0};           // horizontal 3-sums of the product rows
+    float er[3] = {0.f, 0.f, 0.f}, em[3] = {0.f, 0.f, 0.f};                      // eigenvalue rows and their horizontal 3-maxima
     unsigned best = 0;
+    int n_cand = 0;   // uniform
+    unsigned long long* const cand_b = A.cand + b * A.cand_seq_stride;
+    int* const count_b = A.cand_count + b;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int li = tid + q * 256;
-        const int ly = li / kDT_W, lx = li - ly * kDT_W;
-        const int x = bx + lx, y = by + ly;
-        if (x >= g.w || y >= g.h) continue;
-        if (!((allow_bits >> q) & 1u)) continue;
-        const float v = eg[ly + 1][lx + 1];
-        best = max(best, f32_orderable(v));
-        if (x < 1 || y < 1 || x >= g.w - 1 || y >= g.h - 1 || v == 0.f) continue;
-        const bool ismax = v >= eg[ly][lx] && v >= eg[ly][lx + 1] && v >= eg[ly][lx + 2] && v >= eg[ly + 1][lx] && v >= eg[ly + 1][lx + 2] &&
-                           v >= eg[ly + 2][lx] && v >= eg[ly + 2][lx + 1] && v >= eg[ly + 2][lx + 2];
-        if (ismax) {
-            const unsigned long long key = ((unsigned long long)f32_orderable(v) << 32) | (unsigned)(y * g.w + x);
-            const int k = atomicAdd(&n_cand, 1);
-            if (k < kCK) ckeys[k] = key;
-            else {   // plateau-ridden tile: straight to the sequence's list (the order of candidates is settled by the sort that follows)
-                const int slot = atomicAdd(A.cand_count + b, 1);
-                if (slot < A.cand_cap) A.cand[b * A.cand_seq_stride + slot] = key;
+    for (int s = 0; s < NS; s++) {
+        {   // raw row s
+            const uint32_t v = raw[s];
+            const float p0 = (float)(v & 0xffu), p1 = (float)((v >> 8) & 0xffu), p2 = (float)((v >> 16) & 0xffu);
+            hd[s % 3] = p2 - p0;
+            float t = f1 * p0; t += f0 * p1; t += f1 * p2;
+            hm[s % 3] = t;
+        }
+        if (s >= 2) {   // products of row s - 1 and their horizontal sums
+            const float t0 = hd[(s + 1) % 3], t1 = hd[(s + 2) % 3], t2 = hd[s % 3];
+            const float dx = (t0 + t2) * f1 + t1 * f0;
+            const float dy = hm[s % 3] - hm[(s + 1) % 3];
+            float pxx = dx * dx, pxy = dx * dy, pyy = dy * dy;
+            if (fix_h) { pxx = __shfl(pxx, fix_src); pxy = __shfl(pxy, fix_src); pyy = __shfl(pyy, fix_src); }
+            hxx[(s + 2) % 3] = (double)dpp_from_left(pxx) + ((double)pxx + (double)dpp_from_right(pxx));
+            hxy[(s + 2) % 3] = (double)dpp_from_left(pxy) + ((double)pxy + (double)dpp_from_right(pxy));
+            hyy[(s + 2) % 3] = (double)dpp_from_left(pyy) + ((double)pyy + (double)dpp_from_right(pyy));
+        }
+        if (s >= 4) {   // eigenvalues of row s - 2 from the product rows s - 3, s - 2, s - 1
+            int it = s % 3, ib = (s + 2) % 3;
+            const int im = (s + 1) % 3;
+            double txx = hxx[it], txy = hxy[it], tyy = hyy[it], bxx = hxx[ib], bxy = hxy[ib], byy = hyy[ib];
+            const int ey = Y0 - 3 + s - 2;
+            if (fix_v && (ey == 0 || ey == g.h - 1)) {   // rows -1 and h of the product images mirror rows 1 and h - 2 (a real branch: two rows of the image take it)
+                asm volatile("" ::: "memory");
+                if (ey == 0) { if (g.h > 1) { txx = bxx; txy = bxy; tyy = byy; } else { txx = hxx[im]; txy = hxy[im]; tyy = hyy[im]; } }
+                if (ey == g.h - 1) { if (g.h > 1) { bxx = txx; bxy = txy; byy = tyy; } else { bxx = hxx[im]; bxy = hxy[im]; byy = hyy[im]; } }
+            }
+            const double sa = txx + hxx[im] + bxx, sb = txy + hxy[im] + bxy, sc = tyy + hyy[im] + byy;
+            const float a = (float)sa * 0.5f, bb = (float)sb, c = (float)sc * 0.5f;
+            const float e = (a + c) - sqrtf((a - c) * (a - c) + bb * bb);
+            er[im] = e;
+            em[im] = fmaxf(e, fmaxf(dpp_from_left(e), dpp_from_right(e)));
+        }
+        if (s >= 6) {   // row s - 3 = Y0 + r: masked maximum and 3 x 3 local maxima
+            const int r = s - 6;
+            if (r < nrows) {
+                const int y = Y0 + r;
+                const float v = er[s % 3];
+                const bool allowed = (allow >> r) & 1u;
+                if (allowed) best = max(best, f32_orderable(v));
+                const float around = fmaxf(fmaxf(em[(s + 2) % 3], em[(s + 1) % 3]), fmaxf(dpp_from_left(v), dpp_from_right(v)));
+                const bool is_cand = allowed && x >= 1 && x < g.w - 1 && y >= 1 && y < g.h - 1 && v != 0.f && v >= around;
+                const unsigned long long cb = __ballot(is_cand);
+                if (cb) {
+                    if (n_cand > kCap - 64) { strip_flush(cand_b, count_b, A.cand_cap, ckeys, n_cand, lane); n_cand = 0; }
+                    if (is_cand) ckeys[n_cand + __builtin_amdgcn_mbcnt_hi((unsigned)(cb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cb, 0u))] =
+                        ((unsigned long long)f32_orderable(v) << 32) | (unsigned)(y * g.w + x);
+                    n_cand += __builtin_popcountll(cb);
+                }
             }
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o));
-    if ((tid & 63) == 0 && best) atomicMax(&blk_max, best);
-    __syncthreads();
-    if (tid == 0) {
-        if (blk_max) atomicMax(A.maxkey + b, blk_max);
-        n_cand = min(n_cand, kCK);
-        cand_base = n_cand ? atomicAdd(A.cand_count + b, n_cand) : 0;
-    }
-    __syncthreads();
-    for (int k = tid; k < n_cand; k += 256)
-        if (cand_base + k < A.cand_cap) A.cand[b * A.cand_seq_stride + cand_base + k] = ckeys[k];
+    if (lane == 0 && best) atomicMax(A.maxkey + b, best);
+    if (n_cand) strip_flush(cand_b, count_b, A.cand_cap, ckeys, n_cand, lane);
 }
 
 struct SelectArgs {

@@ -36,6 +36,7 @@
 #include <linux/futex.h>
 #include <sys/syscall.h>
 #include <unistd.h>
+#include <ucontext.h>
 
 #include "../../include/groundfusion_hip.h"
 #include "gf_dmath.hpp"
@@ -433,6 +434,18 @@ struct Gate {
     void bump() { gen.fetch_add(1, std::memory_order_acq_rel); syscall(SYS_futex, reinterpret_cast<int*>(&gen), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0); }
 };
 
+// Members of a group run as user-level contexts (fibers) on a pool of worker threads: a member that has to wait for a batch hands its thread to the next
+// member of the same thread instead of putting an operating-system thread to sleep.  The pool has as many threads as the caller allows (GF_GROUP_THREADS; default
+// min(members, hardware threads)): 8 ranks x 256 members on one node are 8 x cores/8 threads, not 2 048.  A fiber always runs on the thread that owns it.
+struct Fiber {
+    ucontext_t ctx;
+    std::unique_ptr<char[]> stack;
+    int state = 0;   // 0 idle, 1 running / runnable, 2 waiting for a batch, 3 frame finished
+};
+static thread_local ucontext_t* tl_sched = nullptr;   // the worker's scheduler context while a fiber runs
+static thread_local Fiber* tl_fiber = nullptr;
+static inline void fiber_yield() { Fiber* f = tl_fiber; f->state = 2; swapcontext(&f->ctx, tl_sched); }
+
 struct BatchSolver {
     struct Req { int kind; gf_ba_window* w; int iters, mode; gf_ba_summary* sum; gf_ba_prior* prior; int rc; std::atomic<bool> done; std::string err;
                  std::vector<ImuPre*> pres; const double* noise; int slot = -1; };   // kind 0 solve, 1 marginalise, 2 IMU pre-integrations of this frame
@@ -459,7 +472,8 @@ struct BatchSolver {
         for (;;) {
             const int seen = finished.now();
             if (r.done.load(std::memory_order_acquire)) break;
-            finished.wait_while(seen);
+            if (tl_fiber) fiber_yield();   // the worker's scheduler resumes this member when a batch has been closed (or just to look again)
+            else finished.wait_while(seen);
         }
         if (r.rc != GF_OK) gf::set_err(r.rc, "%s", r.err.c_str());   // the batch may have run on another thread: carry its message over
         return r.rc;
@@ -1992,24 +2006,61 @@ struct gf_estimator_group {
     std::vector<int> rcs;
     std::vector<std::string> errs;
 
-    void worker(int i) {
+    int n_threads = 1;
+    std::vector<Fiber> fib;
+    static constexpr size_t kFiberStack = 1u << 20;   // per member; pages are touched on use only
+
+    void run_frame(int i) {   // one member's frame (inside its fiber)
+        mem[i]->t_mark = gf_estimator::cpu_now();
+        const int rc = gf_estimator_input_feature(mem[i], t[i], frame_ptr[i], frame_n[i]);   // the caller's buffer: input_features does not return before this is done
+        mem[i]->lap(5);
+        rcs[i] = rc;
+        if (rc != GF_OK) errs[i] = gf_last_error();
+        solver.leave();
+        if (remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) all_done.bump();
+    }
+    static void fiber_entry(unsigned lo, unsigned hi, int i) {
+        gf_estimator_group* g = reinterpret_cast<gf_estimator_group*>(((uintptr_t)hi << 32) | (uintptr_t)lo);
+        g->run_frame(i);
+        g->fib[i].state = 3;   // returning switches to uc_link = the worker's scheduler context
+    }
+    void worker(int w) {   // worker w owns the members w, w + n_threads, ...
         (void)hipSetDevice(device);   // the device is a per-thread setting; whichever member closes a rendezvous launches the batch
+        ucontext_t sched;
+        std::vector<int> mine;
         int seen = 0;   // go starts at generation 0 and is only bumped by input_features / the destructor
         for (;;) {
             while (go.now() == seen && !stop.load(std::memory_order_acquire)) go.wait_while(seen);
             if (stop.load(std::memory_order_acquire)) return;
             seen = go.now();   // one step at a time: input_features does not return before every listed member is done
             // The work list is published per generation: job_gen[i] == seen means "member i is listed in the step this thread just woke for" and, by the
-            // release / acquire pair on it, that t[i] / frames[i] are completely written.  A thread that was not listed in step k and only gets here while
-            // step k + 1 is being set up sees job_gen[i] == k + 1 != seen, goes round the loop, picks up generation k + 1 and runs its frame exactly once.
-            if (job_gen[i].load(std::memory_order_acquire) != seen) continue;
-            mem[i]->t_mark = gf_estimator::cpu_now();
-            const int rc = gf_estimator_input_feature(mem[i], t[i], frame_ptr[i], frame_n[i]);   // the caller's buffer: input_features does not return before this is done
-            mem[i]->lap(5);
-            rcs[i] = rc;
-            if (rc != GF_OK) errs[i] = gf_last_error();
-            solver.leave();
-            if (remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) all_done.bump();
+            // release / acquire pair on it, that t[i] / frame_ptr[i] are completely written.  A thread that only gets here while step k + 1 is being set up
+            // sees job_gen[i] == k + 1 != seen for its members, goes round the loop, picks up generation k + 1 and runs every frame exactly once.
+            mine.clear();
+            for (int i = w; i < (int)mem.size(); i += n_threads) if (job_gen[i].load(std::memory_order_acquire) == seen) mine.push_back(i);
+            for (int i : mine) {
+                Fiber& f = fib[i];
+                if (!f.stack) f.stack.reset(new char[kFiberStack]);
+                getcontext(&f.ctx);
+                f.ctx.uc_stack.ss_sp = f.stack.get(); f.ctx.uc_stack.ss_size = kFiberStack; f.ctx.uc_link = &sched;
+                const uintptr_t self = reinterpret_cast<uintptr_t>(this);
+                makecontext(&f.ctx, reinterpret_cast<void (*)()>(&gf_estimator_group::fiber_entry), 3, (unsigned)(self & 0xffffffffu), (unsigned)(self >> 32), i);
+                f.state = 1;
+            }
+            size_t left = mine.size();
+            while (left) {
+                const int fin_seen = solver.finished.now();   // before the scan: a batch closed during the scan must not be slept through
+                bool all_waiting = true;
+                for (int i : mine) {
+                    Fiber& f = fib[i];
+                    if (f.state == 3) continue;
+                    tl_sched = &sched; tl_fiber = &f; f.state = 1;
+                    swapcontext(&sched, &f.ctx);
+                    tl_fiber = nullptr;
+                    if (f.state == 3) { left--; all_waiting = false; }
+                }
+                if (left && all_waiting) solver.finished.wait_while(fin_seen);   // every member of this thread waits for a batch somebody else will close
+            }
         }
     }
     ~gf_estimator_group() {
@@ -2040,7 +2091,13 @@ int gf_estimator_group_create(const gf_estimator_cfg* c, int n, gf_estimator_gro
     if (const char* e = getenv("GF_GROUP_DEVICE_PREINT")) if (atoi(e) != 0) if (int rc = gf::preint_batch_create(&g->solver.pre)) { delete g; return rc; }
     g->job_gen.reset(new std::atomic<int>[n]); for (int i = 0; i < n; i++) g->job_gen[i].store(0, std::memory_order_relaxed);
     g->t.assign(n, 0.0); g->frame_ptr.assign(n, nullptr); g->frame_n.assign(n, 0); g->rcs.assign(n, GF_OK); g->errs.resize(n);
-    for (int i = 0; i < n; i++) g->thr.emplace_back([g, i] { g->worker(i); });
+    {
+        int nt = std::min(n, std::max(1, (int)std::thread::hardware_concurrency()));
+        if (const char* e = getenv("GF_GROUP_THREADS")) if (atoi(e) > 0) nt = std::min(n, atoi(e));
+        g->n_threads = nt;
+        g->fib.resize(n);
+        for (int w = 0; w < nt; w++) g->thr.emplace_back([g, w] { g->worker(w); });
+    }
     *out = g;
     return GF_OK;
 }

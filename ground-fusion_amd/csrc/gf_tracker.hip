@@ -480,7 +480,7 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
             D.pyr = h->d_img.p + (size_t)h->cur_slot * h->G.img_bytes; D.pyr_seq_stride = 2 * h->G.img_bytes; D.g = h->G.lv[0];
             D.mask = nullptr; D.mask_seq_stride = 0; D.centers = h->d_centers.p; D.n_centers = h->d_ncenters.p; D.cap = cap; D.want = h->d_want.p;
             D.maxkey = h->d_maxkey.p; D.cand = h->d_cand.p; D.cand_seq_stride = (size_t)h->cand_cap; D.cand_cap = h->cand_cap; D.cand_count = h->d_cand_count.p;
-            detect_fused_kernel<<<dim3((W + kDT_W - 1) / kDT_W, (H + kDT_H - 1) / kDT_H, B), 256, 0, h->stream>>>(D, h->disk);
+            detect_strip_kernel<kDS_R><<<dim3((W + kDS_W - 1) / kDS_W, (H + kDS_R - 1) / kDS_R, B), 64, 0, h->stream>>>(D, h->disk);
         }
         SelectArgs S{};
         S.cand = h->d_cand.p; S.cand_seq_stride = (size_t)h->cand_cap; S.cand_cap = h->cand_cap; S.cand_count = h->d_cand_count.p; S.maxkey = h->d_maxkey.p; S.want = h->d_want.p;
@@ -825,7 +825,7 @@ int gf_good_features(const uint8_t* img, int width, int height, const uint8_t* m
             D.pyr = h->d_img.p; D.pyr_seq_stride = 2 * h->G.img_bytes; D.g = h->G.lv[0];
             D.mask = h->d_mask.p; D.mask_seq_stride = h->mask_stride; D.centers = nullptr; D.n_centers = nullptr; D.cap = h->cap; D.want = h->d_want.p;
             D.maxkey = h->d_maxkey.p; D.cand = h->d_cand.p; D.cand_seq_stride = (size_t)h->cand_cap; D.cand_cap = h->cand_cap; D.cand_count = h->d_cand_count.p;
-            gf::detect_fused_kernel<<<dim3((W + gf::kDT_W - 1) / gf::kDT_W, (H + gf::kDT_H - 1) / gf::kDT_H, 1), 256, 0, h->stream>>>(D, h->disk);
+            gf::detect_strip_kernel<gf::kDS_R><<<dim3((W + gf::kDS_W - 1) / gf::kDS_W, (H + gf::kDS_R - 1) / gf::kDS_R, 1), 64, 0, h->stream>>>(D, h->disk);
         }
         gf::SelectArgs S{};
         S.cand = h->d_cand.p; S.cand_seq_stride = (size_t)h->cand_cap; S.cand_cap = h->cand_cap; S.cand_count = h->d_cand_count.p; S.maxkey = h->d_maxkey.p; S.want = h->d_want.p;
