@@ -628,7 +628,13 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     if (misc_win_lds_doubles(d.W) * sizeof(double) + 10 * 1024 > 160 * 1024) { delete h; return gf::set_err(GF_ERR_INVALID, "window_size %d: the IMU / wheel block rows exceed LDS (window_size <= 20 in this build)", d.W); }
 #define A_(x) do { if (int rc_ = (x)) { h->release(); delete h; return rc_; } } while (0)
 #define H_(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { gf::set_err(GF_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); h->release(); delete h; return GF_ERR_HIP; } } while (0)
-    H_(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    {   // the solver is a chain of short launches that each want every CU: its queue goes first when the tracker's kernels of the same process compete for them
+        int least = 0, greatest = 0;
+        H_(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const char* e = getenv("GF_BA_STREAM_PRIORITY");
+        const int prio = (e && !strcmp(e, "default")) ? least + (greatest - least) / 2 : greatest;
+        H_(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio));
+    }
     for (auto& e : h->ev) H_(hipEventCreate(&e));
     const size_t B = d.B, VS = d.RP + d.FP;
     A_(h->xs0.alloc(B * d.XS, true)); A_(h->xs.alloc(2 * B * d.XS, true));

@@ -506,9 +506,10 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
         HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[5])); h->stats.ms_total_gpu += ms;
     }
     if (any_want)
-        for (int b = 0; b < B; b++)
+        for (int b = 0; b < B; b++) {
             if (h->h_want.p[b] > 0 && h->h_cand_count.p[b] > h->cand_cap)
                 return set_err(GF_ERR_CAPACITY, "sequence %d: %d corner candidates exceed capacity %d", b, h->h_cand_count.p[b], h->cand_cap);
+        }
 
     // ---- addPoints, undistortedPts, ptsVelocity, pack (feature_tracker.cpp:85-93, 210-211, 322-368)
     std::atomic<int> a_overflow{-1};
