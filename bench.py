@@ -257,9 +257,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # host bookkeeping threads of the tracker (default 4 per process): keep all ranks of the node within its cores
+    # host bookkeeping threads of the tracker (up to 16 per process): keep all ranks of the node within its cores (the estimator group takes the same share)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    os.environ.setdefault("GF_HOST_THREADS", str(max(1, min(4, (os.cpu_count() or 4) // max(local_world, 1)))))
+    os.environ.setdefault("GF_HOST_THREADS", str(max(1, min(16, (os.cpu_count() or 4) // (2 * max(local_world, 1))))))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the HIP path has no CPU fallback)")
     # GF_BENCH_SINGLE_DEVICE=1 (tests only): every rank on device 0 with the gloo backend, to run the N > 1 path on a one-GPU box
