@@ -298,6 +298,8 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     __syncthreads();
     int rank = n;
     const int tx = tid & 31, ty = tid >> 5;   // 32 x 16 thread grid of the trailing update
+    constexpr int kPB = 8;                    // pivots per block
+    int kb = 0;                               // first pivot of the open block
     for (int k = 0; k < n; k++) {
         // pivot: largest remaining diagonal entry, the lowest lane that holds it on ties (every wavefront computes the same answer)
         double best = -1.0; int bi = k;
@@ -316,16 +318,15 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
         const int p = __builtin_amdgcn_readlane(bi, __ffsll((long long)hit) - 1);
         if (!(piv > eps)) { rank = k; break; }
         if (p != k) {   // symmetric swap k <-> p of the full matrix in one pass: thread t moves the four entries that involve t; the 2 x 2 corner by thread 0
+            // (every load of a thread before its first store: the compiler cannot tell the LDS arrays apart and would wait for each store before the next load)
             for (int t = tid; t < n; t += 512) {
                 if (t == k || t == p) continue;
-                const double a0 = A[k * n + t], a1 = A[p * n + t]; A[k * n + t] = a1; A[p * n + t] = a0;
-                const double b0 = A[t * n + k], b1 = A[t * n + p]; A[t * n + k] = b1; A[t * n + p] = b0;
+                const double a0 = A[k * n + t], a1 = A[p * n + t], b0 = A[t * n + k], b1 = A[t * n + p];
+                A[k * n + t] = a1; A[p * n + t] = a0; A[t * n + k] = b1; A[t * n + p] = b0;
             }
-            if (tid == 0) {
-                const double dk = A[k * n + k]; A[k * n + k] = A[p * n + p]; A[p * n + p] = dk;   // A[k][p] == A[p][k] stay where they are
-                const int tp = perm[k]; perm[k] = perm[p]; perm[p] = tp;
-                const double tz = zb[k]; zb[k] = zb[p]; zb[p] = tz;
-            }
+            if (tid == 64) { const double dk = A[k * n + k], dp = A[p * n + p]; A[k * n + k] = dp; A[p * n + p] = dk; }   // A[k][p] == A[p][k] stay where they are
+            if (tid == 128) { const int tk = perm[k], tp = perm[p]; perm[k] = tp; perm[p] = tk; }
+            if (tid == 192) { const double zk = zb[k], zp = zb[p]; zb[k] = zp; zb[p] = zk; }
             __syncthreads();
         }
 #ifdef GF_MARG_IEEE_SQRT   // conditioning experiments (scripts/gnss_replay_sensitivity.py): the arithmetically equivalent, correctly rounded variant
@@ -342,16 +343,71 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
             dinv = __builtin_fma(0.5 * dinv, e, dinv);
         }
 #endif
+        // Left-looking inside blocks of kPB pivots: row k still lacks the updates of the pivots kb .. k - 1 of its block (rows kb .. k - 1 hold their finished,
+        // scaled columns of L), so one thread per entry applies them now, in pivot order -- the same fma chain, entry by entry, as a trailing update after every
+        // pivot -- and the trailing matrix is touched once per block instead of once per pivot (3.3 k -> 2.9 k cycles per pivot at n = 86: search 0.65 k, swap 0.65 k,
+        // this column 1.0 k, the block's update 3.1 k / 8; what is left are LDS round trips and two barriers per pivot).
         const double rk = zb[k] * dinv;
-        const double* rowk = A + (size_t)k * n;   // = column k (symmetric; rows > k are what the update below writes, row k is final)
-        for (int i = k + 1 + ty; i < n; i += 16) {
-            const double li = rowk[i] * dinv;
-            double* row = A + (size_t)i * n;
-            for (int j = k + 1 + tx; j < n; j += 32) { const double nv = __builtin_fma(-li, rowk[j] * dinv, row[j]); row[j] = nv; if (j == i) dgn[i] = nv; }
+        double* rowk = A + (size_t)k * n;        // = column k (symmetric); becomes column k of L, scaled
+        for (int i = k + 1 + tid; i < n; i += 512) {
+            double acc = rowk[i];
+            double lc[kPB - 1], lk[kPB - 1];
+#pragma unroll
+            for (int q = 0; q < kPB - 1; q++) {   // all loads in flight at once (rows past the open block: row k - 1 again, weighted with zero: fma(-x, 0, acc) == acc)
+                const int c = min(kb + q, k - 1 < kb ? kb : k - 1);
+                lc[q] = A[(size_t)c * n + i];
+                const double v = A[(size_t)c * n + k];
+                lk[q] = kb + q < k ? v : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < kPB - 1; q++) acc = __builtin_fma(-lc[q], lk[q], acc);
+            const double li = acc * dinv;
+            rowk[i] = li;
+            dgn[i] = __builtin_fma(-li, li, dgo[i == p ? k : i]);   // the diagonal copy is not swapped (slower wavefronts may still search it): position p holds old row k
+            zb[i] = __builtin_fma(-li, rk, zb[i]);
         }
-        for (int i = k + 1 + tid; i < n; i += 512) zb[i] = __builtin_fma(-(rowk[i] * dinv), rk, zb[i]);
         if (tid == 0) { dinvs[k] = dinv; zr[k] = rk; }
         __syncthreads();
+        if (k + 1 - kb == kPB || k + 1 == n) {   // close the block: A[i][j] -= sum_c L[i][c] L[j][c], c in pivot order, 2 x 4 entries per thread
+            const int k1 = k + 1;
+            // thread (tx, ty) owns rows i0 + 16 a and columns j0 + 32 q: the lanes of a wavefront read consecutive doubles (4 consecutive columns per lane cost 4-way bank conflicts)
+            // One path for every tile: rows / columns past the matrix are clamped for the loads and skipped by the stores, columns of L past a short last block
+            // weigh zero (fma(-x, 0, v) == v) -- a branch around the edge tiles would put every wavefront through both versions.
+            for (int i0 = k1 + ty; i0 < n; i0 += 64)
+                for (int j0 = k1 + tx; j0 < n; j0 += 64) {
+                    double v[4][2], li[kPB][4], lj[kPB][2];
+                    int ia[4], jq[2];
+#pragma unroll
+                    for (int a = 0; a < 4; a++) ia[a] = min(i0 + 16 * a, n - 1);
+#pragma unroll
+                    for (int q = 0; q < 2; q++) jq[q] = min(j0 + 32 * q, n - 1);
+#pragma unroll
+                    for (int c = 0; c < kPB; c++) {
+                        const bool on = kb + c < k1;
+                        const double* lc = A + (size_t)min(kb + c, k1 - 1) * n;
+#pragma unroll
+                        for (int a = 0; a < 4; a++) li[c][a] = lc[ia[a]];
+#pragma unroll
+                        for (int q = 0; q < 2; q++) { const double t = lc[jq[q]]; lj[c][q] = on ? t : 0.0; }
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int q = 0; q < 2; q++) v[a][q] = A[(size_t)ia[a] * n + jq[q]];
+#pragma unroll
+                    for (int c = 0; c < kPB; c++)
+#pragma unroll
+                        for (int a = 0; a < 4; a++)
+#pragma unroll
+                            for (int q = 0; q < 2; q++) v[a][q] = __builtin_fma(-li[c][a], lj[c][q], v[a][q]);
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int q = 0; q < 2; q++) if (i0 + 16 * a < n && j0 + 32 * q < n) A[(size_t)ia[a] * n + jq[q]] = v[a][q];
+                }
+            kb = k1;
+            __syncthreads();
+        }
     }
     GF_MST(5);
     double* J = out.J + (size_t)b * d.NPRI * d.NPRI;
@@ -359,7 +415,7 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     for (int i = tid; i < n * n; i += 512) {
         const int k = i / n, pos = i % n;   // J[k][perm[pos]] = L[pos][k] for pos >= k, k < rank (column k of A below the diagonal is still unscaled)
         double v = 0.0;
-        if (k < rank && pos >= k) v = pos == k ? 1.0 / dinvs[k] : A[k * n + pos] * dinvs[k];   // row k right of the diagonal = column k below it
+        if (k < rank && pos >= k) v = pos == k ? 1.0 / dinvs[k] : A[k * n + pos];   // row k right of the diagonal = column k of L
         J[(size_t)k * n + perm[pos]] = v;
     }
     for (int k = tid; k < n; k += 512) rr[k] = k < rank ? zr[k] : 0.0;
