@@ -43,9 +43,9 @@ lk.update({"points_per_launch": ppl, "algorithmic_bytes_per_launch": alg, "hbm_b
            "note": "PMC at %d sequences (%d points per launch), profiles/%s_pmc_tracker_fetch.csv / _write.csv: traffic = 2 x FETCH_SIZE + WRITE_SIZE (upper bound: whole 128-B lines; "
                    "lower bound FETCH_SIZE + WRITE_SIZE = %.0f B per point), scaled to this launch by points" % (B, ppl, tag, lk["hbm_bytes_lower"] / ppl)})
 S["lk_track_kernel"] = lk
-for k in ("gf::detect_strip_kernel", "gf::pyr_level0_kernel", "gf::pyr_down_pad4_kernel", "gf::pyr_down_tail_kernel", "gf::select_corners_kernel"):
+for k in ("gf::detect_strip_kernel<30>", "gf::pyr_level0_vec16_kernel", "gf::pyr_down_pad4_kernel", "gf::pyr_down_tail_kernel", "gf::select_corners_kernel"):
     if k in tf:
-        S[k.split("::")[1]] = traffic(k)
+        S[k.split("::")[1].split("<")[0]] = traffic(k)
 def sq(tab, k):
     d = {c: v[0] for c, v in tab[k].items()}
     d["duration_us_profiled"] = list(tab[k].values())[0][2] / 1e3
@@ -65,7 +65,7 @@ for k, name in (("gfb::ba_linearize_visual_win<false; 12>", "ba_linearize_visual
                       "hbm_GBps_lower": (f + wv) / (d["duration_us_profiled"] * 1e-6) / 1e9, "hbm_GBps_upper": (2 * f + wv) / (d["duration_us_profiled"] * 1e-6) / 1e9})
         d["note"] = "counter-derived MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (profiled kernel duration x 2.4 GHz x 1024 SIMDs), profiles/%s_pmc_backend_sq.csv" % tag
         S[name] = d
-for k, name in (("gf::lk_track_kernel", "lk_track_kernel_sq"), ("gf::detect_strip_kernel", "detect_strip_kernel_sq")):
+for k, name in (("gf::lk_track_kernel", "lk_track_kernel_sq"), ("gf::detect_strip_kernel<30>", "detect_strip_kernel_sq")):
     if k in tsq:
         S[name] = sq(tsq, k)
 json.dump(S, open(os.path.join(R, "profiles", "pmc_summary.json"), "w"), indent=1)
