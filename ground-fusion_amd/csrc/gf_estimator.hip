@@ -37,6 +37,7 @@
 #include <sys/syscall.h>
 #include <unistd.h>
 #include <ucontext.h>
+#include <sys/mman.h>
 
 #include "../../include/groundfusion_hip.h"
 #include "gf_dmath.hpp"
@@ -439,8 +440,21 @@ struct Gate {
 // min(members, hardware threads)): 8 ranks x 256 members on one node are 8 x cores/8 threads, not 2 048.  A fiber always runs on the thread that owns it.
 struct Fiber {
     ucontext_t ctx;
-    std::unique_ptr<char[]> stack;
-    int state = 0;   // 0 idle, 1 running / runnable, 2 waiting for a batch, 3 frame finished
+    char* stack = nullptr;   // mmap'ed: pages are touched on use only, the lowest page is a guard (an overflow faults instead of running into a neighbour)
+    int state = 0;           // 0 idle, 1 running / runnable, 2 waiting for a batch, 3 frame finished
+    static constexpr size_t kStack = 2u << 20, kGuard = 4096;
+    bool alloc() {
+        if (stack) return true;
+        void* p = mmap(nullptr, kStack + kGuard, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK | MAP_NORESERVE, -1, 0);
+        if (p == MAP_FAILED) return false;
+        (void)mprotect(p, kGuard, PROT_NONE);
+        stack = static_cast<char*>(p);
+        return true;
+    }
+    ~Fiber() { if (stack) munmap(stack, kStack + kGuard); }
+    Fiber() = default;
+    Fiber(const Fiber&) = delete;
+    Fiber& operator=(const Fiber&) = delete;
 };
 static thread_local ucontext_t* tl_sched = nullptr;   // the worker's scheduler context while a fiber runs
 static thread_local Fiber* tl_fiber = nullptr;
@@ -2007,8 +2021,7 @@ struct gf_estimator_group {
     std::vector<std::string> errs;
 
     int n_threads = 1;
-    std::vector<Fiber> fib;
-    static constexpr size_t kFiberStack = 1u << 20;   // per member; pages are touched on use only
+    std::unique_ptr<Fiber[]> fib;
 
     void run_frame(int i) {   // one member's frame (inside its fiber)
         mem[i]->t_mark = gf_estimator::cpu_now();
@@ -2040,9 +2053,8 @@ struct gf_estimator_group {
             for (int i = w; i < (int)mem.size(); i += n_threads) if (job_gen[i].load(std::memory_order_acquire) == seen) mine.push_back(i);
             for (int i : mine) {
                 Fiber& f = fib[i];
-                if (!f.stack) f.stack.reset(new char[kFiberStack]);
                 getcontext(&f.ctx);
-                f.ctx.uc_stack.ss_sp = f.stack.get(); f.ctx.uc_stack.ss_size = kFiberStack; f.ctx.uc_link = &sched;
+                f.ctx.uc_stack.ss_sp = f.stack + Fiber::kGuard; f.ctx.uc_stack.ss_size = Fiber::kStack; f.ctx.uc_link = &sched;
                 const uintptr_t self = reinterpret_cast<uintptr_t>(this);
                 makecontext(&f.ctx, reinterpret_cast<void (*)()>(&gf_estimator_group::fiber_entry), 3, (unsigned)(self & 0xffffffffu), (unsigned)(self >> 32), i);
                 f.state = 1;
@@ -2099,7 +2111,8 @@ int gf_estimator_group_create(const gf_estimator_cfg* c, int n, gf_estimator_gro
         int nt = std::min(n, std::max(1, (int)std::thread::hardware_concurrency() / (2 * share)));
         if (const char* e = getenv("GF_GROUP_THREADS")) if (atoi(e) > 0) nt = std::min(n, atoi(e));
         g->n_threads = nt;
-        g->fib.resize(n);
+        g->fib.reset(new Fiber[n]);
+        for (int i = 0; i < n; i++) if (!g->fib[i].alloc()) { delete g; return gf::set_err(GF_ERR_INVALID, "cannot map the stack of member %d", i); }
         for (int w = 0; w < nt; w++) g->thr.emplace_back([g, w] { g->worker(w); });
     }
     *out = g;

@@ -222,12 +222,16 @@ def test_replay_images_with_tracker_feedback():
     assert worst["p"] < 1e-6 and worst["r"] < 1e-6, worst
 
 
-@pytest.mark.parametrize("device_preint", [False, True])
-def test_group_of_sequences_on_one_batched_solver(device_preint):
+@pytest.mark.parametrize("device_preint,group_threads", [(False, None), (True, None), (False, 1), (False, 3), (True, 2)])
+def test_group_of_sequences_on_one_batched_solver(device_preint, group_threads, monkeypatch):
     """gf_estimator_group_*: four sequences keep the reference's per-sequence control flow on host threads while their solves and
     marginalisations reach the device as one batch; every member must end up where a stand-alone Estimator on the same inputs does.
     device_preint: the IMU intervals of a step are integrated by one device launch instead of on the members' threads -- bit-identical
-    intervals (tests/test_preint_gpu.py), so the members must land on exactly the same bits as without it."""
+    intervals (tests/test_preint_gpu.py), so the members must land on exactly the same bits as without it.
+    group_threads: the members are user-level contexts on a pool of worker threads (GF_GROUP_THREADS); with 1 thread all four share one worker and hand it to
+    each other at every rendezvous, with 3 the split is uneven -- the bits may not depend on it."""
+    if group_threads is not None:
+        monkeypatch.setenv("GF_GROUP_THREADS", str(group_threads))
     n = 4
     streams = []
     for s in range(n):
