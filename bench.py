@@ -153,7 +153,7 @@ def pmc_summary():
         return {}
 
 
-def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False):
+def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False, device_sweeps=False):
     """The drop-in path on a bounded sample: `nseq` sequences (one seeded synthetic RGB-D + IMU + wheel stream, replicated) through the batched
     tracker (trackImage on every camera frame) and gf_estimator_group_* (inputFeature -> processImage -> batched solve + marginalisation on
     every second frame, the reference's MULTIPLE_THREAD flow): the back end is fed by the tracker's own output; as in the reference the tracker
@@ -164,7 +164,7 @@ def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False):
     import synth_stream as SS
     st = SS.Stream(1, t_still=1.5, t_move=1.5, v_max=0.4, yaw0=0.0, yaw_turn=-0.6, split_x=1.8, turn_delay=0.8)
     cfg = gfamd.default_estimator_cfg(tio=SS.TIO, rio=SS.RIO, multiple_thread=1)
-    grp = gfamd.EstimatorGroup(cfg, nseq, device_preint=device_preint)
+    grp = gfamd.EstimatorGroup(cfg, nseq, device_preint=device_preint, device_sweeps=device_sweeps)
     trk = gfamd.FeatureTracker(gfamd.default_cfg(batch=nseq, max_cnt=max_cnt, min_dist=min_dist))
     frames, cache = [], {}
     for k in range(len(st.cam_t)):      # rendering is input synthesis, outside the timed part; identical poses (the stationary lead-in) share a frame
@@ -252,6 +252,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the bounded end-to-end (drop-in path) sample")
     ap.add_argument("--e2e-seqs", type=int, default=256)
     ap.add_argument("--e2e-device-preint", action="store_true", help="also run the end-to-end sample with the batched device pre-integration of the estimator group")
+    ap.add_argument("--e2e-device-sweeps", action="store_true", help="also run the end-to-end sample with the batched device feature sweeps (triangulateWithDepth, movingConsistencyCheckW) of the estimator group")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -447,6 +448,10 @@ def main():
                 alt = end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, device_preint=True)
                 res["end_to_end"]["with_device_preintegration_window_solves_per_s"] = alt["window_solves_per_s"]
                 res["end_to_end"]["with_device_preintegration_newest_position_norm_m"] = alt["newest_position_norm_m"]
+            if args.e2e_device_sweeps:   # the members' per-feature loops as one device launch each per step (same bits; two more rendezvous per frame)
+                alt = end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, device_sweeps=True)
+                res["end_to_end"]["with_device_feature_sweeps_window_solves_per_s"] = alt["window_solves_per_s"]
+                res["end_to_end"]["with_device_feature_sweeps_newest_position_norm_m"] = alt["newest_position_norm_m"]
             res["end_to_end"]["first_pass_window_solves_per_s"] = cold["window_solves_per_s"]
         if not args.no_cpu_baseline:
             nseq = min(8, B)

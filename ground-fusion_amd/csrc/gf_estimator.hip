@@ -460,13 +460,28 @@ static thread_local ucontext_t* tl_sched = nullptr;   // the worker's scheduler 
 static thread_local Fiber* tl_fiber = nullptr;
 static inline void fiber_yield() { Fiber* f = tl_fiber; f->state = 2; swapcontext(&f->ctx, tl_sched); }
 
+// One member's window as the batched feature sweeps take it (gf_triangulate_with_depth_batch / gf_moving_consistency_batch): the member fills it from its
+// FeatureManager, the rendezvous concatenates the members' tables, launches once and scatters the results back.
+struct SweepIn {
+    int W = 0, nf = 0;
+    std::vector<double> Rs, Ps;          // (W + 1) x 9, (W + 1) x 3
+    double tic[3], ric[9];
+    std::vector<int> start_frame, first_obs, flag, remove;   // per feature; first_obs has nf + 1 entries, relative to this member
+    std::vector<double> obs, depth;      // 4 per observation (x, y, z, depth-camera depth); estimated depth per feature (in / out)
+    double depth_threshold = 0, init_depth = 0, focal_length = 0;
+};
+
 struct BatchSolver {
     struct Req { int kind; gf_ba_window* w; int iters, mode; gf_ba_summary* sum; gf_ba_prior* prior; int rc; std::atomic<bool> done; std::string err;
-                 std::vector<ImuPre*> pres; const double* noise; int slot = -1; };   // kind 0 solve, 1 marginalise, 2 IMU pre-integrations of this frame
+                 std::vector<ImuPre*> pres; const double* noise; int slot = -1; SweepIn* sweep = nullptr; };
+    // kind 0 solve, 1 marginalise, 2 IMU pre-integrations of this frame, 3 a per-feature sweep of this member's window (mode 0 triangulateWithDepth, 1 movingConsistencyCheckW;
+    // SURVEY.md 8(f)4)
     // slot: the member's own slot of the shared handle.  A solve request arrives with its window already packed into that slot by the member's thread
     // (gf_ba_pack_slot), and the member unpacks its result itself: the batching thread only uploads, launches and downloads.
     gf_ba* ba = nullptr;
     gf::PreintBatch* pre = nullptr;   // GF_GROUP_DEVICE_PREINT=1: the members' pending pre-integrations run as one launch per camera frame
+    gf_featsweep* sweeps = nullptr;   // GF_GROUP_DEVICE_SWEEPS=1: triangulateWithDepth / movingConsistencyCheckW of the members as one launch each per camera frame
+    long long sweep_batches = 0, sweep_features = 0; double t_sweep = 0;
     double t_pre = 0; long long pre_batches = 0, pre_intervals = 0;
     std::mutex m;
     Gate finished;                  // bumped after every batch
@@ -502,7 +517,53 @@ struct BatchSolver {
         // Partition by a snapshot of kind / mode BEFORE anything runs, and publish `done` only after the last pass: a submitter that sees done == true
         // returns and destroys its stack-allocated Req, so no request may be looked at again once any flag of this batch is up.
         std::vector<Req*> groups[4];   // pre-integrations, solves, MARGIN_OLD, MARGIN_SECOND_NEW
-        for (Req* r : reqs) groups[r->kind == 2 ? 0 : r->kind == 0 ? 1 : 2 + (r->mode != 0)].push_back(r);
+        std::vector<Req*> sweep_grp[2];   // triangulateWithDepth, movingConsistencyCheckW
+        for (Req* r : reqs) {
+            if (r->kind == 3) sweep_grp[r->mode != 0].push_back(r);
+            else groups[r->kind == 2 ? 0 : r->kind == 0 ? 1 : 2 + (r->mode != 0)].push_back(r);
+        }
+        for (int mode = 0; mode < 2; mode++) {   // the feature sweeps: every member's table behind the other, one launch, results back into the members' tables
+            const std::vector<Req*>& grp = sweep_grp[mode];
+            if (grp.empty()) continue;
+            const auto tc0 = std::chrono::steady_clock::now();
+            const int B = (int)grp.size(), W = grp[0]->sweep->W;
+            std::vector<double> Rs, Ps, tic, ric, obs, depth;
+            std::vector<int> first_feature(1, 0), start_frame, first_obs(1, 0), flag;
+            for (Req* r : grp) {
+                const SweepIn& in = *r->sweep;
+                Rs.insert(Rs.end(), in.Rs.begin(), in.Rs.end()); Ps.insert(Ps.end(), in.Ps.begin(), in.Ps.end());
+                tic.insert(tic.end(), in.tic, in.tic + 3); ric.insert(ric.end(), in.ric, in.ric + 9);
+                const int o0 = first_obs.back();
+                for (int f = 0; f < in.nf; f++) first_obs.push_back(o0 + in.first_obs[f + 1]);
+                start_frame.insert(start_frame.end(), in.start_frame.begin(), in.start_frame.end());
+                obs.insert(obs.end(), in.obs.begin(), in.obs.end()); depth.insert(depth.end(), in.depth.begin(), in.depth.end());
+                flag.insert(flag.end(), in.flag.begin(), in.flag.end());
+                first_feature.push_back(first_feature.back() + in.nf);
+            }
+            const int F = first_feature.back();
+            std::vector<int> remove(std::max(F, 1), 0);
+            int rc = GF_OK;
+            if (F > 0) {
+                const SweepIn& c0 = *grp[0]->sweep;   // members of a group share their configuration
+                if (mode == 0) rc = gf_triangulate_with_depth_batch(sweeps, B, W, Rs.data(), Ps.data(), tic.data(), ric.data(), first_feature.data(), start_frame.data(), first_obs.data(),
+                                                                    obs.data(), c0.depth_threshold, c0.init_depth, depth.data(), flag.data());
+                else rc = gf_moving_consistency_batch(sweeps, B, W, Rs.data(), Ps.data(), tic.data(), ric.data(), first_feature.data(), start_frame.data(), first_obs.data(), obs.data(),
+                                                      depth.data(), c0.focal_length, remove.data());
+            }
+            const std::string err = rc == GF_OK ? std::string() : std::string(gf_last_error());
+            for (int b = 0; b < B; b++) {
+                Req* r = grp[b];
+                SweepIn& in = *r->sweep;
+                if (rc == GF_OK) {
+                    const int f0 = first_feature[b];
+                    if (mode == 0) { std::copy(depth.begin() + f0, depth.begin() + f0 + in.nf, in.depth.begin()); std::copy(flag.begin() + f0, flag.begin() + f0 + in.nf, in.flag.begin()); }
+                    else std::copy(remove.begin() + f0, remove.begin() + f0 + in.nf, in.remove.begin());
+                }
+                r->rc = rc; r->err = err;
+            }
+            t_sweep += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
+            sweep_batches++; sweep_features += F;
+        }
         {   // pre-integrations first: nothing else of the same step can be pending next to them
             const std::vector<Req*>& grp = groups[0];
             if (!grp.empty()) {
@@ -1340,13 +1401,23 @@ struct gf_estimator {
                 Ps[frame_count] = Ps[prev]; Vs[frame_count] = Vs[prev]; Rs[frame_count] = Rs[prev]; Bas[frame_count] = Bas[prev]; Bgs[frame_count] = Bgs[prev];
             }
         } else {
-            f_manager.triangulateWithDepth(Ps.data(), Rs.data(), tic, ric);   // DEPTH, EST:1086-1089
+            // member of a group with the device sweeps on: the two per-feature loops of all members run as one launch each (same bits as the host loops)
+            const bool dev_sweeps = group && group->sweeps;
+            if (dev_sweeps) { if (int rc = deviceSweep(0, nullptr)) return rc; }
+            else f_manager.triangulateWithDepth(Ps.data(), Rs.data(), tic, ric);   // DEPTH, EST:1086-1089
             f_manager.triangulate(Ps.data(), Rs.data(), tic, ric);            // EST:1101
             std::set<int> removeIndex;
-            if (cfg.use_mcc) { movingConsistencyCheckW(removeIndex); f_manager.removeOutlier(removeIndex); }
+            if (cfg.use_mcc) {
+                if (dev_sweeps) { if (int rc = deviceSweep(1, &removeIndex)) return rc; } else movingConsistencyCheckW(removeIndex);
+                f_manager.removeOutlier(removeIndex);
+            }
             if (int rc = optimization()) return rc;
             afterOptimizationGNSS();
-            if (!cfg.use_mcc) { std::set<int> inner; movingConsistencyCheckW(inner); f_manager.removeOutlier(inner); }  // shadowing set, SURVEY.md quirk 13
+            if (!cfg.use_mcc) {   // shadowing set, SURVEY.md quirk 13
+                std::set<int> inner;
+                if (dev_sweeps) { if (int rc = deviceSweep(1, &inner)) return rc; } else movingConsistencyCheckW(inner);
+                f_manager.removeOutlier(inner);
+            }
             if (!cfg.multiple_thread) {
                 remove_ids.assign(removeIndex.begin(), removeIndex.end());
                 predictPtsInNextFrame();
@@ -1644,6 +1715,38 @@ struct gf_estimator {
         const V3 pts_w = Ri * (ric * (uvi * depth) + tic) + Pi;
         const V3 pts_cj = transpose(ric) * (transpose(Rj) * (pts_w - Pj) - tic);
         return norm(pts_cj - uvj) / depth;
+    }
+    // FeatureManager::triangulateWithDepth (mode 0) or movingConsistencyCheckW (mode 1) of this member as part of the group's batched launch: the window's
+    // poses and feature tables go into the member's SweepIn, the rendezvous runs all members' tables at once, the results come back in feature-list order.
+    SweepIn sweep_in;
+    int deviceSweep(int mode, std::set<int>* removeIndex) {
+        SweepIn& in = sweep_in;
+        const int NP = WINDOW_SIZE + 1;
+        in.W = WINDOW_SIZE;
+        in.Rs.resize(9 * NP); in.Ps.resize(3 * NP);
+        for (int i = 0; i < NP; i++) { memcpy(&in.Rs[9 * i], Rs[i].m, 72); in.Ps[3 * i] = Ps[i].x; in.Ps[3 * i + 1] = Ps[i].y; in.Ps[3 * i + 2] = Ps[i].z; }
+        in.tic[0] = tic.x; in.tic[1] = tic.y; in.tic[2] = tic.z; memcpy(in.ric, ric.m, 72);
+        in.start_frame.clear(); in.first_obs.assign(1, 0); in.flag.clear(); in.obs.clear(); in.depth.clear();
+        for (auto& it : f_manager.feature) {
+            it.used_num = (int)it.feature_per_frame.size();   // both host loops leave this behind
+            in.start_frame.push_back(it.start_frame);
+            for (const FeaturePerFrame& fr : it.feature_per_frame) in.obs.insert(in.obs.end(), {fr.point.x, fr.point.y, fr.point.z, fr.depth});
+            in.first_obs.push_back((int)(in.obs.size() / 4));
+            in.depth.push_back(it.estimated_depth); in.flag.push_back(it.estimate_flag);
+        }
+        in.nf = (int)in.start_frame.size();
+        in.remove.assign(in.nf, 0);
+        in.depth_threshold = f_manager.depth_threshold; in.init_depth = f_manager.INIT_DEPTH; in.focal_length = cfg.focal_length;
+        BatchSolver::Req rq{3, nullptr, 0, mode, nullptr, nullptr, GF_OK, false, std::string()};
+        rq.sweep = &in;
+        if (int rc = group->submit(rq)) return rc;
+        int f = 0;
+        for (auto& it : f_manager.feature) {
+            if (mode == 0) { it.estimated_depth = in.depth[f]; it.estimate_flag = in.flag[f]; }
+            else if (in.remove[f]) removeIndex->insert(it.feature_id);
+            f++;
+        }
+        return GF_OK;
     }
     void movingConsistencyCheckW(std::set<int>& removeIndex) {  // EST:3955-3995
         for (auto& it : f_manager.feature) {
@@ -2082,6 +2185,7 @@ struct gf_estimator_group {
         for (gf_estimator* e : mem) delete e;
         if (solver.ba) gf_ba_destroy(solver.ba);
         if (solver.pre) gf::preint_batch_destroy(solver.pre);
+        if (solver.sweeps) gf_featsweep_destroy(solver.sweeps);
     }
 };
 
@@ -2101,6 +2205,7 @@ int gf_estimator_group_create(const gf_estimator_cfg* c, int n, gf_estimator_gro
     g->solver.mem_count = (size_t)n;
     (void)hipGetDevice(&g->device);
     if (const char* e = getenv("GF_GROUP_DEVICE_PREINT")) if (atoi(e) != 0) if (int rc = gf::preint_batch_create(&g->solver.pre)) { delete g; return rc; }
+    if (const char* e = getenv("GF_GROUP_DEVICE_SWEEPS")) if (atoi(e) != 0) if (int rc = gf_featsweep_create(&g->solver.sweeps)) { delete g; return rc; }
     g->job_gen.reset(new std::atomic<int>[n]); for (int i = 0; i < n; i++) g->job_gen[i].store(0, std::memory_order_relaxed);
     g->t.assign(n, 0.0); g->frame_ptr.assign(n, nullptr); g->frame_n.assign(n, 0); g->rcs.assign(n, GF_OK); g->errs.resize(n);
     {
@@ -2127,6 +2232,8 @@ int gf_estimator_group_destroy(gf_estimator_group* g) {
     }
     if (g && getenv("GF_GROUP_TIMING") && g->solver.pre)
         fprintf(stderr, "gf_estimator_group: %lld batched pre-integration launches, %lld intervals, %.1f ms inside them\n", g->solver.pre_batches, g->solver.pre_intervals, 1e3 * g->solver.t_pre);
+    if (g && getenv("GF_GROUP_TIMING") && g->solver.sweeps)
+        fprintf(stderr, "gf_estimator_group: %lld batched feature sweeps, %lld features, %.1f ms inside them\n", g->solver.sweep_batches, g->solver.sweep_features, 1e3 * g->solver.t_sweep);
     if (g && getenv("GF_GROUP_TIMING") && g->solver.ba) {
         gf_ba_stats bs{};
         if (gf_ba_get_stats(g->solver.ba, &bs) == GF_OK)
@@ -2145,6 +2252,13 @@ int gf_estimator_group_set_device_preint(gf_estimator_group* g, int on) {
     std::unique_lock<std::mutex> lk(g->solver.m);
     if (on && !g->solver.pre) return gf::preint_batch_create(&g->solver.pre);
     if (!on && g->solver.pre) { gf::preint_batch_destroy(g->solver.pre); g->solver.pre = nullptr; }
+    return GF_OK;
+}
+int gf_estimator_group_set_device_sweeps(gf_estimator_group* g, int on) {
+    if (!g) return gf::set_err(GF_ERR_INVALID, "null handle");
+    std::unique_lock<std::mutex> lk(g->solver.m);
+    if (on && !g->solver.sweeps) return gf_featsweep_create(&g->solver.sweeps);
+    if (!on && g->solver.sweeps) { gf_featsweep_destroy(g->solver.sweeps); g->solver.sweeps = nullptr; }
     return GF_OK;
 }
 int gf_estimator_group_member(gf_estimator_group* g, int i, gf_estimator** out) {

@@ -740,12 +740,14 @@ def write_pgm(path, img):
 class EstimatorGroup:
     """n Estimators sharing one batched back-end handle; members are SlidingWindowEstimator views (IMU / wheel input, state queries)."""
 
-    def __init__(self, cfg, n, device_preint=None):
+    def __init__(self, cfg, n, device_preint=None, device_sweeps=None):
         self.cfg, self.n = cfg, n
         self.g = C.c_void_p()
         _chk(lib().gf_estimator_group_create(C.byref(cfg), n, C.byref(self.g)))
         if device_preint is not None:   # SURVEY.md 8(f)4: one pre-integration launch per step instead of the members' host loops
             _chk(lib().gf_estimator_group_set_device_preint(self.g, int(bool(device_preint))))
+        if device_sweeps is not None:   # SURVEY.md 8(f)4: triangulateWithDepth / movingConsistencyCheckW of all members as one launch each per step
+            _chk(lib().gf_estimator_group_set_device_sweeps(self.g, int(bool(device_sweeps))))
         self.members = []
         for i in range(n):
             m = SlidingWindowEstimator.__new__(SlidingWindowEstimator)

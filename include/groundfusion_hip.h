@@ -425,6 +425,11 @@ int gf_estimator_group_destroy(gf_estimator_group* g);
  * by one device launch per group step (gf_imu_preintegrate_batch's kernel) instead of on the members' host threads; results are bit-identical either way.
  * Off by default (environment GF_GROUP_DEVICE_PREINT=1 turns it on at creation): it pays on hosts with few cores, DESIGN.md section 8. */
 int gf_estimator_group_set_device_preint(gf_estimator_group* g, int on);
+/* FeatureManager::triangulateWithDepth (feature_manager.cpp:726-799) and Estimator::movingConsistencyCheckW (estimator.cpp:3955-3995) of all members
+ * as one launch each per group step (the kernels of gf_triangulate_with_depth_batch / gf_moving_consistency_batch) instead of the members' host loops; depths, flags
+ * and removed ids are bit-identical either way.  Off by default (environment GF_GROUP_DEVICE_SWEEPS=1 turns it on at creation): each launch is one more rendezvous
+ * of the members, and the host loops cost ~20 us per window. */
+int gf_estimator_group_set_device_sweeps(gf_estimator_group* g, int on);
 int gf_estimator_group_member(gf_estimator_group* g, int i, gf_estimator** out);   /* owned by the group */
 /* Estimator::inputFeature on each listed sequence, concurrently; obs = the frames back to back, n_obs[k] entries for seq[k] */
 int gf_estimator_group_input_features(gf_estimator_group* g, int count, const int* seq, const double* t, const gf_feature_obs* obs, const int* n_obs);

@@ -222,12 +222,15 @@ def test_replay_images_with_tracker_feedback():
     assert worst["p"] < 1e-6 and worst["r"] < 1e-6, worst
 
 
-@pytest.mark.parametrize("device_preint,group_threads", [(False, None), (True, None), (False, 1), (False, 3), (True, 2)])
-def test_group_of_sequences_on_one_batched_solver(device_preint, group_threads, monkeypatch):
+@pytest.mark.parametrize("device_preint,group_threads,device_sweeps,use_mcc", [(False, None, False, 0), (True, None, False, 0), (False, 1, False, 0), (False, 3, False, 0),
+                                                                               (True, 2, False, 0), (False, None, True, 0), (False, 2, True, 1), (True, None, True, 1)])
+def test_group_of_sequences_on_one_batched_solver(device_preint, group_threads, device_sweeps, use_mcc, monkeypatch):
     """gf_estimator_group_*: four sequences keep the reference's per-sequence control flow on host threads while their solves and
     marginalisations reach the device as one batch; every member must end up where a stand-alone Estimator on the same inputs does.
     device_preint: the IMU intervals of a step are integrated by one device launch instead of on the members' threads -- bit-identical
     intervals (tests/test_preint_gpu.py), so the members must land on exactly the same bits as without it.
+    device_sweeps (8(f)4 as well): triangulateWithDepth and movingConsistencyCheckW of all members as one launch each per step (before the solve with use_mcc, after
+    it without) -- depths, flags and removed ids are bit-identical to the host loops (tests/test_featsweep_gpu.py), so again the same bits.
     group_threads: the members are user-level contexts on a pool of worker threads (GF_GROUP_THREADS); with 1 thread all four share one worker and hand it to
     each other at every rendezvous, with 3 the split is uneven -- the bits may not depend on it."""
     if group_threads is not None:
@@ -239,9 +242,9 @@ def test_group_of_sequences_on_one_batched_solver(device_preint, group_threads, 
         st._lm = st._landmarks(900)
         st._pn = np.random.default_rng(4100 + s).normal(0, 1.0, (len(st.cam_t), len(st._lm), 2))
         streams.append(st)
-    cfg = gfamd.default_estimator_cfg(tio=SS.TIO, rio=SS.RIO, multiple_thread=1)
-    grp = gfamd.EstimatorGroup(cfg, n, device_preint=device_preint)
-    solo = [gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(tio=SS.TIO, rio=SS.RIO, multiple_thread=1)) for _ in range(n)]
+    cfg = gfamd.default_estimator_cfg(tio=SS.TIO, rio=SS.RIO, multiple_thread=1, use_mcc=use_mcc)
+    grp = gfamd.EstimatorGroup(cfg, n, device_preint=device_preint, device_sweeps=device_sweeps)
+    solo = [gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(tio=SS.TIO, rio=SS.RIO, multiple_thread=1, use_mcc=use_mcc)) for _ in range(n)]
     tp = [-1.0] * n
     nk = min(len(st.cam_t) for st in streams)
     worst = 0.0
