@@ -99,6 +99,7 @@ struct gf_ba {
     size_t vwinx_lds = 0;  // the same for the variant with camera-extrinsic columns (free extrinsic; MARGIN_OLD sweep)
     size_t vtile_stride = 0;   // doubles per window in vtile (0: both variants keep their tiles in LDS)
     size_t mwin_lds = 0;   // dynamic LDS of the prior / IMU / wheel sweep (ba_linearize_misc_win)
+    bool fuse_misc = false, can_fuse_misc = false;
     int max_vis = 0, max_order = 0, max_prior = 0, max_feat = 0;   // largest n_visual / factor-order length / prior size of the resident batch (what the uploads copy)
     std::vector<const gf_ba_window*> resident;       // the caller's window behind every resident slot (gf_ba_marginalize_resident)
     // what packing a window into slot b found out about it; reduced over the batch when the batch is closed (pack_slot may run on one thread per slot)
@@ -542,12 +543,13 @@ int launch_visual(gf_ba* h, Win w, bool ex, int which, int which_state, int only
     return GF_OK;
 }
 
-int launch_linearize(gf_ba* h, int which, int which_state, int only_valid, bool timed) {
+int launch_linearize(gf_ba* h, int which, int which_state, int only_valid, bool timed, bool misc_with_step = false) {
     const Dims& d = h->d;
     Win w = h->win();
     if (timed) HIPCHK(hipEventRecord(h->ev[2], h->stream));
     if (int rc = launch_visual(h, w, h->any_ex, which, which_state, only_valid)) return rc;
     if (timed) HIPCHK(hipEventRecord(h->ev[3], h->stream));
+    if (misc_with_step) return GF_OK;   // the candidate's prior / IMU / wheel sweep rides in front of the next step (ba_misc_step)
     // same stream as the visual sweep: the two sweeps fill the CUs' LDS and registers and so exclude each other anyway, and a second stream only added the
     // cross-stream join in front of the next ba_step (12 us instead of 6; solve 2.49 -> 2.40 ms)
     ba_linearize_misc_win<<<dim3(d.B), 64 * kMW, h->mwin_lds, h->stream>>>(w, which, which_state, only_valid, 0);
@@ -563,6 +565,7 @@ int run_solve(gf_ba* h, int max_iters) {
     if (int rc = launch_linearize(h, 0, 0, 0, false)) return rc;
     Win w = h->win();
     StepBufs sb = h->sbufs();
+    const bool fuse_misc = h->fuse_misc && h->can_fuse_misc && d.GO == 0;
     for (int it = 0; it <= max_iters; it++) {
         if (h->max_solver_time > 0.0 && it > 0 && it < max_iters) {
             // trust_region_minimizer.cc checks total_solver_time >= max_solver_time_in_seconds at the top of every iteration: with the option on, the host
@@ -573,12 +576,13 @@ int run_solve(gf_ba* h, int max_iters) {
         const bool time_step = it == 1 && max_iters >= 1;
         if (time_step) HIPCHK(hipEventRecord(h->ev[6], h->stream));
         if (h->big_step) ba_step<true><<<dim3(d.B), 512, 0, h->stream>>>(w, sb, it == 0 ? 1 : 0, max_iters, it == max_iters ? 1 : 0);
+        else if (fuse_misc && it > 0) ba_misc_step<<<dim3(d.B), 512, std::max(h->step_lds, h->mwin_lds), h->stream>>>(w, sb, max_iters, it == max_iters ? 1 : 0);
         else ba_step<false><<<dim3(d.B), 512, h->step_lds, h->stream>>>(w, sb, it == 0 ? 1 : 0, max_iters, it == max_iters ? 1 : 0);
         HIPCHK(hipGetLastError());
         if (time_step) { HIPCHK(hipEventRecord(h->ev[7], h->stream)); h->stats.step_launches++; h->stats.step_flops += h->step_flops; }
         if (it < max_iters) {
             // candidate state lives in buffer (1 - cur) of each window: the kernels pick the right one per window
-            if (int rc = launch_linearize(h, -1, -1, 1, it == 0)) return rc;
+            if (int rc = launch_linearize(h, -1, -1, 1, it == 0, fuse_misc)) return rc;
             if (it == 0) { h->stats.jtj_launches++; h->stats.jtj_flops += h->mfma_per_lin * 2048; h->stats.jtj_alg_flops += h->jtj_alg_flops; }
         }
     }
@@ -625,7 +629,7 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     h->big_step = h->step_lds + 27 * 1024 > 160 * 1024 || getenv("GF_BA_FORCE_GLOBAL") != nullptr;   // reduced system too large for LDS: ba_step<true> keeps it in global memory
     if (Rmax + 1 > 512) { delete h; return gf::set_err(GF_ERR_INVALID, "window_size %d: reduced system (%d) exceeds 511 columns", d.W, Rmax); }
     if (d.NV > 65535) { delete h; return gf::set_err(GF_ERR_INVALID, "max_visual %d exceeds 65535", d.NV); }
-    if (misc_win_lds_doubles(d.W) * sizeof(double) + 10 * 1024 > 160 * 1024) { delete h; return gf::set_err(GF_ERR_INVALID, "window_size %d: the IMU / wheel block rows exceed LDS (window_size <= 20 in this build)", d.W); }
+    if (misc_win_lds_doubles(d.W) * sizeof(double) > 160 * 1024) { /* the sweep has no static LDS */ delete h; return gf::set_err(GF_ERR_INVALID, "window_size %d: the IMU / wheel block rows exceed LDS (window_size <= 20 in this build)", d.W); }
 #define A_(x) do { if (int rc_ = (x)) { h->release(); delete h; return rc_; } } while (0)
 #define H_(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { gf::set_err(GF_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); h->release(); delete h; return GF_ERR_HIP; } } while (0)
     {   // the solver is a chain of short launches that each want every CU: its queue goes first when the tracker's kernels of the same process compete for them
@@ -671,6 +675,9 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     if (h->big_step) { h->sg_stride = (h->step_lds / sizeof(double) + 15) & ~(size_t)15; A_(h->Sg.alloc(B * h->sg_stride, false)); }
     if (h->big_marg) { h->mg_stride = (size_t)2 * h->marg_ncap * h->marg_ncap + 1024; A_(h->Mg.alloc(B * h->mg_stride, false)); }
     if (!h->big_step) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_step<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->step_lds));
+    // GF_BA_FUSE_MISC=1: the candidate's prior / IMU / wheel sweep in front of the step that judges it, one launch (ba_misc_step).  Same bits; measured 163 us against
+    // 123 + 33 us for the two launches and 1.75-1.77 instead of 1.79 ms per solve (-1 %): the sweep's time is its blocks' own latency, not a launch boundary.  Off.
+    h->fuse_misc = getenv("GF_BA_FUSE_MISC") != nullptr;
     {   // window-level sweeps: staging areas of the wavefronts (static LDS) + pair tiles / block rows (dynamic LDS, or global memory for long windows)
         const bool glob = getenv("GF_BA_GLOBAL_TILES") != nullptr;   // test switch: pair tiles in global memory also where they fit LDS
         const size_t dyn = vwin_slot_doubles(d.NP, false) * sizeof(double), stat = (size_t)kVW * vwin_sg(false) * vwin_lstr(false) * sizeof(double) + kVW * 64 * sizeof(int) + 512 + 2048;
@@ -682,6 +689,8 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
         if (!h->vwin_lds || !h->vwinx_lds) { h->vtile_stride = (vwin_slot_doubles(d.NP, true) + 3) & ~(size_t)3; A_(h->vtile.alloc(B * h->vtile_stride, false)); }
         h->mwin_lds = misc_win_lds_doubles(d.W) * sizeof(double);
         H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_misc_win), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mwin_lds));
+        h->can_fuse_misc = !h->big_step && std::max(h->step_lds, h->mwin_lds) + 27 * 1024 <= 160 * 1024;
+        if (h->can_fuse_misc) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_misc_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(h->step_lds, h->mwin_lds)));
     }
     if (!h->big_marg) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_marg_finish<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds));
     H_(hipStreamSynchronize(h->stream));

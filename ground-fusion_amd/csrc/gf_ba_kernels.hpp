@@ -928,15 +928,19 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
 constexpr int kMW = 8;
 constexpr int kMJi = 16 * 33, kMJw = 9 * 33, kMScr = 16 * 33;
 __host__ __device__ inline int misc_win_nscr(int W) { return W <= 12 ? kMW : 4; }   // whitening wavefronts (scratch areas)
-__host__ __device__ inline size_t misc_win_lds_doubles(int W) { return (size_t)W * (kMJi + kMJw) + (size_t)misc_win_nscr(W) * kMScr; }
-__global__ void __launch_bounds__(64 * kMW) ba_linearize_misc_win(Win w, int which, int which_state, int only_cand_valid, int frame_filter) {
+__host__ __device__ inline size_t misc_win_rows_doubles(int W) { return (size_t)W * (kMJi + kMJw) + (size_t)misc_win_nscr(W) * kMScr; }
+constexpr int kMTab = 64 + kMW + 2 * 512 + (2 * 512 + 2 * 32 + 2) / 2;   // the small tables behind the rows, in doubles
+__host__ __device__ inline size_t misc_win_lds_doubles(int W) { return misc_win_rows_doubles(W) + kMTab; }
+__device__ __forceinline__ void ba_linearize_misc_body(Win w, int which, int which_state, int only_cand_valid, int frame_filter) {
     extern __shared__ __attribute__((aligned(16))) double m_lds[];
-    __shared__ double s_fcost[64];       // per-factor costs: IMU k at k, wheel k at 32 + k
-    __shared__ double s_wc[kMW];         // prior cost partials of the wavefronts
-    __shared__ double s_dx[512], s_pg[512];   // prior: dx, b0 + A dx by local prior index
-    __shared__ int s_pcol[512], s_pidx[512], s_R;
-    __shared__ int s_imu_at[32], s_wh_at[32];   // factor starting at frame f (or -1)
     const Dims d = w.d;
+    // the kernel's small tables sit behind the block rows in the dynamic area (no static LDS of its own: next to ba_step's 26 KB in ba_misc_step there is no room for it)
+    double* s_fcost = m_lds + misc_win_rows_doubles(d.W);   // [64] per-factor costs: IMU k at k, wheel k at 32 + k
+    double* s_wc = s_fcost + 64;                            // [kMW] prior cost partials of the wavefronts
+    double* s_dx = s_wc + kMW; double* s_pg = s_dx + 512;   // [512] each, prior: dx, b0 + A dx by local prior index
+    int* s_pcol = reinterpret_cast<int*>(s_pg + 512); int* s_pidx = s_pcol + 512;   // [512] each
+    int* s_imu_at = s_pidx + 512; int* s_wh_at = s_imu_at + 32;                     // [32] each: factor starting at frame f (or -1)
+    int& s_R = s_wh_at[32];
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, RP = d.RP, NP = d.NP;
     const SolverState& st = w.st[b];
     const int st_cur = uni(st.cur);
@@ -1154,6 +1158,9 @@ __global__ void __launch_bounds__(64 * kMW) ba_linearize_misc_win(Win w, int whi
     }
     GF_WSTAMP(75);
 }
+__global__ void __launch_bounds__(64 * kMW) ba_linearize_misc_win(Win w, int which, int which_state, int only_cand_valid, int frame_filter) {
+    ba_linearize_misc_body(w, which, which_state, only_cand_valid, frame_filter);
+}
 
 // PoseLocalParameterization::Plus (pose_local_parameterization.cpp:12-28)
 __device__ __forceinline__ void pose_plus(const double* x, const double* dl, double* out) {
@@ -1290,7 +1297,7 @@ __device__ __forceinline__ bool wave_chol16_fused(SPtr S, int j0, int nb, double
 // GS: the packed reduced system lives in global memory (sb.Sg) instead of LDS -- windows whose (R+1)(R+2)/2 doubles exceed 160 KB
 // (WINDOW_SIZE > 10); same code, the triangular solves then run out of L2.
 template <bool GS>
-__global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, int max_iters, int finalize_only) {
+__device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int max_iters, int finalize_only) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double sred[512];
     __shared__ double s_inv[16 * 17];
@@ -1907,6 +1914,15 @@ __global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, in
             st.mu *= 10.0; st.reuse = 0;
         }
     }
+}
+template <bool GS>
+__global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, int max_iters, int finalize_only) { ba_step_body<GS>(w, sb, first, max_iters, finalize_only); }
+// The prior / IMU / wheel sweep of the candidate and the step that judges it in one launch (LDS-resident systems without GNSS blocks): the sweep's H, g and costs
+// are read by the same block right away, and the launch boundary between the two -- with the write-back of everything the sweep stored -- is gone.
+__global__ void __launch_bounds__(512) ba_misc_step(Win w, StepBufs sb, int max_iters, int finalize_only) {
+    ba_linearize_misc_body(w, -1, -1, 1, 0);
+    __syncthreads();
+    ba_step_body<false>(w, sb, 0, max_iters, finalize_only);
 }
 
 }  // namespace gfb
