@@ -294,7 +294,26 @@ __global__ void __launch_bounds__(1024) select_corners_kernel(SelectArgs A) {
     // candidates are all unmasked non-zero local maxima; keep those above the quality threshold (others sort last as 0)
     auto keep = [&](unsigned long long k) -> unsigned long long { return f32_from_orderable((unsigned)(k >> 32)) > thresh ? k : 0ull; };
     if (in_lds) {
-        for (int i = tid; i < npow2; i += 1024) lk[i] = i < n ? keep(gk[i]) : 0ull;
+        // only candidates above the quality threshold take part in the sort: they are packed to the front of the LDS area (their order there is settled by the
+        // sort: keys are unique), one LDS atomic per wavefront; typically half of the local maxima pass, which halves the sort's size and drops a round of stages
+        __shared__ int n_kept;
+        if (tid == 0) n_kept = 0;
+        __syncthreads();
+        for (int i0 = 0; i0 < n; i0 += 1024) {
+            const int i = i0 + tid;
+            const unsigned long long k = i < n ? keep(gk[i]) : 0ull;
+            const unsigned long long bal = __ballot(k != 0ull);
+            int base = 0;
+            if ((tid & 63) == 0 && bal) base = atomicAdd(&n_kept, __builtin_popcountll(bal));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (k) lk[base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = k;
+        }
+        __syncthreads();
+        n = n_kept;
+        if (n == 0) { if (tid == 0) A.out_n[b] = 0; return; }
+        npow2 = 64;
+        while (npow2 < n) npow2 <<= 1;
+        for (int i = n + tid; i < npow2; i += 1024) lk[i] = 0ull;
         __syncthreads();
         bitonic_desc(lk, npow2, tid, 1024);
     } else {
