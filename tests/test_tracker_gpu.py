@@ -82,6 +82,24 @@ def test_good_features_bit_exact(gf, oracle, max_corners, min_dist, masked):
     assert len(a) == len(b) and np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("shape,min_dist", [((120, 160), 8), ((150, 200), 10), ((122, 188), 6), ((62, 36), 4), ((33, 64), 3), ((480, 640), 30)])
+def test_good_features_on_odd_image_sizes(gf, oracle, shape, min_dist):
+    """the Shi-Tomasi pass walks strips of 60 columns x 30 rows: widths / heights that are no multiples of either, images narrower than one strip, and a mask
+    that leaves only pieces of the border strips -- corners and their order must still be OpenCV's"""
+    tex = synth.make_texture(5)
+    img = synth.warp_frame(tex, 2, -3, w=shape[1], h=shape[0])
+    for masked in (False, True):
+        mask = None
+        if masked:
+            mask = np.zeros(img.shape, np.uint8)
+            mask[:, -7:] = 255; mask[-5:, :] = 255; mask[:3, :] = 255; mask[:, :2] = 255   # only the image's rim may hold corners
+            oracle.fill_circle(mask, shape[1] // 2, shape[0] - 1, min_dist)
+        a = oracle.good_features(img, 400, min_dist=float(min_dist), mask=mask)
+        b = gf.good_features(img, 400, min_dist=min_dist, mask=mask)
+        assert len(a) == len(b) and np.array_equal(a, b), (shape, masked)
+        assert masked or len(a) > 20
+
+
 def test_good_features_degenerate_images(gf, oracle):
     flat = np.full((480, 640), 128, np.uint8)
     assert len(gf.good_features(flat, 50)) == 0 == len(oracle.good_features(flat, 50))
