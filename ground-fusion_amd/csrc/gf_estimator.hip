@@ -2227,8 +2227,10 @@ int gf_estimator_group_destroy(gf_estimator_group* g) {
     if (g && getenv("GF_GROUP_TIMING")) {
         double ts[6] = {0, 0, 0, 0, 0, 0};
         for (gf_estimator* e : g->mem) for (int q = 0; q < 6; q++) ts[q] += e->t_sect[q];
-        fprintf(stderr, "gf_estimator_group members, CPU time summed over %zu threads [ms]: before optimization %.1f, window build %.1f, waiting for the solve %.1f, double2vector .. marginalisation request %.1f, "
-                        "waiting for the marginalisation %.1f, rest of the frame %.1f\n", g->mem.size(), 1e3 * ts[0], 1e3 * ts[1], 1e3 * ts[2], 1e3 * ts[3], 1e3 * ts[4], 1e3 * ts[5]);
+        // thread CPU time between the marks of a member: the two "waiting" entries also contain what the OTHER members of the same worker thread computed meanwhile
+        fprintf(stderr, "gf_estimator_group: %zu members on %d worker threads, CPU time summed over the members [ms]: before optimization %.1f, window build %.1f, waiting for the solve %.1f, "
+                        "double2vector .. marginalisation request %.1f, waiting for the marginalisation %.1f, rest of the frame %.1f\n", g->mem.size(), g->n_threads, 1e3 * ts[0], 1e3 * ts[1],
+                1e3 * ts[2], 1e3 * ts[3], 1e3 * ts[4], 1e3 * ts[5]);
     }
     if (g && getenv("GF_GROUP_TIMING") && g->solver.pre)
         fprintf(stderr, "gf_estimator_group: %lld batched pre-integration launches, %lld intervals, %.1f ms inside them\n", g->solver.pre_batches, g->solver.pre_intervals, 1e3 * g->solver.t_pre);
