@@ -2090,6 +2090,15 @@ int gf_estimator_debug(gf_estimator* e, const char* op, const double* in, int n_
         const bool ok = gfinit::solve_pnp_iterative(X, uv, rv, tv, in[1] != 0);
         o.push_back(ok ? 1.0 : 0.0); o.insert(o.end(), rv, rv + 3); o.insert(o.end(), tv, tv + 3);
     }
+    else if (s == "epnp" && n_in >= 1 && (n_in - 1) % 5 == 0) {   // in: n, then (X, Y, Z, u, v) per point; out: ok, rvec, tvec of the EPnP kernel solvePnPRansac runs on its subsets
+        const int n = (int)in[0];
+        if (n_in != 1 + 5 * n || n < 4) return gf::set_err(GF_ERR_INVALID, "epnp: %d values for %d points", n_in, n);
+        std::vector<gfinit::P3> X(n); std::vector<gfinit::P2> uv(n);
+        for (int k = 0; k < n; k++) { X[k] = {in[1 + 5 * k], in[2 + 5 * k], in[3 + 5 * k]}; uv[k] = {in[4 + 5 * k], in[5 + 5 * k]}; }
+        double rv[3] = {0, 0, 0}, tv[3] = {0, 0, 0};
+        const bool ok = gfinit::epnp(X, uv, rv, tv);
+        o.push_back(ok ? 1.0 : 0.0); o.insert(o.end(), rv, rv + 3); o.insert(o.end(), tv, tv + 3);
+    }
     else if (s == "skip_solve" && n_in >= 1) e->debug_skip_solve = in[0] != 0;   // optimization() and slideWindow() become no-ops: host-only parity tests of initialStructure
     else if (s == "init_info") o = {(double)e->init_l, (double)e->init_points, e->init_s, e->init_g.x, e->init_g.y, e->init_g.z, (double)e->init_rc, e->g.x, e->g.y, e->g.z};
     else if (s == "addFeature" && n_in >= 2 && (n_in - 2) % 9 == 0) {

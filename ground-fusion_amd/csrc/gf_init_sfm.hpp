@@ -194,6 +194,45 @@ inline bool polar_rotation(const double* M, double* R) {
     return true;
 }
 
+// U V^T of the SVD M = U S V^T by one-sided (Hestenes) Jacobi rotations of the columns: small singular values come out with their full relative accuracy, which
+// the route through the eigen-decomposition of M^T M above does not give (its error grows with the SQUARE of the condition number -- EPnP's 3 x 3 correlation
+// matrix of five nearly coplanar points has one: scripts/epnp_mpmath_check.py measured 1e-8 ... 4e-2 against a 60-digit evaluation before this was used there).
+inline bool svd_rotation(const double* M, double* R) {
+    double U[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int i = 0; i < 9; i++) U[i] = M[i];
+    for (int sweep = 0; sweep < 60; sweep++) {
+        bool rotated = false;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                double al = 0, be = 0, ga = 0;
+                for (int k = 0; k < 3; k++) { al += U[3 * k + p] * U[3 * k + p]; be += U[3 * k + q] * U[3 * k + q]; ga += U[3 * k + p] * U[3 * k + q]; }
+                if (ga == 0.0 || fabs(ga) <= 1e-17 * sqrt(al * be)) continue;
+                rotated = true;
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int k = 0; k < 3; k++) {
+                    const double x = U[3 * k + p], y = U[3 * k + q]; U[3 * k + p] = c * x - sn * y; U[3 * k + q] = sn * x + c * y;
+                    const double vx = V[3 * k + p], vy = V[3 * k + q]; V[3 * k + p] = c * vx - sn * vy; V[3 * k + q] = sn * vx + c * vy;
+                }
+            }
+        if (!rotated) break;
+    }
+    double sg[3], smax = 0;
+    for (int j = 0; j < 3; j++) { sg[j] = sqrt(U[j] * U[j] + U[3 + j] * U[3 + j] + U[6 + j] * U[6 + j]); smax = std::max(smax, sg[j]); }
+    if (!(smax > 0) || !std::isfinite(smax)) return false;
+    int dead = -1, ndead = 0;
+    for (int j = 0; j < 3; j++) { if (sg[j] > 1e-290 && sg[j] > 1e-200 * smax) for (int k = 0; k < 3; k++) U[3 * k + j] /= sg[j]; else { dead = j; ndead++; } }
+    if (ndead > 1) return false;
+    if (ndead == 1) {   // an exactly singular matrix: the missing left vector completes the other two (its sign is settled by the caller's determinant test)
+        const int a = (dead + 1) % 3, b = (dead + 2) % 3;
+        const double ua[3] = {U[a], U[3 + a], U[6 + a]}, ub[3] = {U[b], U[3 + b], U[6 + b]};
+        U[dead] = ua[1] * ub[2] - ua[2] * ub[1]; U[3 + dead] = ua[2] * ub[0] - ua[0] * ub[2]; U[6 + dead] = ua[0] * ub[1] - ua[1] * ub[0];
+    }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double v = 0; for (int k = 0; k < 3; k++) v += U[3 * i + k] * V[3 * j + k]; R[3 * i + j] = v; }
+    return true;
+}
+
 // ---------------------------------------------------------------- cv::Rodrigues
 inline void rodrigues(const double* r, double* R) {
     const double th = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
@@ -518,7 +557,7 @@ inline bool epnp(const std::vector<P3>& X, const std::vector<P2>& uv, double* rv
         bool fin = true;
         for (double v : ABt) fin = fin && std::isfinite(v);
         double R[9];
-        if (!fin || !polar_rotation(ABt, R)) continue;
+        if (!fin || !svd_rotation(ABt, R)) continue;   // R = U V^T of ABt (epnp.cpp estimate_R_and_t: cvSVD)
         if (m3det(R) < 0) { R[6] = -R[6]; R[7] = -R[7]; R[8] = -R[8]; }
         double t[3], Rp[3];
         m3v(R, c0, Rp);
