@@ -2,7 +2,7 @@
 dropped block, eigen square root of the kept system, both cut at 1e-8) and from the HIP library (block elimination, rank-revealing Cholesky, same threshold),
 each measured against the same route evaluated with 60 digits on the oracle's assembled system (A, b).
 
-  python scripts/marg_mpmath_check.py --dump gpurun_out/marg_dump.pkl [--seed 1] [--w20]   (on the GPU box: solves, marginalises on both sides, stores everything)
+  python scripts/marg_mpmath_check.py --dump gpurun_out/marg_dump.pkl [--seed 1] [--w20 | --novisual]   (on the GPU box: solves, marginalises on both sides, stores everything)
   python scripts/marg_mpmath_check.py gpurun_out/marg_dump.pkl                                 (CPU: the 60-digit evaluation and the comparison)
 
 What is compared: J^T J and J^T r of the two priors (what the next solve sees), entry by entry, scaled by sqrt(A_ii A_jj) of the exact kept system."""
@@ -23,7 +23,14 @@ def dump(path, seed, w20):
     import gfamd
     W, F = (20, 150) if w20 else (10, 150)
     est = gfamd.Estimator(W, F, F * W, 1, max_gnss=12 * (W + 1))
-    w = SW.make_window(seed, O, W=W, gnss=True) if w20 else SW.make_window(seed, O, gnss=True)
+    if "--novisual" in sys.argv:   # tests/test_backend_gpu.py::test_windows_without_a_factor_family[visual]: IMU + wheel + prior only
+        est.close(); est = gfamd.Estimator()
+        w = SW.make_window(seed, O)
+        for k in [k for k in w if isinstance(w[k], np.ndarray) and k.startswith("vis_")]:
+            w[k] = w[k][:0]
+        w["para_Feature"], w["feature_fixed"] = w["para_Feature"][:0], w["feature_fixed"][:0]
+    else:
+        w = SW.make_window(seed, O, W=W, gnss=True) if w20 else SW.make_window(seed, O, gnss=True)
     O.ba_solve(w, 8)
     po = O.ba_marginalize(w, 0, cap_n=512)
     pg = est.marginalize([w], 0, cap_n=512)[0]
@@ -87,7 +94,7 @@ def check(path, dps=60):
             Atb[i] += V2[i, k] * c
     exact_A = np.array([[float(AtA[i, j]) for j in range(n)] for i in range(n)])
     exact_b = np.array([float(Atb[i]) for i in range(n)])
-    sc = np.sqrt(np.maximum(np.diag(exact_A), 1e-300))
+    sc = np.sqrt(np.maximum(np.diag(exact_A), 1e-16 * np.abs(exact_A).max()))   # columns the prior says nothing about (zero rows of the exact system) scale with the top
     bs = np.abs(exact_b).max()
     for name, p in (("oracle", po), ("HIP   ", pg)):
         J = p["J"].reshape(n, n)
@@ -95,8 +102,8 @@ def check(path, dps=60):
         eA = np.abs((Aj - exact_A) / np.outer(sc, sc))
         eb = np.abs(bj - exact_b)
         i, j = np.unravel_index(np.argmax(eA), eA.shape)
-        print("%s vs 60 digits: J^T J scaled max %.2e (entry %d,%d), median %.1e;  J^T r max %.2e (of %.2e), rank of J %d" % (name, eA.max(), i, j, np.median(eA), eb.max(), bs,
-                                                                                                                 int((np.abs(J).max(axis=1) > 0).sum())))
+        print("%s vs 60 digits: J^T J scaled max %.2e (entry %d,%d: %.3e against %.3e), median %.1e, largest absolute %.2e of %.2e;  J^T r max %.2e (of %.2e), rank of J %d"
+              % (name, eA.max(), i, j, Aj[i, j], exact_A[i, j], np.median(eA), np.abs(Aj - exact_A).max(), np.abs(exact_A).max(), eb.max(), bs, int((np.abs(J).max(axis=1) > 0).sum())))
     Jo, Jg = po["J"].reshape(n, n), pg["J"].reshape(n, n)
     print("oracle vs HIP:   J^T J scaled max %.2e;  J^T r max %.2e" % (np.abs((Jo.T @ Jo - Jg.T @ Jg) / np.outer(sc, sc)).max(), np.abs(Jo.T @ po["r"] - Jg.T @ pg["r"]).max()))
 
