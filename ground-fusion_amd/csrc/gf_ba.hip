@@ -113,7 +113,8 @@ struct gf_ba {
     // and stages only the rows that are new; the upload sends those (imu_patch) and a small kernel moves / patches the slot's table.  imu_dev[b]: the device table
     // of slot b equals its host mirror (set by an upload that covered the slot).
     Buf<double> imu_patch; Buf<int> imu_pinfo;   // [B][W][IMU_STRIDE2] rows to write, [B][W + 2]: moved-up flag, number of rows, their positions
-    std::vector<char> imu_dev;
+    std::vector<char> imu_dev;   // 0: device table unknown / behind the mirror, 1: device == mirror, 2: packed for the patch path (mirror ahead by the staged rows until upload() succeeds)
+    std::vector<int> imu_rows;   // rows of the slot's mirror that the device table holds as well (the previous pack's n_imu)
     int max_imu_dirty = 0;
     bool all_pri_res = false, any_pri_res = false, outJ_host_stale = false;
     double max_solver_time = 0.0;   // ceres::Solver::Options::max_solver_time_in_seconds; 0 = not honoured (the fixed schedule runs without host round trips)
@@ -300,19 +301,22 @@ int pack_slot(gf_ba* h, int b, const gf_ba_window& w) {
             double* tab = h->imu_data.h + (size_t)b * d.W * IMU_STRIDE2;
             int* pi = h->imu_pinfo.h + (size_t)b * (d.W + 2);
             const size_t RB = (size_t)IMU_STRIDE2 * sizeof(double);
-            auto same = [&](int k, int old_k) { return old_k < d.W && memcmp(rows.data() + (size_t)k * IMU_STRIDE2, tab + (size_t)old_k * IMU_STRIDE2, RB) == 0; };
+            const bool on_dev = h->imu_dev[b] == 1;   // anything else: a pack that never reached the device (failed batch) left the mirror ahead -> everything is staged again
+            const int old_rows = on_dev ? h->imu_rows[b] : 0;
+            auto same = [&](int k, int old_k) { return old_k < old_rows && memcmp(rows.data() + (size_t)k * IMU_STRIDE2, tab + (size_t)old_k * IMU_STRIDE2, RB) == 0; };
             int shift = 0;
-            if (h->imu_dev[b] && w.n_imu > 0) {
+            if (on_dev && w.n_imu > 0) {
                 int m0 = 0, m1 = 0;
                 for (int k = 0; k < w.n_imu; k++) { m0 += same(k, k); m1 += same(k, k + 1); }
                 shift = m1 > m0 ? 1 : 0;
             }
             int nd = 0;
             for (int k = 0; k < w.n_imu; k++)
-                if (!(h->imu_dev[b] && same(k, k + shift))) { memcpy(h->imu_patch.h + ((size_t)b * d.W + nd) * IMU_STRIDE2, rows.data() + (size_t)k * IMU_STRIDE2, RB); pi[2 + nd++] = k; }
+                if (!(on_dev && same(k, k + shift))) { memcpy(h->imu_patch.h + ((size_t)b * d.W + nd) * IMU_STRIDE2, rows.data() + (size_t)k * IMU_STRIDE2, RB); pi[2 + nd++] = k; }
             pi[0] = shift; pi[1] = nd;
             M.imu_dirty = nd;
-            memcpy(tab, rows.data(), (size_t)w.n_imu * RB);   // the mirror of what the device table holds after the patch (rows beyond n_imu are never read)
+            memcpy(tab, rows.data(), (size_t)w.n_imu * RB);   // the mirror of what the device table holds after the patch (rows beyond n_imu are never read, never compared: imu_rows)
+            h->imu_dev[b] = on_dev ? 2 : 0; h->imu_rows[b] = w.n_imu;
         }
         for (int k = 0; k < w.n_wheel; k++) {
             h->wh_i.h[(size_t)b * d.W + k] = w.wh_i[k];
@@ -471,7 +475,10 @@ int upload(gf_ba* h) {
     HIPCHK(h->order.up2d(s, B, d.NVP, no)); lapb("order");
     HIPCHK(h->vis_data.up2d(s, B, (size_t)d.NV * 6, nv * 6));
     HIPCHK(h->feat_obs.up2d(s, B, (size_t)d.F * 6, nf * 6)); lapb("vis_data + feat_obs");
-    if (!(h->any_pri_res && h->all_pri_res)) HIPCHK(h->pri_J.up2d(s, B, (size_t)d.NPRI * d.NPRI, np2));
+    if (!h->any_pri_res) HIPCHK(h->pri_J.up2d(s, B, (size_t)d.NPRI * d.NPRI, np2));
+    else if (!h->all_pri_res)   // mixed batch: only the active slots that brought a host prior; a slot that sits this batch out keeps what the device holds (its host mirror was never written)
+        for (int b : h->active) if (!h->meta[b].pri_res && h->meta[b].npri > 0)
+            HIPCHK(hipMemcpyAsync(h->pri_J.d + (size_t)b * d.NPRI * d.NPRI, h->pri_J.h + (size_t)b * d.NPRI * d.NPRI, (size_t)h->meta[b].npri * h->meta[b].npri * 8, hipMemcpyHostToDevice, s));
     if (h->any_pri_res) {   // device-resident priors: marginalisation output -> prior table, without the round trip through the host
         const size_t pitch = (size_t)d.NPRI * d.NPRI * 8;
         if (h->all_pri_res) HIPCHK(hipMemcpy2DAsync(h->pri_J.d, pitch, h->outJ.d, pitch, np2 * 8, B, hipMemcpyDeviceToDevice, s));
@@ -480,14 +487,14 @@ int upload(gf_ba* h) {
     lapb("pri_J");
     {   // IMU tables: everything when many rows are new (first frames, whole-batch uploads), else the new rows + one small kernel that moves / patches the slots' tables
         bool all_dev = true;
-        for (int b : h->active) all_dev &= h->imu_dev[b] != 0;
+        for (int b : h->active) all_dev &= h->imu_dev[b] == 2;
         if (all_dev && (int)h->active.size() == d.B && h->max_imu_dirty <= d.W / 2) {
             if (h->max_imu_dirty > 0) HIPCHK(h->imu_patch.up2d(s, B, (size_t)d.W * IMU_STRIDE2, (size_t)h->max_imu_dirty * IMU_STRIDE2));
             HIPCHK(h->imu_pinfo.up(s));
             ba_imu_patch<<<dim3(d.B), 256, 0, s>>>(h->imu_data.d, h->imu_patch.d, h->imu_pinfo.d, d.W);
             HIPCHK(hipGetLastError());
         } else HIPCHK(h->imu_data.up(s));
-        for (int b = 0; b < d.B; b++) h->imu_dev[b] = 1;   // the full upload covers every slot with its mirror; the patch path required it before
+        for (int b = 0; b < d.B; b++) h->imu_dev[b] = 1;   // set only here, behind a successful copy: the full upload covers every slot with its mirror; the patch path required state 2 of every slot
     }
     for (auto* b : {&h->wh_data, &h->pri_r, &h->pri_x0, &h->wpar}) HIPCHK(b->up(s));
     lapb("imu, wheel, pri_r, pri_x0, wpar");
@@ -667,7 +674,7 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     // kept system of the marginalisation: 6 W poses + speed-bias + extrinsics ...; A and V live in LDS up to 92 columns, else in global memory
     const int nkeep = 6 * d.W + 9 + 17 + (gnss ? 9 : 0);
     h->big_marg = nkeep > 92 || getenv("GF_BA_FORCE_GLOBAL") != nullptr;
-    h->meta.assign(d.B, gf_ba::SlotMeta{}); h->outJ_n.assign(d.B, 0); h->imu_dev.assign(d.B, 0);
+    h->meta.assign(d.B, gf_ba::SlotMeta{}); h->outJ_n.assign(d.B, 0); h->imu_dev.assign(d.B, 0); h->imu_rows.assign(d.B, 0);
     A_(h->imu_patch.alloc(B * d.W * IMU_STRIDE2, true)); A_(h->imu_pinfo.alloc(B * (d.W + 2), true));
     for (int mode = 0; mode < 2; mode++) h->keep_ids[mode].assign(d.B, {});
     h->marg_ncap = h->big_marg ? std::min(d.NPRI, nkeep + 16) : 92;

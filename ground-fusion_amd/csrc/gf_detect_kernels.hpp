@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(64) detect_strip_kernel(DetectArgs A, DiskTabl
     int fix_src = lane;
     if (x == -1) fix_src = lane + (g.w > 1 ? 2 : 1);
     if (x == g.w) fix_src = lane - (g.w > 1 ? 2 : 1);
-    const bool fix_v = Y0 == 0 || Y0 + R >= g.h;
+    const bool fix_v = Y0 == 0 || Y0 + R + 1 >= g.h;   // + 1: the halo row Y0 + R (3 x 3 test of the last output row) can be image row h - 1
 
     float hd[3] = {0.f, 0.f, 0.f}, hm[3] = {0.f, 0.f, 0.f};                      // per raw row: (float)(p[x+1] - p[x-1]) and the [f1 f0 f1] row sum
     double hxx[3] = {0, 0, 0}, hxy[3] = {0, 0, 0}, hyy[3] = {0, 0, 0};           // horizontal 3-sums of the product rows

@@ -442,9 +442,16 @@ struct Fiber {
     ucontext_t ctx;
     char* stack = nullptr;   // mmap'ed: pages are touched on use only, the lowest page is a guard (an overflow faults instead of running into a neighbour)
     int state = 0;           // 0 idle, 1 running / runnable, 2 waiting for a batch, 3 frame finished
-    static constexpr size_t kStack = 2u << 20, kGuard = 4096;
+    static constexpr size_t kGuard = 4096;
+    // GF_GROUP_STACK_KB (default 8 MB, what a worker thread of its own would have): MAP_NORESERVE pages cost nothing until a frame touches them
+    static size_t stack_bytes() {
+        static const size_t n = [] { const char* e = getenv("GF_GROUP_STACK_KB"); long kb = e ? atol(e) : 8192; if (kb < 256) kb = 256; return ((size_t)kb << 10) & ~(size_t)4095; }();
+        return n;
+    }
+    size_t kStack = 0;
     bool alloc() {
         if (stack) return true;
+        kStack = stack_bytes();
         void* p = mmap(nullptr, kStack + kGuard, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK | MAP_NORESERVE, -1, 0);
         if (p == MAP_FAILED) return false;
         (void)mprotect(p, kGuard, PROT_NONE);
@@ -2137,7 +2144,12 @@ struct gf_estimator_group {
 
     void run_frame(int i) {   // one member's frame (inside its fiber)
         mem[i]->t_mark = gf_estimator::cpu_now();
-        const int rc = gf_estimator_input_feature(mem[i], t[i], frame_ptr[i], frame_n[i]);   // the caller's buffer: input_features does not return before this is done
+        int rc;
+        // an exception (std::bad_alloc in a member's bookkeeping) must not unwind past makecontext's frame -- that is std::terminate for the whole process: it
+        // becomes this member's frame error, and the member still leaves the rendezvous so that the others' batches close
+        try { rc = gf_estimator_input_feature(mem[i], t[i], frame_ptr[i], frame_n[i]); }   // the caller's buffer: input_features does not return before this is done
+        catch (const std::exception& e) { rc = gf::set_err(GF_ERR_INVALID, "member %d: exception in processImage: %s", i, e.what()); }
+        catch (...) { rc = gf::set_err(GF_ERR_INVALID, "member %d: unknown exception in processImage", i); }
         mem[i]->lap(5);
         rcs[i] = rc;
         if (rc != GF_OK) errs[i] = gf_last_error();
@@ -2166,7 +2178,7 @@ struct gf_estimator_group {
             for (int i : mine) {
                 Fiber& f = fib[i];
                 getcontext(&f.ctx);
-                f.ctx.uc_stack.ss_sp = f.stack + Fiber::kGuard; f.ctx.uc_stack.ss_size = Fiber::kStack; f.ctx.uc_link = &sched;
+                f.ctx.uc_stack.ss_sp = f.stack + Fiber::kGuard; f.ctx.uc_stack.ss_size = f.kStack; f.ctx.uc_link = &sched;
                 const uintptr_t self = reinterpret_cast<uintptr_t>(this);
                 makecontext(&f.ctx, reinterpret_cast<void (*)()>(&gf_estimator_group::fiber_entry), 3, (unsigned)(self & 0xffffffffu), (unsigned)(self >> 32), i);
                 f.state = 1;
