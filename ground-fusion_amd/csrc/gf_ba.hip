@@ -168,7 +168,7 @@ int pack_slot(gf_ba* h, int b, const gf_ba_window& w) {
         if (w.gnss_enabled && (!d.GO || w.n_gnss > d.NG)) return gf::set_err(GF_ERR_CAPACITY, "window %d: %d GNSS factors, handle built for %d (gf_ba_cfg.max_gnss)", b, w.n_gnss, d.NG);
         if (w.gnss_enabled && (!w.para_rcv_dt || !w.para_rcv_ddt || !w.para_yaw_enu_local || !w.para_anc_ecef || !w.gnss_headers || !w.gnss_iono || (w.n_gnss > 0 && (!w.gnss_frame || !w.gnss_lower || !w.gnss_sys || !w.gnss_ratio || !w.gnss_data))))
             return gf::set_err(GF_ERR_INVALID, "window %d: GNSS enabled but a GNSS array is null", b);
-        { double* wp = h->wpar.h + 4 * (size_t)b; wp[0] = w.G[0]; wp[1] = w.G[1]; wp[2] = w.G[2]; wp[3] = w.vis_sqrt_info; }   // gravity and visual sqrt_info are per window (estimator.h `g`)
+        { double* wp = h->wpar.h + WPAR * (size_t)b; wp[0] = w.G[0]; wp[1] = w.G[1]; wp[2] = w.G[2]; wp[3] = w.vis_sqrt_info; wp[4] = (double)(w.ex_pose_mask & 63); wp[5] = (double)(w.ex_wheel_mask & 63); }   // gravity and visual sqrt_info are per window (estimator.h `g`)
         double* x = h->xs0.h + (size_t)b * d.XS;
         memset(x, 0, d.XS * sizeof(double));
         for (int i = 0; i < d.NP; i++) { memcpy(x + off_pose(i), w.para_Pose + 7 * i, 56); memcpy(x + off_sb(i), w.para_SpeedBias + 9 * i, 72); }
@@ -617,6 +617,16 @@ int run_marginalize(gf_ba* h, int mode) {
 
 extern "C" {
 
+int gf_pose_subset_mask(int extrinsic_type) {   // parameters.cpp:394-420 (camera), :280-306 (wheel) -> the index sets of estimator.cpp:2969-2985, :3010-3026 (index 6, qw, is no tangent component)
+    switch (extrinsic_type) {
+        case 0: return 0x00;          // ADJUST_*_ALL: {}
+        case 2: return 0x07;          // ADJUST_*_ROTATION: {0, 1, 2, 6}
+        case 3: return 0x04;          // ADJUST_*_NO_Z: {2, 6}
+        case 4: return 0x3c;          // ADJUST_*_NO_ROTATION_NO_Z: {2, 3, 4, 5, 6}
+        default: return 0x38;         // 1 = ADJUST_*_TRANSLATION: {3, 4, 5, 6}; out of range: the reference warns and keeps its zero-initialised enum, which is *_TRANSLATION
+    }
+}
+
 int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     if (!cfg || !out) return gf::set_err(GF_ERR_INVALID, "null argument");
     *out = nullptr;
@@ -661,7 +671,7 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     }
     h->st.n = h->st0.n = B;
     A_(h->imu_sqrt.alloc(B * d.W * 225, false)); A_(h->wh_sqrt.alloc(B * d.W * 36, false)); A_(h->pri_A.alloc(B * d.NPRI * d.NPRI, false)); A_(h->pri_b.alloc(B * d.NPRI, false));
-    A_(h->pri_c.alloc(B, false)); A_(h->H.alloc(2 * B * d.RP * d.RP, true)); A_(h->g.alloc(2 * B * d.RP, true)); A_(h->Vc.alloc(2 * B * d.NVC, true)); A_(h->wpar.alloc(B * 4, true));
+    A_(h->pri_c.alloc(B, false)); A_(h->H.alloc(2 * B * d.RP * d.RP, true)); A_(h->g.alloc(2 * B * d.RP, true)); A_(h->Vc.alloc(2 * B * d.NVC, true)); A_(h->wpar.alloc(B * WPAR, true));
     A_(h->cost.alloc(6 * B, true)); A_(h->efac.alloc(B * d.NV * EF, false));
     H_(hipMemsetAsync(h->cost.d, 0, 6 * B * sizeof(double), h->stream));
     A_(h->scale.alloc(B * VS, false)); A_(h->diag.alloc(B * VS, false)); A_(h->grad.alloc(B * VS, false)); A_(h->gn.alloc(B * VS, false)); A_(h->step.alloc(B * VS, false));

@@ -91,7 +91,7 @@ struct Win {  // device view of the whole batch
     double* cost;             // [3][2][B]     cost parts: prior + IMU + wheel, visual, GNSS; added in this order
     double* efac;             // [2][B][NV][EF] per-factor products of the eliminated column, rows in feature-list order (vis_pos)
     SolverState* st;          // [B]
-    const double* wpar;       // [B][4] per window: gravity G (3), visual sqrt_info
+    const double* wpar;       // [B][WPAR] per window: gravity G (3), visual sqrt_info, PoseSubsetParameterization masks of the camera / wheel extrinsic (as doubles)
     long long* stamps;        // optional phase timestamps of window 0 (profiling builds, -DGF_PROFILE_STEP)
     double* vtile;            // global home of the visual sweep's pair tiles when they do not fit LDS ([B][vtile_stride]); else null
     size_t vtile_stride;
@@ -104,6 +104,7 @@ struct Win {  // device view of the whole batch
     const int* gn_gitem;      // [B][NG] factor indices in group order
     double* gn_rows;          // [B][NG][38] scratch: residual (2) and Jacobian rows (2 x 18) of every GnssPsrDoppFactor
 };
+constexpr int WPAR = 6;
 constexpr int GN_STRIDE = 18, GN_MISC = 20;   // gn_misc is GN_MISC + NP doubles per window
 constexpr int IMU_STRIDE = 16 + 225 + 225;  // sum_dt, dp3, dq4, dv3, lba3, lbg3(=17 used incl. sum_dt -> 0..16) jac, cov
 constexpr int IMU_JAC = 17, IMU_COV = 17 + 225;
@@ -247,7 +248,7 @@ __device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int
             vd[0] = fi6[0]; vd[1] = fi6[1]; vd[2] = fi6[2]; vd[3] = fj6[0]; vd[4] = fj6[1]; vd[5] = fj6[2]; vd[6] = fi6[3]; vd[7] = fi6[4]; vd[8] = fj6[3]; vd[9] = fj6[4]; vd[10] = fi6[5]; vd[11] = fj6[5];
         }
         visual_eval(xs + off_pose(fi), xs + off_pose(fj), xs + off_ex(d.NP), xs[off_feat(d.NP) + feat], xs[off_td(d.NP)], vd,
-                    w.wpar[4 * b + 3], true, ev);
+                    w.wpar[WPAR * b + 3], true, ev);
         const double r0 = ev.row[0][13], r1 = ev.row[1][13];
         const double sq = r0 * r0 + r1 * r1;
         cost = live ? 0.5 * sq : 0.0;   // inlier (s <= 1): rho = s, rho' = 1, rho'' = 0 -- the corrector is the identity (sqrt_rho1 = residual_scaling = 1, alpha = 0)
@@ -1005,7 +1006,7 @@ __device__ __forceinline__ void ba_linearize_misc_body(Win w, int which, int whi
     if (wave == 0) {
         if (lane < nimu && imu_on(lane)) {
             const int k = lane, i = imu_i[k], j = i + 1;
-            imu_raw(xs + off_pose(i), xs + off_sb(i), xs + off_pose(j), xs + off_sb(j), w.imu_data + ((size_t)b * d.W + k) * IMU_STRIDE2, w.wpar + 4 * b, sJi + kMJi * k + 30,
+            imu_raw(xs + off_pose(i), xs + off_sb(i), xs + off_pose(j), xs + off_sb(j), w.imu_data + ((size_t)b * d.W + k) * IMU_STRIDE2, w.wpar + WPAR * b, sJi + kMJi * k + 30,
                     sJi + kMJi * k, true, true, 33, 33);
         }
         GF_WSTAMP_T(0, 66);
@@ -1897,7 +1898,16 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
             }
             if (c0 < 0) continue;
             const int gs = gsize_kind(kind);
-            if (gs == 7) pose_plus(xs + off, u + c0, xc + off);
+            if (gs == 7) {
+                if (kind == 2 || kind == 3) {   // PoseSubsetParameterization::Plus (pose_subset_parameterization.cpp:27-56): masked components of the increment are dropped -- here only;
+                                                // the columns, the step and the model cost change are those of the full block (its ComputeJacobian is the identity whatever the mask)
+                    const int mask = (int)w.wpar[WPAR * b + (kind == 2 ? 4 : 5)];
+                    double dm[6];
+#pragma unroll
+                    for (int q = 0; q < 6; q++) dm[q] = ((mask >> q) & 1) ? 0.0 : u[c0 + q];
+                    pose_plus(xs + off, dm, xc + off);
+                } else pose_plus(xs + off, u + c0, xc + off);
+            }
             else for (int q = 0; q < gs; q++) xc[off + q] = xs[off + q] + u[c0 + q];
             for (int q = 0; q < gs; q++) { const double dv = xs[off + q] - xc[off + q]; sn += dv * dv; xn += xs[off + q] * xs[off + q]; }
         }

@@ -1497,6 +1497,9 @@ struct gf_estimator {
             if ((cfg.estimate_wheel_extrinsic && frame_count == WINDOW_SIZE && moving) || openExWheelEstimation) openExWheelEstimation = 1; else w.fix_ex_wheel = 1;  // :3032-3041
             if ((cfg.estimate_wheel_intrinsic && frame_count == WINDOW_SIZE && moving) || openIxEstimation) openIxEstimation = 1; else w.fix_ix = 1;                 // :3045-3056
         } else { w.fix_ex_wheel = 1; w.fix_ix = 1; }
+        // PoseSubsetParameterization of the two extrinsics (EST:2969-2985, :3010-3026): chosen by ESTIMATE_EXTRINSIC[_WHEEL], whether or not the block is free yet
+        w.ex_pose_mask = cfg.estimate_extrinsic ? gf_pose_subset_mask(cfg.extrinsic_type) : 0;
+        w.ex_wheel_mask = (wheel_on && cfg.estimate_wheel_extrinsic) ? gf_pose_subset_mask(cfg.extrinsic_type_wheel) : 0;
         w.fix_td = (!cfg.estimate_td || norm(Vs[0]) < 0.2) ? 1 : 0;                                                                                      // :3097-3100
         w.fix_td_wheel = (!cfg.estimate_td_wheel || norm(Vs[0]) < 0.2) ? 1 : 0;
         if (gnss_ready) {   // :2904-2941: the GNSS blocks; yaw_enu_local is held constant, lowspeed drops the factors of this solve

@@ -178,15 +178,13 @@ int gf_estimator_cfg_from_yaml(const char* config_file, gf_estimator_cfg* c) {
         c->estimate_wheel_extrinsic = y.integer("estimate_wheel_extrinsic");
         if (c->estimate_wheel_extrinsic == 2) return gf::set_err(GF_ERR_INVALID, "%s: estimate_wheel_extrinsic: 2 (no prior) is not built", config_file);
         if (!take_transform(y, "body_T_wheel", c->rio, c->tio, err)) return gf::set_err(GF_ERR_INVALID, "%s: %s", config_file, err.c_str());
-        if (c->estimate_wheel_extrinsic && y.integer("extrinsic_type_wheel") != 0)
-            return gf::set_err(GF_ERR_INVALID, "%s: extrinsic_type_wheel %d: only 0 (ADJUST_WHEEL_ALL) is built", config_file, y.integer("extrinsic_type_wheel"));
+        if (c->estimate_wheel_extrinsic) c->extrinsic_type_wheel = y.integer("extrinsic_type_wheel");   // parameters.cpp:278-306 (read only when the wheel extrinsic is estimated)
         c->estimate_wheel_intrinsic = y.integer("estimate_wheel_intrinsic");
     }
     c->estimate_extrinsic = y.integer("estimate_extrinsic");
     if (c->estimate_extrinsic == 2) return gf::set_err(GF_ERR_INVALID, "%s: estimate_extrinsic: 2 (online calibration) is not built", config_file);
     if (!take_transform(y, "body_T_cam0", c->ric, c->tic, err)) return gf::set_err(GF_ERR_INVALID, "%s: %s", config_file, err.c_str());
-    if (c->estimate_extrinsic && y.integer("extrinsic_type") != 0)
-        return gf::set_err(GF_ERR_INVALID, "%s: extrinsic_type %d: only 0 (ADJUST_CAM_ALL) is built", config_file, y.integer("extrinsic_type"));
+    if (c->estimate_extrinsic) c->extrinsic_type = y.integer("extrinsic_type");                          // parameters.cpp:392-420
     c->td = y.real("td"); c->estimate_td = y.integer("estimate_td");
     c->td_wheel = y.real("td_wheel"); c->estimate_td_wheel = y.integer("estimate_td_wheel");
     if (!c->use_imu) { c->estimate_extrinsic = 0; c->estimate_td = 0; }      // parameters.cpp:508-513

@@ -475,7 +475,7 @@ class EstimatorCfg(C.Structure):
                [("tic", C.c_double * 3), ("ric", C.c_double * 9), ("tio", C.c_double * 3), ("rio", C.c_double * 9), ("tracker", TrackerCfg)] + \
                [(k, C.c_int) for k in ("gnss_enable", "gnss_track_num_thres", "max_gnss_per_frame")] + \
                [(k, C.c_double) for k in ("gnss_elevation_thres", "gnss_psr_std_thres", "gnss_dopp_std_thres", "gnss_ddt_sigma", "gnss_local_time_diff")] + \
-               [("gnss_iono", C.c_double * 8), ("max_solver_time", C.c_double)]
+               [("gnss_iono", C.c_double * 8), ("max_solver_time", C.c_double), ("extrinsic_type", C.c_int), ("extrinsic_type_wheel", C.c_int)]
 
 
 class GnssEphem(C.Structure):

@@ -41,7 +41,8 @@ class WindowC(C.Structure):
                 ("gnss_enabled", C.c_int), ("gnss_lowspeed", C.c_int), ("n_gnss", C.c_int), ("has_anchor", C.c_int),
                 ("para_rcv_dt", PD), ("para_rcv_ddt", PD), ("para_yaw_enu_local", PD), ("para_anc_ecef", PD),
                 ("gnss_ddt_weight", C.c_double), ("anchor_value", C.c_double * 7),
-                ("gnss_iono", PD), ("gnss_frame", PI), ("gnss_lower", PI), ("gnss_sys", PI), ("gnss_ratio", PD), ("gnss_data", PD), ("gnss_headers", PD)]
+                ("gnss_iono", PD), ("gnss_frame", PI), ("gnss_lower", PI), ("gnss_sys", PI), ("gnss_ratio", PD), ("gnss_data", PD), ("gnss_headers", PD),
+                ("ex_pose_mask", C.c_int), ("ex_wheel_mask", C.c_int)]
 
 
 class SummaryC(C.Structure):
@@ -56,7 +57,7 @@ _F64 = ["para_Pose", "para_SpeedBias", "para_Ex_Pose", "para_Ex_Pose_wheel", "pa
         "para_rcv_dt", "para_rcv_ddt", "para_yaw_enu_local", "para_anc_ecef", "gnss_iono", "gnss_ratio", "gnss_data", "gnss_headers"]
 _I32 = ["vis_feature", "vis_i", "vis_j", "imu_i", "wh_i", "prior_block_id", "gnss_frame", "gnss_lower", "gnss_sys"]
 _SCALARS = ["W", "n_feature", "n_visual", "n_imu", "n_wheel", "fix_ex_pose", "fix_ex_wheel", "fix_ix", "fix_td", "fix_td_wheel", "fix_poses",
-            "vis_sqrt_info", "prior_n", "prior_nblocks", "gnss_enabled", "gnss_lowspeed", "n_gnss", "has_anchor", "gnss_ddt_weight"]
+            "vis_sqrt_info", "prior_n", "prior_nblocks", "gnss_enabled", "gnss_lowspeed", "n_gnss", "has_anchor", "gnss_ddt_weight", "ex_pose_mask", "ex_wheel_mask"]
 STATE_KEYS = ["para_Pose", "para_SpeedBias", "para_Ex_Pose", "para_Ex_Pose_wheel", "para_Ix", "para_Td", "para_Td_wheel", "para_Feature",
               "para_rcv_dt", "para_rcv_ddt", "para_yaw_enu_local", "para_anc_ecef"]
 

@@ -183,7 +183,16 @@ typedef struct gf_ba_window {
     const double* gnss_ratio;    /* ts_ratio */
     const double* gnss_data;     /* n_gnss x 16 */
     const double* gnss_headers;  /* Headers[0..W]: DtDdtFactor(Headers[i+1] - Headers[i]), estimator.cpp:3214-3223 */
+    /* PoseSubsetParameterization (pose_subset_parameterization.cpp:10-56) of the camera / wheel extrinsic, estimator.cpp:2969-2985, :3010-3026:
+     * bit q (0-2 translation, 3-5 rotation) set = component q of the block's increment is zeroed in Plus.  The block keeps its six columns and the
+     * solver its full step (ComputeJacobian stays the identity: the reference's quirk); only the candidate point is masked.  0 = ADJUST_*_ALL.
+     * Use gf_pose_subset_mask(extrinsic_type) for the YAML values. */
+    int ex_pose_mask, ex_wheel_mask;
 } gf_ba_window;
+
+/* `extrinsic_type` / `extrinsic_type_wheel` of the YAML files (parameters.cpp:280-306, :394-420) -> constancy mask: 0 ALL {}, 1 TRANSLATION {3,4,5},
+ * 2 ROTATION {0,1,2}, 3 NO_Z {2}, 4 NO_ROTATION_NO_Z {2,3,4,5}; any other value leaves the reference's zero-initialised enum = *_TRANSLATION. */
+int gf_pose_subset_mask(int extrinsic_type);
 
 typedef struct gf_ba_summary {
     int iterations, successful_steps, termination; /* 0 max iterations, 1 function tol, 2 parameter tol, 3 gradient tol, 4 failure */
@@ -325,6 +334,9 @@ typedef struct gf_estimator_cfg {
      * (estimator.cpp:3312-3315).  0 = not honoured (parity runs: the oracle counts iterations only).  A wall-clock cut makes the members of one
      * batch end after different iteration counts depending on who shares the batch, so gf_estimator_group_create refuses a value > 0. */
     double max_solver_time;
+    /* extrinsic_type / extrinsic_type_wheel (parameters.cpp:394-420, :280-306): which components of the camera / wheel extrinsic the solver may move
+     * once the block is free (estimate_extrinsic / estimate_wheel_extrinsic): 0 all, 1 translation, 2 rotation, 3 no z, 4 no rotation and no z */
+    int extrinsic_type, extrinsic_type_wheel;
 } gf_estimator_cfg;
 
 /* One L1 observation of a GNSS epoch as Estimator::inputGNSS receives it (ObsPtr), together with what GnssPsrDoppFactor's constructor derives from
@@ -440,7 +452,7 @@ int gf_estimator_group_stats(gf_estimator_group* g, long long* batches, long lon
  * (PinholeCamera::Parameters::readFromYamlFile, camera_models/src/camera_models/PinholeCamera.cc:145-183; path relative to the config
  * file's directory, parameters.cpp:436-443).  Same key names and cv::FileNode defaults (a missing numeric key reads as 0).  Fills the
  * whole cfg including cfg->tracker and sets with_tracker = 1 (gnss_enable and its gnss_* keys are read, parameters.cpp:519-552).  Options
- * outside the built path (use_line, use_yolo, plane, equalize, use_motion, num_of_cam 2, estimate_extrinsic 2, subset extrinsic_type,
+ * outside the built path (use_line, use_yolo, plane, equalize, use_motion, num_of_cam 2, estimate_extrinsic 2,
  * gnss_local_online_sync) return GF_ERR_INVALID instead of being ignored. */
 int gf_estimator_cfg_from_yaml(const char* config_file, gf_estimator_cfg* cfg);
 /* the line pubOdometry appends to VINS_RESULT_PATH (utility/visualization.cpp:346-357): "t x y z qx qy qz qw", fixed, 9 decimals;

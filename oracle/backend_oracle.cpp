@@ -960,6 +960,10 @@ static int solve(gfo_window* w, int max_iters, gfo_summary* sum) {
             const int kind = id / 4096, c0 = P.col_of.at(id), ls = lsize_of(kind);
             double d[9];
             for (int i = 0; i < ls; i++) d[i] = step[c0 + i] * scale[c0 + i];
+            // PoseSubsetParameterization::Plus (pose_subset_parameterization.cpp:27-56): masked components of the increment are dropped; the Jacobian
+            // the solver saw is the full one (ComputeJacobian :57-64 is the identity whatever the mask), so step, model cost change and radius are those of
+            // the unmasked block -- only the evaluated point differs
+            if (kind == EX_POSE || kind == EX_WHEEL) { const int mask = kind == EX_POSE ? w->ex_pose_mask : w->ex_wheel_mask; for (int i = 0; i < 6; i++) if ((mask >> i) & 1) d[i] = 0.0; }
             plus_block(kind, x.ptr(id), d, cand.ptr(id));
         }
         const double cand_cost = P.evaluate(cand, nullptr);

@@ -31,8 +31,15 @@ def default_cfg():
                 tio=np.array([0.0497956, 1.06332, -0.037465]),
                 rio=np.array([[0.352551, -0.935764, -0.00734672], [0.0145238, 0.0133214, -0.999806], [0.93568, 0.352375, 0.0182873]]),
                 gnss_enable=0, gnss_track_num_thres=5, gnss_elevation_thres=30.0, gnss_psr_std_thres=2.0, gnss_dopp_std_thres=2.0, gnss_ddt_sigma=0.1,
-                gnss_local_time_diff=18.0,
+                gnss_local_time_diff=18.0, extrinsic_type=0, extrinsic_type_wheel=0,
                 gnss_iono=np.array([0.1118e-07, 0.2235e-07, -0.4172e-06, 0.6557e-06, 0.1249e+06, -0.4424e+06, 0.1507e+07, -0.2621e+06]))
+
+
+def subset_mask(extrinsic_type):
+    """YAML extrinsic_type[_wheel] -> constancy bits of PoseSubsetParameterization (parameters.cpp:394-420 / :280-306 select the enum, estimator.cpp:2969-2985 /
+    :3010-3026 the index sets; an out-of-range value leaves the zero-initialised enum, which is ADJUST_*_TRANSLATION)"""
+    sets = {0: (), 2: (0, 1, 2), 3: (2,), 4: (2, 3, 4, 5)}
+    return sum(1 << i for i in sets.get(int(extrinsic_type), (3, 4, 5)))
 
 
 # ---------------------------------------------------------------- gnss_comm helpers the estimator itself calls (ecef2geo, ecef2rotation, sat_azel; RTKLIB lineage)
@@ -1374,6 +1381,9 @@ class Estimator:
                 w["fix_ix"] = 1
         else:
             w["fix_ex_wheel"] = w["fix_ix"] = 1
+        # PoseSubsetParameterization masks (EST:2969-2985, :3010-3026; YAML values parameters.cpp:394-420, :280-306)
+        w["ex_pose_mask"] = subset_mask(c.get("extrinsic_type", 0)) if c["estimate_extrinsic"] else 0
+        w["ex_wheel_mask"] = subset_mask(c.get("extrinsic_type_wheel", 0)) if (wheel_on and c["estimate_wheel_extrinsic"]) else 0
         still = np.linalg.norm(self.Vs[0]) < 0.2
         w["fix_td"] = 1 if (not c["estimate_td"] or still) else 0
         w["fix_td_wheel"] = 1 if (not c["estimate_td_wheel"] or still) else 0

@@ -86,6 +86,9 @@ typedef struct gfo_window {
     const double* gnss_ratio;    /* ts_ratio */
     const double* gnss_data;     /* n_gnss x 16 */
     const double* gnss_headers;  /* Headers[0..W]: DtDdtFactor(Headers[i+1] - Headers[i]), estimator.cpp:3214-3223 */
+    /* PoseSubsetParameterization constancy masks of the camera / wheel extrinsic (pose_subset_parameterization.cpp:10-56; estimator.cpp:2969-2985, :3010-3026):
+     * bit q set = increment component q is zeroed in Plus */
+    int ex_pose_mask, ex_wheel_mask;
 } gfo_window;
 
 typedef struct gfo_summary {

@@ -56,6 +56,38 @@ def test_solve_matches_oracle_poses(gf, oracle, seed, kw):
     est.close()
 
 
+@pytest.mark.parametrize("block,mask", [("ex_pose", 0x04), ("ex_pose", 0x07), ("ex_pose", 0x38), ("ex_pose", 0x3c), ("ex_wheel", 0x04), ("ex_wheel", 0x07),
+                                        ("ex_wheel", 0x38), ("ex_wheel", 0x3c)])
+def test_subset_parameterisation_masks_match_oracle(gf, oracle, block, mask):
+    """PoseSubsetParameterization (pose_subset_parameterization.cpp:27-64) on the camera extrinsic (EST:2969-2985, `estimate_extrinsic: 1` with extrinsic_type 3 NO_Z,
+    2 ROTATION, 1 TRANSLATION, 4 NO_ROTATION_NO_Z) and on the wheel extrinsic (EST:3010-3026): the block keeps six columns with full Jacobians, Plus drops the masked
+    increments.  Same iteration / step counts as the oracle, poses 1e-6, and the masked components never move."""
+    kw = {"fix_ex_pose": 0} if block == "ex_pose" else {"fix_ex_wheel": 0}
+    w0 = SW.make_window(21 if block == "ex_pose" else 22, oracle, **kw)
+    w0["%s_mask" % block] = mask
+    key = "para_Ex_Pose" if block == "ex_pose" else "para_Ex_Pose_wheel"
+    wo, wg, wfree = w0.copy(), w0.copy(), w0.copy()
+    wfree["%s_mask" % block] = 0
+    so = oracle.ba_solve(wo, 8)
+    est = gf.Estimator()
+    sg = est.solve([wg], 8)[0]
+    est.solve([wfree], 8)
+    est.close()
+    assert sg["iterations"] == so["iterations"] and sg["successful_steps"] == so["successful_steps"] and sg["termination"] == so["termination"]
+    assert abs(sg["final_cost"] - so["final_cost"]) <= 1e-8 * so["final_cost"]
+    dp, dr = _pose_diff(wo, wg)
+    assert dp < 1e-6 and dr < 1e-6, (dp, dr)
+    for k in ("para_SpeedBias", "para_Feature", "para_Ex_Pose", "para_Ex_Pose_wheel"):
+        assert (np.abs(wo[k] - wg[k]) / np.maximum(1.0, np.abs(wo[k]))).max() < 1e-6, k
+    e0, eg = w0[key], wg[key]
+    if mask & 0x07:
+        held = [i for i in range(3) if (mask >> i) & 1]
+        assert np.array_equal(e0[held], eg[held])                 # x + 0 is exact
+    if (mask & 0x38) == 0x38:
+        assert np.abs(e0[3:] - eg[3:]).max() < 1e-15              # q * deltaQ(0), normalised: the same quaternion up to rounding
+    assert np.abs(wfree[key] - eg).max() > 1e-6                   # and the mask does change the result (the unmasked block moves in those components)
+
+
 def test_batched_solve_matches_single(gf, oracle):
     wins = [SW.make_window(10 + b, oracle) for b in range(5)]
     ref = [w.copy() for w in wins]

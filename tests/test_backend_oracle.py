@@ -249,3 +249,25 @@ def test_gnss_window_solves_and_marginalises(oracle):
     s4 = oracle.ba_solve(nog, 8)
     assert abs(s3["final_cost"] - s4["final_cost"]) < 1e-9 * s4["final_cost"]            # low speed: GNSS factors stay out of the solve
     assert oracle.ba_marginalize(lo, 0)["n"] == p["n"]                                    # ... but not out of the marginalisation
+
+
+@pytest.mark.parametrize("block,mask", [("ex_pose", 0x04), ("ex_pose", 0x3c), ("ex_wheel", 0x07), ("ex_wheel", 0x38)])
+def test_subset_parameterisation_holds_the_masked_components(oracle, block, mask):
+    """PoseSubsetParameterization::Plus (pose_subset_parameterization.cpp:27-56) zeroes the masked increments, ComputeJacobian (:57-64) is the identity: the solver
+    works on the full block and only the candidate point is masked (EST:2969-2985 camera, :3010-3026 wheel)"""
+    import synth_window as SW
+    kw = {"fix_ex_pose": 0} if block == "ex_pose" else {"fix_ex_wheel": 0}
+    w0 = SW.make_window(21 if block == "ex_pose" else 22, oracle, **kw)
+    key = "para_Ex_Pose" if block == "ex_pose" else "para_Ex_Pose_wheel"
+    wm, wf = w0.copy(), w0.copy()
+    wm["%s_mask" % block] = mask
+    sm, sf = oracle.ba_solve(wm, 8), oracle.ba_solve(wf, 8)
+    assert sm["final_cost"] < sm["initial_cost"] and sf["final_cost"] <= sm["final_cost"] * (1 + 1e-9)   # fewer degrees of freedom cannot do better
+    held = [i for i in range(3) if (mask >> i) & 1]
+    assert np.array_equal(w0[key][held], wm[key][held])
+    if (mask & 0x38) == 0x38:
+        assert np.abs(w0[key][3:] - wm[key][3:]).max() < 1e-15
+    free = [i for i in range(3) if not (mask >> i) & 1]
+    if free:
+        assert np.abs(w0[key][free] - wm[key][free]).max() > 1e-9
+    assert np.abs(wf[key] - wm[key]).max() > 1e-6

@@ -136,12 +136,14 @@ def test_replay_from_a_moving_start_initialises_through_sfm(use_wheel):
     est_p.close()
 
 
-@pytest.mark.parametrize("variant", ["use_mcc", "estimate_td", "wheel_slip"])
+@pytest.mark.parametrize("variant", ["use_mcc", "estimate_td", "wheel_slip", "subset_cam", "subset_wheel"])
 def test_replay_configurations_of_the_other_shipped_yaml_files(variant):
     """what the m2dgrp.yaml replays leave untouched: use_mcc: 1 (groundchallenge.yaml:10, idc_rs.yaml:13 -- the consistency check's outliers now reach
     removeOutlier and the tracker feedback, estimator.cpp:1104-1134), estimate_td: 1 (td becomes a free block once the vehicle moves, :3097-3100), and
     a wheel-slip segment (`wdetect`: |dP_wheel - dP_imu| > 0.02 raises wheelanomaly, the wheel factors of that frame are skipped in the solve and in
-    the marginalisation, :633, :3132-3136, :3370).  Same bars as the other replays."""
+    the marginalisation, :633, :3132-3136, :3370), and the PoseSubsetParameterization masks every shipped file selects (`extrinsic_type: 3` = ADJUST_CAM_NO_Z with
+    `estimate_extrinsic: 1`, :2969-2985; the same type on the wheel extrinsic, :3010-3026): the block becomes free once the vehicle moves, its z never does.
+    Same bars as the other replays."""
     st = make_stream(2)
     st._lm = st._landmarks(1600)
     st._pn = np.random.default_rng(4002).normal(0, 1.0, (len(st.cam_t), len(st._lm), 2))
@@ -150,6 +152,10 @@ def test_replay_configurations_of_the_other_shipped_yaml_files(variant):
         kw["use_mcc"] = 1
     if variant == "estimate_td":
         kw["estimate_td"] = 1
+    if variant == "subset_cam":
+        kw.update(estimate_extrinsic=1, extrinsic_type=3)
+    if variant == "subset_wheel":
+        kw.update(estimate_wheel_extrinsic=1, extrinsic_type_wheel=3)
     if variant == "wheel_slip":      # the odometer over-reports for 0.5 s in the middle of the drive (wheel spin)
         sel = (st.wheel_t > 3.0) & (st.wheel_t < 3.5)
         st.wheel_vel[sel] *= 1.6
@@ -169,7 +175,15 @@ def test_replay_configurations_of_the_other_shipped_yaml_files(variant):
         s = est_p.state()
         assert abs(s["td"] - est_o.td) < 1e-6      # seconds; observed 7e-9 on a td of 12 ms
         td_free += int(abs(est_o.td) > 0)
+        if variant == "subset_cam":
+            assert s["tic"][2] == 0.0 == est_o.tic[2] and np.abs(s["tic"] - est_o.tic).max() < 1e-6 * max(1.0, np.abs(est_o.tic).max())
+        if variant == "subset_wheel":
+            assert s["tio"][2] == SS.TIO[2] == est_o.tio[2]
     assert est_o.solver_flag == EO.NON_LINEAR and est_o.n_optimizations > 30
+    if variant == "subset_cam":
+        assert est_o.openExEstimation and np.abs(est_o.tic[:2]).max() > 1e-3      # the block was free and moved where the mask lets it
+    if variant == "subset_wheel":
+        assert est_o.openExWheelEstimation and np.abs(est_o.tio[:2] - np.asarray(SS.TIO)[:2]).max() > 0
     if variant == "estimate_td":
         assert td_free > 5          # td really was estimated
     if variant == "wheel_slip":

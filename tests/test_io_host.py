@@ -114,6 +114,22 @@ def test_yaml_reader_follows_read_parameters(tmp_path):
     assert (t.fx, t.fy, t.cx, t.cy, t.k1, t.k2, t.p1, t.p2) == (611.5, 610.25, 320.5, 241.0, -0.01, 0.002, 1.0e-4, -2.0e-4)
 
 
+def test_yaml_reader_takes_the_subset_parameterisation_types(tmp_path):
+    """extrinsic_type / extrinsic_type_wheel (parameters.cpp:394-420, :280-306) select PoseSubsetParameterization masks (EST:2969-2985, :3010-3026); every shipped
+    config/realsense/*.yaml says extrinsic_type: 3.  The wheel key is only read when the wheel extrinsic is estimated."""
+    c = gfamd.estimator_cfg_from_yaml(write_cfg(tmp_path, CFG.replace("extrinsic_type: 0", "extrinsic_type: 3")))
+    assert (c.estimate_extrinsic, c.extrinsic_type, c.extrinsic_type_wheel) == (1, 3, 0)
+    c = gfamd.estimator_cfg_from_yaml(write_cfg(tmp_path, CFG.replace("estimate_wheel_extrinsic: 0", "estimate_wheel_extrinsic: 1\nextrinsic_type_wheel: 4")))
+    assert (c.estimate_wheel_extrinsic, c.extrinsic_type_wheel) == (1, 4)
+    c = gfamd.estimator_cfg_from_yaml(write_cfg(tmp_path, CFG.replace("estimate_extrinsic: 1", "estimate_extrinsic: 0").replace("extrinsic_type: 0", "extrinsic_type: 3")))
+    assert (c.estimate_extrinsic, c.extrinsic_type) == (0, 0)      # not read when the extrinsic is fixed (parameters.cpp:392)
+    lib = gfamd.lib()
+    assert [lib.gf_pose_subset_mask(t) for t in (0, 1, 2, 3, 4)] == [0x00, 0x38, 0x07, 0x04, 0x3c]
+    assert lib.gf_pose_subset_mask(7) == 0x38                      # out of range: the reference warns and keeps its zero-initialised enum = *_TRANSLATION
+    import estimator_oracle
+    assert [estimator_oracle.subset_mask(t) for t in (0, 1, 2, 3, 4, 7)] == [0x00, 0x38, 0x07, 0x04, 0x3c, 0x38]
+
+
 GNSS_KEYS = """gnss_local_online_sync: 0
 gnss_local_time_diff: 18.0
 gnss_elevation_thres: 30
@@ -144,7 +160,6 @@ def test_yaml_reader_takes_the_gnss_keys(tmp_path):
     (("gnss_enable: 0", "gnss_enable: 1\n" + GNSS_KEYS.replace("gnss_local_online_sync: 0", "gnss_local_online_sync: 1")), "gnss_local_online_sync"),
     (("num_of_cam: 1", "num_of_cam: 2"), "num_of_cam"),
     (("estimate_extrinsic: 1", "estimate_extrinsic: 2"), "estimate_extrinsic"),
-    (("extrinsic_type: 0", "extrinsic_type: 3"), "extrinsic_type"),
     (("w_replace: 1", "w_replace: 1\nuse_line: 1"), "use_line"),
     (("cam0_calib: \"cam_x.yaml\"", "cam0_calib: \"nope.yaml\""), "cannot open"),
     (("0.     ,     0.     ,     0.  ,        1.     ]", "0., 0., 0. ]"), "rows*cols"),
