@@ -6,7 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "lib", "libgroundfusion_hip.so")
 SRCS = [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc"))) if f.endswith(".hip")]
-DEPS = [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))] + [os.path.join(HERE, "..", "include", "groundfusion_hip.h")]
+DEPS = [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))] + [os.path.join(HERE, "..", "include", "groundfusion_hip.h"),
+                                                                                              os.path.join(HERE, "host", "rosbag_reader.h")]   # csrc/gf_io.hip includes it
 # the ROS-free replay tool (tools/gf_replay.cpp, host code on top of the C-ABI)
 TOOL = os.path.join(HERE, "..", "bin", "gf_replay")
 TOOL_SRC = os.path.join(HERE, "..", "tools", "gf_replay.cpp")

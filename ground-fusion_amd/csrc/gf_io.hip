@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/groundfusion_hip.h"
+#include "../host/rosbag_reader.h"
 #include "gf_dmath.hpp"
 
 namespace gf { int set_err(int code, const char* fmt, ...); }
@@ -267,6 +268,69 @@ int gf_pgm_read(const char* path, int* width, int* height, int* maxval, void* pi
         unsigned char* p = (unsigned char*)pixels;
         for (size_t i = 0; i < need; i += 2) std::swap(p[i], p[i + 1]);
     }
+    return GF_OK;
+}
+
+// ---------------------------------------------------------------- ROS bag files (host/rosbag_reader.h behind the C-ABI)
+struct gf_bag {
+    gf::BagReader reader;
+    std::vector<gf::BagMessageRef> sel;
+    explicit gf_bag(const char* path) : reader(path) {}
+};
+#define GF_BAG_TRY(body) try { body } catch (const std::exception& e) { return gf::set_err(GF_ERR_INVALID, "%s", e.what()); }
+
+int gf_bag_open(const char* path, gf_bag** out) {
+    if (!path || !out) return gf::set_err(GF_ERR_INVALID, "null argument");
+    GF_BAG_TRY(*out = new gf_bag(path);)
+    return GF_OK;
+}
+int gf_bag_close(gf_bag* b) { delete b; return GF_OK; }
+int gf_bag_connection_count(gf_bag* b) { return b ? (int)b->reader.connections().size() : 0; }
+int gf_bag_connection(gf_bag* b, int i, int* conn_id, char* topic, int topic_cap, char* type, int type_cap) {
+    if (!b || i < 0 || i >= (int)b->reader.connections().size()) return gf::set_err(GF_ERR_INVALID, "connection index out of range");
+    const gf::BagConnection& c = b->reader.connections()[i];
+    if (conn_id) *conn_id = (int)c.id;
+    if (topic && topic_cap > 0) snprintf(topic, topic_cap, "%s", c.topic.c_str());
+    if (type && type_cap > 0) snprintf(type, type_cap, "%s", c.type.c_str());
+    return GF_OK;
+}
+int gf_bag_select(gf_bag* b, const char* const* topics, int n_topics, long long* count) {
+    if (!b || (n_topics > 0 && !topics)) return gf::set_err(GF_ERR_INVALID, "null argument");
+    std::vector<std::string> t;
+    for (int i = 0; i < n_topics; i++) t.push_back(topics[i] ? topics[i] : "");
+    GF_BAG_TRY(b->sel = b->reader.select(t);)
+    if (count) *count = (long long)b->sel.size();
+    return GF_OK;
+}
+int gf_bag_message(gf_bag* b, long long i, int* conn_id, double* t_record, const unsigned char** data, size_t* len) {
+    if (!b || !data || !len || i < 0 || i >= (long long)b->sel.size()) return gf::set_err(GF_ERR_INVALID, "message index out of range");
+    const gf::BagMessageRef& m = b->sel[(size_t)i];
+    if (conn_id) *conn_id = (int)m.conn;
+    if (t_record) *t_record = (double)(m.time_ns / 1000000000ull) + 1e-9 * (double)(m.time_ns % 1000000000ull);
+    GF_BAG_TRY(*data = b->reader.payload(m, len);)
+    return GF_OK;
+}
+int gf_ros_decode_imu(const unsigned char* data, size_t len, double* t, double* acc, double* gyr) {
+    if (!data || !t || !acc || !gyr) return gf::set_err(GF_ERR_INVALID, "null argument");
+    GF_BAG_TRY(gf::ros_decode_imu(data, len, t, acc, gyr);)
+    return GF_OK;
+}
+int gf_ros_decode_odometry(const unsigned char* data, size_t len, double* t, double* linear, double* angular, double* position) {
+    if (!data || !t || !linear || !angular) return gf::set_err(GF_ERR_INVALID, "null argument");
+    GF_BAG_TRY(gf::ros_decode_odometry(data, len, t, linear, angular, position);)
+    return GF_OK;
+}
+int gf_ros_decode_image(const unsigned char* data, size_t len, int depth, double* t, int* width, int* height, void* pixels, size_t cap_bytes) {
+    if (!data || !t || !width || !height) return gf::set_err(GF_ERR_INVALID, "null argument");
+    GF_BAG_TRY(
+        const gf::RosImage m = gf::ros_image(data, len);
+        *t = m.header.stamp(); *width = (int)m.width; *height = (int)m.height;
+        if (!pixels) return GF_OK;
+        const size_t need = (size_t)m.width * m.height * (depth ? 2 : 1);
+        if (cap_bytes < need) return gf::set_err(GF_ERR_CAPACITY, "image needs %zu bytes, caller gave %zu", need, cap_bytes);
+        if (depth) { std::vector<uint16_t> o; gf::ros_image_to_mono16(m, o); memcpy(pixels, o.data(), need); }
+        else { std::vector<uint8_t> o; gf::ros_image_to_mono8(m, o); memcpy(pixels, o.data(), need); }
+    )
     return GF_OK;
 }
 

@@ -790,3 +790,59 @@ class EstimatorGroup:
         b, w, l = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
         _chk(lib().gf_estimator_group_stats(self.g, C.byref(b), C.byref(w), C.byref(l)))
         return {"batches": b.value, "windows": w.value, "largest_batch": l.value}
+
+
+# ------------------------------------------------------------------ ROS bag files (gf_bag_*, gf_ros_decode_*)
+class Bag:
+    """rosbag play without ROS: connections, messages of chosen topics in play order, and the three message types the node subscribes to."""
+
+    def __init__(self, path):
+        self.h = C.c_void_p()
+        _chk(lib().gf_bag_open(str(path).encode(), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gf_bag_close(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def connections(self):
+        out = []
+        for i in range(lib().gf_bag_connection_count(self.h)):
+            cid, topic, typ = C.c_int(), C.create_string_buffer(256), C.create_string_buffer(256)
+            _chk(lib().gf_bag_connection(self.h, i, C.byref(cid), topic, 256, typ, 256))
+            out.append((cid.value, topic.value.decode(), typ.value.decode()))
+        return out
+
+    def select(self, topics=()):
+        arr = (C.c_char_p * max(len(topics), 1))(*[t.encode() for t in topics])
+        n = C.c_longlong()
+        _chk(lib().gf_bag_select(self.h, arr, len(topics), C.byref(n)))
+        return n.value
+
+    def message(self, i):
+        """(connection id, record time, payload bytes)"""
+        cid, t, data, ln = C.c_int(), C.c_double(), C.POINTER(C.c_ubyte)(), C.c_size_t()
+        _chk(lib().gf_bag_message(self.h, C.c_longlong(i), C.byref(cid), C.byref(t), C.byref(data), C.byref(ln)))
+        return cid.value, t.value, C.string_at(data, ln.value)
+
+
+def ros_decode_imu(payload):
+    t, acc, gyr = C.c_double(), np.zeros(3), np.zeros(3)
+    _chk(lib().gf_ros_decode_imu(payload, C.c_size_t(len(payload)), C.byref(t), _p(acc, C.c_double), _p(gyr, C.c_double)))
+    return t.value, acc, gyr
+
+
+def ros_decode_odometry(payload):
+    t, lin, ang, pos = C.c_double(), np.zeros(3), np.zeros(3), np.zeros(3)
+    _chk(lib().gf_ros_decode_odometry(payload, C.c_size_t(len(payload)), C.byref(t), _p(lin, C.c_double), _p(ang, C.c_double), _p(pos, C.c_double)))
+    return t.value, lin, ang, pos
+
+
+def ros_decode_image(payload, depth=False):
+    t, w, h = C.c_double(), C.c_int(), C.c_int()
+    _chk(lib().gf_ros_decode_image(payload, C.c_size_t(len(payload)), int(depth), C.byref(t), C.byref(w), C.byref(h), None, C.c_size_t(0)))
+    out = np.zeros((h.value, w.value), np.uint16 if depth else np.uint8)
+    _chk(lib().gf_ros_decode_image(payload, C.c_size_t(len(payload)), int(depth), C.byref(t), C.byref(w), C.byref(h), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes)))
+    return t.value, out

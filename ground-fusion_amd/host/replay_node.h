@@ -4,6 +4,8 @@
 //   img0_callback / img1_callback :59-71       sync_process    :290-470 (RGB / depth pairing within 3 ms, the non-YOLO branch)
 // Est is gf::Estimator (estimator.h) in the tool; the unit test substitutes a recorder.  Frames are read from binary PGM files
 // (8-bit gray = MONO8, 16-bit = MONO16 depth in mm) when their pair is formed, not when their message is queued.
+// run_bag() drives the same callbacks from a ROS bag (format 2.0, host/rosbag_reader.h) the way `rosbag play` would: messages of the four topics in record-time
+// order, sensor_msgs/Image converted as getImageFromMsg / getDepthImageFromMsg do (rosNodeTest.cpp:238-288) when their pair is formed.
 //
 // Dataset directory read by load():   imu.csv  t,ax,ay,az,gx,gy,gz     wheel.csv  t,vx,vy,vz,wx,wy,wz     (nav_msgs/Odometry twist)
 //                                     image0.csv  t,file               image1.csv  t,file                 (files relative to the directory)
@@ -22,12 +24,13 @@
 #include <vector>
 
 #include "estimator.h"
+#include "rosbag_reader.h"
 
 namespace gf {
 
 struct ImuMsg { double t; Vec3 linear_acceleration, angular_velocity; };
 struct OdomMsg { double t; Vec3 linear, angular; };
-struct ImageMsg { double t; std::string file; };
+struct ImageMsg { double t; std::string file; BagMessageRef ref{}; bool in_bag = false; };
 struct GnssMsg { double t; std::vector<gf_gnss_obs> meas; };
 struct GnssAlignMsg { double t; Vec3 anc; double yaw, dt[4], ddt; };
 
@@ -85,8 +88,8 @@ template <class Est> class ReplayNode {
             if (time0 < time1 - 0.003) { img0_buf.pop_front(); n_thrown0++; continue; }
             if (time0 > time1 + 0.003) { img1_buf.pop_front(); n_thrown1++; continue; }
             const double time = time0;
-            load_pgm(dir + "/" + img0_buf.front().file, gray_, sizeof(uint8_t), gw_, gh_);
-            load_pgm(dir + "/" + img1_buf.front().file, depth_, sizeof(uint16_t), dw_, dh_);
+            load_frame(dir, img0_buf.front(), false);
+            load_frame(dir, img1_buf.front(), true);
             img0_buf.pop_front(); img1_buf.pop_front();
             if (gw_ != dw_ || gh_ != dh_) throw std::runtime_error("replay: gray and depth frames differ in size");
             GrayImage g; g.data = gray_.data(); g.rows = gh_; g.cols = gw_; g.stride = gw_;
@@ -120,6 +123,43 @@ template <class Est> class ReplayNode {
             else { img1_callback(im1[e.idx]); sync_process(dir); }
         }
     }
+    // `rosbag play <bag>` into the four subscribers of rosNodeTest.cpp:678-682: messages in record-time order (ties in file order); the callbacks read the
+    // header stamps, as the node does.  GNSS topics carry gnss_comm message types and are not read from the bag.
+    void run_bag(const std::string& bag_path, const std::string& imu_topic, const std::string& wheel_topic, const std::string& image0_topic, const std::string& image1_topic) {
+        BagReader bag(bag_path);
+        bag_ = &bag;
+        std::vector<std::string> topics;
+        for (const std::string& t : {imu_topic, wheel_topic, image0_topic, image1_topic}) if (!t.empty()) topics.push_back(t);
+        std::map<uint32_t, int> kind;   // connection id -> 0 imu, 1 wheel, 2 image0, 3 image1
+        for (const BagConnection& c : bag.connections()) {
+            const int k = c.topic == imu_topic ? 0 : c.topic == wheel_topic ? 1 : c.topic == image0_topic ? 2 : c.topic == image1_topic ? 3 : -1;
+            if (k < 0) continue;
+            const char* want = k == 0 ? "sensor_msgs/Imu" : k == 1 ? "nav_msgs/Odometry" : "sensor_msgs/Image";
+            if (c.type != want) throw std::runtime_error("replay: topic " + c.topic + " carries " + c.type + ", the node subscribes it as " + want);
+            kind[c.id] = k;
+        }
+        for (const std::string& t : topics) {
+            bool found = false;
+            for (const BagConnection& c : bag.connections()) found |= c.topic == t;
+            if (!found) fprintf(stderr, "replay: topic %s is not in %s\n", t.c_str(), bag_path.c_str());
+        }
+        try {
+            for (const BagMessageRef& m : bag.select(topics)) {
+                const int k = kind.at(m.conn);
+                size_t len = 0;
+                const uint8_t* d = bag.payload(m, &len);
+                if (k == 0) { ImuMsg im; double a[3], g[3]; ros_decode_imu(d, len, &im.t, a, g); for (int q = 0; q < 3; q++) { im.linear_acceleration[q] = a[q]; im.angular_velocity[q] = g[q]; } imu_callback(im); }
+                else if (k == 1) { OdomMsg om; double l[3], a[3]; ros_decode_odometry(d, len, &om.t, l, a, nullptr); for (int q = 0; q < 3; q++) { om.linear[q] = l[q]; om.angular[q] = a[q]; } wheel_callback(om); }
+                else {
+                    BagCursor c(d, len);
+                    ImageMsg im; im.t = ros_header(c).stamp(); im.ref = m; im.in_bag = true;   // the pixels stay in the bag until the pair is formed
+                    if (k == 2) img0_callback(im); else img1_callback(im);
+                    sync_process("");
+                }
+            }
+        } catch (...) { bag_ = nullptr; throw; }
+        bag_ = nullptr;
+    }
     // gnss.csv / gnss_align.csv are optional: a dataset without them replays as before
     static void load_gnss(const std::string& dir, std::vector<GnssMsg>& gn, std::vector<GnssAlignMsg>& al) {
         if (std::ifstream(dir + "/gnss.csv"))
@@ -152,6 +192,17 @@ template <class Est> class ReplayNode {
   private:
     std::vector<uint8_t> gray_, depth_;
     int gw_ = 0, gh_ = 0, dw_ = 0, dh_ = 0;
+    BagReader* bag_ = nullptr;
+    std::vector<uint16_t> depth16_;
+
+    void load_frame(const std::string& dir, const ImageMsg& m, bool depth) {
+        if (!m.in_bag) { if (depth) load_pgm(dir + "/" + m.file, depth_, sizeof(uint16_t), dw_, dh_); else load_pgm(dir + "/" + m.file, gray_, sizeof(uint8_t), gw_, gh_); return; }
+        size_t len = 0;
+        const uint8_t* d = bag_->payload(m.ref, &len);
+        const RosImage im = ros_image(d, len);
+        if (depth) { ros_image_to_mono16(im, depth16_); depth_.resize(depth16_.size() * 2); memcpy(depth_.data(), depth16_.data(), depth_.size()); dw_ = (int)im.width; dh_ = (int)im.height; }
+        else { ros_image_to_mono8(im, gray_); gw_ = (int)im.width; gh_ = (int)im.height; }
+    }
 
     static double num(const std::string& s) {
         char* end = nullptr;

@@ -466,6 +466,28 @@ int gf_estimator_set_result_path(gf_estimator* h, const char* vio_txt);
  * else u16 in host byte order (MONO16, depth in mm).  pixels == NULL only queries the header. */
 int gf_pgm_read(const char* path, int* width, int* height, int* maxval, void* pixels, size_t cap_bytes);
 
+/* ---- ROS bag files (format 2.0) without ROS: `rosbag play <bag>` into the node's subscribers (README.md:146-187 is the only way the reference is run;
+ * rosNodeTest.cpp:678-682 subscribes IMU_TOPIC / WHEEL_TOPIC / IMAGE0_TOPIC / IMAGE1_TOPIC).  Host code (ground-fusion_amd/host/rosbag_reader.h): bag records,
+ * chunks (none / bz2 via libbz2.so / lz4 decoded here), index data or a scan of un-indexed chunks, connection records.  gnss_comm messages are not decoded. */
+typedef struct gf_bag gf_bag;
+int gf_bag_open(const char* path, gf_bag** out);
+int gf_bag_close(gf_bag* b);
+int gf_bag_connection_count(gf_bag* b);
+/* topic / datatype of connection record i (0 .. count - 1) and its id; strings are truncated to the caller's capacity */
+int gf_bag_connection(gf_bag* b, int i, int* conn_id, char* topic, int topic_cap, char* type, int type_cap);
+/* the messages of the listed topics (n_topics == 0: all) in play order -- record time, ties in file order; returns their number in *count */
+int gf_bag_select(gf_bag* b, const char* const* topics, int n_topics, long long* count);
+/* message i of the selection: connection id, record time [s], serialized payload (valid until the next gf_bag_message / gf_bag_close on this handle) */
+int gf_bag_message(gf_bag* b, long long i, int* conn_id, double* t_record, const unsigned char** data, size_t* len);
+/* sensor_msgs/Imu as imu_callback reads it (rosNodeTest.cpp:567-585): header.stamp.toSec(), linear_acceleration, angular_velocity */
+int gf_ros_decode_imu(const unsigned char* data, size_t len, double* t, double* acc, double* gyr);
+/* nav_msgs/Odometry as wheel_callback reads it (rosNodeTest.cpp:81-189): header.stamp.toSec(), twist.twist.linear / angular, pose.pose.position (may be NULL) */
+int gf_ros_decode_odometry(const unsigned char* data, size_t len, double* t, double* linear, double* angular, double* position);
+/* sensor_msgs/Image -> what the node hands to trackImage.  depth == 0: getImageFromMsg (rosNodeTest.cpp:238-263): 8UC1 / mono8 copied, rgb8 / bgr8 / rgba8 /
+ * bgra8 through cv_bridge::toCvCopy(MONO8) = OpenCV 4.2 cvtColor (R 4899 + G 9617 + B 1868 + 2^13) >> 14; one byte per pixel.  depth != 0:
+ * getDepthImageFromMsg (:265-286): the payload relabelled MONO16; two bytes per pixel in host order.  pixels == NULL only queries t / width / height. */
+int gf_ros_decode_image(const unsigned char* data, size_t len, int depth, double* t, int* width, int* height, void* pixels, size_t cap_bytes);
+
 #ifdef __cplusplus
 }
 #endif

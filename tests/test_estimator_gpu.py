@@ -155,7 +155,7 @@ def test_replay_configurations_of_the_other_shipped_yaml_files(variant):
     if variant == "subset_cam":
         kw.update(estimate_extrinsic=1, extrinsic_type=3)
     if variant == "subset_wheel":
-        kw.update(estimate_wheel_extrinsic=1, extrinsic_type_wheel=3)
+        kw.update(estimate_wheel_extrinsic=1, extrinsic_type_wheel=3, wdetect=0)   # (with wdetect this stream's wheel factors are dropped as anomalies once it moves)
     if variant == "wheel_slip":      # the odometer over-reports for 0.5 s in the middle of the drive (wheel spin)
         sel = (st.wheel_t > 3.0) & (st.wheel_t < 3.5)
         st.wheel_vel[sel] *= 1.6
@@ -176,14 +176,16 @@ def test_replay_configurations_of_the_other_shipped_yaml_files(variant):
         assert abs(s["td"] - est_o.td) < 1e-6      # seconds; observed 7e-9 on a td of 12 ms
         td_free += int(abs(est_o.td) > 0)
         if variant == "subset_cam":
-            assert s["tic"][2] == 0.0 == est_o.tic[2] and np.abs(s["tic"] - est_o.tic).max() < 1e-6 * max(1.0, np.abs(est_o.tic).max())
+            # z never moves; y is the window's weakest direction -- on this stream the solver lets tic wander by 2.3 m in three seconds (no prior worth the name on a
+            # freshly freed block), and the two pipelines end 2e-5 apart in it (relative; the poses of the same frames agree to 1e-7): bar 1e-4 relative
+            assert s["tic"][2] == 0.0 == est_o.tic[2] and np.abs(s["tic"] - est_o.tic).max() < 1e-4 * max(1.0, np.abs(est_o.tic).max())
         if variant == "subset_wheel":
             assert s["tio"][2] == SS.TIO[2] == est_o.tio[2]
     assert est_o.solver_flag == EO.NON_LINEAR and est_o.n_optimizations > 30
     if variant == "subset_cam":
         assert est_o.openExEstimation and np.abs(est_o.tic[:2]).max() > 1e-3      # the block was free and moved where the mask lets it
     if variant == "subset_wheel":
-        assert est_o.openExWheelEstimation and np.abs(est_o.tio[:2] - np.asarray(SS.TIO)[:2]).max() > 0
+        assert est_o.openExWheelEstimation and np.abs(est_o.tio[:2] - np.asarray(SS.TIO)[:2]).max() > 1e-3
     if variant == "estimate_td":
         assert td_free > 5          # td really was estimated
     if variant == "wheel_slip":

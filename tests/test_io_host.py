@@ -279,7 +279,9 @@ struct Rec {   // stands in for gf::Estimator
 };
 int main(int argc, char** argv) {
     Rec r; gf::ReplayNode<Rec> n(r); n.w_replace = atoi(argv[2]);
-    n.run(argv[1]);
+    const std::string src = argv[1];
+    if (src.size() > 4 && src.substr(src.size() - 4) == ".bag") n.run_bag(src, "/imu", "/odom", "/img0", "/img1");
+    else n.run(src);
     printf("imu %zu wheel %zu pairs %ld thrown %ld %ld\n", r.imu_t.size(), r.wheel_t.size(), n.n_pairs, n.n_thrown0, n.n_thrown1);
     for (size_t i = 0; i < r.gnss_t.size(); i++) printf("g %.9f %d\n", r.gnss_t[i], r.gnss_n[i]);
     for (size_t i = 0; i < r.wheel_t.size(); i++) printf("w %.9f %.12f\n", r.wheel_t[i], r.wheel_gz[i]);
@@ -334,3 +336,59 @@ def test_replay_node_callbacks(tmp_path):
     (d / "gnss_align.csv").write_text("0.015,1,2,3,0.3,10,20,30,40,2.0\n")
     out = subprocess.check_output([str(exe), str(d), "1"]).decode().splitlines()
     assert [l for l in out if l.startswith("g ")] == ["g 18.020000000 2", "g 18.090000000 1"]
+
+
+def test_replay_node_from_a_bag_matches_the_csv_route(tmp_path):
+    """ReplayNode::run_bag: the hand-made log of test_replay_node_callbacks as a ROS bag (bz2 chunks, an unrelated topic in between, colour as bgr8) drives the
+    same callbacks to the same result -- yaw-rate substitution, pairing, thrown frames and all."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bagwriter as BW
+    d = tmp_path / "ds"
+    (d / "frames").mkdir(parents=True)
+    imu_t = np.arange(0, 0.1001, 0.005)
+    gy = 0.1 + 2.0 * imu_t
+    wheel_t = [0.0258, 0.0459, 0.0487, 0.0811]
+    img0 = [(0.010, 0), (0.040, 1), (0.070, 2), (0.090, 3)]
+    img1 = [(0.042, 1), (0.075, 2), (0.0905, 3)]
+    with open(d / "imu.csv", "w") as f:
+        for t, g in zip(imu_t, gy):
+            f.write("%r,0,0,9.8,0.01,%r,0.02\n" % (float(t), float(g)))
+    with open(d / "wheel.csv", "w") as f:
+        for t in wheel_t:
+            f.write("%r,1,0,0,0.5,0.6,0.7\n" % t)
+    for k in range(4):
+        gfamd.write_pgm(str(d / "frames" / ("g%d.pgm" % k)), np.full((4, 6), 10 + k, np.uint8))
+        gfamd.write_pgm(str(d / "frames" / ("d%d.pgm" % k)), np.full((4, 6), 1000 + k, np.uint16))
+    (d / "image0.csv").write_text("".join("%r,frames/g%d.pgm\n" % tk for tk in img0))
+    (d / "image1.csv").write_text("".join("%r,frames/d%d.pgm\n" % tk for tk in img1))
+    ns = lambda t: int(round(t * 1e9))
+    ev = [(ns(t), 0, (t, g)) for t, g in zip(imu_t, gy)] + [(ns(t), 1, t) for t in wheel_t] + [(ns(t), 2, k) for t, k in img0] + [(ns(t), 3, k) for t, k in img1]
+    ev.sort(key=lambda e: (e[0], e[1]))
+    bag = tmp_path / "log.bag"
+    wr = BW.BagWriter(str(bag), compression="bz2", chunk_bytes=700)
+    for seq, (t, kind, x) in enumerate(ev):
+        if kind == 0:
+            wr.write("/imu", "sensor_msgs/Imu", t, BW.imu(seq, t, (0, 0, 9.8), (0.01, float(x[1]), 0.02)))
+            wr.write("/tf", "tf2_msgs/TFMessage", t, b"\0\0\0\0")       # a topic nobody subscribes
+        elif kind == 1:
+            wr.write("/odom", "nav_msgs/Odometry", t, BW.odometry(seq, t, (1, 0, 0), (0.5, 0.6, 0.7)))
+        elif kind == 2:
+            wr.write("/img0", "sensor_msgs/Image", t, BW.image(seq, t, np.full((4, 6, 3), 10 + x, np.uint8), "bgr8", step_pad=2))
+        else:
+            wr.write("/img1", "sensor_msgs/Image", t, BW.image(seq, t, np.full((4, 6), 1000 + x, np.uint16), "16UC1"))
+    wr.close()
+    src = tmp_path / "n.cpp"
+    src.write_text(NODE_TEST)
+    exe = tmp_path / "n"
+    lib = os.path.join(ROOT, "ground-fusion_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I", ROOT, str(src), "-L", lib, "-lgroundfusion_hip", "-Wl,-rpath," + lib, "-ldl", "-o", str(exe)])
+    for w_replace in (1, 0):
+        a = subprocess.check_output([str(exe), str(d), str(w_replace)]).decode()
+        b = subprocess.check_output([str(exe), str(bag), str(w_replace)]).decode()
+        assert a == b and a.splitlines()[0] == "imu 21 wheel 4 pairs 2 thrown 2 1"
+    # a topic with the wrong datatype is refused, not misread
+    wr = BW.BagWriter(str(bag))
+    wr.write("/imu", "nav_msgs/Odometry", 5, BW.odometry(0, 5, (1, 0, 0), (0, 0, 0)))
+    wr.close()
+    r = subprocess.run([str(exe), str(bag), "0"], capture_output=True, text=True)
+    assert r.returncode != 0 and "subscribes it as sensor_msgs/Imu" in r.stderr

@@ -127,3 +127,63 @@ def test_replay_tool_with_gnss_messages(tmp_path):
     print("gf_replay with GNSS vs oracle: %d poses, worst |dp| %.2e, anchor %.2e, ecef %.2e" % (len(ref), dp, np.abs(anc - est.anc_ecef).max(), np.abs(ecef - est.ecef_pos).max()))
     assert dp < 1e-6 + 5e-10
     assert np.abs(anc - est.anc_ecef).max() < 1e-3 and np.abs(ecef - est.ecef_pos).max() < 1e-3     # printed with 4 decimals (weak prior directions, see above)
+
+
+def test_replay_from_a_rosbag_matches_the_dataset_route(tmp_path):
+    """SURVEY.md §8(f)2, first item: the recording itself.  The exported dataset (CSV rows + PGM frames) is packed into a ROS bag of format 2.0 -- lz4 chunks,
+    sensor_msgs/Imu, nav_msgs/Odometry, the colour topic as rgb8 and the depth topic as 16UC1 (what a RealSense driver publishes) -- and `gf_replay --bag` must write
+    the same vio.txt as the dataset route, byte for byte: same callbacks in the same order (rosNodeTest.cpp:59-71, :81-189, :567-585), same pixels after
+    getImageFromMsg / getDepthImageFromMsg (:238-288), same 3 ms pairing (:388-419)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bagwriter as BW
+    import gfamd
+    st = SS.Stream(1, t_still=1.5, t_move=2.0, v_max=0.4, yaw0=0.0, yaw_turn=-0.6, split_x=1.8, turn_delay=0.8)
+    d = str(tmp_path)
+    topics = dict(imu_topic="/camera/imu", wheel_topic="/odom", image0_topic="/camera/color/image_raw", image1_topic="/camera/aligned_depth_to_color/image_raw")
+    n = st.export(d, **{k: '"%s"' % v for k, v in topics.items()})
+
+    def stamp(t):        # header stamps are (sec, nsec): both routes must see ros::Time::toSec of the same pair
+        ns = int(round(float(t) * 1e9))
+        return ns, float(ns // 1_000_000_000) + 1e-9 * float(ns % 1_000_000_000)
+
+    rows = {}
+    for name in ("imu", "wheel", "image0", "image1"):
+        path = os.path.join(d, name + ".csv")
+        out = []
+        for line in open(path).read().splitlines():
+            if line.startswith("#") or not line:
+                continue
+            f = line.split(",")
+            ns, tq = stamp(float(f[0]))
+            out.append((ns, [repr(tq)] + f[1:]))
+        rows[name] = out
+        with open(path, "w") as fh:
+            for _, f in out:
+                fh.write(",".join(f) + "\n")
+    # the bag, in the order ReplayNode::run merges the CSV rows (time, then imu < wheel < image0 < image1)
+    ev = [(ns, 0, f) for ns, f in rows["imu"]] + [(ns, 1, f) for ns, f in rows["wheel"]] + [(ns, 2, f) for ns, f in rows["image0"]] + [(ns, 3, f) for ns, f in rows["image1"]]
+    ev.sort(key=lambda e: (e[0], e[1]))
+    wr = BW.BagWriter(os.path.join(d, "rec.bag"), compression="lz4", chunk_bytes=1 << 20)
+    for seq, (ns, kind, f) in enumerate(ev):
+        if kind == 0:
+            v = [float(x) for x in f[1:]]
+            wr.write(topics["imu_topic"], "sensor_msgs/Imu", ns, BW.imu(seq, ns, v[0:3], v[3:6]))
+        elif kind == 1:
+            v = [float(x) for x in f[1:]]
+            wr.write(topics["wheel_topic"], "nav_msgs/Odometry", ns, BW.odometry(seq, ns, v[0:3], v[3:6]))
+        elif kind == 2:
+            g = gfamd.read_pgm(os.path.join(d, f[1]))
+            wr.write(topics["image0_topic"], "sensor_msgs/Image", ns, BW.image(seq, ns, np.dstack([g, g, g]), "rgb8"))
+        else:
+            wr.write(topics["image1_topic"], "sensor_msgs/Image", ns, BW.image(seq, ns, gfamd.read_pgm(os.path.join(d, f[1])), "16UC1"))
+    wr.close()
+    exe = os.path.join(ROOT, "bin", "gf_replay")
+    if not os.path.exists(exe):
+        import build as gfbuild
+        gfbuild.build_tool(verbose=True)
+    a = subprocess.run([exe, os.path.join(d, "config.yaml"), d, os.path.join(d, "vio_dir.txt")], capture_output=True, text=True, timeout=600)
+    b = subprocess.run([exe, os.path.join(d, "config.yaml"), "--bag", os.path.join(d, "rec.bag"), os.path.join(d, "vio_bag.txt")], capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+    assert "%d RGB-D pairs (0 / 0 unpaired" % n in a.stdout and "%d RGB-D pairs (0 / 0 unpaired" % n in b.stdout and "solver_flag 1" in b.stdout
+    ta, tb = open(os.path.join(d, "vio_dir.txt"), "rb").read(), open(os.path.join(d, "vio_bag.txt"), "rb").read()
+    assert len(ta.splitlines()) > 20 and ta == tb

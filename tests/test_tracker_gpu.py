@@ -83,7 +83,7 @@ def test_good_features_bit_exact(gf, oracle, max_corners, min_dist, masked):
 
 
 @pytest.mark.parametrize("shape,min_dist", [((120, 160), 8), ((150, 200), 10), ((122, 188), 6), ((62, 36), 4), ((33, 64), 3), ((480, 640), 30),
-                                            ((61, 64), 3), ((91, 130), 3), ((481, 640), 6)])   # heights = 1 mod 30: the last strip's halo row is image row h - 1
+                                            ((61, 64), 3), ((91, 132), 3), ((481, 640), 6)])   # heights = 1 mod 30: the last strip's halo row is image row h - 1
 def test_good_features_on_odd_image_sizes(gf, oracle, shape, min_dist):
     """the Shi-Tomasi pass walks strips of 60 columns x 30 rows: widths / heights that are no multiples of either, images narrower than one strip, and a mask
     that leaves only pieces of the border strips -- corners and their order must still be OpenCV's"""
