@@ -307,6 +307,7 @@ def main():
 
     newest = torch.zeros((B, 7), dtype=torch.float64, device=dev)   # payload of the pose gather
     gathered = [None]
+    pose_gather = shard.PoseGather(dist, world, [B] * world, dev)     # persistent send / receive buffers, all_gather_into_tensor over RCCL
 
     def do_step(exchange=True):
         k = step[0] % n_frames
@@ -320,7 +321,7 @@ def main():
             est.wait()
             if exchange:   # north_star's only exchange: the newest pose of every sequence, all_gather over RCCL (56 B per sequence, latency-bound)
                 est.export_newest_poses(newest.data_ptr(), B)
-                gathered[0] = shard.gather_poses(newest, dist, world)
+                gathered[0] = pose_gather(newest)
         step[0] += 1
 
     for _ in range(Wm + 1):  # frame 0 only detects; it is part of the warm-up

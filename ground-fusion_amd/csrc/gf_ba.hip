@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/groundfusion_hip.h"
+#include "gf_comm.hpp"
 #include "gf_ba_kernels.hpp"
 #include "gf_ba_marg.hpp"
 #include "gf_ba_gnss.hpp"
@@ -86,6 +87,8 @@ struct gf_ba {
     Buf<SolverState> st, st0;
     // work
     Buf<double> imu_sqrt, wh_sqrt, pri_A, pri_b, pri_c, H, g, Vc, vtile, wpar, cost, efac;
+    Buf<double> gather_send;   // [B][7] newest poses, send buffer of gf_pose_gather (allocated on first use)
+    hipEvent_t ev_gather = nullptr;
     Buf<double> scale, diag, grad, gn, step, u, Et, Es, ete, etb, rhs, yv, Sg, Mg, gn_data, gn_misc;
     Buf<int> ngnss, gn_idx, gn_gptr, gn_gitem;
     Buf<double> gn_rows;
@@ -132,6 +135,8 @@ struct gf_ba {
         outJ.release(); outr.release(); stamps.release();
         st.release(); st0.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (ev_gather) (void)hipEventDestroy(ev_gather);
+        gather_send.release();
         if (stream) (void)hipStreamDestroy(stream);
     }
     Win win() {
@@ -657,6 +662,7 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
         H_(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio));
     }
     for (auto& e : h->ev) H_(hipEventCreate(&e));
+    H_(hipEventCreateWithFlags(&h->ev_gather, hipEventDisableTiming));
     const size_t B = d.B, VS = d.RP + d.FP;
     A_(h->xs0.alloc(B * d.XS, true)); A_(h->xs.alloc(2 * B * d.XS, true));
     A_(h->colf.alloc(B * d.NFB, true)); A_(h->cole.alloc(B * d.F, true)); A_(h->nvis.alloc(B, true)); A_(h->nimu.alloc(B, true)); A_(h->nwh.alloc(B, true)); A_(h->nfeat.alloc(B, true));
@@ -1032,6 +1038,21 @@ int gf_ba_export_newest_poses(gf_ba* h, void* d_out, int count) {
     // waits for the solve -- the exported pose is the solved one; gf_ba_wait afterwards only collects the statistics.)
     HIPCHK(hipStreamSynchronize(h->stream));
     return GF_OK;
+}
+
+// north_star's exchange step as one C call: newest poses of this rank's `count` resident windows -> ncclAllGather -> [world][count][7] on every rank.
+int gf_pose_gather(gf_ba* h, void* nccl_comm, void* stream, int count, double* d_out) {
+    if (!h || !nccl_comm || !d_out || count < 1 || count > h->d.B) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    if (!h->gather_send.d) { if (int rc = h->gather_send.alloc((size_t)h->d.B * 7, false)) return rc; HIPCHK(hipMemsetAsync(h->gather_send.d, 0, (size_t)h->d.B * 7 * sizeof(double), h->stream)); }
+    // ranks must pass the same count (ncclAllGather): a rank with fewer resident windows sends zero rows behind its own
+    const int mine = std::min(count, h->count);
+    if (mine > 0) { ba_export_newest<<<dim3((mine + 63) / 64), 64, 0, h->stream>>>(h->win(), h->gather_send.d, mine); HIPCHK(hipGetLastError()); }
+    if (mine < count) HIPCHK(hipMemsetAsync(h->gather_send.d + (size_t)mine * 7, 0, (size_t)(count - mine) * 7 * sizeof(double), h->stream));
+    if (stream != (void*)h->stream) {   // order the collective behind the export without stalling the host: an event on the solver's stream
+        HIPCHK(hipEventRecord(h->ev_gather, h->stream));
+        HIPCHK(hipStreamWaitEvent(static_cast<hipStream_t>(stream), h->ev_gather, 0));
+    }
+    return gf::rccl_allgather_f64(h->gather_send.d, d_out, (size_t)count * 7, nccl_comm, stream);
 }
 
 int gf_ba_debug_stamps(gf_ba* h, long long* out, int n) {  // phase timestamps of the last ba_step launch (profiling builds)

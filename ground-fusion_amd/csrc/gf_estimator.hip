@@ -40,6 +40,7 @@
 #include <sys/mman.h>
 
 #include "../../include/groundfusion_hip.h"
+#include "gf_comm.hpp"
 #include "gf_dmath.hpp"
 #include "gf_preint.hpp"
 #include "gf_init_sfm.hpp"
@@ -2166,6 +2167,7 @@ struct gf_estimator_group {
     }
     void worker(int w) {   // worker w owns the members w, w + n_threads, ...
         (void)hipSetDevice(device);   // the device is a per-thread setting; whichever member closes a rendezvous launches the batch
+        gf::pin_thread_to_device_node(device);   // this rank's workers onto the cores next to its GPU (GF_NUMA_PIN=0: off)
         ucontext_t sched;
         std::vector<int> mine;
         int seen = 0;   // go starts at generation 0 and is only bumped by input_features / the destructor

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../../include/groundfusion_hip.h"
+#include "gf_comm.hpp"
 #include "gf_detect_kernels.hpp"
 #include "gf_lk_kernels.hpp"
 
@@ -63,8 +64,9 @@ struct SeqState {  // per-sequence FeatureTracker members (feature_tracker.h:76-
 // Small persistent pool for the per-sequence host bookkeeping (sequences are independent).  GF_HOST_THREADS overrides the size.
 class HostPool {
   public:
-    explicit HostPool(int n) {
-        for (int i = 0; i < n; i++) workers_.emplace_back([this] { run(); });
+    // device: the pool's threads go onto the cores of that GPU's NUMA node (8 ranks on one host: every rank's bookkeeping next to its own GPU and memory)
+    explicit HostPool(int n, int device) {
+        for (int i = 0; i < n; i++) workers_.emplace_back([this, device] { gf::pin_thread_to_device_node(device); run(); });
     }
     ~HostPool() {
         { std::lock_guard<std::mutex> l(m_); stop_ = true; gen_++; }
@@ -586,7 +588,9 @@ int gf_tracker_create(const gf_tracker_cfg* cfg, gf_tracker** out) {
         int nthr = std::max(1, std::min(16, (int)std::thread::hardware_concurrency() / (2 * share)));
         if (const char* e = getenv("GF_HOST_THREADS")) nthr = atoi(e);
         nthr = std::max(1, std::min(nthr, (int)std::thread::hardware_concurrency()));
-        h->pool = new gf::HostPool(h->B >= 8 ? nthr - 1 : 0);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        h->pool = new gf::HostPool(h->B >= 8 ? nthr - 1 : 0, dev);
     }
     const int W = cfg->width, H = cfg->height, B = h->B, cap = h->cap;
     int cc = 1024;

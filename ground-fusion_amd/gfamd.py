@@ -846,3 +846,48 @@ def ros_decode_image(payload, depth=False):
     out = np.zeros((h.value, w.value), np.uint16 if depth else np.uint8)
     _chk(lib().gf_ros_decode_image(payload, C.c_size_t(len(payload)), int(depth), C.byref(t), C.byref(w), C.byref(h), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes)))
     return t.value, out
+
+
+# ------------------------------------------------------------------ multi-GPU exchange without torch (gf_comm_*, gf_pose_gather)
+def comm_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0 makes it, the others receive it out of band)"""
+    buf = (C.c_ubyte * 128)()
+    _chk(lib().gf_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """gf_comm: an RCCL communicator of this process's rank on `device`"""
+
+    def __init__(self, unique_id, world, rank, device=0):
+        self.h = C.c_void_p()
+        _chk(lib().gf_comm_create((C.c_ubyte * 128).from_buffer_copy(unique_id), world, rank, device, C.byref(self.h)))
+        self.world, self.rank = world, rank
+
+    def info(self):
+        w, r, d, comm, stream = C.c_int(), C.c_int(), C.c_int(), C.c_void_p(), C.c_void_p()
+        _chk(lib().gf_comm_info(self.h, C.byref(w), C.byref(r), C.byref(d), C.byref(comm), C.byref(stream)))
+        return dict(world=w.value, rank=r.value, device=d.value, nccl_comm=comm.value, stream=stream.value)
+
+    def allgather(self, x):
+        x = np.ascontiguousarray(x, np.float64).reshape(-1)
+        out = np.zeros((self.world, x.size))
+        _chk(lib().gf_comm_allgather_f64(self.h, _p(x, C.c_double), x.size, _p(out, C.c_double)))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gf_comm_destroy(self.h)
+            self.h = None
+
+
+def pose_gather(est, comm, count, d_out_ptr):
+    """gf_pose_gather: est's newest poses -> ncclAllGather on comm's communicator and stream -> device array [world][count][7] at d_out_ptr"""
+    i = comm.info()
+    _chk(lib().gf_pose_gather(est.h, C.c_void_p(i["nccl_comm"]), C.c_void_p(i["stream"]), count, C.c_void_p(d_out_ptr)))
+
+
+def numa_node_of_device(device=0):
+    node, buf = C.c_int(), C.create_string_buffer(512)
+    _chk(lib().gf_numa_node_of_device(device, C.byref(node), buf, 512))
+    return node.value, buf.value.decode()

@@ -48,6 +48,41 @@ def owner_of(seq, per_gpu):
     return seq // per_gpu
 
 
+class PoseGather:
+    """The per-step exchange on persistent buffers: one [world, cmax, 7] receive buffer and one [cmax, 7] send buffer per rank, allocated once;
+    `all_gather_into_tensor` (one flat collective, no per-step tensor lists) where the backend has it -- RCCL does --, else `all_gather` into views of
+    the same persistent buffer (gloo in the CPU tests)."""
+
+    def __init__(self, dist, world, counts, device, dtype=torch.float64):
+        self.dist, self.world, self.counts = dist, world, list(counts)
+        self.cmax = max(self.counts)
+        self.uniform = all(c == self.cmax for c in self.counts)
+        self.send = torch.zeros((self.cmax, 7), dtype=dtype, device=device)
+        self.recv = torch.zeros((world, self.cmax, 7), dtype=dtype, device=device)
+        self.views = list(self.recv.unbind(0))
+        self.flat = None      # None: not probed yet; True / False: all_gather_into_tensor works on this backend
+
+    def __call__(self, newest):
+        """newest: [count(rank), 7] on this rank's device -> [sum(counts), 7], sequences in global order (a view of the persistent buffer when the shards are even)"""
+        if self.dist is None or self.world == 1:
+            return newest
+        n = newest.shape[0]
+        self.send[:n].copy_(newest)
+        if self.flat is not False:
+            try:
+                self.dist.all_gather_into_tensor(self.recv, self.send)
+                self.flat = True
+            except (RuntimeError, NotImplementedError, AttributeError):
+                if self.flat:          # it worked before: a real failure, not a missing feature
+                    raise
+                self.flat = False
+        if self.flat is False:
+            self.dist.all_gather(self.views, self.send)
+        if self.uniform:
+            return self.recv.view(-1, 7)
+        return torch.cat([self.recv[r, :c] for r, c in enumerate(self.counts)], 0)
+
+
 def gather_poses(newest, dist, world, counts=None):
     """newest: [count(rank), 7] float64 tensor on this rank's device.  Returns [sum(counts), 7] on every rank, sequences in global
     order (all_gather keeps ranks symmetric; 56 B per sequence, latency-bound -- one collective per step).  counts: sequences per

@@ -466,6 +466,28 @@ int gf_estimator_set_result_path(gf_estimator* h, const char* vio_txt);
  * else u16 in host byte order (MONO16, depth in mm).  pixels == NULL only queries the header. */
 int gf_pgm_read(const char* path, int* width, int* height, int* maxval, void* pixels, size_t cap_bytes);
 
+/* ---- multi-GPU exchange without torch: one process per GPU, sequences sharded over the ranks, ONE collective -- the all-gather of the newest pose
+ * of every window (7 doubles each) over RCCL / xGMI.  RCCL is resolved at run time (symbols already in the process, else librccl.so.1): the library itself
+ * does not link against it.  The reference has no counterpart (one Estimator per process, rosNodeTest.cpp:713); this is north_star's partitioning. */
+typedef struct gf_comm gf_comm;
+/* rank 0 creates the 128-byte id (ncclGetUniqueId) and hands it to the other ranks out of band; every rank then builds its communicator on its device */
+int gf_comm_unique_id(unsigned char* id128);
+int gf_comm_create(const unsigned char* id128, int world, int rank, int device, gf_comm** out);
+int gf_comm_destroy(gf_comm* c);
+/* world, rank, device, the ncclComm_t and the communicator's own hipStream_t (any of them may be NULL) */
+int gf_comm_info(gf_comm* c, int* world, int* rank, int* device, void** nccl_comm, void** stream);
+/* all-gather of n doubles per rank between host buffers (staged through the device): recv_host = [world][n] */
+int gf_comm_allgather_f64(gf_comm* c, const double* send_host, int n, double* recv_host);
+/* The exchange step of the path: Ps / Rs[WINDOW_SIZE] (px py pz qx qy qz qw) of this rank's first `count` resident windows -> d_out = [world][count][7] on every
+ * rank (device memory), ncclAllGather on `nccl_comm` (ncclComm_t of any owner: gf_comm_info, or torch's) enqueued on `stream` (hipStream_t) behind the solver's
+ * stream.  Every rank passes the same count (the largest shard); rows behind a rank's own resident windows are zero.  Asynchronous: synchronise `stream`. */
+int gf_pose_gather(gf_ba* h, void* nccl_comm, void* stream, int count, double* d_out);
+/* NUMA placement: node of the GPU (/sys/bus/pci/devices/<bus id>/numa_node; -1 = none reported) and its cpulist; gf_pin_thread_to_device_node moves the calling
+ * thread onto those cores (intersection with the process's affinity; GF_NUMA_PIN=0 switches it off) and returns the node or -1.  The tracker's bookkeeping pool
+ * and the estimator group's workers pin themselves this way: 8 ranks x (pool + workers) on one host stay next to their own GPU. */
+int gf_numa_node_of_device(int device, int* node, char* cpulist, int cap);
+int gf_pin_thread_to_device_node(int device);
+
 /* ---- ROS bag files (format 2.0) without ROS: `rosbag play <bag>` into the node's subscribers (README.md:146-187 is the only way the reference is run;
  * rosNodeTest.cpp:678-682 subscribes IMU_TOPIC / WHEEL_TOPIC / IMAGE0_TOPIC / IMAGE1_TOPIC).  Host code (ground-fusion_amd/host/rosbag_reader.h): bag records,
  * chunks (none / bz2 via libbz2.so / lz4 decoded here), index data or a scan of un-indexed chunks, connection records.  gnss_comm messages are not decoded. */

@@ -187,3 +187,42 @@ def test_replay_from_a_rosbag_matches_the_dataset_route(tmp_path):
     assert "%d RGB-D pairs (0 / 0 unpaired" % n in a.stdout and "%d RGB-D pairs (0 / 0 unpaired" % n in b.stdout and "solver_flag 1" in b.stdout
     ta, tb = open(os.path.join(d, "vio_dir.txt"), "rb").read(), open(os.path.join(d, "vio_bag.txt"), "rb").read()
     assert len(ta.splitlines()) > 20 and ta == tb
+
+
+def test_replay_tool_multi_rank_mode(tmp_path):
+    """`gf_replay --ranks N`: SURVEY.md §8(e) as host C++ -- N processes, recordings dealt round-robin, the newest pose of every sequence exchanged with
+    ncclAllGather (gf_comm_*, RCCL resolved at run time, no torch).  On this one-GPU box: world 1 always; world 2 puts both ranks on device 0, which RCCL builds
+    may refuse ("Duplicate GPU") -- then that half is skipped.  Each rank's vio.txt must be the single-sequence replay's, and rank 0's table the files' last lines."""
+    exe = os.path.join(ROOT, "bin", "gf_replay")
+    dirs = []
+    for k in range(2):
+        st = SS.Stream(11 + k, t_still=1.5, t_move=1.2, v_max=0.4, yaw0=0.0, yaw_turn=-0.6, split_x=1.8, turn_delay=0.8)
+        d = tmp_path / ("seq%d" % k)
+        d.mkdir()
+        st.export(str(d))
+        dirs.append(str(d))
+    cfg = os.path.join(dirs[0], "config.yaml")
+    solo = []
+    for d in dirs:
+        out = subprocess.run([exe, cfg, d, os.path.join(d, "solo.txt")], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr
+        solo.append(open(os.path.join(d, "solo.txt"), "rb").read())
+        assert len(solo[-1].splitlines()) > 5
+    for world in (1, 2):
+        for d in dirs:
+            if os.path.exists(os.path.join(d, "vio.txt")):
+                os.remove(os.path.join(d, "vio.txt"))
+        out = subprocess.run([exe, "--ranks", str(world), cfg] + dirs, capture_output=True, text=True, timeout=900)
+        if world == 2 and out.returncode != 0:
+            print("two ranks on one device refused:", out.stderr[-300:])
+            continue
+        assert out.returncode == 0, out.stderr
+        rows = [l for l in out.stdout.splitlines() if l.startswith("gf_replay: sequence")]
+        assert len(rows) == 2
+        for k, d in enumerate(dirs):
+            assert open(os.path.join(d, "vio.txt"), "rb").read() == solo[k]
+            last = solo[k].splitlines()[-1].split()
+            got = rows[k].split("newest pose")[1].split()
+            assert "sequence %d (rank %d)" % (k, k % world) in rows[k]
+            assert [float(x) for x in got[:3]] == [float(x) for x in last[1:4]]
+            assert np.abs(np.array(got[3:], float) - np.array(last[4:], float)).max() < 2e-9

@@ -19,6 +19,12 @@ def _uneven_worker(rank, world, port, n_seq, q):
     plan = shard.Plan(n_seq, world)
     mine = torch.tensor([[float(k)] * 7 for k in range(plan.first(rank), plan.first(rank) + plan.count(rank))], dtype=torch.float64).reshape(-1, 7)
     g = shard.gather_poses(mine, dist, world, plan.counts())
+    # the per-step form on persistent buffers (what bench.py runs inside every timed step): same result, step after step, no new receive buffer
+    pg = shard.PoseGather(dist, world, plan.counts(), "cpu")
+    ptr = pg.recv.data_ptr()
+    for step in range(3):
+        gs = pg(mine + step)
+        assert torch.equal(gs, g + step) and pg.recv.data_ptr() == ptr
     if rank == 0:
         q.put(g.numpy())
     dist.barrier()
