@@ -120,6 +120,7 @@ struct gf_ba {
     std::vector<int> imu_rows;   // rows of the slot's mirror that the device table holds as well (the previous pack's n_imu)
     int max_imu_dirty = 0;
     bool all_pri_res = false, any_pri_res = false, outJ_host_stale = false;
+    int step_waves = 8;
     double max_solver_time = 0.0;   // ceres::Solver::Options::max_solver_time_in_seconds; 0 = not honoured (the fixed schedule runs without host round trips)
     long long mfma_per_lin = 0;   // v_mfma_f64_16x16x4 instructions of one visual linearisation of the resident batch
     long long jtj_alg_flops = 0;  // algorithmic flops of the same: Nv * 2 * 2 * (12 * 13 / 2 + 12 + 1) per window
@@ -587,7 +588,10 @@ int run_solve(gf_ba* h, int max_iters) {
         }
         const bool time_step = it == 1 && max_iters >= 1;
         if (time_step) HIPCHK(hipEventRecord(h->ev[6], h->stream));
-        if (h->big_step) ba_step<true><<<dim3(d.B), 512, 0, h->stream>>>(w, sb, it == 0 ? 1 : 0, max_iters, it == max_iters ? 1 : 0);
+        if (h->step_waves == 4) {
+            if (h->big_step) ba_step<true, 4><<<dim3(d.B), 256, 0, h->stream>>>(w, sb, it == 0 ? 1 : 0, max_iters, it == max_iters ? 1 : 0);
+            else ba_step<false, 4><<<dim3(d.B), 256, h->step_lds, h->stream>>>(w, sb, it == 0 ? 1 : 0, max_iters, it == max_iters ? 1 : 0);
+        } else if (h->big_step) ba_step<true><<<dim3(d.B), 512, 0, h->stream>>>(w, sb, it == 0 ? 1 : 0, max_iters, it == max_iters ? 1 : 0);
         else if (fuse_misc && it > 0) ba_misc_step<<<dim3(d.B), 512, std::max(h->step_lds, h->mwin_lds), h->stream>>>(w, sb, max_iters, it == max_iters ? 1 : 0);
         else ba_step<false><<<dim3(d.B), 512, h->step_lds, h->stream>>>(w, sb, it == 0 ? 1 : 0, max_iters, it == max_iters ? 1 : 0);
         HIPCHK(hipGetLastError());
@@ -698,6 +702,10 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     if (h->big_step) { h->sg_stride = (h->step_lds / sizeof(double) + 15) & ~(size_t)15; A_(h->Sg.alloc(B * h->sg_stride, false)); }
     if (h->big_marg) { h->mg_stride = (size_t)2 * h->marg_ncap * h->marg_ncap + 1024; A_(h->Mg.alloc(B * h->mg_stride, false)); }
     if (!h->big_step) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_step<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->step_lds));
+    // GF_BA_STEP_WAVES=4: ba_step on four wavefronts (half of a CU's registers) so that other kernels' blocks -- the tracker's -- can sit next to it; one setting per
+    // process (the reductions' order depends on it: a window alone and the same window in a batch must run the same variant)
+    h->step_waves = (getenv("GF_BA_STEP_WAVES") && atoi(getenv("GF_BA_STEP_WAVES")) == 4) ? 4 : 8;
+    if (h->step_waves == 4 && !h->big_step) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_step<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->step_lds));
     // GF_BA_FUSE_MISC=1: the candidate's prior / IMU / wheel sweep in front of the step that judges it, one launch (ba_misc_step).  Same bits; measured 163 us against
     // 123 + 33 us for the two launches and 1.75-1.77 instead of 1.79 ms per solve (-1 %): the sweep's time is its blocks' own latency, not a launch boundary.  Off.
     h->fuse_misc = getenv("GF_BA_FUSE_MISC") != nullptr;

@@ -636,7 +636,7 @@ struct StepBufs {  // per-window global scratch of ba_step
 __device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }  // packed lower, i >= j
 
 // 512-thread block reductions through wavefront shuffles + 8 LDS partials (sred >= 64 doubles)
-template <int NV_>
+template <int NV_, int NWV = 8>
 __device__ __forceinline__ void block_sum_n(double (&v)[NV_], double* sred, int tid) {
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
@@ -648,9 +648,11 @@ __device__ __forceinline__ void block_sum_n(double (&v)[NV_], double* sred, int 
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < NV_; q++) { double t = 0; for (int w8 = 0; w8 < 8; w8++) t += sred[w8 * NV_ + q]; v[q] = t; }
+    for (int q = 0; q < NV_; q++) { double t = 0; for (int w8 = 0; w8 < NWV; w8++) t += sred[w8 * NV_ + q]; v[q] = t; }
 }
-__device__ __forceinline__ double block_sum(double v, double* sred, int tid, int nthreads) { double a[1] = {v}; block_sum_n(a, sred, tid); return a[0]; }
+template <int NWV = 8>
+__device__ __forceinline__ double block_sum(double v, double* sred, int tid, int nthreads) { double a[1] = {v}; block_sum_n<1, NWV>(a, sred, tid); return a[0]; }
+template <int NWV = 8>
 __device__ __forceinline__ double block_max(double v, double* sred, int tid, int nthreads) {
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
@@ -659,7 +661,7 @@ __device__ __forceinline__ double block_max(double v, double* sred, int tid, int
     if (lane == 0) sred[wave] = v;
     __syncthreads();
     double t = sred[0];
-    for (int w8 = 1; w8 < 8; w8++) t = fmax(t, sred[w8]);
+    for (int w8 = 1; w8 < NWV; w8++) t = fmax(t, sred[w8]);
     return t;
 }
 
@@ -1297,7 +1299,8 @@ __device__ __forceinline__ bool wave_chol16_fused(SPtr S, int j0, int nb, double
 // (MFMA GEMM) and an LDS-resident blocked Cholesky, candidate point.  first: the call that follows the initial linearisation.
 // GS: the packed reduced system lives in global memory (sb.Sg) instead of LDS -- windows whose (R+1)(R+2)/2 doubles exceed 160 KB
 // (WINDOW_SIZE > 10); same code, the triangular solves then run out of L2.
-template <bool GS>
+// NW: wavefronts per block (8: one block owns a CU's registers; 4: half of them, so that other kernels' wavefronts -- the tracker's -- can sit next to it)
+template <bool GS, int NW = 8>
 __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int max_iters, int finalize_only) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double sred[512];
@@ -1311,6 +1314,7 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
     __shared__ int s_rc[512];        // reduced column -> compact column of the visual system Vc (or -1)
     __shared__ double s_hd[512];     // diagonal of H + Vc
     __shared__ double s_gt[512];     // g + Vc's right-hand-side row
+    constexpr int NT = 64 * NW;
     const Dims d = w.d;
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     SolverState& st = w.st[b];
@@ -1323,7 +1327,7 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
     double* gn = sb.gn + (size_t)b * VS; double* stepv = sb.step + (size_t)b * VS; double* u = sb.u + (size_t)b * VS; double* yv = sb.yv + (size_t)b * VS;
     double* Es = sb.Es + (size_t)b * d.FP * ECW;
     if (tid < ECW) s_cmap[tid] = compact_to_col(tid, colf, d.NP, R);
-    s_rc[tid] = -1;
+    for (int q = tid; q < 512; q += NT) s_rc[q] = -1;
     __syncthreads();
     if (tid < 6 * d.NP + 7) { const int c = s_cmap[tid]; if (c >= 0 && c < R) s_rc[c] = tid; }
     GF_STAMP(0);
@@ -1364,7 +1368,7 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
     // the sum, once per call
     const double* Vc = w.Vc + ((size_t)cur * d.B + b) * d.NVC;
     const int RHSK = 6 * d.NP + 7;
-    for (int c = tid; c < R; c += 512) {
+    for (int c = tid; c < R; c += NT) {
         const int k = s_rc[c];
         s_hd[c] = H[(size_t)c * RP + c] + (k >= 0 ? Vc[pk(k, k)] : 0.0);
         s_gt[c] = g[c] + (k >= 0 ? Vc[pk(RHSK, k)] : 0.0);
@@ -1374,16 +1378,16 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
     if (!uni(st.reuse)) {
         // ---------------- Jacobi scaling from the initial Jacobian (trust_region_minimizer.cc: jacobian_scaling_)
         if (!st.have_scale) {
-            for (int c = tid; c < R; c += 512) scale[c] = 1.0 / (1.0 + sqrt(s_hd[c]));
-            for (int e = tid; e < NE; e += 512) scale[RP + e] = 1.0 / (1.0 + sqrt(ete[e]));
+            for (int c = tid; c < R; c += NT) scale[c] = 1.0 / (1.0 + sqrt(s_hd[c]));
+            for (int e = tid; e < NE; e += NT) scale[RP + e] = 1.0 / (1.0 + sqrt(ete[e]));
             __syncthreads();
             if (tid == 0) st.have_scale = 1;
         }
         // unscaled gradient max norm (gradient tolerance)
         double gm = 0;
-        for (int c = tid; c < R; c += 512) gm = fmax(gm, fabs(s_gt[c]));
-        for (int e = tid; e < NE; e += 512) gm = fmax(gm, fabs(etb[e]));
-        gm = block_max(gm, sred, tid, 512);
+        for (int c = tid; c < R; c += NT) gm = fmax(gm, fabs(s_gt[c]));
+        for (int e = tid; e < NE; e += NT) gm = fmax(gm, fabs(etb[e]));
+        gm = block_max<NW>(gm, sred, tid, NT);
         if (tid == 0) st.gmax = gm;
     }
     GF_STAMP(2);
@@ -1401,11 +1405,11 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
     if (!uni(st.reuse)) {
         GF_STAMP(4);
         // ---------------- dogleg diagonal, scaled gradient, Cauchy point
-        for (int c = tid; c < R; c += 512) {
+        for (int c = tid; c < R; c += NT) {
             const double dd = sqrt(fmin(fmax(scale[c] * scale[c] * s_hd[c], 1e-6), 1e32));
             diag[c] = dd; grad[c] = scale[c] * s_gt[c] / dd; u[c] = scale[c] * (grad[c] / dd);
         }
-        for (int e = tid; e < NE; e += 512) {
+        for (int e = tid; e < NE; e += NT) {
             const double sc = scale[RP + e];
             const double dd = sqrt(fmin(fmax(sc * sc * ete[e], 1e-6), 1e32));
             diag[RP + e] = dd; grad[RP + e] = sc * etb[e] / dd; u[RP + e] = sc * (grad[RP + e] / dd);
@@ -1415,11 +1419,11 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
         if (tid < ECW) { const int c = s_cmap[tid]; s_ucc[tid] = (c >= 0 && c < R) ? u[c] : 0.0; }
         // the passes below read the column scaling and the Cauchy direction once per matrix entry: LDS copies (s_hd and s_rd are free until the
         // next call / the Cholesky)
-        for (int c = tid; c < R; c += 512) { s_hd[c] = scale[c]; s_rd[c] = u[c]; }
+        for (int c = tid; c < R; c += NT) { s_hd[c] = scale[c]; s_rd[c] = u[c]; }
         double gsq = 0;
-        for (int c = tid; c < R; c += 512) gsq += grad[c] * grad[c];
-        for (int e = tid; e < NE; e += 512) gsq += grad[RP + e] * grad[RP + e];
-        gsq = block_sum(gsq, sred, tid, 512);
+        for (int c = tid; c < R; c += NT) gsq += grad[c] * grad[c];
+        for (int e = tid; e < NE; e += NT) gsq += grad[RP + e] * grad[RP + e];
+        gsq = block_sum<NW>(gsq, sred, tid, NT);
         // alpha = |g~|^2 / (u^T H u) of the Cauchy point: the quadratic form is accumulated below, inside the passes that stream Et (Es build) and
         // H (load of the reduced system) anyway, instead of a separate sweep over both
         double uHu_acc = 0.0;
@@ -1435,7 +1439,7 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
             if (!(mu < 1.0)) break;
             GF_STAMP(5);
             // eliminated columns: ete~ = s_e^2 ete + mu D_e^2 (kept in yv's tail), row factor f_e = s_e / sqrt(ete~) (in u's tail)
-            for (int e = tid; e < NE; e += 512) {
+            for (int e = tid; e < NE; e += NT) {
                 const double sc = scale[RP + e], lm = diag[RP + e] * sqrt(mu);
                 const double et = sc * sc * ete[e] + lm * lm;
                 yv[RP + e] = et; u[RP + e] = sc / sqrt(et);
@@ -1447,18 +1451,18 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
             const int NE4 = (NE + 3) & ~3;
             GF_STAMP(6);
             // reduced system in LDS (packed lower): S = s (H + Vc) s + mu D^2, row R = s g.  First the H part, row by row ...
-            for (int r0 = wave; r0 <= R; r0 += 32) {   // four rows per wavefront in flight: all loads first, then the arithmetic
+            for (int r0 = wave; r0 <= R; r0 += 4 * NW) {   // four rows per wavefront in flight: all loads first, then the arithmetic
                 double hv[4][QN];
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
-                    const int r = r0 + 8 * m;
+                    const int r = r0 + NW * m;
                     const double* hr = H + (size_t)min(r, R - 1) * RP;
 #pragma unroll
                     for (int q = 0; q < QN; q++) { const int c = lane + 64 * q; hv[m][q] = (r < R && c <= r) ? hr[c] : 0.0; }
                 }
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
-                    const int r = r0 + 8 * m;
+                    const int r = r0 + NW * m;
                     if (r > R) continue;
                     const int base = pk(r, 0);
                     const double sr = r < R ? s_hd[r] : 1.0, ur = r < R ? s_rd[r] : 0.0;
@@ -1483,18 +1487,18 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
             {
                 const int nka = 6 * d.NP + 7;
                 constexpr int VQ = GS ? 3 : 2;   // 64-column pieces of a compact row (<= 6 NP + 8 columns)
-                for (int ka0 = wave; ka0 < nka; ka0 += 32) {
+                for (int ka0 = wave; ka0 < nka; ka0 += 4 * NW) {
                     double vv[4][VQ];
 #pragma unroll
                     for (int m = 0; m < 4; m++) {
-                        const int ka = ka0 + 8 * m;
+                        const int ka = ka0 + NW * m;
                         const double* vrow = Vc + pk(min(ka, nka - 1), 0);
 #pragma unroll
                         for (int q = 0; q < VQ; q++) { const int kb = lane + 64 * q; vv[m][q] = (ka < nka && kb <= ka) ? vrow[kb] : 0.0; }
                     }
 #pragma unroll
                     for (int m = 0; m < 4; m++) {
-                        const int ka = ka0 + 8 * m;
+                        const int ka = ka0 + NW * m;
                         if (ka >= nka) continue;
                         const int r = s_cmap[ka];
                         if (r < 0 || r >= R) continue;
@@ -1513,7 +1517,7 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
                 }
             }
             if (need_alpha && !asm_alpha_done) {   // the eliminated columns' share of u^T H u (E^T F u and E^T E) follows in the back-substitution pass below, which streams Et anyway
-                for (int e = tid; e < NE; e += 512) { const double ue = gn[RP + e]; uHu_acc += ete[e] * ue * ue; }
+                for (int e = tid; e < NE; e += NT) { const double ue = gn[RP + e]; uHu_acc += ete[e] * ue * ue; }
                 asm_alpha_done = true;
             }
             __syncthreads();
@@ -1526,10 +1530,10 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
                 // f_e = s_e / sqrt(ete~) and f_e etb_e per eliminated column: staged in LDS (sred is free between the reductions) when they fit, else read from global
                 const bool fe_lds = NE4 <= 256;
                 if (fe_lds) {
-                    for (int e = tid; e < NE4; e += 512) { const double f = e < NE ? u[RP + e] : 0.0; sred[e] = f; sred[256 + e] = e < NE ? f * etb[e] : 0.0; }
+                    for (int e = tid; e < NE4; e += NT) { const double f = e < NE ? u[RP + e] : 0.0; sred[e] = f; sred[256 + e] = e < NE ? f * etb[e] : 0.0; }
                     __syncthreads();
                 }
-                for (int t = wave; t < ntiles; t += 8) {
+                for (int t = wave; t < ntiles; t += NW) {
                     const int ti = tri_row(t), tk = t - ti * (ti + 1) / 2;
                     const int ka = 16 * ti + (lane & 15), kb = 16 * tk + (lane & 15), eg = lane >> 4;
                     const int ca = s_cmap[ka], cb = s_cmap[kb];
@@ -1614,7 +1618,7 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
             // one LDS read-modify-write pass per tile and block column, 15 k cycles for the first columns on seven wavefronts next to a serial wavefront that
             // needed 8 k) every tile is written twice in total, the operands of an update are plain loads, and the serial wavefront only waits for its own
             // diagonal tile: it updates that one itself and goes straight on to factor it while the others update the rest of the column.
-            const int NT = (R + 16) / 16;   // tile rows: rows 0 .. R (row R carries the right-hand side)
+            const int NTR = (R + 16) / 16;   // tile rows: rows 0 .. R (row R carries the right-hand side)
             auto upd_tile = [&](int ti, int tj, int k0, int k1) {   // tile (ti, tj), ti >= tj, minus the products of the block rows ti and tj over the block columns k0 .. k1 - 1 (< tj)
                 const int ra = 16 * ti + (lane & 15), rb = 16 * tj + (lane & 15), kq = lane >> 4;
                 const bool va = ra <= R, vb = rb < R;   // row R (rhs) never acts as a column
@@ -1655,8 +1659,8 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
                     diag_block(j0);
                     __builtin_amdgcn_s_setprio(0);
                 } else {
-                    if (jb > 0) for (int t = wave; t < NT - jb; t += 7) upd_tile(jb + t, jb, 0, jb);
-                    if (wave == 7 && jb + 1 < NT && 16 * (jb + 1) < R) upd_tile(jb + 1, jb + 1, 0, jb);
+                    if (jb > 0) for (int t = wave; t < NTR - jb; t += NW - 1) upd_tile(jb + t, jb, 0, jb);
+                    if (wave == NW - 1 && jb + 1 < NTR && 16 * (jb + 1) < R) upd_tile(jb + 1, jb + 1, 0, jb);
                 }
 #ifdef GF_PROFILE_STEP
                 if (blockIdx.x == 0 && sb.stamps && (tid == 0 || tid == 64 || tid == 256) && jb < 12) sb.stamps[(tid == 0 ? 40 : tid == 64 ? 56 : 72) + jb] = clock64() - w0c;
@@ -1669,7 +1673,7 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
                 auto panel = [&](auto full) {
                     constexpr bool FULL = decltype(full)::value;
                     const int nrows = R + 1 - r0, nt = (nrows + 15) / 16;
-                    for (int t = wave; t < nt; t += 8) {
+                    for (int t = wave; t < nt; t += NW) {
                         const int ra = r0 + 16 * t + (lane & 15);
                         const int rb_ = pk(min(ra, R), j0);
                         d4 acc = {0, 0, 0, 0};
@@ -1703,7 +1707,7 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
                 // block's solution to the NEXT block's sixteen entries itself; the other wavefronts apply it to everything below that, one block behind
                 // and into an accumulator of their own (s_rd), so that no entry is updated from both sides.  One barrier per block instead of two, and the
                 // chain no longer waits for the wide update (11 x 3.8 k -> 11 x ~1.7 k cycles).
-                for (int r = tid; r < R; r += 512) s_rd[r] = 0.0;
+                for (int r = tid; r < R; r += NT) s_rd[r] = 0.0;
                 __syncthreads();
                 for (int j0 = ((R - 1) / 16) * 16, par = 0; j0 >= 0; j0 -= 16, par ^= 1) {
                     const int nb = min(16, R - j0);
@@ -1761,7 +1765,7 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
 #endif
                     if (wave > 0) {
                         const double* yb = s_y + 16 * par;
-                        for (int r = tid - 64; r < j0 - 16; r += 448) {
+                        for (int r = tid - 64; r < j0 - 16; r += NT - 64) {
                             double lv[16];
 #pragma unroll
                             for (int c = 0; c < 16; c++) lv[c] = c < nb ? S[pk(j0 + c, r)] : 0.0;
@@ -1776,7 +1780,7 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
                 GF_STAMP(10);
                 // back-substitute the eliminated columns (one wavefront per row), check finiteness
                 double bad = 0;
-                for (int c = tid; c < R; c += 512) if (!isfinite(yv[c])) bad = 1;
+                for (int c = tid; c < R; c += NT) if (!isfinite(yv[c])) bad = 1;
                 if (tid < ECW) { const int c = s_cmap[tid]; s_uc[tid] = (c >= 0 && c < R) ? yv[c] : 0.0; }
                 __syncthreads();
                 {   // sixteen lanes per eliminated column (four columns per wavefront instruction, two such groups in flight): acc_e = sum_k Es[e][k] y_k with
@@ -1784,11 +1788,11 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
                     // direction's dot product with the unscaled row; both reduced inside the 16-lane row by DPP
                     constexpr int EM = GS ? 9 : 5;   // compact columns per lane: ECW <= 16 EM (6 (W + 1) + 8 padded to 16; W <= 10 in LDS, <= 20 in global memory)
                     const int sub = lane & 15, grp = lane >> 4;
-                    for (int e0 = 4 * wave + grp; e0 < NE; e0 += 64) {
+                    for (int e0 = 4 * wave + grp; e0 < NE; e0 += 8 * NW) {
                         double etv[2][EM], fe[2];
 #pragma unroll
                         for (int h = 0; h < 2; h++) {
-                            const int e = e0 + 32 * h;
+                            const int e = e0 + 4 * NW * h;
                             const bool live = e < NE;
                             fe[h] = live ? u[RP + e] : 0.0;
                             const double* src = Et + (size_t)min(e, NE - 1) * ECW;
@@ -1797,7 +1801,7 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
                         }
 #pragma unroll
                         for (int h = 0; h < 2; h++) {
-                            const int e = e0 + 32 * h;
+                            const int e = e0 + 4 * NW * h;
                             double accy = 0.0, accu = 0.0;
 #pragma unroll
                             for (int q = 0; q < EM; q++) {
@@ -1820,18 +1824,18 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
                     }
                 }
                 if (need_alpha) {
-                    const double uHu = block_sum(uHu_acc, sred, tid, 512);
+                    const double uHu = block_sum<NW>(uHu_acc, sred, tid, NT);
                     if (tid == 0) st.alpha = gsq / uHu;
                     need_alpha = false;
                 }
-                bad = block_max(bad, sred, tid, 512);
+                bad = block_max<NW>(bad, sred, tid, NT);
                 if (bad > 0) ok = false;
             }
             if (!ok) { __syncthreads(); if (tid == 0) st.mu *= 10.0; __syncthreads(); }
         }
         if (tid == 0) s_flag[2] = ok ? 1 : 0;
         __syncthreads();
-        if (ok) for (int c = tid; c < R; c += 512) gn[c] = -diag[c] * yv[c];
+        if (ok) for (int c = tid; c < R; c += NT) gn[c] = -diag[c] * yv[c];
         __syncthreads();
         if (tid == 0) { st.reuse = 1; st.mu_solved = st.mu; }
     } else if (tid == 0) s_flag[2] = 1;
@@ -1841,10 +1845,10 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
     // ---------------- traditional dogleg interpolation (dogleg_strategy.cc ComputeTraditionalDoglegStep)
     if (valid) {
         double a = 0, c2 = 0, dt = 0;
-        for (int c = tid; c < R; c += 512) { a += grad[c] * grad[c]; c2 += gn[c] * gn[c]; dt += grad[c] * gn[c]; }
-        for (int e = tid; e < NE; e += 512) { a += grad[RP + e] * grad[RP + e]; c2 += gn[RP + e] * gn[RP + e]; dt += grad[RP + e] * gn[RP + e]; }
+        for (int c = tid; c < R; c += NT) { a += grad[c] * grad[c]; c2 += gn[c] * gn[c]; dt += grad[c] * gn[c]; }
+        for (int e = tid; e < NE; e += NT) { a += grad[RP + e] * grad[RP + e]; c2 += gn[RP + e] * gn[RP + e]; dt += grad[RP + e] * gn[RP + e]; }
         double v3[3] = {a, c2, dt};
-        block_sum_n(v3, sred, tid);
+        block_sum_n<3, NW>(v3, sred, tid);
         const double gnorm = sqrt(v3[0]), gnn = sqrt(v3[1]), gdot = v3[2];
         const double radius = st.radius, alpha = st.alpha;
         double ca, cb, dsn;  // step = ca * grad + cb * gn
@@ -1857,9 +1861,9 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
             ca = -alpha * (1.0 - beta); cb = beta; dsn = -1;
         }
         double nn = 0;
-        for (int c = tid; c < R; c += 512) { const double sv = ca * grad[c] + cb * gn[c]; nn += sv * sv; stepv[c] = sv / diag[c]; u[c] = scale[c] * stepv[c]; }
-        for (int e = tid; e < NE; e += 512) { const double sv = ca * grad[RP + e] + cb * gn[RP + e]; nn += sv * sv; stepv[RP + e] = sv / diag[RP + e]; u[RP + e] = scale[RP + e] * stepv[RP + e]; }
-        nn = block_sum(nn, sred, tid, 512);
+        for (int c = tid; c < R; c += NT) { const double sv = ca * grad[c] + cb * gn[c]; nn += sv * sv; stepv[c] = sv / diag[c]; u[c] = scale[c] * stepv[c]; }
+        for (int e = tid; e < NE; e += NT) { const double sv = ca * grad[RP + e] + cb * gn[RP + e]; nn += sv * sv; stepv[RP + e] = sv / diag[RP + e]; u[RP + e] = scale[RP + e] * stepv[RP + e]; }
+        nn = block_sum<NW>(nn, sred, tid, NT);
         if (dsn < 0) dsn = sqrt(nn);
         if (tid == 0) st.dogleg_step_norm = dsn;
         GF_STAMP(12);
@@ -1879,11 +1883,11 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
     GF_STAMP(13);
     // ---------------- candidate point x (+) delta, delta = step .* scale = u  (its normal equations are written, not accumulated, by the next sweeps)
     double* xc = w.xs + ((size_t)(1 - cur) * d.B + b) * d.XS;
-    for (int i = tid; i < d.XS; i += 512) xc[i] = xs[i];
+    for (int i = tid; i < d.XS; i += NT) xc[i] = xs[i];
     __syncthreads();
     double sn = 0, xn = 0;
     if (valid) {
-        for (int blk = tid; blk < d.NFB + d.F; blk += 512) {
+        for (int blk = tid; blk < d.NFB + d.F; blk += NT) {
             int c0, off, kind;
             if (blk < d.NFB) {
                 c0 = colf[blk];
@@ -1912,7 +1916,7 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
             for (int q = 0; q < gs; q++) { const double dv = xs[off + q] - xc[off + q]; sn += dv * dv; xn += xs[off + q] * xs[off + q]; }
         }
     }
-    { double v2[2] = {sn, xn}; block_sum_n(v2, sred, tid); sn = v2[0]; xn = v2[1]; }
+    { double v2[2] = {sn, xn}; block_sum_n<2, NW>(v2, sred, tid); sn = v2[0]; xn = v2[1]; }
     GF_STAMP(14);
     if (tid == 0) {
         st.step_norm = sqrt(sn); st.x_norm = sqrt(xn);
@@ -1925,8 +1929,8 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
         }
     }
 }
-template <bool GS>
-__global__ void __launch_bounds__(512) ba_step(Win w, StepBufs sb, int first, int max_iters, int finalize_only) { ba_step_body<GS>(w, sb, first, max_iters, finalize_only); }
+template <bool GS, int NW = 8>
+__global__ void __launch_bounds__(64 * NW) ba_step(Win w, StepBufs sb, int first, int max_iters, int finalize_only) { ba_step_body<GS, NW>(w, sb, first, max_iters, finalize_only); }
 // The prior / IMU / wheel sweep of the candidate and the step that judges it in one launch (LDS-resident systems without GNSS blocks): the sweep's H, g and costs
 // are read by the same block right away, and the launch boundary between the two -- with the write-back of everything the sweep stored -- is gone.
 __global__ void __launch_bounds__(512) ba_misc_step(Win w, StepBufs sb, int max_iters, int finalize_only) {

@@ -83,12 +83,16 @@ static int run_rank(int rank, int world, const char* config, const std::vector<s
             if (k < (int)dirs.size()) {
                 gf::Estimator estimator;
                 replay_one(config, dirs[k], false, dirs[k] + "/vio.txt", estimator, true);
-                const int W = estimator.cfg.window_size;
-                const gf::Mat3& R = estimator.Rs[W];
+                // the state straight from the handle: the class mirrors it after inputImage, and the last frame is processed when the IMU samples behind it arrive
+                const int W = estimator.cfg.window_size, N = W + 1;
+                std::vector<double> Pa(3 * N), Ra(9 * N), Va(3 * N), Baa(3 * N), Bga(3 * N), Ha(N);
+                int info[16]; double extr[32];
+                if (gf_estimator_get_state(estimator.handle(), Pa.data(), Ra.data(), Va.data(), Baa.data(), Bga.data(), Ha.data(), info, extr) != GF_OK) throw std::runtime_error(gf_last_error());
+                const double* R = Ra.data() + 9 * W;
                 const double t = R[0] + R[4] + R[8];
                 double q[4] = {0, 0, 0, 1};                   // Eigen::Quaterniond(R) for trace > 0 (a ground vehicle near its start attitude); else left as the identity
                 if (t > 0) { const double s = std::sqrt(t + 1.0) * 2.0; q[3] = 0.25 * s; q[0] = (R[7] - R[5]) / s; q[1] = (R[2] - R[6]) / s; q[2] = (R[3] - R[1]) / s; }
-                for (int c = 0; c < 3; c++) mine[c] = estimator.Ps[W][c];
+                for (int c = 0; c < 3; c++) mine[c] = Pa[3 * W + c];
                 for (int c = 0; c < 4; c++) mine[3 + c] = q[c];
                 mine[7] = 1.0;
             }
@@ -121,7 +125,8 @@ int main(int argc, char** argv) {
         for (int r = 0; r < world; r++) {                    // fork before anything touches the HIP runtime: every rank initialises its own
             const pid_t p = fork();
             if (p < 0) { perror("fork"); return 1; }
-            if (p == 0) _exit(run_rank(r, world, argv[3], dirs, idfile));
+            if (p == 0) { const int rc = run_rank(r, world, argv[3], dirs, idfile); fflush(nullptr); _exit(rc); }   // _exit: the parent's atexit handlers are not this child's
+
             kids.push_back(p);
         }
         int rc = 0;
