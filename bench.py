@@ -153,26 +153,55 @@ def pmc_summary():
         return {}
 
 
-def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False, device_sweeps=False):
-    """The drop-in path on a bounded sample: `nseq` sequences (one seeded synthetic RGB-D + IMU + wheel stream, replicated) through the batched
-    tracker (trackImage on every camera frame) and gf_estimator_group_* (inputFeature -> processImage -> batched solve + marginalisation on
-    every second frame, the reference's MULTIPLE_THREAD flow): the back end is fed by the tracker's own output; as in the reference the tracker
-    (sync_process thread) and the estimators (processThread) run concurrently, one frame apart.  Returns window-solves/s over the frames on
-    which the windows are live (NON_LINEAR): wall-clock including the tracker, host bookkeeping, uploads and downloads, excluding only the
-    Python loop that hands the IMU / wheel samples to the members."""
+_E2E_INPUTS = {}
+
+
+def e2e_inputs(n_streams, dev):
+    """`n_streams` distinct seeded RGB-D + IMU + wheel recordings of the same length, rendered once (input synthesis, outside every timed part).  Stream 0 is the
+    recording the homogeneous sample replicates; the others differ in seed (texture, landmarks, noise), speed, turn and -- the point -- in when they start to move
+    (0.1 s apart), so that at any frame some sequences vote "keyframe" (MARGIN_OLD) while others still stand (MARGIN_SECOND_NEW) and the batches the group forms
+    are mixed.  Returns (streams, gray [frames][n_streams, H, W] u8, depth [frames][n_streams, H, W] i16)."""
+    if n_streams in _E2E_INPUTS:
+        return _E2E_INPUTS[n_streams]
+    import synth_stream as SS
+    T = 3.0
+    streams = []
+    for q in range(n_streams):
+        t_still = 1.5 + 0.1 * q
+        streams.append(SS.Stream(1 + q, t_still=t_still, t_move=T - t_still, v_max=0.4 - 0.02 * (q % 4), yaw0=0.0, yaw_turn=-0.6 if q % 2 == 0 else 0.5, split_x=1.8,
+                                 turn_delay=0.8 - 0.05 * q))
+    n = len(streams[0].cam_t)
+    assert all(len(st.cam_t) == n and np.array_equal(st.cam_t, streams[0].cam_t) for st in streams)
+    gray, depth = [], []
+    for k in range(n):
+        gs, ds = [], []
+        for st in streams:
+            cache = st.__dict__.setdefault("_bench_cache", {})
+            key = (tuple(np.round(st.p_wb(st.cam_t[k]), 9)), round(float(st._at(st._psi, st.cam_t[k])), 9))   # identical poses (the stationary lead-in) share a frame
+            if key not in cache:
+                img, dep = st.image(k)
+                cache[key] = (torch.from_numpy(img), torch.from_numpy(dep.view(np.int16)))
+            gs.append(cache[key][0]); ds.append(cache[key][1])
+        gray.append(torch.stack(gs).to(dev)); depth.append(torch.stack(ds).to(dev))
+    _E2E_INPUTS[n_streams] = (streams, gray, depth)
+    return _E2E_INPUTS[n_streams]
+
+
+def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False, device_sweeps=False, n_streams=1):
+    """The drop-in path on a bounded sample: `nseq` sequences -- `n_streams` distinct seeded recordings dealt round-robin (1: one recording replicated, every
+    member takes the same decisions; 8: staggered starts, mixed batches) -- through the batched tracker (trackImage on every camera frame) and gf_estimator_group_*
+    (inputFeature -> processImage -> batched solve + marginalisation on every second frame, the reference's MULTIPLE_THREAD flow): the back end is fed by the
+    tracker's own output; as in the reference the tracker (sync_process thread) and the estimators (processThread) run concurrently, one frame apart.  Returns
+    window-solves/s over the frames on which all windows are live (NON_LINEAR): wall-clock including the tracker, host bookkeeping, uploads and downloads,
+    excluding only the Python loop that hands the IMU / wheel samples to the members."""
     import ctypes as C
     import synth_stream as SS
-    st = SS.Stream(1, t_still=1.5, t_move=1.5, v_max=0.4, yaw0=0.0, yaw_turn=-0.6, split_x=1.8, turn_delay=0.8)
+    streams, gray, depth = e2e_inputs(n_streams, dev)
+    st0 = streams[0]
     cfg = gfamd.default_estimator_cfg(tio=SS.TIO, rio=SS.RIO, multiple_thread=1)
     grp = gfamd.EstimatorGroup(cfg, nseq, device_preint=device_preint, device_sweeps=device_sweeps)
     trk = gfamd.FeatureTracker(gfamd.default_cfg(batch=nseq, max_cnt=max_cnt, min_dist=min_dist))
-    frames, cache = [], {}
-    for k in range(len(st.cam_t)):      # rendering is input synthesis, outside the timed part; identical poses (the stationary lead-in) share a frame
-        key = (tuple(np.round(st.p_wb(st.cam_t[k]), 9)), round(float(st._at(st._psi, st.cam_t[k])), 9))
-        if key not in cache:
-            img, dep = st.image(k)
-            cache[key] = (torch.from_numpy(img).to(dev), torch.from_numpy(dep.view(np.int16)).to(dev))
-        frames.append(cache[key])
+    assign = torch.arange(nseq, device=dev) % n_streams
     sq = np.arange(nseq, dtype=np.int32)
     import threading
     state = {"thread": None, "err": None}
@@ -192,51 +221,111 @@ def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False, 
         if state["err"] is not None:
             raise state["err"]
 
-    tp, solves, frames_live, t_feed_live = -1.0, 0, 0, 0.0
+    tp, solves, frames_live, t_feed_live = [-1.0] * n_streams, 0, 0, 0.0
     live, t_start = False, None
-    for k in range(len(st.cam_t)):
-        g = frames[k][0].unsqueeze(0).expand(nseq, -1, -1).contiguous()
-        d = frames[k][1].unsqueeze(0).expand(nseq, -1, -1).contiguous()
+    steps_live = mixed = keyframe_votes = votes = 0
+    for k in range(len(st0.cam_t)):
+        g = gray[k].index_select(0, assign) if n_streams > 1 else gray[k].expand(nseq, -1, -1).contiguous()
+        d = depth[k].index_select(0, assign) if n_streams > 1 else depth[k].expand(nseq, -1, -1).contiguous()
         torch.cuda.synchronize()
         # the tracker of this frame runs while the estimators still work on the previous back-end frame (separate threads in the reference too: rosNodeTest.cpp:713)
-        n = trk.trackImageBatchDevice([float(st.cam_t[k])] * nseq, g.data_ptr(), d.data_ptr(), unpack=False)
+        n = trk.trackImageBatchDevice([float(st0.cam_t[k])] * nseq, g.data_ptr(), d.data_ptr(), unpack=False)
         if k % 2 == 0:
             out = trk._out
             obs = np.ascontiguousarray(out[np.arange(out.shape[1])[None, :] < n[:, None]])   # per-sequence frames back to back (a copy: the tracker reuses its buffer)
             no = np.ascontiguousarray(n, np.int32).copy()
             join()
-            now_live = grp.members[0].state()["solver_flag"] == 1
+            reps = [grp.members[q].state() for q in range(n_streams)]        # one representative per recording
+            now_live = all(r["solver_flag"] == 1 for r in reps)
+            if live:          # the decisions of the step that just finished
+                flags = [r["marginalization_flag"] for r in reps]
+                steps_live += 1; mixed += int(len(set(flags)) > 1); keyframe_votes += sum(1 for f in flags if f == 0); votes += len(flags)
             if now_live and not live:
                 live, t_start = True, time.perf_counter()
             t0 = time.perf_counter()
             for kk in (k - 1, k):          # IMU / wheel samples up to this frame: input marshalling through Python, not part of the measured path
                 if kk >= 0:
-                    for m in grp.members:
-                        t1 = st.feed(m, kk, tp)
+                    t1 = list(tp)
+                    for b, m in enumerate(grp.members):
+                        t1[b % n_streams] = streams[b % n_streams].feed(m, kk, tp[b % n_streams])
                     tp = t1
             if live:
                 t_feed_live += time.perf_counter() - t0
                 solves += nseq
                 frames_live += 2
-            state["thread"] = threading.Thread(target=group_step, args=(float(st.cam_t[k]), obs, no))
+            state["thread"] = threading.Thread(target=group_step, args=(float(st0.cam_t[k]), obs, no))
             state["thread"].start()
     join()
     t_live = (time.perf_counter() - t_start - t_feed_live) if t_start is not None else 0.0
     stt = grp.stats()
     pos = float(np.linalg.norm(grp.members[0].state()["Ps"][-1]))
     grp.close(); trk.close()
-    return {"window_solves_per_s": solves / max(t_live, 1e-9), "sequences": nseq, "live_camera_frames": frames_live, "window_solves": solves, "wall_s": t_live,
-            "ms_per_backend_frame": 1e3 * t_live / max(solves // max(nseq, 1), 1), "group_batches": stt["batches"], "largest_batch": stt["largest_batch"],
+    return {"window_solves_per_s": solves / max(t_live, 1e-9), "sequences": nseq, "distinct_recordings": n_streams, "live_camera_frames": frames_live, "window_solves": solves,
+            "wall_s": t_live, "ms_per_backend_frame": 1e3 * t_live / max(solves // max(nseq, 1), 1), "group_batches": stt["batches"], "largest_batch": stt["largest_batch"],
+            "backend_frames_with_mixed_decisions": mixed, "backend_frames_live": steps_live, "keyframe_vote_share": keyframe_votes / max(votes, 1),
             "newest_position_norm_m": pos, "device_preint": bool(device_preint),
             "path": "gf_tracker_track_batch_device -> gf_estimator_group_input_features (inputFeature -> processImage -> gf_ba solve + marginalise, "
                     "windows packed / uploaded / downloaded every frame)"}
 
 
+def pcie_sample(gfamd, trk, est, args, B, frames, depth, dt, step, frame_index, n_host=4, K=24):
+    """The boundary as the reference states it -- trackImage(const cv::Mat&) on HOST images (feature_tracker.h:47) -- next to the device-resident loop of `value`:
+    the same step with every frame (gray u8 + depth u16, 921 600 B per sequence) coming from page-locked host memory through gf_tracker_prefetch_batch /
+    gf_tracker_track_prefetched, i.e. the copy of frame k + 1 on a copy stream under frame k's kernels.  Reports the step both ways, the tracker alone both ways,
+    and the bus rate the copies reached: where the copy is longer than the kernels the path is bound by the bus and that bound is the number."""
+    hg = [frames[frame_index(i)].cpu().pin_memory() for i in range(n_host)]     # a ring of n_host frames x B sequences
+    hd = depth.cpu().pin_memory()
+    bytes_per_step = B * H * W * 3
+
+    def run(host, backend):
+        torch.cuda.synchronize()
+        if host:
+            trk.prefetchHost(hg[0].data_ptr(), hd.data_ptr())
+        t0 = time.perf_counter()
+        for i in range(K):
+            if backend:
+                est.solve_resident_async(args.ba_iters, 0, True)
+            ts = [dt * step[0]] * B
+            if host:
+                trk.prefetchHost(hg[(i + 1) % n_host].data_ptr(), hd.data_ptr())     # frame i + 1 starts to travel ...
+                trk.trackPrefetched(ts, unpack=False)                                 # ... while frame i is tracked
+            else:
+                trk.trackImageBatchDevice(ts, frames.data_ptr() + frame_index(i % n_host) * B * H * W, depth.data_ptr(), unpack=False)
+            if backend:
+                est.wait()
+            step[0] += 1
+        if host:
+            trk.trackPrefetched([dt * step[0]] * B, unpack=False)     # drain the frame that is still staged (outside the timed part)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / K
+
+    # a plain copy of one step's images, alone on the bus: what the host delivers
+    torch.cuda.synchronize()
+    dg, dd = torch.empty_like(frames[0]), torch.empty_like(depth)
+    t0 = time.perf_counter()
+    for i in range(8):
+        dg.copy_(hg[i % n_host], non_blocking=True); dd.copy_(hd, non_blocking=True)
+    torch.cuda.synchronize()
+    t_copy = (time.perf_counter() - t0) / 8
+    run(True, False); run(False, False)       # warm: second pair of frame buffers, copy stream
+    t_trk_dev, t_trk_host = run(False, False), run(True, False)
+    t_dev, t_host = run(False, True), run(True, True)
+    return {"bytes_per_step": bytes_per_step, "sequences": B, "steps": K, "host_frames_in_ring": n_host,
+            "h2d_copy_alone_ms": 1e3 * t_copy, "h2d_GBps": bytes_per_step / t_copy / 1e9,
+            "tracker_only_ms_per_step": {"device_resident": 1e3 * t_trk_dev, "host_images": 1e3 * t_trk_host},
+            "step_ms": {"device_resident": 1e3 * t_dev, "host_images": 1e3 * t_host},
+            "window_solves_per_s": {"device_resident": B / t_dev, "host_images": B / t_host},
+            "host_over_device": t_dev / t_host,
+            "bound": "bus" if t_copy > 0.9 * t_host else "kernels",
+            "note": "host_images: gray + depth of every sequence cross PCIe every frame (gf_tracker_prefetch_batch: the copy of frame k + 1 runs under the kernels of frame k); "
+                    "when h2d_copy_alone_ms exceeds the device-resident step the path is bound by the bus, not by the kernels"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=1, choices=(1, 2, 4),
                     help="index into BASELINE.json configs: 1 = 150 features, W = 10 (the configuration the metric is quoted on; default); 2 = 300 features / min_dist 20, "
                          "W = 10, full HIP path; 4 = 500 features / min_dist 12, W = 20, wheel + GNSS factors (reduced system and kept system in global memory)")
@@ -251,6 +340,8 @@ def main():
     ap.add_argument("--no-backend", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the bounded end-to-end (drop-in path) sample")
     ap.add_argument("--e2e-seqs", type=int, default=256)
+    ap.add_argument("--e2e-streams", type=int, default=8, help="distinct seeded recordings of the end-to-end sample (staggered starts: mixed keyframe / non-keyframe batches)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-image (PCIe-inclusive) sample")
     ap.add_argument("--e2e-device-preint", action="store_true", help="also run the end-to-end sample with the batched device pre-integration of the estimator group")
     ap.add_argument("--e2e-device-sweeps", action="store_true", help="also run the end-to-end sample with the batched device feature sweeps (triangulateWithDepth, movingConsistencyCheckW) of the estimator group")
     args = ap.parse_args()
@@ -293,7 +384,12 @@ def main():
         args.batch = args.strong // world
     B, K, Wm = args.batch, args.steps, args.warmup
     dt = 1.0 / 15.0
-    n_frames = Wm + K + 1 + 4   # + the frames of the isolated tracker passes after the timed region
+    # distinct frames per sequence; longer runs walk the clip forwards and backwards (continuous motion, tracks persist) instead of synthesising hundreds of frames
+    n_frames = min(Wm + K + 1 + 4, 32)
+
+    def frame_index(k):
+        m = k % max(2 * n_frames - 2, 1)
+        return m if m < n_frames else 2 * n_frames - 2 - m
     seq0 = shard.first_sequence(rank, B)  # global sequence ids [seq0, seq0 + B)
     frames, depth = make_frames(n_frames, B, 1000 + seq0, dev)
     torch.cuda.synchronize()
@@ -310,13 +406,13 @@ def main():
     pose_gather = shard.PoseGather(dist, world, [B] * world, dev)     # persistent send / receive buffers, all_gather_into_tensor over RCCL
 
     def do_step(exchange=True):
-        k = step[0] % n_frames
+        k = frame_index(step[0])
         # the back end of this step is enqueued first and runs on its own stream while the tracker (GPU kernels + host bookkeeping)
         # proceeds -- the reference runs processImage and trackImage on separate threads as well (estimator.cpp:209, rosNodeTest.cpp:713)
         if not args.no_backend:
             est.solve_resident_async(args.ba_iters, 0, True)
         if not args.no_frontend:
-            trk.trackImageBatchDevice([dt * k] * B, frames.data_ptr() + k * frame_bytes, depth.data_ptr(), unpack=False)
+            trk.trackImageBatchDevice([dt * step[0]] * B, frames.data_ptr() + k * frame_bytes, depth.data_ptr(), unpack=False)
         if not args.no_backend:
             est.wait()
             if exchange:   # north_star's only exchange: the newest pose of every sequence, all_gather over RCCL (56 B per sequence, latency-bound)
@@ -349,7 +445,7 @@ def main():
     if not args.no_frontend and not args.no_backend:
         trk.reset_stats(); est.reset_stats()
         for _ in range(4):
-            trk.trackImageBatchDevice([dt * (step[0] % n_frames)] * B, frames.data_ptr() + (step[0] % n_frames) * frame_bytes, depth.data_ptr(), unpack=False)
+            trk.trackImageBatchDevice([dt * step[0]] * B, frames.data_ptr() + frame_index(step[0]) * frame_bytes, depth.data_ptr(), unpack=False)
             step[0] += 1
         torch.cuda.synchronize()
         for _ in range(3):
@@ -441,14 +537,21 @@ def main():
                                       "bound by the latency of R/16 sequential 16x16 factor+inverse blocks, not by MFMA issue"},
             "ba_summary_seq0": sums[0],
         }
+        if world == 1 and not args.no_pcie and not args.strong and not (args.no_frontend or args.no_backend):
+            res["pcie_inclusive"] = pcie_sample(gfamd, trk, est, args, B, frames, depth, dt, step, frame_index)
         if world == 1 and not args.no_e2e and not args.strong and args.config == 1 and not (args.no_frontend or args.no_backend):
             trk.close(); trk = None
-            cold = end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist)
+            S = max(1, args.e2e_streams)
+            cold = end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, n_streams=S)
             # warm passes (host allocations and worker threads up, as in a running service): the path alternates host and device phases and a pass moves by +-10 % with
             # whatever else the host runs, so two are taken, the better one is the sample, and all three are listed
-            warm = [end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist) for _ in range(2)]
+            warm = [end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, n_streams=S) for _ in range(2)]
             res["end_to_end"] = max(warm, key=lambda r: r["window_solves_per_s"])
             res["end_to_end"]["passes_window_solves_per_s"] = [cold["window_solves_per_s"]] + [r["window_solves_per_s"] for r in warm]
+            if S > 1:   # the best case for the batching next to it: ONE recording replicated, every member takes the same keyframe decision, every rendezvous is one homogeneous batch
+                homo = end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, n_streams=1)
+                res["end_to_end_homogeneous"] = {k: homo[k] for k in ("window_solves_per_s", "sequences", "distinct_recordings", "ms_per_backend_frame", "group_batches", "largest_batch",
+                                                                      "backend_frames_with_mixed_decisions", "backend_frames_live", "keyframe_vote_share")}
             if args.e2e_device_preint:   # the steps' IMU intervals as one device launch instead of on the members' threads (same bits; slower on a many-core host)
                 alt = end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, device_preint=True)
                 res["end_to_end"]["with_device_preintegration_window_solves_per_s"] = alt["window_solves_per_s"]

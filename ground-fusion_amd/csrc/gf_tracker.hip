@@ -166,6 +166,11 @@ struct gf_tracker {
     DevBuf<uint8_t> d_img, d_raw, d_mask, d_status, d_fwd_status, d_seqmask;
     DevBuf<int> d_npts, d_cand_count, d_want, d_ncenters, d_out_n;
     DevBuf<uint16_t> d_depth, d_depth_out, d_out_depth;
+    // gf_tracker_prefetch_batch: the next frame's images on their way to the second pair of frame buffers while the current frame's kernels run
+    DevBuf<uint8_t> d_raw2; DevBuf<uint16_t> d_depth2;
+    hipStream_t copy_stream = nullptr; hipEvent_t ev_copy[2] = {nullptr, nullptr};
+    int pf_head = 0, pf_count = 0;   // FIFO of staged frames over the two pairs (0: d_raw / d_depth, 1: d_raw2 / d_depth2): oldest pair, number staged (0..2)
+    bool pf_depth[2] = {false, false};
     DevBuf<float2> d_prev_pts, d_init_pts, d_cur_pts, d_out_pts;
     DevBuf<unsigned> d_counters, d_maxkey;
     DevBuf<float> d_eig;
@@ -182,6 +187,9 @@ struct gf_tracker {
     size_t select_lds = 0;
 
     void release() {
+        d_raw2.release(); d_depth2.release();
+        for (auto& e : ev_copy) if (e) (void)hipEventDestroy(e);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
         d_img.release(); d_raw.release(); d_mask.release(); d_status.release(); d_fwd_status.release(); d_seqmask.release(); d_npts.release();
         d_cand_count.release(); d_want.release(); d_ncenters.release(); d_out_n.release(); d_depth.release(); d_depth_out.release();
         d_out_depth.release(); d_prev_pts.release(); d_init_pts.release(); d_cur_pts.release(); d_out_pts.release(); d_counters.release();
@@ -661,6 +669,61 @@ int gf_tracker_track_batch(gf_tracker* h, const double* t, const uint8_t* const*
             HIPCHK(hipMemcpy2DAsync(h->d_depth.p + (size_t)b * W * H, (size_t)W * 2, depth[b], (size_t)dstride * 2, (size_t)W * 2, H, hipMemcpyHostToDevice, h->stream));
     return gf::track_core(h, t, h->d_raw.p, have_depth ? h->d_depth.p : nullptr, out, cap, n_out);
 }
+
+// The host-image boundary (trackImage(const cv::Mat&), feature_tracker.h:47) without serialising on the bus: the images of frame k + 1 go to the second pair of
+// frame buffers on a copy stream while frame k's kernels run; gf_tracker_track_prefetched then only waits for that copy.  The host images must stay valid until
+// the matching gf_tracker_track_prefetched returns, and only page-locked memory (gf_host_alloc / hipHostRegister) makes the copy asynchronous.
+int gf_tracker_prefetch_batch(gf_tracker* h, const uint8_t* const* gray, int stride, const uint16_t* const* depth, int dstride) {
+    if (!h || !gray) return gf::set_err(GF_ERR_INVALID, "null argument");
+    const int W = h->cfg.width, H = h->cfg.height;
+    if (!h->copy_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        for (auto& e : h->ev_copy) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if (int rc = h->d_raw2.alloc((size_t)h->B * W * H)) return rc;
+        if (int rc = h->d_depth2.alloc((size_t)h->B * W * H)) return rc;
+    }
+    if (h->pf_count >= 2) return gf::set_err(GF_ERR_CAPACITY, "two frames are staged already: gf_tracker_track_prefetched has to consume one first");
+    const int slot = (h->pf_head + h->pf_count) & 1;      // a pair no frame in flight uses: track calls return when their frame is done
+    uint8_t* raw = slot ? h->d_raw2.p : h->d_raw.p;
+    uint16_t* dep = slot ? h->d_depth2.p : h->d_depth.p;
+    bool have_depth = depth != nullptr;
+    for (int b = 0; b < h->B; b++) {
+        if (!gray[b]) return gf::set_err(GF_ERR_INVALID, "null image for sequence %d", b);
+        if (have_depth && !depth[b]) have_depth = false;
+    }
+    // images that sit back to back in one allocation (a pinned ring of frames) go as ONE copy per plane: 256 separate 2-D copies cost more host time than the bus needs
+    bool contig = stride == W && (!have_depth || dstride == W);
+    for (int b = 1; b < h->B && contig; b++) contig = gray[b] == gray[0] + (size_t)b * W * H && (!have_depth || depth[b] == depth[0] + (size_t)b * W * H);
+    if (contig) {
+        HIPCHK(hipMemcpyAsync(raw, gray[0], (size_t)h->B * W * H, hipMemcpyHostToDevice, h->copy_stream));
+        if (have_depth) HIPCHK(hipMemcpyAsync(dep, depth[0], (size_t)h->B * W * H * 2, hipMemcpyHostToDevice, h->copy_stream));
+    } else {
+        for (int b = 0; b < h->B; b++) HIPCHK(hipMemcpy2DAsync(raw + (size_t)b * W * H, W, gray[b], stride, W, H, hipMemcpyHostToDevice, h->copy_stream));
+        if (have_depth)
+            for (int b = 0; b < h->B; b++) HIPCHK(hipMemcpy2DAsync(dep + (size_t)b * W * H, (size_t)W * 2, depth[b], (size_t)dstride * 2, (size_t)W * 2, H, hipMemcpyHostToDevice, h->copy_stream));
+    }
+    HIPCHK(hipEventRecord(h->ev_copy[slot], h->copy_stream));
+    h->pf_depth[slot] = have_depth;
+    h->pf_count++;
+    return GF_OK;
+}
+
+int gf_tracker_track_prefetched(gf_tracker* h, const double* t, gf_feature_obs* out, int cap, int* n_out) {
+    if (!h || !t || !out || !n_out) return gf::set_err(GF_ERR_INVALID, "null argument");
+    if (!h->pf_count) return gf::set_err(GF_ERR_INVALID, "gf_tracker_track_prefetched without a staged frame (call gf_tracker_prefetch_batch first)");
+    const int slot = h->pf_head;
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_copy[slot], 0));
+    h->pf_head ^= 1; h->pf_count--;
+    return gf::track_core(h, t, slot ? h->d_raw2.p : h->d_raw.p, h->pf_depth[slot] ? (slot ? h->d_depth2.p : h->d_depth.p) : nullptr, out, cap, n_out);
+}
+
+// page-locked host memory for frames that are handed to gf_tracker_prefetch_batch / gf_tracker_track_batch (pageable memory makes hipMemcpyAsync synchronous)
+int gf_host_alloc(size_t bytes, void** out) {
+    if (!out || !bytes) return gf::set_err(GF_ERR_INVALID, "bad argument");
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipHostMalloc(%zu) failed", bytes);
+    return GF_OK;
+}
+int gf_host_free(void* p) { if (p) (void)hipHostFree(p); return GF_OK; }
 
 int gf_tracker_track(gf_tracker* h, int seq, double t, const uint8_t* gray, int stride, const uint16_t* depth, int dstride, gf_feature_obs* out,
                      int cap, int* n_out) {

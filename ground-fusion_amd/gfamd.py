@@ -138,6 +138,23 @@ class FeatureTracker:
                                                  self._out.ctypes.data_as(C.POINTER(FeatureObs)), self.cap, _p(self._n, C.c_int)))
         return self._unpack(self._out, self._n) if unpack else self._n
 
+    def prefetchHost(self, gray_addr, depth_addr=None):
+        """gf_tracker_prefetch_batch on a block of `batch` frames lying back to back in (page-locked) host memory: gray_addr / depth_addr = integer host addresses
+        of batch x height x width u8 / u16 images; the copy runs on the tracker's copy stream while the frame in flight is processed"""
+        B, n = self.cfg.batch, self.cfg.width * self.cfg.height
+        gp = (C.POINTER(C.c_uint8) * B)(*[C.cast(gray_addr + b * n, C.POINTER(C.c_uint8)) for b in range(B)])
+        dp = (C.POINTER(C.c_uint16) * B)(*[C.cast(depth_addr + 2 * b * n, C.POINTER(C.c_uint16)) for b in range(B)]) if depth_addr else None
+        _chk(lib().gf_tracker_prefetch_batch(self.h, gp, self.cfg.width, dp, self.cfg.width))
+
+    def trackPrefetched(self, ts, unpack=True):
+        B = self.cfg.batch
+        ts = np.ascontiguousarray(ts, np.float64)
+        if not hasattr(self, "_out"):
+            self._out = np.zeros((B, self.cap), OBS_DTYPE)
+            self._n = np.zeros(B, np.int32)
+        _chk(lib().gf_tracker_track_prefetched(self.h, _p(ts, C.c_double), self._out.ctypes.data_as(C.POINTER(FeatureObs)), self.cap, _p(self._n, C.c_int)))
+        return self._unpack(self._out, self._n) if unpack else self._n
+
     def setPrediction(self, ids, xyz, seq=0):
         ids = np.ascontiguousarray(ids, np.int32)
         xyz = np.ascontiguousarray(xyz, np.float64)

@@ -80,6 +80,15 @@ int gf_tracker_track(gf_tracker* h, int seq, double t, const uint8_t* gray, int 
 int gf_tracker_track_batch(gf_tracker* h, const double* t, const uint8_t* const* gray, int stride,
                            const uint16_t* const* depth, int dstride, gf_feature_obs* out, int cap, int* n_out);
 
+/* The same boundary without serialising on the bus: gf_tracker_prefetch_batch starts the host -> device copy of the NEXT frame (a second pair of frame buffers,
+ * a copy stream) and returns; gf_tracker_track_prefetched runs trackImage on the OLDEST staged frame as soon as its copy has landed.  Up to two frames can
+ * be staged; call order: prefetch(0), then per frame k: prefetch(k + 1), track_prefetched(k) -- the copy of k + 1 runs under the kernels of k.  The host images must stay valid until the matching track_prefetched returns; only page-locked memory (gf_host_alloc,
+ * or the caller's hipHostRegister) makes the copy overlap.  Images that lie back to back in one allocation travel as one copy per plane. */
+int gf_tracker_prefetch_batch(gf_tracker* h, const uint8_t* const* gray, int stride, const uint16_t* const* depth, int dstride);
+int gf_tracker_track_prefetched(gf_tracker* h, const double* t, gf_feature_obs* out, int cap, int* n_out);
+int gf_host_alloc(size_t bytes, void** out);
+int gf_host_free(void* p);
+
 /* Same with the images already resident in HBM: d_gray = batch contiguous height*width u8 images,
  * d_depth = batch contiguous height*width u16 images (or NULL).  Device pointers of the current device. */
 int gf_tracker_track_batch_device(gf_tracker* h, const double* t, const void* d_gray, const void* d_depth,

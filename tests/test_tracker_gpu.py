@@ -245,3 +245,33 @@ def test_device_resident_entry_point(gf, oracle):
         oi, oo = otr.track(0.1 * k, f, depth[k])
         assert np.array_equal(oi, gi) and np.array_equal(oo.view(np.uint64), go.view(np.uint64))
     gtr.close()
+
+
+def test_prefetched_host_frames_match_the_device_route(gf):
+    """gf_tracker_prefetch_batch / gf_tracker_track_prefetched (the host-image boundary with the copy of frame k + 1 under frame k's kernels): ids and
+    observations identical to the same frames handed over on the device, over a sequence that alternates the two frame-buffer pairs"""
+    import torch
+    B = 3
+    seqs = [synth.tracker_sequence(40 + b, 6) for b in range(B)]
+    depth = np.full(seqs[0][0].shape, 1800, np.uint16)
+    a = gf.FeatureTracker(gf.default_cfg(batch=B))
+    c = gf.FeatureTracker(gf.default_cfg(batch=B))
+    host_g = [torch.from_numpy(np.stack([seqs[b][k] for b in range(B)])).pin_memory() for k in range(6)]
+    host_d = torch.from_numpy(np.stack([depth] * B).view(np.int16)).pin_memory()
+    c.prefetchHost(host_g[0].data_ptr(), host_d.data_ptr())
+    for k in range(6):
+        dg = host_g[k].cuda()
+        dd = host_d.cuda()
+        ra = a.trackImageBatchDevice([0.0666 * k] * B, dg.data_ptr(), dd.data_ptr())
+        if k + 1 < 6:
+            c.prefetchHost(host_g[k + 1].data_ptr(), host_d.data_ptr())     # two frames staged: k (oldest) and k + 1, whose copy runs under the kernels of k
+        if k == 0:
+            with pytest.raises(gf.GfError, match="two frames are staged"):
+                c.prefetchHost(host_g[2].data_ptr(), host_d.data_ptr())
+        rc_ = c.trackPrefetched([0.0666 * k] * B)
+        for (ia, oa), (ic, oc) in zip(ra, rc_):
+            assert np.array_equal(ia, ic) and np.array_equal(oa.view(np.uint64), oc.view(np.uint64)), k
+        assert len(ra[0][0]) > 50
+    with pytest.raises(gf.GfError, match="without a staged frame"):
+        c.trackPrefetched([1.0] * B)
+    a.close(); c.close()
