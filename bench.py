@@ -187,37 +187,43 @@ def e2e_inputs(n_streams, dev):
     return _E2E_INPUTS[n_streams]
 
 
-def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False, device_sweeps=False, n_streams=1):
+def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False, device_sweeps=False, n_streams=1, n_groups=1):
     """The drop-in path on a bounded sample: `nseq` sequences -- `n_streams` distinct seeded recordings dealt round-robin (1: one recording replicated, every
     member takes the same decisions; 8: staggered starts, mixed batches) -- through the batched tracker (trackImage on every camera frame) and gf_estimator_group_*
     (inputFeature -> processImage -> batched solve + marginalisation on every second frame, the reference's MULTIPLE_THREAD flow): the back end is fed by the
     tracker's own output; as in the reference the tracker (sync_process thread) and the estimators (processThread) run concurrently, one frame apart.  Returns
     window-solves/s over the frames on which all windows are live (NON_LINEAR): wall-clock including the tracker, host bookkeeping, uploads and downloads,
-    excluding only the Python loop that hands the IMU / wheel samples to the members."""
+    excluding only the Python loop that hands the IMU / wheel samples to the members.
+    n_groups > 1: the sequences are split over that many estimator groups (gf_estimator_group_*: own back-end handle, own stream, own worker threads), stepped from
+    one thread each: while one group's batch is on the GPU the other group's members do their host work, so host and device phases of a frame overlap."""
     import ctypes as C
     import synth_stream as SS
     streams, gray, depth = e2e_inputs(n_streams, dev)
     st0 = streams[0]
     cfg = gfamd.default_estimator_cfg(tio=SS.TIO, rio=SS.RIO, multiple_thread=1)
-    grp = gfamd.EstimatorGroup(cfg, nseq, device_preint=device_preint, device_sweeps=device_sweeps)
+    bounds = [nseq * q // n_groups for q in range(n_groups + 1)]
+    grps = [gfamd.EstimatorGroup(cfg, bounds[q + 1] - bounds[q], device_preint=device_preint, device_sweeps=device_sweeps) for q in range(n_groups)]
+    members = [m for g_ in grps for m in g_.members]
     trk = gfamd.FeatureTracker(gfamd.default_cfg(batch=nseq, max_cnt=max_cnt, min_dist=min_dist))
     assign = torch.arange(nseq, device=dev) % n_streams
-    sq = np.arange(nseq, dtype=np.int32)
     import threading
-    state = {"thread": None, "err": None}
+    state = {"threads": [], "err": None}
 
-    def group_step(tk, obs, no):   # inputFeature -> processImage -> solve -> marginalise of all sequences (the reference's processThread, estimator.cpp:209)
+    def group_step(q, tk, obs, no):   # inputFeature -> processImage -> solve -> marginalise of group q's sequences (the reference's processThread, estimator.cpp:209)
         try:
-            tt = np.full(nseq, tk)
-            gfamd._chk(gfamd.lib().gf_estimator_group_input_features(grp.g, nseq, sq.ctypes.data_as(C.POINTER(C.c_int)), tt.ctypes.data_as(C.POINTER(C.c_double)),
-                                                                     obs.ctypes.data_as(C.c_void_p), no.ctypes.data_as(C.POINTER(C.c_int))))
+            cnt = bounds[q + 1] - bounds[q]
+            sq = np.arange(cnt, dtype=np.int32)
+            tt = np.full(cnt, tk)
+            o0 = int(no[:bounds[q]].sum())
+            gfamd._chk(gfamd.lib().gf_estimator_group_input_features(grps[q].g, cnt, sq.ctypes.data_as(C.POINTER(C.c_int)), tt.ctypes.data_as(C.POINTER(C.c_double)),
+                                                                     C.c_void_p(obs.ctypes.data + o0 * obs.itemsize), no[bounds[q]:].ctypes.data_as(C.POINTER(C.c_int))))
         except Exception as e:   # noqa: BLE001
             state["err"] = e
 
     def join():
-        if state["thread"] is not None:
-            state["thread"].join()
-            state["thread"] = None
+        for th in state["threads"]:
+            th.join()
+        state["threads"] = []
         if state["err"] is not None:
             raise state["err"]
 
@@ -235,7 +241,7 @@ def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False, 
             obs = np.ascontiguousarray(out[np.arange(out.shape[1])[None, :] < n[:, None]])   # per-sequence frames back to back (a copy: the tracker reuses its buffer)
             no = np.ascontiguousarray(n, np.int32).copy()
             join()
-            reps = [grp.members[q].state() for q in range(n_streams)]        # one representative per recording
+            reps = [members[q].state() for q in range(n_streams)]        # one representative per recording
             now_live = all(r["solver_flag"] == 1 for r in reps)
             if live:          # the decisions of the step that just finished
                 flags = [r["marginalization_flag"] for r in reps]
@@ -246,21 +252,25 @@ def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False, 
             for kk in (k - 1, k):          # IMU / wheel samples up to this frame: input marshalling through Python, not part of the measured path
                 if kk >= 0:
                     t1 = list(tp)
-                    for b, m in enumerate(grp.members):
+                    for b, m in enumerate(members):
                         t1[b % n_streams] = streams[b % n_streams].feed(m, kk, tp[b % n_streams])
                     tp = t1
             if live:
                 t_feed_live += time.perf_counter() - t0
                 solves += nseq
                 frames_live += 2
-            state["thread"] = threading.Thread(target=group_step, args=(float(st0.cam_t[k]), obs, no))
-            state["thread"].start()
+            state["threads"] = [threading.Thread(target=group_step, args=(q, float(st0.cam_t[k]), obs, no)) for q in range(n_groups)]
+            for th in state["threads"]:
+                th.start()
     join()
     t_live = (time.perf_counter() - t_start - t_feed_live) if t_start is not None else 0.0
-    stt = grp.stats()
-    pos = float(np.linalg.norm(grp.members[0].state()["Ps"][-1]))
-    grp.close(); trk.close()
-    return {"window_solves_per_s": solves / max(t_live, 1e-9), "sequences": nseq, "distinct_recordings": n_streams, "live_camera_frames": frames_live, "window_solves": solves,
+    stts = [g_.stats() for g_ in grps]
+    stt = {"batches": sum(s_["batches"] for s_ in stts), "largest_batch": max(s_["largest_batch"] for s_ in stts)}
+    pos = float(np.linalg.norm(members[0].state()["Ps"][-1]))
+    for g_ in grps:
+        g_.close()
+    trk.close()
+    return {"window_solves_per_s": solves / max(t_live, 1e-9), "sequences": nseq, "distinct_recordings": n_streams, "estimator_groups": n_groups, "live_camera_frames": frames_live, "window_solves": solves,
             "wall_s": t_live, "ms_per_backend_frame": 1e3 * t_live / max(solves // max(nseq, 1), 1), "group_batches": stt["batches"], "largest_batch": stt["largest_batch"],
             "backend_frames_with_mixed_decisions": mixed, "backend_frames_live": steps_live, "keyframe_vote_share": keyframe_votes / max(votes, 1),
             "newest_position_norm_m": pos, "device_preint": bool(device_preint),
@@ -341,6 +351,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the bounded end-to-end (drop-in path) sample")
     ap.add_argument("--e2e-seqs", type=int, default=256)
     ap.add_argument("--e2e-streams", type=int, default=8, help="distinct seeded recordings of the end-to-end sample (staggered starts: mixed keyframe / non-keyframe batches)")
+    ap.add_argument("--e2e-groups", type=int, default=1, help="estimator groups the end-to-end sample splits its sequences over (own handle, stream and workers each: one group's host phase overlaps the other's batch)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-image (PCIe-inclusive) sample")
     ap.add_argument("--e2e-device-preint", action="store_true", help="also run the end-to-end sample with the batched device pre-integration of the estimator group")
     ap.add_argument("--e2e-device-sweeps", action="store_true", help="also run the end-to-end sample with the batched device feature sweeps (triangulateWithDepth, movingConsistencyCheckW) of the estimator group")
@@ -542,15 +553,15 @@ def main():
         if world == 1 and not args.no_e2e and not args.strong and args.config == 1 and not (args.no_frontend or args.no_backend):
             trk.close(); trk = None
             S = max(1, args.e2e_streams)
-            cold = end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, n_streams=S)
+            cold = end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, n_streams=S, n_groups=args.e2e_groups)
             # warm passes (host allocations and worker threads up, as in a running service): the path alternates host and device phases and a pass moves by +-10 % with
             # whatever else the host runs, so two are taken, the better one is the sample, and all three are listed
-            warm = [end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, n_streams=S) for _ in range(2)]
+            warm = [end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, n_streams=S, n_groups=args.e2e_groups) for _ in range(2)]
             res["end_to_end"] = max(warm, key=lambda r: r["window_solves_per_s"])
             res["end_to_end"]["passes_window_solves_per_s"] = [cold["window_solves_per_s"]] + [r["window_solves_per_s"] for r in warm]
             if S > 1:   # the best case for the batching next to it: ONE recording replicated, every member takes the same keyframe decision, every rendezvous is one homogeneous batch
-                homo = end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, n_streams=1)
-                res["end_to_end_homogeneous"] = {k: homo[k] for k in ("window_solves_per_s", "sequences", "distinct_recordings", "ms_per_backend_frame", "group_batches", "largest_batch",
+                homo = end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, n_streams=1, n_groups=args.e2e_groups)
+                res["end_to_end_homogeneous"] = {k: homo[k] for k in ("window_solves_per_s", "sequences", "distinct_recordings", "estimator_groups", "ms_per_backend_frame", "group_batches", "largest_batch",
                                                                       "backend_frames_with_mixed_decisions", "backend_frames_live", "keyframe_vote_share")}
             if args.e2e_device_preint:   # the steps' IMU intervals as one device launch instead of on the members' threads (same bits; slower on a many-core host)
                 alt = end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, device_preint=True)

@@ -499,10 +499,16 @@ struct BatchSolver {
     std::vector<gf_ba_window*> resident;   // per slot: the member's window its last solve left on the device (the marginalisation reuses the device copy)
     size_t mem_count = 0;
     double t_solve = 0, t_marg = 0;        // wall time inside the batched calls [s] (GF_GROUP_TIMING=1 prints them when the group is destroyed)
+    // wall-clock anatomy of a group step (GF_GROUP_TIMING=1): the rendezvous of a step in order -- from the step's start to the first request of a rendezvous
+    // (the fastest member's host phase), from the first to the last request (the slowest member: what the batch waits for), inside the batch
+    std::chrono::steady_clock::time_point t_mark, t_first;
+    double w_to_first[4] = {0, 0, 0, 0}, w_spread[4] = {0, 0, 0, 0}, w_batch[4] = {0, 0, 0, 0}; long long w_n[4] = {0, 0, 0, 0};
+    int rdv = 0;                           // index of the rendezvous inside the current step
 
     int submit(Req& r) {
         {
             std::unique_lock<std::mutex> lk(m);
+            if (pending.empty()) t_first = std::chrono::steady_clock::now();
             pending.push_back(&r);
             maybe_run();
         }
@@ -522,6 +528,7 @@ struct BatchSolver {
         if (pending.empty() || (int)pending.size() < active) return;
         std::vector<Req*> reqs;
         reqs.swap(pending);
+        const auto t_close = std::chrono::steady_clock::now();
         // Partition by a snapshot of kind / mode BEFORE anything runs, and publish `done` only after the last pass: a submitter that sees done == true
         // returns and destroys its stack-allocated Req, so no request may be looked at again once any flag of this batch is up.
         std::vector<Req*> groups[4];   // pre-integrations, solves, MARGIN_OLD, MARGIN_SECOND_NEW
@@ -616,6 +623,13 @@ struct BatchSolver {
             const std::string err = rc == GF_OK ? std::string() : std::string(gf_last_error());
             for (Req* r : grp) { r->rc = rc; r->err = err; }
             batches++; windows += (long long)grp.size(); largest = std::max(largest, (long long)grp.size());
+        }
+        {
+            const auto t_end = std::chrono::steady_clock::now();
+            const int q = std::min(rdv, 3);
+            w_to_first[q] += std::chrono::duration<double>(t_first - t_mark).count(); w_spread[q] += std::chrono::duration<double>(t_close - t_first).count();
+            w_batch[q] += std::chrono::duration<double>(t_end - t_close).count(); w_n[q]++;
+            t_mark = t_end; rdv++;
         }
         for (Req* r : reqs) r->done.store(true, std::memory_order_release);   // last touch of every request
         finished.bump();
@@ -2135,6 +2149,7 @@ struct gf_estimator_group {
     std::mutex m;
     Gate go, all_done;    // a new step for the workers; the last worker of a step
     double t_input = 0;   // wall time inside gf_estimator_group_input_features [s]
+    double t_tail = 0; long long n_steps = 0;   // from the end of a step's last batch to the return of input_features
     std::atomic<int> remaining{0};
     std::atomic<bool> stop{false};
     std::unique_ptr<std::atomic<int>[]> job_gen;   // generation of `go` in which member i has a frame to process (0 = never)
@@ -2272,6 +2287,14 @@ int gf_estimator_group_destroy(gf_estimator_group* g) {
     if (g && getenv("GF_GROUP_TIMING"))
         fprintf(stderr, "gf_estimator_group: %lld batches, %lld windows; %.1f ms inside batched solves, %.1f ms inside batched marginalisations, %.1f ms inside input_features\n",
                 g->solver.batches, g->solver.windows, 1e3 * g->solver.t_solve, 1e3 * g->solver.t_marg, 1e3 * g->t_input);
+    if (g && getenv("GF_GROUP_TIMING") && g->n_steps) {
+        const BatchSolver& S = g->solver;
+        fprintf(stderr, "gf_estimator_group: wall-clock anatomy of %lld steps [ms per step]:", g->n_steps);
+        for (int q = 0; q < 4; q++)
+            if (S.w_n[q]) fprintf(stderr, " rendezvous %d (%lld): to first request %.3f, first..last request %.3f, batch %.3f;", q, S.w_n[q], 1e3 * S.w_to_first[q] / g->n_steps,
+                                  1e3 * S.w_spread[q] / g->n_steps, 1e3 * S.w_batch[q] / g->n_steps);
+        fprintf(stderr, " last batch .. return %.3f; whole step %.3f\n", 1e3 * g->t_tail / g->n_steps, 1e3 * g->t_input / g->n_steps);
+    }
     delete g;
     return GF_OK;
 }
@@ -2315,7 +2338,7 @@ int gf_estimator_group_input_features(gf_estimator_group* g, int count, const in
             g->job_gen[i].store(next, std::memory_order_release);
             off += (size_t)n_obs[k];
         }
-        { std::unique_lock<std::mutex> sl(g->solver.m); g->solver.active = count; }
+        { std::unique_lock<std::mutex> sl(g->solver.m); g->solver.active = count; g->solver.t_mark = tc0; g->solver.rdv = 0; }
         g->remaining.store(count, std::memory_order_release);
     }
     g->go.bump();
@@ -2325,6 +2348,7 @@ int gf_estimator_group_input_features(gf_estimator_group* g, int count, const in
         g->all_done.wait_while(seen);
     }
     g->t_input += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
+    g->t_tail += std::chrono::duration<double>(std::chrono::steady_clock::now() - g->solver.t_mark).count(); g->n_steps++;
     for (int k = 0; k < count; k++) if (g->rcs[seq[k]] != GF_OK) return gf::set_err(g->rcs[seq[k]], "sequence %d: %s", seq[k], g->errs[seq[k]].c_str());
     return GF_OK;
 }

@@ -492,7 +492,8 @@ int gf_comm_allgather_f64(gf_comm* c, const double* send_host, int n, double* re
  * stream.  Every rank passes the same count (the largest shard); rows behind a rank's own resident windows are zero.  Asynchronous: synchronise `stream`. */
 int gf_pose_gather(gf_ba* h, void* nccl_comm, void* stream, int count, double* d_out);
 /* NUMA placement: node of the GPU (/sys/bus/pci/devices/<bus id>/numa_node; -1 = none reported) and its cpulist; gf_pin_thread_to_device_node moves the calling
- * thread onto those cores (intersection with the process's affinity; GF_NUMA_PIN=0 switches it off) and returns the node or -1.  The tracker's bookkeeping pool
+ * thread onto those cores (intersection with the process's affinity) and returns the node or -1; it acts when several ranks share the host (LOCAL_WORLD_SIZE > 1)
+ * or GF_NUMA_PIN=1 says so, GF_NUMA_PIN=0 switches it off.  The tracker's bookkeeping pool
  * and the estimator group's workers pin themselves this way: 8 ranks x (pool + workers) on one host stay next to their own GPU. */
 int gf_numa_node_of_device(int device, int* node, char* cpulist, int cap);
 int gf_pin_thread_to_device_node(int device);
