@@ -130,7 +130,7 @@ struct MargOut { double* J; double* r; };  // [B][NPRI*NPRI], [B][NPRI]
 // equations and g[1-cur] of the right-hand side (ba_linearize_misc_win with the marginalisation's column map), Vc[1-cur] the visual part
 // in compact columns (use_vc: MARGIN_OLD), Et / ete / etb[1-cur] the compact rows of the eliminated feature columns.
 template <bool GS>   // GS: A and V of the kept system live in global memory (sb.Mg) -- priors larger than 96 columns
-__global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const MargInfo* info, MargOut out, int use_vc) {
+__global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const MargInfo* info, MargOut out, int use_vc, double piv_eps, int ls_rhs) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double sP[MPMAX * MPMAX], sPV[MPMAX * MPMAX], sPinv[MPMAX * MPMAX], sbp[MPMAX];
     __shared__ double s_c[64], s_s[64];
@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
         for (int q = 0; q < 4; q++) piv = fmax(piv, __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m), 16 * q), __builtin_amdgcn_readlane(__double2loint(m), 16 * q)));
         const unsigned long long hit = __ballot(best == piv);
         const int p = __builtin_amdgcn_readlane(bi, __ffsll((long long)hit) - 1);
-        if (!(piv > eps)) { rank = k; break; }
+        if (!(piv > piv_eps)) { rank = k; break; }
         if (p != k) {   // symmetric swap k <-> p of the full matrix in one pass: thread t moves the four entries that involve t; the 2 x 2 corner by thread 0
             // (every load of a thread before its first store: the compiler cannot tell the LDS arrays apart and would wait for each store before the next load)
             for (int t = tid; t < n; t += 512) {
@@ -410,6 +410,69 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
         }
     }
     GF_MST(5);
+    // ---- the right-hand side of the prior in the directions the factor does not span.  Forward substitution gives r = L1^-1 (P^T b)_1: J^T r then reproduces b in the
+    // `rank` pivot rows and PREDICTS it in the other m2 = n - rank rows (L2 L1^-1 b_1).  The reference's r = S^-1/2 V^T b (marginalization_factor.cpp:294-302) makes
+    // J^T r the ORTHOGONAL projection of b onto the kept eigenvectors instead.  Where the kept system has eigenvalues near the 1e-8 cut (GNSS windows: yaw_enu_local, the
+    // ECEF anchor) the two differ by up to 5e-3 of 2e3, and the next windows' GNSS states carry that.  The least-squares r -- min |J^T r - b| -- is the orthogonal
+    // projection onto the factor's own range: on the oracle's systems it sits 10-30 x closer to the reference's (scripts/marg_rhs_projection.py).  With K = L2 L1^-1
+    // (m2 x rank, m2 ~ 4-15) and e = b_2 - L2 r_fs (the forward substitution has left it in zb[rank..n)):
+    //     r = r_fs + L1^-1 T w,   T = L1^-T L2^T,   (I + T^T T) w = e
+    // one backward substitution with m2 right-hand sides, an m2 x m2 solve, one forward substitution.  m2 = 0 (full rank) or m2 > 32: nothing is done.
+    {
+        constexpr int kM2 = 32, TS = kM2 + 1;
+        const int m2 = n - rank;
+        if (ls_rhs && rank > 0 && m2 > 0 && m2 <= kM2) {
+            double* Tm = V + 2048;                 // rank x TS
+            double* G = Tm + (size_t)n * TS;       // m2 x (m2 + 1): [I + T^T T | e], then w in its last column
+            double* vv = G + kM2 * (kM2 + 1);      // rank: T w, forward-substituted in place
+            const int tj = tid & 31, tyy = tid >> 5;   // 32 columns of T x 16 row lanes
+            for (int i = tid; i < rank * kM2; i += 512) { const int k = i >> 5, j = i & 31; Tm[k * TS + j] = j < m2 ? A[(size_t)k * n + rank + j] : 0.0; }
+            __syncthreads();
+            double tprev = 0.0;
+            for (int k = rank - 1; k >= 0; k--) {   // column-oriented backward substitution with L1^T: row k is final when step k starts
+                if (tyy == 0 && k + 1 < rank) Tm[(k + 1) * TS + tj] = tprev;   // the scaled row of the previous step (nobody reads row k + 1 any more)
+                const double tk = Tm[k * TS + tj] * dinvs[k];
+                for (int i = tyy; i < k; i += 16) Tm[i * TS + tj] = __builtin_fma(-A[(size_t)i * n + k], tk, Tm[i * TS + tj]);   // L1[k][i] = A[i][k] (row i right of its diagonal)
+                tprev = tk;
+                __syncthreads();
+            }
+            if (tyy == 0) Tm[tj] = tprev;
+            __syncthreads();
+            for (int i = tid; i < m2 * (m2 + 1); i += 512) {
+                const int a = i / (m2 + 1), c = i - a * (m2 + 1);
+                double s;
+                if (c == m2) s = zb[rank + a];
+                else { s = a == c ? 1.0 : 0.0; for (int k = 0; k < rank; k++) s = __builtin_fma(Tm[k * TS + a], Tm[k * TS + c], s); }
+                G[a * (kM2 + 1) + c] = s;
+            }
+            __syncthreads();
+            if (wave == 0) {   // (I + T^T T) w = e: symmetric positive definite with eigenvalues >= 1, Gaussian elimination without pivoting, lane = row
+                const int r = lane;
+                for (int c = 0; c < m2; c++) {
+                    const double f = (r > c && r < m2) ? G[r * (kM2 + 1) + c] / G[c * (kM2 + 1) + c] : 0.0;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    if (r > c && r < m2) for (int q = c; q <= m2; q++) G[r * (kM2 + 1) + q] = __builtin_fma(-f, G[c * (kM2 + 1) + q], G[r * (kM2 + 1) + q]);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                }
+                for (int c = m2 - 1; c >= 0; c--) {
+                    if (r == c) G[c * (kM2 + 1) + m2] /= G[c * (kM2 + 1) + c];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    if (r < c) G[r * (kM2 + 1) + m2] = __builtin_fma(-G[r * (kM2 + 1) + c], G[c * (kM2 + 1) + m2], G[r * (kM2 + 1) + m2]);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                }
+            }
+            __syncthreads();
+            for (int k = tid; k < rank; k += 512) { double s = 0.0; for (int j = 0; j < m2; j++) s = __builtin_fma(Tm[k * TS + j], G[j * (kM2 + 1) + m2], s); vv[k] = s; }
+            __syncthreads();
+            for (int k = 0; k < rank; k++) {   // forward substitution with L1: column k of L1 below its diagonal = row k of A right of it
+                const double sk = vv[k] * dinvs[k];
+                __syncthreads();
+                if (tid == 0) { vv[k] = sk; zr[k] += sk; }
+                for (int i = k + 1 + tid; i < rank; i += 512) vv[i] = __builtin_fma(-A[(size_t)k * n + i], sk, vv[i]);
+                __syncthreads();
+            }
+        }
+    }
     double* J = out.J + (size_t)b * d.NPRI * d.NPRI;
     double* rr = out.r + (size_t)b * d.NPRI;
     for (int i = tid; i < n * n; i += 512) {

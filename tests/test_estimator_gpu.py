@@ -426,7 +426,11 @@ def test_replay_with_gnss_matches_oracle(window_size, own_initialiser, raw):
     # raw: the two pipelines propagate the ephemerides themselves (C++ / numpy), so their factor tables already differ in the last bits, and the own
     # initialiser's first anchor hangs on few epochs: the same script with --own --raw moves anchor / clocks by 6e-3 ... 1e-2 m at 1e-9 and by 2e-2 m at 1e-7
     # (observed here: 2e-2 ... 6e-2 m, next to local poses at 4e-7 m)
-    bar = 0.2 if raw else 5e-3
+    # Round 4: those floors were measured by swapping in factorisations whose right-hand side `r` treats the directions below the rank differently from the
+    # reference's eigen projection (marginalization_factor.cpp:294-302) -- which is what the library did as well.  With the least-squares r (csrc/gf_ba_marg.hpp:
+    # J^T r = orthogonal projection of b onto the factor's range, scripts/marg_rhs_projection.py) the same replays sit at 3e-8 ... 9e-6 m in every variant, raw
+    # ephemerides and own initialiser included (before: 1e-4 handed-in, 4e-4 own initialiser, 1e-2 raw): the bar is 1e-4 m.
+    bar = 1e-4
     assert worst["clk"] < bar and worst["anc"] < bar and worst["ecef"] < bar, worst
     assert worst["anc_low"] < bar and worst["ecef_low"] < bar and worst["rho"] < bar, worst      # rho runs over the `lowspeed` frames too
     est_p.close()
@@ -500,4 +504,4 @@ def test_config4_replay_images_w20_gnss():
     assert {s[:3] for s in r["seen"]} >= {(1, 0, 0), (1, 0, 1)}, r["seen"]      # aligned windows of both marginalisation kinds were solved
     assert r["ate_rmse"] < 0.05
     assert w["p"] < 1e-6 and w["r"] < 1e-6, w
-    assert w["clk"] < 5e-3 and w["anc"] < 5e-3 and w["ecef"] < 5e-3, w     # the floor of these states: test_replay_with_gnss_matches_oracle
+    assert w["clk"] < 1e-4 and w["anc"] < 1e-4 and w["ecef"] < 1e-4, w     # observed 1e-6 (bar and history: test_replay_with_gnss_matches_oracle)
