@@ -375,9 +375,10 @@ def test_gnss_marginalization_and_chain(gf, oracle, seed):
     bo, bg = po["J"].reshape(n, n).T @ po["r"], pg["J"].reshape(n, n).T @ pg["r"]
     # With GNSS the kept system has eigenvalues right at the truncation threshold (1e-8 .. 1e-6 against 1e8 at the top: yaw_enu_local, the ECEF anchor)
     # whose right-hand-side components are rounding noise of the 6.4e6-m ECEF arithmetic: J^T r is defined to ~1e-7 only -- the oracle moves by
-    # 2e-8 .. 9e-8 against itself when its input state is perturbed in the last bit (scripts/gnss_chain_sensitivity.py); observed here 2e-8 .. 4e-7
+    # 2e-8 .. 9e-8 against itself when its input state is perturbed in the last bit (scripts/gnss_chain_sensitivity.py); observed here 6e-9 .. 4e-8 with the
+    # least-squares right-hand side of round 4 (2e-8 .. 4e-7 with the forward-substituted one before it): bar 2e-7
     print("gnss prior seed %d: J^T r rel %.3e" % (seed, np.abs(bo - bg).max() / np.abs(bo).max()))
-    _assert_prior_close(Ao, bo, Ag, bg, b_tol=2e-6)
+    _assert_prior_close(Ao, bo, Ag, bg, b_tol=2e-7)
     w2 = SW.make_window(seed, oracle, gnss=True, frame0=1, prior=pg)
     a, b = w2.copy(), w2.copy()
     so, sg = oracle.ba_solve(a, 8), est.solve([b], 8)[0]
@@ -393,7 +394,7 @@ def test_gnss_marginalization_and_chain(gf, oracle, seed):
     dp, dr = _pose_diff(w2o, w2g)
     shape = np.abs((Pg[:, :3] - Pg[0, :3]) - (Po[:, :3] - Po[0, :3])).max()
     print("gnss chain seed %d: dp %.3e dr %.3e shape %.3e" % (seed, dp, dr, shape))
-    assert dr < 1e-6 and shape < 1e-6 and dp < 2e-4, (dp, dr, shape)
+    assert dr < 1e-6 and shape < 1e-6 and dp < 1e-4, (dp, dr, shape)      # observed 5e-7 and 3.5e-5
     p1o, p1g = oracle.ba_marginalize(a, 1), est.marginalize([a], 1)[0]
     assert p1g["n"] == p1o["n"] == 89 and list(p1g["block_id"]) == list(p1o["block_id"])
     n1 = p1o["n"]
