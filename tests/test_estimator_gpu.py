@@ -289,6 +289,44 @@ def test_group_of_sequences_on_one_batched_solver(device_preint, group_threads, 
         e.close()
 
 
+def test_group_at_the_largest_configuration_w20_500_features(monkeypatch):
+    """BASELINE.json configs[4]'s size as group members (round-3 advisor): 20-frame windows with up to 500 tracked features each run whole frames -- window build,
+    pack_slot of ~9 000 visual factors, initialStructure, the batched launches of whoever closes a rendezvous -- on the members' fiber stacks (GF_GROUP_STACK_KB,
+    8 MB by default, pages touched on use), two members sharing one worker thread.  Same bits as stand-alone estimators."""
+    monkeypatch.setenv("GF_GROUP_THREADS", "1")
+    n = 2
+    streams = []
+    for s in range(n):
+        st = SS.Stream(21 + s, t_still=1.5, t_move=2.2, v_max=0.4, yaw0=0.0, yaw_turn=-0.4 + 0.5 * s, split_x=1.8, turn_delay=0.6)
+        st._lm = st._landmarks(2600)
+        st._pn = np.random.default_rng(4500 + s).normal(0, 1.0, (len(st.cam_t), len(st._lm), 2))
+        streams.append(st)
+    kw = dict(tio=SS.TIO, rio=SS.RIO, multiple_thread=1, window_size=20, max_features=1100, max_visual=12000)
+    grp = gfamd.EstimatorGroup(gfamd.default_estimator_cfg(**kw), n)
+    solo = [gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(**kw)) for _ in range(n)]
+    tp, worst, most = [-1.0] * n, 0.0, 0
+    for k in range(min(len(st.cam_t) for st in streams)):
+        for s, st in enumerate(streams):
+            st.feed(grp.members[s], k, tp[s])
+            tp[s] = st.feed(solo[s], k, tp[s])
+        if k % 2:
+            continue
+        frames = [st.feature_frame(k) for st in streams]
+        grp.inputFeatures(list(range(n)), [float(st.cam_t[k]) for st in streams], frames)
+        for s in range(n):
+            solo[s].inputFeature(float(streams[s].cam_t[k]), frames[s])
+            a, b = grp.members[s].state(), solo[s].state()
+            assert a["frame_count"] == b["frame_count"] and a["solver_flag"] == b["solver_flag"] and a["iterations"] == b["iterations"], (k, s)
+            worst = max(worst, float(np.abs(a["Ps"] - b["Ps"]).max()), rot_angle(a["Rs"], b["Rs"]))
+            most = max(most, len(grp.members[s].features()["id"]))
+    print("W = 20 group: up to %d features per window, worst deviation from stand-alone %.2e, %s" % (most, worst, grp.stats()))
+    assert all(m.state()["solver_flag"] == 1 and m.state()["frame_count"] == 20 for m in grp.members) and most >= 400
+    assert worst == 0.0
+    grp.close()
+    for e in solo:
+        e.close()
+
+
 def test_group_members_initialise_through_sfm():
     """three recordings that begin in motion as members of one group: each member's SfM initialisation (host code on its own thread) and the batched solves
     behind it must land on the bits a stand-alone estimator produces"""
@@ -505,3 +543,36 @@ def test_config4_replay_images_w20_gnss():
     assert r["ate_rmse"] < 0.05
     assert w["p"] < 1e-6 and w["r"] < 1e-6, w
     assert w["clk"] < 1e-4 and w["anc"] < 1e-4 and w["ecef"] < 1e-4, w     # observed 1e-6 (bar and history: test_replay_with_gnss_matches_oracle)
+
+
+def test_moving_start_sweep_of_seeded_recordings():
+    """scripts/sfm_init_sweep.py as a test (round-3 review): 17 seeded recordings that begin in motion at a constant speed drawn per seed (0.3 ... 0.8 m/s, with
+    and without the wheel, turning either way) go through the SfM branch of initialStructure and 2.4 s of closed loop on both pipelines.  Decisions identical at
+    every frame, poses within 1e-6 on all 17 (observed 1e-9 ... 3e-7).  Round 3 had one recording at 5e-6 and blamed the conditioning of the first MARGIN_OLD
+    marginalisation behind such an initialisation (cond(A_mm) ~ 3e12); it was the prior's right-hand side below the rank of its factor, which the reference projects
+    and the library used to predict -- gone with the least-squares r of round 4 (csrc/gf_ba_marg.hpp)."""
+    worst_all = {}
+    for seed in range(1, 18):
+        rng = np.random.default_rng(seed)
+        use_wheel = int(seed % 2)
+        v = float(rng.uniform(0.3, 0.8))
+        st = SS.Stream(seed, t_still=0.0, t_move=2.4, v_max=v, v_start=v, yaw_turn=float(rng.uniform(-0.7, 0.7)))
+        st._lm = st._landmarks(900)
+        st._pn = np.random.default_rng(7000 + seed).normal(0, 1.0, (len(st.cam_t), len(st._lm), 2))
+        kw = dict(tio=SS.TIO, rio=SS.RIO, multiple_thread=1, use_wheel=use_wheel, wdetect=use_wheel)
+        eo, ep = EO.Estimator(dict(kw)), gfamd.SlidingWindowEstimator(gfamd.default_estimator_cfg(**kw))
+        tp, worst = -1.0, 0.0
+        for k in range(0, len(st.cam_t), 3):
+            for e in (eo, ep):
+                t1 = st.feed(e, k, tp)
+            tp = t1
+            fr = st.feature_frame(k)
+            eo.inputFeature(float(st.cam_t[k]), fr); ep.inputFeature(float(st.cam_t[k]), fr)
+            s = ep.state()
+            assert s["solver_flag"] == eo.solver_flag and s["frame_count"] == eo.frame_count and s["marginalization_flag"] == eo.marginalization_flag, (seed, k)
+            worst = max(worst, float(np.abs(s["Ps"] - np.array(eo.Ps)).max()), rot_angle(s["Rs"], eo.Rs))
+        assert eo.solver_flag == EO.NON_LINEAR and not eo.is_imu_excited, seed        # initialised through the SfM branch
+        ep.close()
+        worst_all[seed] = worst
+    print("moving-start sweep, worst |dP| / |dR| per seed:", {k: "%.1e" % v for k, v in worst_all.items()})
+    assert max(worst_all.values()) < 1e-6, worst_all
