@@ -467,8 +467,9 @@ def test_replay_with_gnss_matches_oracle(window_size, own_initialiser, raw):
     # Round 4: those floors were measured by swapping in factorisations whose right-hand side `r` treats the directions below the rank differently from the
     # reference's eigen projection (marginalization_factor.cpp:294-302) -- which is what the library did as well.  With the least-squares r (csrc/gf_ba_marg.hpp:
     # J^T r = orthogonal projection of b onto the factor's range, scripts/marg_rhs_projection.py) the same replays sit at 3e-8 ... 9e-6 m in every variant, raw
-    # ephemerides and own initialiser included (before: 1e-4 handed-in, 4e-4 own initialiser, 1e-2 raw): the bar is 1e-4 m.
-    bar = 1e-4
+    # ephemerides and own initialiser included (before: 1e-4 handed-in, 4e-4 own initialiser, 1e-2 raw): the bar is 2e-5 m, twice the largest observed value
+    # (the modelled range under `lowspeed` at W = 20).
+    bar = 2e-5
     assert worst["clk"] < bar and worst["anc"] < bar and worst["ecef"] < bar, worst
     assert worst["anc_low"] < bar and worst["ecef_low"] < bar and worst["rho"] < bar, worst      # rho runs over the `lowspeed` frames too
     est_p.close()
@@ -542,7 +543,7 @@ def test_config4_replay_images_w20_gnss():
     assert {s[:3] for s in r["seen"]} >= {(1, 0, 0), (1, 0, 1)}, r["seen"]      # aligned windows of both marginalisation kinds were solved
     assert r["ate_rmse"] < 0.05
     assert w["p"] < 1e-6 and w["r"] < 1e-6, w
-    assert w["clk"] < 1e-4 and w["anc"] < 1e-4 and w["ecef"] < 1e-4, w     # observed 1e-6 (bar and history: test_replay_with_gnss_matches_oracle)
+    assert w["clk"] < 1e-5 and w["anc"] < 1e-5 and w["ecef"] < 1e-5, w     # observed 1e-6 (bar and history: test_replay_with_gnss_matches_oracle)
 
 
 def test_moving_start_sweep_of_seeded_recordings():
