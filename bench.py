@@ -466,6 +466,16 @@ def main():
                "pyramid_ms": ti["ms_pyramid"] / 4, "detect_ms": ti["ms_detect"] / 4,
                "jtj_ms": bi["ms_jtj"] / max(bi["jtj_launches"], 1), "step_ms": bi["ms_step"] / max(bi["step_launches"], 1),
                "ba_solve_ms": bi["ms_solve"] / 3, "ba_marginalize_ms": bi["ms_marginalize"] / 3}
+        if not GNSS and WIN <= 10:   # north_star's split formulation next to the fused kernel (fixed extrinsic, LDS-resident tiles): same solves, the visual sweep as two kernels
+            est.set_split_jtj(True)
+            est.solve_resident(args.ba_iters, 0, True)     # warm (allocation of the block-row buffer)
+            est.reset_stats()
+            for _ in range(3):
+                est.solve_resident(args.ba_iters, 0, True)
+            bsplit = est.stats()
+            est.set_split_jtj(False)
+            iso["split"] = {"sweep_plus_contraction_ms": bsplit["ms_jtj"] / max(bsplit["jtj_launches"], 1),
+                            "contraction_ms": bsplit["ms_jtj_contract"] / max(bsplit["jtj_contract_launches"], 1), "ba_solve_ms": bsplit["ms_solve"] / 3}
 
     # the gather keeps the global sequence order: this rank's block of the gathered poses is what it exported
     own_block_ok = True
@@ -541,6 +551,17 @@ def main():
                              "mfma_utilisation_pmc": pmc.get("ba_linearize_visual_win", {}).get("mfma_utilisation") if args.config == 1 and B == 256 else None,   # the PMC passes ran configs[1] at 256 windows
                              "note": "algorithmic flops = Nv*2*2*91 per window (SURVEY.md 8d); issued = 2048 per v_mfma_f64_16x16x4_f64 (16-column tiles, 13 used); the kernel also "
                                      "evaluates every factor's residual / Jacobian (FP64 VALU), reduces the pair tiles and builds the E^T F rows; " + pmc.get("ba_linearize_visual_win", {}).get("note", "")},
+            "roofline_jtj_split": None if "split" not in iso else {
+                "kernel": "ba_linearize_visual_win<MODE 2> (contraction only) behind <MODE 1> (sweep -> block rows in HBM)", "bound": "mfma",
+                "achieved": tf(jtj_alg, iso["split"]["contraction_ms"]), "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf(jtj_alg, iso["split"]["contraction_ms"]) / FP64_MFMA_PEAK_TF,
+                "frac_issued": tf(jtj_issued, iso["split"]["contraction_ms"]) / FP64_MFMA_PEAK_TF, "launch_ms": iso["split"]["contraction_ms"],
+                "sweep_plus_contraction_ms": iso["split"]["sweep_plus_contraction_ms"], "fused_ms": iso.get("jtj_ms"),
+                "ba_solve_ms": {"split": iso["split"]["ba_solve_ms"], "fused": iso.get("ba_solve_ms")},
+                "block_row_bytes_per_launch": 2 * 256.0 * jtj_alg / (4 * 91) if jtj_alg else None,
+                "mfma_utilisation_pmc": pmc.get("ba_linearize_visual_win_contract", {}).get("mfma_utilisation") if args.config == 1 and B == 256 else None,
+                "note": "north_star's formulation measured: the sweep writes 256 B of block rows per factor to HBM and a second kernel only contracts them (then reduces the tiles and builds "
+                        "Vc / E^T F as the fused kernel does); same bits as the fused kernel (tests/test_backend_gpu.py::test_split_jtj_formulation_gives_the_same_bits); off by default "
+                        "because the iteration gets slower, not faster"},
             "roofline_step": {"kernel": "ba_step", "bound": "mfma", "achieved": tf(step_flops, step_t), "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf(step_flops, step_t) / FP64_MFMA_PEAK_TF,
                               "launch_ms": step_t, "launch_ms_in_timed_region": step_ms, "flops_per_launch": step_flops,
                               "mfma_utilisation_pmc": pmc.get("ba_step", {}).get("mfma_utilisation") if args.config == 1 and B == 256 else None,

@@ -121,6 +121,8 @@ struct gf_ba {
     int max_imu_dirty = 0;
     bool all_pri_res = false, any_pri_res = false, outJ_host_stale = false;
     int step_waves = 8;
+    bool split_jtj = false, split_timed = false;   // gf_ba_set_split_jtj: the visual sweep as two kernels (block rows through HBM, contraction-only MFMA kernel)
+    Buf<double> vrows; hipEvent_t ev_split[2] = {nullptr, nullptr};
     double max_solver_time = 0.0;   // ceres::Solver::Options::max_solver_time_in_seconds; 0 = not honoured (the fixed schedule runs without host round trips)
     long long mfma_per_lin = 0;   // v_mfma_f64_16x16x4 instructions of one visual linearisation of the resident batch
     long long jtj_alg_flops = 0;  // algorithmic flops of the same: Nv * 2 * 2 * (12 * 13 / 2 + 12 + 1) per window
@@ -137,6 +139,8 @@ struct gf_ba {
         st.release(); st0.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         if (ev_gather) (void)hipEventDestroy(ev_gather);
+        for (auto& e : ev_split) if (e) (void)hipEventDestroy(e);
+        vrows.release();
         gather_send.release();
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -546,11 +550,19 @@ int reset_state(gf_ba* h) {
 // One linearisation of the resident batch at the state buffer `which_state` into the buffers `which` (-1: the candidate's).
 // Visual sweep (Vc, E^T F rows), then prior / IMU / wheel (H, g) and the GNSS blocks, on the handle's stream.  Every buffer
 // has one writing kernel and every sum a fixed order: no zeroing or reset passes, no atomics.
-int launch_visual(gf_ba* h, Win w, bool ex, int which, int which_state, int only_valid) {
+int launch_visual(gf_ba* h, Win w, bool ex, int which, int which_state, int only_valid, bool timed_split = false) {
     const Dims& d = h->d;
     const size_t lds = ex ? h->vwinx_lds : h->vwin_lds;
     w.vtile = lds ? nullptr : h->vtile.d;
     if (ex) ba_linearize_visual_win<true, kVWX><<<dim3(d.B), 64 * kVWX, lds, h->stream>>>(w, h->sbufs(), which, which_state, only_valid);
+    else if (h->split_jtj && only_valid != 2) {   // north_star's formulation, measured next to the fused kernel: the sweep writes block rows to HBM, a second kernel only contracts them
+        w.vrows = h->vrows.d;
+        ba_linearize_visual_win<false, kVW, 1><<<dim3(d.B), 64 * kVW, lds, h->stream>>>(w, h->sbufs(), which, which_state, only_valid);
+        HIPCHK(hipGetLastError());
+        if (timed_split) HIPCHK(hipEventRecord(h->ev_split[0], h->stream));
+        ba_linearize_visual_win<false, kVW, 2><<<dim3(d.B), 64 * kVW, lds, h->stream>>>(w, h->sbufs(), which, which_state, only_valid);
+        if (timed_split) { HIPCHK(hipEventRecord(h->ev_split[1], h->stream)); h->split_timed = true; }
+    }
     else ba_linearize_visual_win<false, kVW><<<dim3(d.B), 64 * kVW, lds, h->stream>>>(w, h->sbufs(), which, which_state, only_valid);
     HIPCHK(hipGetLastError());
     return GF_OK;
@@ -560,7 +572,7 @@ int launch_linearize(gf_ba* h, int which, int which_state, int only_valid, bool 
     const Dims& d = h->d;
     Win w = h->win();
     if (timed) HIPCHK(hipEventRecord(h->ev[2], h->stream));
-    if (int rc = launch_visual(h, w, h->any_ex, which, which_state, only_valid)) return rc;
+    if (int rc = launch_visual(h, w, h->any_ex, which, which_state, only_valid, timed)) return rc;
     if (timed) HIPCHK(hipEventRecord(h->ev[3], h->stream));
     if (misc_with_step) return GF_OK;   // the candidate's prior / IMU / wheel sweep rides in front of the next step (ba_misc_step)
     // same stream as the visual sweep: the two sweeps fill the CUs' LDS and registers and so exclude each other anyway, and a second stream only added the
@@ -712,6 +724,7 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     if (!h->big_step) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_step<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->step_lds));
     // GF_BA_STEP_WAVES=4: ba_step on four wavefronts (half of a CU's registers) so that other kernels' blocks -- the tracker's -- can sit next to it; one setting per
     // process (the reductions' order depends on it: a window alone and the same window in a batch must run the same variant)
+    if (getenv("GF_BA_SPLIT_JTJ") && atoi(getenv("GF_BA_SPLIT_JTJ"))) if (int rc = gf_ba_set_split_jtj(h, 1)) return rc;
     h->step_waves = (getenv("GF_BA_STEP_WAVES") && atoi(getenv("GF_BA_STEP_WAVES")) == 4) ? 4 : 8;
     if (h->step_waves == 4 && !h->big_step) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_step<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->step_lds));
     // GF_BA_FUSE_MISC=1: the candidate's prior / IMU / wheel sweep in front of the step that judges it, one launch (ba_misc_step).  Same bits; measured 163 us against
@@ -722,6 +735,8 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
         const size_t dyn = vwin_slot_doubles(d.NP, false) * sizeof(double), stat = (size_t)kVW * vwin_sg(false) * vwin_lstr(false) * sizeof(double) + kVW * 64 * sizeof(int) + 512 + 2048;
         h->vwin_lds = (dyn + stat <= 160 * 1024 && !glob) ? dyn : 0;
         if (h->vwin_lds) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_visual_win<false, kVW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->vwin_lds));
+        if (h->vwin_lds) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_visual_win<false, kVW, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->vwin_lds));
+        if (h->vwin_lds) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_visual_win<false, kVW, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->vwin_lds));
         const size_t dynx = vwin_slot_doubles(d.NP, true) * sizeof(double), statx = (size_t)kVWX * vwin_sg(true) * vwin_lstr(true) * sizeof(double) + kVWX * 64 * sizeof(int) + 512 + 2048;
         h->vwinx_lds = (dynx + statx <= 160 * 1024 && !glob) ? dynx : 0;
         if (h->vwinx_lds) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_visual_win<true, kVWX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->vwinx_lds));
@@ -785,6 +800,7 @@ int gf_ba_wait(gf_ba* h) {
     HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); h->stats.ms_solve += ms;
     HIPCHK(hipEventElapsedTime(&ms, h->ev[1], h->ev[4])); h->stats.ms_marginalize += ms;
     if (h->pending_iters > 0) { HIPCHK(hipEventElapsedTime(&ms, h->ev[2], h->ev[3])); h->stats.ms_jtj += ms; }
+    if (h->pending_iters > 0 && h->split_timed) { HIPCHK(hipEventElapsedTime(&ms, h->ev_split[0], h->ev_split[1])); h->stats.ms_jtj_contract += ms; h->stats.jtj_contract_launches++; h->split_timed = false; }
     if (h->pending_iters > 0) { HIPCHK(hipEventElapsedTime(&ms, h->ev[6], h->ev[7])); h->stats.ms_step += ms; }
     return GF_OK;
 }
@@ -1069,6 +1085,16 @@ int gf_pose_gather(gf_ba* h, void* nccl_comm, void* stream, int count, double* d
         HIPCHK(hipStreamWaitEvent(static_cast<hipStream_t>(stream), h->ev_gather, 0));
     }
     return gf::rccl_allgather_f64(h->gather_send.d, d_out, (size_t)count * 7, nccl_comm, stream);
+}
+
+int gf_ba_set_split_jtj(gf_ba* h, int on) {
+    if (!h) return gf::set_err(GF_ERR_INVALID, "null handle");
+    if (on && !h->vrows.d) {
+        if (int rc = h->vrows.alloc((size_t)h->d.B * ((h->d.NVP + 63) & ~63) * 32 + 64 * 32, false)) return rc;
+        for (auto& e : h->ev_split) HIPCHK(hipEventCreate(&e));
+    }
+    h->split_jtj = on != 0;
+    return GF_OK;
 }
 
 int gf_ba_debug_stamps(gf_ba* h, long long* out, int n) {  // phase timestamps of the last ba_step launch (profiling builds)

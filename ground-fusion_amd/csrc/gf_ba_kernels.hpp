@@ -93,6 +93,7 @@ struct Win {  // device view of the whole batch
     SolverState* st;          // [B]
     const double* wpar;       // [B][WPAR] per window: gravity G (3), visual sqrt_info, PoseSubsetParameterization masks of the camera / wheel extrinsic (as doubles)
     long long* stamps;        // optional phase timestamps of window 0 (profiling builds, -DGF_PROFILE_STEP)
+    double* vrows;            // [B][NVP][2][16] block rows of the visual factors in HBM (split formulation only: ba_linearize_visual_win MODE 1 / 2); else null
     double* vtile;            // global home of the visual sweep's pair tiles when they do not fit LDS ([B][vtile_stride]); else null
     size_t vtile_stride;
     // GNSS (Dims::GO > 0)
@@ -745,8 +746,13 @@ __host__ __device__ constexpr int vwin_lstr(bool ex) { return ex ? 65 : 33; }   
 __host__ __device__ constexpr int vwin_tn(bool ex) { return ex ? 210 : 105; }     // packed tile: 20 x 21 / 2, 14 x 15 / 2
 __host__ __device__ inline size_t vwin_slot_doubles(int NP, bool ex) { return ((size_t)NP * (NP - 1) / 2 + (ex ? kVWX : kVW)) * vwin_tn(ex); }
 // EX: the camera extrinsic block has columns (free in the solve, or a kept block of the marginalisation): second 16-column tile
-template <bool EX, int NW>
+// MODE (north_star's formulation as a measured alternative, GF_BA_SPLIT_JTJ / gf_ba_set_split_jtj): 0 = the fused kernel; 1 = the sweep alone -- every factor's block
+// rows [J | r] (2 x 16 doubles, 256 B per factor, in the pair-sorted order so that the four rows of one MFMA are 512 consecutive bytes) go to w.vrows in HBM, with the
+// per-factor products and the cost, and the kernel ends; 2 = the contraction alone -- reads the block rows back (one coalesced 8-byte load per lane and MFMA), J^T J /
+// J^T r per frame pair on the matrix cores, then the tile reduction, Vc and the E^T F rows as in the fused kernel.  Same products in the same order: same bits.
+template <bool EX, int NW, int MODE = 0>
 __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBufs sb, int which, int which_state, int only_cand_valid) {
+    static_assert(MODE == 0 || !EX, "the split formulation is built for the fixed-extrinsic tiles");
     constexpr int COLS = EX ? 32 : 16, LSTR = vwin_lstr(EX), SG = vwin_sg(EX), TN = vwin_tn(EX), NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) double v_dyn[];   // pair-tile slots (when they fit)
     __shared__ double Jst[NW * SG * LSTR];
@@ -818,9 +824,38 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
         const int k = oe < 0 ? -1 : (oe & 0xffff);
         int fi, fj;
         VisEval ev;
-        cost += vis_lane_eval<EX>(w, d, b, which, k, xs, colf, ev, fi, fj);
+        if (MODE != 2) cost += vis_lane_eval<EX>(w, d, b, which, k, xs, colf, ev, fi, fj);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();   // the previous chunk's reads of s_pair are done
         s_pair[lane] = oe < 0 ? -1 : (oe >> 16);
+        if (MODE == 1) {   // block rows of this lane's factor to HBM: rows[entry][r][16], columns 14 / 15 and padding lanes zero
+            if (entry < ((n_order + 63) & ~63)) {
+                double2* dst = reinterpret_cast<double2*>(w.vrows + ((size_t)b * ((d.NVP + 63) & ~63) + entry) * 32);   // windows 64 entries apart: a last, partly filled chunk stays inside its window's rows
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int c = 0; c < 16; c += 2) {
+                        double2 v;
+                        v.x = (c < 14 && k >= 0) ? ev.row[r][c] : 0.0; v.y = (c + 1 < 14 && k >= 0) ? ev.row[r][c + 1] : 0.0;
+                        dst[(r * 16 + c) >> 1] = v;
+                    }
+            }
+            continue;
+        }
+        if (MODE == 2) {   // the contraction alone: 32 MFMAs per chunk, operands straight from HBM (all loads of the chunk in flight before the first product)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+            const double* src = w.vrows + ((size_t)b * ((d.NVP + 63) & ~63) + (size_t)ch * 64) * 32 + lane;
+            double av[32];
+#pragma unroll
+            for (int m = 0; m < 32; m++) av[m] = src[64 * m];
+#pragma unroll
+            for (int m = 0; m < 32; m++) {
+                const int pair = uni(s_pair[2 * m]);
+                if (pair < 0) continue;
+                if (pair != cur_pair) { flush(cur_pair); cur_pair = pair; }
+                acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], av[m], acc00, 0, 0, 0);
+            }
+            continue;
+        }
         // the 64 block rows go through the staging area SG factors at a time
 #pragma unroll
         for (int part = 0; part < 64 / SG; part++) {
@@ -859,7 +894,8 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
     if (lane == 0) s_cost[wave] = cost;
     __syncthreads();
     GF_WSTAMP(83);
-    if (tid == 0) { double c = 0; for (int q = 0; q < NW; q++) c += s_cost[q]; *cost_part(w, 1, which, b) = c; }
+    if (MODE != 2 && tid == 0) { double c = 0; for (int q = 0; q < NW; q++) c += s_cost[q]; *cost_part(w, 1, which, b) = c; }
+    if (MODE == 1) return;
     // ---- continuation slots -> pair slots, in wavefront order
     for (int t = tid; t < TN; t += NT)
         for (int ww = 1; ww < NW; ww++) { const int p = s_cont[ww]; if (p >= 0) slots[(size_t)p * TN + t] += bnd[(size_t)ww * TN + t]; }

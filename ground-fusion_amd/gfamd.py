@@ -244,7 +244,8 @@ class BaPriorC(C.Structure):
 class BaStats(C.Structure):
     _fields_ = [("ms_upload", C.c_double), ("ms_solve", C.c_double), ("ms_marginalize", C.c_double), ("ms_download", C.c_double), ("ms_jtj", C.c_double),
                 ("solves", C.c_longlong), ("jtj_launches", C.c_longlong), ("jtj_flops", C.c_longlong),
-                ("ms_step", C.c_double), ("step_launches", C.c_longlong), ("step_flops", C.c_longlong), ("jtj_alg_flops", C.c_longlong)]
+                ("ms_step", C.c_double), ("step_launches", C.c_longlong), ("step_flops", C.c_longlong), ("jtj_alg_flops", C.c_longlong),
+                ("ms_jtj_contract", C.c_double), ("jtj_contract_launches", C.c_longlong)]
 
 
 EXPORTS += ["gf_ba_create", "gf_ba_destroy", "gf_ba_solve", "gf_ba_marginalize", "gf_ba_upload", "gf_ba_solve_resident", "gf_ba_download", "gf_ba_get_stats",
@@ -355,6 +356,10 @@ class Estimator:
 
     def reset_stats(self):
         _chk(lib().gf_ba_reset_stats(self.h))
+
+    def set_split_jtj(self, on):
+        """the visual sweep as two kernels: block rows through HBM + a contraction-only MFMA kernel (north_star's formulation; same bits as the fused kernel)"""
+        _chk(lib().gf_ba_set_split_jtj(self.h, int(bool(on))))
 
 
 def imu_preintegrate(dt, acc, gyr, acc0, gyr0, ba, bg, noise):

@@ -222,9 +222,15 @@ typedef struct gf_ba_stats {
     double ms_step;                                            /* time inside ba_step (one full dogleg step per solve is timed) */
     long long step_launches, step_flops;                       /* step_flops: Schur SYRK + Cholesky + substitutions of the timed launches */
     long long jtj_alg_flops;                                   /* algorithmic flops of the timed visual J^T J launches: Nv * 2 * 2 * 91 per window */
+    double ms_jtj_contract;                                    /* split formulation (gf_ba_set_split_jtj): time inside the contraction-only MFMA kernel */
+    long long jtj_contract_launches;
 } gf_ba_stats;
 
 int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out);
+/* north_star's formulation of the visual sweep as a measured alternative (fixed camera extrinsic only): "residual/Jacobian sweep ... writing block-rows that an MFMA
+ * J^T J contraction ... reduce[s]" -- the sweep stores every factor's 2 x 16 block row in HBM, a second kernel does nothing but contract them on the matrix cores.
+ * Same bits as the fused kernel (same products, same order).  Off by default: it costs a 256-byte round trip per factor. */
+int gf_ba_set_split_jtj(gf_ba* h, int on);
 int gf_ba_destroy(gf_ba* h);
 /* ceres::Solve on `count` <= batch windows (estimator.cpp:3303-3318 with max_solver_time disabled); states updated in place */
 int gf_ba_solve(gf_ba* h, gf_ba_window* windows, int count, int max_iters, gf_ba_summary* summaries);

@@ -1,6 +1,6 @@
 """torch-free driver for PMC collection (rocprofv3 --pmc segfaults with the torch-bundled HIP runtime in the process).
   python scripts/pmc_driver.py tracker [B]   B sequences x 4 frames through the host-image entry point (default 256: the bench's batch)
-  python scripts/pmc_driver.py backend [B]   B resident windows: 2 x (8-iteration solve + MARGIN_OLD)
+  python scripts/pmc_driver.py backend [B]   B resident windows: 2 x (8-iteration solve + MARGIN_OLD); backend_split: the same with the visual sweep as two kernels
   python scripts/pmc_driver.py calib         the three FETCH_SIZE calibration kernels (known byte counts)"""
 import os, sys, ctypes as C
 os.environ["GF_NO_TORCH_PRELOAD"] = "1"
@@ -20,9 +20,11 @@ if what == "tracker":
     st = trk.stats()
     print("PMCINFO tracker B %d lk_launches %d lk_points %d alg_bytes_per_launch %.1f" % (B, st["lk_launches"], st["lk_points"], (484.0 * 5 * st["lk_level_passes"] + 484.0 * st["lk_iterations"]) / max(st["lk_launches"], 1)))
     trk.close()
-elif what == "backend":
+elif what in ("backend", "backend_split"):
     import synth_window as SW
     est = gfamd.Estimator(batch=B)
+    if what == "backend_split":     # north_star's formulation: sweep -> block rows in HBM -> contraction-only kernel (gf_ba_set_split_jtj)
+        est.set_split_jtj(True)
     base = [SW.make_window(1000 + b, gfamd) for b in range(8)]
     est.upload([base[b % 8] for b in range(B)])
     for it in range(2):

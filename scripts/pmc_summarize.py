@@ -52,8 +52,14 @@ def sq(tab, k):
     return d
 def util(d):   # MFMA busy cycles over SIMD-cycles of the launch (1024 SIMDs at 2.4 GHz)
     return d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (d["duration_us_profiled"] * 1e-6 * 2.4e9 * 1024)
-for k, name in (("gfb::ba_linearize_visual_win<false; 12>", "ba_linearize_visual_win"), ("gfb::ba_step<false>", "ba_step"), ("gfb::ba_linearize_misc_win", "ba_linearize_misc_win"),
-                ("gfb::ba_marg_finish<false>", "ba_marg_finish")):
+def find(tab, *prefixes):   # kernel names carry their template arguments ("gfb::ba_step<false; 8>"): match by prefix, first hit
+    for p in prefixes:
+        for k in tab:
+            if k.startswith(p):
+                return k
+    return None
+for k, name in ((find(bsq, "gfb::ba_linearize_visual_win<false; 12; 0>", "gfb::ba_linearize_visual_win<false; 12>"), "ba_linearize_visual_win"), (find(bsq, "gfb::ba_step<false"), "ba_step"),
+                (find(bsq, "gfb::ba_linearize_misc_win"), "ba_linearize_misc_win"), (find(bsq, "gfb::ba_marg_finish<false>"), "ba_marg_finish")):
     if k in bsq:
         d = sq(bsq, k)
         d.update({c: v[0] for c, v in bsq2.get(k, {}).items()})
@@ -65,6 +71,28 @@ for k, name in (("gfb::ba_linearize_visual_win<false; 12>", "ba_linearize_visual
                       "hbm_GBps_lower": (f + wv) / (d["duration_us_profiled"] * 1e-6) / 1e9, "hbm_GBps_upper": (2 * f + wv) / (d["duration_us_profiled"] * 1e-6) / 1e9})
         d["note"] = "counter-derived MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (profiled kernel duration x 2.4 GHz x 1024 SIMDs), profiles/%s_pmc_backend_sq.csv" % tag
         S[name] = d
+try:   # the split formulation's two kernels (scripts/pmc_collect.sh: backend_split passes)
+    ssq = load("backend_split_sq")
+    try:
+        sf, sw = load("backend_split_fetch"), load("backend_split_write")
+    except OSError:
+        sf, sw = {}, {}
+    for k, name in ((find(ssq, "gfb::ba_linearize_visual_win<false; 12; 2>"), "ba_linearize_visual_win_contract"), (find(ssq, "gfb::ba_linearize_visual_win<false; 12; 1>"), "ba_linearize_visual_win_sweep")):
+        if k:
+            d = sq(ssq, k)
+            d["mfma_utilisation"] = util(d)
+            d["wave_cycle_split"] = {"parked": d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"], "issue_stalled": d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"], "issuing": d["SQ_ACTIVE_INST_ANY"] / d["SQ_WAVE_CYCLES"]}
+            if k in sf and k in sw:
+                f, wv = sf[k]["FETCH_SIZE"][0] * kb, sw[k]["WRITE_SIZE"][0] * kb
+                d.update({"FETCH_SIZE_bytes": f, "WRITE_SIZE_bytes": wv, "hbm_GBps_lower": (f + wv) / (d["duration_us_profiled"] * 1e-6) / 1e9, "hbm_GBps_upper": (2 * f + wv) / (d["duration_us_profiled"] * 1e-6) / 1e9})
+            d["note"] = "split formulation (gf_ba_set_split_jtj), profiles/%s_pmc_backend_split_sq.csv" % tag
+            S[name] = d
+            print(name, "mfma util %.3f" % d["mfma_utilisation"], d["wave_cycle_split"], "dur us", d["duration_us_profiled"])
+    for n in ("backend_split_sq",) + (("backend_split_fetch", "backend_split_write") if sf else ()):
+        for ext in ("csv", "info"):
+            shutil.copy(os.path.join(G, "%s_pmc_%s.%s" % (tag, n, ext)), os.path.join(R, "profiles", "%s_pmc_%s.%s" % (tag, n, ext)))
+except OSError:
+    pass
 for k, name in (("gf::lk_track_kernel", "lk_track_kernel_sq"), ("gf::detect_strip_kernel<30>", "detect_strip_kernel_sq")):
     if k in tsq:
         S[name] = sq(tsq, k)

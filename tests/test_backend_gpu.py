@@ -439,3 +439,22 @@ def test_max_solver_time_is_optional_and_stops_the_schedule(gf):
     assert est.solve([again], 8)[0] == s_free
     with pytest.raises(gf.GfError):
         gf._chk(gf.lib().gf_ba_set_max_solver_time(est.h, C.c_double(-1.0)))
+
+
+def test_split_jtj_formulation_gives_the_same_bits(gf, oracle):
+    """north_star's formulation of the visual sweep -- block rows [J | r] of every factor through HBM, a contraction-only MFMA kernel behind it
+    (gf_ba_set_split_jtj) -- against the fused kernel: same products in the same order, so states, summaries and the next prior are identical to the bit"""
+    wins = [SW.make_window(300 + b, oracle) for b in range(3)]
+    a, c = [w.copy() for w in wins], [w.copy() for w in wins]
+    ea, ec = gf.Estimator(batch=4), gf.Estimator(batch=4)
+    ec.set_split_jtj(True)
+    sa, sc = ea.solve(a, 8), ec.solve(c, 8)
+    pa, pc = ea.marginalize(a, 0), ec.marginalize(c, 0)
+    for wa, wc, x, y, p, q in zip(a, c, sa, sc, pa, pc):
+        assert x == y
+        for k in gw.STATE_KEYS:
+            assert np.array_equal(wa[k], wc[k]), k
+        assert np.array_equal(p["J"], q["J"]) and np.array_equal(p["r"], q["r"])
+    st = ec.stats()
+    assert st["jtj_contract_launches"] > 0 and st["ms_jtj_contract"] > 0
+    ea.close(); ec.close()
