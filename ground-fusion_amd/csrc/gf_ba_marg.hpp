@@ -425,19 +425,25 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
             double* Tm = V + 2048;                 // rank x TS
             double* G = Tm + (size_t)n * TS;       // m2 x (m2 + 1): [I + T^T T | e], then w in its last column
             double* vv = G + kM2 * (kM2 + 1);      // rank: T w, forward-substituted in place
-            const int tj = tid & 31, tyy = tid >> 5;   // 32 columns of T x 16 row lanes
             for (int i = tid; i < rank * kM2; i += 512) { const int k = i >> 5, j = i & 31; Tm[k * TS + j] = j < m2 ? A[(size_t)k * n + rank + j] : 0.0; }
             __syncthreads();
-            double tprev = 0.0;
-            for (int k = rank - 1; k >= 0; k--) {   // column-oriented backward substitution with L1^T: row k is final when step k starts
-                if (tyy == 0 && k + 1 < rank) Tm[(k + 1) * TS + tj] = tprev;   // the scaled row of the previous step (nobody reads row k + 1 any more)
-                const double tk = Tm[k * TS + tj] * dinvs[k];
-                for (int i = tyy; i < k; i += 16) Tm[i * TS + tj] = __builtin_fma(-A[(size_t)i * n + k], tk, Tm[i * TS + tj]);   // L1[k][i] = A[i][k] (row i right of its diagonal)
-                tprev = tk;
-                __syncthreads();
+            // The two substitutions are chains of `rank` dependent steps: one wavefront walks them with wavefront barriers (a block barrier per step made them 40 of the
+            // kernel's 245 us).  Lane = (column j of T, row slice): every entry of T has one owner, a step reads row k before its owner lane rescales it.
+            GF_MST(8);
+            if (wave == 0) {
+                int m2p = 1;
+                while (m2p < m2) m2p <<= 1;
+                const int rs = 64 / m2p, j = lane & (m2p - 1), sl = lane / m2p;
+                for (int k = rank - 1; k >= 0; k--) {   // column-oriented backward substitution with L1^T: row k is final when step k starts
+                    const double tk = j < m2 ? Tm[k * TS + j] * dinvs[k] : 0.0;
+                    if (j < m2) for (int i = sl; i < k; i += rs) Tm[i * TS + j] = __builtin_fma(-A[(size_t)i * n + k], tk, Tm[i * TS + j]);   // L1[k][i] = A[i][k] (row i right of its diagonal)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    if (sl == 0 && j < m2) Tm[k * TS + j] = tk;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
             }
-            if (tyy == 0) Tm[tj] = tprev;
             __syncthreads();
+            GF_MST(9);
             for (int i = tid; i < m2 * (m2 + 1); i += 512) {
                 const int a = i / (m2 + 1), c = i - a * (m2 + 1);
                 double s;
@@ -446,6 +452,7 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
                 G[a * (kM2 + 1) + c] = s;
             }
             __syncthreads();
+            GF_MST(10);
             if (wave == 0) {   // (I + T^T T) w = e: symmetric positive definite with eigenvalues >= 1, Gaussian elimination without pivoting, lane = row
                 const int r = lane;
                 for (int c = 0; c < m2; c++) {
@@ -462,17 +469,23 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
                 }
             }
             __syncthreads();
+            GF_MST(11);
             for (int k = tid; k < rank; k += 512) { double s = 0.0; for (int j = 0; j < m2; j++) s = __builtin_fma(Tm[k * TS + j], G[j * (kM2 + 1) + m2], s); vv[k] = s; }
             __syncthreads();
-            for (int k = 0; k < rank; k++) {   // forward substitution with L1: column k of L1 below its diagonal = row k of A right of it
-                const double sk = vv[k] * dinvs[k];
-                __syncthreads();
-                if (tid == 0) { vv[k] = sk; zr[k] += sk; }
-                for (int i = k + 1 + tid; i < rank; i += 512) vv[i] = __builtin_fma(-A[(size_t)k * n + i], sk, vv[i]);
-                __syncthreads();
-            }
+            if (wave == 0)
+                for (int k = 0; k < rank; k++) {   // forward substitution with L1: column k of L1 below its diagonal = row k of A right of it
+                    const double sk = vv[k] * dinvs[k];
+                    for (int i = k + 1 + lane; i < rank; i += 64) vv[i] = __builtin_fma(-A[(size_t)k * n + i], sk, vv[i]);
+                    if (lane == 0) zr[k] += sk;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                }
+            __syncthreads();
         }
     }
+    GF_MST(6);
+#ifdef GF_PROFILE_STEP
+    if (blockIdx.x == 0 && threadIdx.x == 0 && sb.stamps) sb.stamps[39] = rank * 1000 + n;
+#endif
     double* J = out.J + (size_t)b * d.NPRI * d.NPRI;
     double* rr = out.r + (size_t)b * d.NPRI;
     for (int i = tid; i < n * n; i += 512) {

@@ -13,7 +13,7 @@ for what in "$@"; do
     bench4) timeout 1200 python bench.py --config 4 > gpurun_out/${tag}_bench_c4.json 2> gpurun_out/${tag}_bench_c4.err; echo "bench4 rc $?"; head -c 600 gpurun_out/${tag}_bench_c4.json; echo; tail -3 gpurun_out/${tag}_bench_c4.err ;;
     prof1|prof2|prof4)
       c=${what#prof}
-      ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_${tag}_c$c && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${tag}_c$c -- python $R/bench.py --config $c --no-cpu-baseline --no-e2e > $R/gpurun_out/${tag}_bench_c${c}_traced.json 2> $R/gpurun_out/${tag}_prof_c$c.err )
+      ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_${tag}_c$c && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${tag}_c$c -- python $R/bench.py --config $c --no-cpu-baseline --no-e2e --no-pcie --steps 40 > $R/gpurun_out/${tag}_bench_c${c}_traced.json 2> $R/gpurun_out/${tag}_prof_c$c.err )
       f=$(find /tmp/prof_${tag}_c$c -name "*kernel_stats.csv" | head -1)
       python - "$f" > gpurun_out/${tag}_c${c}_kernel_stats.csv <<'P'
 import sys, csv
