@@ -37,6 +37,20 @@ template <class T> struct Buf {  // device buffer + pinned host mirror
     int alloc(size_t count, bool host) {
         n = count;
         if (hipMalloc((void**)&d, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipMalloc(%zu B) failed", count * sizeof(T));
+        // GF_BA_POISON=1 (debugging aid): fresh device buffers start as 0x5A bytes (2.5e130 as a double -- finite, so that garbage x 0 stays 0 --, 1 515 870 810 as an int) instead of whatever the allocator hands back, so that a kernel reading
+        // what nobody wrote shows as NaN in the results instead of as a dependence on the process's history
+        static const bool poison = getenv("GF_BA_POISON") != nullptr && atoi(getenv("GF_BA_POISON")) != 3;   // 1: device buffers and LDS, 2: device buffers only, 3: LDS only
+        // Every device buffer starts as zeros, explicitly: parts of them are read before anything of THIS handle wrote them (the GNSS cost part of a handle without
+        // GNSS factors, rows beyond what a batch fills, ...) and hipMalloc hands back whatever the previous owner left -- zeros in a fresh process, another handle's
+        // tables later in the same process (round 4: a group member and a stand-alone estimator disagreed once an earlier test had used the memory).
+        bool bad = poison;
+        if (const char* r = getenv("GF_BA_POISON_RANGE")) {   // "lo:hi": only the allocations lo <= index < hi of the process (to find which buffer a kernel reads unwritten)
+            static std::atomic<int> idx{0};
+            const int i = idx++, lo = atoi(r), hi = strchr(r, ':') ? atoi(strchr(r, ':') + 1) : lo + 1;
+            bad = i >= lo && i < hi;
+        }
+        // (hipMemset runs on the null stream and the handle's stream is non-blocking: finished here, before anybody can enqueue a copy into the buffer)
+        if (hipMemset(d, bad ? 0x5A : 0, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipMemset failed");
         if (host) { if (hipHostMalloc((void**)&h, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipHostMalloc failed"); memset(h, 0, std::max<size_t>(count, 1) * sizeof(T)); }
         return GF_OK;
     }
@@ -82,7 +96,7 @@ struct gf_ba {
     // inputs (host mirror + device)
     Buf<double> xs0;     // pristine states [B][XS] (for reset)
     Buf<double> xs;      // [2][B][XS]
-    Buf<int> colf, cole, nvis, nimu, nwh, nfeat, vis_feat, vis_i, vis_j, order, norder, feat_ptr, feat_fac, vis_pos, imu_i, wh_i, pri_n, pri_nb, pri_bid;
+    Buf<int> colf, cole, nvis, nimu, nwh, nfeat, vis_idx, order, norder, feat_ptr, vis_pos, imu_i, wh_i, pri_n, pri_nb, pri_bid;
     Buf<double> vis_data, feat_obs, imu_data, wh_data, pri_J, pri_r, pri_x0;
     Buf<SolverState> st, st0;
     // work
@@ -106,7 +120,7 @@ struct gf_ba {
     int max_vis = 0, max_order = 0, max_prior = 0, max_feat = 0;   // largest n_visual / factor-order length / prior size of the resident batch (what the uploads copy)
     std::vector<const gf_ba_window*> resident;       // the caller's window behind every resident slot (gf_ba_marginalize_resident)
     // what packing a window into slot b found out about it; reduced over the batch when the batch is closed (pack_slot may run on one thread per slot)
-    struct SlotMeta { bool any_ex = false, pri_res = false; long long mfma = 0, step = 0, jtj = 0; int nvis = 0, norder = 0, npri = 0, nfeat = 0, imu_dirty = 0; };
+    struct SlotMeta { int mno[2] = {0, 0}; bool any_ex = false, pri_res = false, pos_ident = true; long long mfma = 0, step = 0, jtj = 0; int nvis = 0, norder = 0, npri = 0, nfeat = 0, imu_dirty = 0; };
     std::vector<SlotMeta> meta;
     // device-resident priors (gf_ba_pack_slot with prior_n > 0 and prior_J == NULL): outJ_n[b] = size of the prior the last gf_ba_marginalize_resident left in
     // the output buffer of slot b (0: none); the next solve of that slot copies it device to device into the prior table instead of taking it from the host
@@ -121,6 +135,7 @@ struct gf_ba {
     int max_imu_dirty = 0;
     bool all_pri_res = false, any_pri_res = false, outJ_host_stale = false;
     int step_waves = 8;
+    bool pos_ident = false;
     bool split_jtj = false, split_timed = false;   // gf_ba_set_split_jtj: the visual sweep as two kernels (block rows through HBM, contraction-only MFMA kernel)
     Buf<double> vrows; hipEvent_t ev_split[2] = {nullptr, nullptr};
     double max_solver_time = 0.0;   // ceres::Solver::Options::max_solver_time_in_seconds; 0 = not honoured (the fixed schedule runs without host round trips)
@@ -129,7 +144,7 @@ struct gf_ba {
     long long step_flops = 0;     // dense algebra of one ba_step over the resident batch: Schur SYRK NE*n_c^2 + Cholesky R^3/3 + substitutions 2 R^2
     std::vector<Buf<double>*> dbl() { return {&xs0, &xs, &vis_data, &feat_obs, &imu_data, &wh_data, &pri_J, &pri_r, &pri_x0, &imu_sqrt, &wh_sqrt, &pri_A, &pri_b, &pri_c, &H, &g, &Vc, &vtile, &wpar, &cost, &efac,
                                               &scale, &diag, &grad, &gn, &step, &u, &Et, &Es, &ete, &etb, &rhs, &yv, &Sg, &Mg, &gn_data, &gn_misc, &gn_rows}; }
-    std::vector<Buf<int>*> ints() { return {&colf, &cole, &nvis, &nimu, &nwh, &nfeat, &vis_feat, &vis_i, &vis_j, &order, &norder, &feat_ptr, &feat_fac, &vis_pos, &imu_i, &wh_i, &pri_n, &pri_nb, &pri_bid, &ngnss, &gn_idx, &gn_gptr, &gn_gitem}; }
+    std::vector<Buf<int>*> ints() { return {&colf, &cole, &nvis, &nimu, &nwh, &nfeat, &vis_idx, &order, &norder, &feat_ptr, &vis_pos, &imu_i, &wh_i, &pri_n, &pri_nb, &pri_bid, &ngnss, &gn_idx, &gn_gptr, &gn_gitem}; }
     void release() {
         for (auto* b : dbl()) b->release();
         for (auto* b : ints()) b->release();
@@ -147,9 +162,9 @@ struct gf_ba {
     Win win() {
         Win w{};
         w.d = d; w.xs = xs.d; w.colf = colf.d; w.cole = cole.d; w.nvis = nvis.d; w.nimu = nimu.d; w.nwh = nwh.d; w.nfeat = nfeat.d;
-        w.vis_feat = vis_feat.d; w.vis_i = vis_i.d; w.vis_j = vis_j.d; w.vis_data = vis_data.d; w.feat_obs = feat_obs.d; w.order = order.d; w.norder = norder.d;
+        w.vis_idx = vis_idx.d; w.vis_data = vis_data.d; w.feat_obs = feat_obs.d; w.order = order.d; w.norder = norder.d;
         w.ngnss = ngnss.d; w.gn_idx = gn_idx.d; w.gn_data = gn_data.d; w.gn_misc = gn_misc.d; w.gn_gptr = gn_gptr.d; w.gn_gitem = gn_gitem.d; w.gn_rows = gn_rows.d;
-        w.feat_ptr = feat_ptr.d; w.feat_fac = feat_fac.d; w.vis_pos = vis_pos.d; w.imu_i = imu_i.d; w.imu_data = imu_data.d; w.wh_i = wh_i.d; w.wh_data = wh_data.d;
+        w.feat_ptr = feat_ptr.d; w.vis_pos = vis_pos.d; w.pos_ident = pos_ident ? 1 : 0; w.imu_i = imu_i.d; w.imu_data = imu_data.d; w.wh_i = wh_i.d; w.wh_data = wh_data.d;
         w.imu_sqrt = imu_sqrt.d; w.wh_sqrt = wh_sqrt.d; w.pri_n = pri_n.d; w.pri_nb = pri_nb.d; w.pri_bid = pri_bid.d; w.pri_J = pri_J.d; w.pri_r = pri_r.d;
         w.pri_x0 = pri_x0.d; w.pri_A = pri_A.d; w.pri_b = pri_b.d; w.pri_c = pri_c.d; w.H = H.d; w.g = g.d; w.Vc = Vc.d; w.cost = cost.d; w.efac = efac.d; w.st = st.d;
         w.wpar = wpar.d; w.vtile = nullptr; w.vtile_stride = vtile_stride; w.stamps = stamps.d;
@@ -251,9 +266,9 @@ int pack_slot(gf_ba* h, int b, const gf_ba_window& w) {
             const size_t kk = (size_t)b * d.NV + k;
             if (w.vis_feature[k] < 0 || w.vis_feature[k] >= w.n_feature || w.vis_i[k] < 0 || w.vis_i[k] >= w.vis_j[k] || w.vis_j[k] > d.W)   // frame i is the feature's start frame: i < j
                 return gf::set_err(GF_ERR_INVALID, "window %d: visual factor %d has bad indices", b, k);
-            h->vis_feat.h[kk] = w.vis_feature[k]; h->vis_i.h[kk] = w.vis_i[k]; h->vis_j.h[kk] = w.vis_j[k];
-            double* vd = h->vis_data.h + kk * 6;
-            memcpy(vd, w.vis_pts_j + 3 * k, 24); memcpy(vd + 3, w.vis_vel_j + 2 * k, 16); vd[5] = w.vis_td_j[k];
+            h->vis_idx.h[kk] = (w.vis_feature[k] << 10) | (w.vis_i[k] << 5) | w.vis_j[k];
+            double* vd = h->vis_data.h + kk * 5;
+            memcpy(vd, w.vis_pts_j + 3 * k, 16); memcpy(vd + 2, w.vis_vel_j + 2 * k, 16); vd[4] = w.vis_td_j[k];   // pts_j.z does not enter the residual
             // the observation in the start frame is stored once per feature: every factor of a feature must bring the same one (they are built from
             // feature_per_frame[0], estimator.cpp:3276-3290)
             double* fo = h->feat_obs.h + ((size_t)b * d.F + w.vis_feature[k]) * 6;
@@ -296,7 +311,9 @@ int pack_slot(gf_ba* h, int b, const gf_ba_window& w) {
             fp[0] = 0;
             for (int f = 0; f < d.F; f++) fp[f + 1] = fp[f] + cnt[f + 1];
             std::vector<int> cur(fp, fp + d.F);
-            for (int k = 0; k < w.n_visual; k++) { const int pos = cur[w.vis_feature[k]]++; h->feat_fac.h[(size_t)b * d.NV + pos] = k; h->vis_pos.h[(size_t)b * d.NV + k] = pos; }
+            bool ident = true;
+            for (int k = 0; k < w.n_visual; k++) { const int pos = cur[w.vis_feature[k]]++; h->vis_pos.h[(size_t)b * d.NV + k] = pos; ident &= pos == k; }
+            M.pos_ident = ident;
         }
         {   // IMU rows: build them, compare with the slot's table, stage what is new (see gf_ba::imu_patch)
             std::vector<double> rows((size_t)std::max(w.n_imu, 1) * IMU_STRIDE2);
@@ -416,7 +433,7 @@ int pack_slot(gf_ba* h, int b, const gf_ba_window& w) {
                     p = q;
                 }
             }
-            h->mnorder[mode].h[b] = no;
+            h->mnorder[mode].h[b] = no; M.mno[mode] = no;
             for (int i = no; i < d.NVP; i++) ord[i] = -1;
         }
     }
@@ -480,10 +497,13 @@ int upload(gf_ba* h) {
     HIPCHK(h->cole.up2d(s, B, d.F, (size_t)d.F));   // whole rows: entries beyond n_feature are -1 markers the kernels rely on
     HIPCHK(h->feat_ptr.up2d(s, B, (size_t)d.F + 1, (size_t)d.F + 1)); lapb("small tables, cole, feat_ptr");
     // per-window tables are laid out for the handle's capacity; only what this batch fills is copied
-    for (auto* b : {&h->vis_feat, &h->vis_i, &h->vis_j, &h->feat_fac, &h->vis_pos}) HIPCHK(b->up2d(s, B, d.NV, nv));
-    lapb("vis int tables x5");
+    HIPCHK(h->vis_idx.up2d(s, B, d.NV, nv));
+    h->pos_ident = true;   // over every slot's last pack (slots that sit a batch out keep their tables)
+    for (const gf_ba::SlotMeta& M : h->meta) h->pos_ident &= M.pos_ident;
+    if (!h->pos_ident) HIPCHK(h->vis_pos.up2d(s, B, d.NV, nv));
+    lapb("vis int tables x2");
     HIPCHK(h->order.up2d(s, B, d.NVP, no)); lapb("order");
-    HIPCHK(h->vis_data.up2d(s, B, (size_t)d.NV * 6, nv * 6));
+    HIPCHK(h->vis_data.up2d(s, B, (size_t)d.NV * 5, nv * 5));
     HIPCHK(h->feat_obs.up2d(s, B, (size_t)d.F * 6, nf * 6)); lapb("vis_data + feat_obs");
     if (!h->any_pri_res) HIPCHK(h->pri_J.up2d(s, B, (size_t)d.NPRI * d.NPRI, np2));
     else if (!h->all_pri_res)   // mixed batch: only the active slots that brought a host prior; a slot that sits this batch out keeps what the device holds (its host mirror was never written)
@@ -511,7 +531,11 @@ int upload(gf_ba* h) {
     if (h->d.GO) { HIPCHK(h->ngnss.up(s)); HIPCHK(h->gn_idx.up(s)); HIPCHK(h->gn_data.up(s)); HIPCHK(h->gn_misc.up(s)); HIPCHK(h->gn_gptr.up(s)); HIPCHK(h->gn_gitem.up(s)); }
     for (int m = 0; m < 2; m++) {
         for (auto* b : {&h->mcolf[m], &h->mcole[m], &h->mnorder[m], &h->minfo[m]}) HIPCHK(b->up(s));
-        HIPCHK(h->morder[m].up2d(s, B, d.NVP, no));
+        {   // the marginalisation's factor order: only as far as this layout fills it (MARGIN_OLD: the factors of the features that start at frame 0; MARGIN_SECOND_NEW: none)
+            size_t mo = 0;
+            for (const gf_ba::SlotMeta& M : h->meta) mo = std::max(mo, (size_t)M.mno[m]);
+            HIPCHK(h->morder[m].up2d(s, B, d.NVP, mo));
+        }
     }
     lapb("gnss + marg layouts");
     HIPCHK(hipMemcpyAsync(h->st0.d, h->st0.h, h->st0.n * sizeof(SolverState), hipMemcpyHostToDevice, s));
@@ -547,6 +571,18 @@ int reset_state(gf_ba* h) {
     return GF_OK;
 }
 
+__global__ void __launch_bounds__(256) ba_poison_lds(int ndoubles) {   // GF_BA_POISON: every CU's LDS full of NaN before a launch (1024 blocks of 160 KB: every CU gets some)
+    extern __shared__ double lds_all[];
+    for (int i = threadIdx.x; i < ndoubles; i += 256) lds_all[i] = __longlong_as_double(-1LL);
+}
+static void poison_lds(gf_ba* h) {
+    static const bool poison = getenv("GF_BA_POISON") != nullptr && atoi(getenv("GF_BA_POISON")) != 2;
+    if (!poison) return;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_poison_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    ba_poison_lds<<<dim3(1024), 256, 160 * 1024, h->stream>>>(160 * 1024 / 8);
+}
+
 // One linearisation of the resident batch at the state buffer `which_state` into the buffers `which` (-1: the candidate's).
 // Visual sweep (Vc, E^T F rows), then prior / IMU / wheel (H, g) and the GNSS blocks, on the handle's stream.  Every buffer
 // has one writing kernel and every sum a fixed order: no zeroing or reset passes, no atomics.
@@ -571,6 +607,7 @@ int launch_visual(gf_ba* h, Win w, bool ex, int which, int which_state, int only
 int launch_linearize(gf_ba* h, int which, int which_state, int only_valid, bool timed, bool misc_with_step = false) {
     const Dims& d = h->d;
     Win w = h->win();
+    poison_lds(h);
     if (timed) HIPCHK(hipEventRecord(h->ev[2], h->stream));
     if (int rc = launch_visual(h, w, h->any_ex, which, which_state, only_valid, timed)) return rc;
     if (timed) HIPCHK(hipEventRecord(h->ev[3], h->stream));
@@ -598,6 +635,7 @@ int run_solve(gf_ba* h, int max_iters) {
             HIPCHK(hipStreamSynchronize(h->stream));
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() >= h->max_solver_time) it = max_iters;
         }
+        poison_lds(h);
         const bool time_step = it == 1 && max_iters >= 1;
         if (time_step) HIPCHK(hipEventRecord(h->ev[6], h->stream));
         if (h->step_waves == 4) {
@@ -621,6 +659,7 @@ int run_solve(gf_ba* h, int max_iters) {
 int run_marginalize(gf_ba* h, int mode) {
     const Dims& d = h->d;
     Win w = h->win();
+    poison_lds(h);
     Win wm = w;   // marginalisation column maps: dropped blocks first, no block constant
     wm.colf = h->mcolf[mode].d; wm.cole = h->mcole[mode].d; wm.order = h->morder[mode].d; wm.norder = h->mnorder[mode].d;
     // the dropped frame's factors are linearised at the current state into the other buffer set
@@ -636,6 +675,7 @@ int run_marginalize(gf_ba* h, int mode) {
     // configs[4]): cut 1e-10: 1e-6 1e-8 3e-8 6e-5 1e-6;  1e-9: 1e-6 1e-8 3e-8 6e-5 3e-4;  1e-8: 1e-6 7e-8 3e-8 2e-7 4e-4;  3e-8: 1e-6 3e-7 3e-8 2e-7 1e-6 [m].
     static const double piv_eps = getenv("GF_MARG_PIVOT_EPS") ? atof(getenv("GF_MARG_PIVOT_EPS")) : 3e-8;
     static const int ls_rhs = getenv("GF_MARG_LS_RHS") ? atoi(getenv("GF_MARG_LS_RHS")) : 1;
+    poison_lds(h);
     if (h->big_marg) ba_marg_finish<true><<<dim3(d.B), 512, 0, h->stream>>>(wm, h->sbufs(), reinterpret_cast<const MargInfo*>(h->minfo[mode].d), mo, mode == 0 ? 1 : 0, piv_eps, ls_rhs);
     else ba_marg_finish<false><<<dim3(d.B), 512, h->marg_lds, h->stream>>>(wm, h->sbufs(), reinterpret_cast<const MargInfo*>(h->minfo[mode].d), mo, mode == 0 ? 1 : 0, piv_eps, ls_rhs);
     HIPCHK(hipGetLastError());
@@ -690,8 +730,8 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     const size_t B = d.B, VS = d.RP + d.FP;
     A_(h->xs0.alloc(B * d.XS, true)); A_(h->xs.alloc(2 * B * d.XS, true));
     A_(h->colf.alloc(B * d.NFB, true)); A_(h->cole.alloc(B * d.F, true)); A_(h->nvis.alloc(B, true)); A_(h->nimu.alloc(B, true)); A_(h->nwh.alloc(B, true)); A_(h->nfeat.alloc(B, true));
-    A_(h->vis_feat.alloc(B * d.NV, true)); A_(h->vis_i.alloc(B * d.NV, true)); A_(h->vis_j.alloc(B * d.NV, true)); A_(h->vis_data.alloc(B * d.NV * 6, true)); A_(h->feat_obs.alloc(B * d.F * 6, true));
-    A_(h->order.alloc(B * d.NVP, true)); A_(h->norder.alloc(B, true)); A_(h->feat_ptr.alloc(B * (d.F + 1), true)); A_(h->feat_fac.alloc(B * d.NV, true)); A_(h->vis_pos.alloc(B * d.NV, true));
+    A_(h->vis_idx.alloc(B * d.NV, true)); A_(h->vis_data.alloc(B * d.NV * 5, true)); A_(h->feat_obs.alloc(B * d.F * 6, true));
+    A_(h->order.alloc(B * d.NVP, true)); A_(h->norder.alloc(B, true)); A_(h->feat_ptr.alloc(B * (d.F + 1), true)); A_(h->vis_pos.alloc(B * d.NV, true));
     A_(h->imu_i.alloc(B * d.W, true)); A_(h->imu_data.alloc(B * d.W * IMU_STRIDE2, true)); A_(h->wh_i.alloc(B * d.W, true)); A_(h->wh_data.alloc(B * d.W * WH_STRIDE, true));
     A_(h->pri_n.alloc(B, true)); A_(h->pri_nb.alloc(B, true)); A_(h->pri_bid.alloc(B * 64, true)); A_(h->pri_J.alloc(B * d.NPRI * d.NPRI, true));
     A_(h->pri_r.alloc(B * d.NPRI, true)); A_(h->pri_x0.alloc(B * d.NPRI * 2, true));

@@ -69,16 +69,16 @@ struct Win {  // device view of the whole batch
     const int* colf;          // [B][NFB] column of each non-feature block or -1 (constant)
     const int* cole;          // [B][F]   index of each free feature among the eliminated columns or -1
     const int* nvis; const int* nimu; const int* nwh; const int* nfeat;   // [B]
-    const int* vis_feat; const int* vis_i; const int* vis_j;              // [B][NV]
-    const double* vis_data;   // [B][NV][6] per factor: pts_j(3) vel_j(2) td_j -- the observation in frame j
+    const int* vis_idx;       // [B][NV] per factor: feature << 10 | frame i << 5 | frame j (one word instead of three tables: 8 bytes per factor less to upload every frame)
+    const double* vis_data;   // [B][NV][5] per factor: pts_j.x, pts_j.y, vel_j(2), td_j -- the observation in frame j (its z never enters the residual: estimator.cpp:3276-3290 passes normalised points)
     const double* feat_obs;   // [B][F][6] per feature: pts_i(3) vel_i(2) td_i -- the observation in the start frame, shared by all factors of the feature
                               // (ProjectionTwoFrameOneCamFactor is built from feature_per_frame[0], estimator.cpp:3276-3290): 96 -> 48 bytes per factor to
                               // upload and to stream in every sweep
     const int* order;         // [B][NVP] factor index sorted by (i,j) pair, pairs padded to even length with -1
     const int* norder;        // [B]
     const int* feat_ptr;      // [B][F+1] CSR: factors of each feature
-    const int* feat_fac;      // [B][NV]
-    const int* vis_pos;       // [B][NV] position of every factor in its feature's list (inverse of feat_fac): row of efac
+    const int* vis_pos;       // [B][NV] position of every factor in its feature's list: row of efac
+    int pos_ident;            // every resident window lists its factors feature by feature (vis_pos[k] == k: what Estimator::optimization() builds): vis_pos is neither uploaded nor read
     const int* imu_i; const double* imu_data;   // [B][W], [B][W][IMU_STRIDE]
     const int* wh_i; const double* wh_data;     // [B][W], [B][W][WH_STRIDE]
     double* imu_sqrt; double* wh_sqrt;          // [B][W][225], [B][W][36]
@@ -242,11 +242,11 @@ __device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int
     }
     {
         const size_t kk = (size_t)b * d.NV + k;
-        fi = w.vis_i[kk]; fj = w.vis_j[kk]; feat = w.vis_feat[kk];
+        { const int pk_ = w.vis_idx[kk]; feat = pk_ >> 10; fi = (pk_ >> 5) & 31; fj = pk_ & 31; }
         double vd[12];
         {
-            const double* fj6 = w.vis_data + kk * 6; const double* fi6 = w.feat_obs + ((size_t)b * d.F + feat) * 6;
-            vd[0] = fi6[0]; vd[1] = fi6[1]; vd[2] = fi6[2]; vd[3] = fj6[0]; vd[4] = fj6[1]; vd[5] = fj6[2]; vd[6] = fi6[3]; vd[7] = fi6[4]; vd[8] = fj6[3]; vd[9] = fj6[4]; vd[10] = fi6[5]; vd[11] = fj6[5];
+            const double* fj5 = w.vis_data + kk * 5; const double* fi6 = w.feat_obs + ((size_t)b * d.F + feat) * 6;
+            vd[0] = fi6[0]; vd[1] = fi6[1]; vd[2] = fi6[2]; vd[3] = fj5[0]; vd[4] = fj5[1]; vd[5] = 1.0; vd[6] = fi6[3]; vd[7] = fi6[4]; vd[8] = fj5[2]; vd[9] = fj5[3]; vd[10] = fi6[5]; vd[11] = fj5[4];
         }
         visual_eval(xs + off_pose(fi), xs + off_pose(fj), xs + off_ex(d.NP), xs[off_feat(d.NP) + feat], xs[off_td(d.NP)], vd,
                     w.wpar[WPAR * b + 3], true, ev);
@@ -277,7 +277,7 @@ __device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int
         if (EX && colf[fb_ex(d.NP)] < 0) for (int c = 16; c < 22; c++) ev.row[0][c] = ev.row[1][c] = 0.0;
         // eliminated (free inverse depth) column: products needed by the Schur complement
         if (live && w.cole[(size_t)b * d.F + feat] >= 0) {
-            double* ef = w.efac + ((size_t)b * d.NV * EF + (size_t)w.vis_pos[kk] * ef_stride<EX>());   // the factors of a feature are contiguous
+            double* ef = w.efac + ((size_t)b * d.NV * EF + (size_t)(w.pos_ident ? k : w.vis_pos[kk]) * ef_stride<EX>());   // the factors of a feature are contiguous
 #pragma unroll
             for (int c = 0; c < 13; c++) ef[c] = ev.jd[0] * ev.row[0][c] + ev.jd[1] * ev.row[1][c];
             const double ete_f = ev.jd[0] * ev.jd[0] + ev.jd[1] * ev.jd[1], etb_f = ev.jd[0] * ev.row[0][13] + ev.jd[1] * ev.row[1][13];

@@ -419,11 +419,14 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     //     r = r_fs + L1^-1 T w,   T = L1^-T L2^T,   (I + T^T T) w = e
     // one backward substitution with m2 right-hand sides, an m2 x m2 solve, one forward substitution.  m2 = 0 (full rank) or m2 > 32: nothing is done.
     {
-        constexpr int kM2 = 32, TS = kM2 + 1;
+        constexpr int kM2 = 32, TS = kM2 + 1, kLsRows = 256;   // kept systems of up to 256 columns (s_dg above has the same bound)
         const int m2 = n - rank;
-        if (ls_rhs && rank > 0 && m2 > 0 && m2 <= kM2) {
-            double* Tm = V + 2048;                 // rank x TS
-            double* G = Tm + (size_t)n * TS;       // m2 x (m2 + 1): [I + T^T T | e], then w in its last column
+        if (ls_rhs && rank > 0 && m2 > 0 && m2 <= kM2 && n <= kLsRows) {
+            // scratch in LDS in both variants: the chains below synchronise lanes of ONE wavefront with wavefront barriers, which orders LDS accesses but not a
+            // store and a later load of another lane through the vector L1 (the global-memory variant keeps A, zb, dinvs, zr in sb.Mg; T, G and vv get their own LDS)
+            __shared__ double s_ls[GS ? kLsRows * TS + kM2 * (kM2 + 1) + kLsRows : 1];
+            double* Tm = GS ? s_ls : V + 2048;     // rank x TS
+            double* G = Tm + (size_t)(GS ? kLsRows : n) * TS;       // m2 x (m2 + 1): [I + T^T T | e], then w in its last column
             double* vv = G + kM2 * (kM2 + 1);      // rank: T w, forward-substituted in place
             for (int i = tid; i < rank * kM2; i += 512) { const int k = i >> 5, j = i & 31; Tm[k * TS + j] = j < m2 ? A[(size_t)k * n + rank + j] : 0.0; }
             __syncthreads();

@@ -105,7 +105,14 @@ class HostPool {
 
 template <class T> struct DevBuf {
     T* p = nullptr; size_t n = 0;
-    int alloc(size_t count) { n = count; hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)); if (e != hipSuccess) return set_err(GF_ERR_HIP, "hipMalloc(%zu B) failed: %s", count * sizeof(T), hipGetErrorString(e)); return GF_OK; }
+    int alloc(size_t count) {
+        n = count;
+        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e != hipSuccess) return set_err(GF_ERR_HIP, "hipMalloc(%zu B) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        // zeros, explicitly and finished before the handle's non-blocking stream can touch the buffer: hipMalloc returns whatever the previous owner left
+        if (hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return set_err(GF_ERR_HIP, "hipMemset failed");
+        return GF_OK;
+    }
     void release() { if (p) (void)hipFree(p); p = nullptr; }
 };
 template <class T> struct PinBuf {
