@@ -137,7 +137,7 @@ struct gf_ba {
     int step_waves = 8;
     bool pos_ident = false;
     bool split_jtj = false, split_timed = false;   // gf_ba_set_split_jtj: the visual sweep as two kernels (block rows through HBM, contraction-only MFMA kernel)
-    Buf<double> vrows; hipEvent_t ev_split[2] = {nullptr, nullptr};
+    Buf<double> vrows, vpair; hipEvent_t ev_split[2] = {nullptr, nullptr};
     double max_solver_time = 0.0;   // ceres::Solver::Options::max_solver_time_in_seconds; 0 = not honoured (the fixed schedule runs without host round trips)
     long long mfma_per_lin = 0;   // v_mfma_f64_16x16x4 instructions of one visual linearisation of the resident batch
     long long jtj_alg_flops = 0;  // algorithmic flops of the same: Nv * 2 * 2 * (12 * 13 / 2 + 12 + 1) per window
@@ -155,7 +155,7 @@ struct gf_ba {
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         if (ev_gather) (void)hipEventDestroy(ev_gather);
         for (auto& e : ev_split) if (e) (void)hipEventDestroy(e);
-        vrows.release();
+        vrows.release(); vpair.release();
         gather_send.release();
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -590,6 +590,7 @@ int launch_visual(gf_ba* h, Win w, bool ex, int which, int which_state, int only
     const Dims& d = h->d;
     const size_t lds = ex ? h->vwinx_lds : h->vwin_lds;
     w.vtile = lds ? nullptr : h->vtile.d;
+    w.vpair = h->vpair.d;
     if (ex) ba_linearize_visual_win<true, kVWX><<<dim3(d.B), 64 * kVWX, lds, h->stream>>>(w, h->sbufs(), which, which_state, only_valid);
     else if (h->split_jtj && only_valid != 2) {   // north_star's formulation, measured next to the fused kernel: the sweep writes block rows to HBM, a second kernel only contracts them
         w.vrows = h->vrows.d;
@@ -750,6 +751,7 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     if (gnss) { A_(h->ngnss.alloc(B, true)); A_(h->gn_idx.alloc(B * d.NG * 4, true)); A_(h->gn_data.alloc(B * d.NG * GN_STRIDE, true)); A_(h->gn_misc.alloc(B * (GN_MISC + d.NP), true)); A_(h->gn_gptr.alloc(B * (d.NGRP + 2), true)); A_(h->gn_gitem.alloc(B * d.NG, true)); A_(h->gn_rows.alloc(B * d.NG * GN_ROW, false)); }
     for (int m = 0; m < 2; m++) { A_(h->mcolf[m].alloc(B * d.NFB, true)); A_(h->mcole[m].alloc(B * d.F, true)); A_(h->morder[m].alloc(B * d.NVP, true)); A_(h->mnorder[m].alloc(B, true)); A_(h->minfo[m].alloc(B * 4, true)); }
     A_(h->minfo_stage.alloc(B * 4, true));
+    A_(h->vpair.alloc(B * (size_t)(d.NP * (d.NP - 1) / 2) * VPG, false));
     A_(h->outJ.alloc(B * (size_t)d.NPRI * d.NPRI, true)); A_(h->outr.alloc(B * d.NPRI, true)); A_(h->stamps.alloc(128, true));
     // kept system of the marginalisation: 6 W poses + speed-bias + extrinsics ...; A and V live in LDS up to 92 columns, else in global memory
     const int nkeep = 6 * d.W + 9 + 17 + (gnss ? 9 : 0);

@@ -93,6 +93,7 @@ struct Win {  // device view of the whole batch
     SolverState* st;          // [B]
     const double* wpar;       // [B][WPAR] per window: gravity G (3), visual sqrt_info, PoseSubsetParameterization masks of the camera / wheel extrinsic (as doubles)
     long long* stamps;        // optional phase timestamps of window 0 (profiling builds, -DGF_PROFILE_STEP)
+    double* vpair;            // [B][NP (NP - 1) / 2][VPG] per frame pair (i < j): what every factor of the pair shares (vis_pair_geo), written by the sweep's own block before it evaluates
     double* vrows;            // [B][NVP][2][16] block rows of the visual factors in HBM (split formulation only: ba_linearize_visual_win MODE 1 / 2); else null
     double* vtile;            // global home of the visual sweep's pair tiles when they do not fit LDS ([B][vtile_stride]); else null
     size_t vtile_stride;
@@ -201,6 +202,72 @@ __device__ __forceinline__ void visual_eval(const double* Pi_, const double* Pj_
     }
 }
 
+// ---- the part of ProjectionTwoFrameOneCamFactor::Evaluate that depends on the frame pair only (round 4).  With X = pts_camera_i the chain of
+// projectionTwoFrameOneCamFactor.cpp:60-66 is  pts_camera_j = M X + t,  M = ric^T Rj^T Ri ric (`tmp_r`, :119),  t = ric^T (Rj^T (Ri tic + Pi - Pj) - tic),  and the Jacobian
+// blocks are built from  A = ric^T Rj^T (:88-91),  A Ri (:92),  M,  ric, tic  and -- with a free camera extrinsic -- ric^T (Rj^T Ri - I) (:111) and t (:115-118).  The factor
+// list is pair-sorted, so the sweep's block computes these once per pair (55 pairs at W = 10 against ~1500 factors) into w.vpair and a lane evaluates its factor from the table:
+// four quaternion rotations, three quaternion-to-matrix conversions and five 3 x 3 products per factor become one matrix-vector product, and the 2 x 3 projection rows are
+// folded into the pair's matrices before the products with the point (q (-[v]x) = v x q), not after them.
+constexpr int VPG = 40;   // A 9, A Ri 9, M 9, t 3, ric^T (Rj^T Ri - I) 9, pad 1
+__device__ __forceinline__ void vis_pair_geo(const double* Pi_, const double* Pj_, const double* Ex_, double* out) {
+    const V3 Pi = p_of(Pi_), Pj = p_of(Pj_), tic = p_of(Ex_);
+    const M3 Ri = qmat(q_of(Pi_)), Rj = qmat(q_of(Pj_)), ric = qmat(q_of(Ex_));
+    const M3 RjT = transpose(Rj), ricT = transpose(ric);
+    const M3 A = ricT * RjT, ARi = A * Ri, M = ARi * ric;
+    const V3 t = ricT * (RjT * (Ri * tic + Pi - Pj) - tic);
+    const M3 Jep = ricT * (RjT * Ri - m3_identity());
+#pragma unroll
+    for (int k = 0; k < 9; k++) { out[k] = A.m[k]; out[9 + k] = ARi.m[k]; out[18 + k] = M.m[k]; out[30 + k] = Jep.m[k]; }
+    out[27] = t.x; out[28] = t.y; out[29] = t.z; out[39] = 0.0;
+}
+__device__ __forceinline__ V3 cross3(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+// the same outputs as visual_eval (want_jac), from the pair table `pg`, the window's ric / tic and the factor's own data
+template <bool EX>
+__device__ __forceinline__ void visual_eval_pg(const double* pg, const M3& ric, V3 tic, double inv_dep_i, double td, const double* vd, double si, VisEval& o) {
+    const V3 pts_i = v3(vd[0], vd[1], vd[2]), vel_i = v3(vd[6], vd[7], 0);
+    const double td_i = vd[10], td_j = vd[11];
+    const V3 pts_i_td = pts_i - vel_i * (td - td_i);
+    const double pjx = vd[3] - vd[8] * (td - td_j), pjy = vd[4] - vd[9] * (td - td_j);
+    const double dep_i = 1.0 / inv_dep_i;
+    const V3 X = pts_i_td * dep_i;                                   // pts_camera_i
+    auto row = [&](int base, int r) { return V3{pg[base + 3 * r], pg[base + 3 * r + 1], pg[base + 3 * r + 2]}; };
+    auto dot = [](V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; };
+    const V3 M0 = row(18, 0), M1 = row(18, 1), M2 = row(18, 2);
+    const V3 pc = V3{dot(M0, X) + pg[27], dot(M1, X) + pg[28], dot(M2, X) + pg[29]};   // pts_camera_j
+    const double idj = 1.0 / pc.z;
+    o.row[0][13] = si * (pc.x * idj - pjx);
+    o.row[1][13] = si * (pc.y * idj - pjy);
+    const double r00 = si * idj, r02 = -si * pc.x * (idj * idj), r12 = -si * pc.y * (idj * idj);
+    // q0 / q1 = the two rows of `reduce` times a 3 x 3 matrix B: r00 B[0] + r02 B[2], r00 B[1] + r12 B[2]
+    auto fold = [&](V3 b0, V3 b1, V3 b2, V3& q0, V3& q1) { q0 = b0 * r00 + b2 * r02; q1 = b1 * r00 + b2 * r12; };
+    V3 a0, a1, b0, b1, m0, m1, c0, c1;
+    fold(row(0, 0), row(0, 1), row(0, 2), a0, a1);                  // reduce * A           -> pose_i position, pose_j position (negated)
+    fold(row(9, 0), row(9, 1), row(9, 2), b0, b1);                  // reduce * A Ri        -> pose_i rotation via -[pts_imu_i]x
+    fold(M0, M1, M2, m0, m1);                                       // reduce * M           -> inverse depth, td
+    fold(V3{ric.m[0], ric.m[3], ric.m[6]}, V3{ric.m[1], ric.m[4], ric.m[7]}, V3{ric.m[2], ric.m[5], ric.m[8]}, c0, c1);   // reduce * ric^T -> pose_j rotation via [pts_imu_j]x
+    const V3 pts_imu_i = ric * X + tic, pts_imu_j = ric * pc + tic;
+    const V3 ji0 = cross3(pts_imu_i, b0), ji1 = cross3(pts_imu_i, b1);   // q (-[v]x) = v x q
+    const V3 jj0 = cross3(c0, pts_imu_j), jj1 = cross3(c1, pts_imu_j);   // q [v]x = q x v
+    o.row[0][0] = a0.x; o.row[0][1] = a0.y; o.row[0][2] = a0.z; o.row[1][0] = a1.x; o.row[1][1] = a1.y; o.row[1][2] = a1.z;
+    o.row[0][3] = ji0.x; o.row[0][4] = ji0.y; o.row[0][5] = ji0.z; o.row[1][3] = ji1.x; o.row[1][4] = ji1.y; o.row[1][5] = ji1.z;
+    o.row[0][6] = -a0.x; o.row[0][7] = -a0.y; o.row[0][8] = -a0.z; o.row[1][6] = -a1.x; o.row[1][7] = -a1.y; o.row[1][8] = -a1.z;
+    o.row[0][9] = jj0.x; o.row[0][10] = jj0.y; o.row[0][11] = jj0.z; o.row[1][9] = jj1.x; o.row[1][10] = jj1.y; o.row[1][11] = jj1.z;
+    {
+        const double f = -(dep_i * dep_i);
+        o.jd[0] = dot(m0, pts_i_td) * f; o.jd[1] = dot(m1, pts_i_td) * f;
+        o.row[0][12] = dot(m0, vel_i) * dep_i * -1.0 + si * vd[8];
+        o.row[1][12] = dot(m1, vel_i) * dep_i * -1.0 + si * vd[9];
+    }
+    if (EX) {
+        V3 e0, e1;
+        fold(row(30, 0), row(30, 1), row(30, 2), e0, e1);            // reduce * ric^T (Rj^T Ri - I)
+        // Jer = -M [X]x + [M X]x + [t]x with M X + t = pc:  reduce Jer = X x m  +  rows of reduce times [pc]x  ( = (r00, 0, r02) x pc, (0, r00, r12) x pc )
+        const V3 g0 = cross3(X, m0) + cross3(V3{r00, 0.0, r02}, pc), g1 = cross3(X, m1) + cross3(V3{0.0, r00, r12}, pc);
+        o.row[0][16] = e0.x; o.row[0][17] = e0.y; o.row[0][18] = e0.z; o.row[1][16] = e1.x; o.row[1][17] = e1.y; o.row[1][18] = e1.z;
+        o.row[0][19] = g0.x; o.row[0][20] = g0.y; o.row[0][21] = g0.z; o.row[1][19] = g1.x; o.row[1][20] = g1.y; o.row[1][21] = g1.z;
+    }
+}
+
 // Sums over lanes without LDS round trips (__shfl_xor on a double is two ds_bpermute per step, six dependent steps per sum): four DPP steps inside each
 // 16-lane row (xor 1, xor 2, half mirror, mirror -- every lane of the row ends with the row's sum), then the four row sums through v_readlane.  The order
 // of the additions is fixed, so the result does not depend on timing; every lane returns the same value.
@@ -248,8 +315,16 @@ __device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int
             const double* fj5 = w.vis_data + kk * 5; const double* fi6 = w.feat_obs + ((size_t)b * d.F + feat) * 6;
             vd[0] = fi6[0]; vd[1] = fi6[1]; vd[2] = fi6[2]; vd[3] = fj5[0]; vd[4] = fj5[1]; vd[5] = 1.0; vd[6] = fi6[3]; vd[7] = fi6[4]; vd[8] = fj5[2]; vd[9] = fj5[3]; vd[10] = fi6[5]; vd[11] = fj5[4];
         }
+#ifdef GF_VIS_PAIRGEO
+        {
+            const double* Ex_ = xs + off_ex(d.NP);
+            visual_eval_pg<EX>(w.vpair + ((size_t)b * (d.NP * (d.NP - 1) / 2) + (size_t)(fj * (fj - 1) / 2 + fi)) * VPG, qmat(q_of(Ex_)), p_of(Ex_), xs[off_feat(d.NP) + feat], xs[off_td(d.NP)], vd,
+                               w.wpar[WPAR * b + 3], ev);
+        }
+#else
         visual_eval(xs + off_pose(fi), xs + off_pose(fj), xs + off_ex(d.NP), xs[off_feat(d.NP) + feat], xs[off_td(d.NP)], vd,
                     w.wpar[WPAR * b + 3], true, ev);
+#endif
         const double r0 = ev.row[0][13], r1 = ev.row[1][13];
         const double sq = r0 * r0 + r1 * r1;
         cost = live ? 0.5 * sq : 0.0;   // inlier (s <= 1): rho = s, rho' = 1, rho'' = 0 -- the corrector is the identity (sqrt_rho1 = residual_scaling = 1, alpha = 0)
@@ -777,6 +852,18 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
     GF_WSTAMP(80);
     for (int i = tid; i < (NPAIR + NW) * TN; i += NT) slots[i] = 0.0;
     if (d.F <= kVFP) for (int i = tid; i <= d.F; i += NT) s_fptr[i] = w.feat_ptr[(size_t)b * (d.F + 1) + i];
+#ifdef GF_VIS_PAIRGEO
+    if (MODE != 2) {   // what the factors of a frame pair share, once per pair (visible to the whole block behind the barrier below: same CU, same L1)
+        for (int p = tid; p < NPAIR; p += NT) {
+            int pj = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+            while (pj * (pj - 1) / 2 > p) pj--;
+            while ((pj + 1) * pj / 2 <= p) pj++;
+            const int pi = p - pj * (pj - 1) / 2;
+            vis_pair_geo(xs + off_pose(pi), xs + off_pose(pj), xs + off_ex(NP), w.vpair + ((size_t)b * NPAIR + p) * VPG);
+        }
+        __threadfence_block();
+    }
+#endif
     // this wavefront's range of chunks, and the pair keys at its ends (a pair that straddles two ranges has a main and a continuation slot)
     const int nchunks = (n_order + 63) / 64, cpw = (nchunks + NW - 1) / NW;
     const int c_lo = min(nchunks, wave * cpw), c_hi = min(nchunks, c_lo + cpw);
