@@ -287,9 +287,14 @@ int pack_slot(gf_ba* h, int b, const gf_ba_window& w) {
         M.nvis = w.n_visual; M.npri = w.prior_n; M.nfeat = w.n_feature;
         h->nvis.h[b] = w.n_visual; h->nimu.h[b] = w.n_imu; h->nwh.h[b] = w.n_wheel; h->nfeat.h[b] = w.n_feature;
         {   // pair-sorted order with even padding (each MFMA consumes two factors of one frame pair)
+            // stable counting sort over the pair keys i * 64 + j (i < j <= W <= 30): the factor lists of a window are built and packed on its member's thread every frame
             std::vector<int> idx(w.n_visual);
-            for (int k = 0; k < w.n_visual; k++) idx[k] = k;
-            std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return w.vis_i[a] * 64 + w.vis_j[a] < w.vis_i[c] * 64 + w.vis_j[c]; });
+            {
+                int cnt[32 * 64 + 1] = {0};
+                for (int k = 0; k < w.n_visual; k++) cnt[w.vis_i[k] * 64 + w.vis_j[k] + 1]++;
+                for (int q = 0; q < 32 * 64; q++) cnt[q + 1] += cnt[q];
+                for (int k = 0; k < w.n_visual; k++) idx[cnt[w.vis_i[k] * 64 + w.vis_j[k]]++] = k;
+            }
             int* ord = h->order.h + (size_t)b * d.NVP;
             int n = 0;
             for (size_t p = 0; p < idx.size();) {
@@ -370,9 +375,10 @@ int pack_slot(gf_ba* h, int b, const gf_ba_window& w) {
     {
         for (int mode = 0; mode < 2; mode++) {
             std::vector<int> dropb, keepb, dropf;
+            std::vector<char> fseen(std::max(w.n_feature, 1), 0);   // a linear search of dropf per visual factor was the most expensive line of pack_slot
             auto has = [](const std::vector<int>& v, int id) { return std::find(v.begin(), v.end(), id) != v.end(); };
             auto touch = [&](int id, bool dropped) {
-                if (id / 4096 == GF_FEATURE) { if (!has(dropf, id)) dropf.push_back(id); return; }
+                if (id / 4096 == GF_FEATURE) { const int f = id % 4096; if (f < w.n_feature ? !fseen[f] : !has(dropf, id)) { dropf.push_back(id); if (f < w.n_feature) fseen[f] = 1; } return; }
                 if (dropped) { if (!has(dropb, id)) { dropb.push_back(id); auto it = std::find(keepb.begin(), keepb.end(), id); if (it != keepb.end()) keepb.erase(it); } }
                 else if (!has(keepb, id) && !has(dropb, id)) keepb.push_back(id);
             };
@@ -423,9 +429,14 @@ int pack_slot(gf_ba* h, int b, const gf_ba_window& w) {
             int* ord = h->morder[mode].h + (size_t)b * d.NVP;
             int no = 0;
             if (mode == 0) {
-                std::vector<int> idx;
-                for (int k = 0; k < w.n_visual; k++) if (w.vis_i[k] == 0) idx.push_back(k);
-                std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return w.vis_j[a] < w.vis_j[c]; });
+                std::vector<int> idx;   // factors of frame 0 by their second frame, stable: counting sort over j
+                {
+                    int cnt[65] = {0};
+                    for (int k = 0; k < w.n_visual; k++) if (w.vis_i[k] == 0) cnt[w.vis_j[k] + 1]++;
+                    for (int q = 0; q < 64; q++) cnt[q + 1] += cnt[q];
+                    idx.resize(cnt[64]);
+                    for (int k = 0; k < w.n_visual; k++) if (w.vis_i[k] == 0) idx[cnt[w.vis_j[k]]++] = k;
+                }
                 for (size_t p = 0; p < idx.size();) {
                     size_t q = p;
                     while (q < idx.size() && w.vis_j[idx[q]] == w.vis_j[idx[p]]) ord[no++] = (w.vis_j[idx[p]] << 16) | idx[q++];   // pair (0, j)
