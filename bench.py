@@ -154,6 +154,7 @@ def pmc_summary():
 
 
 _E2E_INPUTS = {}
+_E2E_STAGED = {}
 
 
 def e2e_inputs(n_streams, dev):
@@ -194,9 +195,8 @@ def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False, 
     tracker's own output; as in the reference the tracker (sync_process thread) and the estimators (processThread) run concurrently, one frame apart.  Returns
     window-solves/s over the frames on which all windows are live (NON_LINEAR): wall-clock including the tracker, host bookkeeping, uploads and downloads,
     excluding only the Python loop that hands the IMU / wheel samples to the members.
-    n_groups > 1: the sequences are split over that many estimator groups (gf_estimator_group_*: own back-end handle, own stream, own worker threads), stepped from
-    one thread each: while one group's batch is on the GPU the other group's members do their host work, so host and device phases of a frame overlap."""
-    import ctypes as C
+    n_groups > 1: the sequences are split over that many estimator groups (gf_estimator_group_*: own back-end handle, own stream, own worker threads): while one
+    group's batch is on the GPU the other group's members do their host work, so host and device phases of a frame overlap."""
     import synth_stream as SS
     streams, gray, depth = e2e_inputs(n_streams, dev)
     st0 = streams[0]
@@ -205,46 +205,55 @@ def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False, 
     grps = [gfamd.EstimatorGroup(cfg, bounds[q + 1] - bounds[q], device_preint=device_preint, device_sweeps=device_sweeps) for q in range(n_groups)]
     members = [m for g_ in grps for m in g_.members]
     trk = gfamd.FeatureTracker(gfamd.default_cfg(batch=nseq, max_cnt=max_cnt, min_dist=min_dist))
-    assign = torch.arange(nseq, device=dev) % n_streams
-    import threading
-    state = {"threads": [], "err": None}
+    # every camera frame of every sequence resident in HBM before the clock starts (the contract of `value`: inputs already on the device), dealt to the sequences
+    key = (n_streams, nseq)
+    if key not in _E2E_STAGED:
+        assign = torch.arange(nseq, device=dev) % n_streams
+        _E2E_STAGED.clear()            # one staged set at a time (~0.9 MB per sequence and frame)
+        torch.cuda.empty_cache()
+        _E2E_STAGED[key] = ([gray[k].index_select(0, assign) for k in range(len(gray))], [depth[k].index_select(0, assign) for k in range(len(depth))])
+    sgray, sdepth = _E2E_STAGED[key]
+    torch.cuda.synchronize()
+    seqs = [np.arange(bounds[q + 1] - bounds[q], dtype=np.int32) for q in range(n_groups)]
+    obs_bufs, obs_at = None, 0      # the frame the estimators work on: a copy of the tracker's padded output table (the tracker reuses its own while they run);
+    #                                 two of them, so that the next frame is copied while the estimators still read the previous one
 
-    def group_step(q, tk, obs, no):   # inputFeature -> processImage -> solve -> marginalise of group q's sequences (the reference's processThread, estimator.cpp:209)
-        try:
-            cnt = bounds[q + 1] - bounds[q]
-            sq = np.arange(cnt, dtype=np.int32)
-            tt = np.full(cnt, tk)
-            o0 = int(no[:bounds[q]].sum())
-            gfamd._chk(gfamd.lib().gf_estimator_group_input_features(grps[q].g, cnt, sq.ctypes.data_as(C.POINTER(C.c_int)), tt.ctypes.data_as(C.POINTER(C.c_double)),
-                                                                     C.c_void_p(obs.ctypes.data + o0 * obs.itemsize), no[bounds[q]:].ctypes.data_as(C.POINTER(C.c_int))))
-        except Exception as e:   # noqa: BLE001
-            state["err"] = e
+    def submit(tk, n, obs_buf):   # inputFeature of every sequence (returns at once; the members' processMeasurements run on the group's workers: estimator.cpp:209, :447-459)
+        for q in range(n_groups):
+            lo, hi = bounds[q], bounds[q + 1]
+            grps[q].submitFeatures(seqs[q], np.full(hi - lo, tk), obs_buf[lo:hi], n[lo:hi], stride=obs_buf.shape[1])
 
     def join():
-        for th in state["threads"]:
-            th.join()
-        state["threads"] = []
-        if state["err"] is not None:
-            raise state["err"]
+        for g_ in grps:
+            g_.wait()
 
     tp, solves, frames_live, t_feed_live = [-1.0] * n_streams, 0, 0, 0.0
     live, t_start = False, None
     steps_live = mixed = keyframe_votes = votes = 0
+    clk = {"tracker": 0.0, "observations": 0.0, "wait_for_estimators": 0.0, "bookkeeping": 0.0}   # where the main thread's wall time goes while live [s]
+    pc = time.perf_counter
     for k in range(len(st0.cam_t)):
-        g = gray[k].index_select(0, assign) if n_streams > 1 else gray[k].expand(nseq, -1, -1).contiguous()
-        d = depth[k].index_select(0, assign) if n_streams > 1 else depth[k].expand(nseq, -1, -1).contiguous()
-        torch.cuda.synchronize()
+        c1 = pc()
         # the tracker of this frame runs while the estimators still work on the previous back-end frame (separate threads in the reference too: rosNodeTest.cpp:713)
-        n = trk.trackImageBatchDevice([float(st0.cam_t[k])] * nseq, g.data_ptr(), d.data_ptr(), unpack=False)
+        n = trk.trackImageBatchDevice([float(st0.cam_t[k])] * nseq, sgray[k].data_ptr(), sdepth[k].data_ptr(), unpack=False)
+        c2 = pc()
+        if live:
+            clk["tracker"] += c2 - c1
         if k % 2 == 0:
-            out = trk._out
-            obs = np.ascontiguousarray(out[np.arange(out.shape[1])[None, :] < n[:, None]])   # per-sequence frames back to back (a copy: the tracker reuses its buffer)
+            if obs_bufs is None:
+                obs_bufs = [np.empty_like(trk._out), np.empty_like(trk._out)]
+            obs_at ^= 1
+            np.copyto(obs_bufs[obs_at], trk._out)
             no = np.ascontiguousarray(n, np.int32).copy()
+            c3 = pc()
             join()
-            reps = [members[q].state() for q in range(n_streams)]        # one representative per recording
-            now_live = all(r["solver_flag"] == 1 for r in reps)
+            c4 = pc()
+            if live:
+                clk["observations"] += c3 - c2; clk["wait_for_estimators"] += c4 - c3
+            reps = [members[q].flags() for q in range(n_streams)]        # one representative per recording: (frame_count, solver_flag, marginalization_flag)
+            now_live = all(r[1] == 1 for r in reps)
             if live:          # the decisions of the step that just finished
-                flags = [r["marginalization_flag"] for r in reps]
+                flags = [r[2] for r in reps]
                 steps_live += 1; mixed += int(len(set(flags)) > 1); keyframe_votes += sum(1 for f in flags if f == 0); votes += len(flags)
             if now_live and not live:
                 live, t_start = True, time.perf_counter()
@@ -255,14 +264,18 @@ def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False, 
                     for b, m in enumerate(members):
                         t1[b % n_streams] = streams[b % n_streams].feed(m, kk, tp[b % n_streams])
                     tp = t1
+            c5 = pc()
             if live:
-                t_feed_live += time.perf_counter() - t0
+                t_feed_live += c5 - t0
                 solves += nseq
                 frames_live += 2
-            state["threads"] = [threading.Thread(target=group_step, args=(q, float(st0.cam_t[k]), obs, no)) for q in range(n_groups)]
-            for th in state["threads"]:
-                th.start()
+            submit(float(st0.cam_t[k]), no, obs_bufs[obs_at])
+            if live:
+                clk["bookkeeping"] += (t0 - c4) + (pc() - c5)
     join()
+    ts_ = trk.stats()
+    calls_ = max(len(st0.cam_t), 1)
+    trk_anatomy = {k_: round(ts_[k_] / calls_, 3) for k_ in ("ms_host_pre", "ms_wait_lk", "ms_host_mid", "ms_wait_detect", "ms_host_post", "ms_total_gpu") if k_ in ts_}
     t_live = (time.perf_counter() - t_start - t_feed_live) if t_start is not None else 0.0
     stts = [g_.stats() for g_ in grps]
     stt = {"batches": sum(s_["batches"] for s_ in stts), "largest_batch": max(s_["largest_batch"] for s_ in stts)}
@@ -274,6 +287,8 @@ def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False, 
             "wall_s": t_live, "ms_per_backend_frame": 1e3 * t_live / max(solves // max(nseq, 1), 1), "group_batches": stt["batches"], "largest_batch": stt["largest_batch"],
             "backend_frames_with_mixed_decisions": mixed, "backend_frames_live": steps_live, "keyframe_vote_share": keyframe_votes / max(votes, 1),
             "newest_position_norm_m": pos, "device_preint": bool(device_preint),
+            "host_hardware_threads": os.cpu_count(), "tracker_ms_per_call": trk_anatomy,
+            "main_thread_ms_per_backend_frame": {k_: round(1e3 * v_ / max(solves // max(nseq, 1), 1), 3) for k_, v_ in clk.items()},
             "path": "gf_tracker_track_batch_device -> gf_estimator_group_input_features (inputFeature -> processImage -> gf_ba solve + marginalise, "
                     "windows packed / uploaded / downloaded every frame)"}
 

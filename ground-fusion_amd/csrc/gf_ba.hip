@@ -34,6 +34,7 @@ namespace {
 std::atomic<long long> g_up_bytes{0}, g_up_calls{0};   // host -> device traffic of this process (GF_GROUP_TIMING prints it)
 template <class T> struct Buf {  // device buffer + pinned host mirror
     T* d = nullptr; T* h = nullptr; size_t n = 0;
+    T* hd = nullptr;   // the host mirror as kernels address it (page-locked memory is mapped into the device's address space), or null
     int alloc(size_t count, bool host) {
         n = count;
         if (hipMalloc((void**)&d, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipMalloc(%zu B) failed", count * sizeof(T));
@@ -51,7 +52,8 @@ template <class T> struct Buf {  // device buffer + pinned host mirror
         }
         // (hipMemset runs on the null stream and the handle's stream is non-blocking: finished here, before anybody can enqueue a copy into the buffer)
         if (hipMemset(d, bad ? 0x5A : 0, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipMemset failed");
-        if (host) { if (hipHostMalloc((void**)&h, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipHostMalloc failed"); memset(h, 0, std::max<size_t>(count, 1) * sizeof(T)); }
+        if (host) { if (hipHostMalloc((void**)&h, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipHostMalloc failed"); memset(h, 0, std::max<size_t>(count, 1) * sizeof(T));
+            void* p = nullptr; hd = hipHostGetDevicePointer(&p, h, 0) == hipSuccess ? static_cast<T*>(p) : nullptr; (void)hipGetLastError(); }
         return GF_OK;
     }
     void release() { if (d) (void)hipFree(d); if (h) (void)hipHostFree(h); d = nullptr; h = nullptr; }
@@ -80,6 +82,57 @@ __global__ void ba_imu_patch(double* tab, const double* patch, const int* pinfo,
     for (int q = 0; q < pi[1]; q++)
         for (int i = tid; i < IMU_STRIDE2; i += 256) t[(size_t)pi[2 + q] * IMU_STRIDE2 + i] = p[(size_t)q * IMU_STRIDE2 + i];
 }
+
+// ---- the upload as ONE kernel (GF_BA_UPLOAD=kernel): every table of a batch is a descriptor (rows x used bytes out of a pitch), the kernel reads the page-locked
+// host mirrors over the bus and writes the device tables.  Forty hipMemcpy(2D)Async calls of 4 KB .. 8 MB each cost more in submission and per-copy latency than
+// their 20 MB cost on the wire; a kernel with 1024 blocks in flight keeps the link busy from its first to its last byte.
+struct UpDesc { const char* src; char* dst; unsigned pitch, used, rows, esize, blk0, nblk; };
+constexpr int kUpMax = 56, kUpBlocks = 1024;
+struct UpList { UpDesc e[kUpMax]; int n; };
+template <class V> __device__ __forceinline__ void up_units(const UpDesc& D, unsigned blk) {
+    const unsigned upr = D.used / sizeof(V);
+    const size_t total = (size_t)upr * D.rows, stride = (size_t)D.nblk * 256;
+    size_t u = (size_t)blk * 256 + threadIdx.x;
+    for (; u + 3 * stride < total; u += 4 * stride) {   // four loads in flight per lane before the first store
+        V v[4]; size_t off[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const size_t uu = u + q * stride; const unsigned row = (unsigned)(uu / upr); off[q] = (size_t)row * D.pitch + (uu - (size_t)row * upr) * sizeof(V); v[q] = *reinterpret_cast<const V*>(D.src + off[q]); }
+#pragma unroll
+        for (int q = 0; q < 4; q++) *reinterpret_cast<V*>(D.dst + off[q]) = v[q];
+    }
+    for (; u < total; u += stride) { const unsigned row = (unsigned)(u / upr); const size_t off = (size_t)row * D.pitch + (u - (size_t)row * upr) * sizeof(V); *reinterpret_cast<V*>(D.dst + off) = *reinterpret_cast<const V*>(D.src + off); }
+}
+__global__ void __launch_bounds__(256) ba_gather_upload(UpList L) {
+    int k = 0;
+    while (k + 1 < L.n && blockIdx.x >= L.e[k + 1].blk0) k++;
+    const UpDesc& D = L.e[k];
+    if (D.esize == 16) up_units<uint4>(D, blockIdx.x - D.blk0);
+    else if (D.esize == 8) up_units<uint2>(D, blockIdx.x - D.blk0);
+    else up_units<unsigned>(D, blockIdx.x - D.blk0);
+}
+struct UpBuilder {
+    UpList L{}; bool ok = true;
+    // rows x `used` elements of `pitch`; host pointer as the device sees it
+    template <class T> void add(const Buf<T>& b, size_t rows, size_t pitch, size_t used) {
+        if (used == 0 || rows == 0) return;
+        if (used >= pitch) { used = pitch * rows; pitch = used; rows = 1; }
+        if (!b.hd || L.n >= kUpMax || used * sizeof(T) >= (1ull << 32) || pitch * sizeof(T) >= (1ull << 32)) { ok = false; return; }
+        UpDesc& D = L.e[L.n++];
+        D.src = reinterpret_cast<const char*>(b.hd); D.dst = reinterpret_cast<char*>(b.d); D.pitch = (unsigned)(pitch * sizeof(T)); D.used = (unsigned)(used * sizeof(T)); D.rows = (unsigned)rows;
+        const size_t al = (size_t)D.pitch | D.used | (size_t)(uintptr_t)D.src | (size_t)(uintptr_t)D.dst;
+        D.esize = al % 16 == 0 ? 16 : al % 8 == 0 ? 8 : 4;
+        g_up_bytes += (long long)D.used * D.rows;
+    }
+    template <class T> void all(const Buf<T>& b) { add(b, 1, b.n, b.n); }
+    void finish() {   // blocks in proportion to the bytes, at least one each
+        double total = 0;
+        for (int k = 0; k < L.n; k++) total += (double)L.e[k].used * L.e[k].rows;
+        unsigned at = 0;
+        for (int k = 0; k < L.n; k++) { UpDesc& D = L.e[k]; D.blk0 = at; D.nblk = std::max(1u, (unsigned)((double)D.used * D.rows / std::max(total, 1.0) * kUpBlocks)); at += D.nblk; }
+        nblocks = at;
+    }
+    unsigned nblocks = 0;
+};
 
 struct gf_ba {
     gf_ba_cfg cfg;
@@ -135,6 +188,7 @@ struct gf_ba {
     int max_imu_dirty = 0;
     bool all_pri_res = false, any_pri_res = false, outJ_host_stale = false;
     int step_waves = 8;
+    bool upload_kernel = true;
     bool pos_ident = false;
     bool split_jtj = false, split_timed = false;   // gf_ba_set_split_jtj: the visual sweep as two kernels (block rows through HBM, contraction-only MFMA kernel)
     Buf<double> vrows, vpair; hipEvent_t ev_split[2] = {nullptr, nullptr};
@@ -501,23 +555,60 @@ int upload(gf_ba* h) {
     static const bool dbg = getenv("GF_BA_UPLOAD_DEBUG") != nullptr;
     long long mark = g_up_bytes; int stage = 0;
     auto lapb = [&](const char* what) { if (dbg) { fprintf(stderr, "upload %d %-28s %8.2f MB\n", stage++, what, (g_up_bytes - mark) / 1e6); mark = g_up_bytes; } };
-    HIPCHK(h->xs0.up(s)); lapb("xs0");
+    // every table either as a copy of its own or as a descriptor of the one gather kernel (h->upload_kernel)
+    UpBuilder U;
+    const bool ker = h->upload_kernel;
+    hipError_t err = hipSuccess;
+    auto up1 = [&](auto& b) { if (ker) U.all(b); else if (err == hipSuccess) err = b.up(s); };
+    auto up2 = [&](auto& b, size_t rows, size_t pitch, size_t used) { if (ker) U.add(b, rows, pitch, used); else if (err == hipSuccess) err = b.up2d(s, rows, pitch, used); };
+    up1(h->xs0); lapb("xs0");
     const size_t nf = (size_t)std::max(h->max_feat, 1);
-    for (auto* b : {&h->colf, &h->nvis, &h->nimu, &h->nwh, &h->nfeat, &h->norder, &h->imu_i, &h->wh_i, &h->pri_n, &h->pri_nb, &h->pri_bid})
-        HIPCHK(b->up(s));
-    HIPCHK(h->cole.up2d(s, B, d.F, (size_t)d.F));   // whole rows: entries beyond n_feature are -1 markers the kernels rely on
-    HIPCHK(h->feat_ptr.up2d(s, B, (size_t)d.F + 1, (size_t)d.F + 1)); lapb("small tables, cole, feat_ptr");
+    for (auto* b : {&h->colf, &h->nvis, &h->nimu, &h->nwh, &h->nfeat, &h->norder, &h->imu_i, &h->wh_i, &h->pri_n, &h->pri_nb, &h->pri_bid}) up1(*b);
+    up2(h->cole, B, d.F, (size_t)d.F);   // whole rows: entries beyond n_feature are -1 markers the kernels rely on
+    up2(h->feat_ptr, B, (size_t)d.F + 1, (size_t)d.F + 1); lapb("small tables, cole, feat_ptr");
     // per-window tables are laid out for the handle's capacity; only what this batch fills is copied
-    HIPCHK(h->vis_idx.up2d(s, B, d.NV, nv));
+    up2(h->vis_idx, B, d.NV, nv);
     h->pos_ident = true;   // over every slot's last pack (slots that sit a batch out keep their tables)
     for (const gf_ba::SlotMeta& M : h->meta) h->pos_ident &= M.pos_ident;
-    if (!h->pos_ident) HIPCHK(h->vis_pos.up2d(s, B, d.NV, nv));
+    if (!h->pos_ident) up2(h->vis_pos, B, d.NV, nv);
     lapb("vis int tables x2");
-    HIPCHK(h->order.up2d(s, B, d.NVP, no)); lapb("order");
-    HIPCHK(h->vis_data.up2d(s, B, (size_t)d.NV * 5, nv * 5));
-    HIPCHK(h->feat_obs.up2d(s, B, (size_t)d.F * 6, nf * 6)); lapb("vis_data + feat_obs");
-    if (!h->any_pri_res) HIPCHK(h->pri_J.up2d(s, B, (size_t)d.NPRI * d.NPRI, np2));
-    else if (!h->all_pri_res)   // mixed batch: only the active slots that brought a host prior; a slot that sits this batch out keeps what the device holds (its host mirror was never written)
+    up2(h->order, B, d.NVP, no); lapb("order");
+    up2(h->vis_data, B, (size_t)d.NV * 5, nv * 5);
+    up2(h->feat_obs, B, (size_t)d.F * 6, nf * 6); lapb("vis_data + feat_obs");
+    if (!h->any_pri_res) up2(h->pri_J, B, (size_t)d.NPRI * d.NPRI, np2);
+    bool imu_patched = false;
+    {   // IMU tables: everything when many rows are new (first frames, whole-batch uploads), else the new rows + one small kernel that moves / patches the slots' tables
+        bool all_dev = true;
+        for (int b : h->active) all_dev &= h->imu_dev[b] == 2;
+        if (all_dev && (int)h->active.size() == d.B && h->max_imu_dirty <= d.W / 2) {
+            if (h->max_imu_dirty > 0) up2(h->imu_patch, B, (size_t)d.W * IMU_STRIDE2, (size_t)h->max_imu_dirty * IMU_STRIDE2);
+            up1(h->imu_pinfo);
+            imu_patched = true;
+        } else up1(h->imu_data);
+    }
+    for (auto* b : {&h->wh_data, &h->pri_r, &h->pri_x0, &h->wpar}) up1(*b);
+    lapb("imu, wheel, pri_r, pri_x0, wpar");
+    if (h->d.GO) { up1(h->ngnss); up1(h->gn_idx); up1(h->gn_data); up1(h->gn_misc); up1(h->gn_gptr); up1(h->gn_gitem); }
+    for (int m = 0; m < 2; m++) {
+        for (auto* b : {&h->mcolf[m], &h->mcole[m], &h->mnorder[m], &h->minfo[m]}) up1(*b);
+        {   // the marginalisation's factor order: only as far as this layout fills it (MARGIN_OLD: the factors of the features that start at frame 0; MARGIN_SECOND_NEW: none)
+            size_t mo = 0;
+            for (const gf_ba::SlotMeta& M : h->meta) mo = std::max(mo, (size_t)M.mno[m]);
+            up2(h->morder[m], B, d.NVP, mo);
+        }
+    }
+    lapb("gnss + marg layouts");
+    up1(h->st0);
+    HIPCHK(err);
+    if (ker) {
+        if (!U.ok) return gf::set_err(GF_ERR_HIP, "upload kernel: a host mirror is not mapped into the device's address space, or too many / too large tables (GF_BA_UPLOAD=copies selects the copy path)");
+        U.finish();
+        g_up_calls++;
+        ba_gather_upload<<<dim3(U.nblocks), 256, 0, s>>>(U.L);
+        HIPCHK(hipGetLastError());
+    }
+    // priors: host tables of the slots that brought one (mixed batches), device-resident ones straight from the marginalisation's output
+    if (h->any_pri_res && !h->all_pri_res)   // mixed batch: only the active slots that brought a host prior; a slot that sits this batch out keeps what the device holds (its host mirror was never written)
         for (int b : h->active) if (!h->meta[b].pri_res && h->meta[b].npri > 0)
             HIPCHK(hipMemcpyAsync(h->pri_J.d + (size_t)b * d.NPRI * d.NPRI, h->pri_J.h + (size_t)b * d.NPRI * d.NPRI, (size_t)h->meta[b].npri * h->meta[b].npri * 8, hipMemcpyHostToDevice, s));
     if (h->any_pri_res) {   // device-resident priors: marginalisation output -> prior table, without the round trip through the host
@@ -526,30 +617,11 @@ int upload(gf_ba* h) {
         else for (int b : h->active) if (h->meta[b].pri_res) HIPCHK(hipMemcpyAsync(h->pri_J.d + (size_t)b * d.NPRI * d.NPRI, h->outJ.d + (size_t)b * d.NPRI * d.NPRI, (size_t)h->meta[b].npri * h->meta[b].npri * 8, hipMemcpyDeviceToDevice, s));
     }
     lapb("pri_J");
-    {   // IMU tables: everything when many rows are new (first frames, whole-batch uploads), else the new rows + one small kernel that moves / patches the slots' tables
-        bool all_dev = true;
-        for (int b : h->active) all_dev &= h->imu_dev[b] == 2;
-        if (all_dev && (int)h->active.size() == d.B && h->max_imu_dirty <= d.W / 2) {
-            if (h->max_imu_dirty > 0) HIPCHK(h->imu_patch.up2d(s, B, (size_t)d.W * IMU_STRIDE2, (size_t)h->max_imu_dirty * IMU_STRIDE2));
-            HIPCHK(h->imu_pinfo.up(s));
-            ba_imu_patch<<<dim3(d.B), 256, 0, s>>>(h->imu_data.d, h->imu_patch.d, h->imu_pinfo.d, d.W);
-            HIPCHK(hipGetLastError());
-        } else HIPCHK(h->imu_data.up(s));
-        for (int b = 0; b < d.B; b++) h->imu_dev[b] = 1;   // set only here, behind a successful copy: the full upload covers every slot with its mirror; the patch path required state 2 of every slot
+    if (imu_patched) {
+        ba_imu_patch<<<dim3(d.B), 256, 0, s>>>(h->imu_data.d, h->imu_patch.d, h->imu_pinfo.d, d.W);
+        HIPCHK(hipGetLastError());
     }
-    for (auto* b : {&h->wh_data, &h->pri_r, &h->pri_x0, &h->wpar}) HIPCHK(b->up(s));
-    lapb("imu, wheel, pri_r, pri_x0, wpar");
-    if (h->d.GO) { HIPCHK(h->ngnss.up(s)); HIPCHK(h->gn_idx.up(s)); HIPCHK(h->gn_data.up(s)); HIPCHK(h->gn_misc.up(s)); HIPCHK(h->gn_gptr.up(s)); HIPCHK(h->gn_gitem.up(s)); }
-    for (int m = 0; m < 2; m++) {
-        for (auto* b : {&h->mcolf[m], &h->mcole[m], &h->mnorder[m], &h->minfo[m]}) HIPCHK(b->up(s));
-        {   // the marginalisation's factor order: only as far as this layout fills it (MARGIN_OLD: the factors of the features that start at frame 0; MARGIN_SECOND_NEW: none)
-            size_t mo = 0;
-            for (const gf_ba::SlotMeta& M : h->meta) mo = std::max(mo, (size_t)M.mno[m]);
-            HIPCHK(h->morder[m].up2d(s, B, d.NVP, mo));
-        }
-    }
-    lapb("gnss + marg layouts");
-    HIPCHK(hipMemcpyAsync(h->st0.d, h->st0.h, h->st0.n * sizeof(SolverState), hipMemcpyHostToDevice, s));
+    for (int b = 0; b < d.B; b++) h->imu_dev[b] = 1;   // set only here, behind a successful copy: the full upload covers every slot with its mirror; the patch path required state 2 of every slot
     ba_setup<<<dim3(h->d.B), 256, 0, s>>>(h->win());
     HIPCHK(hipGetLastError());
     return GF_OK;
@@ -752,6 +824,9 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
         h->release(); delete h; return gf::set_err(GF_ERR_HIP, "allocation of solver state failed");
     }
     h->st.n = h->st0.n = B;
+    { void* p = nullptr; h->st0.hd = hipHostGetDevicePointer(&p, h->st0.h, 0) == hipSuccess ? static_cast<SolverState*>(p) : nullptr; (void)hipGetLastError(); }
+    // GF_BA_UPLOAD=kernel | copies: a batch's tables through one gather kernel that reads the page-locked mirrors over the bus, or one hipMemcpy(2D)Async per table
+    h->upload_kernel = !(getenv("GF_BA_UPLOAD") && !strcmp(getenv("GF_BA_UPLOAD"), "copies"));
     A_(h->imu_sqrt.alloc(B * d.W * 225, false)); A_(h->wh_sqrt.alloc(B * d.W * 36, false)); A_(h->pri_A.alloc(B * d.NPRI * d.NPRI, false)); A_(h->pri_b.alloc(B * d.NPRI, false));
     A_(h->pri_c.alloc(B, false)); A_(h->H.alloc(2 * B * d.RP * d.RP, true)); A_(h->g.alloc(2 * B * d.RP, true)); A_(h->Vc.alloc(2 * B * d.NVC, true)); A_(h->wpar.alloc(B * WPAR, true));
     A_(h->cost.alloc(6 * B, true)); A_(h->efac.alloc(B * d.NV * EF, false));

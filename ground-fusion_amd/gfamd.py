@@ -687,6 +687,12 @@ class SlidingWindowEstimator:
                  final_cost=extr[30], last_average_parallax=extr[31])
         return d
 
+    def flags(self):
+        """(frame_count, solver_flag, marginalization_flag) without the window's states"""
+        info = np.zeros(16, np.int32)
+        _chk(lib().gf_estimator_get_state(self.h, None, None, None, None, None, None, _p(info, C.c_int), None))
+        return int(info[0]), int(info[1]), int(info[2])
+
     def set_state(self, frame_count, solver_flag, Ps=None, Rs=None, Vs=None, Bas=None, Bgs=None):
         f = lambda a: None if a is None else _p(np.ascontiguousarray(a, np.float64), C.c_double)
         keep = [np.ascontiguousarray(a, np.float64) if a is not None else None for a in (Ps, Rs, Vs, Bas, Bgs)]
@@ -807,6 +813,21 @@ class EstimatorGroup:
         tt = np.ascontiguousarray(ts, np.float64)
         no = np.ascontiguousarray([len(im) for im in images], np.int32)
         _chk(lib().gf_estimator_group_input_features(self.g, len(sq), _p(sq, C.c_int), _p(tt, C.c_double), obs, _p(no, C.c_int)))
+
+    def submitFeatures(self, seqs, ts, obs, n_obs, stride=-1):
+        """inputFeature's first half (estimator.cpp:447-459): hand the frames to the group's workers and return.  obs: OBS_DTYPE array, either the frames back to
+        back (stride < 0) or a tracker's padded table [len(seqs)][stride]; the arrays are kept alive until wait()."""
+        sq = np.ascontiguousarray(seqs, np.int32)
+        tt = np.ascontiguousarray(ts, np.float64)
+        no = np.ascontiguousarray(n_obs, np.int32)
+        _chk(lib().gf_estimator_group_submit_features(self.g, len(sq), _p(sq, C.c_int), _p(tt, C.c_double), C.c_void_p(obs.ctypes.data), _p(no, C.c_int), C.c_longlong(stride)))
+        self._flight = (sq, tt, no, obs)
+
+    def wait(self):
+        try:
+            _chk(lib().gf_estimator_group_wait(self.g))
+        finally:
+            self._flight = None
 
     def stats(self):
         b, w, l = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)

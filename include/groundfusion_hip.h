@@ -460,6 +460,13 @@ int gf_estimator_group_set_device_sweeps(gf_estimator_group* g, int on);
 int gf_estimator_group_member(gf_estimator_group* g, int i, gf_estimator** out);   /* owned by the group */
 /* Estimator::inputFeature on each listed sequence, concurrently; obs = the frames back to back, n_obs[k] entries for seq[k] */
 int gf_estimator_group_input_features(gf_estimator_group* g, int count, const int* seq, const double* t, const gf_feature_obs* obs, const int* n_obs);
+/* The same step in two halves, as in the reference: Estimator::inputFeature only queues the frame (estimator.cpp:447-459) and processMeasurements works on it in
+ * its own thread (estimator.cpp:470-560) while the tracker already handles the next image.  submit publishes the frames to the group's workers and returns;
+ * wait blocks until every listed member has finished its frame and reports the first member's error.  stride >= 0: the observations of seq[k] start at
+ * obs + k * stride (a tracker's padded output table as it lies: gf_tracker_track_batch*'s `out` with stride = its capacity); < 0: back to back.
+ * obs / seq / n_obs stay the caller's until wait returns; one step in flight per group. */
+int gf_estimator_group_submit_features(gf_estimator_group* g, int count, const int* seq, const double* t, const gf_feature_obs* obs, const int* n_obs, long long stride);
+int gf_estimator_group_wait(gf_estimator_group* g);
 int gf_estimator_group_stats(gf_estimator_group* g, long long* batches, long long* windows, long long* largest_batch);
 
 /* ---- ROS-free I/O around the path: config files, trajectory output, raw frames ---------------------------------------- */

@@ -289,6 +289,59 @@ def test_group_of_sequences_on_one_batched_solver(device_preint, group_threads, 
         e.close()
 
 
+def test_group_submit_and_wait_on_a_padded_table():
+    """gf_estimator_group_submit_features / _wait: inputFeature's two halves (estimator.cpp:447-459 queues the frame, processMeasurements works on it) with the
+    observations taken from a padded table as a batched tracker leaves it (stride = its capacity).  Same bits as gf_estimator_group_input_features on the frames
+    back to back; a second submit before the wait, and a frame longer than the stride, are refused without touching the step in flight."""
+    n, cap = 3, 160
+    streams = []
+    for s in range(n):
+        st = SS.Stream(11 + s, t_still=1.5, t_move=1.2, v_max=0.4, yaw0=0.0, yaw_turn=0.3 - 0.3 * s, split_x=1.8, turn_delay=0.6)
+        st._lm = st._landmarks(900)
+        st._pn = np.random.default_rng(5200 + s).normal(0, 1.0, (len(st.cam_t), len(st._lm), 2))
+        streams.append(st)
+    cfg = gfamd.default_estimator_cfg(tio=SS.TIO, rio=SS.RIO, multiple_thread=1)
+    ga, gb = gfamd.EstimatorGroup(cfg, n), gfamd.EstimatorGroup(cfg, n)
+    tp = [-1.0] * n
+    nk = min(len(st.cam_t) for st in streams)
+    refused = 0
+    for k in range(nk):
+        for s, st in enumerate(streams):
+            st.feed(ga.members[s], k, tp[s])
+            tp[s] = st.feed(gb.members[s], k, tp[s])
+        if k % 2:
+            continue
+        frames = [st.feature_frame(k) for st in streams]
+        ts = [float(st.cam_t[k]) for st in streams]
+        ga.inputFeatures(list(range(n)), ts, frames)
+        table = np.zeros((n, cap), gfamd.OBS_DTYPE)
+        table["id"] = -7                      # what lies beyond a frame's count is never looked at
+        cnt = np.zeros(n, np.int32)
+        for s, im in enumerate(frames):
+            ids = sorted(im)[:cap]
+            cnt[s] = len(ids)
+            table["id"][s, :len(ids)] = ids
+            table["v"][s, :len(ids)] = np.array([np.asarray(im[i], np.float64).reshape(-1)[:8] for i in ids]).reshape(len(ids), 8)
+            assert len(ids) == len(im)
+        gb.submitFeatures(np.arange(n), ts, table, cnt, stride=cap)
+        if k == 4:
+            with pytest.raises(gfamd.GfError, match="in flight"):
+                gb.submitFeatures(np.arange(n), ts, table, cnt, stride=cap)
+            refused += 1
+        gb.wait()
+        gb.wait()                             # nothing in flight: returns at once
+        for s in range(n):
+            a, b = ga.members[s].state(), gb.members[s].state()
+            assert (a["frame_count"], a["solver_flag"], a["marginalization_flag"], a["iterations"]) == (b["frame_count"], b["solver_flag"], b["marginalization_flag"], b["iterations"]), (k, s)
+            assert np.array_equal(a["Ps"], b["Ps"]) and np.array_equal(a["Rs"], b["Rs"]) and np.array_equal(a["Vs"], b["Vs"]), (k, s)
+            assert gb.members[s].flags() == (b["frame_count"], b["solver_flag"], b["marginalization_flag"])
+    assert refused == 1 and all(m.flags()[1] == 1 for m in gb.members)
+    with pytest.raises(gfamd.GfError, match="stride"):
+        gb.submitFeatures(np.arange(n), ts, table, np.full(n, cap + 1, np.int32), stride=cap)
+    gb.wait()
+    ga.close(); gb.close()
+
+
 def test_group_at_the_largest_configuration_w20_500_features(monkeypatch):
     """BASELINE.json configs[4]'s size as group members (round-3 advisor): 20-frame windows with up to 500 tracked features each run whole frames -- window build,
     pack_slot of ~9 000 visual factors, initialStructure, the batched launches of whoever closes a rendezvous -- on the members' fiber stacks (GF_GROUP_STACK_KB,
