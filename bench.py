@@ -188,21 +188,30 @@ def e2e_inputs(n_streams, dev):
     return _E2E_INPUTS[n_streams]
 
 
-def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False, device_sweeps=False, n_streams=1, n_groups=1):
+def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False, device_sweeps=False, n_streams=1, n_groups=1, stagger=True):
     """The drop-in path on a bounded sample: `nseq` sequences -- `n_streams` distinct seeded recordings dealt round-robin (1: one recording replicated, every
     member takes the same decisions; 8: staggered starts, mixed batches) -- through the batched tracker (trackImage on every camera frame) and gf_estimator_group_*
     (inputFeature -> processImage -> batched solve + marginalisation on every second frame, the reference's MULTIPLE_THREAD flow): the back end is fed by the
     tracker's own output; as in the reference the tracker (sync_process thread) and the estimators (processThread) run concurrently, one frame apart.  Returns
     window-solves/s over the frames on which all windows are live (NON_LINEAR): wall-clock including the tracker, host bookkeeping, uploads and downloads,
     excluding only the Python loop that hands the IMU / wheel samples to the members.
-    n_groups > 1: the sequences are split over that many estimator groups (gf_estimator_group_*: own back-end handle, own stream, own worker threads): while one
-    group's batch is on the GPU the other group's members do their host work, so host and device phases of a frame overlap."""
+    n_groups > 1: the sequences are split over that many estimator groups (gf_estimator_group_*: own back-end handle, own stream, own worker threads).  With
+    `stagger` the groups alternate in which of every two camera frames is "the second one" (inputImageCnt % 2, estimator.cpp:420-428: a sequence that started one
+    frame later) -- every sequence still hands every second frame of its own recording to its back end, but one group's host phase falls on the other group's batch."""
     import synth_stream as SS
     streams, gray, depth = e2e_inputs(n_streams, dev)
     st0 = streams[0]
     cfg = gfamd.default_estimator_cfg(tio=SS.TIO, rio=SS.RIO, multiple_thread=1)
     bounds = [nseq * q // n_groups for q in range(n_groups + 1)]
+    # the library gives ONE group half of this rank's hardware threads as workers; several groups of one process share that half (measured at two groups on 256
+    # hardware threads: 64 workers each 70.6 k window-solves/s, 96 each 68.3 k, 128 each 55 k)
+    own_env = n_groups > 1 and "GF_GROUP_THREADS" not in os.environ
+    if own_env:
+        os.environ["GF_GROUP_THREADS"] = str(max(1, (os.cpu_count() or 2) // (2 * n_groups * max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))))
+    workers = os.environ.get("GF_GROUP_THREADS", "library default")
     grps = [gfamd.EstimatorGroup(cfg, bounds[q + 1] - bounds[q], device_preint=device_preint, device_sweeps=device_sweeps) for q in range(n_groups)]
+    if own_env:
+        del os.environ["GF_GROUP_THREADS"]
     members = [m for g_ in grps for m in g_.members]
     trk = gfamd.FeatureTracker(gfamd.default_cfg(batch=nseq, max_cnt=max_cnt, min_dist=min_dist))
     # every camera frame of every sequence resident in HBM before the clock starts (the contract of `value`: inputs already on the device), dealt to the sequences
@@ -214,82 +223,84 @@ def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False, 
         _E2E_STAGED[key] = ([gray[k].index_select(0, assign) for k in range(len(gray))], [depth[k].index_select(0, assign) for k in range(len(depth))])
     sgray, sdepth = _E2E_STAGED[key]
     torch.cuda.synchronize()
-    seqs = [np.arange(bounds[q + 1] - bounds[q], dtype=np.int32) for q in range(n_groups)]
-    obs_bufs, obs_at = None, 0      # the frame the estimators work on: a copy of the tracker's padded output table (the tracker reuses its own while they run);
-    #                                 two of them, so that the next frame is copied while the estimators still read the previous one
-
-    def submit(tk, n, obs_buf):   # inputFeature of every sequence (returns at once; the members' processMeasurements run on the group's workers: estimator.cpp:209, :447-459)
-        for q in range(n_groups):
-            lo, hi = bounds[q], bounds[q + 1]
-            grps[q].submitFeatures(seqs[q], np.full(hi - lo, tk), obs_buf[lo:hi], n[lo:hi], stride=obs_buf.shape[1])
-
-    def join():
-        for g_ in grps:
-            g_.wait()
-
-    tp, solves, frames_live, t_feed_live = [-1.0] * n_streams, 0, 0, 0.0
+    G = range(n_groups)
+    phase = [(q % 2) if stagger else 0 for q in G]          # the camera frames with k % 2 == phase[q] reach group q's back ends
+    seqs = [np.arange(bounds[q + 1] - bounds[q], dtype=np.int32) for q in G]
+    # the tracker writes every frame's padded output table into one of three, the estimators read their rows of it where it lies (no copy): a group holds the table
+    # of frame k until it is waited for behind the tracker call of frame k + 2, which writes the table frame k - 1 used
+    ring = [(np.zeros((nseq, trk.cap), gfamd.OBS_DTYPE), np.zeros(nseq, np.int32)) for _ in range(3)]
+    ts_all = [np.full(nseq, float(t_)) for t_ in st0.cam_t]
+    reps = [[next(b for b in range(bounds[q], bounds[q + 1]) if b % n_streams == s_) for s_ in range(n_streams)] for q in G]   # one member per recording and group
+    tp = [[-1.0] * n_streams for _ in G]
+    fed = [-1] * n_groups                                   # last camera frame whose IMU / wheel samples group q's members hold
+    glive = [False] * n_groups
+    solves, frames_live, t_feed_live = 0, 0, 0.0
     live, t_start = False, None
     steps_live = mixed = keyframe_votes = votes = 0
     clk = {"tracker": 0.0, "observations": 0.0, "wait_for_estimators": 0.0, "bookkeeping": 0.0}   # where the main thread's wall time goes while live [s]
     pc = time.perf_counter
     for k in range(len(st0.cam_t)):
         c1 = pc()
-        # the tracker of this frame runs while the estimators still work on the previous back-end frame (separate threads in the reference too: rosNodeTest.cpp:713)
-        n = trk.trackImageBatchDevice([float(st0.cam_t[k])] * nseq, sgray[k].data_ptr(), sdepth[k].data_ptr(), unpack=False)
+        # the tracker of this frame runs while the estimators still work on earlier back-end frames (separate threads in the reference too: rosNodeTest.cpp:713)
+        tab, n = ring[k % 3]
+        trk.trackImageBatchDevice(ts_all[k], sgray[k].data_ptr(), sdepth[k].data_ptr(), unpack=False, out=tab, n_out=n)
         c2 = pc()
         if live:
             clk["tracker"] += c2 - c1
-        if k % 2 == 0:
-            if obs_bufs is None:
-                obs_bufs = [np.empty_like(trk._out), np.empty_like(trk._out)]
-            obs_at ^= 1
-            np.copyto(obs_bufs[obs_at], trk._out)
-            no = np.ascontiguousarray(n, np.int32).copy()
+            frames_live += 1
+        for q in G:
+            if k % 2 != phase[q]:
+                continue
+            lo, hi = bounds[q], bounds[q + 1]
+            c2 = pc()
+            buf, no = tab[lo:hi], n[lo:hi]
             c3 = pc()
-            join()
+            grps[q].wait()
             c4 = pc()
             if live:
                 clk["observations"] += c3 - c2; clk["wait_for_estimators"] += c4 - c3
-            reps = [members[q].flags() for q in range(n_streams)]        # one representative per recording: (frame_count, solver_flag, marginalization_flag)
-            now_live = all(r[1] == 1 for r in reps)
+            fl = [members[b].flags() for b in reps[q]]        # (frame_count, solver_flag, marginalization_flag) of one member per recording
             if live:          # the decisions of the step that just finished
-                flags = [r[2] for r in reps]
+                flags = [r[2] for r in fl]
                 steps_live += 1; mixed += int(len(set(flags)) > 1); keyframe_votes += sum(1 for f in flags if f == 0); votes += len(flags)
-            if now_live and not live:
-                live, t_start = True, time.perf_counter()
-            t0 = time.perf_counter()
-            for kk in (k - 1, k):          # IMU / wheel samples up to this frame: input marshalling through Python, not part of the measured path
-                if kk >= 0:
-                    t1 = list(tp)
-                    for b, m in enumerate(members):
-                        t1[b % n_streams] = streams[b % n_streams].feed(m, kk, tp[b % n_streams])
-                    tp = t1
+            glive[q] = all(r[1] == 1 for r in fl)
+            if all(glive) and not live:
+                live, t_start = True, pc()
+            t0 = pc()
+            for kk in range(fed[q] + 1, k + 1):          # IMU / wheel samples up to this frame: input marshalling through Python, not part of the measured path
+                t1 = list(tp[q])
+                for b in range(lo, hi):
+                    t1[b % n_streams] = streams[b % n_streams].feed(members[b], kk, tp[q][b % n_streams])
+                tp[q] = t1
+            fed[q] = k
             c5 = pc()
             if live:
                 t_feed_live += c5 - t0
-                solves += nseq
-                frames_live += 2
-            submit(float(st0.cam_t[k]), no, obs_bufs[obs_at])
+                solves += hi - lo
+            grps[q].submitFeatures(seqs[q], ts_all[k][lo:hi], buf, no, stride=buf.shape[1])   # inputFeature of every sequence of the group (returns at once)
             if live:
                 clk["bookkeeping"] += (t0 - c4) + (pc() - c5)
-    join()
+    for g_ in grps:
+        g_.wait()
     ts_ = trk.stats()
     calls_ = max(len(st0.cam_t), 1)
-    trk_anatomy = {k_: round(ts_[k_] / calls_, 3) for k_ in ("ms_host_pre", "ms_wait_lk", "ms_host_mid", "ms_wait_detect", "ms_host_post", "ms_total_gpu") if k_ in ts_}
-    t_live = (time.perf_counter() - t_start - t_feed_live) if t_start is not None else 0.0
+    trk_anatomy = {k_: round(ts_[k_] / calls_, 3) for k_ in ("ms_host_pre", "ms_wait_lk", "ms_host_mid", "ms_wait_detect", "ms_host_post") if k_ in ts_}
+    t_live = (pc() - t_start - t_feed_live) if t_start is not None else 0.0
     stts = [g_.stats() for g_ in grps]
     stt = {"batches": sum(s_["batches"] for s_ in stts), "largest_batch": max(s_["largest_batch"] for s_ in stts)}
     pos = float(np.linalg.norm(members[0].state()["Ps"][-1]))
     for g_ in grps:
         g_.close()
     trk.close()
-    return {"window_solves_per_s": solves / max(t_live, 1e-9), "sequences": nseq, "distinct_recordings": n_streams, "estimator_groups": n_groups, "live_camera_frames": frames_live, "window_solves": solves,
-            "wall_s": t_live, "ms_per_backend_frame": 1e3 * t_live / max(solves // max(nseq, 1), 1), "group_batches": stt["batches"], "largest_batch": stt["largest_batch"],
-            "backend_frames_with_mixed_decisions": mixed, "backend_frames_live": steps_live, "keyframe_vote_share": keyframe_votes / max(votes, 1),
+    bf = max(frames_live / 2.0, 1e-9)       # back-end frames of a sequence inside the live span
+    return {"window_solves_per_s": solves / max(t_live, 1e-9), "sequences": nseq, "distinct_recordings": n_streams, "estimator_groups": n_groups,
+            "groups_alternate_frames": bool(stagger and n_groups > 1), "live_camera_frames": frames_live, "window_solves": solves,
+            "wall_s": t_live, "ms_per_backend_frame": 1e3 * t_live / bf, "group_batches": stt["batches"], "largest_batch": stt["largest_batch"],
+            "backend_frames_with_mixed_decisions": mixed, "group_steps_live": steps_live, "keyframe_vote_share": keyframe_votes / max(votes, 1),
             "newest_position_norm_m": pos, "device_preint": bool(device_preint),
-            "host_hardware_threads": os.cpu_count(), "tracker_ms_per_call": trk_anatomy,
-            "main_thread_ms_per_backend_frame": {k_: round(1e3 * v_ / max(solves // max(nseq, 1), 1), 3) for k_, v_ in clk.items()},
-            "path": "gf_tracker_track_batch_device -> gf_estimator_group_input_features (inputFeature -> processImage -> gf_ba solve + marginalise, "
+            "host_hardware_threads": os.cpu_count(), "group_worker_threads": workers, "tracker_ms_per_call": trk_anatomy,
+            "main_thread_ms_per_backend_frame": {k_: round(1e3 * v_ / bf, 3) for k_, v_ in clk.items()},
+            "path": "gf_tracker_track_batch_device -> gf_estimator_group_submit_features / _wait (inputFeature -> processImage -> gf_ba solve + marginalise, "
                     "windows packed / uploaded / downloaded every frame)"}
 
 
@@ -366,7 +377,8 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the bounded end-to-end (drop-in path) sample")
     ap.add_argument("--e2e-seqs", type=int, default=256)
     ap.add_argument("--e2e-streams", type=int, default=8, help="distinct seeded recordings of the end-to-end sample (staggered starts: mixed keyframe / non-keyframe batches)")
-    ap.add_argument("--e2e-groups", type=int, default=1, help="estimator groups the end-to-end sample splits its sequences over (own handle, stream and workers each: one group's host phase overlaps the other's batch)")
+    ap.add_argument("--e2e-groups", type=int, default=2, help="estimator groups the end-to-end sample splits its sequences over (own handle, stream and workers each; they alternate in which camera frames reach their back ends, so one group's host phase falls on the other's batch)")
+    ap.add_argument("--e2e-same-frames", action="store_true", help="with several estimator groups: all groups take the same camera frames (default: they alternate, see end_to_end_sample)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-image (PCIe-inclusive) sample")
     ap.add_argument("--e2e-device-preint", action="store_true", help="also run the end-to-end sample with the batched device pre-integration of the estimator group")
     ap.add_argument("--e2e-device-sweeps", action="store_true", help="also run the end-to-end sample with the batched device feature sweeps (triangulateWithDepth, movingConsistencyCheckW) of the estimator group")
@@ -589,16 +601,20 @@ def main():
         if world == 1 and not args.no_e2e and not args.strong and args.config == 1 and not (args.no_frontend or args.no_backend):
             trk.close(); trk = None
             S = max(1, args.e2e_streams)
-            cold = end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, n_streams=S, n_groups=args.e2e_groups)
+            cold = end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, n_streams=S, n_groups=args.e2e_groups, stagger=not args.e2e_same_frames)
             # warm passes (host allocations and worker threads up, as in a running service): the path alternates host and device phases and a pass moves by +-10 % with
             # whatever else the host runs, so two are taken, the better one is the sample, and all three are listed
-            warm = [end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, n_streams=S, n_groups=args.e2e_groups) for _ in range(2)]
+            warm = [end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, n_streams=S, n_groups=args.e2e_groups, stagger=not args.e2e_same_frames) for _ in range(2)]
             res["end_to_end"] = max(warm, key=lambda r: r["window_solves_per_s"])
             res["end_to_end"]["passes_window_solves_per_s"] = [cold["window_solves_per_s"]] + [r["window_solves_per_s"] for r in warm]
+            if args.e2e_groups > 1:   # next to it: all sequences in ONE group, every batch 256 windows (the arrangement of rounds 2-3 and of the first half of round 4)
+                one = end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, n_streams=S, n_groups=1)
+                res["end_to_end_one_group"] = {k: one[k] for k in ("window_solves_per_s", "sequences", "distinct_recordings", "estimator_groups", "ms_per_backend_frame", "group_batches", "largest_batch",
+                                                                   "main_thread_ms_per_backend_frame")}
             if S > 1:   # the best case for the batching next to it: ONE recording replicated, every member takes the same keyframe decision, every rendezvous is one homogeneous batch
-                homo = end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, n_streams=1, n_groups=args.e2e_groups)
+                homo = end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, n_streams=1, n_groups=args.e2e_groups, stagger=not args.e2e_same_frames)
                 res["end_to_end_homogeneous"] = {k: homo[k] for k in ("window_solves_per_s", "sequences", "distinct_recordings", "estimator_groups", "ms_per_backend_frame", "group_batches", "largest_batch",
-                                                                      "backend_frames_with_mixed_decisions", "backend_frames_live", "keyframe_vote_share")}
+                                                                      "backend_frames_with_mixed_decisions", "group_steps_live", "groups_alternate_frames", "keyframe_vote_share")}
             if args.e2e_device_preint:   # the steps' IMU intervals as one device launch instead of on the members' threads (same bits; slower on a many-core host)
                 alt = end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, device_preint=True)
                 res["end_to_end"]["with_device_preintegration_window_solves_per_s"] = alt["window_solves_per_s"]

@@ -126,17 +126,21 @@ class FeatureTracker:
                                           out.ctypes.data_as(C.POINTER(FeatureObs)), self.cap, _p(n, C.c_int)))
         return self._unpack(out, n)
 
-    def trackImageBatchDevice(self, ts, d_gray_ptr, d_depth_ptr=None, unpack=True):
-        """d_*_ptr: integer device addresses (e.g. torch tensor .data_ptr()) of batch contiguous frames."""
+    def trackImageBatchDevice(self, ts, d_gray_ptr, d_depth_ptr=None, unpack=True, out=None, n_out=None):
+        """d_*_ptr: integer device addresses (e.g. torch tensor .data_ptr()) of batch contiguous frames.  out / n_out: the caller's [batch][cap] OBS_DTYPE table
+        and [batch] int32 counts to write into (e.g. one of a ring, while estimators still read the previous frames' tables); default: the tracker's own pair."""
         B = self.cfg.batch
         ts = np.ascontiguousarray(ts, np.float64)
-        if not hasattr(self, "_out"):
-            self._out = np.zeros((B, self.cap), OBS_DTYPE)
-            self._n = np.zeros(B, np.int32)
+        if out is None:
+            if not hasattr(self, "_out"):
+                self._out = np.zeros((B, self.cap), OBS_DTYPE)
+                self._n = np.zeros(B, np.int32)
+            out, n_out = self._out, self._n
+        assert out.shape == (B, self.cap) and out.dtype == OBS_DTYPE and out.flags.c_contiguous and n_out.shape == (B,) and n_out.dtype == np.int32
         _chk(lib().gf_tracker_track_batch_device(self.h, _p(ts, C.c_double), C.c_void_p(d_gray_ptr),
                                                  C.c_void_p(d_depth_ptr) if d_depth_ptr else None,
-                                                 self._out.ctypes.data_as(C.POINTER(FeatureObs)), self.cap, _p(self._n, C.c_int)))
-        return self._unpack(self._out, self._n) if unpack else self._n
+                                                 out.ctypes.data_as(C.POINTER(FeatureObs)), self.cap, _p(n_out, C.c_int)))
+        return self._unpack(out, n_out) if unpack else n_out
 
     def prefetchHost(self, gray_addr, depth_addr=None):
         """gf_tracker_prefetch_batch on a block of `batch` frames lying back to back in (page-locked) host memory: gray_addr / depth_addr = integer host addresses

@@ -262,7 +262,11 @@ def test_prefetched_host_frames_match_the_device_route(gf):
     for k in range(6):
         dg = host_g[k].cuda()
         dd = host_d.cuda()
-        ra = a.trackImageBatchDevice([0.0666 * k] * B, dg.data_ptr(), dd.data_ptr())
+        # the caller's own output table (one of a ring, as a caller does whose estimators still read the previous frames' tables): same content, nothing else touched
+        tab, cnt = np.zeros((B, a.cap), gf.OBS_DTYPE), np.zeros(B, np.int32)
+        tab["id"] = -9
+        ra = a.trackImageBatchDevice([0.0666 * k] * B, dg.data_ptr(), dd.data_ptr(), out=tab, n_out=cnt)
+        assert all(cnt[b] == len(ra[b][0]) and np.all(tab["id"][b, cnt[b]:] == -9) for b in range(B))
         if k + 1 < 6:
             c.prefetchHost(host_g[k + 1].data_ptr(), host_d.data_ptr())     # two frames staged: k (oldest) and k + 1, whose copy runs under the kernels of k
         if k == 0:
