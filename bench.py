@@ -557,6 +557,10 @@ def main():
             "pose_gather": {"rows": int(gathered[0].shape[0]) if gathered[0] is not None else 0, "bytes_per_step": 56 * B * world, "own_block_matches_export": own_block_ok,
                             "backend": "none (1 rank)" if dist is None else ("gloo (GF_BENCH_SINGLE_DEVICE test mode)" if single else "nccl (RCCL)")},
             "host_threads_per_rank": int(os.environ["GF_HOST_THREADS"]),
+            "kernel_rate": value,
+            "value_is": "kernel_rate: tracker frame + solve + marginalisation per step with the windows resident on the device (inputs in HBM, the contract of `value`); "
+                        "the rate through the reference's own call surface (trackImage -> inputFeature -> processImage, windows packed / uploaded / downloaded every frame) is "
+                        "end_to_end.window_solves_per_s, reported at 1 GPU",
             "solves_per_s": solves / el_max, "tracked_features_per_s": tracked / el_max, "frames_per_s": B * world * K / el_max,
             "output_features_per_s": outf / el_max,
             "gpu_ms_per_step": {"pyramid": st["ms_pyramid"] / K, "lk": st["ms_lk"] / K, "detect": st["ms_detect"] / K, "tracker_total": st["ms_total_gpu"] / K,
