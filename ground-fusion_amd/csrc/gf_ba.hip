@@ -22,6 +22,7 @@
 #include "../../include/groundfusion_hip.h"
 #include "gf_comm.hpp"
 #include "gf_ba_kernels.hpp"
+#include "gf_copy_list.hpp"
 #include "gf_ba_marg.hpp"
 #include "gf_ba_gnss.hpp"
 
@@ -83,55 +84,17 @@ __global__ void ba_imu_patch(double* tab, const double* patch, const int* pinfo,
         for (int i = tid; i < IMU_STRIDE2; i += 256) t[(size_t)pi[2 + q] * IMU_STRIDE2 + i] = p[(size_t)q * IMU_STRIDE2 + i];
 }
 
-// ---- the upload as ONE kernel (GF_BA_UPLOAD=kernel): every table of a batch is a descriptor (rows x used bytes out of a pitch), the kernel reads the page-locked
-// host mirrors over the bus and writes the device tables.  Forty hipMemcpy(2D)Async calls of 4 KB .. 8 MB each cost more in submission and per-copy latency than
-// their 20 MB cost on the wire; a kernel with 1024 blocks in flight keeps the link busy from its first to its last byte.
-struct UpDesc { const char* src; char* dst; unsigned pitch, used, rows, esize, blk0, nblk; };
-constexpr int kUpMax = 56, kUpBlocks = 1024;
-struct UpList { UpDesc e[kUpMax]; int n; };
-template <class V> __device__ __forceinline__ void up_units(const UpDesc& D, unsigned blk) {
-    const unsigned upr = D.used / sizeof(V);
-    const size_t total = (size_t)upr * D.rows, stride = (size_t)D.nblk * 256;
-    size_t u = (size_t)blk * 256 + threadIdx.x;
-    for (; u + 3 * stride < total; u += 4 * stride) {   // four loads in flight per lane before the first store
-        V v[4]; size_t off[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) { const size_t uu = u + q * stride; const unsigned row = (unsigned)(uu / upr); off[q] = (size_t)row * D.pitch + (uu - (size_t)row * upr) * sizeof(V); v[q] = *reinterpret_cast<const V*>(D.src + off[q]); }
-#pragma unroll
-        for (int q = 0; q < 4; q++) *reinterpret_cast<V*>(D.dst + off[q]) = v[q];
-    }
-    for (; u < total; u += stride) { const unsigned row = (unsigned)(u / upr); const size_t off = (size_t)row * D.pitch + (u - (size_t)row * upr) * sizeof(V); *reinterpret_cast<V*>(D.dst + off) = *reinterpret_cast<const V*>(D.src + off); }
-}
-__global__ void __launch_bounds__(256) ba_gather_upload(UpList L) {
-    int k = 0;
-    while (k + 1 < L.n && blockIdx.x >= L.e[k + 1].blk0) k++;
-    const UpDesc& D = L.e[k];
-    if (D.esize == 16) up_units<uint4>(D, blockIdx.x - D.blk0);
-    else if (D.esize == 8) up_units<uint2>(D, blockIdx.x - D.blk0);
-    else up_units<unsigned>(D, blockIdx.x - D.blk0);
-}
+// ---- the upload as ONE kernel (GF_BA_UPLOAD=kernel, the default; gf_copy_list.hpp): every table of a batch is a descriptor, the kernel reads the page-locked host
+// mirrors over the bus and writes the device tables
 struct UpBuilder {
-    UpList L{}; bool ok = true;
-    // rows x `used` elements of `pitch`; host pointer as the device sees it
+    gfcopy::Builder B;
     template <class T> void add(const Buf<T>& b, size_t rows, size_t pitch, size_t used) {
         if (used == 0 || rows == 0) return;
-        if (used >= pitch) { used = pitch * rows; pitch = used; rows = 1; }
-        if (!b.hd || L.n >= kUpMax || used * sizeof(T) >= (1ull << 32) || pitch * sizeof(T) >= (1ull << 32)) { ok = false; return; }
-        UpDesc& D = L.e[L.n++];
-        D.src = reinterpret_cast<const char*>(b.hd); D.dst = reinterpret_cast<char*>(b.d); D.pitch = (unsigned)(pitch * sizeof(T)); D.used = (unsigned)(used * sizeof(T)); D.rows = (unsigned)rows;
-        const size_t al = (size_t)D.pitch | D.used | (size_t)(uintptr_t)D.src | (size_t)(uintptr_t)D.dst;
-        D.esize = al % 16 == 0 ? 16 : al % 8 == 0 ? 8 : 4;
-        g_up_bytes += (long long)D.used * D.rows;
+        const long long before = B.bytes;
+        B.add(b.hd, b.d, rows, pitch * sizeof(T), std::min(used, pitch) * sizeof(T));
+        g_up_bytes += B.bytes - before;
     }
     template <class T> void all(const Buf<T>& b) { add(b, 1, b.n, b.n); }
-    void finish() {   // blocks in proportion to the bytes, at least one each
-        double total = 0;
-        for (int k = 0; k < L.n; k++) total += (double)L.e[k].used * L.e[k].rows;
-        unsigned at = 0;
-        for (int k = 0; k < L.n; k++) { UpDesc& D = L.e[k]; D.blk0 = at; D.nblk = std::max(1u, (unsigned)((double)D.used * D.rows / std::max(total, 1.0) * kUpBlocks)); at += D.nblk; }
-        nblocks = at;
-    }
-    unsigned nblocks = 0;
 };
 
 struct gf_ba {
@@ -601,11 +564,9 @@ int upload(gf_ba* h) {
     up1(h->st0);
     HIPCHK(err);
     if (ker) {
-        if (!U.ok) return gf::set_err(GF_ERR_HIP, "upload kernel: a host mirror is not mapped into the device's address space, or too many / too large tables (GF_BA_UPLOAD=copies selects the copy path)");
-        U.finish();
+        if (!U.B.ok) return gf::set_err(GF_ERR_HIP, "upload kernel: a host mirror is not mapped into the device's address space, or too many / too large tables (GF_BA_UPLOAD=copies selects the copy path)");
         g_up_calls++;
-        ba_gather_upload<<<dim3(U.nblocks), 256, 0, s>>>(U.L);
-        HIPCHK(hipGetLastError());
+        HIPCHK(U.B.launch<0>(s));
     }
     // priors: host tables of the slots that brought one (mixed batches), device-resident ones straight from the marginalisation's output
     if (h->any_pri_res && !h->all_pri_res)   // mixed batch: only the active slots that brought a host prior; a slot that sits this batch out keeps what the device holds (its host mirror was never written)

@@ -1,0 +1,69 @@
+// gf_copy_list.hpp — many small transfers between page-locked host memory and device tables as ONE kernel.
+// hipHostMalloc'ed memory is mapped into the device's address space, so a kernel can read (upload) or write (download) it over the bus.  A batch of tables --
+// the ~40 of a back-end upload (gf_ba.hip), the three to five of the tracker's hand-overs around LK and the detection (gf_tracker.hip) -- is a list of
+// descriptors (rows x used bytes out of a pitch); the blocks are shared out by bytes.  One launch replaces one hipMemcpy(2D)Async per table: what those cost is
+// their submission and per-copy latency, not their bytes (20 MB in forty copies: 0.72 ms of device time and as much again on the submitting thread; one kernel:
+// 0.50-0.54 ms).  Direction is whatever the pointers say; source and destination use the same pitch.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+
+namespace gfcopy {
+struct Desc { const char* src; char* dst; unsigned pitch, used, rows, esize, blk0, nblk; };
+constexpr int kMax = 56, kBlocks = 1024;
+struct List { Desc e[kMax]; int n; };
+
+template <class V> __device__ __forceinline__ void units(const Desc& D, unsigned blk) {
+    const unsigned upr = D.used / sizeof(V);
+    const size_t total = (size_t)upr * D.rows, stride = (size_t)D.nblk * 256;
+    size_t u = (size_t)blk * 256 + threadIdx.x;
+    for (; u + 3 * stride < total; u += 4 * stride) {   // four loads in flight per lane before the first store
+        V v[4]; size_t off[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const size_t uu = u + q * stride; const unsigned row = (unsigned)(uu / upr); off[q] = (size_t)row * D.pitch + (uu - (size_t)row * upr) * sizeof(V); v[q] = *reinterpret_cast<const V*>(D.src + off[q]); }
+#pragma unroll
+        for (int q = 0; q < 4; q++) *reinterpret_cast<V*>(D.dst + off[q]) = v[q];
+    }
+    for (; u < total; u += stride) { const unsigned row = (unsigned)(u / upr); const size_t off = (size_t)row * D.pitch + (u - (size_t)row * upr) * sizeof(V); *reinterpret_cast<V*>(D.dst + off) = *reinterpret_cast<const V*>(D.src + off); }
+}
+// TAG: one instantiation per translation unit that launches it (a template has vague linkage; the objects are linked into one library)
+template <int TAG> __global__ void __launch_bounds__(256) copy_list_kernel(List L) {
+    int k = 0;
+    while (k + 1 < L.n && blockIdx.x >= L.e[k + 1].blk0) k++;
+    const Desc& D = L.e[k];
+    if (D.esize == 16) units<uint4>(D, blockIdx.x - D.blk0);
+    else if (D.esize == 8) units<uint2>(D, blockIdx.x - D.blk0);
+    else if (D.esize == 4) units<unsigned>(D, blockIdx.x - D.blk0);
+    else units<unsigned char>(D, blockIdx.x - D.blk0);
+}
+
+struct Builder {
+    List L{}; bool ok = true; unsigned nblocks = 0; long long bytes = 0;
+    // rows x `used` bytes out of `pitch` bytes; both pointers as the device sees them
+    void add(const void* src, void* dst, size_t rows, size_t pitch, size_t used) {
+        if (used == 0 || rows == 0) return;
+        if (used >= pitch) { used = pitch * rows; pitch = used; rows = 1; }
+        if (!src || !dst || L.n >= kMax || used >= (1ull << 32) || pitch >= (1ull << 32)) { ok = false; return; }
+        Desc& D = L.e[L.n++];
+        D.src = static_cast<const char*>(src); D.dst = static_cast<char*>(dst); D.pitch = (unsigned)pitch; D.used = (unsigned)used; D.rows = (unsigned)rows;
+        const size_t al = (size_t)D.pitch | D.used | (size_t)(uintptr_t)D.src | (size_t)(uintptr_t)D.dst;
+        D.esize = al % 16 == 0 ? 16 : al % 8 == 0 ? 8 : al % 4 == 0 ? 4 : 1;
+        bytes += (long long)D.used * D.rows;
+    }
+    void finish() {   // blocks in proportion to the bytes, at least one each; small lists get few blocks (16 KB per block and pass)
+        const double total = (double)std::max<long long>(bytes, 1);
+        const unsigned want = (unsigned)std::min<long long>(kBlocks, std::max<long long>(L.n, bytes / (256 * 16 * 4)));
+        unsigned at = 0;
+        for (int k = 0; k < L.n; k++) { Desc& D = L.e[k]; D.blk0 = at; D.nblk = std::max(1u, (unsigned)((double)D.used * D.rows / total * want)); at += D.nblk; }
+        nblocks = at;
+    }
+    template <int TAG> hipError_t launch(hipStream_t s) {
+        if (L.n == 0) return hipSuccess;
+        finish();
+        copy_list_kernel<TAG><<<dim3(nblocks), 256, 0, s>>>(L);
+        return hipGetLastError();
+    }
+};
+}  // namespace gfcopy

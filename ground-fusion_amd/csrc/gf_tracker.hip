@@ -28,6 +28,7 @@
 #include "gf_comm.hpp"
 #include "gf_detect_kernels.hpp"
 #include "gf_lk_kernels.hpp"
+#include "gf_copy_list.hpp"
 
 namespace gf {
 
@@ -117,7 +118,15 @@ template <class T> struct DevBuf {
 };
 template <class T> struct PinBuf {
     T* p = nullptr; size_t n = 0;
-    int alloc(size_t count) { n = count; hipError_t e = hipHostMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault); if (e != hipSuccess) return set_err(GF_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(e)); memset(p, 0, std::max<size_t>(count, 1) * sizeof(T)); return GF_OK; }
+    T* hd = nullptr;   // the same memory as kernels address it (page-locked memory is mapped into the device's address space), or null
+    int alloc(size_t count) {
+        n = count;
+        hipError_t e = hipHostMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) return set_err(GF_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(e));
+        memset(p, 0, std::max<size_t>(count, 1) * sizeof(T));
+        void* q = nullptr; hd = hipHostGetDevicePointer(&q, p, 0) == hipSuccess ? static_cast<T*>(q) : nullptr; (void)hipGetLastError();
+        return GF_OK;
+    }
     void release() { if (p) (void)hipHostFree(p); p = nullptr; }
 };
 
@@ -163,6 +172,7 @@ struct gf_tracker {
     PyrGeom G;
     DiskTable disk;
     int B = 0, cap = 0, cand_cap = 0, frame = 0, cur_slot = 0, sort_cap = 0;
+    bool copy_lists = true;   // GF_TRACKER_COPIES=1: one hipMemcpyAsync per table instead of the copy-list kernels
     bool profiling = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
@@ -363,6 +373,24 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
     auto tp = clk::now();
     auto lap = [&](double& acc) { auto n = clk::now(); acc += std::chrono::duration<double, std::milli>(n - tp).count(); tp = n; };
     for (int b = 0; b < B; b++) { h->seq[b].cur_time = t[b]; h->seq[b].cur_pts.clear(); h->seq[b].cur_depth.clear(); }
+    // The hand-overs between the host's bookkeeping and the kernels -- two to four small tables down before LK, five up behind it, three down before the detection, four
+    // up behind it -- as one copy-list kernel each (gf_copy_list.hpp) instead of one hipMemcpyAsync per table: sixteen submissions and copy latencies per frame become four.
+    gfcopy::Builder CL;
+    const bool lists = h->copy_lists;
+    hipError_t cerr = hipSuccess;
+    auto down = [&](auto& dev, auto& pin, size_t count) {   // host -> device
+        const size_t bytes = count * sizeof(*pin.p);
+        if (lists) CL.add(pin.hd, dev.p, 1, bytes, bytes); else if (cerr == hipSuccess) cerr = hipMemcpyAsync(dev.p, pin.p, bytes, hipMemcpyHostToDevice, h->stream);
+    };
+    auto up = [&](auto& pin, auto& dev, size_t count) {     // device -> host
+        const size_t bytes = count * sizeof(*pin.p);
+        if (lists) CL.add(dev.p, pin.hd, 1, bytes, bytes); else if (cerr == hipSuccess) cerr = hipMemcpyAsync(pin.p, dev.p, bytes, hipMemcpyDeviceToHost, h->stream);
+    };
+    auto flush = [&]() -> int {
+        HIPCHK(cerr);
+        if (lists) { if (!CL.ok) return set_err(GF_ERR_HIP, "copy list: a page-locked buffer is not mapped into the device's address space (GF_TRACKER_COPIES=1 selects plain copies)"); HIPCHK(CL.launch<1>(h->stream)); CL = gfcopy::Builder(); }
+        return GF_OK;
+    };
     if (prof) HIPCHK(hipEventRecord(h->ev[0], h->stream));
     if (int rc = launch_pyramid(h, d_gray)) return rc;
     if (prof) HIPCHK(hipEventRecord(h->ev[1], h->stream));
@@ -384,30 +412,28 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
     }
     bool lk_timed = false;
     if (any_prev) {
-        HIPCHK(hipMemcpyAsync(h->d_npts.p, h->h_npts.p, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->d_prev_pts.p, h->h_prev_pts.p, (size_t)B * cap * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+        down(h->d_npts, h->h_npts, B);
+        down(h->d_prev_pts, h->h_prev_pts, (size_t)B * cap);
         const uint8_t* mask_plain = nullptr; const uint8_t* mask_pred = nullptr;
         if (any_pred) {
-            HIPCHK(hipMemcpyAsync(h->d_init_pts.p, h->h_init_pts.p, (size_t)B * cap * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+            down(h->d_init_pts, h->h_init_pts, (size_t)B * cap);
             for (int b = 0; b < B; b++) { h->h_seqmask.p[b] = h->seq[b].hasPrediction ? 0 : 1; h->h_seqmask.p[B + b] = h->seq[b].hasPrediction ? 1 : 0; }
-            HIPCHK(hipMemcpyAsync(h->d_seqmask.p, h->h_seqmask.p, 2 * B, hipMemcpyHostToDevice, h->stream));
+            down(h->d_seqmask, h->h_seqmask, 2 * (size_t)B);
             mask_plain = h->d_seqmask.p; mask_pred = h->d_seqmask.p + B;
         }
+        if (int rc = flush()) return rc;
         if (prof) HIPCHK(hipEventRecord(h->ev[2], h->stream));
         const dim3 grid((cap + 3) / 4, B);
         if (any_plain) { lk_track_kernel<<<grid, 256, 0, h->stream>>>(h->G, lk_args(h, 3, 0, h->cfg.flow_back, 1, mask_plain, d_depth)); h->stats.lk_launches++; }
         if (any_pred) { lk_track_kernel<<<grid, 256, 0, h->stream>>>(h->G, lk_args(h, 1, 1, h->cfg.flow_back, 1, mask_pred, d_depth)); h->stats.lk_launches++; }
         HIPCHK(hipGetLastError());
         if (prof) { HIPCHK(hipEventRecord(h->ev[3], h->stream)); lk_timed = true; }
-        auto fetch = [&]() -> int {
-            HIPCHK(hipMemcpyAsync(h->h_cur_pts.p, h->d_cur_pts.p, (size_t)B * cap * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipMemcpyAsync(h->h_status.p, h->d_status.p, (size_t)B * cap, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipMemcpyAsync(h->h_fwd_status.p, h->d_fwd_status.p, (size_t)B * cap, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipMemcpyAsync(h->h_depth_out.p, h->d_depth_out.p, (size_t)B * cap * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipMemcpyAsync(h->h_counters.p, h->d_counters.p, (size_t)B * cap * 2 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
-            return GF_OK;
-        };
-        if (int rc = fetch()) return rc;
+        up(h->h_cur_pts, h->d_cur_pts, (size_t)B * cap);
+        up(h->h_status, h->d_status, (size_t)B * cap);
+        up(h->h_fwd_status, h->d_fwd_status, (size_t)B * cap);
+        up(h->h_depth_out, h->d_depth_out, (size_t)B * cap);
+        up(h->h_counters, h->d_counters, (size_t)B * cap * 2);
+        if (int rc = flush()) return rc;
     }
     HIPCHK(hipEventRecord(h->ev[6], h->stream));
     lap(h->stats.ms_host_pre);
@@ -433,10 +459,11 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
             lk_track_kernel<<<dim3((cap + 3) / 4, B), 256, 0, h->stream>>>(h->G, lk_args(h, 3, 0, h->cfg.flow_back, 1, h->d_seqmask.p, d_depth));
             h->stats.lk_launches++;
             HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(h->h_cur_pts.p, h->d_cur_pts.p, (size_t)B * cap * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipMemcpyAsync(h->h_status.p, h->d_status.p, (size_t)B * cap, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipMemcpyAsync(h->h_depth_out.p, h->d_depth_out.p, (size_t)B * cap * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipMemcpyAsync(h->h_counters.p, h->d_counters.p, (size_t)B * cap * 2 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+            up(h->h_cur_pts, h->d_cur_pts, (size_t)B * cap);
+            up(h->h_status, h->d_status, (size_t)B * cap);
+            up(h->h_depth_out, h->d_depth_out, (size_t)B * cap);
+            up(h->h_counters, h->d_counters, (size_t)B * cap * 2);
+            if (int rc = flush()) return rc;
             HIPCHK(hipStreamSynchronize(h->stream));
             for (int b = 0; b < B; b++) {
                 unsigned* cn = h->h_counters.p + (size_t)b * cap * 2;
@@ -486,9 +513,10 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
 
     // ---- Shi-Tomasi top-up (feature_tracker.cpp:190-206)
     if (any_want) {
-        HIPCHK(hipMemcpyAsync(h->d_centers.p, h->h_centers.p, (size_t)B * cap * sizeof(int2), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->d_ncenters.p, h->h_ncenters.p, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->d_want.p, h->h_want.p, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        down(h->d_centers, h->h_centers, (size_t)B * cap);
+        down(h->d_ncenters, h->h_ncenters, B);
+        down(h->d_want, h->h_want, B);
+        if (int rc = flush()) return rc;
         HIPCHK(hipMemsetAsync(h->d_maxkey.p, 0, B * sizeof(unsigned), h->stream));
         HIPCHK(hipMemsetAsync(h->d_cand_count.p, 0, B * sizeof(int), h->stream));
         if (prof) HIPCHK(hipEventRecord(h->ev[4], h->stream));
@@ -505,10 +533,11 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
         S.depth = d_depth; S.depth_seq_stride = (size_t)W * H; S.depth_stride = W;
         select_corners_kernel<<<dim3(B), 1024, h->select_lds, h->stream>>>(S);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(h->h_out_n.p, h->d_out_n.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(h->h_out_pts.p, h->d_out_pts.p, (size_t)B * cap * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(h->h_out_depth.p, h->d_out_depth.p, (size_t)B * cap * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(h->h_cand_count.p, h->d_cand_count.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        up(h->h_out_n, h->d_out_n, B);
+        up(h->h_out_pts, h->d_out_pts, (size_t)B * cap);
+        up(h->h_out_depth, h->d_out_depth, (size_t)B * cap);
+        up(h->h_cand_count, h->d_cand_count, B);
+        if (int rc = flush()) return rc;
     }
     if (prof && !any_want) HIPCHK(hipEventRecord(h->ev[4], h->stream));
     if (prof) HIPCHK(hipEventRecord(h->ev[5], h->stream));
@@ -606,6 +635,7 @@ int gf_tracker_create(const gf_tracker_cfg* cfg, gf_tracker** out) {
         int dev = 0;
         (void)hipGetDevice(&dev);
         h->pool = new gf::HostPool(h->B >= 8 ? nthr - 1 : 0, dev);
+        h->copy_lists = !(getenv("GF_TRACKER_COPIES") && atoi(getenv("GF_TRACKER_COPIES")) != 0);
     }
     const int W = cfg->width, H = cfg->height, B = h->B, cap = h->cap;
     int cc = 1024;
