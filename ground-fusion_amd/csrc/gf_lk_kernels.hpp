@@ -265,9 +265,28 @@ __device__ __forceinline__ double wave_sum_exact(int v) {
     return (double)s;
 }
 
+// the same sum as the float the reference makes of it: (float)(int64), one rounding.  The sum is wave-uniform, so the conversion's normalisation (find the leading
+// bit, shift, keep a sticky bit) runs on the scalar unit and two vector instructions are left (v_cvt_f32_i32, v_ldexp_f32); the detour through double took five
+__device__ __forceinline__ float wave_sum_f32(int v) {
+    v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);  // row_half_mirror
+    long long s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += (long long)__builtin_amdgcn_readlane(v, k * 8);
+    return (float)s;
+}
+
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float unif(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 
+// cvRound(p * (1 << W_BITS)) of a wave-uniform bilinear weight product 0 <= p <= 1 (lkpyramid.cpp: iw = cvRound(w * (1 << 14))), delivered in a scalar register.
+// p * 2^14 is exact; adding 2^23 in the same fused operation rounds it to an integer, ties to even, as cvRound / rintf do; the integer then sits in the low mantissa
+// bits.  One v_fma + one v_readfirstlane and a scalar subtraction instead of multiply, v_rndne, v_readfirstlane and v_cvt_i32: the weights, their fourth
+// (2^14 minus the other three) and the packing into 16-bit pairs stay on the scalar unit.
+__device__ __forceinline__ int rn14(float p) {
+    return uni(__builtin_bit_cast(int, __builtin_fmaf(p, 16384.f, 8388608.f))) - 0x4B000000;
+}
 __device__ __forceinline__ float i64_to_f32(double v) { return (float)v; }  // v holds an exact integer: one rounding, as (float)(int64) in the reference build
 
 struct __attribute__((packed, aligned(4))) U4a { uint32_t x, y, z, w; };
@@ -331,6 +350,11 @@ __device__ __forceinline__ void scharr8(const uint32_t (&A)[5], const uint32_t (
 __device__ __forceinline__ int dot2_acc(int acc, uint32_t w, uint32_t a) {
     return __builtin_amdgcn_sdot2(as_v2s(a), as_v2s(w), acc, false);
 }
+// the same sum through the three-operand form (v_dot2_i32_i16, selected by its clamp bit; the callers' sums stay far from saturation): the accumulator operand
+// survives, so a constant or a value that is needed again does not have to be copied first
+__device__ __forceinline__ int dot3_acc(int acc, uint32_t w, uint32_t a) {
+    return __builtin_amdgcn_sdot2(as_v2s(a), as_v2s(w), acc, true);
+}
 // the pair (p[k], p[k+1]) out of pairs P[m] = (p[2m], p[2m+1])
 __device__ __forceinline__ uint32_t pair_at(const uint32_t* P, int k) {
     return (k & 1) ? __builtin_amdgcn_alignbit(P[(k + 1) >> 1], P[k >> 1], 16) : P[k >> 1];
@@ -344,6 +368,7 @@ __device__ __forceinline__ int lk_solve(const PyrGeom& G, const LkImages im, flo
     const int r = lane < 63 ? lane / 3 : 20;
     const int s = lane < 63 ? lane - 3 * r : 2;
     const bool live = lane < 63;
+    const uint8_t* tile_r = tile + r * kTileStride;
     const float half = (kWin - 1) * 0.5f;
     int status = 1;
     float nextx = nx, nexty = ny;  // running nextPts[ptidx]
@@ -364,9 +389,9 @@ __device__ __forceinline__ int lk_solve(const PyrGeom& G, const LkImages im, flo
         }
         n_levels++;
         float a = prevx - ipx, b = prevy - ipy;
-        int iw00 = uni(__float2int_rn((1.f - a) * (1.f - b) * 16384.f));
-        int iw01 = uni(__float2int_rn(a * (1.f - b) * 16384.f));
-        int iw10 = uni(__float2int_rn((1.f - a) * b * 16384.f));
+        int iw00 = rn14((1.f - a) * (1.f - b));
+        int iw01 = rn14(a * (1.f - b));
+        int iw10 = rn14((1.f - a) * b);
         int iw11 = 16384 - iw00 - iw01 - iw10;
 
         // ---- template: bilinear I (5 fractional bits) and bilinear Scharr derivative for this lane's 7 pixels.  The derivative is evaluated here
@@ -396,18 +421,17 @@ __device__ __forceinline__ int lk_solve(const PyrGeom& G, const LkImages im, flo
             const uint32_t w0 = ((uint32_t)iw00 & 0xffffu) | ((uint32_t)iw01 << 16), w1 = ((uint32_t)iw10 & 0xffffu) | ((uint32_t)iw11 << 16);
 #pragma unroll
             for (int k = 0; k < 7; k++) {
-                int iv = dot2_acc(dot2_acc(1 << 8, w0, pair_at(R1, k + 1)), w1, pair_at(R2, k + 1)) >> 9;
-                int ix = dot2_acc(dot2_acc(1 << 13, w0, pair_at(XT, k)), w1, pair_at(XB, k)) >> 14;
-                int iy = dot2_acc(dot2_acc(1 << 13, w0, pair_at(YT, k)), w1, pair_at(YB, k)) >> 14;
+                int iv = dot3_acc(dot3_acc(1 << 8, w0, pair_at(R1, k + 1)), w1, pair_at(R2, k + 1)) >> 9;
+                int ix = dot3_acc(dot3_acc(1 << 13, w0, pair_at(XT, k)), w1, pair_at(XB, k)) >> 14;
+                int iy = dot3_acc(dot3_acc(1 << 13, w0, pair_at(YT, k)), w1, pair_at(YB, k)) >> 14;
                 if (!live) { ix = 0; iy = 0; iv = 0; }
                 tI[k] = (1 << 8) - (iv << 9);   // the iteration's accumulator start: (raw >> 9) - iv == (raw - (iv << 9)) >> 9
                 tX[k] = ix; tY[k] = iy;
                 a11 += __mul24(ix, ix); a12 += __mul24(ix, iy); a22 += __mul24(iy, iy);
             }
         }
-        const double iA11 = wave_sum_exact(a11), iA12 = wave_sum_exact(a12), iA22 = wave_sum_exact(a22);
         const float FLT_SCALE = 1.f / (1 << 20);
-        const float A11 = i64_to_f32(iA11) * FLT_SCALE, A12 = i64_to_f32(iA12) * FLT_SCALE, A22 = i64_to_f32(iA22) * FLT_SCALE;
+        const float A11 = wave_sum_f32(a11) * FLT_SCALE, A12 = wave_sum_f32(a12) * FLT_SCALE, A22 = wave_sum_f32(a22) * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * kWin * kWin);
         if (minEig < 1e-4f || D < 1.1920928955078125e-07f) {
@@ -420,7 +444,8 @@ __device__ __forceinline__ int lk_solve(const PyrGeom& G, const LkImages im, flo
         int tx0 = -100000, ty0 = -100000;  // no tile resident
         const uint8_t* Jbase = im.J + g.img_off;
         for (int j = 0; j < 30; j++) {
-            const int inx = uni((int)floorf(npx)), iny = uni((int)floorf(npy));
+            const float fnx = floorf(npx), fny = floorf(npy);   // kept as floats for the fractions below ((float)inx == fnx: no conversion back)
+            const int inx = uni((int)fnx), iny = uni((int)fny);
             if (inx < -kWin || inx >= g.w || iny < -kWin || iny >= g.h) {
                 if (level == 0) status = 0;
                 break;
@@ -439,38 +464,37 @@ __device__ __forceinline__ int lk_solve(const PyrGeom& G, const LkImages im, flo
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
-            a = npx - inx; b = npy - iny;
-            iw00 = uni(__float2int_rn((1.f - a) * (1.f - b) * 16384.f));
-            iw01 = uni(__float2int_rn(a * (1.f - b) * 16384.f));
-            iw10 = uni(__float2int_rn((1.f - a) * b * 16384.f));
+            a = npx - fnx; b = npy - fny;
+            iw00 = rn14((1.f - a) * (1.f - b));
+            iw01 = rn14(a * (1.f - b));
+            iw10 = rn14((1.f - a) * b);
             iw11 = 16384 - iw00 - iw01 - iw10;
             int b1 = 0, b2 = 0;
             {
-                const int xo = inx - tx0 + 7 * s;
+                const int xo = (inx - tx0) + 7 * s;                 // scalar part + lane constant
                 const int o = xo & 3;
-                const uint32_t* q0 = reinterpret_cast<const uint32_t*>(tile + __mul24(iny - ty0 + r, kTileStride) + (xo - o));
+                const uint32_t* q0 = reinterpret_cast<const uint32_t*>(tile_r + (iny - ty0) * kTileStride + (xo & ~3));   // the row offset of the lane is loop-invariant, the window's is scalar
                 const uint32_t* q1 = q0 + kTileStride / 4;
                 uint32_t l0, h0, l1, h1;   // bytes 0..7 of the lane's run in window rows r and r + 1
                 align8(q0[0], q0[1], q0[2], o, l0, h0);
                 align8(q1[0], q1[1], q1[2], o, l1, h1);
-                // (J[k], J[k+1]) as u16 pairs, k = 0..6, for both rows; the bilinear sample is two v_dot2c_i32_i16 against the s16 weight pairs
-                // (iw11 = 2^14 - iw00 - iw01 - iw10 >= -1), started from 2^8 - (I << 9) of the template pixel
-                const uint32_t w0 = ((uint32_t)iw00 & 0xffffu) | ((uint32_t)iw01 << 16), w1 = ((uint32_t)iw10 & 0xffffu) | ((uint32_t)iw11 << 16);
-                const uint32_t T[7] = {__builtin_amdgcn_perm(0u, l0, 0x0c010c00u), __builtin_amdgcn_perm(0u, l0, 0x0c020c01u), __builtin_amdgcn_perm(0u, l0, 0x0c030c02u),
-                                       __builtin_amdgcn_perm(h0, l0, 0x0c040c03u), __builtin_amdgcn_perm(0u, h0, 0x0c010c00u), __builtin_amdgcn_perm(0u, h0, 0x0c020c01u),
-                                       __builtin_amdgcn_perm(0u, h0, 0x0c030c02u)};
-                const uint32_t Bt[7] = {__builtin_amdgcn_perm(0u, l1, 0x0c010c00u), __builtin_amdgcn_perm(0u, l1, 0x0c020c01u), __builtin_amdgcn_perm(0u, l1, 0x0c030c02u),
-                                        __builtin_amdgcn_perm(h1, l1, 0x0c040c03u), __builtin_amdgcn_perm(0u, h1, 0x0c010c00u), __builtin_amdgcn_perm(0u, h1, 0x0c020c01u),
-                                        __builtin_amdgcn_perm(0u, h1, 0x0c030c02u)};
+                // VERTICAL u16 pairs V[k] = (J[r][k], J[r + 1][k]), k = 0..7: one v_perm each (eight; horizontal pairs (J[k], J[k + 1]) of both rows took fourteen).
+                // The bilinear sample is two 16-bit dot products against the s16 weight pairs (iw00, iw10) and (iw01, iw11) (iw11 = 2^14 - iw00 - iw01 - iw10 >= -1),
+                // started from 2^8 - (I << 9) of the template pixel: the same four products and the same integer sum.  The first of the two is the three-operand
+                // form (v_dot2_i32_i16, selected through its clamp bit -- nothing here comes near saturation): it leaves tI[k] where it is, the in-place
+                // v_dot2c needed a copy of it per pixel and iteration; the second uses the same opcode (dependent dot products of one opcode issue back to back).
+                const uint32_t wA = ((uint32_t)iw00 & 0xffffu) | ((uint32_t)iw10 << 16), wB = ((uint32_t)iw01 & 0xffffu) | ((uint32_t)iw11 << 16);
+                const uint32_t V[8] = {__builtin_amdgcn_perm(l1, l0, 0x0c040c00u), __builtin_amdgcn_perm(l1, l0, 0x0c050c01u), __builtin_amdgcn_perm(l1, l0, 0x0c060c02u),
+                                       __builtin_amdgcn_perm(l1, l0, 0x0c070c03u), __builtin_amdgcn_perm(h1, h0, 0x0c040c00u), __builtin_amdgcn_perm(h1, h0, 0x0c050c01u),
+                                       __builtin_amdgcn_perm(h1, h0, 0x0c060c02u), __builtin_amdgcn_perm(h1, h0, 0x0c070c03u)};
 #pragma unroll
                 for (int k = 0; k < 7; k++) {
-                    const int diff = dot2_acc(dot2_acc(tI[k], w0, T[k]), w1, Bt[k]) >> 9;
+                    const int diff = __builtin_amdgcn_sdot2(as_v2s(V[k + 1]), as_v2s(wB), __builtin_amdgcn_sdot2(as_v2s(V[k]), as_v2s(wA), tI[k], true), true) >> 9;
                     b1 = mad_i24(diff, tX[k], b1);
                     b2 = mad_i24(diff, tY[k], b2);
                 }
             }
-            const double ib1 = wave_sum_exact(b1), ib2 = wave_sum_exact(b2);
-            const float fb1 = i64_to_f32(ib1) * FLT_SCALE, fb2 = i64_to_f32(ib2) * FLT_SCALE;
+            const float fb1 = wave_sum_f32(b1) * FLT_SCALE, fb2 = wave_sum_f32(b2) * FLT_SCALE;
             const float dx = (A12 * fb2 - A22 * fb1) * D;
             const float dy = (A12 * fb1 - A11 * fb2) * D;
             npx += dx; npy += dy;
