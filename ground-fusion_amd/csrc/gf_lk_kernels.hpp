@@ -265,15 +265,23 @@ __device__ __forceinline__ double wave_sum_exact(int v) {
     return (double)s;
 }
 
-// the same sum as the float the reference makes of it: (float)(int64), one rounding.  The sum is wave-uniform, so the conversion's normalisation (find the leading
-// bit, shift, keep a sticky bit) runs on the scalar unit and two vector instructions are left (v_cvt_f32_i32, v_ldexp_f32); the detour through double took five
+// the same sum as the float the reference makes of it: (float)(int64), one rounding.  Three DPP adds inside the 8-lane groups (no overflow: 8 x 2^28); the group
+// sums are then split into a signed upper and an unsigned lower half-word, and each half goes through the remaining three levels (row_mirror, row_bcast:15,
+// row_bcast:31: sums of 8 half-words, < 2^19) to lane 63; the scalar unit puts the two together and normalises for the conversion (find the leading bit, shift,
+// sticky bit), two vector instructions finish it (v_cvt_f32_i32, v_ldexp_f32).  Per sum 15 vector + ~12 scalar instructions; reading the eight group sums with
+// v_readlane and adding them as 64-bit scalars took 13 + 31 -- and the scalar unit is shared by the four SIMDs of a CU.
 __device__ __forceinline__ float wave_sum_f32(int v) {
     v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
     v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
-    v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);  // row_half_mirror
-    long long s = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) s += (long long)__builtin_amdgcn_readlane(v, k * 8);
+    v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);  // row_half_mirror: every lane holds the sum of its group of 8
+    int hi = v >> 16, lo = v & 0xffff;                        // v == hi * 65536 + lo
+    hi += __builtin_amdgcn_mov_dpp(hi, 0x140, 0xf, 0xf, true);                 // row_mirror: every lane holds the sum of its row of 16
+    lo += __builtin_amdgcn_mov_dpp(lo, 0x140, 0xf, 0xf, true);
+    hi += __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xa, 0xf, false);          // row_bcast:15 into rows 1 and 3: rows 0 + 1, rows 2 + 3
+    lo += __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xa, 0xf, false);
+    hi += __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xc, 0xf, false);          // row_bcast:31 into rows 2 and 3: lane 63 holds everything
+    lo += __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xc, 0xf, false);
+    const long long s = (long long)__builtin_amdgcn_readlane(hi, 63) * 65536 + (long long)__builtin_amdgcn_readlane(lo, 63);
     return (float)s;
 }
 
