@@ -382,7 +382,7 @@ __device__ __forceinline__ int lk_solve(const PyrGeom& G, const LkImages im, flo
     float nextx = nx, nexty = ny;  // running nextPts[ptidx]
     for (int level = maxLevel; level >= 0; level--) {
         const LevelGeom g = G.lv[level];
-        const float sc = (float)(1. / (1 << level));
+        const float sc = __builtin_bit_cast(float, (127 - level) << 23);   // 2^-level exactly, as (float)(1. / (1 << level)) -- which compiled to a double-precision division per level pass
         float prevx = ppx * sc, prevy = ppy * sc;
         float ntx, nty;
         if (level == maxLevel) {
@@ -407,10 +407,16 @@ __device__ __forceinline__ int lk_solve(const PyrGeom& G, const LkImages im, flo
         int tI[7], tX[7], tY[7];
         int a11 = 0, a12 = 0, a22 = 0;
         {
-            const int x0 = ipx + 7 * s, xb = x0 - 1, o = xb & 3;
-            const uint8_t* irow = im.I + g.img_off + (ptrdiff_t)(ipy + r - 1) * g.stride + (xb - o);
+            // the 16 bytes around columns x0 - 1 .. x0 + 8 (x0 = ipx + 7 s) of rows ipy + r - 1 .. + 2: a wave-uniform base (scalar registers) + a non-negative
+            // 32-bit lane offset, so that the loads take the scalar-base form instead of 64-bit vector address arithmetic
+            const int x0 = ipx + 7 * s;
+            const int e = (ipx & 3) + 7 * s - 1;          // column x0 - 1 relative to ipx & ~3: >= -1
+            const int o = e & 3;
+            const uint8_t* sbase = im.I + g.img_off + (ptrdiff_t)(ipy - 1) * g.stride + (ipx & ~3) - 4;
+            const unsigned loff = (unsigned)(__mul24(r, g.stride) + (e & ~3) + 4);
+            const uint8_t* irow = sbase + loff;
             uint32_t R0[5], R1[5], R2[5], R3[5];   // image rows ipy+r-1 .. ipy+r+2, columns x0-1 .. x0+8
-            load_row10(irow, o, R0); load_row10(irow + g.stride, o, R1); load_row10(irow + 2 * g.stride, o, R2); load_row10(irow + 3 * g.stride, o, R3);
+            load_row10(irow, o, R0); load_row10(sbase + g.stride + loff, o, R1); load_row10(sbase + 2 * g.stride + loff, o, R2); load_row10(sbase + 3 * g.stride + loff, o, R3);
             uint32_t XT[4], YT[4], XB[4], YB[4];   // derivative pairs of rows ipy+r (top) and ipy+r+1 (bottom), columns x0 .. x0+7
             scharr8(R0, R1, R2, XT, YT);
             scharr8(R1, R2, R3, XB, YB);
@@ -432,10 +438,10 @@ __device__ __forceinline__ int lk_solve(const PyrGeom& G, const LkImages im, flo
                 int iv = dot3_acc(dot3_acc(1 << 8, w0, pair_at(R1, k + 1)), w1, pair_at(R2, k + 1)) >> 9;
                 int ix = dot3_acc(dot3_acc(1 << 13, w0, pair_at(XT, k)), w1, pair_at(XB, k)) >> 14;
                 int iy = dot3_acc(dot3_acc(1 << 13, w0, pair_at(YT, k)), w1, pair_at(YB, k)) >> 14;
-                if (!live) { ix = 0; iy = 0; iv = 0; }
-                tI[k] = (1 << 8) - (iv << 9);   // the iteration's accumulator start: (raw >> 9) - iv == (raw - (iv << 9)) >> 9
+                if (!live) { ix = 0; iy = 0; }   // lane 63 repeats lane 62's pixels: with zero derivatives it adds nothing to any of the five sums (its I does not matter then)
+                tI[k] = mad_i24(iv, -512, 1 << 8);   // the iteration's accumulator start 2^8 - (iv << 9): (raw >> 9) - iv == (raw - (iv << 9)) >> 9
                 tX[k] = ix; tY[k] = iy;
-                a11 += __mul24(ix, ix); a12 += __mul24(ix, iy); a22 += __mul24(iy, iy);
+                a11 = mad_i24(ix, ix, a11); a12 = mad_i24(ix, iy, a12); a22 = mad_i24(iy, iy, a22);
             }
         }
         const float FLT_SCALE = 1.f / (1 << 20);
