@@ -15,10 +15,11 @@ struct Desc { const char* src; char* dst; unsigned pitch, used, rows, esize, blk
 constexpr int kMax = 56, kBlocks = 1024;
 struct List { Desc e[kMax]; int n; };
 
-template <class V> __device__ __forceinline__ void units(const Desc& D, unsigned blk) {
+// the units (V = 16, 8, 4 or 1 bytes) thread `tid` of the descriptor's block `blk` moves; host-callable so that tests/test_copy_list_host.py can walk a list on the CPU
+template <class V> __host__ __device__ __forceinline__ void units(const Desc& D, unsigned blk, unsigned tid) {
     const unsigned upr = D.used / sizeof(V);
     const size_t total = (size_t)upr * D.rows, stride = (size_t)D.nblk * 256;
-    size_t u = (size_t)blk * 256 + threadIdx.x;
+    size_t u = (size_t)blk * 256 + tid;
     for (; u + 3 * stride < total; u += 4 * stride) {   // four loads in flight per lane before the first store
         V v[4]; size_t off[4];
 #pragma unroll
@@ -28,16 +29,18 @@ template <class V> __device__ __forceinline__ void units(const Desc& D, unsigned
     }
     for (; u < total; u += stride) { const unsigned row = (unsigned)(u / upr); const size_t off = (size_t)row * D.pitch + (u - (size_t)row * upr) * sizeof(V); *reinterpret_cast<V*>(D.dst + off) = *reinterpret_cast<const V*>(D.src + off); }
 }
-// TAG: one instantiation per translation unit that launches it (a template has vague linkage; the objects are linked into one library)
-template <int TAG> __global__ void __launch_bounds__(256) copy_list_kernel(List L) {
+// what block `block` of the launch does as thread `tid`
+__host__ __device__ __forceinline__ void block_work(const List& L, unsigned block, unsigned tid) {
     int k = 0;
-    while (k + 1 < L.n && blockIdx.x >= L.e[k + 1].blk0) k++;
+    while (k + 1 < L.n && block >= L.e[k + 1].blk0) k++;
     const Desc& D = L.e[k];
-    if (D.esize == 16) units<uint4>(D, blockIdx.x - D.blk0);
-    else if (D.esize == 8) units<uint2>(D, blockIdx.x - D.blk0);
-    else if (D.esize == 4) units<unsigned>(D, blockIdx.x - D.blk0);
-    else units<unsigned char>(D, blockIdx.x - D.blk0);
+    if (D.esize == 16) units<uint4>(D, block - D.blk0, tid);
+    else if (D.esize == 8) units<uint2>(D, block - D.blk0, tid);
+    else if (D.esize == 4) units<unsigned>(D, block - D.blk0, tid);
+    else units<unsigned char>(D, block - D.blk0, tid);
 }
+// TAG: one instantiation per translation unit that launches it (a template has vague linkage; the objects are linked into one library)
+template <int TAG> __global__ void __launch_bounds__(256) copy_list_kernel(List L) { block_work(L, blockIdx.x, threadIdx.x); }
 
 struct Builder {
     List L{}; bool ok = true; unsigned nblocks = 0; long long bytes = 0;
@@ -59,6 +62,8 @@ struct Builder {
         for (int k = 0; k < L.n; k++) { Desc& D = L.e[k]; D.blk0 = at; D.nblk = std::max(1u, (unsigned)((double)D.used * D.rows / total * want)); at += D.nblk; }
         nblocks = at;
     }
+    // the same walk on the CPU (tests only: both sides of every descriptor must be host memory)
+    void run_on_host() { finish(); for (unsigned b = 0; b < nblocks; b++) for (unsigned t = 0; t < 256; t++) block_work(L, b, t); }
     template <int TAG> hipError_t launch(hipStream_t s) {
         if (L.n == 0) return hipSuccess;
         finish();
