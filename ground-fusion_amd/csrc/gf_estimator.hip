@@ -2173,7 +2173,8 @@ struct gf_estimator_group {
     std::vector<std::string> errs;
 
     int n_threads = 1;
-    bool in_flight = false; std::vector<int> flight_seq; std::chrono::steady_clock::time_point flight_t0, t_last_done;   // a submitted step until its wait
+    bool in_flight = false; std::vector<int> flight_seq; std::chrono::steady_clock::time_point flight_t0;   // a submitted step until its wait
+    std::atomic<long long> t_last_done_ns{0};   // when a member last finished its frame (steady clock; every worker stores before it counts itself out, the waiter reads behind the count)
     std::unique_ptr<Fiber[]> fib;
 
     void run_frame(int i) {   // one member's frame (inside its fiber)
@@ -2188,7 +2189,8 @@ struct gf_estimator_group {
         rcs[i] = rc;
         if (rc != GF_OK) errs[i] = gf_last_error();
         solver.leave();
-        if (remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) { t_last_done = std::chrono::steady_clock::now(); all_done.bump(); }
+        t_last_done_ns.store(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(), std::memory_order_relaxed);
+        if (remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) all_done.bump();
     }
     static void fiber_entry(unsigned lo, unsigned hi, int i) {
         gf_estimator_group* g = reinterpret_cast<gf_estimator_group*>(((uintptr_t)hi << 32) | (uintptr_t)lo);
@@ -2378,7 +2380,7 @@ int gf_estimator_group_wait(gf_estimator_group* g) {
     // (with submit / wait apart the step's clock also contains whatever the caller did in between once the members were done: GF_GROUP_TIMING's "whole step" is
     //  the caller's view, the rendezvous clocks are the group's)
     g->t_input += std::chrono::duration<double>(std::chrono::steady_clock::now() - g->flight_t0).count();
-    g->t_tail += std::chrono::duration<double>(g->t_last_done - g->solver.t_mark).count(); g->n_steps++;
+    g->t_tail += 1e-9 * (double)(g->t_last_done_ns.load(std::memory_order_relaxed) - std::chrono::duration_cast<std::chrono::nanoseconds>(g->solver.t_mark.time_since_epoch()).count()); g->n_steps++;
     for (int i : g->flight_seq) if (g->rcs[i] != GF_OK) return gf::set_err(g->rcs[i], "sequence %d: %s", i, g->errs[i].c_str());
     return GF_OK;
 }
