@@ -15,6 +15,28 @@ struct Desc { const char* src; char* dst; unsigned pitch, used, rows, esize, blk
 constexpr int kMax = 56, kBlocks = 1024;
 struct List { Desc e[kMax]; int n; };
 
+#ifdef GF_COPY_LIST_V2
+// (prepared at the end of round 4, verified on the CPU by tests/test_copy_list_host.py, not yet run on a GPU: build with -DGF_COPY_LIST_V2 to try it)
+// The mapping without divisions: a one-row descriptor is a linear run of units; rows of a strided table go to the descriptor's blocks round-robin and a block's
+// threads walk the row.  The default mapping below finds (row, column) of a unit by a 64-bit division by the row length -- eight division sequences, 1 280
+// vector instructions for a copy kernel.
+template <class V> __host__ __device__ __forceinline__ void run_of_units(const char* src, char* dst, size_t n, size_t first, size_t step) {
+    size_t u = first;
+    for (; u + 3 * step < n; u += 4 * step) {   // four loads in flight per lane before the first store
+        V v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const V*>(src + (u + q * step) * sizeof(V));
+#pragma unroll
+        for (int q = 0; q < 4; q++) *reinterpret_cast<V*>(dst + (u + q * step) * sizeof(V)) = v[q];
+    }
+    for (; u < n; u += step) *reinterpret_cast<V*>(dst + u * sizeof(V)) = *reinterpret_cast<const V*>(src + u * sizeof(V));
+}
+template <class V> __host__ __device__ __forceinline__ void units(const Desc& D, unsigned blk, unsigned tid) {
+    const unsigned upr = D.used / sizeof(V);
+    if (D.rows == 1) { run_of_units<V>(D.src, D.dst, upr, (size_t)blk * 256 + tid, (size_t)D.nblk * 256); return; }
+    for (unsigned row = blk; row < D.rows; row += D.nblk) run_of_units<V>(D.src + (size_t)row * D.pitch, D.dst + (size_t)row * D.pitch, upr, tid, 256);
+}
+#else
 // the units (V = 16, 8, 4 or 1 bytes) thread `tid` of the descriptor's block `blk` moves; host-callable so that tests/test_copy_list_host.py can walk a list on the CPU
 template <class V> __host__ __device__ __forceinline__ void units(const Desc& D, unsigned blk, unsigned tid) {
     const unsigned upr = D.used / sizeof(V);
@@ -29,6 +51,7 @@ template <class V> __host__ __device__ __forceinline__ void units(const Desc& D,
     }
     for (; u < total; u += stride) { const unsigned row = (unsigned)(u / upr); const size_t off = (size_t)row * D.pitch + (u - (size_t)row * upr) * sizeof(V); *reinterpret_cast<V*>(D.dst + off) = *reinterpret_cast<const V*>(D.src + off); }
 }
+#endif
 // what block `block` of the launch does as thread `tid`
 __host__ __device__ __forceinline__ void block_work(const List& L, unsigned block, unsigned tid) {
     int k = 0;

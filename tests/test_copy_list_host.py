@@ -8,9 +8,13 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_copy_lists_move_every_byte_once(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("flags", [[], ["-DGF_COPY_LIST_V2"]], ids=["default mapping", "division-free mapping (prepared, off by default)"])
+def test_copy_lists_move_every_byte_once(tmp_path, flags):
     exe = tmp_path / "copy_list_host"
-    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O1", "-std=c++17", "-o", str(exe),
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O1", "-std=c++17"] + flags + ["-o", str(exe),
                            os.path.join(ROOT, "tests", "native", "copy_list_host.hip")])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     print(out.stdout[-2000:])
