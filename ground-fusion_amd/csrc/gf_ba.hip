@@ -31,7 +31,23 @@ namespace gf { int set_err(int code, const char* fmt, ...); }
 
 using namespace gfb;
 
+// GF_BA_POISON=4 (debugging aid, round 5): fresh device buffers start as PLAUSIBLE stale data -- what hipMalloc hands back behind another handle of the process:
+// doubles of ordinary magnitude (zeros, +-1, values in +-10, a few small ones), ints that look like counts, indices and the -1 markers of the tables -- instead of
+// zeros.  Garbage (0x5A...) turns a stray read into NaN or a crash; plausible data turns it into a slightly different result, which is what a deployment would see.
+__global__ void ba_fill_plausible(void* p, size_t n, int is_double, unsigned seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)(i * 2654435761ull) ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        if (is_double) {
+            const int sel = h & 7;
+            const double mag = (double)((int)((h >> 8) % 20001u) - 10000) * 1e-3;
+            static_cast<double*>(p)[i] = sel == 0 ? 0.0 : sel == 1 ? 1.0 : sel == 2 ? -1.0 : sel == 3 ? mag * 1e-4 : mag;
+        } else static_cast<int*>(p)[i] = (h & 3) == 0 ? -1 : (int)((h >> 8) % 200u);
+    }
+}
+
 namespace {
+std::atomic<int> g_alloc_idx{0}, g_alloc_tix{0};
+const char* g_alloc_what = nullptr;   // the allocation statement being executed (GF_BA_ALLOC_TRACE=1 prints it next to the allocation's index: what GF_BA_POISON_RANGE counts)
 std::atomic<long long> g_up_bytes{0}, g_up_calls{0};   // host -> device traffic of this process (GF_GROUP_TIMING prints it)
 template <class T> struct Buf {  // device buffer + pinned host mirror
     T* d = nullptr; T* h = nullptr; size_t n = 0;
@@ -41,18 +57,27 @@ template <class T> struct Buf {  // device buffer + pinned host mirror
         if (hipMalloc((void**)&d, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipMalloc(%zu B) failed", count * sizeof(T));
         // GF_BA_POISON=1 (debugging aid): fresh device buffers start as 0x5A bytes (2.5e130 as a double -- finite, so that garbage x 0 stays 0 --, 1 515 870 810 as an int) instead of whatever the allocator hands back, so that a kernel reading
         // what nobody wrote shows as NaN in the results instead of as a dependence on the process's history
-        static const bool poison = getenv("GF_BA_POISON") != nullptr && atoi(getenv("GF_BA_POISON")) != 3;   // 1: device buffers and LDS, 2: device buffers only, 3: LDS only
+        static const int pmode = getenv("GF_BA_POISON") ? atoi(getenv("GF_BA_POISON")) : 0;   // 1: device buffers and LDS, 2: device buffers only, 3: LDS only, 4: device buffers with plausible stale data
+        static const bool poison = pmode != 0 && pmode != 3;
         // Every device buffer starts as zeros, explicitly: parts of them are read before anything of THIS handle wrote them (the GNSS cost part of a handle without
         // GNSS factors, rows beyond what a batch fills, ...) and hipMalloc hands back whatever the previous owner left -- zeros in a fresh process, another handle's
         // tables later in the same process (round 4: a group member and a stand-alone estimator disagreed once an earlier test had used the memory).
         bool bad = poison;
         if (const char* r = getenv("GF_BA_POISON_RANGE")) {   // "lo:hi": only the allocations lo <= index < hi of the process (to find which buffer a kernel reads unwritten)
-            static std::atomic<int> idx{0};
-            const int i = idx++, lo = atoi(r), hi = strchr(r, ':') ? atoi(strchr(r, ':') + 1) : lo + 1;
+            // one counter for every element type (a static inside this template would count doubles and ints separately, as it did in round 4)
+            const int i = g_alloc_idx++, lo = atoi(r), hi = strchr(r, ':') ? atoi(strchr(r, ':') + 1) : lo + 1;
             bad = i >= lo && i < hi;
         }
         // (hipMemset runs on the null stream and the handle's stream is non-blocking: finished here, before anybody can enqueue a copy into the buffer)
-        if (hipMemset(d, bad ? 0x5A : 0, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipMemset failed");
+        if (hipMemset(d, (bad && pmode != 4) ? 0x5A : 0, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipMemset failed");
+        if (bad && pmode == 4 && count > 0 && (std::is_same<T, double>::value || std::is_same<T, int>::value)) {
+            static std::atomic<unsigned> seed{12345u};   // (per element type; only has to differ from buffer to buffer)
+            size_t lo = 0, hi = count;   // GF_BA_POISON_ELEMS="lo:hi": only these elements of the selected allocation(s) (scripts/stale_bisect.py narrows a dependence down to an element)
+            if (const char* e = getenv("GF_BA_POISON_ELEMS")) { lo = std::min<size_t>(count, strtoull(e, nullptr, 10)); hi = strchr(e, ':') ? std::min<size_t>(count, strtoull(strchr(e, ':') + 1, nullptr, 10)) : count; }
+            if (hi > lo) ba_fill_plausible<<<dim3(256), 256, 0, nullptr>>>(reinterpret_cast<char*>(d) + lo * sizeof(T), hi - lo, std::is_same<T, double>::value ? 1 : 0, seed += 7919u);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return gf::set_err(GF_ERR_HIP, "plausible fill failed");
+        }
+        if (getenv("GF_BA_ALLOC_TRACE")) { fprintf(stderr, "gf_ba alloc %d: %s  %zu x %zu B%s\n", g_alloc_tix++, g_alloc_what ? g_alloc_what : "?", count, sizeof(T), bad ? "  [poisoned]" : ""); }
         if (host) { if (hipHostMalloc((void**)&h, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipHostMalloc failed"); memset(h, 0, std::max<size_t>(count, 1) * sizeof(T));
             void* p = nullptr; hd = hipHostGetDevicePointer(&p, h, 0) == hipSuccess ? static_cast<T*>(p) : nullptr; (void)hipGetLastError(); }
         return GF_OK;
@@ -620,7 +645,8 @@ __global__ void __launch_bounds__(256) ba_poison_lds(int ndoubles) {   // GF_BA_
     for (int i = threadIdx.x; i < ndoubles; i += 256) lds_all[i] = __longlong_as_double(-1LL);
 }
 static void poison_lds(gf_ba* h) {
-    static const bool poison = getenv("GF_BA_POISON") != nullptr && atoi(getenv("GF_BA_POISON")) != 2;
+    static const int pmode = getenv("GF_BA_POISON") ? atoi(getenv("GF_BA_POISON")) : 0;
+    static const bool poison = pmode == 1 || pmode == 3;
     if (!poison) return;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_poison_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
@@ -761,7 +787,7 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     if (Rmax + 1 > 512) { delete h; return gf::set_err(GF_ERR_INVALID, "window_size %d: reduced system (%d) exceeds 511 columns", d.W, Rmax); }
     if (d.NV > 65535) { delete h; return gf::set_err(GF_ERR_INVALID, "max_visual %d exceeds 65535", d.NV); }
     if (misc_win_lds_doubles(d.W) * sizeof(double) > 160 * 1024) { /* the sweep has no static LDS */ delete h; return gf::set_err(GF_ERR_INVALID, "window_size %d: the IMU / wheel block rows exceed LDS (window_size <= 20 in this build)", d.W); }
-#define A_(x) do { if (int rc_ = (x)) { h->release(); delete h; return rc_; } } while (0)
+#define A_(x) do { g_alloc_what = #x; if (int rc_ = (x)) { h->release(); delete h; return rc_; } } while (0)
 #define H_(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { gf::set_err(GF_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); h->release(); delete h; return GF_ERR_HIP; } } while (0)
     {   // the solver is a chain of short launches that each want every CU: its queue goes first when the tracker's kernels of the same process compete for them
         int least = 0, greatest = 0;
@@ -785,6 +811,9 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
         h->release(); delete h; return gf::set_err(GF_ERR_HIP, "allocation of solver state failed");
     }
     h->st.n = h->st0.n = B;
+    // page-locked memory is recycled inside the process like device memory: a slot that was never packed would hand the kernels the SolverState of an earlier handle
+    memset(h->st.h, 0, B * sizeof(SolverState)); memset(h->st0.h, 0, B * sizeof(SolverState));
+    H_(hipMemset(h->st.d, 0, B * sizeof(SolverState))); H_(hipMemset(h->st0.d, 0, B * sizeof(SolverState)));
     { void* p = nullptr; h->st0.hd = hipHostGetDevicePointer(&p, h->st0.h, 0) == hipSuccess ? static_cast<SolverState*>(p) : nullptr; (void)hipGetLastError(); }
     // GF_BA_UPLOAD=kernel | copies: a batch's tables through one gather kernel that reads the page-locked mirrors over the bus, or one hipMemcpy(2D)Async per table
     h->upload_kernel = !(getenv("GF_BA_UPLOAD") && !strcmp(getenv("GF_BA_UPLOAD"), "copies"));

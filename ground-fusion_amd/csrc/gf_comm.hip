@@ -38,9 +38,14 @@ Rccl& rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        void* h = dlsym(RTLD_DEFAULT, "ncclAllGather") ? RTLD_DEFAULT : nullptr;
-        if (!h) for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
-        if (!h) { r.why = std::string("RCCL is not available: ") + (dlerror() ? dlerror() : "librccl.so.1 not found"); return; }
+        // GF_RCCL_LIBRARY names the one library to take RCCL from (a site's own build; tests/test_host_code.py points it at a file that does not exist to
+        // walk the "this machine has no RCCL" path); otherwise symbols already in the process come first -- a torch process carries its own librccl
+        const char* forced = getenv("GF_RCCL_LIBRARY");
+        void* h = (!forced && dlsym(RTLD_DEFAULT, "ncclAllGather")) ? RTLD_DEFAULT : nullptr;
+        std::string last_err;
+        auto try_open = [&](const char* name) { (void)dlerror(); h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (!h) { const char* e = dlerror(); last_err = e ? e : (std::string(name) + " not found"); } return h != nullptr; };   // dlerror() clears the message it returns: read it once
+        if (!h) { if (forced) try_open(forced); else for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if (try_open(name)) break; }
+        if (!h) { r.why = std::string("RCCL is not available: ") + (last_err.empty() ? "librccl.so.1 not found" : last_err); return; }
         r.getUniqueId = (decltype(r.getUniqueId))dlsym(h, "ncclGetUniqueId");
         r.commInitRank = (decltype(r.commInitRank))dlsym(h, "ncclCommInitRank");
         r.commDestroy = (decltype(r.commDestroy))dlsym(h, "ncclCommDestroy");

@@ -71,3 +71,29 @@ def test_cpp_host_mirror_compiles_and_links(tmp_path):
     lib = os.path.join(root, "ground-fusion_amd", "lib")
     subprocess.check_call(["g++", "-std=c++17", "-I", root, str(src), "-L", lib, "-lgroundfusion_hip", "-Wl,-rpath," + lib, "-o", str(exe)])
     assert subprocess.call([str(exe)]) == 0
+
+
+def test_machine_without_rccl_gets_an_error_not_a_crash(tmp_path):
+    """gf_comm_* resolve RCCL at run time; where no librccl can be loaded every entry point must return GF_ERR_NO_DEVICE with a message (round-4 advisor: the
+    message was built from a second dlerror() call, which returns NULL -- std::string + nullptr -- and the advertised graceful path crashed).  Own process: the
+    resolution happens once per process, and GF_RCCL_LIBRARY names the only library it may try."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, ctypes as C\n"
+            "sys.path.insert(0, %r)\n"
+            "import gfamd\n"
+            "L = gfamd.lib()\n"
+            "buf = (C.c_ubyte * 128)()\n"
+            "rc = L.gf_comm_unique_id(buf)\n"
+            "msg = L.gf_last_error().decode()\n"
+            "h = C.c_void_p()\n"
+            "rc2 = L.gf_comm_create(buf, 1, 0, 0, C.byref(h))\n"
+            "print(rc, rc2, msg)\n") % os.path.join(root, "ground-fusion_amd")
+    env = dict(os.environ, GF_RCCL_LIBRARY=str(tmp_path / "no_such_librccl.so"), GF_NO_TORCH_PRELOAD="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stderr[-500:]
+    rc, rc2, msg = out.stdout.strip().split(" ", 2)
+    assert int(rc) != 0 and int(rc) == int(rc2)
+    assert "RCCL is not available" in msg and "no_such_librccl.so" in msg
