@@ -193,8 +193,8 @@ def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False, 
     member takes the same decisions; 8: staggered starts, mixed batches) -- through the batched tracker (trackImage on every camera frame) and gf_estimator_group_*
     (inputFeature -> processImage -> batched solve + marginalisation on every second frame, the reference's MULTIPLE_THREAD flow): the back end is fed by the
     tracker's own output; as in the reference the tracker (sync_process thread) and the estimators (processThread) run concurrently, one frame apart.  Returns
-    window-solves/s over the frames on which all windows are live (NON_LINEAR): wall-clock including the tracker, host bookkeeping, uploads and downloads,
-    excluding only the Python loop that hands the IMU / wheel samples to the members.
+    window-solves/s over the frames on which all windows are live (NON_LINEAR): wall-clock including the tracker, host bookkeeping, uploads and downloads; the IMU /
+    wheel samples are queued before the first frame (round 5: nothing is excluded from the clock).
     n_groups > 1: the sequences are split over that many estimator groups (gf_estimator_group_*: own back-end handle, own stream, own worker threads).  With
     `stagger` the groups alternate in which of every two camera frames is "the second one" (inputImageCnt % 2, estimator.cpp:420-428: a sequence that started one
     frame later) -- every sequence still hands every second frame of its own recording to its back end, but one group's host phase falls on the other group's batch."""
@@ -236,6 +236,18 @@ def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False, 
     glive = [False] * n_groups
     solves, frames_live, t_feed_live = 0, 0, 0.0
     live, t_start = False, None
+    # IMU / wheel samples: ALL of them are queued before the first camera frame (inputIMU / inputWheel only push into the members' buffers, estimator.cpp:318-372; a
+    # member takes the interval of a frame out of its queue when the frame arrives).  Rounds 3-4 fed them frame by frame through ~4 k ctypes calls per back-end frame
+    # and took that time out of the clock -- but with two alternating groups the OTHER group's step kept running during the excluded time (round-4 advisor): the rate
+    # was flattered.  Nothing is excluded from the clock any more.
+    for q in G:
+        lo, hi = bounds[q], bounds[q + 1]
+        for kk in range(len(st0.cam_t)):
+            t1 = list(tp[q])
+            for b in range(lo, hi):
+                t1[b % n_streams] = streams[b % n_streams].feed(members[b], kk, tp[q][b % n_streams])
+            tp[q] = t1
+        fed[q] = len(st0.cam_t) - 1
     steps_live = mixed = keyframe_votes = votes = 0
     clk = {"tracker": 0.0, "observations": 0.0, "wait_for_estimators": 0.0, "bookkeeping": 0.0}   # where the main thread's wall time goes while live [s]
     pc = time.perf_counter
@@ -300,18 +312,19 @@ def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False, 
             "newest_position_norm_m": pos, "device_preint": bool(device_preint),
             "host_hardware_threads": os.cpu_count(), "group_worker_threads": workers, "tracker_ms_per_call": trk_anatomy,
             "main_thread_ms_per_backend_frame": {k_: round(1e3 * v_ / bf, 3) for k_, v_ in clk.items()},
+            "imu_wheel_feed": "every sample queued before the first camera frame; no time is taken out of the wall clock", "t_feed_excluded_s": t_feed_live,
             "path": "gf_tracker_track_batch_device -> gf_estimator_group_submit_features / _wait (inputFeature -> processImage -> gf_ba solve + marginalise, "
                     "windows packed / uploaded / downloaded every frame)"}
 
 
 def pcie_sample(gfamd, trk, est, args, B, frames, depth, dt, step, frame_index, n_host=4, K=24):
     """The boundary as the reference states it -- trackImage(const cv::Mat&) on HOST images (feature_tracker.h:47) -- next to the device-resident loop of `value`:
-    the same step with every frame (gray u8 + depth u16, 921 600 B per sequence) coming from page-locked host memory through gf_tracker_prefetch_batch /
-    gf_tracker_track_prefetched, i.e. the copy of frame k + 1 on a copy stream under frame k's kernels.  Reports the step both ways, the tracker alone both ways,
+    the same step with every frame (gray u8 + depth u16) coming from page-locked host memory through gf_tracker_prefetch_batch / gf_tracker_track_prefetched, i.e.
+    the copy of frame k + 1's gray image (307 200 B per sequence) on a copy stream under frame k's kernels; the depth image stays on the host, where the tracker samples it.  Reports the step both ways, the tracker alone both ways,
     and the bus rate the copies reached: where the copy is longer than the kernels the path is bound by the bus and that bound is the number."""
     hg = [frames[frame_index(i)].cpu().pin_memory() for i in range(n_host)]     # a ring of n_host frames x B sequences
     hd = depth.cpu().pin_memory()
-    bytes_per_step = B * H * W * 3
+    bytes_per_step = B * H * W      # round 5: only the gray image travels; the depth image's <= max_cnt samples per sequence are taken on the host (feature_tracker.cpp:360)
 
     def run(host, backend):
         torch.cuda.synchronize()
@@ -337,10 +350,10 @@ def pcie_sample(gfamd, trk, est, args, B, frames, depth, dt, step, frame_index, 
 
     # a plain copy of one step's images, alone on the bus: what the host delivers
     torch.cuda.synchronize()
-    dg, dd = torch.empty_like(frames[0]), torch.empty_like(depth)
+    dg = torch.empty_like(frames[0])
     t0 = time.perf_counter()
     for i in range(8):
-        dg.copy_(hg[i % n_host], non_blocking=True); dd.copy_(hd, non_blocking=True)
+        dg.copy_(hg[i % n_host], non_blocking=True)
     torch.cuda.synchronize()
     t_copy = (time.perf_counter() - t0) / 8
     run(True, False); run(False, False)       # warm: second pair of frame buffers, copy stream
@@ -353,8 +366,47 @@ def pcie_sample(gfamd, trk, est, args, B, frames, depth, dt, step, frame_index, 
             "window_solves_per_s": {"device_resident": B / t_dev, "host_images": B / t_host},
             "host_over_device": t_dev / t_host,
             "bound": "bus" if t_copy > 0.9 * t_host else "kernels",
-            "note": "host_images: gray + depth of every sequence cross PCIe every frame (gf_tracker_prefetch_batch: the copy of frame k + 1 runs under the kernels of frame k); "
+            "note": "host_images: the gray image of every sequence crosses PCIe every frame (gf_tracker_prefetch_batch: the copy of frame k + 1 runs under the kernels of frame k), the depth image is sampled on the host; "
                     "when h2d_copy_alone_ms exceeds the device-resident step the path is bound by the bus, not by the kernels"}
+
+
+def small_batch_sample(gfamd, dev, args, WIN, GNSS, sizes=(1, 8, 64), K=40):
+    """The same step at the batch sizes BASELINE.json's other configurations name -- one sequence (configs[0] / [1] as written), 8 per GPU (configs[3]: 64 sequences
+    over 8 GPUs), 64 -- on handles of their own: ms per step (tracker frame + solve + MARGIN_OLD, device-resident inputs) and the back end alone.  The default run's
+    256 sequences are what fills the chip; these are the latency end of the same path."""
+    out = {}
+    dt = 1.0 / 15.0
+    for Bs in sizes:
+        frames, depth = make_frames(8, Bs, 5000 + Bs, dev)
+        trk = gfamd.FeatureTracker(gfamd.default_cfg(batch=Bs, max_cnt=args.max_cnt, min_dist=args.min_dist))
+        est, wins = make_windows(gfamd, Bs, 5000 + Bs, args.max_cnt, WIN, GNSS, args.distinct)
+        est.upload(wins)
+        fb = Bs * H * W
+
+        def fi(k):
+            m = k % 14
+            return m if m < 8 else 14 - m
+
+        def run(n, tracker=True, backend=True, k0=0):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                if backend:
+                    est.solve_resident_async(args.ba_iters, 0, True)
+                if tracker:
+                    trk.trackImageBatchDevice([dt * (k0 + i)] * Bs, frames.data_ptr() + fi(k0 + i) * fb, depth.data_ptr(), unpack=False)
+                if backend:
+                    est.wait()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
+        run(4)
+        t_step = run(K, k0=4)
+        t_be = run(K, tracker=False)
+        t_tr = run(K, backend=False, k0=4 + K)
+        out[str(Bs)] = {"ms_per_step": 1e3 * t_step, "window_solves_per_s": Bs / t_step, "backend_alone_ms": 1e3 * t_be, "tracker_alone_ms": 1e3 * t_tr}
+        trk.close(); est.close()
+        del frames, depth
+    return out
 
 
 def main():
@@ -380,6 +432,7 @@ def main():
     ap.add_argument("--e2e-groups", type=int, default=2, help="estimator groups the end-to-end sample splits its sequences over (own handle, stream and workers each; they alternate in which camera frames reach their back ends, so one group's host phase falls on the other's batch)")
     ap.add_argument("--e2e-same-frames", action="store_true", help="with several estimator groups: all groups take the same camera frames (default: they alternate, see end_to_end_sample)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-image (PCIe-inclusive) sample")
+    ap.add_argument("--no-small-batch", action="store_true", help="skip the step times at 1 / 8 / 64 sequences")
     ap.add_argument("--e2e-device-preint", action="store_true", help="also run the end-to-end sample with the batched device pre-integration of the estimator group")
     ap.add_argument("--e2e-device-sweeps", action="store_true", help="also run the end-to-end sample with the batched device feature sweeps (triangulateWithDepth, movingConsistencyCheckW) of the estimator group")
     args = ap.parse_args()
@@ -602,6 +655,8 @@ def main():
         }
         if world == 1 and not args.no_pcie and not args.strong and not (args.no_frontend or args.no_backend):
             res["pcie_inclusive"] = pcie_sample(gfamd, trk, est, args, B, frames, depth, dt, step, frame_index)
+        if world == 1 and not args.no_small_batch and not args.strong and not (args.no_frontend or args.no_backend):
+            res["small_batch"] = small_batch_sample(gfamd, dev, args, WIN, GNSS)
         if world == 1 and not args.no_e2e and not args.strong and args.config == 1 and not (args.no_frontend or args.no_backend):
             trk.close(); trk = None
             S = max(1, args.e2e_streams)

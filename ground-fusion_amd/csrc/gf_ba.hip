@@ -77,7 +77,11 @@ template <class T> struct Buf {  // device buffer + pinned host mirror
             if (hi > lo) ba_fill_plausible<<<dim3(256), 256, 0, nullptr>>>(reinterpret_cast<char*>(d) + lo * sizeof(T), hi - lo, std::is_same<T, double>::value ? 1 : 0, seed += 7919u);
             if (hipGetLastError() != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return gf::set_err(GF_ERR_HIP, "plausible fill failed");
         }
-        if (getenv("GF_BA_ALLOC_TRACE")) { fprintf(stderr, "gf_ba alloc %d: %s  %zu x %zu B%s\n", g_alloc_tix++, g_alloc_what ? g_alloc_what : "?", count, sizeof(T), bad ? "  [poisoned]" : ""); }
+        if (getenv("GF_BA_ALLOC_TRACE")) {   // index, statement, size, and the buffer's first and last 8 bytes as they are now (what a poison mode really left there)
+            unsigned long long first = 0, last = 0; const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+            if (bytes >= 8) { (void)hipMemcpy(&first, d, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(&last, reinterpret_cast<char*>(d) + ((bytes - 8) & ~(size_t)7), 8, hipMemcpyDeviceToHost); }
+            fprintf(stderr, "gf_ba alloc %d: %s  %zu x %zu B%s  first %016llx last %016llx\n", g_alloc_tix++, g_alloc_what ? g_alloc_what : "?", count, sizeof(T), bad ? "  [poisoned]" : "", first, last);
+        }
         if (host) { if (hipHostMalloc((void**)&h, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipHostMalloc failed"); memset(h, 0, std::max<size_t>(count, 1) * sizeof(T));
             void* p = nullptr; hd = hipHostGetDevicePointer(&p, h, 0) == hipSuccess ? static_cast<T*>(p) : nullptr; (void)hipGetLastError(); }
         return GF_OK;

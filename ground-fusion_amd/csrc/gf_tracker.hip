@@ -188,6 +188,7 @@ struct gf_tracker {
     hipStream_t copy_stream = nullptr; hipEvent_t ev_copy[2] = {nullptr, nullptr};
     int pf_head = 0, pf_count = 0;   // FIFO of staged frames over the two pairs (0: d_raw / d_depth, 1: d_raw2 / d_depth2): oldest pair, number staged (0..2)
     bool pf_depth[2] = {false, false};
+    std::vector<const uint16_t*> pf_hdepth[2]; int pf_hdstride[2] = {0, 0};   // the staged frames' depth images (host; sampled by track_core, never copied)
     DevBuf<float2> d_prev_pts, d_init_pts, d_cur_pts, d_out_pts;
     DevBuf<unsigned> d_counters, d_maxkey;
     DevBuf<float> d_eig;
@@ -364,9 +365,14 @@ static void pts_velocity(SeqState& s) {  // feature_tracker.cpp:810-847
     } else for (size_t i = 0; i < n; i++) s.pts_velocity[i] = {0.f, 0.f};
 }
 
+// hdep (host entry points): the callers' depth images, one pointer per sequence, rows of hdstride pixels.  The reference reads ONE pixel of the depth image per
+// feature (feature_tracker.cpp:360 `rightImg.at<ushort>(round(y), round(x))`), and on the host-image entry points both the image and the feature coordinates are on
+// the host anyway: sampling there keeps 614 KB per frame and sequence (two thirds of an RGB-D VGA frame) off the bus.  d_depth (device entry point) keeps the sample
+// in the kernels.  Same pixel, same rounding (round half away from zero on the float coordinates), same u16.
 static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, const uint16_t* d_depth, gf_feature_obs* out, int cap_out,
-                      int* n_out) {
+                      int* n_out, const uint16_t* const* hdep = nullptr, int hdstride = 0) {
     const int B = h->B, cap = h->cap, W = h->cfg.width, H = h->cfg.height;
+    const bool have_depth = d_depth != nullptr || hdep != nullptr;
     const bool prof = h->profiling;
     h->cur_slot = h->frame & 1;
     using clk = std::chrono::steady_clock;
@@ -490,7 +496,8 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
             for (int i = 0; i < n; i++) {
                 const float2 c = h->h_cur_pts.p[(size_t)b * cap + i];
                 s.cur_pts[i] = {c.x, c.y};
-                s.cur_depth[i] = h->h_depth_out.p[(size_t)b * cap + i];
+                if (hdep) { const int ry = (int)std::round((double)c.y), rx = (int)std::round((double)c.x); s.cur_depth[i] = st[i] ? hdep[b][(size_t)ry * hdstride + rx] : (uint16_t)0; }   // st: inside the image (post checks)
+                else s.cur_depth[i] = h->h_depth_out.p[(size_t)b * cap + i];
                 lv += h->h_counters.p[2 * ((size_t)b * cap + i)];
                 it += h->h_counters.p[2 * ((size_t)b * cap + i) + 1];
             }
@@ -566,7 +573,7 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
         for (int i = 0; i < nn; i++) {
             const float2 p = h->h_out_pts.p[(size_t)b * cap + i];
             s.cur_pts.push_back({p.x, p.y}); s.ids.push_back(s.n_id++); s.track_cnt.push_back(1);
-            s.cur_depth.push_back(h->h_out_depth.p[(size_t)b * cap + i]);
+            s.cur_depth.push_back(hdep ? hdep[b][(size_t)(int)p.y * hdstride + (int)p.x] : h->h_out_depth.p[(size_t)b * cap + i]);   // corners sit on pixel centres
         }
         s.cur_un_pts.clear();
         for (auto& p : s.cur_pts) { double X, Y; lift_projective(h->cfg, (double)p.x, (double)p.y, X, Y); s.cur_un_pts.push_back({(float)(X / 1.0), (float)(Y / 1.0)}); }
@@ -576,7 +583,7 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
         const int n = (int)s.ids.size();
         // depth_cam set but no depth image: neither packing loop of the reference runs (feature_tracker.cpp:320 `depth_cam == 0`, :344 `!_img1.empty()`):
         // the returned featureFrame is empty, the tracker state has advanced all the same
-        if (h->cfg.depth_cam && !d_depth) { n_out[b] = 0; return; }
+        if (h->cfg.depth_cam && !have_depth) { n_out[b] = 0; return; }
         if (n > cap_out) { a_overflow = n; n_out[b] = 0; return; }
         gf_feature_obs* o = out + (size_t)b * cap_out;
         for (int i = 0; i < n; i++) {
@@ -656,7 +663,7 @@ int gf_tracker_create(const gf_tracker_cfg* cfg, gf_tracker** out) {
     for (auto& e : h->ev) H_(hipEventCreate(&e));
     A_(h->d_img.alloc((size_t)B * 2 * h->G.img_bytes));
     A_(h->d_raw.alloc((size_t)B * W * H));
-    A_(h->d_depth.alloc((size_t)B * W * H));
+    // (no device copy of the depth images: the host entry points sample them on the host, the device entry point reads the caller's device pointer)
     A_(h->d_mask.alloc(h->mask_stride));  // explicit masks exist only in the gf_good_features building block
     A_(h->d_eig.alloc(h->eig_stride));    // response image materialised only by gf_min_eigen_val
     A_(h->d_cand.alloc((size_t)B * h->cand_cap));
@@ -701,10 +708,8 @@ int gf_tracker_track_batch(gf_tracker* h, const double* t, const uint8_t* const*
         HIPCHK(hipMemcpy2DAsync(h->d_raw.p + (size_t)b * W * H, W, gray[b], stride, W, H, hipMemcpyHostToDevice, h->stream));
         if (have_depth && !depth[b]) have_depth = false;
     }
-    if (have_depth)
-        for (int b = 0; b < h->B; b++)
-            HIPCHK(hipMemcpy2DAsync(h->d_depth.p + (size_t)b * W * H, (size_t)W * 2, depth[b], (size_t)dstride * 2, (size_t)W * 2, H, hipMemcpyHostToDevice, h->stream));
-    return gf::track_core(h, t, h->d_raw.p, have_depth ? h->d_depth.p : nullptr, out, cap, n_out);
+    // the depth image stays where it is: its <= max_cnt samples are taken on the host (track_core)
+    return gf::track_core(h, t, h->d_raw.p, nullptr, out, cap, n_out, have_depth ? depth : nullptr, dstride);
 }
 
 // The host-image boundary (trackImage(const cv::Mat&), feature_tracker.h:47) without serialising on the bus: the images of frame k + 1 go to the second pair of
@@ -717,30 +722,24 @@ int gf_tracker_prefetch_batch(gf_tracker* h, const uint8_t* const* gray, int str
         HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
         for (auto& e : h->ev_copy) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         if (int rc = h->d_raw2.alloc((size_t)h->B * W * H)) return rc;
-        if (int rc = h->d_depth2.alloc((size_t)h->B * W * H)) return rc;
     }
     if (h->pf_count >= 2) return gf::set_err(GF_ERR_CAPACITY, "two frames are staged already: gf_tracker_track_prefetched has to consume one first");
     const int slot = (h->pf_head + h->pf_count) & 1;      // a pair no frame in flight uses: track calls return when their frame is done
     uint8_t* raw = slot ? h->d_raw2.p : h->d_raw.p;
-    uint16_t* dep = slot ? h->d_depth2.p : h->d_depth.p;
     bool have_depth = depth != nullptr;
     for (int b = 0; b < h->B; b++) {
         if (!gray[b]) return gf::set_err(GF_ERR_INVALID, "null image for sequence %d", b);
         if (have_depth && !depth[b]) have_depth = false;
     }
     // images that sit back to back in one allocation (a pinned ring of frames) go as ONE copy per plane: 256 separate 2-D copies cost more host time than the bus needs
-    bool contig = stride == W && (!have_depth || dstride == W);
-    for (int b = 1; b < h->B && contig; b++) contig = gray[b] == gray[0] + (size_t)b * W * H && (!have_depth || depth[b] == depth[0] + (size_t)b * W * H);
-    if (contig) {
-        HIPCHK(hipMemcpyAsync(raw, gray[0], (size_t)h->B * W * H, hipMemcpyHostToDevice, h->copy_stream));
-        if (have_depth) HIPCHK(hipMemcpyAsync(dep, depth[0], (size_t)h->B * W * H * 2, hipMemcpyHostToDevice, h->copy_stream));
-    } else {
-        for (int b = 0; b < h->B; b++) HIPCHK(hipMemcpy2DAsync(raw + (size_t)b * W * H, W, gray[b], stride, W, H, hipMemcpyHostToDevice, h->copy_stream));
-        if (have_depth)
-            for (int b = 0; b < h->B; b++) HIPCHK(hipMemcpy2DAsync(dep + (size_t)b * W * H, (size_t)W * 2, depth[b], (size_t)dstride * 2, (size_t)W * 2, H, hipMemcpyHostToDevice, h->copy_stream));
-    }
+    bool contig = stride == W;
+    for (int b = 1; b < h->B && contig; b++) contig = gray[b] == gray[0] + (size_t)b * W * H;
+    if (contig) HIPCHK(hipMemcpyAsync(raw, gray[0], (size_t)h->B * W * H, hipMemcpyHostToDevice, h->copy_stream));
+    else for (int b = 0; b < h->B; b++) HIPCHK(hipMemcpy2DAsync(raw + (size_t)b * W * H, W, gray[b], stride, W, H, hipMemcpyHostToDevice, h->copy_stream));
     HIPCHK(hipEventRecord(h->ev_copy[slot], h->copy_stream));
-    h->pf_depth[slot] = have_depth;
+    // the depth images do not travel: gf_tracker_track_prefetched samples them on the host (they must stay valid until it returns, like the gray images until the copy is done)
+    h->pf_depth[slot] = have_depth; if (have_depth) h->pf_hdepth[slot].assign(depth, depth + h->B); else h->pf_hdepth[slot].clear();
+    h->pf_hdstride[slot] = dstride;
     h->pf_count++;
     return GF_OK;
 }
@@ -751,7 +750,7 @@ int gf_tracker_track_prefetched(gf_tracker* h, const double* t, gf_feature_obs* 
     const int slot = h->pf_head;
     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_copy[slot], 0));
     h->pf_head ^= 1; h->pf_count--;
-    return gf::track_core(h, t, slot ? h->d_raw2.p : h->d_raw.p, h->pf_depth[slot] ? (slot ? h->d_depth2.p : h->d_depth.p) : nullptr, out, cap, n_out);
+    return gf::track_core(h, t, slot ? h->d_raw2.p : h->d_raw.p, nullptr, out, cap, n_out, h->pf_depth[slot] ? h->pf_hdepth[slot].data() : nullptr, h->pf_hdstride[slot]);
 }
 
 // page-locked host memory for frames that are handed to gf_tracker_prefetch_batch / gf_tracker_track_batch (pageable memory makes hipMemcpyAsync synchronous)

@@ -76,13 +76,16 @@ int gf_tracker_destroy(gf_tracker* h);
 int gf_tracker_track(gf_tracker* h, int seq, double t, const uint8_t* gray, int stride, const uint16_t* depth,
                      int dstride, gf_feature_obs* out, int cap, int* n_out);
 
-/* Same for all `batch` sequences in one pass; gray[b]/depth[b] are host images, out is [batch][cap]. */
+/* Same for all `batch` sequences in one pass; gray[b]/depth[b] are host images, out is [batch][cap].
+ * On the host-image entry points (gf_tracker_track, _track_batch, _prefetch_batch / _track_prefetched) the depth image never crosses the bus: the reference reads one
+ * pixel of it per feature (feature_tracker.cpp:360 `rightImg.at<ushort>(round(y), round(x))`), and those <= max_cnt samples are taken on the host from the caller's
+ * image behind the kernels (round 5: a VGA RGB-D frame costs 307 KB of PCIe traffic instead of 921 KB). */
 int gf_tracker_track_batch(gf_tracker* h, const double* t, const uint8_t* const* gray, int stride,
                            const uint16_t* const* depth, int dstride, gf_feature_obs* out, int cap, int* n_out);
 
 /* The same boundary without serialising on the bus: gf_tracker_prefetch_batch starts the host -> device copy of the NEXT frame (a second pair of frame buffers,
  * a copy stream) and returns; gf_tracker_track_prefetched runs trackImage on the OLDEST staged frame as soon as its copy has landed.  Up to two frames can
- * be staged; call order: prefetch(0), then per frame k: prefetch(k + 1), track_prefetched(k) -- the copy of k + 1 runs under the kernels of k.  The host images must stay valid until the matching track_prefetched returns; only page-locked memory (gf_host_alloc,
+ * be staged; call order: prefetch(0), then per frame k: prefetch(k + 1), track_prefetched(k) -- the copy of k + 1 runs under the kernels of k.  The host images -- the depth images in particular, which are sampled by track_prefetched itself -- must stay valid until the matching track_prefetched returns; only page-locked memory (gf_host_alloc,
  * or the caller's hipHostRegister) makes the copy overlap.  Images that lie back to back in one allocation travel as one copy per plane. */
 int gf_tracker_prefetch_batch(gf_tracker* h, const uint8_t* const* gray, int stride, const uint16_t* const* depth, int dstride);
 int gf_tracker_track_prefetched(gf_tracker* h, const double* t, gf_feature_obs* out, int cap, int* n_out);
