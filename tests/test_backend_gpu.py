@@ -458,3 +458,15 @@ def test_split_jtj_formulation_gives_the_same_bits(gf, oracle):
     st = ec.stats()
     assert st["jtj_contract_launches"] > 0 and st["ms_jtj_contract"] > 0
     ea.close(); ec.close()
+
+
+@pytest.mark.parametrize("name", ["ref_window_free_ex_td", "ref_window_with_prior"])
+def test_normal_equations_meet_the_reference_formulas_at_60_digits(gf, name):
+    """H, g, cost of a whole small window from the HIP sweeps (gf_ba_linearize) against tests/golden/ref_*.json: the reference's ProjectionTwoFrameOneCamFactor, IMUFactor,
+    MarginalizationFactor and Ceres' Huber corrector evaluated with 60 digits by tests/golden/make_ref_golden.py -- numbers neither the oracle nor the library produced"""
+    from test_golden import load_ref_window, check_against_ref
+    w, fx, H, g = load_ref_window(name)
+    est = gf.Estimator(max_features=16, max_visual=256)
+    dev = check_against_ref(est.linearize(w), fx, H, g, tol=1e-11)
+    print(name, "HIP vs reference formulas at 60 digits: H scaled %.1e, g %.1e" % dev)
+    est.close()

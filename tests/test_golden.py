@@ -102,3 +102,41 @@ def test_hip_back_end_meets_golden(gf, oracle):
     assert np.abs(g["para_Pose"] - GOLD["gnss_pose"]).max() < 1e-6 and np.abs(g["para_rcv_dt"] - GOLD["gnss_rcv_dt"]).max() < 1e-6
     assert np.abs(g["para_anc_ecef"] - GOLD["gnss_anc"]).max() < 1e-6
     eg.close()
+
+
+# ---------------------------------------------------------------- fixtures NOT made by this repo's oracle: the reference's formulas at 60 digits
+def load_ref_window(name):
+    """tests/golden/ref_*.json (tests/golden/make_ref_golden.py: ProjectionTwoFrameOneCamFactor, IMUFactor, MarginalizationFactor, HuberLoss + Corrector transcribed
+    from the reference / Ceres into mpmath, independent of oracle/ and of the product): the window and its normal equations"""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "ground-fusion_amd"))
+    import gfwindow as gw
+    with open(os.path.join(HERE, "golden", name + ".json")) as f:
+        fx = json.load(f)
+    w = gw.Window()
+    for k, v in fx["window"].items():
+        w[k] = np.array(v) if isinstance(v, list) else v
+    w.finalize()
+    n = len(fx["ids"])
+    H = np.zeros((n, n))
+    H[np.tril_indices(n)] = fx["H_lower"]
+    H = H + np.tril(H, -1).T
+    return w, fx, H, np.array(fx["g"])
+
+
+def check_against_ref(lin, fx, H, g, tol=1e-11):
+    assert [int(x) for x in lin["ids"]] == fx["ids"] and lin["n_f"] == fx["n_f"] and lin["n_e"] == fx["n_e"]
+    assert abs(lin["cost"] - fx["cost"]) <= tol * fx["cost"]
+    hs = np.sqrt(np.outer(np.abs(np.diag(H)), np.abs(np.diag(H)))) + 1e-300
+    dev_h, dev_g = float(np.abs((lin["H"] - H) / hs).max()), float(np.abs(lin["g"] - g).max() / np.abs(g).max())
+    assert dev_h < tol and dev_g < tol, (dev_h, dev_g)
+    return dev_h, dev_g
+
+
+@pytest.mark.parametrize("name", ["ref_window_free_ex_td", "ref_window_with_prior"])
+def test_oracle_meets_the_reference_formulas_at_60_digits(oracle, name):
+    """rows F1 (visual), F2 (IMU), F5 (prior), L1 (Huber corrector) of SURVEY.md 8a: the oracle's H, g, cost of a whole small window against numbers it did not produce"""
+    w, fx, H, g = load_ref_window(name)
+    dev = check_against_ref(oracle.ba_linearize(w), fx, H, g)
+    print(name, "oracle vs reference formulas at 60 digits: H scaled %.1e, g %.1e" % dev)
