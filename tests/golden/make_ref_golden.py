@@ -3,12 +3,13 @@
 Why: the oracle (oracle/backend_oracle.cpp) and the HIP kernels were written by the same hand from the same reading of the reference; the reference cannot be
 built here (no Eigen / Ceres / ROS) and ships no test vectors, so nothing tied either of them to numbers they did not produce themselves ("parity unpinned").
 This script is a third, independent evaluation route: every formula below is transcribed from the cited reference lines into exact-enough arithmetic (60
-significant digits, own quaternion / matrix algebra, no shared helper with the oracle or the product), and its output is committed as tests/golden/ref_*.json.
+significant digits, own quaternion / matrix algebra, no shared helper with the oracle or the product), and its output is committed as tests/golden/ref_*.json.gz.
 tests/test_golden.py then holds the oracle (CPU) and tests/test_backend_gpu.py the HIP path (through gf_ba_linearize) to these numbers at 1e-11.
 
 What is evaluated (paths under /root/reference/vins_estimator/src):
   factor/projectionTwoFrameOneCamFactor.cpp:43-151   residual and the five Jacobian blocks of ProjectionTwoFrameOneCamFactor::Evaluate
   factor/imu_factor.h:28-191 + factor/integration_base.h:169-195   IMUFactor::Evaluate on top of IntegrationBase::evaluate, sqrt_info = LLT(cov^-1).matrixL()^T
+  factor/wheel_factor.h:28-247 + factor/wheel_integration_base.h:180-219 + utility/sophus_utils.hpp:155-236   WheelFactor::Evaluate (all seven blocks)
   factor/marginalization_factor.cpp:344-392          MarginalizationFactor::Evaluate: r = r0 + J0 dx, dx of pose blocks 2 vec(q0^-1 q) with the sign of its w
   utility/utility.h:23-76                             deltaQ, skewSymmetric, Qleft, Qright (positify returns its argument: line 49-57)
   estimator/estimator.cpp:3269-3297                   which factors get the loss: ceres::HuberLoss(1.0) on the visual factors only
@@ -226,6 +227,108 @@ def imu_factor(Pose_i, SBi, Pose_j, SBj, pre, G):
     return sqrt_info * r, {"pi": sqrt_info * Ji, "sbi": sqrt_info * Jsi, "pj": sqrt_info * Jj, "sbj": sqrt_info * Jsj}
 
 
+# Sophus pieces the wheel factor uses (Sophus itself is not vendored by the reference; factor/wheel_factor.h includes utility/sophus_utils.hpp for the Jacobians)
+SOPHUS_EPS = mp.mpf("1e-10")        # Sophus::Constants<double>::epsilon(); epsilonSqrt() = 1e-5
+
+
+def so3_exp(v):                     # Sophus::SO3d::exp -> unit quaternion (exact exponential; Sophus switches to a Taylor series below |v|^2 < eps^2, same value to 1e-40)
+    th = mp.sqrt(v[0] ** 2 + v[1] ** 2 + v[2] ** 2)
+    if th == 0:
+        return (mp.mpf(1), mp.mpf(0), mp.mpf(0), mp.mpf(0))
+    s = mp.sin(th / 2) / th
+    return (mp.cos(th / 2), s * v[0], s * v[1], s * v[2])
+
+
+def so3_log(q):                     # Sophus::SO3d::log of the NORMALISED quaternion (SO3d(q) normalises): 2 atan(|v| / w) / |v| * v
+    q = qnormalized(q)
+    n = mp.sqrt(q[1] ** 2 + q[2] ** 2 + q[3] ** 2)
+    if n == 0:
+        return M([0, 0, 0])
+    f = 2 * mp.atan(n / q[0]) / n
+    return M([f * q[1], f * q[2], f * q[3]])
+
+
+def right_jacobian_so3(phi):        # sophus_utils.hpp:155-184
+    n2 = phi[0] ** 2 + phi[1] ** 2 + phi[2] ** 2
+    h = skew(phi); h2 = h * h
+    J = mp.eye(3)
+    if n2 > SOPHUS_EPS:
+        n = mp.sqrt(n2)
+        J = J - h * (1 - mp.cos(n)) / n2 + h2 * (n - mp.sin(n)) / (n2 * n)
+    else:
+        J = J - h / 2 + h2 / 6
+    return J
+
+
+def right_jacobian_inv_so3(phi):    # sophus_utils.hpp:195-236
+    n2 = phi[0] ** 2 + phi[1] ** 2 + phi[2] ** 2
+    h = skew(phi); h2 = h * h
+    J = mp.eye(3) + h / 2
+    if n2 > SOPHUS_EPS:
+        n = mp.sqrt(n2)
+        if n < mp.pi - mp.mpf("1e-5"):
+            J = J + h2 * (1 / n2 - (1 + mp.cos(n)) / (2 * n * mp.sin(n)))
+        else:
+            J = J + h2 / (mp.pi * mp.pi)
+    else:
+        J = J + h2 / 12
+    return J
+
+
+def wheel_factor(Pose_i, Pose_j, Exw, sx, sy, sw, td, pre):
+    """wheel_factor.h:28-247 on wheel_integration_base.h:180-219.  Blocks / local columns: pose_i 6, pose_j 6, wheel extrinsic 6, sx, sy, sw, td_wheel (1 each); O_P 0, O_R 3.
+    Returns the whitened r (6) and Jacobians."""
+    Pi, Qi = Pose_i
+    Pj, Qj = Pose_j
+    tio, qio = Exw
+    jac, cov = pre["jacobian"], pre["covariance"]                     # 6 x 3, 6 x 6
+    dp_dsx, dp_dsy, dp_dsw, dq_dsw = jac[0:3, 0], jac[0:3, 1], jac[0:3, 2], jac[3:6, 2]      # wheel_integration_base.h:186-191
+    lsx, lsy, lsw, ltd = pre["lin"]
+    lin_vel, lin_gyr, vel_1, gyr_1 = pre["lin_vel"], pre["lin_gyr"], pre["vel_1"], pre["gyr_1"]
+    dsx, dsy, dsw = sx - lsx, sy - lsy, sw - lsw                                                # :193-195
+    sv = mp.diag([sx, sy, 1])                                                                   # :196
+    Ri, Rj, rio = qmat(Qi), qmat(Qj), qmat(qio)                                                 # :198-200
+    corrected_delta_p = pre["delta_p"] + dp_dsx * dsx + dp_dsy * dsy + dp_dsw * dsw              # :202
+    corrected_delta_q = qnormalized(qmul(qnormalized(pre["delta_q"]), so3_exp(dq_dsw * dsw)))   # :203
+    dtd = td - ltd                                                                              # :204
+    e_fw = so3_exp(sw * lin_gyr * dtd)
+    delta_q_time = qnormalized(qmul(qmul(e_fw, corrected_delta_q), so3_exp(-sw * gyr_1 * dtd)))                          # :206
+    delta_p_time = qmat(e_fw) * (sv * lin_vel * dtd + corrected_delta_p - qrot(corrected_delta_q, sv * vel_1 * dtd))    # :207
+    rp = (Ri * rio).T * (Rj * tio + Pj - Ri * tio - Pi) - delta_p_time                                                    # :212
+    rr = so3_log(qmul(qmul(qmul(qinv(delta_q_time), qinv(qmul(Qi, qio))), Qj), qio))                                      # :213
+    r = M([rp[0], rp[1], rp[2], rr[0], rr[1], rr[2]])
+    sqrt_info = mp.cholesky(cov ** -1).T                                                        # wheel_factor.h:85
+    Jr_delta_q_inv = right_jacobian_inv_so3(rr)                                                 # :106-108 (raw residual)
+    drdsw = dq_dsw * (sw - lsw)
+    Jr_drdsw = right_jacobian_so3(drdsw)                                                        # :110-112
+    Qio = qmul(Qi, qio)
+    Ji, Jj, Jex = mp.zeros(6, 6), mp.zeros(6, 6), mp.zeros(6, 6)
+    setblock(Ji, 0, 0, -qmat(qinv(Qio)))                                                        # :122
+    setblock(Ji, 0, 3, (Ri * rio).T * (Ri * skew(tio)) + rio.T * skew(Ri.T * (Rj * tio + Pj - Ri * tio - Pi)))           # :124
+    setblock(Ji, 3, 3, -Jr_delta_q_inv * qmat(qmul(qinv(qmul(Qj, qio)), Qi)))                   # :133
+    setblock(Jj, 0, 0, qmat(qinv(Qio)))                                                         # :153
+    setblock(Jj, 0, 3, -qmat(qmul(qinv(Qio), Qj)) * skew(tio))                                  # :154
+    setblock(Jj, 3, 3, Jr_delta_q_inv * qmat(qinv(qio)))                                        # :160
+    setblock(Jex, 0, 0, qmat(qinv(Qio)) * (Rj - Ri))                                            # :173
+    setblock(Jex, 0, 3, skew(qrot(qinv(Qio), qrot(Qj, tio) + Pj - qrot(Qi, tio) - Pi)))         # :175
+    setblock(Jex, 3, 3, Jr_delta_q_inv * (mp.eye(3) - qmat(qmul(qmul(qinv(qmul(Qj, qio)), Qi), qio))))                   # :177
+    fcw, fcv, bcv, bcw = sw * lin_gyr * dtd, sv * lin_vel * dtd, sv * vel_1 * dtd, sw * gyr_1 * dtd                        # :184-187
+    Jrtd, Jr_minus_td = right_jacobian_so3(fcw), right_jacobian_so3(-fcw)                       # :189-192
+    I1, I2 = mp.diag([1, 0, 0]), mp.diag([0, 1, 0])                                             # :193-194
+    Rcq = qmat(corrected_delta_q)
+    Efv, Efw = qmat(so3_exp(fcv)), qmat(so3_exp(fcw))
+    Em, Ebw, Rcq_inv = qmat(so3_exp(-rr)), qmat(so3_exp(bcw)), qmat(qinv(corrected_delta_q))
+    Jsx, Jsy, Jsw, Jtd = mp.zeros(6, 1), mp.zeros(6, 1), mp.zeros(6, 1), mp.zeros(6, 1)
+    setblock(Jsx, 0, 0, -(Efv * (I1 * lin_vel * dtd + dp_dsx - Rcq * (I1 * vel_1) * dtd)))     # :199 (exp(forward_compensate_v): as written)
+    setblock(Jsy, 0, 0, -(Efv * (I2 * lin_vel * dtd + dp_dsy - Rcq * (I2 * vel_1) * dtd)))     # :211
+    setblock(Jsw, 0, 0, -(Efw * (dp_dsw - Rcq * skew(Jr_drdsw * dq_dsw) * (sv * vel_1) * dtd + skew(Jrtd * lin_gyr * dtd) * (fcv + corrected_delta_p - qrot(corrected_delta_q, bcv)))))   # :223
+    setblock(Jsw, 3, 0, -(Jr_delta_q_inv * Em * Ebw * (Rcq_inv * (Jrtd * lin_gyr) * dtd + Jr_drdsw * dq_dsw)))          # :225
+    setblock(Jtd, 0, 0, -(Efw * (sv * lin_vel - Rcq * (sv * vel_1) + skew(Jrtd * sw * lin_gyr) * (fcv + corrected_delta_p - Rcq * bcv))))   # :236
+    setblock(Jtd, 3, 0, -(Jr_delta_q_inv * Em * (Ebw * Rcq_inv * (Jrtd * sw * lin_gyr) - Jr_minus_td * sw * gyr_1)))   # :237
+    S = sqrt_info
+    return S * r, {"pi": S * Ji, "pj": S * Jj, "exw": S * Jex, "sx": S * Jsx, "sy": S * Jsy, "sw": S * Jsw, "tdw": S * Jtd}
+
+
 def prior_dx(kind_is_pose, x, x0):
     """marginalization_factor.cpp:356-372"""
     if not kind_is_pose:
@@ -299,6 +402,22 @@ def window_normal_equations(w, ids):
         r, J = imu_factor(pose[i], sb[i], pose[j], sb[j], pre, G)
         cost += (r.T * r)[0] / 2
         add(r, [(gw.bid(gw.POSE, i), J["pi"]), (gw.bid(gw.SPEEDBIAS, i), J["sbi"]), (gw.bid(gw.POSE, j), J["pj"]), (gw.bid(gw.SPEEDBIAS, j), J["sbj"])])
+    # wheel factors (estimator.cpp:3064-3080, no loss)
+    exw = pose_of(w["para_Ex_Pose_wheel"])
+    for k in range(int(w["n_wheel"])):
+        i = int(w["wh_i"][k]); j = i + 1
+        pre = {"delta_p": vec(w["wh_delta_p"][3 * k:3 * k + 3]), "delta_q": tuple(mpf(x) for x in w["wh_delta_q"][4 * k:4 * k + 4]), "jacobian": M(6, 3), "covariance": M(6, 6),
+               "lin": [mpf(x) for x in w["wh_lin"][4 * k:4 * k + 4]], "lin_vel": vec(w["wh_lin_vel"][3 * k:3 * k + 3]), "lin_gyr": vec(w["wh_lin_gyr"][3 * k:3 * k + 3]),
+               "vel_1": vec(w["wh_vel_1"][3 * k:3 * k + 3]), "gyr_1": vec(w["wh_gyr_1"][3 * k:3 * k + 3])}
+        for a in range(6):
+            for c in range(3):
+                pre["jacobian"][a, c] = mpf(w["wh_jacobian"][18 * k + 3 * a + c])
+            for c in range(6):
+                pre["covariance"][a, c] = mpf(w["wh_covariance"][36 * k + 6 * a + c])
+        r, J = wheel_factor(pose[i], pose[j], exw, mpf(w["para_Ix"][0]), mpf(w["para_Ix"][1]), mpf(w["para_Ix"][2]), mpf(w["para_Td_wheel"][0]), pre)
+        cost += (r.T * r)[0] / 2
+        add(r, [(gw.bid(gw.POSE, i), J["pi"]), (gw.bid(gw.POSE, j), J["pj"]), (gw.bid(gw.EX_WHEEL), J["exw"]), (gw.bid(gw.SX), J["sx"]), (gw.bid(gw.SY), J["sy"]), (gw.bid(gw.SW), J["sw"]),
+                (gw.bid(gw.TD_WHEEL), J["tdw"])])
     # visual factors (estimator.cpp:3269-3297, loss_function = HuberLoss(1.0))
     for k in range(int(w["n_visual"])):
         f, i, j = int(w["vis_feature"][k]), int(w["vis_i"][k]), int(w["vis_j"][k])
@@ -320,12 +439,17 @@ def main():
     import gfwindow as gw
     out_dir = HERE
     cases = [("ref_window_free_ex_td", dict(seed=7, max_features=8, n_landmarks=12, use_wheel=False, fix_ex_pose=0, fix_td=0), False),
-             ("ref_window_with_prior", dict(seed=8, max_features=10, n_landmarks=15, use_wheel=False), True)]
+             ("ref_window_with_prior", dict(seed=8, max_features=10, n_landmarks=15, use_wheel=False), True),
+             ("ref_window_wheel", dict(seed=9, max_features=6, n_landmarks=9), False),                                            # the shipped configuration: wheel extrinsic free, intrinsics / td_wheel fixed
+             ("ref_window_wheel_free_ix_td", dict(seed=10, max_features=6, n_landmarks=9, fix_ix=0, fix_td_wheel=0), False)]    # every column of the wheel factor
     for name, kw, with_prior in cases:
         seed = kw.pop("seed")
         w = SW.make_window(seed, O, **kw)
         if name == "ref_window_free_ex_td":
             w["para_Td"][0] = 0.004
+        if name == "ref_window_wheel_free_ix_td":     # away from the linearisation point of the wheel pre-integration (sx = sy = sw = 1, td = 0): every correction term is live
+            w["para_Ix"][:] = [1.013, 0.991, 1.007]
+            w["para_Td_wheel"][0] = 0.006
         if with_prior:     # the prior is input data as well: the oracle's MARGIN_OLD of the window before, renamed to this window
             w0 = SW.make_window(seed, O, **kw)
             O.ba_solve(w0, 4)
@@ -339,7 +463,7 @@ def main():
         Hd = np.array([[float(H[a, c]) for c in range(n)] for a in range(n)])
         gd = np.array([float(g[a]) for a in range(n)])
         hs = np.sqrt(np.outer(np.abs(np.diag(Hd)), np.abs(np.diag(Hd)))) + 1e-300
-        print("%s: %d columns (%d eliminated), %d visual / %d IMU factors, prior %d; cost %.17g" % (name, n, lin["n_e"], w["n_visual"], w["n_imu"], w["prior_n"], float(cost)))
+        print("%s: %d columns (%d eliminated), %d visual / %d IMU / %d wheel factors, prior %d; cost %.17g" % (name, n, lin["n_e"], w["n_visual"], w["n_imu"], w["n_wheel"], w["prior_n"], float(cost)))
         print("   oracle vs 60 digits: cost rel %.2e, H scaled %.2e, g rel %.2e" % (abs(lin["cost"] - float(cost)) / float(cost), np.abs((lin["H"] - Hd) / hs).max(),
                                                                                     np.abs(lin["g"] - gd).max() / np.abs(gd).max()))
         fx = {"about": "normal equations of a small sliding window from the reference's formulas at 60 digits (tests/golden/make_ref_golden.py); inputs = the window, "
@@ -347,9 +471,11 @@ def main():
               "window": {k: (to_list(v) if isinstance(v, np.ndarray) else v) for k, v in dict(w).items()},
               "ids": ids, "n_f": int(lin["n_f"]), "n_e": int(lin["n_e"]), "H_lower": [float(Hd[a, c]) for a in range(n) for c in range(a + 1)], "g": gd.tolist(), "cost": float(cost),
               "cost_30_digits": mp.nstr(cost, 30)}
-        with open(os.path.join(out_dir, name + ".json"), "w") as f:
-            json.dump(fx, f)
-        print("   wrote", os.path.join(out_dir, name + ".json"), os.path.getsize(os.path.join(out_dir, name + ".json")), "bytes")
+        import gzip
+        path = os.path.join(out_dir, name + ".json.gz")
+        with gzip.GzipFile(path, "wb", mtime=0) as f:      # mtime 0: the same bytes on every run
+            f.write(json.dumps(fx).encode())
+        print("   wrote", path, os.path.getsize(path), "bytes")
 
 
 if __name__ == "__main__":

@@ -460,9 +460,9 @@ def test_split_jtj_formulation_gives_the_same_bits(gf, oracle):
     ea.close(); ec.close()
 
 
-@pytest.mark.parametrize("name", ["ref_window_free_ex_td", "ref_window_with_prior"])
+@pytest.mark.parametrize("name", ["ref_window_free_ex_td", "ref_window_with_prior", "ref_window_wheel", "ref_window_wheel_free_ix_td"])
 def test_normal_equations_meet_the_reference_formulas_at_60_digits(gf, name):
-    """H, g, cost of a whole small window from the HIP sweeps (gf_ba_linearize) against tests/golden/ref_*.json: the reference's ProjectionTwoFrameOneCamFactor, IMUFactor,
+    """H, g, cost of a whole small window from the HIP sweeps (gf_ba_linearize) against tests/golden/ref_*.json.gz: the reference's ProjectionTwoFrameOneCamFactor, IMUFactor, WheelFactor,
     MarginalizationFactor and Ceres' Huber corrector evaluated with 60 digits by tests/golden/make_ref_golden.py -- numbers neither the oracle nor the library produced"""
     from test_golden import load_ref_window, check_against_ref
     w, fx, H, g = load_ref_window(name)

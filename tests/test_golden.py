@@ -106,13 +106,14 @@ def test_hip_back_end_meets_golden(gf, oracle):
 
 # ---------------------------------------------------------------- fixtures NOT made by this repo's oracle: the reference's formulas at 60 digits
 def load_ref_window(name):
-    """tests/golden/ref_*.json (tests/golden/make_ref_golden.py: ProjectionTwoFrameOneCamFactor, IMUFactor, MarginalizationFactor, HuberLoss + Corrector transcribed
+    """tests/golden/ref_*.json.gz (tests/golden/make_ref_golden.py: ProjectionTwoFrameOneCamFactor, IMUFactor, WheelFactor, MarginalizationFactor, HuberLoss + Corrector transcribed
     from the reference / Ceres into mpmath, independent of oracle/ and of the product): the window and its normal equations"""
     import json
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "ground-fusion_amd"))
     import gfwindow as gw
-    with open(os.path.join(HERE, "golden", name + ".json")) as f:
+    import gzip
+    with gzip.open(os.path.join(HERE, "golden", name + ".json.gz"), "rt") as f:
         fx = json.load(f)
     w = gw.Window()
     for k, v in fx["window"].items():
@@ -134,9 +135,12 @@ def check_against_ref(lin, fx, H, g, tol=1e-11):
     return dev_h, dev_g
 
 
-@pytest.mark.parametrize("name", ["ref_window_free_ex_td", "ref_window_with_prior"])
+REF_WINDOWS = ["ref_window_free_ex_td", "ref_window_with_prior", "ref_window_wheel", "ref_window_wheel_free_ix_td"]
+
+
+@pytest.mark.parametrize("name", REF_WINDOWS)
 def test_oracle_meets_the_reference_formulas_at_60_digits(oracle, name):
-    """rows F1 (visual), F2 (IMU), F5 (prior), L1 (Huber corrector) of SURVEY.md 8a: the oracle's H, g, cost of a whole small window against numbers it did not produce"""
+    """rows F1 (visual), F2 (IMU), F3 (wheel), F5 (prior), L1 (Huber corrector) of SURVEY.md 8a: the oracle's H, g, cost of a whole small window against numbers it did not produce"""
     w, fx, H, g = load_ref_window(name)
     dev = check_against_ref(oracle.ba_linearize(w), fx, H, g)
     print(name, "oracle vs reference formulas at 60 digits: H scaled %.1e, g %.1e" % dev)
