@@ -148,9 +148,26 @@ def pmc_summary():
     under profiles/ -- never hard-coded here.  Missing file: the fields that need it are null."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_summary.json")) as f:
-            return json.load(f)
+            S = json.load(f)
     except (OSError, ValueError):
         return {}
+    # counters describe the kernels they were collected on: a summary taken on other device code is not quoted (round-4 review: the LK kernel had changed under it)
+    now = kernel_source_sha16()
+    if S.get("kernel_source_sha16") != now:
+        return {"_stale": "profiles/pmc_summary.json was collected on kernel sources %s, this tree has %s: counter-derived fields are null (scripts/pmc_collect.sh + pmc_summarize.py refresh it)"
+                          % (S.get("kernel_source_sha16", "<unrecorded>"), now)}
+    return S
+
+
+def kernel_source_sha16():
+    """first 16 hex digits of the SHA-256 over the device / host sources of the library (ground-fusion_amd/csrc/*.hip, *.hpp, sorted by name)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ground-fusion_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".hpp")):
+            h.update(fn.encode()); h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
 
 
 _E2E_INPUTS = {}
@@ -435,7 +452,31 @@ def main():
     ap.add_argument("--no-small-batch", action="store_true", help="skip the step times at 1 / 8 / 64 sequences")
     ap.add_argument("--e2e-device-preint", action="store_true", help="also run the end-to-end sample with the batched device pre-integration of the estimator group")
     ap.add_argument("--e2e-device-sweeps", action="store_true", help="also run the end-to-end sample with the batched device feature sweeps (triangulateWithDepth, movingConsistencyCheckW) of the estimator group")
+    ap.add_argument("--e2e-only", action="store_true", help="only the end-to-end (drop-in path) sample, as one JSON line (used by the default run for its small-host sample)")
+    ap.add_argument("--host-threads", type=int, default=0, help="with --e2e-only: confine this process to the first N hardware threads (sched_setaffinity) and size the worker pools for them")
+    ap.add_argument("--no-small-host", action="store_true", help="skip the end-to-end sample on 8 hardware threads")
     args = ap.parse_args()
+
+    if args.e2e_only:
+        if args.host_threads > 0:   # the host BASELINE.md plans for: everything this process runs (tracker bookkeeping pool, group workers, Python) shares N hardware threads
+            os.sched_setaffinity(0, set(range(args.host_threads)))
+            os.environ["GF_HOST_THREADS"] = str(max(1, args.host_threads // 2))
+            os.environ["GF_GROUP_THREADS"] = str(max(1, args.host_threads // (2 * max(1, args.e2e_groups))))
+        else:
+            os.environ.setdefault("GF_HOST_THREADS", str(max(1, min(16, (os.cpu_count() or 4) // 2))))
+        import gfamd
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        gfamd._chk(gfamd.lib().gf_set_device(0))
+        S = max(1, args.e2e_streams)
+        kw = dict(n_streams=S, n_groups=args.e2e_groups, stagger=not args.e2e_same_frames)
+        cold = end_to_end_sample(gfamd, args.e2e_seqs, dev, 150, 30, **kw)
+        warm = end_to_end_sample(gfamd, args.e2e_seqs, dev, 150, 30, **kw)
+        warm["passes_window_solves_per_s"] = [cold["window_solves_per_s"], warm["window_solves_per_s"]]
+        warm["affinity_hardware_threads"] = len(os.sched_getaffinity(0))
+        warm["tracker_host_threads"] = int(os.environ["GF_HOST_THREADS"])
+        print(json.dumps(warm))
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -652,6 +693,7 @@ def main():
                               "note": "largest kernel by time; algorithmic flops = Schur SYRK NE*n_c^2 + Cholesky R^3/3 + substitutions 2R^2 per window; one block per window, "
                                       "bound by the latency of R/16 sequential 16x16 factor+inverse blocks, not by MFMA issue"},
             "ba_summary_seq0": sums[0],
+            "kernel_source_sha16": kernel_source_sha16(), "pmc_summary": pmc.get("_stale", "profiles/pmc_summary.json matches this tree's kernel sources"),
         }
         if world == 1 and not args.no_pcie and not args.strong and not (args.no_frontend or args.no_backend):
             res["pcie_inclusive"] = pcie_sample(gfamd, trk, est, args, B, frames, depth, dt, step, frame_index)
@@ -683,6 +725,18 @@ def main():
                 res["end_to_end"]["with_device_feature_sweeps_window_solves_per_s"] = alt["window_solves_per_s"]
                 res["end_to_end"]["with_device_feature_sweeps_newest_position_norm_m"] = alt["newest_position_norm_m"]
             res["end_to_end"]["first_pass_window_solves_per_s"] = cold["window_solves_per_s"]
+            if not args.no_small_host:   # the same sample with the whole process confined to 8 hardware threads (the host BASELINE.md plans for), in a process of its own
+                import subprocess
+                for ng in (1, 2):
+                    try:
+                        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--e2e-only", "--host-threads", "8", "--e2e-groups", str(ng), "--e2e-seqs", str(args.e2e_seqs),
+                                              "--e2e-streams", str(S)], capture_output=True, text=True, timeout=600)
+                        r8 = json.loads(out.stdout.strip().splitlines()[-1])
+                        res["end_to_end_8_host_threads" + ("" if ng == 1 else "_two_groups")] = {k: r8[k] for k in (
+                            "window_solves_per_s", "passes_window_solves_per_s", "sequences", "distinct_recordings", "estimator_groups", "ms_per_backend_frame", "affinity_hardware_threads",
+                            "group_worker_threads", "tracker_host_threads", "main_thread_ms_per_backend_frame", "tracker_ms_per_call")}
+                    except Exception as ex:   # the sample is a side measurement: its failure must not cost the line
+                        res["end_to_end_8_host_threads" + ("" if ng == 1 else "_two_groups")] = {"error": repr(ex)[:300]}
         if not args.no_cpu_baseline:
             nseq = min(8, B)
             cores = min(os.cpu_count() or 1, nseq)

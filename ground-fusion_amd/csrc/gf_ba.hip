@@ -34,19 +34,27 @@ using namespace gfb;
 // GF_BA_POISON=4 (debugging aid, round 5): fresh device buffers start as PLAUSIBLE stale data -- what hipMalloc hands back behind another handle of the process:
 // doubles of ordinary magnitude (zeros, +-1, values in +-10, a few small ones), ints that look like counts, indices and the -1 markers of the tables -- instead of
 // zeros.  Garbage (0x5A...) turns a stray read into NaN or a crash; plausible data turns it into a slightly different result, which is what a deployment would see.
-__global__ void ba_fill_plausible(void* p, size_t n, int is_double, unsigned seed) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+__global__ void ba_fill_plausible(void* p, size_t i0, size_t i1, int is_double, unsigned seed) {   // elements i0 <= i < i1 of the buffer at p; the content of element i does not depend on the range
+    for (size_t i = i0 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < i1; i += (size_t)gridDim.x * blockDim.x) {
         unsigned h = (unsigned)(i * 2654435761ull) ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        // Freed memory does not respect element types: a double buffer inherits int tables (two -1 markers are the bit pattern of a NaN, two small counts a denormal)
+        // and an int buffer the halves of doubles -- the read this mode was built to find (round 5) only showed behind an int table.
         if (is_double) {
             const int sel = h & 7;
             const double mag = (double)((int)((h >> 8) % 20001u) - 10000) * 1e-3;
-            static_cast<double*>(p)[i] = sel == 0 ? 0.0 : sel == 1 ? 1.0 : sel == 2 ? -1.0 : sel == 3 ? mag * 1e-4 : mag;
-        } else static_cast<int*>(p)[i] = (h & 3) == 0 ? -1 : (int)((h >> 8) % 200u);
+            double v = sel == 0 ? 0.0 : sel == 1 ? 1.0 : sel == 2 ? -1.0 : sel == 3 ? mag * 1e-4 : mag;
+            if (sel == 4) v = __longlong_as_double(-1LL);                                                                  // (-1, -1)
+            if (sel == 5) v = __longlong_as_double((long long)((h >> 8) % 200u) << 32 | (long long)((h >> 16) % 200u));     // two small ints
+            static_cast<double*>(p)[i] = v;
+        } else {
+            const int sel = h & 7;
+            static_cast<int*>(p)[i] = sel == 0 ? -1 : sel == 1 ? (int)(0x3FE00000u + ((h >> 8) & 0xFFFFFu)) : sel == 2 ? (int)(h * 2654435761u) : (int)((h >> 8) % 200u);   // markers, high / low words of doubles, counts
+        }
     }
 }
 
 namespace {
-std::atomic<int> g_alloc_idx{0}, g_alloc_tix{0};
+std::atomic<int> g_alloc_idx{0}, g_alloc_tix{0}, g_alloc_seq_ctr{0};
 const char* g_alloc_what = nullptr;   // the allocation statement being executed (GF_BA_ALLOC_TRACE=1 prints it next to the allocation's index: what GF_BA_POISON_RANGE counts)
 std::atomic<long long> g_up_bytes{0}, g_up_calls{0};   // host -> device traffic of this process (GF_GROUP_TIMING prints it)
 template <class T> struct Buf {  // device buffer + pinned host mirror
@@ -54,10 +62,11 @@ template <class T> struct Buf {  // device buffer + pinned host mirror
     T* hd = nullptr;   // the host mirror as kernels address it (page-locked memory is mapped into the device's address space), or null
     int alloc(size_t count, bool host) {
         n = count;
+        const int g_alloc_seq = g_alloc_seq_ctr++;
         if (hipMalloc((void**)&d, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipMalloc(%zu B) failed", count * sizeof(T));
         // GF_BA_POISON=1 (debugging aid): fresh device buffers start as 0x5A bytes (2.5e130 as a double -- finite, so that garbage x 0 stays 0 --, 1 515 870 810 as an int) instead of whatever the allocator hands back, so that a kernel reading
         // what nobody wrote shows as NaN in the results instead of as a dependence on the process's history
-        static const int pmode = getenv("GF_BA_POISON") ? atoi(getenv("GF_BA_POISON")) : 0;   // 1: device buffers and LDS, 2: device buffers only, 3: LDS only, 4: device buffers with plausible stale data
+        static const int pmode = getenv("GF_BA_POISON") ? atoi(getenv("GF_BA_POISON")) : 0;   // 1: device buffers and LDS, 2: device buffers only, 3: LDS only, 4: device buffers with plausible stale data, 5: device buffers full of 0xFF (every double a NaN, every int -1: a read "masked" by a multiplication with zero shows)
         static const bool poison = pmode != 0 && pmode != 3;
         // Every device buffer starts as zeros, explicitly: parts of them are read before anything of THIS handle wrote them (the GNSS cost part of a handle without
         // GNSS factors, rows beyond what a batch fills, ...) and hipMalloc hands back whatever the previous owner left -- zeros in a fresh process, another handle's
@@ -69,12 +78,17 @@ template <class T> struct Buf {  // device buffer + pinned host mirror
             bad = i >= lo && i < hi;
         }
         // (hipMemset runs on the null stream and the handle's stream is non-blocking: finished here, before anybody can enqueue a copy into the buffer)
-        if (hipMemset(d, (bad && pmode != 4) ? 0x5A : 0, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipMemset failed");
+        if (hipMemset(d, (bad && pmode != 4 && pmode != 5) ? 0x5A : 0, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return gf::set_err(GF_ERR_HIP, "hipMemset failed");
+        if (bad && pmode == 5 && count > 0) {   // 0xFF over the elements GF_BA_POISON_ELEMS names (default: all)
+            size_t lo = 0, hi = count;
+            if (const char* e = getenv("GF_BA_POISON_ELEMS")) { lo = std::min<size_t>(count, strtoull(e, nullptr, 10)); hi = strchr(e, ':') ? std::min<size_t>(count, strtoull(strchr(e, ':') + 1, nullptr, 10)) : count; }
+            if (hi > lo && (hipMemset(reinterpret_cast<char*>(d) + lo * sizeof(T), 0xFF, (hi - lo) * sizeof(T)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)) return gf::set_err(GF_ERR_HIP, "hipMemset failed");
+        }
         if (bad && pmode == 4 && count > 0 && (std::is_same<T, double>::value || std::is_same<T, int>::value)) {
-            static std::atomic<unsigned> seed{12345u};   // (per element type; only has to differ from buffer to buffer)
+            const unsigned seed = 12345u + 7919u * (unsigned)g_alloc_seq;   // a function of the allocation's index in the process: the same content whichever other allocations are poisoned (the bisection relies on it)
             size_t lo = 0, hi = count;   // GF_BA_POISON_ELEMS="lo:hi": only these elements of the selected allocation(s) (scripts/stale_bisect.py narrows a dependence down to an element)
             if (const char* e = getenv("GF_BA_POISON_ELEMS")) { lo = std::min<size_t>(count, strtoull(e, nullptr, 10)); hi = strchr(e, ':') ? std::min<size_t>(count, strtoull(strchr(e, ':') + 1, nullptr, 10)) : count; }
-            if (hi > lo) ba_fill_plausible<<<dim3(256), 256, 0, nullptr>>>(reinterpret_cast<char*>(d) + lo * sizeof(T), hi - lo, std::is_same<T, double>::value ? 1 : 0, seed += 7919u);
+            if (hi > lo) ba_fill_plausible<<<dim3(256), 256, 0, nullptr>>>(d, lo, hi, std::is_same<T, double>::value ? 1 : 0, seed);
             if (hipGetLastError() != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return gf::set_err(GF_ERR_HIP, "plausible fill failed");
         }
         if (getenv("GF_BA_ALLOC_TRACE")) {   // index, statement, size, and the buffer's first and last 8 bytes as they are now (what a poison mode really left there)
@@ -147,7 +161,7 @@ struct gf_ba {
     // work
     Buf<double> imu_sqrt, wh_sqrt, pri_A, pri_b, pri_c, H, g, Vc, vtile, wpar, cost, efac;
     Buf<double> gather_send;   // [B][7] newest poses, send buffer of gf_pose_gather (allocated on first use)
-    hipEvent_t ev_gather = nullptr;
+    hipEvent_t ev_gather = nullptr, ev_gather_done = nullptr; bool gather_in_flight = false;   // export -> collective, and collective -> next export (the send buffer is reused)
     Buf<double> scale, diag, grad, gn, step, u, Et, Es, ete, etb, rhs, yv, Sg, Mg, gn_data, gn_misc;
     Buf<int> ngnss, gn_idx, gn_gptr, gn_gitem;
     Buf<double> gn_rows;
@@ -200,6 +214,7 @@ struct gf_ba {
         st.release(); st0.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         if (ev_gather) (void)hipEventDestroy(ev_gather);
+        if (ev_gather_done) (void)hipEventDestroy(ev_gather_done);
         for (auto& e : ev_split) if (e) (void)hipEventDestroy(e);
         vrows.release(); vpair.release();
         gather_send.release();
@@ -802,6 +817,7 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     }
     for (auto& e : h->ev) H_(hipEventCreate(&e));
     H_(hipEventCreateWithFlags(&h->ev_gather, hipEventDisableTiming));
+    H_(hipEventCreateWithFlags(&h->ev_gather_done, hipEventDisableTiming));
     const size_t B = d.B, VS = d.RP + d.FP;
     A_(h->xs0.alloc(B * d.XS, true)); A_(h->xs.alloc(2 * B * d.XS, true));
     A_(h->colf.alloc(B * d.NFB, true)); A_(h->cole.alloc(B * d.F, true)); A_(h->nvis.alloc(B, true)); A_(h->nimu.alloc(B, true)); A_(h->nwh.alloc(B, true)); A_(h->nfeat.alloc(B, true));
@@ -846,7 +862,7 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     if (!h->big_step) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_step<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->step_lds));
     // GF_BA_STEP_WAVES=4: ba_step on four wavefronts (half of a CU's registers) so that other kernels' blocks -- the tracker's -- can sit next to it; one setting per
     // process (the reductions' order depends on it: a window alone and the same window in a batch must run the same variant)
-    if (getenv("GF_BA_SPLIT_JTJ") && atoi(getenv("GF_BA_SPLIT_JTJ"))) if (int rc = gf_ba_set_split_jtj(h, 1)) return rc;
+    if (getenv("GF_BA_SPLIT_JTJ") && atoi(getenv("GF_BA_SPLIT_JTJ"))) if (int rc = gf_ba_set_split_jtj(h, 1)) { h->release(); delete h; return rc; }
     h->step_waves = (getenv("GF_BA_STEP_WAVES") && atoi(getenv("GF_BA_STEP_WAVES")) == 4) ? 4 : 8;
     if (h->step_waves == 4 && !h->big_step) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_step<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->step_lds));
     // GF_BA_FUSE_MISC=1: the candidate's prior / IMU / wheel sweep in front of the step that judges it, one launch (ba_misc_step).  Same bits; measured 163 us against
@@ -1198,6 +1214,8 @@ int gf_ba_export_newest_poses(gf_ba* h, void* d_out, int count) {
 int gf_pose_gather(gf_ba* h, void* nccl_comm, void* stream, int count, double* d_out) {
     if (!h || !nccl_comm || !d_out || count < 1 || count > h->d.B) return gf::set_err(GF_ERR_INVALID, "bad argument");
     if (!h->gather_send.d) { if (int rc = h->gather_send.alloc((size_t)h->d.B * 7, false)) return rc; HIPCHK(hipMemsetAsync(h->gather_send.d, 0, (size_t)h->d.B * 7 * sizeof(double), h->stream)); }
+    // the send buffer is persistent: the export of THIS call must not overtake the collective of the previous one, which reads it on the caller's stream
+    if (h->gather_in_flight) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_gather_done, 0)); h->gather_in_flight = false; }
     // ranks must pass the same count (ncclAllGather): a rank with fewer resident windows sends zero rows behind its own
     const int mine = std::min(count, h->count);
     if (mine > 0) { ba_export_newest<<<dim3((mine + 63) / 64), 64, 0, h->stream>>>(h->win(), h->gather_send.d, mine); HIPCHK(hipGetLastError()); }
@@ -1206,7 +1224,9 @@ int gf_pose_gather(gf_ba* h, void* nccl_comm, void* stream, int count, double* d
         HIPCHK(hipEventRecord(h->ev_gather, h->stream));
         HIPCHK(hipStreamWaitEvent(static_cast<hipStream_t>(stream), h->ev_gather, 0));
     }
-    return gf::rccl_allgather_f64(h->gather_send.d, d_out, (size_t)count * 7, nccl_comm, stream);
+    if (int rc = gf::rccl_allgather_f64(h->gather_send.d, d_out, (size_t)count * 7, nccl_comm, stream)) return rc;
+    if (stream != (void*)h->stream) { HIPCHK(hipEventRecord(h->ev_gather_done, static_cast<hipStream_t>(stream))); h->gather_in_flight = true; }
+    return GF_OK;
 }
 
 int gf_ba_set_split_jtj(gf_ba* h, int on) {

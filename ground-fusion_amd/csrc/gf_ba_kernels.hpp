@@ -456,6 +456,9 @@ __global__ void __launch_bounds__(256) ba_setup(Win w) {
         for (int a = threadIdx.x; a < n; a += 256) { double s = 0; for (int k2 = 0; k2 < n; k2++) s += J[(size_t)k2 * n + a] * r[k2]; w.pri_b[(size_t)b * d.NPRI + a] = s; }
         if (threadIdx.x == 0) { double s = 0; for (int k2 = 0; k2 < n; k2++) s += r[k2] * r[k2]; w.pri_c[b] = s; }
     }
+#ifndef GF_TEST_REINTRODUCE_PRI_C_READ
+    else if (threadIdx.x == 0) w.pri_c[b] = 0.0;   // no prior: a defined value all the same (its one reader does not look at it then)
+#endif
 }
 
 // IMUFactor::Evaluate (imu_factor.h:28-191) + IntegrationBase::evaluate (integration_base.h:169-195): raw (un-whitened) residual and Jacobian.
@@ -1274,7 +1277,14 @@ __device__ __forceinline__ void ba_linearize_misc_body(Win w, int which, int whi
         }
     }
     if (tid == 0) {
+        // A window without a prior has no r0^T r0: ba_setup writes pri_c only for n > 0, so the value must not be READ here (rounds 1-4 multiplied it by zero --
+        // 0.5 * pri_c[b] * (n > 0 ? 1 : 0) -- which is NaN when the allocation still holds a NaN bit pattern, e.g. the -1 markers of a freed handle's int table:
+        // the cost went NaN and the trust-region logic took another path.  Located in round 5: DESIGN.md section 2.)
+#ifdef GF_TEST_REINTRODUCE_PRI_C_READ   // self-test of the stale-memory tooling only (scripts/stale_bisect.py must name pri_c on a library built with this)
         double c = 0.5 * w.pri_c[b] * (n > 0 ? 1.0 : 0.0);
+#else
+        double c = n > 0 ? 0.5 * w.pri_c[b] : 0.0;
+#endif
         for (int q = 2; q < kMW; q++) c += s_wc[q];
         for (int k = 0; k < nimu; k++) c += s_fcost[k];
         for (int k = 0; k < nwh; k++) c += s_fcost[32 + k];

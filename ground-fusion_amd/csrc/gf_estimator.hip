@@ -124,6 +124,7 @@ struct FeaturePerId {
 
 struct FeatureManager {
     std::list<FeaturePerId> feature;
+    bool ascending = true;   // `feature` is ascending in feature_id (see addFeatureCheckParallax)
     int last_track_num = 0, new_feature_num = 0, long_track_num = 0;
     double last_average_parallax = 0;
     int WINDOW_SIZE = 10; double FOCAL_LENGTH = 600, MIN_PARALLAX = 10.0 / 600, INIT_DEPTH = 5, depth_threshold = 3;
@@ -144,12 +145,25 @@ struct FeatureManager {
     bool addFeatureCheckParallax(int frame_count, const gf_feature_obs* obs, int n, double td) {  // FM:57-116; `obs` sorted by id (std::map order)
         double parallax_sum = 0; int parallax_num = 0;
         last_track_num = 0; last_average_parallax = 0; new_feature_num = 0; long_track_num = 0;
+        // The reference looks every observation up with find_if over the list (FM:68-72): O(tracks) per observation.  The list is in insertion order, and a tracker hands
+        // out ascending ids (feature_tracker.cpp:85-93), so the list is normally ascending in feature_id like the frame (std::map order): one merge walk finds the same
+        // elements.  `ascending` is given up -- for good, the find_if route takes over -- the moment an id is appended behind a larger one (callers with ids of their own).
+        auto hint = feature.begin();
+        long long prev_id = -(1LL << 40);
         for (int k = 0; k < n; k++) {
             const double* p = obs[k].v;
             FeaturePerFrame f{v3(p[0], p[1], p[2]), {p[3], p[4]}, {p[5], p[6]}, p[7], td};
             const int feature_id = obs[k].id;
-            auto it = std::find_if(feature.begin(), feature.end(), [feature_id](const FeaturePerId& x) { return x.feature_id == feature_id; });
-            if (it == feature.end()) { feature.emplace_back(feature_id, frame_count); feature.back().feature_per_frame.push_back(f); new_feature_num++; }
+            std::list<FeaturePerId>::iterator it;
+            if (ascending && feature_id > prev_id) {
+                while (hint != feature.end() && hint->feature_id < feature_id) ++hint;
+                it = (hint != feature.end() && hint->feature_id == feature_id) ? hint : feature.end();
+            } else it = std::find_if(feature.begin(), feature.end(), [feature_id](const FeaturePerId& x) { return x.feature_id == feature_id; });
+            prev_id = feature_id;
+            if (it == feature.end()) {
+                if (!feature.empty() && feature.back().feature_id > feature_id) ascending = false;
+                feature.emplace_back(feature_id, frame_count); feature.back().feature_per_frame.push_back(f); new_feature_num++;
+            }
             else { it->feature_per_frame.push_back(f); last_track_num++; if (it->feature_per_frame.size() >= 4) long_track_num++; }
         }
         if (frame_count < 2 || last_track_num < 20 || long_track_num < 40 || new_feature_num > 0.5 * last_track_num) return true;

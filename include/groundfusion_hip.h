@@ -87,6 +87,8 @@ int gf_tracker_track_batch(gf_tracker* h, const double* t, const uint8_t* const*
  * a copy stream) and returns; gf_tracker_track_prefetched runs trackImage on the OLDEST staged frame as soon as its copy has landed.  Up to two frames can
  * be staged; call order: prefetch(0), then per frame k: prefetch(k + 1), track_prefetched(k) -- the copy of k + 1 runs under the kernels of k.  The host images -- the depth images in particular, which are sampled by track_prefetched itself -- must stay valid until the matching track_prefetched returns; only page-locked memory (gf_host_alloc,
  * or the caller's hipHostRegister) makes the copy overlap.  Images that lie back to back in one allocation travel as one copy per plane. */
+/* One caller thread per tracker handle: prefetch / track_prefetched keep an unsynchronised two-slot FIFO, like every other gf_tracker_* entry point they must not
+ * be called concurrently on the same handle. */
 int gf_tracker_prefetch_batch(gf_tracker* h, const uint8_t* const* gray, int stride, const uint16_t* const* depth, int dstride);
 int gf_tracker_track_prefetched(gf_tracker* h, const double* t, gf_feature_obs* out, int cap, int* n_out);
 int gf_host_alloc(size_t bytes, void** out);

@@ -96,6 +96,14 @@ except OSError:
 for k, name in (("gf::lk_track_kernel", "lk_track_kernel_sq"), ("gf::detect_strip_kernel<30>", "detect_strip_kernel_sq")):
     if k in tsq:
         S[name] = sq(tsq, k)
+# which device code the counters describe: bench.py quotes them only while the library's sources still hash to this (same function as bench.kernel_source_sha16)
+import hashlib
+_h = hashlib.sha256()
+_d = os.path.join(R, "ground-fusion_amd", "csrc")
+for _fn in sorted(os.listdir(_d)):
+    if _fn.endswith((".hip", ".hpp")):
+        _h.update(_fn.encode()); _h.update(open(os.path.join(_d, _fn), "rb").read())
+S["kernel_source_sha16"] = _h.hexdigest()[:16]
 json.dump(S, open(os.path.join(R, "profiles", "pmc_summary.json"), "w"), indent=1)
 for n in ("calib_fetch", "tracker_fetch", "tracker_write", "tracker_sq", "backend_sq", "backend_sq2") + (("backend_fetch", "backend_write") if bf else ()):
     for ext in ("csv", "info"):

@@ -66,12 +66,18 @@ def main():
         say("  %-12s %s" % (nm, pois[nm]))
     garb, _ = run(names, GF_BA_POISON=2)
     say("== 0x5A garbage in every fresh device buffer (GF_BA_POISON=2): moved:", [nm for nm in names if garb[nm] != ref[nm]] or "nothing")
+    nan, _ = run(names, GF_BA_POISON=5)
+    moved5 = [nm for nm in names if nan[nm] != ref[nm]]
+    say("== 0xFF (NaN / -1) in every fresh device buffer (GF_BA_POISON=5): moved:", moved5 or "nothing")
+    PM = 4
+    if moved5 and not moved:
+        moved, PM = moved5, 5
 
     for nm in moved:
         if left() < 60:
             say("budget spent before", nm)
             break
-        _, err = run([nm], GF_BA_POISON=4, GF_BA_POISON_RANGE="100000:100001", GF_BA_ALLOC_TRACE=1)
+        _, err = run([nm], GF_BA_POISON=PM, GF_BA_POISON_RANGE="100000:100001", GF_BA_ALLOC_TRACE=1)
         allocs = [ln for ln in err.splitlines() if ln.startswith("gf_ba alloc")]
         n = len(allocs)
         say("== bisecting %s over %d allocations" % (nm, n))
@@ -80,7 +86,7 @@ def main():
         def rec(lo, hi):
             if left() < 30 or len(bad) >= 6:
                 return
-            r, _ = run([nm], GF_BA_POISON=4, GF_BA_POISON_RANGE="%d:%d" % (lo, hi))
+            r, _ = run([nm], GF_BA_POISON=PM, GF_BA_POISON_RANGE="%d:%d" % (lo, hi))
             if r[nm] == ref[nm]:
                 return
             if hi - lo == 1:
@@ -98,7 +104,7 @@ def main():
                 continue
 
             def differs(lo, hi):
-                r, _ = run([nm], GF_BA_POISON=4, GF_BA_POISON_RANGE="%d:%d" % (i, i + 1), GF_BA_POISON_ELEMS="%d:%d" % (lo, hi))
+                r, _ = run([nm], GF_BA_POISON=PM, GF_BA_POISON_RANGE="%d:%d" % (i, i + 1), GF_BA_POISON_ELEMS="%d:%d" % (lo, hi))
                 return r[nm] != ref[nm]
             for prefer_left in (True, False):
                 lo, hi = 0, count

@@ -51,8 +51,32 @@ static void replay_one(const char* config, const std::string& source, bool from_
                node.n_thrown1, node.n_gnss, (int)estimator.solver_flag, out.c_str());
 }
 
-// one rank of `gf_replay --ranks N`: its share of the recordings, then the pose exchange
-static int run_rank(int rank, int world, const char* config, const std::vector<std::string>& dirs, const std::string& idfile) {
+// Eigen::Quaterniond(R) (Eigen/src/Geometry/Quaternion.h, QuaternionBase::operator=(MatrixBase)): the branch on the trace and, for a non-positive trace, on the
+// largest diagonal entry -- a ground vehicle that has turned around has trace(R) < 0
+static void quat_from_R(const double* R, double* q /* x y z w */) {
+    const double t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        double s = std::sqrt(t + 1.0);
+        q[3] = 0.5 * s; s = 0.5 / s;
+        q[0] = (R[7] - R[5]) * s; q[1] = (R[2] - R[6]) * s; q[2] = (R[3] - R[1]) * s;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        double s = std::sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+        q[i] = 0.5 * s; s = 0.5 / s;
+        q[3] = (R[3 * k + j] - R[3 * j + k]) * s;
+        q[j] = (R[3 * j + i] + R[3 * i + j]) * s;
+        q[k] = (R[3 * k + i] + R[3 * i + k]) * s;
+    }
+}
+
+// one rank of `gf_replay --ranks N`: its share of the recordings, then the pose exchange.  The unique id of the communicator arrives over a pipe the parent opened
+// before the fork (rank 0 writes world - 1 copies, every other rank reads its own): no file name in /tmp that somebody else could have created first.
+static int run_rank(int rank, int world, const char* config, const std::vector<std::string>& dirs, int id_read_fd, const std::vector<int>& id_write_fds) {
+    gf_comm* comm = nullptr;
+    int failed = 0;
     try {
         int ndev = 0;
         if (gf_device_count(&ndev) != GF_OK || ndev < 1) throw std::runtime_error("no HIP device");
@@ -62,25 +86,25 @@ static int run_rank(int rank, int world, const char* config, const std::vector<s
         unsigned char id[128];
         if (rank == 0) {
             if (gf_comm_unique_id(id) != GF_OK) throw std::runtime_error(gf_last_error());
-            const std::string tmp = idfile + ".tmp";
-            FILE* f = fopen(tmp.c_str(), "wb");
-            if (!f || fwrite(id, 1, 128, f) != 128) throw std::runtime_error("cannot write " + tmp);
-            fclose(f);
-            if (rename(tmp.c_str(), idfile.c_str()) != 0) throw std::runtime_error("cannot publish " + idfile);
+            for (int fd : id_write_fds) if (write(fd, id, 128) != 128) throw std::runtime_error("cannot hand the unique id to a rank");
         } else {
-            FILE* f = nullptr;
-            for (int tries = 0; tries < 1200 && !(f = fopen(idfile.c_str(), "rb")); tries++) usleep(50000);
-            if (!f || fread(id, 1, 128, f) != 128) throw std::runtime_error("rank " + std::to_string(rank) + ": no unique id from rank 0");
-            fclose(f);
+            size_t got = 0;
+            while (got < 128) { const ssize_t n = read(id_read_fd, id + got, 128 - got); if (n <= 0) throw std::runtime_error("rank " + std::to_string(rank) + ": no unique id from rank 0"); got += (size_t)n; }
         }
-        gf_comm* comm = nullptr;
         if (gf_comm_create(id, world, rank, device, &comm) != GF_OK) throw std::runtime_error(gf_last_error());
-        const int rounds = ((int)dirs.size() + world - 1) / world;
-        std::vector<double> all((size_t)world * 8);
-        for (int j = 0; j < rounds; j++) {
-            const int k = j * world + rank;
-            double mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // px py pz qx qy qz qw, then 1 when this rank had a sequence in this round
-            if (k < (int)dirs.size()) {
+    } catch (const std::exception& e) {
+        fprintf(stderr, "gf_replay rank %d: %s\n", rank, e.what());
+        return 1;      // before the communicator exists nobody waits for this rank inside a collective (ncclCommInitRank of the others fails or times out with it)
+    }
+    const int rounds = ((int)dirs.size() + world - 1) / world;
+    std::vector<double> all((size_t)world * 8);
+    for (int j = 0; j < rounds; j++) {
+        const int k = j * world + rank;
+        double mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // px py pz qx qy qz qw, then 1: this rank had a sequence in this round, -1: it failed on it
+        if (k < (int)dirs.size()) {
+            // a rank whose replay throws (missing directory, bad recording, estimator error) still takes part in this and every later exchange: the others would
+            // otherwise block inside ncclAllGather for good (round-4 advisor)
+            try {
                 gf::Estimator estimator;
                 replay_one(config, dirs[k], false, dirs[k] + "/vio.txt", estimator, true);
                 // the state straight from the handle: the class mirrors it after inputImage, and the last frame is processed when the IMU samples behind it arrive
@@ -88,27 +112,26 @@ static int run_rank(int rank, int world, const char* config, const std::vector<s
                 std::vector<double> Pa(3 * N), Ra(9 * N), Va(3 * N), Baa(3 * N), Bga(3 * N), Ha(N);
                 int info[16]; double extr[32];
                 if (gf_estimator_get_state(estimator.handle(), Pa.data(), Ra.data(), Va.data(), Baa.data(), Bga.data(), Ha.data(), info, extr) != GF_OK) throw std::runtime_error(gf_last_error());
-                const double* R = Ra.data() + 9 * W;
-                const double t = R[0] + R[4] + R[8];
-                double q[4] = {0, 0, 0, 1};                   // Eigen::Quaterniond(R) for trace > 0 (a ground vehicle near its start attitude); else left as the identity
-                if (t > 0) { const double s = std::sqrt(t + 1.0) * 2.0; q[3] = 0.25 * s; q[0] = (R[7] - R[5]) / s; q[1] = (R[2] - R[6]) / s; q[2] = (R[3] - R[1]) / s; }
                 for (int c = 0; c < 3; c++) mine[c] = Pa[3 * W + c];
-                for (int c = 0; c < 4; c++) mine[3 + c] = q[c];
+                quat_from_R(Ra.data() + 9 * W, mine + 3);
                 mine[7] = 1.0;
+            } catch (const std::exception& e) {
+                fprintf(stderr, "gf_replay rank %d: sequence %d (%s): %s\n", rank, k, dirs[k].c_str(), e.what());
+                for (double& v : mine) v = 0.0;
+                mine[7] = -1.0; failed = 1;
             }
-            if (gf_comm_allgather_f64(comm, mine, 8, all.data()) != GF_OK) throw std::runtime_error(gf_last_error());
-            if (rank == 0)
-                for (int r = 0; r < world; r++)
-                    if (all[(size_t)r * 8 + 7] != 0.0)
-                        printf("gf_replay: sequence %d (rank %d): newest pose %.9f %.9f %.9f %.9f %.9f %.9f %.9f\n", j * world + r, r, all[r * 8 + 0], all[r * 8 + 1], all[r * 8 + 2],
-                               all[r * 8 + 3], all[r * 8 + 4], all[r * 8 + 5], all[r * 8 + 6]);
         }
-        gf_comm_destroy(comm);
-    } catch (const std::exception& e) {
-        fprintf(stderr, "gf_replay rank %d: %s\n", rank, e.what());
-        return 1;
+        if (gf_comm_allgather_f64(comm, mine, 8, all.data()) != GF_OK) { fprintf(stderr, "gf_replay rank %d: %s\n", rank, gf_last_error()); failed = 1; break; }
+        if (rank == 0)
+            for (int r = 0; r < world; r++) {
+                if (all[(size_t)r * 8 + 7] > 0.0)
+                    printf("gf_replay: sequence %d (rank %d): newest pose %.9f %.9f %.9f %.9f %.9f %.9f %.9f\n", j * world + r, r, all[r * 8 + 0], all[r * 8 + 1], all[r * 8 + 2],
+                           all[r * 8 + 3], all[r * 8 + 4], all[r * 8 + 5], all[r * 8 + 6]);
+                else if (all[(size_t)r * 8 + 7] < 0.0) { printf("gf_replay: sequence %d (rank %d): FAILED\n", j * world + r, r); failed = 1; }
+            }
     }
-    return 0;
+    gf_comm_destroy(comm);
+    return failed;
 }
 
 int main(int argc, char** argv) {
@@ -116,22 +139,28 @@ int main(int argc, char** argv) {
         const int world = atoi(argv[2]);
         if (world < 1 || world > 64) { fprintf(stderr, "gf_replay: --ranks must be in 1..64\n"); return 2; }
         std::vector<std::string> dirs(argv + 4, argv + argc);
-        char idfile[] = "/tmp/gf_replay_id_XXXXXX";
-        const int fd = mkstemp(idfile);
-        if (fd < 0) { perror("mkstemp"); return 1; }
-        close(fd);
-        unlink(idfile);                                      // rank 0 publishes the id under this name
+        {   // more ranks than devices put two ranks on one GPU, which RCCL refuses ("Duplicate GPU"): say so instead of failing inside ncclCommInitRank
+            // (GF_REPLAY_ALLOW_SHARED_DEVICE=1 tries anyway: some RCCL builds accept it)
+            const pid_t probe = fork();   // the device count from a child: the parent must not touch the HIP runtime before it forks the ranks
+            if (probe == 0) { int n = 0; _exit(gf_device_count(&n) == GF_OK ? std::min(n, 200) : 0); }
+            int st = 0; waitpid(probe, &st, 0);
+            const int ndev = WIFEXITED(st) ? WEXITSTATUS(st) : 0;
+            if (ndev < 1) { fprintf(stderr, "gf_replay: no HIP device\n"); return 1; }
+            if (world > ndev && !getenv("GF_REPLAY_ALLOW_SHARED_DEVICE")) { fprintf(stderr, "gf_replay: --ranks %d on %d device(s): one rank per GPU (RCCL refuses two ranks on one device)\n", world, ndev); return 2; }
+        }
+        std::vector<int> rd(world, -1), wr;
+        for (int r = 1; r < world; r++) { int fds[2]; if (pipe(fds) != 0) { perror("pipe"); return 1; } rd[r] = fds[0]; wr.push_back(fds[1]); }
         std::vector<pid_t> kids;
         for (int r = 0; r < world; r++) {                    // fork before anything touches the HIP runtime: every rank initialises its own
             const pid_t p = fork();
             if (p < 0) { perror("fork"); return 1; }
-            if (p == 0) { const int rc = run_rank(r, world, argv[3], dirs, idfile); fflush(nullptr); _exit(rc); }   // _exit: the parent's atexit handlers are not this child's
-
+            if (p == 0) { const int rc = run_rank(r, world, argv[3], dirs, rd[r], r == 0 ? wr : std::vector<int>()); fflush(nullptr); _exit(rc); }   // _exit: the parent's atexit handlers are not this child's
             kids.push_back(p);
         }
+        for (int fd : rd) if (fd >= 0) close(fd);
+        for (int fd : wr) close(fd);
         int rc = 0;
         for (pid_t p : kids) { int st = 0; waitpid(p, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 1; }
-        unlink(idfile);
         return rc;
     }
     const bool from_bag = argc >= 4 && std::string(argv[2]) == "--bag";
