@@ -469,7 +469,7 @@ def main():
         torch.cuda.set_device(0)
         gfamd._chk(gfamd.lib().gf_set_device(0))
         S = max(1, args.e2e_streams)
-        kw = dict(n_streams=S, n_groups=args.e2e_groups, stagger=not args.e2e_same_frames)
+        kw = dict(n_streams=S, n_groups=args.e2e_groups, stagger=not args.e2e_same_frames, device_preint=args.e2e_device_preint, device_sweeps=args.e2e_device_sweeps)
         cold = end_to_end_sample(gfamd, args.e2e_seqs, dev, 150, 30, **kw)
         warm = end_to_end_sample(gfamd, args.e2e_seqs, dev, 150, 30, **kw)
         warm["passes_window_solves_per_s"] = [cold["window_solves_per_s"], warm["window_solves_per_s"]]

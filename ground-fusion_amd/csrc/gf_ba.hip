@@ -39,15 +39,17 @@ __global__ void ba_fill_plausible(void* p, size_t i0, size_t i1, int is_double, 
         unsigned h = (unsigned)(i * 2654435761ull) ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
         // Freed memory does not respect element types: a double buffer inherits int tables (two -1 markers are the bit pattern of a NaN, two small counts a denormal)
         // and an int buffer the halves of doubles -- the read this mode was built to find (round 5) only showed behind an int table.
+        // The first eight elements walk through all eight kinds, the foreign bit patterns first: a buffer of one or three elements (pri_c is [batch]) must not depend on
+        // its hash to meet a NaN.
         if (is_double) {
-            const int sel = h & 7;
+            const int sel = i < 8 ? (int)((i + 4) & 7) : (int)(h & 7);
             const double mag = (double)((int)((h >> 8) % 20001u) - 10000) * 1e-3;
             double v = sel == 0 ? 0.0 : sel == 1 ? 1.0 : sel == 2 ? -1.0 : sel == 3 ? mag * 1e-4 : mag;
             if (sel == 4) v = __longlong_as_double(-1LL);                                                                  // (-1, -1)
             if (sel == 5) v = __longlong_as_double((long long)((h >> 8) % 200u) << 32 | (long long)((h >> 16) % 200u));     // two small ints
             static_cast<double*>(p)[i] = v;
         } else {
-            const int sel = h & 7;
+            const int sel = i < 8 ? (int)i : (int)(h & 7);
             static_cast<int*>(p)[i] = sel == 0 ? -1 : sel == 1 ? (int)(0x3FE00000u + ((h >> 8) & 0xFFFFFu)) : sel == 2 ? (int)(h * 2654435761u) : (int)((h >> 8) % 200u);   // markers, high / low words of doubles, counts
         }
     }

@@ -70,13 +70,19 @@ def main():
     moved5 = [nm for nm in names if nan[nm] != ref[nm]]
     say("== 0xFF (NaN / -1) in every fresh device buffer (GF_BA_POISON=5): moved:", moved5 or "nothing")
     PM = 4
-    if moved5 and not moved:
+    if moved5:     # 0xFF is the sharper probe (every double a NaN): bisect with it where it shows anything
         moved, PM = moved5, 5
 
     for nm in moved:
         if left() < 60:
             say("budget spent before", nm)
             break
+        single, _ = run([nm])      # the bisection runs one scenario per process: its reference is the same scenario alone
+        ref[nm] = single[nm]
+        chk, _ = run([nm], GF_BA_POISON=PM)
+        if chk[nm] == ref[nm]:
+            say("== %s does not move when it runs alone (mode %d): skipped" % (nm, PM))
+            continue
         _, err = run([nm], GF_BA_POISON=PM, GF_BA_POISON_RANGE="100000:100001", GF_BA_ALLOC_TRACE=1)
         allocs = [ln for ln in err.splitlines() if ln.startswith("gf_ba alloc")]
         n = len(allocs)

@@ -10,6 +10,8 @@ What is evaluated (paths under /root/reference/vins_estimator/src):
   factor/projectionTwoFrameOneCamFactor.cpp:43-151   residual and the five Jacobian blocks of ProjectionTwoFrameOneCamFactor::Evaluate
   factor/imu_factor.h:28-191 + factor/integration_base.h:169-195   IMUFactor::Evaluate on top of IntegrationBase::evaluate, sqrt_info = LLT(cov^-1).matrixL()^T
   factor/wheel_factor.h:28-247 + factor/wheel_integration_base.h:180-219 + utility/sophus_utils.hpp:155-236   WheelFactor::Evaluate (all seven blocks)
+  factor/marginalization_factor.cpp:12-78, :119-308 + estimator/estimator.cpp:3334-3560   the marginalisation itself: MARGIN_OLD / MARGIN_SECOND_NEW factor sets, loss
+                                                     scaling, A / b, eigen pseudo-inverse of A_mm, eigen square root of the kept system (eps 1e-8)  -> ref_marg_*.json.gz
   factor/marginalization_factor.cpp:344-392          MarginalizationFactor::Evaluate: r = r0 + J0 dx, dx of pose blocks 2 vec(q0^-1 q) with the sign of its w
   utility/utility.h:23-76                             deltaQ, skewSymmetric, Qleft, Qright (positify returns its argument: line 49-57)
   estimator/estimator.cpp:3269-3297                   which factors get the loss: ceres::HuberLoss(1.0) on the visual factors only
@@ -429,6 +431,121 @@ def window_normal_equations(w, ids):
     return H, g, cost
 
 
+def marg_golden(w, mode=0):
+    """mode 0 -- MARGIN_OLD as the reference runs it: the factor set of estimator.cpp:3334-3475 (prior, IMU factor 0 -> 1, wheel factor 0 -> 1, the visual factors of the features
+    that start in frame 0; dropped: pose 0, speed-bias 0, those features), ResidualBlockInfo::Evaluate with the loss scaling (marginalization_factor.cpp:12-78),
+    A = sum J^T J, b = sum J^T r over [dropped | kept] columns (:119-239), the eigen pseudo-inverse of A_mm and the eigen square root of the kept system with
+    eps = 1e-8 (:278-302).  Returns the kept block ids (first-appearance order) and J^T J = V S V^T, J^T r = V V^T b_r (what the next window's solver sees: they do
+    not depend on the eigenvector basis nor on the order of the dropped columns), plus the kept system's eigenvalues around the cut.
+    mode 1 -- MARGIN_SECOND_NEW (estimator.cpp:3506-3560): the prior alone, dropped: pose WINDOW_SIZE - 1."""
+    import gfwindow as gw
+    NP = w["W"] + 1
+    pose = [pose_of(w["para_Pose"][7 * i:7 * i + 7]) for i in range(NP)]
+    sb = [vec(w["para_SpeedBias"][9 * i:9 * i + 9]) for i in range(NP)]
+    ex, exw = pose_of(w["para_Ex_Pose"]), pose_of(w["para_Ex_Pose_wheel"])
+    td, G, si = mpf(w["para_Td"][0]), vec(w["G"]), mpf(w["vis_sqrt_info"])
+    factors = []      # (r, [(block id, J)])
+    drop_ids = [gw.bid(gw.POSE, 0), gw.bid(gw.SPEEDBIAS, 0)] if mode == 0 else [gw.bid(gw.POSE, int(w["W"]) - 1)]
+    if w["prior_n"] > 0:
+        npr = int(w["prior_n"])
+        J0 = M(npr, npr)
+        for a in range(npr):
+            for c in range(npr):
+                J0[a, c] = mpf(w["prior_J"][a * npr + c])
+        dx, blocks, idx, xo = mp.zeros(npr, 1), [], 0, 0
+        for bid_ in w["prior_block_id"]:
+            kind, i = int(bid_) // 4096, int(bid_) % 4096
+            gs, ls = gw.gsize(kind), gw.lsize(kind)
+            off = {gw.POSE: ("para_Pose", 7 * i), gw.SPEEDBIAS: ("para_SpeedBias", 9 * i), gw.EX_POSE: ("para_Ex_Pose", 0), gw.EX_WHEEL: ("para_Ex_Pose_wheel", 0),
+                   gw.SX: ("para_Ix", 0), gw.SY: ("para_Ix", 1), gw.SW: ("para_Ix", 2), gw.TD: ("para_Td", 0), gw.TD_WHEEL: ("para_Td_wheel", 0)}[kind]
+            d = prior_dx(gs == 7, w[off[0]][off[1]:off[1] + gs], w["prior_x0"][xo:xo + gs])
+            for q in range(ls):
+                dx[idx + q] = d[q]
+            blocks.append((int(bid_), J0[:, idx:idx + ls]))
+            idx += ls; xo += gs
+        factors.append((vec(w["prior_r"]) + J0 * dx, blocks))
+    for k in range(int(w["n_imu"]) if mode == 0 else 0):
+        if int(w["imu_i"][k]) != 0 or float(w["imu_sum_dt"][k]) >= 10.0:
+            continue
+        pre = {"sum_dt": mpf(w["imu_sum_dt"][k]), "delta_p": vec(w["imu_delta_p"][3 * k:3 * k + 3]), "delta_v": vec(w["imu_delta_v"][3 * k:3 * k + 3]),
+               "delta_q": tuple(mpf(x) for x in w["imu_delta_q"][4 * k:4 * k + 4]), "lin_ba": vec(w["imu_lin_ba"][3 * k:3 * k + 3]), "lin_bg": vec(w["imu_lin_bg"][3 * k:3 * k + 3]),
+               "jacobian": M(15, 15), "covariance": M(15, 15)}
+        for a in range(15):
+            for c in range(15):
+                pre["jacobian"][a, c] = mpf(w["imu_jacobian"][225 * k + 15 * a + c]); pre["covariance"][a, c] = mpf(w["imu_covariance"][225 * k + 15 * a + c])
+        r, J = imu_factor(pose[0], sb[0], pose[1], sb[1], pre, G)
+        factors.append((r, [(gw.bid(gw.POSE, 0), J["pi"]), (gw.bid(gw.SPEEDBIAS, 0), J["sbi"]), (gw.bid(gw.POSE, 1), J["pj"]), (gw.bid(gw.SPEEDBIAS, 1), J["sbj"])]))
+    for k in range(int(w["n_wheel"]) if mode == 0 else 0):
+        if int(w["wh_i"][k]) != 0 or float(w["wh_sum_dt"][k]) >= 10.0:
+            continue
+        pre = {"delta_p": vec(w["wh_delta_p"][3 * k:3 * k + 3]), "delta_q": tuple(mpf(x) for x in w["wh_delta_q"][4 * k:4 * k + 4]), "jacobian": M(6, 3), "covariance": M(6, 6),
+               "lin": [mpf(x) for x in w["wh_lin"][4 * k:4 * k + 4]], "lin_vel": vec(w["wh_lin_vel"][3 * k:3 * k + 3]), "lin_gyr": vec(w["wh_lin_gyr"][3 * k:3 * k + 3]),
+               "vel_1": vec(w["wh_vel_1"][3 * k:3 * k + 3]), "gyr_1": vec(w["wh_gyr_1"][3 * k:3 * k + 3])}
+        for a in range(6):
+            for c in range(3):
+                pre["jacobian"][a, c] = mpf(w["wh_jacobian"][18 * k + 3 * a + c])
+            for c in range(6):
+                pre["covariance"][a, c] = mpf(w["wh_covariance"][36 * k + 6 * a + c])
+        r, J = wheel_factor(pose[0], pose[1], exw, mpf(w["para_Ix"][0]), mpf(w["para_Ix"][1]), mpf(w["para_Ix"][2]), mpf(w["para_Td_wheel"][0]), pre)
+        factors.append((r, [(gw.bid(gw.POSE, 0), J["pi"]), (gw.bid(gw.POSE, 1), J["pj"]), (gw.bid(gw.EX_WHEEL), J["exw"]), (gw.bid(gw.SX), J["sx"]), (gw.bid(gw.SY), J["sy"]),
+                            (gw.bid(gw.SW), J["sw"]), (gw.bid(gw.TD_WHEEL), J["tdw"])]))
+    for k in range(int(w["n_visual"]) if mode == 0 else 0):
+        f, i, j = int(w["vis_feature"][k]), int(w["vis_i"][k]), int(w["vis_j"][k])
+        if i != 0:
+            continue
+        r, J = visual_factor(pose[0], pose[j], ex, mpf(w["para_Feature"][f]), td, vec(w["vis_pts_i"][3 * k:3 * k + 3]), vec(w["vis_pts_j"][3 * k:3 * k + 3]),
+                             vec(w["vis_vel_i"][2 * k:2 * k + 2]), vec(w["vis_vel_j"][2 * k:2 * k + 2]), mpf(w["vis_td_i"][k]), mpf(w["vis_td_j"][k]), si)
+        _, rc, Jc = huber_correct(r, J)                                                         # marginalization_factor.cpp:49-77: the same corrector arithmetic
+        factors.append((rc, [(gw.bid(gw.POSE, 0), Jc["pi"]), (gw.bid(gw.POSE, j), Jc["pj"]), (gw.bid(gw.EX_POSE), Jc["ex"]), (gw.bid(gw.FEATURE, f), Jc["f"]), (gw.bid(gw.TD), Jc["td"])]))
+        if gw.bid(gw.FEATURE, f) not in drop_ids:
+            drop_ids.append(gw.bid(gw.FEATURE, f))
+    present = []
+    for _, blocks in factors:
+        for b, _ in blocks:
+            if b not in present:
+                present.append(b)
+    dropped = [b for b in drop_ids if b in present]
+    kept = [b for b in present if b not in dropped]
+    col, pos = {}, 0
+    for b in dropped + kept:
+        col[b] = pos
+        pos += gw.lsize(b // 4096)
+    m = sum(gw.lsize(b // 4096) for b in dropped)
+    n = pos - m
+    A, bb = mp.zeros(pos, pos), mp.zeros(pos, 1)
+    for r, blocks in factors:
+        for ba, Ja in blocks:
+            ga = Ja.T * r
+            for q in range(Ja.cols):
+                bb[col[ba] + q] += ga[q]
+            for bc, Jc_ in blocks:
+                Hab = Ja.T * Jc_
+                for p_ in range(Ja.cols):
+                    for q in range(Jc_.cols):
+                        A[col[ba] + p_, col[bc] + q] += Hab[p_, q]
+    eps = mp.mpf("1e-8")                                                                         # marginalization_factor.h:28
+    Amm = (A[0:m, 0:m] + A[0:m, 0:m].T) / 2                                                      # :278
+    ev, V = mp.eigsy(Amm)                                                                        # :279
+    Amm_inv = mp.zeros(m, m)
+    for k in range(m):
+        if ev[k] > eps:                                                                          # :283
+            vk = V[:, k]
+            Amm_inv += vk * vk.T / ev[k]
+    Arm, Amr = A[m:pos, 0:m], A[0:m, m:pos]
+    Ar = A[m:pos, m:pos] - Arm * Amm_inv * Amr                                                   # :291
+    br = bb[m:pos, 0] - Arm * Amm_inv * bb[0:m, 0]                                               # :292
+    ev2, V2 = mp.eigsy((Ar + Ar.T) / 2)   # SelfAdjointEigenSolver reads the lower triangle of a matrix that is symmetric up to rounding: symmetrised here  (:294)
+    JtJ, proj = mp.zeros(n, n), mp.zeros(n, n)
+    for k in range(n):
+        if ev2[k] > eps:                                                                         # :295-296
+            vk = V2[:, k]
+            JtJ += vk * vk.T * ev2[k]                                                            # J = sqrt(S) V^T  (:301)  ->  J^T J = V S V^T
+            proj += vk * vk.T                                                                    # r = S^-1/2 V^T b (:302)  ->  J^T r = V V^T b
+    Jtr = proj * br
+    evs = sorted(float(x) for x in ev2)
+    return {"kept": kept, "m": m, "n": n, "JtJ": JtJ, "Jtr": Jtr, "eigenvalues_kept": evs, "eigenvalues_dropped": sorted(float(x) for x in ev)}
+
+
 def to_list(a):
     return np.asarray(a).reshape(-1).tolist()
 
@@ -474,6 +591,34 @@ def main():
         import gzip
         path = os.path.join(out_dir, name + ".json.gz")
         with gzip.GzipFile(path, "wb", mtime=0) as f:      # mtime 0: the same bytes on every run
+            f.write(json.dumps(fx).encode())
+        print("   wrote", path, os.path.getsize(path), "bytes")
+    # ---- marginalisation priors: the window AFTER a solve (input data: the oracle's), MARGIN_OLD without and with a prior, MARGIN_SECOND_NEW
+    import gzip
+    kwm = dict(max_features=10, n_landmarks=15)
+    w0 = SW.make_window(8, O, **kwm)
+    O.ba_solve(w0, 4)
+    p0 = O.ba_marginalize(w0, 0)
+    w1 = SW.make_window(8, O, frame0=1, prior=p0, **kwm)
+    O.ba_solve(w1, 4)
+    for name, w, mode in (("ref_marg_old_first_window", w0, 0), ("ref_marg_old_with_prior", w1, 0), ("ref_marg_second_new", w1, 1)):
+        w.finalize()
+        g = marg_golden(w, mode)
+        n = g["n"]
+        JtJ = np.array([[float(g["JtJ"][a, c]) for c in range(n)] for a in range(n)])
+        Jtr = np.array([float(g["Jtr"][a]) for a in range(n)])
+        po = O.ba_marginalize(w.copy(), mode)
+        Jo = po["J"].reshape(n, n)
+        sc = np.sqrt(np.maximum(np.diag(JtJ), 1e-300))
+        print("%s: %d dropped + %d kept columns; kept eigenvalues around the 1e-8 cut: %s" % (name, g["m"], n, ["%.1e" % x for x in g["eigenvalues_kept"] if 1e-12 < abs(x) < 1e-4][:8]))
+        print("   oracle vs 60 digits: J^T J scaled %.2e, J^T r rel %.2e" % (np.abs((Jo.T @ Jo - JtJ) / np.outer(sc, sc)).max(), np.abs(Jo.T @ po["r"] - Jtr).max() / np.abs(Jtr).max()))
+        fx = {"about": "marginalisation prior of a small window by the reference's route (marginalization_factor.cpp:119-308; factor set estimator.cpp:3334-3560) at 60 digits "
+                       "(tests/golden/make_ref_golden.py marg_golden): inputs = the window and the mode, expected = J^T J (lower triangle) and J^T r of the prior over the kept "
+                       "blocks `kept` (ids BEFORE the address shift, first-appearance order)",
+              "window": {k: (to_list(v) if isinstance(v, np.ndarray) else v) for k, v in dict(w).items()}, "mode": mode, "kept": [int(x) for x in g["kept"]], "m": int(g["m"]), "n": int(n),
+              "JtJ_lower": [float(JtJ[a, c]) for a in range(n) for c in range(a + 1)], "Jtr": Jtr.tolist(), "eigenvalues_kept": g["eigenvalues_kept"]}
+        path = os.path.join(out_dir, name + ".json.gz")
+        with gzip.GzipFile(path, "wb", mtime=0) as f:
             f.write(json.dumps(fx).encode())
         print("   wrote", path, os.path.getsize(path), "bytes")
 

@@ -470,3 +470,15 @@ def test_normal_equations_meet_the_reference_formulas_at_60_digits(gf, name):
     dev = check_against_ref(est.linearize(w), fx, H, g, tol=1e-11)
     print(name, "HIP vs reference formulas at 60 digits: H scaled %.1e, g %.1e" % dev)
     est.close()
+
+
+@pytest.mark.parametrize("name", ["ref_marg_old_first_window", "ref_marg_old_with_prior", "ref_marg_second_new"])
+def test_marginalisation_meets_the_reference_route_at_60_digits(gf, name):
+    """the HIP marginalisation (block elimination + rank-revealing Cholesky + least-squares right-hand side) against the reference's eigen route evaluated with 60 digits
+    (tests/golden/ref_marg_*.json.gz): J^T J and J^T r of the prior, the same bars as the oracle's own test"""
+    from test_golden import load_ref_marg, check_prior_against_ref
+    w, fx, A, b, ids = load_ref_marg(name)
+    est = gf.Estimator(max_features=16, max_visual=256)
+    dev = check_prior_against_ref(est.marginalize([w], fx["mode"])[0], fx, A, b, ids)
+    print(name, "HIP vs reference route at 60 digits: J^T J scaled %.1e, J^T r %.1e" % dev)
+    est.close()
