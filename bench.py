@@ -205,7 +205,7 @@ def e2e_inputs(n_streams, dev):
     return _E2E_INPUTS[n_streams]
 
 
-def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False, device_sweeps=False, n_streams=1, n_groups=1, stagger=True):
+def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=None, device_sweeps=False, n_streams=1, n_groups=1, stagger=True):
     """The drop-in path on a bounded sample: `nseq` sequences -- `n_streams` distinct seeded recordings dealt round-robin (1: one recording replicated, every
     member takes the same decisions; 8: staggered starts, mixed batches) -- through the batched tracker (trackImage on every camera frame) and gf_estimator_group_*
     (inputFeature -> processImage -> batched solve + marginalisation on every second frame, the reference's MULTIPLE_THREAD flow): the back end is fed by the
@@ -326,7 +326,8 @@ def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=False, 
             "groups_alternate_frames": bool(stagger and n_groups > 1), "live_camera_frames": frames_live, "window_solves": solves,
             "wall_s": t_live, "ms_per_backend_frame": 1e3 * t_live / bf, "group_batches": stt["batches"], "largest_batch": stt["largest_batch"],
             "backend_frames_with_mixed_decisions": mixed, "group_steps_live": steps_live, "keyframe_vote_share": keyframe_votes / max(votes, 1),
-            "newest_position_norm_m": pos, "device_preint": bool(device_preint),
+            "newest_position_norm_m": pos,
+            "device_preint": bool(device_preint) if device_preint is not None else "library default (on when a worker thread carries >= 16 members, i.e. on small hosts)",
             "host_hardware_threads": os.cpu_count(), "group_worker_threads": workers, "tracker_ms_per_call": trk_anatomy,
             "main_thread_ms_per_backend_frame": {k_: round(1e3 * v_ / bf, 3) for k_, v_ in clk.items()},
             "imu_wheel_feed": "every sample queued before the first camera frame; no time is taken out of the wall clock", "t_feed_excluded_s": t_feed_live,
@@ -459,9 +460,9 @@ def main():
 
     if args.e2e_only:
         if args.host_threads > 0:   # the host BASELINE.md plans for: everything this process runs (tracker bookkeeping pool, group workers, Python) shares N hardware threads
-            os.sched_setaffinity(0, set(range(args.host_threads)))
+            os.sched_setaffinity(0, set(range(args.host_threads)))   # the library sizes its pools from the affinity mask (half of it for the group's workers / the tracker's pool)
             os.environ["GF_HOST_THREADS"] = str(max(1, args.host_threads // 2))
-            os.environ["GF_GROUP_THREADS"] = str(max(1, args.host_threads // (2 * max(1, args.e2e_groups))))
+            os.environ["GF_GROUP_THREADS"] = str(max(1, args.host_threads // (2 * max(1, args.e2e_groups))))   # several groups of one process share that half
         else:
             os.environ.setdefault("GF_HOST_THREADS", str(max(1, min(16, (os.cpu_count() or 4) // 2))))
         import gfamd
@@ -469,7 +470,7 @@ def main():
         torch.cuda.set_device(0)
         gfamd._chk(gfamd.lib().gf_set_device(0))
         S = max(1, args.e2e_streams)
-        kw = dict(n_streams=S, n_groups=args.e2e_groups, stagger=not args.e2e_same_frames, device_preint=args.e2e_device_preint, device_sweeps=args.e2e_device_sweeps)
+        kw = dict(n_streams=S, n_groups=args.e2e_groups, stagger=not args.e2e_same_frames, device_preint=True if args.e2e_device_preint else None, device_sweeps=args.e2e_device_sweeps)
         cold = end_to_end_sample(gfamd, args.e2e_seqs, dev, 150, 30, **kw)
         warm = end_to_end_sample(gfamd, args.e2e_seqs, dev, 150, 30, **kw)
         warm["passes_window_solves_per_s"] = [cold["window_solves_per_s"], warm["window_solves_per_s"]]

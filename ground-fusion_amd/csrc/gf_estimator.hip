@@ -31,6 +31,7 @@
 #include <set>
 #include <string>
 #include <thread>
+#include <sched.h>
 #include <vector>
 #include <climits>
 #include <linux/futex.h>
@@ -2276,17 +2277,27 @@ int gf_estimator_group_create(const gf_estimator_cfg* c, int n, gf_estimator_gro
     if (int rc = gf_ba_create(&bc, &g->solver.ba)) { delete g; return rc; }
     g->solver.mem_count = (size_t)n;
     (void)hipGetDevice(&g->device);
-    if (const char* e = getenv("GF_GROUP_DEVICE_PREINT")) if (atoi(e) != 0) if (int rc = gf::preint_batch_create(&g->solver.pre)) { delete g; return rc; }
+    // worker threads: half of the hardware threads this PROCESS may run on (its affinity mask: a process confined by taskset / cgroups to 8 threads sizes its pool for
+    // 8, not for the 256 the box has), divided among the ranks that share the node
+    int hw = (int)std::thread::hardware_concurrency();
+    { cpu_set_t cs; CPU_ZERO(&cs); if (sched_getaffinity(0, sizeof cs, &cs) == 0 && CPU_COUNT(&cs) > 0) hw = std::min(hw > 0 ? hw : CPU_COUNT(&cs), CPU_COUNT(&cs)); }
+    int share = 1;
+    if (const char* e = getenv("LOCAL_WORLD_SIZE")) share = std::max(1, atoi(e));
+    int nt = std::min(n, std::max(1, hw / (2 * share)));
+    if (const char* e = getenv("GF_GROUP_THREADS")) if (atoi(e) > 0) nt = std::min(n, atoi(e));
+    // the members' IMU pre-integration as one device launch per camera frame.  It costs one more rendezvous per frame and pays where host threads are
+    // scarce (round 5, 256 members on 8 hardware threads = 4 workers, two alternating groups: 20.9 k against 19.4 k window-solves/s; one group 11.9 k against 11.6 k;
+    // on the 256-thread box it loses: 30.4 k against 47.3 k, round 3).  Default: on when a worker carries sixteen members or more; GF_GROUP_DEVICE_PREINT=0|1 decides otherwise.
+    // The device feature sweeps (triangulateWithDepth, movingConsistencyCheckW) lose on both hosts (8 threads: 14.7 k against 19.4 k) and stay opt-in.
+    bool want_pre = n >= 16 * nt;
+    if (const char* e = getenv("GF_GROUP_DEVICE_PREINT")) want_pre = atoi(e) != 0;
+    if (want_pre) if (int rc = gf::preint_batch_create(&g->solver.pre)) { delete g; return rc; }
     if (const char* e = getenv("GF_GROUP_DEVICE_SWEEPS")) if (atoi(e) != 0) if (int rc = gf_featsweep_create(&g->solver.sweeps)) { delete g; return rc; }
     g->job_gen.reset(new std::atomic<int>[n]); for (int i = 0; i < n; i++) g->job_gen[i].store(0, std::memory_order_relaxed);
     g->t.assign(n, 0.0); g->frame_ptr.assign(n, nullptr); g->frame_n.assign(n, 0); g->rcs.assign(n, GF_OK); g->errs.resize(n);
     {
         // default: half the hardware threads of this rank's share of the node (measured on a 256-thread host with 256 members: 8 threads 13 k window-solves/s end to end,
         // 32: 31 k, 128: 36 k, 256: 30 k -- the tracker's and the runtime's threads want cores too)
-        int share = 1;
-        if (const char* e = getenv("LOCAL_WORLD_SIZE")) share = std::max(1, atoi(e));
-        int nt = std::min(n, std::max(1, (int)std::thread::hardware_concurrency() / (2 * share)));
-        if (const char* e = getenv("GF_GROUP_THREADS")) if (atoi(e) > 0) nt = std::min(n, atoi(e));
         g->n_threads = nt;
         g->fib.reset(new Fiber[n]);
         for (int i = 0; i < n; i++) if (!g->fib[i].alloc()) { delete g; return gf::set_err(GF_ERR_INVALID, "cannot map the stack of member %d", i); }
