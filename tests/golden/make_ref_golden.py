@@ -331,6 +331,164 @@ def wheel_factor(Pose_i, Pose_j, Exw, sx, sy, sw, td, pre):
     return S * r, {"pi": S * Ji, "pj": S * Jj, "exw": S * Jex, "sx": S * Jsx, "sy": S * Jsy, "sw": S * Jsw, "tdw": S * Jtd}
 
 
+# ---- GNSS (factor/gnss_psr_dopp_factor.cpp, gnss_dt_ddt_factor.cpp, gnss_ddt_smooth_factor.cpp are in the reference; ecef2geo / ecef2rotation / sat_azel / the
+# Saastamoinen and Klobuchar delays come from gnss_comm, which the reference does not vendor: those five are restated from their published form -- the SAME reading the
+# oracle and the kernels follow, so they are only pinned against transcription slips here, not against gnss_comm)
+GN_C, GN_OMG, GN_A, GN_E2 = mp.mpf("2.99792458e8"), mp.mpf("7.2921151467e-5"), mp.mpf("6378137.0"), mp.mpf("6.69437999014e-3")
+
+
+def gn_ecef2geo(p):   # latitude [deg], longitude [deg], height [m] (closed form, RTKLIB lineage)
+    if p[0] == 0 and p[1] == 0:
+        return M([0, 0, 0])
+    a = GN_A; a2 = a * a; b2 = a2 * (1 - GN_E2); b = mp.sqrt(b2); ep2 = (a2 - b2) / b2; rho = mp.sqrt(p[0] ** 2 + p[1] ** 2)
+    s1, s2 = p[2] * a, rho * b
+    h = mp.sqrt(s1 * s1 + s2 * s2)
+    st, ct = s1 / h, s2 / h
+    s1 = p[2] + ep2 * b * st ** 3
+    s2 = rho - a * GN_E2 * ct ** 3
+    h = mp.sqrt(s1 * s1 + s2 * s2)
+    sin_lat, cos_lat = s1 / h, s2 / h
+    N = a2 / mp.sqrt(a2 * cos_lat ** 2 + b2 * sin_lat ** 2)
+    return M([mp.atan(s1 / s2) * 180 / mp.pi, mp.atan2(p[1], p[0]) * 180 / mp.pi, rho / cos_lat - N])
+
+
+def gn_geo2rotation(lla):   # R_ecef_enu
+    lat, lon = lla[0] * mp.pi / 180, lla[1] * mp.pi / 180
+    sl, cl, so, co = mp.sin(lat), mp.cos(lat), mp.sin(lon), mp.cos(lon)
+    return M([[-so, -sl * co, cl * co], [co, -sl * so, cl * so], [0, cl, sl]])
+
+
+def gn_sat_azel(rcv, sat):
+    dl = sat - rcv
+    dl = dl / mp.sqrt(dl[0] ** 2 + dl[1] ** 2 + dl[2] ** 2)
+    enu = gn_geo2rotation(gn_ecef2geo(rcv)).T * dl
+    az = mp.mpf(0) if mp.sqrt(dl[0] ** 2 + dl[1] ** 2) < mp.mpf("1e-12") else mp.atan2(enu[0], enu[1])
+    if az < 0:
+        az += 2 * mp.pi
+    return az, mp.asin(enu[2])
+
+
+def gn_trop_delay(lla, el):   # Saastamoinen, standard atmosphere, relative humidity 0.7
+    if lla[2] < -100 or lla[2] > 1e4 or el <= 0:
+        return mp.mpf(0)
+    hgt = mp.mpf(0) if lla[2] < 0 else lla[2]
+    pres = mp.mpf("1013.25") * (1 - mp.mpf("2.2557e-5") * hgt) ** mp.mpf("5.2568")
+    temp = 15 - mp.mpf("6.5e-3") * hgt + mp.mpf("273.16")
+    e = mp.mpf("6.108") * mp.mpf("0.7") * mp.exp((mp.mpf("17.15") * temp - 4684) / (temp - mp.mpf("38.45")))
+    z = mp.pi / 2 - el
+    trph = mp.mpf("0.0022768") * pres / (1 - mp.mpf("0.00266") * mp.cos(2 * lla[0] * mp.pi / 180) - mp.mpf("0.00028") * hgt / 1000) / mp.cos(z)
+    trpw = mp.mpf("0.002277") * (1255 / temp + mp.mpf("0.05")) * e / mp.cos(z)
+    return trph + trpw
+
+
+def gn_ion_delay(tow, ion_in, lla, az, el):   # Klobuchar
+    ion_default = [mp.mpf(x) for x in ("0.1118e-07", "-0.7451e-08", "-0.5961e-07", "0.1192e-06", "0.1167e+06", "-0.2294e+06", "-0.1311e+06", "0.1049e+07")]
+    if lla[2] < -1000 or el <= 0:
+        return mp.mpf(0)
+    nrm = sum(x * x for x in ion_in)
+    ion = ion_default if nrm <= 0 else ion_in
+    psi = mp.mpf("0.0137") / (el / mp.pi + mp.mpf("0.11")) - mp.mpf("0.022")
+    phi = lla[0] / 180 + psi * mp.cos(az)
+    phi = min(max(phi, mp.mpf("-0.416")), mp.mpf("0.416"))
+    lam = lla[1] / 180 + psi * mp.sin(az) / mp.cos(phi * mp.pi)
+    phi += mp.mpf("0.064") * mp.cos((lam - mp.mpf("1.617")) * mp.pi)
+    tt = 43200 * lam + tow
+    tt -= mp.floor(tt / 86400) * 86400
+    f = 1 + 16 * (mp.mpf("0.53") - el / mp.pi) ** 3
+    amp = ion[0] + phi * (ion[1] + phi * (ion[2] + phi * ion[3]))
+    per = ion[4] + phi * (ion[5] + phi * (ion[6] + phi * ion[7]))
+    amp = max(amp, mp.mpf(0)); per = max(per, mp.mpf(72000))
+    x = 2 * mp.pi * (tt - 50400) / per
+    return GN_C * f * ((mp.mpf("5e-9") + amp * (1 + x * x * (mp.mpf("-0.5") + x * x / 24))) if abs(x) < mp.mpf("1.57") else mp.mpf("5e-9"))
+
+
+def gnss_psr_dopp_factor(Pi, Vi, Pj, Vj, rcv_dt, rcv_ddt, yaw_diff, ref_ecef, dat, ratio, iono):
+    """GnssPsrDoppFactor::Evaluate, gnss_psr_dopp_factor.cpp:49-208.  dat: what the constructor (:3-47) leaves in the factor -- sv_pos, sv_vel, svdt, svddt, tgd, pr_uura,
+    dp_uura -- and the observation (psr, dopp, wavelength, time of week).  Returns r (2) and Jacobians: 'pi' 2x6, 'vi' 2x9, 'pj', 'vj', 'dt' 2x1, 'ddt' 2x1, 'yaw' 2x1, 'anc' 2x3"""
+    sv_pos, sv_vel = dat["sv_pos"], dat["sv_vel"]
+    local_pos, local_vel = ratio * Pi + (1 - ratio) * Pj, ratio * Vi + (1 - ratio) * Vj          # :61-62
+    sy, cy = mp.sin(yaw_diff), mp.cos(yaw_diff)
+    R_enu_local = M([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])                                    # :66-69
+    R_ecef_enu = gn_geo2rotation(gn_ecef2geo(ref_ecef))                                          # :70 ecef2rotation
+    R_ecef_local = R_ecef_enu * R_enu_local
+    P_ecef, V_ecef = R_ecef_local * local_pos + ref_ecef, R_ecef_local * local_vel              # :73-74
+    ion_delay = tro_delay = mp.mpf(0)
+    az, el = mp.mpf(0), mp.pi / 2
+    if P_ecef[0] ** 2 + P_ecef[1] ** 2 + P_ecef[2] ** 2 > 0:                                     # :78-84
+        az, el = gn_sat_azel(P_ecef, sv_pos)
+        lla = gn_ecef2geo(P_ecef)
+        tro_delay = gn_trop_delay(lla, el)
+        ion_delay = gn_ion_delay(dat["tow"], iono, lla, az, el)
+    sin_el_2 = mp.sin(el) ** 2
+    pr_weight = sin_el_2 / dat["pr_uura"] * 10                                                   # :87 relative_sqrt_info 10 (:46)
+    dp_weight = sin_el_2 / dat["dp_uura"] * 10 * 5                                               # :88 PSR_TO_DOPP_RATIO 5
+    rcv2sat = sv_pos - P_ecef
+    norm2 = rcv2sat[0] ** 2 + rcv2sat[1] ** 2 + rcv2sat[2] ** 2
+    rng = mp.sqrt(norm2)
+    unit = rcv2sat / rng
+    psr_sagnac = GN_OMG * (sv_pos[0] * P_ecef[1] - sv_pos[1] * P_ecef[0]) / GN_C                 # :93
+    psr_est = rng + psr_sagnac + rcv_dt - dat["svdt"] * GN_C + ion_delay + tro_delay + dat["tgd"] * GN_C   # :94-95
+    dopp_sagnac = GN_OMG / GN_C * (sv_vel[0] * P_ecef[1] + sv_pos[0] * V_ecef[1] - sv_vel[1] * P_ecef[0] - sv_pos[1] * V_ecef[0])   # :99-100
+    dv = sv_vel - V_ecef
+    dopp_est = (dv.T * unit)[0] + dopp_sagnac + rcv_ddt - dat["svddt"] * GN_C                    # :101
+    r = M([(psr_est - dat["psr"]) * pr_weight, (dopp_est + dat["dopp"] * dat["wavelength"]) * dp_weight])   # :97, :103
+    norm3 = rng ** 3
+    u2r = mp.zeros(3, 3)                                                                         # :116-128
+    for a in range(3):
+        for c in range(3):
+            u2r[a, c] = -(((norm2 - rcv2sat[a] * rcv2sat[a]) / norm3) if a == c else ((-rcv2sat[a] * rcv2sat[c]) / norm3))
+    Jpi, Jvi, Jpj, Jvj = mp.zeros(2, 6), mp.zeros(2, 9), mp.zeros(2, 6), mp.zeros(2, 9)
+    top = -(unit.T * R_ecef_local)                                                               # 1 x 3
+    bot = dv.T * u2r * R_ecef_local
+    for c in range(3):
+        Jpi[0, c] = top[0, c] * pr_weight * ratio; Jpi[1, c] = bot[0, c] * dp_weight * ratio                 # :113, :129-130
+        Jvi[1, c] = top[0, c] * dp_weight * ratio                                                                # :138-139
+        Jpj[0, c] = top[0, c] * pr_weight * (1 - ratio); Jpj[1, c] = bot[0, c] * dp_weight * (1 - ratio)         # :147, :163-164
+        Jvj[1, c] = top[0, c] * dp_weight * (1 - ratio)                                                          # :172-173
+    d_yaw = M([[-sy, -cy, 0], [cy, -sy, 0], [0, 0, 0]])                                          # :193-196
+    Jyaw = M([-(unit.T * (R_ecef_enu * (d_yaw * local_pos)))[0] * pr_weight, -(unit.T * (R_ecef_enu * (d_yaw * local_vel)))[0] * dp_weight])   # :197-198
+    Janc = mp.zeros(2, 3)
+    for c in range(3):
+        Janc[0, c] = -unit[c] * pr_weight                                                        # :206 ("approximation for simplicity")
+    return r, {"pi": Jpi, "vi": Jvi, "pj": Jpj, "vj": Jvj, "dt": M([pr_weight, 0]), "ddt": M([0, dp_weight]), "yaw": Jyaw, "anc": Janc}
+
+
+def gnss_factors(w, frames=None):
+    """every GNSS residual block of the window as (r, [(block id, J)]): GnssPsrDoppFactor per observation (estimator.cpp:3182-3208), DtDdtFactor x 4 and DdtSmoothFactor
+    per frame pair (:3211-3229).  frames: only the blocks MARGIN_OLD takes (estimator.cpp:3397-3434: observations of frame 0, clock factors of the pair (0, 1))."""
+    import gfwindow as gw
+    NP = int(w["W"]) + 1
+    out = []
+    P = [vec(w["para_Pose"][7 * i:7 * i + 3]) for i in range(NP)]
+    V = [vec(w["para_SpeedBias"][9 * i:9 * i + 3]) for i in range(NP)]
+    dt = [mpf(x) for x in w["para_rcv_dt"]]
+    ddt = [mpf(x) for x in w["para_rcv_ddt"]]
+    yaw, anc = mpf(w["para_yaw_enu_local"][0]), vec(w["para_anc_ecef"])
+    iono = [mpf(x) for x in w["gnss_iono"]]
+    for k in range(int(w["n_gnss"])):
+        i, lo, sys = int(w["gnss_frame"][k]), int(w["gnss_lower"][k]), int(w["gnss_sys"][k])
+        if frames is not None and i not in frames:
+            continue
+        d = [mpf(x) for x in w["gnss_data"][16 * k:16 * k + 16]]
+        dat = {"sv_pos": M(d[0:3]), "sv_vel": M(d[3:6]), "svdt": d[6], "svddt": d[7], "tgd": d[8], "pr_uura": d[9], "dp_uura": d[10], "psr": d[11], "dopp": d[12],
+               "wavelength": d[13], "tow": d[14]}
+        r, J = gnss_psr_dopp_factor(P[lo], V[lo], P[lo + 1], V[lo + 1], dt[4 * i + sys], ddt[i], yaw, anc, dat, mpf(w["gnss_ratio"][k]), iono)
+        out.append((r, [(gw.bid(gw.POSE, lo), J["pi"]), (gw.bid(gw.SPEEDBIAS, lo), J["vi"]), (gw.bid(gw.POSE, lo + 1), J["pj"]), (gw.bid(gw.SPEEDBIAS, lo + 1), J["vj"]),
+                        (gw.bid(gw.RCV_DT, 4 * i + sys), J["dt"]), (gw.bid(gw.RCV_DDT, i), J["ddt"]), (gw.bid(gw.YAW), J["yaw"]), (gw.bid(gw.ANC), J["anc"])]))
+    hdr = [mpf(x) for x in w["gnss_headers"]]
+    wt = mpf(w["gnss_ddt_weight"])
+    for i in range(NP - 1):
+        if frames is not None and i not in frames:
+            continue
+        delta_t = hdr[i + 1] - hdr[i]
+        for q in range(4):   # gnss_dt_ddt_factor.cpp: dt_info_coeff 50
+            r = M([(dt[4 * (i + 1) + q] - dt[4 * i + q] - (ddt[i] + ddt[i + 1]) / 2 * delta_t) * 50])
+            out.append((r, [(gw.bid(gw.RCV_DT, 4 * i + q), M([[-50]])), (gw.bid(gw.RCV_DT, 4 * (i + 1) + q), M([[50]])), (gw.bid(gw.RCV_DDT, i), M([[-delta_t * 25]])),
+                            (gw.bid(gw.RCV_DDT, i + 1), M([[-delta_t * 25]]))]))
+        out.append((M([(ddt[i] - ddt[i + 1]) * wt]), [(gw.bid(gw.RCV_DDT, i), M([[wt]])), (gw.bid(gw.RCV_DDT, i + 1), M([[-wt]]))]))   # gnss_ddt_smooth_factor.cpp
+    return out
+
+
 def prior_dx(kind_is_pose, x, x0):
     """marginalization_factor.cpp:356-372"""
     if not kind_is_pose:
@@ -382,7 +540,8 @@ def window_normal_equations(w, ids):
             kind, i = int(bid_) // 4096, int(bid_) % 4096
             gs, ls = gw.gsize(kind), gw.lsize(kind)
             off = {gw.POSE: ("para_Pose", 7 * i), gw.SPEEDBIAS: ("para_SpeedBias", 9 * i), gw.EX_POSE: ("para_Ex_Pose", 0), gw.EX_WHEEL: ("para_Ex_Pose_wheel", 0),
-                   gw.SX: ("para_Ix", 0), gw.SY: ("para_Ix", 1), gw.SW: ("para_Ix", 2), gw.TD: ("para_Td", 0), gw.TD_WHEEL: ("para_Td_wheel", 0)}[kind]
+                   gw.SX: ("para_Ix", 0), gw.SY: ("para_Ix", 1), gw.SW: ("para_Ix", 2), gw.TD: ("para_Td", 0), gw.TD_WHEEL: ("para_Td_wheel", 0),
+                   gw.RCV_DT: ("para_rcv_dt", i), gw.RCV_DDT: ("para_rcv_ddt", i), gw.YAW: ("para_yaw_enu_local", 0), gw.ANC: ("para_anc_ecef", 0)}[kind]
             x = w[off[0]][off[1]:off[1] + gs]
             d = prior_dx(gs == 7, x, w["prior_x0"][xo:xo + gs])
             for q in range(ls):
@@ -420,6 +579,11 @@ def window_normal_equations(w, ids):
         cost += (r.T * r)[0] / 2
         add(r, [(gw.bid(gw.POSE, i), J["pi"]), (gw.bid(gw.POSE, j), J["pj"]), (gw.bid(gw.EX_WHEEL), J["exw"]), (gw.bid(gw.SX), J["sx"]), (gw.bid(gw.SY), J["sy"]), (gw.bid(gw.SW), J["sw"]),
                 (gw.bid(gw.TD_WHEEL), J["tdw"])])
+    # GNSS blocks (estimator.cpp:3178-3229: only when gnss_ready and not lowspeed; no loss)
+    if int(w.get("gnss_enabled", 0)) and not int(w.get("gnss_lowspeed", 0)):
+        for r, blocks in gnss_factors(w):
+            cost += (r.T * r)[0] / 2
+            add(r, blocks)
     # visual factors (estimator.cpp:3269-3297, loss_function = HuberLoss(1.0))
     for k in range(int(w["n_visual"])):
         f, i, j = int(w["vis_feature"][k]), int(w["vis_i"][k]), int(w["vis_j"][k])
@@ -457,7 +621,8 @@ def marg_golden(w, mode=0):
             kind, i = int(bid_) // 4096, int(bid_) % 4096
             gs, ls = gw.gsize(kind), gw.lsize(kind)
             off = {gw.POSE: ("para_Pose", 7 * i), gw.SPEEDBIAS: ("para_SpeedBias", 9 * i), gw.EX_POSE: ("para_Ex_Pose", 0), gw.EX_WHEEL: ("para_Ex_Pose_wheel", 0),
-                   gw.SX: ("para_Ix", 0), gw.SY: ("para_Ix", 1), gw.SW: ("para_Ix", 2), gw.TD: ("para_Td", 0), gw.TD_WHEEL: ("para_Td_wheel", 0)}[kind]
+                   gw.SX: ("para_Ix", 0), gw.SY: ("para_Ix", 1), gw.SW: ("para_Ix", 2), gw.TD: ("para_Td", 0), gw.TD_WHEEL: ("para_Td_wheel", 0),
+                   gw.RCV_DT: ("para_rcv_dt", i), gw.RCV_DDT: ("para_rcv_ddt", i), gw.YAW: ("para_yaw_enu_local", 0), gw.ANC: ("para_anc_ecef", 0)}[kind]
             d = prior_dx(gs == 7, w[off[0]][off[1]:off[1] + gs], w["prior_x0"][xo:xo + gs])
             for q in range(ls):
                 dx[idx + q] = d[q]
@@ -489,6 +654,10 @@ def marg_golden(w, mode=0):
         r, J = wheel_factor(pose[0], pose[1], exw, mpf(w["para_Ix"][0]), mpf(w["para_Ix"][1]), mpf(w["para_Ix"][2]), mpf(w["para_Td_wheel"][0]), pre)
         factors.append((r, [(gw.bid(gw.POSE, 0), J["pi"]), (gw.bid(gw.POSE, 1), J["pj"]), (gw.bid(gw.EX_WHEEL), J["exw"]), (gw.bid(gw.SX), J["sx"]), (gw.bid(gw.SY), J["sy"]),
                             (gw.bid(gw.SW), J["sw"]), (gw.bid(gw.TD_WHEEL), J["tdw"])]))
+    if mode == 0 and int(w.get("gnss_enabled", 0)):   # estimator.cpp:3397-3434 (taken whenever gnss_ready, lowspeed or not): dropped with them the frame-0 clocks
+        for r, blocks in gnss_factors(w, frames=(0,)):
+            factors.append((r, blocks))
+        drop_ids += [gw.bid(gw.RCV_DT, q) for q in range(4)] + [gw.bid(gw.RCV_DDT, 0)]
     for k in range(int(w["n_visual"]) if mode == 0 else 0):
         f, i, j = int(w["vis_feature"][k]), int(w["vis_i"][k]), int(w["vis_j"][k])
         if i != 0:
@@ -536,14 +705,28 @@ def marg_golden(w, mode=0):
     br = bb[m:pos, 0] - Arm * Amm_inv * bb[0:m, 0]                                               # :292
     ev2, V2 = mp.eigsy((Ar + Ar.T) / 2)   # SelfAdjointEigenSolver reads the lower triangle of a matrix that is symmetric up to rounding: symmetrised here  (:294)
     JtJ, proj = mp.zeros(n, n), mp.zeros(n, n)
+    Jlin, rlin = mp.zeros(n, n), mp.zeros(n, 1)                                                  # linearized_jacobians / linearized_residuals themselves (one valid basis)
     for k in range(n):
         if ev2[k] > eps:                                                                         # :295-296
             vk = V2[:, k]
             JtJ += vk * vk.T * ev2[k]                                                            # J = sqrt(S) V^T  (:301)  ->  J^T J = V S V^T
             proj += vk * vk.T                                                                    # r = S^-1/2 V^T b (:302)  ->  J^T r = V V^T b
+            sq = mp.sqrt(ev2[k])
+            for c in range(n):
+                Jlin[k, c] = sq * vk[c]
+            rlin[k] = (vk.T * br)[0] / sq
     Jtr = proj * br
     evs = sorted(float(x) for x in ev2)
-    return {"kept": kept, "m": m, "n": n, "JtJ": JtJ, "Jtr": Jtr, "eigenvalues_kept": evs, "eigenvalues_dropped": sorted(float(x) for x in ev)}
+    # linearisation point of the prior: the kept blocks' states (keep_block_data, :214-217), in kept order
+    x0 = []
+    for b in kept:
+        kind, i = b // 4096, b % 4096
+        gs = gw.gsize(kind)
+        off = {gw.POSE: ("para_Pose", 7 * i), gw.SPEEDBIAS: ("para_SpeedBias", 9 * i), gw.EX_POSE: ("para_Ex_Pose", 0), gw.EX_WHEEL: ("para_Ex_Pose_wheel", 0),
+               gw.SX: ("para_Ix", 0), gw.SY: ("para_Ix", 1), gw.SW: ("para_Ix", 2), gw.TD: ("para_Td", 0), gw.TD_WHEEL: ("para_Td_wheel", 0),
+               gw.RCV_DT: ("para_rcv_dt", i), gw.RCV_DDT: ("para_rcv_ddt", i), gw.YAW: ("para_yaw_enu_local", 0), gw.ANC: ("para_anc_ecef", 0)}[kind]
+        x0 += [float(v) for v in w[off[0]][off[1]:off[1] + gs]]
+    return {"kept": kept, "m": m, "n": n, "JtJ": JtJ, "Jtr": Jtr, "J": Jlin, "r": rlin, "x0": x0, "eigenvalues_kept": evs, "eigenvalues_dropped": sorted(float(x) for x in ev)}
 
 
 def to_list(a):
@@ -558,7 +741,8 @@ def main():
     cases = [("ref_window_free_ex_td", dict(seed=7, max_features=8, n_landmarks=12, use_wheel=False, fix_ex_pose=0, fix_td=0), False),
              ("ref_window_with_prior", dict(seed=8, max_features=10, n_landmarks=15, use_wheel=False), True),
              ("ref_window_wheel", dict(seed=9, max_features=6, n_landmarks=9), False),                                            # the shipped configuration: wheel extrinsic free, intrinsics / td_wheel fixed
-             ("ref_window_wheel_free_ix_td", dict(seed=10, max_features=6, n_landmarks=9, fix_ix=0, fix_td_wheel=0), False)]    # every column of the wheel factor
+             ("ref_window_wheel_free_ix_td", dict(seed=10, max_features=6, n_landmarks=9, fix_ix=0, fix_td_wheel=0), False),    # every column of the wheel factor
+             ("ref_window_gnss", dict(seed=11, max_features=6, n_landmarks=9, gnss=True), False)]                                # + 132 pseudorange / Doppler blocks, the clock factors
     for name, kw, with_prior in cases:
         seed = kw.pop("seed")
         w = SW.make_window(seed, O, **kw)
@@ -601,7 +785,9 @@ def main():
     p0 = O.ba_marginalize(w0, 0)
     w1 = SW.make_window(8, O, frame0=1, prior=p0, **kwm)
     O.ba_solve(w1, 4)
-    for name, w, mode in (("ref_marg_old_first_window", w0, 0), ("ref_marg_old_with_prior", w1, 0), ("ref_marg_second_new", w1, 1)):
+    wg = SW.make_window(12, O, gnss=True, **kwm)
+    O.ba_solve(wg, 4)
+    for name, w, mode in (("ref_marg_old_first_window", w0, 0), ("ref_marg_old_with_prior", w1, 0), ("ref_marg_second_new", w1, 1), ("ref_marg_old_gnss", wg, 0)):
         w.finalize()
         g = marg_golden(w, mode)
         n = g["n"]

@@ -460,7 +460,7 @@ def test_split_jtj_formulation_gives_the_same_bits(gf, oracle):
     ea.close(); ec.close()
 
 
-@pytest.mark.parametrize("name", ["ref_window_free_ex_td", "ref_window_with_prior", "ref_window_wheel", "ref_window_wheel_free_ix_td"])
+@pytest.mark.parametrize("name", ["ref_window_free_ex_td", "ref_window_with_prior", "ref_window_wheel", "ref_window_wheel_free_ix_td", "ref_window_gnss"])
 def test_normal_equations_meet_the_reference_formulas_at_60_digits(gf, name):
     """H, g, cost of a whole small window from the HIP sweeps (gf_ba_linearize) against tests/golden/ref_*.json.gz: the reference's ProjectionTwoFrameOneCamFactor, IMUFactor, WheelFactor,
     MarginalizationFactor and Ceres' Huber corrector evaluated with 60 digits by tests/golden/make_ref_golden.py -- numbers neither the oracle nor the library produced"""
@@ -472,7 +472,7 @@ def test_normal_equations_meet_the_reference_formulas_at_60_digits(gf, name):
     est.close()
 
 
-@pytest.mark.parametrize("name", ["ref_marg_old_first_window", "ref_marg_old_with_prior", "ref_marg_second_new"])
+@pytest.mark.parametrize("name", ["ref_marg_old_first_window", "ref_marg_old_with_prior", "ref_marg_second_new", "ref_marg_old_gnss"])
 def test_marginalisation_meets_the_reference_route_at_60_digits(gf, name):
     """the HIP marginalisation (block elimination + rank-revealing Cholesky + least-squares right-hand side) against the reference's eigen route evaluated with 60 digits
     (tests/golden/ref_marg_*.json.gz): J^T J and J^T r of the prior, the same bars as the oracle's own test"""
