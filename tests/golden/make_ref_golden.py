@@ -729,6 +729,51 @@ def marg_golden(w, mode=0):
     return {"kept": kept, "m": m, "n": n, "JtJ": JtJ, "Jtr": Jtr, "J": Jlin, "r": rlin, "x0": x0, "eigenvalues_kept": evs, "eigenvalues_dropped": sorted(float(x) for x in ev)}
 
 
+def first_step_golden(w, ids, H, g):
+    """The first trust-region step at 60 digits: Jacobi scaling s = 1 / (1 + sqrt(diag H)) (trust_region_minimizer.cc), the dogleg's regularised Gauss-Newton step
+    (s H s + mu D^2) y = s g with D^2 = clamp(s^2 diag H, 1e-6, 1e32), mu = 1e-8 (dogleg_strategy.cc: min_diagonal / max_diagonal, min_mu), taken whole when |D y| <= the
+    initial radius 1e4, then x (+) delta, delta = -s o y, with PoseLocalParameterization::Plus (pose_local_parameterization.cpp:12-28) on the poses.  Solved by LU on
+    the FULL system (no Schur complement, no Cholesky).  Returns None when the step is clipped by the radius (the dogleg would interpolate)."""
+    import gfwindow as gw
+    n = len(ids)
+    s = [1 / (1 + mp.sqrt(H[c, c])) for c in range(n)]
+    S = mp.matrix(n, n)
+    for a in range(n):
+        for c in range(n):
+            S[a, c] = s[a] * H[a, c] * s[c]
+    mu = mp.mpf("1e-8")
+    D2 = [min(max(s[c] * s[c] * H[c, c], mp.mpf("1e-6")), mp.mpf("1e32")) for c in range(n)]
+    for c in range(n):
+        S[c, c] += mu * D2[c]
+    y = mp.lu_solve(S, mp.matrix([s[c] * g[c] for c in range(n)]))
+    if mp.sqrt(sum(D2[c] * y[c] * y[c] for c in range(n))) > mp.mpf("1e4"):
+        return None
+    delta = [-s[c] * y[c] for c in range(n)]
+    col0 = {}
+    for c, b in enumerate(ids):
+        col0.setdefault(int(b), c)
+
+    def plus(p7, c0):
+        P, Q = pose_of(p7)
+        q = qnormalized(qmul(Q, delta_q(mp.matrix(delta[c0 + 3:c0 + 6]))))
+        return [float(P[0] + delta[c0]), float(P[1] + delta[c0 + 1]), float(P[2] + delta[c0 + 2]), float(q[1]), float(q[2]), float(q[3]), float(q[0])]
+    out = {"para_Pose": [], "para_SpeedBias": []}
+    for i in range(int(w["W"]) + 1):
+        out["para_Pose"] += plus(w["para_Pose"][7 * i:7 * i + 7], col0[gw.bid(gw.POSE, i)])
+        c0 = col0[gw.bid(gw.SPEEDBIAS, i)]
+        out["para_SpeedBias"] += [float(mpf(w["para_SpeedBias"][9 * i + q]) + delta[c0 + q]) for q in range(9)]
+    if gw.bid(gw.EX_POSE) in col0:
+        out["para_Ex_Pose"] = plus(w["para_Ex_Pose"], col0[gw.bid(gw.EX_POSE)])
+    if gw.bid(gw.EX_WHEEL) in col0:
+        out["para_Ex_Pose_wheel"] = plus(w["para_Ex_Pose_wheel"], col0[gw.bid(gw.EX_WHEEL)])
+    feat = [float(x) for x in w["para_Feature"]]
+    for f in range(int(w["n_feature"])):
+        if gw.bid(gw.FEATURE, f) in col0:
+            feat[f] = float(mpf(w["para_Feature"][f]) + delta[col0[gw.bid(gw.FEATURE, f)]])
+    out["para_Feature"] = feat
+    return out
+
+
 def to_list(a):
     return np.asarray(a).reshape(-1).tolist()
 
@@ -772,6 +817,14 @@ def main():
               "window": {k: (to_list(v) if isinstance(v, np.ndarray) else v) for k, v in dict(w).items()},
               "ids": ids, "n_f": int(lin["n_f"]), "n_e": int(lin["n_e"]), "H_lower": [float(Hd[a, c]) for a in range(n) for c in range(a + 1)], "g": gd.tolist(), "cost": float(cost),
               "cost_30_digits": mp.nstr(cost, 30)}
+        if name in ("ref_window_free_ex_td", "ref_window_wheel"):     # the state after the first trust-region step, when that step is the whole Gauss-Newton step
+            st1 = first_step_golden(w, ids, H, g)
+            if st1 is not None:
+                a1 = w.copy()
+                so = O.ba_solve(a1, 1)
+                dev = max(np.abs(np.array(st1[k]) - a1[k]).max() for k in st1)
+                print("   first step (exact, LU on the full system at 60 digits) vs the oracle's first iteration (successful steps %d): %.2e" % (so["successful_steps"], dev))
+                fx["first_step"] = st1
         import gzip
         path = os.path.join(out_dir, name + ".json.gz")
         with gzip.GzipFile(path, "wb", mtime=0) as f:      # mtime 0: the same bytes on every run

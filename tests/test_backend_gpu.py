@@ -466,8 +466,8 @@ def test_normal_equations_meet_the_reference_formulas_at_60_digits(gf, name):
     MarginalizationFactor and Ceres' Huber corrector evaluated with 60 digits by tests/golden/make_ref_golden.py -- numbers neither the oracle nor the library produced"""
     from test_golden import load_ref_window, check_against_ref
     w, fx, H, g = load_ref_window(name)
-    est = gf.Estimator(max_features=16, max_visual=256)
-    dev = check_against_ref(est.linearize(w), fx, H, g, tol=1e-11)
+    est = gf.Estimator(max_features=16, max_visual=256, max_gnss=132 if w["gnss_enabled"] else 0)
+    dev = check_against_ref(est.linearize(w, cap=1024), fx, H, g, tol=1e-11)
     print(name, "HIP vs reference formulas at 60 digits: H scaled %.1e, g %.1e" % dev)
     est.close()
 
@@ -478,7 +478,16 @@ def test_marginalisation_meets_the_reference_route_at_60_digits(gf, name):
     (tests/golden/ref_marg_*.json.gz): J^T J and J^T r of the prior, the same bars as the oracle's own test"""
     from test_golden import load_ref_marg, check_prior_against_ref
     w, fx, A, b, ids = load_ref_marg(name)
-    est = gf.Estimator(max_features=16, max_visual=256)
+    est = gf.Estimator(max_features=16, max_visual=256, max_gnss=132 if w["gnss_enabled"] else 0)
     dev = check_prior_against_ref(est.marginalize([w], fx["mode"])[0], fx, A, b, ids)
     print(name, "HIP vs reference route at 60 digits: J^T J scaled %.1e, J^T r %.1e" % dev)
+    est.close()
+
+
+def test_first_step_meets_the_exact_step(gf):
+    """ba_step's first iteration (Jacobi scaling, Schur complement on the matrix cores, blocked Cholesky, back-substitution, candidate (+)) against the same step by LU on
+    the full system at 60 digits (tests/golden/ref_window_free_ex_td.json.gz, `first_step`): free camera extrinsic, condition 3e8"""
+    from test_golden import check_first_step
+    est = gf.Estimator(max_features=16, max_visual=256)
+    print("HIP vs exact first step:", check_first_step(lambda a: est.solve([a], 1)[0]))
     est.close()

@@ -200,3 +200,20 @@ def test_oracle_marginalisation_meets_the_reference_route_at_60_digits(oracle, n
     w, fx, A, b, ids = load_ref_marg(name)
     dev = check_prior_against_ref(oracle.ba_marginalize(w, fx["mode"]), fx, A, b, ids)
     print(name, "oracle vs reference route at 60 digits: J^T J scaled %.1e, J^T r %.1e" % dev)
+
+
+def check_first_step(solve_one, name="ref_window_free_ex_td", tol=1e-7):
+    """the state after ONE trust-region iteration against the exact first step stored in the fixture (make_ref_golden.first_step_golden: Jacobi scaling, the dogleg's
+    regularised Gauss-Newton step with mu = 1e-8 inside the initial radius, x (+) delta; LU on the full system at 60 digits -- no Schur complement, no Cholesky)"""
+    w, fx, _, _ = load_ref_window(name)
+    a = w.copy()
+    s = solve_one(a)
+    assert s["successful_steps"] == 1 and s["iterations"] == 1
+    dev = {k: float(np.abs(np.array(v) - a[k]).max()) for k, v in fx["first_step"].items()}
+    assert max(dev.values()) < tol, dev
+    return dev
+
+
+def test_oracle_first_step_meets_the_exact_step(oracle):
+    """row S1 (trust region / dogleg / Schur / Cholesky), first iteration: observed 1e-9 m on a system of condition 3e8"""
+    print("oracle vs exact first step:", check_first_step(lambda a: oracle.ba_solve(a, 1)))
