@@ -394,6 +394,10 @@ def test_gnss_marginalization_and_chain(gf, oracle, seed):
     dp, dr = _pose_diff(w2o, w2g)
     shape = np.abs((Pg[:, :3] - Pg[0, :3]) - (Po[:, :3] - Po[0, :3])).max()
     print("gnss chain seed %d: dp %.3e dr %.3e shape %.3e" % (seed, dp, dr, shape))
+    # Round 5, adjudicated at 60 digits (scripts/adjudicate_gnss_chain.py, output in profiles/r05_adjudicate_gnss_chain.txt): window 2 solved by ONE solver with the exact
+    # prior (the reference's route from the reference's factor formulas in mpmath), the oracle's and the library's -- the ORACLE's chain sits 3.5e-5 m (seed 1) / 3.5e-7 m
+    # (seed 2) from the exact one, the library's 1.5e-5 / 3.5e-7 m: the 1e-4 between the two is the double-precision noise of the reference's own algorithm in the
+    # directions next to its 1e-8 cut (kept eigenvalues 3.4e-8, 1.6e-7 at seed 1), with the oracle the farther of the two.
     assert dr < 1e-6 and shape < 1e-6 and dp < 1e-4, (dp, dr, shape)      # observed 5e-7 and 3.5e-5
     p1o, p1g = oracle.ba_marginalize(a, 1), est.marginalize([a], 1)[0]
     assert p1g["n"] == p1o["n"] == 89 and list(p1g["block_id"]) == list(p1o["block_id"])

@@ -177,7 +177,10 @@ def test_replay_configurations_of_the_other_shipped_yaml_files(variant):
         td_free += int(abs(est_o.td) > 0)
         if variant == "subset_cam":
             # z never moves; y is the window's weakest direction -- on this stream the solver lets tic wander by 2.3 m in three seconds (no prior worth the name on a
-            # freshly freed block), and the two pipelines end 2e-5 apart in it (relative; the poses of the same frames agree to 1e-7): bar 1e-4 relative
+            # freshly freed block), and the two pipelines end 2e-5 apart in it (relative; the poses of the same frames agree to 1e-7): bar 1e-4 relative.
+            # Round 5: one step of such a window against the same step at 60 digits (scripts/adjudicate_free_extrinsic_step.py, tests/golden `first_step`): the scaled,
+            # damped system has condition 3e8 (its smallest eigenvalue IS the mu = 1e-8 damping: the direction is not observed at all), a single step of either
+            # implementation is within 1e-9 m of the exact one -- 2.5e-8 of the step -- and a closed loop of ~40 such solves on a block that moves by metres compounds it.
             assert s["tic"][2] == 0.0 == est_o.tic[2] and np.abs(s["tic"] - est_o.tic).max() < 1e-4 * max(1.0, np.abs(est_o.tic).max())
         if variant == "subset_wheel":
             assert s["tio"][2] == SS.TIO[2] == est_o.tio[2]
@@ -522,6 +525,9 @@ def test_replay_with_gnss_matches_oracle(window_size, own_initialiser, raw):
     # J^T r = orthogonal projection of b onto the factor's range, scripts/marg_rhs_projection.py) the same replays sit at 3e-8 ... 9e-6 m in every variant, raw
     # ephemerides and own initialiser included (before: 1e-4 handed-in, 4e-4 own initialiser, 1e-2 raw): the bar is 2e-5 m, twice the largest observed value
     # (the modelled range under `lowspeed` at W = 20).
+    # Round 5: the same mechanism adjudicated at 60 digits on the two-window chain (scripts/adjudicate_gnss_chain.py): the oracle's own chain is 3.5e-5 m from the chain
+    # with the exact prior in the absolute position / anchor and 4.6e-6 m in the receiver clocks, the library's 1.5e-5 / 1.5e-6 m -- a closed loop of priors between two
+    # double-precision implementations cannot be held tighter than that in these states; the local poses are (1e-6, compare_frame).
     bar = 2e-5
     assert worst["clk"] < bar and worst["anc"] < bar and worst["ecef"] < bar, worst
     assert worst["anc_low"] < bar and worst["ecef_low"] < bar and worst["rho"] < bar, worst      # rho runs over the `lowspeed` frames too
