@@ -456,6 +456,7 @@ def main():
     ap.add_argument("--e2e-only", action="store_true", help="only the end-to-end (drop-in path) sample, as one JSON line (used by the default run for its small-host sample)")
     ap.add_argument("--host-threads", type=int, default=0, help="with --e2e-only: confine this process to the first N hardware threads (sched_setaffinity) and size the worker pools for them")
     ap.add_argument("--no-small-host", action="store_true", help="skip the end-to-end sample on 8 hardware threads")
+    ap.add_argument("--small-host-all", action="store_true", help="the 8-thread end-to-end sample with one estimator group as well (default: two alternating groups only)")
     args = ap.parse_args()
 
     if args.e2e_only:
@@ -728,7 +729,7 @@ def main():
             res["end_to_end"]["first_pass_window_solves_per_s"] = cold["window_solves_per_s"]
             if not args.no_small_host:   # the same sample with the whole process confined to 8 hardware threads (the host BASELINE.md plans for), in a process of its own
                 import subprocess
-                for ng in (1, 2):
+                for ng in ((1, 2) if args.small_host_all else (2,)):   # two alternating groups is the arrangement the default sample uses; one group next to it on request
                     try:
                         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--e2e-only", "--host-threads", "8", "--e2e-groups", str(ng), "--e2e-seqs", str(args.e2e_seqs),
                                               "--e2e-streams", str(S)], capture_output=True, text=True, timeout=600)

@@ -20,6 +20,7 @@ run backend_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 run backend_sq2 "SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" backend 256
 run backend_fetch FETCH_SIZE backend 256
 run backend_write WRITE_SIZE backend 256
+[ -n "$PMC_SKIP_SPLIT" ] && exit 0   # the split J^T J formulation's kernels (a measured, switched-off alternative: DESIGN.md section 4) on request only
 run backend_split_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT" backend_split 256
 run backend_split_fetch FETCH_SIZE backend_split 256
 run backend_split_write WRITE_SIZE backend_split 256
