@@ -25,7 +25,7 @@ trace() {  # name, bench args...
 for what in "$@"; do
   case $what in
     tests)   timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/${tag}_pytest.log 2>&1; echo "pytest rc $?"; tail -4 gpurun_out/${tag}_pytest.log ;;
-    bench1)  /usr/bin/time -v timeout 900 python bench.py > gpurun_out/${tag}_bench_c1.json 2> gpurun_out/${tag}_bench_c1.err; echo "bench1 rc $?"; grep "Elapsed (wall" gpurun_out/${tag}_bench_c1.err; head -c 400 gpurun_out/${tag}_bench_c1.json; echo ;;
+    bench1)  SECONDS=0; timeout 900 python bench.py > gpurun_out/${tag}_bench_c1.json 2> gpurun_out/${tag}_bench_c1.err; echo "bench1 rc $? in $SECONDS s (the whole default run: timed loop, isolated passes, pcie / small-batch / end-to-end samples, cpu baseline)"; head -c 400 gpurun_out/${tag}_bench_c1.json; echo ;;
     bench2)  timeout 600 python bench.py --config 2 --no-e2e --no-cpu-baseline --no-small-batch > gpurun_out/${tag}_bench_c2.json 2> gpurun_out/${tag}_bench_c2.err; echo "bench2 rc $?"; head -c 300 gpurun_out/${tag}_bench_c2.json; echo ;;
     bench4)  timeout 900 python bench.py --config 4 --no-cpu-baseline --no-small-batch > gpurun_out/${tag}_bench_c4.json 2> gpurun_out/${tag}_bench_c4.err; echo "bench4 rc $?"; head -c 300 gpurun_out/${tag}_bench_c4.json; echo ;;
     prof1)   trace c1 ;;
