@@ -174,7 +174,8 @@ struct gf_ba {
     std::vector<std::vector<int>> keep_ids[2];   // per window: kept block ids (before the address shift), in column order
     size_t marg_lds = 0; int marg_ncap = 0, last_marg_mode = -1;
     size_t vwin_lds = 0;   // dynamic LDS of the visual sweep (its pair tiles); 0: the tiles live in global memory (vtile)
-    size_t vwinx_lds = 0;  // the same for the variant with camera-extrinsic columns (free extrinsic; MARGIN_OLD sweep)
+    size_t vwinx_lds = 0;  // the same for the variant with camera-extrinsic columns (free extrinsic)
+    size_t vwinm_lds = 0;  // dynamic LDS of the MARGIN_OLD sweep (NP - 1 pair tiles + continuation slots: always fits)
     size_t vtile_stride = 0;   // doubles per window in vtile (0: both variants keep their tiles in LDS)
     size_t mwin_lds = 0;   // dynamic LDS of the prior / IMU / wheel sweep (ba_linearize_misc_win)
     bool fuse_misc = false, can_fuse_misc = false;
@@ -682,7 +683,11 @@ int launch_visual(gf_ba* h, Win w, bool ex, int which, int which_state, int only
     const size_t lds = ex ? h->vwinx_lds : h->vwin_lds;
     w.vtile = lds ? nullptr : h->vtile.d;
     w.vpair = h->vpair.d;
-    if (ex) ba_linearize_visual_win<true, kVWX><<<dim3(d.B), 64 * kVWX, lds, h->stream>>>(w, h->sbufs(), which, which_state, only_valid);
+    if (ex && only_valid == 2) {   // MARGIN_OLD pass: eight wavefronts, NP - 1 pair tiles, always in LDS
+        w.vtile = nullptr;
+        ba_linearize_visual_win<true, kVWM><<<dim3(d.B), 64 * kVWM, h->vwinm_lds, h->stream>>>(w, h->sbufs(), which, which_state, only_valid);
+    }
+    else if (ex) ba_linearize_visual_win<true, kVWX><<<dim3(d.B), 64 * kVWX, lds, h->stream>>>(w, h->sbufs(), which, which_state, only_valid);
     else if (h->split_jtj && only_valid != 2) {   // north_star's formulation, measured next to the fused kernel: the sweep writes block rows to HBM, a second kernel only contracts them
         w.vrows = h->vrows.d;
         ba_linearize_visual_win<false, kVW, 1><<<dim3(d.B), 64 * kVW, lds, h->stream>>>(w, h->sbufs(), which, which_state, only_valid);
@@ -880,6 +885,8 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
         const size_t dynx = vwin_slot_doubles(d.NP, true) * sizeof(double), statx = (size_t)kVWX * vwin_sg(true) * vwin_lstr(true) * sizeof(double) + kVWX * 64 * sizeof(int) + 512 + 2048;
         h->vwinx_lds = (dynx + statx <= 160 * 1024 && !glob) ? dynx : 0;
         if (h->vwinx_lds) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_visual_win<true, kVWX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->vwinx_lds));
+        h->vwinm_lds = vwin_marg_slot_doubles(d.NP) * sizeof(double);
+        H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_visual_win<true, kVWM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->vwinm_lds));
         if (!h->vwin_lds || !h->vwinx_lds) { h->vtile_stride = (vwin_slot_doubles(d.NP, true) + 3) & ~(size_t)3; A_(h->vtile.alloc(B * h->vtile_stride, false)); }
         h->mwin_lds = misc_win_lds_doubles(d.W) * sizeof(double);
         H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_misc_win), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->mwin_lds));

@@ -114,11 +114,13 @@ constexpr int IMU_STRIDE2 = 17 + 450;
 constexpr int WH_STRIDE = 1 + 3 + 4 + 18 + 36 + 4 + 12;  // sum_dt, dp, dq, jac(6x3), cov(6x6), lin(4), lin_vel, lin_gyr, vel_1, gyr_1
 // per-factor eliminated-column products, one scratch buffer per batch (written and consumed inside one ba_linearize_visual_win launch).
 //   EX (camera extrinsic carries columns): 24 doubles = Jd^T[Ji(6) Jj(6) Jtd(1) Jex(6)], Jd^T Jd, Jd^T r, then the factor's frames i, j (as doubles)
-//   else: 16 doubles = ONE 128-byte line: Jd^T[Ji(6) Jj(6) Jtd(1)], Jd^T Jd, Jd^T r, frames (i, j) as two ints in the last slot.
+//   else (round 5): 10 doubles = 80 bytes: Jd^T[Ji(6) Jtd(1)], Jd^T Jd, Jd^T r, frames (i, j) as two ints in the last slot.  The six products Jd^T Jj are unique to their factor
+//         (its second frame): the evaluating lane stores them straight into the feature's E^T F row instead of parking them here for et_rows8 to copy (rounds 3-4: 16 doubles,
+//         one 128-byte line; these products were 98 of the ~130 MB a launch of 256 windows moves).
 // The sweeps are bound by memory traffic as much as by arithmetic (all 256 windows of a launch move their tables at once: ~3.7 TB/s over the launch); the
 // products were 2 x 73 MB (double-buffered, 192 B per factor) against a 256 MB Infinity Cache; now 49 MB.
 constexpr int EF = 24;
-template <bool EX> __host__ __device__ constexpr int ef_stride() { return EX ? 24 : 16; }
+template <bool EX> __host__ __device__ constexpr int ef_stride() { return EX ? 24 : 10; }
 #ifdef GF_PROFILE_STEP
 #define GF_WSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && w.stamps) w.stamps[i] = clock64(); } while (0)
 #define GF_WSTAMP_T(t, i) do { if (blockIdx.x == 0 && threadIdx.x == (t) && w.stamps) w.stamps[i] = clock64(); } while (0)
@@ -293,7 +295,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // One visual factor per lane: residual, Jacobians, Huber correction, zeroed columns of constant blocks, and the products the Schur
 // complement needs for a free inverse depth (stored to efac).  k < 0: padding lane (all zero).  Returns the factor's cost.
 template <bool EX>
-__device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int b, int which, int k, const double* xs, const int* colf, VisEval& ev, int& fi, int& fj) {
+__device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int b, int which, int k, const double* xs, const int* colf, VisEval& ev, int& fi, int& fj, double* etw = nullptr) {   // etw (!EX): this window's E^T F rows (zeroed by the caller)
     double cost = 0.0;
     int feat = 0;
     fi = 0; fj = 0;
@@ -353,14 +355,22 @@ __device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int
         // eliminated (free inverse depth) column: products needed by the Schur complement
         if (live && w.cole[(size_t)b * d.F + feat] >= 0) {
             double* ef = w.efac + ((size_t)b * d.NV * EF + (size_t)(w.pos_ident ? k : w.vis_pos[kk]) * ef_stride<EX>());   // the factors of a feature are contiguous
-#pragma unroll
-            for (int c = 0; c < 13; c++) ef[c] = ev.jd[0] * ev.row[0][c] + ev.jd[1] * ev.row[1][c];
             const double ete_f = ev.jd[0] * ev.jd[0] + ev.jd[1] * ev.jd[1], etb_f = ev.jd[0] * ev.row[0][13] + ev.jd[1] * ev.row[1][13];
             if (EX) {
 #pragma unroll
+                for (int c = 0; c < 13; c++) ef[c] = ev.jd[0] * ev.row[0][c] + ev.jd[1] * ev.row[1][c];
+#pragma unroll
                 for (int c = 0; c < 6; c++) ef[13 + c] = ev.jd[0] * ev.row[0][16 + c] + ev.jd[1] * ev.row[1][16 + c];
                 ef[19] = ete_f; ef[20] = etb_f; ef[21] = (double)fi; ef[22] = (double)fj;
-            } else { ef[13] = ete_f; ef[14] = etb_f; ef[15] = __hiloint2double(fj, fi); }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 6; c++) ef[c] = ev.jd[0] * ev.row[0][c] + ev.jd[1] * ev.row[1][c];                       // pose i: summed over the feature's factors (et_rows8)
+                ef[6] = ev.jd[0] * ev.row[0][12] + ev.jd[1] * ev.row[1][12];                                                    // td: summed
+                ef[7] = ete_f; ef[8] = etb_f; ef[9] = __hiloint2double(fj, fi);
+                double* er = etw + (size_t)w.cole[(size_t)b * d.F + feat] * d.ECW + 6 * fj;                                      // pose j: this factor's alone, straight into its place
+#pragma unroll
+                for (int c = 0; c < 6; c++) er[c] = ev.jd[0] * ev.row[0][6 + c] + ev.jd[1] * ev.row[1][6 + c];
+            }
         }
     }
     return cost;
@@ -763,6 +773,30 @@ __device__ __forceinline__ void et_rows8(const Win& w, const StepBufs& sb, const
     const int p0 = e >= 0 ? fptr[f] : 0, p1 = e >= 0 ? fptr[f + 1] : 0;
     const double* efac = w.efac + (size_t)b * d.NV * EF;
     double* Et = sb.Et + (((size_t)which * d.B + b) * d.FP + max(e, 0)) * d.ECW;
+    if (!EX) {   // round 5: the row was zeroed at the head of the kernel and already holds every factor's pose-j products; what is left are the sums
+        double acc = 0.0, accb = 0.0;
+        int fi = 0;
+        constexpr int NF = 10;
+        for (int pb = p0; pb < p1; pb += NF) {
+            double v[NF], vb[NF], fr0;
+#pragma unroll
+            for (int q = 0; q < NF; q++) {
+                const bool on = pb + q < p1;
+                const double* row = efac + (size_t)(on ? pb + q : p0) * EFS;
+                v[q] = on ? row[sub] : 0.0; vb[q] = (on && sub == 0) ? row[8] : 0.0;
+                if (q == 0) fr0 = row[9];
+            }
+            fi = __double2loint(fr0);
+#pragma unroll
+            for (int q = 0; q < NF; q++) { if (pb + q >= p1) continue; acc += v[q]; accb += vb[q]; }
+        }
+        if (e < 0) return;
+        if (sub < 6) Et[6 * fi + sub] = acc;                                   // pose i
+        else if (sub == 6) Et[6 * d.NP + 6] = acc;                             // td
+        else sb.ete[((size_t)which * d.B + b) * d.FP + e] = acc;               // sub == 7
+        if (sub == 0) sb.etb[((size_t)which * d.B + b) * d.FP + e] = accb;
+        return;
+    }
     if (e >= 0) for (int c = sub; c < d.ECW; c += 8) Et[c] = 0.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
     // EX:   lane `sub` owns the products sub (0-5 pose_i, 6-7 pose_j), 8 + sub (8-11 pose_j, 12 td, 13-15 ex 0-2) and 16 + sub (16-18 ex 3-5, 19 ete, 20 etb) of every factor
@@ -818,6 +852,8 @@ __device__ __forceinline__ void et_rows8(const Win& w, const StepBufs& sb, const
 // Slots: NP (NP - 1) / 2 + NW tiles of 14 x 14 (EX: 20 x 20) packed lower triangles, in LDS when they fit (W = 10), else in w.vtile.
 constexpr int kVW = 12;               // wavefronts per block, fixed extrinsic (three per SIMD at the kernel's ~150 VGPRs)
 constexpr int kVWX = 6;               // wavefronts per block when the camera extrinsic carries columns
+constexpr int kVWM = 8;               // wavefronts per block of the MARGIN_OLD pass (extrinsic columns, pairs (0, j) only: see ba_linearize_visual_win)
+__host__ __device__ inline size_t vwin_marg_slot_doubles(int NP) { return ((size_t)(NP - 1) + kVWM) * 210; }
 constexpr int kVFP = 511;             // feature lists up to this many features are staged in LDS
 __host__ __device__ constexpr int vwin_sg(bool ex) { return ex ? 16 : 32; }       // factors staged per pass
 __host__ __device__ constexpr int vwin_lstr(bool ex) { return ex ? 65 : 33; }     // staging row stride: 2 rows x COLS + 1
@@ -849,11 +885,18 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
     if (which_state == -2) which_state = st_cur; else if (which_state < 0) which_state = 1 - st_cur;
     const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
     const int* colf = w.colf + (size_t)b * d.NFB;
-    const int NPAIR = NP * (NP - 1) / 2;
+    // MARGIN_OLD pass (only_cand_valid == 2: its factor order holds the factors that start in frame 0 and nothing else): the pairs are (0, j), j = 1 .. NP - 1 -- NP - 1 tile
+    // slots instead of NP (NP - 1) / 2, which is what lets this pass run on kVWM = 8 wavefronts with its tiles in LDS at any window size (round 5; it ran on the six wavefronts
+    // the 55 + 6 slots of the solve's variant leave room for: 105 us against 50 us for the twelve-wavefront sweep of a whole window)
+    const bool pairs0 = EX && only_cand_valid == 2;
+    const int NPAIR = pairs0 ? NP - 1 : NP * (NP - 1) / 2;
+    auto slot_of = [&](int pi, int pj) -> int { return pairs0 ? pj - 1 : pj * (pj - 1) / 2 + pi; };
     double* slots = w.vtile ? w.vtile + (size_t)b * w.vtile_stride : v_dyn;
     double* bnd = slots + (size_t)NPAIR * TN;
     GF_WSTAMP(80);
     for (int i = tid; i < (NPAIR + NW) * TN; i += NT) slots[i] = 0.0;
+    double* etw = EX ? nullptr : sb.Et + ((size_t)which * d.B + b) * d.FP * d.ECW;   // this window's E^T F rows: zeroed here, filled by the evaluating lanes (pose j) and by et_rows8 (sums)
+    if (!EX && MODE != 2) { const int ne = uni(st.NE); for (int i = tid; i < ne * d.ECW; i += NT) etw[i] = 0.0; }
     if (d.F <= kVFP) for (int i = tid; i <= d.F; i += NT) s_fptr[i] = w.feat_ptr[(size_t)b * (d.F + 1) + i];
 #ifdef GF_VIS_PAIRGEO
     if (MODE != 2) {   // what the factors of a frame pair share, once per pair (visible to the whole block behind the barrier below: same CU, same L1)
@@ -885,7 +928,7 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
     __syncthreads();
     const int first_key = s_first[wave];
     const bool continuing = wave > 0 && first_key >= 0 && s_last[wave - 1] == first_key;
-    if (lane == 0) s_cont[wave] = continuing ? ((first_key & 63) * ((first_key & 63) - 1) / 2 + (first_key >> 6)) : -1;
+    if (lane == 0) s_cont[wave] = continuing ? slot_of(first_key >> 6, first_key & 63) : -1;
     GF_WSTAMP(81);
     double* Jbuf = Jst + wave * SG * LSTR;
     int* s_pair = s_pr[wave];
@@ -895,7 +938,7 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
     auto flush = [&](int pair) {   // store the finished tile of `pair` (local columns: 0-5 pose_i, 6-11 pose_j, 12 td, 13 residual, 14-19 extrinsic)
         if (pair < 0) return;
         const int pi = pair >> 6, pj = pair & 63;
-        double* dst = (continuing && pair == first_key) ? bnd + (size_t)wave * TN : slots + (size_t)(pj * (pj - 1) / 2 + pi) * TN;
+        double* dst = (continuing && pair == first_key) ? bnd + (size_t)wave * TN : slots + (size_t)slot_of(pi, pj) * TN;
         const int tb = lane & 15;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -914,7 +957,7 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
         const int k = oe < 0 ? -1 : (oe & 0xffff);
         int fi, fj;
         VisEval ev;
-        if (MODE != 2) cost += vis_lane_eval<EX>(w, d, b, which, k, xs, colf, ev, fi, fj);
+        if (MODE != 2) cost += vis_lane_eval<EX>(w, d, b, which, k, xs, colf, ev, fi, fj, etw);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();   // the previous chunk's reads of s_pair are done
         s_pair[lane] = oe < 0 ? -1 : (oe >> 16);
         if (MODE == 1) {   // block rows of this lane's factor to HBM: rows[entry][r][16], columns 14 / 15 and padding lanes zero
@@ -997,7 +1040,8 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
         double* Vc = w.Vc + ((size_t)which * d.B + b) * d.NVC;
         auto T = [&](int i, int j, int la, int lb) -> double {   // tile of pair (i < j), local entry (la, lb)
             const int hi = max(la, lb), lo = min(la, lb);
-            return slots[(size_t)(j * (j - 1) / 2 + i) * TN + hi * (hi + 1) / 2 + lo];
+            if (pairs0 && i > 0) return 0.0;   // no such pair in a MARGIN_OLD pass
+            return slots[(size_t)slot_of(i, j) * TN + hi * (hi + 1) / 2 + lo];
         };
         auto loc_other = [&](int k) -> int { return k < TD ? (EX ? 14 + (k - EXC) : -1) : k == TD ? 12 : 13; };   // local index of a non-pose column
         for (int idx = tid; idx < NCc * (NCc + 1) / 2; idx += NT) {
