@@ -554,6 +554,14 @@ def main():
                 gathered[0] = pose_gather(newest)
         step[0] += 1
 
+    t_phase = [time.perf_counter()]
+
+    def phase(name):   # where the wall clock of the whole run goes (stderr; the JSON line stays the only thing on stdout)
+        now = time.perf_counter()
+        if rank == 0:
+            print("bench.py: %-28s %6.1f s" % (name, now - t_phase[0]), file=sys.stderr, flush=True)
+        t_phase[0] = now
+    phase("setup (frames, windows)")
     for _ in range(Wm + 1):  # frame 0 only detects; it is part of the warm-up
         do_step()
     trk.reset_stats()
@@ -570,6 +578,7 @@ def main():
         do_step()
     barrier()
     el = time.perf_counter() - t0
+    phase("warm-up + timed loop")
     st = trk.stats()
     bs = est.stats()
     sums = est.download(wins) if not args.no_backend else [None]
@@ -697,10 +706,13 @@ def main():
             "ba_summary_seq0": sums[0],
             "kernel_source_sha16": kernel_source_sha16(), "pmc_summary": pmc.get("_stale", "profiles/pmc_summary.json matches this tree's kernel sources"),
         }
+        phase("isolated passes")
         if world == 1 and not args.no_pcie and not args.strong and not (args.no_frontend or args.no_backend):
             res["pcie_inclusive"] = pcie_sample(gfamd, trk, est, args, B, frames, depth, dt, step, frame_index)
+            phase("pcie_inclusive")
         if world == 1 and not args.no_small_batch and not args.strong and not (args.no_frontend or args.no_backend):
             res["small_batch"] = small_batch_sample(gfamd, dev, args, WIN, GNSS)
+            phase("small_batch")
         if world == 1 and not args.no_e2e and not args.strong and args.config == 1 and not (args.no_frontend or args.no_backend):
             trk.close(); trk = None
             S = max(1, args.e2e_streams)
@@ -727,18 +739,33 @@ def main():
                 res["end_to_end"]["with_device_feature_sweeps_window_solves_per_s"] = alt["window_solves_per_s"]
                 res["end_to_end"]["with_device_feature_sweeps_newest_position_norm_m"] = alt["newest_position_norm_m"]
             res["end_to_end"]["first_pass_window_solves_per_s"] = cold["window_solves_per_s"]
-            if not args.no_small_host:   # the same sample with the whole process confined to 8 hardware threads (the host BASELINE.md plans for), in a process of its own
-                import subprocess
-                for ng in ((1, 2) if args.small_host_all else (2,)):   # two alternating groups is the arrangement the default sample uses; one group next to it on request
+            if not args.no_small_host:
+                # The same sample on the host BASELINE.md plans for: this thread and every thread the library creates from here on (the tracker's bookkeeping pool, the
+                # groups' workers: both pools are sized from the affinity mask) confined to 8 hardware threads.  In this process -- the rendered recordings are reused --;
+                # the HIP runtime's own helper threads, created earlier, keep their mask (`python bench.py --e2e-only --host-threads 8` confines a whole process).
+                all_cpus = os.sched_getaffinity(0)
+                saved = {k_: os.environ.get(k_) for k_ in ("GF_HOST_THREADS", "GF_GROUP_THREADS")}
+                for ng in ((1, 2) if args.small_host_all else (2,)):
+                    key_ = "end_to_end_8_host_threads" + ("" if ng == 1 else "_two_groups")
                     try:
-                        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--e2e-only", "--host-threads", "8", "--e2e-groups", str(ng), "--e2e-seqs", str(args.e2e_seqs),
-                                              "--e2e-streams", str(S)], capture_output=True, text=True, timeout=600)
-                        r8 = json.loads(out.stdout.strip().splitlines()[-1])
-                        res["end_to_end_8_host_threads" + ("" if ng == 1 else "_two_groups")] = {k: r8[k] for k in (
-                            "window_solves_per_s", "passes_window_solves_per_s", "sequences", "distinct_recordings", "estimator_groups", "ms_per_backend_frame", "affinity_hardware_threads",
-                            "group_worker_threads", "tracker_host_threads", "main_thread_ms_per_backend_frame", "tracker_ms_per_call")}
+                        os.sched_setaffinity(0, set(sorted(all_cpus)[:8]))
+                        os.environ["GF_HOST_THREADS"] = "4"
+                        os.environ["GF_GROUP_THREADS"] = str(max(1, 4 // ng))
+                        p8 = [end_to_end_sample(gfamd, args.e2e_seqs, dev, args.max_cnt, args.min_dist, n_streams=S, n_groups=ng) for _ in range(2)]
+                        r8 = p8[1]
+                        res[key_] = {k_: r8[k_] for k_ in ("window_solves_per_s", "sequences", "distinct_recordings", "estimator_groups", "ms_per_backend_frame", "group_worker_threads",
+                                                            "main_thread_ms_per_backend_frame", "tracker_ms_per_call", "device_preint")}
+                        res[key_].update({"passes_window_solves_per_s": [r_["window_solves_per_s"] for r_ in p8], "affinity_hardware_threads": len(os.sched_getaffinity(0)), "tracker_host_threads": 4})
                     except Exception as ex:   # the sample is a side measurement: its failure must not cost the line
-                        res["end_to_end_8_host_threads" + ("" if ng == 1 else "_two_groups")] = {"error": repr(ex)[:300]}
+                        res[key_] = {"error": repr(ex)[:300]}
+                    finally:
+                        os.sched_setaffinity(0, all_cpus)
+                        for k_, v_ in saved.items():
+                            if v_ is None:
+                                os.environ.pop(k_, None)
+                            else:
+                                os.environ[k_] = v_
+        phase("end_to_end samples")
         if not args.no_cpu_baseline:
             nseq = min(8, B)
             cores = min(os.cpu_count() or 1, nseq)
@@ -752,6 +779,7 @@ def main():
                                              "(variant a x %d cores); then sequence 0 once more as variant b; %.1f s wall, ~%.0f s of CPU work; box has %d host cores"
                                              % (nseq, cb["repeat"], fh.shape[0], cb["repeat"] * max(1, fh.shape[0] // 4), cb["build"], cores, cores, cb["wall_s"], cb["wall_s"] * cores, os.cpu_count() or 1),
                                    "detail": cb}
+        phase("cpu_baseline")
         print(json.dumps(res))
     if trk is not None:
         trk.close()
