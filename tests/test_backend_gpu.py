@@ -398,6 +398,8 @@ def test_gnss_marginalization_and_chain(gf, oracle, seed):
     # prior (the reference's route from the reference's factor formulas in mpmath), the oracle's and the library's -- the ORACLE's chain sits 3.5e-5 m (seed 1) / 3.5e-7 m
     # (seed 2) from the exact one, the library's 1.5e-5 / 3.5e-7 m: the 1e-4 between the two is the double-precision noise of the reference's own algorithm in the
     # directions next to its 1e-8 cut (kept eigenvalues 3.4e-8, 1.6e-7 at seed 1), with the oracle the farther of the two.
+    # Later in round 5 the whole chain was run at 60 digits (tests/golden/ref_chain_gnss.json.gz, this seed): the library's chain ends 9.1e-8 m from it, the oracle's 3.5e-5 m --
+    # this bar measures the oracle; the library's own bar against the exact chain is 1e-6 (test_chain_meets_the_chain_at_60_digits below).
     assert dr < 1e-6 and shape < 1e-6 and dp < 1e-4, (dp, dr, shape)      # observed 5e-7 and 3.5e-5
     p1o, p1g = oracle.ba_marginalize(a, 1), est.marginalize([a], 1)[0]
     assert p1g["n"] == p1o["n"] == 89 and list(p1g["block_id"]) == list(p1o["block_id"])
@@ -494,4 +496,25 @@ def test_first_step_meets_the_exact_step(gf):
     from test_golden import check_first_step
     est = gf.Estimator(max_features=16, max_visual=256)
     print("HIP vs exact first step:", check_first_step(lambda a: est.solve([a], 1)[0]))
+    est.close()
+
+
+@pytest.mark.parametrize("name", ["ref_solve_free_ex_td", "ref_solve_with_prior", "ref_solve_wheel", "ref_solve_wheel_free_ix_td", "ref_solve_gnss"])
+def test_solve_meets_the_loop_at_60_digits(gf, name):
+    """the whole HIP solve -- 8 trust-region iterations: linearisation kernels, ba_step's Schur complement / blocked Cholesky / dogleg, candidate evaluation, step
+    acceptance -- against the same loop with every number at 60 digits (tests/golden/ref_solve_*.json.gz, made by tests/golden/make_ref_solve_golden.py from the
+    reference's factor formulas and Ceres' loop; LU on the full system): iterations, accepted steps, termination, final cost, final state"""
+    from test_golden import check_solve
+    est = gf.Estimator(max_features=16, max_visual=256, max_gnss=132 if "gnss" in name else 0)
+    print(name, "HIP vs the loop at 60 digits:", check_solve(lambda a: est.solve([a], 8)[0], name))
+    est.close()
+
+
+@pytest.mark.parametrize("name", ["ref_chain_gnss", "ref_chain_wheel"])
+def test_chain_meets_the_chain_at_60_digits(gf, name):
+    """the library's own chain through the C-ABI -- gf_ba_solve, gf_ba_marginalize (MARGIN_OLD), gf_ba_solve with that prior -- against the chain with every number at 60
+    digits (tests/golden/ref_chain_*.json.gz; bars and their reasons: tests/test_golden.py CHAIN_BARS_HIP -- 1e-6 on every block but one)"""
+    from test_golden import check_chain, CHAIN_BARS_HIP
+    est = gf.Estimator(max_features=16, max_visual=256, max_gnss=132 if "gnss" in name else 0)
+    print(name, "HIP chain vs 60 digits:", check_chain(lambda a: est.solve([a], 8)[0], lambda a: est.marginalize([a], 0)[0], name, CHAIN_BARS_HIP[name]))
     est.close()

@@ -171,6 +171,11 @@ def test_track_image_prediction_and_outlier_feedback(gf, oracle):
                         np.full(len(uv), 2.0)], 1)
         otr.set_prediction(ids[sel], xyz); gtr.setPrediction(ids[sel], xyz)
     gtr.close()
+    # ... and not only against the oracle: the library's x, y, vx, vy against the reference's formulas in other arithmetic (mpmath at 60 digits / numpy IEEE floats)
+    from test_golden import check_t8_against_the_reference_formulas
+    exact, total = check_t8_against_the_reference_formulas(outs, [0.0666 * k for k in range(len(frames))], K)
+    print("undistorted coordinates: %d of %d floats equal the 60-digit value rounded to float" % (exact, total))
+    assert exact >= 0.999 * total
 
 
 def test_depth_camera_without_depth_image_returns_an_empty_frame(gf, oracle):
@@ -203,9 +208,11 @@ def test_track_image_with_lens_distortion(gf, oracle):
     depth = np.full(frames[0].shape, 2100, np.uint16)
     otr, gtr = oracle.Tracker(ocfg), gf.FeatureTracker(gcfg)
     rng = np.random.default_rng(3)
+    outs = []
     for k, f in enumerate(frames):
         oi, oo = otr.track(0.0666 * k, f, depth)
         gi, go = gtr.trackImage(0.0666 * k, f, depth)
+        outs.append((gi.copy(), go.copy()))
         assert np.array_equal(oi, gi), "frame %d: ids differ" % k
         assert np.array_equal(oo.view(np.uint64), go.view(np.uint64)), "frame %d: observations differ" % k
         # the undistorted coordinates really differ from the pinhole ones
@@ -216,6 +223,11 @@ def test_track_image_with_lens_distortion(gf, oracle):
         xyz = np.stack([go[sel, 0] * 2.0, go[sel, 1] * 2.0, np.full(sel.sum(), 2.0)], 1) + rng.normal(0, 0.002, (sel.sum(), 3))
         otr.set_prediction(ids[sel], xyz); gtr.setPrediction(ids[sel], xyz)
     gtr.close()
+    # ... and not only against the oracle: the library's x, y, vx, vy against the reference's formulas in other arithmetic (mpmath at 60 digits / numpy IEEE floats)
+    from test_golden import check_t8_against_the_reference_formulas
+    exact, total = check_t8_against_the_reference_formulas(outs, [0.0666 * k for k in range(len(frames))], K)
+    print("undistorted coordinates: %d of %d floats equal the 60-digit value rounded to float" % (exact, total))
+    assert exact >= 0.999 * total
 
 
 def test_batched_sequences_match_individual_runs(gf, oracle):
