@@ -396,3 +396,29 @@ def test_oracle_camera_model_and_velocities_meet_the_reference_formulas(oracle):
     exact, total = check_t8_against_the_reference_formulas(out, times, IDC_CAM)
     print("oracle undistorted coordinates: %d of %d floats equal the 60-digit value rounded to float (the rest within one ulp)" % (exact, total))
     assert exact >= 0.999 * total
+
+
+# ---------------------------------------------------------------- row B2: IMU / wheel pre-integration against the reference's formulas at 60 digits
+def check_preint_against_ref(imu_fn, wheel_fn, tol=1e-13):
+    """tests/golden/ref_preint.json.gz (make_ref_preint_golden.py: IntegrationBase / WheelIntegrationBase::midPointIntegration + propagate transcribed into mpmath): every
+    output within `tol` of the 60-digit value, relative to the largest entry of its array (observed 1e-15)"""
+    import gzip
+    import json
+    with gzip.open(os.path.join(HERE, "golden", "ref_preint.json.gz"), "rt") as f:
+        fx = json.load(f)
+    worst = 0.0
+    for kind, fn in (("imu", imu_fn), ("wheel", wheel_fn)):
+        if fn is None:
+            continue
+        for c in fx[kind]:
+            got = fn(**c["input"])
+            for k, v in c["expected"].items():
+                e = np.asarray(v, np.float64).reshape(-1)
+                dev = float(np.abs(np.asarray(got[k], np.float64).reshape(-1) - e).max() / np.abs(e).max())
+                assert dev < tol, (kind, len(c["input"]["dt"]), k, dev)
+                worst = max(worst, dev)
+    return worst
+
+
+def test_oracle_preintegration_meets_the_reference_formulas_at_60_digits(oracle):
+    print("oracle pre-integration vs 60 digits: %.1e" % check_preint_against_ref(oracle.imu_preintegrate, oracle.wheel_preintegrate))

@@ -21,6 +21,14 @@ def test_host_preintegration_matches_oracle(oracle):
         assert np.allclose(a[k], b[k], rtol=1e-12, atol=1e-15), k
 
 
+def test_host_preintegration_meets_the_reference_formulas_at_60_digits():
+    """row B2 of the PRODUCT (gf_imu_preintegrate / gf_wheel_preintegrate are host code: no GPU needed, no oracle involved) against integration_base.h /
+    wheel_integration_base.h evaluated with 60 digits (tests/golden/ref_preint.json.gz)"""
+    import gfamd
+    from test_golden import check_preint_against_ref
+    print("library pre-integration vs 60 digits: %.1e" % check_preint_against_ref(gfamd.imu_preintegrate, gfamd.wheel_preintegrate))
+
+
 def test_double2vector_keeps_yaw_and_position_of_pose0(oracle):
     import gfamd
     w = SW.make_window(3, oracle)
@@ -41,6 +49,66 @@ def test_double2vector_keeps_yaw_and_position_of_pose0(oracle):
     yaw = lambda R: np.arctan2(R[1, 0], R[0, 0])
     assert abs(yaw(Rs[0]) - yaw(R0)) < 1e-12
     assert np.allclose(Rs[5] @ Rs[5].T, np.eye(3), atol=1e-12)
+
+
+def test_double2vector_meets_the_reference_formulas_at_60_digits(oracle):
+    """row B3a: Estimator::double2vector's pose part (estimator.cpp:2440-2494) with Utility::R2ypr / ypr2R (utility.h:78-117) transcribed into mpmath at 60 digits,
+    against the library's gf_ba_double2vector (host code) and the oracle's: the yaw of frame 0 and its position are put back, everything else rotated along"""
+    import math
+    import pytest
+    mp = pytest.importorskip("mpmath")
+    import gfamd
+    mp.mp.dps = 60
+    f = lambda x: mp.mpf(float(x))
+    PI = f(math.pi)     # M_PI, the double
+
+    def qmat(q7):       # Quaterniond(w, x, y, z).toRotationMatrix() of para_Pose's px py pz qx qy qz qw
+        x, y, z, w = (f(v) for v in q7[3:7])
+        return mp.matrix([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                          [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    def R2ypr(R):
+        n, o, a = R[:, 0], R[:, 1], R[:, 2]
+        y = mp.atan2(n[1], n[0])
+        p = mp.atan2(-n[2], n[0] * mp.cos(y) + n[1] * mp.sin(y))
+        r = mp.atan2(a[0] * mp.sin(y) - a[1] * mp.cos(y), -o[0] * mp.sin(y) + o[1] * mp.cos(y))
+        return [v / PI * 180 for v in (y, p, r)]
+
+    def ypr2R(ypr):
+        y, p, r = (v / 180 * PI for v in ypr)
+        Rz = mp.matrix([[mp.cos(y), -mp.sin(y), 0], [mp.sin(y), mp.cos(y), 0], [0, 0, 1]])
+        Ry = mp.matrix([[mp.cos(p), 0, mp.sin(p)], [0, 1, 0], [-mp.sin(p), 0, mp.cos(p)]])
+        Rx = mp.matrix([[1, 0, 0], [0, mp.cos(r), -mp.sin(r)], [0, mp.sin(r), mp.cos(r)]])
+        return Rz * Ry * Rx
+    for seed in (3, 11):
+        w = SW.make_window(seed, oracle)
+        W = int(w["W"])
+        R0m, P0 = qmat(w["para_Pose"][:7]), [f(v) for v in w["para_Pose"][:3]]
+        R0 = np.array([[float(R0m[r, c]) for c in range(3)] for r in range(3)])
+        P0d = np.array([float(v) for v in P0])
+        oracle.ba_solve(w, 4)        # the solve moves pose 0 along the gauge directions
+        R0m = mp.matrix([[f(R0[r, c]) for c in range(3)] for r in range(3)])      # what the estimator holds in Rs[0] is the double matrix
+        o0, o00 = R2ypr(R0m), R2ypr(qmat(w["para_Pose"][:7]))
+        assert abs(abs(o0[1]) - 90) > 1 and abs(abs(o00[1]) - 90) > 1          # not the singular branch
+        rot = ypr2R([o0[0] - o00[0], 0, 0])
+        Rs, Ps, Vs = [], [], []
+        for i in range(W + 1):
+            pp, sb = w["para_Pose"][7 * i:7 * i + 7], w["para_SpeedBias"][9 * i:9 * i + 9]
+            n = mp.sqrt(sum(f(v) ** 2 for v in pp[3:7]))
+            q = list(pp[:3]) + [f(v) / n for v in pp[3:7]]                   # .normalized()
+            Rs.append(rot * qmat(q))
+            Ps.append(rot * mp.matrix([f(pp[k]) - f(w["para_Pose"][k]) for k in range(3)]) + mp.matrix([f(v) for v in P0d]))
+            Vs.append(rot * mp.matrix([f(sb[k]) for k in range(3)]))
+        eR = np.array([[float(R[r, c]) for r in range(3) for c in range(3)] for R in Rs]).reshape(-1)
+        eP = np.array([[float(v) for v in P] for P in Ps]).reshape(-1)
+        eV = np.array([[float(v) for v in V] for V in Vs]).reshape(-1)
+        for name, fn in (("library", gfamd.double2vector), ("oracle", oracle.double2vector)):
+            got = fn(W, R0, P0d, w["para_Pose"], w["para_SpeedBias"])
+            dev = [float(np.abs(np.asarray(got[0]) - eR).max()), float(np.abs(np.asarray(got[1]) - eP).max()), float(np.abs(np.asarray(got[2]) - eV).max())]
+            assert max(dev) < 1e-13, (name, dev)
+            sbs = w["para_SpeedBias"].reshape(-1, 9)
+            assert np.array_equal(np.asarray(got[3]).reshape(-1, 3), sbs[:, 3:6]) and np.array_equal(np.asarray(got[4]).reshape(-1, 3), sbs[:, 6:9])
+            print(name, "double2vector vs 60 digits (Rs, Ps, Vs):", ["%.1e" % v for v in dev])
 
 
 def test_cpp_host_mirror_compiles_and_links(tmp_path):

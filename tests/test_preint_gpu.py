@@ -50,6 +50,19 @@ def test_device_intervals_are_bit_identical_to_the_host_loop():
     pb.close()
 
 
+def test_device_intervals_meet_the_reference_formulas_at_60_digits():
+    """the device kernel against integration_base.h evaluated with 60 digits (tests/golden/ref_preint.json.gz): all intervals of the fixture in ONE launch"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_golden import check_preint_against_ref
+    pb = gfamd.PreintBatch()
+
+    def one(dt, acc, gyr, acc0, gyr0, ba, bg, noise):
+        out = pb.run([0, len(dt)], dt, acc, gyr, [acc0], [gyr0], [ba], [bg], noise)
+        return {k: v[0] for k, v in out.items()}
+    print("device pre-integration vs 60 digits: %.1e" % check_preint_against_ref(one, None))
+    pb.close()
+
+
 def test_batch_sizes_and_repeated_calls():
     pb = gfamd.PreintBatch()
     ref = None
