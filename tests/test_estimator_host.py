@@ -132,6 +132,133 @@ def test_triangulation_and_depth_bookkeeping():
     compare_features(est_o, est_p, tol=1e-8)
 
 
+# ---- the two per-feature sweeps against the reference's formulas in other arithmetic (mpmath, 60 digits): used here on the host loops, in test_featsweep_gpu.py on the kernels
+def sweep_window(est_o, est_p):
+    """the estimator's window as plain arrays: poses from the library's state, observations from the (identical) feature list of the numpy oracle"""
+    s, fp = est_p.state(), est_p.features()
+    fo = est_o.f_manager.feature
+    assert [f.feature_id for f in fo] == list(fp["id"])
+    obs = [np.array([[fr.point[0], fr.point[1], fr.point[2], fr.depth] for fr in f.feature_per_frame]) for f in fo]
+    return dict(Rs=s["Rs"].copy(), Ps=s["Ps"].copy(), tic=est_o.tic.copy(), ric=est_o.ric.copy(), start_frame=fp["start_frame"].copy(), obs=obs,
+                estimated_depth=fp["estimated_depth"].copy(), estimate_flag=fp["estimate_flag"].copy(), ids=fp["id"].copy())
+
+
+def _mp():
+    mp = pytest.importorskip("mpmath")
+    mp.mp.dps = 60
+    return mp, (lambda a: mp.matrix([[mp.mpf(float(v)) for v in row] for row in np.atleast_2d(a)])), (lambda a: mp.matrix([mp.mpf(float(v)) for v in np.asarray(a).reshape(-1)]))
+
+
+def exact_triangulate_with_depth(w, depth_threshold, init_depth):
+    """FeatureManager::triangulateWithDepth (feature_manager.cpp:726-799) transcribed: per feature (depth, flag, margin) -- `margin` is how far the closest accept / reject
+    decision (|residual| < 10 / 460, depth in [0.1, threshold], average < 0.1) sits from its threshold, so that a caller can tell a rounding tie from a wrong result"""
+    mp, Mx, Vx = _mp()
+    tic, ric = Vx(np.asarray(w["tic"]).reshape(-1)[:3]), Mx(np.asarray(w["ric"]).reshape(-1)[:9].reshape(3, 3))
+    Rs, Ps = [Mx(R) for R in w["Rs"]], [Vx(P) for P in w["Ps"]]
+    out = []
+    for f, obs in enumerate(w["obs"]):
+        dep, flag = float(w["estimated_depth"][f]), int(w["estimate_flag"][f])
+        if len(obs) < 4 or dep > 0:
+            out.append((dep, flag, np.inf))
+            continue
+        s = int(w["start_frame"][f])
+        tr, Rr = Ps[s] + Rs[s] * tic, Rs[s] * ric
+        ver, margin = [], mp.inf
+        for i in range(len(obs)):
+            d = float(obs[i][3])
+            if d < 0.1 or d > depth_threshold:
+                continue
+            t0, R0 = Ps[s + i] + Rs[s + i] * tic, Rs[s + i] * ric
+            point0 = Vx(obs[i][:3]) * mp.mpf(d)
+            t2r, R2r = Rr.T * (t0 - tr), Rr.T * R0
+            for j in range(len(obs)):
+                if i == j:
+                    continue
+                t1, R1 = Ps[s + j] + Rs[s + j] * tic, Rs[s + j] * ric
+                t20, R20 = R0.T * (t1 - t0), R0.T * R1
+                pp = R20.T * point0 - R20.T * t20
+                rx, ry = mp.mpf(float(obs[j][0])) - pp[0] / pp[2], mp.mpf(float(obs[j][1])) - pp[1] / pp[2]
+                res = mp.sqrt(rx * rx + ry * ry)
+                margin = min(margin, abs(res - mp.mpf(10) / 460))
+                if res < mp.mpf(10) / 460:
+                    ver.append((R2r * point0 + t2r)[2])
+        if not ver:
+            out.append((dep, flag, float(margin)))
+            continue
+        ave = sum(ver) / len(ver)
+        margin = min(margin, abs(ave - mp.mpf("0.1")))
+        out.append((float(ave), 1, float(margin)) if ave >= mp.mpf("0.1") else (float(init_depth), 0, float(margin)))
+    return out
+
+
+def exact_moving_consistency(w, focal_length):
+    """Estimator::movingConsistencyCheckW with reprojectionError / reprojectionError3D (estimator.cpp:3888-3907, :3968-4012) transcribed: per feature (removed, margin)"""
+    mp, Mx, Vx = _mp()
+    W = len(w["Ps"]) - 1
+    tic, ric = Vx(np.asarray(w["tic"]).reshape(-1)[:3]), Mx(np.asarray(w["ric"]).reshape(-1)[:9].reshape(3, 3))
+    Rs, Ps = [Mx(R) for R in w["Rs"]], [Vx(P) for P in w["Ps"]]
+    out = []
+    for f, obs in enumerate(w["obs"]):
+        s, depth = int(w["start_frame"][f]), mp.mpf(float(w["estimated_depth"][f]))
+        if not (len(obs) >= 2 and s < W - 2) or depth < 0:
+            out.append((False, np.inf))
+            continue
+        uvi = Vx(obs[0][:3])
+        err = err3 = mp.mpf(0)
+        cnt = 0
+        for k in range(1, len(obs)):
+            j = s + k
+            uvj = Vx(obs[k][:3])
+            pts_w = Rs[s] * (ric * (depth * uvi) + tic) + Ps[s]
+            pc = ric.T * (Rs[j].T * (pts_w - Ps[j]) - tic)
+            rx, ry = pc[0] / pc[2] - uvj[0], pc[1] / pc[2] - uvj[1]
+            err += mp.sqrt(rx * rx + ry * ry)
+            dv = pc - uvj
+            err3 += mp.sqrt(dv[0] ** 2 + dv[1] ** 2 + dv[2] ** 2) / depth
+            cnt += 1
+        if cnt == 0:
+            out.append((False, np.inf))
+            continue
+        a, b = mp.mpf(float(focal_length)) * err / cnt, err3 / cnt
+        out.append((bool(a > 10 or b > 2), float(min(abs(a - 10), abs(b - 2)))))
+    return out
+
+
+def check_depth_sweep(w, got_depth, got_flag, depth_threshold, init_depth, tol=1e-12):
+    ex = exact_triangulate_with_depth(w, depth_threshold, init_depth)
+    worst = 0.0
+    for f, (d, fl, margin) in enumerate(ex):
+        if margin < 1e-9:       # a decision within rounding of its threshold: either answer is the reference's
+            continue
+        assert int(got_flag[f]) == fl, (f, int(got_flag[f]), fl, margin)
+        dev = abs(float(got_depth[f]) - d) / max(1.0, abs(d))
+        assert dev < tol, (f, float(got_depth[f]), d)
+        worst = max(worst, dev)
+    return worst, sum(1 for e in ex if e[1] == 1)
+
+
+def test_host_sweeps_meet_the_reference_formulas_at_60_digits():
+    """triangulateWithDepth and movingConsistencyCheckW of the library's host code (no GPU, no oracle in the comparison) against the transcriptions above"""
+    c = gfamd.default_estimator_cfg()
+    for seed in (3, 5):
+        st, est_o, est_p, k, tp = fill_window(seed)
+        _seed_truth(st, est_o, est_p)
+        w0 = sweep_window(est_o, est_p)
+        est_p.debug("triangulateWithDepth")
+        fp = est_p.features()
+        worst, n1 = check_depth_sweep(w0, fp["estimated_depth"], fp["estimate_flag"], c.depth_threshold, c.init_depth)
+        assert n1 > 20
+        est_p.debug("triangulate")
+        est_o.f_manager.triangulateWithDepth(est_o.Ps, est_o.Rs, est_o.tic, est_o.ric); est_o.f_manager.triangulate(est_o.Ps, est_o.Rs, est_o.tic, est_o.ric)
+        w2 = sweep_window(est_o, est_p)
+        removed = set(int(i) for i in est_p.debug("movingConsistencyCheckW"))
+        ex = exact_moving_consistency(w2, c.focal_length)
+        for f, (rem, margin) in enumerate(ex):
+            if margin > 1e-9:
+                assert (int(w2["ids"][f]) in removed) == rem, (f, rem, margin)
+        print("seed %d: %d depths within %.1e of the 60-digit average; movingConsistencyCheckW decisions equal on %d tracks" % (seed, n1, worst, len(ex)))
+
+
 @pytest.mark.parametrize("flag", [0, 1])
 def test_slide_window_and_feedback(flag):
     """slideWindow (EST:3638-3837) with removeBackShiftDepth / removeFront, movingConsistencyCheckW and predictPtsInNextFrame (EST:3862-3995)."""

@@ -69,6 +69,31 @@ def test_device_sweeps_match_the_host_loops_bit_for_bit():
     fs.close()
 
 
+def test_device_sweeps_meet_the_reference_formulas_at_60_digits():
+    """the two kernels against FeatureManager::triangulateWithDepth / Estimator::movingConsistencyCheckW transcribed into mpmath (tests/test_estimator_host.py): neither the
+    library's host loops nor the oracle take part in the comparison"""
+    fs = gfamd.FeatureSweeps()
+    c = gfamd.default_estimator_cfg()
+    for seed in (3, 5):
+        st, est_o, est_p, k, tp = TH.fill_window(seed)
+        TH._seed_truth(st, est_o, est_p)
+        w0 = TH.sweep_window(est_o, est_p)
+        dep, flag = fs.triangulate_with_depth([w0], c.depth_threshold, c.init_depth)[0]
+        worst, n1 = TH.check_depth_sweep(w0, dep, flag, c.depth_threshold, c.init_depth)
+        assert n1 > 20
+        for e in (est_p,):
+            e.debug("triangulateWithDepth"); e.debug("triangulate")
+        est_o.f_manager.triangulateWithDepth(est_o.Ps, est_o.Rs, est_o.tic, est_o.ric); est_o.f_manager.triangulate(est_o.Ps, est_o.Rs, est_o.tic, est_o.ric)
+        w2 = TH.sweep_window(est_o, est_p)
+        rem = fs.moving_consistency([w2], c.focal_length)[0]
+        ex = TH.exact_moving_consistency(w2, c.focal_length)
+        for f, (r, margin) in enumerate(ex):
+            if margin > 1e-9:
+                assert bool(rem[f]) == r, (f, r, margin)
+        print("seed %d: %d device depths within %.1e of the 60-digit average; decisions equal on %d tracks" % (seed, n1, worst, len(ex)))
+    fs.close()
+
+
 def test_throughput_of_the_sweeps():
     """256 windows of one camera frame in one launch each: kernel time (hipEvents), call time, and the host loop on one core"""
     st, est_o, est_p, k, tp = TH.fill_window(3)
