@@ -293,6 +293,41 @@ def test_slide_window_and_feedback(flag):
     assert (s["sum_of_back"], s["sum_of_front"]) == (est_o.sum_of_back, est_o.sum_of_front)
 
 
+def test_remove_back_shift_depth_meets_the_reference_formula_at_60_digits():
+    """FeatureManager::removeBackShiftDepth (feature_manager.cpp:818-856) of the library's host code against the formula in mpmath: a track that starts in the dropped frame
+    moves its depth into its next frame's camera; a track left with one observation goes; every other track only renumbers its start frame"""
+    mp, Mx, Vx = _mp()
+    c = gfamd.default_estimator_cfg()
+    st, est_o, est_p, k, tp = fill_window(4)
+    _seed_truth(st, est_o, est_p)
+    for name in ("triangulateWithDepth", "triangulate"):
+        est_p.debug(name)
+        getattr(est_o.f_manager, name)(est_o.Ps, est_o.Rs, est_o.tic, est_o.ric)
+    w = sweep_window(est_o, est_p)
+    ric, tic = np.asarray(w["ric"]).reshape(-1)[:9].reshape(3, 3), np.asarray(w["tic"]).reshape(-1)[:3]
+    # slideWindowOld hands in the camera poses of frames 0 and 1 (estimator.cpp:3721-3740); this recording stands still there, so the second pose is taken from the middle
+    # of the window (the vehicle has moved and turned by then): the formula does not care which two poses it gets
+    m = len(w["Ps"]) // 2
+    R0, P0, R1, P1 = w["Rs"][0] @ ric, w["Ps"][0] + w["Rs"][0] @ tic, w["Rs"][m] @ ric, w["Ps"][m] + w["Rs"][m] @ tic
+    assert np.linalg.norm(P1 - P0) > 0.05
+    est_p.debug("removeBackShiftDepth", list(R0.reshape(-1)) + list(P0) + list(R1.reshape(-1)) + list(P1))
+    fp = est_p.features()
+    want = []
+    for f, obs in enumerate(w["obs"]):
+        if int(w["start_frame"][f]) != 0:
+            want.append((int(w["ids"][f]), int(w["start_frame"][f]) - 1, len(obs), float(w["estimated_depth"][f])))
+        elif len(obs) - 1 >= 2:
+            pts_i = Vx(obs[0][:3]) * mp.mpf(float(w["estimated_depth"][f]))
+            pts_j = Mx(R1).T * (Mx(R0) * pts_i + Vx(P0) - Vx(P1))
+            want.append((int(w["ids"][f]), 0, len(obs) - 1, float(pts_j[2]) if pts_j[2] > 0 else float(c.init_depth)))
+    assert [int(i) for i in fp["id"]] == [t[0] for t in want] and [int(v) for v in fp["start_frame"]] == [t[1] for t in want] and [int(v) for v in fp["n_obs"]] == [t[2] for t in want]
+    dev = np.abs(fp["estimated_depth"] - np.array([t[3] for t in want])) / np.maximum(1.0, np.abs([t[3] for t in want]))
+    shifted = sum(1 for f, obs in enumerate(w["obs"]) if int(w["start_frame"][f]) == 0 and len(obs) >= 3)
+    moved = np.abs(fp["estimated_depth"] - np.array([w["estimated_depth"][f] for f, obs in enumerate(w["obs"]) if int(w["start_frame"][f]) != 0 or len(obs) >= 3])).max()
+    assert shifted > 10 and dev.max() < 1e-13 and moved > 0.01, (shifted, dev.max(), moved)
+    print("removeBackShiftDepth: %d shifted depths within %.1e of the 60-digit value, %d tracks dropped" % (shifted, dev.max(), len(w["obs"]) - len(want)))
+
+
 def test_remove_back_initial_phase():
     """slideWindowOld in the INITIAL phase uses removeBack (FM:858-874), no depth shift."""
     st, est_o, est_p, k, tp = fill_window(5)
