@@ -171,11 +171,6 @@ def test_track_image_prediction_and_outlier_feedback(gf, oracle):
                         np.full(len(uv), 2.0)], 1)
         otr.set_prediction(ids[sel], xyz); gtr.setPrediction(ids[sel], xyz)
     gtr.close()
-    # ... and not only against the oracle: the library's x, y, vx, vy against the reference's formulas in other arithmetic (mpmath at 60 digits / numpy IEEE floats)
-    from test_golden import check_t8_against_the_reference_formulas
-    exact, total = check_t8_against_the_reference_formulas(outs, [0.0666 * k for k in range(len(frames))], K)
-    print("undistorted coordinates: %d of %d floats equal the 60-digit value rounded to float" % (exact, total))
-    assert exact >= 0.999 * total
 
 
 def test_depth_camera_without_depth_image_returns_an_empty_frame(gf, oracle):
