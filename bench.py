@@ -766,7 +766,7 @@ def main():
                             else:
                                 os.environ[k_] = v_
         phase("end_to_end samples")
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is an N = 1 measurement (the other ranks would sit in the closing barrier meanwhile)
             nseq = min(8, B)
             cores = min(os.cpu_count() or 1, nseq)
             fh = frames[: min(n_frames, 13), :nseq].cpu().numpy()
