@@ -328,6 +328,47 @@ def test_remove_back_shift_depth_meets_the_reference_formula_at_60_digits():
     print("removeBackShiftDepth: %d shifted depths within %.1e of the 60-digit value, %d tracks dropped" % (shifted, dev.max(), len(w["obs"]) - len(want)))
 
 
+def test_predict_pts_in_next_frame_meets_the_reference_formula_at_60_digits():
+    """Estimator::predictPtsInNextFrame (estimator.cpp:3839-3886: constant-velocity next pose curT (prevT^-1 curT), the track's first observation at its depth carried into the
+    predicted camera) of the library's host code against the formula in mpmath (the 4 x 4 inverse exact)"""
+    mp, Mx, Vx = _mp()
+    st, est_o, est_p, k, tp = fill_window(4)
+    _seed_truth(st, est_o, est_p)
+    for name in ("triangulateWithDepth", "triangulate"):
+        est_p.debug(name)
+        getattr(est_o.f_manager, name)(est_o.Ps, est_o.Rs, est_o.tic, est_o.ric)
+    w = sweep_window(est_o, est_p)
+    W = len(w["Ps"]) - 1
+    got = est_p.debug("predictPtsInNextFrame").reshape(-1, 4)
+
+    def T4(R, P):
+        T = mp.eye(4)
+        for r in range(3):
+            for c in range(3):
+                T[r, c] = mp.mpf(float(R[r, c]))
+            T[r, 3] = mp.mpf(float(P[r]))
+        return T
+    curT, prevT = T4(w["Rs"][W], w["Ps"][W]), T4(w["Rs"][W - 1], w["Ps"][W - 1])
+    nextT = curT * (prevT ** -1 * curT)
+    nR, nP = nextT[0:3, 0:3], nextT[0:3, 3]
+    ric, tic = Mx(np.asarray(w["ric"]).reshape(-1)[:9].reshape(3, 3)), Vx(np.asarray(w["tic"]).reshape(-1)[:3])
+    want = {}
+    for f, obs in enumerate(w["obs"]):
+        s0, dep = int(w["start_frame"][f]), float(w["estimated_depth"][f])
+        if dep > 0 and len(obs) >= 2 and s0 + len(obs) - 1 == W:
+            pts_j = ric * (Vx(obs[0][:3]) * mp.mpf(dep)) + tic
+            pts_w = Mx(w["Rs"][s0]) * pts_j + Vx(w["Ps"][s0])
+            pc = ric.T * (nR.T * (pts_w - nP) - tic)
+            want[int(w["ids"][f])] = [float(v) for v in pc]
+    assert [int(v) for v in got[:, 0]] == sorted(want) and len(want) > 50
+    E = np.array([want[i] for i in sorted(want)])
+    dev = np.abs(got[:, 1:] - E).max() / np.abs(E).max()
+    assert dev < 1e-13
+    moved = float(mp.sqrt(sum((nP[r] - mp.mpf(float(w["Ps"][W][r]))) ** 2 for r in range(3))))
+    assert moved > 0.01          # the predicted pose is not the current one: the formula is exercised
+    print("predictPtsInNextFrame: %d predictions within %.1e of the 60-digit value (next pose %.3f m ahead)" % (len(want), dev, moved))
+
+
 def test_remove_back_initial_phase():
     """slideWindowOld in the INITIAL phase uses removeBack (FM:858-874), no depth shift."""
     st, est_o, est_p, k, tp = fill_window(5)
