@@ -369,6 +369,61 @@ def test_predict_pts_in_next_frame_meets_the_reference_formula_at_60_digits():
     print("predictPtsInNextFrame: %d predictions within %.1e of the 60-digit value (next pose %.3f m ahead)" % (len(want), dev, moved))
 
 
+def test_triangulate_meets_the_exact_singular_vector_at_60_digits():
+    """FeatureManager::triangulate (feature_manager.cpp:669-723): the depth is v[2] / v[3] of the right singular vector of the smallest singular value of the 2n x 4 system
+    of all observations of a track.  Here that vector is the eigenvector of A^T A by mpmath's eigsy at 60 digits -- no Jacobi sweeps, no LAPACK -- and both the library's
+    one-sided Jacobi SVD and the oracle's numpy SVD are measured against it (they agree with each other to 1e-8 in test_triangulation_and_depth_bookkeeping: this says where
+    the truth lies between them)"""
+    mp, Mx, Vx = _mp()
+    c = gfamd.default_estimator_cfg()
+    st, est_o, est_p, k, tp = fill_window(3)
+    _seed_truth(st, est_o, est_p)
+    est_p.debug("triangulateWithDepth")
+    est_o.f_manager.triangulateWithDepth(est_o.Ps, est_o.Rs, est_o.tic, est_o.ric)
+    w = sweep_window(est_o, est_p)
+    est_p.debug("triangulate")
+    est_o.f_manager.triangulate(est_o.Ps, est_o.Rs, est_o.tic, est_o.ric)
+    fp = est_p.features()
+    dep_o = np.array([f.estimated_depth for f in est_o.f_manager.feature])
+    ric, tic = Mx(np.asarray(w["ric"]).reshape(-1)[:9].reshape(3, 3)), Vx(np.asarray(w["tic"]).reshape(-1)[:3])
+    Rs, Ps = [Mx(R) for R in w["Rs"]], [Vx(P) for P in w["Ps"]]
+    worst_p = worst_o = 0.0
+    n = 0
+    for f, obs in enumerate(w["obs"]):
+        if float(w["estimated_depth"][f]) > 0 or len(obs) < 4:
+            continue
+        s0 = int(w["start_frame"][f])
+        t0, R0 = Ps[s0] + Rs[s0] * tic, Rs[s0] * ric
+        A = mp.zeros(2 * len(obs), 4)
+        for i in range(len(obs)):
+            t1, R1 = Ps[s0 + i] + Rs[s0 + i] * tic, Rs[s0 + i] * ric
+            t, R = R0.T * (t1 - t0), R0.T * R1
+            P = mp.zeros(3, 4)
+            Rt = R.T
+            mRt_t = -(Rt * t)
+            for r in range(3):
+                for cc in range(3):
+                    P[r, cc] = Rt[r, cc]
+                P[r, 3] = mRt_t[r]
+            pt = Vx(obs[i][:3])
+            fn = pt / mp.sqrt(pt[0] ** 2 + pt[1] ** 2 + pt[2] ** 2)
+            for cc in range(4):
+                A[2 * i, cc] = fn[0] * P[2, cc] - fn[2] * P[0, cc]
+                A[2 * i + 1, cc] = fn[1] * P[2, cc] - fn[2] * P[1, cc]
+        E, Q = mp.eigsy(A.T * A)
+        j = min(range(4), key=lambda q: E[q])
+        exact = Q[2, j] / Q[3, j]
+        if exact < mp.mpf("0.1"):
+            assert int(fp["estimate_flag"][f]) == 0 and fp["estimated_depth"][f] == c.init_depth
+            continue
+        assert int(fp["estimate_flag"][f]) == 2
+        worst_p = max(worst_p, abs(float(fp["estimated_depth"][f]) - float(exact)) / float(exact))
+        worst_o = max(worst_o, abs(float(dep_o[f]) - float(exact)) / float(exact))
+        n += 1
+    assert n > 5 and worst_p < 1e-8 and worst_o < 1e-8, (n, worst_p, worst_o)
+    print("triangulate: %d depths; library's Jacobi SVD within %.1e of the exact singular vector, the oracle's LAPACK SVD within %.1e" % (n, worst_p, worst_o))
+
+
 def test_remove_back_initial_phase():
     """slideWindowOld in the INITIAL phase uses removeBack (FM:858-874), no depth shift."""
     st, est_o, est_p, k, tp = fill_window(5)
