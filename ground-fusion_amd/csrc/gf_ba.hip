@@ -57,7 +57,7 @@ __global__ void ba_fill_plausible(void* p, size_t i0, size_t i1, int is_double, 
 
 namespace {
 std::atomic<int> g_alloc_idx{0}, g_alloc_tix{0}, g_alloc_seq_ctr{0};
-const char* g_alloc_what = nullptr;   // the allocation statement being executed (GF_BA_ALLOC_TRACE=1 prints it next to the allocation's index: what GF_BA_POISON_RANGE counts)
+thread_local const char* g_alloc_what = nullptr;   // the allocation statement being executed (GF_BA_ALLOC_TRACE=1 prints it next to the allocation's index: what GF_BA_POISON_RANGE counts)
 std::atomic<long long> g_up_bytes{0}, g_up_calls{0};   // host -> device traffic of this process (GF_GROUP_TIMING prints it)
 template <class T> struct Buf {  // device buffer + pinned host mirror
     T* d = nullptr; T* h = nullptr; size_t n = 0;
@@ -326,10 +326,22 @@ int pack_slot(gf_ba* h, int b, const gf_ba_window& w) {
         st.radius = 1e4; st.mu = 1e-8; st.R = col; st.last_successful = 1;
         // visual factors
         std::vector<char> used(std::max(w.n_feature, 1), 0);
+        std::vector<uint32_t> seen_j(std::max(w.n_feature, 1), 0);   // frames j a feature already has a factor for (j <= W <= 30)
+        std::vector<signed char> start_i(std::max(w.n_feature, 1), -1);
         for (int k = 0; k < w.n_visual; k++) {
             const size_t kk = (size_t)b * d.NV + k;
             if (w.vis_feature[k] < 0 || w.vis_feature[k] >= w.n_feature || w.vis_i[k] < 0 || w.vis_i[k] >= w.vis_j[k] || w.vis_j[k] > d.W)   // frame i is the feature's start frame: i < j
                 return gf::set_err(GF_ERR_INVALID, "window %d: visual factor %d has bad indices", b, k);
+            {   // the fixed-extrinsic sweep STORES a factor's Jd^T Jj block into its feature's E^T F row at frame j (vis_lane_eval) and et_rows8 stores the pose-i sum: a second
+                // factor of the same (feature, j), or a feature whose factors name different start frames, would lose a term without a trace (round-5 advisor).  The reference
+                // cannot build either (one factor per later observation of a feature, all from feature_per_frame[0]: estimator.cpp:3269-3297); a caller-built window can.
+                const int f = w.vis_feature[k];
+                if (start_i[f] >= 0 && start_i[f] != w.vis_i[k])
+                    return gf::set_err(GF_ERR_INVALID, "window %d: visual factor %d names start frame %d for feature %d, an earlier factor named %d", b, k, w.vis_i[k], f, (int)start_i[f]);
+                if (seen_j[f] >> w.vis_j[k] & 1u)
+                    return gf::set_err(GF_ERR_INVALID, "window %d: visual factor %d repeats the observation of feature %d in frame %d", b, k, f, w.vis_j[k]);
+                start_i[f] = (signed char)w.vis_i[k]; seen_j[f] |= 1u << w.vis_j[k];
+            }
             h->vis_idx.h[kk] = (w.vis_feature[k] << 10) | (w.vis_i[k] << 5) | w.vis_j[k];
             double* vd = h->vis_data.h + kk * 5;
             memcpy(vd, w.vis_pts_j + 3 * k, 16); memcpy(vd + 2, w.vis_vel_j + 2 * k, 16); vd[4] = w.vis_td_j[k];   // pts_j.z does not enter the residual
@@ -1222,7 +1234,7 @@ int gf_ba_export_newest_poses(gf_ba* h, void* d_out, int count) {
 // north_star's exchange step as one C call: newest poses of this rank's `count` resident windows -> ncclAllGather -> [world][count][7] on every rank.
 int gf_pose_gather(gf_ba* h, void* nccl_comm, void* stream, int count, double* d_out) {
     if (!h || !nccl_comm || !d_out || count < 1 || count > h->d.B) return gf::set_err(GF_ERR_INVALID, "bad argument");
-    if (!h->gather_send.d) { if (int rc = h->gather_send.alloc((size_t)h->d.B * 7, false)) return rc; HIPCHK(hipMemsetAsync(h->gather_send.d, 0, (size_t)h->d.B * 7 * sizeof(double), h->stream)); }
+    if (!h->gather_send.d) { g_alloc_what = "gather_send.alloc (first gf_pose_gather)"; if (int rc = h->gather_send.alloc((size_t)h->d.B * 7, false)) return rc; HIPCHK(hipMemsetAsync(h->gather_send.d, 0, (size_t)h->d.B * 7 * sizeof(double), h->stream)); }
     // the send buffer is persistent: the export of THIS call must not overtake the collective of the previous one, which reads it on the caller's stream
     if (h->gather_in_flight) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_gather_done, 0)); h->gather_in_flight = false; }
     // ranks must pass the same count (ncclAllGather): a rank with fewer resident windows sends zero rows behind its own

@@ -13,7 +13,7 @@
 //   Estimator::slideWindow / slideWindowNew / Old  EST:3638-3837
 //   Estimator::predictPtsInNextFrame, movingConsistencyCheckW, reprojectionError(3D)  EST:3862-4010
 //   FeatureManager::*                              FM:43-110, :198-302, :669-934, :978-1010
-// Unsupported switches are rejected at create time: ESTIMATE_EXTRINSIC==2, USE_LINE, USE_PLANE, USE_MOTION, GNSS_ENABLE, STEREO, !USE_IMU.
+// Unsupported switches are rejected at create time: ESTIMATE_EXTRINSIC==2, USE_LINE, USE_PLANE, USE_MOTION, STEREO, !USE_IMU.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -2279,10 +2279,12 @@ int gf_estimator_group_create(const gf_estimator_cfg* c, int n, gf_estimator_gro
     (void)hipGetDevice(&g->device);
     // worker threads: half of the hardware threads this PROCESS may run on (its affinity mask: a process confined by taskset / cgroups to 8 threads sizes its pool for
     // 8, not for the 256 the box has), divided among the ranks that share the node
-    int hw = (int)std::thread::hardware_concurrency();
+    const int hw_box = (int)std::thread::hardware_concurrency();
+    int hw = hw_box;
     { cpu_set_t cs; CPU_ZERO(&cs); if (sched_getaffinity(0, sizeof cs, &cs) == 0 && CPU_COUNT(&cs) > 0) hw = std::min(hw > 0 ? hw : CPU_COUNT(&cs), CPU_COUNT(&cs)); }
     int share = 1;
-    if (const char* e = getenv("LOCAL_WORLD_SIZE")) share = std::max(1, atoi(e));
+    // a launcher that pins every rank to its part of the node (numactl, cgroups, torchrun binding) has divided already: the mask IS the rank's share (round-5 advisor)
+    if (const char* e = getenv("LOCAL_WORLD_SIZE")) if (hw_box <= 0 || hw >= hw_box) share = std::max(1, atoi(e));
     int nt = std::min(n, std::max(1, hw / (2 * share)));
     if (const char* e = getenv("GF_GROUP_THREADS")) if (atoi(e) > 0) nt = std::min(n, atoi(e));
     // the members' IMU pre-integration as one device launch per camera frame.  It costs one more rendezvous per frame and pays where host threads are
@@ -2291,7 +2293,13 @@ int gf_estimator_group_create(const gf_estimator_cfg* c, int n, gf_estimator_gro
     // The device feature sweeps (triangulateWithDepth, movingConsistencyCheckW) lose on both hosts (8 threads: 14.7 k against 19.4 k) and stay opt-in.
     bool want_pre = n >= 16 * nt;
     if (const char* e = getenv("GF_GROUP_DEVICE_PREINT")) want_pre = atoi(e) != 0;
-    if (want_pre) if (int rc = gf::preint_batch_create(&g->solver.pre)) { delete g; return rc; }
+    const bool pre_forced = getenv("GF_GROUP_DEVICE_PREINT") != nullptr;
+    if (want_pre) if (int rc = gf::preint_batch_create(&g->solver.pre)) {
+        if (pre_forced) { delete g; return rc; }   // asked for by name: its failure is the caller's to see
+        g->solver.pre = nullptr;                   // chosen by the heuristic: the host loops give the same bits
+        fprintf(stderr, "gf_estimator_group: device pre-integration could not be set up (%s); the members pre-integrate on the host\n", gf_last_error());
+    }
+    if (getenv("GF_GROUP_TIMING")) fprintf(stderr, "gf_estimator_group: %d members, %d worker threads (%d usable hardware threads, node share 1/%d), pre-integration on the %s\n", n, nt, hw, share, g->solver.pre ? "device" : "host");
     if (const char* e = getenv("GF_GROUP_DEVICE_SWEEPS")) if (atoi(e) != 0) if (int rc = gf_featsweep_create(&g->solver.sweeps)) { delete g; return rc; }
     g->job_gen.reset(new std::atomic<int>[n]); for (int i = 0; i < n; i++) g->job_gen[i].store(0, std::memory_order_relaxed);
     g->t.assign(n, 0.0); g->frame_ptr.assign(n, nullptr); g->frame_n.assign(n, 0); g->rcs.assign(n, GF_OK); g->errs.resize(n);

@@ -636,9 +636,11 @@ int gf_tracker_create(const gf_tracker_cfg* cfg, gf_tracker** out) {
     {
         // default: up to 16 threads out of this rank's share of the node (a frame of 256 sequences spends 1.3 ms in the bookkeeping with 4 threads, 0.5 ms with 16)
         int share = 1;
-        if (const char* e = getenv("LOCAL_WORLD_SIZE")) share = std::max(1, atoi(e));
-        int hw = (int)std::thread::hardware_concurrency();   // ... of the hardware threads this process may run on (its affinity mask, not the box)
+        const int hw_box = (int)std::thread::hardware_concurrency();
+        int hw = hw_box;   // ... of the hardware threads this process may run on (its affinity mask, not the box)
         { cpu_set_t cs; CPU_ZERO(&cs); if (sched_getaffinity(0, sizeof cs, &cs) == 0 && CPU_COUNT(&cs) > 0) hw = std::min(hw > 0 ? hw : CPU_COUNT(&cs), CPU_COUNT(&cs)); }
+        // divide among the node's ranks only when the mask is the whole machine: a launcher that pins each rank has divided already (round-5 advisor)
+        if (const char* e = getenv("LOCAL_WORLD_SIZE")) if (hw_box <= 0 || hw >= hw_box) share = std::max(1, atoi(e));
         int nthr = std::max(1, std::min(16, hw / (2 * share)));
         if (const char* e = getenv("GF_HOST_THREADS")) nthr = atoi(e);
         nthr = std::max(1, std::min(nthr, std::max(hw, 1)));

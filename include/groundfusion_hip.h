@@ -168,6 +168,8 @@ typedef struct gf_ba_window {
     double* para_Feature;     /* n_feature inverse depths */
     const unsigned char* feature_fixed; /* estimate_flag == 1 -> constant (estimator.cpp:3291-3292) */
     /* ProjectionTwoFrameOneCamFactor(pts_i, pts_j, velocity_i, velocity_j, td_i, td_j) on (Pose[i], Pose[j], Ex_Pose, Feature[f], Td) */
+    /* preconditions, checked at upload (GF_ERR_INVALID): i < j; all factors of a feature name the same start frame i and bring the same start-frame observation;
+       a feature has at most one factor per frame j -- what estimator.cpp:3269-3297 builds (one factor per later observation, all from feature_per_frame[0]) */
     const int* vis_feature; const int* vis_i; const int* vis_j;
     const double* vis_pts_i; const double* vis_pts_j; const double* vis_vel_i; const double* vis_vel_j; const double* vis_td_i; const double* vis_td_j;
     /* IMUFactor(pre_integrations[i+1]) on (Pose[i], SpeedBias[i], Pose[i+1], SpeedBias[i+1]); delta_q as (w,x,y,z); 15x15 row-major */

@@ -518,3 +518,31 @@ def test_chain_meets_the_chain_at_60_digits(gf, name):
     est = gf.Estimator(max_features=16, max_visual=256, max_gnss=132 if "gnss" in name else 0)
     print(name, "HIP chain vs 60 digits:", check_chain(lambda a: est.solve([a], 8)[0], lambda a: est.marginalize([a], 0)[0], name, CHAIN_BARS_HIP[name]))
     est.close()
+
+
+def test_upload_refuses_a_repeated_observation_and_a_second_start_frame(gf):
+    """Round-5 advisor: the fixed-extrinsic sweep STORES a factor's Jd^T Jj block into its feature's E^T F row at frame j, so a window with two factors of one
+    (feature, j) -- or a feature whose factors name different start frames -- would lose a term silently.  The reference cannot build such a window
+    (estimator.cpp:3269-3297: one factor per later observation, all from feature_per_frame[0]); a caller of the C-ABI can, and is told so at upload."""
+    est = gf.Estimator(batch=1)
+    base = SW.make_window(1004, gf)
+    ok = base.copy()
+    est.solve([ok], 1)
+    rep = base.copy()
+    rep["vis_j"] = rep["vis_j"].copy()
+    f0 = int(rep["vis_feature"][0])
+    same = np.nonzero(rep["vis_feature"] == f0)[0]
+    assert len(same) >= 2
+    rep["vis_j"][same[1]] = rep["vis_j"][same[0]]
+    with pytest.raises(gf.GfError, match="repeats the observation"):
+        est.solve([rep], 1)
+    two = base.copy()
+    two["vis_i"] = two["vis_i"].copy()
+    k = same[-1]
+    assert two["vis_j"][k] - two["vis_i"][k] >= 2
+    two["vis_i"][k] += 1
+    with pytest.raises(gf.GfError, match="names start frame"):
+        est.solve([two], 1)
+    again = base.copy()
+    assert est.solve([again], 1)[0] == est.solve([base.copy()], 1)[0]
+    est.close()

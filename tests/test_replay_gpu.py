@@ -226,3 +226,21 @@ def test_replay_tool_multi_rank_mode(tmp_path):
             assert "sequence %d (rank %d)" % (k, k % world) in rows[k]
             assert [float(x) for x in got[:3]] == [float(x) for x in last[1:4]]
             assert np.abs(np.array(got[3:], float) - np.array(last[4:], float)).max() < 2e-9
+
+
+def test_replay_tool_ranks_do_not_hang_when_rank0_fails_before_the_id(tmp_path):
+    """Round-5 advisor: every forked rank inherited every pipe write end, so when rank 0 failed before it wrote the communicator id (here: RCCL cannot be loaded) the
+    other ranks sat in read() without EOF and the parent in waitpid behind them.  Now a child keeps only its own ends (and polls with a bound): the tool must come back,
+    with an error, in seconds."""
+    import time
+    exe = os.path.join(ROOT, "bin", "gf_replay")
+    st = SS.Stream(11, t_still=1.5, t_move=0.4, v_max=0.4, yaw0=0.0, yaw_turn=-0.6, split_x=1.8, turn_delay=0.8)
+    d = tmp_path / "seq0"
+    d.mkdir()
+    st.export(str(d))
+    env = dict(os.environ, GF_RCCL_LIBRARY="/nonexistent/librccl.so", GF_REPLAY_ALLOW_SHARED_DEVICE="1", GF_REPLAY_ID_TIMEOUT_S="20")
+    t0 = time.time()
+    out = subprocess.run([exe, "--ranks", "3", os.path.join(str(d), "config.yaml"), str(d), str(d), str(d)], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode != 0
+    assert time.time() - t0 < 60, "the ranks waited for an id that could not come"
+    assert "no unique id from rank 0" in out.stderr, out.stderr[-600:]

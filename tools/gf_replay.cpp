@@ -8,6 +8,7 @@
 // reads the reference's own YAML configuration (parameters.cpp key names), replays the recorded IMU / wheel / RGB / depth messages of
 // <dataset dir> (layout in host/replay_node.h) through FeatureTracker::trackImage and Estimator::processImage on the GPU, and writes the
 // trajectory file the reference writes (output_path/vio.txt, TUM format) — to <vio.txt> when given, else to `output_path` of the config.
+#include <poll.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -89,7 +90,15 @@ static int run_rank(int rank, int world, const char* config, const std::vector<s
             for (int fd : id_write_fds) if (write(fd, id, 128) != 128) throw std::runtime_error("cannot hand the unique id to a rank");
         } else {
             size_t got = 0;
-            while (got < 128) { const ssize_t n = read(id_read_fd, id + got, 128 - got); if (n <= 0) throw std::runtime_error("rank " + std::to_string(rank) + ": no unique id from rank 0"); got += (size_t)n; }
+            while (got < 128) {   // EOF = rank 0 is gone; and a bound on the wait in case it hangs inside the runtime (GF_REPLAY_ID_TIMEOUT_S, default 120 s)
+                struct pollfd pf = {id_read_fd, POLLIN, 0};
+                static const int tmo_ms = 1000 * (getenv("GF_REPLAY_ID_TIMEOUT_S") ? std::max(1, atoi(getenv("GF_REPLAY_ID_TIMEOUT_S"))) : 120);
+                const int pr = poll(&pf, 1, tmo_ms);
+                if (pr == 0) throw std::runtime_error("rank " + std::to_string(rank) + ": no unique id from rank 0 within " + std::to_string(tmo_ms / 1000) + " s");
+                const ssize_t n = pr > 0 ? read(id_read_fd, id + got, 128 - got) : -1;
+                if (n <= 0) throw std::runtime_error("rank " + std::to_string(rank) + ": no unique id from rank 0 (it failed before the exchange)");
+                got += (size_t)n;
+            }
         }
         if (gf_comm_create(id, world, rank, device, &comm) != GF_OK) throw std::runtime_error(gf_last_error());
     } catch (const std::exception& e) {
@@ -154,7 +163,14 @@ int main(int argc, char** argv) {
         for (int r = 0; r < world; r++) {                    // fork before anything touches the HIP runtime: every rank initialises its own
             const pid_t p = fork();
             if (p < 0) { perror("fork"); return 1; }
-            if (p == 0) { const int rc = run_rank(r, world, argv[3], dirs, rd[r], r == 0 ? wr : std::vector<int>()); fflush(nullptr); _exit(rc); }   // _exit: the parent's atexit handlers are not this child's
+            if (p == 0) {
+                // a child keeps only the pipe ends it uses (round-5 advisor): with every inherited write end open in ranks >= 1, a rank 0 that died before it wrote the id
+                // left the others in read() for good (no EOF while any copy of the write end is open) and the parent in waitpid behind them
+                for (int q = 1; q < world; q++) if (q != r) close(rd[q]);
+                if (r != 0) for (int fd : wr) close(fd);
+                const int rc = run_rank(r, world, argv[3], dirs, rd[r], r == 0 ? wr : std::vector<int>());
+                fflush(nullptr); _exit(rc);   // _exit: the parent's atexit handlers are not this child's; rank 0's write ends close with it, on the error paths too
+            }
             kids.push_back(p);
         }
         for (int fd : rd) if (fd >= 0) close(fd);
