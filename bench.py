@@ -379,16 +379,17 @@ def pcie_sample(gfamd, trk, est, args, B, frames, depth, dt, step, frame_index, 
                     "when h2d_copy_alone_ms exceeds the device-resident step the path is bound by the bus, not by the kernels"}
 
 
-def small_batch_sample(gfamd, dev, args, WIN, GNSS, sizes=(1, 8, 64), K=40):
+def small_batch_sample(gfamd, dev, args, WIN, GNSS, sizes=(1, 8, 64), K=40, distinct=None):
     """The same step at the batch sizes BASELINE.json's other configurations name -- one sequence (configs[0] / [1] as written), 8 per GPU (configs[3]: 64 sequences
     over 8 GPUs), 64 -- on handles of their own: ms per step (tracker frame + solve + MARGIN_OLD, device-resident inputs) and the back end alone.  The default run's
-    256 sequences are what fills the chip; these are the latency end of the same path."""
+    256 sequences are what fills the chip; these are the latency end of the same path.  `large_batch` (round 6) is the same function at 512 / 1024 sequences per GPU
+    (64 distinct seeded windows dealt round-robin: host synthesis of a thousand windows is not what is measured): where more than one window per CU is resident."""
     out = {}
     dt = 1.0 / 15.0
     for Bs in sizes:
         frames, depth = make_frames(8, Bs, 5000 + Bs, dev)
         trk = gfamd.FeatureTracker(gfamd.default_cfg(batch=Bs, max_cnt=args.max_cnt, min_dist=args.min_dist))
-        est, wins = make_windows(gfamd, Bs, 5000 + Bs, args.max_cnt, WIN, GNSS, args.distinct)
+        est, wins = make_windows(gfamd, Bs, 5000 + Bs, args.max_cnt, WIN, GNSS, distinct if distinct else args.distinct)
         est.upload(wins)
         fb = Bs * H * W
 
@@ -418,6 +419,72 @@ def small_batch_sample(gfamd, dev, args, WIN, GNSS, sizes=(1, 8, 64), K=40):
     return out
 
 
+CONFIGS = {1: dict(max_cnt=150, min_dist=30, window=10, gnss=False, batch=256, distinct=None),
+           2: dict(max_cnt=300, min_dist=20, window=10, gnss=False, batch=256, distinct=None),
+           4: dict(max_cnt=500, min_dist=12, window=20, gnss=True, batch=64, distinct=16)}
+
+
+def config_sample(gfamd, dev, cfg_index, K=20, Wm=3, ba_iters=8, distinct=None):
+    """BASELINE.json configs[cfg_index] as a short kernel-rate sample inside the default run (round-5 review: configs[2] and configs[4] only existed as builder-run files
+    under profiles/): the same step as `value` -- tracker frame + 8 dogleg iterations + MARGIN_OLD for every sequence, inputs resident in HBM -- on handles of its own,
+    K timed steps, then the three roofline kernels on an otherwise idle GPU for their fractions.  `python bench.py --config N` is the long form of the same."""
+    C = CONFIGS[cfg_index]
+    B, dt = C["batch"], 1.0 / 15.0
+    nf = 8
+    frames, depth = make_frames(nf, B, 7000 + cfg_index, dev)
+    trk = gfamd.FeatureTracker(gfamd.default_cfg(batch=B, max_cnt=C["max_cnt"], min_dist=C["min_dist"]))
+    trk.set_profiling(True)
+    est, wins = make_windows(gfamd, B, 7000 + cfg_index, C["max_cnt"], C["window"], C["gnss"], distinct if distinct is not None else (C["distinct"] or 32))
+    est.upload(wins)
+    fb = B * H * W
+    step = [0]
+
+    def fi(k):
+        m = k % (2 * nf - 2)
+        return m if m < nf else 2 * nf - 2 - m
+
+    def do_step():
+        est.solve_resident_async(ba_iters, 0, True)
+        trk.trackImageBatchDevice([dt * step[0]] * B, frames.data_ptr() + fi(step[0]) * fb, depth.data_ptr(), unpack=False)
+        est.wait()
+        step[0] += 1
+    for _ in range(Wm + 1):
+        do_step()
+    trk.reset_stats(); est.reset_stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        do_step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    st, bs = trk.stats(), est.stats()
+    trk.reset_stats(); est.reset_stats()
+    for _ in range(3):
+        trk.trackImageBatchDevice([dt * step[0]] * B, frames.data_ptr() + fi(step[0]) * fb, depth.data_ptr(), unpack=False)
+        step[0] += 1
+    torch.cuda.synchronize()
+    for _ in range(2):
+        est.solve_resident(ba_iters, 0, True)
+    ti, bi = trk.stats(), est.stats()
+    tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    lk_ms = ti["ms_lk"] / max(ti["lk_launches"], 1)
+    lk_bytes = (484.0 * 5.0 * ti["lk_level_passes"] + 484.0 * ti["lk_iterations"]) / max(ti["lk_launches"], 1)
+    jtj_ms, step_ms = bi["ms_jtj"] / max(bi["jtj_launches"], 1), bi["ms_step"] / max(bi["step_launches"], 1)
+    out = {"workload": "configs[%d]: %d features / min_dist %d, %d-frame window, visual+IMU+wheel%s+prior, %d sequences on one GPU" % (cfg_index, C["max_cnt"], C["min_dist"], C["window"], "+GNSS" if C["gnss"] else "", B),
+           "sequences_per_gpu": B, "steps": K, "warmup": Wm, "value": bs["solves"] / el, "unit": "window-solves/s (each with its tracker frame)", "ms_per_step": 1e3 * el / K,
+           "tracked_features_per_s": st["tracked_features"] / el,
+           "roofline_frac_isolated": lk_bytes / (lk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if lk_ms > 0 else None,
+           "roofline_jtj_frac": tf(bi["jtj_alg_flops"] / max(bi["jtj_launches"], 1), jtj_ms) / FP64_MFMA_PEAK_TF,
+           "roofline_step_frac": tf(bi["step_flops"] / max(bi["step_launches"], 1), step_ms) / FP64_MFMA_PEAK_TF,
+           "launch_ms_isolated": {"lk_track_kernel": lk_ms, "ba_linearize_visual_win": jtj_ms, "ba_step": step_ms},
+           "ba_solve_ms_isolated": bi["ms_solve"] / 2, "ba_marginalize_ms_isolated": bi["ms_marginalize"] / 2,
+           "reduced_system_in": "global memory (ba_step<true>)" if C["window"] > 10 or C["gnss"] else "LDS"}
+    trk.close(); est.close()
+    del frames, depth
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -442,6 +509,9 @@ def main():
     ap.add_argument("--e2e-same-frames", action="store_true", help="with several estimator groups: all groups take the same camera frames (default: they alternate, see end_to_end_sample)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-image (PCIe-inclusive) sample")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the step times at 1 / 8 / 64 sequences")
+    ap.add_argument("--no-large-batch", action="store_true", help="skip the step times at 512 / 1024 sequences per GPU")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the 20-step kernel-rate samples of configs[2] and configs[4]")
+    ap.add_argument("--no-long-run", action="store_true", help="skip the extra 200-step run next to a short timed loop")
     ap.add_argument("--e2e-device-preint", action="store_true", help="also run the end-to-end sample with the batched device pre-integration of the estimator group")
     ap.add_argument("--e2e-device-sweeps", action="store_true", help="also run the end-to-end sample with the batched device feature sweeps (triangulateWithDepth, movingConsistencyCheckW) of the estimator group")
     ap.add_argument("--e2e-only", action="store_true", help="only the end-to-end (drop-in path) sample, as one JSON line (used by the default run for its small-host sample)")
@@ -495,9 +565,7 @@ def main():
     import gfamd
     import shard
     gfamd._chk(gfamd.lib().gf_set_device(device_index))
-    CFG = {1: dict(max_cnt=150, min_dist=30, window=10, gnss=False, batch=256, distinct=None),
-           2: dict(max_cnt=300, min_dist=20, window=10, gnss=False, batch=256, distinct=None),
-           4: dict(max_cnt=500, min_dist=12, window=20, gnss=True, batch=64, distinct=16)}[args.config]
+    CFG = CONFIGS[args.config]
     args.max_cnt = args.max_cnt or CFG["max_cnt"]
     args.min_dist = args.min_dist or CFG["min_dist"]
     args.batch = args.batch or CFG["batch"]
@@ -573,6 +641,19 @@ def main():
     st = trk.stats()
     bs = est.stats()
     sums = est.download(wins) if not args.no_backend else [None]
+    # the driver's command times 20 steps (57 ms): box-to-box and host jitter are larger than that sample resolves (round-5 review), so the same loop once more over 200
+    # steps, reported next to `value` (N = 1 only: the driver's own multi-GPU lines stay what its command measures)
+    long_run = None
+    if world == 1 and K < 200 and not args.no_long_run and not (args.no_frontend or args.no_backend):
+        s0 = est.stats()["solves"]
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(200):
+            do_step()
+        barrier()
+        el2 = time.perf_counter() - t1
+        long_run = {"steps": 200, "value": (est.stats()["solves"] - s0) / el2, "ms_per_step": 1e3 * el2 / 200}
+        phase("200-step run")
 
     # the roofline kernels once more on an otherwise idle GPU: their hipEvent times without the other half's kernels in between
     iso = {}
@@ -654,6 +735,7 @@ def main():
                             "backend": "none (1 rank)" if dist is None else ("gloo (GF_BENCH_SINGLE_DEVICE test mode)" if single else "nccl (RCCL)")},
             "host_threads_per_rank": int(os.environ["GF_HOST_THREADS"]),
             "kernel_rate": value,
+            "value_200_steps": long_run["value"] if long_run else (value if K >= 200 else None), "ms_per_step_200_steps": long_run["ms_per_step"] if long_run else (1e3 * el_max / K if K >= 200 else None),
             "value_is": "kernel_rate: tracker frame + solve + marginalisation per step with the windows resident on the device (inputs in HBM, the contract of `value`); "
                         "the rate through the reference's own call surface (trackImage -> inputFeature -> processImage, windows packed / uploaded / downloaded every frame) is "
                         "end_to_end.window_solves_per_s, reported at 1 GPU",
@@ -704,6 +786,21 @@ def main():
         if world == 1 and not args.no_small_batch and not args.strong and not (args.no_frontend or args.no_backend):
             res["small_batch"] = small_batch_sample(gfamd, dev, args, WIN, GNSS)
             phase("small_batch")
+        if world == 1 and not args.no_large_batch and not args.strong and args.config == 1 and B == 256 and not (args.no_frontend or args.no_backend):
+            # round-5 review: "256 sequences per GPU is the builder's number" -- the same step with two and four windows per CU resident
+            lb = small_batch_sample(gfamd, dev, args, WIN, GNSS, sizes=(512, 1024), K=20, distinct=64)
+            for k_, v_ in lb.items():
+                v_["sequences_per_gpu"] = int(k_); v_["vs_256_sequences"] = v_["window_solves_per_s"] / value
+            res["large_batch"] = lb
+            phase("large_batch")
+        if world == 1 and not args.no_other_configs and not args.strong and args.config == 1 and not (args.no_frontend or args.no_backend):
+            res["other_configs"] = {}
+            for ci in (2, 4):
+                try:
+                    res["other_configs"]["configs[%d]" % ci] = config_sample(gfamd, dev, ci, ba_iters=args.ba_iters)
+                except Exception as ex:   # a side measurement: its failure must not cost the line
+                    res["other_configs"]["configs[%d]" % ci] = {"error": repr(ex)[:300]}
+            phase("other_configs")
         if world == 1 and not args.no_e2e and not args.strong and args.config == 1 and not (args.no_frontend or args.no_backend):
             trk.close(); trk = None
             S = max(1, args.e2e_streams)

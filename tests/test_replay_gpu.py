@@ -121,12 +121,17 @@ def test_replay_tool_with_gnss_messages(tmp_path):
     ref = est.trajectory
     assert len(ref) > 20 and got.shape == (len(ref), 8)
     dp = max(float(np.abs(row[1:4] - P).max()) for row, (t, P, R) in zip(got, ref))
-    line = [l for l in out.stdout.splitlines() if "gnss_ready" in l][0].replace(",", " ").split()
-    anc = np.array([float(x) for x in line[line.index("anchor") + 1:line.index("anchor") + 4]])
-    ecef = np.array([float(x) for x in line[line.index("ecef") + 1:line.index("ecef") + 4]])
+    # the tool's state bit for bit (its `gnss_state_bits` line carries hex floats), not the 4-decimal printout (round-5 review: that line could only carry a 1e-3 bar)
+    line = [l for l in out.stdout.splitlines() if "gnss_state_bits" in l][0].split()
+    anc = np.array([float.fromhex(x) for x in line[line.index("anchor") + 1:line.index("anchor") + 4]])
+    ecef = np.array([float.fromhex(x) for x in line[line.index("ecef") + 1:line.index("ecef") + 4]])
+    shown = [l for l in out.stdout.splitlines() if "gnss_ready" in l][0].replace(",", " ").split()
+    assert np.abs(np.array([float(x) for x in shown[shown.index("anchor") + 1:shown.index("anchor") + 4]]) - anc).max() <= 5.1e-5      # the printout is that state, rounded
     print("gf_replay with GNSS vs oracle: %d poses, worst |dp| %.2e, anchor %.2e, ecef %.2e" % (len(ref), dp, np.abs(anc - est.anc_ecef).max(), np.abs(ecef - est.ecef_pos).max()))
     assert dp < 1e-6 + 5e-10
-    assert np.abs(anc - est.anc_ecef).max() < 1e-3 and np.abs(ecef - est.ecef_pos).max() < 1e-3     # printed with 4 decimals (weak prior directions, see above)
+    # the bar of the closed-loop GNSS replays (tests/test_estimator_gpu.py: 2e-5 m, adjudicated at 60 digits in profiles/r05_adjudicate_gnss_chain.txt: two double-precision
+    # chains of marginalisation priors cannot be held tighter in the anchor / absolute position; the local poses above are at 1e-6)
+    assert np.abs(anc - est.anc_ecef).max() < 2e-5 and np.abs(ecef - est.ecef_pos).max() < 2e-5
 
 
 def test_replay_from_a_rosbag_matches_the_dataset_route(tmp_path):
