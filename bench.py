@@ -220,11 +220,12 @@ def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=None, d
     st0 = streams[0]
     cfg = gfamd.default_estimator_cfg(tio=SS.TIO, rio=SS.RIO, multiple_thread=1)
     bounds = [nseq * q // n_groups for q in range(n_groups + 1)]
-    # the library gives ONE group half of this rank's hardware threads as workers; several groups of one process share that half (measured at two groups on 256
-    # hardware threads: 64 workers each 70.6 k window-solves/s, 96 each 68.3 k, 128 each 55 k)
+    # the library gives ONE group up to 32 workers (half of this rank's hardware threads when that is less); several groups of one process share that many.  Round 6, honest
+    # clock, 256 hardware threads, gate spin off: 2 groups x 16 workers 34.6-45.4 k window-solves/s, 2 x 32: 40.6-44.6 k, 2 x 64: 28.3 k, 4 x 8: 40.2 k, 4 x 16: 43.7 k,
+    # 8 x 4: 34.0 k (profiles/r06_e2e_pools.txt; the figures quoted here in round 5 -- "64 workers each 70.6 k" -- came from the clock that subtracted 0.56 s of 0.65)
     own_env = n_groups > 1 and "GF_GROUP_THREADS" not in os.environ
     if own_env:
-        os.environ["GF_GROUP_THREADS"] = str(max(1, (os.cpu_count() or 2) // (2 * n_groups * max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))))
+        os.environ["GF_GROUP_THREADS"] = str(max(1, min(32, (os.cpu_count() or 2) // (2 * max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))) // n_groups))
     workers = os.environ.get("GF_GROUP_THREADS", "library default")
     grps = [gfamd.EstimatorGroup(cfg, bounds[q + 1] - bounds[q], device_preint=device_preint, device_sweeps=device_sweeps) for q in range(n_groups)]
     if own_env:

@@ -182,7 +182,7 @@ struct gf_ba {
     int max_vis = 0, max_order = 0, max_prior = 0, max_feat = 0;   // largest n_visual / factor-order length / prior size of the resident batch (what the uploads copy)
     std::vector<const gf_ba_window*> resident;       // the caller's window behind every resident slot (gf_ba_marginalize_resident)
     // what packing a window into slot b found out about it; reduced over the batch when the batch is closed (pack_slot may run on one thread per slot)
-    struct SlotMeta { int mno[2] = {0, 0}; bool any_ex = false, pri_res = false, pos_ident = true; long long mfma = 0, step = 0, jtj = 0; int nvis = 0, norder = 0, npri = 0, nfeat = 0, imu_dirty = 0; };
+    struct SlotMeta { int mno[2] = {0, 0}; int R = 0; bool chain = false; bool any_ex = false, pri_res = false, pos_ident = true; long long mfma = 0, step = 0, jtj = 0; int nvis = 0, norder = 0, npri = 0, nfeat = 0, imu_dirty = 0; };
     std::vector<SlotMeta> meta;
     // device-resident priors (gf_ba_pack_slot with prior_n > 0 and prior_J == NULL): outJ_n[b] = size of the prior the last gf_ba_marginalize_resident left in
     // the output buffer of slot b (0: none); the next solve of that slot copies it device to device into the prior table instead of taking it from the host
@@ -197,6 +197,9 @@ struct gf_ba {
     int max_imu_dirty = 0;
     bool all_pri_res = false, any_pri_res = false, outJ_host_stale = false;
     int step_waves = 8;
+    // chain form of ba_step (round 6; gf_ba_kernels.hpp, note in front of ba_step_body): GF_BA_CHAIN=1 or gf_ba_set_chain().  One setting per process for the same reason as
+    // step_waves: the two forms pivot in different orders, and a window alone must run the form it runs inside a batch.
+    bool chain_mode = false; int n_chain = 0, n_dense = 0, chain_nd = 0; size_t yg_stride = 0; Buf<double> Yg;
     bool upload_kernel = true;
     bool pos_ident = false;
     bool split_jtj = false, split_timed = false;   // gf_ba_set_split_jtj: the visual sweep as two kernels (block rows through HBM, contraction-only MFMA kernel)
@@ -206,7 +209,7 @@ struct gf_ba {
     long long jtj_alg_flops = 0;  // algorithmic flops of the same: Nv * 2 * 2 * (12 * 13 / 2 + 12 + 1) per window
     long long step_flops = 0;     // dense algebra of one ba_step over the resident batch: Schur SYRK NE*n_c^2 + Cholesky R^3/3 + substitutions 2 R^2
     std::vector<Buf<double>*> dbl() { return {&xs0, &xs, &vis_data, &feat_obs, &imu_data, &wh_data, &pri_J, &pri_r, &pri_x0, &imu_sqrt, &wh_sqrt, &pri_A, &pri_b, &pri_c, &H, &g, &Vc, &vtile, &wpar, &cost, &efac,
-                                              &scale, &diag, &grad, &gn, &step, &u, &Et, &Es, &ete, &etb, &rhs, &yv, &Sg, &Mg, &gn_data, &gn_misc, &gn_rows}; }
+                                              &scale, &diag, &grad, &gn, &step, &u, &Et, &Es, &ete, &etb, &rhs, &yv, &Sg, &Mg, &Yg, &gn_data, &gn_misc, &gn_rows}; }
     std::vector<Buf<int>*> ints() { return {&colf, &cole, &nvis, &nimu, &nwh, &nfeat, &vis_idx, &order, &norder, &feat_ptr, &vis_pos, &imu_i, &wh_i, &pri_n, &pri_nb, &pri_bid, &ngnss, &gn_idx, &gn_gptr, &gn_gitem}; }
     void release() {
         for (auto* b : dbl()) b->release();
@@ -238,6 +241,7 @@ struct gf_ba {
         StepBufs s{};
         s.scale = scale.d; s.diag = diag.d; s.grad = grad.d; s.gn = gn.d; s.step = step.d; s.u = u.d; s.Et = Et.d; s.Es = Es.d; s.ete = ete.d; s.etb = etb.d;
         s.rhs = rhs.d; s.yv = yv.d; s.VS = d.RP + d.FP; s.stamps = stamps.d; s.Sg = Sg.d; s.SgStride = sg_stride; s.Mg = Mg.d; s.MgStride = mg_stride;
+        s.Yg = Yg.d; s.YgStride = yg_stride;
         return s;
     }
 };
@@ -324,6 +328,12 @@ int pack_slot(gf_ba* h, int b, const gf_ba_window& w) {
         SolverState& st = h->st0.h[b];
         memset(&st, 0, sizeof st);
         st.radius = 1e4; st.mu = 1e-8; st.R = col; st.last_successful = 1;
+        {   // chain form of ba_step: every pose and speed-bias block free (then pose_i sits at column 15 i, sb_i at 15 i + 6), no GNSS blocks, and no speed-bias block in
+            // the prior but frame 0's (what marginalisation leaves: estimator.cpp:3448-3520) -- the structure the elimination order relies on
+            bool ok = h->chain_mode && !h->big_step && d.GO == 0 && !w.fix_poses;
+            for (int q = 0; q < w.prior_nblocks && ok; q++) if (w.prior_block_id[q] / 4096 == GF_SPEEDBIAS && w.prior_block_id[q] % 4096 != 0) ok = false;
+            M.chain = ok; M.R = col; st.chain = ok ? 1 : 0;
+        }
         // visual factors
         std::vector<char> used(std::max(w.n_feature, 1), 0);
         std::vector<uint32_t> seen_j(std::max(w.n_feature, 1), 0);   // frames j a feature already has a factor for (j <= W <= 30)
@@ -539,6 +549,11 @@ void finalize_pack(gf_ba* h, const int* active, int n_active, int count) {
         any_ex |= M.any_ex; mfma += M.mfma; step += M.step; jtj += M.jtj; mv = std::max(mv, M.nvis); mo = std::max(mo, M.norder); mp = std::max(mp, M.npri); mf = std::max(mf, M.nfeat);
     }
     h->any_ex = any_ex; h->mfma_per_lin = mfma; h->step_flops = step; h->jtj_alg_flops = jtj;
+    h->n_chain = h->n_dense = h->chain_nd = 0;
+    for (int q = 0; q < n_active; q++) {
+        const gf_ba::SlotMeta& M = h->meta[active ? active[q] : q];
+        if (M.chain) { h->n_chain++; h->chain_nd = std::max(h->chain_nd, M.R - 9 * d.NP); } else h->n_dense++;
+    }
     h->max_vis = mv; h->max_order = mo; h->max_prior = mp; h->max_feat = mf;
     h->max_imu_dirty = 0;
     for (int q = 0; q < n_active; q++) h->max_imu_dirty = std::max(h->max_imu_dirty, h->meta[active ? active[q] : q].imu_dirty);
@@ -736,7 +751,7 @@ int run_solve(gf_ba* h, int max_iters) {
     if (int rc = launch_linearize(h, 0, 0, 0, false)) return rc;
     Win w = h->win();
     StepBufs sb = h->sbufs();
-    const bool fuse_misc = h->fuse_misc && h->can_fuse_misc && d.GO == 0;
+    const bool fuse_misc = h->fuse_misc && h->can_fuse_misc && d.GO == 0 && h->n_chain == 0;
     for (int it = 0; it <= max_iters; it++) {
         if (h->max_solver_time > 0.0 && it > 0 && it < max_iters) {
             // trust_region_minimizer.cc checks total_solver_time >= max_solver_time_in_seconds at the top of every iteration: with the option on, the host
@@ -747,7 +762,10 @@ int run_solve(gf_ba* h, int max_iters) {
         poison_lds(h);
         const bool time_step = it == 1 && max_iters >= 1;
         if (time_step) HIPCHK(hipEventRecord(h->ev[6], h->stream));
-        if (h->step_waves == 4) {
+        // windows in the chain form first (256 threads, two per CU), then -- if the batch holds any -- the others in the dense form; each kernel leaves the other's windows alone
+        if (h->n_chain > 0) ba_step_chain<<<dim3(d.B), 256, ch_lds_doubles(h->chain_nd) * sizeof(double), h->stream>>>(w, sb, it == 0 ? 1 : 0, max_iters, it == max_iters ? 1 : 0);
+        if (h->n_chain > 0 && h->n_dense == 0) { }
+        else if (h->step_waves == 4) {
             if (h->big_step) ba_step<true, 4><<<dim3(d.B), 256, 0, h->stream>>>(w, sb, it == 0 ? 1 : 0, max_iters, it == max_iters ? 1 : 0);
             else ba_step<false, 4><<<dim3(d.B), 256, h->step_lds, h->stream>>>(w, sb, it == 0 ? 1 : 0, max_iters, it == max_iters ? 1 : 0);
         } else if (h->big_step) ba_step<true><<<dim3(d.B), 512, 0, h->stream>>>(w, sb, it == 0 ? 1 : 0, max_iters, it == max_iters ? 1 : 0);
@@ -883,6 +901,16 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     // process (the reductions' order depends on it: a window alone and the same window in a batch must run the same variant)
     if (getenv("GF_BA_SPLIT_JTJ") && atoi(getenv("GF_BA_SPLIT_JTJ"))) if (int rc = gf_ba_set_split_jtj(h, 1)) { h->release(); delete h; return rc; }
     h->step_waves = (getenv("GF_BA_STEP_WAVES") && atoi(getenv("GF_BA_STEP_WAVES")) == 4) ? 4 : 8;
+    h->chain_mode = getenv("GF_BA_CHAIN") && atoi(getenv("GF_BA_CHAIN")) != 0 && !h->big_step && !gnss;
+    if (h->chain_mode) {
+        const int nd_max = Rmax - 9 * d.NP;
+        if (ch_lds_doubles(nd_max) * sizeof(double) + 20 * 1024 > 160 * 1024) h->chain_mode = false;   // (cannot happen where the dense form fits LDS; kept as the guard it is)
+        else {
+            h->yg_stride = ch_y_stride(nd_max);
+            A_(h->Yg.alloc(B * d.NP * h->yg_stride, false));
+            H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_step_chain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ch_lds_doubles(nd_max) * sizeof(double))));
+        }
+    }
     if (h->step_waves == 4 && !h->big_step) H_(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_step<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->step_lds));
     // GF_BA_FUSE_MISC=1: the candidate's prior / IMU / wheel sweep in front of the step that judges it, one launch (ba_misc_step).  Same bits; measured 163 us against
     // 123 + 33 us for the two launches and 1.75-1.77 instead of 1.79 ms per solve (-1 %): the sweep's time is its blocks' own latency, not a launch boundary.  Off.

@@ -59,6 +59,7 @@ struct SolverState {  // per window, lives in device memory
     int reuse, done, termination, iterations, successful, invalid_run, last_successful, have_scale, cand_valid;
     int R, NE;          // reduced dimension and number of eliminated (free inverse-depth) columns
     double mu_solved;   // the mu of the Gauss-Newton solve that gn / yv currently hold
+    int chain;          // this window's ba_step runs in the chain form (ba_step_chain; set by the host when the window is packed: standard column layout, no GNSS blocks)
     int h_prior[2];     // buffer set q holds the prior's part of H for this solve's column map (written by its first linearisation: the part outside the band
                         // the IMU / wheel factors touch does not depend on the state, and rewriting 150 KB per window and iteration made the sweep write-bound)
 };
@@ -718,6 +719,8 @@ struct StepBufs {  // per-window global scratch of ba_step
     size_t SgStride;
     double* Mg;     // [B][MgStride] same for the kept system of the marginalisation
     size_t MgStride;
+    double* Yg;     // [B][NP][YgStride] chain form of ba_step: the finished panel, factor inverse and coupling block of every speed-bias block (ch_y_stride); else null
+    size_t YgStride;
     long long* stamps;  // optional phase timestamps of window 0 (builds with -DGF_PROFILE_STEP)
     int VS;
 };
@@ -1471,40 +1474,87 @@ __device__ __forceinline__ bool wave_chol16_fused(SPtr S, int j0, int nb, double
     return good;
 }
 
+// ---- round 6: the reduced system by its structure ("chain" form of ba_step, template parameter CH).
+// With every pose and speed-bias block free the reduced columns are laid out pose_0 (6) sb_0 (9) pose_1 sb_1 ... then the trailing blocks (extrinsics, sx sy sw, td, td_wheel).
+// No factor couples speed-bias blocks of frames that are not neighbours (IMUFactor: pose_i sb_i pose_j sb_j, imu_factor.h:28; WheelFactor: poses and wheel blocks only; the prior
+// holds sb_0 alone, estimator.cpp:3448-3520), so S restricted to the 9 NP speed-bias columns V is block tridiagonal, and eliminating V first, from sb_{NP-1} down to sb_0, needs
+// per step a 9 x 9 factor, the 9 x 9 coupling to the next block and a (ND + 1) x 9 panel against the dense rest D (poses + trailing blocks, ND = R - 9 NP, + the right-hand-side row).
+// Only D's packed triangle -- 21 KB at ND = 72 instead of 118 KB at R = 171 -- and two panels live in LDS; the finished panels go to global memory (L2) for the backward pass.
+// What this buys is footprint, not a shorter chain (171 pivots stay 171 pivots): two windows fit one CU (ba_step_chain: 256 threads, <= 256 registers, < 80 KB LDS).
+__device__ __forceinline__ int ch_dm(int c, int NP) { return c < 15 * NP ? 6 * (c / 15) + (c % 15) : c - 9 * NP; }   // reduced column of D (or the rhs slot R) -> its index in D; NOT for speed-bias columns
+__device__ __forceinline__ int ch_d2c(int dj, int NP) { return dj < 6 * NP ? 15 * (dj / 6) + dj % 6 : dj + 9 * NP; }
+__device__ __forceinline__ bool ch_isv(int c, int NP) { return c < 15 * NP && (c % 15) >= 6; }
+constexpr int kChPS = 13;    // row stride of a panel in LDS: 9 columns + 3 of zero padding (K = 12 for three MFMAs) + 1 against bank conflicts
+constexpr int kChYS = 9;     // row stride of a finished panel in global memory
+__host__ __device__ inline int ch_panel_rows(int ND) { return (ND + 1 + 15) & ~15; }
+__host__ __device__ inline size_t ch_lds_doubles(int ND) { return (((size_t)(ND + 1) * (ND + 2) / 2 + 1) & ~(size_t)1) + 2 * (size_t)ch_panel_rows(ND) * kChPS + 3 * 272; }
+__host__ __device__ inline size_t ch_y_stride(int ND) { return (size_t)ch_panel_rows(ND) * kChYS + 2 * 81; }   // per (window, frame): panel, W = L_kk^-1, E = L[sb_{k-1}, sb_k]
+// factor + explicit inverse of the nb x nb block held in a 17-stride LDS tile (lower part read), identity-padded to 16: the inverse goes to s_inv (17-stride)
+__device__ __forceinline__ bool wave_chol_tile(const double* sA, int nb, double* s_inv, int lane) {
+    int r = lane & 15;
+    const int g = lane >> 4;
+    double a[16], t[4];
+    {
+        const double* src = sA + min(r, nb - 1) * 17;
+#pragma unroll
+        for (int c = 0; c < 16; c++) a[c] = src[c];
+#pragma unroll
+        for (int c = 0; c < 16; c++) a[c] = (r < nb && c < nb) ? a[c] : (r == c ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) t[m] = (4 * m + g == r) ? 1.0 : 0.0;
+    double rd_own = 0.0;
+    bool good = true;
+    Chol16Step<0>::run(a, t, r, rd_own, good);
+#pragma unroll
+    for (int m = 0; m < 4; m++) s_inv[r * 17 + 4 * m + g] = t[m] * rd_own;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    return good;
+}
+
 // One 512-thread block per window: accept/reject of the previous candidate (trust_region_minimizer.cc), then the next
 // dogleg step (dogleg_strategy.cc): Jacobi scaling, Cauchy point, Gauss-Newton step through the Schur complement
 // (MFMA GEMM) and an LDS-resident blocked Cholesky, candidate point.  first: the call that follows the initial linearisation.
 // GS: the packed reduced system lives in global memory (sb.Sg) instead of LDS -- windows whose (R+1)(R+2)/2 doubles exceed 160 KB
 // (WINDOW_SIZE > 10); same code, the triangular solves then run out of L2.
 // NW: wavefronts per block (8: one block owns a CU's registers; 4: half of them, so that other kernels' wavefronts -- the tracker's -- can sit next to it)
-template <bool GS, int NW = 8>
+template <bool GS, int NW = 8, bool CH = false>
 __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int max_iters, int finalize_only) {
+    static_assert(!(CH && GS), "the chain form keeps its dense part in LDS");
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NRC = CH ? 256 : 512;   // capacity of the per-reduced-column tables (chain form: R <= 15 NP + 17 <= 195 by the host's choice)
+    constexpr int NCC = CH ? 96 : 256;    // capacity of the per-compact-column tables (chain form: ECW = 80)
     __shared__ double sred[512];
     __shared__ double s_inv[16 * 17];
     __shared__ double s_y[32];   // the solution of the current block of the backward substitution, double-buffered
     __shared__ int s_flag[4];
-    __shared__ int s_cmap[256];      // compact column -> reduced column (or -1), right-hand-side slot -> R
-    __shared__ double s_uc[256];     // a vector gathered to the compact layout (the Gauss-Newton solution during the back-substitution)
-    __shared__ double s_ucc[256];    // the Cauchy direction in the compact layout (kept for the quadratic form u^T H u)
-    __shared__ double s_rd[512];     // scratch: the Cauchy direction during the Schur pass, the solution during the backward substitution
-    __shared__ int s_rc[512];        // reduced column -> compact column of the visual system Vc (or -1)
-    __shared__ double s_hd[512];     // diagonal of H + Vc
-    __shared__ double s_gt[512];     // g + Vc's right-hand-side row
+    __shared__ int s_cmap[NCC];      // compact column -> reduced column (or -1), right-hand-side slot -> R
+    __shared__ double s_uc[NCC];     // a vector gathered to the compact layout (the Gauss-Newton solution during the back-substitution)
+    __shared__ double s_ucc[NCC];    // the Cauchy direction in the compact layout (kept for the quadratic form u^T H u)
+    __shared__ double s_rd[NRC];     // scratch: the Cauchy direction during the Schur pass, the solution during the backward substitution
+    __shared__ int s_rc[NRC];        // reduced column -> compact column of the visual system Vc (or -1)
+    __shared__ double s_hd[NRC];     // diagonal of H + Vc
+    __shared__ double s_gt[NRC];     // g + Vc's right-hand-side row
+    __shared__ double s_yd[CH ? 96 : 1];   // chain form: the solution of the dense part
     constexpr int NT = 64 * NW;
     const Dims d = w.d;
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     SolverState& st = w.st[b];
     if (uni(st.done)) return;
+    if ((uni(st.chain) != 0) != CH) return;   // a batch may hold windows of both kinds: each form of the kernel takes its own (the host launches a form only when the batch has such windows)
     const int R = uni(st.R), NE = uni(st.NE), RP = d.RP, VS = sb.VS, ECW = d.ECW;
     double* S = GS ? sb.Sg + (size_t)blockIdx.x * sb.SgStride : smem;  // packed lower (R+1)(R+2)/2: row R carries the right-hand side
+    // chain form: S is the packed triangle of the DENSE part only (poses + trailing blocks, ND columns, row ND = right-hand side); RC = dimension of what the blocked
+    // Cholesky below factors; DMAP: reduced column (or the right-hand-side slot R) -> row / column of S
+    const int CNP = d.NP, ND = CH ? R - 9 * CNP : R, RC = CH ? ND : R;
+#define DMAP(c) (CH ? ch_dm((c), CNP) : (c))
     const int* colf = w.colf + (size_t)b * d.NFB;
     const int* cole = w.cole + (size_t)b * d.F;
     double* scale = sb.scale + (size_t)b * VS; double* diag = sb.diag + (size_t)b * VS; double* grad = sb.grad + (size_t)b * VS;
     double* gn = sb.gn + (size_t)b * VS; double* stepv = sb.step + (size_t)b * VS; double* u = sb.u + (size_t)b * VS; double* yv = sb.yv + (size_t)b * VS;
     double* Es = sb.Es + (size_t)b * d.FP * ECW;
     if (tid < ECW) s_cmap[tid] = compact_to_col(tid, colf, d.NP, R);
-    for (int q = tid; q < 512; q += NT) s_rc[q] = -1;
+    for (int q = tid; q < NRC; q += NT) s_rc[q] = -1;
     __syncthreads();
     if (tid < 6 * d.NP + 7) { const int c = s_cmap[tid]; if (c >= 0 && c < R) s_rc[c] = tid; }
     GF_STAMP(0);
@@ -1605,6 +1655,7 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
         // H (load of the reduced system) anyway, instead of a separate sweep over both
         double uHu_acc = 0.0;
         bool need_alpha = true, asm_alpha_done = false;
+        int ch_alpha_k = 1 << 20;   // chain form: the fronts k >= ch_alpha_k have added their entries of H to u^T H u already (a retry with a larger mu must not add them again)
         constexpr int QN = GS ? 8 : 3;
         double uk[QN];
 #pragma unroll
@@ -1628,32 +1679,36 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
             const int NE4 = (NE + 3) & ~3;
             GF_STAMP(6);
             // reduced system in LDS (packed lower): S = s (H + Vc) s + mu D^2, row R = s g.  First the H part, row by row ...
-            for (int r0 = wave; r0 <= R; r0 += 4 * NW) {   // four rows per wavefront in flight: all loads first, then the arithmetic
+            // (chain form: only the rows and columns of the dense part; what a speed-bias column holds reaches its front in the elimination below)
+            for (int r0 = wave; r0 <= RC; r0 += 4 * NW) {   // four rows per wavefront in flight: all loads first, then the arithmetic
                 double hv[4][QN];
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
-                    const int r = r0 + NW * m;
+                    const int dr = r0 + NW * m;
+                    const int r = CH ? (dr < RC ? ch_d2c(dr, CNP) : R) : dr;
                     const double* hr = H + (size_t)min(r, R - 1) * RP;
 #pragma unroll
                     for (int q = 0; q < QN; q++) { const int c = lane + 64 * q; hv[m][q] = (r < R && c <= r) ? hr[c] : 0.0; }
                 }
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
-                    const int r = r0 + NW * m;
-                    if (r > R) continue;
-                    const int base = pk(r, 0);
+                    const int dr = r0 + NW * m;
+                    if (dr > RC) continue;
+                    const int r = CH ? (dr < RC ? ch_d2c(dr, CNP) : R) : dr;
+                    const int base = pk(dr, 0);
                     const double sr = r < R ? s_hd[r] : 1.0, ur = r < R ? s_rd[r] : 0.0;
 #pragma unroll
                     for (int q = 0; q < QN; q++) {
                         const int c = lane + 64 * q;
+                        if (CH && ch_isv(c, CNP)) continue;
                         if (r < R) {
                             if (c <= r) {
                                 double v = sr * s_hd[c] * hv[m][q];
                                 if (c == r) { const double lm = diag[r] * sqrt(mu); v += lm * lm; }
-                                S[base + c] = v;
+                                S[base + DMAP(c)] = v;
                                 if (!asm_alpha_done) uHu_acc += (c == r ? 1.0 : 2.0) * hv[m][q] * uk[q] * ur;   // H holds its lower triangle
                             }
-                        } else if (c < R) S[base + c] = s_hd[c] * s_gt[c];   // row R: the right-hand side s g (visual part included in s_gt)
+                        } else if (c < R) S[base + DMAP(c)] = s_hd[c] * s_gt[c];   // row R: the right-hand side s g (visual part included in s_gt)
                     }
                 }
             }
@@ -1687,7 +1742,7 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
                             const int c = s_cmap[kb];
                             if (c < 0) continue;
                             const double v = vv[m][q];
-                            S[pk(r, c)] += sr * s_hd[c] * v;
+                            S[pk(DMAP(r), DMAP(c))] += sr * s_hd[c] * v;
                             if (!asm_alpha_done) uHu_acc += (c == r ? 1.0 : 2.0) * v * ur * s_rd[c];
                         }
                     }
@@ -1754,7 +1809,7 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int row = s_cmap[16 * ti + (lane >> 4) + 4 * r];   // compact -> reduced is monotone: lower stays lower
-                        if (row >= 0 && col >= 0 && col <= row && col < R) S[pk(row, col)] -= acc[r];
+                        if (row >= 0 && col >= 0 && col <= row && col < R) S[pk(DMAP(row), DMAP(col))] -= acc[r];
                     }
                 }
             }
@@ -1764,6 +1819,142 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
             //      substitution.  Diagonal block: in-register factor + explicit inverse (wavefront 0); panel and trailing update: MFMA.
             if (tid == 0) s_flag[1] = 1;
             __syncthreads();
+            if (CH) {
+                // ---------------- chain form: eliminate the speed-bias blocks sb_{NP-1} ... sb_0 (see the note in front of this function).  Step k:
+                //  (1) the front of sb_k receives what column block k + 1 left:  P_k <- -(Y_{k+1} E_{k+1}^T),  A_k <- -(E_{k+1} E_{k+1}^T)  (MFMA), and the dense part's update
+                //      accumulators take Y_{k+1} Y_{k+1}^T (registers: S itself is touched once, behind the loop);
+                //  (2) the entries H itself holds for the front are added: A_k + mu D^2, C_k = S(sb_k, sb_{k-1}), the panel rows of the poses k - 1 .. k + 1 (k = 0: every row,
+                //      the prior is dense in sb_0) and the right-hand side -- and their share of the Cauchy point's u^T H u;
+                //  (3) wavefront 0 factors the 9 x 9 block and inverts the factor (W_k);
+                //  (4) Y_k = P_k W_k^T in place, E_k = C_k^T W_k^T; Y_k, W_k, E_k go to global memory for the backward pass.
+                const int PR = ch_panel_rows(ND), NTD = PR >> 4, NTT = NTD * (NTD + 1) / 2;
+                double* Pb0 = smem + ((((size_t)(ND + 1) * (ND + 2) / 2) + 1) & ~(size_t)1);
+                double* sA = Pb0 + 2 * (size_t)PR * kChPS; double* sC = sA + 272; double* sE = sC + 272;
+                double* Yg = sb.Yg + (size_t)b * CNP * sb.YgStride;
+                for (int q = tid; q < 2 * PR * kChPS + 3 * 272; q += NT) Pb0[q] = 0.0;   // padding columns 9 .. 12 and the rows behind ND stay zero for good
+                __syncthreads();
+                constexpr int MT = 6;   // update tiles of the dense part per wavefront: <= 6 tile rows -> 21 tiles over 4 wavefronts
+                d4 dacc[MT];
+#pragma unroll
+                for (int m = 0; m < MT; m++) dacc[m] = d4{0, 0, 0, 0};
+                const double smu = sqrt(mu);
+                const int ti_ = lane & 15, kq_ = lane >> 4;
+                auto dense_acc = [&](const double* Y) {
+#pragma unroll
+                    for (int m = 0; m < MT; m++) {
+                        const int t = wave + NW * m;
+                        if (t >= NTT) continue;
+                        const int ti = tri_row(t), tj = t - ti * (ti + 1) / 2;
+                        const double* pa = Y + (size_t)(16 * ti + ti_) * kChPS + kq_;
+                        const double* pb = Y + (size_t)(16 * tj + ti_) * kChPS + kq_;
+                        const double a0 = pa[0], a1 = pa[4], a2 = pa[8], b0 = pb[0], b1 = pb[4], b2 = pb[8];
+                        dacc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, dacc[m], 0, 0, 0);
+                        dacc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, dacc[m], 0, 0, 0);
+                        dacc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, dacc[m], 0, 0, 0);
+                    }
+                };
+                for (int k = CNP - 1; k >= 0; k--) {
+                    double* Pc = Pb0 + (size_t)((CNP - 1 - k) & 1) * PR * kChPS;   // this step's panel
+                    const double* Pp = Pb0 + (size_t)((CNP - k) & 1) * PR * kChPS;  // the finished panel of step k + 1
+                    const int sbk = 15 * k + 6;
+                    if (k < CNP - 1) {   // (1)
+                        for (int t = wave; t <= NTD; t += NW) {   // tile NTD is the 9 x 9 block
+                            d4 acc = {0, 0, 0, 0};
+                            const double* pa = t < NTD ? Pp + (size_t)(16 * t + ti_) * kChPS + kq_ : sE + ti_ * 17 + kq_;
+                            const double* pb = sE + ti_ * 17 + kq_;
+                            const double a0 = pa[0], a1 = pa[4], a2 = pa[8], b0 = pb[0], b1 = pb[4], b2 = pb[8];
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc, 0, 0, 0);
+                            if (ti_ < 9) {
+#pragma unroll
+                                for (int r = 0; r < 4; r++) {
+                                    const int row = kq_ + 4 * r;
+                                    if (t < NTD) Pc[(size_t)(16 * t + row) * kChPS + ti_] = -acc[r];
+                                    else if (row < 9) sA[row * 17 + ti_] = -acc[r];
+                                }
+                            }
+                        }
+                        dense_acc(Pp);
+                    }
+                    __syncthreads();
+                    {   // (2)
+                        const int lo = k == 0 ? 0 : 6 * (k - 1), nrow = k == 0 ? ND : min(18, 6 * CNP - lo);
+                        const int nC = k >= 1 ? 81 : 0, nE = 45 + nC + 9 * nrow + 9;
+                        const bool want_alpha = need_alpha && k < ch_alpha_k;
+                        for (int e = tid; e < nE; e += NT) {
+                            if (e < 45) {
+                                const int a = tri_row(e), bb = e - a * (a + 1) / 2, r = sbk + a, c = sbk + bb;
+                                const double hh = H[(size_t)r * RP + c];
+                                double v = s_hd[r] * s_hd[c] * hh;
+                                if (a == bb) { const double lm = diag[r] * smu; v += lm * lm; }
+                                sA[a * 17 + bb] += v;
+                                if (want_alpha) uHu_acc += (a == bb ? 1.0 : 2.0) * hh * s_rd[r] * s_rd[c];
+                            } else if (e < 45 + nC) {
+                                const int e2 = e - 45, a = e2 / 9, bb = e2 - 9 * a, r = sbk + a, c = sbk - 15 + bb;
+                                const double hh = H[(size_t)r * RP + c];
+                                sC[a * 17 + bb] = s_hd[r] * s_hd[c] * hh;
+                                if (want_alpha) uHu_acc += 2.0 * hh * s_rd[r] * s_rd[c];
+                            } else if (e < nE - 9) {
+                                const int e2 = e - 45 - nC, dq = e2 / 9, bb = e2 - 9 * dq, dj = lo + dq, cD = ch_d2c(dj, CNP), col = sbk + bb;
+                                const double hh = cD > col ? H[(size_t)cD * RP + col] : H[(size_t)col * RP + cD];
+                                Pc[(size_t)dj * kChPS + bb] += s_hd[cD] * s_hd[col] * hh;
+                                if (want_alpha) uHu_acc += 2.0 * hh * s_rd[cD] * s_rd[col];
+                            } else {
+                                const int bb = e - (nE - 9), col = sbk + bb;
+                                Pc[(size_t)ND * kChPS + bb] += s_hd[col] * s_gt[col];
+                            }
+                        }
+                        if (want_alpha) ch_alpha_k = k;
+                    }
+                    __syncthreads();
+                    if (wave == 0) {   // (3)
+                        __builtin_amdgcn_s_setprio(3);
+                        const bool good = wave_chol_tile(sA, 9, s_inv, lane);
+                        if (!good && lane == 0) s_flag[1] = 0;
+                        __builtin_amdgcn_s_setprio(0);
+                    }
+                    __syncthreads();
+                    if (!uni(s_flag[1])) break;
+                    double* Yk = Yg + (size_t)k * sb.YgStride;
+                    for (int t = wave; t <= NTD; t += NW) {   // (4)
+                        d4 acc = {0, 0, 0, 0};
+                        double a0, a1, a2;
+                        if (t < NTD) { const double* pa = Pc + (size_t)(16 * t + ti_) * kChPS + kq_; a0 = pa[0]; a1 = pa[4]; a2 = pa[8]; }
+                        else { const double* pa = sC + kq_ * 17 + ti_; a0 = pa[0]; a1 = pa[4 * 17]; a2 = pa[8 * 17]; }   // C_k^T: row i, k index a -> sC[a][i]
+                        const double* pb = s_inv + ti_ * 17 + kq_;
+                        const double b0 = pb[0], b1 = pb[4], b2 = pb[8];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc, 0, 0, 0);
+                        if (ti_ < 9) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const int row = kq_ + 4 * r;
+                                if (t < NTD) { Pc[(size_t)(16 * t + row) * kChPS + ti_] = acc[r]; Yk[(size_t)(16 * t + row) * kChYS + ti_] = acc[r]; }
+                                else if (row < 9) { sE[row * 17 + ti_] = acc[r]; Yk[(size_t)PR * kChYS + 81 + row * 9 + ti_] = acc[r]; }
+                            }
+                        }
+                    }
+                    if (tid < 81) Yk[(size_t)PR * kChYS + tid] = s_inv[(tid / 9) * 17 + tid % 9];
+                    __syncthreads();
+                }
+                if (uni(s_flag[1])) {   // the dense part takes the sum of all eleven panel products at once
+                    dense_acc(Pb0 + (size_t)((CNP - 1) & 1) * PR * kChPS);
+#pragma unroll
+                    for (int m = 0; m < MT; m++) {
+                        const int t = wave + NW * m;
+                        if (t >= NTT) continue;
+                        const int ti = tri_row(t), tj = t - ti * (ti + 1) / 2;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int row = 16 * ti + kq_ + 4 * r, col = 16 * tj + ti_;
+                            if (row <= ND && col <= row && col < ND) S[pk(row, col)] -= dacc[m][r];
+                        }
+                    }
+                }
+                __syncthreads();
+            }
 #ifdef GF_PROFILE_STEP
             long long tA = 0, tB = 0, tC = 0, t0c = clock64();
             if (blockIdx.x == 0 && tid == 0 && sb.stamps) { sb.stamps[24] = sb.stamps[25] = sb.stamps[26] = sb.stamps[27] = sb.stamps[28] = sb.stamps[29] = sb.stamps[30] = sb.stamps[31] = 0; }
@@ -1773,7 +1964,7 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
 #endif
             // diagonal block j0: in-register factor + explicit inverse (wavefront 0 only)
             auto diag_block = [&](int j0) {
-                const int nb = min(16, R - j0);
+                const int nb = min(16, RC - j0);
 #ifdef GF_PROFILE_STEP
                 long long d0 = clock64();
 #define GF_DSUB(i) do { const long long n_ = clock64(); if (blockIdx.x == 0 && tid == 0 && sb.stamps) sb.stamps[i] += n_ - d0; d0 = n_; } while (0)
@@ -1795,11 +1986,11 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
             // one LDS read-modify-write pass per tile and block column, 15 k cycles for the first columns on seven wavefronts next to a serial wavefront that
             // needed 8 k) every tile is written twice in total, the operands of an update are plain loads, and the serial wavefront only waits for its own
             // diagonal tile: it updates that one itself and goes straight on to factor it while the others update the rest of the column.
-            const int NTR = (R + 16) / 16;   // tile rows: rows 0 .. R (row R carries the right-hand side)
+            const int NTR = (RC + 16) / 16;   // tile rows: rows 0 .. R (row R carries the right-hand side)
             auto upd_tile = [&](int ti, int tj, int k0, int k1) {   // tile (ti, tj), ti >= tj, minus the products of the block rows ti and tj over the block columns k0 .. k1 - 1 (< tj)
                 const int ra = 16 * ti + (lane & 15), rb = 16 * tj + (lane & 15), kq = lane >> 4;
-                const bool va = ra <= R, vb = rb < R;   // row R (rhs) never acts as a column
-                const int base_a = pk(min(ra, R), 0) + kq, base_b = pk(min(rb, R - 1), 0) + kq;
+                const bool va = ra <= RC, vb = rb < RC;   // row R (rhs) never acts as a column
+                const int base_a = pk(min(ra, RC), 0) + kq, base_b = pk(min(rb, RC - 1), 0) + kq;
                 d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
                 if (k0 >= k1) return;
 #pragma unroll 2
@@ -1817,11 +2008,12 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tj + (lane & 15);
-                    if (row <= R && col <= row && col < R) S[pk(row, col)] -= acc0[r] + acc1[r];
+                    if (row <= RC && col <= row && col < RC) S[pk(row, col)] -= acc0[r] + acc1[r];
                 }
             };
-            for (int j0 = 0; j0 < R; j0 += 16) {
-                const int nb = min(16, R - j0), jb = j0 >> 4;
+            const bool chain_ok = !CH || uni(s_flag[1]) != 0;
+            for (int j0 = 0; j0 < RC && chain_ok; j0 += 16) {
+                const int nb = min(16, RC - j0), jb = j0 >> 4;
 #ifdef GF_PROFILE_STEP
                 const long long w0c = clock64();
 #endif
@@ -1837,7 +2029,7 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
                     __builtin_amdgcn_s_setprio(0);
                 } else {
                     if (jb > 0) for (int t = wave; t < NTR - jb; t += NW - 1) upd_tile(jb + t, jb, 0, jb);
-                    if (wave == NW - 1 && jb + 1 < NTR && 16 * (jb + 1) < R) upd_tile(jb + 1, jb + 1, 0, jb);
+                    if (wave == NW - 1 && jb + 1 < NTR && 16 * (jb + 1) < RC) upd_tile(jb + 1, jb + 1, 0, jb);
                 }
 #ifdef GF_PROFILE_STEP
                 if (blockIdx.x == 0 && sb.stamps && (tid == 0 || tid == 64 || tid == 256) && jb < 12) sb.stamps[(tid == 0 ? 40 : tid == 64 ? 56 : 72) + jb] = clock64() - w0c;
@@ -1849,15 +2041,15 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
                 const int r0 = j0 + nb;
                 auto panel = [&](auto full) {
                     constexpr bool FULL = decltype(full)::value;
-                    const int nrows = R + 1 - r0, nt = (nrows + 15) / 16;
+                    const int nrows = RC + 1 - r0, nt = (nrows + 15) / 16;
                     for (int t = wave; t < nt; t += NW) {
                         const int ra = r0 + 16 * t + (lane & 15);
-                        const int rb_ = pk(min(ra, R), j0);
+                        const int rb_ = pk(min(ra, RC), j0);
                         d4 acc = {0, 0, 0, 0};
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
                             const int kc = 4 * k + (lane >> 4);
-                            const double av = (ra <= R && (FULL || kc < nb)) ? S[rb_ + kc] : 0.0;
+                            const double av = (ra <= RC && (FULL || kc < nb)) ? S[rb_ + kc] : 0.0;
                             const double bv2 = s_inv[(lane & 15) * 17 + kc];          // B[k][c] = Linv[c][k]
                             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv2, acc, 0, 0, 0);
                         }
@@ -1865,7 +2057,7 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             const int row = r0 + 16 * t + (lane >> 4) + 4 * r, c = lane & 15;
-                            if (row <= R && (FULL || c < nb)) S[pk(row, j0 + c)] = acc[r];
+                            if (row <= RC && (FULL || c < nb)) S[pk(row, j0 + c)] = acc[r];
                         }
                     }
                 };
@@ -1884,10 +2076,10 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
                 // block's solution to the NEXT block's sixteen entries itself; the other wavefronts apply it to everything below that, one block behind
                 // and into an accumulator of their own (s_rd), so that no entry is updated from both sides.  One barrier per block instead of two, and the
                 // chain no longer waits for the wide update (11 x 3.8 k -> 11 x ~1.7 k cycles).
-                for (int r = tid; r < R; r += NT) s_rd[r] = 0.0;
+                for (int r = tid; r < RC; r += NT) s_rd[r] = 0.0;
                 __syncthreads();
-                for (int j0 = ((R - 1) / 16) * 16, par = 0; j0 >= 0; j0 -= 16, par ^= 1) {
-                    const int nb = min(16, R - j0);
+                for (int j0 = ((RC - 1) / 16) * 16, par = 0; j0 >= 0; j0 -= 16, par ^= 1) {
+                    const int nb = min(16, RC - j0);
 #ifdef GF_PROFILE_STEP
                     const long long bq0 = clock64();
 #endif
@@ -1896,7 +2088,7 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
                         // every load below is unconditional, from an index clamped into the block, and masked afterwards: predicated loads compiled into a branch each
                         // (700 instructions per block for ~150 of arithmetic)
                         const int cc = lane & 15, lz = min(lane, nb - 1);
-                        double z = S[pk(R, j0 + lz)] + s_rd[j0 + lz];
+                        double z = S[pk(RC, j0 + lz)] + s_rd[j0 + lz];
                         z = lane < nb ? z : 0.0;
                         double wc[16];   // column cc of the block's inverse factor (stored in place of the factor): y_c = sum_{r >= c} Linv[r][c] z_r
                         double lnext[16];   // rows of the block at the columns of the next block: L[j0 + c][j0 - 16 + lane]; rows beyond the block meet a zero solution entry
@@ -1916,18 +2108,18 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
 #pragma unroll
                             for (int c = 0; c < 16; c++) lnext[c] = S[pk(j0 + min(c, nb - 1), rn)];
                         }
-                        const double zn = S[pk(R, rn)];
+                        const double zn = S[pk(RC, rn)];
                         double y0 = 0.0, y1 = 0.0;
 #pragma unroll
                         for (int rr = 0; rr < 16; rr += 2) { y0 += wc[rr] * row_bcast(z, rr); y1 += wc[rr + 1] * row_bcast(z, rr + 1); }
                         z = y0 + y1;
-                        if (lane < nb) { s_y[16 * par + lane] = z; yv[j0 + lane] = z; }
+                        if (lane < nb) { s_y[16 * par + lane] = z; if (CH) s_yd[j0 + lane] = z; else yv[j0 + lane] = z; }
                         if (lane >= nb && lane < 16) s_y[16 * par + lane] = 0.0;
                         if (j0 > 0) {
                             double sv = zn;
 #pragma unroll
                             for (int c = 0; c < 16; c++) sv -= lnext[c] * row_bcast(z, c);
-                            if (lane < 16) S[pk(R, rn)] = sv;
+                            if (lane < 16) S[pk(RC, rn)] = sv;
                         }
                         __builtin_amdgcn_s_setprio(0);
                     }
@@ -1954,6 +2146,49 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
                     }
                 }
                 __syncthreads();
+                if (CH) {
+                    // the dense part's solution sits in s_yd.  Backward through the chain, in reverse elimination order:  y_k = W_k^T (z_k - Y_k[D]^T y_D - E_k^T y_{k-1}),
+                    // z_k = the right-hand-side row of the finished panel.  First everything that does not depend on the chain, by all wavefronts: W_k, E_k and z_k into LDS
+                    // (the panels' space is free now) and t_k = Y_k[D]^T y_D; then eleven 9 x 9 products on one wavefront.
+                    const int PR = ch_panel_rows(ND);
+                    double* sWE = smem + ((((size_t)(ND + 1) * (ND + 2) / 2) + 1) & ~(size_t)1);   // [NP][162], then t [NP][9], then z [NP][9]
+                    double* st_ = sWE + CNP * 162; double* sz_ = st_ + CNP * 9;
+                    const double* Yg = sb.Yg + (size_t)b * CNP * sb.YgStride;
+                    for (int q = tid; q < CNP * 162; q += NT) { const int k = q / 162, o = q - 162 * k; sWE[q] = Yg[(size_t)k * sb.YgStride + (size_t)PR * kChYS + o]; }
+                    for (int q = tid; q < CNP * 9; q += NT) { const int k = q / 9, c = q - 9 * k; sz_[q] = Yg[(size_t)k * sb.YgStride + (size_t)ND * kChYS + c]; }
+                    for (int k = wave; k < CNP; k += NW) {
+                        const int c = lane & 15, part = lane >> 4;
+                        const double* Yk = Yg + (size_t)k * sb.YgStride;
+                        double acc = 0.0;
+                        if (c < 9) for (int dj = part; dj < ND; dj += 4) acc += Yk[(size_t)dj * kChYS + c] * s_yd[dj];
+                        acc += __shfl_xor(acc, 16); acc += __shfl_xor(acc, 32);
+                        if (lane < 9) st_[k * 9 + lane] = acc;
+                    }
+                    __syncthreads();
+                    if (wave == 0) {
+                        const int c = lane & 15, cc = min(c, 8);   // the four 16-lane rows compute the same thing: every broadcast stays inside a DPP row
+                        double yprev = 0.0;
+                        for (int k = 0; k < CNP; k++) {
+                            const double* Wk = sWE + k * 162; const double* Ek = Wk + 81;
+                            double wcol[9], ecol[9];
+#pragma unroll
+                            for (int a = 0; a < 9; a++) { wcol[a] = Wk[a * 9 + cc]; ecol[a] = Ek[a * 9 + cc]; }
+                            double v = sz_[k * 9 + cc] - st_[k * 9 + cc];
+                            if (k > 0) {
+#pragma unroll
+                                for (int a = 0; a < 9; a++) v -= ecol[a] * row_bcast(yprev, a);
+                            }
+                            v = c < 9 ? v : 0.0;
+                            double y = 0.0;
+#pragma unroll
+                            for (int a = 0; a < 9; a++) y += wcol[a] * row_bcast(v, a);
+                            yprev = c < 9 ? y : 0.0;
+                            if (lane < 9) yv[15 * k + 6 + lane] = y;
+                        }
+                    }
+                    for (int dj = tid; dj < ND; dj += NT) yv[ch_d2c(dj, CNP)] = s_yd[dj];
+                    __syncthreads();
+                }
                 GF_STAMP(10);
                 // back-substitute the eliminated columns (one wavefront per row), check finiteness
                 double bad = 0;
@@ -2108,6 +2343,8 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
 }
 template <bool GS, int NW = 8>
 __global__ void __launch_bounds__(64 * NW) ba_step(Win w, StepBufs sb, int first, int max_iters, int finalize_only) { ba_step_body<GS, NW>(w, sb, first, max_iters, finalize_only); }
+// the chain form: four wavefronts, at most 256 registers, < 80 KB of LDS -- two windows per CU (see the note in front of ba_step_body)
+__global__ void __launch_bounds__(256, 2) ba_step_chain(Win w, StepBufs sb, int first, int max_iters, int finalize_only) { ba_step_body<false, 4, true>(w, sb, first, max_iters, finalize_only); }
 // The prior / IMU / wheel sweep of the candidate and the step that judges it in one launch (LDS-resident systems without GNSS blocks): the sweep's H, g and costs
 // are read by the same block right away, and the launch boundary between the two -- with the write-back of everything the sweep stored -- is gone.
 __global__ void __launch_bounds__(512) ba_misc_step(Win w, StepBufs sb, int max_iters, int finalize_only) {

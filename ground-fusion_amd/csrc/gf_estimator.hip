@@ -450,7 +450,10 @@ struct Gate {
     // GF_GROUP_SPIN_US (default 300): look at the counter for that long before going to sleep -- most waits of a group step are shorter than a sleep and a wake-up
     // of 128 threads.  Measured end to end, 256 members on 128 workers: 0 us 46.9 k window-solves/s (first..last request of the solve rendezvous 1.2 ms),
     // 300 us 48.8 k (0.77 ms), 3000 us 16 k (the spinning workers take the cores the tracker's pool and the batch's own thread need).
-    static int spin_us() { static const int v = [] { const char* e = getenv("GF_GROUP_SPIN_US"); return e ? atoi(e) : 300; }(); return v; }
+    // Round 6, with nothing taken out of the end-to-end clock any more (bench.py): spinning workers cost the caller's tracker thread and its bookkeeping pool more than they
+    // save (two groups of 128 members, 256 hardware threads: 16 workers each 40.8 k window-solves/s at 300 us against 45.4 k at 0; 32: 32.3 k / 44.6 k; 64: 21.5 k / 28.3 k;
+    // profiles/r06_e2e_pools.txt).  Default 0: straight to the futex.
+    static int spin_us() { static const int v = [] { const char* e = getenv("GF_GROUP_SPIN_US"); return e ? atoi(e) : 0; }(); return v; }
     void wait_while(int seen) {   // returns at once if gen != seen
         if (const int us = spin_us()) {
             const auto t0 = std::chrono::steady_clock::now();
@@ -2285,7 +2288,9 @@ int gf_estimator_group_create(const gf_estimator_cfg* c, int n, gf_estimator_gro
     int share = 1;
     // a launcher that pins every rank to its part of the node (numactl, cgroups, torchrun binding) has divided already: the mask IS the rank's share (round-5 advisor)
     if (const char* e = getenv("LOCAL_WORLD_SIZE")) if (hw_box <= 0 || hw >= hw_box) share = std::max(1, atoi(e));
-    int nt = std::min(n, std::max(1, hw / (2 * share)));
+    // ... and at most 32: a group step is three short host phases between two device batches, and beyond that the wake-ups (one futex, a hundred sleepers in idle states) cost
+    // more than the extra workers carry (round 6, honest clock, one group of 256: 8 workers 15.6 k window-solves/s, 16: 22.8 k, 32: 33.3 k, 128: 20.0 k)
+    int nt = std::min(n, std::max(1, std::min(32, hw / (2 * share))));
     if (const char* e = getenv("GF_GROUP_THREADS")) if (atoi(e) > 0) nt = std::min(n, atoi(e));
     // the members' IMU pre-integration as one device launch per camera frame.  It costs one more rendezvous per frame and pays where host threads are
     // scarce (round 5, 256 members on 8 hardware threads = 4 workers, two alternating groups: 20.9 k against 19.4 k window-solves/s; one group 11.9 k against 11.6 k;

@@ -546,3 +546,47 @@ def test_upload_refuses_a_repeated_observation_and_a_second_start_frame(gf):
     again = base.copy()
     assert est.solve([again], 1)[0] == est.solve([base.copy()], 1)[0]
     est.close()
+
+
+@pytest.mark.parametrize("seed,kw", [(1, {}), (2, {"use_wheel": False}), (3, {"fix_ex_pose": 0}), (4, {"fix_td": 0, "fix_ex_wheel": 1}), (6, {"max_features": 60}), (21, {"prior_chain": True})])
+def test_chain_form_of_the_step_matches_the_dense_form_and_the_oracle(gf, oracle, monkeypatch, seed, kw):
+    """Round 6: ba_step in its chain form (GF_BA_CHAIN=1: the speed-bias blocks eliminated first, block by block, along the chain the IMU factors make of them; only the
+    dense part -- poses + trailing blocks -- is an LDS-resident triangle, so that two windows share a CU) solves the same systems in another pivot order.  Against the dense
+    form: the same iteration counts, accepted steps and termination, states within 1e-9 (relative; two orders of summation of the same sums); against the oracle: the
+    bars of test_solve_matches_oracle_poses.  Windows with a prior (made by the library's own marginalisation), with free camera extrinsic / td (a larger dense part), without
+    wheel factors, and a batch of them in one launch."""
+    kw = dict(kw)
+    chain_prior = kw.pop("prior_chain", False)
+    w0 = SW.make_window(seed, oracle, **kw)
+    if chain_prior:
+        e0 = gf.Estimator()
+        wa = w0.copy()
+        e0.solve([wa], 8)
+        pr = e0.marginalize([wa], 0)[0]
+        e0.close()
+        w0 = SW.make_window(seed, oracle, frame0=1, prior=pr, **kw)
+    wo, wd, wc = w0.copy(), w0.copy(), w0.copy()
+    so = oracle.ba_solve(wo, 8)
+    est_d = gf.Estimator()
+    sd = est_d.solve([wd], 8)[0]
+    monkeypatch.setenv("GF_BA_CHAIN", "1")
+    est_c = gf.Estimator(batch=4)
+    sc = est_c.solve([wc], 8)[0]
+    for k_ in ("iterations", "successful_steps", "termination"):
+        assert sc[k_] == sd[k_] == so[k_], (k_, sc, sd, so)
+    assert abs(sc["final_cost"] - sd["final_cost"]) <= 1e-10 * sd["final_cost"]
+    for k_ in gw.STATE_KEYS:
+        if k_ in wd and np.size(wd[k_]):
+            assert (np.abs(wc[k_] - wd[k_]) / np.maximum(1.0, np.abs(wd[k_]))).max() < 1e-9, k_
+    dp, dr = _pose_diff(wo, wc)
+    assert dp < 1e-6 and dr < 1e-6, (dp, dr)
+    # the same window three times in one launch next to itself: every block computes what the lone window computed, to the bit
+    ws = [w0.copy() for _ in range(3)]
+    est_c.solve(ws, 8)
+    for w_ in ws:
+        assert all(np.array_equal(w_[k_], wc[k_]) for k_ in gw.STATE_KEYS if k_ in wc)
+    # and the marginalisation behind a chain-form solve is the one behind a dense-form solve (it reads the solved state only)
+    pd_, pc_ = est_d.marginalize([wd], 0)[0], est_c.marginalize([wc], 0)[0]
+    Ad, bd, _ = _prior_invariants(pd_); Ac, bc, _ = _prior_invariants(pc_)
+    _assert_prior_close(Ad, bd, Ac, bc)
+    est_d.close(); est_c.close()

@@ -188,10 +188,11 @@ int main(int argc, char** argv) {
         replay_one(argv[1], from_bag ? argv[3] : argv[2], from_bag, out, estimator, false);
         if (estimator.cfg.gnss_enable) {   // gnss_result.txt of the reference carries the ECEF / ENU position; here as one closing line
             int gi[8]; double yaw, anc[3], ecef[3], enu[3];
-            if (gf_estimator_get_gnss_state(estimator.handle(), gi, nullptr, nullptr, &yaw, anc, ecef, enu) == GF_OK)
+            if (gf_estimator_get_gnss_state(estimator.handle(), gi, nullptr, nullptr, &yaw, anc, ecef, enu) == GF_OK) {
                 printf("gf_replay: gnss_ready %d, anchor %.4f %.4f %.4f, ecef %.4f %.4f %.4f\n", gi[0], anc[0], anc[1], anc[2], ecef[0], ecef[1], ecef[2]);
                 // the same state without the rounding of the line above (hex floats: every bit), for whoever compares it with another pipeline (tests/test_replay_gpu.py)
                 printf("gf_replay: gnss_state_bits anchor %a %a %a ecef %a %a %a yaw %a\n", anc[0], anc[1], anc[2], ecef[0], ecef[1], ecef[2], yaw);
+            }
         }
     } catch (const std::exception& e) {
         fprintf(stderr, "gf_replay: %s\n", e.what());
