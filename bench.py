@@ -793,6 +793,22 @@ def main():
             for k_, v_ in lb.items():
                 v_["sequences_per_gpu"] = int(k_); v_["vs_256_sequences"] = v_["window_solves_per_s"] / value
             res["large_batch"] = lb
+            # the same with ba_step in its chain form (round 6: speed-bias blocks eliminated first, dense part only in LDS, 256 threads: two windows per CU; the switch is
+            # read when a handle is created, results agree with the dense form to 1e-9: tests/test_backend_gpu.py::test_chain_form_...)
+            had = os.environ.get("GF_BA_CHAIN")
+            os.environ["GF_BA_CHAIN"] = "1"
+            try:
+                lc = small_batch_sample(gfamd, dev, args, WIN, GNSS, sizes=(256, 512, 1024), K=20, distinct=64)
+                for k_, v_ in lc.items():
+                    v_["sequences_per_gpu"] = int(k_); v_["vs_256_sequences_dense_form"] = v_["window_solves_per_s"] / value
+                res["large_batch_chain_form"] = lc
+            except Exception as ex:
+                res["large_batch_chain_form"] = {"error": repr(ex)[:300]}
+            finally:
+                if had is None:
+                    os.environ.pop("GF_BA_CHAIN", None)
+                else:
+                    os.environ["GF_BA_CHAIN"] = had
             phase("large_batch")
         if world == 1 and not args.no_other_configs and not args.strong and args.config == 1 and not (args.no_frontend or args.no_backend):
             res["other_configs"] = {}

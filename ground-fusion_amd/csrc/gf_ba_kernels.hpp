@@ -1403,16 +1403,16 @@ template <int J> __device__ __forceinline__ double row_bcast64_c(double v) { ret
 // The block is read straight from the packed lower triangle S (rows / columns j0 .. j0 + nb - 1, padded with the identity); the inverse goes to s_inv
 // (operand of the panel product) and, packed, back into S in place of the block -- the factor itself is not needed again.
 // the 16 steps as template recursion: every lane index of a DPP control and every index into a[] / t[] is a compile-time constant
-template <int J, int C> struct Chol16A {   // a_r[c] -= L_cj * L_rj for the columns c > j
-    static __device__ __forceinline__ void run(double (&a)[16], double nl, double l) { fmac_bcast_c<C>(a[C], nl, l); Chol16A<J, C + 1>::run(a, nl, l); }
+template <int J, int C, int N = 16> struct Chol16A {   // a_r[c] -= L_cj * L_rj for the columns c > j (N: order of the block, columns from N on are identity padding)
+    static __device__ __forceinline__ void run(double (&a)[16], double nl, double l) { fmac_bcast_c<C>(a[C], nl, l); Chol16A<J, C + 1, N>::run(a, nl, l); }
 };
-template <int J> struct Chol16A<J, 16> { static __device__ __forceinline__ void run(double (&)[16], double, double) {} };
+template <int J, int N> struct Chol16A<J, N, N> { static __device__ __forceinline__ void run(double (&)[16], double, double) {} };
 template <int J, int M> struct Chol16W {   // t_r[4m + g] += t_j[4m + g] * nlw for the accumulators whose column can be <= j
     static __device__ __forceinline__ void fence(double (&t)[4]) { if (4 * M <= J) { dpp_fence(t[M]); Chol16W<J, M + 1>::fence(t); } }
     static __device__ __forceinline__ void run(double (&t)[4], double nlw) { if (4 * M <= J) { fmac_bcast_c<J>(t[M], t[M], nlw); Chol16W<J, M + 1>::run(t, nlw); } }
 };
 template <int J> struct Chol16W<J, 4> { static __device__ __forceinline__ void fence(double (&)[4]) {} static __device__ __forceinline__ void run(double (&)[4], double) {} };
-template <int J> struct Chol16Step {
+template <int J, int N = 16> struct Chol16Step {
     static __device__ __forceinline__ void run(double (&a)[16], double (&t)[4], int& r, double& rd_own, bool& good) {
         dpp_fence(a[J]);                                    // a[J] was last written by the previous step's DPP multiply-add
         const double piv = row_bcast64_c<J>(a[J]);
@@ -1433,15 +1433,15 @@ template <int J> struct Chol16Step {
         const double nlw = (r > J) ? -(l * rs) : 0.0;
         if (J > 0) Chol16W<J, 0>::fence(t);
         Chol16W<J, 0>::run(t, nlw);
-        if (J < 15) {
+        if (J < N - 1) {
             double nl = -l;
             dpp_fence(nl);
-            Chol16A<J, J + 1>::run(a, nl, l);
+            Chol16A<J, J + 1, N>::run(a, nl, l);
         }
-        Chol16Step<J + 1>::run(a, t, r, rd_own, good);
+        Chol16Step<J + 1, N>::run(a, t, r, rd_own, good);
     }
 };
-template <> struct Chol16Step<16> { static __device__ __forceinline__ void run(double (&)[16], double (&)[4], int&, double&, bool&) {} };
+template <int N> struct Chol16Step<N, N> { static __device__ __forceinline__ void run(double (&)[16], double (&)[4], int&, double&, bool&) {} };
 template <class SPtr>
 __device__ __forceinline__ bool wave_chol16_fused(SPtr S, int j0, int nb, double* s_inv, int lane) {
     int r = lane & 15;
@@ -1490,22 +1490,23 @@ __host__ __device__ inline int ch_panel_rows(int ND) { return (ND + 1 + 15) & ~1
 __host__ __device__ inline size_t ch_lds_doubles(int ND) { return (((size_t)(ND + 1) * (ND + 2) / 2 + 1) & ~(size_t)1) + 2 * (size_t)ch_panel_rows(ND) * kChPS + 3 * 272; }
 __host__ __device__ inline size_t ch_y_stride(int ND) { return (size_t)ch_panel_rows(ND) * kChYS + 2 * 81; }   // per (window, frame): panel, W = L_kk^-1, E = L[sb_{k-1}, sb_k]
 // factor + explicit inverse of the nb x nb block held in a 17-stride LDS tile (lower part read), identity-padded to 16: the inverse goes to s_inv (17-stride)
-__device__ __forceinline__ bool wave_chol_tile(const double* sA, int nb, double* s_inv, int lane) {
+template <int NB, int LD>
+__device__ __forceinline__ bool wave_chol_tile(const double* sA, double* s_inv, int lane) {
     int r = lane & 15;
     const int g = lane >> 4;
     double a[16], t[4];
     {
-        const double* src = sA + min(r, nb - 1) * 17;
+        const double* src = sA + min(r, NB - 1) * LD;
 #pragma unroll
-        for (int c = 0; c < 16; c++) a[c] = src[c];
+        for (int c = 0; c < 16; c++) a[c] = c < NB ? src[c] : 0.0;
 #pragma unroll
-        for (int c = 0; c < 16; c++) a[c] = (r < nb && c < nb) ? a[c] : (r == c ? 1.0 : 0.0);
+        for (int c = 0; c < 16; c++) a[c] = (r < NB && c < NB) ? a[c] : (r == c ? 1.0 : 0.0);
     }
 #pragma unroll
     for (int m = 0; m < 4; m++) t[m] = (4 * m + g == r) ? 1.0 : 0.0;
-    double rd_own = 0.0;
+    double rd_own = 1.0;   // rows from NB on are identity padding: the NB steps of the sweep never reach them
     bool good = true;
-    Chol16Step<0>::run(a, t, r, rd_own, good);
+    Chol16Step<0, NB>::run(a, t, r, rd_own, good);
 #pragma unroll
     for (int m = 0; m < 4; m++) s_inv[r * 17 + 4 * m + g] = t[m] * rd_own;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
@@ -1821,48 +1822,141 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
             __syncthreads();
             if (CH) {
                 // ---------------- chain form: eliminate the speed-bias blocks sb_{NP-1} ... sb_0 (see the note in front of this function).  Step k:
-                //  (1) the front of sb_k receives what column block k + 1 left:  P_k <- -(Y_{k+1} E_{k+1}^T),  A_k <- -(E_{k+1} E_{k+1}^T)  (MFMA), and the dense part's update
-                //      accumulators take Y_{k+1} Y_{k+1}^T (registers: S itself is touched once, behind the loop);
-                //  (2) the entries H itself holds for the front are added: A_k + mu D^2, C_k = S(sb_k, sb_{k-1}), the panel rows of the poses k - 1 .. k + 1 (k = 0: every row,
-                //      the prior is dense in sb_0) and the right-hand side -- and their share of the Cauchy point's u^T H u;
-                //  (3) wavefront 0 factors the 9 x 9 block and inverts the factor (W_k);
-                //  (4) Y_k = P_k W_k^T in place, E_k = C_k^T W_k^T; Y_k, W_k, E_k go to global memory for the backward pass.
+                //  (1) all wavefronts: the front of sb_k -- its entries of H are in place already -- receives what column block k + 1 left,
+                //      P_k -= Y_{k+1} E_{k+1}^T,  A_k -= E_{k+1} E_{k+1}^T  (MFMA), and the dense part takes Y_{k+1} Y_{k+1}^T;
+                //  (2) wavefront 0 factors the 9 x 9 block and inverts the factor (W_k).  Meanwhile the other wavefronts set up the NEXT front in the panel that has just
+                //      become free: A_{k-1} + mu D^2, C_{k-1} = S(sb_{k-1}, sb_{k-2}), the panel rows of the poses k - 2 .. k (k - 1 = 0: every row, the prior is dense in sb_0)
+                //      and the right-hand side, from values of H loaded one step earlier (and their share of the Cauchy point's u^T H u), and issue the loads of the front behind it;
+                //  (3) all wavefronts: Y_k = P_k W_k^T in place, E_k = C_k^T W_k^T; Y_k, W_k, E_k go to global memory for the backward pass.
+                // Three block barriers per step; the serial part of a step is the 9 x 9 factor.
                 const int PR = ch_panel_rows(ND), NTD = PR >> 4, NTT = NTD * (NTD + 1) / 2;
                 double* Pb0 = smem + ((((size_t)(ND + 1) * (ND + 2) / 2) + 1) & ~(size_t)1);
-                double* sA = Pb0 + 2 * (size_t)PR * kChPS; double* sC = sA + 272; double* sE = sC + 272;
+                double* sA0 = Pb0 + 2 * (size_t)PR * kChPS; double* sC0 = sA0 + 272; double* sE = sC0 + 272;   // sA, sC: two 9 x 9 tiles each (row stride 15), one per parity of the step; sE: 16 x 17
                 double* Yg = sb.Yg + (size_t)b * CNP * sb.YgStride;
                 for (int q = tid; q < 2 * PR * kChPS + 3 * 272; q += NT) Pb0[q] = 0.0;   // padding columns 9 .. 12 and the rows behind ND stay zero for good
+                for (int c = tid; c < R; c += NT) sred[c] = diag[c];                    // the dogleg diagonal next to the fronts (sred is free between the reductions)
                 __syncthreads();
-                constexpr int MT = 6;   // update tiles of the dense part per wavefront: <= 6 tile rows -> 21 tiles over 4 wavefronts
-                d4 dacc[MT];
-#pragma unroll
-                for (int m = 0; m < MT; m++) dacc[m] = d4{0, 0, 0, 0};
+                const int uw = uni(wave);
                 const double smu = sqrt(mu);
                 const int ti_ = lane & 15, kq_ = lane >> 4;
-                auto dense_acc = [&](const double* Y) {
+                // A finished panel Y_k is zero above row 6 (k - 1) (the fill of the elimination order: sb_k meets the poses k - 1 .. NP - 1 and, k = 0, everything): row tiles
+                // in front of ftile(k) are skipped by every product that involves Y_k -- a third of the tile work of the loop.
+                auto ftile = [&](int k) -> int { return k == 0 ? 0 : (6 * (k - 1)) >> 4; };
+                // the dense part takes Y Y^T of a finished panel straight away: tile by tile, three MFMAs and one read-modify-write of the tile's own entries of S (an update
+                // held in registers over the whole loop -- 48 VGPRs -- pushed the kernel into scratch memory)
+                auto dense_update = [&](const double* Y, int ft) {
+                    int cnt = 0;
+                    for (int ti = ft; ti < NTD; ti++)
+                        for (int tj = ft; tj <= ti; tj++) {
+                            if ((cnt++ & (NW - 1)) != uw) continue;
+                            const double* pa = Y + (size_t)(16 * ti + ti_) * kChPS + kq_;
+                            const double* pb = Y + (size_t)(16 * tj + ti_) * kChPS + kq_;
+                            const double a0 = pa[0], a1 = pa[4], a2 = pa[8], b0 = pb[0], b1 = pb[4], b2 = pb[8];
+                            d4 acc = {0, 0, 0, 0};
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc, 0, 0, 0);
+                            const int col = 16 * tj + ti_, r0 = 16 * ti + kq_;
+                            double* sp = S + pk(r0, col);
+                            double cur[4];   // the four entries first, then the four stores: written as read-modify-write per entry the compiler kept them in order, one LDS round trip each
 #pragma unroll
-                    for (int m = 0; m < MT; m++) {
-                        const int t = wave + NW * m;
-                        if (t >= NTT) continue;
-                        const int ti = tri_row(t), tj = t - ti * (ti + 1) / 2;
-                        const double* pa = Y + (size_t)(16 * ti + ti_) * kChPS + kq_;
-                        const double* pb = Y + (size_t)(16 * tj + ti_) * kChPS + kq_;
-                        const double a0 = pa[0], a1 = pa[4], a2 = pa[8], b0 = pb[0], b1 = pb[4], b2 = pb[8];
-                        dacc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, dacc[m], 0, 0, 0);
-                        dacc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, dacc[m], 0, 0, 0);
-                        dacc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, dacc[m], 0, 0, 0);
-                    }
+                            for (int r = 0; r < 4; r++) { const int row = r0 + 4 * r; cur[r] = (row <= ND && col <= row && col < ND) ? sp[4 * r * r0 + 2 * r * (4 * r + 1)] : 0.0; }   // pk(r0 + 4 r, col) - pk(r0, col) = 4 r r0 + 2 r (4 r + 1)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) { const int row = r0 + 4 * r; if (row <= ND && col <= row && col < ND) sp[4 * r * r0 + 2 * r * (4 * r + 1)] = cur[r] - acc[r]; }
+                        }
                 };
+                // the entries of H a front takes, enumerated per thread of the wavefronts 1 .. NW - 1.  Fronts k >= 1 have one shape (A lower 45, C 81, three pose blocks
+                // 162): entry e of thread t3 is the same kind of entry in every front, its address moves by 15 rows and 15 columns per frame, and its value is loaded one step
+                // before it is stored.  Front 0 (no C, every dense row: 45 + 9 ND entries) is gathered by the whole block when its turn comes.
+                constexpr int NTF = 64 * (NW - 1);
+                const int t3 = tid - 64;
+                int f_hb[2], f_r0[2], f_c0[2], f_tg[2], f_kind[2];   // k >= 1: H offset at k = 0, reduced row / column at k = 0, LDS target, kind (0 A, 1 C, 2 P of pose k-1 / k, 3 P of pose k+1, -1 none)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int e = t3 + NTF * j;
+                    f_kind[j] = -1; f_hb[j] = 0; f_r0[j] = 0; f_c0[j] = 0; f_tg[j] = 0;
+                    if (t3 < 0) continue;
+                    if (e < 45) { const int a = tri_row(e), bb = e - a * (a + 1) / 2; f_kind[j] = 0; f_r0[j] = 6 + a; f_c0[j] = 6 + bb; f_hb[j] = (6 + a) * RP + 6 + bb; f_tg[j] = a * 15 + bb; }
+                    else if (e < 126) { const int e2 = e - 45, a = e2 / 9, bb = e2 - 9 * a; f_kind[j] = 1; f_r0[j] = 6 + a; f_c0[j] = bb - 9; f_hb[j] = (6 + a) * RP + bb - 9; f_tg[j] = a * 15 + bb; }
+                    else if (e < 288) {
+                        const int e2 = e - 126, dq = e2 / 9, bb = e2 - 9 * dq, dc = 15 * (dq / 6) - 15 + dq % 6, cc = 6 + bb;   // dense column dc + 15 k, speed-bias column cc + 15 k
+                        f_kind[j] = dq < 12 ? 2 : 3; f_r0[j] = dc; f_c0[j] = cc;
+                        f_hb[j] = dc > cc ? dc * RP + cc : cc * RP + dc; f_tg[j] = (dq - 6) * kChPS + bb;   // panel row 6 (k - 1) + dq = 6 k + dq - 6
+                    }
+                }
+                double pf[2];
+                auto front_load = [&](int k) {   // k >= 1: issue the loads of front k's entries of H (stored one step later)
+                    const size_t sh = (size_t)k * (15 * RP + 15);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) pf[j] = (f_kind[j] >= 0 && !(f_kind[j] == 3 && k == CNP - 1)) ? H[sh + f_hb[j]] : 0.0;
+                };
+                auto front_store = [&](int k, double* Pn, double* sAn, double* sCn) {   // k >= 1: front k into the (zeroed) panel Pn and the tiles sAn / sCn
+                    const bool want_alpha = need_alpha && k < ch_alpha_k;
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        if (f_kind[j] < 0 || (f_kind[j] == 3 && k == CNP - 1)) continue;
+                        const int r = f_r0[j] + 15 * k, c = f_c0[j] + 15 * k;
+                        const double hh = pf[j];
+                        double v = s_hd[r] * s_hd[c] * hh;
+                        if (f_kind[j] == 0) { if (r == c) { const double lm = sred[r] * smu; v += lm * lm; } sAn[f_tg[j]] = v; }
+                        else if (f_kind[j] == 1) sCn[f_tg[j]] = v;
+                        else Pn[(size_t)6 * k * kChPS + f_tg[j]] = v;
+                        if (want_alpha) uHu_acc += (r == c ? 1.0 : 2.0) * hh * s_rd[r] * s_rd[c];
+                    }
+                    if (t3 >= 0 && t3 < 9) { const int col = 15 * k + 6 + t3; Pn[(size_t)ND * kChPS + t3] = s_hd[col] * s_gt[col]; }   // right-hand side s g at the speed-bias columns
+                    if (want_alpha) ch_alpha_k = k;
+                };
+                auto front0_gather = [&](double* Pn, double* sAn) {   // every thread of the block; the panel is zero
+                    const bool want_alpha = need_alpha && 0 < ch_alpha_k;
+                    const int nE = 45 + 9 * ND;
+#pragma unroll 4
+                    for (int e = tid; e < nE; e += NT) {
+                        if (e < 45) {
+                            const int a = tri_row(e), bb = e - a * (a + 1) / 2, r = 6 + a, c = 6 + bb;
+                            const double hh = H[(size_t)r * RP + c];
+                            double v = s_hd[r] * s_hd[c] * hh;
+                            if (a == bb) { const double lm = sred[r] * smu; v += lm * lm; }
+                            sAn[a * 15 + bb] = v;
+                            if (want_alpha) uHu_acc += (a == bb ? 1.0 : 2.0) * hh * s_rd[r] * s_rd[c];
+                        } else {
+                            const int e2 = e - 45, dj = e2 / 9, bb = e2 - 9 * dj, cD = ch_d2c(dj, CNP), col = 6 + bb;
+                            const double hh = cD > col ? H[(size_t)cD * RP + col] : H[(size_t)col * RP + cD];
+                            Pn[(size_t)dj * kChPS + bb] = s_hd[cD] * s_hd[col] * hh;
+                            if (want_alpha) uHu_acc += 2.0 * hh * s_rd[cD] * s_rd[col];
+                        }
+                    }
+                    if (tid < 9) { const int col = 6 + tid; Pn[(size_t)ND * kChPS + tid] = s_hd[col] * s_gt[col]; }
+                    if (want_alpha) ch_alpha_k = 0;
+                };
+                // the first front; the loads of the second
+                if (CNP == 1) front0_gather(Pb0, sA0);
+                else {
+                    if (t3 >= 0) { front_load(CNP - 1); front_store(CNP - 1, Pb0, sA0, sC0); if (CNP >= 3) front_load(CNP - 2); }
+                }
+                __syncthreads();
+#ifdef GF_PROFILE_STEP
+                long long cq[5] = {0, 0, 0, 0, 0}, cq0 = clock64();
+#define GF_CQ(i) do { const long long n_ = clock64(); cq[i] += n_ - cq0; cq0 = n_; } while (0)
+#else
+#define GF_CQ(i) do { } while (0)
+#endif
                 for (int k = CNP - 1; k >= 0; k--) {
-                    double* Pc = Pb0 + (size_t)((CNP - 1 - k) & 1) * PR * kChPS;   // this step's panel
-                    const double* Pp = Pb0 + (size_t)((CNP - k) & 1) * PR * kChPS;  // the finished panel of step k + 1
-                    const int sbk = 15 * k + 6;
+                    const int par = (CNP - 1 - k) & 1;
+                    double* Pc = Pb0 + (size_t)par * PR * kChPS;          // this step's panel (front k in place)
+                    double* Pp = Pb0 + (size_t)(par ^ 1) * PR * kChPS;    // the finished panel of step k + 1; then the next front
+                    double* sA = sA0 + 136 * par; double* sC = sC0 + 136 * par;
                     if (k < CNP - 1) {   // (1)
-                        for (int t = wave; t <= NTD; t += NW) {   // tile NTD is the 9 x 9 block
+                        const int ft = ftile(k + 1);
+                        for (int t = ft + uw; t <= NTD; t += NW) {   // tile NTD is the 9 x 9 block
                             d4 acc = {0, 0, 0, 0};
                             const double* pa = t < NTD ? Pp + (size_t)(16 * t + ti_) * kChPS + kq_ : sE + ti_ * 17 + kq_;
                             const double* pb = sE + ti_ * 17 + kq_;
                             const double a0 = pa[0], a1 = pa[4], a2 = pa[8], b0 = pb[0], b1 = pb[4], b2 = pb[8];
+                            double c0[4];
+                            if (ti_ < 9) {
+#pragma unroll
+                                for (int r = 0; r < 4; r++) { const int row = kq_ + 4 * r; c0[r] = t < NTD ? Pc[(size_t)(16 * t + row) * kChPS + ti_] : (row < 9 ? sA[row * 15 + ti_] : 0.0); }
+                            }
                             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
                             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
                             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc, 0, 0, 0);
@@ -1870,58 +1964,32 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
 #pragma unroll
                                 for (int r = 0; r < 4; r++) {
                                     const int row = kq_ + 4 * r;
-                                    if (t < NTD) Pc[(size_t)(16 * t + row) * kChPS + ti_] = -acc[r];
-                                    else if (row < 9) sA[row * 17 + ti_] = -acc[r];
+                                    if (t < NTD) Pc[(size_t)(16 * t + row) * kChPS + ti_] = c0[r] - acc[r];
+                                    else if (row < 9) sA[row * 15 + ti_] = c0[r] - acc[r];
                                 }
                             }
                         }
-                        dense_acc(Pp);
+                        dense_update(Pp, ft);
                     }
                     __syncthreads();
-                    {   // (2)
-                        const int lo = k == 0 ? 0 : 6 * (k - 1), nrow = k == 0 ? ND : min(18, 6 * CNP - lo);
-                        const int nC = k >= 1 ? 81 : 0, nE = 45 + nC + 9 * nrow + 9;
-                        const bool want_alpha = need_alpha && k < ch_alpha_k;
-                        for (int e = tid; e < nE; e += NT) {
-                            if (e < 45) {
-                                const int a = tri_row(e), bb = e - a * (a + 1) / 2, r = sbk + a, c = sbk + bb;
-                                const double hh = H[(size_t)r * RP + c];
-                                double v = s_hd[r] * s_hd[c] * hh;
-                                if (a == bb) { const double lm = diag[r] * smu; v += lm * lm; }
-                                sA[a * 17 + bb] += v;
-                                if (want_alpha) uHu_acc += (a == bb ? 1.0 : 2.0) * hh * s_rd[r] * s_rd[c];
-                            } else if (e < 45 + nC) {
-                                const int e2 = e - 45, a = e2 / 9, bb = e2 - 9 * a, r = sbk + a, c = sbk - 15 + bb;
-                                const double hh = H[(size_t)r * RP + c];
-                                sC[a * 17 + bb] = s_hd[r] * s_hd[c] * hh;
-                                if (want_alpha) uHu_acc += 2.0 * hh * s_rd[r] * s_rd[c];
-                            } else if (e < nE - 9) {
-                                const int e2 = e - 45 - nC, dq = e2 / 9, bb = e2 - 9 * dq, dj = lo + dq, cD = ch_d2c(dj, CNP), col = sbk + bb;
-                                const double hh = cD > col ? H[(size_t)cD * RP + col] : H[(size_t)col * RP + cD];
-                                Pc[(size_t)dj * kChPS + bb] += s_hd[cD] * s_hd[col] * hh;
-                                if (want_alpha) uHu_acc += 2.0 * hh * s_rd[cD] * s_rd[col];
-                            } else {
-                                const int bb = e - (nE - 9), col = sbk + bb;
-                                Pc[(size_t)ND * kChPS + bb] += s_hd[col] * s_gt[col];
-                            }
-                        }
-                        if (want_alpha) ch_alpha_k = k;
-                    }
-                    __syncthreads();
-                    if (wave == 0) {   // (3)
+                    GF_CQ(0);
+                    if (uw == 0) {   // (2)
                         __builtin_amdgcn_s_setprio(3);
-                        const bool good = wave_chol_tile(sA, 9, s_inv, lane);
+                        const bool good = wave_chol_tile<9, 15>(sA, s_inv, lane);
                         if (!good && lane == 0) s_flag[1] = 0;
                         __builtin_amdgcn_s_setprio(0);
+                    } else if (k >= 1) {   // the panel of step k + 1 is free now: cleared here, filled with the next front behind the next barrier (another thread's entry must not meet this zero late)
+                        for (int q = t3; q < PR * 9; q += NTF) { const int rr = q / 9; Pp[(size_t)rr * kChPS + q - 9 * rr] = 0.0; }
                     }
                     __syncthreads();
+                    GF_CQ(1);
                     if (!uni(s_flag[1])) break;
                     double* Yk = Yg + (size_t)k * sb.YgStride;
-                    for (int t = wave; t <= NTD; t += NW) {   // (4)
+                    for (int t = ftile(k) + uw; t <= NTD; t += NW) {   // (3)
                         d4 acc = {0, 0, 0, 0};
                         double a0, a1, a2;
                         if (t < NTD) { const double* pa = Pc + (size_t)(16 * t + ti_) * kChPS + kq_; a0 = pa[0]; a1 = pa[4]; a2 = pa[8]; }
-                        else { const double* pa = sC + kq_ * 17 + ti_; a0 = pa[0]; a1 = pa[4 * 17]; a2 = pa[8 * 17]; }   // C_k^T: row i, k index a -> sC[a][i]
+                        else { const int i9 = min(ti_, 8); a0 = sC[kq_ * 15 + i9]; a1 = sC[(kq_ + 4) * 15 + i9]; a2 = kq_ == 0 ? sC[8 * 15 + i9] : 0.0; if (ti_ >= 9) { a0 = 0.0; a1 = 0.0; a2 = 0.0; } }   // C_k^T: A[i][a] = C[a][i]
                         const double* pb = s_inv + ti_ * 17 + kq_;
                         const double b0 = pb[0], b1 = pb[4], b2 = pb[8];
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
@@ -1937,22 +2005,16 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
                         }
                     }
                     if (tid < 81) Yk[(size_t)PR * kChYS + tid] = s_inv[(tid / 9) * 17 + tid % 9];
+                    // the next front into the cleared panel (values of H loaded one step ago), then the loads of the one behind it
+                    if (k >= 2) { if (t3 >= 0) { front_store(k - 1, Pp, sA0 + 136 * (par ^ 1), sC0 + 136 * (par ^ 1)); if (k >= 3) front_load(k - 2); } }
+                    else if (k == 1) front0_gather(Pp, sA0 + 136 * (par ^ 1));
                     __syncthreads();
+                    GF_CQ(2);
                 }
-                if (uni(s_flag[1])) {   // the dense part takes the sum of all eleven panel products at once
-                    dense_acc(Pb0 + (size_t)((CNP - 1) & 1) * PR * kChPS);
-#pragma unroll
-                    for (int m = 0; m < MT; m++) {
-                        const int t = wave + NW * m;
-                        if (t >= NTT) continue;
-                        const int ti = tri_row(t), tj = t - ti * (ti + 1) / 2;
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int row = 16 * ti + kq_ + 4 * r, col = 16 * tj + ti_;
-                            if (row <= ND && col <= row && col < ND) S[pk(row, col)] -= dacc[m][r];
-                        }
-                    }
-                }
+#ifdef GF_PROFILE_STEP
+                if (blockIdx.x == 0 && tid == 0 && sb.stamps) { sb.stamps[87] = cq[0]; sb.stamps[88] = cq[1]; sb.stamps[89] = cq[2]; sb.stamps[90] = clock64(); }
+#endif
+                if (uni(s_flag[1])) dense_update(Pb0 + (size_t)((CNP - 1) & 1) * PR * kChPS, 0);   // the last panel
                 __syncthreads();
             }
 #ifdef GF_PROFILE_STEP
@@ -2146,42 +2208,63 @@ __device__ __forceinline__ void ba_step_body(Win w, StepBufs sb, int first, int 
                     }
                 }
                 __syncthreads();
+#ifdef GF_PROFILE_STEP
+                if (CH && blockIdx.x == 0 && tid == 0 && sb.stamps) sb.stamps[91] = clock64();
+#endif
                 if (CH) {
                     // the dense part's solution sits in s_yd.  Backward through the chain, in reverse elimination order:  y_k = W_k^T (z_k - Y_k[D]^T y_D - E_k^T y_{k-1}),
-                    // z_k = the right-hand-side row of the finished panel.  First everything that does not depend on the chain, by all wavefronts: W_k, E_k and z_k into LDS
-                    // (the panels' space is free now) and t_k = Y_k[D]^T y_D; then eleven 9 x 9 products on one wavefront.
+                    // z_k = the right-hand-side row of the finished panel.  Everything that does not depend on the chain first, by all wavefronts: W_k, E_k into LDS (the panels'
+                    // space is free now), z_k - Y_k[D]^T y_D, then  a_k = W_k^T (z_k - t_k)  and  B_k = W_k^T E_k^T;  what is left for one wavefront are eleven 9 x 9
+                    // matrix-vector products  y_k = a_k - B_k y_{k-1}.
                     const int PR = ch_panel_rows(ND);
-                    double* sWE = smem + ((((size_t)(ND + 1) * (ND + 2) / 2) + 1) & ~(size_t)1);   // [NP][162], then t [NP][9], then z [NP][9]
-                    double* st_ = sWE + CNP * 162; double* sz_ = st_ + CNP * 9;
+                    double* sWE = smem + ((((size_t)(ND + 1) * (ND + 2) / 2) + 1) & ~(size_t)1);   // [NP][162] W_k, E_k; then B [NP][81]
+                    double* sB = sWE + CNP * 162;
+                    double* szt = sred; double* sa_ = sred + 128;   // [NP][9] each: z_k - t_k, a_k (sred is free here)
                     const double* Yg = sb.Yg + (size_t)b * CNP * sb.YgStride;
-                    for (int q = tid; q < CNP * 162; q += NT) { const int k = q / 162, o = q - 162 * k; sWE[q] = Yg[(size_t)k * sb.YgStride + (size_t)PR * kChYS + o]; }
-                    for (int q = tid; q < CNP * 9; q += NT) { const int k = q / 9, c = q - 9 * k; sz_[q] = Yg[(size_t)k * sb.YgStride + (size_t)ND * kChYS + c]; }
+                    {   // 162 doubles per frame, <= 8 per thread at NP = 11: all loads before the first store
+                        double wv[8];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) { const int q = min(tid + NT * j, CNP * 162 - 1), k = q / 162, o = q - 162 * k; wv[j] = Yg[(size_t)k * sb.YgStride + (size_t)PR * kChYS + o]; }
+#pragma unroll
+                        for (int j = 0; j < 8; j++) { const int q = tid + NT * j; if (q < CNP * 162) sWE[q] = wv[j]; }
+                        for (int q = tid + NT * 8; q < CNP * 162; q += NT) { const int k = q / 162, o = q - 162 * k; sWE[q] = Yg[(size_t)k * sb.YgStride + (size_t)PR * kChYS + o]; }
+                    }
                     for (int k = wave; k < CNP; k += NW) {
-                        const int c = lane & 15, part = lane >> 4;
+                        const int c = lane & 15, part = lane >> 4, cc = min(c, 8);
                         const double* Yk = Yg + (size_t)k * sb.YgStride;
+                        const int r0 = k == 0 ? 0 : ((6 * (k - 1)) >> 4) << 4;   // the panel's rows in front of its first tile were never written (they are zero by structure)
                         double acc = 0.0;
-                        if (c < 9) for (int dj = part; dj < ND; dj += 4) acc += Yk[(size_t)dj * kChYS + c] * s_yd[dj];
+                        {   // <= 24 rows per lane (ND <= 96): every load issued before the first use (one at a time this was a chain of L2 round trips)
+                            double yv_[24];
+#pragma unroll
+                            for (int q = 0; q < 24; q++) { const int dj = part + 4 * q; yv_[q] = Yk[(size_t)min(max(dj, r0), ND - 1) * kChYS + cc]; }
+#pragma unroll
+                            for (int q = 0; q < 24; q++) { const int dj = part + 4 * q; if (dj >= r0 && dj < ND && c < 9) acc += yv_[q] * s_yd[dj]; }
+                        }
                         acc += __shfl_xor(acc, 16); acc += __shfl_xor(acc, 32);
-                        if (lane < 9) st_[k * 9 + lane] = acc;
+                        if (lane < 9) szt[k * 9 + lane] = Yk[(size_t)ND * kChYS + lane] - acc;
+                    }
+                    __syncthreads();
+                    for (int q = tid; q < CNP * 90; q += NT) {   // B_k[c][b] = sum_a W_k[a][c] E_k[b][a] (q % 90 < 81), a_k[c] = sum_a W_k[a][c] (z_k - t_k)[a] (the other nine)
+                        const int k = q / 90, o = q - 90 * k;
+                        const double* Wk = sWE + k * 162; const double* Ek = Wk + 81;
+                        double v = 0.0;
+                        if (o < 81) { const int c = o / 9, bb = o - 9 * c; for (int a2 = 0; a2 < 9; a2++) v += Wk[a2 * 9 + c] * Ek[bb * 9 + a2]; sB[k * 81 + o] = v; }
+                        else { const int c = o - 81; for (int a2 = 0; a2 < 9; a2++) v += Wk[a2 * 9 + c] * szt[k * 9 + a2]; sa_[k * 9 + c] = v; }
                     }
                     __syncthreads();
                     if (wave == 0) {
                         const int c = lane & 15, cc = min(c, 8);   // the four 16-lane rows compute the same thing: every broadcast stays inside a DPP row
                         double yprev = 0.0;
                         for (int k = 0; k < CNP; k++) {
-                            const double* Wk = sWE + k * 162; const double* Ek = Wk + 81;
-                            double wcol[9], ecol[9];
+                            double brow[9];
 #pragma unroll
-                            for (int a = 0; a < 9; a++) { wcol[a] = Wk[a * 9 + cc]; ecol[a] = Ek[a * 9 + cc]; }
-                            double v = sz_[k * 9 + cc] - st_[k * 9 + cc];
+                            for (int a2 = 0; a2 < 9; a2++) brow[a2] = sB[k * 81 + cc * 9 + a2];
+                            double y = sa_[k * 9 + cc];
                             if (k > 0) {
 #pragma unroll
-                                for (int a = 0; a < 9; a++) v -= ecol[a] * row_bcast(yprev, a);
+                                for (int a2 = 0; a2 < 9; a2++) y -= brow[a2] * row_bcast(yprev, a2);
                             }
-                            v = c < 9 ? v : 0.0;
-                            double y = 0.0;
-#pragma unroll
-                            for (int a = 0; a < 9; a++) y += wcol[a] * row_bcast(v, a);
                             yprev = c < 9 ? y : 0.0;
                             if (lane < 9) yv[15 * k + 6 + lane] = y;
                         }
