@@ -608,6 +608,297 @@ __global__ void __launch_bounds__(256, 7) lk_track_kernel(PyrGeom G, LkBatchArgs
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 6: P points per wavefront (P = 2 or 4).  What one point costs per Gauss-Newton iteration in lk_solve is 47 vector instructions that touch pixels, 30 for the two exact
+// 64-lane sums and 38 of wave-uniform float work (weights, the 2 x 2 solve, the termination tests): two thirds of an iteration do not scale with the window.  Here every lane
+// keeps its seven template pixels of P points; the per-pixel work runs point after point (skipped for a point that has converged: the branch is scalar), and everything that was
+// wave-uniform becomes one instruction stream for all P points -- lanes [16 p, 16 p + 16) (P = 4) or [32 p, 32 p + 32) (P = 2) carry the scalars of point p -- and the P sums of a
+// kind are reduced together: v_permlane32_swap / v_permlane16_swap fold value p onto the lanes of group p, four DPP steps finish inside the 16-lane rows.  The arithmetic of a
+// point is the arithmetic of lk_solve, operation for operation (exact integer sums, the same float expressions in the same order): results are bit-identical.
+template <int P> struct LkGroup { static constexpr int SH = P == 4 ? 4 : 5; };   // a point's scalars live in 1 << SH lanes
+template <int P> __device__ __forceinline__ int lk_rl(int v, int p) { return __builtin_amdgcn_readlane(v, p << LkGroup<P>::SH); }   // point p's value as a scalar
+
+__device__ __forceinline__ int fold32(int x, int y) {   // lanes 0..31: x[l] + x[l + 32]; lanes 32..63: y[l - 32] + y[l]
+#if __has_builtin(__builtin_amdgcn_permlane32_swap)
+    const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    return (int)r[0] + (int)r[1];
+#else
+    const int xs = __shfl_xor(x, 32), ys = __shfl_xor(y, 32);
+    return (threadIdx.x & 32) ? y + ys : x + xs;
+#endif
+}
+__device__ __forceinline__ int fold16(int x, int y) {   // rows 0, 2: x.row r + x.row (r + 1); rows 1, 3: y.row (r - 1) + y.row r
+#if __has_builtin(__builtin_amdgcn_permlane16_swap)
+    const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+    return (int)r[0] + (int)r[1];
+#else
+    const int xs = __shfl_xor(x, 16), ys = __shfl_xor(y, 16);
+    return (threadIdx.x & 16) ? y + ys : x + xs;
+#endif
+}
+__device__ __forceinline__ int row16_sum(int v) {   // every lane of a 16-lane row ends with the row's sum
+    v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);   // row_half_mirror
+    v += __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true);   // row_mirror
+    return v;
+}
+// exact sums over the wavefront of P per-lane partials (|v| < 2^28), each delivered to the lanes of its point's group as the float the reference makes of the int64 sum
+// ((float)(int64): one rounding).  Signed upper / unsigned lower half-words are summed separately (64 x 2^16 fits an int32) and put together in double, where the sum is
+// exact; the conversion to float then rounds once.
+template <int P> __device__ __forceinline__ float multi_sum_f32(const int (&v)[P]) {
+    int hi[P], lo[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) { hi[p] = v[p] >> 16; lo[p] = v[p] & 0xffff; }
+    int h, l;
+    if (P == 4) {
+        const int h02 = fold32(hi[0], hi[2]), h13 = fold32(hi[1], hi[P - 1]), l02 = fold32(lo[0], lo[2]), l13 = fold32(lo[1], lo[P - 1]);
+        h = row16_sum(fold16(h02, h13)); l = row16_sum(fold16(l02, l13));
+    } else {
+        h = row16_sum(fold32(hi[0], hi[P - 1])); l = row16_sum(fold32(lo[0], lo[P - 1]));
+        h = fold16(h, h); l = fold16(l, l);   // the two rows of a half
+    }
+    return (float)((double)h * 65536.0 + (double)l);
+}
+__device__ __forceinline__ int rn14v(float p) { return __builtin_bit_cast(int, __builtin_fmaf(p, 16384.f, 8388608.f)) - 0x4B000000; }   // rn14 per lane
+
+// template of one point at one level (the block of lk_solve, unchanged): ipx, ipy, w0, w1 wave-uniform
+__device__ __forceinline__ void lk_template(const LevelGeom& g, const uint8_t* imI, int ipx, int ipy, uint32_t w0, uint32_t w1, int r, int s, bool live,
+                                            int (&tI)[7], int (&tX)[7], int (&tY)[7], int& a11, int& a12, int& a22) {
+    const int x0 = ipx + 7 * s;
+    const int e = (ipx & 3) + 7 * s - 1;
+    const int o = e & 3;
+    const uint8_t* sbase = imI + g.img_off + (ptrdiff_t)(ipy - 1) * g.stride + (ipx & ~3) - 4;
+    const unsigned loff = (unsigned)(__mul24(r, g.stride) + (e & ~3) + 4);
+    const uint8_t* irow = sbase + loff;
+    uint32_t R0[5], R1[5], R2[5], R3[5];
+    load_row10(irow, o, R0); load_row10(sbase + g.stride + loff, o, R1); load_row10(sbase + 2 * g.stride + loff, o, R2); load_row10(sbase + 3 * g.stride + loff, o, R3);
+    uint32_t XT[4], YT[4], XB[4], YB[4];
+    scharr8(R0, R1, R2, XT, YT);
+    scharr8(R1, R2, R3, XB, YB);
+    if (!(ipx >= 0 && ipy >= 0 && ipx + kWin < g.w && ipy + kWin < g.h)) {
+        const int yt = ipy + r;
+        const uint32_t mt = (yt >= 0 && yt < g.h) ? 0xffffffffu : 0u, mb = (yt + 1 >= 0 && yt + 1 < g.h) ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int xa = x0 + 2 * m;
+            const uint32_t mx = ((xa >= 0 && xa < g.w) ? 0x0000ffffu : 0u) | ((xa + 1 >= 0 && xa + 1 < g.w) ? 0xffff0000u : 0u);
+            XT[m] &= mx & mt; YT[m] &= mx & mt; XB[m] &= mx & mb; YB[m] &= mx & mb;
+        }
+    }
+    a11 = 0; a12 = 0; a22 = 0;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        int iv = dot3_acc(dot3_acc(1 << 8, w0, pair_at(R1, k + 1)), w1, pair_at(R2, k + 1)) >> 9;
+        int ix = dot3_acc(dot3_acc(1 << 13, w0, pair_at(XT, k)), w1, pair_at(XB, k)) >> 14;
+        int iy = dot3_acc(dot3_acc(1 << 13, w0, pair_at(YT, k)), w1, pair_at(YB, k)) >> 14;
+        if (!live) { ix = 0; iy = 0; }
+        tI[k] = mad_i24(iv, -512, 1 << 8);
+        tX[k] = ix; tY[k] = iy;
+        a11 = mad_i24(ix, ix, a11); a12 = mad_i24(ix, iy, a12); a22 = mad_i24(iy, iy, a22);
+    }
+}
+// the residual sums of one point at its current position (the block of lk_solve's iteration): inx, iny, tx0, ty0, wA, wB wave-uniform
+__device__ __forceinline__ void lk_pixels(const uint8_t* tile_r, int inx, int iny, int tx0, int ty0, int s, uint32_t wA, uint32_t wB,
+                                          const int (&tI)[7], const int (&tX)[7], const int (&tY)[7], int& b1, int& b2) {
+    const int xo = (inx - tx0) + 7 * s;
+    const int o = xo & 3;
+    const uint32_t* q0 = reinterpret_cast<const uint32_t*>(tile_r + (iny - ty0) * kTileStride + (xo & ~3));
+    const uint32_t* q1 = q0 + kTileStride / 4;
+    uint32_t l0, h0, l1, h1;
+    align8(q0[0], q0[1], q0[2], o, l0, h0);
+    align8(q1[0], q1[1], q1[2], o, l1, h1);
+    const uint32_t V[8] = {__builtin_amdgcn_perm(l1, l0, 0x0c040c00u), __builtin_amdgcn_perm(l1, l0, 0x0c050c01u), __builtin_amdgcn_perm(l1, l0, 0x0c060c02u),
+                           __builtin_amdgcn_perm(l1, l0, 0x0c070c03u), __builtin_amdgcn_perm(h1, h0, 0x0c040c00u), __builtin_amdgcn_perm(h1, h0, 0x0c050c01u),
+                           __builtin_amdgcn_perm(h1, h0, 0x0c060c02u), __builtin_amdgcn_perm(h1, h0, 0x0c070c03u)};
+    b1 = 0; b2 = 0;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const int diff = __builtin_amdgcn_sdot2(as_v2s(V[k + 1]), as_v2s(wB), __builtin_amdgcn_sdot2(as_v2s(V[k]), as_v2s(wA), tI[k], true), true) >> 9;
+        b1 = mad_i24(diff, tX[k], b1);
+        b2 = mad_i24(diff, tY[k], b2);
+    }
+}
+__device__ __forceinline__ void lk_refill(uint8_t* tile, const uint8_t* Jbase, int stride, int tx0, int ty0, int lane) {
+    const int trow = lane >> 1, thalf = lane & 1;
+    const U4a v = *reinterpret_cast<const U4a*>(Jbase + (ptrdiff_t)(ty0 + trow) * stride + tx0 + thalf * 16);
+    __builtin_amdgcn_wave_barrier();
+    uint2* dst = reinterpret_cast<uint2*>(tile + trow * kTileStride + thalf * 16);
+    dst[0] = make_uint2(v.x, v.y);
+    dst[1] = make_uint2(v.z, v.w);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// P pyramidal LK solves by one wavefront.  Per-lane arguments carry the values of the lane's point (the same in every lane of a group); `on`: the point takes part.
+template <int P>
+__device__ __forceinline__ int lk_solve_mp(const PyrGeom& G, const uint8_t* imI, const uint8_t* imJ, float ppx, float ppy, float& nx, float& ny, bool on,
+                                           int maxLevel, bool useInitial, uint8_t* tiles, int lane, unsigned& n_levels, unsigned& n_iters) {
+    constexpr int SH = LkGroup<P>::SH;
+    const int r = lane < 63 ? lane / 3 : 20;
+    const int s = lane < 63 ? lane - 3 * r : 2;
+    const bool live = lane < 63;
+    const float half = (kWin - 1) * 0.5f;
+    int status = 1;
+    float nextx = nx, nexty = ny;
+    int tI[P][7], tX[P][7], tY[P][7];
+    for (int level = maxLevel; level >= 0; level--) {
+        const LevelGeom g = G.lv[level];
+        const float sc = __builtin_bit_cast(float, (127 - level) << 23);
+        float prevx = ppx * sc, prevy = ppy * sc;
+        float ntx, nty;
+        if (level == maxLevel) {
+            if (useInitial) { ntx = nextx * sc; nty = nexty * sc; } else { ntx = prevx; nty = prevy; }
+        } else { ntx = nextx * 2.f; nty = nexty * 2.f; }
+        nextx = ntx; nexty = nty;
+        prevx -= half; prevy -= half;
+        const int ipx = (int)floorf(prevx), ipy = (int)floorf(prevy);
+        const bool lvl = on && !(ipx < -kWin || ipx >= g.w || ipy < -kWin || ipy >= g.h);
+        if (on && !lvl && level == 0) status = 0;
+        n_levels += lvl ? 1u : 0u;
+        float a = prevx - ipx, b = prevy - ipy;
+        int iw00 = rn14v((1.f - a) * (1.f - b));
+        int iw01 = rn14v(a * (1.f - b));
+        int iw10 = rn14v((1.f - a) * b);
+        int iw11 = 16384 - iw00 - iw01 - iw10;
+        const int w0 = (int)(((uint32_t)iw00 & 0xffffu) | ((uint32_t)iw01 << 16)), w1 = (int)(((uint32_t)iw10 & 0xffffu) | ((uint32_t)iw11 << 16));
+        const unsigned long long lm = __ballot(lvl);
+        if (lm == 0) continue;
+        int a11[P], a12[P], a22[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            a11[p] = 0; a12[p] = 0; a22[p] = 0;
+            if ((lm >> (p << SH)) & 1ull)
+                lk_template(g, imI, lk_rl<P>(ipx, p), lk_rl<P>(ipy, p), (uint32_t)lk_rl<P>(w0, p), (uint32_t)lk_rl<P>(w1, p), r, s, live, tI[p], tX[p], tY[p], a11[p], a12[p], a22[p]);
+        }
+        const float FLT_SCALE = 1.f / (1 << 20);
+        const float A11 = multi_sum_f32<P>(a11) * FLT_SCALE, A12 = multi_sum_f32<P>(a12) * FLT_SCALE, A22 = multi_sum_f32<P>(a22) * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * kWin * kWin);
+        const bool itok = lvl && !(minEig < 1e-4f || D < 1.1920928955078125e-07f);
+        if (lvl && !itok && level == 0) status = 0;
+        D = 1.f / D;
+        float npx = ntx - half, npy = nty - half;
+        float pdx = 0.f, pdy = 0.f;
+        bool act = itok;
+        int tx0[P], ty0[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) { tx0[p] = -100000; ty0[p] = -100000; }
+        const uint8_t* Jbase = imJ + g.img_off;
+        for (int j = 0; j < 30; j++) {
+            const float fnx = floorf(npx), fny = floorf(npy);
+            const int inx = (int)fnx, iny = (int)fny;
+            if (act && (inx < -kWin || inx >= g.w || iny < -kWin || iny >= g.h)) {
+                if (level == 0) status = 0;
+                act = false;
+            }
+            const unsigned long long am = __ballot(act);
+            if (am == 0) break;
+            n_iters += act ? 1u : 0u;
+            a = npx - fnx; b = npy - fny;
+            iw00 = rn14v((1.f - a) * (1.f - b));
+            iw01 = rn14v(a * (1.f - b));
+            iw10 = rn14v((1.f - a) * b);
+            iw11 = 16384 - iw00 - iw01 - iw10;
+            const int wA = (int)(((uint32_t)iw00 & 0xffffu) | ((uint32_t)iw10 << 16)), wB = (int)(((uint32_t)iw01 & 0xffffu) | ((uint32_t)iw11 << 16));
+            int b1[P], b2[P];
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                b1[p] = 0; b2[p] = 0;
+                if ((am >> (p << SH)) & 1ull) {
+                    const int sx = lk_rl<P>(inx, p), sy = lk_rl<P>(iny, p);
+                    uint8_t* tile = tiles + p * kTileBytes;
+                    if ((unsigned)(sx - tx0[p]) > (unsigned)(kTileW - 22) || (unsigned)(sy - ty0[p]) > (unsigned)(kTileH - 22)) {
+                        tx0[p] = (sx - 4) & ~3;
+                        ty0[p] = sy - 5;
+                        lk_refill(tile, Jbase, g.stride, tx0[p], ty0[p], lane);
+                    }
+                    lk_pixels(tile + r * kTileStride, sx, sy, tx0[p], ty0[p], s, (uint32_t)lk_rl<P>(wA, p), (uint32_t)lk_rl<P>(wB, p), tI[p], tX[p], tY[p], b1[p], b2[p]);
+                }
+            }
+            const float fb1 = multi_sum_f32<P>(b1) * FLT_SCALE, fb2 = multi_sum_f32<P>(b2) * FLT_SCALE;
+            const float dx = (A12 * fb2 - A22 * fb1) * D;
+            const float dy = (A12 * fb1 - A11 * fb2) * D;
+            if (act) {
+                npx += dx; npy += dy;
+                nextx = npx + half; nexty = npy + half;
+                const bool small = (double)dx * dx + (double)dy * dy <= 0.01 * 0.01;
+                const bool osc = !small && j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01;
+                if (osc) { nextx -= dx * 0.5f; nexty -= dy * 0.5f; }
+                if (small || osc) act = false;
+                pdx = dx; pdy = dy;
+            }
+        }
+        if (itok && status && level == 0) {
+            const int inx = (int)floorf(nextx - half), iny = (int)floorf(nexty - half);
+            if (inx < -kWin || inx >= g.w || iny < -kWin || iny >= g.h) status = 0;
+        }
+    }
+    nx = nextx; ny = nexty;
+    return status;
+}
+
+// P points per wavefront, four wavefronts per block: grid.x = ceil(cap / (4 P)), grid.y = sequence.  Same outputs as lk_track_kernel, bit for bit.
+template <int P>
+__global__ void __launch_bounds__(256, P == 4 ? 2 : 3) lk_track_mp_kernel(PyrGeom G, LkBatchArgs A) {
+    __shared__ __attribute__((aligned(16))) uint8_t tiles[4 * P * kTileBytes];
+    constexpr int SH = LkGroup<P>::SH;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
+    const int i0 = (blockIdx.x * 4 + wave) * P;
+    if (A.seq_mask && !A.seq_mask[b]) return;
+    const int n = A.n_pts[b];
+    if (i0 >= n) return;
+    const int i = i0 + (lane >> SH);
+    const bool valid = i < n;
+    uint8_t* tile = tiles + wave * P * kTileBytes;
+    const size_t pi = (size_t)b * A.cap + min(i, n - 1);
+    const float2 pp = A.prev_pts[pi];
+    const uint8_t* prevI = A.img + ((size_t)b * 2 + A.prev_slot) * G.img_bytes;
+    const uint8_t* curI = A.img + ((size_t)b * 2 + (1 - A.prev_slot)) * G.img_bytes;
+    unsigned n_levels = 0, n_iters = 0;
+    float cx, cy;
+    if (A.fwd_use_init) { const float2 ip = A.init_pts[pi]; cx = ip.x; cy = ip.y; } else { cx = 0.f; cy = 0.f; }
+    int st = lk_solve_mp<P>(G, prevI, curI, pp.x, pp.y, cx, cy, valid, min(A.fwd_max_level, G.nlevels - 1), A.fwd_use_init != 0, tile, lane, n_levels, n_iters);
+    const int fwd_st = st;
+    if (A.flow_back) {
+        const bool back = valid && st != 0;
+        if (__ballot(back)) {
+            float rx = pp.x, ry = pp.y;
+            const int rst = lk_solve_mp<P>(G, curI, prevI, cx, cy, rx, ry, back, min(1, G.nlevels - 1), true, tile, lane, n_levels, n_iters);
+            if (back) {
+                const double ddx = (double)(pp.x - rx), ddy = (double)(pp.y - ry);
+                st = (rst && sqrt(ddx * ddx + ddy * ddy) <= 0.5) ? 1 : 0;
+            }
+        }
+    }
+    const LevelGeom g0 = G.lv[0];
+    if (st && A.post_checks) {
+        const int bx = __float2int_rn(cx), by = __float2int_rn(cy);
+        if (!(1 <= bx && bx < g0.w - 1 && 1 <= by && by < g0.h - 1)) st = 0;
+    }
+    if (valid && st && A.post_checks) {
+        const int p_u = (int)cx, p_v = (int)cy;  // x used as ROW (feature_tracker.cpp:160-163)
+        int grey = 0;
+        if (p_u >= 0 && p_u < g0.h && p_v >= 0 && p_v < g0.w) grey = curI[g0.img_off + (size_t)p_u * g0.stride + p_v];
+        if (grey > 250) st = 0;
+    }
+    if (valid && (lane & ((1 << SH) - 1)) == 0) {
+        const size_t po = (size_t)b * A.cap + i;
+        A.cur_pts[po] = make_float2(cx, cy);
+        A.status[po] = (uint8_t)st;
+        A.fwd_status[po] = (uint8_t)fwd_st;
+        uint16_t d = 0;
+        if (st && A.depth && A.post_checks) {
+            const int ry = (int)round((double)cy), rx = (int)round((double)cx);
+            d = A.depth[b * A.depth_seq_stride + (size_t)ry * A.depth_stride + rx];
+        }
+        A.depth_out[po] = d;
+        A.counters[2 * po] = n_levels;
+        A.counters[2 * po + 1] = n_iters;
+    }
+}
+
 // The derivative image of one level as lk_solve evaluates it (same device functions), for gf_pyramid_level's parity check against calcSharrDeriv:
 // thread = eight consecutive pixels of one row; out[y][x] = (dx, dy) as s16 pairs.
 __global__ void __launch_bounds__(256) deriv_probe_kernel(const uint8_t* __restrict__ pyr, LevelGeom g, int* __restrict__ out) {

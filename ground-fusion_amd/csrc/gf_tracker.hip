@@ -174,6 +174,7 @@ struct gf_tracker {
     DiskTable disk;
     int B = 0, cap = 0, cand_cap = 0, frame = 0, cur_slot = 0, sort_cap = 0;
     bool copy_lists = true;   // GF_TRACKER_COPIES=1: one hipMemcpyAsync per table instead of the copy-list kernels
+    int lk_points = 1;        // points per wavefront of the LK kernel: 1 (lk_track_kernel), 2 or 4 (lk_track_mp_kernel, round 6); GF_LK_POINTS
     bool profiling = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
@@ -297,6 +298,13 @@ static int launch_pyramid(gf_tracker* h, const uint8_t* d_raw_frames) {
     }
     HIPCHK(hipGetLastError());
     return GF_OK;
+}
+
+static void launch_lk(gf_tracker* h, int batch, const LkBatchArgs& A) {   // one LK launch over `batch` sequences in the form the handle was created for (same results in every form)
+    const int cap = h->cap;
+    if (h->lk_points == 4) lk_track_mp_kernel<4><<<dim3((cap + 15) / 16, batch), 256, 0, h->stream>>>(h->G, A);
+    else if (h->lk_points == 2) lk_track_mp_kernel<2><<<dim3((cap + 7) / 8, batch), 256, 0, h->stream>>>(h->G, A);
+    else lk_track_kernel<<<dim3((cap + 3) / 4, batch), 256, 0, h->stream>>>(h->G, A);
 }
 
 static LkBatchArgs lk_args(gf_tracker* h, int fwd_max_level, int use_init, int flow_back, int post_checks, const uint8_t* seqmask,
@@ -430,9 +438,8 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
         }
         if (int rc = flush()) return rc;
         if (prof) HIPCHK(hipEventRecord(h->ev[2], h->stream));
-        const dim3 grid((cap + 3) / 4, B);
-        if (any_plain) { lk_track_kernel<<<grid, 256, 0, h->stream>>>(h->G, lk_args(h, 3, 0, h->cfg.flow_back, 1, mask_plain, d_depth)); h->stats.lk_launches++; }
-        if (any_pred) { lk_track_kernel<<<grid, 256, 0, h->stream>>>(h->G, lk_args(h, 1, 1, h->cfg.flow_back, 1, mask_pred, d_depth)); h->stats.lk_launches++; }
+        if (any_plain) { launch_lk(h, B, lk_args(h, 3, 0, h->cfg.flow_back, 1, mask_plain, d_depth)); h->stats.lk_launches++; }
+        if (any_pred) { launch_lk(h, B, lk_args(h, 1, 1, h->cfg.flow_back, 1, mask_pred, d_depth)); h->stats.lk_launches++; }
         HIPCHK(hipGetLastError());
         if (prof) { HIPCHK(hipEventRecord(h->ev[3], h->stream)); lk_timed = true; }
         up(h->h_cur_pts, h->d_cur_pts, (size_t)B * cap);
@@ -463,7 +470,7 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
             std::vector<uint16_t> keep_depth(h->h_depth_out.p, h->h_depth_out.p + (size_t)B * cap);
             std::vector<unsigned> keep_cnt(h->h_counters.p, h->h_counters.p + (size_t)B * cap * 2);
             HIPCHK(hipMemcpyAsync(h->d_seqmask.p, h->h_seqmask.p, B, hipMemcpyHostToDevice, h->stream));
-            lk_track_kernel<<<dim3((cap + 3) / 4, B), 256, 0, h->stream>>>(h->G, lk_args(h, 3, 0, h->cfg.flow_back, 1, h->d_seqmask.p, d_depth));
+            launch_lk(h, B, lk_args(h, 3, 0, h->cfg.flow_back, 1, h->d_seqmask.p, d_depth));
             h->stats.lk_launches++;
             HIPCHK(hipGetLastError());
             up(h->h_cur_pts, h->d_cur_pts, (size_t)B * cap);
@@ -648,6 +655,7 @@ int gf_tracker_create(const gf_tracker_cfg* cfg, gf_tracker** out) {
         (void)hipGetDevice(&dev);
         h->pool = new gf::HostPool(h->B >= 8 ? nthr - 1 : 0, dev);
         h->copy_lists = !(getenv("GF_TRACKER_COPIES") && atoi(getenv("GF_TRACKER_COPIES")) != 0);
+        if (const char* e = getenv("GF_LK_POINTS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) h->lk_points = v; }
     }
     const int W = cfg->width, H = cfg->height, B = h->B, cap = h->cap;
     int cc = 1024;
@@ -849,7 +857,7 @@ int gf_lk_track(const uint8_t* prev, const uint8_t* next, int width, int height,
         HIPCHK(hipMemcpyAsync(h->d_npts.p, h->h_npts.p, sizeof(int), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d_prev_pts.p, h->h_prev_pts.p, (size_t)h->cap * sizeof(float2), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d_init_pts.p, h->h_init_pts.p, (size_t)h->cap * sizeof(float2), hipMemcpyHostToDevice, h->stream));
-        gf::lk_track_kernel<<<dim3((h->cap + 3) / 4, 1), 256, 0, h->stream>>>(h->G, gf::lk_args(h, max_level, use_initial_flow ? 1 : 0, 0, 0, nullptr, nullptr));
+        gf::launch_lk(h, 1, gf::lk_args(h, max_level, use_initial_flow ? 1 : 0, 0, 0, nullptr, nullptr));
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h->h_cur_pts.p, h->d_cur_pts.p, (size_t)h->cap * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(h->h_status.p, h->d_status.p, (size_t)h->cap, hipMemcpyDeviceToHost, h->stream));
