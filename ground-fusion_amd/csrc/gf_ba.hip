@@ -774,8 +774,12 @@ int run_solve(gf_ba* h, int max_iters) {
         HIPCHK(hipGetLastError());
         if (time_step) { HIPCHK(hipEventRecord(h->ev[7], h->stream)); h->stats.step_launches++; h->stats.step_flops += h->step_flops; }
         if (it < max_iters) {
-            // candidate state lives in buffer (1 - cur) of each window: the kernels pick the right one per window
-            if (int rc = launch_linearize(h, -1, -1, 1, it == 0, fuse_misc)) return rc;
+            // candidate state lives in buffer (1 - cur) of each window: the kernels pick the right one per window.  The candidate of the LAST iteration is only judged by its
+            // cost (the step behind it accepts or rejects and the solve ends): its sweeps run cost-only (only_valid = 3; round 6.  Not with GNSS blocks, whose kernel adds
+            // into H and the cost in one pass, not in the split formulation, not when the wall-clock cut may end the solve at another iteration; GF_BA_COST_ONLY=0: off)
+            static const bool cost_only_on = !(getenv("GF_BA_COST_ONLY") && atoi(getenv("GF_BA_COST_ONLY")) == 0);
+            const bool cost_only = cost_only_on && it == max_iters - 1 && it > 0 && d.GO == 0 && !h->split_jtj && !fuse_misc && !(h->max_solver_time > 0.0);
+            if (int rc = launch_linearize(h, -1, -1, cost_only ? 3 : 1, it == 0, fuse_misc)) return rc;
             if (it == 0) { h->stats.jtj_launches++; h->stats.jtj_flops += h->mfma_per_lin * 2048; h->stats.jtj_alg_flops += h->jtj_alg_flops; }
         }
     }

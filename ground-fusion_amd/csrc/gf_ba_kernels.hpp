@@ -377,6 +377,25 @@ __device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int
     return cost;
 }
 
+// the cost of one visual factor and nothing else (round 6: the candidate of a solve's last iteration is only ever judged by its cost -- the step behind it accepts or
+// rejects and the solve ends -- so its sweep evaluates residuals, not Jacobians: Ceres linearises that point in full as well and throws the result away)
+template <bool EX>
+__device__ __forceinline__ double vis_lane_cost(const Win& w, const Dims& d, int b, int k, const double* xs) {
+    if (k < 0) return 0.0;
+    const size_t kk = (size_t)b * d.NV + k;
+    const int pk_ = w.vis_idx[kk], feat = pk_ >> 10, fi = (pk_ >> 5) & 31, fj = pk_ & 31;
+    double vd[12];
+    {
+        const double* fj5 = w.vis_data + kk * 5; const double* fi6 = w.feat_obs + ((size_t)b * d.F + feat) * 6;
+        vd[0] = fi6[0]; vd[1] = fi6[1]; vd[2] = fi6[2]; vd[3] = fj5[0]; vd[4] = fj5[1]; vd[5] = 1.0; vd[6] = fi6[3]; vd[7] = fi6[4]; vd[8] = fj5[2]; vd[9] = fj5[3]; vd[10] = fi6[5]; vd[11] = fj5[4];
+    }
+    VisEval ev;
+    visual_eval(xs + off_pose(fi), xs + off_pose(fj), xs + off_ex(d.NP), xs[off_feat(d.NP) + feat], xs[off_td(d.NP)], vd, w.wpar[WPAR * b + 3], false, ev);
+    const double r0 = ev.row[0][13], r1 = ev.row[1][13];
+    const double sq = r0 * r0 + r1 * r1;
+    return sq > 1.0 ? 0.5 * (2.0 * sqrt(sq) - 1.0) : 0.5 * sq;   // Huber(1.0): rho(s) = 2 sqrt(s) - 1 beyond s = 1 (huber_corrector's rho0)
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // small dense helpers on LDS matrices, executed by one wavefront
 __device__ inline void wave_inverse_spd_sqrt(double* M, double* T, int n, int lane) {
@@ -882,12 +901,28 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
     const SolverState& st = w.st[b];
     const int st_cur = uni(st.cur);   // per-window scalars: uniform by construction, kept in scalar registers
     if (uni(st.done) && only_cand_valid != 2) return;   // only_cand_valid == 2: marginalisation pass (runs on finished windows)
-    if (only_cand_valid == 1 && !uni(st.cand_valid)) return;
+    if ((only_cand_valid == 1 || only_cand_valid == 3) && !uni(st.cand_valid)) return;
     const int n_order = uni(w.norder[b]);
     if (which < 0) which = 1 - st_cur;
     if (which_state == -2) which_state = st_cur; else if (which_state < 0) which_state = 1 - st_cur;
     const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
     const int* colf = w.colf + (size_t)b * d.NFB;
+    if (only_cand_valid == 3) {   // the last iteration's candidate: its cost only (same chunks, same order of the additions as the full sweep's cost)
+        const int nchunks = (n_order + 63) / 64, cpw = (nchunks + NW - 1) / NW;
+        const int c_lo = min(nchunks, wave * cpw), c_hi = min(nchunks, c_lo + cpw);
+        const int* ord = w.order + (size_t)b * d.NVP;
+        double cost = 0.0;
+        for (int ch = c_lo; ch < c_hi; ch++) {
+            const int entry = ch * 64 + lane;
+            const int oe = entry < n_order ? ord[entry] : -1;
+            cost += vis_lane_cost<EX>(w, d, b, oe < 0 ? -1 : (oe & 0xffff), xs);
+        }
+        cost = wave_sum_f64(cost);
+        if (lane == 0) s_cost[wave] = cost;
+        __syncthreads();
+        if (tid == 0) { double c = 0; for (int q = 0; q < NW; q++) c += s_cost[q]; *cost_part(w, 1, which, b) = c; }
+        return;
+    }
     // MARGIN_OLD pass (only_cand_valid == 2: its factor order holds the factors that start in frame 0 and nothing else): the pairs are (0, j), j = 1 .. NP - 1 -- NP - 1 tile
     // slots instead of NP (NP - 1) / 2, which is what lets this pass run on kVWM = 8 wavefronts with its tiles in LDS at any window size (round 5; it ran on the six wavefronts
     // the 55 + 6 slots of the solve's variant leave room for: 105 us against 50 us for the twelve-wavefront sweep of a whole window)
@@ -1032,6 +1067,7 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
     GF_WSTAMP(83);
     if (MODE != 2 && tid == 0) { double c = 0; for (int q = 0; q < NW; q++) c += s_cost[q]; *cost_part(w, 1, which, b) = c; }
     if (MODE == 1) return;
+    constexpr int NWV = NW / 2;   // wavefronts that build the compact system; the other NW - NWV build the E^T F rows at the same time
     // ---- continuation slots -> pair slots, in wavefront order
     for (int t = tid; t < TN; t += NT)
         for (int ww = 1; ww < NW; ww++) { const int p = s_cont[ww]; if (p >= 0) slots[(size_t)p * TN + t] += bnd[(size_t)ww * TN + t]; }
@@ -1047,7 +1083,9 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
             return slots[(size_t)slot_of(i, j) * TN + hi * (hi + 1) / 2 + lo];
         };
         auto loc_other = [&](int k) -> int { return k < TD ? (EX ? 14 + (k - EXC) : -1) : k == TD ? 12 : 13; };   // local index of a non-pose column
-        for (int idx = tid; idx < NCc * (NCc + 1) / 2; idx += NT) {
+        // Round 6: the compact system (LDS reads with computed addresses) and the E^T F rows below (global loads of the per-factor products) are both chains of latencies that
+        // share nothing: the first NWV wavefronts build Vc while the others build the rows -- one phase under the other instead of one behind the other (same sums, same order).
+        if (wave < NWV) for (int idx = tid; idx < NCc * (NCc + 1) / 2; idx += 64 * NWV) {
             const int ka = tri_row(idx), kb = idx - ka * (ka + 1) / 2;
             double s = 0.0;
             if (ka < EXC) {                                   // pose x pose (kb <= ka: also a pose column)
@@ -1083,7 +1121,7 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
         const int nfeat = uni(w.nfeat[b]);
         const int* cole = w.cole + (size_t)b * d.F;
         const int* fptr = d.F <= kVFP ? s_fptr : w.feat_ptr + (size_t)b * (d.F + 1);
-        for (int f0 = 8 * wave; f0 < nfeat; f0 += 8 * NW) et_rows8<EX>(w, sb, d, b, f0, nfeat, cole, fptr, which, lane);
+        if (wave >= NWV) for (int f0 = 8 * (wave - NWV); f0 < nfeat; f0 += 8 * (NW - NWV)) et_rows8<EX>(w, sb, d, b, f0, nfeat, cole, fptr, which, lane);
     }
     GF_WSTAMP(86);
 }
@@ -1121,7 +1159,8 @@ __device__ __forceinline__ void ba_linearize_misc_body(Win w, int which, int whi
     const SolverState& st = w.st[b];
     const int st_cur = uni(st.cur);
     if (uni(st.done) && only_cand_valid != 2) return;
-    if (only_cand_valid == 1 && !uni(st.cand_valid)) return;
+    const bool cost_only = only_cand_valid == 3;   // the last iteration's candidate: H and g of this point are never read (see vis_lane_cost)
+    if ((only_cand_valid == 1 || cost_only) && !uni(st.cand_valid)) return;
     if (which < 0) which = 1 - st_cur;
     if (which_state == -2) which_state = st_cur; else if (which_state < 0) which_state = 1 - st_cur;
     const double* xs = w.xs + ((size_t)which_state * d.B + b) * d.XS;
@@ -1203,16 +1242,16 @@ __device__ __forceinline__ void ba_linearize_misc_body(Win w, int which, int whi
             for (int c2 = 0; c2 < n; c2++) v += A[(size_t)a * n + c2] * s_dx[c2];
             pc += s_dx[a] * (b0[a] + 0.5 * v);
             s_pg[a] = b0[a] + v;
-            if (s_pcol[a] >= 0) g[s_pcol[a]] = b0[a] + v;
+            if (s_pcol[a] >= 0 && !cost_only) g[s_pcol[a]] = b0[a] + v;
         }
-        for (int c = t6; c < R; c += NT6) if (s_pidx[c] < 0) g[c] = 0.0;
+        if (!cost_only) for (int c = t6; c < R; c += NT6) if (s_pidx[c] < 0) g[c] = 0.0;
         pc = wave_sum_f64(pc);
         if (lane == 0) s_wc[wave] = pc;
         GF_WSTAMP_T(128, 68);
         // H <- A gathered to this pass's columns: lower triangle of the first R rows, four rows per wavefront in flight.  Outside the band of phase 3 the
         // entries are the prior's alone and constant over the solve: each of the two buffer sets receives them once (marginalisation passes always: their
         // column map is another one).
-        if (!h_have) for (int r0 = wave - 2; r0 < R; r0 += 4 * (kMW - 2)) {
+        if (!h_have && !cost_only) for (int r0 = wave - 2; r0 < R; r0 += 4 * (kMW - 2)) {
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 const int r = r0 + (kMW - 2) * m;
@@ -1250,7 +1289,7 @@ __device__ __forceinline__ void ba_linearize_misc_body(Win w, int which, int whi
     // ---- phase 3: the band.  Local tile indices: IMU factor at frame i: comp c (0-5 pose, 6-14 speed-bias) of frame i -> c, of frame i + 1 -> 15 + c,
     // residual 30; wheel factor at frame i: pose comp q of frame i -> q, of frame i + 1 -> 6 + q, shared column s (wheel extrinsic 0-5, sx, sy, sw,
     // td_wheel) -> 12 + s, residual 22.
-    {
+    if (!cost_only) {
         auto TI = [&](int k, int la, int lb) -> double { const int hi = max(la, lb), lo = min(la, lb); return sJi[kMJi * k + hi * (hi + 1) / 2 + lo]; };
         auto TW = [&](int k, int la, int lb) -> double { const int hi = max(la, lb), lo = min(la, lb); return sJw[kMJw * k + hi * (hi + 1) / 2 + lo]; };
         auto fcol = [&](int f, int c) -> int { const int c0 = colf[c < 6 ? fb_pose(f) : fb_sb(f)]; return c0 >= 0 ? c0 + (c < 6 ? c : c - 6) : -1; };
@@ -1337,7 +1376,7 @@ __device__ __forceinline__ void ba_linearize_misc_body(Win w, int which, int whi
         for (int k = 0; k < nwh; k++) c += s_fcost[32 + k];
         *cost_part(w, 0, which, b) = c;
         *cost_part(w, 2, which, b) = 0.0;   // the GNSS kernel (same stream, later) adds its part
-        w.st[b].h_prior[which] = h_keeps ? 1 : 0;
+        if (!cost_only) w.st[b].h_prior[which] = h_keeps ? 1 : 0;   // (a cost-only pass leaves the buffer set's H as it found it)
     }
     GF_WSTAMP(75);
 }
