@@ -143,6 +143,24 @@ def cpu_baseline(frames_host, dt, wins, threads, ba_iters, max_cnt, min_dist, re
                           "note": "one sequence at a time, the reference's own intra-sequence parallelism; Ceres itself stays single-threaded (estimator.cpp:3306)"}}
 
 
+def usable_cpus():
+    """hardware threads this process can really use: its affinity mask AND its container's CPU quota (cgroup v2 cpu.max / v1 cfs quota) -- the boxes of round 6 show 256
+    hardware threads and grant 16 cores' worth of bandwidth; the library sizes its pools the same way (csrc/gf_host_cpus.hpp)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, -(-q // p)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def pmc_summary():
     """counter-derived figures of the roofline kernels, collected by separate rocprofv3 --pmc passes (scripts/pmc_collect.sh) and kept
     under profiles/ -- never hard-coded here.  Missing file: the fields that need it are null."""
@@ -225,7 +243,7 @@ def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=None, d
     # 8 x 4: 34.0 k (profiles/r06_e2e_pools.txt; the figures quoted here in round 5 -- "64 workers each 70.6 k" -- came from the clock that subtracted 0.56 s of 0.65)
     own_env = n_groups > 1 and "GF_GROUP_THREADS" not in os.environ
     if own_env:
-        os.environ["GF_GROUP_THREADS"] = str(max(1, min(32, (os.cpu_count() or 2) // (2 * max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))) // n_groups))
+        os.environ["GF_GROUP_THREADS"] = str(max(1, min(32, 2 * usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))) // n_groups))
     workers = os.environ.get("GF_GROUP_THREADS", "library default")
     grps = [gfamd.EstimatorGroup(cfg, bounds[q + 1] - bounds[q], device_preint=device_preint, device_sweeps=device_sweeps) for q in range(n_groups)]
     if own_env:
@@ -320,7 +338,7 @@ def end_to_end_sample(gfamd, nseq, dev, max_cnt, min_dist, device_preint=None, d
             "backend_frames_with_mixed_decisions": mixed, "group_steps_live": steps_live, "keyframe_vote_share": keyframe_votes / max(votes, 1),
             "newest_position_norm_m": pos,
             "device_preint": bool(device_preint) if device_preint is not None else "library default (on when a worker thread carries >= 16 members, i.e. on small hosts)",
-            "host_hardware_threads": os.cpu_count(), "group_worker_threads": workers, "tracker_ms_per_call": trk_anatomy,
+            "host_hardware_threads": os.cpu_count(), "host_usable_cpus": usable_cpus(), "group_worker_threads": workers, "tracker_ms_per_call": trk_anatomy,
             "main_thread_ms_per_backend_frame": {k_: round(1e3 * v_ / bf, 3) for k_, v_ in clk.items()},
             "imu_wheel_feed": "every sample queued before the first camera frame; the loop below it makes no feed() call and nothing is subtracted from the wall clock",
             "path": "gf_tracker_track_batch_device -> gf_estimator_group_submit_features / _wait (inputFeature -> processImage -> gf_ba solve + marginalise, "
@@ -527,7 +545,7 @@ def main():
             os.environ["GF_HOST_THREADS"] = str(max(1, args.host_threads // 2))
             os.environ["GF_GROUP_THREADS"] = str(max(1, args.host_threads // (2 * max(1, args.e2e_groups))))   # several groups of one process share that half
         else:
-            os.environ.setdefault("GF_HOST_THREADS", str(max(1, min(16, (os.cpu_count() or 4) // 2))))
+            os.environ.setdefault("GF_HOST_THREADS", str(max(1, min(16, usable_cpus() // 2))))
         import gfamd
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(0)
@@ -547,7 +565,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # host bookkeeping threads of the tracker (up to 16 per process): keep all ranks of the node within its cores (the estimator group takes the same share)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    os.environ.setdefault("GF_HOST_THREADS", str(max(1, min(16, (os.cpu_count() or 4) // (2 * max(local_world, 1))))))
+    os.environ.setdefault("GF_HOST_THREADS", str(max(1, min(16, usable_cpus() // (2 * max(local_world, 1))))))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the HIP path has no CPU fallback)")
     # GF_BENCH_SINGLE_DEVICE=1 (tests only): every rank on device 0 with the gloo backend, to run the N > 1 path on a one-GPU box
@@ -881,8 +899,8 @@ def main():
             res["cpu_baseline"] = {"value": cb["steps_per_s"] if not args.no_backend else cb["tracked_features_per_s"],
                                    "unit": unit, "cores": cores, "kind": "port",
                                    "sample": "%d sequences x %d x %d frames (tracker) and %d solve+marginalise per sequence through the CPU oracle (%s), %d threads, one sequence per thread "
-                                             "(variant a x %d cores); then sequence 0 once more as variant b; %.1f s wall, ~%.0f s of CPU work; box has %d host cores"
-                                             % (nseq, cb["repeat"], fh.shape[0], cb["repeat"] * max(1, fh.shape[0] // 4), cb["build"], cores, cores, cb["wall_s"], cb["wall_s"] * cores, os.cpu_count() or 1),
+                                             "(variant a x %d cores); then sequence 0 once more as variant b; %.1f s wall, ~%.0f s of CPU work; box shows %d hardware threads, %d usable under its CPU quota"
+                                             % (nseq, cb["repeat"], fh.shape[0], cb["repeat"] * max(1, fh.shape[0] // 4), cb["build"], cores, cores, cb["wall_s"], cb["wall_s"] * cores, os.cpu_count() or 1, usable_cpus()),
                                    "detail": cb}
         phase("cpu_baseline")
         print(json.dumps(res))

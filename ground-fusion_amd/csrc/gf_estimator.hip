@@ -44,6 +44,7 @@
 #include "gf_comm.hpp"
 #include "gf_dmath.hpp"
 #include "gf_preint.hpp"
+#include "gf_host_cpus.hpp"
 #include "gf_init_sfm.hpp"
 
 namespace gf { int set_err(int code, const char* fmt, ...); }
@@ -2282,15 +2283,15 @@ int gf_estimator_group_create(const gf_estimator_cfg* c, int n, gf_estimator_gro
     (void)hipGetDevice(&g->device);
     // worker threads: half of the hardware threads this PROCESS may run on (its affinity mask: a process confined by taskset / cgroups to 8 threads sizes its pool for
     // 8, not for the 256 the box has), divided among the ranks that share the node
-    const int hw_box = (int)std::thread::hardware_concurrency();
-    int hw = hw_box;
-    { cpu_set_t cs; CPU_ZERO(&cs); if (sched_getaffinity(0, sizeof cs, &cs) == 0 && CPU_COUNT(&cs) > 0) hw = std::min(hw > 0 ? hw : CPU_COUNT(&cs), CPU_COUNT(&cs)); }
+    int hw_box = 0, hw = 0;
+    gf::host_cpus(hw_box, hw);   // affinity mask AND the container's CPU quota (gf_host_cpus.hpp): the boxes of round 6 show 256 hardware threads and grant 16
     int share = 1;
     // a launcher that pins every rank to its part of the node (numactl, cgroups, torchrun binding) has divided already: the mask IS the rank's share (round-5 advisor)
     if (const char* e = getenv("LOCAL_WORLD_SIZE")) if (hw_box <= 0 || hw >= hw_box) share = std::max(1, atoi(e));
-    // ... and at most 32: a group step is three short host phases between two device batches, and beyond that the wake-ups (one futex, a hundred sleepers in idle states) cost
-    // more than the extra workers carry (round 6, honest clock, one group of 256: 8 workers 15.6 k window-solves/s, 16: 22.8 k, 32: 33.3 k, 128: 20.0 k)
-    int nt = std::min(n, std::max(1, std::min(32, hw / (2 * share))));
+    // Twice as many workers as the rank can run in parallel, at most 32: a group step is three short host phases between two device batches and a worker mostly sleeps on
+    // the batch its members wait for, so a modest oversubscription pays; far beyond the quota the threads are throttled, not run (round 6, honest clock, 16-core quota, one
+    // group of 256: 8 workers 15.6 k window-solves/s, 16: 22.8 k, 32: 33.3 k, 128: 20.0 k; two groups: 2 x 8: 22.6 k, 2 x 16: 34.6-45.4 k, 2 x 32: 40.6-44.6 k, 2 x 64: 28.3 k)
+    int nt = std::min(n, std::max(1, std::min(32, 2 * hw / share)));
     if (const char* e = getenv("GF_GROUP_THREADS")) if (atoi(e) > 0) nt = std::min(n, atoi(e));
     // the members' IMU pre-integration as one device launch per camera frame.  It costs one more rendezvous per frame and pays where host threads are
     // scarce (round 5, 256 members on 8 hardware threads = 4 workers, two alternating groups: 20.9 k against 19.4 k window-solves/s; one group 11.9 k against 11.6 k;

@@ -30,6 +30,7 @@
 #include "gf_detect_kernels.hpp"
 #include "gf_lk_kernels.hpp"
 #include "gf_copy_list.hpp"
+#include "gf_host_cpus.hpp"
 
 namespace gf {
 
@@ -643,9 +644,8 @@ int gf_tracker_create(const gf_tracker_cfg* cfg, gf_tracker** out) {
     {
         // default: up to 16 threads out of this rank's share of the node (a frame of 256 sequences spends 1.3 ms in the bookkeeping with 4 threads, 0.5 ms with 16)
         int share = 1;
-        const int hw_box = (int)std::thread::hardware_concurrency();
-        int hw = hw_box;   // ... of the hardware threads this process may run on (its affinity mask, not the box)
-        { cpu_set_t cs; CPU_ZERO(&cs); if (sched_getaffinity(0, sizeof cs, &cs) == 0 && CPU_COUNT(&cs) > 0) hw = std::min(hw > 0 ? hw : CPU_COUNT(&cs), CPU_COUNT(&cs)); }
+        int hw_box = 0, hw = 0;   // ... of the hardware threads this process can really use (its affinity mask and its container's CPU quota, not the box: gf_host_cpus.hpp)
+        gf::host_cpus(hw_box, hw);
         // divide among the node's ranks only when the mask is the whole machine: a launcher that pins each rank has divided already (round-5 advisor)
         if (const char* e = getenv("LOCAL_WORLD_SIZE")) if (hw_box <= 0 || hw >= hw_box) share = std::max(1, atoi(e));
         int nthr = std::max(1, std::min(16, hw / (2 * share)));
