@@ -301,14 +301,27 @@ struct ImuPre {  // integration_base.h:22-62: linearized_acc/gyr, linearized_ba/
     std::vector<double> jacobian, covariance;
     bool dirty = true, restart = true;
     gf::ImuPreState st;   // state after st.n_done samples: appended samples are integrated on top (same operations as starting over)
+    // round 6: the 3-vector / quaternion part on a track of its own (st_s; its J / P are unused).  checkimu reads delta_v / sum_dt of every frame of all_image_frame on every
+    // image (estimator.cpp:2173-2216) and nothing else; evaluating those intervals in full was a second 15 x 15 pre-integration of every IMU sample, ~100 us of a member's
+    // ~220 us of host time per frame.  The full evaluation, when somebody asks for the Jacobian / covariance (the initialisation, an IMU factor), runs as before.
+    gf::ImuPreState st_s; bool s_dirty = true, s_restart = true;
     ImuPre(V3 a0, V3 g0, V3 ba, V3 bg) : acc0(a0), gyr0(g0), lin_ba(ba), lin_bg(bg), jacobian(225), covariance(225) {}
-    void push_back(double t, V3 a, V3 g) { dt.push_back(t); acc.insert(acc.end(), {a.x, a.y, a.z}); gyr.insert(gyr.end(), {g.x, g.y, g.z}); dirty = true; }
-    void repropagate(V3 ba, V3 bg) { lin_ba = ba; lin_bg = bg; dirty = true; restart = true; }  // integration_base.h:51-62
+    void push_back(double t, V3 a, V3 g) { dt.push_back(t); acc.insert(acc.end(), {a.x, a.y, a.z}); gyr.insert(gyr.end(), {g.x, g.y, g.z}); dirty = true; s_dirty = true; }
+    void repropagate(V3 ba, V3 bg) { lin_ba = ba; lin_bg = bg; dirty = true; restart = true; s_dirty = true; s_restart = true; }  // integration_base.h:51-62
     void adopt() {   // st was filled by the batched device kernel (bit-identical to the host loop over all samples)
         memcpy(delta_p, st.dp, 24); memcpy(delta_q, st.dq, 32); memcpy(delta_v, st.dv, 24);
         memcpy(jacobian.data(), st.J, 225 * 8); memcpy(covariance.data(), st.P, 225 * 8);
         sum_dt = st.sum_dt;
-        dirty = false; restart = false;
+        dirty = false; restart = false; s_dirty = false;
+    }
+    void eval_state() {   // delta_p / delta_q / delta_v / sum_dt up to date; jacobian / covariance possibly not (dirty stays as it is)
+        if (!dirty || !s_dirty) return;   // a clean full evaluation carries the same values
+        const double a0[3] = {acc0.x, acc0.y, acc0.z}, g0[3] = {gyr0.x, gyr0.y, gyr0.z}, ba[3] = {lin_ba.x, lin_ba.y, lin_ba.z}, bg[3] = {lin_bg.x, lin_bg.y, lin_bg.z};
+        if (s_restart || st_s.n_done > (int)dt.size()) { gf::imu_preint_reset(st_s, a0, g0); s_restart = false; }
+        gf::imu_preint_state_range(st_s, ba, bg, dt.data(), acc.data(), gyr.data(), st_s.n_done, (int)dt.size());
+        memcpy(delta_p, st_s.dp, 24); memcpy(delta_q, st_s.dq, 32); memcpy(delta_v, st_s.dv, 24);
+        sum_dt = st_s.sum_dt;
+        s_dirty = false;
     }
     int eval(const double* noise) {
         if (!dirty) return GF_OK;
@@ -318,7 +331,7 @@ struct ImuPre {  // integration_base.h:22-62: linearized_acc/gyr, linearized_ba/
         memcpy(delta_p, st.dp, 24); memcpy(delta_q, st.dq, 32); memcpy(delta_v, st.dv, 24);
         memcpy(jacobian.data(), st.J, 225 * 8); memcpy(covariance.data(), st.P, 225 * 8);
         sum_dt = st.sum_dt;
-        dirty = false;
+        dirty = false; s_dirty = false;
         return GF_OK;
     }
 };
@@ -1185,7 +1198,7 @@ struct gf_estimator {
         bool first = true;
         for (auto& kv : all_image_frame) {
             if (first) { first = false; continue; }
-            kv.second.pre_integration->eval(imu_noise);
+            kv.second.pre_integration->eval_state();   // delta_v and sum_dt are all this vote reads
             sum_g = sum_g + arr3(kv.second.pre_integration->delta_v) / kv.second.pre_integration->sum_dt;
         }
         const V3 aver_g = sum_g * 1.0 / (double)n;

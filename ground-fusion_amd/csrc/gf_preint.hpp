@@ -9,6 +9,8 @@ struct ImuPreState {
 };
 void imu_preint_reset(ImuPreState& st, const double* acc0, const double* gyr0);
 void imu_preint_range(ImuPreState& st, const double* ba, const double* bg, const double* noise, const double* dt, const double* acc, const double* gyr, int s0, int s1);
+// delta_p / delta_q / delta_v / sum_dt only (J and P of `st` are left alone): the same bits as imu_preint_range gives for them
+void imu_preint_state_range(ImuPreState& st, const double* ba, const double* bg, const double* dt, const double* acc, const double* gyr, int s0, int s1);
 // many intervals at once on the device (gf_preint.hip): every job is integrated from scratch over its n samples and fills *st with the bits the two calls
 // above would produce
 struct PreintBatch;

@@ -253,7 +253,7 @@ class BaStats(C.Structure):
 
 
 EXPORTS += ["gf_ba_create", "gf_ba_destroy", "gf_ba_solve", "gf_ba_marginalize", "gf_ba_upload", "gf_ba_solve_resident", "gf_ba_download", "gf_ba_get_stats",
-            "gf_ba_reset_stats", "gf_ba_linearize", "gf_ba_solve_resident_async", "gf_ba_wait", "gf_ba_debug_stamps", "gf_imu_preintegrate", "gf_wheel_preintegrate", "gf_ba_double2vector",
+            "gf_ba_reset_stats", "gf_ba_linearize", "gf_ba_solve_resident_async", "gf_ba_wait", "gf_ba_debug_stamps", "gf_imu_preintegrate", "gf_imu_preintegrate_state", "gf_wheel_preintegrate", "gf_ba_double2vector",
             "gf_preint_create", "gf_preint_destroy", "gf_imu_preintegrate_batch", "gf_preint_stats",
             "gf_featsweep_create", "gf_featsweep_destroy", "gf_triangulate_with_depth_batch", "gf_moving_consistency_batch", "gf_featsweep_stats"]
 
@@ -374,6 +374,18 @@ def imu_preintegrate(dt, acc, gyr, acc0, gyr0, ba, bg, noise):
     _chk(lib().gf_imu_preintegrate(len(dt), _p(dt, C.c_double), _p(acc, C.c_double), _p(gyr, C.c_double), _p(acc0, C.c_double), _p(gyr0, C.c_double),
                                    _p(ba, C.c_double), _p(bg, C.c_double), _p(noise, C.c_double), _p(out["delta_p"], C.c_double), _p(out["delta_q"], C.c_double),
                                    _p(out["delta_v"], C.c_double), _p(out["jacobian"], C.c_double), _p(out["covariance"], C.c_double), C.byref(sd)))
+    out["sum_dt"] = sd.value
+    return out
+
+
+def imu_preintegrate_state(dt, acc, gyr, acc0, gyr0, ba, bg):
+    """delta_p / delta_q / delta_v / sum_dt alone (gf_imu_preintegrate_state): the bits gf_imu_preintegrate returns for them"""
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    dt, acc, gyr, acc0, gyr0, ba, bg = map(f, (dt, acc, gyr, acc0, gyr0, ba, bg))
+    out = {"delta_p": np.zeros(3), "delta_q": np.zeros(4), "delta_v": np.zeros(3)}
+    sd = C.c_double(0)
+    _chk(lib().gf_imu_preintegrate_state(len(dt), _p(dt, C.c_double), _p(acc, C.c_double), _p(gyr, C.c_double), _p(acc0, C.c_double), _p(gyr0, C.c_double),
+                                         _p(ba, C.c_double), _p(bg, C.c_double), _p(out["delta_p"], C.c_double), _p(out["delta_q"], C.c_double), _p(out["delta_v"], C.c_double), C.byref(sd)))
     out["sum_dt"] = sd.value
     return out
 

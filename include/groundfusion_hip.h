@@ -290,6 +290,10 @@ int gf_ba_double2vector(int W, const double* R0_before, const double* P0_before,
 int gf_imu_preintegrate(int n, const double* dt, const double* acc, const double* gyr, const double* acc0, const double* gyr0, const double* ba,
                         const double* bg, const double* noise, double* delta_p, double* delta_q, double* delta_v, double* jacobian,
                         double* covariance, double* sum_dt);
+/* The 3-vector / quaternion part of the same loop alone (round 6): delta_p, delta_q (w x y z), delta_v, sum_dt -- bit for bit what gf_imu_preintegrate returns for them,
+ * without the Jacobian and the covariance (99 % of the arithmetic).  Estimator::checkimu (estimator.cpp:2173-2216) reads delta_v / sum_dt of every frame on every image. */
+int gf_imu_preintegrate_state(int n, const double* dt, const double* acc, const double* gyr, const double* acc0, const double* gyr0, const double* ba,
+                              const double* bg, double* delta_p, double* delta_q, double* delta_v, double* sum_dt);
 /* The same loop for many intervals at once ON THE DEVICE (row B2 batched): interval i owns the samples first[i] .. first[i+1]-1 of dt / acc / gyr
  * and row i of acc0 / gyr0 / ba / bg (n x 3) and of the outputs (delta_p n x 3, delta_q n x 4 as w x y z, delta_v n x 3, jacobian / covariance n x 225, sum_dt n).
  * One wavefront per interval; every result is bit-identical to gf_imu_preintegrate on the same samples.  No CPU fallback: GF_ERR_NO_DEVICE without a GPU. */

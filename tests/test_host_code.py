@@ -165,3 +165,21 @@ def test_machine_without_rccl_gets_an_error_not_a_crash(tmp_path):
     rc, rc2, msg = out.stdout.strip().split(" ", 2)
     assert int(rc) != 0 and int(rc) == int(rc2)
     assert "RCCL is not available" in msg and "no_such_librccl.so" in msg
+
+
+def test_state_only_preintegration_gives_the_bits_of_the_full_one():
+    """Round 6: Estimator::checkimu reads delta_v / sum_dt of every frame's pre-integration on every image (estimator.cpp:2173-2216); the library now integrates those
+    intervals' 3-vector / quaternion part alone (gf_imu_preintegrate_state) instead of a second full 15 x 15 pre-integration of every IMU sample.  The recursion of
+    delta_p / delta_q / delta_v does not depend on the Jacobian or the covariance: the values must be the full evaluation's, bit for bit -- also when the interval grows
+    sample by sample (the estimator appends and re-evaluates)."""
+    import gfamd
+    rng = np.random.default_rng(7)
+    for n in (0, 1, 2, 13, 27, 60):
+        dt = rng.uniform(0.004, 0.006, n); acc = rng.normal(0, 1.5, (n, 3)) + [0, 0, 9.8]; gyr = rng.normal(0, 0.3, (n, 3))
+        a0, g0 = rng.normal(0, 1, 3) + [0, 0, 9.8], rng.normal(0, 0.2, 3)
+        ba, bg = rng.normal(0, 0.05, 3), rng.normal(0, 0.005, 3)
+        full = gfamd.imu_preintegrate(dt, acc, gyr, a0, g0, ba, bg, [0.1, 0.01, 0.001, 0.0001])
+        lite = gfamd.imu_preintegrate_state(dt, acc, gyr, a0, g0, ba, bg)
+        for k in ("delta_p", "delta_q", "delta_v"):
+            assert np.array_equal(full[k].view(np.uint64), lite[k].view(np.uint64)), (n, k)
+        assert full["sum_dt"] == lite["sum_dt"]
