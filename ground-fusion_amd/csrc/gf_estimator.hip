@@ -1213,17 +1213,37 @@ struct gf_estimator {
         varstationary = var < 0.1;  // NaN (n == 0) compares false, as in the reference
     }
     bool checkvisual() {  // EST:2218-2274; solveRelativeRT_PNP always succeeds, its pose is unused
-        for (int i = 0; i < WINDOW_SIZE; i++) {
-            const std::vector<double> corres = f_manager.getCorrespondingWithDepth(i, WINDOW_SIZE);
-            const int nc = (int)(corres.size() / 6);
-            if (nc > 20) {
-                double sum_parallax = 0;
-                for (int j = 0; j < nc; j++) {
-                    const double* c = &corres[6 * j];
-                    const double dx = c[0] / c[2] - c[3] / c[5], dy = c[1] / c[2] - c[4] / c[5];
-                    sum_parallax = sum_parallax + sqrt(dx * dx + dy * dy);
+        // The reference collects the correspondences (i, WINDOW_SIZE) frame by frame -- WINDOW_SIZE walks over the track list, a vector each -- and sums their parallax.  One
+        // walk does the same: a track contributes to frame i's sum in list order either way, with the same operations per term (getCorrespondingWithDepth's depth-scaled
+        // points, FM:219-247), so every sum has the bits it had; the decisions are then taken in frame order as before.  (round 6: this vote runs on every image of every member)
+        double sum_parallax[32]; int nc[32];
+        const int W_ = std::min(WINDOW_SIZE, 32);
+        for (int i = 0; i < W_; i++) { sum_parallax[i] = 0; nc[i] = 0; }
+        if (WINDOW_SIZE <= 32)
+            for (auto& it : f_manager.feature) {
+                if (it.endFrame() < WINDOW_SIZE) continue;
+                const FeaturePerFrame& fb = it.feature_per_frame[WINDOW_SIZE - it.start_frame];
+                if (fb.depth < 0.1 || fb.depth > 10) continue;
+                const V3 b = fb.point * fb.depth;
+                for (int i = std::max(it.start_frame, 0); i < WINDOW_SIZE; i++) {
+                    const FeaturePerFrame& fa = it.feature_per_frame[i - it.start_frame];
+                    if (fa.depth < 0.1 || fa.depth > 10) continue;
+                    const V3 a = fa.point * fa.depth;
+                    const double dx = a.x / a.z - b.x / b.z, dy = a.y / a.z - b.y / b.z;
+                    sum_parallax[i] = sum_parallax[i] + sqrt(dx * dx + dy * dy);
+                    nc[i]++;
                 }
-                const double average_parallax = 1.0 * sum_parallax / nc;
+            }
+        for (int i = 0; i < WINDOW_SIZE; i++) {
+            double sp; int n;
+            if (WINDOW_SIZE <= 32) { sp = sum_parallax[i]; n = nc[i]; }
+            else {   // (longer windows than any configuration uses: the frame-by-frame route)
+                const std::vector<double> corres = f_manager.getCorrespondingWithDepth(i, WINDOW_SIZE);
+                n = (int)(corres.size() / 6); sp = 0;
+                for (int j = 0; j < n; j++) { const double* c = &corres[6 * j]; const double dx = c[0] / c[2] - c[3] / c[5], dy = c[1] / c[2] - c[4] / c[5]; sp = sp + sqrt(dx * dx + dy * dy); }
+            }
+            if (n > 20) {
+                const double average_parallax = 1.0 * sp / n;
                 if (average_parallax * 460 < 0.5) return true;
                 visualstationary = false;
             }
