@@ -200,6 +200,7 @@ struct gf_ba {
     // chain form of ba_step (round 6; gf_ba_kernels.hpp, note in front of ba_step_body): GF_BA_CHAIN=1 or gf_ba_set_chain().  One setting per process for the same reason as
     // step_waves: the two forms pivot in different orders, and a window alone must run the form it runs inside a batch.
     bool chain_mode = false; int n_chain = 0, n_dense = 0, chain_nd = 0; size_t yg_stride = 0; Buf<double> Yg;
+    bool cost_only = true;   // the last iteration's candidate is linearised cost-only (GF_BA_COST_ONLY=0 when the handle is created: in full, as every other candidate)
     bool upload_kernel = true;
     bool pos_ident = false;
     bool split_jtj = false, split_timed = false;   // gf_ba_set_split_jtj: the visual sweep as two kernels (block rows through HBM, contraction-only MFMA kernel)
@@ -777,8 +778,7 @@ int run_solve(gf_ba* h, int max_iters) {
             // candidate state lives in buffer (1 - cur) of each window: the kernels pick the right one per window.  The candidate of the LAST iteration is only judged by its
             // cost (the step behind it accepts or rejects and the solve ends): its sweeps run cost-only (only_valid = 3; round 6.  Not with GNSS blocks, whose kernel adds
             // into H and the cost in one pass, not in the split formulation, not when the wall-clock cut may end the solve at another iteration; GF_BA_COST_ONLY=0: off)
-            static const bool cost_only_on = !(getenv("GF_BA_COST_ONLY") && atoi(getenv("GF_BA_COST_ONLY")) == 0);
-            const bool cost_only = cost_only_on && it == max_iters - 1 && it > 0 && d.GO == 0 && !h->split_jtj && !fuse_misc && !(h->max_solver_time > 0.0);
+            const bool cost_only = h->cost_only && it == max_iters - 1 && it > 0 && d.GO == 0 && !h->split_jtj && !fuse_misc && !(h->max_solver_time > 0.0);
             if (int rc = launch_linearize(h, -1, -1, cost_only ? 3 : 1, it == 0, fuse_misc)) return rc;
             if (it == 0) { h->stats.jtj_launches++; h->stats.jtj_flops += h->mfma_per_lin * 2048; h->stats.jtj_alg_flops += h->jtj_alg_flops; }
         }
@@ -906,6 +906,7 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
     if (getenv("GF_BA_SPLIT_JTJ") && atoi(getenv("GF_BA_SPLIT_JTJ"))) if (int rc = gf_ba_set_split_jtj(h, 1)) { h->release(); delete h; return rc; }
     h->step_waves = (getenv("GF_BA_STEP_WAVES") && atoi(getenv("GF_BA_STEP_WAVES")) == 4) ? 4 : 8;
     h->chain_mode = getenv("GF_BA_CHAIN") && atoi(getenv("GF_BA_CHAIN")) != 0 && !h->big_step && !gnss;
+    h->cost_only = !(getenv("GF_BA_COST_ONLY") && atoi(getenv("GF_BA_COST_ONLY")) == 0);
     if (h->chain_mode) {
         const int nd_max = Rmax - 9 * d.NP;
         if (ch_lds_doubles(nd_max) * sizeof(double) + 20 * 1024 > 160 * 1024) h->chain_mode = false;   // (cannot happen where the dense form fits LDS; kept as the guard it is)

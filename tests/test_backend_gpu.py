@@ -591,3 +591,49 @@ def test_chain_form_of_the_step_matches_the_dense_form_and_the_oracle(gf, oracle
         Ad, bd, _ = _prior_invariants(pd_); Ac, bc, _ = _prior_invariants(pc_)
         _assert_prior_close(Ad, bd, Ac, bc)
     est_d.close(); est_c.close()
+
+
+def test_chain_form_in_a_mixed_batch(gf, oracle, monkeypatch):
+    """A batch may hold windows the chain form takes (standard column layout) next to windows it leaves to the dense form (here: a stationary window, every pose and
+    speed-bias block constant: estimator.cpp:3233-3246): both kernels are launched, each takes its own windows, and every window comes out as it does alone."""
+    monkeypatch.setenv("GF_BA_CHAIN", "1")
+    a, c = SW.make_window(31, oracle), SW.make_window(33, oracle, use_wheel=False)   # (no free camera extrinsic in the batch: one such window switches the whole batch's visual sweep to its extrinsic-column variant, another order of the same sums)
+    b = SW.make_window(32, oracle)
+    b["fix_poses"] = 1
+    est = gf.Estimator(batch=4)
+    solo = []
+    for w_ in (a, b, c):
+        x = w_.copy()
+        solo.append((x, est.solve([x], 8)[0]))
+    mixed = [a.copy(), b.copy(), c.copy(), a.copy()]
+    sums = est.solve(mixed, 8)
+    for k, (x, s_) in enumerate(solo):
+        assert sums[k] == s_, (k, sums[k], s_)
+        assert all(np.array_equal(mixed[k][key], x[key]) for key in gw.STATE_KEYS if key in x), k
+    assert sums[3] == solo[0][1] and all(np.array_equal(mixed[3][key], solo[0][0][key]) for key in gw.STATE_KEYS if key in a)
+    # and the stationary window is the dense form's result: the same bits as a handle without the switch
+    monkeypatch.delenv("GF_BA_CHAIN")
+    est_d = gf.Estimator(batch=1)
+    y = b.copy()
+    assert est_d.solve([y], 8)[0] == solo[1][1] and all(np.array_equal(y[key], solo[1][0][key]) for key in gw.STATE_KEYS if key in y)
+    est.close(); est_d.close()
+
+
+def test_cost_only_last_linearisation_changes_nothing_but_the_last_bits_of_the_cost(gf, oracle, monkeypatch):
+    """Round 6: the candidate of a solve's last iteration is linearised cost-only (the closing step only accepts or rejects it).  Against GF_BA_COST_ONLY=0 -- every candidate
+    in full -- the states are the same to the bit (no state depends on that linearisation), counts and termination are the same, and the costs agree to rounding (the residuals
+    come out of a different instantiation of the same arithmetic)."""
+    for seed, kw in ((1, {}), (3, {"fix_ex_pose": 0}), (5, {"use_wheel": False})):
+        w0 = SW.make_window(seed, oracle, **kw)
+        wa, wb = w0.copy(), w0.copy()
+        est_a = gf.Estimator(batch=1)
+        sa = est_a.solve([wa], 8)[0]
+        monkeypatch.setenv("GF_BA_COST_ONLY", "0")
+        est_b = gf.Estimator(batch=1)
+        sb = est_b.solve([wb], 8)[0]
+        monkeypatch.delenv("GF_BA_COST_ONLY")
+        for k_ in ("iterations", "successful_steps", "termination"):
+            assert sa[k_] == sb[k_], (seed, k_, sa, sb)
+        assert abs(sa["final_cost"] - sb["final_cost"]) <= 1e-13 * sb["final_cost"]
+        assert all(np.array_equal(wa[key], wb[key]) for key in gw.STATE_KEYS if key in wa), seed
+        est_a.close(); est_b.close()

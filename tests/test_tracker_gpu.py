@@ -286,3 +286,33 @@ def test_prefetched_host_frames_match_the_device_route(gf):
     with pytest.raises(gf.GfError, match="without a staged frame"):
         c.trackPrefetched([1.0] * B)
     a.close(); c.close()
+
+
+@pytest.mark.parametrize("points", [2, 4])
+def test_lk_with_several_points_per_wavefront_is_bit_identical(gf, oracle, monkeypatch, points):
+    """Round 6: lk_track_mp_kernel<P> (GF_LK_POINTS = 2 | 4, read when a tracker is created): every lane keeps its seven template pixels of P points, the wave-uniform work and
+    the exact sums are shared between them.  Same arithmetic per point: the building block (hard cases: border, outside, flat areas; plain and predicted-start passes; a point
+    count that is no multiple of P) and a tracked sequence must come out bit for bit as the oracle's -- which is what the one-point kernel is held to."""
+    monkeypatch.setenv("GF_LK_POINTS", str(points))
+    tex = synth.make_texture(21)
+    f0 = synth.warp_frame(tex, 0, 0)
+    f1 = synth.warp_frame(tex, -3.7, 2.2, 0.004, 1.003)
+    pts = oracle.good_features(f0, 301, min_dist=15.0)
+    rng = np.random.default_rng(4)
+    extra = np.array([[0.2, 0.3], [639.5, 479.2], [-30.0, 10.0], [700.0, 100.0], [320.25, 1.5], [5.5, 470.1]], np.float32)
+    pts = np.concatenate([pts, extra, rng.uniform(0, 1, (41, 2)).astype(np.float32) * [640, 480]]).astype(np.float32)
+    for max_level, use_init in ((3, False), (1, True)):
+        init = (pts + rng.normal(0, 1.5, pts.shape)).astype(np.float32) if use_init else None
+        r_pts, r_st, r_it = oracle.lk(f0, f1, pts, init, max_level=max_level)
+        g_pts, g_st, g_it = gf.lk_track(f0, f1, pts, init, max_level=max_level)
+        assert np.array_equal(r_st, g_st) and r_it == g_it
+        assert np.array_equal(r_pts[r_st > 0].view(np.uint32), g_pts[r_st > 0].view(np.uint32))
+    frames = _frames(1001, 6)
+    depth = np.full(frames[0].shape, 1500, np.uint16)
+    otr = oracle.Tracker(oracle.default_cfg(max_cnt=300, min_dist=20))
+    gtr = gf.FeatureTracker(gf.default_cfg(max_cnt=300, min_dist=20))
+    for k, f in enumerate(frames):
+        oi, oo = otr.track(0.0666 * k, f, depth)
+        gi, go = gtr.trackImage(0.0666 * k, f, depth)
+        assert np.array_equal(oi, gi) and np.array_equal(oo.view(np.uint64), go.view(np.uint64)), k
+    gtr.close()
