@@ -288,6 +288,7 @@ def test_config3_300_features_matches_oracle(gf, oracle):
 
 def test_lds_and_global_reduced_system_agree(gf, oracle, monkeypatch):
     """the global-memory variant of the step / marginalisation kernels on a window that also fits LDS"""
+    monkeypatch.delenv("GF_BA_CHAIN", raising=False)   # two placements of the DENSE form's system are compared here (a suite run under GF_BA_CHAIN=1 would put the chain form on one side)
     w = SW.make_window(4, oracle)
     a, b = w.copy(), w.copy()
     e1 = gf.Estimator(); e1.solve([a], 8); p1 = e1.marginalize([a], 0)[0]; e1.close()
