@@ -88,35 +88,42 @@ __device__ inline void block_jacobi_eig(double* A, double* V, int n, double* s_c
 }
 
 constexpr int MPMAX = 20;   // dropped pose + speed-bias (+ receiver clock blocks) columns
-// Inverse of a symmetric positive definite n x n block (n <= MPMAX) by Gauss-Jordan without pivoting, one wavefront.  T: n x 2n work
-// area.  Returns true and Ainv when every pivot is positive and 1 / |A^-1|_F > eps: then lambda_min(A) >= 1 / |A^-1|_2 > eps, no
-// eigenvalue falls under the reference's truncation threshold (marginalization_factor.cpp:279-283) and the pseudo-inverse it builds from
-// the eigen-decomposition is this inverse.  Otherwise the caller takes the eigen route.
-__device__ inline bool wave_spd_inverse(const double* A, double* T, double* Ainv, int n, double eps, int lane) {
-    constexpr int Q = (MPMAX * 2 * MPMAX + 63) / 64;
+// Inverse of a symmetric positive definite n x n block (n <= MPMAX) by Gauss-Jordan without pivoting.  T: n x 2n work area.  The elimination runs on the whole
+// block (two entries of [A | I] per thread, two block barriers per pivot: as a one-wavefront job with 13 entries per lane and a division by the run-time row length
+// per entry and pivot it was 35 k cycles of the kernel at n = 15), the symmetrisation and the norm on wavefront 0.  True and Ainv when every pivot is positive and
+// 1 / |A^-1|_F > eps: then lambda_min(A) >= 1 / |A^-1|_2 > eps, no eigenvalue falls under the reference's truncation threshold
+// (marginalization_factor.cpp:279-283) and the pseudo-inverse it builds from the eigen-decomposition is this inverse.  Otherwise the caller takes the eigen route.
+__device__ inline bool block_spd_eliminate(const double* A, double* T, int n, int tid) {   // every thread of the 512; ends behind a block barrier
+    constexpr int Q = (MPMAX * 2 * MPMAX + 511) / 512;
     const int n2 = 2 * n, tot = n * n2;
-    for (int i = lane; i < tot; i += 64) { const int r = i / n2, c = i - r * n2; T[i] = c < n ? A[r * n + c] : (c - n == r ? 1.0 : 0.0); }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-    bool ok = true;
-    for (int k = 0; k < n && ok; k++) {
-        const double piv = T[k * n2 + k];
-        if (!(piv > 0.0)) { ok = false; break; }
+    int rr[Q], cc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) { const int i = tid + 512 * q; rr[q] = i / max(n2, 1); cc[q] = i - rr[q] * n2; }
+#pragma unroll
+    for (int q = 0; q < Q; q++) { const int i = tid + 512 * q; if (i < tot) T[i] = cc[q] < n ? A[rr[q] * n + cc[q]] : (cc[q] - n == rr[q] ? 1.0 : 0.0); }
+    __syncthreads();
+    for (int k = 0; k < n; k++) {
+        const double piv = T[k * n2 + k];   // the same word for every thread: all of them leave together
+        if (!(piv > 0.0)) return false;
         const double dinv = 1.0 / piv;
         double fr[Q], pv[Q], cur[Q];
 #pragma unroll
         for (int q = 0; q < Q; q++) {
-            const int i = lane + 64 * q;
-            if (i < tot) { const int r = i / n2, c = i - r * n2; fr[q] = T[r * n2 + k]; pv[q] = T[k * n2 + c]; cur[q] = T[i]; }
+            const int i = tid + 512 * q;
+            if (i < tot) { fr[q] = T[rr[q] * n2 + k]; pv[q] = T[k * n2 + cc[q]]; cur[q] = T[i]; }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        __syncthreads();
 #pragma unroll
         for (int q = 0; q < Q; q++) {
-            const int i = lane + 64 * q;
-            if (i < tot) { const int r = i / n2; T[i] = r == k ? cur[q] * dinv : cur[q] - fr[q] * dinv * pv[q]; }
+            const int i = tid + 512 * q;
+            if (i < tot) T[i] = rr[q] == k ? cur[q] * dinv : cur[q] - fr[q] * dinv * pv[q];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        __syncthreads();
     }
-    if (!ok) return false;
+    return true;
+}
+__device__ inline bool wave_spd_finish(const double* T, double* Ainv, int n, double eps, int lane) {   // one wavefront
+    const int n2 = 2 * n;
     double f2 = 0.0;
     for (int i = lane; i < n * n; i += 64) { const int r = i / n, c = i - r * n; const double v = 0.5 * (T[r * n2 + n + c] + T[c * n2 + n + r]); Ainv[i] = v; f2 += v * v; }
     f2 = wave_sum_f64(f2);
@@ -234,9 +241,13 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     for (int i = tid; i < mp * mp; i += 512) { const int r = i / mp, c = i % mp; sP[i] = M[(size_t)max(r, c) * RP + min(r, c)]; }
     __syncthreads();
     // well-conditioned block (the usual case): plain inverse; else eigen-decomposition with the truncation of the reference
-    if (wave == 0) {
-        const bool fast = wave_spd_inverse(sP, GS ? sb.Mg + (size_t)blockIdx.x * sb.MgStride : smem, sPinv, mp, eps, lane);
-        if (lane == 0) s_fastinv = fast ? 1 : 0;
+    {
+        double* Tw = GS ? sb.Mg + (size_t)blockIdx.x * sb.MgStride : smem;
+        const bool elim = block_spd_eliminate(sP, Tw, mp, tid);
+        if (wave == 0) {
+            const bool fast = elim && wave_spd_finish(Tw, sPinv, mp, eps, lane);
+            if (lane == 0) s_fastinv = fast ? 1 : 0;
+        }
     }
     __syncthreads();
     if (!s_fastinv) {
@@ -258,21 +269,31 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     double* V = A + n * n;       // n x n
     double* br = sb.rhs + (size_t)b * RP;
     double* T = V;   // T = Pinv * M_pk (mp x n), staged in the not-yet-used V area
+    // M_kp (n x mp) goes through LDS once (rows of M are contiguous in a; the product below would read them n times each from global memory), and M_kk is copied
+    // row by row with its mirror image written next to it -- the lower triangle is what M holds, reading the upper one as M[c][r] made half of the loads strided by
+    // a row (57 k cycles for this stage at n = 86, mp = 15; profiles/README.md round 6).  Sums and their order are unchanged.
+    double* Mkp = V + (size_t)mp * n;   // n x mp
+    for (int i = tid; i < n * mp; i += 512) { const int r = i / mp, a = i - r * mp; Mkp[i] = M[(size_t)(mp + r) * RP + a]; }
+    for (int i = tid; i < n * n; i += 512) {
+        const int r = i / n, c = i - r * n;
+        if (c <= r) { const double v = M[(size_t)(mp + r) * RP + mp + c]; A[i] = v; A[c * n + r] = v; }
+    }
+    __syncthreads();
     for (int i = tid; i < mp * n; i += 512) {
         const int a = i / n, c = i % n;
         double t = 0;
-        for (int k = 0; k < mp; k++) t += sPinv[a * mp + k] * M[(size_t)(mp + c) * RP + k];
+        for (int k = 0; k < mp; k++) t += sPinv[a * mp + k] * Mkp[c * mp + k];
         T[i] = t;
     }
     __syncthreads();
     for (int i = tid; i < n * n; i += 512) {
         const int r = i / n, c = i % n;
-        double v = M[(size_t)(mp + max(r, c)) * RP + mp + min(r, c)];
-        const double* mr = M + (size_t)(mp + r) * RP;
+        double v = A[i];
+        const double* mr = Mkp + r * mp;
         for (int a = 0; a < mp; a++) v -= mr[a] * T[a * n + c];
         A[i] = v;
     }
-    for (int r = tid; r < n; r += 512) { double v = bv[mp + r]; for (int a = 0; a < mp; a++) v -= M[(size_t)(mp + r) * RP + a] * sbp[a]; br[r] = v; }
+    for (int r = tid; r < n; r += 512) { double v = bv[mp + r]; for (int a = 0; a < mp; a++) v -= Mkp[r * mp + a] * sbp[a]; br[r] = v; }
     __syncthreads();
     for (int i = tid; i < n * n; i += 512) { const int r = i / n, c = i % n; if (c > r) { const double v = 0.5 * (A[i] + A[c * n + r]); A[i] = v; A[c * n + r] = v; } }
     __syncthreads();
@@ -299,77 +320,124 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     int rank = n;
     const int tx = tid & 31, ty = tid >> 5;   // 32 x 16 thread grid of the trailing update
     constexpr int kPB = 8;                    // pivots per block
-    int kb = 0;                               // first pivot of the open block
-    for (int k = 0; k < n; k++) {
-        // pivot: largest remaining diagonal entry, the lowest lane that holds it on ties (every wavefront computes the same answer)
-        double best = -1.0; int bi = k;
-        const double* dgo = s_dg[k & 1];
-        double* dgn = s_dg[(k + 1) & 1];
-        for (int i = k + lane; i < n; i += 64) { const double v = dgo[i]; if (v > best) { best = v; bi = i; } }
-        double m = best;
+    // Who walks the pivots of a block.  LDS variant (n <= 92): wavefront 0 alone -- search, swap and the left-looking column of a pivot are n-sized jobs, two
+    // entries per lane, and with one wavefront the steps of a block are ordered by wavefront barriers (LDS accesses of one wavefront execute in order) instead
+    // of two block barriers per pivot; the other seven wavefronts sleep at the block barrier until the block's update of the trailing matrix, which is theirs too
+    // (2.9 k -> 1.2 k cycles per pivot at n = 86, profiles/README.md round 6).  Global-memory variant: all 512 threads with block barriers as before -- a store
+    // and a later load of ANOTHER lane through the vector L1 are not ordered by a wavefront barrier.  The arithmetic is the same entry by entry in both.
+    const int t0 = GS ? tid : lane;
+    constexpr int tstr = GS ? 512 : 64;
+    __shared__ int s_rank;
+#ifdef GF_PROFILE_STEP
+    long long pq[5] = {0, 0, 0, 0, 0}, pt = clock64();   // cycles of block 0 / thread 0 in: pivot search, swap, column, hand-over barrier, trailing update
+#define GF_PQ(i) do { const long long t_ = clock64(); pq[i] += t_ - pt; pt = t_; } while (0)
+#else
+#define GF_PQ(i) do { } while (0)
+#endif
+#define GF_PIV_SYNC() do { if constexpr (GS) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); } } while (0)
+    for (int kb = 0; kb < n; kb += kPB) {     // kb: first pivot of the open block
+        const int k1 = min(kb + kPB, n);
+        if (GS || wave == 0)
+        for (int k = kb; k < k1; k++) {
+            // pivot: largest remaining diagonal entry, the lowest lane that holds it on ties (every wavefront computes the same answer)
+            double best = -1.0; int bi = k;
+            const double* dgo = s_dg[k & 1];
+            double* dgn = s_dg[(k + 1) & 1];
+            for (int i = k + lane; i < n; i += 64) { const double v = dgo[i]; if (v > best) { best = v; bi = i; } }
+            double m = best;
 #define GF_DPP_MAX(ctrl) do { const int lo_ = __builtin_amdgcn_mov_dpp(__double2loint(m), ctrl, 0xf, 0xf, true), hi_ = __builtin_amdgcn_mov_dpp(__double2hiint(m), ctrl, 0xf, 0xf, true); \
                               m = fmax(m, __hiloint2double(hi_, lo_)); } while (0)
-        GF_DPP_MAX(0xB1); GF_DPP_MAX(0x4E); GF_DPP_MAX(0x141); GF_DPP_MAX(0x140);   // quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+            GF_DPP_MAX(0xB1); GF_DPP_MAX(0x4E); GF_DPP_MAX(0x141); GF_DPP_MAX(0x140);   // quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
 #undef GF_DPP_MAX
-        double piv = -1.0;
+            double piv = -1.0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) piv = fmax(piv, __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m), 16 * q), __builtin_amdgcn_readlane(__double2loint(m), 16 * q)));
-        const unsigned long long hit = __ballot(best == piv);
-        const int p = __builtin_amdgcn_readlane(bi, __ffsll((long long)hit) - 1);
-        if (!(piv > piv_eps)) { rank = k; break; }
-        if (p != k) {   // symmetric swap k <-> p of the full matrix in one pass: thread t moves the four entries that involve t; the 2 x 2 corner by thread 0
-            // (every load of a thread before its first store: the compiler cannot tell the LDS arrays apart and would wait for each store before the next load)
-            for (int t = tid; t < n; t += 512) {
-                if (t == k || t == p) continue;
-                const double a0 = A[k * n + t], a1 = A[p * n + t], b0 = A[t * n + k], b1 = A[t * n + p];
-                A[k * n + t] = a1; A[p * n + t] = a0; A[t * n + k] = b1; A[t * n + p] = b0;
+            for (int q = 0; q < 4; q++) piv = fmax(piv, __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m), 16 * q), __builtin_amdgcn_readlane(__double2loint(m), 16 * q)));
+            const unsigned long long hit = __ballot(best == piv);
+            const int p = __builtin_amdgcn_readlane(bi, __ffsll((long long)hit) - 1);
+            if (!(piv > piv_eps)) { rank = k; break; }
+            GF_PQ(0);
+            if (p != k) {   // symmetric swap k <-> p of the full matrix in one pass: thread t moves the four entries that involve t; the 2 x 2 corner by one thread
+                // (every load of a thread before its first store: the compiler cannot tell the LDS arrays apart and would wait for each store before the next load)
+                if constexpr (GS) {
+                    for (int t = tid; t < n; t += 512) {
+                        if (t == k || t == p) continue;
+                        const double a0 = A[k * n + t], a1 = A[p * n + t], b0 = A[t * n + k], b1 = A[t * n + p];
+                        A[k * n + t] = a1; A[p * n + t] = a0; A[t * n + k] = b1; A[t * n + p] = b0;
+                    }
+                    if (tid == 64) { const double dk = A[k * n + k], dp = A[p * n + p]; A[k * n + k] = dp; A[p * n + p] = dk; }   // A[k][p] == A[p][k] stay where they are
+                    if (tid == 128) { const int tk = perm[k], tp = perm[p]; perm[k] = tp; perm[p] = tk; }
+                    if (tid == 192) { const double zk = zb[k], zp = zb[p]; zb[k] = zp; zb[p] = zk; }
+                } else {   // n <= 128: two entries per lane, the corner, perm and zb read by every lane (broadcast) and written by lane 0
+                    double a0[2], a1[2], b0[2], b1[2];
+                    bool on[2];
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const int t = lane + 64 * q;
+                        on[q] = t < n && t != k && t != p;
+                        const int tt = on[q] ? t : k;
+                        a0[q] = A[k * n + tt]; a1[q] = A[p * n + tt]; b0[q] = A[tt * n + k]; b1[q] = A[tt * n + p];
+                    }
+                    const double dk = A[k * n + k], dp = A[p * n + p], zk = zb[k], zp = zb[p];
+                    const int tk = perm[k], tp = perm[p];
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const int t = lane + 64 * q;
+                        if (on[q]) { A[k * n + t] = a1[q]; A[p * n + t] = a0[q]; A[t * n + k] = b1[q]; A[t * n + p] = b0[q]; }
+                    }
+                    if (lane == 0) { A[k * n + k] = dp; A[p * n + p] = dk; perm[k] = tp; perm[p] = tk; zb[k] = zp; zb[p] = zk; }
+                }
+                GF_PIV_SYNC();
             }
-            if (tid == 64) { const double dk = A[k * n + k], dp = A[p * n + p]; A[k * n + k] = dp; A[p * n + p] = dk; }   // A[k][p] == A[p][k] stay where they are
-            if (tid == 128) { const int tk = perm[k], tp = perm[p]; perm[k] = tp; perm[p] = tk; }
-            if (tid == 192) { const double zk = zb[k], zp = zb[p]; zb[k] = zp; zb[p] = zk; }
-            __syncthreads();
-        }
+            GF_PQ(1);
 #ifdef GF_MARG_IEEE_SQRT   // conditioning experiments (scripts/gnss_replay_sensitivity.py): the arithmetically equivalent, correctly rounded variant
-        double dinv = 1.0 / sqrt(piv);
+            double dinv = 1.0 / sqrt(piv);
 #else
-        // 1 / sqrt(piv): hardware seed, one plain Newton step, one with the residual 1 - piv y^2 formed exactly (product split by an fma), which leaves
-        // the final rounding as the only error (an IEEE sqrt and a division cost ~500 cycles per pivot).  Accuracy matters here: a relative error d of 1 / L_kk
-        // puts 2 d |l_i l_j| ~ 1e-7 (entries of 1e9) into the trailing block, which is the size of the weak GNSS directions the prior has to carry
-        double dinv = __builtin_amdgcn_rsq(piv);
-        dinv = dinv * (1.5 - 0.5 * piv * dinv * dinv);
-        {
-            const double h = piv * dinv, hl = __builtin_fma(piv, dinv, -h);
-            const double e = __builtin_fma(-h, dinv, 1.0) - hl * dinv;
-            dinv = __builtin_fma(0.5 * dinv, e, dinv);
-        }
-#endif
-        // Left-looking inside blocks of kPB pivots: row k still lacks the updates of the pivots kb .. k - 1 of its block (rows kb .. k - 1 hold their finished,
-        // scaled columns of L), so one thread per entry applies them now, in pivot order -- the same fma chain, entry by entry, as a trailing update after every
-        // pivot -- and the trailing matrix is touched once per block instead of once per pivot (3.3 k -> 2.9 k cycles per pivot at n = 86: search 0.65 k, swap 0.65 k,
-        // this column 1.0 k, the block's update 3.1 k / 8; what is left are LDS round trips and two barriers per pivot).
-        const double rk = zb[k] * dinv;
-        double* rowk = A + (size_t)k * n;        // = column k (symmetric); becomes column k of L, scaled
-        for (int i = k + 1 + tid; i < n; i += 512) {
-            double acc = rowk[i];
-            double lc[kPB - 1], lk[kPB - 1];
-#pragma unroll
-            for (int q = 0; q < kPB - 1; q++) {   // all loads in flight at once (rows past the open block: row k - 1 again, weighted with zero: fma(-x, 0, acc) == acc)
-                const int c = min(kb + q, k - 1 < kb ? kb : k - 1);
-                lc[q] = A[(size_t)c * n + i];
-                const double v = A[(size_t)c * n + k];
-                lk[q] = kb + q < k ? v : 0.0;
+            // 1 / sqrt(piv): hardware seed, one plain Newton step, one with the residual 1 - piv y^2 formed exactly (product split by an fma), which leaves
+            // the final rounding as the only error (an IEEE sqrt and a division cost ~500 cycles per pivot).  Accuracy matters here: a relative error d of 1 / L_kk
+            // puts 2 d |l_i l_j| ~ 1e-7 (entries of 1e9) into the trailing block, which is the size of the weak GNSS directions the prior has to carry
+            double dinv = __builtin_amdgcn_rsq(piv);
+            dinv = dinv * (1.5 - 0.5 * piv * dinv * dinv);
+            {
+                const double h = piv * dinv, hl = __builtin_fma(piv, dinv, -h);
+                const double e = __builtin_fma(-h, dinv, 1.0) - hl * dinv;
+                dinv = __builtin_fma(0.5 * dinv, e, dinv);
             }
+#endif
+            // Left-looking inside blocks of kPB pivots: row k still lacks the updates of the pivots kb .. k - 1 of its block (rows kb .. k - 1 hold their finished,
+            // scaled columns of L), so one thread per entry applies them now, in pivot order -- the same fma chain, entry by entry, as a trailing update after every
+            // pivot -- and the trailing matrix is touched once per block instead of once per pivot.
+            const double rk = zb[k] * dinv;
+            double* rowk = A + (size_t)k * n;        // = column k (symmetric); becomes column k of L, scaled
+            for (int i = k + 1 + t0; i < n; i += tstr) {
+                double acc = rowk[i];
+                double lc[kPB - 1], lk[kPB - 1];
 #pragma unroll
-            for (int q = 0; q < kPB - 1; q++) acc = __builtin_fma(-lc[q], lk[q], acc);
-            const double li = acc * dinv;
-            rowk[i] = li;
-            dgn[i] = __builtin_fma(-li, li, dgo[i == p ? k : i]);   // the diagonal copy is not swapped (slower wavefronts may still search it): position p holds old row k
-            zb[i] = __builtin_fma(-li, rk, zb[i]);
+                for (int q = 0; q < kPB - 1; q++) {   // all loads in flight at once (rows past the open block: row k - 1 again, weighted with zero: fma(-x, 0, acc) == acc)
+                    const int c = min(kb + q, k - 1 < kb ? kb : k - 1);
+                    lc[q] = A[(size_t)c * n + i];
+                    const double v = A[(size_t)c * n + k];
+                    lk[q] = kb + q < k ? v : 0.0;
+                }
+                const double dold = dgo[i == p ? k : i], zold = zb[i];   // the diagonal copy is not swapped (slower wavefronts may still search it): position p holds old row k
+#pragma unroll
+                for (int q = 0; q < kPB - 1; q++) acc = __builtin_fma(-lc[q], lk[q], acc);
+                const double li = acc * dinv;
+                rowk[i] = li;
+                dgn[i] = __builtin_fma(-li, li, dold);
+                zb[i] = __builtin_fma(-li, rk, zold);
+            }
+            if (t0 == 0) { dinvs[k] = dinv; zr[k] = rk; }
+            GF_PIV_SYNC();
+            GF_PQ(2);
         }
-        if (tid == 0) { dinvs[k] = dinv; zr[k] = rk; }
-        __syncthreads();
-        if (k + 1 - kb == kPB || k + 1 == n) {   // close the block: A[i][j] -= sum_c L[i][c] L[j][c], c in pivot order, 2 x 4 entries per thread
-            const int k1 = k + 1;
+        if constexpr (!GS) {   // the other wavefronts learn from wavefront 0 whether the block went through
+            if (tid == 0) s_rank = rank;
+            __syncthreads();
+            rank = s_rank;
+        }
+        GF_PQ(3);
+        if (rank != n) break;
+        {   // close the block: A[i][j] -= sum_c L[i][c] L[j][c], c in pivot order, 2 x 4 entries per thread
             // thread (tx, ty) owns rows i0 + 16 a and columns j0 + 32 q: the lanes of a wavefront read consecutive doubles (4 consecutive columns per lane cost 4-way bank conflicts)
             // One path for every tile: rows / columns past the matrix are clamped for the loads and skipped by the stores, columns of L past a short last block
             // weigh zero (fma(-x, 0, v) == v) -- a branch around the edge tiles would put every wavefront through both versions.
@@ -405,10 +473,15 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
 #pragma unroll
                         for (int q = 0; q < 2; q++) if (i0 + 16 * a < n && j0 + 32 * q < n) A[(size_t)ia[a] * n + jq[q]] = v[a][q];
                 }
-            kb = k1;
             __syncthreads();
+            GF_PQ(4);
         }
     }
+#ifdef GF_PROFILE_STEP
+    if (blockIdx.x == 0 && threadIdx.x == 0 && sb.stamps) for (int q = 0; q < 5; q++) sb.stamps[100 + q] = pq[q];
+#endif
+#undef GF_PQ
+#undef GF_PIV_SYNC
     GF_MST(5);
     // ---- the right-hand side of the prior in the directions the factor does not span.  Forward substitution gives r = L1^-1 (P^T b)_1: J^T r then reproduces b in the
     // `rank` pivot rows and PREDICTS it in the other m2 = n - rank rows (L2 L1^-1 b_1).  The reference's r = S^-1/2 V^T b (marginalization_factor.cpp:294-302) makes
@@ -427,23 +500,54 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
             __shared__ double s_ls[GS ? kLsRows * TS + kM2 * (kM2 + 1) + kLsRows : 1];
             double* Tm = GS ? s_ls : V + 2048;     // rank x TS
             double* G = Tm + (size_t)(GS ? kLsRows : n) * TS;       // m2 x (m2 + 1): [I + T^T T | e], then w in its last column
-            double* vv = G + kM2 * (kM2 + 1);      // rank: T w, forward-substituted in place
-            for (int i = tid; i < rank * kM2; i += 512) { const int k = i >> 5, j = i & 31; Tm[k * TS + j] = j < m2 ? A[(size_t)k * n + rank + j] : 0.0; }
-            __syncthreads();
-            // The two substitutions are chains of `rank` dependent steps: one wavefront walks them with wavefront barriers (a block barrier per step made them 40 of the
-            // kernel's 245 us).  Lane = (column j of T, row slice): every entry of T has one owner, a step reads row k before its owner lane rescales it.
+            // The two substitutions are chains of `rank` dependent steps.  Each runs out of registers: a lane owns the rows lane + 64 q of its vector, a step takes the
+            // pivot entry with a readlane (the step index is uniform) and the entries of L1 it multiplies are read-only here, so the loads of step k - 1 are issued
+            // before the arithmetic of step k -- ~60 cycles per step where the LDS-resident version (Tm / vv read, updated and written back per step, four LDS round
+            // trips, ~500 cycles) made the chains 79 k of the kernel's cycles.  The m2 columns of T are independent: one wavefront each.  Same fma chain per entry.
+            constexpr int QR = GS ? 4 : 2;   // rows per lane: n <= 256 / n <= 128
+            auto rl = [](double v, int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l)); };
             GF_MST(8);
-            if (wave == 0) {
-                int m2p = 1;
-                while (m2p < m2) m2p <<= 1;
-                const int rs = 64 / m2p, j = lane & (m2p - 1), sl = lane / m2p;
-                for (int k = rank - 1; k >= 0; k--) {   // column-oriented backward substitution with L1^T: row k is final when step k starts
-                    const double tk = j < m2 ? Tm[k * TS + j] * dinvs[k] : 0.0;
-                    if (j < m2) for (int i = sl; i < k; i += rs) Tm[i * TS + j] = __builtin_fma(-A[(size_t)i * n + k], tk, Tm[i * TS + j]);   // L1[k][i] = A[i][k] (row i right of its diagonal)
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                    if (sl == 0 && j < m2) Tm[k * TS + j] = tk;
+            {
+                double dv[QR];
+#pragma unroll
+                for (int q = 0; q < QR; q++) { const int i = lane + 64 * q; dv[q] = i < rank ? dinvs[i] : 0.0; }
+                for (int j = wave; j < m2; j += 8) {   // column-oriented backward substitution with L1^T: row k is final when step k starts
+                    double t[QR], a[4][QR], nx[4][QR];
+                    // L1[k][i] = A[i][k] (row i right of its diagonal); rows / columns past the ends are clamped for the load and not used
+                    auto col = [&](double (&a)[QR], int kc) {
+#pragma unroll
+                        for (int q = 0; q < QR; q++) a[q] = A[(size_t)min(lane + 64 * q, rank - 1) * n + max(kc, 0)];
+                    };
+                    auto step = [&](int k, const double (&ac)[QR]) {
+                        const int kq = k >> 6, kl = k & 63;
+                        double ts = t[0], ds = dv[0];
+#pragma unroll
+                        for (int q = 1; q < QR; q++) if (kq == q) { ts = t[q]; ds = dv[q]; }
+                        const double tk = rl(ts, kl) * rl(ds, kl);
+#pragma unroll
+                        for (int q = 0; q < QR; q++) { const int i = lane + 64 * q; if (i < k) t[q] = __builtin_fma(-ac[q], tk, t[q]); else if (i == k) t[q] = tk; }
+                    };
+#pragma unroll
+                    for (int q = 0; q < QR; q++) { const int i = lane + 64 * q; t[q] = i < rank ? A[(size_t)i * n + rank + j] : 0.0; }
+                    // four steps per trip: the loads of the next four columns are issued before the four dependent steps of this trip and land while they run
+#pragma unroll
+                    for (int u = 0; u < 4; u++) col(a[u], rank - 1 - u);
+                    int k = rank - 1;
+                    for (; k >= 3; k -= 4) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) col(nx[u], k - 4 - u);
+#pragma unroll
+                        for (int u = 0; u < 4; u++) step(k - u, a[u]);
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+#pragma unroll
+                            for (int q = 0; q < QR; q++) a[u][q] = nx[u][q];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 3; u++) if (k - u >= 0) step(k - u, a[u]);
+#pragma unroll
+                    for (int q = 0; q < QR; q++) { const int i = lane + 64 * q; if (i < rank) Tm[i * TS + j] = t[q]; }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
             }
             __syncthreads();
             GF_MST(9);
@@ -473,15 +577,46 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
             }
             __syncthreads();
             GF_MST(11);
-            for (int k = tid; k < rank; k += 512) { double s = 0.0; for (int j = 0; j < m2; j++) s = __builtin_fma(Tm[k * TS + j], G[j * (kM2 + 1) + m2], s); vv[k] = s; }
-            __syncthreads();
-            if (wave == 0)
-                for (int k = 0; k < rank; k++) {   // forward substitution with L1: column k of L1 below its diagonal = row k of A right of it
-                    const double sk = vv[k] * dinvs[k];
-                    for (int i = k + 1 + lane; i < rank; i += 64) vv[i] = __builtin_fma(-A[(size_t)k * n + i], sk, vv[i]);
-                    if (lane == 0) zr[k] += sk;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+            if (wave == 0) {   // vv = T w, then the forward substitution with L1 (column k of L1 below its diagonal = row k of A right of it); zr += L1^-1 T w
+                double v[QR], dv[QR], a[4][QR], nx[4][QR], zadd[QR] = {};
+#pragma unroll
+                for (int q = 0; q < QR; q++) {
+                    const int i = lane + 64 * q;
+                    double s = 0.0;
+                    if (i < rank) for (int j = 0; j < m2; j++) s = __builtin_fma(Tm[i * TS + j], G[j * (kM2 + 1) + m2], s);
+                    v[q] = s; dv[q] = i < rank ? dinvs[i] : 0.0;
                 }
+                auto row = [&](double (&a)[QR], int kr) {
+#pragma unroll
+                    for (int q = 0; q < QR; q++) a[q] = A[(size_t)min(kr, rank - 1) * n + min(lane + 64 * q, n - 1)];
+                };
+                auto step = [&](int k, const double (&ac)[QR]) {
+                    const int kq = k >> 6, kl = k & 63;
+                    double vs = v[0], ds = dv[0];
+#pragma unroll
+                    for (int q = 1; q < QR; q++) if (kq == q) { vs = v[q]; ds = dv[q]; }
+                    const double sk = rl(vs, kl) * rl(ds, kl);
+#pragma unroll
+                    for (int q = 0; q < QR; q++) { const int i = lane + 64 * q; if (i > k && i < rank) v[q] = __builtin_fma(-ac[q], sk, v[q]); else if (i == k) zadd[q] = sk; }
+                };
+#pragma unroll
+                for (int u = 0; u < 4; u++) row(a[u], u);
+                int k = 0;
+                for (; k + 3 < rank; k += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) row(nx[u], k + 4 + u);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) step(k + u, a[u]);
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+#pragma unroll
+                        for (int q = 0; q < QR; q++) a[u][q] = nx[u][q];
+                }
+#pragma unroll
+                for (int u = 0; u < 3; u++) if (k + u < rank) step(k + u, a[u]);
+#pragma unroll
+                for (int q = 0; q < QR; q++) { const int i = lane + 64 * q; if (i < rank) zr[i] += zadd[q]; }
+            }
             __syncthreads();
         }
     }
