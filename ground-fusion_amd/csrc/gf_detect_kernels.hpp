@@ -155,6 +155,17 @@ __global__ void __launch_bounds__(64) detect_strip_kernel(DetectArgs A, DiskTabl
         if (col_out) allow = ~covered & rows_all;
     }
     if (!__ballot(allow != 0)) return;   // nothing of this strip may hold a corner: no contribution to the masked maximum, no candidate
+    // Which rows the strip has to work on at all.  With the window's tracks alive the circles cover most of the image (150 points at MIN_DIST 30: ~90 %), and an output
+    // row none of whose pixels is allowed needs neither its own eigenvalues nor -- unless a neighbouring row does -- the product and raw rows under them.  Bit s of
+    // the four masks = raw-row index s (image row Y0 - 3 + s): outputs wanted, eigenvalue rows (outputs +- 1: the 3 x 3 test), product rows (+- 1: box filter), raw
+    // rows (+- 1: Sobel).  All four are wavefront-uniform, the stages below branch on them; a skipped stage leaves stale registers nobody reads.
+    unsigned long long need_out = allow;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) need_out |= (unsigned)__shfl_xor((int)(unsigned)need_out, o);
+    need_out = (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)need_out) << 3;
+    const unsigned long long need_eig = need_out | (need_out << 1) | (need_out >> 1);
+    const unsigned long long need_prod = need_eig | (need_eig << 1) | (need_eig >> 1);
+    const unsigned long long need_raw = need_prod | (need_prod << 1) | (need_prod >> 1);
 
     const uint8_t* img = A.pyr + b * A.pyr_seq_stride + g.img_off;
     const float f1 = (float)(1.0 * (1.0 / (4.0 * 3.0 * 255.0))), f0 = (float)(2.0 * (1.0 / (4.0 * 3.0 * 255.0)));
@@ -165,7 +176,8 @@ __global__ void __launch_bounds__(64) detect_strip_kernel(DetectArgs A, DiskTabl
 #pragma unroll
         for (int s = 0; s < NS; s++) {
             const int y = min(Y0 - 3 + s, g.h + 1);
-            raw[s] = *reinterpret_cast<const u32_unaligned*>(img + (ptrdiff_t)y * g.stride + xl);
+            raw[s] = 0;
+            if ((need_raw >> s) & 1ull) raw[s] = *reinterpret_cast<const u32_unaligned*>(img + (ptrdiff_t)y * g.stride + xl);
         }
     }
     // the box filter's own border (BORDER_REFLECT_101 on the product images): column -1 takes the products of column 1, column w those of column w - 2
@@ -184,14 +196,14 @@ __global__ void __launch_bounds__(64) detect_strip_kernel(DetectArgs A, DiskTabl
     int* const count_b = A.cand_count + b;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-        {   // raw row s
+        if ((need_raw >> s) & 1ull) {   // raw row s
             const uint32_t v = raw[s];
             const float p0 = (float)(v & 0xffu), p1 = (float)((v >> 8) & 0xffu), p2 = (float)((v >> 16) & 0xffu);
             hd[s % 3] = p2 - p0;
             float t = f1 * p0; t += f0 * p1; t += f1 * p2;
             hm[s % 3] = t;
         }
-        if (s >= 2) {   // products of row s - 1 and their horizontal sums
+        if (s >= 2 && ((need_prod >> (s - 1)) & 1ull)) {   // products of row s - 1 and their horizontal sums
             const float t0 = hd[(s + 1) % 3], t1 = hd[(s + 2) % 3], t2 = hd[s % 3];
             const float dx = (t0 + t2) * f1 + t1 * f0;
             const float dy = hm[s % 3] - hm[(s + 1) % 3];
@@ -201,7 +213,7 @@ __global__ void __launch_bounds__(64) detect_strip_kernel(DetectArgs A, DiskTabl
             hxy[(s + 2) % 3] = (double)dpp_from_left(pxy) + ((double)pxy + (double)dpp_from_right(pxy));
             hyy[(s + 2) % 3] = (double)dpp_from_left(pyy) + ((double)pyy + (double)dpp_from_right(pyy));
         }
-        if (s >= 4) {   // eigenvalues of row s - 2 from the product rows s - 3, s - 2, s - 1
+        if (s >= 4 && ((need_eig >> (s - 2)) & 1ull)) {   // eigenvalues of row s - 2 from the product rows s - 3, s - 2, s - 1
             int it = s % 3, ib = (s + 2) % 3;
             const int im = (s + 1) % 3;
             double txx = hxx[it], txy = hxy[it], tyy = hyy[it], bxx = hxx[ib], bxy = hxy[ib], byy = hyy[ib];
@@ -217,7 +229,7 @@ __global__ void __launch_bounds__(64) detect_strip_kernel(DetectArgs A, DiskTabl
             er[im] = e;
             em[im] = fmaxf(e, fmaxf(dpp_from_left(e), dpp_from_right(e)));
         }
-        if (s >= 6) {   // row s - 3 = Y0 + r: masked maximum and 3 x 3 local maxima
+        if (s >= 6 && ((need_out >> (s - 3)) & 1ull)) {   // row s - 3 = Y0 + r: masked maximum and 3 x 3 local maxima
             const int r = s - 6;
             if (r < nrows) {
                 const int y = Y0 + r;
