@@ -807,8 +807,8 @@ int run_marginalize(gf_ba* h, int mode) {
     static const double piv_eps = getenv("GF_MARG_PIVOT_EPS") ? atof(getenv("GF_MARG_PIVOT_EPS")) : 3e-8;
     static const int ls_rhs = getenv("GF_MARG_LS_RHS") ? atoi(getenv("GF_MARG_LS_RHS")) : 1;
     poison_lds(h);
-    if (h->big_marg) ba_marg_finish<true><<<dim3(d.B), 512, 0, h->stream>>>(wm, h->sbufs(), reinterpret_cast<const MargInfo*>(h->minfo[mode].d), mo, mode == 0 ? 1 : 0, piv_eps, ls_rhs);
-    else ba_marg_finish<false><<<dim3(d.B), 512, h->marg_lds, h->stream>>>(wm, h->sbufs(), reinterpret_cast<const MargInfo*>(h->minfo[mode].d), mo, mode == 0 ? 1 : 0, piv_eps, ls_rhs);
+    if (h->big_marg) ba_marg_finish<true><<<dim3(d.B), 512, 0, h->stream>>>(wm, h->sbufs(), reinterpret_cast<const MargInfo*>(h->minfo[mode].d), mo, mode == 0 ? 1 : 0, piv_eps, ls_rhs, 0);
+    else ba_marg_finish<false><<<dim3(d.B), 512, h->marg_lds, h->stream>>>(wm, h->sbufs(), reinterpret_cast<const MargInfo*>(h->minfo[mode].d), mo, mode == 0 ? 1 : 0, piv_eps, ls_rhs, (int)(h->marg_lds / sizeof(double)));
     HIPCHK(hipGetLastError());
     return GF_OK;
 }

@@ -137,7 +137,7 @@ struct MargOut { double* J; double* r; };  // [B][NPRI*NPRI], [B][NPRI]
 // equations and g[1-cur] of the right-hand side (ba_linearize_misc_win with the marginalisation's column map), Vc[1-cur] the visual part
 // in compact columns (use_vc: MARGIN_OLD), Et / ete / etb[1-cur] the compact rows of the eliminated feature columns.
 template <bool GS>   // GS: A and V of the kept system live in global memory (sb.Mg) -- priors larger than 96 columns
-__global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const MargInfo* info, MargOut out, int use_vc, double piv_eps, int ls_rhs) {
+__global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const MargInfo* info, MargOut out, int use_vc, double piv_eps, int ls_rhs, int lds_doubles) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double sP[MPMAX * MPMAX], sPV[MPMAX * MPMAX], sPinv[MPMAX * MPMAX], sbp[MPMAX];
     __shared__ double s_c[64], s_s[64];
@@ -146,6 +146,9 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     const Dims d = w.d;
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const MargInfo mi = info[b];
+#ifdef GF_PROFILE_STEP
+    const long long t_entry = clock64();
+#endif
     if (!uni(mi.valid)) return;
     const SolverState& st = w.st[b];
     const int o = 1 - uni(st.cur), RP = d.RP;
@@ -182,8 +185,12 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
     double* feb = sb.yv + (size_t)b * sb.VS;  // per-feature b_f/sqrt(d_f)  (two scratch vectors of VS = RP + FP entries each: F entries fit either, not both in one)
     for (int e = tid; e < NE; e += 512) { const double df = ete[e]; const double f = df > eps ? 1.0 / sqrt(df) : 0.0; fe[e] = f; feb[e] = f * etb[e]; }
     __syncthreads();
-    {   // Es = diag(fe) Et on the kept compact columns: one wavefront per row, eight rows in flight (every load issued before the first store)
-        const int NE4 = (NE + 3) & ~3;
+    // Es = diag(fe) Et on the kept compact columns (one wavefront per row, eight rows in flight: every load issued before the first store), then bv -= Es^T feb and
+    // M -= Es^T Es.  Es lives in the block's LDS when it fits (the kept system that will occupy it does not exist yet): its column sums and the operands of the
+    // rank update then come from LDS instead of L2 -- the two stages were serialised global-load latencies (46 k + 31 k cycles at 86 kept columns) -- else in global
+    // memory as before (sb.Es).  Same sums in the same order either way.
+    const int NE4 = (NE + 3) & ~3;
+    auto eliminate = [&](double* EsP) {
         constexpr int EN = GS ? 4 : 2;   // 64-column pieces of a compact row
         for (int e0 = wave; e0 < NE4; e0 += 64) {
             double ev[8][EN], fv[8];
@@ -199,32 +206,30 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
                 const int e = e0 + 8 * m;
                 if (e >= NE4) continue;
 #pragma unroll
-                for (int q = 0; q < EN; q++) { const int k = lane + 64 * q; if (k < ECW) Es[(size_t)e * ECW + k] = (e < NE && s_cmap[k] >= 0) ? ev[m][q] * fv[m] : 0.0; }
+                for (int q = 0; q < EN; q++) { const int k = lane + 64 * q; if (k < ECW) EsP[(size_t)e * ECW + k] = (e < NE && s_cmap[k] >= 0) ? ev[m][q] * fv[m] : 0.0; }
             }
         }
-    }
-    __syncthreads();
-    for (int k = tid; k < ECW; k += 512) {   // bv -= Es^T feb: the sum runs in row order as before, the loads of eight rows at a time are issued together
-        const int c = s_cmap[k];
-        if (c < 0) continue;
-        double v = bv[c];
-        for (int e0 = 0; e0 < NE; e0 += 8) {
-            double a[8], f[8];
+        __syncthreads();
+        for (int k = tid; k < ECW; k += 512) {   // bv -= Es^T feb: the sum runs in row order as before, the loads of eight rows at a time are issued together
+            const int c = s_cmap[k];
+            if (c < 0) continue;
+            double v = bv[c];
+            for (int e0 = 0; e0 < NE; e0 += 8) {
+                double a[8], f[8];
 #pragma unroll
-            for (int m = 0; m < 8; m++) { const int e = min(e0 + m, NE - 1); a[m] = Es[(size_t)e * ECW + k]; f[m] = feb[e]; }
+                for (int m = 0; m < 8; m++) { const int e = min(e0 + m, NE - 1); a[m] = EsP[(size_t)e * ECW + k]; f[m] = feb[e]; }
 #pragma unroll
-            for (int m = 0; m < 8; m++) if (e0 + m < NE) v -= a[m] * f[m];
+                for (int m = 0; m < 8; m++) if (e0 + m < NE) v -= a[m] * f[m];
+            }
+            bv[c] = v;
         }
-        bv[c] = v;
-    }
-    GF_MST(1);
-    {
+        GF_MST(1);
         const int nt = ECW / 16, ntiles = nt * (nt + 1) / 2, nk = (NE + 3) / 4;
         for (int t = wave; t < ntiles; t += 8) {
             const int ti = tri_row(t), tk = t - ti * (ti + 1) / 2;
             d4 acc = {0, 0, 0, 0};
-            const double* pa = Es + (size_t)(lane >> 4) * ECW + 16 * ti + (lane & 15);
-            const double* pb = Es + (size_t)(lane >> 4) * ECW + 16 * tk + (lane & 15);
+            const double* pa = EsP + (size_t)(lane >> 4) * ECW + 16 * ti + (lane & 15);
+            const double* pb = EsP + (size_t)(lane >> 4) * ECW + 16 * tk + (lane & 15);
             for (int k = 0; k < nk; k++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(size_t)4 * k * ECW], pb[(size_t)4 * k * ECW], acc, 0, 0, 0);
             const int col = s_cmap[16 * tk + (lane & 15)];
 #pragma unroll
@@ -234,7 +239,9 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
                 if (row >= 0 && col >= 0 && (ti != tk || (lane >> 4) + 4 * r >= (lane & 15))) M[(size_t)max(row, col) * RP + min(row, col)] -= acc[r];
             }
         }
-    }
+    };
+    if (!GS && NE4 * ECW <= lds_doubles) eliminate(smem);
+    else eliminate(Es);
     __syncthreads();
     GF_MST(2);
     // ---- pseudo-inverse of the dropped pose / speed-bias block (eigenvalues <= eps are dropped)
@@ -286,12 +293,33 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
         T[i] = t;
     }
     __syncthreads();
-    for (int i = tid; i < n * n; i += 512) {
-        const int r = i / n, c = i % n;
-        double v = A[i];
-        const double* mr = Mkp + r * mp;
-        for (int a = 0; a < mp; a++) v -= mr[a] * T[a * n + c];
-        A[i] = v;
+    {   // A -= M_kp T on 4 x 4 register tiles (eight LDS loads for sixteen products instead of two per product); a thread's rows / columns are nq apart, so
+        // that the lanes of a wavefront read consecutive doubles of a row of T and share their rows of M_kp.  Per entry the same subtractions in the same order.
+        const int nq = (n + 3) >> 2;
+        for (int t = tid; t < nq * nq; t += 512) {
+            const int tr = t / nq, tc = t - tr * nq;
+            int ri[4], ci[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { ri[q] = min(tr + q * nq, n - 1); ci[q] = min(tc + q * nq, n - 1); }
+            double v[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[a][q] = A[ri[a] * n + ci[q]];
+            for (int k = 0; k < mp; k++) {
+                double m[4], tt[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { m[q] = Mkp[ri[q] * mp + k]; tt[q] = T[k * n + ci[q]]; }
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v[a][q] -= m[a] * tt[q];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) if (tr + a * nq < n && tc + q * nq < n) A[ri[a] * n + ci[q]] = v[a][q];
+        }
     }
     for (int r = tid; r < n; r += 512) { double v = bv[mp + r]; for (int a = 0; a < mp; a++) v -= Mkp[r * mp + a] * sbp[a]; br[r] = v; }
     __syncthreads();
@@ -633,6 +661,14 @@ __global__ void __launch_bounds__(512) ba_marg_finish(Win w, StepBufs sb, const 
         J[(size_t)k * n + perm[pos]] = v;
     }
     for (int k = tid; k < n; k += 512) rr[k] = k < rank ? zr[k] : 0.0;
+#ifdef GF_PROFILE_STEP
+    __syncthreads();
+    if (threadIdx.x == 0 && sb.stamps) {   // entry -> first stamp, last stamp -> exit of block 0; the longest block of the launch
+        const long long t_exit = clock64();
+        if (blockIdx.x == 0) { sb.stamps[106] = sb.stamps[32] - t_entry; sb.stamps[107] = t_exit - sb.stamps[38]; sb.stamps[108] = t_exit - t_entry; }
+        atomicMax(reinterpret_cast<unsigned long long*>(sb.stamps + 109), (unsigned long long)(t_exit - t_entry));
+    }
+#endif
 }
 
 }  // namespace gfb
