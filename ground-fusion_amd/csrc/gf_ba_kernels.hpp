@@ -995,9 +995,12 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
         const int k = oe < 0 ? -1 : (oe & 0xffff);
         int fi, fj;
         VisEval ev;
+        if (ch == c_lo) GF_WSTAMP(92);
         if (MODE != 2) cost += vis_lane_eval<EX>(w, d, b, which, k, xs, colf, ev, fi, fj, etw);
+        if (ch == c_lo) GF_WSTAMP(93);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();   // the previous chunk's reads of s_pair are done
-        s_pair[lane] = oe < 0 ? -1 : (oe >> 16);
+        const int mykey = oe < 0 ? -1 : (oe >> 16);
+        if (MODE == 2) s_pair[lane] = mykey;
         if (MODE == 1) {   // block rows of this lane's factor to HBM: rows[entry][r][16], columns 14 / 15 and padding lanes zero
             if (entry < ((n_order + 63) & ~63)) {
                 double2* dst = reinterpret_cast<double2*>(w.vrows + ((size_t)b * ((d.NVP + 63) & ~63) + entry) * 32);   // windows 64 entries apart: a last, partly filled chunk stays inside its window's rows
@@ -1028,6 +1031,9 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
             continue;
         }
         // the 64 block rows go through the staging area SG factors at a time
+#ifdef GF_PROFILE_STEP
+        long long vq_t = clock64(), vq_stage = 0, vq_mfma = 0;
+#endif
 #pragma unroll
         for (int part = 0; part < 64 / SG; part++) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();   // the previous part's reads are done
@@ -1044,21 +1050,35 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+#ifdef GF_PROFILE_STEP
+            { const long long t_ = clock64(); vq_stage += t_ - vq_t; vq_t = t_; }
+#endif
+            // The pair of entries 2m, 2m + 1 comes out of the lanes' own keys (a readlane; through s_pair it was an LDS round trip in front of every product), and the
+            // operands of step m + 1 are loaded before the products of step m: what is left per step is the matrix core's own time (224 -> ~90 cycles per step).
+            const int jb = ((lane >> 5) * LSTR) + ((lane >> 4) & 1) * COLS + (lane & 15);
+            double a0n = Jbuf[jb], a1n = EX ? Jbuf[jb + 16] : 0.0;
+#pragma unroll
             for (int m = 0; m < SG / 2; m++) {
-                const int pair = uni(s_pair[SG * part + 2 * m]);   // pairs are padded to even length: entries 2m and 2m+1 share the pair (or are padding); the same in every lane
+                const double a0 = a0n, a1 = a1n;
+                if (m + 1 < SG / 2) { a0n = Jbuf[2 * (m + 1) * LSTR + jb]; if (EX) a1n = Jbuf[2 * (m + 1) * LSTR + jb + 16]; }
+                const int pair = __builtin_amdgcn_readlane(mykey, SG * part + 2 * m);   // pairs are padded to even length: entries 2m and 2m+1 share the pair (or are padding)
                 if (pair < 0) continue;
                 if (pair != cur_pair) { flush(cur_pair); cur_pair = pair; }
-                const int e = 2 * m + (lane >> 5), r = (lane >> 4) & 1, c = lane & 15;
-                const double a0 = Jbuf[e * LSTR + r * COLS + c];
                 acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc00, 0, 0, 0);
                 if (EX) {
-                    const double a1 = Jbuf[e * LSTR + r * COLS + 16 + c];
                     acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a1, acc01, 0, 0, 0);
                     acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc11, 0, 0, 0);
                 }
             }
+#ifdef GF_PROFILE_STEP
+            { const long long t_ = clock64(); vq_mfma += t_ - vq_t; vq_t = t_; }
+#endif
         }
+#ifdef GF_PROFILE_STEP
+        if (ch == c_lo && blockIdx.x == 0 && threadIdx.x == 0 && w.stamps) { w.stamps[95] = vq_stage; w.stamps[96] = vq_mfma; }
+#endif
     }
+    GF_WSTAMP(94);
     flush(cur_pair);
     GF_WSTAMP(82);
     cost = wave_sum_f64(cost);
