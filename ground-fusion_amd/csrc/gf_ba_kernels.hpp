@@ -296,7 +296,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // One visual factor per lane: residual, Jacobians, Huber correction, zeroed columns of constant blocks, and the products the Schur
 // complement needs for a free inverse depth (stored to efac).  k < 0: padding lane (all zero).  Returns the factor's cost.
 template <bool EX>
-__device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int b, int which, int k, const double* xs, const int* colf, VisEval& ev, int& fi, int& fj, double* etw = nullptr) {   // etw (!EX): this window's E^T F rows (zeroed by the caller)
+__device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int b, int which, int k, const double* xs, const int* colf, VisEval& ev, int& fi, int& fj, double* etw = nullptr) {   // etw (!EX): this window's E^T F rows (every other column of a row is written by et_rows8)
     double cost = 0.0;
     int feat = 0;
     fi = 0; fj = 0;
@@ -795,27 +795,37 @@ __device__ __forceinline__ void et_rows8(const Win& w, const StepBufs& sb, const
     const int p0 = e >= 0 ? fptr[f] : 0, p1 = e >= 0 ? fptr[f + 1] : 0;
     const double* efac = w.efac + (size_t)b * d.NV * EF;
     double* Et = sb.Et + (((size_t)which * d.B + b) * d.FP + max(e, 0)) * d.ECW;
-    if (!EX) {   // round 5: the row was zeroed at the head of the kernel and already holds every factor's pose-j products; what is left are the sums
+    if (!EX) {   // the row already holds every factor's pose-j products (round 5: stored by the evaluating lanes); what is left are the sums -- and (round 6) the zeros:
+        // the row is no longer cleared at the head of the kernel (with the tracks of a window alive 66 of its 80 columns were written twice, 16 MB of the launch's
+        // 78 MB of writes), the eight lanes of the feature clear the columns of the frames that hold no observation of it, the extrinsic columns and the padding
         double acc = 0.0, accb = 0.0;
         int fi = 0;
+        unsigned seen = 0;   // frames j with a factor of this feature: their six columns are written by the evaluating lanes
         constexpr int NF = 10;
         for (int pb = p0; pb < p1; pb += NF) {
-            double v[NF], vb[NF], fr0;
+            double v[NF], vb[NF], fr[NF];
 #pragma unroll
             for (int q = 0; q < NF; q++) {
                 const bool on = pb + q < p1;
                 const double* row = efac + (size_t)(on ? pb + q : p0) * EFS;
                 v[q] = on ? row[sub] : 0.0; vb[q] = (on && sub == 0) ? row[8] : 0.0;
-                if (q == 0) fr0 = row[9];
+                fr[q] = row[9];
             }
-            fi = __double2loint(fr0);
+            fi = __double2loint(fr[0]);
 #pragma unroll
-            for (int q = 0; q < NF; q++) { if (pb + q >= p1) continue; acc += v[q]; accb += vb[q]; }
+            for (int q = 0; q < NF; q++) { if (pb + q >= p1) continue; acc += v[q]; accb += vb[q]; seen |= 1u << __double2hiint(fr[q]); }
         }
         if (e < 0) return;
-        if (sub < 6) Et[6 * fi + sub] = acc;                                   // pose i
-        else if (sub == 6) Et[6 * d.NP + 6] = acc;                             // td
-        else sb.ete[((size_t)which * d.B + b) * d.FP + e] = acc;               // sub == 7
+        if (p1 > p0) seen |= 1u << fi;   // pose i: the six sums below
+        for (int c = sub; c < d.ECW; c += 8) {
+            const bool written = c < 6 * d.NP ? ((seen >> (c / 6)) & 1u) != 0 : c == 6 * d.NP + 6;
+            if (!written) Et[c] = 0.0;
+        }
+        if (p1 > p0) {
+            if (sub < 6) Et[6 * fi + sub] = acc;                               // pose i
+        }
+        if (sub == 6) Et[6 * d.NP + 6] = acc;                                  // td
+        else if (sub == 7) sb.ete[((size_t)which * d.B + b) * d.FP + e] = acc;
         if (sub == 0) sb.etb[((size_t)which * d.B + b) * d.FP + e] = accb;
         return;
     }
@@ -933,8 +943,7 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
     double* bnd = slots + (size_t)NPAIR * TN;
     GF_WSTAMP(80);
     for (int i = tid; i < (NPAIR + NW) * TN; i += NT) slots[i] = 0.0;
-    double* etw = EX ? nullptr : sb.Et + ((size_t)which * d.B + b) * d.FP * d.ECW;   // this window's E^T F rows: zeroed here, filled by the evaluating lanes (pose j) and by et_rows8 (sums)
-    if (!EX && MODE != 2) { const int ne = uni(st.NE); for (int i = tid; i < ne * d.ECW; i += NT) etw[i] = 0.0; }
+    double* etw = EX ? nullptr : sb.Et + ((size_t)which * d.B + b) * d.FP * d.ECW;   // this window's E^T F rows: filled by the evaluating lanes (pose j) and by et_rows8 (sums, and zeros everywhere else)
     if (d.F <= kVFP) for (int i = tid; i <= d.F; i += NT) s_fptr[i] = w.feat_ptr[(size_t)b * (d.F + 1) + i];
 #ifdef GF_VIS_PAIRGEO
     if (MODE != 2) {   // what the factors of a frame pair share, once per pair (visible to the whole block behind the barrier below: same CU, same L1)
