@@ -107,29 +107,33 @@ __global__ void __launch_bounds__(256) pyr_down_kernel(uint8_t* __restrict__ pyr
 // loads, one dword store per thread.  Same integer arithmetic as the scalar kernel above.
 __device__ __forceinline__ int byte_of(uint32_t v, int k) { return (int)((v >> (8 * k)) & 0xffu); }
 
-// four consecutive interior pixels (y, x .. x+3) of level d from level s (x a multiple of 4), packed into one dword
-__device__ __forceinline__ uint32_t pyr_down_quad(const uint8_t* __restrict__ base, const LevelGeom& s, int y, int x) {
-    const uint8_t* sp = base + s.img_off + (ptrdiff_t)(2 * y - 2) * s.stride + 2 * x;   // 8-byte aligned
-    int acc[4] = {0, 0, 0, 0};
+// four consecutive pixels (y, x .. x+3) of the next level (x a multiple of 4), packed into one dword, from a pointer to source column 2x of source row 2y - 2
+// (rows `stride` bytes apart, four readable bytes to the left of it): global memory or LDS
+__device__ __forceinline__ uint32_t pyr_down_quad_at(const uint8_t* sp, ptrdiff_t stride) {
+    // Output i of the quad is the [1 4 6 4 1] row sum over source bytes 2 + 2i .. 6 + 2i of the sixteen loaded ones: the first four of them as one dword (the
+    // loaded dword itself or a v_alignbyte of two), weighted by v_dot4_u32_u8, plus the fifth byte -- 14 instructions per source row instead of ~50 of
+    // shifts, masks and multiply-adds.  Integer arithmetic: the same sums.
+    unsigned acc[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int dy = 0; dy < 5; dy++) {
-        const int ky = dy == 0 || dy == 4 ? 1 : (dy == 2 ? 6 : 4);
-        const uint32_t* r = reinterpret_cast<const uint32_t*>(sp + (ptrdiff_t)dy * s.stride);
+        const unsigned ky = dy == 0 || dy == 4 ? 1 : (dy == 2 ? 6 : 4);
+        const uint32_t* r = reinterpret_cast<const uint32_t*>(sp + (ptrdiff_t)dy * stride);
         const uint32_t w0 = r[-1], w1 = r[0], w2 = r[1], w3 = r[2];   // source columns 2x-4 .. 2x+11
-        int p[12];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { p[k] = byte_of(w0, k); p[4 + k] = byte_of(w1, k); p[8 + k] = byte_of(w2, k); }
-        const int p12 = byte_of(w3, 0);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {   // output i: source columns 2(x+i)-2 .. 2(x+i)+2 = p[2 + 2i] .. p[6 + 2i]
-            const int e = 6 + 2 * i < 12 ? p[(6 + 2 * i) < 12 ? 6 + 2 * i : 11] : p12;
-            acc[i] += ky * (p[2 + 2 * i] + 4 * p[3 + 2 * i] + 6 * p[4 + 2 * i] + 4 * p[5 + 2 * i] + e);
-        }
+        const uint32_t d0 = __builtin_amdgcn_alignbyte(w1, w0, 2), d2 = __builtin_amdgcn_alignbyte(w2, w1, 2);   // bytes 2..5, 6..9 (d1 = w1: 4..7, d3 = w2: 8..11)
+        constexpr uint32_t kTaps = 0x04060401u;   // weights of bytes 0..3
+        acc[0] += ky * __builtin_amdgcn_udot4(d0, kTaps, (w1 >> 16) & 0xffu, false);
+        acc[1] += ky * __builtin_amdgcn_udot4(w1, kTaps, w2 & 0xffu, false);
+        acc[2] += ky * __builtin_amdgcn_udot4(d2, kTaps, (w2 >> 16) & 0xffu, false);
+        acc[3] += ky * __builtin_amdgcn_udot4(w2, kTaps, w3 & 0xffu, false);
     }
     uint32_t out = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) out |= (uint32_t)((acc[i] + 128) >> 8) << (8 * i);
+    for (int i = 0; i < 4; i++) out |= ((acc[i] + 128u) >> 8) << (8 * i);
     return out;
+}
+// ... of level d from the padded level s in global memory
+__device__ __forceinline__ uint32_t pyr_down_quad(const uint8_t* __restrict__ base, const LevelGeom& s, int y, int x) {
+    return pyr_down_quad_at(base + s.img_off + (ptrdiff_t)(2 * y - 2) * s.stride + 2 * x, s.stride);   // 8-byte aligned
 }
 // one pixel of level d at interior coordinates (y, x)
 __device__ __forceinline__ uint32_t pyr_down_one(const uint8_t* __restrict__ base, const LevelGeom& s, int y, int x) {
@@ -247,6 +251,73 @@ __global__ void __launch_bounds__(512) pyr_down_tail_kernel(uint8_t* __restrict_
     }
     __syncthreads();
     write_padded_rows(base, e, ldsB, r0, r0, r1);
+}
+
+// Levels 0 and 1 in ONE launch (round 6): the raw frame is read once.  grid = (bands of kHeadRows rows of level 1, sequences).  A block loads the 2 kHeadRows + 3
+// raw rows under its band into LDS (rows past the image as their REFLECT_101 images, four mirrored bytes either side of a row), writes its 2 kHeadRows rows of
+// level 0 with their borders in 16-byte units, filters its band of level 1 from LDS (the arithmetic of pyr_down_quad, four aligned dwords per row and quad) and
+// writes that with its borders.  Before: a copy kernel (78.6 MB read, 98 MB written: 55 us per 256 VGA frames) and pyr_down_pad4_kernel reading level 0 back
+// (32 us).  Needs an even height and a width that is a multiple of 16; other sizes keep the two kernels.
+constexpr int kHeadRows = 16;
+__host__ __device__ inline size_t pyr_head_lds_bytes(int w0) { return (size_t)(2 * kHeadRows + 3) * (w0 + 8) + (size_t)kHeadRows * (w0 / 2); }
+__global__ void __launch_bounds__(512) pyr_head_kernel(const uint8_t* __restrict__ raw, size_t raw_seq_stride, int raw_stride,
+                                                       uint8_t* __restrict__ pyr, size_t pyr_seq_stride, LevelGeom g0, LevelGeom g1) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t head_sm[];
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * kHeadRows, r1 = min(g1.h, r0 + kHeadRows);   // this block's rows of level 1
+    const int ya = 2 * r0 - 2, nrow = 2 * (r1 - r0) + 3;                    // level-0 rows ya .. ya + nrow - 1 in LDS
+    const int SA = g0.w + 8;                                                // LDS row: 4 mirrored bytes, w pixels, 4 mirrored bytes (a multiple of 8)
+    uint8_t* A = head_sm;
+    uint8_t* Bq = head_sm + (size_t)(2 * kHeadRows + 3) * SA;               // the band of level 1, no borders
+    const uint8_t* src = raw + blockIdx.y * raw_seq_stride;
+    uint8_t* base = pyr + blockIdx.y * pyr_seq_stride;
+    {
+        const int qi = g0.w >> 4;
+        for (int t = tid; t < qi * nrow; t += 512) {
+            const int yy = t / qi, u = t - yy * qi;
+            const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)reflect101(ya + yy, g0.h) * raw_stride + 16 * u);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(A + (size_t)yy * SA + 4 + 16 * u);
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < nrow * 8; t += 512) {   // columns -1 .. -4 and w .. w + 3
+        const int yy = t >> 3, k = t & 7;
+        uint8_t* rowp = A + (size_t)yy * SA + 4;
+        if (k < 4) rowp[-1 - k] = rowp[1 + k]; else rowp[g0.w + (k - 4)] = rowp[g0.w - 2 - (k - 4)];
+    }
+    __syncthreads();
+    {   // level 0 with its borders: rows 2 r0 .. 2 r1 - 1, each also to the border rows it mirrors to
+        const int q0 = (g0.w + 2 * kPad) >> 4, nout = 2 * (r1 - r0);
+        uint8_t* img0 = base + g0.img_off;
+        for (int t = tid; t < q0 * nout; t += 512) {
+            const int yy = t / q0, px = (t - yy * q0) << 4, y = 2 * r0 + yy;
+            const uint8_t* rowp = A + (size_t)(y - ya) * SA + 4;
+            uint4 v;
+            if (px >= kPad && px + 15 < kPad + g0.w) {
+                const uint32_t* s4 = reinterpret_cast<const uint32_t*>(rowp + (px - kPad));
+                v = make_uint4(s4[0], s4[1], s4[2], s4[3]);
+            } else {
+                uint32_t w4[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 16; k++) w4[k >> 2] |= (uint32_t)rowp[reflect_once(px + k - kPad, g0.w)] << (8 * (k & 3));
+                v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            }
+            uint8_t* col = img0 + (px - kPad);
+            *reinterpret_cast<uint4*>(col + (ptrdiff_t)y * g0.stride) = v;
+            if (y >= 1 && y <= kPad) *reinterpret_cast<uint4*>(col - (ptrdiff_t)y * g0.stride) = v;
+            if (y >= g0.h - 1 - kPad && y <= g0.h - 2) *reinterpret_cast<uint4*>(col + (ptrdiff_t)(2 * (g0.h - 1) - y) * g0.stride) = v;
+        }
+    }
+    {   // the band of level 1 from LDS
+        const int qe = g1.w >> 2;
+        for (int t = tid; t < qe * (r1 - r0); t += 512) {
+            const int yy = t / qe, x = (t - yy * qe) << 2;
+            *reinterpret_cast<uint32_t*>(Bq + (size_t)yy * g1.w + x) = pyr_down_quad_at(A + (size_t)(2 * yy) * SA + 4 + 2 * x, SA);
+        }
+    }
+    __syncthreads();
+    write_padded_rows(base, g1, Bq, r0, r0, r1);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -266,22 +266,28 @@ static int launch_pyramid(gf_tracker* h, const uint8_t* d_raw_frames) {
     const LevelGeom g0 = G.lv[0];
     const bool v16 = !((g0.w | g0.stride | (int)(((size_t)g0.w * g0.h) & 15) | (int)(seq_img & 15) | (int)((g0.img_off - kPad * g0.stride - kPad) & 15)) & 15) &&
                      !((reinterpret_cast<uintptr_t>(d_raw_frames) | reinterpret_cast<uintptr_t>(img)) & 15);
-    if (v16) {
+    bool vec = true;   // four-pixel kernels need level widths (and with them strides, offsets) that are multiples of 4
+    for (int l = 0; l < G.nlevels; l++) vec = vec && !(G.lv[l].w & 3) && !(G.lv[l].img_off & 3);
+    for (int l = 1; l < G.nlevels; l++) vec = vec && G.lv[l].w > kPad + 1 && G.lv[l].h > kPad + 1;   // one reflection reaches every border pixel
+    // levels 0 and 1 from one read of the raw frame (pyr_head_kernel) when the sizes allow it; GF_PYR_HEAD=0 keeps the two kernels (A/B and fallback)
+    static const bool head_on = !(getenv("GF_PYR_HEAD") && atoi(getenv("GF_PYR_HEAD")) == 0);
+    const bool head = head_on && v16 && vec && G.nlevels >= 2 && !(g0.h & 1) && G.lv[1].h * 2 == g0.h && G.lv[1].w * 2 == g0.w && g0.h > kPad + 2 && g0.w > kPad + 2 &&
+                      pyr_head_lds_bytes(g0.w) <= 64 * 1024;
+    if (head) {
+        pyr_head_kernel<<<dim3((G.lv[1].h + kHeadRows - 1) / kHeadRows, h->B), 512, pyr_head_lds_bytes(g0.w), h->stream>>>(d_raw_frames, (size_t)g0.w * g0.h, g0.w, img, seq_img, g0, G.lv[1]);
+    } else if (v16) {
         const int n = ((g0.w + 2 * kPad) / 16) * (g0.h + 2 * kPad);
         pyr_level0_vec16_kernel<<<dim3((n + 255) / 256, h->B), 256, 0, h->stream>>>(d_raw_frames, (size_t)g0.w * g0.h, g0.w, img, seq_img, g0);
     } else {
         const int n = ((g0.w + 2 * kPad) / 4) * (g0.h + 2 * kPad);
         pyr_level0_kernel<<<dim3((n + 255) / 256, h->B), 256, 0, h->stream>>>(d_raw_frames, (size_t)g0.w * g0.h, g0.w, img, seq_img, g0);
     }
-    bool vec = true;   // four-pixel kernels need level widths (and with them strides, offsets) that are multiples of 4
-    for (int l = 0; l < G.nlevels; l++) vec = vec && !(G.lv[l].w & 3) && !(G.lv[l].img_off & 3);
-    for (int l = 1; l < G.nlevels; l++) vec = vec && G.lv[l].w > kPad + 1 && G.lv[l].h > kPad + 1;   // one reflection reaches every border pixel
     if (vec) {
         auto down = [&](int l) {
             const LevelGeom d = G.lv[l];
             pyr_down_pad4_kernel<<<dim3(((d.w >> 2) * d.h + 255) / 256, h->B), 256, 0, h->stream>>>(img, seq_img, G.lv[l - 1], d);
         };
-        if (G.nlevels > 1) down(1);
+        if (G.nlevels > 1 && !head) down(1);
         if (G.nlevels > 2) {
             const int parts = 4, last = std::min(G.nlevels - 1, 3);
             const LevelGeom d = G.lv[2], e = G.lv[last];
