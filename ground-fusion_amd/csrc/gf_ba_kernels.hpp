@@ -121,7 +121,7 @@ constexpr int WH_STRIDE = 1 + 3 + 4 + 18 + 36 + 4 + 12;  // sum_dt, dp, dq, jac(
 // The sweeps are bound by memory traffic as much as by arithmetic (all 256 windows of a launch move their tables at once: ~3.7 TB/s over the launch); the
 // products were 2 x 73 MB (double-buffered, 192 B per factor) against a 256 MB Infinity Cache; now 49 MB.
 constexpr int EF = 24;
-template <bool EX> __host__ __device__ constexpr int ef_stride() { return EX ? 24 : 10; }
+template <bool EX> __host__ __device__ constexpr int ef_stride() { return EX ? 16 : 10; }
 #ifdef GF_PROFILE_STEP
 #define GF_WSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && w.stamps) w.stamps[i] = clock64(); } while (0)
 #define GF_WSTAMP_T(t, i) do { if (blockIdx.x == 0 && threadIdx.x == (t) && w.stamps) w.stamps[i] = clock64(); } while (0)
@@ -357,12 +357,16 @@ __device__ __forceinline__ double vis_lane_eval(const Win& w, const Dims& d, int
         if (live && w.cole[(size_t)b * d.F + feat] >= 0) {
             double* ef = w.efac + ((size_t)b * d.NV * EF + (size_t)(w.pos_ident ? k : w.vis_pos[kk]) * ef_stride<EX>());   // the factors of a feature are contiguous
             const double ete_f = ev.jd[0] * ev.jd[0] + ev.jd[1] * ev.jd[1], etb_f = ev.jd[0] * ev.row[0][13] + ev.jd[1] * ev.row[1][13];
-            if (EX) {
+            if (EX) {   // round 6: one 128-byte line per factor as well -- pose i (summed), td, the six extrinsic products (summed), ete, etb, the frames; pose j goes straight into the row
 #pragma unroll
-                for (int c = 0; c < 13; c++) ef[c] = ev.jd[0] * ev.row[0][c] + ev.jd[1] * ev.row[1][c];
+                for (int c = 0; c < 6; c++) ef[c] = ev.jd[0] * ev.row[0][c] + ev.jd[1] * ev.row[1][c];
+                ef[6] = ev.jd[0] * ev.row[0][12] + ev.jd[1] * ev.row[1][12];
 #pragma unroll
-                for (int c = 0; c < 6; c++) ef[13 + c] = ev.jd[0] * ev.row[0][16 + c] + ev.jd[1] * ev.row[1][16 + c];
-                ef[19] = ete_f; ef[20] = etb_f; ef[21] = (double)fi; ef[22] = (double)fj;
+                for (int c = 0; c < 6; c++) ef[7 + c] = ev.jd[0] * ev.row[0][16 + c] + ev.jd[1] * ev.row[1][16 + c];
+                ef[13] = ete_f; ef[14] = etb_f; ef[15] = __hiloint2double(fj, fi);
+                double* er = etw + (size_t)w.cole[(size_t)b * d.F + feat] * d.ECW + 6 * fj;
+#pragma unroll
+                for (int c = 0; c < 6; c++) er[c] = ev.jd[0] * ev.row[0][6 + c] + ev.jd[1] * ev.row[1][6 + c];
             } else {
 #pragma unroll
                 for (int c = 0; c < 6; c++) ef[c] = ev.jd[0] * ev.row[0][c] + ev.jd[1] * ev.row[1][c];                       // pose i: summed over the feature's factors (et_rows8)
@@ -829,46 +833,36 @@ __device__ __forceinline__ void et_rows8(const Win& w, const StepBufs& sb, const
         if (sub == 0) sb.etb[((size_t)which * d.B + b) * d.FP + e] = accb;
         return;
     }
-    if (e >= 0) for (int c = sub; c < d.ECW; c += 8) Et[c] = 0.0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-    // EX:   lane `sub` owns the products sub (0-5 pose_i, 6-7 pose_j), 8 + sub (8-11 pose_j, 12 td, 13-15 ex 0-2) and 16 + sub (16-18 ex 3-5, 19 ete, 20 etb) of every factor
-    // else: lane `sub` owns the products sub (0-5 pose_i, 6-7 pose_j) and 8 + sub (8-11 pose_j, 12 td, 13 ete, 14 etb, 15 the frames) -- one 128-byte line per factor
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    // EX (round 6: the layout of the other variant plus the extrinsic products -- before, a factor parked all 19 products here and this pass cleared the row and copied
+    // the pose-j ones over): lane `sub` owns the products sub (0-5 pose_i, 6 td, 7 ex 0) and 8 + sub (8-12 ex 1-5, 13 ete, 14 etb; 15 holds the frames)
+    double acc0 = 0.0, acc1 = 0.0;
     int fi = 0;
-    constexpr int NF = 10;   // factors in flight: every load of a batch is issued before the first store (a track spans <= W frames)
+    unsigned seen = 0;
+    constexpr int NF = 10;   // factors in flight (a track spans <= W frames)
     for (int pb = p0; pb < p1; pb += NF) {
-        double v0[NF], v1[NF], v2[NF], fr[NF], fid[NF];
+        double v0[NF], v1[NF], fr[NF];
 #pragma unroll
         for (int q = 0; q < NF; q++) {
             const bool on = pb + q < p1;
             const double* row = efac + (size_t)(on ? pb + q : p0) * EFS;
-            v0[q] = on ? row[sub] : 0.0; v1[q] = on ? row[8 + sub] : 0.0;
-            if (EX) { v2[q] = (on && sub < 5) ? row[16 + sub] : 0.0; fid[q] = row[21]; fr[q] = row[22]; }
-            else { v2[q] = 0.0; fid[q] = 0.0; fr[q] = row[15]; }
+            v0[q] = on ? row[sub] : 0.0; v1[q] = (on && sub < 7) ? row[8 + sub] : 0.0; fr[q] = row[15];
         }
-        fi = EX ? (int)fid[0] : __double2loint(fr[0]);
+        fi = __double2loint(fr[0]);
 #pragma unroll
-        for (int q = 0; q < NF; q++) {
-            if (pb + q >= p1) continue;
-            const int fj6 = 6 * (EX ? (int)fr[q] : __double2hiint(fr[q]));
-            if (sub >= 6) Et[fj6 + sub - 6] = v0[q]; else acc0 += v0[q];
-            if (sub < 4) Et[fj6 + 2 + sub] = v1[q]; else if (EX || sub < 7) acc1 += v1[q];
-            acc2 += v2[q];
-        }
+        for (int q = 0; q < NF; q++) { if (pb + q >= p1) continue; acc0 += v0[q]; acc1 += v1[q]; seen |= 1u << __double2hiint(fr[q]); }
     }
     if (e < 0) return;
-    if (sub < 6) Et[6 * fi + sub] = acc0;
-    if (EX) {
-        if (sub == 4) Et[6 * d.NP + 6] = acc1;                             // td
-        else if (sub >= 5) Et[6 * d.NP + sub - 5] = acc1;                  // ex 0-2
-        if (sub < 3) Et[6 * d.NP + 3 + sub] = acc2;                        // ex 3-5
-        else if (sub == 3) sb.ete[((size_t)which * d.B + b) * d.FP + e] = acc2;
-        else if (sub == 4) sb.etb[((size_t)which * d.B + b) * d.FP + e] = acc2;
-    } else {
-        if (sub == 4) Et[6 * d.NP + 6] = acc1;                             // td
-        else if (sub == 5) sb.ete[((size_t)which * d.B + b) * d.FP + e] = acc1;
-        else if (sub == 6) sb.etb[((size_t)which * d.B + b) * d.FP + e] = acc1;
+    if (p1 > p0) seen |= 1u << fi;
+    for (int c = sub; c < d.ECW; c += 8) {
+        const bool written = c < 6 * d.NP ? ((seen >> (c / 6)) & 1u) != 0 : c <= 6 * d.NP + 6;
+        if (!written) Et[c] = 0.0;
     }
+    if (sub < 6) { if (p1 > p0) Et[6 * fi + sub] = acc0; }                 // pose i
+    else if (sub == 6) Et[6 * d.NP + 6] = acc0;                            // td
+    else Et[6 * d.NP] = acc0;                                              // ex 0
+    if (sub < 5) Et[6 * d.NP + 1 + sub] = acc1;                            // ex 1-5
+    else if (sub == 5) sb.ete[((size_t)which * d.B + b) * d.FP + e] = acc1;
+    else if (sub == 6) sb.etb[((size_t)which * d.B + b) * d.FP + e] = acc1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -943,7 +937,7 @@ __global__ void __launch_bounds__(64 * NW) ba_linearize_visual_win(Win w, StepBu
     double* bnd = slots + (size_t)NPAIR * TN;
     GF_WSTAMP(80);
     for (int i = tid; i < (NPAIR + NW) * TN; i += NT) slots[i] = 0.0;
-    double* etw = EX ? nullptr : sb.Et + ((size_t)which * d.B + b) * d.FP * d.ECW;   // this window's E^T F rows: filled by the evaluating lanes (pose j) and by et_rows8 (sums, and zeros everywhere else)
+    double* etw = sb.Et + ((size_t)which * d.B + b) * d.FP * d.ECW;   // this window's E^T F rows: filled by the evaluating lanes (pose j) and by et_rows8 (sums, and zeros everywhere else)
     if (d.F <= kVFP) for (int i = tid; i <= d.F; i += NT) s_fptr[i] = w.feat_ptr[(size_t)b * (d.F + 1) + i];
 #ifdef GF_VIS_PAIRGEO
     if (MODE != 2) {   // what the factors of a frame pair share, once per pair (visible to the whole block behind the barrier below: same CU, same L1)
