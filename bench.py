@@ -419,18 +419,13 @@ def small_batch_sample(gfamd, dev, args, WIN, GNSS, sizes=(1, 8, 64), K=40, dist
         def run(n, tracker=True, backend=True, k0=0):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            queued = False
             for i in range(n):
-                if backend and not queued:
+                if backend:
                     est.solve_resident_async(args.ba_iters, 0, True)
-                queued = False
                 if tracker:
                     trk.trackImageBatchDevice([dt * (k0 + i)] * Bs, frames.data_ptr() + fi(k0 + i) * fb, depth.data_ptr(), unpack=False)
                 if backend:
-                    if i + 1 < n and not args.no_pipeline:   # as the main loop: the next step's back end behind the running one before the host joins it
-                        est.solve_resident_async(args.ba_iters, 0, True)
-                        queued = True
-                    est.wait_oldest()
+                    est.wait()
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / n
         run(4)
@@ -448,7 +443,7 @@ CONFIGS = {1: dict(max_cnt=150, min_dist=30, window=10, gnss=False, batch=256, d
            4: dict(max_cnt=500, min_dist=12, window=20, gnss=True, batch=64, distinct=16)}
 
 
-def config_sample(gfamd, dev, cfg_index, K=20, Wm=3, ba_iters=8, distinct=None, pipeline=True):
+def config_sample(gfamd, dev, cfg_index, K=20, Wm=3, ba_iters=8, distinct=None):
     """BASELINE.json configs[cfg_index] as a short kernel-rate sample inside the default run (round-5 review: configs[2] and configs[4] only existed as builder-run files
     under profiles/): the same step as `value` -- tracker frame + 8 dogleg iterations + MARGIN_OLD for every sequence, inputs resident in HBM -- on handles of its own,
     K timed steps, then the three roofline kernels on an otherwise idle GPU for their fractions.  `python bench.py --config N` is the long form of the same."""
@@ -467,25 +462,18 @@ def config_sample(gfamd, dev, cfg_index, K=20, Wm=3, ba_iters=8, distinct=None, 
         m = k % (2 * nf - 2)
         return m if m < nf else 2 * nf - 2 - m
 
-    queued = [False]
-
-    def do_step(more=False):   # as the main loop's step (without the pose exchange): the next step's back end goes behind the running one before the host joins it
-        if not queued[0]:
-            est.solve_resident_async(ba_iters, 0, True)
-        queued[0] = False
+    def do_step():
+        est.solve_resident_async(ba_iters, 0, True)
         trk.trackImageBatchDevice([dt * step[0]] * B, frames.data_ptr() + fi(step[0]) * fb, depth.data_ptr(), unpack=False)
-        if more and pipeline:
-            est.solve_resident_async(ba_iters, 0, True)
-            queued[0] = True
-        est.wait_oldest()
+        est.wait()
         step[0] += 1
-    for i in range(Wm + 1):
-        do_step(more=i < Wm)
+    for _ in range(Wm + 1):
+        do_step()
     trk.reset_stats(); est.reset_stats()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(K):
-        do_step(more=i + 1 < K)
+    for _ in range(K):
+        do_step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     st, bs = trk.stats(), est.stats()
@@ -543,7 +531,6 @@ def main():
     ap.add_argument("--no-large-batch", action="store_true", help="skip the step times at 512 / 1024 sequences per GPU")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the 20-step kernel-rate samples of configs[2] and configs[4]")
     ap.add_argument("--no-long-run", action="store_true", help="skip the extra 200-step run next to a short timed loop")
-    ap.add_argument("--no-pipeline", action="store_true", help="join every step's solve before the next one is enqueued (rounds 1-5; default: the next step's back end is enqueued behind the running one)")
     ap.add_argument("--e2e-device-preint", action="store_true", help="also run the end-to-end sample with the batched device pre-integration of the estimator group")
     ap.add_argument("--e2e-device-sweeps", action="store_true", help="also run the end-to-end sample with the batched device feature sweeps (triangulateWithDepth, movingConsistencyCheckW) of the estimator group")
     ap.add_argument("--e2e-only", action="store_true", help="only the end-to-end (drop-in path) sample, as one JSON line (used by the default run for its small-host sample)")
@@ -630,29 +617,18 @@ def main():
     gathered = [None]
     pose_gather = shard.PoseGather(dist, world, [B] * world, dev)     # persistent send / receive buffers, all_gather_into_tensor over RCCL
 
-    queued = [False]   # the back end of the coming step is already on the estimator's stream
-
-    def do_step(exchange=True, more=False):
-        """one step: the solve + marginalisation of the resident windows, one tracker frame, the export and gather of the newest poses.  `more`: another step follows --
-        its back end is enqueued behind this one's (and behind the export of this one's poses) as soon as this step's tracker frame is through, BEFORE the host joins
-        this step's solve: the stream orders the two solves, the GPU does not wait for the host's round trip between them (gf_ba_wait_oldest; --no-pipeline: off).
-        The reference's processThread takes the next feature frame off featureBuf the moment it is through with the last (estimator.cpp:209-246)."""
+    def do_step(exchange=True):
         k = frame_index(step[0])
         # the back end of this step is enqueued first and runs on its own stream while the tracker (GPU kernels + host bookkeeping)
         # proceeds -- the reference runs processImage and trackImage on separate threads as well (estimator.cpp:209, rosNodeTest.cpp:713)
-        if not args.no_backend and not queued[0]:
+        if not args.no_backend:
             est.solve_resident_async(args.ba_iters, 0, True)
-        queued[0] = False
         if not args.no_frontend:
             trk.trackImageBatchDevice([dt * step[0]] * B, frames.data_ptr() + k * frame_bytes, depth.data_ptr(), unpack=False)
         if not args.no_backend:
+            est.wait()
             if exchange:   # north_star's only exchange: the newest pose of every sequence, all_gather over RCCL (56 B per sequence, latency-bound)
-                est.export_newest_poses_async(newest.data_ptr(), B)
-            if more and not args.no_pipeline:
-                est.solve_resident_async(args.ba_iters, 0, True)
-                queued[0] = True
-            est.wait_oldest()     # this step's solve and the export behind it
-            if exchange:
+                est.export_newest_poses(newest.data_ptr(), B)
                 gathered[0] = pose_gather(newest)
         step[0] += 1
 
@@ -664,8 +640,8 @@ def main():
             print("bench.py: %-28s %6.1f s" % (name, now - t_phase[0]), file=sys.stderr, flush=True)
         t_phase[0] = now
     phase("setup (frames, windows)")
-    for i in range(Wm + 1):  # frame 0 only detects; it is part of the warm-up
-        do_step(more=i < Wm)   # (nothing of the timed region is enqueued before its clock starts)
+    for _ in range(Wm + 1):  # frame 0 only detects; it is part of the warm-up
+        do_step()
     trk.reset_stats()
     est.reset_stats()
 
@@ -676,8 +652,8 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for i in range(K):
-        do_step(more=i + 1 < K)
+    for _ in range(K):
+        do_step()
     barrier()
     el = time.perf_counter() - t0
     phase("warm-up + timed loop")
@@ -691,8 +667,8 @@ def main():
         s0 = est.stats()["solves"]
         barrier()
         t1 = time.perf_counter()
-        for i in range(200):
-            do_step(more=i + 1 < 200)
+        for _ in range(200):
+            do_step()
         barrier()
         el2 = time.perf_counter() - t1
         long_run = {"steps": 200, "value": (est.stats()["solves"] - s0) / el2, "ms_per_step": 1e3 * el2 / 200}
@@ -856,7 +832,7 @@ def main():
             res["other_configs"] = {}
             for ci in (2, 4):
                 try:
-                    res["other_configs"]["configs[%d]" % ci] = config_sample(gfamd, dev, ci, ba_iters=args.ba_iters, pipeline=not args.no_pipeline)
+                    res["other_configs"]["configs[%d]" % ci] = config_sample(gfamd, dev, ci, ba_iters=args.ba_iters)
                 except Exception as ex:   # a side measurement: its failure must not cost the line
                     res["other_configs"]["configs[%d]" % ci] = {"error": repr(ex)[:300]}
             phase("other_configs")

@@ -149,15 +149,9 @@ struct gf_ba {
     bool any_ex = false; // some window estimates the camera extrinsic
     hipStream_t stream = nullptr;
     hipEvent_t ev[10] = {};   // 6, 7: around the second ba_step of a solve (the first full dogleg step); 8, 9: around the upload of gf_ba_solve_packed
-    hipEvent_t evB[10] = {};  // the same for a solve queued behind one that is still in flight (gf_ba_solve_resident_async with one solve pending)
-    hipEvent_t* evs = ev;     // the set the solve being enqueued records into
-    hipEvent_t ev_export[2] = {nullptr, nullptr};   // behind gf_ba_export_newest_poses_async, one per event set
     bool packed_upload_timed = false;
-    // Asynchronous solves in flight, oldest first (0..2).  Two, so that the solve of the next frame can be enqueued behind the running one without a host round trip in
-    // between: the stream orders them (and the export of the first one's poses between them); gf_ba_wait_oldest collects one at a time.
-    struct Pend { hipEvent_t* set = nullptr; int iters = 0; bool split_timed = false, exported = false; };
-    Pend pq[2];
-    int pending = 0;
+    bool pending = false;   // an asynchronous solve is in flight
+    int pending_iters = 0;
     gf_ba_stats stats{};
     size_t step_lds = 0, sg_stride = 0, mg_stride = 0; bool big_step = false, big_marg = false;
     // inputs (host mirror + device)
@@ -226,8 +220,6 @@ struct gf_ba {
         outJ.release(); outr.release(); stamps.release();
         st.release(); st0.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
-        for (auto& e : evB) if (e) (void)hipEventDestroy(e);
-        for (auto& e : ev_export) if (e) (void)hipEventDestroy(e);
         if (ev_gather) (void)hipEventDestroy(ev_gather);
         if (ev_gather_done) (void)hipEventDestroy(ev_gather_done);
         for (auto& e : ev_split) if (e) (void)hipEventDestroy(e);
@@ -741,9 +733,9 @@ int launch_linearize(gf_ba* h, int which, int which_state, int only_valid, bool 
     const Dims& d = h->d;
     Win w = h->win();
     poison_lds(h);
-    if (timed) HIPCHK(hipEventRecord(h->evs[2], h->stream));
+    if (timed) HIPCHK(hipEventRecord(h->ev[2], h->stream));
     if (int rc = launch_visual(h, w, h->any_ex, which, which_state, only_valid, timed)) return rc;
-    if (timed) HIPCHK(hipEventRecord(h->evs[3], h->stream));
+    if (timed) HIPCHK(hipEventRecord(h->ev[3], h->stream));
     if (misc_with_step) return GF_OK;   // the candidate's prior / IMU / wheel sweep rides in front of the next step (ba_misc_step)
     // same stream as the visual sweep: the two sweeps fill the CUs' LDS and registers and so exclude each other anyway, and a second stream only added the
     // cross-stream join in front of the next ba_step (12 us instead of 6; solve 2.49 -> 2.40 ms)
@@ -770,7 +762,7 @@ int run_solve(gf_ba* h, int max_iters) {
         }
         poison_lds(h);
         const bool time_step = it == 1 && max_iters >= 1;
-        if (time_step) HIPCHK(hipEventRecord(h->evs[6], h->stream));
+        if (time_step) HIPCHK(hipEventRecord(h->ev[6], h->stream));
         // windows in the chain form first (256 threads, two per CU), then -- if the batch holds any -- the others in the dense form; each kernel leaves the other's windows alone
         if (h->n_chain > 0) ba_step_chain<<<dim3(d.B), 256, ch_lds_doubles(h->chain_nd) * sizeof(double), h->stream>>>(w, sb, it == 0 ? 1 : 0, max_iters, it == max_iters ? 1 : 0);
         if (h->n_chain > 0 && h->n_dense == 0) { }
@@ -781,7 +773,7 @@ int run_solve(gf_ba* h, int max_iters) {
         else if (fuse_misc && it > 0) ba_misc_step<<<dim3(d.B), 512, std::max(h->step_lds, h->mwin_lds), h->stream>>>(w, sb, max_iters, it == max_iters ? 1 : 0);
         else ba_step<false><<<dim3(d.B), 512, h->step_lds, h->stream>>>(w, sb, it == 0 ? 1 : 0, max_iters, it == max_iters ? 1 : 0);
         HIPCHK(hipGetLastError());
-        if (time_step) { HIPCHK(hipEventRecord(h->evs[7], h->stream)); h->stats.step_launches++; h->stats.step_flops += h->step_flops; }
+        if (time_step) { HIPCHK(hipEventRecord(h->ev[7], h->stream)); h->stats.step_launches++; h->stats.step_flops += h->step_flops; }
         if (it < max_iters) {
             // candidate state lives in buffer (1 - cur) of each window: the kernels pick the right one per window.  The candidate of the LAST iteration is only judged by its
             // cost (the step behind it accepts or rejects and the solve ends): its sweeps run cost-only (only_valid = 3; round 6.  Not with GNSS blocks, whose kernel adds
@@ -865,8 +857,6 @@ int gf_ba_create(const gf_ba_cfg* cfg, gf_ba** out) {
         H_(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio));
     }
     for (auto& e : h->ev) H_(hipEventCreate(&e));
-    for (auto& e : h->evB) H_(hipEventCreate(&e));
-    for (auto& e : h->ev_export) H_(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     H_(hipEventCreateWithFlags(&h->ev_gather, hipEventDisableTiming));
     H_(hipEventCreateWithFlags(&h->ev_gather_done, hipEventDisableTiming));
     const size_t B = d.B, VS = d.RP + d.FP;
@@ -980,51 +970,30 @@ int gf_ba_upload(gf_ba* h, const gf_ba_window* windows, int count) {
 
 int gf_ba_solve_resident_async(gf_ba* h, int max_iters, int marginalize_mode, int reset) {
     if (!h || h->count < 1) return gf::set_err(GF_ERR_INVALID, "no resident windows");
-    if (h->pending >= 2) return gf::set_err(GF_ERR_INVALID, "two solves are already in flight: call gf_ba_wait_oldest (or gf_ba_wait) first");
-    if (h->pending == 1 && h->split_jtj) return gf::set_err(GF_ERR_INVALID, "the split formulation times one solve at a time: call gf_ba_wait first");
+    if (h->pending) return gf::set_err(GF_ERR_INVALID, "a solve is already in flight: call gf_ba_wait first");
     if (max_iters < 0 || max_iters > 64) return gf::set_err(GF_ERR_INVALID, "max_iters out of range");
     if (marginalize_mode > 1) return gf::set_err(GF_ERR_INVALID, "marginalize_mode must be -1, 0 or 1");
-    gf_ba::Pend& P = h->pq[h->pending];
-    P.set = (h->pending == 1 && h->pq[0].set == h->ev) ? h->evB : h->ev;   // the set the older solve does not hold
-    h->evs = P.set;
     if (reset) { if (int rc = reset_state(h)) return rc; }
-    HIPCHK(hipEventRecord(P.set[0], h->stream));
+    HIPCHK(hipEventRecord(h->ev[0], h->stream));
     if (int rc = run_solve(h, max_iters)) return rc;
-    HIPCHK(hipEventRecord(P.set[1], h->stream));
+    HIPCHK(hipEventRecord(h->ev[1], h->stream));
     if (marginalize_mode >= 0) { if (int rc = run_marginalize(h, marginalize_mode)) return rc; h->last_marg_mode = marginalize_mode; }
-    HIPCHK(hipEventRecord(P.set[4], h->stream));
-    P.iters = max_iters; P.split_timed = h->split_timed; h->split_timed = false; P.exported = false;
-    h->pending++;
+    HIPCHK(hipEventRecord(h->ev[4], h->stream));
+    h->pending = true; h->pending_iters = max_iters;
     return GF_OK;
 }
 
-// the oldest solve in flight (and the export enqueued behind it, if any): wait for it and book its timings
-static int wait_one(gf_ba* h) {
-    const gf_ba::Pend P = h->pq[0];
-    HIPCHK(hipEventSynchronize(P.set[4]));
-    if (P.exported) HIPCHK(hipEventSynchronize(h->ev_export[P.set == h->ev ? 0 : 1]));
-    h->pq[0] = h->pq[1]; h->pq[1] = gf_ba::Pend{};
-    h->pending--;
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, P.set[0], P.set[1])); h->stats.ms_solve += ms;
-    HIPCHK(hipEventElapsedTime(&ms, P.set[1], P.set[4])); h->stats.ms_marginalize += ms;
-    if (P.iters > 0) { HIPCHK(hipEventElapsedTime(&ms, P.set[2], P.set[3])); h->stats.ms_jtj += ms; }
-    if (P.iters > 0 && P.split_timed) { HIPCHK(hipEventElapsedTime(&ms, h->ev_split[0], h->ev_split[1])); h->stats.ms_jtj_contract += ms; h->stats.jtj_contract_launches++; }
-    if (P.iters > 0) { HIPCHK(hipEventElapsedTime(&ms, P.set[6], P.set[7])); h->stats.ms_step += ms; }
-    return GF_OK;
-}
-
-int gf_ba_wait_oldest(gf_ba* h) {
+int gf_ba_wait(gf_ba* h) {
     if (!h) return gf::set_err(GF_ERR_INVALID, "null handle");
     if (!h->pending) return GF_OK;
-    return wait_one(h);
-}
-
-int gf_ba_wait(gf_ba* h) {   // everything enqueued on the handle's stream
-    if (!h) return gf::set_err(GF_ERR_INVALID, "null handle");
-    if (!h->pending) return GF_OK;
-    while (h->pending) { if (int rc = wait_one(h)) return rc; }
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->pending = false;
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[1])); h->stats.ms_solve += ms;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev[1], h->ev[4])); h->stats.ms_marginalize += ms;
+    if (h->pending_iters > 0) { HIPCHK(hipEventElapsedTime(&ms, h->ev[2], h->ev[3])); h->stats.ms_jtj += ms; }
+    if (h->pending_iters > 0 && h->split_timed) { HIPCHK(hipEventElapsedTime(&ms, h->ev_split[0], h->ev_split[1])); h->stats.ms_jtj_contract += ms; h->stats.jtj_contract_launches++; h->split_timed = false; }
+    if (h->pending_iters > 0) { HIPCHK(hipEventElapsedTime(&ms, h->ev[6], h->ev[7])); h->stats.ms_step += ms; }
     return GF_OK;
 }
 
@@ -1292,20 +1261,6 @@ int gf_ba_export_newest_poses(gf_ba* h, void* d_out, int count) {
     // Always synchronise: the caller hands d_out to a collective on ANOTHER stream right after this returns.  (With a solve in flight this also
     // waits for the solve -- the exported pose is the solved one; gf_ba_wait afterwards only collects the statistics.)
     HIPCHK(hipStreamSynchronize(h->stream));
-    return GF_OK;
-}
-
-// The same without the host waiting: the kernel is enqueued behind whatever the handle's stream holds (the newest solve in flight: the exported poses are its
-// result), and gf_ba_wait_oldest / gf_ba_wait for that solve also waits for this export.  A solve enqueued AFTER this call runs behind the export.
-int gf_ba_export_newest_poses_async(gf_ba* h, void* d_out, int count) {
-    if (!h || !d_out || count < 1 || count > h->count) return gf::set_err(GF_ERR_INVALID, "bad argument");
-    ba_export_newest<<<dim3((count + 63) / 64), 64, 0, h->stream>>>(h->win(), static_cast<double*>(d_out), count);
-    HIPCHK(hipGetLastError());
-    if (h->pending > 0) {
-        gf_ba::Pend& P = h->pq[h->pending - 1];
-        HIPCHK(hipEventRecord(h->ev_export[P.set == h->ev ? 0 : 1], h->stream));
-        P.exported = true;
-    }
     return GF_OK;
 }
 

@@ -253,7 +253,7 @@ class BaStats(C.Structure):
 
 
 EXPORTS += ["gf_ba_create", "gf_ba_destroy", "gf_ba_solve", "gf_ba_marginalize", "gf_ba_upload", "gf_ba_solve_resident", "gf_ba_download", "gf_ba_get_stats",
-            "gf_ba_reset_stats", "gf_ba_linearize", "gf_ba_solve_resident_async", "gf_ba_wait", "gf_ba_wait_oldest", "gf_ba_export_newest_poses_async", "gf_ba_debug_stamps", "gf_imu_preintegrate", "gf_imu_preintegrate_state", "gf_wheel_preintegrate", "gf_ba_double2vector",
+            "gf_ba_reset_stats", "gf_ba_linearize", "gf_ba_solve_resident_async", "gf_ba_wait", "gf_ba_debug_stamps", "gf_imu_preintegrate", "gf_imu_preintegrate_state", "gf_wheel_preintegrate", "gf_ba_double2vector",
             "gf_preint_create", "gf_preint_destroy", "gf_imu_preintegrate_batch", "gf_preint_stats",
             "gf_featsweep_create", "gf_featsweep_destroy", "gf_triangulate_with_depth_batch", "gf_moving_consistency_batch", "gf_featsweep_stats"]
 
@@ -308,14 +308,6 @@ class Estimator:
 
     def wait(self):
         _chk(lib().gf_ba_wait(self.h))
-
-    def wait_oldest(self):
-        """joins the older of (up to) two asynchronous solves in flight, and the pose export enqueued behind it"""
-        _chk(lib().gf_ba_wait_oldest(self.h))
-
-    def export_newest_poses_async(self, d_ptr, count):
-        """export_newest_poses without the host waiting: behind the newest solve in flight on the handle's stream; complete once that solve has been joined"""
-        _chk(lib().gf_ba_export_newest_poses_async(self.h, C.c_void_p(d_ptr), count))
 
     def download(self, wins=None, with_priors=False, cap_n=256):
         wins = wins if wins is not None else self._keep[0]

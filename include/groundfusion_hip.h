@@ -254,19 +254,11 @@ int gf_ba_solve_resident(gf_ba* h, int max_iters, int marginalize_mode /* -1: no
 /* same, returning as soon as the work is enqueued (the reference runs processImage on its own thread, estimator.cpp:209); gf_ba_wait joins */
 int gf_ba_solve_resident_async(gf_ba* h, int max_iters, int marginalize_mode, int reset_state);
 int gf_ba_wait(gf_ba* h);
-/* Two asynchronous solves may be in flight: a second gf_ba_solve_resident_async is accepted while the first is running and is ordered behind it on the handle's
- * stream -- the back end of the next frame without a host round trip between two solves (the reference's processThread takes the next feature frame off
- * featureBuf as soon as it is through with the last, estimator.cpp:209-246).  gf_ba_wait_oldest joins the OLDER one (and the pose export enqueued behind it);
- * gf_ba_wait joins everything.  Uploads and downloads need gf_ba_wait first, as before. */
-int gf_ba_wait_oldest(gf_ba* h);
 int gf_ba_download(gf_ba* h, gf_ba_window* windows, int count, gf_ba_summary* summaries, gf_ba_prior* priors);
 /* the newest pose (para_Pose[W]: px py pz qx qy qz qw) of the first `count` resident windows into a DEVICE array [count][7] -- the payload of the
  * per-step pose gather across GPUs (north_star; there is no counterpart in the single-process reference).  Enqueued behind a pending
  * asynchronous solve (complete after gf_ba_wait); otherwise complete on return. */
 int gf_ba_export_newest_poses(gf_ba* h, void* d_out, int count);
-/* the same without waiting: enqueued behind the newest solve in flight, complete when that solve has been joined (gf_ba_wait_oldest / gf_ba_wait); a solve
- * enqueued after this call runs behind the export */
-int gf_ba_export_newest_poses_async(gf_ba* h, void* d_out, int count);
 /* The same solve for callers that own many windows on many threads (gf_estimator_group_*; no counterpart in the reference, whose Estimator owns one
  * window): gf_ba_pack_slot packs one window into slot `slot` of the handle's staging tables -- callable concurrently for different slots, one thread per
  * slot --, gf_ba_solve_packed closes the batch (upload, ceres::Solve on the listed slots -- slots not listed sit this batch out --, one download of all

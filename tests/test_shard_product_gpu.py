@@ -205,40 +205,3 @@ def test_two_ranks_gather_over_rccl_on_one_device(tmp_path):
     _, ref = _solve_newest(gfamd, _windows(gfamd, 0, N_SEQ))
     for _, rank, g in res:
         assert g.shape == (N_SEQ, 7) and np.array_equal(g, ref), rank
-
-
-def test_two_solves_in_flight_export_the_bits_of_one_at_a_time():
-    """gf_ba_solve_resident_async accepts a second solve behind a running one (round 6): solve, export of its poses, next solve -- all enqueued before the host joins
-    the first.  The export must hold the FIRST solve's poses (not the reset or the second solve's state), a third solve is refused until one has been joined,
-    and the statistics count both."""
-    for p in (ROOT, os.path.join(ROOT, "ground-fusion_amd")):
-        if p not in sys.path:
-            sys.path.insert(0, p)
-    import gfamd
-    wins = _windows(gfamd, 0, 4)
-    ref, _ = _solve_newest(gfamd, _windows(gfamd, 0, 4))
-    est = gfamd.Estimator(10, 80, 800, len(wins))
-    est.upload(wins)
-    est.reset_stats()
-    a = torch.zeros((len(wins), 7), dtype=torch.float64, device="cuda:0")
-    b = torch.full((len(wins), 7), -1.0, dtype=torch.float64, device="cuda:0")
-    torch.cuda.synchronize()
-    est.solve_resident_async(ITERS, 0, True)
-    est.export_newest_poses_async(a.data_ptr(), len(wins))
-    est.solve_resident_async(2, 0, True)                      # another solve (fewer iterations: another result) right behind
-    with pytest.raises(Exception):
-        est.solve_resident_async(ITERS, 0, True)              # two in flight: refused
-    est.export_newest_poses_async(b.data_ptr(), len(wins))
-    est.wait_oldest()                                         # the first solve and the export behind it
-    assert np.array_equal(a.cpu().numpy(), ref.cpu().numpy())
-    est.wait_oldest()
-    est.wait()                                                # nothing left: returns
-    assert not np.array_equal(b.cpu().numpy(), ref.cpu().numpy()) and np.all(np.isfinite(b.cpu().numpy()))
-    st = est.stats()
-    assert st["solves"] >= 2 and st["ms_solve"] > 0 and st["ms_marginalize"] > 0
-    # and the handle is where a single solve leaves it: one more, joined the old way
-    est.solve_resident(ITERS, 0, True)
-    c = torch.zeros((len(wins), 7), dtype=torch.float64, device="cuda:0")
-    est.export_newest_poses(c.data_ptr(), len(wins))
-    assert np.array_equal(c.cpu().numpy(), ref.cpu().numpy())
-    est.close()
