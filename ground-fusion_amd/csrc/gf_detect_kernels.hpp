@@ -265,6 +265,7 @@ struct SelectArgs {
     uint16_t* out_depth;     // [batch][out_cap]
     int* out_n;              // [batch]
     const uint16_t* depth; size_t depth_seq_stride; int depth_stride;
+    int skip_small;          // sequences that want <= kTopKMax corners have been served by select_topk_kernel
 };
 
 constexpr int kSortLds = 16384;  // most keys sorted inside LDS (128 KiB); larger candidate sets sort in global memory
@@ -285,6 +286,96 @@ __device__ __forceinline__ void bitonic_desc(P keys, int npow2, int tid, int nth
         }
 }
 
+// The few corners a frame with its tracks alive asks for (round 6).  In steady state a sequence wants 3-4 new corners out of ~1 500 candidates; sorting them all
+// (66 barrier-separated stages of a bitonic network in 128 KB of LDS) to read the first handful was 37 us per frame.  The greedy selection in sorted order is the
+// same as: take the largest remaining key, drop every candidate closer than min_dist to it, repeat -- a candidate is rejected in the sorted walk exactly when an
+// accepted corner with a larger key lies within min_dist of it.  One 1024-thread block per sequence, one block-wide 64-bit maximum and one barrier per corner, the
+// candidates streamed from global memory (L2) each round, the accepted corners in registers of every thread; no dynamic LDS, so the block does not keep a CU's
+// LDS from the back end's kernels.  Sequences that want more than kTopKMax corners (the first frame, a lost scene) are left to select_corners_kernel.
+constexpr int kTopKMax = 16;
+constexpr int kTopKQ = 4;   // candidates per thread held in registers (4 096 per sequence; more are streamed from global memory every round)
+__global__ void __launch_bounds__(1024) select_topk_kernel(SelectArgs A) {
+    __shared__ unsigned long long s_best[3];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int want = A.want[b];
+    if (want <= 0) { if (tid == 0) A.out_n[b] = 0; return; }
+    if (want > kTopKMax) return;
+    int n = A.cand_count[b];
+    if (n > A.cand_cap) n = A.cand_cap;
+    if (n == 0) { if (tid == 0) A.out_n[b] = 0; return; }
+    const unsigned long long* gk = A.cand + b * A.cand_seq_stride;
+    const unsigned mk = A.maxkey[b];
+    const double maxVal = mk ? (double)f32_from_orderable(mk) : 0.0;
+    const float thresh = (float)(maxVal * 0.01);
+    const int md2 = A.min_dist * A.min_dist;
+    if (tid < 3) s_best[tid] = 0ull;
+    // this thread's candidates above the quality threshold, with their coordinates (0: none / decided)
+    unsigned long long kq[kTopKQ];
+    int kx[kTopKQ], ky[kTopKQ];
+#pragma unroll
+    for (int q = 0; q < kTopKQ; q++) {
+        const int i = tid + 1024 * q;
+        unsigned long long k = i < n ? gk[i] : 0ull;
+        if (!(f32_from_orderable((unsigned)(k >> 32)) > thresh)) k = 0ull;
+        const unsigned off = (unsigned)(k & 0xffffffffu);
+        ky[q] = (int)(off / (unsigned)A.w); kx[q] = (int)(off - (unsigned)ky[q] * A.w);
+        kq[q] = k;
+    }
+    const bool streamed = n > 1024 * kTopKQ;   // the rest of a very long list is read again every round and tested against every accepted corner
+    int ax[kTopKMax], ay[kTopKMax];
+#pragma unroll
+    for (int a = 0; a < kTopKMax; a++) { ax[a] = 0; ay[a] = 0; }
+    unsigned long long last = ~0ull;
+    __syncthreads();
+    int nacc = 0;
+    for (int r = 0; r < want; r++) {
+        unsigned long long best = 0;
+#pragma unroll
+        for (int q = 0; q < kTopKQ; q++) if (kq[q] > best) best = kq[q];
+        if (streamed)
+            for (int i = tid + 1024 * kTopKQ; i < n; i += 1024) {
+                const unsigned long long k = gk[i];
+                if (k >= last || !(f32_from_orderable((unsigned)(k >> 32)) > thresh)) continue;
+                const unsigned off = (unsigned)(k & 0xffffffffu);
+                const int y = (int)(off / (unsigned)A.w), x = (int)(off - (unsigned)y * A.w);
+                bool ok = true;
+#pragma unroll
+                for (int a = 0; a < kTopKMax; a++) {
+                    const int dx = x - ax[a], dy = y - ay[a];
+                    if (a < nacc && dx * dx + dy * dy < md2) ok = false;
+                }
+                if (ok && k > best) best = k;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(best >> 32), o), lo = (unsigned)__shfl_xor((int)(unsigned)best, o);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            if (other > best) best = other;
+        }
+        if (lane == 0 && best) atomicMax(&s_best[r % 3], best);
+        if (tid == 0) s_best[(r + 1) % 3] = 0ull;   // the next round's cell: last read two rounds ago, behind a barrier since
+        __syncthreads();
+        best = s_best[r % 3];
+        if (best == 0) break;   // the same word in every thread
+        const unsigned off = (unsigned)(best & 0xffffffffu);
+        const int y = (int)(off / (unsigned)A.w), x = (int)(off - (unsigned)y * A.w);
+#pragma unroll
+        for (int a = 0; a < kTopKMax; a++) if (a == nacc) { ax[a] = x; ay[a] = y; }
+#pragma unroll
+        for (int q = 0; q < kTopKQ; q++) {   // the corner itself and every candidate closer than min_dist to it are decided
+            const int dx = kx[q] - x, dy = ky[q] - y;
+            if (kq[q] == best || dx * dx + dy * dy < md2) kq[q] = 0ull;
+        }
+        if (tid == 0) {
+            A.out_pts[(size_t)b * A.out_cap + nacc] = make_float2((float)x, (float)y);
+            A.out_depth[(size_t)b * A.out_cap + nacc] = A.depth ? A.depth[b * A.depth_seq_stride + (size_t)y * A.depth_stride + x] : (uint16_t)0;
+        }
+        nacc++;
+        last = best;
+    }
+    if (tid == 0) A.out_n[b] = nacc;
+}
+
 // One 1024-thread block per sequence: sort candidates (value desc, address desc), then wavefront 0 runs the
 // greedy minimum-distance selection 64 candidates at a time against a cell grid of accepted corners.
 __global__ void __launch_bounds__(1024) select_corners_kernel(SelectArgs A) {
@@ -292,6 +383,7 @@ __global__ void __launch_bounds__(1024) select_corners_kernel(SelectArgs A) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const int want = A.want[b];
     if (want <= 0) { if (tid == 0) A.out_n[b] = 0; return; }
+    if (A.skip_small && want <= kTopKMax) return;
     int n = A.cand_count[b];
     if (n > A.cand_cap) n = A.cand_cap;
     if (n == 0) { if (tid == 0) A.out_n[b] = 0; return; }

@@ -553,7 +553,14 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
         S.cand = h->d_cand.p; S.cand_seq_stride = (size_t)h->cand_cap; S.cand_cap = h->cand_cap; S.cand_count = h->d_cand_count.p; S.maxkey = h->d_maxkey.p; S.want = h->d_want.p;
         S.w = W; S.h = H; S.min_dist = h->cfg.min_dist; S.out_cap = cap; S.sort_cap = h->sort_cap; S.out_pts = h->d_out_pts.p; S.out_depth = h->d_out_depth.p; S.out_n = h->d_out_n.p;
         S.depth = d_depth; S.depth_seq_stride = (size_t)W * H; S.depth_stride = W;
-        select_corners_kernel<<<dim3(B), 1024, h->select_lds, h->stream>>>(S);
+        {   // the sequences that want a handful of corners (every frame but the first ones): one maximum per corner instead of a sort (select_topk_kernel; GF_SELECT_TOPK=0: off)
+            static const bool topk_on = !(getenv("GF_SELECT_TOPK") && atoi(getenv("GF_SELECT_TOPK")) == 0);
+            int max_want = 0;
+            for (int b = 0; b < B; b++) max_want = std::max(max_want, h->h_want.p[b]);
+            S.skip_small = topk_on ? 1 : 0;
+            if (topk_on) select_topk_kernel<<<dim3(B), 1024, 0, h->stream>>>(S);
+            if (!topk_on || max_want > kTopKMax) select_corners_kernel<<<dim3(B), 1024, h->select_lds, h->stream>>>(S);
+        }
         HIPCHK(hipGetLastError());
         up(h->h_out_n, h->d_out_n, B);
         up(h->h_out_pts, h->d_out_pts, (size_t)B * cap);
