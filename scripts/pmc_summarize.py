@@ -43,7 +43,7 @@ lk.update({"points_per_launch": ppl, "algorithmic_bytes_per_launch": alg, "hbm_b
            "note": "PMC at %d sequences (%d points per launch), profiles/%s_pmc_tracker_fetch.csv / _write.csv: traffic = 2 x FETCH_SIZE + WRITE_SIZE (upper bound: whole 128-B lines; "
                    "lower bound FETCH_SIZE + WRITE_SIZE = %.0f B per point), scaled to this launch by points" % (B, ppl, tag, lk["hbm_bytes_lower"] / ppl)})
 S["lk_track_kernel"] = lk
-for k in ("gf::detect_strip_kernel<30>", "gf::pyr_head_kernel", "gf::pyr_level0_vec16_kernel", "gf::pyr_down_pad4_kernel", "gf::pyr_down_tail_kernel", "gf::select_corners_kernel"):
+for k in ("gf::detect_strip_kernel<30>", "gf::pyr_head_kernel", "gf::pyr_level0_vec16_kernel", "gf::pyr_down_pad4_kernel", "gf::pyr_down_tail_kernel", "gf::select_topk_kernel", "gf::select_corners_kernel"):
     if k in tf:
         S[k.split("::")[1].split("<")[0]] = traffic(k)
 def sq(tab, k):
