@@ -175,6 +175,8 @@ struct gf_tracker {
     DiskTable disk;
     int B = 0, cap = 0, cand_cap = 0, frame = 0, cur_slot = 0, sort_cap = 0;
     bool copy_lists = true;   // GF_TRACKER_COPIES=1: one hipMemcpyAsync per table instead of the copy-list kernels
+    bool pyr_head = true;     // GF_PYR_HEAD=0: levels 0 and 1 of the pyramid as two kernels (read when the tracker is created, as the other switches)
+    bool select_topk = true;  // GF_SELECT_TOPK=0: every frame's corners through the sort
     int lk_points = 1;        // points per wavefront of the LK kernel: 1 (lk_track_kernel), 2 or 4 (lk_track_mp_kernel, round 6); GF_LK_POINTS
     bool profiling = false;
     hipStream_t stream = nullptr;
@@ -270,8 +272,7 @@ static int launch_pyramid(gf_tracker* h, const uint8_t* d_raw_frames) {
     for (int l = 0; l < G.nlevels; l++) vec = vec && !(G.lv[l].w & 3) && !(G.lv[l].img_off & 3);
     for (int l = 1; l < G.nlevels; l++) vec = vec && G.lv[l].w > kPad + 1 && G.lv[l].h > kPad + 1;   // one reflection reaches every border pixel
     // levels 0 and 1 from one read of the raw frame (pyr_head_kernel) when the sizes allow it; GF_PYR_HEAD=0 keeps the two kernels (A/B and fallback)
-    static const bool head_on = !(getenv("GF_PYR_HEAD") && atoi(getenv("GF_PYR_HEAD")) == 0);
-    const bool head = head_on && v16 && vec && G.nlevels >= 2 && !(g0.h & 1) && G.lv[1].h * 2 == g0.h && G.lv[1].w * 2 == g0.w && g0.h > kPad + 2 && g0.w > kPad + 2 &&
+    const bool head = h->pyr_head && v16 && vec && G.nlevels >= 2 && !(g0.h & 1) && G.lv[1].h * 2 == g0.h && G.lv[1].w * 2 == g0.w && g0.h > kPad + 2 && g0.w > kPad + 2 &&
                       pyr_head_lds_bytes(g0.w) <= 64 * 1024;
     if (head) {
         pyr_head_kernel<<<dim3((G.lv[1].h + kHeadRows - 1) / kHeadRows, h->B), 512, pyr_head_lds_bytes(g0.w), h->stream>>>(d_raw_frames, (size_t)g0.w * g0.h, g0.w, img, seq_img, g0, G.lv[1]);
@@ -554,7 +555,7 @@ static int track_core(gf_tracker* h, const double* t, const uint8_t* d_gray, con
         S.w = W; S.h = H; S.min_dist = h->cfg.min_dist; S.out_cap = cap; S.sort_cap = h->sort_cap; S.out_pts = h->d_out_pts.p; S.out_depth = h->d_out_depth.p; S.out_n = h->d_out_n.p;
         S.depth = d_depth; S.depth_seq_stride = (size_t)W * H; S.depth_stride = W;
         {   // the sequences that want a handful of corners (every frame but the first ones): one maximum per corner instead of a sort (select_topk_kernel; GF_SELECT_TOPK=0: off)
-            static const bool topk_on = !(getenv("GF_SELECT_TOPK") && atoi(getenv("GF_SELECT_TOPK")) == 0);
+            const bool topk_on = h->select_topk;
             int max_want = 0;
             for (int b = 0; b < B; b++) max_want = std::max(max_want, h->h_want.p[b]);
             S.skip_small = topk_on ? 1 : 0;
@@ -668,6 +669,8 @@ int gf_tracker_create(const gf_tracker_cfg* cfg, gf_tracker** out) {
         (void)hipGetDevice(&dev);
         h->pool = new gf::HostPool(h->B >= 8 ? nthr - 1 : 0, dev);
         h->copy_lists = !(getenv("GF_TRACKER_COPIES") && atoi(getenv("GF_TRACKER_COPIES")) != 0);
+        h->pyr_head = !(getenv("GF_PYR_HEAD") && atoi(getenv("GF_PYR_HEAD")) == 0);
+        h->select_topk = !(getenv("GF_SELECT_TOPK") && atoi(getenv("GF_SELECT_TOPK")) == 0);
         if (const char* e = getenv("GF_LK_POINTS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) h->lk_points = v; }
     }
     const int W = cfg->width, H = cfg->height, B = h->B, cap = h->cap;

@@ -316,3 +316,28 @@ def test_lk_with_several_points_per_wavefront_is_bit_identical(gf, oracle, monke
         gi, go = gtr.trackImage(0.0666 * k, f, depth)
         assert np.array_equal(oi, gi) and np.array_equal(oo.view(np.uint64), go.view(np.uint64)), k
     gtr.close()
+
+
+@pytest.mark.parametrize("switch", ["GF_PYR_HEAD", "GF_SELECT_TOPK"])
+def test_the_older_forms_of_the_pyramid_head_and_the_corner_selection_stay_bit_identical(gf, oracle, monkeypatch, switch):
+    """Round 6: levels 0 + 1 of the pyramid come from one kernel (pyr_head_kernel) and the handful of corners a frame with its tracks alive asks for from repeated block-wide
+    maxima (select_topk_kernel); the forms they replace stay behind GF_PYR_HEAD=0 / GF_SELECT_TOPK=0 (read when a tracker is created).  Both forms are held to the oracle's
+    bits: a tracked sequence in which the first frame wants every corner (the sort) and the later ones a few (the maxima), and a batch of sequences with different needs."""
+    monkeypatch.setenv(switch, "0")
+    frames = _frames(1003, 7)
+    depth = np.full(frames[0].shape, 1500, np.uint16)
+    otr = oracle.Tracker(oracle.default_cfg(max_cnt=150, min_dist=30))
+    gtr = gf.FeatureTracker(gf.default_cfg(max_cnt=150, min_dist=30))
+    for k, f in enumerate(frames):
+        oi, oo = otr.track(0.0666 * k, f, depth)
+        gi, go = gtr.trackImage(0.0666 * k, f, depth)
+        assert np.array_equal(oi, gi) and np.array_equal(oo.view(np.uint64), go.view(np.uint64)), k
+    gtr.close()
+    monkeypatch.delenv(switch)
+    gtr = gf.FeatureTracker(gf.default_cfg(max_cnt=150, min_dist=30))      # and the default forms on the same frames
+    otr = oracle.Tracker(oracle.default_cfg(max_cnt=150, min_dist=30))
+    for k, f in enumerate(frames):
+        oi, oo = otr.track(0.0666 * k, f, depth)
+        gi, go = gtr.trackImage(0.0666 * k, f, depth)
+        assert np.array_equal(oi, gi) and np.array_equal(oo.view(np.uint64), go.view(np.uint64)), k
+    gtr.close()
